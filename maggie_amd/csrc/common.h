@@ -1,0 +1,73 @@
+// Shared device helpers for the MaGGIe gfx950 kernels (CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MG_F32 0
+#define MG_BF16 1
+
+#define MG_ACT_NONE 0
+#define MG_ACT_RELU 1
+#define MG_ACT_LRELU 2
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef uint16_t bf16raw;
+
+__device__ __forceinline__ float bf2f(bf16raw v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16raw f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16raw)((u >> 16) | 0x40u);   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                           // round to nearest even
+    return (bf16raw)(u >> 16);
+}
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+    static constexpr int CE = 4;      // elements per 16-byte chunk
+    static constexpr int EPS = 16;    // elements per 64-byte K slab
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+    __device__ static __forceinline__ float rnd(float v) { return v; }
+    __device__ static __forceinline__ void unpack(const uint4& q, float* f) {
+        f[0] = __uint_as_float(q.x); f[1] = __uint_as_float(q.y); f[2] = __uint_as_float(q.z); f[3] = __uint_as_float(q.w);
+    }
+    __device__ static __forceinline__ uint4 pack(const float* f) {
+        return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    }
+};
+template <> struct ElemTraits<bf16raw> {
+    static constexpr int CE = 8;
+    static constexpr int EPS = 32;
+    __device__ static __forceinline__ float ld(const bf16raw* p) { return bf2f(*p); }
+    __device__ static __forceinline__ void st(bf16raw* p, float v) { *p = f2bf(v); }
+    __device__ static __forceinline__ float rnd(float v) { return bf2f(f2bf(v)); }
+    __device__ static __forceinline__ void unpack(const uint4& q, float* f) {
+        f[0] = __uint_as_float(q.x << 16); f[1] = __uint_as_float(q.x & 0xffff0000u);
+        f[2] = __uint_as_float(q.y << 16); f[3] = __uint_as_float(q.y & 0xffff0000u);
+        f[4] = __uint_as_float(q.z << 16); f[5] = __uint_as_float(q.z & 0xffff0000u);
+        f[6] = __uint_as_float(q.w << 16); f[7] = __uint_as_float(q.w & 0xffff0000u);
+    }
+    __device__ static __forceinline__ uint4 pack(const float* f) {
+        return make_uint4((uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16), (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16),
+                          (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16), (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16));
+    }
+};
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+    if (act == MG_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == MG_ACT_LRELU) return v > 0.f ? v : v * slope;
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+#define MG_CHECK_LAUNCH()                              \
+    do {                                               \
+        hipError_t e__ = hipGetLastError();            \
+        if (e__ != hipSuccess) return (int)e__;        \
+    } while (0)

@@ -1,0 +1,542 @@
+// Implicit-GEMM convolution family for gfx950 (CDNA4): one MFMA kernel template serves
+//   * dense conv fprop            (MODE_CONV : NHWC activations, KRSC weights)
+//   * dense dgrad / ConvTranspose (MODE_TCONV: "transposed" row provider, any stride)
+//   * sparse gather conv          (MODE_GATHER: SubM / inverse / strided sparse conv via a neighbour table)
+// replacing cuDNN conv calls (reference: maggie/network/encoder/resnet.py:15-18,61-66,169-172,
+// maggie/network/decoder/resnet.py:20-25, maggie/network/module/aspp.py:14-30) and spconv's
+// gather-GEMM-scatter (maggie/network/decoder/resnet_inst_matt_spconv.py:61-130).
+//
+//   Y[m, co] = epilogue( sum_{tap, ci} X[src(m, tap), ci] * W[co, tap, ci] )
+//
+// Tiling: 256 threads = 4 waves, block tile 128 (rows) x BN (out channels), K walked in 64-byte slabs
+// (32 bf16 / 16 f32 per row) staged global -> VGPR -> LDS (double buffered, one barrier per slab; rows padded to
+// 80 B so the ds_read_b128 fragment reads are bank-conflict free). bf16 uses v_mfma_f32_16x16x32_bf16, fp32 uses
+// the exact v_mfma_f32_16x16x4_f32 (4 per slab, K permuted consistently between A and B).
+// Epilogue goes through an fp32 LDS tile so global stores / residual loads are 16-byte vectors and the per-channel
+// BatchNorm statistics (sum, sum of squares) are reduced per block before one atomicAdd per channel.
+#include "common.h"
+#include "../../include/maggie_hip.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int ROWB = 80;   // padded LDS row pitch in bytes (64 B of K + 16 B pad)
+
+template <int BN> struct TileCfg;
+template <> struct TileCfg<128> { static constexpr int WAVES_M = 2, WAVES_N = 2; };
+template <> struct TileCfg<64>  { static constexpr int WAVES_M = 2, WAVES_N = 2; };
+template <> struct TileCfg<32>  { static constexpr int WAVES_M = 4, WAVES_N = 1; };
+template <> struct TileCfg<16>  { static constexpr int WAVES_M = 4, WAVES_N = 1; };
+
+template <int BN> constexpr int stage_bytes() { return 2 * (BM + BN) * ROWB; }
+template <int BN> constexpr int ctile_bytes() { return (BM / (BN == 128 ? 2 : 1)) * (BN + 4) * 4 + 2 * BN * 4; }
+template <int BN> constexpr int lds_bytes() { return stage_bytes<BN>() > ctile_bytes<BN>() ? stage_bytes<BN>() : ctile_bytes<BN>(); }
+
+struct RowCoord { int n, ho, wo; bool ok; };
+
+template <typename T, int BN, int MODE>
+__global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p) {
+    using TR = ElemTraits<T>;
+    constexpr int CE = TR::CE, EPS = TR::EPS;
+    constexpr int WAVES_M = TileCfg<BN>::WAVES_M, WAVES_N = TileCfg<BN>::WAVES_N;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, FM = WM / 16, FN = WN / 16;
+    constexpr int B_ITERS = (BN * 4 + 255) / 256;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* sA = smem;                       // [2][BM][ROWB]
+    char* sB = smem + 2 * BM * ROWB;       // [2][BN][ROWB]
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int taps = p.R * p.S;
+    const int Ktot = taps * p.Cin;
+    const int nslab = (Ktot + EPS - 1) / EPS;
+    const char* __restrict__ xb = (const char*)p.x;
+    const char* __restrict__ wb = (const char*)p.w;
+
+    // ---- per-thread A rows (2 rows, fixed chunk column) ----
+    const int a_c = t & 3;
+    RowCoord rc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int m = m0 + (t >> 2) + i * 64;
+        rc[i].ok = m < p.M;
+        if (MODE != MG_MODE_GATHER) {
+            int hw = p.Hout * p.Wout;
+            int mm = rc[i].ok ? m : 0;
+            rc[i].n = mm / hw;
+            int rem = mm - rc[i].n * hw;
+            rc[i].ho = rem / p.Wout;
+            rc[i].wo = rem - rc[i].ho * p.Wout;
+        } else {
+            rc[i].n = m; rc[i].ho = 0; rc[i].wo = 0;
+        }
+    }
+    int a_k = a_c * CE;                    // running k index of this thread's chunk
+    int a_tap = a_k / p.Cin;
+    int a_ci = a_k - a_tap * p.Cin;
+
+    uint4 ra[2], rb[B_ITERS];
+
+    auto load_slab = [&](int s) {
+        // A operand
+        int ky = a_tap / p.S, kx = a_tap - ky * p.S;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            long src = -1;
+            if (rc[i].ok && a_tap < taps) {
+                if (MODE == MG_MODE_CONV) {
+                    int hi = rc[i].ho * p.stride - p.pad + ky * p.dil;
+                    int wi = rc[i].wo * p.stride - p.pad + kx * p.dil;
+                    if (hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win) src = ((long)rc[i].n * p.Hin + hi) * p.Win + wi;
+                } else if (MODE == MG_MODE_TCONV) {
+                    int th = rc[i].ho + p.pad - ky * p.dil;
+                    int tw = rc[i].wo + p.pad - kx * p.dil;
+                    if (th >= 0 && tw >= 0) {
+                        int hi = th / p.stride, wi = tw / p.stride;
+                        if (hi * p.stride == th && wi * p.stride == tw && hi < p.Hin && wi < p.Win)
+                            src = ((long)rc[i].n * p.Hin + hi) * p.Win + wi;
+                    }
+                } else {
+                    src = p.nbr[(long)rc[i].n * taps + a_tap];
+                }
+            }
+            if (src >= 0) ra[i] = *(const uint4*)(xb + (src * p.ldx + a_ci) * (long)sizeof(T));
+            else ra[i] = make_uint4(0, 0, 0, 0);
+        }
+        // B operand (weights, K-contiguous)
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i) {
+            int idx = t + i * 256;
+            int co = idx >> 2, c = idx & 3;
+            int k0 = s * EPS + c * CE;
+            if (idx < BN * 4 && (n0 + co) < p.Cout && k0 < Ktot)
+                rb[i] = *(const uint4*)(wb + ((long)(n0 + co) * Ktot + k0) * (long)sizeof(T));
+            else rb[i] = make_uint4(0, 0, 0, 0);
+        }
+        // advance the running (tap, ci)
+        a_ci += EPS;
+        while (a_ci >= p.Cin) { a_ci -= p.Cin; ++a_tap; }
+    };
+    auto store_slab = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            *(uint4*)(sA + buf * BM * ROWB + ((t >> 2) + i * 64) * ROWB + a_c * 16) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_ITERS; ++i) {
+            int idx = t + i * 256;
+            if (idx < BN * 4) *(uint4*)(sB + buf * BN * ROWB + (idx >> 2) * ROWB + (idx & 3) * 16) = rb[i];
+        }
+    };
+
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int lr = lane & 15, lg = lane >> 4;
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    load_slab(0);
+    store_slab(0);
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nslab) load_slab(s + 1);
+        const char* a_base = sA + buf * BM * ROWB + (wm * WM + lr) * ROWB + lg * 16;
+        const char* b_base = sB + buf * BN * ROWB + (wn * WN + lr) * ROWB + lg * 16;
+        uint4 fa[FM], fb[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) fa[i] = *(const uint4*)(a_base + i * 16 * ROWB);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) fb[j] = *(const uint4*)(b_base + j * 16 * ROWB);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                if constexpr (sizeof(T) == 2) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&fa[i], *(const bf16x8*)&fb[j], acc[i][j], 0, 0, 0);
+                } else {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i].x), __uint_as_float(fb[j].x), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i].y), __uint_as_float(fb[j].y), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i].z), __uint_as_float(fb[j].z), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i].w), __uint_as_float(fb[j].w), acc[i][j], 0, 0, 0);
+                }
+            }
+        if (s + 1 < nslab) store_slab(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue: accumulators -> fp32 LDS tile -> vectorised global stores ----------------
+    // (BN == 128 runs two 64-row passes so the fp32 tile fits beside nothing larger than the staging buffers)
+    constexpr int EP = (BN == 128) ? 2 : 1;
+    constexpr int PR = BM / EP;                       // tile rows per pass
+    constexpr int LDC = BN + 4;
+    float* sC = (float*)smem;                         // [PR][LDC]
+    float* sStat = (float*)(smem + PR * LDC * 4);     // [2][BN]
+    constexpr int CPR = BN / CE;                      // 16-byte chunks per tile row
+    constexpr int RPP = 256 / CPR;                    // rows per sweep
+    const int cc = t % CPR, rr = t / CPR;
+    const int cbase = n0 + cc * CE;
+    float sc[CE], sh[CE], s1[CE], s2[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+        int c = cbase + e;
+        sc[e] = (p.scale && c < p.Cout) ? p.scale[c] : 1.f;
+        sh[e] = (p.shift && c < p.Cout) ? p.shift[c] : 0.f;
+        s1[e] = 0.f; s2[e] = 0.f;
+    }
+    const bool full_vec = (cbase + CE <= p.Cout);
+    T* __restrict__ yb = (T*)p.y;
+    const T* __restrict__ r1b = (const T*)p.res;
+    const T* __restrict__ r2b = (const T*)p.res2;
+    if (t < 2 * BN) sStat[t] = 0.f;
+#pragma unroll
+    for (int ep = 0; ep < EP; ++ep) {
+        if (ep > 0) __syncthreads();
+        if ((wm * WM) / PR == ep) {
+            const int rbase = wm * WM - ep * PR;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        sC[(rbase + i * 16 + lg * 4 + e) * LDC + wn * WN + j * 16 + lr] = acc[i][j][e];
+        }
+        __syncthreads();
+        for (int r = rr; r < PR; r += RPP) {
+            int m = m0 + ep * PR + r;
+            if (m >= p.M || cbase >= p.Cout) continue;
+            float v[CE];
+#pragma unroll
+            for (int e = 0; e < CE; ++e) v[e] = sC[r * LDC + cc * CE + e];
+            long rrow = m;
+            if (p.res_mode == 2) {                    // residual lives at half resolution (nearest x2 upsample)
+                int hw = p.Hout * p.Wout;
+                int n = m / hw; int rem = m - n * hw; int ho = rem / p.Wout; int wo = rem - ho * p.Wout;
+                rrow = ((long)n * (p.Hout >> 1) + (ho >> 1)) * (p.Wout >> 1) + (wo >> 1);
+            }
+            float rv[CE], rv2[CE];
+#pragma unroll
+            for (int e = 0; e < CE; ++e) { rv[e] = 0.f; rv2[e] = 0.f; }
+            if (r1b) {
+                if (full_vec) { uint4 q = *(const uint4*)(r1b + rrow * p.ldr + cbase); TR::unpack(q, rv); }
+                else {
+#pragma unroll
+                    for (int e = 0; e < CE; ++e) if (cbase + e < p.Cout) rv[e] = TR::ld(r1b + rrow * p.ldr + cbase + e);
+                }
+            }
+            if (r2b) {
+                if (full_vec) { uint4 q = *(const uint4*)(r2b + (long)m * p.ldr2 + cbase); TR::unpack(q, rv2); }
+                else {
+#pragma unroll
+                    for (int e = 0; e < CE; ++e) if (cbase + e < p.Cout) rv2[e] = TR::ld(r2b + (long)m * p.ldr2 + cbase + e);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
+                float x = v[e];
+                if (p.pre_act) x = apply_act(x, p.act, p.slope);
+                x = x * sc[e] + sh[e];
+                x += rv[e];
+                if (!p.pre_act) x = apply_act(x, p.act, p.slope);
+                x += rv2[e];
+                x = TR::rnd(x);
+                v[e] = x;
+                s1[e] += x; s2[e] += x * x;
+            }
+            T* dst = yb + (long)m * p.ldy + p.yoff + cbase;
+            if (full_vec) *(uint4*)dst = TR::pack(v);
+            else {
+#pragma unroll
+                for (int e = 0; e < CE; ++e) if (cbase + e < p.Cout) TR::st(dst + e, v[e]);
+            }
+        }
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int e = 0; e < CE; ++e) {
+            atomicAdd(&sStat[cc * CE + e], s1[e]);
+            atomicAdd(&sStat[BN + cc * CE + e], s2[e]);
+        }
+        __syncthreads();
+        if (t < BN && n0 + t < p.Cout) {
+            atomicAdd(&p.stats[n0 + t], sStat[t]);
+            atomicAdd(&p.stats[p.Cout + n0 + t], sStat[BN + t]);
+        }
+    }
+}
+
+template <typename T, int BN>
+int launch_fprop(const mg_conv_params& p, hipStream_t st) {
+    dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN);
+    size_t lds = lds_bytes<BN>();
+    switch (p.mode) {
+        case MG_MODE_CONV: hipLaunchKernelGGL((igemm_fprop_kernel<T, BN, MG_MODE_CONV>), grid, dim3(256), lds, st, p); break;
+        case MG_MODE_TCONV: hipLaunchKernelGGL((igemm_fprop_kernel<T, BN, MG_MODE_TCONV>), grid, dim3(256), lds, st, p); break;
+        case MG_MODE_GATHER: hipLaunchKernelGGL((igemm_fprop_kernel<T, BN, MG_MODE_GATHER>), grid, dim3(256), lds, st, p); break;
+        default: return -2;
+    }
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T>
+int dispatch_fprop(const mg_conv_params& p, hipStream_t st) {
+    if (p.Cout > 64) return launch_fprop<T, 128>(p, st);
+    if (p.Cout > 32) return launch_fprop<T, 64>(p, st);
+    if (p.Cout > 16) return launch_fprop<T, 32>(p, st);
+    return launch_fprop<T, 16>(p, st);
+}
+
+}  // namespace
+
+extern "C" int mg_conv_fprop(const mg_conv_params* pp, void* stream) {
+    if (!pp) return -1;
+    const mg_conv_params& p = *pp;
+    const int ce = p.dtype == MG_BF16 ? 8 : 4;
+    if (p.M <= 0) return 0;
+    if (p.Cin % ce != 0 || p.ldx % ce != 0) return -3;                 // K chunks must not straddle taps / be 16-B aligned
+    if (p.Cout >= ce && (p.ldy % ce != 0 || p.yoff % ce != 0)) return -4;
+    if (p.mode == MG_MODE_GATHER && !p.nbr) return -5;
+    hipStream_t st = (hipStream_t)stream;
+    if (p.dtype == MG_BF16) return dispatch_fprop<bf16raw>(p, st);
+    if (p.dtype == MG_F32) return dispatch_fprop<float>(p, st);
+    return -6;
+}
+
+// =====================================================================================================================
+// Weight gradient:  dW[co, tap, ci] += sum_m dY[m, co] * X[src(m, tap), ci]
+// One block = one (co tile, tap, ci tile, row range). The reduction dimension (rows) is the NHWC-strided one, so the
+// MFMA operands are "K-strided" in memory: tiles are staged row-major in LDS and read transposed -- with
+// ds_read_b64_tr_b16 for bf16 (gfx950 transpose read; K permuted consistently between A and B) and with plain
+// ds_read_b32 for the f32 16x16x4 MFMA whose operand layout is already one (row, k) scalar per lane.
+// The 4 waves of a block split each row step between them (intra-block split-K), are reduced through LDS float
+// atomics, and the block tile is added to the fp32 dW with global atomics (row ranges of different blocks overlap).
+// =====================================================================================================================
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+
+template <typename T, int TCO, int TCI, int MODE>
+__global__ __launch_bounds__(256) void igemm_wgrad_kernel(const mg_conv_params p, const int rows_per_block) {
+    using TR = ElemTraits<T>;
+    constexpr int CE = TR::CE;
+    constexpr bool BF = sizeof(T) == 2;
+    constexpr int KSTEP = BF ? 128 : 64;
+    constexpr int WROWS = KSTEP / 4;
+    constexpr int PAD = BF ? 8 : 16;
+    constexpr int PCO = TCO + PAD, PCI = TCI + PAD;
+    constexpr int CPY = TCO / CE, CPX = TCI / CE;                // 16-byte chunks per tile row
+    constexpr int ITY = (KSTEP * CPY) / 256, ITX = (KSTEP * CPX) / 256;
+    constexpr int FM = TCO / 16, FN = TCI / 16;
+    static_assert((KSTEP * CPY) % 256 == 0 && (KSTEP * CPX) % 256 == 0, "tile/threads mismatch");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* sY = (T*)smem;                                            // [KSTEP][PCO]
+    T* sX = (T*)(smem + KSTEP * PCO * sizeof(T));                // [KSTEP][PCI]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int taps = p.R * p.S;
+    const int nci = (p.Cin + TCI - 1) / TCI;
+    const int tap = blockIdx.y / nci;
+    const int ci0 = (blockIdx.y - tap * nci) * TCI;
+    const int co0 = blockIdx.z * TCO;
+    const int mbeg = blockIdx.x * rows_per_block;
+    const int mend = min(p.M, mbeg + rows_per_block);
+    if (mbeg >= mend) return;
+    const int ky = tap / p.S, kx = tap - ky * p.S;
+    const T* __restrict__ yb = (const T*)p.y;
+    const T* __restrict__ xb = (const T*)p.x;
+    const bool yvec = (p.ldy % CE == 0) && (p.yoff % CE == 0);
+
+    uint4 ry[ITY], rx[ITX];
+    auto load_step = [&](int mb) {
+#pragma unroll
+        for (int i = 0; i < ITY; ++i) {
+            int idx = t + i * 256;
+            int row = idx / CPY, c = idx - row * CPY;
+            int m = mb + row, co = co0 + c * CE;
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if (m < mend && co < p.Cout) {
+                const T* src = yb + (long)m * p.ldy + p.yoff + co;
+                if (yvec && co + CE <= p.Cout) q = *(const uint4*)src;
+                else {
+                    float f[CE];
+#pragma unroll
+                    for (int e = 0; e < CE; ++e) f[e] = (co + e < p.Cout) ? TR::ld(src + e) : 0.f;
+                    q = TR::pack(f);
+                }
+            }
+            ry[i] = q;
+        }
+#pragma unroll
+        for (int i = 0; i < ITX; ++i) {
+            int idx = t + i * 256;
+            int row = idx / CPX, c = idx - row * CPX;
+            int m = mb + row, ci = ci0 + c * CE;
+            long src = -1;
+            if (m < mend && ci < p.Cin) {
+                if (MODE == MG_MODE_GATHER) {
+                    src = p.nbr[(long)m * taps + tap];
+                } else {
+                    int hw = p.Hout * p.Wout;
+                    int n = m / hw; int rem = m - n * hw; int ho = rem / p.Wout; int wo = rem - ho * p.Wout;
+                    if (MODE == MG_MODE_CONV) {
+                        int hi = ho * p.stride - p.pad + ky * p.dil, wi = wo * p.stride - p.pad + kx * p.dil;
+                        if (hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win) src = ((long)n * p.Hin + hi) * p.Win + wi;
+                    } else {
+                        int th = ho + p.pad - ky * p.dil, tw = wo + p.pad - kx * p.dil;
+                        if (th >= 0 && tw >= 0) {
+                            int hi = th / p.stride, wi = tw / p.stride;
+                            if (hi * p.stride == th && wi * p.stride == tw && hi < p.Hin && wi < p.Win)
+                                src = ((long)n * p.Hin + hi) * p.Win + wi;
+                        }
+                    }
+                }
+            }
+            rx[i] = (src >= 0) ? *(const uint4*)(xb + src * p.ldx + ci) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_step = [&]() {
+#pragma unroll
+        for (int i = 0; i < ITY; ++i) {
+            int idx = t + i * 256; int row = idx / CPY, c = idx - row * CPY;
+            *(uint4*)(sY + row * PCO + c * CE) = ry[i];
+        }
+#pragma unroll
+        for (int i = 0; i < ITX; ++i) {
+            int idx = t + i * 256; int row = idx / CPX, c = idx - row * CPX;
+            *(uint4*)(sX + row * PCI + c * CE) = rx[i];
+        }
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int wr = wave * WROWS;
+    load_step(mbeg);
+    for (int mb = mbeg; mb < mend; mb += KSTEP) {
+        store_step();
+        __syncthreads();
+        if (mb + KSTEP < mend) load_step(mb + KSTEP);
+        if constexpr (BF) {
+            s16x4 a[FM][2], b[FN][2];
+            const int r0 = wr + g * 4 + (li >> 2), cq = (li & 3) * 4;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                a[i][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sY + r0 * PCO + i * 16 + cq));
+                a[i][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sY + (r0 + 16) * PCO + i * 16 + cq));
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                b[j][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sX + r0 * PCI + j * 16 + cq));
+                b[j][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sX + (r0 + 16) * PCI + j * 16 + cq));
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    union { s16x4 h[2]; bf16x8 v; } ua, ub;
+                    ua.h[0] = a[i][0]; ua.h[1] = a[i][1]; ub.h[0] = b[j][0]; ub.h[1] = b[j][1];
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc[i][j], 0, 0, 0);
+                }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < WROWS / 4; ++kk) {
+                float a[FM], b[FN];
+                const int r = wr + kk * 4 + g;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) a[i] = ((const float*)sY)[r * PCO + i * 16 + li];
+#pragma unroll
+                for (int j = 0; j < FN; ++j) b[j] = ((const float*)sX)[r * PCI + j * 16 + li];
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // reduce the 4 waves through LDS, then one global atomic per tile element
+    float* sR = (float*)smem;                                     // [TCO][TCI + 1]
+    constexpr int LDRR = TCI + 1;
+    for (int i = t; i < TCO * LDRR; i += 256) sR[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                atomicAdd(&sR[(i * 16 + g * 4 + e) * LDRR + j * 16 + li], acc[i][j][e]);
+    __syncthreads();
+    float* __restrict__ dw = p.stats;
+    for (int i = t; i < TCO * TCI; i += 256) {
+        int co = i / TCI, ci = i - co * TCI;
+        if (co0 + co < p.Cout && ci0 + ci < p.Cin)
+            atomicAdd(&dw[((long)(co0 + co) * taps + tap) * p.Cin + ci0 + ci], sR[co * LDRR + ci]);
+    }
+}
+
+template <typename T, int TCO, int TCI>
+int launch_wgrad(const mg_conv_params& p, hipStream_t st) {
+    constexpr bool BF = sizeof(T) == 2;
+    constexpr int KSTEP = BF ? 128 : 64;
+    constexpr int PAD = BF ? 8 : 16;
+    const int taps = p.R * p.S;
+    const int nci = (p.Cin + TCI - 1) / TCI, nco = (p.Cout + TCO - 1) / TCO;
+    const long tiles = (long)taps * nci * nco;
+    long want = (2048 + tiles - 1) / tiles;                       // aim at ~2048 blocks
+    long max_splits = (p.M + KSTEP - 1) / KSTEP;
+    long splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
+    int rpb = (int)((p.M + splits - 1) / splits);
+    rpb = ((rpb + KSTEP - 1) / KSTEP) * KSTEP;
+    splits = (p.M + rpb - 1) / rpb;
+    dim3 grid((unsigned)splits, (unsigned)(taps * nci), (unsigned)nco);
+    size_t stage = (size_t)KSTEP * (TCO + PAD + TCI + PAD) * sizeof(T);
+    size_t red = (size_t)TCO * (TCI + 1) * 4;
+    size_t lds = stage > red ? stage : red;
+    switch (p.mode) {
+        case MG_MODE_CONV: hipLaunchKernelGGL((igemm_wgrad_kernel<T, TCO, TCI, MG_MODE_CONV>), grid, dim3(256), lds, st, p, rpb); break;
+        case MG_MODE_TCONV: hipLaunchKernelGGL((igemm_wgrad_kernel<T, TCO, TCI, MG_MODE_TCONV>), grid, dim3(256), lds, st, p, rpb); break;
+        case MG_MODE_GATHER: hipLaunchKernelGGL((igemm_wgrad_kernel<T, TCO, TCI, MG_MODE_GATHER>), grid, dim3(256), lds, st, p, rpb); break;
+        default: return -2;
+    }
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T>
+int dispatch_wgrad(const mg_conv_params& p, hipStream_t st) {
+    const bool small_co = p.Cout <= 32, small_ci = p.Cin <= 32;
+    if (small_co && small_ci) return launch_wgrad<T, 32, 32>(p, st);
+    if (small_co) return launch_wgrad<T, 32, 64>(p, st);
+    if (small_ci) return launch_wgrad<T, 64, 32>(p, st);
+    return launch_wgrad<T, 64, 64>(p, st);
+}
+
+}  // namespace
+
+extern "C" int mg_conv_wgrad(const mg_conv_params* pp, void* stream) {
+    if (!pp) return -1;
+    const mg_conv_params& p = *pp;
+    const int ce = p.dtype == MG_BF16 ? 8 : 4;
+    if (p.M <= 0) return 0;
+    if (p.Cin % ce != 0 || p.ldx % ce != 0) return -3;
+    if (!p.stats) return -4;
+    if (p.mode == MG_MODE_GATHER && !p.nbr) return -5;
+    hipStream_t st = (hipStream_t)stream;
+    if (p.dtype == MG_BF16) return dispatch_wgrad<bf16raw>(p, st);
+    if (p.dtype == MG_F32) return dispatch_wgrad<float>(p, st);
+    return -6;
+}

@@ -1,0 +1,87 @@
+"""ctypes binding of the C ABI in include/maggie_hip.h (libmaggie_hip.so, hand-written HIP for gfx950).
+
+PyTorch is only plumbing here: it owns device memory and streams; every call below hands raw device pointers,
+sizes and the current HIP stream to the C ABI. There is NO fallback: if the shared library is missing or fails to
+load, importing a kernel raises -- the product path never silently routes through PyTorch/CPU code.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmaggie_hip.so')
+_LIB = None
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+MODE_CONV, MODE_TCONV, MODE_GATHER = 0, 1, 2
+
+
+class MaggieHipError(RuntimeError):
+    pass
+
+
+class ConvParams(ctypes.Structure):
+    _fields_ = [
+        ('x', ctypes.c_void_p), ('w', ctypes.c_void_p), ('y', ctypes.c_void_p), ('nbr', ctypes.c_void_p),
+        ('scale', ctypes.c_void_p), ('shift', ctypes.c_void_p), ('res', ctypes.c_void_p), ('res2', ctypes.c_void_p),
+        ('stats', ctypes.c_void_p),
+        ('dtype', ctypes.c_int32), ('mode', ctypes.c_int32),
+        ('N', ctypes.c_int32), ('Hin', ctypes.c_int32), ('Win', ctypes.c_int32), ('Cin', ctypes.c_int32),
+        ('Hout', ctypes.c_int32), ('Wout', ctypes.c_int32), ('Cout', ctypes.c_int32),
+        ('R', ctypes.c_int32), ('S', ctypes.c_int32), ('stride', ctypes.c_int32), ('pad', ctypes.c_int32),
+        ('dil', ctypes.c_int32), ('M', ctypes.c_int32),
+        ('ldx', ctypes.c_int32), ('ldy', ctypes.c_int32), ('yoff', ctypes.c_int32), ('ldr', ctypes.c_int32),
+        ('ldr2', ctypes.c_int32),
+        ('act', ctypes.c_int32), ('pre_act', ctypes.c_int32), ('res_mode', ctypes.c_int32),
+        ('slope', ctypes.c_float),
+    ]
+
+
+def lib():
+    """Load libmaggie_hip.so (built in-tree by __graft_entry__.build()); fail loudly if it is not there."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.isfile(LIB_PATH):
+            raise MaggieHipError(
+                'libmaggie_hip.so not found at %s -- run `python -c "import __graft_entry__ as g; g.build()"` '
+                '(hipcc --offload-arch=gfx950). There is no CPU / PyTorch fallback for the MaGGIe hot path.' % LIB_PATH)
+        _LIB = ctypes.CDLL(LIB_PATH)
+        _LIB.mg_abi_version.restype = ctypes.c_int
+    return _LIB
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise MaggieHipError('unsupported dtype %s' % t.dtype)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise MaggieHipError('%s failed with code %d' % (what, rc))
+
+
+def need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise MaggieHipError('MaGGIe HIP kernels need device tensors (got a CPU tensor); there is no CPU fallback')
+
+
+def call(name, *args):
+    fn = getattr(lib(), name)
+    fn.restype = ctypes.c_int
+    check(fn(*args), name)

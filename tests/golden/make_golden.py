@@ -1,0 +1,188 @@
+"""Generate the golden fixtures in this directory FROM THE REFERENCE (run in the build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference's own Python modules are imported from /root/reference by oracle/ref_loader.py (nothing is
+copied) and run on CPU fp32 with
+  * weights  = maggie_amd.utils.synth.fill_state_dict_(state_dict, seed)   (regenerable, not stored)
+  * inputs   = maggie_amd.utils.synth.synthetic_batch(...)                 (regenerable, not stored)
+Only OUTPUTS are stored (npz, compressed).
+
+Pinning status of each fixture:
+  PINNED    -- produced by the reference's own code with stock torch ops only (no stand-in on the data path):
+               dense_*.npz (SpectralNorm state, encoder, ASPP, os32->os8, InstanceMatteDecoder, ConvGRU,
+               losses) and the `alpha_os8` / `loss_*_os8` / `loss_max_atten` entries of model_*.npz.
+  UNPINNED  -- anything downstream of `cv2.dilate` or `spconv`: the reference's glue code ran on top of
+               oracle/standins (our restatement of those third-party libraries), so these pin the reference's
+               orchestration, not the third-party arithmetic: detail_mask, alpha_os4, alpha_os1, refined_masks ...
+"""
+import copy
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.dont_write_bytecode = True
+
+from oracle import ref_loader                                   # noqa: E402
+from maggie_amd.utils import synth, config                      # noqa: E402
+
+WSEED = 7
+DSEED = 3
+RSEED = 11
+
+
+def seed_all(s):
+    np.random.seed(s)
+    random.seed(s)
+    torch.manual_seed(s)
+
+
+def build(ns, kind):
+    mc = config.MODEL_IMAGE if kind == 'image' else config.MODEL_VIDEO
+    cls = ns.MaGGIe if kind == 'image' else ns.MaGGIe_Temp
+    m = cls(ns.CfgNode(copy.deepcopy(mc)))
+    sd = m.state_dict()
+    synth.fill_state_dict_(sd, WSEED)
+    m.load_state_dict(sd)
+    return m
+
+
+def pack(t):
+    t = t.detach()
+    if t.dtype == torch.uint8 or t.dtype == torch.bool:
+        return np.packbits(t.numpy().astype(np.uint8).reshape(-1))
+    return t.float().numpy()
+
+
+def model_fixture(ns, kind, train, b, n_f, n_inst, hw, it, max_inst, name):
+    m = build(ns, kind)
+    m.train(train)
+    batch = synth.synthetic_batch(b, n_f, n_inst, hw, hw, seed=DSEED, train=train, it=it, max_inst=max_inst)
+    seed_all(RSEED)
+    out = {}
+    if train:
+        o, loss = m(batch)
+        loss['total'].backward()
+        for k, v in loss.items():
+            out['loss/' + k] = np.float32(float(v))
+        gn = {}
+        for n, p in m.named_parameters():
+            if p.grad is not None:
+                gn[n] = float(p.grad.double().norm())
+        keys = sorted(gn)
+        out['grad_norm_names'] = np.array(keys)
+        out['grad_norms'] = np.array([gn[k] for k in keys], np.float64)
+        sd = m.state_dict()
+        out['bn/encoder.bn1.running_mean'] = sd['encoder.bn1.running_mean'].numpy()
+        out['bn/decoder.refine_OS1.1.running_var'] = sd['decoder.refine_OS1.1.running_var'].numpy()
+    else:
+        with torch.no_grad():
+            o = m(batch)
+    for k, v in o.items():
+        if torch.is_tensor(v):
+            out['out/' + k] = pack(v)
+            out['shape/' + k] = np.array(v.shape)
+    sd = m.state_dict()
+    out['sn/encoder.conv1.module.weight_u'] = sd['encoder.conv1.module.weight_u'].numpy()
+    out['meta'] = np.array([b, n_f, n_inst, hw, it, -1 if max_inst is None else max_inst, WSEED, DSEED, RSEED])
+    np.savez_compressed(os.path.join(HERE, name), **out)
+    print('wrote', name, {k: (v.shape if hasattr(v, 'shape') else v) for k, v in list(out.items())[:4]})
+
+
+def dense_fixture(ns):
+    """PINNED: reference modules that need no third-party stand-in."""
+    out = {}
+    torch.manual_seed(0)
+    # SpectralNorm state after 1 and 2 calls (spectral_norm.py:22-35,73-80)
+    m = build(ns, 'video')
+    m.eval()
+    conv = m.encoder.layer1[0].conv1
+    x = torch.from_numpy(np.random.RandomState(5).normal(size=(1, 64, 8, 8)).astype(np.float32))
+    with torch.no_grad():
+        y1 = conv(x)
+        out['sn/u1'] = conv.module.weight_u.numpy().copy()
+        out['sn/v1'] = conv.module.weight_v.numpy().copy()
+        y2 = conv(x)
+        out['sn/u2'] = conv.module.weight_u.numpy().copy()
+        out['sn/y1'] = y1.numpy()
+        out['sn/y2'] = y2.numpy()
+    # encoder / aspp / decoder dense / IMD, eval and train(batch-stat) mode, 64x64, 2 frames
+    for mode in ('eval', 'train'):
+        m = build(ns, 'image')
+        m.train(mode == 'train')
+        batch = synth.synthetic_batch(2, 1, 2, 64, 64, seed=DSEED, train=True, max_inst=10)
+        with torch.no_grad():
+            masks, alphas, trans_gt, b, n_f, h, w, n_i, chosen, emb, mid = m.forward_encoder(batch)
+            out[mode + '/enc_embedding_aspp'] = emb.numpy()
+            for i, f in enumerate(mid['shortcut']):
+                out['%s/fea%d_sum' % (mode, i + 1)] = f.double().sum(dim=(2, 3)).numpy()
+            out[mode + '/fea5'] = mid['shortcut'][4].numpy()
+            x, masks5, valid, gt_masks, f1, f2, f3, image, h, w = m.decoder.os32_to_os8(emb, mid, b, n_f, n_i, masks, alphas)
+            out[mode + '/os8_feat'] = x.numpy()
+            x_os8, xf, queries, loss_max, _ = m.decoder.refine_OS8(x, masks5, use_mask_atten=False, gt_mask=gt_masks)
+            out[mode + '/imd_logits'] = x_os8.numpy()
+            out[mode + '/imd_out_feat'] = xf.numpy()
+            out[mode + '/imd_tokens'] = queries.numpy()
+            out[mode + '/imd_max_loss'] = np.float32(float(loss_max))
+    # ConvGRU 'bi' + bidirectional fusion (video decoder pieces)
+    m = build(ns, 'video')
+    m.eval()
+    rs = np.random.RandomState(9)
+    feat = torch.from_numpy(rs.normal(size=(1, 3, 128, 8, 8)).astype(np.float32))
+    with torch.no_grad():
+        o, hdn = m.decoder.os8_temp_module.propagate_features(feat.clone(), n_f=3, prev_h_state=None, temp_method='bi')
+        out['gru/out'] = o.numpy()
+        out['gru/hidden'] = hdn.numpy()
+        f64 = torch.from_numpy(rs.normal(size=(1, 3, 64, 8, 8)).astype(np.float32))
+        preds = torch.from_numpy(rs.uniform(size=(1, 3, 2, 64, 64)).astype(np.float32))
+        df, db, fu = m.decoder.bidirectional_fusion(f64, preds)
+        out['bifuse/df'] = df.numpy()
+        out['bifuse/db'] = db.numpy()
+        out['bifuse/fused'] = fu.numpy()
+    # losses incl. the LapLoss channel quirk (loss.py:67-191, arch/maggie.py:237-266)
+    a = torch.from_numpy(rs.uniform(size=(2, 3, 32, 32)).astype(np.float32))
+    g = torch.from_numpy(rs.uniform(size=(2, 3, 32, 32)).astype(np.float32))
+    wgt = torch.from_numpy((rs.uniform(size=(2, 3, 32, 32)) > 0.5).astype(np.float32))
+    lap = ns.loss.LapLoss()
+    grd = ns.loss.GradientLoss()
+    out['loss/lap'] = np.float32(float(lap(a.view(-1, 1, 32, 32), g.view(-1, 1, 32, 32), wgt.view(-1, 1, 32, 32))))
+    out['loss/grad'] = np.float32(float(grd(a, g, wgt)))
+    out['loss/l1'] = np.float32(float(ns.MaGGIe.regression_loss(a, g, loss_type='l1', weight=wgt)))
+    out['loss/dtssd'] = np.float32(float(ns.loss.loss_dtSSD(a.view(1, 2, 3, 32, 32), g.view(1, 2, 3, 32, 32), wgt.view(1, 2, 3, 32, 32))))
+    np.savez_compressed(os.path.join(HERE, 'dense_pinned.npz'), **out)
+    print('wrote dense_pinned.npz', len(out))
+
+
+def layout_fixture(ns):
+    """Checkpoint layout (parameter / buffer names, shapes, dtypes) of the reference models: the state_dict
+    keys are an API (checkpoint/resume)."""
+    import json
+    for kind in ('image', 'video'):
+        m = build(ns, kind)
+        lay = {k: [list(v.shape), str(v.dtype).replace('torch.', '')] for k, v in m.state_dict().items()}
+        trainable = sorted(n for n, p in m.named_parameters() if p.requires_grad)
+        with open(os.path.join(HERE, 'state_dict_layout_%s.json' % kind), 'w') as f:
+            json.dump({'state_dict': lay, 'trainable': trainable}, f, indent=0, sort_keys=True)
+        print('wrote layout', kind, len(lay))
+
+
+def main():
+    ns = ref_loader.load_reference()
+    layout_fixture(ns)
+    dense_fixture(ns)
+    model_fixture(ns, 'image', False, 1, 1, 2, 128, 0, None, 'model_image_eval.npz')
+    model_fixture(ns, 'image', True, 2, 1, 2, 128, 10000, 10, 'model_image_train.npz')
+    model_fixture(ns, 'image', True, 2, 1, 2, 128, 100, None, 'model_image_train_warmup.npz')
+    model_fixture(ns, 'video', False, 1, 3, 2, 128, 0, None, 'model_video_eval.npz')
+    model_fixture(ns, 'video', True, 1, 3, 2, 128, 10000, 10, 'model_video_train.npz')
+
+
+if __name__ == '__main__':
+    main()
+
+

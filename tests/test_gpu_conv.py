@@ -1,0 +1,154 @@
+"""GPU parity of the implicit-GEMM convolution family (C ABI: mg_conv_fprop / mg_conv_wgrad) against a plain
+PyTorch fp32 CPU reference of the same op. fp32 kernels use the exact f32 MFMA: tolerance 2e-4 relative to the
+output scale; bf16 kernels: inputs are rounded to bf16 first, tolerance 2e-2 (bf16 output rounding)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    return torch.device('cuda:0')
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _krsc(w):                         # (Cout, Cin, R, S) -> (Cout, R*S, Cin)
+    co, ci, r, s = w.shape
+    return w.permute(0, 2, 3, 1).reshape(co, r * s, ci).contiguous()
+
+
+def _tol(dtype):
+    return 2e-4 if dtype == torch.float32 else 2.5e-2
+
+
+CASES = [
+    # N, Cin, Cout, H, W, k, stride, pad, dil
+    (2, 8, 32, 20, 24, 3, 1, 1, 1),
+    (1, 32, 64, 17, 19, 3, 2, 1, 1),
+    (2, 64, 128, 12, 12, 3, 1, 2, 2),
+    (1, 128, 256, 9, 9, 1, 1, 0, 1),
+    (1, 256, 16, 8, 8, 3, 1, 1, 1),
+    (3, 40, 72, 11, 13, 3, 1, 1, 1),
+    (1, 32, 1, 16, 16, 3, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', CASES)
+def test_conv_fprop_dgrad_wgrad(case, dtype):
+    from maggie_amd import kernels as K
+    dev = _dev()
+    N, Cin, Cout, H, W, k, stride, pad, dil = case
+    rs = np.random.RandomState(hash(case) % 1000)
+    x = torch.from_numpy(rs.normal(size=(N, Cin, H, W)).astype(np.float32))
+    w = torch.from_numpy((rs.normal(size=(Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32))
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    x.requires_grad_(True)
+    w.requires_grad_(True)
+    y_ref = F.conv2d(x, w, None, stride, pad, dil)
+    Ho, Wo = y_ref.shape[-2:]
+    gy = torch.from_numpy(rs.normal(size=tuple(y_ref.shape)).astype(np.float32))
+    if dtype == torch.bfloat16:
+        gy = gy.bfloat16().float()
+    y_ref.backward(gy)
+
+    xd = _nhwc(x.detach()).to(dev, dtype)
+    wd = _krsc(w.detach()).to(dev, dtype)
+    y = K.conv_fprop(xd, wd, mode=K.MODE_CONV, N=N, Hin=H, Win=W, R=k, S=k, stride=stride, pad=pad, dil=dil)
+    y = y.float().cpu().reshape(N, Ho, Wo, Cout).permute(0, 3, 1, 2)
+    scale = y_ref.abs().max().item()
+    assert (y - y_ref.detach()).abs().max().item() <= _tol(dtype) * scale
+
+    # dgrad = TCONV-mode implicit GEMM with (Cin, taps, Cout) weights
+    gyd = _nhwc(gy).to(dev, dtype)
+    wt = w.detach().permute(1, 2, 3, 0).reshape(Cin, k * k, Cout).contiguous().to(dev, dtype)
+    if Cout % 8 == 0:
+        dx = K.conv_fprop(gyd, wt, mode=K.MODE_TCONV, N=N, Hin=Ho, Win=Wo, Hout=H, Wout=W, R=k, S=k, stride=stride,
+                          pad=pad, dil=dil)
+        dx = dx.float().cpu().reshape(N, H, W, Cin).permute(0, 3, 1, 2)
+        assert (dx - x.grad).abs().max().item() <= _tol(dtype) * x.grad.abs().max().item()
+
+    dw = K.conv_wgrad(xd, gyd, cout=Cout, mode=K.MODE_CONV, N=N, Hin=H, Win=W, Hout=Ho, Wout=Wo, R=k, S=k, stride=stride,
+                      pad=pad, dil=dil)
+    dw = dw.cpu().reshape(Cout, k, k, Cin).permute(0, 3, 1, 2)
+    assert (dw - w.grad).abs().max().item() <= _tol(dtype) * w.grad.abs().max().item()
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_conv_epilogue_and_stats(dtype):
+    from maggie_amd import kernels as K
+    dev = _dev()
+    N, Cin, Cout, H, W = 2, 32, 64, 16, 16
+    rs = np.random.RandomState(3)
+    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    x = q(torch.from_numpy(rs.normal(size=(N, Cin, H, W)).astype(np.float32)))
+    w = q(torch.from_numpy((rs.normal(size=(Cout, Cin, 3, 3)) / 17).astype(np.float32)))
+    res = q(torch.from_numpy(rs.normal(size=(N, Cout, H // 2, W // 2)).astype(np.float32)))
+    res2 = q(torch.from_numpy(rs.normal(size=(N, Cout, H, W)).astype(np.float32)))
+    scale = torch.from_numpy(rs.uniform(0.5, 1.5, Cout).astype(np.float32))
+    shift = torch.from_numpy(rs.normal(size=Cout).astype(np.float32))
+    y_ref = F.conv2d(x, w, None, 1, 1) * scale[None, :, None, None] + shift[None, :, None, None]
+    y_ref = F.leaky_relu(y_ref + F.interpolate(res, scale_factor=2, mode='nearest'), 0.2) + res2
+    stats = torch.zeros(2 * Cout, device=dev)
+    big = torch.zeros((N * H * W, 2 * Cout), device=dev, dtype=dtype)
+    K.conv_fprop(_nhwc(x).to(dev, dtype), _krsc(w).to(dev, dtype), N=N, Hin=H, Win=W, R=3, S=3, pad=1,
+                 scale=scale.to(dev), shift=shift.to(dev), res=_nhwc(res).to(dev, dtype), res_mode=2,
+                 res2=_nhwc(res2).to(dev, dtype), act=K.ACT_LRELU, slope=0.2, stats=stats, out=big, yoff=Cout)
+    y = big[:, Cout:].float().cpu().reshape(N, H, W, Cout).permute(0, 3, 1, 2)
+    assert big[:, :Cout].abs().max().item() == 0
+    assert (y - y_ref).abs().max().item() <= _tol(dtype) * y_ref.abs().max().item()
+    s = stats.cpu()
+    assert torch.allclose(s[:Cout], y.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
+    assert torch.allclose(s[Cout:], (y * y).sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_conv_transpose_k4s2(dtype):
+    """ConvTranspose2d(k=4, s=2, p=1) forward == TCONV-mode implicit GEMM (decoder/resnet.py:20)."""
+    from maggie_amd import kernels as K
+    dev = _dev()
+    N, Cin, Cout, H, W = 2, 64, 48, 7, 9
+    rs = np.random.RandomState(4)
+    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    x = q(torch.from_numpy(rs.normal(size=(N, Cin, H, W)).astype(np.float32)))
+    w = q(torch.from_numpy((rs.normal(size=(Cin, Cout, 4, 4)) / 20).astype(np.float32)))
+    y_ref = F.conv_transpose2d(x, w, None, 2, 1)
+    wk = w.permute(1, 2, 3, 0).reshape(Cout, 16, Cin).contiguous().to(dev, dtype)
+    y = K.conv_fprop(_nhwc(x).to(dev, dtype), wk, mode=K.MODE_TCONV, N=N, Hin=H, Win=W, Hout=2 * H, Wout=2 * W, R=4, S=4,
+                     stride=2, pad=1)
+    y = y.float().cpu().reshape(N, 2 * H, 2 * W, Cout).permute(0, 3, 1, 2)
+    assert (y - y_ref).abs().max().item() <= _tol(dtype) * y_ref.abs().max().item()
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_gather_conv(dtype):
+    """MG_MODE_GATHER against the oracle's gather restatement (submanifold 3x3 over a random active set)."""
+    from maggie_amd import kernels as K
+    from oracle import region, refmodel
+    dev = _dev()
+    rs = np.random.RandomState(5)
+    act = rs.uniform(size=(3, 24, 20)) > 0.6
+    nbr = region.subm_neighbors(act)
+    R_, Cin, Cout = nbr.shape[0], 64, 32
+    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    feat = q(torch.from_numpy(rs.normal(size=(R_, Cin)).astype(np.float32)))
+    w = q(torch.from_numpy((rs.normal(size=(Cout, 3, 3, Cin)) / 24).astype(np.float32)))
+    bias = torch.from_numpy(rs.normal(size=Cout).astype(np.float32))
+    y_ref = refmodel._gather_conv(feat, nbr, w, bias)
+    y = K.conv_fprop(feat.to(dev, dtype), w.reshape(Cout, 9, Cin).to(dev, dtype), mode=K.MODE_GATHER,
+                     nbr=torch.from_numpy(nbr).to(dev), R=3, S=3, shift=bias.to(dev))
+    assert (y.float().cpu() - y_ref).abs().max().item() <= _tol(dtype) * y_ref.abs().max().item()
+    gy = q(torch.from_numpy(rs.normal(size=(R_, Cout)).astype(np.float32)))
+    w_ = w.clone().requires_grad_(True)
+    refmodel._gather_conv(feat, nbr, w_, None).backward(gy)
+    dw = K.conv_wgrad(feat.to(dev, dtype), gy.to(dev, dtype), cout=Cout, mode=K.MODE_GATHER,
+                      nbr=torch.from_numpy(nbr).to(dev), R=3, S=3)
+    assert (dw.cpu().reshape(Cout, 3, 3, Cin) - w_.grad).abs().max().item() <= _tol(dtype) * w_.grad.abs().max().item()
