@@ -68,6 +68,102 @@ int mg_conv_fprop(const mg_conv_params* p, void* stream);
  * `w` unused, `stats` = dW. Replaces cuDNN wgrad / spconv's indice_conv_backward filter gradient. */
 int mg_conv_wgrad(const mg_conv_params* p, void* stream);
 
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Row x channel normalisation / activation kernels (HBM-bound, 16-byte vector accesses).
+ * Replace nn.BatchNorm2d / nn.BatchNorm1d (+ ReLU / LeakyReLU(0.2) / residual add) in
+ *   maggie/network/encoder/resnet.py:23-39,167-175; maggie/network/decoder/resnet.py:28-45;
+ *   maggie/network/module/aspp.py:34-56; maggie/network/decoder/resnet_inst_matt_spconv.py:69-130 (BatchNorm1d over
+ *   the active rows), and nn.AvgPool2d(2,2) / nn.UpsamplingNearest2d(2) (encoder/resnet.py:113, decoder:143).
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct mg_rowwise_params {
+    const void* x;        /* [M, ldx] pre-normalisation input (conv output)                       */
+    void* y;              /* [M, ldy] (+yoff) output of the forward / saved output in backward     */
+    const void* dy;       /* [M, lddy] upstream gradient (backward)                                */
+    void* dx;             /* [M, lddx] gradient w.r.t. x (backward) or NULL                        */
+    const void* res;      /* residual added before the activation, or NULL                         */
+    const void* res2;     /* residual added after the activation, or NULL                          */
+    void* dres;           /* [M, lddres] gradient of `res` (= dy * act'), or NULL                   */
+    const float* scale;   /* [C] gamma*invstd (forward) / (backward)                               */
+    const float* shift;   /* [C] beta - mean*gamma*invstd                                          */
+    const float* mean;    /* [C] (backward)                                                        */
+    const float* invstd;  /* [C] (backward)                                                        */
+    float* sums;          /* [2C] backward reductions: sum g, sum g*xhat                            */
+    const float* count_ptr; /* optional device scalar row count (SyncBN); else `count`               */
+    int32_t dtype, M, C, H, W;
+    int32_t ldx, ldy, yoff, ldr, ldr2, lddy, lddx, lddres;
+    int32_t act, res_mode, mask_x_pos;
+    float slope, count;
+} mg_rowwise_params;
+
+/* stats[c] += sum_m x[m,c], stats[C+c] += sum_m x[m,c]^2 (fp32, pre-zeroed) */
+int mg_colstats(const void* x, int dtype, int M, int C, int ld, float* stats, void* stream);
+/* batch statistics -> scale/shift/mean/invstd, running-stat update with momentum and unbiased variance */
+int mg_bn_finalize(const float* stats, const float* count_ptr, float count, int C, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
+                   float* mean_out, float* invstd_out, void* stream);
+/* eval mode: fold running statistics into scale/shift */
+int mg_bn_fold(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+               float eps, float* scale, float* shift, void* stream);
+/* y = act(x*scale + shift + res) + res2 */
+int mg_affine_act(const mg_rowwise_params* p, void* stream);
+/* BatchNorm backward: reduce (sums) then apply (dx, dres) */
+int mg_bn_bwd_reduce(const mg_rowwise_params* p, void* stream);
+int mg_bn_bwd_apply(const mg_rowwise_params* p, void* stream);
+/* op 0: 2x2 average pool, 1: 2x2 sum pool (out Ho x Wo from 2Ho x 2Wo); 2: 0.25*nearest-upsample, 3: nearest-upsample
+ * (out Ho x Wo from Ho/2 x Wo/2) */
+int mg_pool2x2(const void* in, void* out, int dtype, int op, int N, int Ho, int Wo, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Region ops on bit-packed planes (uint64 words, bit b of word j <-> pixel x = 64*j + b; rows padded to whole words).
+ * Replace compute_unknown (maggie/utils/utils.py:27-55: threshold + CPU cv2.dilate with MORPH_ELLIPSE + H2D copy),
+ * the rule-book side of spconv (`dummy_downscale`, maggie/network/decoder/resnet_inst_matt_spconv.py:61-66,217-218)
+ * and torch.nonzero (:206). Integer work: results are bit-exact w.r.t. oracle/region.py.
+ * ------------------------------------------------------------------------------------------------------------- */
+#define MG_U8 2
+/* mode 0: bit = (lo < a < hi); mode 1: bit = (a > 0). `a` is [P,H,W] planes of dtype MG_F32 or MG_U8. */
+int mg_bits_pack(const void* a, int dtype, void* bits, int P, int H, int W, int mode, float lo, float hi, void* stream);
+int mg_bits_unpack_u8(const void* bits, uint8_t* out, int P, int H, int W, void* stream);
+/* out = dilate(in, ellipse(width)) [& andmask]; `widths` = per-plane device int32[P] (train mode) or NULL + width_all */
+int mg_bits_dilate(const void* in, void* out, const void* andmask, int P, int H, int W, const int32_t* widths, int width_all,
+                   void* stream);
+/* SparseConv2d(k3,s2,p1) output-site rule: coarse is [P, ceil(Hf/2), ceil(Wf/2)] */
+int mg_bits_downsample(const void* fine, void* coarse, int P, int Hf, int Wf, void* stream);
+/* per-row exclusive scan: rowoff[P*H + 1] (rowoff[P*H] = number of active sites), wordoff[P*H*Ww] = rank of each word */
+int mg_bits_rank(const void* bits, int P, int H, int W, int32_t* counts_tmp, int32_t* rowoff, int32_t* wordoff, void* stream);
+/* coords[R,3] = (plane, y, x) of the active sites in sorted order (== torch.nonzero) */
+int mg_bits_coords(const void* bits, const int32_t* wordoff, int P, int H, int W, int32_t* coords, void* stream);
+/* gather tables [R, k*k] into the (src_bits, src_wordoff) level. kind 0: submanifold k x k; kind 1: inverse conv
+ * (rows fine, source coarse, tap valid iff fine = 2*coarse - 1 + tap); kind 2: strided (rows coarse, source fine) */
+int mg_gather_table(const int32_t* coords, int R, int ksize, int kind, const void* src_bits, const int32_t* src_wordoff, int Hs,
+                    int Ws, int32_t* nbr, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Dense <-> sparse gathers, alpha-plane kernels, input packing
+ * (maggie/network/decoder/resnet_inst_matt_spconv.py:161-194,221-232,247-251,264-268,303-304,360-362;
+ *  maggie/network/encoder/resnet.py:211-229).
+ * ------------------------------------------------------------------------------------------------------------- */
+/* out[r, yoff+c] = dense[plane/n_i, y, x, c] * (mul ? mul[plane/n_i, plane%n_i, c] : 1) */
+int mg_gather_rows(const void* dense, int dtype, const int32_t* coords, int R, int n_i, int Hd, int Wd, int C, const float* mul,
+                   int mul_ninst, void* out, int ldo, int yoff, void* stream);
+int mg_gather_rows_bwd(const void* dout, int dtype, int ldo, int yoff, const int32_t* coords, int R, int n_i, int Hd, int Wd, int C,
+                       const float* mul, int mul_ninst, const void* dense, float* ddense, float* dmul, void* stream);
+/* plane[P,H,W] = fill everywhere, vals[r, col] at the active sites (SparseConvTensor.dense() - 99 trick) */
+int mg_scatter_plane(const void* vals, int dtype, int ldv, int col, const int32_t* coords, int R, int P, int H, int W, float fill,
+                     float* plane, void* stream);
+int mg_gather_plane(const float* plane, const int32_t* coords, int R, int H, int W, void* vals, int dtype, int ldv, int col,
+                    void* stream);
+/* x[N,H,W,8] = [RGB, mask-ID embedding (3), 0, 0] from NCHW fp32 image, (N,n_m,Hm,Wm) masks (nearest upsampled) */
+int mg_mask_embed(const float* image, const float* masks, const float* table, int N, int H, int W, int n_m, int Hm, int Wm,
+                  int n_embed, void* out, int dtype, void* stream);
+int mg_mask_embed_bwd(const void* dx, int dtype, const float* masks, int N, int H, int W, int n_m, int Hm, int Wm, int n_embed,
+                      float* dtable, void* stream);
+/* out[N,C,h*s,w*s] (fp32 planes) = (tanh(bilinear_up(in)) + 1)/2 ; `in` addressed with explicit strides */
+int mg_upsample_tanh(const void* in, int dtype, long sn, long sc, long sy, long sx, int N, int C, int h, int w, int scale,
+                     int apply_tanh, float* out, void* stream);
+int mg_upsample_tanh_bwd(const float* dout, const float* out, long sn, long sc, long sy, long sx, int N, int C, int h, int w,
+                         int scale, int apply_tanh, float* din, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

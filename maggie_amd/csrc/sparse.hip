@@ -1,0 +1,312 @@
+// Wavefront-level gather / scatter kernels between dense NHWC feature maps and sparse (active-site) feature rows,
+// plus the input packing and the alpha-plane kernels of the refinement head. All HBM-bound; one 16-byte chunk per lane,
+// consecutive lanes on consecutive channels of the same site so every gathered row is read/written as whole lines.
+// Replaces the fancy-indexing + spconv.SparseConvTensor glue of
+//   maggie/network/decoder/resnet_inst_matt_spconv.py:161-194 (combine_dense_sparse_feat / instance_spec_guidance),
+//   :221-232 (OS8 gather + instance guidance), :247-251,264-268 (.dense() and the -99 fill),
+//   :303-304,360-362 (bilinear upsample + (tanh+1)/2), maggie/network/encoder/resnet.py:211-229 (mask-ID embedding).
+#include "common.h"
+#include "../../include/maggie_hip.h"
+
+namespace {
+
+constexpr int NT = 256;
+inline int grid_for(long total) { long b = (total + NT - 1) / NT; return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
+
+// out[r, yoff + c] = dense[frame(r), y, x, c] * (mul ? mul[frame, inst, c] : 1)
+template <typename T>
+__global__ __launch_bounds__(NT) void gather_rows_kernel(const T* __restrict__ dense, const int* __restrict__ coords, int R, int n_i, int Hd,
+                                                         int Wd, int C, const float* __restrict__ mul, int mul_ninst, T* __restrict__ out,
+                                                         int ldo, int yoff) {
+    using TR = ElemTraits<T>;
+    constexpr int CE = TR::CE;
+    const int cpr = C / CE;
+    const long total = (long)R * cpr;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        int r = (int)(i / cpr), cc = (int)(i - (long)r * cpr);
+        int p = coords[(long)r * 3], y = coords[(long)r * 3 + 1], x = coords[(long)r * 3 + 2];
+        int frame = p / n_i;
+        float f[CE];
+        TR::unpack(*(const uint4*)(dense + (((long)frame * Hd + y) * Wd + x) * C + cc * CE), f);
+        if (mul) {
+            const float* mv = mul + ((long)frame * mul_ninst + (p - frame * n_i)) * C + cc * CE;
+#pragma unroll
+            for (int e = 0; e < CE; ++e) f[e] *= mv[e];
+        }
+        *(uint4*)(out + (long)r * ldo + yoff + cc * CE) = TR::pack(f);
+    }
+}
+
+// backward of the gather: ddense[frame,y,x,c] += dout[r,c] * mul ; dmul[frame,inst,c] += dout[r,c]*dense[...]
+template <typename T>
+__global__ __launch_bounds__(NT) void gather_rows_bwd_kernel(const T* __restrict__ dout, int ldo, int yoff, const int* __restrict__ coords,
+                                                             int R, int n_i, int Hd, int Wd, int C, const float* __restrict__ mul,
+                                                             int mul_ninst, const T* __restrict__ dense, float* __restrict__ ddense,
+                                                             float* __restrict__ dmul) {
+    using TR = ElemTraits<T>;
+    constexpr int CE = TR::CE;
+    const int cpr = C / CE;
+    const long total = (long)R * cpr;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        int r = (int)(i / cpr), cc = (int)(i - (long)r * cpr);
+        int p = coords[(long)r * 3], y = coords[(long)r * 3 + 1], x = coords[(long)r * 3 + 2];
+        int frame = p / n_i;
+        long drow = (((long)frame * Hd + y) * Wd + x) * C + cc * CE;
+        float g[CE];
+        TR::unpack(*(const uint4*)(dout + (long)r * ldo + yoff + cc * CE), g);
+        if (mul) {
+            long mrow = ((long)frame * mul_ninst + (p - frame * n_i)) * C + cc * CE;
+            if (dmul) {
+                float d[CE];
+                TR::unpack(*(const uint4*)(dense + drow), d);
+#pragma unroll
+                for (int e = 0; e < CE; ++e) atomicAdd(&dmul[mrow + e], g[e] * d[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < CE; ++e) g[e] *= mul[mrow + e];
+        }
+        if (ddense) {
+#pragma unroll
+            for (int e = 0; e < CE; ++e) atomicAdd(&ddense[drow + e], g[e]);
+        }
+    }
+}
+
+// plane[p, y, x] = vals[r, col]  (plane pre-filled by the caller's fill kernel)
+template <typename T>
+__global__ __launch_bounds__(NT) void scatter_plane_kernel(const T* __restrict__ vals, int ldv, int col, const int* __restrict__ coords,
+                                                           int R, int H, int W, float* __restrict__ plane) {
+    for (int r = blockIdx.x * NT + threadIdx.x; r < R; r += gridDim.x * NT) {
+        int p = coords[(long)r * 3], y = coords[(long)r * 3 + 1], x = coords[(long)r * 3 + 2];
+        plane[((long)p * H + y) * W + x] = ElemTraits<T>::ld(vals + (long)r * ldv + col);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void gather_plane_kernel(const float* __restrict__ plane, const int* __restrict__ coords, int R, int H, int W,
+                                                          T* __restrict__ vals, int ldv, int col) {
+    for (int r = blockIdx.x * NT + threadIdx.x; r < R; r += gridDim.x * NT) {
+        int p = coords[(long)r * 3], y = coords[(long)r * 3 + 1], x = coords[(long)r * 3 + 2];
+        ElemTraits<T>::st(vals + (long)r * ldv + col, plane[((long)p * H + y) * W + x]);
+    }
+}
+
+__global__ __launch_bounds__(NT) void fill_kernel(float* __restrict__ p, long n, float v) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) p[i] = v;
+}
+
+// ---- input packing: RGB + mask-ID embedding -> NHWC with 8 channels (6 real + 2 zero) -----------------------------------
+// emb[c] = sum_i [mask_i>0] E[i+1, c] / (count + 1e-6)   with ids = (mask_i * (i+1)).long()   (encoder/resnet.py:214-225)
+template <typename T>
+__global__ __launch_bounds__(NT) void mask_embed_kernel(const float* __restrict__ image, const float* __restrict__ masks,
+                                                        const float* __restrict__ table, int N, int H, int W, int n_m, int Hm, int Wm,
+                                                        int n_embed, T* __restrict__ out) {
+    const long total = (long)N * H * W;
+    const int sy = H / Hm, sx = W / Wm;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        int x = (int)(i % W); long r = i / W; int y = (int)(r % H); int n = (int)(r / H);
+        float f[8];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) f[c] = image[(((long)n * 3 + c) * H + y) * W + x];
+        float e[3] = {0.f, 0.f, 0.f};
+        float cnt = 0.f;
+        const float* mp = masks + ((long)n * n_m * Hm + (y / sy)) * Wm + (x / sx);
+        for (int k = 0; k < n_m; ++k) {
+            float mv = mp[(long)k * Hm * Wm];
+            long id = (long)(mv * (float)(k + 1));                 // (masks * mask_ids).long()
+            if (id > 0) {
+                cnt += 1.f;
+                for (int c = 0; c < n_embed && c < 3; ++c) e[c] += table[id * n_embed + c];
+            }
+        }
+        float inv = 1.f / (cnt + 1e-6f);
+        f[3] = e[0] * inv; f[4] = e[1] * inv; f[5] = e[2] * inv; f[6] = 0.f; f[7] = 0.f;
+        T* dst = out + i * 8;
+        if (sizeof(T) == 2) *(uint4*)dst = ElemTraits<bf16raw>::pack(f);
+        else { *(uint4*)dst = ElemTraits<float>::pack(f); *(uint4*)((float*)dst + 4) = ElemTraits<float>::pack(f + 4); }
+    }
+}
+
+// dtable[id, c] += sum_pixels [id active] * g[pixel, 3 + c] / (cnt + 1e-6)
+template <typename T>
+__global__ __launch_bounds__(NT) void mask_embed_bwd_kernel(const T* __restrict__ dx, const float* __restrict__ masks, int N, int H, int W,
+                                                            int n_m, int Hm, int Wm, int n_embed, float* __restrict__ dtable) {
+    __shared__ float acc[64 * 3];
+    for (int i = threadIdx.x; i < 64 * 3; i += NT) acc[i] = 0.f;
+    __syncthreads();
+    const long total = (long)N * H * W;
+    const int sy = H / Hm, sx = W / Wm;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        int x = (int)(i % W); long r = i / W; int y = (int)(r % H); int n = (int)(r / H);
+        const float* mp = masks + ((long)n * n_m * Hm + (y / sy)) * Wm + (x / sx);
+        float cnt = 0.f;
+        for (int k = 0; k < n_m; ++k) { long id = (long)(mp[(long)k * Hm * Wm] * (float)(k + 1)); if (id > 0) cnt += 1.f; }
+        if (cnt == 0.f) continue;
+        float inv = 1.f / (cnt + 1e-6f);
+        float g[3];
+        for (int c = 0; c < 3; ++c) g[c] = ElemTraits<T>::ld(dx + i * 8 + 3 + c) * inv;
+        for (int k = 0; k < n_m; ++k) {
+            long id = (long)(mp[(long)k * Hm * Wm] * (float)(k + 1));
+            if (id > 0 && id < 64) for (int c = 0; c < n_embed && c < 3; ++c) atomicAdd(&acc[id * 3 + c], g[c]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (n_m + 1) * 3; i += NT) {
+        int id = i / 3, c = i - id * 3;
+        if (c < n_embed && acc[i] != 0.f) atomicAdd(&dtable[id * n_embed + c], acc[i]);
+    }
+}
+
+// ---- bilinear upsample (align_corners=False) + (tanh+1)/2 into fp32 NCHW planes ------------------------------------------
+// in element (n, c, y, x) at in[n*sn + c*sc + y*sy + x*sx]
+__device__ __forceinline__ void bil_src(int d, int scale, int in_size, int& i0, int& i1, float& lam) {
+    float s = ((float)d + 0.5f) / (float)scale - 0.5f;
+    if (s < 0.f) s = 0.f;
+    i0 = (int)s;
+    i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+    lam = s - (float)i0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void upsample_tanh_kernel(const T* __restrict__ in, long sn, long sc, long sy, long sx, int N, int C, int h,
+                                                           int w, int scale, int apply_tanh, float* __restrict__ out) {
+    const int H = h * scale, W = w * scale;
+    const long total = (long)N * C * H * W;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        int X = (int)(i % W); long r = i / W; int Y = (int)(r % H); r /= H; int c = (int)(r % C); int n = (int)(r / C);
+        float v;
+        const T* base = in + n * sn + c * sc;
+        if (scale == 1) {
+            v = ElemTraits<T>::ld(base + Y * sy + X * sx);
+        } else {
+            int y0, y1, x0, x1; float ly, lx;
+            bil_src(Y, scale, h, y0, y1, ly);
+            bil_src(X, scale, w, x0, x1, lx);
+            float v00 = ElemTraits<T>::ld(base + y0 * sy + x0 * sx), v01 = ElemTraits<T>::ld(base + y0 * sy + x1 * sx);
+            float v10 = ElemTraits<T>::ld(base + y1 * sy + x0 * sx), v11 = ElemTraits<T>::ld(base + y1 * sy + x1 * sx);
+            v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+        }
+        out[i] = apply_tanh ? (tanhf(v) + 1.f) * 0.5f : v;
+    }
+}
+
+// backward: din(n,c,y,x) (fp32, same strides, pre-zeroed) += bilinear^T( dout * (1 - t^2)/2 ), t = 2*out - 1
+__global__ __launch_bounds__(NT) void upsample_tanh_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out, long sn, long sc,
+                                                               long sy, long sx, int N, int C, int h, int w, int scale, int apply_tanh,
+                                                               float* __restrict__ din) {
+    const int H = h * scale, W = w * scale;
+    const long total = (long)N * C * H * W;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        float g = dout[i];
+        if (apply_tanh) { float t = 2.f * out[i] - 1.f; g *= 0.5f * (1.f - t * t); }
+        if (g == 0.f) continue;
+        int X = (int)(i % W); long r = i / W; int Y = (int)(r % H); r /= H; int c = (int)(r % C); int n = (int)(r / C);
+        float* base = din + n * sn + c * sc;
+        if (scale == 1) { atomicAdd(base + Y * sy + X * sx, g); continue; }
+        int y0, y1, x0, x1; float ly, lx;
+        bil_src(Y, scale, h, y0, y1, ly);
+        bil_src(X, scale, w, x0, x1, lx);
+        atomicAdd(base + y0 * sy + x0 * sx, g * (1.f - ly) * (1.f - lx));
+        atomicAdd(base + y0 * sy + x1 * sx, g * (1.f - ly) * lx);
+        atomicAdd(base + y1 * sy + x0 * sx, g * ly * (1.f - lx));
+        atomicAdd(base + y1 * sy + x1 * sx, g * ly * lx);
+    }
+}
+
+}  // namespace
+
+extern "C" int mg_gather_rows(const void* dense, int dtype, const int32_t* coords, int R, int n_i, int Hd, int Wd, int C, const float* mul,
+                              int mul_ninst, void* out, int ldo, int yoff, void* stream) {
+    if (R <= 0) return 0;
+    const int ce = dtype == MG_BF16 ? 8 : 4;
+    if (C % ce || ldo % ce || yoff % ce) return -3;
+    long total = (long)R * (C / ce);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MG_BF16) hipLaunchKernelGGL(gather_rows_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const bf16raw*)dense, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, (bf16raw*)out, ldo, yoff);
+    else hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, st, (const float*)dense, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, (float*)out, ldo, yoff);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_gather_rows_bwd(const void* dout, int dtype, int ldo, int yoff, const int32_t* coords, int R, int n_i, int Hd, int Wd, int C,
+                                  const float* mul, int mul_ninst, const void* dense, float* ddense, float* dmul, void* stream) {
+    if (R <= 0) return 0;
+    const int ce = dtype == MG_BF16 ? 8 : 4;
+    if (C % ce || ldo % ce || yoff % ce) return -3;
+    long total = (long)R * (C / ce);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MG_BF16) hipLaunchKernelGGL(gather_rows_bwd_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const bf16raw*)dout, ldo, yoff, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, (const bf16raw*)dense, ddense, dmul);
+    else hipLaunchKernelGGL(gather_rows_bwd_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, st, (const float*)dout, ldo, yoff, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, (const float*)dense, ddense, dmul);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_scatter_plane(const void* vals, int dtype, int ldv, int col, const int32_t* coords, int R, int P, int H, int W, float fill,
+                                float* plane, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    long n = (long)P * H * W;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(NT), 0, st, plane, n, fill);
+    if (R > 0) {
+        if (dtype == MG_BF16) hipLaunchKernelGGL(scatter_plane_kernel<bf16raw>, dim3(grid_for(R)), dim3(NT), 0, st, (const bf16raw*)vals, ldv, col, coords, R, H, W, plane);
+        else hipLaunchKernelGGL(scatter_plane_kernel<float>, dim3(grid_for(R)), dim3(NT), 0, st, (const float*)vals, ldv, col, coords, R, H, W, plane);
+    }
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_gather_plane(const float* plane, const int32_t* coords, int R, int H, int W, void* vals, int dtype, int ldv, int col,
+                               void* stream) {
+    if (R <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MG_BF16) hipLaunchKernelGGL(gather_plane_kernel<bf16raw>, dim3(grid_for(R)), dim3(NT), 0, st, plane, coords, R, H, W, (bf16raw*)vals, ldv, col);
+    else hipLaunchKernelGGL(gather_plane_kernel<float>, dim3(grid_for(R)), dim3(NT), 0, st, plane, coords, R, H, W, (float*)vals, ldv, col);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_mask_embed(const float* image, const float* masks, const float* table, int N, int H, int W, int n_m, int Hm, int Wm,
+                             int n_embed, void* out, int dtype, void* stream) {
+    long total = (long)N * H * W;
+    if (total <= 0) return 0;
+    if (H % Hm || W % Wm || n_embed > 3) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MG_BF16) hipLaunchKernelGGL(mask_embed_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), 0, st, image, masks, table, N, H, W, n_m, Hm, Wm, n_embed, (bf16raw*)out);
+    else hipLaunchKernelGGL(mask_embed_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, st, image, masks, table, N, H, W, n_m, Hm, Wm, n_embed, (float*)out);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_mask_embed_bwd(const void* dx, int dtype, const float* masks, int N, int H, int W, int n_m, int Hm, int Wm, int n_embed,
+                                 float* dtable, void* stream) {
+    long total = (long)N * H * W;
+    if (total <= 0) return 0;
+    if (n_m + 1 > 64) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    int g = grid_for(total); if (g > 1024) g = 1024;
+    if (dtype == MG_BF16) hipLaunchKernelGGL(mask_embed_bwd_kernel<bf16raw>, dim3(g), dim3(NT), 0, st, (const bf16raw*)dx, masks, N, H, W, n_m, Hm, Wm, n_embed, dtable);
+    else hipLaunchKernelGGL(mask_embed_bwd_kernel<float>, dim3(g), dim3(NT), 0, st, (const float*)dx, masks, N, H, W, n_m, Hm, Wm, n_embed, dtable);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_upsample_tanh(const void* in, int dtype, long sn, long sc, long sy, long sx, int N, int C, int h, int w, int scale,
+                                int apply_tanh, float* out, void* stream) {
+    long total = (long)N * C * h * w * scale * scale;
+    if (total <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MG_BF16) hipLaunchKernelGGL(upsample_tanh_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const bf16raw*)in, sn, sc, sy, sx, N, C, h, w, scale, apply_tanh, out);
+    else hipLaunchKernelGGL(upsample_tanh_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, st, (const float*)in, sn, sc, sy, sx, N, C, h, w, scale, apply_tanh, out);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_upsample_tanh_bwd(const float* dout, const float* out, long sn, long sc, long sy, long sx, int N, int C, int h, int w,
+                                    int scale, int apply_tanh, float* din, void* stream) {
+    long total = (long)N * C * h * w * scale * scale;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(upsample_tanh_bwd_kernel, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, dout, out, sn, sc, sy, sx, N, C, h, w,
+                       scale, apply_tanh, din);
+    MG_CHECK_LAUNCH();
+    return 0;
+}

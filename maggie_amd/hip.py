@@ -85,3 +85,21 @@ def call(name, *args):
     fn = getattr(lib(), name)
     fn.restype = ctypes.c_int
     check(fn(*args), name)
+
+
+class RowwiseParams(ctypes.Structure):
+    _fields_ = [
+        ('x', ctypes.c_void_p), ('y', ctypes.c_void_p), ('dy', ctypes.c_void_p), ('dx', ctypes.c_void_p),
+        ('res', ctypes.c_void_p), ('res2', ctypes.c_void_p), ('dres', ctypes.c_void_p),
+        ('scale', ctypes.c_void_p), ('shift', ctypes.c_void_p), ('mean', ctypes.c_void_p), ('invstd', ctypes.c_void_p),
+        ('sums', ctypes.c_void_p), ('count_ptr', ctypes.c_void_p),
+        ('dtype', ctypes.c_int32), ('M', ctypes.c_int32), ('C', ctypes.c_int32), ('H', ctypes.c_int32), ('W', ctypes.c_int32),
+        ('ldx', ctypes.c_int32), ('ldy', ctypes.c_int32), ('yoff', ctypes.c_int32), ('ldr', ctypes.c_int32),
+        ('ldr2', ctypes.c_int32), ('lddy', ctypes.c_int32), ('lddx', ctypes.c_int32), ('lddres', ctypes.c_int32),
+        ('act', ctypes.c_int32), ('res_mode', ctypes.c_int32), ('mask_x_pos', ctypes.c_int32),
+        ('slope', ctypes.c_float), ('count', ctypes.c_float),
+    ]
+
+
+U8 = 2
+c_int, c_float, c_long = ctypes.c_int, ctypes.c_float, ctypes.c_long

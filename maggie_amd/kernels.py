@@ -13,7 +13,7 @@ from .hip import ConvParams, MODE_CONV, MODE_TCONV, MODE_GATHER, ACT_NONE, ACT_R
 
 def _ld(t):
     """Row pitch (elements) of a channel-contiguous tensor."""
-    assert t.stride(-1) == 1, 'channel dimension must be contiguous'
+    assert t.shape[-1] == 1 or t.stride(-1) == 1, 'channel dimension must be contiguous'
     return t.stride(-2) if t.dim() >= 2 else t.shape[-1]
 
 
@@ -91,3 +91,268 @@ def conv_wgrad(x, dy, *, cout, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=1, Wout=1
                      stats=out, yoff=yoff)
     hip.call('mg_conv_wgrad', ctypes.byref(p), hip.stream())
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BatchNorm / row-wise kernels
+# ------------------------------------------------------------------------------------------------------------------
+from .hip import RowwiseParams, c_int, c_float, c_long  # noqa: E402
+
+
+def colstats(x, stats=None):
+    """stats[2C] (fp32) += column sum / sum of squares of x (M, C)."""
+    M, C = x.shape[0], x.shape[-1]
+    if stats is None:
+        stats = torch.zeros(2 * C, dtype=torch.float32, device=x.device)
+    hip.need_cuda(x, stats)
+    hip.call('mg_colstats', hip.ptr(x), c_int(hip.dtype_code(x)), c_int(M), c_int(C), c_int(_ld(x)), hip.ptr(stats), hip.stream())
+    return stats
+
+
+def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps, count_ptr=None):
+    """-> scale, shift, mean, invstd (each fp32 [C]); updates the running statistics in place when given."""
+    C = stats.numel() // 2
+    out = torch.empty((4, C), dtype=torch.float32, device=stats.device)
+    hip.need_cuda(stats, gamma, beta, running_mean, running_var)
+    hip.call('mg_bn_finalize', hip.ptr(stats), hip.ptr(count_ptr), c_float(float(count)), c_int(C), hip.ptr(gamma), hip.ptr(beta),
+             hip.ptr(running_mean), hip.ptr(running_var), c_float(momentum), c_float(eps), hip.ptr(out[0]), hip.ptr(out[1]),
+             hip.ptr(out[2]), hip.ptr(out[3]), hip.stream())
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_fold(gamma, beta, running_mean, running_var, eps):
+    C = running_mean.numel()
+    out = torch.empty((2, C), dtype=torch.float32, device=running_mean.device)
+    hip.need_cuda(gamma, beta, running_mean, running_var)
+    hip.call('mg_bn_fold', c_int(C), hip.ptr(gamma), hip.ptr(beta), hip.ptr(running_mean), hip.ptr(running_var), c_float(eps),
+             hip.ptr(out[0]), hip.ptr(out[1]), hip.stream())
+    return out[0], out[1]
+
+
+def _rowwise(x, M, C):
+    p = RowwiseParams()
+    p.dtype, p.M, p.C = hip.dtype_code(x), M, C
+    p.x, p.ldx = hip.ptr(x), _ld(x)
+    return p
+
+
+def affine_act(x, scale=None, shift=None, res=None, res_mode=1, res2=None, act=ACT_NONE, slope=0.2, H=1, W=1, out=None, yoff=0):
+    """y = act(x*scale + shift + res) + res2 over rows x channels."""
+    M, C = x.shape[0], x.shape[-1]
+    if out is None:
+        out = torch.empty((M, C), dtype=x.dtype, device=x.device)
+    hip.need_cuda(x, scale, shift, res, res2, out)
+    p = _rowwise(x, M, C)
+    p.y, p.ldy, p.yoff = hip.ptr(out), _ld(out), yoff
+    p.scale, p.shift = hip.ptr(scale), hip.ptr(shift)
+    p.res, p.ldr, p.res_mode = hip.ptr(res), (_ld(res) if res is not None else 0), (res_mode if res is not None else 0)
+    p.res2, p.ldr2 = hip.ptr(res2), (_ld(res2) if res2 is not None else 0)
+    p.act, p.slope, p.H, p.W = act, slope, H, W
+    hip.call('mg_affine_act', ctypes.byref(p), hip.stream())
+    return out
+
+
+def bn_backward(dy, y, x, scale, mean, invstd, count, act=ACT_NONE, slope=0.2, want_dres=False, mask_x_pos=False, yoff=0,
+                count_ptr=None, sums=None, want_dx=True, reduce_only=False, apply_only=False):
+    """BatchNorm(+activation) backward over rows x channels.
+    Returns (dx, dres, sums) with sums = [sum g, sum g*xhat] (= dbeta, dgamma)."""
+    M, C = x.shape[0], x.shape[-1]
+    hip.need_cuda(dy, y, x, scale, mean, invstd)
+    p = _rowwise(x, M, C)
+    p.dy, p.lddy = hip.ptr(dy), _ld(dy)
+    p.y, p.ldy, p.yoff = hip.ptr(y), (_ld(y) if y is not None else 0), yoff
+    p.scale, p.mean, p.invstd = hip.ptr(scale), hip.ptr(mean), hip.ptr(invstd)
+    if sums is None:
+        sums = torch.zeros(2 * C, dtype=torch.float32, device=x.device)
+    p.sums = hip.ptr(sums)
+    p.count, p.count_ptr = float(count), hip.ptr(count_ptr)
+    p.act, p.slope, p.mask_x_pos = act, slope, int(mask_x_pos)
+    dx = dres = None
+    if not apply_only:
+        hip.call('mg_bn_bwd_reduce', ctypes.byref(p), hip.stream())
+    if reduce_only:
+        return None, None, sums
+    if want_dx:
+        dx = torch.empty((M, C), dtype=x.dtype, device=x.device)
+        p.dx, p.lddx = hip.ptr(dx), C
+    if want_dres:
+        dres = torch.empty((M, C), dtype=x.dtype, device=x.device)
+        p.dres, p.lddres = hip.ptr(dres), C
+    hip.call('mg_bn_bwd_apply', ctypes.byref(p), hip.stream())
+    return dx, dres, sums
+
+
+def pool2x2(x, op, N, Ho, Wo):
+    """x: NHWC rows. op 0 avg-pool, 1 sum-pool (input 2Ho x 2Wo); 2 = 0.25*nearest-up, 3 = nearest-up (input Ho/2 x Wo/2)."""
+    C = x.shape[-1]
+    assert x.is_contiguous()
+    out = torch.empty((N * Ho * Wo, C), dtype=x.dtype, device=x.device)
+    hip.need_cuda(x)
+    hip.call('mg_pool2x2', hip.ptr(x), hip.ptr(out), c_int(hip.dtype_code(x)), c_int(op), c_int(N), c_int(Ho), c_int(Wo), c_int(C),
+             hip.stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# region ops on bit planes
+# ------------------------------------------------------------------------------------------------------------------
+LOWER_THRES = 1.0 / 255.0
+UPPER_THRES = 254.0 / 255.0
+
+
+def words(W):
+    return (W + 63) // 64
+
+
+def bits_pack(a, mode=0, lo=LOWER_THRES, hi=UPPER_THRES):
+    """a: (..., H, W) fp32 or uint8 planes (contiguous) -> int64 bit planes (P, H, Ww)."""
+    H, W = a.shape[-2:]
+    P = a.numel() // (H * W)
+    assert a.is_contiguous()
+    hip.need_cuda(a)
+    dt = hip.U8 if a.dtype == torch.uint8 else hip.F32
+    assert dt == hip.U8 or a.dtype == torch.float32
+    bits = torch.empty((P, H, words(W)), dtype=torch.int64, device=a.device)
+    hip.call('mg_bits_pack', hip.ptr(a), c_int(dt), hip.ptr(bits), c_int(P), c_int(H), c_int(W), c_int(mode), c_float(lo), c_float(hi),
+             hip.stream())
+    return bits
+
+
+def bits_unpack_u8(bits, W, shape=None):
+    P, H, Ww = bits.shape
+    out = torch.empty((P, H, W), dtype=torch.uint8, device=bits.device)
+    hip.call('mg_bits_unpack_u8', hip.ptr(bits), hip.ptr(out), c_int(P), c_int(H), c_int(W), hip.stream())
+    return out if shape is None else out.view(*shape)
+
+
+def bits_dilate(bits, W, width=None, widths=None, andmask=None):
+    """Binary dilation with OpenCV's ellipse of the given width (scalar) or per-plane device int32 `widths`."""
+    P, H, Ww = bits.shape
+    out = torch.empty_like(bits)
+    if widths is not None:
+        assert widths.dtype == torch.int32 and widths.numel() == P and widths.is_cuda
+    hip.call('mg_bits_dilate', hip.ptr(bits), hip.ptr(out), hip.ptr(andmask), c_int(P), c_int(H), c_int(W), hip.ptr(widths),
+             c_int(0 if width is None else int(width)), hip.stream())
+    return out
+
+
+def bits_downsample(bits, Wf):
+    P, Hf, _ = bits.shape
+    Hc, Wc = (Hf - 1) // 2 + 1, (Wf - 1) // 2 + 1
+    out = torch.empty((P, Hc, words(Wc)), dtype=torch.int64, device=bits.device)
+    hip.call('mg_bits_downsample', hip.ptr(bits), hip.ptr(out), c_int(P), c_int(Hf), c_int(Wf), hip.stream())
+    return out, Hc, Wc
+
+
+def bits_rank(bits, W):
+    """-> rowoff (P*H+1,) int32 [last = number of active sites], wordoff (P,H,Ww) int32."""
+    P, H, Ww = bits.shape
+    tmp = torch.empty((P * H,), dtype=torch.int32, device=bits.device)
+    rowoff = torch.empty((P * H + 1,), dtype=torch.int32, device=bits.device)
+    wordoff = torch.empty((P, H, Ww), dtype=torch.int32, device=bits.device)
+    hip.call('mg_bits_rank', hip.ptr(bits), c_int(P), c_int(H), c_int(W), hip.ptr(tmp), hip.ptr(rowoff), hip.ptr(wordoff), hip.stream())
+    return rowoff, wordoff
+
+
+def bits_coords(bits, wordoff, W, R):
+    P, H, Ww = bits.shape
+    coords = torch.empty((R, 3), dtype=torch.int32, device=bits.device)
+    if R > 0:
+        hip.call('mg_bits_coords', hip.ptr(bits), hip.ptr(wordoff), c_int(P), c_int(H), c_int(W), hip.ptr(coords), hip.stream())
+    return coords
+
+
+def gather_table(coords, ksize, kind, src_bits, src_wordoff, Hs, Ws):
+    R = coords.shape[0]
+    nbr = torch.empty((R, ksize * ksize), dtype=torch.int32, device=coords.device)
+    if R > 0:
+        hip.call('mg_gather_table', hip.ptr(coords), c_int(R), c_int(ksize), c_int(kind), hip.ptr(src_bits), hip.ptr(src_wordoff),
+                 c_int(Hs), c_int(Ws), hip.ptr(nbr), hip.stream())
+    return nbr
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# dense <-> sparse, alpha planes, input packing
+# ------------------------------------------------------------------------------------------------------------------
+def gather_rows(dense, coords, n_i, mul=None, out=None, yoff=0):
+    """dense: (N, Hd, Wd, C) NHWC contiguous; coords (R,3) at that level; mul: fp32 (N, n_tok, C) or None."""
+    N, Hd, Wd, C = dense.shape
+    R = coords.shape[0]
+    assert dense.is_contiguous() and coords.is_contiguous() and coords.dtype == torch.int32
+    if out is None:
+        out = torch.empty((R, C), dtype=dense.dtype, device=dense.device)
+    hip.need_cuda(dense, coords, mul, out)
+    if mul is not None:
+        assert mul.dtype == torch.float32 and mul.is_contiguous() and mul.shape[-1] == C
+    hip.call('mg_gather_rows', hip.ptr(dense), c_int(hip.dtype_code(dense)), hip.ptr(coords), c_int(R), c_int(n_i), c_int(Hd), c_int(Wd),
+             c_int(C), hip.ptr(mul), c_int(mul.shape[1] if mul is not None else 0), hip.ptr(out), c_int(_ld(out)), c_int(yoff), hip.stream())
+    return out
+
+
+def gather_rows_bwd(dout, coords, n_i, dense_shape, mul=None, dense=None, yoff=0, want_ddense=True, want_dmul=False):
+    N, Hd, Wd, C = dense_shape
+    R = coords.shape[0]
+    ddense = torch.zeros(dense_shape, dtype=torch.float32, device=dout.device) if want_ddense else None
+    dmul = torch.zeros_like(mul) if (want_dmul and mul is not None) else None
+    hip.call('mg_gather_rows_bwd', hip.ptr(dout), c_int(hip.dtype_code(dout)), c_int(_ld(dout)), c_int(yoff), hip.ptr(coords), c_int(R),
+             c_int(n_i), c_int(Hd), c_int(Wd), c_int(C), hip.ptr(mul), c_int(mul.shape[1] if mul is not None else 0), hip.ptr(dense),
+             hip.ptr(ddense), hip.ptr(dmul), hip.stream())
+    return ddense, dmul
+
+
+def scatter_plane(vals, col, coords, P, H, W, fill=-99.0):
+    R = coords.shape[0]
+    plane = torch.empty((P, H, W), dtype=torch.float32, device=coords.device)
+    hip.call('mg_scatter_plane', hip.ptr(vals), c_int(hip.dtype_code(vals) if vals is not None else 0),
+             c_int(_ld(vals) if vals is not None and R > 0 else 1), c_int(col), hip.ptr(coords), c_int(R), c_int(P), c_int(H), c_int(W),
+             c_float(fill), hip.ptr(plane), hip.stream())
+    return plane
+
+
+def gather_plane(plane, coords, like):
+    """-> (R, 1) tensor of dtype like.dtype with plane values at the sites."""
+    R = coords.shape[0]
+    P, H, W = plane.shape
+    out = torch.empty((R, 1), dtype=like, device=plane.device)
+    hip.call('mg_gather_plane', hip.ptr(plane), hip.ptr(coords), c_int(R), c_int(H), c_int(W), hip.ptr(out),
+             c_int(hip.BF16 if like == torch.bfloat16 else hip.F32), c_int(1), c_int(0), hip.stream())
+    return out
+
+
+def mask_embed(image, masks, table, dtype):
+    """image (N,3,H,W) fp32, masks (N,n_m,Hm,Wm) fp32, table (n_m+1, n_embed) fp32 -> (N,H,W,8) NHWC of `dtype`."""
+    N, _, H, W = image.shape
+    n_m, Hm, Wm = masks.shape[1:]
+    assert image.is_contiguous() and masks.is_contiguous() and image.dtype == torch.float32 and masks.dtype == torch.float32
+    hip.need_cuda(image, masks, table)
+    out = torch.empty((N, H, W, 8), dtype=dtype, device=image.device)
+    hip.call('mg_mask_embed', hip.ptr(image), hip.ptr(masks), hip.ptr(table), c_int(N), c_int(H), c_int(W), c_int(n_m), c_int(Hm), c_int(Wm),
+             c_int(table.shape[1]), hip.ptr(out), c_int(hip.dtype_code(out)), hip.stream())
+    return out
+
+
+def mask_embed_bwd(dx, masks, table_shape):
+    N, H, W, _ = dx.shape
+    n_m, Hm, Wm = masks.shape[1:]
+    dtable = torch.zeros(table_shape, dtype=torch.float32, device=dx.device)
+    hip.call('mg_mask_embed_bwd', hip.ptr(dx), c_int(hip.dtype_code(dx)), hip.ptr(masks), c_int(N), c_int(H), c_int(W), c_int(n_m), c_int(Hm),
+             c_int(Wm), c_int(table_shape[1]), hip.ptr(dtable), hip.stream())
+    return dtable
+
+
+def upsample_tanh(x, strides, N, C, h, w, scale, apply_tanh=True):
+    """x addressed as (n, c, y, x) with element strides -> fp32 (N, C, h*scale, w*scale) = (tanh(bilinear(x)) + 1)/2."""
+    out = torch.empty((N, C, h * scale, w * scale), dtype=torch.float32, device=x.device)
+    sn, sc, sy, sx = strides
+    hip.need_cuda(x)
+    hip.call('mg_upsample_tanh', hip.ptr(x), c_int(hip.dtype_code(x)), c_long(sn), c_long(sc), c_long(sy), c_long(sx), c_int(N), c_int(C),
+             c_int(h), c_int(w), c_int(scale), c_int(int(apply_tanh)), hip.ptr(out), hip.stream())
+    return out
+
+
+def upsample_tanh_bwd(dout, out, strides, N, C, h, w, scale, din, apply_tanh=True):
+    """din: fp32 buffer with the input's strides (pre-zeroed), accumulated atomically."""
+    sn, sc, sy, sx = strides
+    hip.call('mg_upsample_tanh_bwd', hip.ptr(dout), hip.ptr(out), c_long(sn), c_long(sc), c_long(sy), c_long(sx), c_int(N), c_int(C), c_int(h),
+             c_int(w), c_int(scale), c_int(int(apply_tanh)), hip.ptr(din), hip.stream())
+    return din

@@ -162,7 +162,7 @@ def active_pyramid(roi: np.ndarray):
 def coords_of(act: np.ndarray) -> np.ndarray:
     """Row-major sorted (batch, y, x) int32 coordinates of active sites == torch.nonzero order
     (resnet_inst_matt_spconv.py:206-214)."""
-    return np.argwhere(act).astype(np.int32)
+    return np.ascontiguousarray(np.argwhere(act).astype(np.int32))
 
 
 def index_grid(act: np.ndarray) -> np.ndarray:

@@ -1,0 +1,225 @@
+"""GPU parity of the HBM-bound kernels (BatchNorm family, region/bit-plane ops, dense<->sparse gathers, alpha planes)
+through the C ABI, against the CPU oracle (oracle/region.py: bit-exact) or a plain PyTorch fp32 CPU reference."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    return torch.device('cuda:0')
+
+
+def _q(dtype):
+    return (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+
+
+def _tol(dtype):
+    return 1e-5 if dtype == torch.float32 else 1.6e-2
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('act', [0, 1, 2])
+def test_bn_train_forward_backward(dtype, act):
+    from maggie_amd import kernels as K
+    dev = _dev()
+    rs = np.random.RandomState(1)
+    M, C = 1000, 64
+    q = _q(dtype)
+    x = q(torch.from_numpy(rs.normal(1.0, 2.0, (M, C)).astype(np.float32))).requires_grad_(True)
+    res = q(torch.from_numpy(rs.normal(size=(M, C)).astype(np.float32))).requires_grad_(True)
+    gamma = torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32)).requires_grad_(True)
+    beta = torch.from_numpy(rs.normal(size=C).astype(np.float32)).requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    y_ref = F.batch_norm(x, rm, rv, gamma, beta, True, 0.1, 1e-5) + res
+    y_ref = [lambda t: t, F.relu, lambda t: F.leaky_relu(t, 0.2)][act](y_ref)
+    gy = q(torch.from_numpy(rs.normal(size=(M, C)).astype(np.float32)))
+    y_ref.backward(gy)
+
+    xd, resd = x.detach().to(dev, dtype), res.detach().to(dev, dtype)
+    rmd, rvd = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    stats = K.colstats(xd)
+    scale, shift, mean, invstd = K.bn_finalize(stats, M, gamma.detach().to(dev), beta.detach().to(dev), rmd, rvd, 0.1, 1e-5)
+    y = K.affine_act(xd, scale, shift, res=resd, act=act, slope=0.2)
+    tol = _tol(dtype)
+    assert (y.float().cpu() - y_ref.detach()).abs().max() <= tol * y_ref.abs().max() + 1e-6
+    assert torch.allclose(rmd.cpu(), rm, atol=1e-4) and torch.allclose(rvd.cpu(), rv, atol=1e-3)
+    dx, dres, sums = K.bn_backward(gy.to(dev, dtype), y, xd, scale, mean, invstd, M, act=act, slope=0.2, want_dres=True)
+    assert (dx.float().cpu() - x.grad).abs().max() <= max(tol, 2e-4) * x.grad.abs().max() * 2
+    assert (dres.float().cpu() - res.grad).abs().max() <= tol * res.grad.abs().max() + 1e-6
+    assert torch.allclose(sums[:C].cpu(), beta.grad, rtol=2e-2, atol=2e-2 * beta.grad.abs().max().item())
+    assert torch.allclose(sums[C:].cpu(), gamma.grad, rtol=2e-2, atol=2e-2 * gamma.grad.abs().max().item())
+
+
+def test_bn_fold_and_pool():
+    from maggie_amd import kernels as K
+    dev = _dev()
+    rs = np.random.RandomState(2)
+    C = 32
+    g, b, rm, rv = [torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32)) for _ in range(4)]
+    scale, shift = K.bn_fold(g.to(dev), b.to(dev), rm.to(dev), rv.to(dev), 1e-5)
+    x = torch.from_numpy(rs.normal(size=(2, C, 8, 6)).astype(np.float32))
+    y_ref = F.batch_norm(x, rm, rv, g, b, False, 0.1, 1e-5)
+    xr = x.permute(0, 2, 3, 1).reshape(-1, C).contiguous().to(dev)
+    y = K.affine_act(xr, scale, shift).cpu().reshape(2, 8, 6, C).permute(0, 3, 1, 2)
+    assert torch.allclose(y, y_ref, atol=1e-5)
+    p = K.pool2x2(xr, 0, 2, 4, 3).cpu().reshape(2, 4, 3, C).permute(0, 3, 1, 2)
+    assert torch.allclose(p, F.avg_pool2d(x, 2, 2), atol=1e-6)
+    u = K.pool2x2(xr, 3, 2, 16, 12).cpu().reshape(2, 16, 12, C).permute(0, 3, 1, 2)
+    assert torch.equal(u, F.interpolate(x, scale_factor=2, mode='nearest'))
+
+
+@pytest.mark.parametrize('hw', [(64, 64), (96, 160), (40, 200)])
+def test_compute_unknown_bit_exact(hw):
+    """threshold + ellipse dilation == oracle.region.compute_unknown, eval width and random train widths."""
+    from maggie_amd import kernels as K
+    from oracle import region
+    dev = _dev()
+    H, W = hw
+    rs = np.random.RandomState(H + W)
+    a = rs.uniform(size=(5, H, W)).astype(np.float32)
+    a[a < 0.7] = 0.0
+    a[a > 0.95] = 1.0
+    a[0, :3, :3] = 0.5
+    a[1, -2:, -2:] = 0.5
+    a[2] = 0
+    a[2, H // 2, W - 1] = 0.3
+    bits = K.bits_pack(torch.from_numpy(a).to(dev))
+    for k in (30, 27, 15):
+        ref = region.compute_unknown(a, k, False)
+        out = K.bits_unpack_u8(K.bits_dilate(bits, W, width=k // 2), W).cpu().numpy()
+        assert np.array_equal(out, ref), k
+    widths = rs.randint(1, 30, size=5).astype(np.int32)
+    ref = region.compute_unknown(a, 30, True, widths=widths)
+    out = K.bits_unpack_u8(K.bits_dilate(bits, W, widths=torch.from_numpy(widths).to(dev)), W).cpu().numpy()
+    assert np.array_equal(out, ref)
+    for k in range(1, 30):                                  # every structuring element incl. even widths
+        ref = region.compute_unknown(a[:2], 30, True, widths=np.array([k, k]))
+        out = K.bits_unpack_u8(K.bits_dilate(bits[:2].contiguous(), W, width=k), W).cpu().numpy()
+        assert np.array_equal(out, ref), k
+
+
+@pytest.mark.parametrize('hw', [(64, 64), (72, 136)])
+def test_active_pyramid_and_tables_bit_exact(hw):
+    from maggie_amd import kernels as K
+    from oracle import region
+    dev = _dev()
+    H, W = hw
+    rs = np.random.RandomState(7)
+    roi = (rs.uniform(size=(3, H, W)) > 0.93).astype(np.uint8)
+    roi[1] = 0
+    roi[2, 10:30, 5:50] = 1
+    pyr = region.active_pyramid(roi)
+    b1 = K.bits_pack(torch.from_numpy(roi).to(dev), mode=1)
+    levels = [(b1, H, W)]
+    for _ in range(3):
+        bb, hh, ww = K.bits_downsample(levels[-1][0], levels[-1][2])
+        levels.append((bb, hh, ww))
+    ranks, coords = [], []
+    for (bb, hh, ww), act in zip(levels, pyr):
+        assert np.array_equal(K.bits_unpack_u8(bb, ww).cpu().numpy().astype(bool), act)
+        rowoff, wordoff = K.bits_rank(bb, ww)
+        R = int(rowoff[-1].item())
+        assert R == int(act.sum())
+        c = K.bits_coords(bb, wordoff, ww, R)
+        assert np.array_equal(c.cpu().numpy(), region.coords_of(act))
+        ranks.append(wordoff)
+        coords.append(c)
+    for lv in (0, 2):
+        bb, hh, ww = levels[lv]
+        nbr = K.gather_table(coords[lv], 3, 0, bb, ranks[lv], hh, ww)
+        assert np.array_equal(nbr.cpu().numpy(), region.subm_neighbors(pyr[lv]))
+    for lv in (0, 1, 2):
+        bc, hc, wc = levels[lv + 1]
+        nbr = K.gather_table(coords[lv], 3, 1, bc, ranks[lv + 1], hc, wc)
+        ref = region.inverse_neighbors(pyr[lv], pyr[lv + 1])
+        assert np.array_equal(nbr.cpu().numpy(), ref)
+        # strided table = transpose of the inverse table
+        bf, hf, wf = levels[lv]
+        down = K.gather_table(coords[lv + 1], 3, 2, bf, ranks[lv], hf, wf).cpu().numpy()
+        chk = np.full_like(down, -1)
+        rr, kk = np.nonzero(ref >= 0)
+        chk[ref[rr, kk], kk] = rr
+        assert np.array_equal(down, chk)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_gather_scatter_rows_and_planes(dtype):
+    from maggie_amd import kernels as K
+    from oracle import region
+    dev = _dev()
+    rs = np.random.RandomState(8)
+    N, n_i, H, W, C = 2, 3, 16, 24, 32
+    act = rs.uniform(size=(N * n_i, H, W)) > 0.8
+    co = region.coords_of(act)
+    R = co.shape[0]
+    q = _q(dtype)
+    dense = q(torch.from_numpy(rs.normal(size=(N, H, W, C)).astype(np.float32)))
+    mul = torch.from_numpy(rs.normal(size=(N, 10, C)).astype(np.float32))
+    fr = torch.from_numpy(co[:, 0] // n_i).long()
+    inst = torch.from_numpy(co[:, 0] % n_i).long()
+    yy, xx = torch.from_numpy(co[:, 1]).long(), torch.from_numpy(co[:, 2]).long()
+    ref = dense[fr, yy, xx] * mul[fr, inst]
+    cod = torch.from_numpy(co).to(dev)
+    big = torch.zeros((R, 2 * C), device=dev, dtype=dtype)
+    K.gather_rows(dense.to(dev, dtype), cod, n_i, mul=mul.to(dev), out=big, yoff=C)
+    assert (big[:, C:].float().cpu() - ref).abs().max() <= _tol(dtype) * ref.abs().max()
+    g = q(torch.from_numpy(rs.normal(size=(R, C)).astype(np.float32)))
+    dd, dm = K.gather_rows_bwd(g.to(dev, dtype), cod, n_i, (N, H, W, C), mul=mul.to(dev), dense=dense.to(dev, dtype), want_dmul=True)
+    dref = torch.zeros(N, H, W, C).index_put((fr, yy, xx), g * mul[fr, inst], accumulate=True)
+    mref = torch.zeros(N, 10, C).index_put((fr, inst), g * dense[fr, yy, xx], accumulate=True)
+    assert torch.allclose(dd.cpu(), dref, atol=1e-4) and torch.allclose(dm.cpu(), mref, rtol=1e-3, atol=1e-3)
+    vals = q(torch.from_numpy(rs.normal(size=(R, 1)).astype(np.float32)))
+    plane = K.scatter_plane(vals.to(dev, dtype), 0, cod, N * n_i, H, W, -99.0).cpu()
+    pref = torch.full((N * n_i, H, W), -99.0)
+    pref[torch.from_numpy(co[:, 0]).long(), yy, xx] = vals[:, 0]
+    assert torch.equal(plane, pref)
+    back = K.gather_plane(plane.to(dev), cod, dtype).float().cpu()
+    assert torch.equal(back, vals)
+
+
+@pytest.mark.parametrize('scale', [1, 4, 8])
+def test_upsample_tanh(scale):
+    from maggie_amd import kernels as K
+    dev = _dev()
+    rs = np.random.RandomState(scale)
+    N, C, h, w = 2, 3, 8, 12
+    x = torch.from_numpy(rs.normal(size=(N, h, w, 16)).astype(np.float32) * 2)     # NHWC, only first C channels used
+    xin = x[..., :C].permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    up = xin if scale == 1 else F.interpolate(xin, scale_factor=float(scale), mode='bilinear', align_corners=False)
+    ref = (torch.tanh(up) + 1) / 2
+    g = torch.from_numpy(rs.normal(size=tuple(ref.shape)).astype(np.float32))
+    ref.backward(g)
+    xd = x.to(dev)
+    strides = (h * w * 16, 1, w * 16, 16)
+    out = K.upsample_tanh(xd, strides, N, C, h, w, scale)
+    assert torch.allclose(out.cpu(), ref.detach(), atol=2e-6)
+    din = torch.zeros((N, h, w, 16), device=dev)
+    K.upsample_tanh_bwd(g.to(dev), out, strides, N, C, h, w, scale, din)
+    assert torch.allclose(din[..., :C].cpu().permute(0, 3, 1, 2), xin.grad, atol=1e-5)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_mask_embed(dtype):
+    from maggie_amd import kernels as K
+    from oracle import refmodel
+    dev = _dev()
+    rs = np.random.RandomState(9)
+    N, H, W, n_m = 2, 32, 48, 10
+    image = torch.from_numpy(rs.normal(size=(N, 3, H, W)).astype(np.float32))
+    masks = torch.from_numpy((rs.uniform(size=(N, n_m, H // 8, W // 8)) > 0.6).astype(np.float32))
+    table = torch.from_numpy(rs.normal(size=(n_m + 1, 3)).astype(np.float32)).requires_grad_(True)
+    emb = refmodel.mask_id_embedding({'e.mask_embed_layer.weight': table}, 'e', F.interpolate(masks, size=(H, W), mode='nearest'))
+    ref = torch.cat([image, emb], 1)
+    out = K.mask_embed(image.to(dev), masks.to(dev), table.detach().to(dev), dtype)
+    o = out.float().cpu()
+    assert o[..., 6:].abs().max() == 0
+    assert (o[..., :6].permute(0, 3, 1, 2) - ref.detach()).abs().max() <= _tol(dtype) * 4
+    g = torch.from_numpy(rs.normal(size=(N, H, W, 8)).astype(np.float32))
+    emb.backward(g[..., 3:6].permute(0, 3, 1, 2))
+    dt = K.mask_embed_bwd(g.to(dev), masks.to(dev), (n_m + 1, 3))
+    assert torch.allclose(dt.cpu(), table.grad, rtol=1e-3, atol=1e-3)
