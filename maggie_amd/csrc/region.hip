@@ -220,25 +220,32 @@ __device__ __forceinline__ int rank_of(const u64* __restrict__ bits, const int* 
     return wordoff[wi] + __popcll(m & ((1ull << b) - 1ull));
 }
 
-// kind 0: submanifold k x k (same level);  kind 1: inverse-conv gather (rows = fine sites, source = coarse level,
-// tap (ky,kx) valid iff (y+1-ky) even ...);  kind 2: strided gather (rows = coarse sites, source = fine level, i = 2o-1+k)
-__global__ __launch_bounds__(256) void table_kernel(const int* __restrict__ coords, int R, int ksize, int kind, const u64* __restrict__ sbits,
+// KIND 0: submanifold k x k (same level);  KIND 1: inverse-conv gather (rows = fine sites, source = coarse level,
+// tap (ky,kx) valid iff (y+1-ky) even ...);  KIND 2: strided gather (rows = coarse sites, source = fine level, i = 2o-1+k)
+template <int KIND>
+__global__ __launch_bounds__(256) void table_kernel(const int* __restrict__ coords, int R, int ksize, const u64* __restrict__ sbits,
                                                     const int* __restrict__ swordoff, int Hs, int Ws, int Wws, int* __restrict__ nbr) {
     const int taps = ksize * ksize;
-    long total = (long)R * taps;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        int r = (int)(i / taps), tap = (int)(i - (long)r * taps);
-        int ky = tap / ksize, kx = tap - ky * ksize;
-        int p = coords[(long)r * 3], y = coords[(long)r * 3 + 1], x = coords[(long)r * 3 + 2];
+    const int total = R * taps;
+    const int c = ksize / 2;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int r = i / taps, tap = i - r * taps;
+        const int ky = tap / ksize, kx = tap - ky * ksize;
+        const int p = coords[r * 3], y = coords[r * 3 + 1], x = coords[r * 3 + 2];
+        int sy, sx;
+        bool ok = true;
+        if (KIND == 0) { sy = y + ky - c; sx = x + kx - c; }
+        else if (KIND == 1) {
+            const int ty = y + 1 - ky, tx = x + 1 - kx;
+            ok = (ty >= 0) && (tx >= 0) && ((ty & 1) == 0) && ((tx & 1) == 0);
+            sy = ty >> 1; sx = tx >> 1;
+        } else { sy = 2 * y - 1 + ky; sx = 2 * x - 1 + kx; }
         int v = -1;
-        if (kind == 0) {
-            int c = ksize / 2;
-            v = rank_of(sbits, swordoff, p, y + ky - c, x + kx - c, Hs, Ws, Wws);
-        } else if (kind == 1) {
-            int ty = y + 1 - ky, tx = x + 1 - kx;
-            if (ty >= 0 && tx >= 0 && !(ty & 1) && !(tx & 1)) v = rank_of(sbits, swordoff, p, ty >> 1, tx >> 1, Hs, Ws, Wws);
-        } else {
-            v = rank_of(sbits, swordoff, p, 2 * y - 1 + ky, 2 * x - 1 + kx, Hs, Ws, Wws);
+        if (ok && sy >= 0 && sy < Hs && sx >= 0 && sx < Ws) {
+            const int wi = (p * Hs + sy) * Wws + (sx >> 6);
+            const u64 m = sbits[wi];
+            const int b = sx & 63;
+            if ((m >> b) & 1ull) v = swordoff[wi] + __popcll(m & ((1ull << b) - 1ull));
         }
         nbr[i] = v;
     }
@@ -324,8 +331,13 @@ extern "C" int mg_gather_table(const int32_t* coords, int R, int ksize, int kind
     if (R <= 0) return 0;
     if (kind < 0 || kind > 2) return -2;
     long total = (long)R * ksize * ksize;
-    hipLaunchKernelGGL(table_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, coords, R, ksize, kind,
-                       (const u64*)src_bits, src_wordoff, Hs, Ws, (Ws + 63) / 64, nbr);
+    if (total >= (1l << 31)) return -7;
+    dim3 g(grid_for(total, 256)), b(256);
+    hipStream_t st = (hipStream_t)stream;
+    const int Wws = (Ws + 63) / 64;
+    if (kind == 0) hipLaunchKernelGGL(table_kernel<0>, g, b, 0, st, coords, R, ksize, (const u64*)src_bits, src_wordoff, Hs, Ws, Wws, nbr);
+    else if (kind == 1) hipLaunchKernelGGL(table_kernel<1>, g, b, 0, st, coords, R, ksize, (const u64*)src_bits, src_wordoff, Hs, Ws, Wws, nbr);
+    else hipLaunchKernelGGL(table_kernel<2>, g, b, 0, st, coords, R, ksize, (const u64*)src_bits, src_wordoff, Hs, Ws, Wws, nbr);
     MG_CHECK_LAUNCH();
     return 0;
 }

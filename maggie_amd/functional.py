@@ -1,0 +1,435 @@
+"""Autograd-visible operators of the MaGGIe hot path, built on the HIP kernels (maggie_amd.kernels -> C ABI).
+
+Dense activations are NHWC tensors (N, H, W, C) in the compute dtype (bf16 under torch.autocast, else fp32) with C
+padded to a multiple of 8; sparse features are (R, C) row matrices over the sorted active sites. Every forward
+AND backward below launches hand-written HIP kernels; PyTorch only provides the autograd graph, memory and streams.
+"""
+import torch
+import torch.distributed as dist
+
+from . import kernels as K
+from .kernels import MODE_CONV, MODE_TCONV, MODE_GATHER, ACT_NONE, ACT_RELU, ACT_LRELU  # noqa: F401
+
+LRELU_SLOPE = 0.2
+
+
+def compute_dtype():
+    """bf16 inside torch.autocast(device_type='cuda') (the reference's --precision 16 path uses fp16 autocast,
+    engine/train.py:208,227-229; bf16 is this build's choice), fp32 otherwise."""
+    if torch.is_autocast_enabled():
+        return torch.bfloat16
+    return torch.float32
+
+
+def pad8(c):
+    return (c + 7) // 8 * 8
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# weight layout plumbing (tiny tensors; plain torch so gradients flow back to the OIHW / KRSC parameters)
+# ----------------------------------------------------------------------------------------------------------------------
+
+def weight_oihw_to_krsc(w, dtype, cin_pad=None, cout_pad=None):
+    """(Cout, Cin, R, S) -> (Cout_pad, R*S, Cin_pad) in `dtype`."""
+    co, ci, r, s = w.shape
+    w = w.permute(0, 2, 3, 1).reshape(co, r * s, ci)
+    return _pad_krsc(w, dtype, cin_pad, cout_pad)
+
+
+def weight_iohw_to_krsc(w, dtype, cin_pad=None, cout_pad=None):
+    """ConvTranspose2d weight (Cin, Cout, R, S) -> (Cout_pad, R*S, Cin_pad)."""
+    ci, co, r, s = w.shape
+    w = w.permute(1, 2, 3, 0).reshape(co, r * s, ci)
+    return _pad_krsc(w, dtype, cin_pad, cout_pad)
+
+
+def weight_krsc_param(w, dtype, cin_pad=None, cout_pad=None):
+    """spconv-layout parameter (Cout, R, S, Cin) -> (Cout_pad, R*S, Cin_pad)."""
+    co, r, s, ci = w.shape
+    return _pad_krsc(w.reshape(co, r * s, ci), dtype, cin_pad, cout_pad)
+
+
+def _pad_krsc(w, dtype, cin_pad, cout_pad):
+    co, taps, ci = w.shape
+    cin_pad = pad8(ci) if cin_pad is None else cin_pad
+    cout_pad = co if cout_pad is None else cout_pad
+    if cin_pad != ci or cout_pad != co:
+        w = torch.nn.functional.pad(w, (0, cin_pad - ci, 0, 0, 0, cout_pad - co))
+    return w.to(dtype).contiguous()
+
+
+def pad_vec(v, n):
+    if v is None or v.numel() == n:
+        return v
+    return torch.nn.functional.pad(v, (0, n - v.numel()))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# dense convolution (implicit GEMM) with optional bias / ReLU-before-BN epilogue and fused BN statistics
+# ----------------------------------------------------------------------------------------------------------------------
+
+class ConvRaw(torch.autograd.Function):
+    """y = [relu]( conv(x, w) + bias ).  x: (N,H,W,Cin) NHWC; w: (Cout, R*S, Cin) KRSC; transposed=True is
+    ConvTranspose2d(k, stride, pad). `stats` (fp32 [2*Cout(+1)], zeroed) receives the BN batch statistics of y."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, R, S, stride, pad, dil, transposed, pre_relu, stats):
+        N, H, W_, Cin = x.shape
+        Cout = w.shape[0]
+        x = x.contiguous()
+        mode = MODE_TCONV if transposed else MODE_CONV
+        Ho = K.conv_out_size(mode, H, R, stride, pad, dil)
+        Wo = K.conv_out_size(mode, W_, S, stride, pad, dil)
+        y = K.conv_fprop(x.view(-1, Cin), w, mode=mode, N=N, Hin=H, Win=W_, Hout=Ho, Wout=Wo, R=R, S=S, stride=stride,
+                         pad=pad, dil=dil, shift=bias, act=ACT_RELU if pre_relu else ACT_NONE, pre_act=False,
+                         stats=stats)
+        y = y.view(N, Ho, Wo, Cout)
+        ctx.save_for_backward(x, w, y if pre_relu else None)
+        ctx.geom = (N, H, W_, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, transposed, pre_relu, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        N, H, W_, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, transposed, pre_relu, has_bias = ctx.geom
+        dy = dy.contiguous()
+        if pre_relu:
+            dy = dy * (y > 0).to(dy.dtype)
+        dy2 = dy.view(-1, Cout)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = w.permute(2, 1, 0).contiguous()                      # (Cin, taps, Cout)
+            dmode = MODE_CONV if transposed else MODE_TCONV
+            dx = K.conv_fprop(dy2, wt, mode=dmode, N=N, Hin=Ho, Win=Wo, Hout=H, Wout=W_, R=R, S=S, stride=stride, pad=pad,
+                              dil=dil).view(N, H, W_, Cin)
+        if ctx.needs_input_grad[1]:
+            if not transposed:
+                dw = K.conv_wgrad(x.view(-1, Cin), dy2, cout=Cout, mode=MODE_CONV, N=N, Hin=H, Win=W_, Hout=Ho, Wout=Wo,
+                                  R=R, S=S, stride=stride, pad=pad, dil=dil)
+            else:
+                # dW[ci, tap, co] = sum_o x[o, ci] * dy[2o - pad + k, co]  (roles of x and dy swapped)
+                dwt = K.conv_wgrad(dy2, x.view(-1, Cin), cout=Cin, mode=MODE_CONV, N=N, Hin=Ho, Win=Wo, Hout=H, Wout=W_,
+                                   R=R, S=S, stride=stride, pad=pad, dil=dil)
+                dw = dwt.permute(2, 1, 0).contiguous()
+            dw = dw.to(w.dtype)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dy2.float().sum(0)
+        return dx, dw, db, None, None, None, None, None, None, None, None
+
+
+def conv2d(x, w, bias=None, R=3, S=3, stride=1, pad=1, dil=1, transposed=False, pre_relu=False, stats=None):
+    return ConvRaw.apply(x, w, bias, R, S, stride, pad, dil, transposed, pre_relu, stats)
+
+
+def linear_rows(x2d, w, bias=None, pre_relu=False, stats=None):
+    """Per-row linear map (1x1 conv over a rows x channels matrix). w: (Cout, 1, Cin)."""
+    R_, C = x2d.shape
+    return conv2d(x2d.view(1, 1, R_, C), w, bias, 1, 1, 1, 0, 1, False, pre_relu, stats).view(R_, -1)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# BatchNorm (+ residual + activation), training (batch statistics, running-stat update, SyncBN) and eval
+# ----------------------------------------------------------------------------------------------------------------------
+
+def _sync_group(bn):
+    if isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return bn.process_group if bn.process_group is not None else dist.group.WORLD
+    return None
+
+
+class BNAct(torch.autograd.Function):
+    """y = act( BN(x) + res ).  x, y: (..., C) rows x channels. Training uses batch statistics (optionally
+    pre-accumulated by the producing conv's epilogue) and updates running stats in place."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, res, running_mean, running_var, training, momentum, eps, act, stats, res_mode, group,
+                mask_x_pos):
+        shape = x.shape
+        C = shape[-1]
+        x2 = x.contiguous().view(-1, C)
+        M = x2.shape[0]
+        H, W_ = (shape[1], shape[2]) if x.dim() == 4 else (1, 1)
+        g32 = pad_vec(gamma.float(), C)
+        b32 = pad_vec(beta.float(), C)
+        count = float(M)
+        cnt_t = None
+        if training:
+            if stats is None:
+                stats = K.colstats(x2)
+            if group is not None:
+                pack = torch.cat([stats[:2 * C], torch.full((1,), float(M), device=x.device)])
+                dist.all_reduce(pack, group=group)
+                stats, cnt_t = pack[:2 * C], pack[2 * C:]
+            rm = running_mean if running_mean.numel() == C else None
+            rv = running_var if running_var.numel() == C else None
+            rm_p, rv_p = rm, rv
+            if rm is None and running_mean is not None:       # padded channel count: update through a temp
+                rm_p, rv_p = pad_vec(running_mean, C).clone(), pad_vec(running_var, C).clone()
+            scale, shift, mean, invstd = K.bn_finalize(stats, count, g32, b32, rm_p, rv_p, momentum, eps, count_ptr=cnt_t)
+            if rm is None and running_mean is not None:
+                running_mean.copy_(rm_p[:running_mean.numel()])
+                running_var.copy_(rv_p[:running_var.numel()])
+        else:
+            scale, shift = K.bn_fold(g32, b32, pad_vec(running_mean, C), pad_vec(running_var, C), eps)
+            mean = pad_vec(running_mean, C)
+            invstd = torch.rsqrt(pad_vec(running_var, C) + eps)
+        r2 = None if res is None else res.contiguous().view(-1, C)
+        y = K.affine_act(x2, scale, shift, res=r2, res_mode=res_mode, act=act, slope=LRELU_SLOPE, H=H, W=W_)
+        ctx.save_for_backward(x2, y, scale, mean, invstd, cnt_t)
+        ctx.meta = (shape, M, C, act, res is not None, res_mode, training, group, mask_x_pos, gamma.numel(), res.shape if res is not None else None)
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, y, scale, mean, invstd, cnt_t = ctx.saved_tensors
+        shape, M, C, act, has_res, res_mode, training, group, mask_x_pos, nch, res_shape = ctx.meta
+        dy2 = dy.contiguous().view(-1, C)
+        if training:
+            _, _, sums = K.bn_backward(dy2, y, x2, scale, mean, invstd, M, act=act, slope=LRELU_SLOPE, reduce_only=True)
+            if group is not None:
+                dist.all_reduce(sums, group=group)
+            dx, dres, sums = K.bn_backward(dy2, y, x2, scale, mean, invstd, M, act=act, slope=LRELU_SLOPE, want_dres=has_res,
+                                           mask_x_pos=mask_x_pos, sums=sums, apply_only=True, count_ptr=cnt_t)
+            dgamma, dbeta = sums[C:2 * C][:nch].clone(), sums[:C][:nch].clone()
+        else:
+            # eval statistics are constants: dx = g * scale
+            zeros = torch.zeros(2 * C, dtype=torch.float32, device=dy.device)
+            dx, dres, _ = K.bn_backward(dy2, y, x2, scale, mean, invstd, M, act=act, slope=LRELU_SLOPE, want_dres=has_res,
+                                        mask_x_pos=mask_x_pos, sums=zeros, apply_only=True)
+            _, _, sums = K.bn_backward(dy2, y, x2, scale, mean, invstd, M, act=act, slope=LRELU_SLOPE, reduce_only=True)
+            dgamma, dbeta = sums[C:2 * C][:nch].clone(), sums[:C][:nch].clone()
+        dx = dx.view(shape)
+        if has_res:
+            if res_mode == 2:
+                N, H, W_ = shape[0], shape[1], shape[2]
+                dres = K.pool2x2(dres, 1, N, H // 2, W_ // 2).view(res_shape)
+            else:
+                dres = dres.view(res_shape)
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None
+
+
+def batch_norm_act(x, bn, act=ACT_NONE, res=None, stats=None, res_mode=1, mask_x_pos=False):
+    """`bn` is an nn.BatchNorm{1,2}d / nn.SyncBatchNorm used as the parameter + running-stat holder."""
+    training = bn.training or (bn.running_mean is None)
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    mom = 0.1 if bn.momentum is None else bn.momentum
+    return BNAct.apply(x, bn.weight, bn.bias, res, bn.running_mean, bn.running_var, training, mom, bn.eps, act, stats, res_mode,
+                       _sync_group(bn) if training else None, mask_x_pos)
+
+
+def new_stats(channels, device):
+    return torch.zeros(2 * channels, dtype=torch.float32, device=device)
+
+
+def conv_bn_act(x, w, bn, act=ACT_NONE, R=3, S=3, stride=1, pad=1, dil=1, transposed=False, res=None, res_mode=1, res2=None,
+                relu_before_bn=False, bias=None):
+    """conv -> BN -> (+res) -> act (-> +res2).  In inference (no grad, eval BN) this is ONE fused kernel; in training the
+    conv epilogue accumulates the batch statistics and a second HBM pass applies them."""
+    Cout = w.shape[0]
+    fused = (not bn.training) and (not torch.is_grad_enabled())
+    if fused:
+        N, H, W_, Cin = x.shape
+        mode = MODE_TCONV if transposed else MODE_CONV
+        Ho = K.conv_out_size(mode, H, R, stride, pad, dil)
+        Wo = K.conv_out_size(mode, W_, S, stride, pad, dil)
+        scale, shift = K.bn_fold(pad_vec(bn.weight.float(), Cout), pad_vec(bn.bias.float(), Cout), pad_vec(bn.running_mean, Cout),
+                                 pad_vec(bn.running_var, Cout), bn.eps)
+        if bias is not None:
+            shift = shift + scale * bias if not relu_before_bn else shift
+        y = K.conv_fprop(x.contiguous().view(-1, Cin), w, mode=mode, N=N, Hin=H, Win=W_, Hout=Ho, Wout=Wo, R=R, S=S, stride=stride,
+                         pad=pad, dil=dil, scale=scale, shift=shift,
+                         res=None if res is None else res.contiguous().view(-1, Cout), res_mode=res_mode,
+                         res2=None if res2 is None else res2.contiguous().view(-1, Cout),
+                         act=ACT_RELU if relu_before_bn else act, pre_act=relu_before_bn, slope=LRELU_SLOPE)
+        return y.view(N, Ho, Wo, Cout)
+    stats = new_stats(Cout, x.device) if bn.training else None
+    y = conv2d(x, w, bias, R, S, stride, pad, dil, transposed, relu_before_bn, stats)
+    y = batch_norm_act(y, bn, ACT_NONE if relu_before_bn else act, res=res, stats=stats, res_mode=res_mode)
+    if res2 is not None:
+        y = y + res2
+    return y
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# sparse (gather) convolution over active sites
+# ----------------------------------------------------------------------------------------------------------------------
+
+class GatherConv(torch.autograd.Function):
+    """y[r] = act( sum_k W[:, k, :] x[nbr[r, k]] + bias ).  `nbr_t`: table for the input-gradient gather
+    (same table with reversed taps for submanifold convs, the strided table for inverse convs)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, nbr, nbr_t, reverse_taps, ksize, stats, act):
+        Cout = w.shape[0]
+        x = x.contiguous()
+        y = K.conv_fprop(x, w, mode=MODE_GATHER, nbr=nbr, R=ksize, S=ksize, shift=bias, stats=stats, act=act, pre_act=False)
+        ctx.save_for_backward(x, w, nbr, nbr_t, y if act != ACT_NONE else None)
+        ctx.meta = (reverse_taps, ksize, Cout, bias is not None, act)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, nbr, nbr_t, y = ctx.saved_tensors
+        reverse_taps, ksize, Cout, has_bias, act = ctx.meta
+        dy = dy.contiguous()
+        if act == ACT_RELU:
+            dy = dy * (y > 0).to(dy.dtype)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = w.permute(2, 1, 0)
+            if reverse_taps:
+                wt = wt.flip(1)
+            wt = wt.contiguous()
+            dx = K.conv_fprop(dy, wt, mode=MODE_GATHER, nbr=nbr_t, R=ksize, S=ksize)
+        if ctx.needs_input_grad[1]:
+            dw = K.conv_wgrad(x, dy, cout=Cout, mode=MODE_GATHER, nbr=nbr, R=ksize, S=ksize).to(w.dtype)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dy.float().sum(0)
+        return dx, dw, db, None, None, None, None, None, None
+
+
+def gather_conv(x, w, nbr, nbr_t, reverse_taps, ksize=3, bias=None, stats=None, act=ACT_NONE):
+    return GatherConv.apply(x, w, bias, nbr, nbr_t, reverse_taps, ksize, stats, act)
+
+
+class GatherRows(torch.autograd.Function):
+    """rows[r] = dense[frame(r), y, x] (* tokens[frame, inst])."""
+
+    @staticmethod
+    def forward(ctx, dense, coords, n_i, mul):
+        dense = dense.contiguous()
+        mul32 = None if mul is None else mul.float().contiguous()
+        y = K.gather_rows(dense, coords, n_i, mul=mul32)
+        ctx.save_for_backward(dense, coords, mul32)
+        ctx.meta = (n_i, dense.shape, mul is not None, None if mul is None else mul.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dense, coords, mul32 = ctx.saved_tensors
+        n_i, dshape, has_mul, mul_dtype = ctx.meta
+        dy = dy.contiguous()
+        ddense, dmul = K.gather_rows_bwd(dy, coords, n_i, dshape, mul=mul32, dense=dense,
+                                         want_ddense=ctx.needs_input_grad[0], want_dmul=has_mul and ctx.needs_input_grad[3])
+        if ddense is not None:
+            ddense = ddense.to(dense.dtype)
+        if dmul is not None:
+            dmul = dmul.to(mul_dtype)
+        return ddense, None, None, dmul
+
+
+def gather_rows(dense, coords, n_i, mul=None):
+    return GatherRows.apply(dense, coords, n_i, mul)
+
+
+class ScatterPlane(torch.autograd.Function):
+    """SparseConvTensor.dense() with the reference's -99 background (resnet_inst_matt_spconv.py:247-251,264-268)."""
+
+    @staticmethod
+    def forward(ctx, vals, coords, P, H, W, fill):
+        plane = K.scatter_plane(vals, 0, coords, P, H, W, fill)
+        ctx.save_for_backward(coords)
+        ctx.meta = (vals.shape, vals.dtype)
+        return plane
+
+    @staticmethod
+    def backward(ctx, dplane):
+        (coords,) = ctx.saved_tensors
+        vshape, vdtype = ctx.meta
+        g = K.gather_plane(dplane.contiguous(), coords, vdtype)
+        if vshape[1] != 1:
+            g = torch.nn.functional.pad(g, (0, vshape[1] - 1))
+        return g, None, None, None, None, None
+
+
+def scatter_plane(vals, coords, P, H, W, fill=-99.0):
+    return ScatterPlane.apply(vals, coords, P, H, W, fill)
+
+
+class UpsampleTanh(torch.autograd.Function):
+    """(tanh(bilinear_up(x, scale)) + 1) / 2 -> fp32 planes (N, C, h*scale, w*scale). x: NHWC rows (N,h,w,Cpad) when
+    `nhwc`, else fp32 planes (N, C, h, w)."""
+
+    @staticmethod
+    def forward(ctx, x, C, scale, nhwc, apply_tanh):
+        x = x.contiguous()
+        if nhwc:
+            N, h, w, Cp = x.shape
+            strides = (h * w * Cp, 1, w * Cp, Cp)
+        else:
+            N, _, h, w = x.shape
+            strides = (C * h * w, h * w, w, 1)
+        out = K.upsample_tanh(x, strides, N, C, h, w, scale, apply_tanh)
+        ctx.save_for_backward(out)
+        ctx.meta = (x.shape, x.dtype, strides, N, C, h, w, scale, apply_tanh)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        xshape, xdtype, strides, N, C, h, w, scale, apply_tanh = ctx.meta
+        din = torch.zeros(xshape, dtype=torch.float32, device=dout.device)
+        K.upsample_tanh_bwd(dout.contiguous(), out, strides, N, C, h, w, scale, din, apply_tanh)
+        return din.to(xdtype), None, None, None, None
+
+
+def upsample_tanh(x, C, scale, nhwc, apply_tanh=True):
+    return UpsampleTanh.apply(x, C, scale, nhwc, apply_tanh)
+
+
+class MaskEmbed(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, masks, table, dtype):
+        out = K.mask_embed(image.contiguous(), masks.contiguous(), table.float().contiguous(), dtype)
+        ctx.save_for_backward(masks)
+        ctx.tshape = tuple(table.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dx):
+        (masks,) = ctx.saved_tensors
+        return None, None, K.mask_embed_bwd(dx.contiguous(), masks.contiguous(), ctx.tshape), None
+
+
+def mask_embed(image, masks, table, dtype):
+    return MaskEmbed.apply(image, masks, table, dtype)
+
+
+class AvgPool2x2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        N, H, W_, C = x.shape
+        ctx.shape = x.shape
+        return K.pool2x2(x.contiguous().view(-1, C), 0, N, H // 2, W_ // 2).view(N, H // 2, W_ // 2, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W_, C = ctx.shape
+        return K.pool2x2(dy.contiguous().view(-1, C), 2, N, H, W_).view(N, H, W_, C)
+
+
+def avg_pool2x2(x):
+    return AvgPool2x2.apply(x)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# region ops (no gradients: integer / boolean work on bit planes)
+# ----------------------------------------------------------------------------------------------------------------------
+
+def unknown_bits(alpha, k_size=30, is_train=False, andmask=None):
+    """compute_unknown (maggie/utils/utils.py:28-55) on fp32 planes (..., H, W) -> bit planes (P, H, Ww).
+    Train mode draws one np.random.randint(1, k_size) per slice from the GLOBAL numpy RNG (reference order)."""
+    import numpy as np
+    a = alpha.detach()
+    if a.dtype != torch.float32:
+        a = a.float()
+    a = a.contiguous()
+    H, W_ = a.shape[-2:]
+    P = a.numel() // (H * W_)
+    bits = K.bits_pack(a, mode=0)
+    if is_train:
+        widths = np.array([np.random.randint(1, k_size) for _ in range(P)], np.int32)
+        wd = torch.from_numpy(widths).to(a.device, non_blocking=True)
+        return K.bits_dilate(bits, W_, widths=wd, andmask=andmask)
+    return K.bits_dilate(bits, W_, width=k_size // 2, andmask=andmask)

@@ -1,0 +1,235 @@
+"""MaGGIe -- mirrors maggie/network/arch/maggie.py:18-368: same constructor (`CfgNode | dict`), same
+`forward(batch, **kwargs)` contract (eval -> dict of (b, n_f, n_i, h, w) tensors; train -> (dict, loss_dict)),
+same loss names, same host-RNG consumption order (np.random / random), same state_dict keys."""
+import logging
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn import functional as F
+
+try:                                                     # optional: the reference mixes this in for from_pretrained()
+    from huggingface_hub import PyTorchModelHubMixin
+except Exception:                                        # pragma: no cover
+    class PyTorchModelHubMixin:                          # type: ignore
+        pass
+
+from ...utils.config import CfgNode
+from ... import functional as MF
+from ... import kernels as K
+from ..module import ASPP
+from ..encoder import *      # noqa: F401,F403  (factory names are resolved by eval(), like the reference)
+from ..decoder import *      # noqa: F401,F403
+from ..loss import LapLoss, loss_dtSSD, GradientLoss
+
+
+class MaGGIe(nn.Module, PyTorchModelHubMixin):
+    def __init__(self, cfg):
+        super().__init__()
+        if isinstance(cfg, dict) and not hasattr(cfg, 'encoder_args'):
+            cfg = CfgNode(cfg)
+        self.cfg = cfg
+        self.num_masks = cfg.encoder_args.num_mask
+        self.encoder = eval(cfg.encoder)(**cfg.encoder_args)
+        self.aspp = ASPP(in_channel=cfg.aspp.in_channels, out_channel=cfg.aspp.out_channels)
+        self.decoder = eval(cfg.decoder)(**cfg.decoder_args)
+        self.loss_alpha_w = cfg.loss_alpha_w
+        self.loss_alpha_lap_w = cfg.loss_alpha_lap_w
+        self.loss_alpha_grad_w = cfg.loss_alpha_grad_w
+        self.loss_atten_w = cfg.loss_atten_w
+        self.reweight_os8 = cfg.loss_reweight_os8
+        self.loss_dtSSD_w = cfg.loss_dtSSD_w
+        self.lap_loss = LapLoss()
+        self.grad_loss = GradientLoss()
+        for module in [self.aspp, self.decoder]:
+            for name, p in module.named_parameters():
+                if "context_token" in name:
+                    continue
+                if p.dim() > 1:
+                    nn.init.xavier_uniform_(p)
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def forward(self, batch, **kwargs):
+        masks, alphas, trans_gt, b, n_f, h, w, n_i, chosen_ids, embedding, mid_fea = self.forward_encoder(batch)
+        pred = self.decoder(embedding, mid_fea, b=b, n_f=n_f, n_i=n_i, masks=masks, iter=batch.get('iter', 0), gt_alphas=alphas,
+                            spar_gt=trans_gt, **kwargs)
+        if isinstance(pred, tuple):
+            pred = pred[0]
+        alpha_pred = pred.pop("refined_masks")
+        weight_os4 = pred["detail_mask"].type(alpha_pred.dtype)
+        weight_os1 = weight_os4
+        if self.training and 'weight_os4' in pred and np.random.rand() < 0.75:
+            weight_os4 = pred.pop("weight_os4")
+            weight_os1 = pred.pop("weight_os1")
+        output = self.transform_output(b, n_f, h, w, n_i, pred, alpha_pred)
+        if self.training:
+            alphas = alphas.view(-1, n_i, h, w)
+            trans_gt = trans_gt.view(-1, n_i, h, w)
+            valid_masks = (trans_gt.sum((2, 3), keepdim=True) > 0).float()
+            for k, v in list(pred.items()):
+                if 'loss' in k or 'mem_' in k:
+                    continue
+                pred[k] = v * valid_masks
+            loss_dict = self.compute_loss(pred, weight_os4, weight_os1, alphas, trans_gt, (b, n_f, self.num_masks, h, w),
+                                          reweight_os8=self.reweight_os8)
+            self.update_additional_decoder_loss(pred, loss_dict)
+            if chosen_ids is not None:
+                for k, v in output.items():
+                    output[k] = v[:, :, chosen_ids, :, :]
+            return output, loss_dict
+        for k, v in output.items():
+            output[k] = v[:, :, :n_i]
+        for k in pred:
+            if k.startswith("mem_"):
+                output[k] = pred[k]
+        return output
+
+    def update_additional_decoder_loss(self, pred, loss_dict):
+        if 'loss_max_atten' in pred and self.loss_atten_w > 0:
+            loss_dict['loss_max_atten'] = pred['loss_max_atten']
+            loss_dict['total'] += loss_dict['loss_max_atten'] * self.loss_atten_w
+
+    def transform_output(self, b, n_f, h, w, n_i, pred, alpha_pred):
+        output = {}
+        n_out = self.num_masks if (self.training and self.num_masks > 0) else n_i
+        if 'alpha_os1' in pred:
+            output['alpha_os1'] = pred['alpha_os1'][:, :n_out].reshape(b, n_f, n_out, h, w)
+            output['alpha_os4'] = pred['alpha_os4'][:, :n_out].reshape(b, n_f, n_out, h, w)
+        output['alpha_os8'] = pred['alpha_os8'][:, :n_out].reshape(b, n_f, n_out, h, w)
+        output['refined_masks'] = alpha_pred[:, :n_out].reshape(b, n_f, n_out, h, w)
+        if 'detail_mask' in pred:
+            output['detail_mask'] = pred['detail_mask'][:, :n_out].reshape(b, n_f, n_out, h, w)
+        return output
+
+    def forward_encoder(self, batch):
+        x = batch['image']
+        masks = batch['mask']
+        alphas = batch.get('alpha', None)
+        trans_gt = batch.get('transition', None)
+        b, n_f, _, h, w = x.shape
+        n_i = masks.shape[2]
+        if not x.is_cuda:
+            raise K.hip.MaggieHipError('MaGGIe (MI355X build) runs on the GPU only: move the batch to cuda (no CPU fallback)')
+        x = x.reshape(-1, 3, h, w).float()
+        masks_lr = masks.flatten(0, 1).float()                      # kept at its own resolution for the packing kernel
+        if masks.shape[-1] != w:
+            masks = F.interpolate(masks_lr, size=(h, w), mode="nearest")
+        else:
+            masks = masks_lr
+        masks, alphas, trans_gt, n_i, chosen_ids, enc_masks = self.prepare_input(x, masks, masks_lr, alphas, trans_gt, b, n_f, h, w, n_i)
+        if alphas is not None:
+            alphas = alphas.reshape(-1, n_i, h, w)
+        if trans_gt is not None:
+            trans_gt = trans_gt.reshape(-1, n_i, h, w)
+        embedding, mid_fea = self.encoder(x.contiguous(), enc_masks.contiguous())
+        embedding = self.aspp(embedding)
+        return masks, alphas, trans_gt, b, n_f, h, w, n_i, chosen_ids, embedding, mid_fea
+
+    def prepare_input(self, x, masks, masks_lr, alphas, trans_gt, b, n_f, h, w, n_i):
+        """arch/maggie.py:200-235: pad the guidance masks to `num_mask` channels (eval: zeros at the end; train: random
+        slots via np.random.choice). Returns the (possibly re-slotted) masks and the low-resolution masks for the encoder."""
+        chosen_ids = None
+        enc_masks = masks_lr
+        if self.num_masks - n_i > 0:
+            hm, wm = masks_lr.shape[-2:]
+            if not self.training:
+                enc_masks = torch.cat([masks_lr, masks_lr.new_zeros((b * n_f, self.num_masks - n_i, hm, wm))], dim=1)
+            else:
+                chosen_ids = np.random.choice(self.num_masks, n_i, replace=False)
+                enc_masks = masks_lr.new_zeros((b * n_f, self.num_masks, hm, wm))
+                enc_masks[:, chosen_ids] = masks_lr
+                new_masks = masks.new_zeros((b * n_f, self.num_masks, h, w))
+                new_masks[:, chosen_ids] = masks
+                masks = new_masks
+                if alphas is not None:
+                    na = alphas.new_zeros((b, n_f, self.num_masks, h, w))
+                    na[:, :, chosen_ids] = alphas
+                    alphas = na
+                if trans_gt is not None:
+                    nt = trans_gt.new_zeros((b, n_f, self.num_masks, h, w))
+                    nt[:, :, chosen_ids] = trans_gt
+                    trans_gt = nt
+                n_i = self.num_masks
+        return masks, alphas, trans_gt, n_i, chosen_ids, enc_masks
+
+    # ------------------------------------------------------------------------------------------------ losses
+    @staticmethod
+    def regression_loss(logit, target, loss_type='l1', weight=None, topk=-1):
+        if weight is None:
+            if loss_type == 'l1':
+                return F.l1_loss(logit, target)
+            elif loss_type == 'l2':
+                return F.mse_loss(logit, target)
+            raise NotImplementedError("NotImplemented loss type {}".format(loss_type))
+        if loss_type == 'l1':
+            loss = F.l1_loss(logit * weight, target * weight, reduction='none')
+            if topk > 0:
+                topk = int(weight.sum() * 0.5)
+                loss, _ = torch.topk(loss.view(-1), topk)
+                return loss.sum() / (topk + 1e-8)
+            return loss.sum() / (torch.sum(weight) + 1e-8)
+        elif loss_type == 'l2':
+            return F.mse_loss(logit * weight, target * weight, reduction='sum') / (torch.sum(weight) + 1e-8)
+        raise NotImplementedError("NotImplemented loss type {}".format(loss_type))
+
+    def compute_loss(self, pred, weight_os4, weight_os1, alphas, trans_gt, alpha_shape, reweight_os8=True):
+        a1, a4, a8 = pred.get('alpha_os1', None), pred.get('alpha_os4', None), pred['alpha_os8']
+        loss_dict = {}
+        weight_os8 = torch.ones_like(a8)
+        valid_mask = alphas.sum((2, 3), keepdim=True) > 0
+        weight_os8 = weight_os8 * valid_mask
+        if reweight_os8:
+            unknown_gt = (alphas <= 254.0 / 255.0) & (alphas >= 1.0 / 255.0)
+            unknown_pred_os8 = (a8 <= 254.0 / 255.0) & (a8 >= 1.0 / 255.0)
+            weight_os8 = (unknown_gt | unknown_pred_os8).type(weight_os8.dtype) + weight_os8
+        n_i = alphas.shape[1]
+        if self.num_masks - n_i > 0:
+            padding = torch.zeros((alphas.shape[0], self.num_masks - n_i, *alphas.shape[-2:]), device=alphas.device)
+            alphas = torch.cat([alphas, padding], dim=1)
+            trans_gt = torch.cat([trans_gt, padding], dim=1)
+        total_loss = 0
+        lt = self.cfg.loss_alpha_type
+        if self.loss_alpha_w > 0:
+            ref_alpha_loss = 0
+            if a1 is not None:
+                r1 = self.regression_loss(a1, alphas, loss_type=lt, weight=weight_os1)
+                r4 = self.regression_loss(a4, alphas, loss_type=lt, weight=weight_os4)
+                r8 = self.regression_loss(a8, alphas, loss_type=lt, weight=weight_os8)
+                ref_alpha_loss = ref_alpha_loss + r1 * 2 + r4 + r8
+                loss_dict['loss_rec_os1'], loss_dict['loss_rec_os4'], loss_dict['loss_rec_os8'] = r1, r4, r8
+            loss_dict['loss_rec'] = ref_alpha_loss
+            total_loss = total_loss + ref_alpha_loss * self.loss_alpha_w
+        if self.loss_alpha_lap_w > 0:
+            logging.debug("Computing lap loss")
+            h, w = a8.shape[-2:]
+            lap_loss = 0
+            if a1 is not None:
+                v = lambda t: t.reshape(-1, 1, h, w)
+                l1_ = self.lap_loss(v(a1), v(alphas), v(weight_os1))
+                l4_ = self.lap_loss(v(a4), v(alphas), v(weight_os4))
+                l8_ = self.lap_loss(v(a8), v(alphas), v(weight_os8))
+                loss_dict['loss_lap_os1'], loss_dict['loss_lap_os4'], loss_dict['loss_lap_os8'] = l1_, l4_, l8_
+                lap_loss = lap_loss + l1_ * 2 + l4_ + l8_
+            loss_dict['loss_lap'] = lap_loss
+            total_loss = total_loss + lap_loss * self.loss_alpha_lap_w
+        if self.loss_alpha_grad_w > 0:
+            grad_loss = 0
+            if a1 is not None:
+                g1 = self.grad_loss(a1, alphas, weight_os1)
+                g4 = self.grad_loss(a4, alphas, weight_os4)
+                g8 = self.grad_loss(a8, alphas, weight_os8)
+                grad_loss = grad_loss + g1 * 2 + g4 + g8
+                loss_dict['loss_grad_os1'], loss_dict['loss_grad_os4'], loss_dict['loss_grad_os8'] = g1, g4, g8
+            loss_dict['loss_grad'] = grad_loss
+            total_loss = total_loss + grad_loss * self.loss_alpha_grad_w
+        if self.loss_dtSSD_w > 0:
+            rs = lambda t: t.reshape(*alpha_shape)
+            d1 = loss_dtSSD(rs(a1), rs(alphas), rs(weight_os1))
+            d4 = loss_dtSSD(rs(a4), rs(alphas), rs(weight_os4))
+            d8 = loss_dtSSD(rs(a8), rs(alphas), rs(weight_os8))
+            dt = d1 * 2 + d4 + d8
+            loss_dict['loss_dtSSD_os1'], loss_dict['loss_dtSSD_os4'], loss_dict['loss_dtSSD_os8'] = d1, d4, d8
+            loss_dict['loss_dtSSD'] = dt
+            total_loss = total_loss + dt * self.loss_dtSSD_w
+        loss_dict['total'] = total_loss
+        return loss_dict

@@ -1,0 +1,311 @@
+"""MaGGIe image decoder: dense OS32->OS8, instance matte decoder, sparse progressive refinement OS8->OS4->OS2->OS1 --
+mirrors maggie/network/decoder/resnet_inst_matt_spconv.py:14-391 (same module tree / state_dict keys).
+
+The spconv calls of the reference are replaced by: bit-plane region kernels (active-site pyramid, gather tables) and the
+MG_MODE_GATHER implicit-GEMM kernel. `dummy_downscale` (reference :61-66) existed only to make spconv build rule books;
+its parameters are kept (frozen) for checkpoint compatibility and never executed."""
+import random
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from ... import functional as MF
+from ... import kernels as K
+from .resnet import BasicBlock
+from ..module import SpectralNorm, conv1x1, InstanceMatteDecoder, Marker
+from ..module.mask_attention import FFNLayer
+
+
+class SparseConvWeight(nn.Module):
+    """Parameter holder with spconv's layout: weight (Cout, k, k, Cin) [+ bias]."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, bias=True, kind='subm', indice_key=None, **kw):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size, self.kind, self.indice_key = in_channels, out_channels, kernel_size, kind, indice_key
+        self.weight = nn.Parameter(torch.empty(out_channels, kernel_size, kernel_size, in_channels))
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(out_channels))
+        else:
+            self.register_parameter('bias', None)
+
+    def krsc(self, dtype):
+        return MF.weight_krsc_param(self.weight, dtype, None, MF.pad8(self.out_channels))
+
+    def bias32(self):
+        return None if self.bias is None else MF.pad_vec(self.bias.float(), MF.pad8(self.out_channels))
+
+
+def SubMConv2d(i, o, kernel_size, padding=0, bias=True, indice_key=None, stride=1):
+    return SparseConvWeight(i, o, kernel_size, bias, 'subm', indice_key)
+
+
+def SparseConv2d(i, o, kernel_size, stride=2, padding=1, bias=True, indice_key=None):
+    return SparseConvWeight(i, o, kernel_size, bias, 'down', indice_key)
+
+
+def SparseInverseConv2d(i, o, kernel_size, bias=True, indice_key=None):
+    return SparseConvWeight(i, o, kernel_size, bias, 'inverse', indice_key)
+
+
+class SiteLevel:
+    """Active sites of one resolution level: bit planes, ranks, sorted coords and the gather tables built on demand."""
+
+    def __init__(self, bits, H, W):
+        self.bits, self.H, self.W = bits, H, W
+        self.rowoff, self.wordoff = K.bits_rank(bits, W)
+        self.count = None
+        self.coords = None
+        self._subm = None
+
+    def finalize(self, count):
+        self.count = count
+        self.coords = K.bits_coords(self.bits, self.wordoff, self.W, count)
+
+    def subm_table(self):
+        if self._subm is None:
+            self._subm = K.gather_table(self.coords, 3, 0, self.bits, self.wordoff, self.H, self.W)
+        return self._subm
+
+
+class ActivePyramid:
+    """Index pyramid OS1 -> OS2 -> OS4 -> OS8 of the detail region (spconv SparseConv2d(k3,s2,p1) output rule). One host sync:
+    the four site counts needed to size the feature matrices."""
+
+    def __init__(self, roi_bits, H, W):
+        lv = [SiteLevel(roi_bits, H, W)]
+        for _ in range(3):
+            b, h, w = K.bits_downsample(lv[-1].bits, lv[-1].W)
+            lv.append(SiteLevel(b, h, w))
+        counts = torch.stack([l.rowoff[-1] for l in lv]).tolist()          # the single device->host read
+        for l, c in zip(lv, counts):
+            l.finalize(int(c))
+        self.levels = lv                                                   # [OS1, OS2, OS4, OS8]
+        self._inv, self._down = {}, {}
+
+    def inverse_tables(self, fine):
+        """(fine<-coarse gather table, coarse<-fine table for the input gradient) of SparseInverseConv2d at level `fine`."""
+        if fine not in self._inv:
+            f, c = self.levels[fine], self.levels[fine + 1]
+            self._inv[fine] = K.gather_table(f.coords, 3, 1, c.bits, c.wordoff, c.H, c.W)
+            self._down[fine] = K.gather_table(c.coords, 3, 2, f.bits, f.wordoff, f.H, f.W)
+        return self._inv[fine], self._down[fine]
+
+
+class ResShortCut_InstMattSpconv_Dec(nn.Module):
+    def __init__(self, block, layers, norm_layer=None, large_kernel=False, late_downsample=False, atten_stride=1, atten_dim=128,
+                 atten_block=2, atten_head=1, final_channel=32, max_inst=10, use_id_pe=True, warmup_mask_atten_iter=4000,
+                 warmup_detail_iter=3000, use_query_temp=False, use_detail_temp=False, detail_mask_dropout=0.2, **kwargs):
+        super().__init__()
+        norm_layer = norm_layer or nn.BatchNorm2d
+        self._norm_layer = norm_layer
+        assert not large_kernel
+        self.kernel_size = 3
+        self.max_inst = max_inst
+        self.inplanes = 512 if layers[0] > 0 else 256
+        self.midplanes = 64 if late_downsample else 32
+        self.warmup_mask_atten_iter = warmup_mask_atten_iter
+        self.warmup_detail_iter = warmup_detail_iter
+        self.leaky_relu = Marker('LeakyReLU(0.2)')
+        self.inst_spec_layer = FFNLayer(final_channel, final_channel, 0.1)
+        self.layer1 = self._make_layer(block, 256, layers[0], stride=2)
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.refine_OS8 = InstanceMatteDecoder(input_dim=128, atten_stride=atten_stride, attention_dim=atten_dim, n_block=atten_block,
+                                               n_head=atten_head, output_dim=final_channel, max_inst=max_inst, return_feat=True,
+                                               use_temp_pe=False, use_id_pe=use_id_pe)
+        self.dummy_downscale = nn.Sequential(
+            SubMConv2d(3, 32, 3, padding=1, bias=False, indice_key="subminp"),
+            SparseConv2d(32, 32, 3, stride=2, padding=1, bias=False, indice_key="subm1.2"),
+            SparseConv2d(32, 64, 3, stride=2, padding=1, bias=False, indice_key="subm2.4"),
+            SparseConv2d(64, 64, 3, stride=2, padding=1, bias=False, indice_key="subm4.8"))
+        for p in self.dummy_downscale.parameters():      # never receives a gradient in the reference either (no_grad, :217-218)
+            p.requires_grad_(False)
+        lr = self.leaky_relu
+        self.layer3 = nn.Sequential(SparseInverseConv2d(final_channel, 64, 3, bias=False, indice_key="subm4.8"), nn.BatchNorm1d(64), lr,
+                                    SubMConv2d(64, 64, 3, padding=1, bias=False, indice_key="subm4.4"))
+        self.guidance_layer = nn.Sequential(SubMConv2d(128, 64, 1, padding=0, bias=False, indice_key="subm_inst.0"), nn.BatchNorm1d(64), lr,
+                                            SubMConv2d(64, 64, 3, padding=1, bias=True, indice_key="subm_inst.1"), Marker('Sigmoid'))
+        self.layer3_smooth = nn.Sequential(SubMConv2d(64, 64, 1, padding=0, bias=True, indice_key="subm4.smooth"), Marker('ReLU'),
+                                           nn.BatchNorm1d(64))
+        self.layer4 = nn.Sequential(SparseInverseConv2d(64, 32, 3, bias=False, indice_key="subm2.4"), nn.BatchNorm1d(32), lr,
+                                    SubMConv2d(32, 32, 1, padding=1, bias=False, indice_key="subm2.2"))
+        self.layer4_smooth = nn.Sequential(SubMConv2d(64, 32, 1, padding=0, bias=True, indice_key="subm2.smooth"), Marker('ReLU'),
+                                           nn.BatchNorm1d(32))
+        self.layer5 = nn.Sequential(SparseInverseConv2d(32, 32, 3, bias=False, indice_key="subm1.2"), nn.BatchNorm1d(32), lr,
+                                    SubMConv2d(32, 32, 3, padding=1, bias=False, indice_key="subm1.1"))
+        self.layer5_smooth = nn.Sequential(SubMConv2d(64, 32, 1, padding=0, bias=True, indice_key="subm1.smooth"), Marker('ReLU'),
+                                           nn.BatchNorm1d(32))
+        self.refine_OS4 = nn.Sequential(SubMConv2d(64, 32, 3, stride=1, padding=1, bias=False), nn.BatchNorm1d(32), lr,
+                                        SubMConv2d(32, 1, 3, stride=1, padding=1))
+        self.refine_OS1 = nn.Sequential(SubMConv2d(32, 32, 3, stride=1, padding=1, bias=False), nn.BatchNorm1d(32), lr,
+                                        SubMConv2d(32, 1, 3, stride=1, padding=1))
+        self.fea_dropout = nn.Dropout2d(detail_mask_dropout)
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        if blocks == 0:
+            return nn.Sequential(nn.Identity())
+        norm_layer = self._norm_layer
+        upsample = None
+        if stride != 1:
+            upsample = nn.Sequential(Marker('UpsamplingNearest2d(2)'), SpectralNorm(conv1x1(self.inplanes, planes * block.expansion)),
+                                     norm_layer(planes * block.expansion))
+        elif self.inplanes != planes * block.expansion:
+            upsample = nn.Sequential(SpectralNorm(conv1x1(self.inplanes, planes * block.expansion)), norm_layer(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, upsample, norm_layer)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes, norm_layer=norm_layer))
+        return nn.Sequential(*layers)
+
+    # ------------------------------------------------------------------ sparse refinement head
+    @staticmethod
+    def _bn_rows(x, bn, act=MF.ACT_NONE, stats=None):
+        if x.shape[0] == 0:
+            return x
+        return MF.batch_norm_act(x, bn, act, stats=stats)
+
+    def _subm3(self, x, conv, lvl, stats=None, act=MF.ACT_NONE):
+        t = lvl.subm_table()
+        return MF.gather_conv(x, conv.krsc(x.dtype), t, t, True, 3, conv.bias32(), stats, act)
+
+    def _inverse(self, x, conv, pyr, fine, stats=None):
+        t, tt = pyr.inverse_tables(fine)
+        return MF.gather_conv(x, conv.krsc(x.dtype), t, tt, False, 3, conv.bias32(), stats)
+
+    @staticmethod
+    def _lin(x, conv, stats=None, pre_relu=False):
+        return MF.linear_rows(x, conv.krsc(x.dtype), conv.bias32(), pre_relu, stats)
+
+    def _stats(self, bn, x):
+        return MF.new_stats(x.shape[-1], x.device) if (bn.training and False) else None
+
+    def predict_details(self, os8_feat, roi_bits, n_i, inst_guidance_os8, dense_features, H, W):
+        """os8_feat (N,h8,w8,64) NHWC; roi_bits (N*n_i, H, Ww) bit planes; inst_guidance_os8 (N,10,64);
+        dense_features = fea1 (N,H,W,32), fea2 (N,H/2,W/2,32), fea3 (N,H/4,W/4,64).
+        Returns fp32 planes (N*n_i, H/4, W/4) and (N*n_i, H, W) with -99 outside the active sites, and the pyramid."""
+        fea1, fea2, fea3 = dense_features
+        P = roi_bits.shape[0]
+        pyr = ActivePyramid(roi_bits, H, W)
+        l1, l2, l4, l8 = pyr.levels
+        # OS8 gather * instance guidance -> FFN (inst_spec_layer)  (:221-232)
+        x = MF.gather_rows(os8_feat, l8.coords, n_i, mul=inst_guidance_os8)
+        x = self.inst_spec_layer(x.float()).to(os8_feat.dtype) if x.shape[0] > 0 else x
+        # layer3: inverse conv OS8->OS4, BN, LeakyReLU, SubM 3x3
+        x = self._inverse(x, self.layer3[0], pyr, 2)
+        x = self._bn_rows(x, self.layer3[1], MF.ACT_LRELU)
+        x = self._subm3(x, self.layer3[3], l4)
+        # instance_spec_guidance with fea3 (:172-194)
+        detail = MF.gather_rows(fea3, l4.coords, n_i)
+        g = self._lin(torch.cat([detail, x], 1), self.guidance_layer[0])
+        g = self._bn_rows(g, self.guidance_layer[1], MF.ACT_LRELU)
+        g = torch.sigmoid(self._subm3(g, self.guidance_layer[3], l4).float()).to(detail.dtype)
+        x = detail * g
+        # layer3_smooth, refine_OS4
+        x = self._lin(x, self.layer3_smooth[0], pre_relu=True)
+        x = self._bn_rows(x, self.layer3_smooth[2])
+        o4 = self._subm3(x, self.refine_OS4[0], l4)
+        o4 = self._bn_rows(o4, self.refine_OS4[1], MF.ACT_LRELU)
+        o4 = self._subm3(o4, self.refine_OS4[3], l4)
+        x_os4 = MF.scatter_plane(o4, l4.coords, P, l4.H, l4.W, -99.0)
+        # layer4 (OS4->OS2), fea2, layer4_smooth
+        x = self._inverse(x, self.layer4[0], pyr, 1)
+        x = self._bn_rows(x, self.layer4[1], MF.ACT_LRELU)
+        x = self._lin(x, self.layer4[3])
+        x = torch.cat([MF.gather_rows(fea2, l2.coords, n_i), x], 1)
+        x = self._lin(x, self.layer4_smooth[0], pre_relu=True)
+        x = self._bn_rows(x, self.layer4_smooth[2])
+        # layer5 (OS2->OS1), fea1, layer5_smooth, refine_OS1
+        x = self._inverse(x, self.layer5[0], pyr, 0)
+        x = self._bn_rows(x, self.layer5[1], MF.ACT_LRELU)
+        x = self._subm3(x, self.layer5[3], l1)
+        x = torch.cat([MF.gather_rows(fea1, l1.coords, n_i), x], 1)
+        x = self._lin(x, self.layer5_smooth[0], pre_relu=True)
+        x = self._bn_rows(x, self.layer5_smooth[2])
+        o1 = self._subm3(x, self.refine_OS1[0], l1)
+        o1 = self._bn_rows(o1, self.refine_OS1[1], MF.ACT_LRELU)
+        o1 = self._subm3(o1, self.refine_OS1[3], l1)
+        x_os1 = MF.scatter_plane(o1, l1.coords, P, H, W, -99.0)
+        return x_os4, x_os1, pyr
+
+    def fuse(self, pred, detail_bits):
+        """Progressive refinement (:272-290) with the two compute_unknown calls on device bit planes."""
+        a1, a4, a8 = pred['alpha_os1'], pred['alpha_os4'], pred['alpha_os8']
+        H, W = a8.shape[-2:]
+        alpha = a8
+        w4 = K.bits_unpack_u8(MF.unknown_bits(alpha, 27, self.training, andmask=detail_bits), W, a8.shape).to(alpha.dtype)
+        alpha = a4.type(alpha.dtype) * w4 + alpha * (1 - w4)
+        w1 = K.bits_unpack_u8(MF.unknown_bits(alpha, 15, self.training, andmask=detail_bits), W, a8.shape).to(alpha.dtype)
+        alpha = a1.type(alpha.dtype) * w1 + alpha * (1 - w1)
+        return alpha, w4, w1
+
+    def os32_to_os8(self, x, mid_fea, b, n_f, n_i, masks, gt_alphas):
+        masks = masks.reshape(b, n_f, n_i, masks.shape[2], masks.shape[3])
+        valid_masks = masks.flatten(0, 1).sum((2, 3), keepdim=True) > 0
+        gt_masks = None
+        if self.training:
+            gt_masks = (gt_alphas > 0).reshape(b, n_f, n_i, gt_alphas.shape[2], gt_alphas.shape[3])
+        fea1, fea2, fea3, fea4, fea5 = mid_fea['shortcut']
+        image = mid_fea['image']
+        x = self.layer1[0](x)
+        x = self.layer1[1](x, post_add=fea5)
+        x = self.layer2[0](x)
+        x = self.layer2[1](x)
+        x = self.layer2[2](x, post_add=fea4)
+        h, w = image.shape[-2:]
+        return x, masks, valid_masks, gt_masks, fea1, fea2, fea3, image, h, w
+
+    def process_os4_os1(self, x, b, n_f, fea1, fea2, fea3, image, x_os8, queries, n_i, detail_bits):
+        """:346-366. Returns alpha_os4, alpha_os1 (N, n_i, H, W) fp32 and the (possibly patched) detail bit planes."""
+        H, W = image.shape[-2:]
+        N = b * n_f
+        queries = queries[:, None].expand(-1, n_f, -1, -1).reshape(N, *queries.shape[1:]).contiguous()
+        x_os4, x_os1, pyr = self.predict_details(x, detail_bits, n_i, queries, [fea1, fea2, fea3], H, W)
+        if pyr.levels[0].count == 0:
+            if self.training and H > 200 and W > 200:                       # "dummy code to prevent all zeros" (:347-348)
+                patch = torch.zeros((N * n_i, H, W), dtype=torch.uint8, device=image.device)
+                patch[:, 200:250, 200:250] = 1
+                detail_bits = K.bits_pack(patch, mode=1)
+                x_os4, x_os1, pyr = self.predict_details(x, detail_bits, n_i, queries, [fea1, fea2, fea3], H, W)
+            elif not self.training:
+                z = torch.zeros((N, n_i, H, W), device=image.device)
+                return z, torch.zeros_like(z), detail_bits
+        x_os4 = MF.upsample_tanh(x_os4.view(N, n_i, H // 4, W // 4), n_i, 4, False)
+        x_os1 = MF.upsample_tanh(x_os1.view(N, n_i, H, W), n_i, 1, False)
+        return x_os4, x_os1, detail_bits
+
+    def forward(self, x, mid_fea, b, n_f, n_i, masks, iter, gt_alphas, **kwargs):
+        x, masks, valid_masks, gt_masks, fea1, fea2, fea3, image, h, w = self.os32_to_os8(x, mid_fea, b, n_f, n_i, masks, gt_alphas)
+        x_os8, x, queries, loss_max_atten, _ = self.refine_OS8(x, masks, use_mask_atten=False, gt_mask=gt_masks)
+        n_all = self.max_inst
+        x_os8 = MF.upsample_tanh(x_os8, n_all, h // x_os8.shape[1], True)                  # (N, 10, H, W) fp32
+        if self.training:
+            x_os8 = x_os8 * valid_masks
+        else:
+            x_os8 = x_os8[:, :n_i].contiguous()
+        guided = x_os8
+        is_use_alphas_gt = False
+        if self.training and (iter < self.warmup_detail_iter or bool(x_os8.sum() == 0)
+                              or (iter < self.warmup_detail_iter * 3 and random.random() < 0.5)):
+            guided = gt_alphas
+            is_use_alphas_gt = True
+        n_cur = guided.shape[1]
+        detail_bits = MF.unknown_bits(guided, 30, False)                                   # (N*n_cur, H, Ww)
+        x_os4, x_os1, detail_bits = self.process_os4_os1(x, b, n_f, fea1, fea2, fea3, image, x_os8, queries, n_cur, detail_bits)
+        ret = {'alpha_os1': x_os1, 'alpha_os4': x_os4, 'alpha_os8': x_os8}
+        alpha_pred, weight_os4, weight_os1 = self.fuse(ret, detail_bits)
+        ret['refined_masks'] = alpha_pred
+        unknown_os8 = K.bits_unpack_u8(detail_bits, w, x_os8.shape)
+        if is_use_alphas_gt:
+            weight_os4 = K.bits_unpack_u8(MF.unknown_bits(gt_alphas, 30, self.training, andmask=detail_bits), w, x_os8.shape)
+            weight_os1 = K.bits_unpack_u8(MF.unknown_bits(gt_alphas, 15, self.training, andmask=detail_bits), w, x_os8.shape)
+        ret['weight_os4'] = weight_os4
+        ret['weight_os1'] = weight_os1
+        ret['detail_mask'] = unknown_os8
+        if self.training and iter >= self.warmup_mask_atten_iter:
+            ret['loss_max_atten'] = loss_max_atten
+        return ret
+
+
+def res_shortcut_inst_matt_spconv_22(**kwargs):
+    return ResShortCut_InstMattSpconv_Dec(BasicBlock, [2, 3, 3, 2], **kwargs)

@@ -1,0 +1,38 @@
+"""ASPP -- mirrors maggie/network/module/aspp.py:4-56 (1x1, three dilated 3x3, pooled branch, 1x1 fuse; all +BN+ReLU)."""
+import torch
+from torch import nn
+
+from ... import functional as MF
+from .base import ConvWeight
+
+
+class ASPP(nn.Module):
+    def __init__(self, in_channel, out_channel, conv=None, norm=nn.BatchNorm2d):
+        super().__init__()
+        mid = 256
+        d = [1, 2, 4, 8]
+        self.aspp1 = ConvWeight(in_channel, mid, 1, 1, 0, d[0])
+        self.aspp2 = ConvWeight(in_channel, mid, 3, 1, d[1], d[1])
+        self.aspp3 = ConvWeight(in_channel, mid, 3, 1, d[2], d[2])
+        self.aspp4 = ConvWeight(in_channel, mid, 3, 1, d[3], d[3])
+        self.aspp5 = ConvWeight(in_channel, mid, 1, 1, 0, 1)
+        self.aspp1_bn, self.aspp2_bn, self.aspp3_bn = norm(mid), norm(mid), norm(mid)
+        self.aspp4_bn, self.aspp5_bn = norm(mid), norm(mid)
+        self.conv2 = ConvWeight(mid * 5, out_channel, 1, 1, 0, 1)
+        self.bn2 = norm(out_channel)
+
+    def forward(self, x):
+        """x: (N, H, W, 512) NHWC."""
+        dt = x.dtype
+        outs = []
+        for conv, bn in ((self.aspp1, self.aspp1_bn), (self.aspp2, self.aspp2_bn), (self.aspp3, self.aspp3_bn), (self.aspp4, self.aspp4_bn)):
+            w = MF.weight_oihw_to_krsc(conv.weight, dt)
+            outs.append(MF.conv_bn_act(x, w, bn, MF.ACT_RELU, conv.kernel_size, conv.kernel_size, 1, conv.padding, conv.dilation))
+        N, H, W_, C = x.shape
+        pooled = x.float().mean((1, 2), keepdim=True).to(dt)                       # AdaptiveAvgPool2d(1)
+        w5 = MF.weight_oihw_to_krsc(self.aspp5.weight, dt)
+        x5 = MF.conv_bn_act(pooled, w5, self.aspp5_bn, MF.ACT_RELU, 1, 1, 1, 0, 1)
+        outs.append(x5.expand(N, H, W_, x5.shape[-1]))                             # nearest upsample of a 1x1 map
+        y = torch.cat(outs, -1)
+        w2 = MF.weight_oihw_to_krsc(self.conv2.weight, dt)
+        return MF.conv_bn_act(y, w2, self.bn2, MF.ACT_RELU, 1, 1, 1, 0, 1)

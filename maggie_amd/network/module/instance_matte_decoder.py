@@ -1,0 +1,138 @@
+"""InstanceMatteDecoder -- mirrors maggie/network/module/instance_matte_decoder.py:9-307 at the target configuration
+(atten_stride=1, 1 head, use_id_pe=True, use_temp_pe=False, use_mask_atten=False).
+
+Inputs/outputs are NHWC: ori_feat (b*n_f, h, w, C); mask (b, n_f, n_i, H, W) float. Returns
+(logits (b*n_f, h, w, 16 [10 real]), out_feat (b*n_f, h, w, 64), tokens (b, 10, 64), max_loss, hidden_state)."""
+import torch
+import torch.nn as nn
+from torch.nn import functional as F
+
+from ... import functional as MF
+from .base import ConvWeight, Marker
+from .mask_attention import MLP, SelfAttentionLayer, CrossAttentionLayer, FFNLayer
+
+
+class InstanceMatteDecoder(nn.Module):
+    def __init__(self, input_dim=256, atten_stride=1.0, attention_dim=256, n_block=2, n_head=4, output_dim=32, return_feat=True,
+                 max_inst=10, use_temp_pe=True, use_id_pe=True):
+        super().__init__()
+        assert atten_stride == 1 and not use_temp_pe, 'only the configuration of maggie_{image,video}.yaml is built'
+        self.n_block = n_block
+        self.atten_dim = attention_dim
+        self.atten_stride = atten_stride
+        self.return_feat = return_feat
+        self.max_inst = max_inst
+        self.use_id_pe = use_id_pe
+        self.feat_proj = MLP(input_dim, attention_dim, attention_dim, 1)
+        self.sa_layers = nn.ModuleList()
+        self.token_feat_ca_layers = nn.ModuleList()
+        self.mlp_layers = nn.ModuleList()
+        self.feat_token_ca_layers = nn.ModuleList()
+        for _ in range(n_block):
+            self.sa_layers.append(SelfAttentionLayer(attention_dim, n_head))
+            self.token_feat_ca_layers.append(CrossAttentionLayer(attention_dim, n_head))
+            self.mlp_layers.append(FFNLayer(attention_dim, attention_dim, 0.0))
+            self.feat_token_ca_layers.append(CrossAttentionLayer(attention_dim, n_head))
+        self.final_token_feat_ca = CrossAttentionLayer(attention_dim, n_head)
+        self.final_mlp = MLP(attention_dim, attention_dim, output_dim, 1)
+        self.decoder_norm = nn.LayerNorm(output_dim)
+        self.n_temp_embed = 0
+        self.n_id_embed = self.atten_dim
+        self.query_feat = nn.Embedding(max_inst, attention_dim)
+        self.id_embedding = nn.Embedding(max_inst + 1, self.n_id_embed)
+        nn.init.xavier_uniform_(self.id_embedding.weight)
+        nn.init.xavier_uniform_(self.query_feat.weight)
+        self.conv = nn.Sequential(
+            ConvWeight(attention_dim, attention_dim, 3, 1, 1, 1), nn.BatchNorm2d(attention_dim), Marker('LeakyReLU(0.2)'),
+            ConvWeight(attention_dim, output_dim, 1, 1, 0, 1), nn.BatchNorm2d(output_dim), Marker('LeakyReLU(0.2)'))
+        for m in self.conv:
+            if isinstance(m, ConvWeight):
+                nn.init.xavier_uniform_(m.weight)
+
+    def compute_atten_loss(self, b, n_f, guidance_mask, atten_mat):
+        atten_values = (guidance_mask * atten_mat).sum(2)
+        atten_gt = (guidance_mask.sum(2) != 0).to(atten_values.dtype)
+        return (atten_gt - atten_values).sum() / (n_f * b)
+
+    def _smooth(self, x):
+        c0, bn0, _, c1, bn1, _ = self.conv
+        x = MF.conv_bn_act(x, MF.weight_oihw_to_krsc(c0.weight, x.dtype), bn0, MF.ACT_LRELU, 3, 3, 1, 1, 1)
+        return MF.conv_bn_act(x, MF.weight_oihw_to_krsc(c1.weight, x.dtype), bn1, MF.ACT_LRELU, 1, 1, 1, 0, 1)
+
+    def forward(self, ori_feat, mask, use_mask_atten=False, gt_mask=None, aggregate_mem_fn=None):
+        assert not use_mask_atten
+        N, h, w, C = ori_feat.shape
+        b, n_f, n_in = mask.shape[:3]
+        dt = ori_feat.dtype
+        # mask -> OS8 binary (resizeAnyShape(..., use_avg_pool_binary=True), utils.py:16-21)
+        stride = mask.shape[-1] // w
+        m8 = mask.reshape(b * n_f, n_in, mask.shape[-2], mask.shape[-1]).float()
+        if stride > 1:
+            m8 = (F.avg_pool2d(m8, stride, stride) > 0).float()
+        m8 = m8.view(b, n_f, n_in, h, w)
+        # ID position of every feature pixel = max over instances of id*mask (:150-153)
+        ids = torch.arange(1, n_in + 1, device=mask.device, dtype=torch.float32)[None, None, :, None, None]
+        feat_ids = (m8 * ids).amax(2).long().reshape(b, n_f * h * w)                       # (b, L), l = f*hw + p
+        id_table = self.id_embedding.weight.float() if self.use_id_pe else None
+        token_pos = self.id_embedding.weight[1:self.max_inst + 1].float()[None].expand(b, -1, -1)
+        tokens = self.query_feat.weight.float()[None].expand(b, -1, -1)
+
+        # feature projection (Linear 128->128 over all rows) on the implicit-GEMM kernel
+        lin = self.feat_proj.layers[0]
+        wproj = MF._pad_krsc(lin.weight[:, None, :], dt, None, None)
+        feat = MF.linear_rows(ori_feat.reshape(-1, C), wproj, lin.bias.float()).float().view(b, n_f * h * w, -1)
+
+        n_i = self.max_inst
+        guidance_mask = None
+        if self.training:
+            gm = gt_mask.reshape(b * n_f, gt_mask.shape[2], gt_mask.shape[-2], gt_mask.shape[-1]).float()
+            gs = gm.shape[-1] // w
+            if gs > 1:
+                gm = F.max_pool2d(gm, gs, gs)
+            gm = gm.view(b, n_f, -1, h * w)
+            if gm.shape[2] < n_i:
+                gm = torch.cat([gm, gm.new_zeros((b, n_f, n_i - gm.shape[2], h * w))], 2)
+            guidance_mask = (gm > 0).permute(0, 2, 1, 3).reshape(b, n_i, n_f * h * w).float()
+
+        max_loss = 0
+        valid_tokens = m8.sum((1, 3, 4)) > 0
+        if valid_tokens.shape[1] < n_i:
+            valid_tokens = torch.cat([valid_tokens, valid_tokens.new_zeros((b, n_i - valid_tokens.shape[1]))], 1)
+        token_padding_mask = ~valid_tokens
+        pos_t = token_pos if self.use_id_pe else None
+        tbl = id_table if self.use_id_pe else None
+
+        for i in range(self.n_block):
+            tokens, att = self.token_feat_ca_layers[i].tokens_from_features(tokens, pos_t, feat, feat_ids, tbl)
+            if self.training:
+                max_loss = max_loss + self.compute_atten_loss(b, n_f, guidance_mask, att)
+            tokens = self.mlp_layers[i](tokens)
+            tokens = self.sa_layers[i](tokens, tgt_key_padding_mask=token_padding_mask, query_pos=token_pos)
+            feat = self.feat_token_ca_layers[i].features_from_tokens(feat, feat_ids, tbl, tokens, pos_t, token_padding_mask)
+        tokens, att = self.final_token_feat_ca.tokens_from_features(tokens, token_pos, feat, feat_ids, id_table)
+        if self.training:
+            max_loss = max_loss + self.compute_atten_loss(b, n_f, guidance_mask, att)
+        max_loss = max_loss / (self.n_block + 1)
+
+        feat = feat.to(dt).view(N, h, w, -1)
+        hidden_state = None
+        if aggregate_mem_fn is not None:
+            no_temp_feat = feat
+            feat, hidden_state = aggregate_mem_fn(feat.view(b, n_f, h, w, -1))
+            feat = feat.flatten(0, 1)
+            out_feat = self._smooth(no_temp_feat)
+            feat = self._smooth(feat)
+        else:
+            feat = self._smooth(feat)
+            out_feat = feat
+
+        tokens = self.decoder_norm(self.final_mlp(tokens))                                    # (b, 10, c_out) fp32
+        # einsum('bqc,btchw->btqhw'): a per-batch-element 1x1 conv whose weights are the tokens (padded to 16 outputs)
+        cq = MF.pad8(n_i) if MF.pad8(n_i) >= 16 else 16
+        logits = []
+        fr = feat.view(b, n_f * h * w, -1)
+        for bi in range(b):
+            wtok = MF._pad_krsc(tokens[bi][:, None, :], dt, None, cq)
+            logits.append(MF.linear_rows(fr[bi], wtok))
+        output_mask = torch.stack(logits, 0).view(N, h, w, cq)
+        return output_mask, out_feat, tokens, max_loss, hidden_state

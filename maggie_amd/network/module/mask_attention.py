@@ -1,0 +1,136 @@
+"""Attention blocks of the instance matte decoder -- mirror maggie/network/module/mask_attention.py:9-206
+(SelfAttentionLayer / CrossAttentionLayer / FFNLayer / MLP, post-norm, dropout 0, ONE head).
+
+MI355X-first restructuring: one side of every cross attention is only `max_inst` (=10) tokens wide, so the big-side
+Q/K/V projections (L x 128 x 128 GEMMs, L = n_f*h*w) are never materialised. The token side is folded into the
+projection weights and the ID position embedding into an (max_inst+1)-row lookup table:
+
+  tokens <- features :  score[q, l] = (Q_q Wk) . f_l + (Q_q . (E[id_l] Wk^T + bk)),   ctx_q = sum_l P[q,l] f_l,
+                        out_q = (ctx_q Wv^T + bv) Wo^T + bo                      (sum_l P = 1)
+  features <- tokens :  score[l, j] = f_l . (Wq^T K_j) + ((E[id_l] Wq^T + bq) . K_j),  out_l = sum_j P[l,j] (V_j Wo^T) + bo
+
+which is algebraically identical to nn.MultiheadAttention(q + pos_q, k + pos_k, v) and turns each block into one
+pass over the (L x 128) feature rows. The row-side math below is small fp32 torch plumbing; the kernels that matter
+(feature projection, 3x3 / 1x1 convolutions, BN) are HIP.
+"""
+import math
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+
+def _split_in_proj(mha):
+    d = mha.embed_dim
+    w, b = mha.in_proj_weight, mha.in_proj_bias
+    return (w[:d], w[d:2 * d], w[2 * d:]), (b[:d], b[d:2 * d], b[2 * d:])
+
+
+class SelfAttentionLayer(nn.Module):
+    def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False):
+        super().__init__()
+        assert nhead == 1 and dropout == 0.0 and not normalize_before
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.norm = nn.LayerNorm(d_model)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, tgt, tgt_key_padding_mask=None, query_pos=None):
+        """tgt: (b, T, d) tokens; key padding mask (b, T) True = ignore."""
+        (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.self_attn)
+        qk = tgt if query_pos is None else tgt + query_pos
+        q = F.linear(qk, wq, bq)
+        k = F.linear(qk, wk, bk)
+        v = F.linear(tgt, wv, bv)
+        s = torch.matmul(q, k.transpose(1, 2)) / math.sqrt(q.shape[-1])
+        if tgt_key_padding_mask is not None:
+            s = s.masked_fill(tgt_key_padding_mask[:, None, :], float('-inf'))
+        p = torch.softmax(s, -1)
+        out = self.self_attn.out_proj(torch.matmul(p, v))
+        return self.norm(tgt + out)
+
+
+class CrossAttentionLayer(nn.Module):
+    def __init__(self, d_model, nhead, dropout=0.0, activation="relu", normalize_before=False):
+        super().__init__()
+        assert nhead == 1 and dropout == 0.0 and not normalize_before
+        self.multihead_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.norm = nn.LayerNorm(d_model)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def tokens_from_features(self, tokens, token_pos, feat, feat_ids, id_table):
+        """tokens (b,T,d) <- feat (b,L,d) with key position = id_table[feat_ids] ((b,L) long). Returns new tokens and the
+        attention matrix (b,T,L)."""
+        if torch.isnan(tokens).any():
+            raise ValueError("Mask is empty")
+        (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.multihead_attn)
+        d = tokens.shape[-1]
+        q = F.linear(tokens if token_pos is None else tokens + token_pos, wq, bq)            # (b,T,d)
+        qk = torch.matmul(q, wk)                                                             # fold Wk into the queries
+        s = torch.matmul(qk, feat.transpose(1, 2))                                           # (b,T,L)
+        if id_table is not None:
+            tbl = torch.matmul(q, (F.linear(id_table, wk)).t()) + (q * bk).sum(-1, keepdim=True)      # (b,T,n_id)
+            s = s + torch.gather(tbl, 2, feat_ids[:, None, :].expand(-1, q.shape[1], -1))
+        else:
+            s = s + (q * bk).sum(-1, keepdim=True)
+        p = torch.softmax(s / math.sqrt(d), -1)
+        ctx = torch.matmul(p, feat)                                                          # (b,T,d)
+        out = self.multihead_attn.out_proj(F.linear(ctx, wv, bv))
+        return self.norm(tokens + out), p
+
+    def features_from_tokens(self, feat, feat_ids, id_table, tokens, token_pos, token_padding_mask):
+        """feat (b,L,d) <- tokens (b,T,d); query position = id_table[feat_ids]."""
+        if torch.isnan(feat).any():
+            raise ValueError("Mask is empty")
+        (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.multihead_attn)
+        d = feat.shape[-1]
+        k = F.linear(tokens if token_pos is None else tokens + token_pos, wk, bk)            # (b,T,d)
+        v = self.multihead_attn.out_proj.weight @ F.linear(tokens, wv, bv).transpose(1, 2)   # (b,d,T): Wo V^T
+        kq = torch.matmul(k, wq)                                                             # (b,T,d): fold Wq into the keys
+        s = torch.matmul(feat, kq.transpose(1, 2))                                           # (b,L,T)
+        if id_table is not None:
+            tbl = torch.matmul(F.linear(id_table, wq, bq), k.transpose(1, 2))                # (b,n_id,T)
+            s = s + torch.gather(tbl, 1, feat_ids[:, :, None].expand(-1, -1, k.shape[1]))
+        else:
+            s = s + torch.matmul(k, bq)[:, None, :]
+        s = s / math.sqrt(d)
+        if token_padding_mask is not None:
+            s = s.masked_fill(token_padding_mask[:, None, :], float('-inf'))
+        p = torch.softmax(s, -1)
+        out = torch.matmul(p, v.transpose(1, 2)) + self.multihead_attn.out_proj.bias
+        return self.norm(feat + out)
+
+
+class FFNLayer(nn.Module):
+    def __init__(self, d_model, dim_feedforward=2048, dropout=0.0, activation="relu", normalize_before=False):
+        super().__init__()
+        assert not normalize_before
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm = nn.LayerNorm(d_model)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, tgt):
+        tgt2 = self.linear2(self.dropout(F.relu(self.linear1(tgt))))
+        return self.norm(tgt + self.dropout(tgt2))
+
+
+class MLP(nn.Module):
+    """Very simple multi-layer perceptron (also called FFN)"""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        h = [hidden_dim] * (num_layers - 1)
+        self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            x = F.relu(layer(x)) if i < self.num_layers - 1 else layer(x)
+        return x

@@ -1,0 +1,35 @@
+"""One small invocation of the hot path on cuda:0 through the C ABI, checked against the CPU oracle
+(used by __graft_entry__.smoke())."""
+import torch
+
+
+def run():
+    from maggie_amd.network import build_model
+    from maggie_amd.utils import config, synth
+    from oracle import refmodel
+    assert torch.cuda.is_available(), 'smoke() needs a GPU'
+    dev = torch.device('cuda:0')
+    cfg = config.model_config('image')
+    model, _ = build_model(cfg)
+    sd = model.state_dict()
+    synth.fill_state_dict_(sd, 7)
+    model.load_state_dict(sd)
+    sd_cpu = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(dev).eval()
+    batch = synth.synthetic_batch(1, 1, 2, 128, 128, seed=3, train=False)
+    with torch.no_grad():
+        out = model({k: v.to(dev) for k, v in batch.items()})
+        ref = refmodel.maggie_forward(sd_cpu, dict(config.MODEL_IMAGE), batch, False)
+    err = (out['refined_masks'].float().cpu() - ref['refined_masks']).abs().max().item()
+    same = bool((out['detail_mask'].cpu() == ref['detail_mask']).all())
+    print('smoke: alpha max-abs err vs CPU oracle = %.3g, detail_mask bit-exact = %s' % (err, same))
+    assert err <= 1e-3 and same
+    # one tiny training step (forward + backward) in bf16 autocast
+    model.train()
+    tb = synth.synthetic_batch(2, 1, 2, 128, 128, seed=3, train=True, it=10000, max_inst=10)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        _, loss = model({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in tb.items()})
+    loss['total'].backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss['total']).item()
+    print('smoke: bf16 train step ok, total loss %.4f' % float(loss['total']))

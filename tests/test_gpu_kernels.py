@@ -223,3 +223,33 @@ def test_mask_embed(dtype):
     emb.backward(g[..., 3:6].permute(0, 3, 1, 2))
     dt = K.mask_embed_bwd(g.to(dev), masks.to(dev), (n_m + 1, 3))
     assert torch.allclose(dt.cpu(), table.grad, rtol=1e-3, atol=1e-3)
+
+
+def test_gather_tables_real_roi_regression():
+    """A detail region captured from the video model (thin bands reaching the right image border, 6 planes). An earlier
+    table kernel was mis-compiled for it (non-deterministic -1 entries); must be exact and repeatable."""
+    import os
+    from maggie_amd import kernels as K
+    from oracle import region
+    dev = _dev()
+    z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'roi_band_regression.npz'))
+    shape = tuple(z['shape'])
+    roi = np.unpackbits(z['bits'])[:int(np.prod(shape))].reshape(shape)
+    pyr = region.active_pyramid(roi)
+    H, W = shape[-2:]
+    b1 = K.bits_pack(torch.from_numpy(roi).to(dev), mode=1)
+    b2, h2, w2 = K.bits_downsample(b1, W)
+    ro1, wo1 = K.bits_rank(b1, W)
+    ro2, wo2 = K.bits_rank(b2, w2)
+    c1 = K.bits_coords(b1, wo1, W, int(ro1[-1]))
+    c2 = K.bits_coords(b2, wo2, w2, int(ro2[-1]))
+    ref_inv = region.inverse_neighbors(pyr[0], pyr[1])
+    ref_sub = region.subm_neighbors(pyr[0])
+    for _ in range(3):
+        assert np.array_equal(K.gather_table(c1, 3, 1, b2, wo2, h2, w2).cpu().numpy(), ref_inv)
+        assert np.array_equal(K.gather_table(c1, 3, 0, b1, wo1, H, W).cpu().numpy(), ref_sub)
+        down = K.gather_table(c2, 3, 2, b1, wo1, H, W).cpu().numpy()
+        chk = np.full_like(down, -1)
+        rr, kk = np.nonzero(ref_inv >= 0)
+        chk[ref_inv[rr, kk], kk] = rr
+        assert np.array_equal(down, chk)
