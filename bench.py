@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""bench.py -- MaGGIe hot-path benchmark on MI355X (driver contract: python bench.py --gpus N --steps K --warmup W).
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): maggie_image.yaml, 512x512, 2 real
+instances (10 slots), batch 4 PER GPU, bf16 autocast, one full training step = forward + losses + backward +
+gradient-norm clip + AdamW update (+ DDP gradient all-reduce over RCCL when N > 1; weak scaling: per-GPU work fixed).
+Synthetic data / deterministic random-init weights (maggie_amd.utils.synth): no dataset or checkpoint is reachable offline.
+
+Prints ONE JSON line on rank 0. `value` = whole-job instance-frames/s with the batch already resident in HBM.
+`roofline` = the dominant kernel family (implicit-GEMM MFMA conv kernels), measured live with HIP events on extra
+instrumented steps of the same workload; `cpu_baseline` = the CPU oracle (oracle/refmodel.py, a port, never the product)
+timed on this host's cores on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak of MI355X (/opt/skills/guides/MI355X_MICROARCH.md)
+DENSE_GFLOP_PER_FRAME_FWD = 69.2
+SPARSE_KFLOP_PER_ACTIVE_PX_FWD = 64.5
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=4, help='frames per GPU')
+    ap.add_argument('--instances', type=int, default=2)
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--iter', type=int, default=10000, help="batch['iter'] (past every warm-up of the reference)")
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--sync-bn', action='store_true', help='nn.SyncBatchNorm like configs/maggie_image.yaml:33 (N > 1)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--video', action='store_true', help='maggie_video.yaml, T=3 (BASELINE configs[3]); not the headline line')
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    from maggie_amd.network import build_model
+    from maggie_amd.utils import config, synth
+    from maggie_amd import hip, parallel
+
+    kind = 'video' if args.video else 'image'
+    n_f = 3 if args.video else 1
+    b = 1 if args.video else args.batch
+    cfg = config.model_config(kind)
+    model, _ = build_model(cfg)
+    sd = model.state_dict()
+    synth.fill_state_dict_(sd, 1234)
+    model.load_state_dict(sd)
+    model.to(dev).train()
+    if world > 1 and args.sync_bn:
+        model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    net = model
+    if world > 1:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        net = DDP(model, device_ids=[local_rank], find_unused_parameters=True, gradient_as_bucket_view=True)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1.5e-4, betas=(0.9, 0.999), weight_decay=0.01)      # maggie_image.yaml:90-98
+
+    batch = synth.synthetic_batch(b, n_f, args.instances, args.size, args.size, seed=1234 + rank, train=True, it=args.iter, max_inst=10)
+    batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    np.random.seed(1234 + rank)
+    import random
+    random.seed(1234 + rank)
+    torch.manual_seed(1234 + rank)
+    use_bf16 = args.dtype == 'bf16'
+    stats = {}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=use_bf16):
+            out, loss = net(batch)
+        loss['total'].backward()
+        torch.nn.utils.clip_grad_norm_(params, 0.01)                                    # engine/train.py:274
+        opt.step()
+        stats['active_px'] = out['detail_mask']
+        stats['loss'] = loss['total']
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0)
+
+    inst_frames_per_step = b * n_f * args.instances * world
+    value = inst_frames_per_step * args.steps / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+    active_px = float(stats['active_px'].float().sum().item())
+    active_ratio = active_px / (b * n_f * args.instances * args.size * args.size)
+    loss_val = float(stats['loss'].item())
+
+    roofline = None
+    if not args.no_roofline:
+        names = ['mg_conv_fprop', 'mg_conv_wgrad']
+        hip.enable_timing(names)
+        n_prof = 2
+        for _ in range(n_prof):
+            step()
+        torch.cuda.synchronize()
+        rec = hip.disable_timing()['records']
+        fam = {}
+        for n in names:
+            for s, e, work, tag in rec[n]:
+                key = '%s/%s' % (n, tag[0])
+                d = fam.setdefault(key, [0.0, 0.0, 0])
+                d[0] += s.elapsed_time(e) * 1e-3
+                d[1] += work
+                d[2] += 1
+        dom = max(fam.items(), key=lambda kv: kv[1][0])
+        tot_t = sum(v[0] for v in fam.values())
+        tot_w = sum(v[1] for v in fam.values())
+        ach = dom[1][1] / dom[1][0] / 1e12
+        frames_s = b * n_f * args.steps / elapsed
+        scale = (args.size / 512.0) ** 2
+        step_tflops = (frames_s * DENSE_GFLOP_PER_FRAME_FWD * 3 * scale * 1e9 + (active_px / ms_per_step * 1e3) * SPARSE_KFLOP_PER_ACTIVE_PX_FWD * 3e3) / 1e12
+        roofline = {
+            'bound': 'mfma', 'kernel': 'igemm ' + dom[0], 'achieved': round(ach, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(ach / PEAK_BF16_TFLOPS, 5), 'traffic': None,
+            'launches_per_step': dom[1][2] // n_prof, 'avg_launch_us': round(1e6 * dom[1][0] / dom[1][2], 2),
+            'alg_gflop_per_launch': round(dom[1][1] / dom[1][2] / 1e9, 4),
+            'conv_family_ms_per_step': round(1e3 * tot_t / n_prof, 3), 'conv_family_tflops': round(tot_w / tot_t / 1e12, 2),
+            'families': {k: {'ms_per_step': round(1e3 * v[0] / n_prof, 3), 'tflops': round(v[1] / v[0] / 1e12, 2), 'launches': v[2] // n_prof}
+                         for k, v in fam.items()},
+            'step_algorithmic_tflops_per_gpu': round(step_tflops, 2), 'step_frac_of_mfma_peak': round(step_tflops / PEAK_BF16_TFLOPS, 5),
+        }
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(kind, args)
+
+    if rank == 0:
+        line = {
+            'metric': 'instance-frames/sec (fwd+bwd+optimizer step, %dx%d, %s)' % (args.size, args.size, args.dtype),
+            'value': round(value, 3), 'unit': 'instance-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.dtype, 'data': 'synthetic',
+            'per_gpu': round(value / world, 3),
+            'config': {'workload': 'maggie_%s.yaml train step: %dx%d, %d instances (10 slots), batch %d frames/GPU x %d frame(s), iter=%d, '
+                                   'fwd+loss+bwd+clip+AdamW' % (kind, args.size, args.size, args.instances, b, n_f, args.iter),
+                       'global_batch': b * world, 'parallelism': 'dp%d' % world, 'sync_bn': bool(args.sync_bn and world > 1),
+                       'active_ratio': round(active_ratio, 4), 'active_pixels_per_step_per_gpu': int(active_px), 'loss_total': round(loss_val, 4)},
+            'roofline': roofline, 'cpu_baseline': cpu_baseline,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_cpu_baseline(kind, args):
+    """The CPU oracle (a port of the reference path, test infrastructure) timed on this host: one bounded train step."""
+    import copy
+    from maggie_amd.network import build_model
+    from maggie_amd.utils import config, synth
+    from oracle import refmodel
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model, _ = build_model(config.model_config(kind))
+    sd = model.state_dict()
+    synth.fill_state_dict_(sd, 1234)
+    sd = {k: v.clone() for k, v in sd.items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and not k.endswith(('_u', '_v', 'running_mean', 'running_var')):
+            v.requires_grad_(True)
+    n_f = 3 if kind == 'video' else 1
+    b = 1 if kind == 'video' else 2
+    size = min(args.size, 512)
+    batch = synth.synthetic_batch(b, n_f, args.instances, size, size, seed=1234, train=True, it=args.iter, max_inst=10)
+    mcfg = copy.deepcopy(config.MODEL_VIDEO if kind == 'video' else config.MODEL_IMAGE)
+    np.random.seed(0)
+
+    def one():
+        for v in sd.values():
+            if v.grad is not None:
+                v.grad = None
+        out, loss = refmodel.maggie_forward(sd, mcfg, batch, True)
+        loss['total'].backward()
+    one()                      # warm-up
+    t0 = time.perf_counter()
+    one()
+    dt = time.perf_counter() - t0
+    return {'value': round(b * n_f * args.instances / dt, 4), 'unit': 'instance-frames/s', 'cores': cores, 'kind': 'port',
+            'sample': 'oracle/refmodel.py fp32 train step (fwd+loss+bwd, no optimizer), %dx%d, batch %d x %d frame(s), %d instances, '
+                      '1 warm-up + 1 timed step = %.1f s' % (size, size, b, n_f, args.instances, dt),
+            'threads': torch.get_num_threads()}
+
+
+if __name__ == '__main__':
+    main()

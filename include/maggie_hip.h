@@ -99,7 +99,10 @@ typedef struct mg_rowwise_params {
 /* stats[c] += sum_m x[m,c], stats[C+c] += sum_m x[m,c]^2 (fp32, pre-zeroed) */
 int mg_colstats(const void* x, int dtype, int M, int C, int ld, float* stats, void* stream);
 /* batch statistics -> scale/shift/mean/invstd, running-stat update with momentum and unbiased variance */
-int mg_bn_finalize(const float* stats, const float* count_ptr, float count, int C, const float* gamma, const float* beta,
+/* exact two-pass variant for small M: stats[0:C] = sum, stats[C:2C] = sum (x - mean)^2 (stats is overwritten) */
+int mg_colstats_centered(const void* x, int dtype, int M, int C, int ld, float* stats, void* stream);
+/* `centered` != 0: stats[C:2C] holds the centred second moment (mg_colstats_centered) instead of sum x^2 */
+int mg_bn_finalize(const float* stats, const float* count_ptr, float count, int C, int centered, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
                    float* mean_out, float* invstd_out, void* stream);
 /* eval mode: fold running statistics into scale/shift */

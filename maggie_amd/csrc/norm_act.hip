@@ -49,10 +49,45 @@ __global__ __launch_bounds__(NT) void colstats_kernel(const T* __restrict__ x, i
     for (int i = t; i < 2 * C; i += NT) atomicAdd(&stats[i], sred[i]);
 }
 
+// second pass of the exact two-pass variance: stats[C+c] += sum_m (x[m,c] - stats[c]/M)^2   (stats[0:C] = column sums)
+template <typename T>
+__global__ __launch_bounds__(NT) void colstats_centered_kernel(const T* __restrict__ x, int M, int C, int ld, float* __restrict__ stats,
+                                                               int rows_per_block) {
+    using TR = ElemTraits<T>;
+    constexpr int CE = TR::CE;
+    const int cpr = C / CE;
+    const int t = threadIdx.x;
+    const int tpr = cpr < NT ? cpr : NT;
+    const int rstep = NT / tpr;
+    const int cc0 = t % tpr, rr = t / tpr;
+    extern __shared__ float sred[];               // [C]
+    for (int i = t; i < C; i += NT) sred[i] = 0.f;
+    __syncthreads();
+    const float inv_m = 1.f / (float)M;
+    const int mbeg = blockIdx.x * rows_per_block, mend = min(M, mbeg + rows_per_block);
+    if (rr < rstep) {
+        for (int cc = cc0; cc < cpr; cc += tpr) {
+            float s2[CE], mu[CE];
+#pragma unroll
+            for (int e = 0; e < CE; ++e) { s2[e] = 0.f; mu[e] = stats[cc * CE + e] * inv_m; }
+            for (int m = mbeg + rr; m < mend; m += rstep) {
+                float f[CE];
+                TR::unpack(*(const uint4*)(x + (long)m * ld + cc * CE), f);
+#pragma unroll
+                for (int e = 0; e < CE; ++e) { float d = f[e] - mu[e]; s2[e] += d * d; }
+            }
+#pragma unroll
+            for (int e = 0; e < CE; ++e) atomicAdd(&sred[cc * CE + e], s2[e]);
+        }
+    }
+    __syncthreads();
+    for (int i = t; i < C; i += NT) atomicAdd(&stats[C + i], sred[i]);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // finalize: batch statistics -> (scale, shift, mean, invstd) + running-stat update (momentum, unbiased var)
 // ---------------------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ count_ptr, float count, int C,
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ count_ptr, float count, int C, int centered,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
                                    float* running_var, float momentum, float eps, float* __restrict__ scale,
                                    float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ invstd_out) {
@@ -60,7 +95,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, const float*
     if (c >= C) return;
     float n = count_ptr ? *count_ptr : count;
     float mean = stats[c] / n;
-    float var = stats[C + c] / n - mean * mean;
+    float var = centered ? stats[C + c] / n : stats[C + c] / n - mean * mean;
     var = var > 0.f ? var : 0.f;
     float invstd = rsqrtf(var + eps);
     float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -276,10 +311,34 @@ extern "C" int mg_colstats(const void* x, int dtype, int M, int C, int ld, float
     return 0;
 }
 
-extern "C" int mg_bn_finalize(const float* stats, const float* count_ptr, float count, int C, const float* gamma, const float* beta,
+extern "C" int mg_colstats_centered(const void* x, int dtype, int M, int C, int ld, float* stats, void* stream) {
+    if (M <= 0) return 0;
+    const int ce = dtype == MG_BF16 ? 8 : 4;
+    if (C % ce || ld % ce) return -3;
+    int blocks = (M + 255) / 256; if (blocks > 1024) blocks = 1024;
+    int rpb = (M + blocks - 1) / blocks;
+    blocks = (M + rpb - 1) / rpb;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(stats, 0, (size_t)2 * C * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    if (dtype == MG_BF16) {
+        hipLaunchKernelGGL(colstats_kernel<bf16raw>, dim3(blocks), dim3(NT), 2 * C * 4, st, (const bf16raw*)x, M, C, ld, stats, rpb);
+        e = hipMemsetAsync(stats + C, 0, (size_t)C * sizeof(float), st);
+        hipLaunchKernelGGL(colstats_centered_kernel<bf16raw>, dim3(blocks), dim3(NT), C * 4, st, (const bf16raw*)x, M, C, ld, stats, rpb);
+    } else {
+        hipLaunchKernelGGL(colstats_kernel<float>, dim3(blocks), dim3(NT), 2 * C * 4, st, (const float*)x, M, C, ld, stats, rpb);
+        e = hipMemsetAsync(stats + C, 0, (size_t)C * sizeof(float), st);
+        hipLaunchKernelGGL(colstats_centered_kernel<float>, dim3(blocks), dim3(NT), C * 4, st, (const float*)x, M, C, ld, stats, rpb);
+    }
+    if (e != hipSuccess) return (int)e;
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_bn_finalize(const float* stats, const float* count_ptr, float count, int C, int centered, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
                               float* mean_out, float* invstd_out, void* stream) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, count_ptr, count, C, gamma,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, count_ptr, count, C, centered, gamma,
                        beta, running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out);
     MG_CHECK_LAUNCH();
     return 0;

@@ -11,6 +11,7 @@ from . import kernels as K
 from .kernels import MODE_CONV, MODE_TCONV, MODE_GATHER, ACT_NONE, ACT_RELU, ACT_LRELU  # noqa: F401
 
 LRELU_SLOPE = 0.2
+EXACT_STATS_ROWS = 32768      # BatchNorm layers with at most this many rows use the exact two-pass variance
 
 
 def compute_dtype():
@@ -153,8 +154,12 @@ class BNAct(torch.autograd.Function):
         b32 = pad_vec(beta.float(), C)
         count = float(M)
         cnt_t = None
+        centered = False
         if training:
-            if stats is None:
+            if group is None and M <= EXACT_STATS_ROWS:
+                # few samples per channel: exact two-pass variance (E[x^2]-E[x]^2 cancels badly when var << mean^2)
+                stats, centered = K.colstats_centered(x2), True
+            elif stats is None:
                 stats = K.colstats(x2)
             if group is not None:
                 pack = torch.cat([stats[:2 * C], torch.full((1,), float(M), device=x.device)])
@@ -165,7 +170,7 @@ class BNAct(torch.autograd.Function):
             rm_p, rv_p = rm, rv
             if rm is None and running_mean is not None:       # padded channel count: update through a temp
                 rm_p, rv_p = pad_vec(running_mean, C).clone(), pad_vec(running_var, C).clone()
-            scale, shift, mean, invstd = K.bn_finalize(stats, count, g32, b32, rm_p, rv_p, momentum, eps, count_ptr=cnt_t)
+            scale, shift, mean, invstd = K.bn_finalize(stats, count, g32, b32, rm_p, rv_p, momentum, eps, count_ptr=cnt_t, centered=centered)
             if rm is None and running_mean is not None:
                 running_mean.copy_(rm_p[:running_mean.numel()])
                 running_var.copy_(rv_p[:running_var.numel()])

@@ -81,9 +81,33 @@ def need_cuda(*ts):
             raise MaggieHipError('MaGGIe HIP kernels need device tensors (got a CPU tensor); there is no CPU fallback')
 
 
-def call(name, *args):
+_TIMING = None          # set by enable_timing(): {'names': set, 'records': {name: [(start, end, work, tag)]}}
+
+
+def enable_timing(names):
+    """bench.py instrumentation: bracket every launch of the named entry points with HIP events on the launch stream
+    (torch.cuda.Event records on torch's current stream, which is the stream the kernels are launched on)."""
+    global _TIMING
+    _TIMING = {'names': set(names), 'records': {n: [] for n in names}}
+
+
+def disable_timing():
+    global _TIMING
+    t, _TIMING = _TIMING, None
+    return t
+
+
+def call(name, *args, work=None, tag=None):
     fn = getattr(lib(), name)
     fn.restype = ctypes.c_int
+    if _TIMING is not None and name in _TIMING['names']:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = fn(*args)
+        e.record()
+        _TIMING['records'][name].append((s, e, work, tag))
+        check(rc, name)
+        return
     check(fn(*args), name)
 
 

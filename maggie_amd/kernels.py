@@ -71,7 +71,8 @@ def conv_fprop(x, w, *, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=None, Wout=None,
             assert v.dtype == torch.float32 and v.numel() >= Cout
     p = _conv_params(x, w, out, mode, N, Hin, Win, Hout, Wout, R, S, stride, pad, dil, M, Cin, Cout, nbr, scale, shift,
                      res, res_mode, res2, act, pre_act, slope, stats, yoff)
-    hip.call('mg_conv_fprop', ctypes.byref(p), hip.stream())
+    hip.call('mg_conv_fprop', ctypes.byref(p), hip.stream(), work=2.0 * M * Cout * R * S * Cin,
+             tag=('bf16' if x.dtype == torch.bfloat16 else 'f32', mode, Cout, R * S * Cin, M))
     return out
 
 
@@ -89,7 +90,8 @@ def conv_wgrad(x, dy, *, cout, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=1, Wout=1
     assert dy.dtype == x.dtype
     p = _conv_params(x, None, dy, mode, N, Hin, Win, Hout, Wout, R, S, stride, pad, dil, M, Cin, cout, nbr,
                      stats=out, yoff=yoff)
-    hip.call('mg_conv_wgrad', ctypes.byref(p), hip.stream())
+    hip.call('mg_conv_wgrad', ctypes.byref(p), hip.stream(), work=2.0 * M * cout * R * S * Cin,
+             tag=('bf16' if x.dtype == torch.bfloat16 else 'f32', mode, cout, R * S * Cin, M))
     return out
 
 
@@ -109,12 +111,21 @@ def colstats(x, stats=None):
     return stats
 
 
-def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps, count_ptr=None):
+def colstats_centered(x):
+    """Exact two-pass statistics (for small row counts): stats[0:C] = sum, stats[C:2C] = sum (x - mean)^2."""
+    M, C = x.shape[0], x.shape[-1]
+    stats = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    hip.need_cuda(x)
+    hip.call('mg_colstats_centered', hip.ptr(x), c_int(hip.dtype_code(x)), c_int(M), c_int(C), c_int(_ld(x)), hip.ptr(stats), hip.stream())
+    return stats
+
+
+def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps, count_ptr=None, centered=False):
     """-> scale, shift, mean, invstd (each fp32 [C]); updates the running statistics in place when given."""
     C = stats.numel() // 2
     out = torch.empty((4, C), dtype=torch.float32, device=stats.device)
     hip.need_cuda(stats, gamma, beta, running_mean, running_var)
-    hip.call('mg_bn_finalize', hip.ptr(stats), hip.ptr(count_ptr), c_float(float(count)), c_int(C), hip.ptr(gamma), hip.ptr(beta),
+    hip.call('mg_bn_finalize', hip.ptr(stats), hip.ptr(count_ptr), c_float(float(count)), c_int(C), c_int(int(centered)), hip.ptr(gamma), hip.ptr(beta),
              hip.ptr(running_mean), hip.ptr(running_var), c_float(momentum), c_float(eps), hip.ptr(out[0]), hip.ptr(out[1]),
              hip.ptr(out[2]), hip.ptr(out[3]), hip.stream())
     return out[0], out[1], out[2], out[3]

@@ -44,6 +44,9 @@ def test_bn_train_forward_backward(dtype, act):
     rmd, rvd = torch.zeros(C, device=dev), torch.ones(C, device=dev)
     stats = K.colstats(xd)
     scale, shift, mean, invstd = K.bn_finalize(stats, M, gamma.detach().to(dev), beta.detach().to(dev), rmd, rvd, 0.1, 1e-5)
+    st2 = K.colstats_centered(xd)
+    sc2, sh2, _, _ = K.bn_finalize(st2, M, gamma.detach().to(dev), beta.detach().to(dev), None, None, 0.1, 1e-5, centered=True)
+    assert torch.allclose(sc2, scale, rtol=1e-4) and torch.allclose(sh2, shift, rtol=1e-3, atol=1e-4)
     y = K.affine_act(xd, scale, shift, res=resd, act=act, slope=0.2)
     tol = _tol(dtype)
     assert (y.float().cpu() - y_ref.detach()).abs().max() <= tol * y_ref.abs().max() + 1e-6
