@@ -167,6 +167,17 @@ int mg_upsample_tanh(const void* in, int dtype, long sn, long sc, long sy, long 
 int mg_upsample_tanh_bwd(const float* dout, const float* out, long sn, long sc, long sy, long sx, int N, int C, int h, int w,
                          int scale, int apply_tanh, float* din, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * SpectralNorm weight preparation (maggie/network/module/spectral_norm.py:22-35,73-80): one power iteration on every
+ * forward (u, v updated in place), sigma = u^T W v, and W/sigma written in the conv kernels' (Cout, taps, Cin_pad) layout.
+ * W: fp32 [A][B][taps] (Conv2d: A=Cout,B=Cin; ConvTranspose2d (transposed=1): A=Cin,B=Cout). work: fp32 [B*taps + A + 4].
+ * ------------------------------------------------------------------------------------------------------------- */
+int mg_spectral_norm(const float* W, float* u, float* v, int A, int B, int taps, int transposed, int pad_in, void* out,
+                     int out_dtype, float* work, void* stream);
+/* dW = G/sigma - (<G,W>/sigma^2) u v^T ; G fp32 in the (Cout, taps, pad_in) layout; u, v, work as left by the forward */
+int mg_spectral_norm_bwd(const float* G, const float* W, const float* u, const float* v, int A, int B, int taps, int transposed,
+                         int pad_in, float* work, float* dW, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,28 @@ def _pad_krsc(w, dtype, cin_pad, cout_pad):
     return w.to(dtype).contiguous()
 
 
+class SpectralNormWeight(torch.autograd.Function):
+    """W_bar / sigma after ONE power iteration (u, v updated in place, no gradient through them), emitted directly in the
+    conv kernels' layout and compute dtype -- one fused HIP pipeline instead of torch.mv/norm/dot per wrapped conv."""
+
+    @staticmethod
+    def forward(ctx, w_bar, u, v, transposed, dtype, pad_in):
+        w = w_bar.detach().contiguous()
+        out, work = K.spectral_norm(w, u, v, transposed, dtype, pad_in)
+        ctx.save_for_backward(w, u.detach().clone(), v.detach().clone(), work)
+        ctx.transposed = transposed
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        w, u, v, work = ctx.saved_tensors
+        return K.spectral_norm_bwd(G, w, u, v, ctx.transposed, work), None, None, None, None, None
+
+
+def spectral_norm_weight(w_bar, u, v, transposed, dtype, pad_in):
+    return SpectralNormWeight.apply(w_bar, u.data, v.data, transposed, dtype, pad_in)
+
+
 def pad_vec(v, n):
     if v is None or v.numel() == n:
         return v

@@ -367,3 +367,32 @@ def upsample_tanh_bwd(dout, out, strides, N, C, h, w, scale, din, apply_tanh=Tru
     hip.call('mg_upsample_tanh_bwd', hip.ptr(dout), hip.ptr(out), c_long(sn), c_long(sc), c_long(sy), c_long(sx), c_int(N), c_int(C), c_int(h),
              c_int(w), c_int(scale), c_int(int(apply_tanh)), hip.ptr(din), hip.stream())
     return din
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# SpectralNorm weight preparation
+# ------------------------------------------------------------------------------------------------------------------
+def spectral_norm(w_bar, u, v, transposed, dtype, pad_in):
+    """w_bar fp32 (A, B, k, k); u (A), v (B*k*k) updated IN PLACE (one power iteration). Returns
+    (w_sn (Cout, k*k, pad_in) in `dtype`, work scratch [.., sigma])."""
+    A, B, kh, kw = w_bar.shape
+    taps = kh * kw
+    cout = B if transposed else A
+    hip.need_cuda(w_bar, u, v)
+    assert w_bar.dtype == torch.float32 and w_bar.is_contiguous() and u.dtype == torch.float32 and v.dtype == torch.float32
+    out = torch.empty((cout, taps, pad_in), dtype=dtype, device=w_bar.device)
+    work = torch.empty((B * taps + A + 4,), dtype=torch.float32, device=w_bar.device)
+    hip.call('mg_spectral_norm', hip.ptr(w_bar), hip.ptr(u), hip.ptr(v), c_int(A), c_int(B), c_int(taps), c_int(int(transposed)),
+             c_int(pad_in), hip.ptr(out), c_int(hip.dtype_code(out)), hip.ptr(work), hip.stream())
+    return out, work
+
+
+def spectral_norm_bwd(G, w_bar, u, v, transposed, work):
+    A, B, kh, kw = w_bar.shape
+    taps = kh * kw
+    pad_in = G.shape[-1]
+    G = G.float().contiguous()
+    dW = torch.empty_like(w_bar)
+    hip.call('mg_spectral_norm_bwd', hip.ptr(G), hip.ptr(w_bar), hip.ptr(u), hip.ptr(v), c_int(A), c_int(B), c_int(taps),
+             c_int(int(transposed)), c_int(pad_in), hip.ptr(work), hip.ptr(dW), hip.stream())
+    return dW

@@ -45,11 +45,13 @@ class SpectralNorm(nn.Module):
         return w / sigma
 
     def krsc(self, dtype, cin_pad=None):
-        """Spectrally-normalised weight in the kernels' (Cout, taps, Cin_pad) layout and compute dtype."""
-        w = self.normalized_weight()
-        if self.module.transposed:
-            return MF.weight_iohw_to_krsc(w, dtype, cin_pad)
-        return MF.weight_oihw_to_krsc(w, dtype, cin_pad)
+        """Spectrally-normalised weight in the kernels' (Cout, taps, Cin_pad) layout and compute dtype (fused HIP path:
+        power iteration + sigma + scaling + layout/dtype conversion; u and v are updated in place)."""
+        m = self.module
+        cin = m.in_channels
+        pad_in = MF.pad8(cin) if cin_pad is None else cin_pad
+        assert self.power_iterations == 1
+        return MF.spectral_norm_weight(m.weight_bar, m.weight_u, m.weight_v, m.transposed, dtype, pad_in)
 
     def forward(self, x, **kw):
         m = self.module
