@@ -42,6 +42,7 @@ def parse():
     ap.add_argument('--sync-bn', action='store_true', help='nn.SyncBatchNorm like configs/maggie_image.yaml:33 (N > 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--layers', action='store_true', help='print the per-shape conv kernel table to stderr')
     ap.add_argument('--video', action='store_true', help='maggie_video.yaml, T=3 (BASELINE configs[3]); not the headline line')
     return ap.parse_args()
 
@@ -138,6 +139,16 @@ def main():
                 d[0] += s.elapsed_time(e) * 1e-3
                 d[1] += work
                 d[2] += 1
+        if args.layers and rank == 0:
+            per = {}
+            for n in names:
+                for s_, e_, work, tag in rec[n]:
+                    k_ = (n,) + tuple(tag)
+                    d_ = per.setdefault(k_, [0.0, 0.0, 0])
+                    d_[0] += s_.elapsed_time(e_) * 1e-3; d_[1] += work; d_[2] += 1
+            sys.stderr.write('%-14s %-5s %4s %5s %6s %8s %6s %9s %8s\n' % ('entry', 'dtype', 'mode', 'Cout', 'K', 'M', 'calls', 'us/call', 'TFLOP/s'))
+            for k_, d_ in sorted(per.items(), key=lambda kv: -kv[1][0]):
+                sys.stderr.write('%-14s %-5s %4d %5d %6d %8d %6d %9.1f %8.1f\n' % (k_[0], k_[1], k_[2], k_[3], k_[4], k_[5], d_[2] // n_prof, 1e6 * d_[0] / d_[2], d_[1] / d_[0] / 1e12))
         dom = max(fam.items(), key=lambda kv: kv[1][0])
         tot_t = sum(v[0] for v in fam.values())
         tot_w = sum(v[1] for v in fam.values())

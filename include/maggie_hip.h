@@ -178,6 +178,27 @@ int mg_spectral_norm(const float* W, float* u, float* v, int A, int B, int taps,
 int mg_spectral_norm_bwd(const float* G, const float* W, const float* u, const float* v, int A, int B, int taps, int transposed,
                          int pad_in, float* work, float* dW, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Fused matting losses on fp32 planes [P,H,W] (maggie/network/arch/maggie.py:237-266,290-346; maggie/network/loss.py:67-191):
+ * weighted L1, Sobel-gradient L1, 3-level Laplacian-pyramid L1 -- forward sums and exact backward. `flags[p]` = the
+ * plane has any non-zero weight (planes with all-zero weights contribute nothing and are skipped).
+ * ------------------------------------------------------------------------------------------------------------- */
+int mg_plane_flags(const float* w, int P, int HW, int32_t* flags, void* stream);
+/* d = p - t; sums[0] += w|d|, sums[1] += |sobel(p*w) - sobel(t*w)|, sums[2] += w */
+int mg_loss_point_fwd(const float* p, const float* t, const float* w, const int32_t* flags, int P, int H, int W, float* d,
+                      float* sums, void* stream);
+/* out[P,h/2,w/2] = (gauss5 (reflect) * x)[::2, ::2] */
+int mg_pyr_down(const float* x, const int32_t* flags, int P, int h, int w, float* out, void* stream);
+/* L = x - 4*gauss5*zero_stuff(down); sums[0] += |L|*wl, sums[1] += wl, G = wl*sign(L); wl = w0[y<<lvl, x<<lvl] */
+int mg_pyr_lap_fwd(const float* x, const float* down, const float* w0, int lvl, int H0, int W0, const int32_t* flags, int P, int h,
+                   int w, float* G, float* sums, void* stream);
+/* r[P,h/2,w/2] = add - U^T(coef*q) ;  dd[P,h,w] = coef*q + D^T(r)   (adjoints of the pyramid's up / down operators) */
+int mg_pyr_upT(const float* q, const float* coef, const float* add, const int32_t* flags, int P, int h, int w, float* r, void* stream);
+int mg_pyr_downT(const float* r, const float* q, const float* coef, const int32_t* flags, int P, int h, int w, float* dd, void* stream);
+/* dp = coef_rec*w*sign(p-t) + dd + coef_grad*w*SobelAdjoint(...)  (A, B: [P,H,W] scratch) */
+int mg_loss_point_bwd(const float* p, const float* t, const float* w, const int32_t* flags, int P, int H, int W, const float* coef_rec,
+                      const float* coef_grad, const float* dd, float* A, float* B, float* dp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

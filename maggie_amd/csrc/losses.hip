@@ -1,0 +1,357 @@
+// Fused matting-loss kernels on fp32 alpha planes [P, H, W] (P = frames x instance slots):
+//   weighted L1, Sobel-gradient L1 and the 3-level Laplacian-pyramid L1 -- forward sums and analytic backward.
+// Reference: maggie/network/arch/maggie.py:237-266,290-346 (regression_loss / compute_loss) and
+// maggie/network/loss.py:67-118 (GradientLoss), :120-191 (LapLoss). There the pyramids are ~50 cuDNN/elementwise
+// launches per scale over all 10 instance slots; here
+//   * the Laplacian pyramid is linear, so lap(pred) - lap(target) = lap(pred - target): one pyramid of d = pred - target;
+//   * blur+decimate and zero-stuff+blur are evaluated directly at the surviving samples (reflect padding folded into the index);
+//   * planes whose weight map is identically zero (padded instance slots: 8 of 10 in the headline workload) contribute
+//     exactly 0 to every sum and are skipped through a per-plane flag;
+//   * the backward pass applies the exact adjoints (U^T, D^T with their reflect-border terms) instead of autograd graphs.
+// All kernels are HBM/L2-bound stencils; each block reduces its partial sums before one atomicAdd per sum.
+#include "common.h"
+#include "../../include/maggie_hip.h"
+
+namespace {
+
+constexpr int NT = 256;
+__device__ __constant__ float c_g1[5] = {1.f / 16.f, 4.f / 16.f, 6.f / 16.f, 4.f / 16.f, 1.f / 16.f};
+
+__device__ __forceinline__ int refl(int k, int n) { return k < 0 ? -k : (k >= n ? 2 * (n - 1) - k : k); }
+__device__ __forceinline__ int clampi(int k, int n) { return k < 0 ? 0 : (k >= n ? n - 1 : k); }
+
+__device__ __forceinline__ void block_add(float v, float* dst, float* sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < NT / 64; ++i) s += sh[i];
+        if (s != 0.f) atomicAdd(dst, s);
+    }
+    __syncthreads();
+}
+
+// flags[p] = any(w[p] > 0)
+__global__ __launch_bounds__(NT) void plane_flags_kernel(const float* __restrict__ w, int HW, int* __restrict__ flags) {
+    const int p = blockIdx.y;
+    const float* wp = w + (long)p * HW;
+    int any = 0;
+    for (int i = blockIdx.x * NT + threadIdx.x; i < HW; i += gridDim.x * NT) any |= (wp[i] > 0.f);
+    if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(&flags[p], 1);
+}
+
+__device__ __forceinline__ float sobel_mag(const float* __restrict__ a, const float* __restrict__ w, int y, int x, int H, int W, float& gx,
+                                           float& gy) {
+    float v[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            int yy = clampi(y + i - 1, H), xx = clampi(x + j - 1, W);
+            v[i][j] = a[yy * W + xx] * w[yy * W + xx];
+        }
+    gx = ((v[0][2] - v[0][0]) + 2.f * (v[1][2] - v[1][0]) + (v[2][2] - v[2][0])) * 0.125f;
+    gy = ((v[2][0] - v[0][0]) + 2.f * (v[2][1] - v[0][1]) + (v[2][2] - v[0][2])) * 0.125f;
+    return sqrtf(gx * gx + gy * gy + 1e-6f);
+}
+
+// d = p - t ; sums[0] += w|d| ; sums[1] += |sobel(p w) - sobel(t w)| ; sums[2] += w
+__global__ __launch_bounds__(NT) void point_fwd_kernel(const float* __restrict__ p, const float* __restrict__ t, const float* __restrict__ w,
+                                                       const int* __restrict__ flags, int H, int W, float* __restrict__ d,
+                                                       float* __restrict__ sums) {
+    __shared__ float sh[NT / 64];
+    const int pl = blockIdx.y;
+    if (!flags[pl]) return;
+    const long off = (long)pl * H * W;
+    const float *pp = p + off, *tp = t + off, *wp = w + off;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int i = blockIdx.x * NT + threadIdx.x; i < H * W; i += gridDim.x * NT) {
+        int y = i / W, x = i - y * W;
+        float dv = pp[i] - tp[i], wv = wp[i];
+        d[off + i] = dv;
+        s0 += wv * fabsf(dv);
+        s2 += wv;
+        float gx, gy;
+        float mp = sobel_mag(pp, wp, y, x, H, W, gx, gy);
+        float mt = sobel_mag(tp, wp, y, x, H, W, gx, gy);
+        s1 += fabsf(mp - mt);
+    }
+    block_add(s0, &sums[0], sh);
+    block_add(s1, &sums[1], sh);
+    block_add(s2, &sums[2], sh);
+}
+
+// out[P, h/2, w/2] = (gauss5 * x)(2y, 2x), reflect padding
+__global__ __launch_bounds__(NT) void pyr_down_kernel(const float* __restrict__ x, const int* __restrict__ flags, int h, int w,
+                                                      float* __restrict__ out) {
+    const int pl = blockIdx.y;
+    if (!flags[pl]) return;
+    const int hd = h >> 1, wd = w >> 1;
+    const float* xp = x + (long)pl * h * w;
+    for (int o = blockIdx.x * NT + threadIdx.x; o < hd * wd; o += gridDim.x * NT) {
+        int y = o / wd, xx = o - y * wd;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            int yy = refl(2 * y + i - 2, h);
+            float r = 0.f;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) r += c_g1[j] * xp[yy * w + refl(2 * xx + j - 2, w)];
+            acc += c_g1[i] * r;
+        }
+        out[(long)pl * hd * wd + o] = acc;
+    }
+}
+
+// L = x - 4 * gauss5 * zero_stuff(down);  sums[0] += |L| wl ; sums[1] += wl ; G = wl * sign(L);  wl = w0[(y << lvl), (x << lvl)]
+__global__ __launch_bounds__(NT) void pyr_lap_fwd_kernel(const float* __restrict__ x, const float* __restrict__ down, const float* __restrict__ w0,
+                                                         int lvl, int H0, int W0, const int* __restrict__ flags, int h, int w,
+                                                         float* __restrict__ G, float* __restrict__ sums) {
+    __shared__ float sh[NT / 64];
+    const int pl = blockIdx.y;
+    if (!flags[pl]) return;
+    const int hd = h >> 1, wd = w >> 1;
+    const float* xp = x + (long)pl * h * w;
+    const float* dp = down + (long)pl * hd * wd;
+    const float* wp = w0 + (long)pl * H0 * W0;
+    float s0 = 0.f, s1 = 0.f;
+    for (int o = blockIdx.x * NT + threadIdx.x; o < h * w; o += gridDim.x * NT) {
+        int y = o / w, xx = o - y * w;
+        float up = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            int yy = refl(y + i - 2, h);
+            if (yy & 1) continue;
+            float r = 0.f;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                int xs = refl(xx + j - 2, w);
+                if (!(xs & 1)) r += c_g1[j] * dp[(yy >> 1) * wd + (xs >> 1)];
+            }
+            up += c_g1[i] * r;
+        }
+        float L = xp[o] - 4.f * up;
+        float wl = wp[(long)(y << lvl) * W0 + (xx << lvl)];
+        s0 += fabsf(L) * wl;
+        s1 += wl;
+        G[(long)pl * h * w + o] = L > 0.f ? wl : (L < 0.f ? -wl : 0.f);
+    }
+    block_add(s0, &sums[0], sh);
+    block_add(s1, &sums[1], sh);
+}
+
+// r[P, h/2, w/2] = add - coef * U^T(q),  U = 4 * gauss5 * zero_stuff (reflect); q: [P, h, w]
+__global__ __launch_bounds__(NT) void pyr_upT_kernel(const float* __restrict__ q, const float* __restrict__ coef, const float* __restrict__ add,
+                                                     const int* __restrict__ flags, int h, int w, float* __restrict__ r) {
+    const int pl = blockIdx.y;
+    if (!flags[pl]) return;
+    const int hd = h >> 1, wd = w >> 1;
+    const float* qp = q + (long)pl * h * w;
+    const float c = coef[0];
+    for (int o = blockIdx.x * NT + threadIdx.x; o < hd * wd; o += gridDim.x * NT) {
+        int a = o / wd, b = o - a * wd;
+        float acc = 0.f;
+        // stuffed index 2a and its reflect pre-images: -2a (a == 1), 2(h-1) - 2a (== h when a == h/2 - 1)
+#pragma unroll
+        for (int sa = 0; sa < 3; ++sa) {
+            int ma = sa == 0 ? 2 * a : (sa == 1 ? -2 * a : 2 * (h - 1) - 2 * a);
+            if (sa == 1 && a != 1) continue;
+            if (sa == 2 && ma != h) continue;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                int y = ma - i + 2;
+                if (y < 0 || y >= h) continue;
+                float rowacc = 0.f;
+#pragma unroll
+                for (int sb = 0; sb < 3; ++sb) {
+                    int mb = sb == 0 ? 2 * b : (sb == 1 ? -2 * b : 2 * (w - 1) - 2 * b);
+                    if (sb == 1 && b != 1) continue;
+                    if (sb == 2 && mb != w) continue;
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        int x = mb - j + 2;
+                        if (x < 0 || x >= w) continue;
+                        rowacc += c_g1[j] * qp[y * w + x];
+                    }
+                }
+                acc += c_g1[i] * rowacc;
+            }
+        }
+        float base = add ? add[(long)pl * hd * wd + o] : 0.f;
+        r[(long)pl * hd * wd + o] = base - 4.f * c * acc;
+    }
+}
+
+// dd[P, h, w] = coef * q + D^T(r),  D = decimate2(gauss5 * . ) (reflect); r: [P, h/2, w/2]
+__global__ __launch_bounds__(NT) void pyr_downT_kernel(const float* __restrict__ r, const float* __restrict__ q, const float* __restrict__ coef,
+                                                       const int* __restrict__ flags, int h, int w, float* __restrict__ dd) {
+    const int pl = blockIdx.y;
+    if (!flags[pl]) return;
+    const int hd = h >> 1, wd = w >> 1;
+    const float* rp = r + (long)pl * hd * wd;
+    const float c = coef[0];
+    for (int o = blockIdx.x * NT + threadIdx.x; o < h * w; o += gridDim.x * NT) {
+        int Y = o / w, X = o - Y * w;
+        float acc = 0.f;
+#pragma unroll
+        for (int sa = 0; sa < 3; ++sa) {
+            int my = sa == 0 ? Y : (sa == 1 ? -Y : 2 * (h - 1) - Y);
+            if (sa == 1 && !(Y == 1 || Y == 2)) continue;
+            if (sa == 2 && !(Y == h - 2 || Y == h - 3)) continue;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                int ty = my - i + 2;
+                if (ty < 0 || (ty & 1)) continue;
+                int y = ty >> 1;
+                if (y >= hd) continue;
+                float rowacc = 0.f;
+#pragma unroll
+                for (int sb = 0; sb < 3; ++sb) {
+                    int mx = sb == 0 ? X : (sb == 1 ? -X : 2 * (w - 1) - X);
+                    if (sb == 1 && !(X == 1 || X == 2)) continue;
+                    if (sb == 2 && !(X == w - 2 || X == w - 3)) continue;
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) {
+                        int tx = mx - j + 2;
+                        if (tx < 0 || (tx & 1)) continue;
+                        int x = tx >> 1;
+                        if (x >= wd) continue;
+                        rowacc += c_g1[j] * rp[y * wd + x];
+                    }
+                }
+                acc += c_g1[i] * rowacc;
+            }
+        }
+        dd[(long)pl * h * w + o] = c * q[(long)pl * h * w + o] + acc;
+    }
+}
+
+// Sobel backward pass 1: A = s * gx / mag, B = s * gy / mag with s = sign(mag_p - mag_t)   (coef applied in pass 2)
+__global__ __launch_bounds__(NT) void sobel_bwd1_kernel(const float* __restrict__ p, const float* __restrict__ t, const float* __restrict__ w,
+                                                        const int* __restrict__ flags, int H, int W, float* __restrict__ A, float* __restrict__ B) {
+    const int pl = blockIdx.y;
+    if (!flags[pl]) return;
+    const long off = (long)pl * H * W;
+    const float *pp = p + off, *tp = t + off, *wp = w + off;
+    for (int i = blockIdx.x * NT + threadIdx.x; i < H * W; i += gridDim.x * NT) {
+        int y = i / W, x = i - y * W;
+        float gx, gy, tx, ty;
+        float mp = sobel_mag(pp, wp, y, x, H, W, gx, gy);
+        float mt = sobel_mag(tp, wp, y, x, H, W, tx, ty);
+        float s = mp > mt ? 1.f : (mp < mt ? -1.f : 0.f);
+        A[off + i] = s * gx / mp;
+        B[off + i] = s * gy / mp;
+    }
+}
+
+// dpred = coef_rec * w * sign(p - t) + dd_lap + coef_grad * w * SobelAdjoint(A, B)   (replicate padding adjoint)
+__global__ __launch_bounds__(NT) void point_bwd_kernel(const float* __restrict__ p, const float* __restrict__ t, const float* __restrict__ w,
+                                                       const int* __restrict__ flags, int H, int W, const float* __restrict__ coef_rec,
+                                                       const float* __restrict__ coef_grad, const float* __restrict__ dd,
+                                                       const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ dp) {
+    const int pl = blockIdx.y;
+    if (!flags[pl]) return;
+    const long off = (long)pl * H * W;
+    const float cr = coef_rec[0], cg = coef_grad[0];
+    const float kx[3][3] = {{-1.f, 0.f, 1.f}, {-2.f, 0.f, 2.f}, {-1.f, 0.f, 1.f}};
+    for (int idx = blockIdx.x * NT + threadIdx.x; idx < H * W; idx += gridDim.x * NT) {
+        int Y = idx / W, X = idx - Y * W;
+        float dv = p[off + idx] - t[off + idx];
+        float wv = w[off + idx];
+        float g = cr * wv * (dv > 0.f ? 1.f : (dv < 0.f ? -1.f : 0.f));
+        if (dd) g += dd[off + idx];
+        float acc = 0.f;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            int y = Y + dy;
+            if (y < 0 || y >= H) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                int x = X + dx;
+                if (x < 0 || x >= W) continue;
+                float a = A[off + y * W + x], b = B[off + y * W + x];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    if (clampi(y + i - 1, H) != Y) continue;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        if (clampi(x + j - 1, W) != X) continue;
+                        acc += kx[i][j] * a + kx[j][i] * b;
+                    }
+                }
+            }
+        }
+        dp[off + idx] = g + cg * wv * acc * 0.125f;
+    }
+}
+
+inline dim3 grid2(long per_plane, int P) {
+    long b = (per_plane + NT - 1) / NT;
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return dim3((unsigned)b, (unsigned)P);
+}
+
+}  // namespace
+
+extern "C" int mg_plane_flags(const float* w, int P, int HW, int32_t* flags, void* stream) {
+    if (P <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(flags, 0, (size_t)P * sizeof(int32_t), st);
+    if (e != hipSuccess) return (int)e;
+    dim3 g = grid2(HW, P);
+    if (g.x > 64) g.x = 64;
+    hipLaunchKernelGGL(plane_flags_kernel, g, dim3(NT), 0, st, w, HW, flags);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_loss_point_fwd(const float* p, const float* t, const float* w, const int32_t* flags, int P, int H, int W, float* d,
+                                 float* sums, void* stream) {
+    if (P <= 0) return 0;
+    hipLaunchKernelGGL(point_fwd_kernel, grid2((long)H * W, P), dim3(NT), 0, (hipStream_t)stream, p, t, w, flags, H, W, d, sums);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_pyr_down(const float* x, const int32_t* flags, int P, int h, int w, float* out, void* stream) {
+    if (P <= 0) return 0;
+    if ((h & 1) || (w & 1) || h < 4 || w < 4) return -2;
+    hipLaunchKernelGGL(pyr_down_kernel, grid2((long)(h / 2) * (w / 2), P), dim3(NT), 0, (hipStream_t)stream, x, flags, h, w, out);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_pyr_lap_fwd(const float* x, const float* down, const float* w0, int lvl, int H0, int W0, const int32_t* flags, int P, int h,
+                              int w, float* G, float* sums, void* stream) {
+    if (P <= 0) return 0;
+    hipLaunchKernelGGL(pyr_lap_fwd_kernel, grid2((long)h * w, P), dim3(NT), 0, (hipStream_t)stream, x, down, w0, lvl, H0, W0, flags, h, w, G, sums);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_pyr_upT(const float* q, const float* coef, const float* add, const int32_t* flags, int P, int h, int w, float* r, void* stream) {
+    if (P <= 0) return 0;
+    hipLaunchKernelGGL(pyr_upT_kernel, grid2((long)(h / 2) * (w / 2), P), dim3(NT), 0, (hipStream_t)stream, q, coef, add, flags, h, w, r);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_pyr_downT(const float* r, const float* q, const float* coef, const int32_t* flags, int P, int h, int w, float* dd, void* stream) {
+    if (P <= 0) return 0;
+    hipLaunchKernelGGL(pyr_downT_kernel, grid2((long)h * w, P), dim3(NT), 0, (hipStream_t)stream, r, q, coef, flags, h, w, dd);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_loss_point_bwd(const float* p, const float* t, const float* w, const int32_t* flags, int P, int H, int W, const float* coef_rec,
+                                 const float* coef_grad, const float* dd, float* A, float* B, float* dp, void* stream) {
+    if (P <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sobel_bwd1_kernel, grid2((long)H * W, P), dim3(NT), 0, st, p, t, w, flags, H, W, A, B);
+    hipLaunchKernelGGL(point_bwd_kernel, grid2((long)H * W, P), dim3(NT), 0, st, p, t, w, flags, H, W, coef_rec, coef_grad, dd, A, B, dp);
+    MG_CHECK_LAUNCH();
+    return 0;
+}

@@ -460,3 +460,81 @@ def unknown_bits(alpha, k_size=30, is_train=False, andmask=None):
         wd = torch.from_numpy(widths).to(a.device, non_blocking=True)
         return K.bits_dilate(bits, W_, widths=wd, andmask=andmask)
     return K.bits_dilate(bits, W_, width=k_size // 2, andmask=andmask)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# fused matting losses on fp32 planes
+# ----------------------------------------------------------------------------------------------------------------------
+
+class MattingLosses(torch.autograd.Function):
+    """(weighted L1, Laplacian-pyramid L1, Sobel-gradient L1) of pred vs target under `weight`, all (.., H, W) fp32 planes.
+    Returns a 3-vector; backward yields d/dpred only (target and weight are constants of the loss)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, weight):
+        H, W_ = pred.shape[-2:]
+        assert H % 8 == 0 and W_ % 8 == 0
+        p = pred.detach().float().contiguous()
+        t = target.detach().float().contiguous()
+        w = weight.detach().float().contiguous()
+        P = p.numel() // (H * W_)
+        dev = p.device
+        hipc, c_int = K.hip.call, K.c_int
+        ptr, st = K.hip.ptr, K.hip.stream
+        flags = torch.empty(P, dtype=torch.int32, device=dev)
+        hipc('mg_plane_flags', ptr(w), c_int(P), c_int(H * W_), ptr(flags), st())
+        sums = torch.zeros(9, dtype=torch.float32, device=dev)          # [l1, grad, w, lap0, w0, lap1, w1, lap2, w2]
+        d = torch.empty((P, H, W_), dtype=torch.float32, device=dev)
+        hipc('mg_loss_point_fwd', ptr(p), ptr(t), ptr(w), ptr(flags), c_int(P), c_int(H), c_int(W_), ptr(d), ptr(sums), st())
+        x, h, ww = d, H, W_
+        Gs = []
+        for lvl in range(3):
+            down = torch.empty((P, h // 2, ww // 2), dtype=torch.float32, device=dev)
+            hipc('mg_pyr_down', ptr(x), ptr(flags), c_int(P), c_int(h), c_int(ww), ptr(down), st())
+            G = torch.empty((P, h, ww), dtype=torch.float32, device=dev)
+            hipc('mg_pyr_lap_fwd', ptr(x), ptr(down), ptr(w), c_int(lvl), c_int(H), c_int(W_), ptr(flags), c_int(P), c_int(h), c_int(ww),
+                 ptr(G), ptr(sums[3 + 2 * lvl:]), st())
+            Gs.append(G)
+            x, h, ww = down, h // 2, ww // 2
+        rec = sums[0] / (sums[2] + 1e-8)
+        grad = sums[1] / (sums[2] + 1e-6)
+        lap = 3.0 * (sums[3] / (sums[4] + 1e-6) + sums[5] / (sums[6] + 1e-6) + sums[7] / (sums[8] + 1e-6))
+        ctx.save_for_backward(p, t, w, flags, sums, *Gs)
+        ctx.shape = pred.shape
+        return torch.stack([rec, lap, grad])
+
+    @staticmethod
+    def backward(ctx, g):
+        p, t, w, flags, sums, G0, G1, G2 = ctx.saved_tensors
+        P, H, W_ = G0.shape
+        dev = p.device
+        hipc, c_int = K.hip.call, K.c_int
+        ptr, st = K.hip.ptr, K.hip.stream
+        g = g.float()
+        coef = torch.stack([g[0] / (sums[2] + 1e-8), g[2] / (sums[2] + 1e-6), 3.0 * g[1] / (sums[4] + 1e-6),
+                            3.0 * g[1] / (sums[6] + 1e-6), 3.0 * g[1] / (sums[8] + 1e-6)]).contiguous()
+        c_rec, c_grad, c0, c1, c2 = [coef[i:i + 1] for i in range(5)]
+        new = lambda hh, ww: torch.empty((P, hh, ww), dtype=torch.float32, device=dev)
+        r2 = new(H // 8, W_ // 8)
+        hipc('mg_pyr_upT', ptr(G2), ptr(c2), None, ptr(flags), c_int(P), c_int(H // 4), c_int(W_ // 4), ptr(r2), st())
+        dd2 = new(H // 4, W_ // 4)
+        hipc('mg_pyr_downT', ptr(r2), ptr(G2), ptr(c2), ptr(flags), c_int(P), c_int(H // 4), c_int(W_ // 4), ptr(dd2), st())
+        r1 = new(H // 4, W_ // 4)
+        hipc('mg_pyr_upT', ptr(G1), ptr(c1), ptr(dd2), ptr(flags), c_int(P), c_int(H // 2), c_int(W_ // 2), ptr(r1), st())
+        dd1 = new(H // 2, W_ // 2)
+        hipc('mg_pyr_downT', ptr(r1), ptr(G1), ptr(c1), ptr(flags), c_int(P), c_int(H // 2), c_int(W_ // 2), ptr(dd1), st())
+        r0 = new(H // 2, W_ // 2)
+        hipc('mg_pyr_upT', ptr(G0), ptr(c0), ptr(dd1), ptr(flags), c_int(P), c_int(H), c_int(W_), ptr(r0), st())
+        dd0 = new(H, W_)
+        hipc('mg_pyr_downT', ptr(r0), ptr(G0), ptr(c0), ptr(flags), c_int(P), c_int(H), c_int(W_), ptr(dd0), st())
+        A, B = new(H, W_), new(H, W_)
+        dp = torch.zeros((P, H, W_), dtype=torch.float32, device=dev)
+        hipc('mg_loss_point_bwd', ptr(p), ptr(t), ptr(w), ptr(flags), c_int(P), c_int(H), c_int(W_), ptr(c_rec), ptr(c_grad), ptr(dd0),
+             ptr(A), ptr(B), ptr(dp), st())
+        return dp.view(ctx.shape), None, None
+
+
+def matting_losses(pred, target, weight):
+    """-> (rec, lap, grad) scalars."""
+    out = MattingLosses.apply(pred, target, weight.expand_as(pred) if weight.shape != pred.shape else weight)
+    return out[0], out[1], out[2]

@@ -189,12 +189,19 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             trans_gt = torch.cat([trans_gt, padding], dim=1)
         total_loss = 0
         lt = self.cfg.loss_alpha_type
+        fused = (a1 is not None and lt == 'l1' and a8.shape[-1] % 8 == 0 and a8.shape[-2] % 8 == 0)
+        if fused:
+            # one fused HIP pipeline per scale: weighted L1 + Laplacian-pyramid L1 + Sobel-gradient L1 (fwd sums + exact bwd)
+            r1, l1_, g1 = MF.matting_losses(a1, alphas, weight_os1)
+            r4, l4_, g4 = MF.matting_losses(a4, alphas, weight_os4)
+            r8, l8_, g8 = MF.matting_losses(a8, alphas, weight_os8)
         if self.loss_alpha_w > 0:
             ref_alpha_loss = 0
             if a1 is not None:
-                r1 = self.regression_loss(a1, alphas, loss_type=lt, weight=weight_os1)
-                r4 = self.regression_loss(a4, alphas, loss_type=lt, weight=weight_os4)
-                r8 = self.regression_loss(a8, alphas, loss_type=lt, weight=weight_os8)
+                if not fused:
+                    r1 = self.regression_loss(a1, alphas, loss_type=lt, weight=weight_os1)
+                    r4 = self.regression_loss(a4, alphas, loss_type=lt, weight=weight_os4)
+                    r8 = self.regression_loss(a8, alphas, loss_type=lt, weight=weight_os8)
                 ref_alpha_loss = ref_alpha_loss + r1 * 2 + r4 + r8
                 loss_dict['loss_rec_os1'], loss_dict['loss_rec_os4'], loss_dict['loss_rec_os8'] = r1, r4, r8
             loss_dict['loss_rec'] = ref_alpha_loss
@@ -204,10 +211,11 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             h, w = a8.shape[-2:]
             lap_loss = 0
             if a1 is not None:
-                v = lambda t: t.reshape(-1, 1, h, w)
-                l1_ = self.lap_loss(v(a1), v(alphas), v(weight_os1))
-                l4_ = self.lap_loss(v(a4), v(alphas), v(weight_os4))
-                l8_ = self.lap_loss(v(a8), v(alphas), v(weight_os8))
+                if not fused:
+                    v = lambda t: t.reshape(-1, 1, h, w)
+                    l1_ = self.lap_loss(v(a1), v(alphas), v(weight_os1))
+                    l4_ = self.lap_loss(v(a4), v(alphas), v(weight_os4))
+                    l8_ = self.lap_loss(v(a8), v(alphas), v(weight_os8))
                 loss_dict['loss_lap_os1'], loss_dict['loss_lap_os4'], loss_dict['loss_lap_os8'] = l1_, l4_, l8_
                 lap_loss = lap_loss + l1_ * 2 + l4_ + l8_
             loss_dict['loss_lap'] = lap_loss
@@ -215,9 +223,10 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         if self.loss_alpha_grad_w > 0:
             grad_loss = 0
             if a1 is not None:
-                g1 = self.grad_loss(a1, alphas, weight_os1)
-                g4 = self.grad_loss(a4, alphas, weight_os4)
-                g8 = self.grad_loss(a8, alphas, weight_os8)
+                if not fused:
+                    g1 = self.grad_loss(a1, alphas, weight_os1)
+                    g4 = self.grad_loss(a4, alphas, weight_os4)
+                    g8 = self.grad_loss(a8, alphas, weight_os8)
                 grad_loss = grad_loss + g1 * 2 + g4 + g8
                 loss_dict['loss_grad_os1'], loss_dict['loss_grad_os4'], loss_dict['loss_grad_os8'] = g1, g4, g8
             loss_dict['loss_grad'] = grad_loss

@@ -256,3 +256,33 @@ def test_gather_tables_real_roi_regression():
         rr, kk = np.nonzero(ref_inv >= 0)
         chk[ref_inv[rr, kk], kk] = rr
         assert np.array_equal(down, chk)
+
+
+@pytest.mark.parametrize('hw', [(64, 64), (40, 72)])
+def test_fused_matting_losses_forward_backward(hw):
+    """Fused L1 + Laplacian-pyramid + Sobel losses (C ABI) against the oracle's torch-CPU restatement incl. gradients."""
+    from maggie_amd import functional as MF
+    from oracle import refmodel
+    dev = _dev()
+    H, W = hw
+    rs = np.random.RandomState(H)
+    P = (2, 5)
+    pred = torch.from_numpy(rs.uniform(size=P + (H, W)).astype(np.float32))
+    tgt = torch.from_numpy(rs.uniform(size=P + (H, W)).astype(np.float32))
+    wgt = torch.from_numpy((rs.uniform(size=P + (H, W)) > 0.4).astype(np.float32))
+    wgt[:, 1] = 0
+    wgt[:, 3] *= 2                         # os8-style weights in {0, 1, 2}
+    wgt[0, 4, :3, :] = 1
+    wgt[0, 4, :, -3:] = 1                  # make sure borders are exercised
+    pr = pred.clone().requires_grad_(True)
+    v = lambda t: t.reshape(-1, 1, H, W)
+    ref = torch.stack([refmodel.regression_loss(pr, tgt, wgt), refmodel.lap_loss(v(pr), v(tgt), v(wgt)), refmodel.grad_loss(pr, tgt, wgt)])
+    coefs = torch.tensor([1.3, 0.7, 2.1])
+    (ref * coefs).sum().backward()
+    pd = pred.clone().to(dev).requires_grad_(True)
+    out = torch.stack(MF.matting_losses(pd, tgt.to(dev), wgt.to(dev)))
+    assert torch.allclose(out.cpu(), ref.detach(), rtol=2e-5, atol=1e-6), (out.cpu(), ref)
+    (out * coefs.to(dev)).sum().backward()
+    err = (pd.grad.cpu() - pr.grad).abs().max().item()
+    assert err <= 2e-3 * pr.grad.abs().max().item(), (err, pr.grad.abs().max().item())
+    assert float(pd.grad[:, 1].abs().max()) == 0.0
