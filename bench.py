@@ -53,8 +53,12 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     import torch.distributed as dist
-    if world > 1:
+    force_ddp = os.environ.get('MAGGIE_FORCE_DDP') == '1'          # exercise the RCCL/DDP path on a single GPU (smoke test)
+    if world > 1 or force_ddp:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29517')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -72,14 +76,17 @@ def main():
     synth.fill_state_dict_(sd, 1234)
     model.load_state_dict(sd)
     model.to(dev).train()
-    if world > 1 and args.sync_bn:
+    if (world > 1 or force_ddp) and args.sync_bn:
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     net = model
-    if world > 1:
+    if world > 1 or force_ddp:
         from torch.nn.parallel import DistributedDataParallel as DDP
         net = DDP(model, device_ids=[local_rank], find_unused_parameters=True, gradient_as_bucket_view=True)
     params = [p for p in model.parameters() if p.requires_grad]
-    opt = torch.optim.AdamW(params, lr=1.5e-4, betas=(0.9, 0.999), weight_decay=0.01)      # maggie_image.yaml:90-98
+    # AdamW as maggie_image.yaml:90-98; lr = max_lr / 25 = the first value of the reference's OneCycleLR schedule
+    # (engine/optim.py:117-118, default div_factor) -- a full max_lr step on random-init weights makes the detail region
+    # (and therefore the sparse workload) drift wildly between the few timed steps.
+    opt = torch.optim.AdamW(params, lr=1.5e-4 / 25, betas=(0.9, 0.999), weight_decay=0.01)
 
     batch = synth.synthetic_batch(b, n_f, args.instances, args.size, args.size, seed=1234 + rank, train=True, it=args.iter, max_inst=10)
     batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
@@ -99,10 +106,11 @@ def main():
         opt.step()
         stats['active_px'] = out['detail_mask']
         stats['loss'] = loss['total']
+        stats.setdefault('active_hist', []).append(out['detail_mask'].float().mean() * 5.0)      # 2 of 10 slots are real
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_ddp:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -181,11 +189,11 @@ def main():
             'config': {'workload': 'maggie_%s.yaml train step: %dx%d, %d instances (10 slots), batch %d frames/GPU x %d frame(s), iter=%d, '
                                    'fwd+loss+bwd+clip+AdamW' % (kind, args.size, args.size, args.instances, b, n_f, args.iter),
                        'global_batch': b * world, 'parallelism': 'dp%d' % world, 'sync_bn': bool(args.sync_bn and world > 1),
-                       'active_ratio': round(active_ratio, 4), 'active_pixels_per_step_per_gpu': int(active_px), 'loss_total': round(loss_val, 4)},
+                       'active_ratio': round(active_ratio, 4), 'active_ratio_per_timed_step': [round(float(v), 3) for v in stats['active_hist'][-args.steps - 2:-2]] if not args.no_roofline else None, 'active_pixels_per_step_per_gpu': int(active_px), 'loss_total': round(loss_val, 4)},
             'roofline': roofline, 'cpu_baseline': cpu_baseline,
         }
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or force_ddp:
         dist.destroy_process_group()
 
 

@@ -27,6 +27,8 @@ extern "C" {
 #define MG_ACT_RELU 1
 #define MG_ACT_LRELU 2
 
+#define MG_STAT_REPLICAS 32 /* BatchNorm statistic accumulators are [MG_STAT_REPLICAS][2*C]: atomics of different blocks spread over replicas */
+
 #define MG_MODE_CONV 0   /* src(m,tap) = (n, ho*stride - pad + ky*dil, wo*stride - pad + kx*dil)                 */
 #define MG_MODE_TCONV 1  /* src(m,tap) = (n, (ho + pad - ky*dil)/stride, ...) when divisible: dgrad / ConvTranspose */
 #define MG_MODE_GATHER 2 /* src(m,tap) = nbr[m*taps + tap]  (-1 = no neighbour): sparse convolutions               */
@@ -52,7 +54,7 @@ typedef struct mg_conv_params {
     const float* shift;  /* [Cout] or NULL (bias / folded BN shift)                               */
     const void* res;     /* residual, [M or M/4, ldr], same dtype, or NULL                        */
     const void* res2;    /* post-activation residual, [M, ldr2] or NULL                           */
-    float* stats;        /* [2*Cout] fp32 or NULL                                                 */
+    float* stats;        /* [MG_STAT_REPLICAS][2*Cout] fp32 (pre-zeroed) or NULL                  */
     int32_t dtype, mode;
     int32_t N, Hin, Win, Cin, Hout, Wout, Cout, R, S, stride, pad, dil;
     int32_t M;           /* output rows (N*Hout*Wout, or active sites)                            */
@@ -96,13 +98,13 @@ typedef struct mg_rowwise_params {
     float slope, count;
 } mg_rowwise_params;
 
-/* stats[c] += sum_m x[m,c], stats[C+c] += sum_m x[m,c]^2 (fp32, pre-zeroed) */
+/* stats[rep][c] += sum_m x[m,c], stats[rep][C+c] += sum_m x[m,c]^2 (fp32 [MG_STAT_REPLICAS][2C], pre-zeroed) */
 int mg_colstats(const void* x, int dtype, int M, int C, int ld, float* stats, void* stream);
-/* batch statistics -> scale/shift/mean/invstd, running-stat update with momentum and unbiased variance */
+/* batch statistics (`nrep` replicas of [2C], summed here) -> scale/shift/mean/invstd, running-stat update (momentum, unbiased var) */
 /* exact two-pass variant for small M: stats[0:C] = sum, stats[C:2C] = sum (x - mean)^2 (stats is overwritten) */
 int mg_colstats_centered(const void* x, int dtype, int M, int C, int ld, float* stats, void* stream);
 /* `centered` != 0: stats[C:2C] holds the centred second moment (mg_colstats_centered) instead of sum x^2 */
-int mg_bn_finalize(const float* stats, const float* count_ptr, float count, int C, int centered, const float* gamma, const float* beta,
+int mg_bn_finalize(const float* stats, int nrep, const float* count_ptr, float count, int C, int centered, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
                    float* mean_out, float* invstd_out, void* stream);
 /* eval mode: fold running statistics into scale/shift */

@@ -19,26 +19,24 @@
 
 namespace {
 
-constexpr int BM = 128;
 constexpr int ROWB = 80;   // padded LDS row pitch in bytes (64 B of K + 16 B pad)
 
-template <int BN> struct TileCfg;
-template <> struct TileCfg<128> { static constexpr int WAVES_M = 2, WAVES_N = 2; };
-template <> struct TileCfg<64>  { static constexpr int WAVES_M = 2, WAVES_N = 2; };
-template <> struct TileCfg<32>  { static constexpr int WAVES_M = 4, WAVES_N = 1; };
-template <> struct TileCfg<16>  { static constexpr int WAVES_M = 4, WAVES_N = 1; };
+// wave arrangement per (BM, BN) block tile; every wave tile is a multiple of 16 x 16
+template <int BM, int BN> struct TileCfg { static constexpr int WAVES_M = (BN >= 64 ? 2 : 4), WAVES_N = (BN >= 64 ? 2 : 1); };
 
-template <int BN> constexpr int stage_bytes() { return 2 * (BM + BN) * ROWB; }
-template <int BN> constexpr int ctile_bytes() { return (BM / (BN == 128 ? 2 : 1)) * (BN + 4) * 4 + 2 * BN * 4; }
-template <int BN> constexpr int lds_bytes() { return stage_bytes<BN>() > ctile_bytes<BN>() ? stage_bytes<BN>() : ctile_bytes<BN>(); }
+template <int BM, int BN> constexpr int ep_passes() { return (BM * (BN + 4) * 4 > 40960) ? 2 : 1; }
+template <int BM, int BN> constexpr int stage_bytes() { return 2 * (BM + BN) * ROWB; }
+template <int BM, int BN> constexpr int ctile_bytes() { return (BM / ep_passes<BM, BN>()) * (BN + 4) * 4 + 2 * BN * 4; }
+template <int BM, int BN> constexpr int lds_bytes() { return stage_bytes<BM, BN>() > ctile_bytes<BM, BN>() ? stage_bytes<BM, BN>() : ctile_bytes<BM, BN>(); }
 
 struct RowCoord { int n, ho, wo; bool ok; };
 
-template <typename T, int BN, int MODE>
+template <typename T, int BM, int BN, int MODE>
 __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE, EPS = TR::EPS;
-    constexpr int WAVES_M = TileCfg<BN>::WAVES_M, WAVES_N = TileCfg<BN>::WAVES_N;
+    constexpr int WAVES_M = TileCfg<BM, BN>::WAVES_M, WAVES_N = TileCfg<BM, BN>::WAVES_N;
+    constexpr int A_ROWS = BM / 64;                 // A rows staged per thread
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, FM = WM / 16, FN = WN / 16;
     constexpr int B_ITERS = (BN * 4 + 255) / 256;
 
@@ -57,9 +55,9 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
 
     // ---- per-thread A rows (2 rows, fixed chunk column) ----
     const int a_c = t & 3;
-    RowCoord rc[2];
+    RowCoord rc[A_ROWS];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < A_ROWS; ++i) {
         int m = m0 + (t >> 2) + i * 64;
         rc[i].ok = m < p.M;
         if (MODE != MG_MODE_GATHER) {
@@ -77,13 +75,13 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
     int a_tap = a_k / p.Cin;
     int a_ci = a_k - a_tap * p.Cin;
 
-    uint4 ra[2], rb[B_ITERS];
+    uint4 ra[A_ROWS], rb[B_ITERS];
 
     auto load_slab = [&](int s) {
         // A operand
         int ky = a_tap / p.S, kx = a_tap - ky * p.S;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < A_ROWS; ++i) {
             long src = -1;
             if (rc[i].ok && a_tap < taps) {
                 if (MODE == MG_MODE_CONV) {
@@ -121,7 +119,7 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
     };
     auto store_slab = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < A_ROWS; ++i)
             *(uint4*)(sA + buf * BM * ROWB + ((t >> 2) + i * 64) * ROWB + a_c * 16) = ra[i];
 #pragma unroll
         for (int i = 0; i < B_ITERS; ++i) {
@@ -169,8 +167,8 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
     }
 
     // ---------------- epilogue: accumulators -> fp32 LDS tile -> vectorised global stores ----------------
-    // (BN == 128 runs two 64-row passes so the fp32 tile fits beside nothing larger than the staging buffers)
-    constexpr int EP = (BN == 128) ? 2 : 1;
+    // (large tiles run two half-height passes so the fp32 tile stays within the staging buffers' LDS footprint)
+    constexpr int EP = ep_passes<BM, BN>();
     constexpr int PR = BM / EP;                       // tile rows per pass
     constexpr int LDC = BN + 4;
     float* sC = (float*)smem;                         // [PR][LDC]
@@ -263,20 +261,21 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
         }
         __syncthreads();
         if (t < BN && n0 + t < p.Cout) {
-            atomicAdd(&p.stats[n0 + t], sStat[t]);
-            atomicAdd(&p.stats[p.Cout + n0 + t], sStat[BN + t]);
+            float* st = p.stats + (size_t)(blockIdx.x & (MG_STAT_REPLICAS - 1)) * 2 * p.Cout;   // spread same-address atomics
+            atomicAdd(&st[n0 + t], sStat[t]);
+            atomicAdd(&st[p.Cout + n0 + t], sStat[BN + t]);
         }
     }
 }
 
-template <typename T, int BN>
+template <typename T, int BM, int BN>
 int launch_fprop(const mg_conv_params& p, hipStream_t st) {
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN);
-    size_t lds = lds_bytes<BN>();
+    size_t lds = lds_bytes<BM, BN>();
     switch (p.mode) {
-        case MG_MODE_CONV: hipLaunchKernelGGL((igemm_fprop_kernel<T, BN, MG_MODE_CONV>), grid, dim3(256), lds, st, p); break;
-        case MG_MODE_TCONV: hipLaunchKernelGGL((igemm_fprop_kernel<T, BN, MG_MODE_TCONV>), grid, dim3(256), lds, st, p); break;
-        case MG_MODE_GATHER: hipLaunchKernelGGL((igemm_fprop_kernel<T, BN, MG_MODE_GATHER>), grid, dim3(256), lds, st, p); break;
+        case MG_MODE_CONV: hipLaunchKernelGGL((igemm_fprop_kernel<T, BM, BN, MG_MODE_CONV>), grid, dim3(256), lds, st, p); break;
+        case MG_MODE_TCONV: hipLaunchKernelGGL((igemm_fprop_kernel<T, BM, BN, MG_MODE_TCONV>), grid, dim3(256), lds, st, p); break;
+        case MG_MODE_GATHER: hipLaunchKernelGGL((igemm_fprop_kernel<T, BM, BN, MG_MODE_GATHER>), grid, dim3(256), lds, st, p); break;
         default: return -2;
     }
     MG_CHECK_LAUNCH();
@@ -285,10 +284,19 @@ int launch_fprop(const mg_conv_params& p, hipStream_t st) {
 
 template <typename T>
 int dispatch_fprop(const mg_conv_params& p, hipStream_t st) {
-    if (p.Cout > 64) return launch_fprop<T, 128>(p, st);
-    if (p.Cout > 32) return launch_fprop<T, 64>(p, st);
-    if (p.Cout > 16) return launch_fprop<T, 32>(p, st);
-    return launch_fprop<T, 16>(p, st);
+    // largest tile that still yields >= ~1 block per CU (256 CUs); small-M / wide-N layers drop to 64-row tiles
+    auto blocks = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn); };
+    if (p.Cout > 64) {
+        if (blocks(128, 128) >= 256) return launch_fprop<T, 128, 128>(p, st);
+        if (blocks(128, 64) >= 256) return launch_fprop<T, 128, 64>(p, st);
+        return launch_fprop<T, 64, 64>(p, st);
+    }
+    if (p.Cout > 32) {
+        if (blocks(128, 64) >= 256) return launch_fprop<T, 128, 64>(p, st);
+        return launch_fprop<T, 64, 64>(p, st);
+    }
+    if (p.Cout > 16) return launch_fprop<T, 128, 32>(p, st);
+    return launch_fprop<T, 128, 16>(p, st);
 }
 
 }  // namespace
@@ -496,7 +504,7 @@ int launch_wgrad(const mg_conv_params& p, hipStream_t st) {
     const int taps = p.R * p.S;
     const int nci = (p.Cin + TCI - 1) / TCI, nco = (p.Cout + TCO - 1) / TCO;
     const long tiles = (long)taps * nci * nco;
-    long want = (2048 + tiles - 1) / tiles;                       // aim at ~2048 blocks
+    long want = (512 + tiles - 1) / tiles;                        // ~2 blocks per CU: each extra row split costs a full tile of global atomics
     long max_splits = (p.M + KSTEP - 1) / KSTEP;
     long splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
     int rpb = (int)((p.M + splits - 1) / splits);

@@ -17,7 +17,7 @@ constexpr int NT = 256;
 // ---------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(NT) void colstats_kernel(const T* __restrict__ x, int M, int C, int ld, float* __restrict__ stats,
-                                                      int rows_per_block) {
+                                                      int rows_per_block, int nrep) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
     const int cpr = C / CE;                       // chunks per row (C % CE == 0)
@@ -46,7 +46,8 @@ __global__ __launch_bounds__(NT) void colstats_kernel(const T* __restrict__ x, i
         }
     }
     __syncthreads();
-    for (int i = t; i < 2 * C; i += NT) atomicAdd(&stats[i], sred[i]);
+    float* st = stats + (size_t)(blockIdx.x & (nrep - 1)) * 2 * C;
+    for (int i = t; i < 2 * C; i += NT) atomicAdd(&st[i], sred[i]);
 }
 
 // second pass of the exact two-pass variance: stats[C+c] += sum_m (x[m,c] - stats[c]/M)^2   (stats[0:C] = column sums)
@@ -87,15 +88,17 @@ __global__ __launch_bounds__(NT) void colstats_centered_kernel(const T* __restri
 // ---------------------------------------------------------------------------------------------------
 // finalize: batch statistics -> (scale, shift, mean, invstd) + running-stat update (momentum, unbiased var)
 // ---------------------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, const float* __restrict__ count_ptr, float count, int C, int centered,
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int nrep, const float* __restrict__ count_ptr, float count, int C, int centered,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
                                    float* running_var, float momentum, float eps, float* __restrict__ scale,
                                    float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ invstd_out) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float n = count_ptr ? *count_ptr : count;
-    float mean = stats[c] / n;
-    float var = centered ? stats[C + c] / n : stats[C + c] / n - mean * mean;
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = 0; r < nrep; ++r) { s1 += stats[(size_t)r * 2 * C + c]; s2 += stats[(size_t)r * 2 * C + C + c]; }
+    float mean = s1 / n;
+    float var = centered ? s2 / n : s2 / n - mean * mean;
     var = var > 0.f ? var : 0.f;
     float invstd = rsqrtf(var + eps);
     float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -305,8 +308,8 @@ extern "C" int mg_colstats(const void* x, int dtype, int M, int C, int ld, float
     int rpb = (M + blocks - 1) / blocks;
     blocks = (M + rpb - 1) / rpb;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MG_BF16) hipLaunchKernelGGL(colstats_kernel<bf16raw>, dim3(blocks), dim3(NT), 2 * C * 4, st, (const bf16raw*)x, M, C, ld, stats, rpb);
-    else hipLaunchKernelGGL(colstats_kernel<float>, dim3(blocks), dim3(NT), 2 * C * 4, st, (const float*)x, M, C, ld, stats, rpb);
+    if (dtype == MG_BF16) hipLaunchKernelGGL(colstats_kernel<bf16raw>, dim3(blocks), dim3(NT), 2 * C * 4, st, (const bf16raw*)x, M, C, ld, stats, rpb, MG_STAT_REPLICAS);
+    else hipLaunchKernelGGL(colstats_kernel<float>, dim3(blocks), dim3(NT), 2 * C * 4, st, (const float*)x, M, C, ld, stats, rpb, MG_STAT_REPLICAS);
     MG_CHECK_LAUNCH();
     return 0;
 }
@@ -322,11 +325,11 @@ extern "C" int mg_colstats_centered(const void* x, int dtype, int M, int C, int 
     hipError_t e = hipMemsetAsync(stats, 0, (size_t)2 * C * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
     if (dtype == MG_BF16) {
-        hipLaunchKernelGGL(colstats_kernel<bf16raw>, dim3(blocks), dim3(NT), 2 * C * 4, st, (const bf16raw*)x, M, C, ld, stats, rpb);
+        hipLaunchKernelGGL(colstats_kernel<bf16raw>, dim3(blocks), dim3(NT), 2 * C * 4, st, (const bf16raw*)x, M, C, ld, stats, rpb, 1);
         e = hipMemsetAsync(stats + C, 0, (size_t)C * sizeof(float), st);
         hipLaunchKernelGGL(colstats_centered_kernel<bf16raw>, dim3(blocks), dim3(NT), C * 4, st, (const bf16raw*)x, M, C, ld, stats, rpb);
     } else {
-        hipLaunchKernelGGL(colstats_kernel<float>, dim3(blocks), dim3(NT), 2 * C * 4, st, (const float*)x, M, C, ld, stats, rpb);
+        hipLaunchKernelGGL(colstats_kernel<float>, dim3(blocks), dim3(NT), 2 * C * 4, st, (const float*)x, M, C, ld, stats, rpb, 1);
         e = hipMemsetAsync(stats + C, 0, (size_t)C * sizeof(float), st);
         hipLaunchKernelGGL(colstats_centered_kernel<float>, dim3(blocks), dim3(NT), C * 4, st, (const float*)x, M, C, ld, stats, rpb);
     }
@@ -335,10 +338,10 @@ extern "C" int mg_colstats_centered(const void* x, int dtype, int M, int C, int 
     return 0;
 }
 
-extern "C" int mg_bn_finalize(const float* stats, const float* count_ptr, float count, int C, int centered, const float* gamma, const float* beta,
+extern "C" int mg_bn_finalize(const float* stats, int nrep, const float* count_ptr, float count, int C, int centered, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
                               float* mean_out, float* invstd_out, void* stream) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, count_ptr, count, C, centered, gamma,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, nrep, count_ptr, count, C, centered, gamma,
                        beta, running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out);
     MG_CHECK_LAUNCH();
     return 0;

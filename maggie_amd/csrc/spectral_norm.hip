@@ -84,8 +84,11 @@ __global__ __launch_bounds__(NT) void sn_bwd_dot_kernel(const float* __restrict_
         int co = transposed ? b : a, ci = transposed ? a : b;
         acc += G[((long)co * taps + tap) * pad_in + ci] * W[e];
     }
+    __shared__ float sh[NT / 64];
     acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&scratch[2], acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&scratch[2], sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
 __global__ __launch_bounds__(NT) void sn_bwd_apply_kernel(const float* __restrict__ G, const float* __restrict__ u, const float* __restrict__ v,
@@ -143,7 +146,8 @@ extern "C" int mg_spectral_norm_bwd(const float* G, const float* W, const float*
     hipError_t e = hipMemsetAsync(scratch + 2, 0, sizeof(float), st);
     if (e != hipSuccess) return (int)e;
     long total = (long)A * B * taps;
-    hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(grid_for(total)), dim3(NT), 0, st, G, W, A, B, taps, transposed, pad_in, scratch);
+    int dot_blocks = grid_for(total / 8); if (dot_blocks > 256) dot_blocks = 256;
+    hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(dot_blocks), dim3(NT), 0, st, G, W, A, B, taps, transposed, pad_in, scratch);
     hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(grid_for(total)), dim3(NT), 0, st, G, u, v, scratch, A, B, taps, transposed, pad_in, dW);
     MG_CHECK_LAUNCH();
     return 0;

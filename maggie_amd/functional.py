@@ -184,7 +184,8 @@ class BNAct(torch.autograd.Function):
             elif stats is None:
                 stats = K.colstats(x2)
             if group is not None:
-                pack = torch.cat([stats[:2 * C], torch.full((1,), float(M), device=x.device)])
+                flat = stats.sum(0) if stats.dim() == 2 else stats
+                pack = torch.cat([flat[:2 * C], torch.full((1,), float(M), device=x.device)])
                 dist.all_reduce(pack, group=group)
                 stats, cnt_t = pack[:2 * C], pack[2 * C:]
             rm = running_mean if running_mean.numel() == C else None
@@ -246,7 +247,7 @@ def batch_norm_act(x, bn, act=ACT_NONE, res=None, stats=None, res_mode=1, mask_x
 
 
 def new_stats(channels, device):
-    return torch.zeros(2 * channels, dtype=torch.float32, device=device)
+    return torch.zeros((K.STAT_REPLICAS, 2 * channels), dtype=torch.float32, device=device)
 
 
 def conv_bn_act(x, w, bn, act=ACT_NONE, R=3, S=3, stride=1, pad=1, dil=1, transposed=False, res=None, res_mode=1, res2=None,

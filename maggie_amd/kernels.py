@@ -65,7 +65,7 @@ def conv_fprop(x, w, *, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=None, Wout=None,
     if res2 is not None:
         assert res2.dtype == x.dtype
     if stats is not None:
-        assert stats.dtype == torch.float32 and stats.numel() >= 2 * Cout
+        assert stats.dtype == torch.float32 and stats.numel() >= STAT_REPLICAS * 2 * Cout
     for v in (scale, shift):
         if v is not None:
             assert v.dtype == torch.float32 and v.numel() >= Cout
@@ -101,11 +101,14 @@ def conv_wgrad(x, dy, *, cout, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=1, Wout=1
 from .hip import RowwiseParams, c_int, c_float, c_long  # noqa: E402
 
 
+STAT_REPLICAS = 32
+
+
 def colstats(x, stats=None):
-    """stats[2C] (fp32) += column sum / sum of squares of x (M, C)."""
+    """stats[STAT_REPLICAS][2C] (fp32) += column sum / sum of squares of x (M, C), spread over replicas."""
     M, C = x.shape[0], x.shape[-1]
     if stats is None:
-        stats = torch.zeros(2 * C, dtype=torch.float32, device=x.device)
+        stats = torch.zeros((STAT_REPLICAS, 2 * C), dtype=torch.float32, device=x.device)
     hip.need_cuda(x, stats)
     hip.call('mg_colstats', hip.ptr(x), c_int(hip.dtype_code(x)), c_int(M), c_int(C), c_int(_ld(x)), hip.ptr(stats), hip.stream())
     return stats
@@ -122,10 +125,11 @@ def colstats_centered(x):
 
 def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum, eps, count_ptr=None, centered=False):
     """-> scale, shift, mean, invstd (each fp32 [C]); updates the running statistics in place when given."""
-    C = stats.numel() // 2
+    nrep = stats.shape[0] if stats.dim() == 2 else 1
+    C = stats.shape[-1] // 2
     out = torch.empty((4, C), dtype=torch.float32, device=stats.device)
     hip.need_cuda(stats, gamma, beta, running_mean, running_var)
-    hip.call('mg_bn_finalize', hip.ptr(stats), hip.ptr(count_ptr), c_float(float(count)), c_int(C), c_int(int(centered)), hip.ptr(gamma), hip.ptr(beta),
+    hip.call('mg_bn_finalize', hip.ptr(stats), c_int(nrep), hip.ptr(count_ptr), c_float(float(count)), c_int(C), c_int(int(centered)), hip.ptr(gamma), hip.ptr(beta),
              hip.ptr(running_mean), hip.ptr(running_var), c_float(momentum), c_float(eps), hip.ptr(out[0]), hip.ptr(out[1]),
              hip.ptr(out[2]), hip.ptr(out[3]), hip.stream())
     return out[0], out[1], out[2], out[3]

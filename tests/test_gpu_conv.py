@@ -97,7 +97,7 @@ def test_conv_epilogue_and_stats(dtype):
     shift = torch.from_numpy(rs.normal(size=Cout).astype(np.float32))
     y_ref = F.conv2d(x, w, None, 1, 1) * scale[None, :, None, None] + shift[None, :, None, None]
     y_ref = F.leaky_relu(y_ref + F.interpolate(res, scale_factor=2, mode='nearest'), 0.2) + res2
-    stats = torch.zeros(2 * Cout, device=dev)
+    stats = torch.zeros((K.STAT_REPLICAS, 2 * Cout), device=dev)
     big = torch.zeros((N * H * W, 2 * Cout), device=dev, dtype=dtype)
     K.conv_fprop(_nhwc(x).to(dev, dtype), _krsc(w).to(dev, dtype), N=N, Hin=H, Win=W, R=3, S=3, pad=1,
                  scale=scale.to(dev), shift=shift.to(dev), res=_nhwc(res).to(dev, dtype), res_mode=2,
@@ -105,7 +105,7 @@ def test_conv_epilogue_and_stats(dtype):
     y = big[:, Cout:].float().cpu().reshape(N, H, W, Cout).permute(0, 3, 1, 2)
     assert big[:, :Cout].abs().max().item() == 0
     assert (y - y_ref).abs().max().item() <= _tol(dtype) * y_ref.abs().max().item()
-    s = stats.cpu()
+    s = stats.sum(0).cpu()
     assert torch.allclose(s[:Cout], y.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
     assert torch.allclose(s[Cout:], (y * y).sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
 

@@ -66,7 +66,6 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dp, f)).read()
                 if f == 'smoke.py':
                     continue            # smoke() is the checker entry allowed to call the oracle
-                assert 'oracle' not in src.replace('"""', '').split('import')[0] or True
                 assert not re.search(r'^\s*(from|import)\s+oracle', src, re.M), os.path.join(dp, f)
 
 
