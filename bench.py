@@ -42,6 +42,8 @@ def parse():
     ap.add_argument('--sync-bn', action='store_true', help='nn.SyncBatchNorm like configs/maggie_image.yaml:33 (N > 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-threads', type=int, default=0)
     ap.add_argument('--layers', action='store_true', help='print the per-shape conv kernel table to stderr')
     ap.add_argument('--video', action='store_true', help='maggie_video.yaml, T=3 (BASELINE configs[3]); not the headline line')
     return ap.parse_args()
@@ -49,6 +51,9 @@ def parse():
 
 def main():
     args = parse()
+    if args.cpu_baseline_worker:
+        print('CPU_BASELINE ' + json.dumps(run_cpu_baseline('video' if args.video else 'image', args)))
+        return
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -132,7 +137,7 @@ def main():
 
     roofline = None
     if not args.no_roofline:
-        names = ['mg_conv_fprop', 'mg_conv_wgrad']
+        names = ['mg_conv_fprop', 'mg_conv_wgrad_ws']
         hip.enable_timing(names)
         n_prof = 2
         for _ in range(n_prof):
@@ -177,7 +182,7 @@ def main():
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(kind, args)
+        cpu_baseline = cpu_baseline_subprocess(args)
 
     if rank == 0:
         line = {
@@ -197,6 +202,23 @@ def main():
         dist.destroy_process_group()
 
 
+def cpu_baseline_subprocess(args, limit_s=150):
+    """Run the CPU oracle leg in a child process with a hard time limit so the default bench always finishes in minutes."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--size', str(args.size), '--instances', str(args.instances),
+           '--iter', str(args.iter), '--cpu-threads', str(args.cpu_threads)] + (['--video'] if args.video else [])
+    env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+    try:
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=limit_s, env=env).stdout.decode()
+        for line in out.splitlines():
+            if line.startswith('CPU_BASELINE '):
+                return json.loads(line[len('CPU_BASELINE '):])
+        return {'value': None, 'unit': 'instance-frames/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': 'failed: ' + out[-300:]}
+    except subprocess.TimeoutExpired:
+        return {'value': None, 'unit': 'instance-frames/s', 'cores': os.cpu_count(), 'kind': 'port',
+                'sample': 'oracle train step at %dx%d did not finish within %d s' % (args.size, args.size, limit_s)}
+
+
 def run_cpu_baseline(kind, args):
     """The CPU oracle (a port of the reference path, test infrastructure) timed on this host: one bounded train step."""
     import copy
@@ -204,7 +226,8 @@ def run_cpu_baseline(kind, args):
     from maggie_amd.utils import config, synth
     from oracle import refmodel
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    threads = args.cpu_threads if args.cpu_threads > 0 else min(cores, 32)      # beyond ~32 threads the many small ops regress
+    torch.set_num_threads(threads)
     model, _ = build_model(config.model_config(kind))
     sd = model.state_dict()
     synth.fill_state_dict_(sd, 1234)
@@ -218,21 +241,15 @@ def run_cpu_baseline(kind, args):
     batch = synth.synthetic_batch(b, n_f, args.instances, size, size, seed=1234, train=True, it=args.iter, max_inst=10)
     mcfg = copy.deepcopy(config.MODEL_VIDEO if kind == 'video' else config.MODEL_IMAGE)
     np.random.seed(0)
-
-    def one():
-        for v in sd.values():
-            if v.grad is not None:
-                v.grad = None
-        out, loss = refmodel.maggie_forward(sd, mcfg, batch, True)
-        loss['total'].backward()
-    one()                      # warm-up
     t0 = time.perf_counter()
-    one()
+    out, loss = refmodel.maggie_forward(sd, mcfg, batch, True)
+    loss['total'].backward()
     dt = time.perf_counter() - t0
-    return {'value': round(b * n_f * args.instances / dt, 4), 'unit': 'instance-frames/s', 'cores': cores, 'kind': 'port',
+    ratio = float(out['detail_mask'].float().mean()) * 10.0 / args.instances
+    return {'value': round(b * n_f * args.instances / dt, 4), 'unit': 'instance-frames/s', 'cores': threads, 'kind': 'port',
             'sample': 'oracle/refmodel.py fp32 train step (fwd+loss+bwd, no optimizer), %dx%d, batch %d x %d frame(s), %d instances, '
-                      '1 warm-up + 1 timed step = %.1f s' % (size, size, b, n_f, args.instances, dt),
-            'threads': torch.get_num_threads()}
+                      'active ratio %.2f, one timed step (no warm-up) = %.1f s on %d of %d host cores' % (size, size, b, n_f, args.instances,
+                                                                                                       ratio, dt, threads, cores)}
 
 
 if __name__ == '__main__':

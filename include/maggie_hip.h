@@ -69,6 +69,10 @@ int mg_conv_fprop(const mg_conv_params* p, void* stream);
  * row splits; dW must be pre-zeroed fp32 [Cout, R*S, Cin]). Same geometry struct; `y` = dY (read), `res` unused,
  * `w` unused, `stats` = dW. Replaces cuDNN wgrad / spconv's indice_conv_backward filter gradient. */
 int mg_conv_wgrad(const mg_conv_params* p, void* stream);
+/* Deterministic, atomic-free variant: with `workspace` >= mg_conv_wgrad_workspace(p) floats every row split writes its own
+ * partial and a second kernel reduces them; dW is then OVERWRITTEN (no pre-zeroing needed). */
+long mg_conv_wgrad_workspace(const mg_conv_params* p);
+int mg_conv_wgrad_ws(const mg_conv_params* p, float* workspace, long workspace_floats, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------------------------
@@ -153,6 +157,9 @@ int mg_gather_rows(const void* dense, int dtype, const int32_t* coords, int R, i
                    int mul_ninst, void* out, int ldo, int yoff, void* stream);
 int mg_gather_rows_bwd(const void* dout, int dtype, int ldo, int yoff, const int32_t* coords, int R, int n_i, int Hd, int Wd, int C,
                        const float* mul, int mul_ninst, const void* dense, float* ddense, float* dmul, void* stream);
+/* atomic-free d(dense): each dense pixel sums the rows of the instance planes active there (bits/wordoff of that level) */
+int mg_gather_rows_bwd_dense(const void* dout, int dtype, int ldo, int yoff, const void* bits, const int32_t* wordoff, int n_i, int N,
+                             int Hd, int Wd, int C, const float* mul, int mul_ninst, void* ddense, void* stream);
 /* plane[P,H,W] = fill everywhere, vals[r, col] at the active sites (SparseConvTensor.dense() - 99 trick) */
 int mg_scatter_plane(const void* vals, int dtype, int ldv, int col, const int32_t* coords, int R, int P, int H, int W, float fill,
                      float* plane, void* stream);

@@ -19,30 +19,38 @@
 
 namespace {
 
-constexpr int ROWB = 80;   // padded LDS row pitch in bytes (64 B of K + 16 B pad)
-
 // wave arrangement per (BM, BN) block tile; every wave tile is a multiple of 16 x 16
 template <int BM, int BN> struct TileCfg { static constexpr int WAVES_M = (BN >= 64 ? 2 : 4), WAVES_N = (BN >= 64 ? 2 : 1); };
 
+// LDS row pitch of a K stage of KS 64-byte slabs: +16 B so that the 16 rows of a ds_read_b128 fragment read fall on 16
+// different 16-byte slots (pitch/16 is odd for KS = 1, 2, 4)
+template <int KS> constexpr int rowb() { return 64 * KS + 16; }
 template <int BM, int BN> constexpr int ep_passes() { return (BM * (BN + 4) * 4 > 40960) ? 2 : 1; }
-template <int BM, int BN> constexpr int stage_bytes() { return 2 * (BM + BN) * ROWB; }
+template <int BM, int BN, int KS> constexpr int stage_bytes() { return (BM + BN) * rowb<KS>(); }
 template <int BM, int BN> constexpr int ctile_bytes() { return (BM / ep_passes<BM, BN>()) * (BN + 4) * 4 + 2 * BN * 4; }
-template <int BM, int BN> constexpr int lds_bytes() { return stage_bytes<BM, BN>() > ctile_bytes<BM, BN>() ? stage_bytes<BM, BN>() : ctile_bytes<BM, BN>(); }
+template <int BM, int BN, int KS> constexpr int lds_bytes() {
+    return stage_bytes<BM, BN, KS>() > ctile_bytes<BM, BN>() ? stage_bytes<BM, BN, KS>() : ctile_bytes<BM, BN>();
+}
 
 struct RowCoord { int n, ho, wo; bool ok; };
 
-template <typename T, int BM, int BN, int MODE>
+// K is walked in STAGES of KS slabs (KS*64 bytes per row). The loads of stage s+1 are issued right after the barrier that
+// publishes stage s and stay in flight under its KS*FM*FN MFMAs; one LDS buffer, two barriers per stage. KS = 4 is used for
+// K-heavy layers (few, fat memory round trips: these GEMMs are small, so exposed load latency -- not bandwidth or MFMA rate --
+// is what bounds them), KS = 1 for the thin-K high-resolution layers.
+template <typename T, int BM, int BN, int KS, int MODE>
 __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE, EPS = TR::EPS;
     constexpr int WAVES_M = TileCfg<BM, BN>::WAVES_M, WAVES_N = TileCfg<BM, BN>::WAVES_N;
-    constexpr int A_ROWS = BM / 64;                 // A rows staged per thread
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, FM = WM / 16, FN = WN / 16;
-    constexpr int B_ITERS = (BN * 4 + 255) / 256;
+    constexpr int A_ROWS = BM / 64;                 // A rows staged per thread (per slab)
+    constexpr int B_ITERS = (BN * 4 + 255) / 256;   // B chunks per thread (per slab)
+    constexpr int ROWB = rowb<KS>();
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* sA = smem;                       // [2][BM][ROWB]
-    char* sB = smem + 2 * BM * ROWB;       // [2][BN][ROWB]
+    char* sA = smem;                       // [BM][ROWB]
+    char* sB = smem + BM * ROWB;           // [BN][ROWB]
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -50,10 +58,11 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
     const int taps = p.R * p.S;
     const int Ktot = taps * p.Cin;
     const int nslab = (Ktot + EPS - 1) / EPS;
+    const int nstage = (nslab + KS - 1) / KS;
     const char* __restrict__ xb = (const char*)p.x;
     const char* __restrict__ wb = (const char*)p.w;
 
-    // ---- per-thread A rows (2 rows, fixed chunk column) ----
+    // ---- per-thread A rows (A_ROWS rows, fixed 16-byte chunk column inside every slab) ----
     const int a_c = t & 3;
     RowCoord rc[A_ROWS];
 #pragma unroll
@@ -71,60 +80,67 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
             rc[i].n = m; rc[i].ho = 0; rc[i].wo = 0;
         }
     }
-    int a_k = a_c * CE;                    // running k index of this thread's chunk
+    int a_k = a_c * CE;                    // running k index of this thread's chunk in slab 0 of the current stage
     int a_tap = a_k / p.Cin;
     int a_ci = a_k - a_tap * p.Cin;
 
-    uint4 ra[A_ROWS], rb[B_ITERS];
+    uint4 ra[KS][A_ROWS], rb[KS][B_ITERS];
 
-    auto load_slab = [&](int s) {
-        // A operand
-        int ky = a_tap / p.S, kx = a_tap - ky * p.S;
+    auto load_stage = [&](int s) {
+        int tap = a_tap, ci = a_ci;
 #pragma unroll
-        for (int i = 0; i < A_ROWS; ++i) {
-            long src = -1;
-            if (rc[i].ok && a_tap < taps) {
-                if (MODE == MG_MODE_CONV) {
-                    int hi = rc[i].ho * p.stride - p.pad + ky * p.dil;
-                    int wi = rc[i].wo * p.stride - p.pad + kx * p.dil;
-                    if (hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win) src = ((long)rc[i].n * p.Hin + hi) * p.Win + wi;
-                } else if (MODE == MG_MODE_TCONV) {
-                    int th = rc[i].ho + p.pad - ky * p.dil;
-                    int tw = rc[i].wo + p.pad - kx * p.dil;
-                    if (th >= 0 && tw >= 0) {
-                        int hi = th / p.stride, wi = tw / p.stride;
-                        if (hi * p.stride == th && wi * p.stride == tw && hi < p.Hin && wi < p.Win)
-                            src = ((long)rc[i].n * p.Hin + hi) * p.Win + wi;
+        for (int j = 0; j < KS; ++j) {
+            // A operand
+            int ky = tap / p.S, kx = tap - ky * p.S;
+#pragma unroll
+            for (int i = 0; i < A_ROWS; ++i) {
+                long src = -1;
+                if (rc[i].ok && tap < taps) {
+                    if (MODE == MG_MODE_CONV) {
+                        int hi = rc[i].ho * p.stride - p.pad + ky * p.dil;
+                        int wi = rc[i].wo * p.stride - p.pad + kx * p.dil;
+                        if (hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win) src = ((long)rc[i].n * p.Hin + hi) * p.Win + wi;
+                    } else if (MODE == MG_MODE_TCONV) {
+                        int th = rc[i].ho + p.pad - ky * p.dil;
+                        int tw = rc[i].wo + p.pad - kx * p.dil;
+                        if (th >= 0 && tw >= 0) {
+                            int hi = th / p.stride, wi = tw / p.stride;
+                            if (hi * p.stride == th && wi * p.stride == tw && hi < p.Hin && wi < p.Win)
+                                src = ((long)rc[i].n * p.Hin + hi) * p.Win + wi;
+                        }
+                    } else {
+                        src = p.nbr[(long)rc[i].n * taps + tap];
                     }
-                } else {
-                    src = p.nbr[(long)rc[i].n * taps + a_tap];
                 }
+                if (src >= 0) ra[j][i] = *(const uint4*)(xb + (src * p.ldx + ci) * (long)sizeof(T));
+                else ra[j][i] = make_uint4(0, 0, 0, 0);
             }
-            if (src >= 0) ra[i] = *(const uint4*)(xb + (src * p.ldx + a_ci) * (long)sizeof(T));
-            else ra[i] = make_uint4(0, 0, 0, 0);
-        }
-        // B operand (weights, K-contiguous)
+            // B operand (weights, K-contiguous)
 #pragma unroll
-        for (int i = 0; i < B_ITERS; ++i) {
-            int idx = t + i * 256;
-            int co = idx >> 2, c = idx & 3;
-            int k0 = s * EPS + c * CE;
-            if (idx < BN * 4 && (n0 + co) < p.Cout && k0 < Ktot)
-                rb[i] = *(const uint4*)(wb + ((long)(n0 + co) * Ktot + k0) * (long)sizeof(T));
-            else rb[i] = make_uint4(0, 0, 0, 0);
+            for (int i = 0; i < B_ITERS; ++i) {
+                int idx = t + i * 256;
+                int co = idx >> 2, c = idx & 3;
+                int k0 = (s * KS + j) * EPS + c * CE;
+                if (idx < BN * 4 && (n0 + co) < p.Cout && k0 < Ktot)
+                    rb[j][i] = *(const uint4*)(wb + ((long)(n0 + co) * Ktot + k0) * (long)sizeof(T));
+                else rb[j][i] = make_uint4(0, 0, 0, 0);
+            }
+            ci += EPS;
+            while (ci >= p.Cin) { ci -= p.Cin; ++tap; }
         }
-        // advance the running (tap, ci)
-        a_ci += EPS;
-        while (a_ci >= p.Cin) { a_ci -= p.Cin; ++a_tap; }
+        a_tap = tap; a_ci = ci;
     };
-    auto store_slab = [&](int buf) {
+    auto store_stage = [&]() {
 #pragma unroll
-        for (int i = 0; i < A_ROWS; ++i)
-            *(uint4*)(sA + buf * BM * ROWB + ((t >> 2) + i * 64) * ROWB + a_c * 16) = ra[i];
+        for (int j = 0; j < KS; ++j) {
 #pragma unroll
-        for (int i = 0; i < B_ITERS; ++i) {
-            int idx = t + i * 256;
-            if (idx < BN * 4) *(uint4*)(sB + buf * BN * ROWB + (idx >> 2) * ROWB + (idx & 3) * 16) = rb[i];
+            for (int i = 0; i < A_ROWS; ++i)
+                *(uint4*)(sA + ((t >> 2) + i * 64) * ROWB + j * 64 + a_c * 16) = ra[j][i];
+#pragma unroll
+            for (int i = 0; i < B_ITERS; ++i) {
+                int idx = t + i * 256;
+                if (idx < BN * 4) *(uint4*)(sB + (idx >> 2) * ROWB + j * 64 + (idx & 3) * 16) = rb[j][i];
+            }
         }
     };
 
@@ -136,33 +152,34 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    load_slab(0);
-    store_slab(0);
-    __syncthreads();
-    for (int s = 0; s < nslab; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < nslab) load_slab(s + 1);
-        const char* a_base = sA + buf * BM * ROWB + (wm * WM + lr) * ROWB + lg * 16;
-        const char* b_base = sB + buf * BN * ROWB + (wn * WN + lr) * ROWB + lg * 16;
-        uint4 fa[FM], fb[FN];
+    const char* a_base = sA + (wm * WM + lr) * ROWB + lg * 16;
+    const char* b_base = sB + (wn * WN + lr) * ROWB + lg * 16;
+    load_stage(0);
+    for (int s = 0; s < nstage; ++s) {
+        store_stage();
+        __syncthreads();
+        if (s + 1 < nstage) load_stage(s + 1);
 #pragma unroll
-        for (int i = 0; i < FM; ++i) fa[i] = *(const uint4*)(a_base + i * 16 * ROWB);
+        for (int j = 0; j < KS; ++j) {
+            uint4 fa[FM], fb[FN];
 #pragma unroll
-        for (int j = 0; j < FN; ++j) fb[j] = *(const uint4*)(b_base + j * 16 * ROWB);
+            for (int i = 0; i < FM; ++i) fa[i] = *(const uint4*)(a_base + i * 16 * ROWB + j * 64);
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
+            for (int i = 0; i < FN; ++i) fb[i] = *(const uint4*)(b_base + i * 16 * ROWB + j * 64);
 #pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                if constexpr (sizeof(T) == 2) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&fa[i], *(const bf16x8*)&fb[j], acc[i][j], 0, 0, 0);
-                } else {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i].x), __uint_as_float(fb[j].x), acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i].y), __uint_as_float(fb[j].y), acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i].z), __uint_as_float(fb[j].z), acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i].w), __uint_as_float(fb[j].w), acc[i][j], 0, 0, 0);
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int jj = 0; jj < FN; ++jj) {
+                    if constexpr (sizeof(T) == 2) {
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&fa[i], *(const bf16x8*)&fb[jj], acc[i][jj], 0, 0, 0);
+                    } else {
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i].x), __uint_as_float(fb[jj].x), acc[i][jj], 0, 0, 0);
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i].y), __uint_as_float(fb[jj].y), acc[i][jj], 0, 0, 0);
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i].z), __uint_as_float(fb[jj].z), acc[i][jj], 0, 0, 0);
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i].w), __uint_as_float(fb[jj].w), acc[i][jj], 0, 0, 0);
+                    }
                 }
-            }
-        if (s + 1 < nslab) store_slab(buf ^ 1);
+        }
         __syncthreads();
     }
 
@@ -268,35 +285,50 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
     }
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int KS>
 int launch_fprop(const mg_conv_params& p, hipStream_t st) {
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN);
-    size_t lds = lds_bytes<BM, BN>();
+    constexpr size_t lds = lds_bytes<BM, BN, KS>();
+    static bool attr_set = false;
+    if (lds > 65536 && !attr_set) {
+        hipFuncSetAttribute((const void*)igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_TCONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
     switch (p.mode) {
-        case MG_MODE_CONV: hipLaunchKernelGGL((igemm_fprop_kernel<T, BM, BN, MG_MODE_CONV>), grid, dim3(256), lds, st, p); break;
-        case MG_MODE_TCONV: hipLaunchKernelGGL((igemm_fprop_kernel<T, BM, BN, MG_MODE_TCONV>), grid, dim3(256), lds, st, p); break;
-        case MG_MODE_GATHER: hipLaunchKernelGGL((igemm_fprop_kernel<T, BM, BN, MG_MODE_GATHER>), grid, dim3(256), lds, st, p); break;
+        case MG_MODE_CONV: hipLaunchKernelGGL((igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_CONV>), grid, dim3(256), lds, st, p); break;
+        case MG_MODE_TCONV: hipLaunchKernelGGL((igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_TCONV>), grid, dim3(256), lds, st, p); break;
+        case MG_MODE_GATHER: hipLaunchKernelGGL((igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_GATHER>), grid, dim3(256), lds, st, p); break;
         default: return -2;
     }
     MG_CHECK_LAUNCH();
     return 0;
 }
 
-template <typename T>
-int dispatch_fprop(const mg_conv_params& p, hipStream_t st) {
+template <typename T, int KS>
+int dispatch_fprop_ks(const mg_conv_params& p, hipStream_t st) {
     // largest tile that still yields >= ~1 block per CU (256 CUs); small-M / wide-N layers drop to 64-row tiles
     auto blocks = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn); };
     if (p.Cout > 64) {
-        if (blocks(128, 128) >= 256) return launch_fprop<T, 128, 128>(p, st);
-        if (blocks(128, 64) >= 256) return launch_fprop<T, 128, 64>(p, st);
-        return launch_fprop<T, 64, 64>(p, st);
+        if (blocks(128, 128) >= 256) return launch_fprop<T, 128, 128, KS>(p, st);
+        if (blocks(128, 64) >= 256) return launch_fprop<T, 128, 64, KS>(p, st);
+        return launch_fprop<T, 64, 64, KS>(p, st);
     }
     if (p.Cout > 32) {
-        if (blocks(128, 64) >= 256) return launch_fprop<T, 128, 64>(p, st);
-        return launch_fprop<T, 64, 64>(p, st);
+        if (blocks(128, 64) >= 256) return launch_fprop<T, 128, 64, KS>(p, st);
+        return launch_fprop<T, 64, 64, KS>(p, st);
     }
-    if (p.Cout > 16) return launch_fprop<T, 128, 32>(p, st);
-    return launch_fprop<T, 128, 16>(p, st);
+    if (p.Cout > 16) return launch_fprop<T, 128, 32, KS>(p, st);
+    return launch_fprop<T, 128, 16, KS>(p, st);
+}
+
+template <typename T>
+int dispatch_fprop(const mg_conv_params& p, hipStream_t st) {
+    const int eps = sizeof(T) == 2 ? 32 : 16;
+    const int nslab = (p.R * p.S * p.Cin + eps - 1) / eps;
+    if (nslab >= 8) return dispatch_fprop_ks<T, 4>(p, st);
+    return dispatch_fprop_ks<T, 1>(p, st);
 }
 
 }  // namespace
@@ -330,7 +362,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 
 template <typename T, int TCO, int TCI, int MODE>
-__global__ __launch_bounds__(256) void igemm_wgrad_kernel(const mg_conv_params p, const int rows_per_block) {
+__global__ __launch_bounds__(256) void igemm_wgrad_kernel(const mg_conv_params p, const int rows_per_block, float* __restrict__ ws) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
     constexpr bool BF = sizeof(T) == 2;
@@ -489,6 +521,16 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const mg_conv_params p
                 atomicAdd(&sR[(i * 16 + g * 4 + e) * LDRR + j * 16 + li], acc[i][j][e]);
     __syncthreads();
     float* __restrict__ dw = p.stats;
+    if (ws) {
+        // deterministic two-stage reduction: this row-split's partial tile goes to its own slab of the workspace
+        float* __restrict__ slab = ws + (long)blockIdx.x * p.Cout * taps * p.Cin;
+        for (int i = t; i < TCO * TCI; i += 256) {
+            int co = i / TCI, ci = i - co * TCI;
+            if (co0 + co < p.Cout && ci0 + ci < p.Cin)
+                slab[((long)(co0 + co) * taps + tap) * p.Cin + ci0 + ci] = sR[co * LDRR + ci];
+        }
+        return;
+    }
     for (int i = t; i < TCO * TCI; i += 256) {
         int co = i / TCI, ci = i - co * TCI;
         if (co0 + co < p.Cout && ci0 + ci < p.Cin)
@@ -496,55 +538,109 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const mg_conv_params p
     }
 }
 
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, long n, float* __restrict__ dw) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float a = 0.f;
+        for (int s = 0; s < splits; ++s) a += ws[(long)s * n + i];
+        dw[i] = a;
+    }
+}
+
+struct WgradPlan { long splits; int rpb; };
+
 template <typename T, int TCO, int TCI>
-int launch_wgrad(const mg_conv_params& p, hipStream_t st) {
-    constexpr bool BF = sizeof(T) == 2;
-    constexpr int KSTEP = BF ? 128 : 64;
-    constexpr int PAD = BF ? 8 : 16;
+WgradPlan plan_wgrad(const mg_conv_params& p) {
+    constexpr int KSTEP = sizeof(T) == 2 ? 128 : 64;
     const int taps = p.R * p.S;
     const int nci = (p.Cin + TCI - 1) / TCI, nco = (p.Cout + TCO - 1) / TCO;
     const long tiles = (long)taps * nci * nco;
-    long want = (512 + tiles - 1) / tiles;                        // ~2 blocks per CU: each extra row split costs a full tile of global atomics
+    long want = (768 + tiles - 1) / tiles;                        // ~3 blocks per CU
     long max_splits = (p.M + KSTEP - 1) / KSTEP;
     long splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
     int rpb = (int)((p.M + splits - 1) / splits);
     rpb = ((rpb + KSTEP - 1) / KSTEP) * KSTEP;
     splits = (p.M + rpb - 1) / rpb;
-    dim3 grid((unsigned)splits, (unsigned)(taps * nci), (unsigned)nco);
+    return {splits, rpb};
+}
+
+template <typename T, int TCO, int TCI>
+int launch_wgrad(const mg_conv_params& p, float* ws, long ws_floats, hipStream_t st) {
+    constexpr bool BF = sizeof(T) == 2;
+    constexpr int KSTEP = BF ? 128 : 64;
+    constexpr int PAD = BF ? 8 : 16;
+    const int taps = p.R * p.S;
+    const int nci = (p.Cin + TCI - 1) / TCI, nco = (p.Cout + TCO - 1) / TCO;
+    WgradPlan pl = plan_wgrad<T, TCO, TCI>(p);
+    const long n = (long)p.Cout * taps * p.Cin;
+    float* use_ws = nullptr;
+    if (pl.splits > 1 && ws && ws_floats >= pl.splits * n) use_ws = ws;
+    mg_conv_params q = p;
+    if (pl.splits == 1) use_ws = p.stats;                          // single split: the "slab" is dW itself (no atomics, no reduce)
+    dim3 grid((unsigned)pl.splits, (unsigned)(taps * nci), (unsigned)nco);
     size_t stage = (size_t)KSTEP * (TCO + PAD + TCI + PAD) * sizeof(T);
     size_t red = (size_t)TCO * (TCI + 1) * 4;
     size_t lds = stage > red ? stage : red;
     switch (p.mode) {
-        case MG_MODE_CONV: hipLaunchKernelGGL((igemm_wgrad_kernel<T, TCO, TCI, MG_MODE_CONV>), grid, dim3(256), lds, st, p, rpb); break;
-        case MG_MODE_TCONV: hipLaunchKernelGGL((igemm_wgrad_kernel<T, TCO, TCI, MG_MODE_TCONV>), grid, dim3(256), lds, st, p, rpb); break;
-        case MG_MODE_GATHER: hipLaunchKernelGGL((igemm_wgrad_kernel<T, TCO, TCI, MG_MODE_GATHER>), grid, dim3(256), lds, st, p, rpb); break;
+        case MG_MODE_CONV: hipLaunchKernelGGL((igemm_wgrad_kernel<T, TCO, TCI, MG_MODE_CONV>), grid, dim3(256), lds, st, q, pl.rpb, use_ws); break;
+        case MG_MODE_TCONV: hipLaunchKernelGGL((igemm_wgrad_kernel<T, TCO, TCI, MG_MODE_TCONV>), grid, dim3(256), lds, st, q, pl.rpb, use_ws); break;
+        case MG_MODE_GATHER: hipLaunchKernelGGL((igemm_wgrad_kernel<T, TCO, TCI, MG_MODE_GATHER>), grid, dim3(256), lds, st, q, pl.rpb, use_ws); break;
         default: return -2;
+    }
+    if (use_ws && pl.splits > 1) {
+        long b = (n + 255) / 256; if (b > 2048) b = 2048;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)b), dim3(256), 0, st, use_ws, (int)pl.splits, n, p.stats);
     }
     MG_CHECK_LAUNCH();
     return 0;
 }
 
 template <typename T>
-int dispatch_wgrad(const mg_conv_params& p, hipStream_t st) {
+int dispatch_wgrad(const mg_conv_params& p, float* ws, long ws_floats, long* need, hipStream_t st) {
     const bool small_co = p.Cout <= 32, small_ci = p.Cin <= 32;
-    if (small_co && small_ci) return launch_wgrad<T, 32, 32>(p, st);
-    if (small_co) return launch_wgrad<T, 32, 64>(p, st);
-    if (small_ci) return launch_wgrad<T, 64, 32>(p, st);
-    return launch_wgrad<T, 64, 64>(p, st);
+    const long n = (long)p.Cout * p.R * p.S * p.Cin;
+#define MG_WG(TCO, TCI)                                                                             \
+    do {                                                                                            \
+        if (need) { WgradPlan pl = plan_wgrad<T, TCO, TCI>(p); *need = pl.splits > 1 ? pl.splits * n : 0; return 0; } \
+        return launch_wgrad<T, TCO, TCI>(p, ws, ws_floats, st);                                     \
+    } while (0)
+    if (small_co && small_ci) MG_WG(32, 32);
+    if (small_co) MG_WG(32, 64);
+    if (small_ci) MG_WG(64, 32);
+    MG_WG(64, 64);
+#undef MG_WG
+}
+
+int wgrad_check(const mg_conv_params* pp) {
+    if (!pp) return -1;
+    const mg_conv_params& p = *pp;
+    const int ce = p.dtype == MG_BF16 ? 8 : 4;
+    if (p.Cin % ce != 0 || p.ldx % ce != 0) return -3;
+    if (p.mode == MG_MODE_GATHER && !p.nbr) return -5;
+    if (p.dtype != MG_BF16 && p.dtype != MG_F32) return -6;
+    return 0;
 }
 
 }  // namespace
 
-extern "C" int mg_conv_wgrad(const mg_conv_params* pp, void* stream) {
-    if (!pp) return -1;
-    const mg_conv_params& p = *pp;
-    const int ce = p.dtype == MG_BF16 ? 8 : 4;
-    if (p.M <= 0) return 0;
-    if (p.Cin % ce != 0 || p.ldx % ce != 0) return -3;
-    if (!p.stats) return -4;
-    if (p.mode == MG_MODE_GATHER && !p.nbr) return -5;
-    hipStream_t st = (hipStream_t)stream;
-    if (p.dtype == MG_BF16) return dispatch_wgrad<bf16raw>(p, st);
-    if (p.dtype == MG_F32) return dispatch_wgrad<float>(p, st);
-    return -6;
+// floats of workspace that make mg_conv_wgrad_ws deterministic and atomic-free for this geometry (0 = none needed)
+extern "C" long mg_conv_wgrad_workspace(const mg_conv_params* pp) {
+    if (wgrad_check(pp) || pp->M <= 0) return 0;
+    long need = 0;
+    if (pp->dtype == MG_BF16) dispatch_wgrad<bf16raw>(*pp, nullptr, 0, &need, nullptr);
+    else dispatch_wgrad<float>(*pp, nullptr, 0, &need, nullptr);
+    return need;
 }
+
+// dW (fp32, p->stats) is fully OVERWRITTEN when a sufficient workspace is given (two-stage reduction over row splits);
+// without workspace it is accumulated with atomics and must be pre-zeroed.
+extern "C" int mg_conv_wgrad_ws(const mg_conv_params* pp, float* workspace, long workspace_floats, void* stream) {
+    int rc = wgrad_check(pp);
+    if (rc) return rc;
+    if (!pp->stats) return -4;
+    if (pp->M <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (pp->dtype == MG_BF16) return dispatch_wgrad<bf16raw>(*pp, workspace, workspace_floats, nullptr, st);
+    return dispatch_wgrad<float>(*pp, workspace, workspace_floats, nullptr, st);
+}
+
+extern "C" int mg_conv_wgrad(const mg_conv_params* pp, void* stream) { return mg_conv_wgrad_ws(pp, nullptr, 0, stream); }

@@ -376,7 +376,8 @@ extern "C" int mg_affine_act(const mg_rowwise_params* p, void* stream) {
 extern "C" int mg_bn_bwd_reduce(const mg_rowwise_params* p, void* stream) {
     int rc = rowwise_check(p); if (rc) return rc;
     if (p->M <= 0) return 0;
-    int blocks = (p->M + 255) / 256; if (blocks > 1024) blocks = 1024;
+    // every block ends with 2C global atomics on the same 2C addresses: keep the block count near 2 per CU
+    int blocks = (p->M + 255) / 256; if (blocks > 512) blocks = 512;
     int rpb = (p->M + blocks - 1) / blocks;
     blocks = (p->M + rpb - 1) / rpb;
     if (p->dtype == MG_BF16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16raw>, dim3(blocks), dim3(NT), 2 * p->C * 4, (hipStream_t)stream, *p, rpb);

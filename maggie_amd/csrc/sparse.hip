@@ -72,6 +72,45 @@ __global__ __launch_bounds__(NT) void gather_rows_bwd_kernel(const T* __restrict
     }
 }
 
+// atomic-free input gradient of the gather: every dense pixel sums the rows of the (at most n_i) instance planes that are
+// active at its position; the row id comes from the level's bit plane + per-word rank (same lookup as the gather tables)
+template <typename T>
+__global__ __launch_bounds__(NT) void gather_rows_bwd_dense_kernel(const T* __restrict__ dout, int ldo, int yoff,
+                                                                   const unsigned long long* __restrict__ bits, const int* __restrict__ wordoff,
+                                                                   int n_i, int N, int Hd, int Wd, int C, const float* __restrict__ mul,
+                                                                   int mul_ninst, T* __restrict__ ddense) {
+    using TR = ElemTraits<T>;
+    constexpr int CE = TR::CE;
+    const int cpr = C / CE;
+    const int Ww = (Wd + 63) >> 6;
+    const long total = (long)N * Hd * Wd * cpr;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        int cc = (int)(i % cpr); long r = i / cpr;
+        int x = (int)(r % Wd); r /= Wd; int y = (int)(r % Hd); int frame = (int)(r / Hd);
+        float acc[CE];
+#pragma unroll
+        for (int e = 0; e < CE; ++e) acc[e] = 0.f;
+        for (int inst = 0; inst < n_i; ++inst) {
+            int p = frame * n_i + inst;
+            long wi = ((long)p * Hd + y) * Ww + (x >> 6);
+            unsigned long long m = bits[wi];
+            int b = x & 63;
+            if (!((m >> b) & 1ull)) continue;
+            int row = wordoff[wi] + __popcll(m & ((1ull << b) - 1ull));
+            float g[CE];
+            TR::unpack(*(const uint4*)(dout + (long)row * ldo + yoff + cc * CE), g);
+            if (mul) {
+                const float* mv = mul + ((long)frame * mul_ninst + inst) * C + cc * CE;
+#pragma unroll
+                for (int e = 0; e < CE; ++e) g[e] *= mv[e];
+            }
+#pragma unroll
+            for (int e = 0; e < CE; ++e) acc[e] += g[e];
+        }
+        *(uint4*)(ddense + (((long)frame * Hd + y) * Wd + x) * C + cc * CE) = TR::pack(acc);
+    }
+}
+
 // plane[p, y, x] = vals[r, col]  (plane pre-filled by the caller's fill kernel)
 template <typename T>
 __global__ __launch_bounds__(NT) void scatter_plane_kernel(const T* __restrict__ vals, int ldv, int col, const int* __restrict__ coords,
@@ -237,6 +276,19 @@ extern "C" int mg_gather_rows_bwd(const void* dout, int dtype, int ldo, int yoff
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MG_BF16) hipLaunchKernelGGL(gather_rows_bwd_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const bf16raw*)dout, ldo, yoff, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, (const bf16raw*)dense, ddense, dmul);
     else hipLaunchKernelGGL(gather_rows_bwd_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, st, (const float*)dout, ldo, yoff, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, (const float*)dense, ddense, dmul);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_gather_rows_bwd_dense(const void* dout, int dtype, int ldo, int yoff, const void* bits, const int32_t* wordoff, int n_i, int N,
+                                        int Hd, int Wd, int C, const float* mul, int mul_ninst, void* ddense, void* stream) {
+    const int ce = dtype == MG_BF16 ? 8 : 4;
+    if (C % ce || ldo % ce || yoff % ce) return -3;
+    long total = (long)N * Hd * Wd * (C / ce);
+    if (total <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MG_BF16) hipLaunchKernelGGL(gather_rows_bwd_dense_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const bf16raw*)dout, ldo, yoff, (const unsigned long long*)bits, wordoff, n_i, N, Hd, Wd, C, mul, mul_ninst, (bf16raw*)ddense);
+    else hipLaunchKernelGGL(gather_rows_bwd_dense_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, st, (const float*)dout, ldo, yoff, (const unsigned long long*)bits, wordoff, n_i, N, Hd, Wd, C, mul, mul_ninst, (float*)ddense);
     MG_CHECK_LAUNCH();
     return 0;
 }

@@ -322,33 +322,35 @@ def gather_conv(x, w, nbr, nbr_t, reverse_taps, ksize=3, bias=None, stats=None, 
 
 
 class GatherRows(torch.autograd.Function):
-    """rows[r] = dense[frame(r), y, x] (* tokens[frame, inst])."""
+    """rows[r] = dense[frame(r), y, x] (* tokens[frame, inst]).  `bits`/`wordoff`: the level's bit planes and ranks (used by the
+    atomic-free backward)."""
 
     @staticmethod
-    def forward(ctx, dense, coords, n_i, mul):
+    def forward(ctx, dense, coords, bits, wordoff, n_i, mul):
         dense = dense.contiguous()
         mul32 = None if mul is None else mul.float().contiguous()
         y = K.gather_rows(dense, coords, n_i, mul=mul32)
-        ctx.save_for_backward(dense, coords, mul32)
+        ctx.save_for_backward(dense, coords, bits, wordoff, mul32)
         ctx.meta = (n_i, dense.shape, mul is not None, None if mul is None else mul.dtype)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        dense, coords, mul32 = ctx.saved_tensors
+        dense, coords, bits, wordoff, mul32 = ctx.saved_tensors
         n_i, dshape, has_mul, mul_dtype = ctx.meta
         dy = dy.contiguous()
-        ddense, dmul = K.gather_rows_bwd(dy, coords, n_i, dshape, mul=mul32, dense=dense,
-                                         want_ddense=ctx.needs_input_grad[0], want_dmul=has_mul and ctx.needs_input_grad[3])
-        if ddense is not None:
-            ddense = ddense.to(dense.dtype)
-        if dmul is not None:
+        ddense = dmul = None
+        if ctx.needs_input_grad[0]:
+            ddense = K.gather_rows_bwd_dense(dy, bits, wordoff, n_i, dshape, mul=mul32)
+        if has_mul and ctx.needs_input_grad[5]:
+            _, dmul = K.gather_rows_bwd(dy, coords, n_i, dshape, mul=mul32, dense=dense, want_ddense=False, want_dmul=True)
             dmul = dmul.to(mul_dtype)
-        return ddense, None, None, dmul
+        return ddense, None, None, None, None, dmul
 
 
-def gather_rows(dense, coords, n_i, mul=None):
-    return GatherRows.apply(dense, coords, n_i, mul)
+def gather_rows(dense, level, n_i, mul=None):
+    """`level`: object with .coords, .bits, .wordoff of the resolution level `dense` lives at."""
+    return GatherRows.apply(dense, level.coords, level.bits, level.wordoff, n_i, mul)
 
 
 class ScatterPlane(torch.autograd.Function):

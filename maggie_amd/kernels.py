@@ -85,14 +85,32 @@ def conv_wgrad(x, dy, *, cout, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=1, Wout=1
         M = nbr.shape[0] if M is None else M
     else:
         M = N * Hout * Wout
-    if out is None:
-        out = torch.zeros((cout, R * S, Cin), dtype=torch.float32, device=x.device)
     assert dy.dtype == x.dtype
-    p = _conv_params(x, None, dy, mode, N, Hin, Win, Hout, Wout, R, S, stride, pad, dil, M, Cin, cout, nbr,
-                     stats=out, yoff=yoff)
-    hip.call('mg_conv_wgrad', ctypes.byref(p), hip.stream(), work=2.0 * M * cout * R * S * Cin,
-             tag=('bf16' if x.dtype == torch.bfloat16 else 'f32', mode, cout, R * S * Cin, M))
+    p = _conv_params(x, None, dy, mode, N, Hin, Win, Hout, Wout, R, S, stride, pad, dil, M, Cin, cout, nbr, yoff=yoff)
+    lib = hip.lib()
+    lib.mg_conv_wgrad_workspace.restype = ctypes.c_long
+    need = lib.mg_conv_wgrad_workspace(ctypes.byref(p)) if M > 0 else 0
+    if out is None:
+        # with a workspace (or a single row split) dW is overwritten; only the (rare) atomic fallback needs zeros
+        out = torch.empty((cout, R * S, Cin), dtype=torch.float32, device=x.device) if M > 0 else \
+            torch.zeros((cout, R * S, Cin), dtype=torch.float32, device=x.device)
+    ws = _wgrad_workspace(need, x.device) if need > 0 else None
+    p.stats = hip.ptr(out)
+    hip.call('mg_conv_wgrad_ws', ctypes.byref(p), hip.ptr(ws), ctypes.c_long(need if ws is not None else 0), hip.stream(),
+             work=2.0 * M * cout * R * S * Cin, tag=('bf16' if x.dtype == torch.bfloat16 else 'f32', mode, cout, R * S * Cin, M))
     return out
+
+
+_WS = {}
+
+
+def _wgrad_workspace(floats, device):
+    """One growing fp32 scratch buffer per device (kernels on one stream execute in order, so reuse is safe)."""
+    buf = _WS.get(device)
+    if buf is None or buf.numel() < floats:
+        buf = torch.empty(int(floats * 1.25) + 1024, dtype=torch.float32, device=device)
+        _WS[device] = buf
+    return buf
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -313,6 +331,16 @@ def gather_rows_bwd(dout, coords, n_i, dense_shape, mul=None, dense=None, yoff=0
              c_int(n_i), c_int(Hd), c_int(Wd), c_int(C), hip.ptr(mul), c_int(mul.shape[1] if mul is not None else 0), hip.ptr(dense),
              hip.ptr(ddense), hip.ptr(dmul), hip.stream())
     return ddense, dmul
+
+
+def gather_rows_bwd_dense(dout, bits, wordoff, n_i, dense_shape, mul=None, yoff=0):
+    """Atomic-free input gradient of gather_rows: (N, Hd, Wd, C) in dout's dtype."""
+    N, Hd, Wd, C = dense_shape
+    ddense = torch.empty(dense_shape, dtype=dout.dtype, device=dout.device)
+    hip.call('mg_gather_rows_bwd_dense', hip.ptr(dout), c_int(hip.dtype_code(dout)), c_int(_ld(dout)), c_int(yoff), hip.ptr(bits), hip.ptr(wordoff),
+             c_int(n_i), c_int(N), c_int(Hd), c_int(Wd), c_int(C), hip.ptr(mul), c_int(mul.shape[1] if mul is not None else 0), hip.ptr(ddense),
+             hip.stream())
+    return ddense
 
 
 def scatter_plane(vals, col, coords, P, H, W, fill=-99.0):

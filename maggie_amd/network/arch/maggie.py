@@ -69,6 +69,8 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             for k, v in list(pred.items()):
                 if 'loss' in k or 'mem_' in k:
                     continue
+                if k in ('detail_mask', 'weight_os4', 'weight_os1'):
+                    continue        # the reference multiplies these too (:114-117) but never reads them again
                 pred[k] = v * valid_masks
             loss_dict = self.compute_loss(pred, weight_os4, weight_os1, alphas, trans_gt, (b, n_f, self.num_masks, h, w),
                                           reweight_os8=self.reweight_os8)

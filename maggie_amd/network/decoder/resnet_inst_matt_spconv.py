@@ -189,14 +189,14 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
         pyr = ActivePyramid(roi_bits, H, W)
         l1, l2, l4, l8 = pyr.levels
         # OS8 gather * instance guidance -> FFN (inst_spec_layer)  (:221-232)
-        x = MF.gather_rows(os8_feat, l8.coords, n_i, mul=inst_guidance_os8)
+        x = MF.gather_rows(os8_feat, l8, n_i, mul=inst_guidance_os8)
         x = self.inst_spec_layer(x.float()).to(os8_feat.dtype) if x.shape[0] > 0 else x
         # layer3: inverse conv OS8->OS4, BN, LeakyReLU, SubM 3x3
         x = self._inverse(x, self.layer3[0], pyr, 2)
         x = self._bn_rows(x, self.layer3[1], MF.ACT_LRELU)
         x = self._subm3(x, self.layer3[3], l4)
         # instance_spec_guidance with fea3 (:172-194)
-        detail = MF.gather_rows(fea3, l4.coords, n_i)
+        detail = MF.gather_rows(fea3, l4, n_i)
         g = self._lin(torch.cat([detail, x], 1), self.guidance_layer[0])
         g = self._bn_rows(g, self.guidance_layer[1], MF.ACT_LRELU)
         g = torch.sigmoid(self._subm3(g, self.guidance_layer[3], l4).float()).to(detail.dtype)
@@ -212,14 +212,14 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
         x = self._inverse(x, self.layer4[0], pyr, 1)
         x = self._bn_rows(x, self.layer4[1], MF.ACT_LRELU)
         x = self._lin(x, self.layer4[3])
-        x = torch.cat([MF.gather_rows(fea2, l2.coords, n_i), x], 1)
+        x = torch.cat([MF.gather_rows(fea2, l2, n_i), x], 1)
         x = self._lin(x, self.layer4_smooth[0], pre_relu=True)
         x = self._bn_rows(x, self.layer4_smooth[2])
         # layer5 (OS2->OS1), fea1, layer5_smooth, refine_OS1
         x = self._inverse(x, self.layer5[0], pyr, 0)
         x = self._bn_rows(x, self.layer5[1], MF.ACT_LRELU)
         x = self._subm3(x, self.layer5[3], l1)
-        x = torch.cat([MF.gather_rows(fea1, l1.coords, n_i), x], 1)
+        x = torch.cat([MF.gather_rows(fea1, l1, n_i), x], 1)
         x = self._lin(x, self.layer5_smooth[0], pre_relu=True)
         x = self._bn_rows(x, self.layer5_smooth[2])
         o1 = self._subm3(x, self.refine_OS1[0], l1)

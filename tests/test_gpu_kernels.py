@@ -176,6 +176,11 @@ def test_gather_scatter_rows_and_planes(dtype):
     dref = torch.zeros(N, H, W, C).index_put((fr, yy, xx), g * mul[fr, inst], accumulate=True)
     mref = torch.zeros(N, 10, C).index_put((fr, inst), g * dense[fr, yy, xx], accumulate=True)
     assert torch.allclose(dd.cpu(), dref, atol=1e-4) and torch.allclose(dm.cpu(), mref, rtol=1e-3, atol=1e-3)
+    # atomic-free variant driven by the level's bit planes / ranks
+    bits = K.bits_pack(torch.from_numpy(act.astype(np.uint8)).to(dev), mode=1)
+    rowoff, wordoff = K.bits_rank(bits, W)
+    dd2 = K.gather_rows_bwd_dense(g.to(dev, dtype), bits, wordoff, n_i, (N, H, W, C), mul=mul.to(dev))
+    assert (dd2.float().cpu() - dref).abs().max() <= _tol(dtype) * dref.abs().max() + 1e-5
     vals = q(torch.from_numpy(rs.normal(size=(R, 1)).astype(np.float32)))
     plane = K.scatter_plane(vals.to(dev, dtype), 0, cod, N * n_i, H, W, -99.0).cpu()
     pref = torch.full((N * n_i, H, W), -99.0)
