@@ -208,6 +208,22 @@ int mg_pyr_downT(const float* r, const float* q, const float* coef, const int32_
 int mg_loss_point_bwd(const float* p, const float* t, const float* w, const int32_t* flags, int P, int H, int W, const float* coef_rec,
                       const float* coef_grad, const float* dd, float* A, float* B, float* dp, void* stream);
 
+/* Batched SpectralNorm: all wrapped convolutions of a model in five launches. `descs` lives in device memory. */
+typedef struct mg_sn_desc {
+    const float* W;      /* fp32 parameter weight_bar, [A][B][taps]                                   */
+    float* u;            /* weight_u [A]  (updated in place)                                          */
+    float* v;            /* weight_v [B*taps] (updated in place)                                      */
+    int64_t out_off;     /* element offset of this conv's (Cout, taps, pad_in) block in the output    */
+    int64_t work_off;    /* float offset of this conv's [v (B*taps) | u (A) | scratch (4)] block      */
+    int64_t dw_off;      /* float offset of this conv's gradient block (backward)                     */
+    int32_t A, B, taps, transposed, pad_in, reserved;
+} mg_sn_desc;
+int mg_spectral_norm_batched(const mg_sn_desc* descs, int n_conv, const int32_t* items_k1, int n1, const int32_t* items_k2, int n2,
+                             const int32_t* items_k3, int n3, float* work_base, long work_floats, void* out_base, int out_dtype,
+                             void* stream);
+int mg_spectral_norm_batched_bwd(const mg_sn_desc* descs, int n_conv, const int32_t* items_k3, int n3, const void* const* Gptrs,
+                                 int g_dtype, float* work_base, float* dW_base, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,20 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Division by a loop-invariant divisor without v_rcp sequences in hot loops: q = umulhi(n, floor((2^32-1)/d)) is at most
+// 2 below floor(n/d) for n < 2^31; two compare-and-fix steps make it exact.
+struct FastDiv {
+    uint32_t d, m;
+    __device__ __forceinline__ explicit FastDiv(int div) : d((uint32_t)div), m(0xFFFFFFFFu / (uint32_t)div) {}
+    __device__ __forceinline__ void divmod(int n, int& q, int& r) const {
+        uint32_t qq = __umulhi((uint32_t)n, m);
+        uint32_t rr = (uint32_t)n - qq * d;
+        if (rr >= d) { ++qq; rr -= d; }
+        if (rr >= d) { ++qq; rr -= d; }
+        q = (int)qq; r = (int)rr;
+    }
+};
+
 #define MG_CHECK_LAUNCH()                              \
     do {                                               \
         hipError_t e__ = hipGetLastError();            \

@@ -16,6 +16,7 @@
 // BatchNorm statistics (sum, sum of squares) are reduced per block before one atomicAdd per channel.
 #include "common.h"
 #include "../../include/maggie_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -85,13 +86,15 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
     int a_ci = a_k - a_tap * p.Cin;
 
     uint4 ra[KS][A_ROWS], rb[KS][B_ITERS];
+    const int invS = (65536 + p.S - 1) / p.S;                       // tap / S == (tap * invS) >> 16 for tap < 256
+    const int sshift = p.stride == 1 ? 0 : (p.stride == 2 ? 1 : (p.stride == 4 ? 2 : -1));
 
     auto load_stage = [&](int s) {
         int tap = a_tap, ci = a_ci;
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
             // A operand
-            int ky = tap / p.S, kx = tap - ky * p.S;
+            int ky = (tap * invS) >> 16, kx = tap - ky * p.S;
 #pragma unroll
             for (int i = 0; i < A_ROWS; ++i) {
                 long src = -1;
@@ -104,7 +107,9 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
                         int th = rc[i].ho + p.pad - ky * p.dil;
                         int tw = rc[i].wo + p.pad - kx * p.dil;
                         if (th >= 0 && tw >= 0) {
-                            int hi = th / p.stride, wi = tw / p.stride;
+                            int hi, wi;
+                            if (sshift >= 0) { hi = th >> sshift; wi = tw >> sshift; }       // stride 1 / 2 / 4: no integer division
+                            else { hi = th / p.stride; wi = tw / p.stride; }
                             if (hi * p.stride == th && wi * p.stride == tw && hi < p.Hin && wi < p.Win)
                                 src = ((long)rc[i].n * p.Hin + hi) * p.Win + wi;
                         }
@@ -390,6 +395,8 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const mg_conv_params p
     const int mend = min(p.M, mbeg + rows_per_block);
     if (mbeg >= mend) return;
     const int ky = tap / p.S, kx = tap - ky * p.S;
+    const FastDiv div_hw(MODE == MG_MODE_GATHER ? 1 : p.Hout * p.Wout), div_w(MODE == MG_MODE_GATHER ? 1 : p.Wout);
+    const int sshift = p.stride == 1 ? 0 : (p.stride == 2 ? 1 : (p.stride == 4 ? 2 : -1));
     const T* __restrict__ yb = (const T*)p.y;
     const T* __restrict__ xb = (const T*)p.x;
     const bool yvec = (p.ldy % CE == 0) && (p.yoff % CE == 0);
@@ -424,15 +431,18 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const mg_conv_params p
                 if (MODE == MG_MODE_GATHER) {
                     src = p.nbr[(long)m * taps + tap];
                 } else {
-                    int hw = p.Hout * p.Wout;
-                    int n = m / hw; int rem = m - n * hw; int ho = rem / p.Wout; int wo = rem - ho * p.Wout;
+                    int n, rem, ho, wo;
+                    div_hw.divmod(m, n, rem);
+                    div_w.divmod(rem, ho, wo);
                     if (MODE == MG_MODE_CONV) {
                         int hi = ho * p.stride - p.pad + ky * p.dil, wi = wo * p.stride - p.pad + kx * p.dil;
                         if (hi >= 0 && hi < p.Hin && wi >= 0 && wi < p.Win) src = ((long)n * p.Hin + hi) * p.Win + wi;
                     } else {
                         int th = ho + p.pad - ky * p.dil, tw = wo + p.pad - kx * p.dil;
                         if (th >= 0 && tw >= 0) {
-                            int hi = th / p.stride, wi = tw / p.stride;
+                            int hi, wi;
+                            if (sshift >= 0) { hi = th >> sshift; wi = tw >> sshift; }
+                            else { hi = th / p.stride; wi = tw / p.stride; }
                             if (hi * p.stride == th && wi * p.stride == tw && hi < p.Hin && wi < p.Win)
                                 src = ((long)n * p.Hin + hi) * p.Win + wi;
                         }
@@ -507,18 +517,18 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const mg_conv_params p
         __syncthreads();
     }
 
-    // reduce the 4 waves through LDS, then one global atomic per tile element
-    float* sR = (float*)smem;                                     // [TCO][TCI + 1]
+    // combine the 4 waves' partial tiles: each wave parks its accumulators in its own LDS slab (no LDS atomics: those
+    // serialise badly), then all threads sum the four slabs for the elements they write out
+    float* sR = (float*)smem;                                     // [4][TCO][TCI + 1]
     constexpr int LDRR = TCI + 1;
-    for (int i = t; i < TCO * LDRR; i += 256) sR[i] = 0.f;
-    __syncthreads();
+    constexpr int SLAB = TCO * LDRR;
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                atomicAdd(&sR[(i * 16 + g * 4 + e) * LDRR + j * 16 + li], acc[i][j][e]);
+                sR[wave * SLAB + (i * 16 + g * 4 + e) * LDRR + j * 16 + li] = acc[i][j][e];
     __syncthreads();
     float* __restrict__ dw = p.stats;
     if (ws) {
@@ -527,22 +537,39 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const mg_conv_params p
         for (int i = t; i < TCO * TCI; i += 256) {
             int co = i / TCI, ci = i - co * TCI;
             if (co0 + co < p.Cout && ci0 + ci < p.Cin)
-                slab[((long)(co0 + co) * taps + tap) * p.Cin + ci0 + ci] = sR[co * LDRR + ci];
+                slab[((long)(co0 + co) * taps + tap) * p.Cin + ci0 + ci] =
+                    sR[co * LDRR + ci] + sR[SLAB + co * LDRR + ci] + sR[2 * SLAB + co * LDRR + ci] + sR[3 * SLAB + co * LDRR + ci];
         }
         return;
     }
     for (int i = t; i < TCO * TCI; i += 256) {
         int co = i / TCI, ci = i - co * TCI;
         if (co0 + co < p.Cout && ci0 + ci < p.Cin)
-            atomicAdd(&dw[((long)(co0 + co) * taps + tap) * p.Cin + ci0 + ci], sR[co * LDRR + ci]);
+            atomicAdd(&dw[((long)(co0 + co) * taps + tap) * p.Cin + ci0 + ci],
+                      sR[co * LDRR + ci] + sR[SLAB + co * LDRR + ci] + sR[2 * SLAB + co * LDRR + ci] + sR[3 * SLAB + co * LDRR + ci]);
     }
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, long n, float* __restrict__ dw) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int s = 0;
+        for (; s + 4 <= splits; s += 4) {
+            a0 += ws[(long)s * n + i]; a1 += ws[(long)(s + 1) * n + i]; a2 += ws[(long)(s + 2) * n + i]; a3 += ws[(long)(s + 3) * n + i];
+        }
+        for (; s < splits; ++s) a0 += ws[(long)s * n + i];
+        dw[i] = (a0 + a1) + (a2 + a3);
+    }
+}
+
+// many splits x few elements: one wave per element, lanes stride over the splits
+__global__ __launch_bounds__(256) void wgrad_reduce_wave_kernel(const float* __restrict__ ws, int splits, long n, float* __restrict__ dw) {
+    const int lane = threadIdx.x & 63;
+    for (long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (long)gridDim.x * 4) {
         float a = 0.f;
-        for (int s = 0; s < splits; ++s) a += ws[(long)s * n + i];
-        dw[i] = a;
+        for (int s = lane; s < splits; s += 64) a += ws[(long)s * n + i];
+        a = wave_sum(a);
+        if (lane == 0) dw[i] = a;
     }
 }
 
@@ -554,9 +581,19 @@ WgradPlan plan_wgrad(const mg_conv_params& p) {
     const int taps = p.R * p.S;
     const int nci = (p.Cin + TCI - 1) / TCI, nco = (p.Cout + TCO - 1) / TCO;
     const long tiles = (long)taps * nci * nco;
-    long want = (768 + tiles - 1) / tiles;                        // ~3 blocks per CU
-    long max_splits = (p.M + KSTEP - 1) / KSTEP;
-    long splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
+    // design point: ~8 row steps per block (amortises the tile epilogue), bounded by ~2048 blocks, 512 splits and a 64 MB
+    // partial-tile workspace; never fewer blocks than ~1 per CU when the rows allow it
+    static const long target = [] { const char* e = getenv("MG_WGRAD_BLOCKS"); return e ? atol(e) : 256l; }();
+    const long n = (long)p.Cout * taps * p.Cin;
+    long splits = p.M / (8 * KSTEP);
+    long lo = (target + tiles - 1) / tiles;
+    long by_rows = (p.M + 2 * KSTEP - 1) / (2 * KSTEP);           // at least 2 steps per block
+    if (lo > by_rows) lo = by_rows;
+    if (splits < lo) splits = lo;
+    if (splits > 2048 / tiles) splits = 2048 / tiles;
+    if (splits > 512) splits = 512;
+    if (splits > (16l << 20) / n) splits = (16l << 20) / n;
+    if (splits < 1) splits = 1;
     int rpb = (int)((p.M + splits - 1) / splits);
     rpb = ((rpb + KSTEP - 1) / KSTEP) * KSTEP;
     splits = (p.M + rpb - 1) / rpb;
@@ -578,7 +615,7 @@ int launch_wgrad(const mg_conv_params& p, float* ws, long ws_floats, hipStream_t
     if (pl.splits == 1) use_ws = p.stats;                          // single split: the "slab" is dW itself (no atomics, no reduce)
     dim3 grid((unsigned)pl.splits, (unsigned)(taps * nci), (unsigned)nco);
     size_t stage = (size_t)KSTEP * (TCO + PAD + TCI + PAD) * sizeof(T);
-    size_t red = (size_t)TCO * (TCI + 1) * 4;
+    size_t red = (size_t)4 * TCO * (TCI + 1) * 4;
     size_t lds = stage > red ? stage : red;
     switch (p.mode) {
         case MG_MODE_CONV: hipLaunchKernelGGL((igemm_wgrad_kernel<T, TCO, TCI, MG_MODE_CONV>), grid, dim3(256), lds, st, q, pl.rpb, use_ws); break;
@@ -587,8 +624,13 @@ int launch_wgrad(const mg_conv_params& p, float* ws, long ws_floats, hipStream_t
         default: return -2;
     }
     if (use_ws && pl.splits > 1) {
-        long b = (n + 255) / 256; if (b > 2048) b = 2048;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)b), dim3(256), 0, st, use_ws, (int)pl.splits, n, p.stats);
+        if (pl.splits > 32 && n <= (1l << 16)) {
+            long b = (n + 3) / 4; if (b > 8192) b = 8192;
+            hipLaunchKernelGGL(wgrad_reduce_wave_kernel, dim3((unsigned)b), dim3(256), 0, st, use_ws, (int)pl.splits, n, p.stats);
+        } else {
+            long b = (n + 255) / 256; if (b > 2048) b = 2048;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)b), dim3(256), 0, st, use_ws, (int)pl.splits, n, p.stats);
+        }
     }
     MG_CHECK_LAUNCH();
     return 0;

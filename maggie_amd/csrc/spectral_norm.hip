@@ -152,3 +152,178 @@ extern "C" int mg_spectral_norm_bwd(const float* G, const float* W, const float*
     MG_CHECK_LAUNCH();
     return 0;
 }
+
+// =====================================================================================================================
+// Batched variant: ALL spectrally-normalised convolutions of a model in a handful of launches (the image model wraps 54
+// convs; per-conv launches are ~11 tiny kernels/memsets each). A descriptor table (device memory, built once) holds the
+// parameter pointers and geometry; per-forward buffers (normalised weights, work) are passed as bases + per-conv offsets.
+// =====================================================================================================================
+namespace {
+
+__global__ __launch_bounds__(NT) void snb_wt_u_kernel(const mg_sn_desc* __restrict__ descs, const int4* __restrict__ items, float* __restrict__ work_base) {
+    const int4 it = items[blockIdx.x];                       // (conv, column block, row block, -)
+    const mg_sn_desc d = descs[it.x];
+    const int Wd = d.B * d.taps;
+    const int j = it.y * NT + threadIdx.x;
+    const int i0 = it.z * 32, i1 = min(d.A, i0 + 32);
+    if (j >= Wd) return;
+    float acc = 0.f;
+    for (int i = i0; i < i1; ++i) acc += d.W[(long)i * Wd + j] * d.u[i];
+    atomicAdd(&work_base[d.work_off + j], acc);
+}
+
+__global__ __launch_bounds__(NT) void snb_w_t_kernel(const mg_sn_desc* __restrict__ descs, const int4* __restrict__ items, float* __restrict__ work_base) {
+    const int4 it = items[blockIdx.x];                       // (conv, row group of 4, first-group flag, -)
+    const mg_sn_desc d = descs[it.x];
+    const int Wd = d.B * d.taps;
+    const float* t = work_base + d.work_off;
+    float* s = work_base + d.work_off + Wd;
+    float* scratch = s + d.A;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = it.y * 4 + wave;
+    if (i < d.A) {
+        float acc = 0.f;
+        for (int j = lane; j < Wd; j += 64) acc += d.W[(long)i * Wd + j] * t[j];
+        acc = wave_sum(acc);
+        if (lane == 0) { s[i] = acc; atomicAdd(&scratch[1], acc * acc); }
+    }
+    if (it.y == 0) {
+        float a = 0.f;
+        for (int j = threadIdx.x; j < Wd; j += NT) a += t[j] * t[j];
+        a = wave_sum(a);
+        if (lane == 0) atomicAdd(&scratch[0], a);
+    }
+}
+
+// writes u, v back to the parameters, leaves normalised copies in work (t <- v, s <- u) for the backward, emits W / sigma
+template <typename T>
+__global__ __launch_bounds__(NT) void snb_finish_kernel(const mg_sn_desc* __restrict__ descs, const int4* __restrict__ items, float* __restrict__ work_base,
+                                                        T* __restrict__ out_base) {
+    const int4 it = items[blockIdx.x];                       // (conv, chunk index, chunks of this conv, -)
+    const mg_sn_desc d = descs[it.x];
+    const int Wd = d.B * d.taps;
+    float* t = work_base + d.work_off;
+    float* s = t + Wd;
+    float* scratch = s + d.A;
+    const float nt = sqrtf(scratch[0]);
+    const float sv = 1.f / (nt + SN_EPS);
+    const float ns = sqrtf(scratch[1]) * sv;
+    const float su = sv / (ns + SN_EPS);
+    const float sigma = ns * ns / (ns + SN_EPS);
+    const float inv_sigma = 1.f / sigma;
+    const long gid = (long)it.y * NT + threadIdx.x;
+    const long stride = (long)it.z * NT;
+    const int Cout = d.transposed ? d.B : d.A, Cin = d.transposed ? d.A : d.B;
+    const long total = (long)Cout * d.taps * d.pad_in;
+    T* out = out_base + d.out_off;
+    for (long o = gid; o < total; o += stride) {
+        int ci = (int)(o % d.pad_in); long r = o / d.pad_in; int tap = (int)(r % d.taps); int co = (int)(r / d.taps);
+        float val = 0.f;
+        if (ci < Cin) {
+            int a = d.transposed ? ci : co, b = d.transposed ? co : ci;
+            val = d.W[((long)a * d.B + b) * d.taps + tap] * inv_sigma;
+        }
+        ElemTraits<T>::st(out + o, val);
+    }
+    // the vectors are finalised by a second tiny kernel (snb_vectors_kernel) so that no block reads t/s after they changed
+}
+
+__global__ __launch_bounds__(NT) void snb_vectors_kernel(const mg_sn_desc* __restrict__ descs, int n, float* __restrict__ work_base) {
+    const int c = blockIdx.x;
+    if (c >= n) return;
+    const mg_sn_desc d = descs[c];
+    const int Wd = d.B * d.taps;
+    float* t = work_base + d.work_off;
+    float* s = t + Wd;
+    float* scratch = s + d.A;
+    const float nt = sqrtf(scratch[0]);
+    const float sv = 1.f / (nt + SN_EPS);
+    const float ns = sqrtf(scratch[1]) * sv;
+    const float su = sv / (ns + SN_EPS);
+    for (int j = threadIdx.x; j < Wd; j += NT) { float v = t[j] * sv; t[j] = v; d.v[j] = v; }
+    for (int i = threadIdx.x; i < d.A; i += NT) { float u = s[i] * su; s[i] = u; d.u[i] = u; }
+    if (threadIdx.x == 0) scratch[3] = ns * ns / (ns + SN_EPS);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void snb_bwd_dot_kernel(const mg_sn_desc* __restrict__ descs, const int4* __restrict__ items,
+                                                         const void* const* __restrict__ Gptrs, float* __restrict__ work_base) {
+    const int4 it = items[blockIdx.x];                       // (conv, chunk, chunks, -)
+    const mg_sn_desc d = descs[it.x];
+    const T* G = (const T*)Gptrs[it.x];
+    if (!G) return;
+    const int Wd = d.B * d.taps;
+    float* scratch = work_base + d.work_off + Wd + d.A;
+    const long total = (long)d.A * d.B * d.taps;
+    float acc = 0.f;
+    for (long e = (long)it.y * NT + threadIdx.x; e < total; e += (long)it.z * NT) {
+        int tap = (int)(e % d.taps); long r = e / d.taps; int b = (int)(r % d.B); int a = (int)(r / d.B);
+        int co = d.transposed ? b : a, ci = d.transposed ? a : b;
+        acc += ElemTraits<T>::ld(G + ((long)co * d.taps + tap) * d.pad_in + ci) * d.W[e];
+    }
+    __shared__ float sh[NT / 64];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&scratch[2], sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void snb_bwd_apply_kernel(const mg_sn_desc* __restrict__ descs, const int4* __restrict__ items,
+                                                           const void* const* __restrict__ Gptrs, const float* __restrict__ work_base,
+                                                           float* __restrict__ dW_base) {
+    const int4 it = items[blockIdx.x];
+    const mg_sn_desc d = descs[it.x];
+    const T* G = (const T*)Gptrs[it.x];
+    const int Wd = d.B * d.taps;
+    const float* v = work_base + d.work_off;
+    const float* u = v + Wd;
+    const float* scratch = u + d.A;
+    float* dW = dW_base + d.dw_off;
+    const long total = (long)d.A * d.B * d.taps;
+    if (!G) { for (long e = (long)it.y * NT + threadIdx.x; e < total; e += (long)it.z * NT) dW[e] = 0.f; return; }
+    const float inv_sigma = 1.f / scratch[3];
+    const float coef = scratch[2] * inv_sigma * inv_sigma;
+    for (long e = (long)it.y * NT + threadIdx.x; e < total; e += (long)it.z * NT) {
+        int tap = (int)(e % d.taps); long r = e / d.taps; int b = (int)(r % d.B); int a = (int)(r / d.B);
+        int co = d.transposed ? b : a, ci = d.transposed ? a : b;
+        float g = ElemTraits<T>::ld(G + ((long)co * d.taps + tap) * d.pad_in + ci);
+        dW[e] = g * inv_sigma - coef * u[a] * v[b * d.taps + tap];
+    }
+}
+
+}  // namespace
+
+// items_*: int32[n][4] work lists built by the host (see maggie_amd/functional.py: SpectralNormPlan)
+extern "C" int mg_spectral_norm_batched(const mg_sn_desc* descs, int n_conv, const int32_t* items_k1, int n1, const int32_t* items_k2, int n2,
+                                        const int32_t* items_k3, int n3, float* work_base, long work_floats, void* out_base, int out_dtype,
+                                        void* stream) {
+    if (n_conv <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(work_base, 0, (size_t)work_floats * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(snb_wt_u_kernel, dim3(n1), dim3(NT), 0, st, descs, (const int4*)items_k1, work_base);
+    hipLaunchKernelGGL(snb_w_t_kernel, dim3(n2), dim3(NT), 0, st, descs, (const int4*)items_k2, work_base);
+    if (out_dtype == MG_BF16) hipLaunchKernelGGL(snb_finish_kernel<bf16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, work_base, (bf16raw*)out_base);
+    else hipLaunchKernelGGL(snb_finish_kernel<float>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, work_base, (float*)out_base);
+    hipLaunchKernelGGL(snb_vectors_kernel, dim3(n_conv), dim3(NT), 0, st, descs, n_conv, work_base);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+// Gptrs: device array of n_conv pointers to the weight gradients in the (Cout, taps, pad_in) layout (NULL = no gradient);
+// work_base: the forward's work buffer; dW_base: fp32 output, conv c at descs[c].dw_off laid out like the parameter.
+extern "C" int mg_spectral_norm_batched_bwd(const mg_sn_desc* descs, int n_conv, const int32_t* items_k3, int n3, const void* const* Gptrs,
+                                            int g_dtype, float* work_base, float* dW_base, void* stream) {
+    if (n_conv <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (g_dtype == MG_BF16) {
+        hipLaunchKernelGGL(snb_bwd_dot_kernel<bf16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, work_base);
+        hipLaunchKernelGGL(snb_bwd_apply_kernel<bf16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, work_base, dW_base);
+    } else {
+        hipLaunchKernelGGL(snb_bwd_dot_kernel<float>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, work_base);
+        hipLaunchKernelGGL(snb_bwd_apply_kernel<float>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, work_base, dW_base);
+    }
+    MG_CHECK_LAUNCH();
+    return 0;
+}

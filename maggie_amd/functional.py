@@ -81,6 +81,106 @@ def spectral_norm_weight(w_bar, u, v, transposed, dtype, pad_in):
     return SpectralNormWeight.apply(w_bar, u.data, v.data, transposed, dtype, pad_in)
 
 
+class SpectralNormPlan:
+    """Descriptor table + work lists for the batched SpectralNorm kernels (built once per model / dtype / device)."""
+
+    def __init__(self, modules, dtype):
+        import ctypes
+        import numpy as np
+        self.modules = modules
+        self.dtype = dtype
+        dev = modules[0].module.weight_bar.device
+        n = len(modules)
+        descs = (K.hip.SnDesc * n)()
+        out_off = work_off = dw_off = 0
+        k1, k2, k3 = [], [], []
+        self.shapes, self.out_slices, self.dw_slices = [], [], []
+        for c, m in enumerate(modules):
+            w = m.module.weight_bar
+            A, B, kh, kw = w.shape
+            taps = kh * kw
+            transposed = int(m.module.transposed)
+            pad_in = pad8(m.module.in_channels)
+            cout = B if transposed else A
+            d = descs[c]
+            d.W, d.u, d.v = w.data_ptr(), m.module.weight_u.data_ptr(), m.module.weight_v.data_ptr()
+            d.out_off, d.work_off, d.dw_off = out_off, work_off, dw_off
+            d.A, d.B, d.taps, d.transposed, d.pad_in = A, B, taps, transposed, pad_in
+            Wd = B * taps
+            n_out = cout * taps * pad_in
+            self.shapes.append((cout, taps, pad_in, tuple(w.shape)))
+            self.out_slices.append((out_off, n_out))
+            self.dw_slices.append((dw_off, w.numel()))
+            for cb in range((Wd + 255) // 256):
+                for rb in range((A + 31) // 32):
+                    k1.append((c, cb, rb, 0))
+            for rg in range((A + 3) // 4):
+                k2.append((c, rg, 0, 0))
+            chunks = max(1, min(64, (max(n_out, w.numel()) + 256 * 8 - 1) // (256 * 8)))
+            for ch in range(chunks):
+                k3.append((c, ch, chunks, 0))
+            out_off += (n_out + 7) // 8 * 8
+            work_off += (Wd + A + 4 + 3) // 4 * 4
+            dw_off += (w.numel() + 3) // 4 * 4
+        self.n, self.total_out, self.total_work, self.total_dw = n, out_off, work_off, dw_off
+        raw = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).clone()
+        self.descs = raw.to(dev)
+        mk = lambda lst: torch.from_numpy(np.asarray(lst, np.int32).reshape(-1, 4)).to(dev)
+        self.k1, self.k2, self.k3 = mk(k1), mk(k2), mk(k3)
+        self.ptr_key = self._ptrs()
+
+    def _ptrs(self):
+        return tuple((m.module.weight_bar.data_ptr(), m.module.weight_u.data_ptr(), m.module.weight_v.data_ptr()) for m in self.modules)
+
+    def valid(self, dtype):
+        return dtype == self.dtype and self._ptrs() == self.ptr_key
+
+
+class SpectralNormBatch(torch.autograd.Function):
+    """All spectrally-normalised weights of a model in one batched HIP pipeline (forward: 5 launches; backward: 2)."""
+
+    @staticmethod
+    def forward(ctx, plan, *w_bars):
+        dev = w_bars[0].device
+        out = torch.empty(plan.total_out, dtype=plan.dtype, device=dev)
+        work = torch.empty(plan.total_work, dtype=torch.float32, device=dev)
+        hipc, c_int = K.hip.call, K.c_int
+        hipc('mg_spectral_norm_batched', K.hip.ptr(plan.descs), c_int(plan.n), K.hip.ptr(plan.k1), c_int(plan.k1.shape[0]), K.hip.ptr(plan.k2),
+             c_int(plan.k2.shape[0]), K.hip.ptr(plan.k3), c_int(plan.k3.shape[0]), K.hip.ptr(work), K.c_long(plan.total_work), K.hip.ptr(out),
+             c_int(K.hip.dtype_code(out)), K.hip.stream())
+        ctx.plan = plan
+        ctx.save_for_backward(work)
+        return tuple(out[o:o + n].view(sh[0], sh[1], sh[2]) for (o, n), sh in zip(plan.out_slices, plan.shapes))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        plan = ctx.plan
+        (work,) = ctx.saved_tensors
+        dev = work.device
+        keep = [None if g is None else g.to(plan.dtype).contiguous() for g in grads]
+        ptrs = torch.tensor([0 if g is None else g.data_ptr() for g in keep], dtype=torch.int64).to(dev, non_blocking=True)
+        dW = torch.empty(plan.total_dw, dtype=torch.float32, device=dev)
+        K.hip.call('mg_spectral_norm_batched_bwd', K.hip.ptr(plan.descs), K.c_int(plan.n), K.hip.ptr(plan.k3), K.c_int(plan.k3.shape[0]),
+                   K.hip.ptr(ptrs), K.c_int(K.hip.BF16 if plan.dtype == torch.bfloat16 else K.hip.F32), K.hip.ptr(work), K.hip.ptr(dW),
+                   K.hip.stream())
+        outs = tuple(dW[o:o + n].view(sh[3]) for (o, n), sh in zip(plan.dw_slices, plan.shapes))
+        return (None,) + outs
+
+
+def spectral_norm_prepare(modules, dtype, cache):
+    """Batched power iteration + normalisation for `modules` (list of SpectralNorm); stores each result on the module
+    (`_prepared`) for its next `krsc()` call. `cache` is a dict owned by the model holding the plan."""
+    if not modules:
+        return
+    plan = cache.get('plan')
+    if plan is None or not plan.valid(dtype):
+        plan = SpectralNormPlan(modules, dtype)
+        cache['plan'] = plan
+    outs = SpectralNormBatch.apply(plan, *[m.module.weight_bar for m in modules])
+    for m, o in zip(modules, outs):
+        m._prepared = o
+
+
 def pad_vec(v, n):
     if v is None or v.numel() == n:
         return v

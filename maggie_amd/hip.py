@@ -127,3 +127,9 @@ class RowwiseParams(ctypes.Structure):
 
 U8 = 2
 c_int, c_float, c_long = ctypes.c_int, ctypes.c_float, ctypes.c_long
+
+
+class SnDesc(ctypes.Structure):
+    _fields_ = [('W', ctypes.c_void_p), ('u', ctypes.c_void_p), ('v', ctypes.c_void_p), ('out_off', ctypes.c_int64),
+                ('work_off', ctypes.c_int64), ('dw_off', ctypes.c_int64), ('A', ctypes.c_int32), ('B', ctypes.c_int32),
+                ('taps', ctypes.c_int32), ('transposed', ctypes.c_int32), ('pad_in', ctypes.c_int32), ('reserved', ctypes.c_int32)]

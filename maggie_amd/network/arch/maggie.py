@@ -49,7 +49,20 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
                     nn.init.xavier_uniform_(p)
 
     # ------------------------------------------------------------------------------------------------ forward
+    def _prepare_spectral_norm(self):
+        """One batched HIP pipeline computes every spectrally-normalised weight of this forward (each SpectralNorm conv does
+        exactly one power iteration per call; convs called more than once per forward fall back to the per-call kernels)."""
+        from ..module.spectral_norm import SpectralNorm
+        mods = self.__dict__.get('_sn_modules')
+        if mods is None:
+            mods = [m for m in self.modules() if isinstance(m, SpectralNorm)]
+            self.__dict__['_sn_modules'] = mods
+            self.__dict__['_sn_cache'] = {}
+        MF.spectral_norm_prepare(mods, MF.compute_dtype(), self.__dict__['_sn_cache'])
+
     def forward(self, batch, **kwargs):
+        if batch['image'].is_cuda:
+            self._prepare_spectral_norm()
         masks, alphas, trans_gt, b, n_f, h, w, n_i, chosen_ids, embedding, mid_fea = self.forward_encoder(batch)
         pred = self.decoder(embedding, mid_fea, b=b, n_f=n_f, n_i=n_i, masks=masks, iter=batch.get('iter', 0), gt_alphas=alphas,
                             spar_gt=trans_gt, **kwargs)

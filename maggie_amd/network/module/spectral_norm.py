@@ -17,6 +17,7 @@ class SpectralNorm(nn.Module):
         self.module = module
         self.name = name
         self.power_iterations = power_iterations
+        self._prepared = None            # set by functional.spectral_norm_prepare (batched path), consumed by krsc()
         if not hasattr(module, name + '_bar'):
             w = getattr(module, name)
             height = w.data.shape[0]
@@ -51,6 +52,11 @@ class SpectralNorm(nn.Module):
         cin = m.in_channels
         pad_in = MF.pad8(cin) if cin_pad is None else cin_pad
         assert self.power_iterations == 1
+        w = self._prepared
+        if w is not None:
+            self._prepared = None
+            if w.dtype == dtype and w.shape[-1] == pad_in:
+                return w
         return MF.spectral_norm_weight(m.weight_bar, m.weight_u, m.weight_v, m.transposed, dtype, pad_in)
 
     def forward(self, x, **kw):
