@@ -105,7 +105,7 @@ typedef struct mg_rowwise_params {
 /* stats[rep][c] += sum_m x[m,c], stats[rep][C+c] += sum_m x[m,c]^2 (fp32 [MG_STAT_REPLICAS][2C], pre-zeroed) */
 int mg_colstats(const void* x, int dtype, int M, int C, int ld, float* stats, void* stream);
 /* batch statistics (`nrep` replicas of [2C], summed here) -> scale/shift/mean/invstd, running-stat update (momentum, unbiased var) */
-/* exact two-pass variant for small M: stats[0:C] = sum, stats[C:2C] = sum (x - mean)^2 (stats is overwritten) */
+/* exact two-pass variant for small M: stats[0:C] += sum, stats[C:2C] += sum (x - mean)^2 (stats [2C] must arrive zeroed) */
 int mg_colstats_centered(const void* x, int dtype, int M, int C, int ld, float* stats, void* stream);
 /* `centered` != 0: stats[C:2C] holds the centred second moment (mg_colstats_centered) instead of sum x^2 */
 int mg_bn_finalize(const float* stats, int nrep, const float* count_ptr, float count, int C, int centered, const float* gamma, const float* beta,

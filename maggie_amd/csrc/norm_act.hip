@@ -17,7 +17,7 @@ constexpr int NT = 256;
 // ---------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(NT) void colstats_kernel(const T* __restrict__ x, int M, int C, int ld, float* __restrict__ stats,
-                                                      int rows_per_block, int nrep) {
+                                                      int rows_per_block, int nrep, int only_sum) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
     const int cpr = C / CE;                       // chunks per row (C % CE == 0)
@@ -47,7 +47,8 @@ __global__ __launch_bounds__(NT) void colstats_kernel(const T* __restrict__ x, i
     }
     __syncthreads();
     float* st = stats + (size_t)(blockIdx.x & (nrep - 1)) * 2 * C;
-    for (int i = t; i < 2 * C; i += NT) atomicAdd(&st[i], sred[i]);
+    const int lim = only_sum ? C : 2 * C;
+    for (int i = t; i < lim; i += NT) atomicAdd(&st[i], sred[i]);
 }
 
 // second pass of the exact two-pass variance: stats[C+c] += sum_m (x[m,c] - stats[c]/M)^2   (stats[0:C] = column sums)
@@ -308,8 +309,8 @@ extern "C" int mg_colstats(const void* x, int dtype, int M, int C, int ld, float
     int rpb = (M + blocks - 1) / blocks;
     blocks = (M + rpb - 1) / rpb;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MG_BF16) hipLaunchKernelGGL(colstats_kernel<bf16raw>, dim3(blocks), dim3(NT), 2 * C * 4, st, (const bf16raw*)x, M, C, ld, stats, rpb, MG_STAT_REPLICAS);
-    else hipLaunchKernelGGL(colstats_kernel<float>, dim3(blocks), dim3(NT), 2 * C * 4, st, (const float*)x, M, C, ld, stats, rpb, MG_STAT_REPLICAS);
+    if (dtype == MG_BF16) hipLaunchKernelGGL(colstats_kernel<bf16raw>, dim3(blocks), dim3(NT), 2 * C * 4, st, (const bf16raw*)x, M, C, ld, stats, rpb, MG_STAT_REPLICAS, 0);
+    else hipLaunchKernelGGL(colstats_kernel<float>, dim3(blocks), dim3(NT), 2 * C * 4, st, (const float*)x, M, C, ld, stats, rpb, MG_STAT_REPLICAS, 0);
     MG_CHECK_LAUNCH();
     return 0;
 }
@@ -322,18 +323,15 @@ extern "C" int mg_colstats_centered(const void* x, int dtype, int M, int C, int 
     int rpb = (M + blocks - 1) / blocks;
     blocks = (M + rpb - 1) / rpb;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(stats, 0, (size_t)2 * C * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
+    // `stats` must arrive zeroed (the caller hands out slices of a per-step zero arena): pass 1 adds the column sums only,
+    // pass 2 the centred second moments
     if (dtype == MG_BF16) {
-        hipLaunchKernelGGL(colstats_kernel<bf16raw>, dim3(blocks), dim3(NT), 2 * C * 4, st, (const bf16raw*)x, M, C, ld, stats, rpb, 1);
-        e = hipMemsetAsync(stats + C, 0, (size_t)C * sizeof(float), st);
+        hipLaunchKernelGGL(colstats_kernel<bf16raw>, dim3(blocks), dim3(NT), 2 * C * 4, st, (const bf16raw*)x, M, C, ld, stats, rpb, 1, 1);
         hipLaunchKernelGGL(colstats_centered_kernel<bf16raw>, dim3(blocks), dim3(NT), C * 4, st, (const bf16raw*)x, M, C, ld, stats, rpb);
     } else {
-        hipLaunchKernelGGL(colstats_kernel<float>, dim3(blocks), dim3(NT), 2 * C * 4, st, (const float*)x, M, C, ld, stats, rpb, 1);
-        e = hipMemsetAsync(stats + C, 0, (size_t)C * sizeof(float), st);
+        hipLaunchKernelGGL(colstats_kernel<float>, dim3(blocks), dim3(NT), 2 * C * 4, st, (const float*)x, M, C, ld, stats, rpb, 1, 1);
         hipLaunchKernelGGL(colstats_centered_kernel<float>, dim3(blocks), dim3(NT), C * 4, st, (const float*)x, M, C, ld, stats, rpb);
     }
-    if (e != hipSuccess) return (int)e;
     MG_CHECK_LAUNCH();
     return 0;
 }

@@ -38,6 +38,8 @@ __global__ __launch_bounds__(NT) void gather_rows_kernel(const T* __restrict__ d
 }
 
 // backward of the gather: ddense[frame,y,x,c] += dout[r,c] * mul ; dmul[frame,inst,c] += dout[r,c]*dense[...]
+// Rows are sorted by plane, so each thread (fixed channel chunk, ascending rows) keeps a running dmul sum for its current
+// plane and flushes it with one atomic per channel only when the plane changes: R*C atomics become ~threads*planes*CE.
 template <typename T>
 __global__ __launch_bounds__(NT) void gather_rows_bwd_kernel(const T* __restrict__ dout, int ldo, int yoff, const int* __restrict__ coords,
                                                              int R, int n_i, int Hd, int Wd, int C, const float* __restrict__ mul,
@@ -46,9 +48,16 @@ __global__ __launch_bounds__(NT) void gather_rows_bwd_kernel(const T* __restrict
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
     const int cpr = C / CE;
-    const long total = (long)R * cpr;
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
-        int r = (int)(i / cpr), cc = (int)(i - (long)r * cpr);
+    const int tid = blockIdx.x * NT + threadIdx.x;
+    const int nthreads = gridDim.x * NT;
+    const int cc = tid % cpr;
+    const int rstep = nthreads / cpr;
+    if (tid >= rstep * cpr) return;
+    float run[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) run[e] = 0.f;
+    long run_row = -1;
+    for (int r = tid / cpr; r < R; r += rstep) {
         int p = coords[(long)r * 3], y = coords[(long)r * 3 + 1], x = coords[(long)r * 3 + 2];
         int frame = p / n_i;
         long drow = (((long)frame * Hd + y) * Wd + x) * C + cc * CE;
@@ -57,10 +66,17 @@ __global__ __launch_bounds__(NT) void gather_rows_bwd_kernel(const T* __restrict
         if (mul) {
             long mrow = ((long)frame * mul_ninst + (p - frame * n_i)) * C + cc * CE;
             if (dmul) {
+                if (mrow != run_row) {
+                    if (run_row >= 0) {
+#pragma unroll
+                        for (int e = 0; e < CE; ++e) { atomicAdd(&dmul[run_row + e], run[e]); run[e] = 0.f; }
+                    }
+                    run_row = mrow;
+                }
                 float d[CE];
                 TR::unpack(*(const uint4*)(dense + drow), d);
 #pragma unroll
-                for (int e = 0; e < CE; ++e) atomicAdd(&dmul[mrow + e], g[e] * d[e]);
+                for (int e = 0; e < CE; ++e) run[e] += g[e] * d[e];
             }
 #pragma unroll
             for (int e = 0; e < CE; ++e) g[e] *= mul[mrow + e];
@@ -69,6 +85,10 @@ __global__ __launch_bounds__(NT) void gather_rows_bwd_kernel(const T* __restrict
 #pragma unroll
             for (int e = 0; e < CE; ++e) atomicAdd(&ddense[drow + e], g[e]);
         }
+    }
+    if (dmul && run_row >= 0) {
+#pragma unroll
+        for (int e = 0; e < CE; ++e) atomicAdd(&dmul[run_row + e], run[e]);
     }
 }
 
@@ -274,8 +294,8 @@ extern "C" int mg_gather_rows_bwd(const void* dout, int dtype, int ldo, int yoff
     if (C % ce || ldo % ce || yoff % ce) return -3;
     long total = (long)R * (C / ce);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MG_BF16) hipLaunchKernelGGL(gather_rows_bwd_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const bf16raw*)dout, ldo, yoff, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, (const bf16raw*)dense, ddense, dmul);
-    else hipLaunchKernelGGL(gather_rows_bwd_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, st, (const float*)dout, ldo, yoff, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, (const float*)dense, ddense, dmul);
+    if (dtype == MG_BF16) hipLaunchKernelGGL(gather_rows_bwd_kernel<bf16raw>, dim3(grid_for(total) > 512 ? 512 : grid_for(total)), dim3(NT), 0, st, (const bf16raw*)dout, ldo, yoff, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, (const bf16raw*)dense, ddense, dmul);
+    else hipLaunchKernelGGL(gather_rows_bwd_kernel<float>, dim3(grid_for(total) > 512 ? 512 : grid_for(total)), dim3(NT), 0, st, (const float*)dout, ldo, yoff, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, (const float*)dense, ddense, dmul);
     MG_CHECK_LAUNCH();
     return 0;
 }

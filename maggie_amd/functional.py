@@ -14,6 +14,39 @@ LRELU_SLOPE = 0.2
 EXACT_STATS_ROWS = 32768      # BatchNorm layers with at most this many rows use the exact two-pass variance
 
 
+class ZeroArena:
+    """Per-step pool of zero-initialised fp32 scratch (BatchNorm statistic / gradient-sum accumulators). One memset per
+    forward replaces ~300 tiny fill kernels; slices are handed out by pointer bump and never outlive the step."""
+
+    def __init__(self):
+        self.buf = None
+        self.off = 0
+        self.used = 0
+        self.need = 1 << 20
+
+    def reset(self, device):
+        self.need = max(self.need, self.used + (1 << 16))
+        if self.buf is None or self.buf.device != device or self.buf.numel() < self.need:
+            self.buf = torch.zeros(self.need, dtype=torch.float32, device=device)
+        else:
+            self.buf.zero_()
+        self.off = 0
+        self.used = 0
+
+    def take(self, n, device):
+        n_al = (n + 63) // 64 * 64
+        self.used += n_al
+        if self.buf is None or self.buf.device != device or self.off + n_al > self.buf.numel():
+            return torch.zeros(n, dtype=torch.float32, device=device)
+        v = self.buf[self.off:self.off + n]
+        self.off += n_al
+        return v
+
+
+ARENA = ZeroArena()
+DEFER_BN_COUNTERS = False      # set by MaGGIe.forward: num_batches_tracked of all BN layers is bumped by one foreach op per step
+
+
 def compute_dtype():
     """bf16 inside torch.autocast(device_type='cuda') (the reference's --precision 16 path uses fp16 autocast,
     engine/train.py:208,227-229; bf16 is this build's choice), fp32 otherwise."""
@@ -280,7 +313,7 @@ class BNAct(torch.autograd.Function):
         if training:
             if group is None and M <= EXACT_STATS_ROWS:
                 # few samples per channel: exact two-pass variance (E[x^2]-E[x]^2 cancels badly when var << mean^2)
-                stats, centered = K.colstats_centered(x2), True
+                stats, centered = K.colstats_centered(x2, ARENA.take(2 * C, x.device)), True
             elif stats is None:
                 stats = K.colstats(x2)
             if group is not None:
@@ -313,7 +346,8 @@ class BNAct(torch.autograd.Function):
         shape, M, C, act, has_res, res_mode, training, group, mask_x_pos, nch, res_shape = ctx.meta
         dy2 = dy.contiguous().view(-1, C)
         if training:
-            _, _, sums = K.bn_backward(dy2, y, x2, scale, mean, invstd, M, act=act, slope=LRELU_SLOPE, reduce_only=True)
+            _, _, sums = K.bn_backward(dy2, y, x2, scale, mean, invstd, M, act=act, slope=LRELU_SLOPE, reduce_only=True,
+                                       sums=ARENA.take(2 * C, dy.device))
             if group is not None:
                 dist.all_reduce(sums, group=group)
             dx, dres, sums = K.bn_backward(dy2, y, x2, scale, mean, invstd, M, act=act, slope=LRELU_SLOPE, want_dres=has_res,
@@ -339,7 +373,7 @@ class BNAct(torch.autograd.Function):
 def batch_norm_act(x, bn, act=ACT_NONE, res=None, stats=None, res_mode=1, mask_x_pos=False):
     """`bn` is an nn.BatchNorm{1,2}d / nn.SyncBatchNorm used as the parameter + running-stat holder."""
     training = bn.training or (bn.running_mean is None)
-    if training and bn.num_batches_tracked is not None:
+    if training and bn.num_batches_tracked is not None and not DEFER_BN_COUNTERS:
         bn.num_batches_tracked.add_(1)
     mom = 0.1 if bn.momentum is None else bn.momentum
     return BNAct.apply(x, bn.weight, bn.bias, res, bn.running_mean, bn.running_var, training, mom, bn.eps, act, stats, res_mode,
@@ -347,7 +381,7 @@ def batch_norm_act(x, bn, act=ACT_NONE, res=None, stats=None, res_mode=1, mask_x
 
 
 def new_stats(channels, device):
-    return torch.zeros((K.STAT_REPLICAS, 2 * channels), dtype=torch.float32, device=device)
+    return ARENA.take(K.STAT_REPLICAS * 2 * channels, device).view(K.STAT_REPLICAS, 2 * channels)
 
 
 def conv_bn_act(x, w, bn, act=ACT_NONE, R=3, S=3, stride=1, pad=1, dil=1, transposed=False, res=None, res_mode=1, res2=None,

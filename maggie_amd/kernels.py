@@ -132,10 +132,12 @@ def colstats(x, stats=None):
     return stats
 
 
-def colstats_centered(x):
-    """Exact two-pass statistics (for small row counts): stats[0:C] = sum, stats[C:2C] = sum (x - mean)^2."""
+def colstats_centered(x, stats=None):
+    """Exact two-pass statistics (for small row counts): stats[0:C] = sum, stats[C:2C] = sum (x - mean)^2.
+    `stats` must be zero on entry (a slice of the per-step zero arena)."""
     M, C = x.shape[0], x.shape[-1]
-    stats = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    if stats is None:
+        stats = torch.zeros(2 * C, dtype=torch.float32, device=x.device)
     hip.need_cuda(x)
     hip.call('mg_colstats_centered', hip.ptr(x), c_int(hip.dtype_code(x)), c_int(M), c_int(C), c_int(_ld(x)), hip.ptr(stats), hip.stream())
     return stats

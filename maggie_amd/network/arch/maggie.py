@@ -60,9 +60,35 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             self.__dict__['_sn_cache'] = {}
         MF.spectral_norm_prepare(mods, MF.compute_dtype(), self.__dict__['_sn_cache'])
 
+    def _begin_step(self, device):
+        """Per-forward bookkeeping done ONCE instead of per layer: zero the accumulator arena, bump every BatchNorm's
+        num_batches_tracked with a single foreach op."""
+        MF.ARENA.reset(device)
+        if self._defer_bn_counters():
+            ctr = self.__dict__.get('_bn_counters')
+            if ctr is None or any(c.device != device for c in ctr):
+                ctr = [m.num_batches_tracked for m in self.modules()
+                       if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.num_batches_tracked is not None]
+                self.__dict__['_bn_counters'] = ctr
+            if ctr:
+                torch._foreach_add_(ctr, 1)
+
+    def _defer_bn_counters(self):
+        # the temporal decoder calls some BatchNorm layers several times per forward (IMD smoothing convs, diff module):
+        # their counters must advance per call, so only the image model batches the increments
+        return self.training and not hasattr(self.decoder, 'os8_temp_module')
+
     def forward(self, batch, **kwargs):
         if batch['image'].is_cuda:
+            self._begin_step(batch['image'].device)
             self._prepare_spectral_norm()
+        MF.DEFER_BN_COUNTERS = self._defer_bn_counters() and batch['image'].is_cuda
+        try:
+            return self._forward_impl(batch, **kwargs)
+        finally:
+            MF.DEFER_BN_COUNTERS = False
+
+    def _forward_impl(self, batch, **kwargs):
         masks, alphas, trans_gt, b, n_f, h, w, n_i, chosen_ids, embedding, mid_fea = self.forward_encoder(batch)
         pred = self.decoder(embedding, mid_fea, b=b, n_f=n_f, n_i=n_i, masks=masks, iter=batch.get('iter', 0), gt_alphas=alphas,
                             spar_gt=trans_gt, **kwargs)
