@@ -102,13 +102,21 @@ def main():
     use_bf16 = args.dtype == 'bf16'
     stats = {}
 
+    host_t = [] if os.environ.get('MAGGIE_HOST_TIMES') == '1' else None     # host-side (launch) time per phase, no device syncs
+
     def step():
+        t = [time.perf_counter()]
         opt.zero_grad(set_to_none=True)
         with torch.autocast('cuda', dtype=torch.bfloat16, enabled=use_bf16):
             out, loss = net(batch)
+        t.append(time.perf_counter())
         loss['total'].backward()
+        t.append(time.perf_counter())
         torch.nn.utils.clip_grad_norm_(params, 0.01)                                    # engine/train.py:274
         opt.step()
+        t.append(time.perf_counter())
+        if host_t is not None:
+            host_t.append([1e3 * (t[i + 1] - t[i]) for i in range(3)])
         stats['active_px'] = out['detail_mask']
         stats['loss'] = loss['total']
         stats.setdefault('active_hist', []).append(out['detail_mask'].float().mean() * 5.0)      # 2 of 10 slots are real
@@ -122,12 +130,24 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    if os.environ.get('MAGGIE_CPROFILE'):                     # host-side profile of the launch path (backward on this thread)
+        import cProfile, pstats
+        torch.autograd.set_multithreading_enabled(False)
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(args.steps):
+            step()
+        pr.disable()
+        sync()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats(os.environ['MAGGIE_CPROFILE']).print_stats(70)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync()
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0)
 
+    if host_t and rank == 0:
+        sys.stderr.write('host ms/step (forward+loss, backward, clip+AdamW): %s\n' % np.round(np.mean(host_t[-args.steps:], 0), 2).tolist())
     inst_frames_per_step = b * n_f * args.instances * world
     value = inst_frames_per_step * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps

@@ -80,6 +80,21 @@ struct FastDiv {
     }
 };
 
+// Zero `n` 32-bit words with a kernel instead of hipMemsetAsync: memset nodes captured into a hipGraph were observed not to
+// be ordered before the kernels that follow them on replay (ROCm 7.2), which corrupts accumulators; a kernel node is.
+static __global__ void mg_zero_words_kernel(uint32_t* __restrict__ p, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long step = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += step) p[i] = 0u;
+}
+static inline hipError_t mg_zero_words(void* p, long n_words, hipStream_t st) {
+    if (n_words <= 0) return hipSuccess;
+    long blocks = (n_words + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(mg_zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint32_t*)p, n_words);
+    return hipGetLastError();
+}
+
 #define MG_CHECK_LAUNCH()                              \
     do {                                               \
         hipError_t e__ = hipGetLastError();            \

@@ -313,15 +313,17 @@ int launch_fprop(const mg_conv_params& p, hipStream_t st) {
 
 template <typename T, int KS>
 int dispatch_fprop_ks(const mg_conv_params& p, hipStream_t st) {
-    // largest tile that still yields >= ~1 block per CU (256 CUs); small-M / wide-N layers drop to 64-row tiles
+    // Largest tile that still yields >= `want` blocks: these GEMMs are small, so exposed load latency is hidden by having
+    // several co-resident blocks per CU (256 CUs), not by a deeper per-block pipeline.
+    static const long want = [] { const char* e = getenv("MG_FPROP_BLOCKS"); return e ? atol(e) : 768l; }();
     auto blocks = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn); };
     if (p.Cout > 64) {
-        if (blocks(128, 128) >= 256) return launch_fprop<T, 128, 128, KS>(p, st);
-        if (blocks(128, 64) >= 256) return launch_fprop<T, 128, 64, KS>(p, st);
+        if (blocks(128, 128) >= want) return launch_fprop<T, 128, 128, KS>(p, st);
+        if (blocks(128, 64) >= want) return launch_fprop<T, 128, 64, KS>(p, st);
         return launch_fprop<T, 64, 64, KS>(p, st);
     }
     if (p.Cout > 32) {
-        if (blocks(128, 64) >= 256) return launch_fprop<T, 128, 64, KS>(p, st);
+        if (blocks(128, 64) >= want) return launch_fprop<T, 128, 64, KS>(p, st);
         return launch_fprop<T, 64, 64, KS>(p, st);
     }
     if (p.Cout > 16) return launch_fprop<T, 128, 32, KS>(p, st);

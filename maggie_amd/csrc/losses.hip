@@ -299,7 +299,7 @@ inline dim3 grid2(long per_plane, int P) {
 extern "C" int mg_plane_flags(const float* w, int P, int HW, int32_t* flags, void* stream) {
     if (P <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(flags, 0, (size_t)P * sizeof(int32_t), st);
+    hipError_t e = mg_zero_words(flags, (long)P, st);
     if (e != hipSuccess) return (int)e;
     dim3 g = grid2(HW, P);
     if (g.x > 64) g.x = 64;

@@ -119,7 +119,7 @@ extern "C" int mg_spectral_norm(const float* W, float* u, float* v, int A, int B
     float* t = work;
     float* s = work + Wd;
     float* scratch = work + Wd + A;
-    hipError_t e = hipMemsetAsync(work, 0, (size_t)(Wd + A + 4) * sizeof(float), st);
+    hipError_t e = mg_zero_words(work, (long)(Wd + A + 4), st);
     if (e != hipSuccess) return (int)e;
     int rpb = 32;
     dim3 g1((Wd + NT - 1) / NT, (A + rpb - 1) / rpb);
@@ -143,7 +143,7 @@ extern "C" int mg_spectral_norm_bwd(const float* G, const float* W, const float*
     const int Wd = B * taps;
     hipStream_t st = (hipStream_t)stream;
     float* scratch = work + Wd + A;
-    hipError_t e = hipMemsetAsync(scratch + 2, 0, sizeof(float), st);
+    hipError_t e = mg_zero_words(scratch + 2, 1, st);
     if (e != hipSuccess) return (int)e;
     long total = (long)A * B * taps;
     int dot_blocks = grid_for(total / 8); if (dot_blocks > 256) dot_blocks = 256;
@@ -300,7 +300,7 @@ extern "C" int mg_spectral_norm_batched(const mg_sn_desc* descs, int n_conv, con
                                         void* stream) {
     if (n_conv <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(work_base, 0, (size_t)work_floats * sizeof(float), st);
+    hipError_t e = mg_zero_words(work_base, (long)work_floats, st);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(snb_wt_u_kernel, dim3(n1), dim3(NT), 0, st, descs, (const int4*)items_k1, work_base);
     hipLaunchKernelGGL(snb_w_t_kernel, dim3(n2), dim3(NT), 0, st, descs, (const int4*)items_k2, work_base);

@@ -16,13 +16,19 @@ EXACT_STATS_ROWS = 32768      # BatchNorm layers with at most this many rows use
 
 class ZeroArena:
     """Per-step pool of zero-initialised fp32 scratch (BatchNorm statistic / gradient-sum accumulators). One memset per
-    forward replaces ~300 tiny fill kernels; slices are handed out by pointer bump and never outlive the step."""
+    forward replaces ~300 tiny fill kernels; slices are handed out by pointer bump and never outlive the step.
+
+    While a hipGraph is being captured (maggie_amd/graphs.py) slices come from a capture-owned buffer instead: it is
+    allocated and zeroed INSIDE the capture (one memset node per graph), so every replay starts from zeros and no captured
+    kernel points into the eager arena, which may be re-allocated later."""
 
     def __init__(self):
         self.buf = None
         self.off = 0
         self.used = 0
         self.need = 1 << 20
+        self.cap_buf = None
+        self.cap_off = 0
 
     def reset(self, device):
         self.need = max(self.need, self.used + (1 << 16))
@@ -33,8 +39,22 @@ class ZeroArena:
         self.off = 0
         self.used = 0
 
+    def begin_capture(self, device):
+        """Called by the graph builder right after capture starts (forward graph and backward graph each get their own)."""
+        self.cap_buf = torch.zeros(max(self.need, 1 << 20), dtype=torch.float32, device=device)
+        self.cap_off = 0
+
+    def end_capture(self):
+        self.cap_buf = None
+
     def take(self, n, device):
         n_al = (n + 63) // 64 * 64
+        if self.cap_buf is not None and torch.cuda.is_current_stream_capturing():
+            if self.cap_off + n_al > self.cap_buf.numel():
+                return torch.zeros(n, dtype=torch.float32, device=device)
+            v = self.cap_buf[self.cap_off:self.cap_off + n]
+            self.cap_off += n_al
+            return v
         self.used += n_al
         if self.buf is None or self.buf.device != device or self.off + n_al > self.buf.numel():
             return torch.zeros(n, dtype=torch.float32, device=device)
@@ -44,6 +64,16 @@ class ZeroArena:
 
 
 ARENA = ZeroArena()
+CAPTURE_FIXUPS = []            # (slice of CAPTURE_TABLE, host tensor to upload once the capture has ended)
+CAPTURE_TABLE = [None, 0]      # [int64 device buffer owned by the graph being captured, bump offset]
+
+
+def capture_table(n):
+    buf, off = CAPTURE_TABLE
+    if buf is None or off + n > buf.numel():
+        raise RuntimeError('capture table exhausted')
+    CAPTURE_TABLE[1] = off + n
+    return buf[off:off + n]
 DEFER_BN_COUNTERS = False      # set by MaGGIe.forward: num_batches_tracked of all BN layers is bumped by one foreach op per step
 
 
@@ -191,7 +221,16 @@ class SpectralNormBatch(torch.autograd.Function):
         (work,) = ctx.saved_tensors
         dev = work.device
         keep = [None if g is None else g.to(plan.dtype).contiguous() for g in grads]
-        ptrs = torch.tensor([0 if g is None else g.data_ptr() for g in keep], dtype=torch.int64).to(dev, non_blocking=True)
+        host_ptrs = torch.tensor([0 if g is None else g.data_ptr() for g in keep], dtype=torch.int64)
+        if torch.cuda.is_current_stream_capturing():
+            # no host->device traffic inside a capture: the table is carved from a buffer the graph builder allocated
+            # BEFORE the capture (memory allocated during a capture is recycled between the nodes of the graphs sharing
+            # its pool, so it cannot hold constants) and is filled once, right after the capture ends -- the gradient
+            # addresses are fixed for the life of the graph
+            ptrs = capture_table(len(keep))
+            CAPTURE_FIXUPS.append((ptrs, host_ptrs))
+        else:
+            ptrs = host_ptrs.to(dev, non_blocking=True)
         dW = torch.empty(plan.total_dw, dtype=torch.float32, device=dev)
         K.hip.call('mg_spectral_norm_batched_bwd', K.hip.ptr(plan.descs), K.c_int(plan.n), K.hip.ptr(plan.k3), K.c_int(plan.k3.shape[0]),
                    K.hip.ptr(ptrs), K.c_int(K.hip.BF16 if plan.dtype == torch.bfloat16 else K.hip.F32), K.hip.ptr(work), K.hip.ptr(dW),

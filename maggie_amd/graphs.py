@@ -1,0 +1,163 @@
+"""hipGraph capture of the static-shape part of a training / inference step.
+
+The dense trunk of MaGGIe (mask embedding -> encoder -> ASPP -> OS32..OS8 decoder -> instance matte decoder) is ~2000
+small kernel launches per training step whose shapes depend only on the batch geometry. Launched one by one from Python the
+MI355X idles ~40% of the step waiting for the host (tools/gaps.py on a rocprofv3 kernel trace); captured once into two
+hipGraphs (forward, backward) the host cost is two graph launches. The data-dependent part of the step (detail region,
+sparse refinement, losses) stays eager.
+
+`GraphedCallable` is a small, explicit version of torch.cuda.make_graphed_callables with the hooks this code base needs:
+  * the warm-up iterations' side effects on buffers (BatchNorm running statistics, SpectralNorm u/v) are rolled back, so a
+    graphed model stays step-for-step identical to the eager one;
+  * the zero arena / wgrad scratch are re-pointed at capture-owned memory (functional.ZeroArena.begin_capture);
+  * parameter gradients are copied out of the graph's static buffers (one foreach copy), so `.grad` never aliases memory
+    the next replay overwrites (gradient accumulation and zero_grad(set_to_none=False) stay correct);
+  * a forward-only graph for torch.no_grad() inference.
+"""
+import torch
+
+from . import functional as MF
+
+
+class _Replay(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, *params):
+        g.fwd.replay()
+        ctx.g = g
+        outs = tuple(o.detach() for o in g.static_outputs)
+        ctx.mark_non_differentiable(*[o for o, s in zip(outs, g.static_outputs) if not s.requires_grad])
+        return outs
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *grads):
+        g = ctx.g
+        src, dst = [], []
+        for s, gr in zip(g.static_grad_outputs, grads):
+            if s is not None and gr is not None and s.data_ptr() != gr.data_ptr():
+                src.append(gr.to(s.dtype) if gr.dtype != s.dtype else gr)
+                dst.append(s)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        g.bwd.replay()
+        return (None,) + g.export_param_grads()
+
+
+class _ParamAliases:
+    """While capturing, every trainable parameter of `module` is replaced by a fresh leaf tensor sharing its memory.
+
+    autograd routes a leaf's gradient through its AccumulateGrad node, which remembers the stream that was current when
+    the node was created. The real parameters' nodes usually exist already (an earlier eager step, DDP) and belong to the
+    default stream, so differentiating with respect to them inside a capture on a side stream makes the engine
+    synchronise the two streams -- which drags the default stream into the capture and breaks it. Aliases created inside
+    the side-stream context have no such history; same memory, same values, same gradients."""
+
+    def __init__(self, module, training):
+        self.slots, self.params, self.aliases = [], [], []
+        if not training:
+            return
+        seen = {}
+        for m in module.modules():
+            for name, p in m._parameters.items():
+                if p is not None and p.requires_grad:
+                    if id(p) not in seen:
+                        seen[id(p)] = len(self.params)
+                        self.params.append(p)
+                    self.slots.append((m, name, p, seen[id(p)]))
+
+    def __enter__(self):
+        self.aliases = [p.detach().requires_grad_(True) for p in self.params]
+        for m, name, _, i in self.slots:
+            m._parameters[name] = self.aliases[i]
+        return self
+
+    def __exit__(self, *exc):
+        for m, name, p, _ in self.slots:
+            m._parameters[name] = p
+        return False
+
+
+class GraphedCallable:
+    """fn(*inputs) -> tuple of tensors, captured for fixed input shapes. `module`: the nn.Module whose parameters fn reads
+    (requires_grad ones get gradients). `mutable`: tensors fn mutates in place (rolled back after warm-up)."""
+
+    def __init__(self, fn, inputs, module, mutable, training, warmup=2):
+        dev = inputs[0].device
+        self.training = training
+        self.static_inputs = [i.detach().clone() for i in inputs]
+        snap = [m.detach().clone() for m in mutable]
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side), _ParamAliases(module, training) as aliases:
+            self.params, cap_params, used = aliases.params, aliases.aliases, None
+            for _ in range(warmup):
+                outs = fn(*self.static_inputs)
+                if training:
+                    req = [o for o in outs if o.requires_grad]
+                    gr = torch.autograd.grad(req, cap_params, [torch.ones_like(o) for o in req], allow_unused=True)
+                    used = [x is not None for x in gr]
+                    del gr
+                del outs
+            if training:
+                self.params = [p for p, u in zip(self.params, used) if u]
+                cap_params = [p for p, u in zip(cap_params, used) if u]
+            self.pool = torch.cuda.graph_pool_handle()
+            self.fwd = torch.cuda.CUDAGraph()
+            MF.CAPTURE_FIXUPS[:] = []
+            self.table = torch.zeros(1 << 14, dtype=torch.int64, device=dev)      # constants of the captured kernels
+            MF.CAPTURE_TABLE[:] = [self.table, 0]
+            try:
+                with torch.cuda.graph(self.fwd, pool=self.pool, stream=side):
+                    MF.ARENA.begin_capture(dev)
+                    self.static_outputs = tuple(fn(*self.static_inputs))
+                self.static_grad_outputs, self.static_param_grads, self.bwd = None, None, None
+                if training:
+                    self.static_grad_outputs = [torch.zeros_like(o) if o.requires_grad else None for o in self.static_outputs]
+                    self.bwd = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.bwd, pool=self.pool, stream=side):
+                        MF.ARENA.begin_capture(dev)
+                        self.static_param_grads = torch.autograd.grad(
+                            [o for o in self.static_outputs if o.requires_grad], cap_params,
+                            [g for g in self.static_grad_outputs if g is not None], allow_unused=True)
+            finally:
+                MF.ARENA.end_capture()
+                fix, MF.CAPTURE_FIXUPS[:] = list(MF.CAPTURE_FIXUPS), []
+                MF.CAPTURE_TABLE[:] = [None, 0]
+            for dev_t, host_t in fix:
+                dev_t.copy_(host_t)
+        cur.wait_stream(side)
+        with torch.no_grad():
+            for m, s in zip(mutable, snap):
+                m.copy_(s)
+        if training:
+            self._layout = {}
+            for p, g in zip(self.params, self.static_param_grads):
+                self._layout.setdefault(g.dtype, []).append(g)
+
+    def export_param_grads(self):
+        """Fresh copies of the static gradient buffers: one flat allocation + one foreach copy per dtype."""
+        out = {}
+        for dt, gs in self._layout.items():
+            flat = torch.empty(sum(g.numel() for g in gs), dtype=dt, device=gs[0].device)
+            views, o = [], 0
+            for g in gs:
+                views.append(flat[o:o + g.numel()].view(g.shape))
+                o += g.numel()
+            torch._foreach_copy_(views, gs)
+            for g, v in zip(gs, views):
+                out[id(g)] = v
+        return tuple(out[id(g)] for g in self.static_param_grads)
+
+    def __call__(self, *inputs):
+        src, dst = [], []
+        for s, i in zip(self.static_inputs, inputs):
+            if s.data_ptr() != i.data_ptr():
+                src.append(i if i.dtype == s.dtype else i.to(s.dtype))
+                dst.append(s)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        if self.training:
+            return _Replay.apply(self, *self.params)
+        self.fwd.replay()
+        return tuple(o.detach() for o in self.static_outputs)

@@ -66,7 +66,14 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream():
+    """The hipStream_t torch is currently launching on (raw query: torch.cuda.current_stream() builds a Python Stream object
+    per call, ~5 us, and this runs once per kernel launch)."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch._C._cuda_getDevice()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -97,9 +104,15 @@ def disable_timing():
     return t
 
 
+_FN = {}
+
+
 def call(name, *args, work=None, tag=None):
-    fn = getattr(lib(), name)
-    fn.restype = ctypes.c_int
+    fn = _FN.get(name)
+    if fn is None:
+        fn = getattr(lib(), name)
+        fn.restype = ctypes.c_int
+        _FN[name] = fn
     if _TIMING is not None and name in _TIMING['names']:
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()

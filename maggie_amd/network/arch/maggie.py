@@ -49,16 +49,25 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
                     nn.init.xavier_uniform_(p)
 
     # ------------------------------------------------------------------------------------------------ forward
-    def _prepare_spectral_norm(self):
+    def _sn_groups(self):
+        """SpectralNorm modules split by stage: 'trunk' (encoder, ASPP, dense decoder stage) and 'detail' (the rest)."""
+        groups = self.__dict__.get('_sn_groups_cache')
+        if groups is None:
+            from ..module.spectral_norm import SpectralNorm
+            trunk_roots = [self.encoder, self.aspp] + list(self.decoder.dense_modules())
+            trunk_ids = {id(m) for r in trunk_roots for m in r.modules() if isinstance(m, SpectralNorm)}
+            allm = [m for m in self.modules() if isinstance(m, SpectralNorm)]
+            groups = {'all': allm, 'trunk': [m for m in allm if id(m) in trunk_ids],
+                      'detail': [m for m in allm if id(m) not in trunk_ids]}
+            self.__dict__['_sn_groups_cache'] = groups
+            self.__dict__['_sn_cache'] = {k: {} for k in groups}
+        return groups
+
+    def _prepare_spectral_norm(self, group='all'):
         """One batched HIP pipeline computes every spectrally-normalised weight of this forward (each SpectralNorm conv does
         exactly one power iteration per call; convs called more than once per forward fall back to the per-call kernels)."""
-        from ..module.spectral_norm import SpectralNorm
-        mods = self.__dict__.get('_sn_modules')
-        if mods is None:
-            mods = [m for m in self.modules() if isinstance(m, SpectralNorm)]
-            self.__dict__['_sn_modules'] = mods
-            self.__dict__['_sn_cache'] = {}
-        MF.spectral_norm_prepare(mods, MF.compute_dtype(), self.__dict__['_sn_cache'])
+        mods = self._sn_groups()[group]
+        MF.spectral_norm_prepare(mods, MF.compute_dtype(), self.__dict__['_sn_cache'][group])
 
     def _begin_step(self, device):
         """Per-forward bookkeeping done ONCE instead of per layer: zero the accumulator arena, bump every BatchNorm's
@@ -79,19 +88,87 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         return self.training and not hasattr(self.decoder, 'os8_temp_module')
 
     def forward(self, batch, **kwargs):
-        if batch['image'].is_cuda:
-            self._begin_step(batch['image'].device)
-            self._prepare_spectral_norm()
-        MF.DEFER_BN_COUNTERS = self._defer_bn_counters() and batch['image'].is_cuda
+        if not batch['image'].is_cuda:
+            raise K.hip.MaggieHipError('MaGGIe (MI355X build) runs on the GPU only: move the batch to cuda (no CPU fallback)')
+        self._begin_step(batch['image'].device)
+        MF.DEFER_BN_COUNTERS = self._defer_bn_counters()
         try:
             return self._forward_impl(batch, **kwargs)
         finally:
             MF.DEFER_BN_COUNTERS = False
 
+    # ------------------------------------------------------------------------------------------------ dense trunk
+    def _trunk(self, geom, prepare_sn, x, enc_masks, masks, gt_alphas=None, mem_feat=None):
+        """Static-shape part of the step: mask embedding + encoder + ASPP + dense decoder stage. Tensors in, tensors out."""
+        b, n_f, n_i = geom
+        if prepare_sn:
+            self._prepare_spectral_norm('trunk')
+        embedding, mid_fea = self.encoder(x, enc_masks)
+        embedding = self.aspp(embedding)
+        dense = self.decoder.dense_stage(embedding, mid_fea, b, n_f, n_i, masks, gt_alphas, mem_feat)
+        return tuple(t for t in dense if t is not None)
+
+    def _graph_policy(self):
+        """hipGraph capture of the trunk: attribute `hip_graphs` (True/False) or env MAGGIE_HIP_GRAPHS (default on)."""
+        flag = self.__dict__.get('hip_graphs')
+        if flag is None:
+            import os
+            flag = os.environ.get('MAGGIE_HIP_GRAPHS', '1') != '0'
+        if not flag:
+            return False
+        if self.training != torch.is_grad_enabled():
+            return False
+        if self.training and torch.distributed.is_available() and torch.distributed.is_initialized() \
+                and torch.distributed.get_world_size() > 1 and any(isinstance(m, nn.SyncBatchNorm) for m in self.modules()):
+            return False                  # SyncBN all-reduces inside the trunk: collectives are not captured
+        return True
+
+    def _run_trunk(self, geom, x, enc_masks, masks, gt_alphas, mem_feat):
+        """Eager the first time a batch geometry is seen, captured into hipGraphs from the second time on."""
+        inputs = [x, enc_masks, masks] + ([gt_alphas] if (self.training and gt_alphas is not None) else [])
+        has_hidden = hasattr(self.decoder, 'os8_temp_module')
+        graphs = self.__dict__.setdefault('_trunk_graphs', {})
+        key = None
+        if mem_feat is None and self._graph_policy():
+            key = (geom, self.training, MF.compute_dtype(), tuple((tuple(t.shape), t.dtype) for t in inputs))
+        entry = graphs.get(key) if key is not None else None
+        if isinstance(entry, int) and entry >= 1:
+            entry = self._capture_trunk(geom, inputs)
+            graphs[key] = entry
+            while len(graphs) > 4:                                # bounded: each graph pins its own activation pool
+                graphs.pop(next(iter(graphs)))
+        if entry is None or isinstance(entry, int) or entry == 'failed':
+            if key is not None and entry != 'failed':
+                graphs[key] = (entry or 0) + 1
+            self._prepare_spectral_norm('all')
+            out = self._trunk(geom, False, *inputs, mem_feat=mem_feat)
+        else:
+            self._prepare_spectral_norm('detail')
+            out = entry(*inputs)
+            from ..module.instance_matte_decoder import check_tokens
+            check_tokens(out[2])
+            out = (out[0].clone(),) + tuple(out[1:])              # alpha_os8 is handed to the caller: never alias graph memory
+        out = list(out)
+        if not has_hidden:
+            out.insert(4, None)
+        return tuple(out)
+
+    def _capture_trunk(self, geom, inputs):
+        from ... import graphs
+        mutable = [t for t in self.buffers()] + [p for p in self.parameters() if not p.requires_grad]
+        fn = lambda *t: self._trunk(geom, True, *t)               # noqa: E731
+        try:
+            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=torch.is_autocast_enabled(), cache_enabled=False):
+                return graphs.GraphedCallable(fn, inputs, self, mutable, self.training)
+        except Exception as e:                                    # pragma: no cover - capture is an optimisation, never fatal
+            logging.warning('hipGraph capture of the MaGGIe trunk failed (%s: %s); staying eager', type(e).__name__, e)
+            return 'failed'
+
     def _forward_impl(self, batch, **kwargs):
-        masks, alphas, trans_gt, b, n_f, h, w, n_i, chosen_ids, embedding, mid_fea = self.forward_encoder(batch)
-        pred = self.decoder(embedding, mid_fea, b=b, n_f=n_f, n_i=n_i, masks=masks, iter=batch.get('iter', 0), gt_alphas=alphas,
-                            spar_gt=trans_gt, **kwargs)
+        masks, alphas, trans_gt, b, n_f, h, w, n_i, chosen_ids, x, enc_masks = self.forward_inputs(batch)
+        dense = self._run_trunk((b, n_f, n_i), x, enc_masks, masks, alphas, kwargs.get('mem_feat'))
+        pred = self.decoder.detail_stage(dense, x, b, n_f, n_i, batch.get('iter', 0), alphas, spar_gt=trans_gt,
+                                         **{k: v for k, v in kwargs.items() if k != 'mem_feat'})
         if isinstance(pred, tuple):
             pred = pred[0]
         alpha_pred = pred.pop("refined_masks")
@@ -142,7 +219,8 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             output['detail_mask'] = pred['detail_mask'][:, :n_out].reshape(b, n_f, n_out, h, w)
         return output
 
-    def forward_encoder(self, batch):
+    def forward_inputs(self, batch):
+        """Input plumbing of arch/maggie.py:160-198 up to (not including) the encoder call."""
         x = batch['image']
         masks = batch['mask']
         alphas = batch.get('alpha', None)
@@ -162,7 +240,13 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             alphas = alphas.reshape(-1, n_i, h, w)
         if trans_gt is not None:
             trans_gt = trans_gt.reshape(-1, n_i, h, w)
-        embedding, mid_fea = self.encoder(x.contiguous(), enc_masks.contiguous())
+        return masks, alphas, trans_gt, b, n_f, h, w, n_i, chosen_ids, x.contiguous(), enc_masks.contiguous()
+
+    def forward_encoder(self, batch):
+        """Same return tuple as the reference's forward_encoder (arch/maggie.py:160-198)."""
+        masks, alphas, trans_gt, b, n_f, h, w, n_i, chosen_ids, x, enc_masks = self.forward_inputs(batch)
+        self._prepare_spectral_norm('all')
+        embedding, mid_fea = self.encoder(x, enc_masks)
         embedding = self.aspp(embedding)
         return masks, alphas, trans_gt, b, n_f, h, w, n_i, chosen_ids, embedding, mid_fea
 

@@ -274,14 +274,36 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
         x_os1 = MF.upsample_tanh(x_os1.view(N, n_i, H, W), n_i, 1, False)
         return x_os4, x_os1, detail_bits
 
-    def forward(self, x, mid_fea, b, n_f, n_i, masks, iter, gt_alphas, **kwargs):
+    # The forward pass is split at the point where shapes stop being a function of the batch geometry alone:
+    #   dense_stage  -- OS32 -> OS8 decoder + instance matte decoder (static shapes: capturable in a hipGraph, graphs.py)
+    #   detail_stage -- detail region, sparse refinement, fusion (data-dependent row counts)
+    def dense_modules(self):
+        """Sub-modules whose parameters are touched by dense_stage only."""
+        return [self.layer1, self.layer2, self.refine_OS8]
+
+    def _refine_os8(self, x, masks, gt_masks, n_f, mem_feat):
+        return self.refine_OS8(x, masks, use_mask_atten=False, gt_mask=gt_masks)
+
+    def dense_stage(self, x, mid_fea, b, n_f, n_i, masks, gt_alphas, mem_feat=None):
+        """:318-339. Returns (alpha_os8 (N, 10, H, W) fp32 [train: times valid_masks], OS8 features, queries, loss_max_atten,
+        hidden_state | None, fea1, fea2, fea3)."""
         x, masks, valid_masks, gt_masks, fea1, fea2, fea3, image, h, w = self.os32_to_os8(x, mid_fea, b, n_f, n_i, masks, gt_alphas)
-        x_os8, x, queries, loss_max_atten, _ = self.refine_OS8(x, masks, use_mask_atten=False, gt_mask=gt_masks)
-        n_all = self.max_inst
-        x_os8 = MF.upsample_tanh(x_os8, n_all, h // x_os8.shape[1], True)                  # (N, 10, H, W) fp32
+        x_os8, x, queries, loss_max_atten, hidden_state = self._refine_os8(x, masks, gt_masks, n_f, mem_feat)
+        x_os8 = MF.upsample_tanh(x_os8, self.max_inst, h // x_os8.shape[1], True)          # (N, 10, H, W) fp32
         if self.training:
             x_os8 = x_os8 * valid_masks
-        else:
+        if not torch.is_tensor(loss_max_atten):
+            loss_max_atten = x_os8.new_zeros(())
+        return x_os8, x, queries, loss_max_atten, hidden_state, fea1, fea2, fea3
+
+    def forward(self, x, mid_fea, b, n_f, n_i, masks, iter, gt_alphas, **kwargs):
+        dense = self.dense_stage(x, mid_fea, b, n_f, n_i, masks, gt_alphas, kwargs.get('mem_feat'))
+        return self.detail_stage(dense, mid_fea['image'], b, n_f, n_i, iter, gt_alphas, **kwargs)
+
+    def detail_stage(self, dense, image, b, n_f, n_i, iter, gt_alphas, **kwargs):
+        x_os8, x, queries, loss_max_atten, _, fea1, fea2, fea3 = dense
+        h, w = image.shape[-2:]
+        if not self.training:
             x_os8 = x_os8[:, :n_i].contiguous()
         guided = x_os8
         is_use_alphas_gt = False

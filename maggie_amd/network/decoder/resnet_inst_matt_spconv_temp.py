@@ -77,17 +77,19 @@ class ResShortCut_InstMattSpconv_BiTempSpar_Dec(ResShortCut_InstMattSpconv_Dec):
                 fuse_preds.append((forward_preds[i] + backward_preds[i]) / 2)
         return forward_diffs, backward_diffs, torch.stack(fuse_preds, dim=1)
 
-    def forward(self, x, mid_fea, b, n_f, n_i, masks, iter, gt_alphas, mem_feat=None, spar_gt=None, **kwargs):
-        x, masks, valid_masks, gt_masks, fea1, fea2, fea3, image, h, w = self.os32_to_os8(x, mid_fea, b, n_f, n_i, masks, gt_alphas)
+    def dense_modules(self):
+        return super().dense_modules() + [self.os8_temp_module]
+
+    def _refine_os8(self, x, masks, gt_masks, n_f, mem_feat):
         prop = partial(self.os8_temp_module.propagate_features, n_f=n_f, prev_h_state=mem_feat, temp_method=self.temp_method)
-        x_os8, x, queries, loss_max_atten, hidden_state = self.refine_OS8(x, masks, use_mask_atten=False, gt_mask=gt_masks,
-                                                                          aggregate_mem_fn=prop)
+        return self.refine_OS8(x, masks, use_mask_atten=False, gt_mask=gt_masks, aggregate_mem_fn=prop)
+
+    def detail_stage(self, dense, image, b, n_f, n_i, iter, gt_alphas, mem_feat=None, spar_gt=None, **kwargs):
+        x_os8, x, queries, loss_max_atten, hidden_state, fea1, fea2, fea3 = dense
+        h, w = image.shape[-2:]
         mem_feat = hidden_state
         feat_os8 = x.view(b, n_f, *x.shape[1:]).detach()
-        x_os8 = MF.upsample_tanh(x_os8, self.max_inst, 8, True)
-        if self.training:
-            x_os8 = x_os8 * valid_masks
-        else:
+        if not self.training:
             x_os8 = x_os8[:, :n_i].contiguous()
         guided = x_os8
         is_use_alphas_gt = False

@@ -12,6 +12,12 @@ from .base import ConvWeight, Marker
 from .mask_attention import MLP, SelfAttentionLayer, CrossAttentionLayer, FFNLayer
 
 
+def check_tokens(tokens):
+    """mask_attention.py:95-98: NaN queries mean an empty guidance mask poisoned the attention."""
+    if bool(torch.isnan(tokens).any()):
+        raise ValueError("Mask is empty")
+
+
 class InstanceMatteDecoder(nn.Module):
     def __init__(self, input_dim=256, atten_stride=1.0, attention_dim=256, n_block=2, n_head=4, output_dim=32, return_feat=True,
                  max_inst=10, use_temp_pe=True, use_id_pe=True):
@@ -113,6 +119,8 @@ class InstanceMatteDecoder(nn.Module):
         if self.training:
             max_loss = max_loss + self.compute_atten_loss(b, n_f, guidance_mask, att)
         max_loss = max_loss / (self.n_block + 1)
+        if not torch.cuda.is_current_stream_capturing():          # captured runs are checked by the graph owner after replay
+            check_tokens(tokens)
 
         feat = feat.to(dt).view(N, h, w, -1)
         hidden_state = None

@@ -12,6 +12,10 @@ projection weights and the ID position embedding into an (max_inst+1)-row lookup
 which is algebraically identical to nn.MultiheadAttention(q + pos_q, k + pos_k, v) and turns each block into one
 pass over the (L x 128) feature rows. The row-side math below is small fp32 torch plumbing; the kernels that matter
 (feature projection, 3x3 / 1x1 convolutions, BN) are HIP.
+
+The reference raises ValueError("Mask is empty") when a query/feature tensor holds NaN (mask_attention.py:95-98,129-132).
+NaNs propagate through every later block, so the check is made ONCE on the final tokens (InstanceMatteDecoder.forward; one
+host sync instead of five, and none inside a captured hipGraph).
 """
 import math
 
@@ -64,8 +68,6 @@ class CrossAttentionLayer(nn.Module):
     def tokens_from_features(self, tokens, token_pos, feat, feat_ids, id_table):
         """tokens (b,T,d) <- feat (b,L,d) with key position = id_table[feat_ids] ((b,L) long). Returns new tokens and the
         attention matrix (b,T,L)."""
-        if torch.isnan(tokens).any():
-            raise ValueError("Mask is empty")
         (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.multihead_attn)
         d = tokens.shape[-1]
         q = F.linear(tokens if token_pos is None else tokens + token_pos, wq, bq)            # (b,T,d)
@@ -83,8 +85,6 @@ class CrossAttentionLayer(nn.Module):
 
     def features_from_tokens(self, feat, feat_ids, id_table, tokens, token_pos, token_padding_mask):
         """feat (b,L,d) <- tokens (b,T,d); query position = id_table[feat_ids]."""
-        if torch.isnan(feat).any():
-            raise ValueError("Mask is empty")
         (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.multihead_attn)
         d = feat.shape[-1]
         k = F.linear(tokens if token_pos is None else tokens + token_pos, wk, bk)            # (b,T,d)
