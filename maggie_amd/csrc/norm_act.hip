@@ -13,77 +13,114 @@ namespace {
 constexpr int NT = 256;
 
 // ---------------------------------------------------------------------------------------------------
-// column statistics: stats[c] += sum_m x[m,c]; stats[C+c] += sum_m x[m,c]^2
+// Column reductions over a (M x C) row-major matrix. Grid = (row blocks, channel groups): a block owns TX 16-byte channel
+// chunks (<= 8, i.e. one 128-byte line of bf16) and TY = 256/TX row lanes, so deep layers (few rows, many channels) still
+// fill the chip. Per-thread register partials -> LDS [TY][TX*CE*NACC] -> one global atomicAdd per channel per block.
 // ---------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(NT) void colstats_kernel(const T* __restrict__ x, int M, int C, int ld, float* __restrict__ stats,
-                                                      int rows_per_block, int nrep, int only_sum) {
-    using TR = ElemTraits<T>;
-    constexpr int CE = TR::CE;
-    const int cpr = C / CE;                       // chunks per row (C % CE == 0)
-    const int t = threadIdx.x;
-    const int tpr = cpr < NT ? cpr : NT;          // threads used per row sweep
-    const int rstep = NT / tpr;
-    const int cc0 = t % tpr, rr = t / tpr;
-    extern __shared__ float sred[];               // [2*C]
-    for (int i = t; i < 2 * C; i += NT) sred[i] = 0.f;
-    __syncthreads();
-    const int mbeg = blockIdx.x * rows_per_block, mend = min(M, mbeg + rows_per_block);
-    if (rr < rstep) {
-        for (int cc = cc0; cc < cpr; cc += tpr) {
-            float s1[CE], s2[CE];
+struct ColGeom {
+    int tx, ty, groups, rb, rpb;
+};
+static inline ColGeom col_geom(int M, int C, int ce, int max_rb) {
+    ColGeom g;
+    const int cpr = C / ce;
+    g.tx = cpr < 8 ? cpr : 8;
+    g.ty = NT / g.tx;
+    g.groups = (cpr + g.tx - 1) / g.tx;
+    int want = 1024 / g.groups; if (want < 1) want = 1; if (want > max_rb) want = max_rb;
+    int rb = (M + g.ty * 4 - 1) / (g.ty * 4); if (rb < 1) rb = 1; if (rb > want) rb = want;
+    g.rpb = (M + rb - 1) / rb;
+    g.rb = (M + g.rpb - 1) / g.rpb;
+    return g;
+}
+
+template <int NV>
+__device__ __forceinline__ void col_block_reduce(float* sred, const float* part, int tx, int ty, int ix, int iy, bool active,
+                                                 float* __restrict__ dst0, float* __restrict__ dst1, int c_base, int C, int ce) {
+    // sred: [ty][tx*NV]; part: this thread's NV values (NV = ce * NACC, channel-major: [acc][e])
+    const int width = tx * NV;
+    if (active) {
 #pragma unroll
-            for (int e = 0; e < CE; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-            for (int m = mbeg + rr; m < mend; m += rstep) {
-                uint4 q = *(const uint4*)(x + (long)m * ld + cc * CE);
-                float f[CE];
-                TR::unpack(q, f);
-#pragma unroll
-                for (int e = 0; e < CE; ++e) { s1[e] += f[e]; s2[e] += f[e] * f[e]; }
-            }
-#pragma unroll
-            for (int e = 0; e < CE; ++e) { atomicAdd(&sred[cc * CE + e], s1[e]); atomicAdd(&sred[C + cc * CE + e], s2[e]); }
-        }
+        for (int k = 0; k < NV; ++k) sred[iy * width + ix * NV + k] = part[k];
     }
     __syncthreads();
+    for (int j = threadIdx.x; j < width; j += NT) {
+        float acc = 0.f;
+        for (int r = 0; r < ty; ++r) acc += sred[r * width + j];
+        const int cx = j / NV, k = j - cx * NV, a = k / ce, e = k - a * ce;
+        const int c = c_base + cx * ce + e;
+        if (c < C) atomicAdd((a == 0 ? dst0 : dst1) + c, acc);
+    }
+}
+
+// column statistics: stats[c] += sum_m x[m,c]; stats[C+c] += sum_m x[m,c]^2
+template <typename T>
+__global__ __launch_bounds__(NT) void colstats_kernel(const T* __restrict__ x, int M, int C, int ld, float* __restrict__ stats,
+                                                      int rows_per_block, int nrep, int only_sum, int tx, int ty) {
+    using TR = ElemTraits<T>;
+    constexpr int CE = TR::CE;
+    extern __shared__ float sred[];
+    const int ix = threadIdx.x % tx, iy = threadIdx.x / tx;
+    const int cc = blockIdx.y * tx + ix;
+    const bool active = iy < ty && cc * CE < C;
+    float part[2 * CE];
+#pragma unroll
+    for (int k = 0; k < 2 * CE; ++k) part[k] = 0.f;
+    const int mbeg = blockIdx.x * rows_per_block, mend = min(M, mbeg + rows_per_block);
+    if (active) {
+        const T* xp = x + cc * CE;
+        int m = mbeg + iy;
+        for (; m + ty < mend; m += 2 * ty) {                 // two independent loads in flight
+            float f0[CE], f1[CE];
+            TR::unpack(*(const uint4*)(xp + (long)m * ld), f0);
+            TR::unpack(*(const uint4*)(xp + (long)(m + ty) * ld), f1);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) { part[e] += f0[e] + f1[e]; part[CE + e] += f0[e] * f0[e] + f1[e] * f1[e]; }
+        }
+        if (m < mend) {
+            float f0[CE];
+            TR::unpack(*(const uint4*)(xp + (long)m * ld), f0);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) { part[e] += f0[e]; part[CE + e] += f0[e] * f0[e]; }
+        }
+    }
     float* st = stats + (size_t)(blockIdx.x & (nrep - 1)) * 2 * C;
-    const int lim = only_sum ? C : 2 * C;
-    for (int i = t; i < lim; i += NT) atomicAdd(&st[i], sred[i]);
+    if (only_sum) col_block_reduce<CE>(sred, part, tx, ty, ix, iy, active, st, st, blockIdx.y * tx * CE, C, CE);
+    else col_block_reduce<2 * CE>(sred, part, tx, ty, ix, iy, active, st, st + C, blockIdx.y * tx * CE, C, CE);
 }
 
 // second pass of the exact two-pass variance: stats[C+c] += sum_m (x[m,c] - stats[c]/M)^2   (stats[0:C] = column sums)
 template <typename T>
 __global__ __launch_bounds__(NT) void colstats_centered_kernel(const T* __restrict__ x, int M, int C, int ld, float* __restrict__ stats,
-                                                               int rows_per_block) {
+                                                               int rows_per_block, int tx, int ty) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
-    const int cpr = C / CE;
-    const int t = threadIdx.x;
-    const int tpr = cpr < NT ? cpr : NT;
-    const int rstep = NT / tpr;
-    const int cc0 = t % tpr, rr = t / tpr;
-    extern __shared__ float sred[];               // [C]
-    for (int i = t; i < C; i += NT) sred[i] = 0.f;
-    __syncthreads();
+    extern __shared__ float sred[];
+    const int ix = threadIdx.x % tx, iy = threadIdx.x / tx;
+    const int cc = blockIdx.y * tx + ix;
+    const bool active = iy < ty && cc * CE < C;
+    float part[CE], mu[CE];
     const float inv_m = 1.f / (float)M;
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { part[e] = 0.f; mu[e] = active ? stats[cc * CE + e] * inv_m : 0.f; }
     const int mbeg = blockIdx.x * rows_per_block, mend = min(M, mbeg + rows_per_block);
-    if (rr < rstep) {
-        for (int cc = cc0; cc < cpr; cc += tpr) {
-            float s2[CE], mu[CE];
+    if (active) {
+        const T* xp = x + cc * CE;
+        int m = mbeg + iy;
+        for (; m + ty < mend; m += 2 * ty) {
+            float f0[CE], f1[CE];
+            TR::unpack(*(const uint4*)(xp + (long)m * ld), f0);
+            TR::unpack(*(const uint4*)(xp + (long)(m + ty) * ld), f1);
 #pragma unroll
-            for (int e = 0; e < CE; ++e) { s2[e] = 0.f; mu[e] = stats[cc * CE + e] * inv_m; }
-            for (int m = mbeg + rr; m < mend; m += rstep) {
-                float f[CE];
-                TR::unpack(*(const uint4*)(x + (long)m * ld + cc * CE), f);
+            for (int e = 0; e < CE; ++e) { float d0 = f0[e] - mu[e], d1 = f1[e] - mu[e]; part[e] += d0 * d0 + d1 * d1; }
+        }
+        if (m < mend) {
+            float f0[CE];
+            TR::unpack(*(const uint4*)(xp + (long)m * ld), f0);
 #pragma unroll
-                for (int e = 0; e < CE; ++e) { float d = f[e] - mu[e]; s2[e] += d * d; }
-            }
-#pragma unroll
-            for (int e = 0; e < CE; ++e) atomicAdd(&sred[cc * CE + e], s2[e]);
+            for (int e = 0; e < CE; ++e) { float d0 = f0[e] - mu[e]; part[e] += d0 * d0; }
         }
     }
-    __syncthreads();
-    for (int i = t; i < C; i += NT) atomicAdd(&stats[C + i], sred[i]);
+    col_block_reduce<CE>(sred, part, tx, ty, ix, iy, active, stats + C, stats + C, blockIdx.y * tx * CE, C, CE);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -193,34 +230,45 @@ __device__ __forceinline__ void load_g(const mg_rowwise_params& p, int m, int c0
 }
 
 template <typename T>
-__global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const mg_rowwise_params p, int rows_per_block) {
+__global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const mg_rowwise_params p, int rows_per_block, int tx, int ty) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
-    const int C = p.C, cpr = C / CE, t = threadIdx.x;
-    const int tpr = cpr < NT ? cpr : NT, rstep = NT / tpr, cc0 = t % tpr, rr = t / tpr;
     extern __shared__ float sred[];
-    for (int i = t; i < 2 * C; i += NT) sred[i] = 0.f;
-    __syncthreads();
+    const int C = p.C;
+    const int ix = threadIdx.x % tx, iy = threadIdx.x / tx;
+    const int cc = blockIdx.y * tx + ix;
+    const bool active = iy < ty && cc * CE < C;
+    const int c0 = cc * CE;
+    float part[2 * CE], mu[CE], is[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+        part[e] = 0.f; part[CE + e] = 0.f;
+        mu[e] = active ? p.mean[c0 + e] : 0.f; is[e] = active ? p.invstd[c0 + e] : 0.f;
+    }
     const int mbeg = blockIdx.x * rows_per_block, mend = min(p.M, mbeg + rows_per_block);
-    if (rr < rstep) {
-        for (int cc = cc0; cc < cpr; cc += tpr) {
-            const int c0 = cc * CE;
-            float s1[CE], s2[CE], mu[CE], is[CE];
+    if (active) {
+        int m = mbeg + iy;
+        for (; m + ty < mend; m += 2 * ty) {                 // two independent row groups in flight
+            float g0[CE], g1[CE], x0[CE], x1[CE];
+            load_g<T>(p, m, c0, g0);
+            load_g<T>(p, m + ty, c0, g1);
+            TR::unpack(*(const uint4*)((const T*)p.x + (long)m * p.ldx + c0), x0);
+            TR::unpack(*(const uint4*)((const T*)p.x + (long)(m + ty) * p.ldx + c0), x1);
 #pragma unroll
-            for (int e = 0; e < CE; ++e) { s1[e] = 0.f; s2[e] = 0.f; mu[e] = p.mean[c0 + e]; is[e] = p.invstd[c0 + e]; }
-            for (int m = mbeg + rr; m < mend; m += rstep) {
-                float g[CE], xv[CE];
-                load_g<T>(p, m, c0, g);
-                TR::unpack(*(const uint4*)((const T*)p.x + (long)m * p.ldx + c0), xv);
-#pragma unroll
-                for (int e = 0; e < CE; ++e) { s1[e] += g[e]; s2[e] += g[e] * (xv[e] - mu[e]) * is[e]; }
+            for (int e = 0; e < CE; ++e) {
+                part[e] += g0[e] + g1[e];
+                part[CE + e] += (g0[e] * (x0[e] - mu[e]) + g1[e] * (x1[e] - mu[e])) * is[e];
             }
+        }
+        if (m < mend) {
+            float g0[CE], x0[CE];
+            load_g<T>(p, m, c0, g0);
+            TR::unpack(*(const uint4*)((const T*)p.x + (long)m * p.ldx + c0), x0);
 #pragma unroll
-            for (int e = 0; e < CE; ++e) { atomicAdd(&sred[c0 + e], s1[e]); atomicAdd(&sred[C + c0 + e], s2[e]); }
+            for (int e = 0; e < CE; ++e) { part[e] += g0[e]; part[CE + e] += g0[e] * (x0[e] - mu[e]) * is[e]; }
         }
     }
-    __syncthreads();
-    for (int i = t; i < 2 * C; i += NT) atomicAdd(&p.sums[i], sred[i]);
+    col_block_reduce<2 * CE>(sred, part, tx, ty, ix, iy, active, p.sums, p.sums + C, blockIdx.y * tx * CE, C, CE);
 }
 
 template <typename T>
@@ -305,12 +353,11 @@ extern "C" int mg_colstats(const void* x, int dtype, int M, int C, int ld, float
     if (M <= 0) return 0;
     const int ce = dtype == MG_BF16 ? 8 : 4;
     if (C % ce || ld % ce) return -3;
-    int blocks = (M + 255) / 256; if (blocks > 1024) blocks = 1024;
-    int rpb = (M + blocks - 1) / blocks;
-    blocks = (M + rpb - 1) / rpb;
+    const ColGeom g = col_geom(M, C, ce, 1024);
+    const size_t lds = (size_t)g.ty * g.tx * 2 * ce * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MG_BF16) hipLaunchKernelGGL(colstats_kernel<bf16raw>, dim3(blocks), dim3(NT), 2 * C * 4, st, (const bf16raw*)x, M, C, ld, stats, rpb, MG_STAT_REPLICAS, 0);
-    else hipLaunchKernelGGL(colstats_kernel<float>, dim3(blocks), dim3(NT), 2 * C * 4, st, (const float*)x, M, C, ld, stats, rpb, MG_STAT_REPLICAS, 0);
+    if (dtype == MG_BF16) hipLaunchKernelGGL(colstats_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const bf16raw*)x, M, C, ld, stats, g.rpb, MG_STAT_REPLICAS, 0, g.tx, g.ty);
+    else hipLaunchKernelGGL(colstats_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const float*)x, M, C, ld, stats, g.rpb, MG_STAT_REPLICAS, 0, g.tx, g.ty);
     MG_CHECK_LAUNCH();
     return 0;
 }
@@ -319,18 +366,17 @@ extern "C" int mg_colstats_centered(const void* x, int dtype, int M, int C, int 
     if (M <= 0) return 0;
     const int ce = dtype == MG_BF16 ? 8 : 4;
     if (C % ce || ld % ce) return -3;
-    int blocks = (M + 255) / 256; if (blocks > 1024) blocks = 1024;
-    int rpb = (M + blocks - 1) / blocks;
-    blocks = (M + rpb - 1) / rpb;
+    const ColGeom g = col_geom(M, C, ce, 256);
+    const size_t lds = (size_t)g.ty * g.tx * 2 * ce * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     // `stats` must arrive zeroed (the caller hands out slices of a per-step zero arena): pass 1 adds the column sums only,
     // pass 2 the centred second moments
     if (dtype == MG_BF16) {
-        hipLaunchKernelGGL(colstats_kernel<bf16raw>, dim3(blocks), dim3(NT), 2 * C * 4, st, (const bf16raw*)x, M, C, ld, stats, rpb, 1, 1);
-        hipLaunchKernelGGL(colstats_centered_kernel<bf16raw>, dim3(blocks), dim3(NT), C * 4, st, (const bf16raw*)x, M, C, ld, stats, rpb);
+        hipLaunchKernelGGL(colstats_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const bf16raw*)x, M, C, ld, stats, g.rpb, 1, 1, g.tx, g.ty);
+        hipLaunchKernelGGL(colstats_centered_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const bf16raw*)x, M, C, ld, stats, g.rpb, g.tx, g.ty);
     } else {
-        hipLaunchKernelGGL(colstats_kernel<float>, dim3(blocks), dim3(NT), 2 * C * 4, st, (const float*)x, M, C, ld, stats, rpb, 1, 1);
-        hipLaunchKernelGGL(colstats_centered_kernel<float>, dim3(blocks), dim3(NT), C * 4, st, (const float*)x, M, C, ld, stats, rpb);
+        hipLaunchKernelGGL(colstats_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const float*)x, M, C, ld, stats, g.rpb, 1, 1, g.tx, g.ty);
+        hipLaunchKernelGGL(colstats_centered_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const float*)x, M, C, ld, stats, g.rpb, g.tx, g.ty);
     }
     MG_CHECK_LAUNCH();
     return 0;
@@ -374,12 +420,11 @@ extern "C" int mg_affine_act(const mg_rowwise_params* p, void* stream) {
 extern "C" int mg_bn_bwd_reduce(const mg_rowwise_params* p, void* stream) {
     int rc = rowwise_check(p); if (rc) return rc;
     if (p->M <= 0) return 0;
-    // every block ends with 2C global atomics on the same 2C addresses: keep the block count near 2 per CU
-    int blocks = (p->M + 255) / 256; if (blocks > 512) blocks = 512;
-    int rpb = (p->M + blocks - 1) / blocks;
-    blocks = (p->M + rpb - 1) / rpb;
-    if (p->dtype == MG_BF16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16raw>, dim3(blocks), dim3(NT), 2 * p->C * 4, (hipStream_t)stream, *p, rpb);
-    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(blocks), dim3(NT), 2 * p->C * 4, (hipStream_t)stream, *p, rpb);
+    const int ce = p->dtype == MG_BF16 ? 8 : 4;
+    const ColGeom g = col_geom(p->M, p->C, ce, 512);
+    const size_t lds = (size_t)g.ty * g.tx * 2 * ce * sizeof(float);
+    if (p->dtype == MG_BF16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty);
+    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty);
     MG_CHECK_LAUNCH();
     return 0;
 }

@@ -391,7 +391,9 @@ class BNAct(torch.autograd.Function):
                 dist.all_reduce(sums, group=group)
             dx, dres, sums = K.bn_backward(dy2, y, x2, scale, mean, invstd, M, act=act, slope=LRELU_SLOPE, want_dres=has_res,
                                            mask_x_pos=mask_x_pos, sums=sums, apply_only=True, count_ptr=cnt_t)
-            dgamma, dbeta = sums[C:2 * C][:nch].clone(), sums[:C][:nch].clone()
+            if not torch.cuda.is_current_stream_capturing():
+                sums = sums.clone()              # the arena slice dies with the step; inside a graph it is the graph's own
+            dgamma, dbeta = sums[C:2 * C][:nch], sums[:C][:nch]
         else:
             # eval statistics are constants: dx = g * scale
             zeros = torch.zeros(2 * C, dtype=torch.float32, device=dy.device)
