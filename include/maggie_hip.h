@@ -61,6 +61,7 @@ typedef struct mg_conv_params {
     int32_t ldx, ldy, yoff, ldr, ldr2;
     int32_t act, pre_act, res_mode; /* res_mode: 1 = same rows, 2 = residual at half resolution (nearest x2) */
     float slope;
+    int32_t dw_dtype;    /* mg_conv_wgrad_ws only: dtype dW is written in (MG_F32 = 0 default, MG_BF16 needs a workspace) */
 } mg_conv_params;
 
 int mg_conv_fprop(const mg_conv_params* p, void* stream);

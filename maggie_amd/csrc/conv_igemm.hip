@@ -85,11 +85,13 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
     int a_tap = a_k / p.Cin;
     int a_ci = a_k - a_tap * p.Cin;
 
-    uint4 ra[KS][A_ROWS], rb[KS][B_ITERS];
+    // register prefetch depth: PF stages of loads in flight per thread
+    constexpr int PF = 1;           // measured (PMC): waves are parked ~40% / issuing ~40% per stage; deeper prefetch only costs registers
+    uint4 ra[PF][KS][A_ROWS], rb[PF][KS][B_ITERS];
     const int invS = (65536 + p.S - 1) / p.S;                       // tap / S == (tap * invS) >> 16 for tap < 256
     const int sshift = p.stride == 1 ? 0 : (p.stride == 2 ? 1 : (p.stride == 4 ? 2 : -1));
 
-    auto load_stage = [&](int s) {
+    auto load_stage = [&](int s, int u) {
         int tap = a_tap, ci = a_ci;
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
@@ -117,8 +119,8 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
                         src = p.nbr[(long)rc[i].n * taps + tap];
                     }
                 }
-                if (src >= 0) ra[j][i] = *(const uint4*)(xb + (src * p.ldx + ci) * (long)sizeof(T));
-                else ra[j][i] = make_uint4(0, 0, 0, 0);
+                if (src >= 0) ra[u][j][i] = *(const uint4*)(xb + (src * p.ldx + ci) * (long)sizeof(T));
+                else ra[u][j][i] = make_uint4(0, 0, 0, 0);
             }
             // B operand (weights, K-contiguous)
 #pragma unroll
@@ -127,24 +129,81 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
                 int co = idx >> 2, c = idx & 3;
                 int k0 = (s * KS + j) * EPS + c * CE;
                 if (idx < BN * 4 && (n0 + co) < p.Cout && k0 < Ktot)
-                    rb[j][i] = *(const uint4*)(wb + ((long)(n0 + co) * Ktot + k0) * (long)sizeof(T));
-                else rb[j][i] = make_uint4(0, 0, 0, 0);
+                    rb[u][j][i] = *(const uint4*)(wb + ((long)(n0 + co) * Ktot + k0) * (long)sizeof(T));
+                else rb[u][j][i] = make_uint4(0, 0, 0, 0);
             }
             ci += EPS;
             while (ci >= p.Cin) { ci -= p.Cin; ++tap; }
         }
         a_tap = tap; a_ci = ci;
     };
-    auto store_stage = [&]() {
+    // ---- aligned fast path (Cin % EPS == 0: every 64-byte K slab lies inside ONE filter tap) ----------------------
+    // The tap walk (tap, ky, kx, channel offset) is then uniform over the block and lives in SGPRs; per (row, slab) the
+    // vector work is two adds, two unsigned range checks, one address mad. The generic path above costs ~25 VALU + ~15
+    // SALU per load and made the stage loop issue-bound (16 MFMAs against ~340 ALU instructions per stage).
+    const bool al = (p.Cin % EPS == 0) && (MODE != MG_MODE_TCONV || sshift >= 0);
+    int hb[A_ROWS], wbs[A_ROWS], rbase[A_ROWS];
+    const char* bptr[B_ITERS];
+    bool bok[B_ITERS];
+#pragma unroll
+    for (int i = 0; i < A_ROWS; ++i) {
+        if (MODE == MG_MODE_CONV) { hb[i] = rc[i].ho * p.stride - p.pad; wbs[i] = rc[i].wo * p.stride - p.pad; }
+        else { hb[i] = rc[i].ho + p.pad; wbs[i] = rc[i].wo + p.pad; }
+        rbase[i] = (MODE == MG_MODE_GATHER) ? rc[i].n * taps : rc[i].n * p.Hin;
+    }
+#pragma unroll
+    for (int i = 0; i < B_ITERS; ++i) {
+        int idx = t + i * 256;
+        int co = idx >> 2, c = idx & 3;
+        bok[i] = idx < BN * 4 && (n0 + co) < p.Cout;
+        bptr[i] = wb + ((long)(n0 + (bok[i] ? co : 0)) * Ktot + c * CE) * (long)sizeof(T);
+    }
+    const int spt = p.Cin / EPS;             // slabs per tap (aligned path)
+    int q_slab = 0, q_sub = 0, q_ky = 0, q_kx = 0, q_tap = 0;
+    auto load_stage_al = [&](int u) {
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            const bool live = q_slab < nslab;
+            const int dh = q_ky * p.dil, dw = q_kx * p.dil;
+            const long coff = ((long)q_sub * EPS + a_c * CE) * (long)sizeof(T);
+#pragma unroll
+            for (int i = 0; i < A_ROWS; ++i) {
+                long src = -1;
+                if (MODE == MG_MODE_CONV) {
+                    const int hi = hb[i] + dh, wi = wbs[i] + dw;
+                    if ((unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win) src = (long)(rbase[i] + hi) * p.Win + wi;
+                } else if (MODE == MG_MODE_TCONV) {
+                    const int th = hb[i] - dh, tw = wbs[i] - dw;
+                    const int hi = th >> sshift, wi = tw >> sshift;
+                    if (th >= 0 && tw >= 0 && ((th | tw) & (p.stride - 1)) == 0 && hi < p.Hin && wi < p.Win)
+                        src = (long)(rbase[i] + hi) * p.Win + wi;
+                } else {
+                    if (rc[i].ok && live) src = p.nbr[(long)rbase[i] + q_tap];
+                }
+                if (src >= 0 && rc[i].ok && live) ra[u][j][i] = *(const uint4*)(xb + src * ((long)p.ldx * (long)sizeof(T)) + coff);
+                else ra[u][j][i] = make_uint4(0, 0, 0, 0);
+            }
+            const long boff = (long)q_slab * EPS * (long)sizeof(T);
+#pragma unroll
+            for (int i = 0; i < B_ITERS; ++i) {
+                if (bok[i] && live) rb[u][j][i] = *(const uint4*)(bptr[i] + boff);
+                else rb[u][j][i] = make_uint4(0, 0, 0, 0);
+            }
+            ++q_slab;
+            if (++q_sub == spt) { q_sub = 0; ++q_tap; if (++q_kx == p.S) { q_kx = 0; ++q_ky; } }
+        }
+    };
+
+    auto store_stage = [&](int u) {
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
 #pragma unroll
             for (int i = 0; i < A_ROWS; ++i)
-                *(uint4*)(sA + ((t >> 2) + i * 64) * ROWB + j * 64 + a_c * 16) = ra[j][i];
+                *(uint4*)(sA + ((t >> 2) + i * 64) * ROWB + j * 64 + a_c * 16) = ra[u][j][i];
 #pragma unroll
             for (int i = 0; i < B_ITERS; ++i) {
                 int idx = t + i * 256;
-                if (idx < BN * 4) *(uint4*)(sB + (idx >> 2) * ROWB + j * 64 + (idx & 3) * 16) = rb[j][i];
+                if (idx < BN * 4) *(uint4*)(sB + (idx >> 2) * ROWB + j * 64 + (idx & 3) * 16) = rb[u][j][i];
             }
         }
     };
@@ -159,33 +218,41 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
 
     const char* a_base = sA + (wm * WM + lr) * ROWB + lg * 16;
     const char* b_base = sB + (wn * WN + lr) * ROWB + lg * 16;
-    load_stage(0);
-    for (int s = 0; s < nstage; ++s) {
-        store_stage();
-        __syncthreads();
-        if (s + 1 < nstage) load_stage(s + 1);
 #pragma unroll
-        for (int j = 0; j < KS; ++j) {
-            uint4 fa[FM], fb[FN];
+    for (int u = 0; u < PF; ++u)
+        if (u < nstage) { if (al) load_stage_al(u); else load_stage(u, u); }
+    for (int s0 = 0; s0 < nstage; s0 += PF) {
 #pragma unroll
-            for (int i = 0; i < FM; ++i) fa[i] = *(const uint4*)(a_base + i * 16 * ROWB + j * 64);
-#pragma unroll
-            for (int i = 0; i < FN; ++i) fb[i] = *(const uint4*)(b_base + i * 16 * ROWB + j * 64);
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int jj = 0; jj < FN; ++jj) {
-                    if constexpr (sizeof(T) == 2) {
-                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&fa[i], *(const bf16x8*)&fb[jj], acc[i][jj], 0, 0, 0);
-                    } else {
-                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i].x), __uint_as_float(fb[jj].x), acc[i][jj], 0, 0, 0);
-                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i].y), __uint_as_float(fb[jj].y), acc[i][jj], 0, 0, 0);
-                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i].z), __uint_as_float(fb[jj].z), acc[i][jj], 0, 0, 0);
-                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i].w), __uint_as_float(fb[jj].w), acc[i][jj], 0, 0, 0);
-                    }
+        for (int u = 0; u < PF; ++u) {                 // fully unrolled: `u` is a compile-time register-bank index
+            const int s = s0 + u;
+            if (s < nstage) {
+                store_stage(u);
+                __syncthreads();
+                if (s + PF < nstage) { if (al) load_stage_al(u); else load_stage(s + PF, u); }
+        #pragma unroll
+                for (int j = 0; j < KS; ++j) {
+                    uint4 fa[FM], fb[FN];
+        #pragma unroll
+                    for (int i = 0; i < FM; ++i) fa[i] = *(const uint4*)(a_base + i * 16 * ROWB + j * 64);
+        #pragma unroll
+                    for (int i = 0; i < FN; ++i) fb[i] = *(const uint4*)(b_base + i * 16 * ROWB + j * 64);
+        #pragma unroll
+                    for (int i = 0; i < FM; ++i)
+        #pragma unroll
+                        for (int jj = 0; jj < FN; ++jj) {
+                            if constexpr (sizeof(T) == 2) {
+                                acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&fa[i], *(const bf16x8*)&fb[jj], acc[i][jj], 0, 0, 0);
+                            } else {
+                                acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i].x), __uint_as_float(fb[jj].x), acc[i][jj], 0, 0, 0);
+                                acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i].y), __uint_as_float(fb[jj].y), acc[i][jj], 0, 0, 0);
+                                acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i].z), __uint_as_float(fb[jj].z), acc[i][jj], 0, 0, 0);
+                                acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i].w), __uint_as_float(fb[jj].w), acc[i][jj], 0, 0, 0);
+                            }
+                        }
                 }
+                __syncthreads();
+            }
         }
-        __syncthreads();
     }
 
     // ---------------- epilogue: accumulators -> fp32 LDS tile -> vectorised global stores ----------------
@@ -552,7 +619,8 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const mg_conv_params p
     }
 }
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, long n, float* __restrict__ dw) {
+template <typename TO>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, long n, TO* __restrict__ dw) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         int s = 0;
@@ -560,18 +628,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
             a0 += ws[(long)s * n + i]; a1 += ws[(long)(s + 1) * n + i]; a2 += ws[(long)(s + 2) * n + i]; a3 += ws[(long)(s + 3) * n + i];
         }
         for (; s < splits; ++s) a0 += ws[(long)s * n + i];
-        dw[i] = (a0 + a1) + (a2 + a3);
+        ElemTraits<TO>::st(dw + i, (a0 + a1) + (a2 + a3));
     }
 }
 
 // many splits x few elements: one wave per element, lanes stride over the splits
-__global__ __launch_bounds__(256) void wgrad_reduce_wave_kernel(const float* __restrict__ ws, int splits, long n, float* __restrict__ dw) {
+template <typename TO>
+__global__ __launch_bounds__(256) void wgrad_reduce_wave_kernel(const float* __restrict__ ws, int splits, long n, TO* __restrict__ dw) {
     const int lane = threadIdx.x & 63;
     for (long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (long)gridDim.x * 4) {
         float a = 0.f;
         for (int s = lane; s < splits; s += 64) a += ws[(long)s * n + i];
         a = wave_sum(a);
-        if (lane == 0) dw[i] = a;
+        if (lane == 0) ElemTraits<TO>::st(dw + i, a);
     }
 }
 
@@ -611,10 +680,12 @@ int launch_wgrad(const mg_conv_params& p, float* ws, long ws_floats, hipStream_t
     const int nci = (p.Cin + TCI - 1) / TCI, nco = (p.Cout + TCO - 1) / TCO;
     WgradPlan pl = plan_wgrad<T, TCO, TCI>(p);
     const long n = (long)p.Cout * taps * p.Cin;
+    const bool out_bf16 = p.dw_dtype == MG_BF16;                   // dW in bf16: always partials -> (converting) reduce
     float* use_ws = nullptr;
-    if (pl.splits > 1 && ws && ws_floats >= pl.splits * n) use_ws = ws;
+    if ((pl.splits > 1 || out_bf16) && ws && ws_floats >= pl.splits * n) use_ws = ws;
+    if (out_bf16 && !use_ws) return -4;
     mg_conv_params q = p;
-    if (pl.splits == 1) use_ws = p.stats;                          // single split: the "slab" is dW itself (no atomics, no reduce)
+    if (pl.splits == 1 && !out_bf16) use_ws = p.stats;             // single split: the "slab" is dW itself (no atomics, no reduce)
     dim3 grid((unsigned)pl.splits, (unsigned)(taps * nci), (unsigned)nco);
     size_t stage = (size_t)KSTEP * (TCO + PAD + TCI + PAD) * sizeof(T);
     size_t red = (size_t)4 * TCO * (TCI + 1) * 4;
@@ -625,13 +696,15 @@ int launch_wgrad(const mg_conv_params& p, float* ws, long ws_floats, hipStream_t
         case MG_MODE_GATHER: hipLaunchKernelGGL((igemm_wgrad_kernel<T, TCO, TCI, MG_MODE_GATHER>), grid, dim3(256), lds, st, q, pl.rpb, use_ws); break;
         default: return -2;
     }
-    if (use_ws && pl.splits > 1) {
+    if (use_ws && (pl.splits > 1 || out_bf16)) {
         if (pl.splits > 32 && n <= (1l << 16)) {
             long b = (n + 3) / 4; if (b > 8192) b = 8192;
-            hipLaunchKernelGGL(wgrad_reduce_wave_kernel, dim3((unsigned)b), dim3(256), 0, st, use_ws, (int)pl.splits, n, p.stats);
+            if (out_bf16) hipLaunchKernelGGL(wgrad_reduce_wave_kernel<bf16raw>, dim3((unsigned)b), dim3(256), 0, st, use_ws, (int)pl.splits, n, (bf16raw*)p.stats);
+            else hipLaunchKernelGGL(wgrad_reduce_wave_kernel<float>, dim3((unsigned)b), dim3(256), 0, st, use_ws, (int)pl.splits, n, p.stats);
         } else {
             long b = (n + 255) / 256; if (b > 2048) b = 2048;
-            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)b), dim3(256), 0, st, use_ws, (int)pl.splits, n, p.stats);
+            if (out_bf16) hipLaunchKernelGGL(wgrad_reduce_kernel<bf16raw>, dim3((unsigned)b), dim3(256), 0, st, use_ws, (int)pl.splits, n, (bf16raw*)p.stats);
+            else hipLaunchKernelGGL(wgrad_reduce_kernel<float>, dim3((unsigned)b), dim3(256), 0, st, use_ws, (int)pl.splits, n, p.stats);
         }
     }
     MG_CHECK_LAUNCH();
@@ -644,7 +717,7 @@ int dispatch_wgrad(const mg_conv_params& p, float* ws, long ws_floats, long* nee
     const long n = (long)p.Cout * p.R * p.S * p.Cin;
 #define MG_WG(TCO, TCI)                                                                             \
     do {                                                                                            \
-        if (need) { WgradPlan pl = plan_wgrad<T, TCO, TCI>(p); *need = pl.splits > 1 ? pl.splits * n : 0; return 0; } \
+        if (need) { WgradPlan pl = plan_wgrad<T, TCO, TCI>(p); *need = (pl.splits > 1 || p.dw_dtype == MG_BF16) ? pl.splits * n : 0; return 0; } \
         return launch_wgrad<T, TCO, TCI>(p, ws, ws_floats, st);                                     \
     } while (0)
     if (small_co && small_ci) MG_WG(32, 32);

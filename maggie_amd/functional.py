@@ -300,13 +300,12 @@ class ConvRaw(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if not transposed:
                 dw = K.conv_wgrad(x.view(-1, Cin), dy2, cout=Cout, mode=MODE_CONV, N=N, Hin=H, Win=W_, Hout=Ho, Wout=Wo,
-                                  R=R, S=S, stride=stride, pad=pad, dil=dil)
+                                  R=R, S=S, stride=stride, pad=pad, dil=dil, out_dtype=w.dtype)
             else:
                 # dW[ci, tap, co] = sum_o x[o, ci] * dy[2o - pad + k, co]  (roles of x and dy swapped)
                 dwt = K.conv_wgrad(dy2, x.view(-1, Cin), cout=Cin, mode=MODE_CONV, N=N, Hin=Ho, Win=Wo, Hout=H, Wout=W_,
-                                   R=R, S=S, stride=stride, pad=pad, dil=dil)
+                                   R=R, S=S, stride=stride, pad=pad, dil=dil, out_dtype=w.dtype)
                 dw = dwt.permute(2, 1, 0).contiguous()
-            dw = dw.to(w.dtype)
         if has_bias and ctx.needs_input_grad[2]:
             db = dy2.float().sum(0)
         return dx, dw, db, None, None, None, None, None, None, None, None
@@ -486,7 +485,7 @@ class GatherConv(torch.autograd.Function):
             wt = wt.contiguous()
             dx = K.conv_fprop(dy, wt, mode=MODE_GATHER, nbr=nbr_t, R=ksize, S=ksize)
         if ctx.needs_input_grad[1]:
-            dw = K.conv_wgrad(x, dy, cout=Cout, mode=MODE_GATHER, nbr=nbr, R=ksize, S=ksize).to(w.dtype)
+            dw = K.conv_wgrad(x, dy, cout=Cout, mode=MODE_GATHER, nbr=nbr, R=ksize, S=ksize, out_dtype=w.dtype)
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.float().sum(0)
         return dx, dw, db, None, None, None, None, None, None

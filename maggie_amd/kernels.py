@@ -77,9 +77,10 @@ def conv_fprop(x, w, *, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=None, Wout=None,
 
 
 def conv_wgrad(x, dy, *, cout, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=1, Wout=1, R=1, S=1, stride=1, pad=0, dil=1,
-               M=None, nbr=None, yoff=0, out=None):
-    """dW[co, tap, ci] = sum_m dY[m, co] X[src(m,tap), ci]; fp32 (Cout, R*S, Cin). `dy` may be a channel slice
-    (yoff) of a wider buffer."""
+               M=None, nbr=None, yoff=0, out=None, out_dtype=torch.float32):
+    """dW[co, tap, ci] = sum_m dY[m, co] X[src(m,tap), ci]; (Cout, R*S, Cin) accumulated in fp32 and written as
+    `out_dtype` (fp32 / bf16 -- the converting reduce saves a separate cast pass). `dy` may be a channel slice (yoff) of
+    a wider buffer."""
     Cin = x.shape[-1]
     if mode == MODE_GATHER:
         M = nbr.shape[0] if M is None else M
@@ -87,13 +88,16 @@ def conv_wgrad(x, dy, *, cout, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=1, Wout=1
         M = N * Hout * Wout
     assert dy.dtype == x.dtype
     p = _conv_params(x, None, dy, mode, N, Hin, Win, Hout, Wout, R, S, stride, pad, dil, M, Cin, cout, nbr, yoff=yoff)
+    if out is not None:
+        out_dtype = out.dtype
+    p.dw_dtype = hip.BF16 if out_dtype == torch.bfloat16 else hip.F32
     lib = hip.lib()
     lib.mg_conv_wgrad_workspace.restype = ctypes.c_long
     need = lib.mg_conv_wgrad_workspace(ctypes.byref(p)) if M > 0 else 0
     if out is None:
         # with a workspace (or a single row split) dW is overwritten; only the (rare) atomic fallback needs zeros
-        out = torch.empty((cout, R * S, Cin), dtype=torch.float32, device=x.device) if M > 0 else \
-            torch.zeros((cout, R * S, Cin), dtype=torch.float32, device=x.device)
+        out = torch.empty((cout, R * S, Cin), dtype=out_dtype, device=x.device) if M > 0 else \
+            torch.zeros((cout, R * S, Cin), dtype=out_dtype, device=x.device)
     ws = _wgrad_workspace(need, x.device) if need > 0 else None
     p.stats = hip.ptr(out)
     hip.call('mg_conv_wgrad_ws', ctypes.byref(p), hip.ptr(ws), ctypes.c_long(need if ws is not None else 0), hip.stream(),

@@ -108,17 +108,20 @@ class InstanceMatteDecoder(nn.Module):
         pos_t = token_pos if self.use_id_pe else None
         tbl = id_table if self.use_id_pe else None
 
-        for i in range(self.n_block):
-            tokens, att = self.token_feat_ca_layers[i].tokens_from_features(tokens, pos_t, feat, feat_ids, tbl)
+        # The attention blocks run in fp32 with autocast OFF: every operand is a small fp32 tensor (10 tokens per sample, one
+        # (L x 128) feature matrix), so autocast would only add a cast kernel per operand per op (~250 launches per step)
+        with torch.autocast('cuda', enabled=False):
+            for i in range(self.n_block):
+                tokens, att = self.token_feat_ca_layers[i].tokens_from_features(tokens, pos_t, feat, feat_ids, tbl)
+                if self.training:
+                    max_loss = max_loss + self.compute_atten_loss(b, n_f, guidance_mask, att)
+                tokens = self.mlp_layers[i](tokens)
+                tokens = self.sa_layers[i](tokens, tgt_key_padding_mask=token_padding_mask, query_pos=token_pos)
+                feat = self.feat_token_ca_layers[i].features_from_tokens(feat, feat_ids, tbl, tokens, pos_t, token_padding_mask)
+            tokens, att = self.final_token_feat_ca.tokens_from_features(tokens, token_pos, feat, feat_ids, id_table)
             if self.training:
                 max_loss = max_loss + self.compute_atten_loss(b, n_f, guidance_mask, att)
-            tokens = self.mlp_layers[i](tokens)
-            tokens = self.sa_layers[i](tokens, tgt_key_padding_mask=token_padding_mask, query_pos=token_pos)
-            feat = self.feat_token_ca_layers[i].features_from_tokens(feat, feat_ids, tbl, tokens, pos_t, token_padding_mask)
-        tokens, att = self.final_token_feat_ca.tokens_from_features(tokens, token_pos, feat, feat_ids, id_table)
-        if self.training:
-            max_loss = max_loss + self.compute_atten_loss(b, n_f, guidance_mask, att)
-        max_loss = max_loss / (self.n_block + 1)
+            max_loss = max_loss / (self.n_block + 1)
         if not torch.cuda.is_current_stream_capturing():          # captured runs are checked by the graph owner after replay
             check_tokens(tokens)
 
@@ -134,7 +137,8 @@ class InstanceMatteDecoder(nn.Module):
             feat = self._smooth(feat)
             out_feat = feat
 
-        tokens = self.decoder_norm(self.final_mlp(tokens))                                    # (b, 10, c_out) fp32
+        with torch.autocast('cuda', enabled=False):
+            tokens = self.decoder_norm(self.final_mlp(tokens))                                # (b, 10, c_out) fp32
         # einsum('bqc,btchw->btqhw'): a per-batch-element 1x1 conv whose weights are the tokens (padded to 16 outputs)
         cq = MF.pad8(n_i) if MF.pad8(n_i) >= 16 else 16
         logits = []

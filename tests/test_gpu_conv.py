@@ -80,6 +80,12 @@ def test_conv_fprop_dgrad_wgrad(case, dtype):
                       pad=pad, dil=dil)
     dw = dw.cpu().reshape(Cout, k, k, Cin).permute(0, 3, 1, 2)
     assert (dw - w.grad).abs().max().item() <= _tol(dtype) * w.grad.abs().max().item()
+    if dtype == torch.bfloat16:                       # converting reduce: dW written directly in bf16
+        dwb = K.conv_wgrad(xd, gyd, cout=Cout, mode=K.MODE_CONV, N=N, Hin=H, Win=W, Hout=Ho, Wout=Wo, R=k, S=k, stride=stride,
+                           pad=pad, dil=dil, out_dtype=torch.bfloat16)
+        assert dwb.dtype == torch.bfloat16
+        dwb = dwb.float().cpu().reshape(Cout, k, k, Cin).permute(0, 3, 1, 2)
+        assert (dwb - dw).abs().max().item() <= 1e-2 * dw.abs().max().item()
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])

@@ -1,4 +1,4 @@
-import sys, os; sys.path.insert(0, '.')
+import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 from maggie_amd import kernels as K
 dev = torch.device('cuda:0')
