@@ -157,13 +157,18 @@ def main():
 
     roofline = None
     if not args.no_roofline:
+        # Per-launch HIP-event timing needs every conv launched individually: the instrumented extra steps run the trunk
+        # eagerly (the timed steps above replay it from hipGraphs, where the same kernels run back to back).
         names = ['mg_conv_fprop', 'mg_conv_wgrad_ws']
+        graphs_flag = model.__dict__.get('hip_graphs')
+        model.hip_graphs = False
         hip.enable_timing(names)
         n_prof = 2
         for _ in range(n_prof):
             step()
         torch.cuda.synchronize()
         rec = hip.disable_timing()['records']
+        model.__dict__['hip_graphs'] = graphs_flag
         fam = {}
         for n in names:
             for s, e, work, tag in rec[n]:
@@ -198,6 +203,7 @@ def main():
             'families': {k: {'ms_per_step': round(1e3 * v[0] / n_prof, 3), 'tflops': round(v[1] / v[0] / 1e12, 2), 'launches': v[2] // n_prof}
                          for k, v in fam.items()},
             'step_algorithmic_tflops_per_gpu': round(step_tflops, 2), 'step_frac_of_mfma_peak': round(step_tflops / PEAK_BF16_TFLOPS, 5),
+            'hip_graphs': bool(getattr(model, '_trunk_graphs', None)) and any(not isinstance(v, (int, str)) for v in model._trunk_graphs.values()),
         }
 
     cpu_baseline = None

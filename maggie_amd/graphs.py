@@ -19,6 +19,12 @@ import torch
 from . import functional as MF
 
 
+# "thread_local": only this thread's unsafe HIP calls are policed during a capture. Other threads keep working -- in
+# particular the RCCL watchdog of torch.distributed, whose hipEventQuery polling would otherwise invalidate the capture and
+# then abort the process ("operation not permitted when stream is capturing").
+CAPTURE_MODE = 'thread_local'
+
+
 class _Replay(torch.autograd.Function):
     @staticmethod
     def forward(ctx, g, *params):
@@ -108,14 +114,14 @@ class GraphedCallable:
             self.table = torch.zeros(1 << 14, dtype=torch.int64, device=dev)      # constants of the captured kernels
             MF.CAPTURE_TABLE[:] = [self.table, 0]
             try:
-                with torch.cuda.graph(self.fwd, pool=self.pool, stream=side):
+                with torch.cuda.graph(self.fwd, pool=self.pool, stream=side, capture_error_mode=CAPTURE_MODE):
                     MF.ARENA.begin_capture(dev)
                     self.static_outputs = tuple(fn(*self.static_inputs))
                 self.static_grad_outputs, self.static_param_grads, self.bwd = None, None, None
                 if training:
                     self.static_grad_outputs = [torch.zeros_like(o) if o.requires_grad else None for o in self.static_outputs]
                     self.bwd = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self.bwd, pool=self.pool, stream=side):
+                    with torch.cuda.graph(self.bwd, pool=self.pool, stream=side, capture_error_mode=CAPTURE_MODE):
                         MF.ARENA.begin_capture(dev)
                         self.static_param_grads = torch.autograd.grad(
                             [o for o in self.static_outputs if o.requires_grad], cap_params,
