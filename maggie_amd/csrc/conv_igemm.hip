@@ -35,6 +35,18 @@ template <int BM, int BN, int KS> constexpr int lds_bytes() {
 
 struct RowCoord { int n, ho, wo; bool ok; };
 
+// XCD-aware work order. The dispatcher places workgroup b on XCD b % 8 (8 XCDs, private 4 MiB L2 each), so consecutive
+// block ids never share an L2. Launch 8 * ceil(L/8) blocks and give XCD x the CONTIGUOUS work items [x*chunk, (x+1)*chunk):
+// neighbouring tiles (which share input halos, or the same rows under different filter taps) then hit the same L2 close in
+// time. Returns false for the <= 7 padding blocks. (A speed choice only: any placement is correct.)
+constexpr int NXCD = 8;
+__device__ __forceinline__ bool xcd_order(int L, int& v) {
+    const int chunk = (L + NXCD - 1) / NXCD;
+    v = ((int)blockIdx.x % NXCD) * chunk + (int)blockIdx.x / NXCD;
+    return v < L;
+}
+static inline unsigned xcd_grid(long L) { return (unsigned)(((L + NXCD - 1) / NXCD) * NXCD); }
+
 // K is walked in STAGES of KS slabs (KS*64 bytes per row). The loads of stage s+1 are issued right after the barrier that
 // publishes stage s and stay in flight under its KS*FM*FN MFMAs; one LDS buffer, two barriers per stage. KS = 4 is used for
 // K-heavy layers (few, fat memory round trips: these GEMMs are small, so exposed load latency -- not bandwidth or MFMA rate --
@@ -55,7 +67,11 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int ntn = (p.Cout + BN - 1) / BN;
+    int work;
+    if (!xcd_order(((p.M + BM - 1) / BM) * ntn, work)) return;
+    const int mt = work / ntn;                   // channel tiles of one row tile are consecutive: they share the A rows
+    const int m0 = mt * BM, n0 = (work - mt * ntn) * BN;
     const int taps = p.R * p.S;
     const int Ktot = taps * p.Cin;
     const int nslab = (Ktot + EPS - 1) / EPS;
@@ -350,7 +366,7 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
         }
         __syncthreads();
         if (t < BN && n0 + t < p.Cout) {
-            float* st = p.stats + (size_t)(blockIdx.x & (MG_STAT_REPLICAS - 1)) * 2 * p.Cout;   // spread same-address atomics
+            float* st = p.stats + (size_t)(mt & (MG_STAT_REPLICAS - 1)) * 2 * p.Cout;   // spread same-address atomics
             atomicAdd(&st[n0 + t], sStat[t]);
             atomicAdd(&st[p.Cout + n0 + t], sStat[BN + t]);
         }
@@ -359,7 +375,7 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
 
 template <typename T, int BM, int BN, int KS>
 int launch_fprop(const mg_conv_params& p, hipStream_t st) {
-    dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN);
+    dim3 grid(xcd_grid((long)((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN)));
     constexpr size_t lds = lds_bytes<BM, BN, KS>();
     static bool attr_set = false;
     if (lds > 65536 && !attr_set) {
@@ -457,10 +473,19 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const mg_conv_params p
     const int li = lane & 15, g = lane >> 4;
     const int taps = p.R * p.S;
     const int nci = (p.Cin + TCI - 1) / TCI;
-    const int tap = blockIdx.y / nci;
-    const int ci0 = (blockIdx.y - tap * nci) * TCI;
-    const int co0 = blockIdx.z * TCO;
-    const int mbeg = blockIdx.x * rows_per_block;
+    // work order: (tap, ci tile) fastest, then the co tile, then the row split -- every block of one row split reads the same
+    // rows of x and dY, so they run back to back on one XCD
+    const int nco = (p.Cout + TCO - 1) / TCO;
+    const int nsplit = (p.M + rows_per_block - 1) / rows_per_block;
+    int work;
+    if (!xcd_order(nsplit * taps * nci * nco, work)) return;
+    const int tc = work % (taps * nci);
+    const int rest = work / (taps * nci);
+    const int split = rest / nco;
+    const int tap = tc / nci;
+    const int ci0 = (tc - tap * nci) * TCI;
+    const int co0 = (rest - split * nco) * TCO;
+    const int mbeg = split * rows_per_block;
     const int mend = min(p.M, mbeg + rows_per_block);
     if (mbeg >= mend) return;
     const int ky = tap / p.S, kx = tap - ky * p.S;
@@ -602,7 +627,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const mg_conv_params p
     float* __restrict__ dw = p.stats;
     if (ws) {
         // deterministic two-stage reduction: this row-split's partial tile goes to its own slab of the workspace
-        float* __restrict__ slab = ws + (long)blockIdx.x * p.Cout * taps * p.Cin;
+        float* __restrict__ slab = ws + (long)split * p.Cout * taps * p.Cin;
         for (int i = t; i < TCO * TCI; i += 256) {
             int co = i / TCI, ci = i - co * TCI;
             if (co0 + co < p.Cout && ci0 + ci < p.Cin)
@@ -686,7 +711,7 @@ int launch_wgrad(const mg_conv_params& p, float* ws, long ws_floats, hipStream_t
     if (out_bf16 && !use_ws) return -4;
     mg_conv_params q = p;
     if (pl.splits == 1 && !out_bf16) use_ws = p.stats;             // single split: the "slab" is dW itself (no atomics, no reduce)
-    dim3 grid((unsigned)pl.splits, (unsigned)(taps * nci), (unsigned)nco);
+    dim3 grid(xcd_grid((long)pl.splits * taps * nci * nco));
     size_t stage = (size_t)KSTEP * (TCO + PAD + TCI + PAD) * sizeof(T);
     size_t red = (size_t)4 * TCO * (TCI + 1) * 4;
     size_t lds = stage > red ? stage : red;
