@@ -28,7 +28,7 @@ template <int BM, int BN> struct TileCfg { static constexpr int WAVES_M = (BN >=
 template <int KS> constexpr int rowb() { return 64 * KS + 16; }
 template <int BM, int BN> constexpr int ep_passes() { return (BM * (BN + 4) * 4 > 40960) ? 2 : 1; }
 template <int BM, int BN, int KS> constexpr int stage_bytes() { return (BM + BN) * rowb<KS>(); }
-template <int BM, int BN> constexpr int ctile_bytes() { return (BM / ep_passes<BM, BN>()) * (BN + 4) * 4 + 2 * BN * 4; }
+template <int BM, int BN> constexpr int ctile_bytes() { return (BM / ep_passes<BM, BN>()) * (BN + 4) * 4 + 8 * BN * 4; }
 template <int BM, int BN, int KS> constexpr int lds_bytes() {
     return stage_bytes<BM, BN, KS>() > ctile_bytes<BM, BN>() ? stage_bytes<BM, BN, KS>() : ctile_bytes<BM, BN>();
 }
@@ -157,7 +157,9 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
     // The tap walk (tap, ky, kx, channel offset) is then uniform over the block and lives in SGPRs; per (row, slab) the
     // vector work is two adds, two unsigned range checks, one address mad. The generic path above costs ~25 VALU + ~15
     // SALU per load and made the stage loop issue-bound (16 MFMAs against ~340 ALU instructions per stage).
-    const bool al = (p.Cin % EPS == 0) && (MODE != MG_MODE_TCONV || sshift >= 0);
+    // second aligned case: Cin == one 16-byte chunk (the 8-channel network input): chunk c of slab q IS filter tap 4q + c
+    const bool c8 = (CE == 8 && p.Cin == 8);
+    const bool al = (p.Cin % EPS == 0 || c8) && (MODE != MG_MODE_TCONV || sshift >= 0);
     int hb[A_ROWS], wbs[A_ROWS], rbase[A_ROWS];
     const char* bptr[B_ITERS];
     bool bok[B_ITERS];
@@ -179,9 +181,15 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
     auto load_stage_al = [&](int u) {
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
-            const bool live = q_slab < nslab;
-            const int dh = q_ky * p.dil, dw = q_kx * p.dil;
-            const long coff = ((long)q_sub * EPS + a_c * CE) * (long)sizeof(T);
+            bool live = q_slab < nslab;
+            int dh = q_ky * p.dil, dw = q_kx * p.dil, tap_g = q_tap;
+            long coff = ((long)q_sub * EPS + a_c * CE) * (long)sizeof(T);
+            if (c8) {
+                tap_g = q_slab * 4 + a_c;
+                live = tap_g < taps;
+                const int ky = (tap_g * invS) >> 16, kx = tap_g - ky * p.S;
+                dh = ky * p.dil; dw = kx * p.dil; coff = 0;
+            }
 #pragma unroll
             for (int i = 0; i < A_ROWS; ++i) {
                 long src = -1;
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
                     if (th >= 0 && tw >= 0 && ((th | tw) & (p.stride - 1)) == 0 && hi < p.Hin && wi < p.Win)
                         src = (long)(rbase[i] + hi) * p.Win + wi;
                 } else {
-                    if (rc[i].ok && live) src = p.nbr[(long)rbase[i] + q_tap];
+                    if (rc[i].ok && live) src = p.nbr[(long)rbase[i] + tap_g];
                 }
                 if (src >= 0 && rc[i].ok && live) ra[u][j][i] = *(const uint4*)(xb + src * ((long)p.ldx * (long)sizeof(T)) + coff);
                 else ra[u][j][i] = make_uint4(0, 0, 0, 0);
@@ -202,7 +210,8 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
             const long boff = (long)q_slab * EPS * (long)sizeof(T);
 #pragma unroll
             for (int i = 0; i < B_ITERS; ++i) {
-                if (bok[i] && live) rb[u][j][i] = *(const uint4*)(bptr[i] + boff);
+                const bool blive = q_slab * EPS + ((t + i * 256) & 3) * CE < Ktot;
+                if (bok[i] && blive) rb[u][j][i] = *(const uint4*)(bptr[i] + boff);
                 else rb[u][j][i] = make_uint4(0, 0, 0, 0);
             }
             ++q_slab;
@@ -277,7 +286,7 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
     constexpr int PR = BM / EP;                       // tile rows per pass
     constexpr int LDC = BN + 4;
     float* sC = (float*)smem;                         // [PR][LDC]
-    float* sStat = (float*)(smem + PR * LDC * 4);     // [2][BN]
+    float* sStat = (float*)(smem + PR * LDC * 4);     // [4 waves][2][BN]
     constexpr int CPR = BN / CE;                      // 16-byte chunks per tile row
     constexpr int RPP = 256 / CPR;                    // rows per sweep
     const int cc = t % CPR, rr = t / CPR;
@@ -294,7 +303,6 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
     T* __restrict__ yb = (T*)p.y;
     const T* __restrict__ r1b = (const T*)p.res;
     const T* __restrict__ r2b = (const T*)p.res2;
-    if (t < 2 * BN) sStat[t] = 0.f;
 #pragma unroll
     for (int ep = 0; ep < EP; ++ep) {
         if (ep > 0) __syncthreads();
@@ -359,16 +367,30 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
         }
     }
     if (p.stats) {
+        // lanes t, t+CPR, t+2*CPR, ... of a wave hold the same channel chunk: butterfly over them (CPR is a power of two <= 32),
+        // one LDS row per wave, then one global atomic per channel per block into 1 of 32 replicas. (LDS float atomics here
+        // serialised 64-way on the narrow tiles and doubled the kernel time of the 512x512 layers.)
+        static_assert((CPR & (CPR - 1)) == 0 && CPR <= 32, "channel chunks per tile row must be a power of two");
 #pragma unroll
-        for (int e = 0; e < CE; ++e) {
-            atomicAdd(&sStat[cc * CE + e], s1[e]);
-            atomicAdd(&sStat[BN + cc * CE + e], s2[e]);
+        for (int o = CPR; o < 64; o <<= 1) {
+#pragma unroll
+            for (int e = 0; e < CE; ++e) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+        }
+        if (lane < CPR) {
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
+                sStat[wave * 2 * BN + lane * CE + e] = s1[e];
+                sStat[wave * 2 * BN + BN + lane * CE + e] = s2[e];
+            }
         }
         __syncthreads();
-        if (t < BN && n0 + t < p.Cout) {
-            float* st = p.stats + (size_t)(mt & (MG_STAT_REPLICAS - 1)) * 2 * p.Cout;   // spread same-address atomics
-            atomicAdd(&st[n0 + t], sStat[t]);
-            atomicAdd(&st[p.Cout + n0 + t], sStat[BN + t]);
+        if (t < 2 * BN) {
+            const int c = t < BN ? t : t - BN;
+            if (n0 + c < p.Cout) {
+                const float v = (sStat[t] + sStat[2 * BN + t]) + (sStat[4 * BN + t] + sStat[6 * BN + t]);
+                float* st = p.stats + (size_t)(mt & (MG_STAT_REPLICAS - 1)) * 2 * p.Cout;   // spread same-address atomics
+                atomicAdd(&st[(t < BN ? 0 : p.Cout) + n0 + c], v);
+            }
         }
     }
 }
