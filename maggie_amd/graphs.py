@@ -126,6 +126,7 @@ class GraphedCallable:
                         self.static_param_grads = torch.autograd.grad(
                             [o for o in self.static_outputs if o.requires_grad], cap_params,
                             [g for g in self.static_grad_outputs if g is not None], allow_unused=True)
+                        self._pack_grads()
             finally:
                 MF.ARENA.end_capture()
                 fix, MF.CAPTURE_FIXUPS[:] = list(MF.CAPTURE_FIXUPS), []
@@ -136,24 +137,27 @@ class GraphedCallable:
         with torch.no_grad():
             for m, s in zip(mutable, snap):
                 m.copy_(s)
-        if training:
-            self._layout = {}
-            for p, g in zip(self.params, self.static_param_grads):
-                self._layout.setdefault(g.dtype, []).append(g)
 
     def export_param_grads(self):
-        """Fresh copies of the static gradient buffers: one flat allocation + one foreach copy per dtype."""
-        out = {}
-        for dt, gs in self._layout.items():
-            flat = torch.empty(sum(g.numel() for g in gs), dtype=dt, device=gs[0].device)
-            views, o = [], 0
-            for g in gs:
-                views.append(flat[o:o + g.numel()].view(g.shape))
-                o += g.numel()
-            torch._foreach_copy_(views, gs)
-            for g, v in zip(gs, views):
-                out[id(g)] = v
-        return tuple(out[id(g)] for g in self.static_param_grads)
+        """Fresh copies of the parameter gradients. The backward graph ends by concatenating them into one flat buffer per
+        dtype (`_pack_grads`, captured), so leaving the graph costs ONE device copy per dtype plus views."""
+        out = []
+        fresh = {dt: flat.clone() for dt, flat in self.flat_grads.items()}
+        for dt, off, n, shape in self.grad_slots:
+            out.append(fresh[dt][off:off + n].view(shape))
+        return tuple(out)
+
+    def _pack_grads(self):
+        """Called INSIDE the backward capture."""
+        by_dt = {}
+        for g in self.static_param_grads:
+            by_dt.setdefault(g.dtype, []).append(g)
+        self.flat_grads = {dt: torch.cat([g.reshape(-1) for g in gs]) for dt, gs in by_dt.items()}
+        offs = {dt: 0 for dt in by_dt}
+        self.grad_slots = []
+        for g in self.static_param_grads:
+            self.grad_slots.append((g.dtype, offs[g.dtype], g.numel(), g.shape))
+            offs[g.dtype] += g.numel()
 
     def __call__(self, *inputs):
         src, dst = [], []
