@@ -194,6 +194,11 @@ int mg_spectral_norm_bwd(const float* G, const float* W, const float* u, const f
  * plane has any non-zero weight (planes with all-zero weights contribute nothing and are skipped).
  * ------------------------------------------------------------------------------------------------------------- */
 int mg_plane_flags(const float* w, int P, int HW, int32_t* flags, void* stream);
+/* sums[9] = [l1, grad, w, lap0, w0, lap1, w1, lap2, w2] (accumulated by mg_loss_point_fwd / mg_pyr_lap_fwd) -> out3 = (rec, lap, grad)
+ * with the reference's normalisations (arch/maggie.py:237-262: eps 1e-8 on the L1 term; loss.py:137-191: eps 1e-6, 3-fold LapLoss);
+ * mg_loss_coef: upstream gradient g3 of those three -> the five per-term coefficients the backward kernels take. */
+int mg_loss_finish(const float* sums, float* out3, void* stream);
+int mg_loss_coef(const float* g3, const float* sums, float* coef5, void* stream);
 /* d = p - t; sums[0] += w|d|, sums[1] += |sobel(p*w) - sobel(t*w)|, sums[2] += w */
 int mg_loss_point_fwd(const float* p, const float* t, const float* w, const int32_t* flags, int P, int H, int W, float* d,
                       float* sums, void* stream);

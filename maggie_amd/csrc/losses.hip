@@ -294,7 +294,39 @@ inline dim3 grid2(long per_plane, int P) {
     return dim3((unsigned)b, (unsigned)P);
 }
 
+// sums = [l1, grad, w, lap0, w0, lap1, w1, lap2, w2] -> (rec, lap, grad) exactly as arch/maggie.py:237-262 / loss.py:67-191
+// normalise them (eps 1e-8 for the L1 term, 1e-6 for the others; LapLoss is the 3-fold channel sum)
+__global__ void loss_finish_kernel(const float* __restrict__ sums, float* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        out[0] = sums[0] / (sums[2] + 1e-8f);
+        out[1] = 3.0f * (sums[3] / (sums[4] + 1e-6f) + sums[5] / (sums[6] + 1e-6f) + sums[7] / (sums[8] + 1e-6f));
+        out[2] = sums[1] / (sums[2] + 1e-6f);
+    }
+}
+// upstream gradient (d rec, d lap, d grad) -> the five per-term coefficients of the backward kernels
+__global__ void loss_coef_kernel(const float* __restrict__ g, const float* __restrict__ sums, float* __restrict__ coef) {
+    if (threadIdx.x == 0) {
+        coef[0] = g[0] / (sums[2] + 1e-8f);
+        coef[1] = g[2] / (sums[2] + 1e-6f);
+        coef[2] = 3.0f * g[1] / (sums[4] + 1e-6f);
+        coef[3] = 3.0f * g[1] / (sums[6] + 1e-6f);
+        coef[4] = 3.0f * g[1] / (sums[8] + 1e-6f);
+    }
+}
+
 }  // namespace
+
+extern "C" int mg_loss_finish(const float* sums, float* out3, void* stream) {
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, out3);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_loss_coef(const float* g3, const float* sums, float* coef5, void* stream) {
+    hipLaunchKernelGGL(loss_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, g3, sums, coef5);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int mg_plane_flags(const float* w, int P, int HW, int32_t* flags, void* stream) {
     if (P <= 0) return 0;

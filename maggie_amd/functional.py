@@ -673,12 +673,11 @@ class MattingLosses(torch.autograd.Function):
                  ptr(G), ptr(sums[3 + 2 * lvl:]), st())
             Gs.append(G)
             x, h, ww = down, h // 2, ww // 2
-        rec = sums[0] / (sums[2] + 1e-8)
-        grad = sums[1] / (sums[2] + 1e-6)
-        lap = 3.0 * (sums[3] / (sums[4] + 1e-6) + sums[5] / (sums[6] + 1e-6) + sums[7] / (sums[8] + 1e-6))
+        out = torch.empty(3, dtype=torch.float32, device=dev)                   # (rec, lap, grad)
+        hipc('mg_loss_finish', ptr(sums), ptr(out), st())
         ctx.save_for_backward(p, t, w, flags, sums, *Gs)
         ctx.shape = pred.shape
-        return torch.stack([rec, lap, grad])
+        return out
 
     @staticmethod
     def backward(ctx, g):
@@ -687,9 +686,9 @@ class MattingLosses(torch.autograd.Function):
         dev = p.device
         hipc, c_int = K.hip.call, K.c_int
         ptr, st = K.hip.ptr, K.hip.stream
-        g = g.float()
-        coef = torch.stack([g[0] / (sums[2] + 1e-8), g[2] / (sums[2] + 1e-6), 3.0 * g[1] / (sums[4] + 1e-6),
-                            3.0 * g[1] / (sums[6] + 1e-6), 3.0 * g[1] / (sums[8] + 1e-6)]).contiguous()
+        g = g.float().contiguous()
+        coef = torch.empty(5, dtype=torch.float32, device=dev)
+        hipc('mg_loss_coef', ptr(g), ptr(sums), ptr(coef), st())
         c_rec, c_grad, c0, c1, c2 = [coef[i:i + 1] for i in range(5)]
         new = lambda hh, ww: torch.empty((P, hh, ww), dtype=torch.float32, device=dev)
         r2 = new(H // 8, W_ // 8)
