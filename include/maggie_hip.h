@@ -189,6 +189,28 @@ int mg_spectral_norm_bwd(const float* G, const float* W, const float* u, const f
                          int pad_in, float* work, float* dW, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Instance-token <-> feature cross attention (fp32, one head, D = 128, T = 10 tokens) -- replaces the
+ * nn.MultiheadAttention calls of CrossAttentionLayer (maggie/network/module/mask_attention.py:63-133) inside
+ * InstanceMatteDecoder.forward (maggie/network/module/instance_matte_decoder.py:170-236). The token side (Q/K/V/out
+ * projections of 10 tokens, ID position table) is folded into small matrices by the caller; these kernels make one pass
+ * over the (B, L, D) feature rows per direction. ids[b,l] in [0, NID) selects the ID position row of a feature pixel.
+ *   tok_fwd : S[t,l] = (qk[t].F[l] + btab[t,ids[l]])*scale; p = softmax_l S (B,T,L); ctx[t] = sum_l p F[l] (B,T,D)
+ *   tok_bwd : given dctx (B,T,D) and dp (B,T,L or NULL): dqk, dbtab (B,T,NID), dfeat (B,L,D); gbuf (B,T,L), rowdot (B,T) scratch
+ *   feat_fwd: S[l,t] = (F[l].kq[t] + b2[ids[l],t])*scale, -inf where pad_mask[b,t]; p = softmax_t (B,L,T);
+ *             out[l] = sum_t p vp[t] + obias (B,L,D)
+ *   feat_bwd: given dout: dfeat, dkq, dvp (B,T,D), db2 (B,NID,T), dobias (D or NULL)
+ * Accumulated outputs are zeroed by the entry points. Returns -3 for unsupported D / T.
+ * ------------------------------------------------------------------------------------------------------------- */
+int mg_attn_tok_fwd(const float* qk, const float* btab, const float* feat, const int32_t* ids, int B, int T, int L, int D, int NID,
+                    float scale, float* p, float* ctx, void* stream);
+int mg_attn_tok_bwd(const float* p, const float* feat, const float* qk, const int32_t* ids, const float* dctx, const float* dp, int B, int T,
+                    int L, int D, int NID, float scale, float* gbuf, float* rowdot, float* dqk, float* dbtab, float* dfeat, void* stream);
+int mg_attn_feat_fwd(const float* feat, const float* kq, const float* b2, const float* vp, const float* obias, const uint8_t* pad_mask,
+                     const int32_t* ids, int B, int T, int L, int D, int NID, float scale, float* out, float* p, void* stream);
+int mg_attn_feat_bwd(const float* dout, const float* p, const float* feat, const float* kq, const float* vp, const int32_t* ids, int B, int T,
+                     int L, int D, int NID, float scale, float* dfeat, float* dkq, float* dvp, float* db2, float* dobias, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Fused matting losses on fp32 planes [P,H,W] (maggie/network/arch/maggie.py:237-266,290-346; maggie/network/loss.py:67-191):
  * weighted L1, Sobel-gradient L1, 3-level Laplacian-pyramid L1 -- forward sums and exact backward. `flags[p]` = the
  * plane has any non-zero weight (planes with all-zero weights contribute nothing and are skipped).

@@ -1,0 +1,454 @@
+// Instance-token <-> feature cross attention of the instance matte decoder (fp32, one head, d = 128, T <= 16 tokens).
+// Reference: maggie/network/module/mask_attention.py:63-133 (CrossAttentionLayer = nn.MultiheadAttention(q + pos, k + pos, v))
+// as used by maggie/network/module/instance_matte_decoder.py:170-236. One side of every attention is only `max_inst` (10)
+// tokens wide, so the token side is folded into small matrices on the host side (maggie_amd/network/module/mask_attention.py)
+// and the kernels here make ONE pass over the (L x 128) feature rows per direction:
+//
+//   tokens <- features:  S[t,l] = (Qk[t] . F[l] + Btab[t, id[l]]) * scale,  P = softmax_l(S),  Ctx[t] = sum_l P[t,l] F[l]
+//   features <- tokens:  S[l,t] = (F[l] . Kq[t] + B2[id[l], t]) * scale (masked),  P = softmax_t(S),  O[l] = sum_t P[l,t] Vp[t] + bias
+//
+// and their exact backward passes. A feature row is handled by 16 consecutive lanes (8 channels each, two float4 loads), the
+// 10 token vectors live in LDS, dot products finish with a 4-step butterfly inside the 16-lane group. Token-side gradient
+// accumulators stay in registers across the rows of a group and are reduced wave -> LDS -> one atomicAdd per value per block.
+// All kernels are HBM/L2-bound: F is read once (forward) / twice (backward) per direction.
+#include "common.h"
+#include "../../include/maggie_hip.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int D = 128;          // attention width
+constexpr int GL = 16;          // lanes per feature row
+constexpr int CPL = D / GL;     // channels per lane (8)
+constexpr int NG = NT / GL;     // row groups per block (16)
+constexpr int RPG = 4;          // rows per group per block
+constexpr int RPB = NG * RPG;   // rows per block (64)
+
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+}
+__device__ __forceinline__ void ld8(const float* __restrict__ p, float* f) {
+    const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+__device__ __forceinline__ void st8(float* __restrict__ p, const float* f) {
+    *(float4*)p = make_float4(f[0], f[1], f[2], f[3]);
+    *(float4*)(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
+}
+template <int T>
+__device__ __forceinline__ float pick(const float* v, int i) {       // v[i] for a lane-dependent i without dynamic register indexing
+    float r = v[0];
+#pragma unroll
+    for (int t = 1; t < T; ++t) r = (i == t) ? v[t] : r;
+    return r;
+}
+__device__ __forceinline__ void stage_tokens(float* dst, const float* __restrict__ src, int n) {
+    for (int i = threadIdx.x; i < n; i += NT) dst[i] = src[i];
+}
+// acc[T][CPL] summed over the 4 groups of a wave, then over the 4 waves through LDS, then atomically into dst[T][D]
+template <int T>
+__device__ __forceinline__ void reduce_token_acc(float (&acc)[T][CPL], float* sred, float* __restrict__ dst) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & (GL - 1);
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) {
+            float v = acc[t][e];
+            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            acc[t][e] = v;
+        }
+    __syncthreads();
+    if (lane < GL) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) sred[(wave * T + t) * D + li * CPL + e] = acc[t][e];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < T * D; i += NT) {
+        const float v = (sred[i] + sred[T * D + i]) + (sred[2 * T * D + i] + sred[3 * T * D + i]);
+        if (v != 0.f) atomicAdd(dst + i, v);
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------ tokens <- features
+template <int T>
+__global__ __launch_bounds__(NT) void tok_scores_kernel(const float* __restrict__ qk, const float* __restrict__ btab, const float* __restrict__ feat,
+                                                        const int32_t* __restrict__ ids, int L, int NID, float scale, float* __restrict__ s_out) {
+    __shared__ float sq[T * D];
+    const int b = blockIdx.y;
+    stage_tokens(sq, qk + (long)b * T * D, T * D);
+    __syncthreads();
+    const int g = threadIdx.x / GL, li = threadIdx.x % GL;
+#pragma unroll
+    for (int r = 0; r < RPG; ++r) {
+        const int l = blockIdx.x * RPB + r * NG + g;
+        if (l >= L) continue;
+        float f[CPL], s[T];
+        ld8(feat + ((long)b * L + l) * D + li * CPL, f);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            float a = 0.f;
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) a += f[e] * sq[t * D + li * CPL + e];
+            s[t] = group_sum(a);
+        }
+        if (li < T) {
+            const int id = ids[(long)b * L + l];
+            s_out[((long)b * T + li) * L + l] = (pick<T>(s, li) + btab[((long)b * T + li) * NID + id]) * scale;
+        }
+    }
+}
+
+// in-place softmax over the last dimension of a (rows x n) matrix, one block per row
+__global__ __launch_bounds__(NT) void softmax_rows_kernel(float* __restrict__ x, int n) {
+    __shared__ float sh[NT / 64];
+    float* row = x + (long)blockIdx.x * n;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += NT) m = fmaxf(m, row[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) sh[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    __syncthreads();
+    float z = 0.f;
+    for (int i = threadIdx.x; i < n; i += NT) z += __expf(row[i] - m);
+    z = wave_sum(z);
+    if (lane == 0) sh[wave] = z;
+    __syncthreads();
+    z = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    const float inv = 1.f / z;
+    for (int i = threadIdx.x; i < n; i += NT) row[i] = __expf(row[i] - m) * inv;
+}
+
+// ctx[t, c] += sum_{l in chunk} P[t,l] F[l,c]
+template <int T>
+__global__ __launch_bounds__(NT) void tok_ctx_kernel(const float* __restrict__ p, const float* __restrict__ feat, int L, float* __restrict__ ctx) {
+    constexpr int CH = 128;
+    __shared__ float sp[T * CH];
+    __shared__ float sr[T * D];
+    const int b = blockIdx.y, l0 = blockIdx.x * CH;
+    for (int i = threadIdx.x; i < T * CH; i += NT) {
+        const int t = i / CH, r = i - t * CH;
+        sp[i] = (l0 + r < L) ? p[((long)b * T + t) * L + l0 + r] : 0.f;
+    }
+    __syncthreads();
+    const int c = threadIdx.x & (D - 1), half = threadIdx.x / D;
+    float acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = 0.f;
+    const int rbeg = half * (CH / 2), rend = min(rbeg + CH / 2, L - l0);
+    for (int r = rbeg; r < rend; ++r) {
+        const float f = feat[((long)b * L + l0 + r) * D + c];
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] += sp[t * CH + r] * f;
+    }
+    if (half == 1) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) sr[t * D + c] = acc[t];
+    }
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) atomicAdd(&ctx[((long)b * T + t) * D + c], acc[t] + sr[t * D + c]);
+    }
+}
+
+// backward pass 1: G[t,l] = dP[t,l] + dCtx[t] . F[l];  rowdot[t] += sum_l P[t,l] G[t,l]
+template <int T>
+__global__ __launch_bounds__(NT) void tok_bwd1_kernel(const float* __restrict__ p, const float* __restrict__ feat, const float* __restrict__ dctx,
+                                                      const float* __restrict__ dp, int L, float* __restrict__ gbuf, float* __restrict__ rowdot) {
+    __shared__ float sd[T * D];
+    __shared__ float sacc[(NT / 64) * 16];
+    const int b = blockIdx.y;
+    stage_tokens(sd, dctx + (long)b * T * D, T * D);
+    __syncthreads();
+    const int g = threadIdx.x / GL, li = threadIdx.x % GL;
+    float rd = 0.f;
+#pragma unroll
+    for (int r = 0; r < RPG; ++r) {
+        const int l = blockIdx.x * RPB + r * NG + g;
+        if (l >= L) continue;
+        float f[CPL], s[T];
+        ld8(feat + ((long)b * L + l) * D + li * CPL, f);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            float a = 0.f;
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) a += f[e] * sd[t * D + li * CPL + e];
+            s[t] = group_sum(a);
+        }
+        if (li < T) {
+            const long o = ((long)b * T + li) * L + l;
+            const float gv = pick<T>(s, li) + (dp ? dp[o] : 0.f);
+            gbuf[o] = gv;
+            rd += p[o] * gv;
+        }
+    }
+    rd += __shfl_xor(rd, 16, 64); rd += __shfl_xor(rd, 32, 64);          // the 4 groups of a wave share the lane -> token map
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < 16) sacc[wave * 16 + lane] = rd;
+    __syncthreads();
+    if (threadIdx.x < T) {
+        const float v = (sacc[threadIdx.x] + sacc[16 + threadIdx.x]) + (sacc[32 + threadIdx.x] + sacc[48 + threadIdx.x]);
+        atomicAdd(&rowdot[b * T + threadIdx.x], v);
+    }
+}
+
+// backward pass 2: dS = P (G - rowdot) scale;  dF[l] = sum_t dS Qk[t] + P dCtx[t];  dQk[t] += sum_l dS F[l];  dBtab[t, id] += dS
+template <int T>
+__global__ __launch_bounds__(NT) void tok_bwd2_kernel(const float* __restrict__ p, const float* __restrict__ feat, const float* __restrict__ qk,
+                                                      const float* __restrict__ dctx, const int32_t* __restrict__ ids, const float* __restrict__ gbuf,
+                                                      const float* __restrict__ rowdot, int L, int NID, float scale, float* __restrict__ dfeat,
+                                                      float* __restrict__ dqk, float* __restrict__ dbtab) {
+    extern __shared__ float smem[];
+    float* sq = smem;                    // [T][D]
+    float* sd = smem + T * D;            // [T][D]
+    float* sred = smem + 2 * T * D;      // [4][T][D]
+    float* sb = sred + 4 * T * D;        // [T][NID]
+    const int b = blockIdx.y;
+    stage_tokens(sq, qk + (long)b * T * D, T * D);
+    stage_tokens(sd, dctx + (long)b * T * D, T * D);
+    for (int i = threadIdx.x; i < T * NID; i += NT) sb[i] = 0.f;
+    __syncthreads();
+    const int g = threadIdx.x / GL, li = threadIdx.x % GL, gbase = (threadIdx.x & 63) - li;
+    const float rdot = li < T ? rowdot[b * T + li] : 0.f;
+    float acc[T][CPL];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) acc[t][e] = 0.f;
+#pragma unroll
+    for (int r = 0; r < RPG; ++r) {
+        const int l = blockIdx.x * RPB + r * NG + g;
+        const bool ok = l < L;                                   // uniform inside a 16-lane group
+        float f[CPL], out[CPL], pv = 0.f, ds = 0.f;
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) { f[e] = 0.f; out[e] = 0.f; }
+        if (ok) {
+            ld8(feat + ((long)b * L + l) * D + li * CPL, f);
+            if (li < T) {
+                const long o = ((long)b * T + li) * L + l;
+                pv = p[o];
+                ds = pv * (gbuf[o] - rdot) * scale;
+                if (ds != 0.f) atomicAdd(&sb[li * NID + ids[(long)b * L + l]], ds);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const float dst = __shfl(ds, gbase + t, 64), pt = __shfl(pv, gbase + t, 64);
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) {
+                out[e] += dst * sq[t * D + li * CPL + e] + pt * sd[t * D + li * CPL + e];
+                acc[t][e] += dst * f[e];
+            }
+        }
+        if (ok) st8(dfeat + ((long)b * L + l) * D + li * CPL, out);
+    }
+    reduce_token_acc<T>(acc, sred, dqk + (long)b * T * D);
+    for (int i = threadIdx.x; i < T * NID; i += NT)
+        if (sb[i] != 0.f) atomicAdd(&dbtab[(long)b * T * NID + i], sb[i]);
+}
+
+// ------------------------------------------------------------------------------------------------ features <- tokens
+template <int T>
+__global__ __launch_bounds__(NT) void feat_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ kq, const float* __restrict__ b2,
+                                                      const float* __restrict__ vp, const float* __restrict__ obias, const uint8_t* __restrict__ pad,
+                                                      const int32_t* __restrict__ ids, int L, int NID, float scale, float* __restrict__ out,
+                                                      float* __restrict__ p_out) {
+    __shared__ float sk[T * D];
+    __shared__ float sv[T * D];
+    const int b = blockIdx.y;
+    stage_tokens(sk, kq + (long)b * T * D, T * D);
+    stage_tokens(sv, vp + (long)b * T * D, T * D);
+    __syncthreads();
+    const int g = threadIdx.x / GL, li = threadIdx.x % GL;
+    float ob[CPL];
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) ob[e] = obias ? obias[li * CPL + e] : 0.f;
+#pragma unroll
+    for (int r = 0; r < RPG; ++r) {
+        const int l = blockIdx.x * RPB + r * NG + g;
+        if (l >= L) continue;
+        float f[CPL], s[T];
+        ld8(feat + ((long)b * L + l) * D + li * CPL, f);
+        const int id = ids[(long)b * L + l];
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            float a = 0.f;
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) a += f[e] * sk[t * D + li * CPL + e];
+            a = (group_sum(a) + b2[((long)b * NID + id) * T + t]) * scale;
+            if (pad && pad[b * T + t]) a = -INFINITY;
+            s[t] = a;
+            m = fmaxf(m, a);
+        }
+        float z = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) { s[t] = __expf(s[t] - m); z += s[t]; }
+        const float inv = 1.f / z;
+        float o[CPL];
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) o[e] = ob[e];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            s[t] *= inv;
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) o[e] += s[t] * sv[t * D + li * CPL + e];
+        }
+        st8(out + ((long)b * L + l) * D + li * CPL, o);
+        if (li < T) p_out[((long)b * L + l) * T + li] = pick<T>(s, li);
+    }
+}
+
+template <int T>
+__global__ __launch_bounds__(NT) void feat_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ p, const float* __restrict__ feat,
+                                                      const float* __restrict__ kq, const float* __restrict__ vp, const int32_t* __restrict__ ids,
+                                                      int L, int NID, float scale, float* __restrict__ dfeat, float* __restrict__ dkq,
+                                                      float* __restrict__ dvp, float* __restrict__ db2, float* __restrict__ dob) {
+    extern __shared__ float smem[];
+    float* sk = smem;                    // [T][D]
+    float* sv = smem + T * D;            // [T][D]
+    float* sred = smem + 2 * T * D;      // [4][T][D]
+    float* sb = sred + 4 * T * D;        // [NID][T]
+    const int b = blockIdx.y;
+    stage_tokens(sk, kq + (long)b * T * D, T * D);
+    stage_tokens(sv, vp + (long)b * T * D, T * D);
+    for (int i = threadIdx.x; i < T * NID; i += NT) sb[i] = 0.f;
+    __syncthreads();
+    const int g = threadIdx.x / GL, li = threadIdx.x % GL;
+    float akq[T][CPL], avp[T][CPL], aob[CPL];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) { akq[t][e] = 0.f; avp[t][e] = 0.f; }
+#pragma unroll
+    for (int e = 0; e < CPL; ++e) aob[e] = 0.f;
+#pragma unroll
+    for (int r = 0; r < RPG; ++r) {
+        const int l = blockIdx.x * RPB + r * NG + g;
+        const bool ok = l < L;
+        float f[CPL], go[CPL], pr[T], ds[T], df[CPL];
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) { f[e] = 0.f; go[e] = 0.f; df[e] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < T; ++t) pr[t] = 0.f;
+        if (ok) {
+            ld8(feat + ((long)b * L + l) * D + li * CPL, f);
+            ld8(dout + ((long)b * L + l) * D + li * CPL, go);
+#pragma unroll
+            for (int t = 0; t < T; ++t) pr[t] = p[((long)b * L + l) * T + t];
+        }
+        float dot = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            float a = 0.f;
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) a += go[e] * sv[t * D + li * CPL + e];
+            ds[t] = group_sum(a);                                  // dP[t]
+            dot += pr[t] * ds[t];
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            ds[t] = pr[t] * (ds[t] - dot) * scale;
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) {
+                df[e] += ds[t] * sk[t * D + li * CPL + e];
+                akq[t][e] += ds[t] * f[e];
+                avp[t][e] += pr[t] * go[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) aob[e] += go[e];
+        if (ok) {
+            st8(dfeat + ((long)b * L + l) * D + li * CPL, df);
+            if (li < T) {
+                const float v = pick<T>(ds, li);
+                if (v != 0.f) atomicAdd(&sb[ids[(long)b * L + l] * T + li], v);
+            }
+        }
+    }
+    reduce_token_acc<T>(akq, sred, dkq + (long)b * T * D);
+    reduce_token_acc<T>(avp, sred, dvp + (long)b * T * D);
+    // bias gradient: 16-lane channel slices over the 16 groups of the block
+    {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int e = 0; e < CPL; ++e) { float v = aob[e]; v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); aob[e] = v; }
+        if (lane < GL) {
+#pragma unroll
+            for (int e = 0; e < CPL; ++e) sred[wave * D + li * CPL + e] = aob[e];
+        }
+        __syncthreads();
+        if (dob && threadIdx.x < D) {
+            const float v = (sred[threadIdx.x] + sred[D + threadIdx.x]) + (sred[2 * D + threadIdx.x] + sred[3 * D + threadIdx.x]);
+            if (v != 0.f) atomicAdd(&dob[threadIdx.x], v);
+        }
+    }
+    for (int i = threadIdx.x; i < T * NID; i += NT)
+        if (sb[i] != 0.f) atomicAdd(&db2[(long)b * NID * T + i], sb[i]);
+}
+
+inline dim3 row_grid(int L, int B) { return dim3((L + RPB - 1) / RPB, B); }
+inline int attn_check(int B, int T, int L, int Dm, int NID) {
+    if (Dm != D || T != 10 || NID < 1 || NID > 64) return -3;      // built for maggie_{image,video}.yaml: attention_dim 128, max_inst 10
+    if (B <= 0 || L <= 0) return -1;
+    return 0;
+}
+constexpr int TT = 10;
+
+}  // namespace
+
+extern "C" int mg_attn_tok_fwd(const float* qk, const float* btab, const float* feat, const int32_t* ids, int B, int T, int L, int Dm, int NID,
+                               float scale, float* p, float* ctx, void* stream) {
+    int rc = attn_check(B, T, L, Dm, NID); if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(tok_scores_kernel<TT>, row_grid(L, B), dim3(NT), 0, st, qk, btab, feat, ids, L, NID, scale, p);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(B * T), dim3(NT), 0, st, p, L);
+    hipError_t e = mg_zero_words(ctx, (long)B * T * Dm, st); if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(tok_ctx_kernel<TT>, dim3((L + 127) / 128, B), dim3(NT), 0, st, p, feat, L, ctx);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_attn_tok_bwd(const float* p, const float* feat, const float* qk, const int32_t* ids, const float* dctx, const float* dp, int B, int T,
+                               int L, int Dm, int NID, float scale, float* gbuf, float* rowdot, float* dqk, float* dbtab, float* dfeat,
+                               void* stream) {
+    int rc = attn_check(B, T, L, Dm, NID); if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = mg_zero_words(rowdot, (long)B * T, st); if (e != hipSuccess) return (int)e;
+    e = mg_zero_words(dqk, (long)B * T * Dm, st); if (e != hipSuccess) return (int)e;
+    e = mg_zero_words(dbtab, (long)B * T * NID, st); if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(tok_bwd1_kernel<TT>, row_grid(L, B), dim3(NT), 0, st, p, feat, dctx, dp, L, gbuf, rowdot);
+    const size_t lds = (size_t)(6 * TT * D + TT * NID) * sizeof(float);
+    hipLaunchKernelGGL(tok_bwd2_kernel<TT>, row_grid(L, B), dim3(NT), lds, st, p, feat, qk, dctx, ids, gbuf, rowdot, L, NID, scale, dfeat, dqk, dbtab);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_attn_feat_fwd(const float* feat, const float* kq, const float* b2, const float* vp, const float* obias, const uint8_t* pad_mask,
+                                const int32_t* ids, int B, int T, int L, int Dm, int NID, float scale, float* out, float* p, void* stream) {
+    int rc = attn_check(B, T, L, Dm, NID); if (rc) return rc;
+    hipLaunchKernelGGL(feat_fwd_kernel<TT>, row_grid(L, B), dim3(NT), 0, (hipStream_t)stream, feat, kq, b2, vp, obias, pad_mask, ids, L, NID, scale, out, p);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_attn_feat_bwd(const float* dout, const float* p, const float* feat, const float* kq, const float* vp, const int32_t* ids, int B, int T,
+                                int L, int Dm, int NID, float scale, float* dfeat, float* dkq, float* dvp, float* db2, float* dobias, void* stream) {
+    int rc = attn_check(B, T, L, Dm, NID); if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = mg_zero_words(dkq, (long)B * T * Dm, st); if (e != hipSuccess) return (int)e;
+    e = mg_zero_words(dvp, (long)B * T * Dm, st); if (e != hipSuccess) return (int)e;
+    e = mg_zero_words(db2, (long)B * NID * T, st); if (e != hipSuccess) return (int)e;
+    if (dobias) { e = mg_zero_words(dobias, (long)Dm, st); if (e != hipSuccess) return (int)e; }
+    const size_t lds = (size_t)(6 * TT * D + TT * NID) * sizeof(float);
+    hipLaunchKernelGGL(feat_bwd_kernel<TT>, row_grid(L, B), dim3(NT), lds, st, dout, p, feat, kq, vp, ids, L, NID, scale, dfeat, dkq, dvp, db2, dobias);
+    MG_CHECK_LAUNCH();
+    return 0;
+}

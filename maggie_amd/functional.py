@@ -714,3 +714,55 @@ def matting_losses(pred, target, weight):
     """-> (rec, lap, grad) scalars."""
     out = MattingLosses.apply(pred, target, weight.expand_as(pred) if weight.shape != pred.shape else weight)
     return out[0], out[1], out[2]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# instance-token <-> feature cross attention (maggie_amd/csrc/attention.hip)
+# ----------------------------------------------------------------------------------------------------------------------
+
+class AttnTokensFromFeatures(torch.autograd.Function):
+    """p = softmax_l((qk . F^T + btab[:, ids]) * scale), ctx = p F.   qk (B,T,D), btab (B,T,NID), feat (B,L,D), ids (B,L) int32."""
+
+    @staticmethod
+    def forward(ctx, qk, btab, feat, ids, scale):
+        qk, btab, feat = qk.float().contiguous(), btab.float().contiguous(), feat.float().contiguous()
+        p, c = K.attn_tok_fwd(qk, btab, feat, ids, scale)
+        ctx.save_for_backward(qk, feat, ids, p)
+        ctx.scale, ctx.nid = scale, btab.shape[2]
+        return p, c
+
+    @staticmethod
+    def backward(ctx, dp, dctx):
+        qk, feat, ids, p = ctx.saved_tensors
+        dctx = torch.zeros_like(qk) if dctx is None else dctx.float().contiguous()
+        dp = None if dp is None else dp.float().contiguous()
+        dqk, dbtab, dfeat = K.attn_tok_bwd(p, feat, qk, ids, dctx, dp, ctx.scale, ctx.nid)
+        return dqk, dbtab, dfeat, None, None
+
+
+class AttnFeaturesFromTokens(torch.autograd.Function):
+    """out = softmax_t((F . kq^T + b2[ids]) * scale, masked) vp + obias.   kq / vp (B,T,D), b2 (B,NID,T), pad (B,T) bool or None."""
+
+    @staticmethod
+    def forward(ctx, feat, kq, b2, vp, obias, pad, ids, scale):
+        feat, kq, b2, vp = feat.float().contiguous(), kq.float().contiguous(), b2.float().contiguous(), vp.float().contiguous()
+        ob = None if obias is None else obias.float().contiguous()
+        pd = None if pad is None else pad.to(torch.uint8).contiguous()
+        out, p = K.attn_feat_fwd(feat, kq, b2, vp, ob, pd, ids, scale)
+        ctx.save_for_backward(feat, kq, vp, ids, p)
+        ctx.scale, ctx.nid, ctx.has_bias = scale, b2.shape[1], obias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        feat, kq, vp, ids, p = ctx.saved_tensors
+        dfeat, dkq, dvp, db2, dob = K.attn_feat_bwd(dout.float().contiguous(), p, feat, kq, vp, ids, ctx.scale, ctx.nid, ctx.has_bias)
+        return dfeat, dkq, db2, dvp, dob, None, None, None
+
+
+def attn_tokens_from_features(qk, btab, feat, ids, scale):
+    return AttnTokensFromFeatures.apply(qk, btab, feat, ids, scale)
+
+
+def attn_features_from_tokens(feat, kq, b2, vp, obias, pad, ids, scale):
+    return AttnFeaturesFromTokens.apply(feat, kq, b2, vp, obias, pad, ids, scale)

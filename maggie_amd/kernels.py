@@ -437,3 +437,58 @@ def spectral_norm_bwd(G, w_bar, u, v, transposed, work):
     hip.call('mg_spectral_norm_bwd', hip.ptr(G), hip.ptr(w_bar), hip.ptr(u), hip.ptr(v), c_int(A), c_int(B), c_int(taps),
              c_int(int(transposed)), c_int(pad_in), hip.ptr(work), hip.ptr(dW), hip.stream())
     return dW
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# instance-token <-> feature cross attention (fp32)
+# ------------------------------------------------------------------------------------------------------------------
+def attn_tok_fwd(qk, btab, feat, ids, scale):
+    """tokens <- features. qk (B,T,D), btab (B,T,NID), feat (B,L,D) fp32 contiguous, ids (B,L) int32 -> p (B,T,L), ctx (B,T,D)."""
+    hip.need_cuda(qk, btab, feat, ids)
+    B, L, D = feat.shape
+    T, NID = qk.shape[1], btab.shape[2]
+    p = torch.empty((B, T, L), dtype=torch.float32, device=feat.device)
+    ctx = torch.empty((B, T, D), dtype=torch.float32, device=feat.device)
+    hip.call('mg_attn_tok_fwd', hip.ptr(qk), hip.ptr(btab), hip.ptr(feat), hip.ptr(ids), c_int(B), c_int(T), c_int(L), c_int(D), c_int(NID),
+             c_float(scale), hip.ptr(p), hip.ptr(ctx), hip.stream())
+    return p, ctx
+
+
+def attn_tok_bwd(p, feat, qk, ids, dctx, dp, scale, NID):
+    B, L, D = feat.shape
+    T = qk.shape[1]
+    dev = feat.device
+    gbuf = torch.empty((B, T, L), dtype=torch.float32, device=dev)
+    rowdot = torch.empty((B, T), dtype=torch.float32, device=dev)
+    dqk = torch.empty((B, T, D), dtype=torch.float32, device=dev)
+    dbtab = torch.empty((B, T, NID), dtype=torch.float32, device=dev)
+    dfeat = torch.empty((B, L, D), dtype=torch.float32, device=dev)
+    hip.call('mg_attn_tok_bwd', hip.ptr(p), hip.ptr(feat), hip.ptr(qk), hip.ptr(ids), hip.ptr(dctx), hip.ptr(dp), c_int(B), c_int(T), c_int(L),
+             c_int(D), c_int(NID), c_float(scale), hip.ptr(gbuf), hip.ptr(rowdot), hip.ptr(dqk), hip.ptr(dbtab), hip.ptr(dfeat), hip.stream())
+    return dqk, dbtab, dfeat
+
+
+def attn_feat_fwd(feat, kq, b2, vp, obias, pad, ids, scale):
+    """features <- tokens. feat (B,L,D), kq / vp (B,T,D), b2 (B,NID,T), obias (D) or None, pad (B,T) uint8 or None -> out (B,L,D), p (B,L,T)."""
+    hip.need_cuda(feat, kq, b2, vp, ids)
+    B, L, D = feat.shape
+    T, NID = kq.shape[1], b2.shape[1]
+    out = torch.empty((B, L, D), dtype=torch.float32, device=feat.device)
+    p = torch.empty((B, L, T), dtype=torch.float32, device=feat.device)
+    hip.call('mg_attn_feat_fwd', hip.ptr(feat), hip.ptr(kq), hip.ptr(b2), hip.ptr(vp), hip.ptr(obias), hip.ptr(pad), hip.ptr(ids), c_int(B), c_int(T),
+             c_int(L), c_int(D), c_int(NID), c_float(scale), hip.ptr(out), hip.ptr(p), hip.stream())
+    return out, p
+
+
+def attn_feat_bwd(dout, p, feat, kq, vp, ids, scale, NID, want_bias):
+    B, L, D = feat.shape
+    T = kq.shape[1]
+    dev = feat.device
+    dfeat = torch.empty((B, L, D), dtype=torch.float32, device=dev)
+    dkq = torch.empty((B, T, D), dtype=torch.float32, device=dev)
+    dvp = torch.empty((B, T, D), dtype=torch.float32, device=dev)
+    db2 = torch.empty((B, NID, T), dtype=torch.float32, device=dev)
+    dob = torch.empty((D,), dtype=torch.float32, device=dev) if want_bias else None
+    hip.call('mg_attn_feat_bwd', hip.ptr(dout), hip.ptr(p), hip.ptr(feat), hip.ptr(kq), hip.ptr(vp), hip.ptr(ids), c_int(B), c_int(T), c_int(L),
+             c_int(D), c_int(NID), c_float(scale), hip.ptr(dfeat), hip.ptr(dkq), hip.ptr(dvp), hip.ptr(db2), hip.ptr(dob), hip.stream())
+    return dfeat, dkq, dvp, db2, dob

@@ -78,7 +78,7 @@ class InstanceMatteDecoder(nn.Module):
         m8 = m8.view(b, n_f, n_in, h, w)
         # ID position of every feature pixel = max over instances of id*mask (:150-153)
         ids = torch.arange(1, n_in + 1, device=mask.device, dtype=torch.float32)[None, None, :, None, None]
-        feat_ids = (m8 * ids).amax(2).long().reshape(b, n_f * h * w)                       # (b, L), l = f*hw + p
+        feat_ids = (m8 * ids).amax(2).to(torch.int32).reshape(b, n_f * h * w).contiguous()  # (b, L), l = f*hw + p
         id_table = self.id_embedding.weight.float() if self.use_id_pe else None
         token_pos = self.id_embedding.weight[1:self.max_inst + 1].float()[None].expand(b, -1, -1)
         tokens = self.query_feat.weight.float()[None].expand(b, -1, -1)
@@ -107,6 +107,8 @@ class InstanceMatteDecoder(nn.Module):
         token_padding_mask = ~valid_tokens
         pos_t = token_pos if self.use_id_pe else None
         tbl = id_table if self.use_id_pe else None
+        if not self.use_id_pe:
+            feat_ids = torch.zeros_like(feat_ids)
 
         # The attention blocks run in fp32 with autocast OFF: every operand is a small fp32 tensor (10 tokens per sample, one
         # (L x 128) feature matrix), so autocast would only add a cast kernel per operand per op (~250 launches per step)

@@ -10,8 +10,8 @@ projection weights and the ID position embedding into an (max_inst+1)-row lookup
   features <- tokens :  score[l, j] = f_l . (Wq^T K_j) + ((E[id_l] Wq^T + bq) . K_j),  out_l = sum_j P[l,j] (V_j Wo^T) + bo
 
 which is algebraically identical to nn.MultiheadAttention(q + pos_q, k + pos_k, v) and turns each block into one
-pass over the (L x 128) feature rows. The row-side math below is small fp32 torch plumbing; the kernels that matter
-(feature projection, 3x3 / 1x1 convolutions, BN) are HIP.
+pass over the (L x 128) feature rows -- done by the HIP kernels of maggie_amd/csrc/attention.hip (forward and exact
+backward). The 10-token projections around them are small fp32 torch ops.
 
 The reference raises ValueError("Mask is empty") when a query/feature tensor holds NaN (mask_attention.py:95-98,129-132).
 NaNs propagate through every later block, so the check is made ONCE on the final tokens (InstanceMatteDecoder.forward; one
@@ -22,6 +22,13 @@ import math
 import torch
 from torch import nn
 from torch.nn import functional as F
+
+from ... import functional as MF
+
+
+def _hip_attention(n_tokens, d):
+    """The HIP attention kernels are built for the configuration of maggie_{image,video}.yaml (10 instance tokens, width 128)."""
+    return n_tokens == 10 and d == 128
 
 
 def _split_in_proj(mha):
@@ -66,41 +73,48 @@ class CrossAttentionLayer(nn.Module):
                 nn.init.xavier_uniform_(p)
 
     def tokens_from_features(self, tokens, token_pos, feat, feat_ids, id_table):
-        """tokens (b,T,d) <- feat (b,L,d) with key position = id_table[feat_ids] ((b,L) long). Returns new tokens and the
-        attention matrix (b,T,L)."""
+        """tokens (b,T,d) <- feat (b,L,d) with key position = id_table[feat_ids] ((b,L) int32). Returns new tokens and the
+        attention matrix (b,T,L). The pass over the feature rows (scores, softmax over L, context) is one HIP pipeline
+        (mg_attn_tok_fwd / _bwd); the 10-token projections around it are small fp32 torch ops."""
         (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.multihead_attn)
         d = tokens.shape[-1]
         q = F.linear(tokens if token_pos is None else tokens + token_pos, wq, bq)            # (b,T,d)
         qk = torch.matmul(q, wk)                                                             # fold Wk into the queries
-        s = torch.matmul(qk, feat.transpose(1, 2))                                           # (b,T,L)
+        qb = (q * bk).sum(-1, keepdim=True)
         if id_table is not None:
-            tbl = torch.matmul(q, (F.linear(id_table, wk)).t()) + (q * bk).sum(-1, keepdim=True)      # (b,T,n_id)
-            s = s + torch.gather(tbl, 2, feat_ids[:, None, :].expand(-1, q.shape[1], -1))
+            tbl = torch.matmul(q, (F.linear(id_table, wk)).t()) + qb                         # (b,T,n_id)
         else:
-            s = s + (q * bk).sum(-1, keepdim=True)
-        p = torch.softmax(s / math.sqrt(d), -1)
-        ctx = torch.matmul(p, feat)                                                          # (b,T,d)
+            tbl = qb                                                                         # (b,T,1); feat_ids are all 0
+        if _hip_attention(tokens.shape[1], d):
+            p, ctx = MF.attn_tokens_from_features(qk, tbl, feat, feat_ids, 1.0 / math.sqrt(d))
+        else:                                                                                # other widths: plain torch
+            s = torch.matmul(qk, feat.transpose(1, 2)) + torch.gather(tbl, 2, feat_ids.long()[:, None, :].expand(-1, q.shape[1], -1))
+            p = torch.softmax(s / math.sqrt(d), -1)
+            ctx = torch.matmul(p, feat)                                                      # (b,T,d)
         out = self.multihead_attn.out_proj(F.linear(ctx, wv, bv))
         return self.norm(tokens + out), p
 
     def features_from_tokens(self, feat, feat_ids, id_table, tokens, token_pos, token_padding_mask):
-        """feat (b,L,d) <- tokens (b,T,d); query position = id_table[feat_ids]."""
+        """feat (b,L,d) <- tokens (b,T,d); query position = id_table[feat_ids]. Scores, masked softmax over the T tokens and
+        the value mix are one HIP kernel per direction (mg_attn_feat_fwd / _bwd)."""
         (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.multihead_attn)
         d = feat.shape[-1]
         k = F.linear(tokens if token_pos is None else tokens + token_pos, wk, bk)            # (b,T,d)
-        v = self.multihead_attn.out_proj.weight @ F.linear(tokens, wv, bv).transpose(1, 2)   # (b,d,T): Wo V^T
+        vp = F.linear(F.linear(tokens, wv, bv), self.multihead_attn.out_proj.weight)         # (b,T,d): rows of (Wo V^T)^T
         kq = torch.matmul(k, wq)                                                             # (b,T,d): fold Wq into the keys
-        s = torch.matmul(feat, kq.transpose(1, 2))                                           # (b,L,T)
         if id_table is not None:
             tbl = torch.matmul(F.linear(id_table, wq, bq), k.transpose(1, 2))                # (b,n_id,T)
-            s = s + torch.gather(tbl, 1, feat_ids[:, :, None].expand(-1, -1, k.shape[1]))
         else:
-            s = s + torch.matmul(k, bq)[:, None, :]
-        s = s / math.sqrt(d)
-        if token_padding_mask is not None:
-            s = s.masked_fill(token_padding_mask[:, None, :], float('-inf'))
-        p = torch.softmax(s, -1)
-        out = torch.matmul(p, v.transpose(1, 2)) + self.multihead_attn.out_proj.bias
+            tbl = torch.matmul(k, bq)[:, None, :]                                            # (b,1,T)
+        if _hip_attention(tokens.shape[1], d):
+            out = MF.attn_features_from_tokens(feat, kq, tbl, vp, self.multihead_attn.out_proj.bias, token_padding_mask, feat_ids,
+                                               1.0 / math.sqrt(d))
+        else:
+            s = torch.matmul(feat, kq.transpose(1, 2)) + torch.gather(tbl, 1, feat_ids.long()[:, :, None].expand(-1, -1, k.shape[1]))
+            s = s / math.sqrt(d)
+            if token_padding_mask is not None:
+                s = s.masked_fill(token_padding_mask[:, None, :], float('-inf'))
+            out = torch.matmul(torch.softmax(s, -1), vp) + self.multihead_attn.out_proj.bias
         return self.norm(feat + out)
 
 

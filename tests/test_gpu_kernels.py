@@ -291,3 +291,61 @@ def test_fused_matting_losses_forward_backward(hw):
     err = (pd.grad.cpu() - pr.grad).abs().max().item()
     assert err <= 2e-3 * pr.grad.abs().max().item(), (err, pr.grad.abs().max().item())
     assert float(pd.grad[:, 1].abs().max()) == 0.0
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# instance-token <-> feature cross attention (mg_attn_*), fp32, against plain torch autograd on the CPU
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('L,nid', [(200, 11), (4096, 11), (333, 1)])
+def test_attention_tokens_from_features(L, nid):
+    from maggie_amd import functional as MF
+    dev = _dev()
+    rs = np.random.RandomState(L + nid)
+    B, T, D = 2, 10, 128
+    t = lambda *sh: torch.from_numpy(rs.normal(size=sh).astype(np.float32))
+    qk, btab, feat = t(B, T, D) * 0.3, t(B, T, nid), t(B, L, D)
+    ids = torch.from_numpy(rs.randint(0, nid, size=(B, L)).astype(np.int32))
+    r_ctx, r_p = t(B, T, D), t(B, T, L)
+    scale = 1.0 / np.sqrt(D)
+    ref_in = [x.clone().requires_grad_(True) for x in (qk, btab, feat)]
+    s = torch.matmul(ref_in[0], ref_in[2].transpose(1, 2)) + torch.gather(ref_in[1], 2, ids.long()[:, None, :].expand(-1, T, -1))
+    p_ref = torch.softmax(s * scale, -1)
+    ctx_ref = torch.matmul(p_ref, ref_in[2])
+    ((ctx_ref * r_ctx).sum() + (p_ref * r_p).sum()).backward()
+    gin = [x.clone().to(dev).requires_grad_(True) for x in (qk, btab, feat)]
+    p, ctx = MF.attn_tokens_from_features(gin[0], gin[1], gin[2], ids.to(dev), scale)
+    ((ctx * r_ctx.to(dev)).sum() + (p * r_p.to(dev)).sum()).backward()
+    # (with a single ID row the bias gradient is identically 0 by softmax shift invariance: absolute floor)
+    close = lambda a, b, tol: float((a.cpu() - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-2)
+    assert close(p.detach(), p_ref.detach(), 2e-5) and close(ctx.detach(), ctx_ref.detach(), 2e-5)
+    for g, r, name in zip(gin, ref_in, ('dqk', 'dbtab', 'dfeat')):
+        assert close(g.grad, r.grad, 2e-4), name
+
+
+@pytest.mark.parametrize('L,nid,masked', [(200, 11, True), (4096, 11, True), (333, 1, False)])
+def test_attention_features_from_tokens(L, nid, masked):
+    from maggie_amd import functional as MF
+    dev = _dev()
+    rs = np.random.RandomState(L + 7 * nid)
+    B, T, D = 2, 10, 128
+    t = lambda *sh: torch.from_numpy(rs.normal(size=sh).astype(np.float32))
+    feat, kq, b2, vp, ob = t(B, L, D), t(B, T, D) * 0.3, t(B, nid, T), t(B, T, D), t(D)
+    ids = torch.from_numpy(rs.randint(0, nid, size=(B, L)).astype(np.int32))
+    pad = torch.zeros((B, T), dtype=torch.bool)
+    if masked:
+        pad[0, 2:] = True
+        pad[1, 7:] = True
+    r_out = t(B, L, D)
+    scale = 1.0 / np.sqrt(D)
+    ref_in = [x.clone().requires_grad_(True) for x in (feat, kq, b2, vp, ob)]
+    s = torch.matmul(ref_in[0], ref_in[1].transpose(1, 2)) + torch.gather(ref_in[2], 1, ids.long()[:, :, None].expand(-1, -1, T))
+    s = (s * scale).masked_fill(pad[:, None, :], float('-inf'))
+    out_ref = torch.matmul(torch.softmax(s, -1), ref_in[3]) + ref_in[4]
+    (out_ref * r_out).sum().backward()
+    gin = [x.clone().to(dev).requires_grad_(True) for x in (feat, kq, b2, vp, ob)]
+    out = MF.attn_features_from_tokens(gin[0], gin[1], gin[2], gin[3], gin[4], pad.to(dev) if masked else None, ids.to(dev), scale)
+    (out * r_out.to(dev)).sum().backward()
+    close = lambda a, b, tol: float((a.cpu() - b).abs().max()) <= tol * max(float(b.abs().max()), 1e-2)
+    assert close(out.detach(), out_ref.detach(), 2e-5)
+    for g, r, name in zip(gin, ref_in, ('dfeat', 'dkq', 'db2', 'dvp', 'dobias')):
+        assert close(g.grad, r.grad, 2e-4), name
