@@ -101,7 +101,8 @@ class GraphedCallable:
                 outs = fn(*self.static_inputs)
                 if training:
                     req = [o for o in outs if o.requires_grad]
-                    gr = torch.autograd.grad(req, cap_params, [torch.ones_like(o) for o in req], allow_unused=True)
+                    with torch.autocast('cuda', enabled=False):      # backward never runs under autocast (see below)
+                        gr = torch.autograd.grad(req, cap_params, [torch.ones_like(o) for o in req], allow_unused=True)
                     used = [x is not None for x in gr]
                     del gr
                 del outs
@@ -121,7 +122,11 @@ class GraphedCallable:
                 if training:
                     self.static_grad_outputs = [torch.zeros_like(o) if o.requires_grad else None for o in self.static_outputs]
                     self.bwd = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self.bwd, pool=self.pool, stream=side, capture_error_mode=CAPTURE_MODE):
+                    # A training loop calls loss.backward() OUTSIDE its autocast block, so backward ops run in the dtypes the
+                    # forward saved. The capture happens inside the caller's autocast block: switch it off for the backward,
+                    # or every fp32 matmul gradient is re-cast to bf16 (~300 extra cast kernels and a precision loss).
+                    with torch.cuda.graph(self.bwd, pool=self.pool, stream=side, capture_error_mode=CAPTURE_MODE), \
+                            torch.autocast('cuda', enabled=False):
                         MF.ARENA.begin_capture(dev)
                         self.static_param_grads = torch.autograd.grad(
                             [o for o in self.static_outputs if o.requires_grad], cap_params,

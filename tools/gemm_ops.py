@@ -1,0 +1,37 @@
+import sys, os, random, collections, traceback
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from torch.utils._python_dispatch import TorchDispatchMode
+from maggie_amd.network import build_model
+from maggie_amd.utils import config, synth
+dev = torch.device('cuda:0')
+model, _ = build_model(config.model_config('image'))
+sd = model.state_dict(); synth.fill_state_dict_(sd, 1234); model.load_state_dict(sd)
+model.to(dev).train(); model.hip_graphs = True
+batch = synth.synthetic_batch(4, 1, 2, 512, 512, seed=1234, train=True, it=100, max_inst=10)
+batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+np.random.seed(1); random.seed(1); torch.manual_seed(1)
+agg = collections.Counter()
+class Spy(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func).replace('aten.', '')
+        if torch.cuda.is_current_stream_capturing() and any(w in name for w in ('mm', 'bmm', 'linear', '_to_copy')):
+            frame = 'autograd/other'
+            for fs in reversed(traceback.extract_stack(limit=30)):
+                if 'maggie_amd' in fs.filename and not fs.filename.endswith('hip.py'):
+                    frame = '%s:%d' % (fs.filename.split('maggie_amd/')[-1], fs.lineno); break
+            dts = tuple(str(a.dtype).replace('torch.', '') for a in args if torch.is_tensor(a))
+            shp = tuple(tuple(a.shape) for a in args if torch.is_tensor(a))[:2]
+            agg[(name, dts, frame, shp if 'mm' in name else ())] += 1
+        return func(*args, **(kwargs or {}))
+def step():
+    model.zero_grad(set_to_none=True)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        out, loss = model(batch)
+    loss['total'].backward()
+torch.autograd.set_multithreading_enabled(False)
+step()
+with Spy():
+    step()
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:60]:
+    print(v, k)
