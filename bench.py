@@ -45,6 +45,8 @@ def parse():
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--cpu-threads', type=int, default=0)
     ap.add_argument('--layers', action='store_true', help='print the per-shape conv kernel table to stderr')
+    ap.add_argument('--ddp', action='store_true', help='all-reduce gradients with torch DistributedDataParallel (like the reference) instead of '
+                                                      'maggie_amd.parallel.GradSync (flat-buffer RCCL all-reduce, the default for N > 1)')
     ap.add_argument('--video', action='store_true', help='maggie_video.yaml, T=3 (BASELINE configs[3]); not the headline line')
     return ap.parse_args()
 
@@ -84,9 +86,16 @@ def main():
     if (world > 1 or force_ddp) and args.sync_bn:
         model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
     net = model
+    grad_sync = None
     if world > 1 or force_ddp:
-        from torch.nn.parallel import DistributedDataParallel as DDP
-        net = DDP(model, device_ids=[local_rank], find_unused_parameters=True, gradient_as_bucket_view=True)
+        if args.ddp:
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            net = DDP(model, device_ids=[local_rank], find_unused_parameters=True, gradient_as_bucket_view=True)
+        else:
+            # same start on every rank (DDP broadcasts rank 0's state at construction), then flat-buffer gradient all-reduce
+            for t_ in list(model.parameters()) + list(model.buffers()):
+                dist.broadcast(t_.data, 0)
+            grad_sync = parallel.GradSync(model)
     params = [p for p in model.parameters() if p.requires_grad]
     # AdamW as maggie_image.yaml:90-98; lr = max_lr / 25 = the first value of the reference's OneCycleLR schedule
     # (engine/optim.py:117-118, default div_factor) -- a full max_lr step on random-init weights makes the detail region
@@ -111,6 +120,8 @@ def main():
             out, loss = net(batch)
         t.append(time.perf_counter())
         loss['total'].backward()
+        if grad_sync is not None:
+            grad_sync()
         t.append(time.perf_counter())
         torch.nn.utils.clip_grad_norm_(params, 0.01)                                    # engine/train.py:274
         opt.step()
@@ -228,6 +239,7 @@ def main():
             'config': {'workload': 'maggie_%s.yaml train step: %dx%d, %d instances (10 slots), batch %d frames/GPU x %d frame(s), iter=%d, '
                                    'fwd+loss+bwd+clip+AdamW' % (kind, args.size, args.size, args.instances, b, n_f, args.iter),
                        'global_batch': b * world, 'parallelism': 'dp%d' % world, 'sync_bn': bool(args.sync_bn and world > 1),
+                       'grad_allreduce': None if world == 1 and not force_ddp else ('torch DDP' if args.ddp else 'GradSync (flat-buffer RCCL all-reduce)'),
                        'active_ratio': round(active_ratio, 4), 'active_ratio_per_timed_step': [round(float(v), 3) for v in stats['active_hist'][-args.steps - 2:-2]] if not args.no_roofline else None, 'active_pixels_per_step_per_gpu': int(active_px), 'loss_total': round(loss_val, 4)},
             'roofline': roofline, 'cpu_baseline': cpu_baseline,
         }

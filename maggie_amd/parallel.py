@@ -1,8 +1,16 @@
 """Data-parallel helpers (one process per GPU, torch.distributed; backend "nccl" is RCCL over xGMI on ROCm).
 
-The hot path shards on the batch axis only: gradients are all-reduced by
-torch.nn.parallel.DistributedDataParallel (bucketed, overlapped with backward on RCCL's stream); the only other exchange
-is the BatchNorm statistics of `sync_bn: true` (`nn.SyncBatchNorm` holders are honoured by functional.BNAct)."""
+The hot path shards on the batch axis only: the only data-path exchange is the gradient all-reduce
+(plus the BatchNorm statistics of `sync_bn: true`; `nn.SyncBatchNorm` holders are honoured by functional.BNAct).
+
+Two ways to all-reduce gradients:
+  * torch.nn.parallel.DistributedDataParallel (`wrap_ddp`, what the reference's engine/train.py:159-164 does) -- works unchanged,
+    also with the hipGraph trunk;
+  * `GradSync` -- the MI355X-first variant. With the trunk in a hipGraph, its ~150 parameter gradients leave the backward
+    graph as views of ONE flat buffer (graphs.GraphedCallable.export_param_grads), so the whole trunk is a single large RCCL
+    all-reduce with no per-parameter hooks, bucket copies or autograd-graph traversal; the detail-stage gradients (ready
+    before the backward graph is even launched) are coalesced into a second, small one. xGMI is point-to-point: few large
+    ring all-reduces are exactly what it wants."""
 import torch
 import torch.distributed as dist
 
@@ -36,3 +44,56 @@ def wrap_ddp(model, device_index):
     """SyncBatchNorm conversion + DDP exactly like the reference's engine/train.py:159-164."""
     from torch.nn.parallel import DistributedDataParallel as DDP
     return DDP(model, device_ids=[device_index], find_unused_parameters=False, gradient_as_bucket_view=True)
+
+
+class GradSync:
+    """Average the gradients of `model` over the process group after backward(): `sync = GradSync(model)` once, then
+    `loss.backward(); sync(); optimizer.step()`.
+
+    Gradients that are views of one flat 1-D buffer (the hipGraph trunk's export) are reduced in place through that buffer;
+    the rest are coalesced into one temporary flat tensor per dtype. Every rank must call it every step with the same set of
+    trainable parameters: a parameter without a gradient on this rank contributes zeros, so the collectives always have the
+    same shape on every rank (no hang when one rank's detail region is empty)."""
+
+    def __init__(self, model, group=None):
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.group = group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.avg = dist.is_available() and dist.is_initialized() and dist.get_backend(group) == 'nccl'
+
+    def _all_reduce(self, flat):
+        if self.avg:
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+        else:                                                     # gloo has no AVG
+            dist.all_reduce(flat, group=self.group)
+            flat.div_(self.world)
+
+    def __call__(self):
+        if self.world <= 1 and not (dist.is_available() and dist.is_initialized()):
+            return
+        bases, loose = {}, {}
+        for p in self.params:
+            g = p.grad
+            if g is None:
+                g = p.grad = torch.zeros_like(p)
+            b = g._base
+            if b is not None and b.dim() == 1 and b.is_contiguous() and g.is_contiguous():
+                ent = bases.setdefault(id(b), [b, 0])
+                ent[1] += g.numel()
+            else:
+                loose.setdefault(g.dtype, []).append(g)
+        for b, covered in bases.values():
+            if covered == b.numel():                              # the buffer holds gradients and nothing else
+                self._all_reduce(b)
+            else:                                                 # partially used base: treat its views like loose gradients
+                for p in self.params:
+                    if p.grad._base is b:
+                        loose.setdefault(p.grad.dtype, []).append(p.grad)
+        for dt, gs in loose.items():
+            flat = torch.cat([g.reshape(-1) for g in gs])
+            self._all_reduce(flat)
+            outs, o = [], 0
+            for g in gs:
+                outs.append(flat[o:o + g.numel()].view(g.shape))
+                o += g.numel()
+            torch._foreach_copy_(gs, outs)

@@ -107,6 +107,25 @@ assert sorted(g[0] + g[1]) == list(range(16)) and len(g[0]) == len(g[1])
 # max-over-ranks timing helper
 t = parallel.max_over_ranks(1.0 + dist.get_rank())
 assert abs(t - 2.0) < 1e-9
+# GradSync: gradients that are views of one flat buffer (hipGraph trunk export) + loose gradients + one missing gradient
+import torch.nn as nn
+m = nn.Sequential(nn.Linear(4, 3), nn.Linear(3, 2), nn.Linear(2, 1))
+r = dist.get_rank()
+ps = list(m.parameters())
+flat = torch.arange(sum(p.numel() for p in ps[:4]), dtype=torch.float32) * (r + 1)
+o = 0
+for p in ps[:4]:                                   # first two layers: views of one flat buffer
+    p.grad = flat[o:o + p.numel()].view(p.shape); o += p.numel()
+ps[4].grad = torch.full_like(ps[4], float(10 * (r + 1)))      # loose gradient
+if r == 0:
+    ps[5].grad = torch.full_like(ps[5], 4.0)                  # rank 1 has no gradient for this one
+parallel.GradSync(m)()
+o = 0
+for p in ps[:4]:
+    exp = torch.arange(o, o + p.numel(), dtype=torch.float32).view(p.shape) * 1.5
+    assert torch.allclose(p.grad, exp), (p.grad, exp); o += p.numel()
+assert torch.allclose(ps[4].grad, torch.full_like(ps[4], 15.0))
+assert torch.allclose(ps[5].grad, torch.full_like(ps[5], 2.0))
 dist.destroy_process_group()
 print('OK', dist.get_rank() if False else '')
 '''
