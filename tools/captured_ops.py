@@ -1,3 +1,4 @@
+"""Which aten ops end up INSIDE the captured trunk graphs? (TorchDispatchMode active during the capture step; edit the op filter)"""
 import sys, os, random, collections, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -15,14 +16,14 @@ agg = collections.Counter()
 class Spy(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = str(func).replace('aten.', '')
-        if torch.cuda.is_current_stream_capturing() and any(w in name for w in ('mm', 'bmm', 'linear', '_to_copy')):
+        if torch.cuda.is_current_stream_capturing() and any(w in name for w in ('clone', 'copy_', 'contiguous', 'fill_', 'zeros', 'zero_', 'add.Tensor', 'add_.Tensor', 'sum')):
             frame = 'autograd/other'
             for fs in reversed(traceback.extract_stack(limit=30)):
                 if 'maggie_amd' in fs.filename and not fs.filename.endswith('hip.py'):
                     frame = '%s:%d' % (fs.filename.split('maggie_amd/')[-1], fs.lineno); break
             dts = tuple(str(a.dtype).replace('torch.', '') for a in args if torch.is_tensor(a))
-            shp = tuple(tuple(a.shape) for a in args if torch.is_tensor(a))[:2]
-            agg[(name, dts, frame, shp if 'mm' in name else ())] += 1
+            contig = tuple(bool(a.is_contiguous()) for a in args if torch.is_tensor(a))[:2]
+            agg[(name, dts, frame, contig)] += 1
         return func(*args, **(kwargs or {}))
 def step():
     model.zero_grad(set_to_none=True)
