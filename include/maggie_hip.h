@@ -247,8 +247,8 @@ typedef struct mg_sn_desc {
     int32_t A, B, taps, transposed, pad_in, reserved;
 } mg_sn_desc;
 int mg_spectral_norm_batched(const mg_sn_desc* descs, int n_conv, const int32_t* items_k1, int n1, const int32_t* items_k2, int n2,
-                             const int32_t* items_k3, int n3, float* work_base, long work_floats, void* out_base, int out_dtype,
-                             void* stream);
+                             const int32_t* items_k3, int n3, float* work_base, long work_floats, void* out_base, void* out_t_base,
+                             int out_dtype, void* stream);   /* out_t_base (or NULL): same offsets, (Cin_pad, taps, Cout) copies for dgrad */
 int mg_spectral_norm_batched_bwd(const mg_sn_desc* descs, int n_conv, const int32_t* items_k3, int n3, const void* const* Gptrs,
                                  int g_dtype, float* work_base, float* dW_base, void* stream);
 

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(NT) void snb_w_t_kernel(const mg_sn_desc* __restric
 // writes u, v back to the parameters, leaves normalised copies in work (t <- v, s <- u) for the backward, emits W / sigma
 template <typename T>
 __global__ __launch_bounds__(NT) void snb_finish_kernel(const mg_sn_desc* __restrict__ descs, const int4* __restrict__ items, float* __restrict__ work_base,
-                                                        T* __restrict__ out_base) {
+                                                        T* __restrict__ out_base, T* __restrict__ out_t_base) {
     const int4 it = items[blockIdx.x];                       // (conv, chunk index, chunks of this conv, -)
     const mg_sn_desc d = descs[it.x];
     const int Wd = d.B * d.taps;
@@ -224,6 +224,9 @@ __global__ __launch_bounds__(NT) void snb_finish_kernel(const mg_sn_desc* __rest
             val = d.W[((long)a * d.B + b) * d.taps + tap] * inv_sigma;
         }
         ElemTraits<T>::st(out + o, val);
+        // the data-gradient kernel wants the same weights as (Cin_pad, taps, Cout): emit them here instead of one
+        // permute+copy launch per conv in every backward pass (plain convs only; ConvTranspose keeps its own layout)
+        if (out_t_base && !d.transposed) ElemTraits<T>::st(out_t_base + d.out_off + ((long)ci * d.taps + tap) * Cout + co, val);
     }
     // the vectors are finalised by a second tiny kernel (snb_vectors_kernel) so that no block reads t/s after they changed
 }
@@ -296,16 +299,16 @@ __global__ __launch_bounds__(NT) void snb_bwd_apply_kernel(const mg_sn_desc* __r
 
 // items_*: int32[n][4] work lists built by the host (see maggie_amd/functional.py: SpectralNormPlan)
 extern "C" int mg_spectral_norm_batched(const mg_sn_desc* descs, int n_conv, const int32_t* items_k1, int n1, const int32_t* items_k2, int n2,
-                                        const int32_t* items_k3, int n3, float* work_base, long work_floats, void* out_base, int out_dtype,
-                                        void* stream) {
+                                        const int32_t* items_k3, int n3, float* work_base, long work_floats, void* out_base, void* out_t_base,
+                                        int out_dtype, void* stream) {
     if (n_conv <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = mg_zero_words(work_base, (long)work_floats, st);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(snb_wt_u_kernel, dim3(n1), dim3(NT), 0, st, descs, (const int4*)items_k1, work_base);
     hipLaunchKernelGGL(snb_w_t_kernel, dim3(n2), dim3(NT), 0, st, descs, (const int4*)items_k2, work_base);
-    if (out_dtype == MG_BF16) hipLaunchKernelGGL(snb_finish_kernel<bf16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, work_base, (bf16raw*)out_base);
-    else hipLaunchKernelGGL(snb_finish_kernel<float>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, work_base, (float*)out_base);
+    if (out_dtype == MG_BF16) hipLaunchKernelGGL(snb_finish_kernel<bf16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, work_base, (bf16raw*)out_base, (bf16raw*)out_t_base);
+    else hipLaunchKernelGGL(snb_finish_kernel<float>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, work_base, (float*)out_base, (float*)out_t_base);
     hipLaunchKernelGGL(snb_vectors_kernel, dim3(n_conv), dim3(NT), 0, st, descs, n_conv, work_base);
     MG_CHECK_LAUNCH();
     return 0;

@@ -206,14 +206,22 @@ class SpectralNormBatch(torch.autograd.Function):
     def forward(ctx, plan, *w_bars):
         dev = w_bars[0].device
         out = torch.empty(plan.total_out, dtype=plan.dtype, device=dev)
+        want_t = any(ctx.needs_input_grad[1:])                    # a backward pass will need the transposed twins
+        out_t = torch.empty(plan.total_out, dtype=plan.dtype, device=dev) if want_t else None
         work = torch.empty(plan.total_work, dtype=torch.float32, device=dev)
         hipc, c_int = K.hip.call, K.c_int
         hipc('mg_spectral_norm_batched', K.hip.ptr(plan.descs), c_int(plan.n), K.hip.ptr(plan.k1), c_int(plan.k1.shape[0]), K.hip.ptr(plan.k2),
              c_int(plan.k2.shape[0]), K.hip.ptr(plan.k3), c_int(plan.k3.shape[0]), K.hip.ptr(work), K.c_long(plan.total_work), K.hip.ptr(out),
-             c_int(K.hip.dtype_code(out)), K.hip.stream())
+             K.hip.ptr(out_t), c_int(K.hip.dtype_code(out)), K.hip.stream())
         ctx.plan = plan
         ctx.save_for_backward(work)
-        return tuple(out[o:o + n].view(sh[0], sh[1], sh[2]) for (o, n), sh in zip(plan.out_slices, plan.shapes))
+        outs = tuple(out[o:o + n].view(sh[0], sh[1], sh[2]) for (o, n), sh in zip(plan.out_slices, plan.shapes))
+        if out_t is not None:
+            # (Cin_pad, taps, Cout) twins for the data-gradient convolution ride along as a Python attribute of each weight
+            for t_, (o, n), sh, m in zip(outs, plan.out_slices, plan.shapes, plan.modules):
+                if not m.module.transposed:
+                    t_._mg_wt = out_t[o:o + n].view(sh[2], sh[1], sh[0])
+        return outs
 
     @staticmethod
     def backward(ctx, *grads):
@@ -279,6 +287,7 @@ class ConvRaw(torch.autograd.Function):
                          pad=pad, dil=dil, shift=bias, act=ACT_RELU if pre_relu else ACT_NONE, pre_act=False,
                          stats=stats)
         y = y.view(N, Ho, Wo, Cout)
+        ctx.wt = getattr(w, '_mg_wt', None)                       # pre-transposed weights from the batched SpectralNorm kernel
         ctx.save_for_backward(x, w, y if pre_relu else None)
         ctx.geom = (N, H, W_, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, transposed, pre_relu, bias is not None)
         return y
@@ -293,7 +302,7 @@ class ConvRaw(torch.autograd.Function):
         dy2 = dy.view(-1, Cout)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wt = w.permute(2, 1, 0).contiguous()                      # (Cin, taps, Cout)
+            wt = ctx.wt if (ctx.wt is not None and not transposed) else w.permute(2, 1, 0).contiguous()      # (Cin, taps, Cout)
             dmode = MODE_CONV if transposed else MODE_TCONV
             dx = K.conv_fprop(dy2, wt, mode=dmode, N=N, Hin=Ho, Win=Wo, Hout=H, Wout=W_, R=R, S=S, stride=stride, pad=pad,
                               dil=dil).view(N, H, W_, Cin)
