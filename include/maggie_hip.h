@@ -252,6 +252,14 @@ int mg_spectral_norm_batched(const mg_sn_desc* descs, int n_conv, const int32_t*
 int mg_spectral_norm_batched_bwd(const mg_sn_desc* descs, int n_conv, const int32_t* items_k3, int n3, const void* const* Gptrs,
                                  int g_dtype, float* work_base, float* dW_base, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Inference post-path: `reverse_transform_tensor` (maggie/utils/postprocessing.py:36-64: crop the
+ * bottom/right padding to (crop_h, crop_w), bilinear resize with align_corners=True to (Hout, Wout)) fused with the alpha
+ * snapping of maggie/engine/test.py:139-142,229-231 (<= 1/255 -> 0, >= 254/255 -> 1 when `snap`). fp32 planes [P,Hin,Win].
+ * ------------------------------------------------------------------------------------------------------------- */
+int mg_postprocess_alpha(const float* in, int P, int Hin, int Win, int crop_h, int crop_w, int Hout, int Wout, int snap, float* out,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

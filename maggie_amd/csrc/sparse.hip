@@ -408,3 +408,51 @@ extern "C" int mg_upsample_tanh_bwd(const float* dout, const float* out, long sn
     MG_CHECK_LAUNCH();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Inference post-path: maggie/utils/postprocessing.py:36-64 `reverse_transform_tensor` (crop the bottom/right
+// padding, bilinear resize with align_corners=True back to the original size) fused with the alpha snapping of
+// maggie/engine/test.py:139-142,229-231 (alpha <= 1/255 -> 0, >= 254/255 -> 1), on fp32 planes [P, Hin, Win] -> [P, Hout, Wout].
+// The reference does the resize on the GPU, copies to the host and snaps in numpy; this keeps the result on the device.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(NT) void postprocess_alpha_kernel(const float* __restrict__ in, int Hin, int Win, int Hc, int Wc, int Hout, int Wout,
+                                                              float sy, float sx, int snap, float* __restrict__ out) {
+    const int p = blockIdx.y;
+    const long n = (long)Hout * Wout;
+    const float* src = in + (long)p * Hin * Win;
+    float* dst = out + (long)p * n;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+        const int y = (int)(i / Wout), x = (int)(i - (long)y * Wout);
+        // F.interpolate(mode='bilinear', align_corners=True): source = dst * (in - 1) / (out - 1) on the CROPPED (Hc x Wc) image
+        const float fy = y * sy, fx = x * sx;
+        int y0 = (int)fy, x0 = (int)fx;
+        if (y0 > Hc - 1) y0 = Hc - 1;
+        if (x0 > Wc - 1) x0 = Wc - 1;
+        const int y1 = y0 + 1 < Hc ? y0 + 1 : Hc - 1, x1 = x0 + 1 < Wc ? x0 + 1 : Wc - 1;
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float v00 = src[(long)y0 * Win + x0], v01 = src[(long)y0 * Win + x1];
+        const float v10 = src[(long)y1 * Win + x0], v11 = src[(long)y1 * Win + x1];
+        float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+        if (snap) {
+            if (v <= 1.0f / 255.0f) v = 0.f;
+            if (v >= 254.0f / 255.0f) v = 1.f;
+        }
+        dst[i] = v;
+    }
+}
+}  // namespace
+
+extern "C" int mg_postprocess_alpha(const float* in, int P, int Hin, int Win, int crop_h, int crop_w, int Hout, int Wout, int snap, float* out,
+                                    void* stream) {
+    if (P <= 0 || Hout <= 0 || Wout <= 0) return 0;
+    if (crop_h <= 0 || crop_w <= 0 || crop_h > Hin || crop_w > Win) return -2;
+    const float sy = Hout > 1 ? (float)(crop_h - 1) / (float)(Hout - 1) : 0.f;
+    const float sx = Wout > 1 ? (float)(crop_w - 1) / (float)(Wout - 1) : 0.f;
+    long blocks = ((long)Hout * Wout + NT - 1) / NT;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(postprocess_alpha_kernel, dim3((unsigned)blocks, P), dim3(NT), 0, (hipStream_t)stream, in, Hin, Win, crop_h, crop_w, Hout,
+                       Wout, sy, sx, snap, out);
+    MG_CHECK_LAUNCH();
+    return 0;
+}

@@ -171,8 +171,36 @@ def layout_fixture(ns):
         print('wrote layout', kind, len(lay))
 
 
+def postprocess_fixture():
+    """reverse_transform_tensor of the reference itself (maggie/utils/postprocessing.py) on seeded planes. Its module imports
+    skimage / cv2 at the top (used by other functions only): empty stand-ins are enough to import it."""
+    import importlib, sys, types
+    for name in ('skimage', 'skimage.measure'):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules['skimage.measure'].label = None
+    if 'maggie.utils.metric' not in sys.modules:                     # postprocessing.py only needs reshape2D from it
+        m = types.ModuleType('maggie.utils.metric')
+        m.reshape2D = lambda x: x.reshape(-1, *x.shape[-2:])
+        sys.modules['maggie.utils.metric'] = m
+    pp = importlib.import_module('maggie.utils.postprocessing')
+    rs = np.random.RandomState(21)
+    out = {}
+    cases = {'resize_pad': ((2, 3, 40, 56), [{'name': ['resize'], 'ori_size': (torch.tensor(37), torch.tensor(61))},
+                                            {'name': ['padding'], 'pad_size': (torch.tensor(5), torch.tensor(8))}]),
+             'pad_resize_same': ((1, 2, 32, 48), [{'name': 'resize', 'ori_size': (29, 48)}, {'name': 'padding', 'pad_size': (3, 0)}]),
+             'resize_only': ((3, 24, 24), [{'name': 'resize', 'ori_size': (50, 33)}])}
+    for key, (shape, info) in cases.items():
+        x = torch.from_numpy(rs.uniform(-0.05, 1.05, size=shape).astype(np.float32))
+        y = pp.reverse_transform_tensor(x, info).numpy()
+        out[key] = y
+    np.savez_compressed(os.path.join(HERE, 'postprocess_pinned.npz'), **out)
+    print('wrote postprocess_pinned.npz', {k: v.shape for k, v in out.items()})
+
+
 def main():
     ns = ref_loader.load_reference()
+    postprocess_fixture()
     layout_fixture(ns)
     dense_fixture(ns)
     model_fixture(ns, 'image', False, 1, 1, 2, 128, 0, None, 'model_image_eval.npz')

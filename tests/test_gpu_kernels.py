@@ -349,3 +349,34 @@ def test_attention_features_from_tokens(L, nid, masked):
     assert close(out.detach(), out_ref.detach(), 2e-5)
     for g, r, name in zip(gin, ref_in, ('dfeat', 'dkq', 'db2', 'dvp', 'dobias')):
         assert close(g.grad, r.grad, 2e-4), name
+
+
+def test_postprocess_alpha_matches_reference_fixture_and_oracle():
+    """mg_postprocess_alpha through maggie_amd.utils.postprocessing.reverse_transform_tensor: against the reference's own outputs
+    (tests/golden/postprocess_pinned.npz) and, with snapping, against oracle/postprocess.py."""
+    from helpers import load_golden
+    from maggie_amd.utils.postprocessing import reverse_transform_tensor
+    from oracle import postprocess as opp
+    dev = _dev()
+    gold = load_golden('postprocess_pinned.npz')
+    rs = np.random.RandomState(21)
+    cases = {'resize_pad': ((2, 3, 40, 56), [{'name': ['resize'], 'ori_size': (torch.tensor(37), torch.tensor(61))},
+                                            {'name': ['padding'], 'pad_size': (torch.tensor(5), torch.tensor(8))}]),
+             'pad_resize_same': ((1, 2, 32, 48), [{'name': 'resize', 'ori_size': (29, 48)}, {'name': 'padding', 'pad_size': (3, 0)}]),
+             'resize_only': ((3, 24, 24), [{'name': 'resize', 'ori_size': (50, 33)}])}
+    for key, (shape, info) in cases.items():
+        x = torch.from_numpy(rs.uniform(-0.05, 1.05, size=shape).astype(np.float32))
+        y = reverse_transform_tensor(x.to(dev), info).cpu().numpy()
+        assert y.shape == gold[key].shape
+        assert np.abs(y - gold[key]).max() <= 2e-6, key
+        ys = reverse_transform_tensor(x.to(dev), info, snap=True).cpu().numpy()
+        ref = opp.snap_alpha(gold[key])
+        flip = (np.abs(gold[key] - 1 / 255.0) < 1e-5) | (np.abs(gold[key] - 254 / 255.0) < 1e-5)       # knife-edge values may snap either way
+        assert np.abs(ys - ref)[~flip].max() <= 2e-6, key
+    # a full-size call: 1080p output from a padded 512x512 prediction, values stay in [0, 1] and endpoints are exact copies
+    x = torch.rand((1, 3, 2, 512, 512), device=dev)
+    info = [{'name': 'resize', 'ori_size': (1080, 1920)}, {'name': 'padding', 'pad_size': (32, 0)}]
+    y = reverse_transform_tensor(x, info, snap=True)
+    assert y.shape == (1, 3, 2, 1080, 1920) and float(y.min()) >= 0.0 and float(y.max()) <= 1.0
+    x0 = opp.snap_alpha(x[0, 0, 0, 0, 0].item())
+    assert abs(float(y[0, 0, 0, 0, 0]) - float(x0)) <= 1e-6

@@ -116,3 +116,25 @@ def test_full_model_train_vs_reference_glue():
                 bad.append(n)
     assert not bad, bad[:5]
     assert _close(sd['encoder.bn1.running_mean'].detach(), gold['bn/encoder.bn1.running_mean'], 1e-6)
+
+
+def test_postprocess_oracle_matches_reference_fixture():
+    """oracle/postprocess.py against tests/golden/postprocess_pinned.npz (outputs of the reference's own
+    maggie/utils/postprocessing.py:reverse_transform_tensor on seeded planes; generator: tests/golden/make_golden.py)."""
+    import numpy as np
+    import torch
+    from helpers import load_golden
+    from oracle import postprocess as pp
+    gold = load_golden('postprocess_pinned.npz')
+    rs = np.random.RandomState(21)
+    cases = {'resize_pad': ((2, 3, 40, 56), [{'name': ['resize'], 'ori_size': (torch.tensor(37), torch.tensor(61))},
+                                            {'name': ['padding'], 'pad_size': (torch.tensor(5), torch.tensor(8))}]),
+             'pad_resize_same': ((1, 2, 32, 48), [{'name': 'resize', 'ori_size': (29, 48)}, {'name': 'padding', 'pad_size': (3, 0)}]),
+             'resize_only': ((3, 24, 24), [{'name': 'resize', 'ori_size': (50, 33)}])}
+    for key, (shape, info) in cases.items():
+        x = torch.from_numpy(rs.uniform(-0.05, 1.05, size=shape).astype(np.float32))
+        y = pp.reverse_transform_tensor(x, info).numpy()
+        assert y.shape == gold[key].shape
+        assert np.abs(y - gold[key]).max() <= 1e-6, key
+    a = pp.snap_alpha(np.array([0.0, 1 / 255.0, 0.004, 0.5, 254 / 255.0, 0.9999], np.float32))
+    assert a.tolist() == [0.0, 0.0, np.float32(0.004), 0.5, 1.0, 1.0]
