@@ -287,12 +287,15 @@ __global__ __launch_bounds__(NT) void point_bwd_kernel(const float* __restrict__
     }
 }
 
-inline dim3 grid2(long per_plane, int P) {
+inline dim3 grid2(long per_plane, int P, long max_blocks = 1024) {
     long b = (per_plane + NT - 1) / NT;
-    if (b > 1024) b = 1024;
+    if (b > max_blocks) b = max_blocks;
     if (b < 1) b = 1;
     return dim3((unsigned)b, (unsigned)P);
 }
+// kernels that end with one atomicAdd per sum per block: every block hits the same 2-3 addresses, so keep the block count low
+// (8 planes x 1024 blocks x 3 same-address atomics cost more than the stencil itself)
+constexpr long REDUCING_BLOCKS_PER_PLANE = 48;
 
 // sums = [l1, grad, w, lap0, w0, lap1, w1, lap2, w2] -> (rec, lap, grad) exactly as arch/maggie.py:237-262 / loss.py:67-191
 // normalise them (eps 1e-8 for the L1 term, 1e-6 for the others; LapLoss is the 3-fold channel sum)
@@ -343,7 +346,7 @@ extern "C" int mg_plane_flags(const float* w, int P, int HW, int32_t* flags, voi
 extern "C" int mg_loss_point_fwd(const float* p, const float* t, const float* w, const int32_t* flags, int P, int H, int W, float* d,
                                  float* sums, void* stream) {
     if (P <= 0) return 0;
-    hipLaunchKernelGGL(point_fwd_kernel, grid2((long)H * W, P), dim3(NT), 0, (hipStream_t)stream, p, t, w, flags, H, W, d, sums);
+    hipLaunchKernelGGL(point_fwd_kernel, grid2((long)H * W, P, REDUCING_BLOCKS_PER_PLANE), dim3(NT), 0, (hipStream_t)stream, p, t, w, flags, H, W, d, sums);
     MG_CHECK_LAUNCH();
     return 0;
 }
@@ -359,7 +362,7 @@ extern "C" int mg_pyr_down(const float* x, const int32_t* flags, int P, int h, i
 extern "C" int mg_pyr_lap_fwd(const float* x, const float* down, const float* w0, int lvl, int H0, int W0, const int32_t* flags, int P, int h,
                               int w, float* G, float* sums, void* stream) {
     if (P <= 0) return 0;
-    hipLaunchKernelGGL(pyr_lap_fwd_kernel, grid2((long)h * w, P), dim3(NT), 0, (hipStream_t)stream, x, down, w0, lvl, H0, W0, flags, h, w, G, sums);
+    hipLaunchKernelGGL(pyr_lap_fwd_kernel, grid2((long)h * w, P, REDUCING_BLOCKS_PER_PLANE), dim3(NT), 0, (hipStream_t)stream, x, down, w0, lvl, H0, W0, flags, h, w, G, sums);
     MG_CHECK_LAUNCH();
     return 0;
 }

@@ -5,6 +5,7 @@
 // Replaces nn.BatchNorm2d / nn.BatchNorm1d (+ReLU / LeakyReLU / residual adds) of
 //   maggie/network/encoder/resnet.py:23-39,167-175; maggie/network/decoder/resnet.py:28-45;
 //   maggie/network/module/aspp.py:34-56; maggie/network/decoder/resnet_inst_matt_spconv.py:69-130.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/maggie_hip.h"
 
@@ -421,7 +422,8 @@ extern "C" int mg_bn_bwd_reduce(const mg_rowwise_params* p, void* stream) {
     int rc = rowwise_check(p); if (rc) return rc;
     if (p->M <= 0) return 0;
     const int ce = p->dtype == MG_BF16 ? 8 : 4;
-    const ColGeom g = col_geom(p->M, p->C, ce, 512);
+    static const int max_rb = [] { const char* e = getenv("MG_BN_RB"); return e ? atoi(e) : 512; }();
+    const ColGeom g = col_geom(p->M, p->C, ce, max_rb);
     const size_t lds = (size_t)g.ty * g.tx * 2 * ce * sizeof(float);
     if (p->dtype == MG_BF16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty);
     else hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty);
