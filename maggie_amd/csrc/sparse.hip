@@ -287,7 +287,7 @@ __global__ __launch_bounds__(NT) void upsample_tanh_bwd_kernel(const float* __re
         if (g == 0.f) continue;
         int X = (int)(i % W); long r = i / W; int Y = (int)(r % H); r /= H; int c = (int)(r % C); int n = (int)(r / C);
         float* base = din + n * sn + c * sc;
-        if (scale == 1) { atomicAdd(base + Y * sy + X * sx, g); continue; }
+        if (scale == 1) { base[Y * sy + X * sx] += g; continue; }             // one writer per element
         int y0, y1, x0, x1; float ly, lx;
         bil_src(Y, scale, h, y0, y1, ly);
         bil_src(X, scale, w, x0, x1, lx);
@@ -296,6 +296,63 @@ __global__ __launch_bounds__(NT) void upsample_tanh_bwd_kernel(const float* __re
         atomicAdd(base + y1 * sy + x0 * sx, g * ly * (1.f - lx));
         atomicAdd(base + y1 * sy + x1 * sx, g * ly * lx);
     }
+}
+
+// Atomic-free transpose of the x4 / x8 bilinear upsampling: a block owns an 8x8 tile of SOURCE pixels, stages the tanh-scaled
+// output gradient of the (8+2)*SCALE square that can reach them in LDS, and every source pixel gathers its weights. (The
+// scatter version issues 4 atomics per output pixel, ~64-256 of them onto each source address.)
+template <int SCALE>
+__global__ __launch_bounds__(NT) void upsample_tanh_bwd_tile_kernel(const float* __restrict__ dout, const float* __restrict__ out, long sn, long sc,
+                                                                    long sy, long sx, int C, int h, int w, int apply_tanh,
+                                                                    float* __restrict__ din) {
+    constexpr int TS = 8, R = (TS + 2) * SCALE;                   // LDS tile edge in output pixels
+    __shared__ float sg[R * R];
+    const int H = h * SCALE, W = w * SCALE;
+    const int plane = blockIdx.z, n = plane / C, c = plane - n * C;
+    const int y_src0 = blockIdx.y * TS, x_src0 = blockIdx.x * TS;
+    const int Y0 = (y_src0 - 1) * SCALE, X0 = (x_src0 - 1) * SCALE;
+    const long pbase = (long)plane * H * W;
+    for (int i = threadIdx.x; i < R * R; i += NT) {
+        const int ry = i / R, rx = i - ry * R, Y = Y0 + ry, X = X0 + rx;
+        float g = 0.f;
+        if (Y >= 0 && Y < H && X >= 0 && X < W) {
+            g = dout[pbase + (long)Y * W + X];
+            if (apply_tanh) { const float t = 2.f * out[pbase + (long)Y * W + X] - 1.f; g *= 0.5f * (1.f - t * t); }
+        }
+        sg[i] = g;
+    }
+    __syncthreads();
+    // 4 threads per source pixel: each takes a quarter of the window rows
+    const int sp = threadIdx.x >> 2, part = threadIdx.x & 3;
+    const int ys = y_src0 + (sp >> 3), xs = x_src0 + (sp & 7);
+    float acc = 0.f;
+    constexpr int WIN = 2 * SCALE + 2;
+    const int wy0 = (ys - 1) * SCALE + SCALE / 2 - 1, wx0 = (xs - 1) * SCALE + SCALE / 2 - 1;
+    for (int iy = part; iy < WIN; iy += 4) {
+        const int Y = wy0 + iy;
+        if (Y < 0 || Y >= H) continue;
+        int a0, a1; float la;
+        bil_src(Y, SCALE, h, a0, a1, la);
+        float wyv = 0.f;
+        if (a0 == ys) wyv += 1.f - la;
+        if (a1 == ys) wyv += la;
+        if (wyv == 0.f) continue;
+        float rowacc = 0.f;
+        for (int ix = 0; ix < WIN; ++ix) {
+            const int X = wx0 + ix;
+            if (X < 0 || X >= W) continue;
+            int b0, b1; float lb;
+            bil_src(X, SCALE, w, b0, b1, lb);
+            float wxv = 0.f;
+            if (b0 == xs) wxv += 1.f - lb;
+            if (b1 == xs) wxv += lb;
+            if (wxv != 0.f) rowacc += wxv * sg[(Y - Y0) * R + (X - X0)];
+        }
+        acc += wyv * rowacc;
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (part == 0) din[n * sn + c * sc + ys * sy + xs * sx] += acc;
 }
 
 }  // namespace
@@ -403,8 +460,13 @@ extern "C" int mg_upsample_tanh_bwd(const float* dout, const float* out, long sn
                                     int scale, int apply_tanh, float* din, void* stream) {
     long total = (long)N * C * h * w * scale * scale;
     if (total <= 0) return 0;
-    hipLaunchKernelGGL(upsample_tanh_bwd_kernel, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, dout, out, sn, sc, sy, sx, N, C, h, w,
-                       scale, apply_tanh, din);
+    hipStream_t st = (hipStream_t)stream;
+    if (scale == 4 && h % 8 == 0 && w % 8 == 0)
+        hipLaunchKernelGGL(upsample_tanh_bwd_tile_kernel<4>, dim3(w / 8, h / 8, N * C), dim3(NT), 0, st, dout, out, sn, sc, sy, sx, C, h, w, apply_tanh, din);
+    else if (scale == 8 && h % 8 == 0 && w % 8 == 0)
+        hipLaunchKernelGGL(upsample_tanh_bwd_tile_kernel<8>, dim3(w / 8, h / 8, N * C), dim3(NT), 0, st, dout, out, sn, sc, sy, sx, C, h, w, apply_tanh, din);
+    else
+        hipLaunchKernelGGL(upsample_tanh_bwd_kernel, dim3(grid_for(total)), dim3(NT), 0, st, dout, out, sn, sc, sy, sx, N, C, h, w, scale, apply_tanh, din);
     MG_CHECK_LAUNCH();
     return 0;
 }
