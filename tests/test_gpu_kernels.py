@@ -190,12 +190,13 @@ def test_gather_scatter_rows_and_planes(dtype):
     assert torch.equal(back, vals)
 
 
-@pytest.mark.parametrize('scale', [1, 4, 8])
-def test_upsample_tanh(scale):
+@pytest.mark.parametrize('scale,h,w', [(1, 8, 12), (4, 8, 12), (8, 8, 12), (4, 16, 24), (8, 8, 16), (8, 24, 16)])
+def test_upsample_tanh(scale, h, w):
+    """(h, w) multiples of 8 take the LDS-tiled atomic-free backward, the others the scatter kernel."""
     from maggie_amd import kernels as K
     dev = _dev()
     rs = np.random.RandomState(scale)
-    N, C, h, w = 2, 3, 8, 12
+    N, C = 2, 3
     x = torch.from_numpy(rs.normal(size=(N, h, w, 16)).astype(np.float32) * 2)     # NHWC, only first C channels used
     xin = x[..., :C].permute(0, 3, 1, 2).contiguous().requires_grad_(True)
     up = xin if scale == 1 else F.interpolate(xin, scale_factor=float(scale), mode='bilinear', align_corners=False)
