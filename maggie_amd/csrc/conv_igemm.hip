@@ -439,6 +439,10 @@ template <typename T>
 int dispatch_fprop(const mg_conv_params& p, hipStream_t st) {
     const int eps = sizeof(T) == 2 ? 32 : 16;
     const int nslab = (p.R * p.S * p.Cin + eps - 1) / eps;
+    // stage width: 4 slabs (256 B of K per row) for the K-heavy layers, 2 slabs for K <= 576 (C32 / C64 3x3 layers: half the LDS
+    // and staging registers -> more co-resident blocks; measured +31 % on the 512x512 C32 layers, +8 % on C64), 1 for tiny K
+    static const int ks2_max = [] { const char* e = getenv("MG_FPROP_KS2_MAX"); return e ? atoi(e) : 18; }();
+    if (nslab >= 8 && nslab <= ks2_max) return dispatch_fprop_ks<T, 2>(p, st);
     if (nslab >= 8) return dispatch_fprop_ks<T, 4>(p, st);
     return dispatch_fprop_ks<T, 1>(p, st);
 }
