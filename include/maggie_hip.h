@@ -62,6 +62,8 @@ typedef struct mg_conv_params {
     int32_t act, pre_act, res_mode; /* res_mode: 1 = same rows, 2 = residual at half resolution (nearest x2) */
     float slope;
     int32_t dw_dtype;    /* mg_conv_wgrad_ws only: dtype dW is written in (MG_F32 = 0 default, MG_BF16 needs a workspace) */
+    int32_t stat_mode;   /* mg_conv_fprop `stats`: 0 = [MG_STAT_REPLICAS][2*Cout] sum and sum of squares (default);
+                            1 = ONE row [2*Cout], column sums only (small layers: feeds the exact two-pass variance) */
 } mg_conv_params;
 
 int mg_conv_fprop(const mg_conv_params* p, void* stream);
@@ -107,7 +109,7 @@ typedef struct mg_rowwise_params {
 int mg_colstats(const void* x, int dtype, int M, int C, int ld, float* stats, void* stream);
 /* batch statistics (`nrep` replicas of [2C], summed here) -> scale/shift/mean/invstd, running-stat update (momentum, unbiased var) */
 /* exact two-pass variant for small M: stats[0:C] += sum, stats[C:2C] += sum (x - mean)^2 (stats [2C] must arrive zeroed) */
-int mg_colstats_centered(const void* x, int dtype, int M, int C, int ld, float* stats, void* stream);
+int mg_colstats_centered(const void* x, int dtype, int M, int C, int ld, float* stats, int have_sum, void* stream);
 /* `centered` != 0: stats[C:2C] holds the centred second moment (mg_colstats_centered) instead of sum x^2 */
 int mg_bn_finalize(const float* stats, int nrep, const float* count_ptr, float count, int C, int centered, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,

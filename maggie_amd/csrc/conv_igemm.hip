@@ -388,8 +388,12 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
             const int c = t < BN ? t : t - BN;
             if (n0 + c < p.Cout) {
                 const float v = (sStat[t] + sStat[2 * BN + t]) + (sStat[4 * BN + t] + sStat[6 * BN + t]);
-                float* st = p.stats + (size_t)(mt & (MG_STAT_REPLICAS - 1)) * 2 * p.Cout;   // spread same-address atomics
-                atomicAdd(&st[(t < BN ? 0 : p.Cout) + n0 + c], v);
+                if (p.stat_mode == 1) {                                       // one row, sums only
+                    if (t < BN) atomicAdd(&p.stats[n0 + c], v);
+                } else {
+                    float* st = p.stats + (size_t)(mt & (MG_STAT_REPLICAS - 1)) * 2 * p.Cout;   // spread same-address atomics
+                    atomicAdd(&st[(t < BN ? 0 : p.Cout) + n0 + c], v);
+                }
             }
         }
     }

@@ -363,20 +363,20 @@ extern "C" int mg_colstats(const void* x, int dtype, int M, int C, int ld, float
     return 0;
 }
 
-extern "C" int mg_colstats_centered(const void* x, int dtype, int M, int C, int ld, float* stats, void* stream) {
+extern "C" int mg_colstats_centered(const void* x, int dtype, int M, int C, int ld, float* stats, int have_sum, void* stream) {
     if (M <= 0) return 0;
     const int ce = dtype == MG_BF16 ? 8 : 4;
     if (C % ce || ld % ce) return -3;
     const ColGeom g = col_geom(M, C, ce, 256);
     const size_t lds = (size_t)g.ty * g.tx * 2 * ce * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    // `stats` must arrive zeroed (the caller hands out slices of a per-step zero arena): pass 1 adds the column sums only,
-    // pass 2 the centred second moments
+    // `stats` must arrive zeroed (the caller hands out slices of a per-step zero arena): pass 1 adds the column sums only
+    // (skipped when the producing conv's epilogue already did: have_sum), pass 2 the centred second moments
     if (dtype == MG_BF16) {
-        hipLaunchKernelGGL(colstats_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const bf16raw*)x, M, C, ld, stats, g.rpb, 1, 1, g.tx, g.ty);
+        if (!have_sum) hipLaunchKernelGGL(colstats_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const bf16raw*)x, M, C, ld, stats, g.rpb, 1, 1, g.tx, g.ty);
         hipLaunchKernelGGL(colstats_centered_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const bf16raw*)x, M, C, ld, stats, g.rpb, g.tx, g.ty);
     } else {
-        hipLaunchKernelGGL(colstats_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const float*)x, M, C, ld, stats, g.rpb, 1, 1, g.tx, g.ty);
+        if (!have_sum) hipLaunchKernelGGL(colstats_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const float*)x, M, C, ld, stats, g.rpb, 1, 1, g.tx, g.ty);
         hipLaunchKernelGGL(colstats_centered_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const float*)x, M, C, ld, stats, g.rpb, g.tx, g.ty);
     }
     MG_CHECK_LAUNCH();

@@ -359,8 +359,12 @@ class BNAct(torch.autograd.Function):
         centered = False
         if training:
             if group is None and M <= EXACT_STATS_ROWS:
-                # few samples per channel: exact two-pass variance (E[x^2]-E[x]^2 cancels badly when var << mean^2)
-                stats, centered = K.colstats_centered(x2, ARENA.take(2 * C, x.device)), True
+                # few samples per channel: exact two-pass variance (E[x^2]-E[x]^2 cancels badly when var << mean^2). A 1-D
+                # `stats` row already holds the column sums from the producing conv's epilogue (new_stats(.., rows)).
+                if stats is not None and stats.dim() == 1:
+                    stats, centered = K.colstats_centered(x2, stats, have_sum=True), True
+                else:
+                    stats, centered = K.colstats_centered(x2, ARENA.take(2 * C, x.device)), True
             elif stats is None:
                 stats = K.colstats(x2)
             if group is not None:
@@ -429,7 +433,11 @@ def batch_norm_act(x, bn, act=ACT_NONE, res=None, stats=None, res_mode=1, mask_x
                        _sync_group(bn) if training else None, mask_x_pos)
 
 
-def new_stats(channels, device):
+def new_stats(channels, device, rows=None, bn=None):
+    """Zeroed accumulator for the conv epilogue's BatchNorm statistics. Layers that will use the exact two-pass variance
+    (`rows` <= EXACT_STATS_ROWS, no SyncBN) only need the column sums: one row [2*channels] (conv stat_mode 1)."""
+    if rows is not None and rows <= EXACT_STATS_ROWS and (bn is None or _sync_group(bn) is None):
+        return ARENA.take(2 * channels, device)
     return ARENA.take(K.STAT_REPLICAS * 2 * channels, device).view(K.STAT_REPLICAS, 2 * channels)
 
 
@@ -454,7 +462,11 @@ def conv_bn_act(x, w, bn, act=ACT_NONE, R=3, S=3, stride=1, pad=1, dil=1, transp
                          res2=None if res2 is None else res2.contiguous().view(-1, Cout),
                          act=ACT_RELU if relu_before_bn else act, pre_act=relu_before_bn, slope=LRELU_SLOPE)
         return y.view(N, Ho, Wo, Cout)
-    stats = new_stats(Cout, x.device) if bn.training else None
+    stats = None
+    if bn.training:
+        mode_ = MODE_TCONV if transposed else MODE_CONV
+        rows = x.shape[0] * K.conv_out_size(mode_, x.shape[1], R, stride, pad, dil) * K.conv_out_size(mode_, x.shape[2], S, stride, pad, dil)
+        stats = new_stats(Cout, x.device, rows, bn)
     y = conv2d(x, w, bias, R, S, stride, pad, dil, transposed, relu_before_bn, stats)
     y = batch_norm_act(y, bn, ACT_NONE if relu_before_bn else act, res=res, stats=stats, res_mode=res_mode)
     if res2 is not None:

@@ -35,7 +35,7 @@ class ConvParams(ctypes.Structure):
         ('ldx', ctypes.c_int32), ('ldy', ctypes.c_int32), ('yoff', ctypes.c_int32), ('ldr', ctypes.c_int32),
         ('ldr2', ctypes.c_int32),
         ('act', ctypes.c_int32), ('pre_act', ctypes.c_int32), ('res_mode', ctypes.c_int32),
-        ('slope', ctypes.c_float), ('dw_dtype', ctypes.c_int32),
+        ('slope', ctypes.c_float), ('dw_dtype', ctypes.c_int32), ('stat_mode', ctypes.c_int32),
     ]
 
 

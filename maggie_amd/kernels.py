@@ -64,13 +64,16 @@ def conv_fprop(x, w, *, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=None, Wout=None,
         assert res.dtype == x.dtype
     if res2 is not None:
         assert res2.dtype == x.dtype
+    stat_mode = 0
     if stats is not None:
-        assert stats.dtype == torch.float32 and stats.numel() >= STAT_REPLICAS * 2 * Cout
+        stat_mode = 1 if stats.dim() == 1 else 0                 # 1-D [2*Cout]: single row, column sums only
+        assert stats.dtype == torch.float32 and stats.numel() >= (1 if stat_mode else STAT_REPLICAS) * 2 * Cout
     for v in (scale, shift):
         if v is not None:
             assert v.dtype == torch.float32 and v.numel() >= Cout
     p = _conv_params(x, w, out, mode, N, Hin, Win, Hout, Wout, R, S, stride, pad, dil, M, Cin, Cout, nbr, scale, shift,
                      res, res_mode, res2, act, pre_act, slope, stats, yoff)
+    p.stat_mode = stat_mode
     hip.call('mg_conv_fprop', ctypes.byref(p), hip.stream(), work=2.0 * M * Cout * R * S * Cin,
              tag=('bf16' if x.dtype == torch.bfloat16 else 'f32', mode, Cout, R * S * Cin, M))
     return out
@@ -139,14 +142,16 @@ def colstats(x, stats=None):
     return stats
 
 
-def colstats_centered(x, stats=None):
+def colstats_centered(x, stats=None, have_sum=False):
     """Exact two-pass statistics (for small row counts): stats[0:C] = sum, stats[C:2C] = sum (x - mean)^2.
-    `stats` must be zero on entry (a slice of the per-step zero arena)."""
+    `stats` must be zero on entry (a slice of the per-step zero arena) -- or, with have_sum, already hold the column sums in
+    stats[0:C] (accumulated by the producing conv's epilogue) and zeros in stats[C:2C]."""
     M, C = x.shape[0], x.shape[-1]
     if stats is None:
         stats = torch.zeros(2 * C, dtype=torch.float32, device=x.device)
     hip.need_cuda(x)
-    hip.call('mg_colstats_centered', hip.ptr(x), c_int(hip.dtype_code(x)), c_int(M), c_int(C), c_int(_ld(x)), hip.ptr(stats), hip.stream())
+    hip.call('mg_colstats_centered', hip.ptr(x), c_int(hip.dtype_code(x)), c_int(M), c_int(C), c_int(_ld(x)), hip.ptr(stats),
+             c_int(int(have_sum)), hip.stream())
     return stats
 
 
