@@ -426,14 +426,17 @@ int dispatch_fprop_ks(const mg_conv_params& p, hipStream_t st) {
     // several co-resident blocks per CU (256 CUs), not by a deeper per-block pipeline.
     static const long want = [] { const char* e = getenv("MG_FPROP_BLOCKS"); return e ? atol(e) : 768l; }();
     auto blocks = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn); };
+    static const long want_small = [] { const char* e = getenv("MG_FPROP_BLOCKS_SMALL"); return e ? atol(e) : 300l; }();   // below this many 64x64 blocks, 64x32 tiles (C512 16x16: +11 %, C256 32x32: +4 %)
     if (p.Cout > 64) {
         if (blocks(128, 128) >= want) return launch_fprop<T, 128, 128, KS>(p, st);
         if (blocks(128, 64) >= want) return launch_fprop<T, 128, 64, KS>(p, st);
-        return launch_fprop<T, 64, 64, KS>(p, st);
+        if (blocks(64, 64) >= want_small) return launch_fprop<T, 64, 64, KS>(p, st);
+        return launch_fprop<T, 64, 32, KS>(p, st);
     }
     if (p.Cout > 32) {
         if (blocks(128, 64) >= want) return launch_fprop<T, 128, 64, KS>(p, st);
-        return launch_fprop<T, 64, 64, KS>(p, st);
+        if (blocks(64, 64) >= want_small) return launch_fprop<T, 64, 64, KS>(p, st);
+        return launch_fprop<T, 64, 32, KS>(p, st);
     }
     if (p.Cout > 16) return launch_fprop<T, 128, 32, KS>(p, st);
     return launch_fprop<T, 128, 16, KS>(p, st);
