@@ -255,6 +255,24 @@ int mg_spectral_norm_batched_bwd(const mg_sn_desc* descs, int n_conv, const int3
                                  int g_dtype, float* work_base, float* dW_base, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Temporal (video) elementwise kernels. Rows x channels (NHWC) in `dtype`; rz = first gate conv's output (M, 2C) = [r | z] before
+ * the sigmoid, cpre = second gate conv's output (M, C) before the tanh.
+ *   mg_gru_gate_fwd : xrh (M,2C) = [x | sigmoid(r) * h]                      (maggie/network/module/conv_gru.py:24-25)
+ *   mg_gru_out_fwd  : hn = (1 - sigmoid(z)) * h + sigmoid(z) * tanh(cpre)    (conv_gru.py:25-26)
+ *   mg_gru_out_bwd  : from dhn: drz[:, C:], dc_pre, dh_part = dhn * (1 - z)
+ *   mg_gru_gate_bwd : from dxrh: dx = dxrh[:, :C], drz[:, :C], dh_part = dxrh[:, C:] * r
+ *   mg_temporal_fuse: eval-time alpha-level aggregation over frames (t-1, t, t+1) of maggie/network/arch/maggie_temp.py:34-77,
+ *                     in place on fp32 planes (3, P, H*W): thresholds the difference maps at 0.5, propagates t-1 -> t and t+1 -> t,
+ *                     keeps the model's own prediction where the two disagree, then propagates t -> t+1.
+ * ------------------------------------------------------------------------------------------------------------- */
+int mg_gru_gate_fwd(const void* rz, const void* x, const void* h, int dtype, int M, int C, void* xrh, void* stream);
+int mg_gru_gate_bwd(const void* dxrh, const void* rz, const void* h, int dtype, int M, int C, void* dx, void* drz, void* dh_part, void* stream);
+int mg_gru_out_fwd(const void* rz, const void* cpre, const void* h, int dtype, int M, int C, void* hn, void* stream);
+int mg_gru_out_bwd(const void* dhn, const void* rz, const void* cpre, const void* h, int dtype, int M, int C, void* drz, void* dc_pre,
+                   void* dh_part, void* stream);
+int mg_temporal_fuse(float* alphas, const float* prev, const float* df, const float* db, long plane_elems, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Inference post-path: `reverse_transform_tensor` (maggie/utils/postprocessing.py:36-64: crop the
  * bottom/right padding to (crop_h, crop_w), bilinear resize with align_corners=True to (Hout, Wout)) fused with the alpha
  * snapping of maggie/engine/test.py:139-142,229-231 (<= 1/255 -> 0, >= 254/255 -> 1 when `snap`). fp32 planes [P,Hin,Win].

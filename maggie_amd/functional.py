@@ -787,3 +787,37 @@ def attn_tokens_from_features(qk, btab, feat, ids, scale):
 
 def attn_features_from_tokens(feat, kq, b2, vp, obias, pad, ids, scale):
     return AttnFeaturesFromTokens.apply(feat, kq, b2, vp, obias, pad, ids, scale)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# ConvGRU gate math around the two gate convolutions (maggie_amd/csrc/temporal.hip)
+# ----------------------------------------------------------------------------------------------------------------------
+
+class GruGate(torch.autograd.Function):
+    """[x | sigmoid(r) * h] from the first gate conv's pre-activation rz = [r | z] (.., 2C)."""
+
+    @staticmethod
+    def forward(ctx, rz, x, h):
+        rz, x, h = rz.contiguous(), x.contiguous(), h.contiguous()
+        ctx.save_for_backward(rz, h)
+        return K.gru_gate_fwd(rz, x, h)
+
+    @staticmethod
+    def backward(ctx, dxrh):
+        rz, h = ctx.saved_tensors
+        return K.gru_gate_bwd(dxrh.contiguous(), rz, h)
+
+
+class GruOut(torch.autograd.Function):
+    """(1 - sigmoid(z)) * h + sigmoid(z) * tanh(cpre)."""
+
+    @staticmethod
+    def forward(ctx, rz, cpre, h):
+        rz, cpre, h = rz.contiguous(), cpre.contiguous(), h.contiguous()
+        ctx.save_for_backward(rz, cpre, h)
+        return K.gru_out_fwd(rz, cpre, h)
+
+    @staticmethod
+    def backward(ctx, dhn):
+        rz, cpre, h = ctx.saved_tensors
+        return K.gru_out_bwd(dhn.contiguous(), rz, cpre, h)

@@ -497,3 +497,46 @@ def attn_feat_bwd(dout, p, feat, kq, vp, ids, scale, NID, want_bias):
     hip.call('mg_attn_feat_bwd', hip.ptr(dout), hip.ptr(p), hip.ptr(feat), hip.ptr(kq), hip.ptr(vp), hip.ptr(ids), c_int(B), c_int(T), c_int(L),
              c_int(D), c_int(NID), c_float(scale), hip.ptr(dfeat), hip.ptr(dkq), hip.ptr(dvp), hip.ptr(db2), hip.ptr(dob), hip.stream())
     return dfeat, dkq, dvp, db2, dob
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# temporal (video) elementwise kernels: ConvGRU gate math, eval-time alpha aggregation
+# ------------------------------------------------------------------------------------------------------------------
+def gru_gate_fwd(rz, x, h):
+    M, C = x.numel() // x.shape[-1], x.shape[-1]
+    xrh = torch.empty(x.shape[:-1] + (2 * C,), dtype=x.dtype, device=x.device)
+    hip.call('mg_gru_gate_fwd', hip.ptr(rz), hip.ptr(x), hip.ptr(h), c_int(hip.dtype_code(x)), c_int(M), c_int(C), hip.ptr(xrh), hip.stream())
+    return xrh
+
+
+def gru_gate_bwd(dxrh, rz, h):
+    M, C = h.numel() // h.shape[-1], h.shape[-1]
+    dx, dh = torch.empty_like(h), torch.empty_like(h)
+    drz = torch.zeros_like(rz)                                    # this call fills the r half, the z half comes from gru_out_bwd
+    hip.call('mg_gru_gate_bwd', hip.ptr(dxrh), hip.ptr(rz), hip.ptr(h), c_int(hip.dtype_code(h)), c_int(M), c_int(C), hip.ptr(dx), hip.ptr(drz),
+             hip.ptr(dh), hip.stream())
+    return drz, dx, dh
+
+
+def gru_out_fwd(rz, cpre, h):
+    M, C = h.numel() // h.shape[-1], h.shape[-1]
+    hn = torch.empty_like(h)
+    hip.call('mg_gru_out_fwd', hip.ptr(rz), hip.ptr(cpre), hip.ptr(h), c_int(hip.dtype_code(h)), c_int(M), c_int(C), hip.ptr(hn), hip.stream())
+    return hn
+
+
+def gru_out_bwd(dhn, rz, cpre, h):
+    M, C = h.numel() // h.shape[-1], h.shape[-1]
+    dc, dh = torch.empty_like(h), torch.empty_like(h)
+    drz = torch.zeros_like(rz)
+    hip.call('mg_gru_out_bwd', hip.ptr(dhn), hip.ptr(rz), hip.ptr(cpre), hip.ptr(h), c_int(hip.dtype_code(h)), c_int(M), c_int(C), hip.ptr(drz),
+             hip.ptr(dc), hip.ptr(dh), hip.stream())
+    return drz, dc, dh
+
+
+def temporal_fuse_(alphas3, prev, df3, db3):
+    """In place on alphas3 (3, ...) fp32 contiguous: frames (t-1, t, t+1); prev (...) or None; df3 / db3 like alphas3."""
+    assert alphas3.is_contiguous() and df3.is_contiguous() and db3.is_contiguous() and alphas3.dtype == torch.float32
+    n = alphas3[0].numel()
+    hip.call('mg_temporal_fuse', hip.ptr(alphas3), hip.ptr(prev), hip.ptr(df3), hip.ptr(db3), c_long(n), hip.stream())
+    return alphas3

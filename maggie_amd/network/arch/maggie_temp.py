@@ -1,49 +1,44 @@
-"""MaGGIe_Temp -- mirrors maggie/network/arch/maggie_temp.py:5-79 (extra outputs/losses of the temporal decoder and the
-eval-time alpha-level aggregation over exactly frames 0,1,2)."""
-import torch
-
+"""MaGGIe_Temp -- the video model (maggie/network/arch/maggie_temp.py:5-79): MaGGIe plus the temporal decoder's extra outputs and
+losses, and at inference the alpha-level aggregation over a 3-frame window (t-1, t, t+1), here ONE in-place HIP kernel
+(mg_temporal_fuse, maggie_amd/csrc/temporal.hip) instead of ~15 elementwise launches."""
+from ... import kernels as K
 from .maggie import MaGGIe
+
+# decoder entry -> output name of the temporal extras (transform_output) and decoder loss -> loss_dict name
+_EXTRA_OUTPUTS = (('diff_backward', 'diff_pred_backward'), ('diff_forward', 'diff_pred_forward'))
+_EXTRA_LOSSES = ('loss_temp_fusion', 'loss_temp_dtssd')
 
 
 class MaGGIe_Temp(MaGGIe):
     def transform_output(self, b, n_f, h, w, n_i, pred, alpha_pred):
         output = super().transform_output(b, n_f, h, w, n_i, pred, alpha_pred)
-        diff_pred_forward = pred.pop('diff_forward', None)
-        diff_pred_backward = pred.pop('diff_backward', None)
+        extras = {name: pred.pop(key, None) for key, name in _EXTRA_OUTPUTS}
         temp_alpha = pred.pop('temp_alpha', None)
-        if diff_pred_backward is not None:
-            output['diff_pred_backward'] = diff_pred_backward.repeat(1, 1, n_i, 1, 1)
-            output['diff_pred_forward'] = diff_pred_forward.repeat(1, 1, n_i, 1, 1)
+        if extras['diff_pred_backward'] is not None:
+            for name, diff in extras.items():                                   # one difference map per frame, shared by the instances
+                output[name] = diff.repeat(1, 1, n_i, 1, 1)
             output['temp_alpha'] = temp_alpha
         return output
 
     def update_additional_decoder_loss(self, pred, loss_dict):
         super().update_additional_decoder_loss(pred, loss_dict)
-        if 'loss_temp' in pred:
-            loss_dict['loss_temp_bce'] = pred['loss_temp_bce']
-            loss_dict['loss_temp'] = pred['loss_temp']
+        if 'loss_temp' in pred:                                                 # BCE + dtSSD on the difference maps, already weighted
+            loss_dict['loss_temp_bce'], loss_dict['loss_temp'] = pred['loss_temp_bce'], pred['loss_temp']
             loss_dict['total'] += pred['loss_temp']
-        if 'loss_temp_fusion' in pred:
-            loss_dict['loss_temp_fusion'] = pred['loss_temp_fusion']
-        if 'loss_temp_dtssd' in pred:
-            loss_dict['loss_temp_dtssd'] = pred['loss_temp_dtssd']
+        loss_dict.update({k: pred[k] for k in _EXTRA_LOSSES if k in pred})
 
     def forward(self, batch, **kwargs):
         output = super().forward(batch, **kwargs)
-        if not self.training:
-            alphas = output["refined_masks"]                                   # (1, 3, n_i, H, W)
-            prev_pred = kwargs.get('prev_pred', None)
-            if prev_pred is None:
-                prev_pred = alphas[:, 0]
-            prev_pred = prev_pred.to(alphas.device)
-            next_pred = alphas[:, -1]
-            diff_forward = (output['diff_pred_forward'] > 0.5).float()
-            diff_backward = (output['diff_pred_backward'] > 0.5).float()
-            pred_forward01 = prev_pred * (1 - diff_forward[:, 1]) + alphas[:, 1] * diff_forward[:, 1]
-            pred_backward21 = next_pred * (1 - diff_backward[:, 1]) + alphas[:, 1] * diff_backward[:, 1]
-            diff = torch.abs(pred_forward01 - pred_backward21)
-            pred_forward01 = torch.where(diff > 0.0, alphas[:, 1], pred_forward01)
-            alphas[:, 1] = pred_forward01
-            pred_forward12 = pred_forward01 * (1 - diff_forward[:, 2]) + next_pred * diff_forward[:, 2]
-            alphas[:, 2] = pred_forward12
+        if self.training:
+            return output
+        # window aggregation (hard-wired to frames 0, 1, 2 like the reference): refined_masks[:, 1:3] are rewritten in place
+        alphas = output['refined_masks']                                        # (1, 3, n_i, H, W)
+        assert alphas.shape[0] == 1 and alphas.shape[1] == 3, 'the eval-time aggregation works on one 3-frame window'
+        prev = kwargs.get('prev_pred')                                          # fused t-1 of the previous window, else frame 0
+        if prev is not None:
+            prev = prev.to(alphas.device).float().contiguous()
+        fused = alphas[0].float().contiguous()
+        K.temporal_fuse_(fused, prev, output['diff_pred_forward'][0].float().contiguous(),
+                         output['diff_pred_backward'][0].float().contiguous())
+        alphas[0, 1:3] = fused[1:3]
         return output

@@ -1,5 +1,9 @@
-"""ConvGRU -- mirrors maggie/network/module/conv_gru.py:4-69 (per-frame GRU over OS8 features, 'bi' = second pass over
-the reversed clip, averaged). The two 3x3 gate convolutions run on the implicit-GEMM HIP kernel (bias in the epilogue)."""
+"""ConvGRU over the OS8 feature clip (maggie/network/module/conv_gru.py:4-69; same parameters: `ih.0`, `hh.0` conv weights).
+
+Per frame:  [r | z] = sigmoid(W_ih * [x, h]);  c = tanh(W_hh * [x, r.h]);  h' = (1 - z).h + z.c.
+The two 3x3 gate convolutions run on the implicit-GEMM HIP kernel (bias in the epilogue); everything between them is two fused
+HIP kernels (functional.GruGate / GruOut: sigmoid, gating, concatenation, tanh, blend -- forward and backward).
+Tensors are NHWC: x, h (b, H, W, C); clips (b, n_f, H, W, C)."""
 import torch
 from torch import nn
 
@@ -11,52 +15,56 @@ class ConvGRU(nn.Module):
     def __init__(self, channels, dilation=1, kernel_size=3, padding=1):
         super().__init__()
         self.channels = channels
-        self.ih = nn.Sequential(ConvWeight(channels * 2, channels * 2, kernel_size, 1, padding, dilation, bias=True), nn.Sigmoid())
-        self.hh = nn.Sequential(ConvWeight(channels * 2, channels, kernel_size, 1, padding, dilation, bias=True), nn.Tanh())
+        gate = lambda cout: ConvWeight(channels * 2, cout, kernel_size, 1, padding, dilation, bias=True)      # noqa: E731
+        self.ih = nn.Sequential(gate(channels * 2), nn.Sigmoid())        # activations live in the fused kernels; kept for the
+        self.hh = nn.Sequential(gate(channels), nn.Tanh())               # reference's module / state_dict layout
 
-    def _conv(self, holder, x):
-        c = holder[0]
-        w = MF.weight_oihw_to_krsc(c.weight, x.dtype)
-        return MF.conv2d(x, w, c.bias.float(), c.kernel_size, c.kernel_size, 1, c.padding, c.dilation)
+    @staticmethod
+    def _gate_conv(seq, inp):
+        conv = seq[0]
+        return MF.conv2d(inp, MF.weight_oihw_to_krsc(conv.weight, inp.dtype), conv.bias.float(), conv.kernel_size, conv.kernel_size, 1,
+                         conv.padding, conv.dilation)
 
+    def cell(self, x, h):
+        rz = self._gate_conv(self.ih, torch.cat((x, h), -1))             # pre-activation [r | z]
+        cand = self._gate_conv(self.hh, MF.GruGate.apply(rz, x, h))      # pre-activation candidate from [x | r.h]
+        return MF.GruOut.apply(rz, cand, h)
+
+    def run(self, clip, h):
+        """clip (b, n, H, W, C) -> all hidden states (b, n, H, W, C)."""
+        states = []
+        for t in range(clip.shape[1]):
+            h = self.cell(clip[:, t], h)
+            states.append(h)
+        return torch.stack(states, 1)
+
+    def forward(self, x, h):
+        """Single frame (b, H, W, C) -> (h', h'); clip (b, n, H, W, C) -> (states, states), like the reference."""
+        if h is None:
+            h = x.new_zeros(x.shape[:1] + x.shape[-3:])
+        if x.dim() == 5:
+            out = self.run(x, h)
+            return out, out
+        h = self.cell(x, h)
+        return h, h
+
+    # reference-compatible aliases
     def forward_single_frame(self, x, h):
-        """x, h: (b, H, W, C) NHWC."""
-        rz = torch.sigmoid(self._conv(self.ih, torch.cat([x, h], -1)))
-        r, z = rz.split(self.channels, dim=-1)
-        c = torch.tanh(self._conv(self.hh, torch.cat([x, r * h], -1)))
-        h = (1 - z) * h + z * c
+        h = self.cell(x, h)
         return h, h
 
     def forward_time_series(self, x, h):
-        o = []
-        for t in range(x.shape[1]):
-            ot, h = self.forward_single_frame(x[:, t], h)
-            o.append(ot)
-        o = torch.stack(o, dim=1)
-        return o, o
-
-    def forward(self, x, h):
-        if h is None:
-            h = torch.zeros((x.size(0), x.size(-3), x.size(-2), x.size(-1)), device=x.device, dtype=x.dtype)
-        if x.ndim == 5:
-            return self.forward_time_series(x, h)
-        return self.forward_single_frame(x, h)
+        out = self.run(x, h)
+        return out, out
 
     def propagate_features(self, feat, n_f, prev_h_state=None, temp_method='none'):
-        """feat: (b, n_f, H, W, C) NHWC."""
-        hidden_state = None
+        """feat (b, n_f, H, W, C). 'none': every frame on its own; otherwise a forward pass over the clip, and for 'bi' a second
+        pass over the reversed clip (seeded with the last forward state) averaged into all frames but the last."""
         if temp_method == 'none':
-            all_x = []
-            for j in range(n_f):
-                o, hidden_state = self.forward(x=feat[:, j], h=None)
-                all_x.append(o)
-            feat = torch.stack(all_x, dim=1)
-        else:
-            feat_forward, hidden_state = self.forward(x=feat, h=prev_h_state)
-            if temp_method == 'bi':
-                feat_backward, _ = self.forward(x=torch.flip(feat[:, :-1], dims=(1,)), h=hidden_state[:, -1])
-                feat_backward = torch.flip(feat_backward, dims=(1,))
-                feat = torch.cat([(feat_forward[:, :-1] + feat_backward) / 2, feat_forward[:, -1:]], 1)
-            else:
-                feat = feat_forward
-        return feat, hidden_state
+            frames = [self.forward(feat[:, j], None) for j in range(n_f)]
+            return torch.stack([f[0] for f in frames], 1), frames[-1][1]
+        fwd = self.run(feat, prev_h_state if prev_h_state is not None else feat.new_zeros(feat.shape[:1] + feat.shape[-3:]))
+        if temp_method != 'bi':
+            return fwd, fwd
+        rev = self.run(feat[:, :-1].flip(1), fwd[:, -1]).flip(1)
+        return torch.cat(((fwd[:, :-1] + rev) * 0.5, fwd[:, -1:]), 1), fwd

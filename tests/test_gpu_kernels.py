@@ -381,3 +381,49 @@ def test_postprocess_alpha_matches_reference_fixture_and_oracle():
     assert y.shape == (1, 3, 2, 1080, 1920) and float(y.min()) >= 0.0 and float(y.max()) <= 1.0
     x0 = opp.snap_alpha(x[0, 0, 0, 0, 0].item())
     assert abs(float(y[0, 0, 0, 0, 0]) - float(x0)) <= 1e-6
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_conv_gru_gate_kernels(dtype):
+    """mg_gru_gate_{fwd,bwd} / mg_gru_out_{fwd,bwd} against the torch formulas of conv_gru.py:22-27 (autograd on the CPU)."""
+    from maggie_amd import functional as MF
+    dev = _dev()
+    rs = np.random.RandomState(8)
+    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    t = lambda *sh: q(torch.from_numpy(rs.normal(size=sh).astype(np.float32)))
+    b, H, W, C = 2, 5, 6, 16
+    rz, x, h, cp, g1, g2 = t(b, H, W, 2 * C), t(b, H, W, C), t(b, H, W, C), t(b, H, W, C), t(b, H, W, 2 * C), t(b, H, W, C)
+    ref = [v.clone().requires_grad_(True) for v in (rz, x, h, cp)]
+    r, z = torch.sigmoid(ref[0]).split(C, -1)
+    xrh_ref = torch.cat([ref[1], r * ref[2]], -1)
+    hn_ref = (1 - z) * ref[2] + z * torch.tanh(ref[3])
+    ((xrh_ref * g1).sum() + (hn_ref * g2).sum()).backward()
+    gin = [v.clone().to(dev, dtype).requires_grad_(True) for v in (rz, x, h, cp)]
+    xrh = MF.GruGate.apply(gin[0], gin[1], gin[2])
+    hn = MF.GruOut.apply(gin[0], gin[3], gin[2])
+    ((xrh.float() * g1.to(dev)).sum() + (hn.float() * g2.to(dev)).sum()).backward()
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    close = lambda a, c: float((a.float().cpu() - c).abs().max()) <= tol * max(float(c.abs().max()), 1.0)
+    assert close(xrh.detach(), xrh_ref.detach()) and close(hn.detach(), hn_ref.detach())
+    for gi, ri, name in zip(gin, ref, ('drz', 'dx', 'dh', 'dc')):
+        assert close(gi.grad, ri.grad), name
+
+
+def test_temporal_fuse_kernel():
+    """mg_temporal_fuse against the torch restatement of maggie_temp.py:34-77 (the oracle's decoder_video epilogue uses the same)."""
+    from maggie_amd import kernels as K
+    dev = _dev()
+    rs = np.random.RandomState(5)
+    a = torch.from_numpy(rs.uniform(size=(3, 4, 16, 24)).astype(np.float32))
+    df = torch.from_numpy(rs.uniform(size=(3, 4, 16, 24)).astype(np.float32))
+    db = torch.from_numpy(rs.uniform(size=(3, 4, 16, 24)).astype(np.float32))
+    for prev in (None, torch.from_numpy(rs.uniform(size=(4, 16, 24)).astype(np.float32))):
+        al = a.clone()
+        pv = al[0] if prev is None else prev
+        f, bk = (df > 0.5).float(), (db > 0.5).float()
+        p01 = pv * (1 - f[1]) + al[1] * f[1]
+        p21 = al[2] * (1 - bk[1]) + al[1] * bk[1]
+        p01 = torch.where((p01 - p21).abs() > 0, al[1], p01)
+        p12 = p01 * (1 - f[2]) + al[2] * f[2]
+        out = K.temporal_fuse_(a.clone().to(dev), None if prev is None else prev.to(dev), df.to(dev), db.to(dev)).cpu()
+        assert torch.equal(out[0], a[0]) and torch.allclose(out[1], p01, atol=1e-7) and torch.allclose(out[2], p12, atol=1e-7)
