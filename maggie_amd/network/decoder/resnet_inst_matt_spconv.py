@@ -190,7 +190,7 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
         l1, l2, l4, l8 = pyr.levels
         # OS8 gather * instance guidance -> FFN (inst_spec_layer)  (:221-232)
         x = MF.gather_rows(os8_feat, l8, n_i, mul=inst_guidance_os8)
-        x = self.inst_spec_layer(x.float()).to(os8_feat.dtype) if x.shape[0] > 0 else x
+        x = self._inst_spec(x) if x.shape[0] > 0 else x
         # layer3: inverse conv OS8->OS4, BN, LeakyReLU, SubM 3x3
         x = self._inverse(x, self.layer3[0], pyr, 2)
         x = self._bn_rows(x, self.layer3[1], MF.ACT_LRELU)
@@ -227,6 +227,18 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
         o1 = self._subm3(o1, self.refine_OS1[3], l1)
         x_os1 = MF.scatter_plane(o1, l1.coords, P, H, W, -99.0)
         return x_os4, x_os1, pyr
+
+    def _inst_spec(self, x):
+        """inst_spec_layer = FFNLayer(64, 64, dropout 0.1) over the gathered OS8 rows (:228-232; mask_attention.py:170-182): both 64x64
+        linears on the implicit-GEMM kernel (bias / ReLU in the epilogue), the two dropouts in the reference's order (they consume
+        the torch RNG), residual + LayerNorm in fp32."""
+        ffn = self.inst_spec_layer
+        dt = x.dtype
+        w1 = MF._pad_krsc(ffn.linear1.weight[:, None, :], dt, None, None)
+        w2 = MF._pad_krsc(ffn.linear2.weight[:, None, :], dt, None, None)
+        hid = ffn.dropout(MF.linear_rows(x, w1, ffn.linear1.bias.float(), pre_relu=True))
+        out = ffn.dropout(MF.linear_rows(hid, w2, ffn.linear2.bias.float()))
+        return ffn.norm(x.float() + out.float()).to(dt)
 
     def fuse(self, pred, detail_bits):
         """Progressive refinement (:272-290) with the two compute_unknown calls on device bit planes."""
