@@ -73,6 +73,17 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         """Per-forward bookkeeping done ONCE instead of per layer: zero the accumulator arena, bump every BatchNorm's
         num_batches_tracked with a single foreach op."""
         MF.ARENA.reset(device)
+        # Everything cached by address (captured graphs, the BatchNorm counter list) is dropped when the parameters were
+        # re-allocated: model.to(...) / .half() / .float() / a re-assigned .data
+        sentinel = self.__dict__.get('_addr_sentinels')
+        if sentinel is None:
+            ps = list(self.parameters())
+            sentinel = self.__dict__['_addr_sentinels'] = [ps[0], ps[len(ps) // 2], ps[-1]]
+        sig = tuple(p.data_ptr() for p in sentinel)
+        if self.__dict__.get('_addr_sig') != sig:
+            self.__dict__.get('_trunk_graphs', {}).clear()
+            self.__dict__.pop('_bn_counters', None)
+            self.__dict__['_addr_sig'] = sig
         if self._defer_bn_counters():
             ctr = self.__dict__.get('_bn_counters')
             if ctr is None or any(c.device != device for c in ctr):

@@ -105,3 +105,25 @@ def test_graph_grads_do_not_alias_static_buffers():
     one()
     double = model.get_parameter(name).grad
     assert float((double - 2 * single).abs().max()) <= 0.05 * float(single.abs().max())
+
+
+def test_graphs_are_dropped_when_parameters_move():
+    """model.float()/.to()/.half() re-allocate the parameters; graphs captured on the old addresses must not be replayed, and a
+    new capture on the new addresses must again reproduce the eager result."""
+    from maggie_amd.utils import synth
+    dev = _dev()
+    model, _ = _build('image', dev, False)
+    batch = _to(synth.synthetic_batch(1, 1, 2, 64, 64, seed=DSEED, train=False), dev)
+    state = copy.deepcopy(model.state_dict())
+    for _ in range(3):
+        _one_step(model, state, batch, True, False, False)
+    assert any(not isinstance(v, (int, str)) for v in model._trunk_graphs.values())
+    model.double().float()                                         # new storage for every parameter, same values
+    first = _one_step(model, state, batch, True, False, False)
+    assert all(isinstance(v, (int, str)) for v in model._trunk_graphs.values()), 'stale graphs must have been dropped'
+    eager = _one_step(model, state, batch, False, False, False)
+    _one_step(model, state, batch, True, False, False)             # capture on the new addresses
+    replay = _one_step(model, state, batch, True, False, False)
+    assert any(not isinstance(v, (int, str)) for v in model._trunk_graphs.values())
+    for r in (first, replay):
+        assert float((r['alpha'] - eager['alpha']).abs().max()) <= 1e-4 and torch.equal(r['mask'], eager['mask'])
