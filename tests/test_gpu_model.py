@@ -185,3 +185,50 @@ def test_dense_path_matches_reference_pinned(mode):
         print(mode, k, 'max abs %.3g rel-to-max %.3g' % (np.abs(a - r).max(), rel))
         worst = max(worst, rel)
     assert worst < (2e-5 if mode == 'eval' else 5e-4)
+
+
+@pytest.mark.parametrize('kind,b,n_f,n_inst,h,w,mask_scale', [
+    ('image', 1, 1, 1, 96, 160, 8),        # one instance, non-square, W not a multiple of 64 (ragged bit-plane words)
+    ('image', 2, 1, 3, 64, 96, 8),         # batch of two different images, three instances
+    ('image', 1, 1, 2, 128, 64, 1),        # guidance masks given at full resolution
+    ('video', 1, 3, 1, 96, 128, 8),        # video window, one instance, non-square
+])
+def test_eval_edge_geometries_match_oracle(kind, b, n_f, n_inst, h, w, mask_scale):
+    """Geometries the reference handles (arch/maggie.py:170-198: masks at 1/8 or full resolution, any instance count, any H x W that
+    is a multiple of 32) against the CPU oracle: alpha within 1e-3, detail mask bit-exact (image)."""
+    from maggie_amd.utils import synth
+    from oracle import refmodel
+    dev = _dev()
+    model, sd = _build(kind, dev, False)
+    batch = synth.synthetic_batch(b, n_f, n_inst, h, w, seed=DSEED + 1, train=False, mask_scale=mask_scale)
+    with torch.no_grad():
+        out = model(_to(batch, dev))
+        ref = refmodel.maggie_forward({k: v.clone() for k, v in sd.items()}, model_cfg(kind), batch, False)
+    budget = 1e-3 if kind == 'video' else 0.0          # the video decoder's >= 0.95 snap is a float discontinuity (see above)
+    for k in ('alpha_os8', 'alpha_os4', 'alpha_os1', 'refined_masks'):
+        o = out[k].float().cpu()
+        assert o.shape == ref[k].shape == (b, n_f, n_inst, h, w)
+        bad = float(((o - ref[k]).abs() > ALPHA_TOL).float().mean())
+        assert bad <= budget, '%s: %.2e of pixels beyond %.0e (max %.3g)' % (k, bad, ALPHA_TOL, float((o - ref[k]).abs().max()))
+    dm, rm = out['detail_mask'].cpu().numpy(), ref['detail_mask'].numpy()
+    if kind == 'image':
+        assert np.array_equal(dm, rm), 'active-pixel index map must be bit-exact'
+    else:
+        assert float((dm != rm).mean()) <= 2e-3
+
+
+def test_empty_guidance_mask_raises_like_the_reference():
+    """An instance whose guidance mask is empty poisons the attention with NaNs; the reference raises ValueError("Mask is empty")
+    (mask_attention.py:95-98) -- so do the oracle and this build (eager and graphed)."""
+    from maggie_amd.utils import synth
+    from oracle import refmodel
+    dev = _dev()
+    model, sd = _build('image', dev, False)
+    batch = synth.synthetic_batch(1, 1, 2, 64, 64, seed=DSEED, train=False)
+    batch['mask'][:] = 0
+    with torch.no_grad():
+        with pytest.raises(ValueError, match='Mask is empty'):
+            refmodel.maggie_forward({k: v.clone() for k, v in sd.items()}, model_cfg('image'), batch, False)
+        for _ in range(3):                               # eager, capture step, replay
+            with pytest.raises(ValueError, match='Mask is empty'):
+                model(_to(batch, dev))
