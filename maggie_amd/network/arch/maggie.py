@@ -156,6 +156,8 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         else:
             self._prepare_spectral_norm('detail')
             out = entry(*inputs)
+            if torch.is_grad_enabled() == self.training:          # same autograd mode as the detail stage that will consume them
+                self.decoder.prefetch_detail_weights(MF.compute_dtype())
             from ..module.instance_matte_decoder import check_tokens
             check_tokens(out[2])
             out = (out[0].clone(),) + tuple(out[1:])              # alpha_os8 is handed to the caller: never alias graph memory

@@ -30,10 +30,22 @@ class SparseConvWeight(nn.Module):
         else:
             self.register_parameter('bias', None)
 
+    def prefetch(self, dtype):
+        """Convert weight / bias now (the host is otherwise idle while the trunk graph runs); consumed by the next krsc() / bias32()."""
+        self.__dict__['_pre_w'] = (dtype, MF.weight_krsc_param(self.weight, dtype, None, MF.pad8(self.out_channels)))
+        if self.bias is not None:
+            self.__dict__['_pre_b'] = MF.pad_vec(self.bias.float(), MF.pad8(self.out_channels))
+
     def krsc(self, dtype):
+        pre = self.__dict__.pop('_pre_w', None)
+        if pre is not None and pre[0] == dtype:
+            return pre[1]
         return MF.weight_krsc_param(self.weight, dtype, None, MF.pad8(self.out_channels))
 
     def bias32(self):
+        pre = self.__dict__.pop('_pre_b', None)
+        if pre is not None:
+            return pre
         return None if self.bias is None else MF.pad_vec(self.bias.float(), MF.pad8(self.out_channels))
 
 
@@ -289,6 +301,16 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
     # The forward pass is split at the point where shapes stop being a function of the batch geometry alone:
     #   dense_stage  -- OS32 -> OS8 decoder + instance matte decoder (static shapes: capturable in a hipGraph, graphs.py)
     #   detail_stage -- detail region, sparse refinement, fusion (data-dependent row counts)
+    def prefetch_detail_weights(self, dtype):
+        """Layout / dtype conversion of every sparse-stage weight, issued right after the trunk graph launch: ~100 small host-side
+        ops that would otherwise sit on the host-paced critical path of the detail stage."""
+        mods = self.__dict__.get('_detail_convs')
+        if mods is None:
+            skip = {id(m) for m in self.dummy_downscale.modules()}
+            mods = self.__dict__['_detail_convs'] = [m for m in self.modules() if isinstance(m, SparseConvWeight) and id(m) not in skip]
+        for m in mods:
+            m.prefetch(dtype)
+
     def dense_modules(self):
         """Sub-modules whose parameters are touched by dense_stage only."""
         return [self.layer1, self.layer2, self.refine_OS8]
