@@ -162,6 +162,8 @@ class SpectralNormPlan:
             w = m.module.weight_bar
             A, B, kh, kw = w.shape
             taps = kh * kw
+            if taps > 16:
+                raise K.hip.MaggieHipError(f'batched SpectralNorm tiles hold up to 16 taps (SN_MAXTAPS), got a {kh}x{kw} kernel')
             transposed = int(m.module.transposed)
             pad_in = pad8(m.module.in_channels)
             cout = B if transposed else A
@@ -179,9 +181,9 @@ class SpectralNormPlan:
                     k1.append((c, cb, rb, 0))
             for rg in range((A + 3) // 4):
                 k2.append((c, rg, 0, 0))
-            chunks = max(1, min(64, (max(n_out, w.numel()) + 256 * 8 - 1) // (256 * 8)))
-            for ch in range(chunks):
-                k3.append((c, ch, chunks, 0))
+            for at in range((A + 15) // 16):                      # (SN_TA x SN_TB) parameter tiles, csrc/spectral_norm.hip
+                for bt in range((B + 31) // 32):
+                    k3.append((c, at, bt, 0))
             out_off += (n_out + 7) // 8 * 8
             work_off += (Wd + A + 4 + 3) // 4 * 4
             dw_off += (w.numel() + 3) // 4 * 4
