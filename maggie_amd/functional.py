@@ -736,7 +736,7 @@ class MattingLosses(torch.autograd.Function):
 def matting_losses(pred, target, weight):
     """-> (rec, lap, grad) scalars."""
     out = MattingLosses.apply(pred, target, weight.expand_as(pred) if weight.shape != pred.shape else weight)
-    return out[0], out[1], out[2]
+    return out.unbind(0)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -145,8 +145,7 @@ class InstanceMatteDecoder(nn.Module):
         cq = MF.pad8(n_i) if MF.pad8(n_i) >= 16 else 16
         logits = []
         fr = feat.view(b, n_f * h * w, -1)
-        for bi in range(b):
-            wtok = MF._pad_krsc(tokens[bi][:, None, :], dt, None, cq)
-            logits.append(MF.linear_rows(fr[bi], wtok))
+        for tok_b, fr_b in zip(tokens.unbind(0), fr.unbind(0)):
+            logits.append(MF.linear_rows(fr_b, MF._pad_krsc(tok_b[:, None, :], dt, None, cq)))
         output_mask = torch.stack(logits, 0).view(N, h, w, cq)
         return output_mask, out_feat, tokens, max_loss, hidden_state

@@ -33,8 +33,8 @@ def _hip_attention(n_tokens, d):
 
 def _split_in_proj(mha):
     d = mha.embed_dim
-    w, b = mha.in_proj_weight, mha.in_proj_bias
-    return (w[:d], w[d:2 * d], w[2 * d:]), (b[:d], b[d:2 * d], b[2 * d:])
+    # unbind, not three slices: its backward is ONE stack of the three gradients (a slice costs zeros + copy + add each)
+    return mha.in_proj_weight.view(3, d, d).unbind(0), mha.in_proj_bias.view(3, d).unbind(0)
 
 
 class SelfAttentionLayer(nn.Module):

@@ -46,6 +46,46 @@ def wrap_ddp(model, device_index):
     return DDP(model, device_ids=[device_index], find_unused_parameters=False, gradient_as_bucket_view=True)
 
 
+def grad_buffers(params, fill_missing=False):
+    """Tensors that together hold every gradient of `params` exactly once: a flat 1-D base buffer where all of it is covered
+    by gradient views (the hipGraph trunk's export: ~150 gradients = ONE tensor), the gradients themselves otherwise."""
+    bases, loose = {}, []
+    for p in params:
+        g = p.grad
+        if g is None:
+            if not fill_missing:
+                continue
+            g = p.grad = torch.zeros_like(p)
+        b = g._base
+        if b is not None and b.dim() == 1 and b.is_contiguous() and g.is_contiguous():
+            ent = bases.setdefault(id(b), [b, 0, []])
+            ent[1] += g.numel()
+            ent[2].append(g)
+        else:
+            loose.append(g)
+    whole = []
+    for b, covered, views in bases.values():
+        if covered == b.numel():
+            whole.append(b)
+        else:                                                     # partially used base: its views count as loose gradients
+            loose.extend(views)
+    return whole, loose
+
+
+def clip_grad_norm_(params, max_norm, eps=1e-6):
+    """torch.nn.utils.clip_grad_norm_(params, max_norm) (2-norm; what engine/train.py:274 calls), computed over the flat
+    gradient buffers: a handful of launches instead of one multi-tensor pass over every parameter. Returns the total norm."""
+    whole, loose = grad_buffers(list(params))
+    bufs = whole + loose
+    if not bufs:
+        return torch.zeros(())
+    norms = torch._foreach_norm(bufs)
+    total = torch.linalg.vector_norm(torch.stack([n.float() for n in norms]))
+    coef = (max_norm / (total + eps)).clamp(max=1.0)
+    torch._foreach_mul_(bufs, coef)
+    return total
+
+
 class GradSync:
     """Average the gradients of `model` over the process group after backward(): `sync = GradSync(model)` once, then
     `loss.backward(); sync(); optimizer.step()`.
@@ -71,24 +111,12 @@ class GradSync:
     def __call__(self):
         if self.world <= 1 and not (dist.is_available() and dist.is_initialized()):
             return
-        bases, loose = {}, {}
-        for p in self.params:
-            g = p.grad
-            if g is None:
-                g = p.grad = torch.zeros_like(p)
-            b = g._base
-            if b is not None and b.dim() == 1 and b.is_contiguous() and g.is_contiguous():
-                ent = bases.setdefault(id(b), [b, 0])
-                ent[1] += g.numel()
-            else:
-                loose.setdefault(g.dtype, []).append(g)
-        for b, covered in bases.values():
-            if covered == b.numel():                              # the buffer holds gradients and nothing else
-                self._all_reduce(b)
-            else:                                                 # partially used base: treat its views like loose gradients
-                for p in self.params:
-                    if p.grad._base is b:
-                        loose.setdefault(p.grad.dtype, []).append(p.grad)
+        whole, rest = grad_buffers(self.params, fill_missing=True)
+        for b in whole:                                           # the buffer holds gradients and nothing else
+            self._all_reduce(b)
+        loose = {}
+        for g in rest:
+            loose.setdefault(g.dtype, []).append(g)
         for dt, gs in loose.items():
             flat = torch.cat([g.reshape(-1) for g in gs])
             self._all_reduce(flat)

@@ -141,3 +141,30 @@ def test_world_size_2_gloo_path(tmp_path):
     for p in procs:
         out, _ = p.communicate(timeout=120)
         assert p.returncode == 0, out.decode()
+
+
+def test_flat_clip_grad_norm_matches_torch():
+    """parallel.clip_grad_norm_ == torch.nn.utils.clip_grad_norm_ (the call of engine/train.py:274) for gradients that are
+    views of a flat buffer (fully and partially covered) mixed with ordinary ones, and for a missing gradient."""
+    import torch
+    from maggie_amd import parallel
+    g = torch.Generator().manual_seed(3)
+    shapes = [(4, 3, 3, 3), (7,), (5, 2), (6,), (2, 2)]
+    for max_norm in (0.01, 1e6):
+        ours = [torch.nn.Parameter(torch.zeros(s)) for s in shapes] + [torch.nn.Parameter(torch.zeros(3))]
+        ref = [torch.nn.Parameter(torch.zeros(s)) for s in shapes] + [torch.nn.Parameter(torch.zeros(3))]
+        grads = [torch.randn(s, generator=g) for s in shapes]
+        flat = torch.cat([grads[0].reshape(-1), grads[1].reshape(-1)])                 # fully covered base
+        ours[0].grad, ours[1].grad = flat[:108].view(shapes[0]), flat[108:].view(shapes[1])
+        part = torch.cat([grads[2].reshape(-1), torch.full((5,), 1e9)])                # base with foreign content: must not count
+        ours[2].grad = part[:10].view(shapes[2])
+        ours[3].grad, ours[4].grad = grads[3].clone(), grads[4].clone()
+        for p, gr in zip(ref, grads):
+            p.grad = gr.clone()
+        n_ref = torch.nn.utils.clip_grad_norm_(ref, max_norm)
+        n_ours = parallel.clip_grad_norm_(ours, max_norm)
+        assert torch.allclose(n_ours, n_ref, rtol=1e-6)
+        for a, b in zip(ours[:5], ref[:5]):
+            assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=0)
+        assert ours[5].grad is None
+        assert float(part[10:].min()) == 1e9
