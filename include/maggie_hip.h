@@ -273,6 +273,28 @@ int mg_gru_out_bwd(const void* dhn, const void* rz, const void* cpre, const void
 int mg_temporal_fuse(float* alphas, const float* prev, const float* df, const float* db, long plane_elems, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Sparse refinement head, parameter side (maggie/network/decoder/resnet_inst_matt_spconv.py:69-130: the spconv layers' weights
+ * (Cout, k, k, Cin) and biases, and inst_spec_layer's two nn.Linear). One launch converts ALL of them for a step, one launch
+ * brings all their gradients back:
+ *   backward == 0: src fp32 parameter (cout, taps, cin) -> dst (cout_pad, taps, cin_pad) zero padded, in `dtype`;
+ *                  dst_t (or NULL) (cin_pad, taps, cout_pad), taps reversed when flip_t (input-gradient operand of a
+ *                  submanifold conv). A bias is an entry with cout = taps = 1.
+ *   backward != 0: src (cout_pad, taps, cin_pad) in `dtype` (NULL = no gradient) -> dst fp32 (cout, taps, cin).
+ * `entries` is a HOST array (n <= MG_WB_MAX_ENTRIES); it travels in the kernel arguments.
+ *   mg_bias_act_bwd: backward of a "+bias, ReLU" epilogue over rows x C: g = dy * (y > 0) (y, g NULL: no activation) and
+ *                  db[c] = sum_m g[m,c] (db NULL: no bias), one pass.
+ * ------------------------------------------------------------------------------------------------------------- */
+#define MG_WB_MAX_ENTRIES 64
+typedef struct mg_wb_entry {
+    const void* src;
+    void* dst;
+    void* dst_t;
+    int32_t cout, taps, cin, cout_pad, cin_pad, flip_t, dtype, reserved;
+} mg_wb_entry;
+int mg_weight_bank(const mg_wb_entry* entries, int n, int backward, void* stream);
+int mg_bias_act_bwd(const void* dy, const void* y, void* g, int dtype, int M, int C, float* db, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Inference post-path: `reverse_transform_tensor` (maggie/utils/postprocessing.py:36-64: crop the
  * bottom/right padding to (crop_h, crop_w), bilinear resize with align_corners=True to (Hout, Wout)) fused with the alpha
  * snapping of maggie/engine/test.py:139-142,229-231 (<= 1/255 -> 0, >= 254/255 -> 1 when `snap`). fp32 planes [P,Hin,Win].

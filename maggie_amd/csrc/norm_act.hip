@@ -89,6 +89,40 @@ __global__ __launch_bounds__(NT) void colstats_kernel(const T* __restrict__ x, i
     else col_block_reduce<2 * CE>(sred, part, tx, ty, ix, iy, active, st, st + C, blockIdx.y * tx * CE, C, CE);
 }
 
+// backward of "+ bias, ReLU" epilogues (sparse convs / linears without a BatchNorm behind them): g = dy * (y > 0) and
+// db[c] = sum_m g[m,c] in one pass (the torch formulation was compare + cast + multiply + cast + sum: 5 launches)
+template <typename T>
+__global__ __launch_bounds__(NT) void bias_act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ g, int M, int C,
+                                                          float* __restrict__ db, int rows_per_block, int tx, int ty) {
+    using TR = ElemTraits<T>;
+    constexpr int CE = TR::CE;
+    extern __shared__ float sred[];
+    const int ix = threadIdx.x % tx, iy = threadIdx.x / tx;
+    const int cc = blockIdx.y * tx + ix;
+    const bool active = iy < ty && cc * CE < C;
+    float part[CE];
+#pragma unroll
+    for (int k = 0; k < CE; ++k) part[k] = 0.f;
+    const int mbeg = blockIdx.x * rows_per_block, mend = min(M, mbeg + rows_per_block);
+    if (active) {
+        for (int m = mbeg + iy; m < mend; m += ty) {
+            const long off = (long)m * C + cc * CE;
+            float f[CE];
+            TR::unpack(*(const uint4*)(dy + off), f);
+            if (y) {
+                float yv[CE];
+                TR::unpack(*(const uint4*)(y + off), yv);
+#pragma unroll
+                for (int e = 0; e < CE; ++e) f[e] = yv[e] > 0.f ? f[e] : 0.f;
+                *(uint4*)(g + off) = TR::pack(f);
+            }
+#pragma unroll
+            for (int e = 0; e < CE; ++e) part[e] += f[e];
+        }
+    }
+    if (db) col_block_reduce<CE>(sred, part, tx, ty, ix, iy, active, db, db, blockIdx.y * tx * CE, C, CE);
+}
+
 // second pass of the exact two-pass variance: stats[C+c] += sum_m (x[m,c] - stats[c]/M)^2   (stats[0:C] = column sums)
 template <typename T>
 __global__ __launch_bounds__(NT) void colstats_centered_kernel(const T* __restrict__ x, int M, int C, int ld, float* __restrict__ stats,
@@ -359,6 +393,21 @@ extern "C" int mg_colstats(const void* x, int dtype, int M, int C, int ld, float
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MG_BF16) hipLaunchKernelGGL(colstats_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const bf16raw*)x, M, C, ld, stats, g.rpb, MG_STAT_REPLICAS, 0, g.tx, g.ty);
     else hipLaunchKernelGGL(colstats_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const float*)x, M, C, ld, stats, g.rpb, MG_STAT_REPLICAS, 0, g.tx, g.ty);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_bias_act_bwd(const void* dy, const void* y, void* g, int dtype, int M, int C, float* db, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (db) { hipError_t e = mg_zero_words(db, C, st); if (e != hipSuccess) return (int)e; }
+    if (M <= 0) return 0;
+    const int ce = dtype == MG_BF16 ? 8 : 4;
+    if (C % ce) return -3;
+    if (y && !g) return -3;
+    const ColGeom gm = col_geom(M, C, ce, 64);
+    const size_t lds = (size_t)gm.ty * gm.tx * ce * sizeof(float);
+    if (dtype == MG_BF16) hipLaunchKernelGGL(bias_act_bwd_kernel<bf16raw>, dim3(gm.rb, gm.groups), dim3(NT), lds, st, (const bf16raw*)dy, (const bf16raw*)y, (bf16raw*)g, M, C, db, gm.rpb, gm.tx, gm.ty);
+    else hipLaunchKernelGGL(bias_act_bwd_kernel<float>, dim3(gm.rb, gm.groups), dim3(NT), lds, st, (const float*)dy, (const float*)y, (float*)g, M, C, db, gm.rpb, gm.tx, gm.ty);
     MG_CHECK_LAUNCH();
     return 0;
 }

@@ -122,6 +122,93 @@ def _pad_krsc(w, dtype, cin_pad, cout_pad):
     return w.to(dtype).contiguous()
 
 
+class WeightBankPlan:
+    """Static description of a set of small parameters converted together (csrc/weight_bank.hip). `items`: list of
+    (parameter, (cout, taps, cin), cout_pad, cin_pad, flip_t, is_bias); a bias is (1, 1, C) and stays fp32."""
+    MAX = 64
+
+    def __init__(self, items):
+        if len(items) > self.MAX:
+            raise K.hip.MaggieHipError('weight bank holds at most %d parameters, got %d' % (self.MAX, len(items)))
+        self.items = items
+        self.n = len(items)
+        self.fwd, self.bwd = (K.hip.WbEntry * self.n)(), (K.hip.WbEntry * self.n)()
+        self.w_off, self.b_off, self.g_off = [], [], []
+        wo = bo = go = 0
+        for i, (p, (co, taps, ci), co_pad, ci_pad, flip_t, is_bias) in enumerate(items):
+            for e in (self.fwd[i], self.bwd[i]):
+                e.cout, e.taps, e.cin, e.cout_pad, e.cin_pad, e.flip_t = co, taps, ci, co_pad, ci_pad, flip_t
+            n_out = co_pad * taps * ci_pad
+            self.w_off.append(None if is_bias else wo)
+            self.b_off.append(bo if is_bias else None)
+            self.g_off.append(go)
+            if is_bias:
+                bo += (n_out + 3) // 4 * 4
+            else:
+                wo += (n_out + 7) // 8 * 8
+            go += (co * taps * ci + 3) // 4 * 4
+        self.total_w, self.total_b, self.total_g = wo, bo, go
+
+
+class WeightBank(torch.autograd.Function):
+    """All parameters of `plan` -> kernel layouts in one launch; all their gradients back in one launch."""
+
+    @staticmethod
+    def forward(ctx, plan, dtype, *params):
+        dev = params[0].device
+        want_t = any(ctx.needs_input_grad[2:])
+        code = K.hip.BF16 if dtype == torch.bfloat16 else K.hip.F32
+        esz = 2 if dtype == torch.bfloat16 else 4
+        w = torch.empty(plan.total_w, dtype=dtype, device=dev)
+        wt = torch.empty(plan.total_w, dtype=dtype, device=dev) if want_t else None
+        b = torch.empty(max(plan.total_b, 1), dtype=torch.float32, device=dev)
+        wp, wtp, bp = w.data_ptr(), (wt.data_ptr() if want_t else 0), b.data_ptr()
+        outs = []
+        for i, (it, p) in enumerate(zip(plan.items, params)):
+            e = plan.fwd[i]
+            (co, taps, ci), co_pad, ci_pad, is_bias = it[1], it[2], it[3], it[5]
+            e.src = p.data_ptr()
+            n_out = co_pad * taps * ci_pad
+            if is_bias:
+                o = plan.b_off[i]
+                e.dst, e.dst_t, e.dtype = bp + 4 * o, None, K.hip.F32
+                outs.append(b[o:o + n_out])
+            else:
+                o = plan.w_off[i]
+                e.dst, e.dst_t, e.dtype = wp + esz * o, (wtp + esz * o) if want_t else None, code
+                v = w[o:o + n_out].view(co_pad, taps, ci_pad)
+                if want_t:
+                    v._mg_wt = wt[o:o + n_out].view(ci_pad, taps, co_pad)
+                outs.append(v)
+        K.hip.call('mg_weight_bank', plan.fwd, K.c_int(plan.n), K.c_int(0), K.hip.stream())
+        ctx.plan, ctx.code, ctx.dtype = plan, code, dtype
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        plan = ctx.plan
+        dev = next(g for g in grads if g is not None).device
+        flat = torch.empty(plan.total_g, dtype=torch.float32, device=dev)
+        fp = flat.data_ptr()
+        keep, outs = [], []
+        for i, (it, g) in enumerate(zip(plan.items, grads)):
+            e = plan.bwd[i]
+            (co, taps, ci), is_bias = it[1], it[5]
+            want = torch.float32 if is_bias else ctx.dtype
+            if g is not None and (g.dtype != want or not g.is_contiguous()):
+                g = g.to(want).contiguous()
+            keep.append(g)
+            e.src, e.dst, e.dst_t = (None if g is None else g.data_ptr()), fp + 4 * plan.g_off[i], None
+            e.dtype = K.hip.F32 if is_bias else ctx.code
+            outs.append(flat[plan.g_off[i]:plan.g_off[i] + co * taps * ci].view(it[0].shape) if ctx.needs_input_grad[2 + i] else None)
+        K.hip.call('mg_weight_bank', plan.bwd, K.c_int(plan.n), K.c_int(1), K.hip.stream())
+        return (None, None) + tuple(outs)
+
+
+def weight_bank(plan, dtype):
+    return WeightBank.apply(plan, dtype, *[it[0] for it in plan.items])
+
+
 class SpectralNormWeight(torch.autograd.Function):
     """W_bar / sigma after ONE power iteration (u, v updated in place, no gradient through them), emitted directly in the
     conv kernels' layout and compute dtype -- one fused HIP pipeline instead of torch.mv/norm/dot per wrapped conv."""
@@ -298,11 +385,11 @@ class ConvRaw(torch.autograd.Function):
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
         N, H, W_, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, transposed, pre_relu, has_bias = ctx.geom
-        dy = dy.contiguous()
-        if pre_relu:
-            dy = dy * (y > 0).to(dy.dtype)
-        dy2 = dy.view(-1, Cout)
+        dy2 = dy.contiguous().view(-1, Cout)
         dx = dw = db = None
+        want_db = has_bias and ctx.needs_input_grad[2]
+        if pre_relu or want_db:                                   # ReLU mask and bias gradient in one pass
+            dy2, db = K.bias_act_bwd(dy2, y.view(-1, Cout) if pre_relu else None, want_db)
         if ctx.needs_input_grad[0]:
             wt = ctx.wt if (ctx.wt is not None and not transposed) else w.permute(2, 1, 0).contiguous()      # (Cin, taps, Cout)
             dmode = MODE_CONV if transposed else MODE_TCONV
@@ -317,8 +404,6 @@ class ConvRaw(torch.autograd.Function):
                 dwt = K.conv_wgrad(dy2, x.view(-1, Cin), cout=Cin, mode=MODE_CONV, N=N, Hin=Ho, Win=Wo, Hout=H, Wout=W_,
                                    R=R, S=S, stride=stride, pad=pad, dil=dil, out_dtype=w.dtype)
                 dw = dwt.permute(2, 1, 0).contiguous()
-        if has_bias and ctx.needs_input_grad[2]:
-            db = dy2.float().sum(0)
         return dx, dw, db, None, None, None, None, None, None, None, None
 
 
@@ -491,6 +576,7 @@ class GatherConv(torch.autograd.Function):
         y = K.conv_fprop(x, w, mode=MODE_GATHER, nbr=nbr, R=ksize, S=ksize, shift=bias, stats=stats, act=act, pre_act=False)
         ctx.save_for_backward(x, w, nbr, nbr_t, y if act != ACT_NONE else None)
         ctx.meta = (reverse_taps, ksize, Cout, bias is not None, act)
+        ctx.wt = getattr(w, '_mg_wt', None)          # (Cin_pad, taps [reversed for submanifold], Cout) twin from the weight bank
         return y
 
     @staticmethod
@@ -498,19 +584,20 @@ class GatherConv(torch.autograd.Function):
         x, w, nbr, nbr_t, y = ctx.saved_tensors
         reverse_taps, ksize, Cout, has_bias, act = ctx.meta
         dy = dy.contiguous()
-        if act == ACT_RELU:
-            dy = dy * (y > 0).to(dy.dtype)
         dx = dw = db = None
+        want_db = has_bias and ctx.needs_input_grad[2]
+        if act == ACT_RELU or want_db:
+            dy, db = K.bias_act_bwd(dy, y if act == ACT_RELU else None, want_db)
         if ctx.needs_input_grad[0]:
-            wt = w.permute(2, 1, 0)
-            if reverse_taps:
-                wt = wt.flip(1)
-            wt = wt.contiguous()
+            wt = ctx.wt
+            if wt is None:
+                wt = w.permute(2, 1, 0)
+                if reverse_taps:
+                    wt = wt.flip(1)
+                wt = wt.contiguous()
             dx = K.conv_fprop(dy, wt, mode=MODE_GATHER, nbr=nbr_t, R=ksize, S=ksize)
         if ctx.needs_input_grad[1]:
             dw = K.conv_wgrad(x, dy, cout=Cout, mode=MODE_GATHER, nbr=nbr, R=ksize, S=ksize, out_dtype=w.dtype)
-        if has_bias and ctx.needs_input_grad[2]:
-            db = dy.float().sum(0)
         return dx, dw, db, None, None, None, None, None, None
 
 

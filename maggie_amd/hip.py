@@ -142,6 +142,13 @@ U8 = 2
 c_int, c_float, c_long = ctypes.c_int, ctypes.c_float, ctypes.c_long
 
 
+class WbEntry(ctypes.Structure):
+    """mg_wb_entry (include/maggie_hip.h)."""
+    _fields_ = [('src', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('dst_t', ctypes.c_void_p), ('cout', ctypes.c_int32),
+                ('taps', ctypes.c_int32), ('cin', ctypes.c_int32), ('cout_pad', ctypes.c_int32), ('cin_pad', ctypes.c_int32),
+                ('flip_t', ctypes.c_int32), ('dtype', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
 class SnDesc(ctypes.Structure):
     _fields_ = [('W', ctypes.c_void_p), ('u', ctypes.c_void_p), ('v', ctypes.c_void_p), ('out_off', ctypes.c_int64),
                 ('work_off', ctypes.c_int64), ('dw_off', ctypes.c_int64), ('A', ctypes.c_int32), ('B', ctypes.c_int32),

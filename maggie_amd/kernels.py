@@ -142,6 +142,16 @@ def colstats(x, stats=None):
     return stats
 
 
+def bias_act_bwd(dy, y, want_db):
+    """g = dy * (y > 0) (y None: g = dy) and db = g.sum(0) in fp32 (None unless want_db) -- one pass (mg_bias_act_bwd)."""
+    M, C = dy.shape
+    g = torch.empty_like(dy) if y is not None else dy
+    db = torch.empty(C, dtype=torch.float32, device=dy.device) if want_db else None
+    hip.call('mg_bias_act_bwd', hip.ptr(dy), hip.ptr(y), hip.ptr(g if y is not None else None), c_int(hip.dtype_code(dy)), c_int(M), c_int(C),
+             hip.ptr(db), hip.stream())
+    return g, db
+
+
 def colstats_centered(x, stats=None, have_sum=False):
     """Exact two-pass statistics (for small row counts): stats[0:C] = sum, stats[C:2C] = sum (x - mean)^2.
     `stats` must be zero on entry (a slice of the per-step zero arena) -- or, with have_sum, already hold the column sums in

@@ -84,6 +84,7 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             self.__dict__.get('_trunk_graphs', {}).clear()
             self.__dict__.pop('_bn_counters', None)
             self.__dict__['_addr_sig'] = sig
+        self.decoder.drop_prefetched()                            # a step that died half way must not leak converted weights
         if self._defer_bn_counters():
             ctr = self.__dict__.get('_bn_counters')
             if ctr is None or any(c.device != device for c in ctr):
@@ -153,6 +154,8 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
                 graphs[key] = (entry or 0) + 1
             self._prepare_spectral_norm('all')
             out = self._trunk(geom, False, *inputs, mem_feat=mem_feat)
+            if torch.is_grad_enabled() == self.training:
+                self.decoder.prefetch_detail_weights(MF.compute_dtype())
         else:
             self._prepare_spectral_norm('detail')
             out = entry(*inputs)

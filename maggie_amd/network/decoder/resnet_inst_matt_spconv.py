@@ -30,12 +30,6 @@ class SparseConvWeight(nn.Module):
         else:
             self.register_parameter('bias', None)
 
-    def prefetch(self, dtype):
-        """Convert weight / bias now (the host is otherwise idle while the trunk graph runs); consumed by the next krsc() / bias32()."""
-        self.__dict__['_pre_w'] = (dtype, MF.weight_krsc_param(self.weight, dtype, None, MF.pad8(self.out_channels)))
-        if self.bias is not None:
-            self.__dict__['_pre_b'] = MF.pad_vec(self.bias.float(), MF.pad8(self.out_channels))
-
     def krsc(self, dtype):
         pre = self.__dict__.pop('_pre_w', None)
         if pre is not None and pre[0] == dtype:
@@ -240,16 +234,22 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
         x_os1 = MF.scatter_plane(o1, l1.coords, P, H, W, -99.0)
         return x_os4, x_os1, pyr
 
+    @staticmethod
+    def _banked_linear(lin, dt):
+        pre_w, pre_b = lin.__dict__.pop('_pre_w', None), lin.__dict__.pop('_pre_b', None)
+        if pre_w is not None and pre_w[0] == dt and pre_b is not None:
+            return pre_w[1], pre_b
+        return MF._pad_krsc(lin.weight[:, None, :], dt, None, None), lin.bias.float()
+
     def _inst_spec(self, x):
         """inst_spec_layer = FFNLayer(64, 64, dropout 0.1) over the gathered OS8 rows (:228-232; mask_attention.py:170-182): both 64x64
         linears on the implicit-GEMM kernel (bias / ReLU in the epilogue), the two dropouts in the reference's order (they consume
         the torch RNG), residual + LayerNorm in fp32."""
         ffn = self.inst_spec_layer
         dt = x.dtype
-        w1 = MF._pad_krsc(ffn.linear1.weight[:, None, :], dt, None, None)
-        w2 = MF._pad_krsc(ffn.linear2.weight[:, None, :], dt, None, None)
-        hid = ffn.dropout(MF.linear_rows(x, w1, ffn.linear1.bias.float(), pre_relu=True))
-        out = ffn.dropout(MF.linear_rows(hid, w2, ffn.linear2.bias.float()))
+        (w1, b1), (w2, b2) = (self._banked_linear(lin, dt) for lin in (ffn.linear1, ffn.linear2))
+        hid = ffn.dropout(MF.linear_rows(x, w1, b1, pre_relu=True))
+        out = ffn.dropout(MF.linear_rows(hid, w2, b2))
         return ffn.norm(x.float() + out.float()).to(dt)
 
     def fuse(self, pred, detail_bits):
@@ -301,15 +301,47 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
     # The forward pass is split at the point where shapes stop being a function of the batch geometry alone:
     #   dense_stage  -- OS32 -> OS8 decoder + instance matte decoder (static shapes: capturable in a hipGraph, graphs.py)
     #   detail_stage -- detail region, sparse refinement, fusion (data-dependent row counts)
-    def prefetch_detail_weights(self, dtype):
-        """Layout / dtype conversion of every sparse-stage weight, issued right after the trunk graph launch: ~100 small host-side
-        ops that would otherwise sit on the host-paced critical path of the detail stage."""
-        mods = self.__dict__.get('_detail_convs')
-        if mods is None:
+    def _weight_bank_plan(self):
+        """Every parameter the sparse head converts per step: the spconv-layout weights / biases and inst_spec_layer's linears."""
+        plan = self.__dict__.get('_wb_plan')
+        if plan is None:
             skip = {id(m) for m in self.dummy_downscale.modules()}
-            mods = self.__dict__['_detail_convs'] = [m for m in self.modules() if isinstance(m, SparseConvWeight) and id(m) not in skip]
-        for m in mods:
-            m.prefetch(dtype)
+            convs = [m for m in self.modules() if isinstance(m, SparseConvWeight) and id(m) not in skip]
+            items, slots = [], []
+            for m in convs:
+                co, k, ci = m.out_channels, m.kernel_size, m.in_channels
+                items.append((m.weight, (co, k * k, ci), MF.pad8(co), MF.pad8(ci), int(m.kind == 'subm' and k > 1), False))
+                slots.append((m, 'w'))
+                if m.bias is not None:
+                    items.append((m.bias, (1, 1, co), 1, MF.pad8(co), 0, True))
+                    slots.append((m, 'b'))
+            ffn = self.inst_spec_layer
+            for lin in (ffn.linear1, ffn.linear2):
+                co, ci = lin.weight.shape
+                items.append((lin.weight, (co, 1, ci), co, MF.pad8(ci), 0, False))
+                slots.append((lin, 'w'))
+                items.append((lin.bias, (1, 1, co), 1, co, 0, True))
+                slots.append((lin, 'b'))
+            plan = self.__dict__['_wb_plan'] = (MF.WeightBankPlan(items), slots)
+        return plan
+
+    def prefetch_detail_weights(self, dtype):
+        """Layout / dtype conversion of every sparse-stage parameter in ONE launch (functional.WeightBank), issued right after the
+        trunk graph launch when there is one; each result waits on its module for the next krsc() / bias32() call."""
+        plan, slots = self._weight_bank_plan()
+        outs = MF.weight_bank(plan, dtype)
+        for (m, what), t in zip(slots, outs):
+            if what == 'w':
+                m.__dict__['_pre_w'] = (dtype, t)
+            else:
+                m.__dict__['_pre_b'] = t
+
+    def drop_prefetched(self):
+        plan = self.__dict__.get('_wb_plan')
+        if plan is not None:
+            for m, _ in plan[1]:
+                m.__dict__.pop('_pre_w', None)
+                m.__dict__.pop('_pre_b', None)
 
     def dense_modules(self):
         """Sub-modules whose parameters are touched by dense_stage only."""

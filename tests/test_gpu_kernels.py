@@ -427,3 +427,69 @@ def test_temporal_fuse_kernel():
         p12 = p01 * (1 - f[2]) + al[2] * f[2]
         out = K.temporal_fuse_(a.clone().to(dev), None if prev is None else prev.to(dev), df.to(dev), db.to(dev)).cpu()
         assert torch.equal(out[0], a[0]) and torch.allclose(out[1], p01, atol=1e-7) and torch.allclose(out[2], p12, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_weight_bank_matches_per_parameter_conversion(dtype):
+    """One-launch conversion of all sparse-head parameters (mg_weight_bank) == the per-parameter cast/pad/permute/flip chains,
+    bit for bit, forward (kernel layout + input-gradient twin) and backward (gradient back in the parameter's layout)."""
+    from maggie_amd import functional as MF
+    from maggie_amd.network import build_model
+    from maggie_amd.utils import config
+    DEV = _dev()
+    torch.manual_seed(5)
+    model, _ = build_model(config.model_config('image'))
+    dec = model.decoder.to(DEV)
+    for p in dec.parameters():
+        p.data.normal_()
+    plan, slots = dec._weight_bank_plan()
+    assert plan.n == len(slots) >= 25
+    outs = MF.weight_bank(plan, dtype)
+    n_twin = 0
+    for (m, what), it, o in zip(slots, plan.items, outs):
+        p, (co, taps, ci), co_pad, ci_pad, flip_t, is_bias = it
+        if is_bias:
+            ref = F.pad(p.detach().float(), (0, ci_pad - ci))
+            assert o.dtype == torch.float32 and torch.equal(o, ref)
+            continue
+        ref = F.pad(p.detach().reshape(co, taps, ci), (0, ci_pad - ci, 0, 0, 0, co_pad - co)).to(dtype)
+        assert o.dtype == dtype and o.shape == ref.shape and torch.equal(o, ref), (what, tuple(p.shape))
+        twin = ref.permute(2, 1, 0)
+        if flip_t:
+            twin = twin.flip(1)
+            n_twin += 1
+        assert torch.equal(o._mg_wt, twin.contiguous())
+    assert n_twin == 7                                            # the 3x3 submanifold convs
+    grads = [torch.randn_like(o) for o in outs]
+    torch.autograd.backward(outs, grads)
+    for it, g in zip(plan.items, grads):
+        p, (co, taps, ci), co_pad, ci_pad, flip_t, is_bias = it
+        ref = g.float()[:ci] if is_bias else g.float()[:co, :, :ci]
+        assert p.grad.dtype == torch.float32 and torch.equal(p.grad.reshape(ref.shape), ref)
+    # the module accessors hand out the banked tensors once, then fall back to converting on their own
+    dec.prefetch_detail_weights(dtype)
+    conv = dec.refine_OS1[3]
+    a, b = conv.krsc(dtype), conv.krsc(dtype)
+    assert hasattr(a, '_mg_wt') and not hasattr(b, '_mg_wt') and torch.equal(a, b)
+    dec.drop_prefetched()
+    assert '_pre_w' not in dec.refine_OS4[0].__dict__
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('M,C', [(0, 32), (1, 8), (777, 64), (20000, 32)])
+def test_bias_act_bwd(dtype, M, C):
+    from maggie_amd import kernels as K
+    DEV = _dev()
+    torch.manual_seed(M + C)
+    dy = torch.randn(M, C, device=DEV).to(dtype)
+    y = torch.randn(M, C, device=DEV).to(dtype)
+    g, db = K.bias_act_bwd(dy, y, True)
+    ref = dy * (y > 0).to(dtype)
+    assert torch.equal(g, ref)
+    assert torch.allclose(db, ref.double().sum(0).float(), rtol=1e-4, atol=1e-3 * max(1.0, M ** 0.5))
+    g2, db2 = K.bias_act_bwd(dy, None, True)
+    assert g2 is dy and torch.allclose(db2, dy.double().sum(0).float(), rtol=1e-4, atol=1e-3 * max(1.0, M ** 0.5))
+    g3, db3 = K.bias_act_bwd(dy, y, False)
+    assert db3 is None and torch.equal(g3, ref)
