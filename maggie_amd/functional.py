@@ -4,6 +4,8 @@ Dense activations are NHWC tensors (N, H, W, C) in the compute dtype (bf16 under
 padded to a multiple of 8; sparse features are (R, C) row matrices over the sorted active sites. Every forward
 AND backward below launches hand-written HIP kernels; PyTorch only provides the autograd graph, memory and streams.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -120,6 +122,43 @@ def _pad_krsc(w, dtype, cin_pad, cout_pad):
     if cin_pad != ci or cout_pad != co:
         w = torch.nn.functional.pad(w, (0, cin_pad - ci, 0, 0, 0, cout_pad - co))
     return w.to(dtype).contiguous()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# side streams: work that is off the data-gradient critical path (the weight-gradient GEMMs of the trunk) is issued on a second
+# HIP stream, so that inside the captured backward graph it forms a parallel branch: a deep-layer dgrad GEMM (one workgroup per
+# CU) and the previous layer's wgrad GEMM share the chip instead of running back to back.
+# ----------------------------------------------------------------------------------------------------------------------
+SIDE_WGRAD = os.environ.get('MAGGIE_SIDE_WGRAD', '1') != '0'
+_SIDE_STREAMS = {}
+_FORKED = []
+
+
+def side_stream(device, idx=0):
+    key = (device.index, idx)
+    s = _SIDE_STREAMS.get(key)
+    if s is None:
+        s = _SIDE_STREAMS[key] = torch.cuda.Stream(device)
+    return s
+
+
+def fork_side(device, idx=0):
+    """-> (side stream ordered after everything issued so far on the current stream, the current stream)."""
+    main = torch.cuda.current_stream(device)
+    side = side_stream(device, idx)
+    side.wait_stream(main)
+    if side not in _FORKED:
+        _FORKED.append(side)
+    return side, main
+
+
+def join_side():
+    """The current stream waits for every side stream that was forked since the last join."""
+    if _FORKED:
+        main = torch.cuda.current_stream()
+        for s in _FORKED:
+            main.wait_stream(s)
+        del _FORKED[:]
 
 
 class WeightBankPlan:
@@ -305,6 +344,8 @@ class SpectralNormBatch(torch.autograd.Function):
         ctx.plan = plan
         ctx.save_for_backward(work)
         outs = tuple(out[o:o + n].view(sh[0], sh[1], sh[2]) for (o, n), sh in zip(plan.out_slices, plan.shapes))
+        for t_ in outs:
+            t_._mg_side_wgrad = True                              # every dW of these weights meets again in backward() below: the join point
         if out_t is not None:
             # (Cin_pad, taps, Cout) twins for the data-gradient convolution ride along as a Python attribute of each weight
             for t_, (o, n), sh, m in zip(outs, plan.out_slices, plan.shapes, plan.modules):
@@ -317,6 +358,7 @@ class SpectralNormBatch(torch.autograd.Function):
         plan = ctx.plan
         (work,) = ctx.saved_tensors
         dev = work.device
+        join_side()                                               # the weight-gradient GEMMs ran on the side stream
         keep = [None if g is None else g.to(plan.dtype).contiguous() for g in grads]
         host_ptrs = torch.tensor([0 if g is None else g.data_ptr() for g in keep], dtype=torch.int64)
         if torch.cuda.is_current_stream_capturing():
@@ -377,6 +419,7 @@ class ConvRaw(torch.autograd.Function):
                          stats=stats)
         y = y.view(N, Ho, Wo, Cout)
         ctx.wt = getattr(w, '_mg_wt', None)                       # pre-transposed weights from the batched SpectralNorm kernel
+        ctx.side = SIDE_WGRAD and getattr(w, '_mg_side_wgrad', False) and not transposed
         ctx.save_for_backward(x, w, y if pre_relu else None)
         ctx.geom = (N, H, W_, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, transposed, pre_relu, bias is not None)
         return y
@@ -396,7 +439,15 @@ class ConvRaw(torch.autograd.Function):
             dx = K.conv_fprop(dy2, wt, mode=dmode, N=N, Hin=Ho, Win=Wo, Hout=H, Wout=W_, R=R, S=S, stride=stride, pad=pad,
                               dil=dil).view(N, H, W_, Cin)
         if ctx.needs_input_grad[1]:
-            if not transposed:
+            if ctx.side:
+                side, main = fork_side(dy2.device)
+                with torch.cuda.stream(side):
+                    dw = K.conv_wgrad(x.view(-1, Cin), dy2, cout=Cout, mode=MODE_CONV, N=N, Hin=H, Win=W_, Hout=Ho, Wout=Wo,
+                                      R=R, S=S, stride=stride, pad=pad, dil=dil, out_dtype=w.dtype)
+                x.record_stream(side)                             # allocator: not to be recycled under the side stream's feet
+                dy2.record_stream(side)
+                dw.record_stream(main)
+            elif not transposed:
                 dw = K.conv_wgrad(x.view(-1, Cin), dy2, cout=Cout, mode=MODE_CONV, N=N, Hin=H, Win=W_, Hout=Ho, Wout=Wo,
                                   R=R, S=S, stride=stride, pad=pad, dil=dil, out_dtype=w.dtype)
             else:

@@ -104,6 +104,7 @@ class GraphedCallable:
                     with torch.autocast('cuda', enabled=False):      # backward never runs under autocast (see below)
                         gr = torch.autograd.grad(req, cap_params, [torch.ones_like(o) for o in req], allow_unused=True)
                     used = [x is not None for x in gr]
+                    MF.join_side()
                     del gr
                 del outs
             if training:
@@ -118,6 +119,7 @@ class GraphedCallable:
                 with torch.cuda.graph(self.fwd, pool=self.pool, stream=side, capture_error_mode=CAPTURE_MODE):
                     MF.ARENA.begin_capture(dev)
                     self.static_outputs = tuple(fn(*self.static_inputs))
+                    MF.join_side()
                 self.static_grad_outputs, self.static_param_grads, self.bwd = None, None, None
                 if training:
                     self.static_grad_outputs = [torch.zeros_like(o) if o.requires_grad else None for o in self.static_outputs]
@@ -131,6 +133,7 @@ class GraphedCallable:
                         self.static_param_grads = torch.autograd.grad(
                             [o for o in self.static_outputs if o.requires_grad], cap_params,
                             [g for g in self.static_grad_outputs if g is not None], allow_unused=True)
+                        MF.join_side()                            # every forked branch must be back before the capture ends
                         self._pack_grads()
             finally:
                 MF.ARENA.end_capture()

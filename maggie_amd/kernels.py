@@ -112,14 +112,15 @@ _WS = {}
 
 
 def _wgrad_workspace(floats, device):
-    """One growing fp32 scratch buffer per device (kernels on one stream execute in order, so reuse is safe)."""
+    """One growing fp32 scratch buffer per device and stream (kernels on one stream execute in order, so reuse is safe)."""
     if torch.cuda.is_current_stream_capturing():
         # graph-owned scratch: the shared buffer may be re-allocated after the capture
         return torch.empty(int(floats), dtype=torch.float32, device=device)
-    buf = _WS.get(device)
+    key = (device, hip.stream().value)
+    buf = _WS.get(key)
     if buf is None or buf.numel() < floats:
         buf = torch.empty(int(floats * 1.25) + 1024, dtype=torch.float32, device=device)
-        _WS[device] = buf
+        _WS[key] = buf
     return buf
 
 
