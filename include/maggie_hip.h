@@ -295,6 +295,34 @@ int mg_weight_bank(const mg_wb_entry* entries, int n, int backward, void* stream
 int mg_bias_act_bwd(const void* dy, const void* y, void* g, int dtype, int M, int C, float* db, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Input side: the tensor work of the reference's DataLoader after decoding, from uint8 buffers.
+ *   mg_preprocess_image : ToTensor + Normalize (maggie/dataloader/transforms.py:720-778): in uint8 [frames][HW][3] ->
+ *                         out fp32 [frames][3][HW] = (x / 255 - mean[c]) / std[c]  (IEEE divisions: bit-exact). HW % 4 == 0.
+ *   mg_preprocess_planes: alpha / mask planes (transforms.py:744 `alphas < 5 -> 0`; maggie/dataloader/him.py:157-173): in uint8
+ *                         [frames][n_in][H][W] -> out fp32 [frames][n_slots][Ho][Wo] = v / 255 of plane src_of_slot[frame*n_slots
+ *                         + slot] (device int32; < 0 = empty slot -> zeros; NULL = identity), values below `thresh` -> 0,
+ *                         sampled like F.interpolate(mode="nearest") when (Ho, Wo) != (H, W).
+ * ------------------------------------------------------------------------------------------------------------- */
+int mg_preprocess_image(const uint8_t* in, float* out, const float* mean3, const float* std3, long frames, long HW, void* stream);
+int mg_preprocess_planes(const uint8_t* in, float* out, const int32_t* src_of_slot, int frames, int n_in, int n_slots, int H, int W,
+                         int Ho, int Wo, int thresh, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Validation metrics on the device (maggie/utils/metric.py). fp32 planes, fp64 results. `trimap` may be NULL;
+ * mask_mode: 0 = all ones, 1 = (trimap > 0) (Metric.update :47), 2 = (trimap == 1) (dtSSD.update :427).
+ *   mg_metric_plane_sums: out[P][3] = per plane { sum |pred-gt| m, sum (pred-gt)^2 m, sum m }      (SAD :68-78, MSE :80-90, MAD :92-97)
+ *   mg_metric_grad      : out[P] = per plane sum (|G(gt_n)| - |G(pred_n)|)^2 m, G = 9x9 Gaussian-derivative pair (filter_x81,
+ *                         filter_y = its transpose, zero padding), x_n = (x - min) / (max - min + 1e-6) over the WHOLE tensor
+ *                         (:388-405); scratch4: 4 int32 of device scratch
+ *   mg_metric_dtssd     : pred/gt/trimap [B][T][N][HW]; out[N] = sum_{b,t<T-1,px} ((p[t+1]-p[t]) - (g[t+1]-g[t]))^2 m[t]  (:436-441)
+ * ------------------------------------------------------------------------------------------------------------- */
+int mg_metric_plane_sums(const float* pred, const float* gt, const float* trimap, int mask_mode, int P, long HW, double* out, void* stream);
+int mg_metric_grad(const float* pred, const float* gt, const float* trimap, int mask_mode, int P, int H, int W, const float* filter_x81,
+                   int32_t* scratch4, double* out, void* stream);
+int mg_metric_dtssd(const float* pred, const float* gt, const float* trimap, int mask_mode, int B, int T, int N, long HW, double* out,
+                    void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Inference post-path: `reverse_transform_tensor` (maggie/utils/postprocessing.py:36-64: crop the
  * bottom/right padding to (crop_h, crop_w), bilinear resize with align_corners=True to (Hout, Wout)) fused with the alpha
  * snapping of maggie/engine/test.py:139-142,229-231 (<= 1/255 -> 0, >= 254/255 -> 1 when `snap`). fp32 planes [P,Hin,Win].

@@ -198,9 +198,85 @@ def postprocess_fixture():
     print('wrote postprocess_pinned.npz', {k: v.shape for k, v in out.items()})
 
 
+def preprocess_fixture():
+    """Input side: the reference's ToTensor / Normalize classes (maggie/dataloader/transforms.py:720-778) and the item-assembly
+    statements of HIMDataset.__getitem__ (maggie/dataloader/him.py:157-173, executed here statement by statement with stock torch)
+    on seeded uint8 inputs. transforms.py imports cv2 / albumentations / imgaug / skimage at the top for OTHER classes: empty
+    stand-ins are enough to import it (nothing on this data path touches them)."""
+    import importlib, sys, types
+    import torch.nn.functional as F
+    for name in ('cv2', 'albumentations', 'imgaug', 'imgaug.augmenters', 'imgaug.parameters', 'skimage', 'skimage.exposure'):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules['imgaug'].augmenters, sys.modules['imgaug'].parameters = sys.modules['imgaug.augmenters'], sys.modules['imgaug.parameters']
+    sys.modules['skimage'].exposure = sys.modules['skimage.exposure']
+    if 'maggie.dataloader' not in sys.modules:
+        dl = types.ModuleType('maggie.dataloader')
+        dl.__path__ = [os.path.join(ref_loader.REF_ROOT, 'maggie', 'dataloader')]
+        sys.modules['maggie.dataloader'] = dl
+    T = importlib.import_module('maggie.dataloader.transforms')
+    out = {}
+    for key, (n_f, n_i, H, W, max_inst, seed) in {'image_train': (1, 3, 64, 96, 10, 5), 'video_eval': (3, 2, 40, 56, None, 6),
+                                                  'odd_size': (1, 1, 36, 52, 10, 7)}.items():
+        rs = np.random.RandomState(seed)
+        frames = rs.randint(0, 256, size=(n_f, H, W, 3)).astype(np.uint8)
+        alphas = rs.randint(0, 256, size=(n_f * n_i, H, W)).astype(np.uint8)
+        alphas[rs.rand(*alphas.shape) < 0.3] = rs.randint(0, 8)                    # exercise the `< 5 -> 0` rule
+        masks = (rs.rand(n_f * n_i, H, W) < 0.5).astype(np.uint8) * 255
+        d = {'frames': frames.copy(), 'alphas': alphas.copy(), 'masks': masks.copy()}
+        d = T.Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])(T.ToTensor()(d))
+        image, alpha, mask = d['frames'], d['alphas'], d['masks']
+        alpha = alpha * 1.0 / 255                                                # him.py:157
+        mask = mask * 1.0 / 255                                                  # him.py:158
+        if max_inst is not None:                                                 # him.py:159-167 (is_train)
+            chosen_ids = rs.choice(range(max_inst), alpha.shape[1], replace=False)
+            new_alpha = torch.zeros(alpha.shape[0], max_inst, *alpha.shape[2:])
+            new_mask = torch.zeros(alpha.shape[0], max_inst, *mask.shape[2:])
+            new_alpha[:, chosen_ids] = alpha.float()
+            new_mask[:, chosen_ids] = mask.float()
+            mask, alpha = new_mask, new_alpha
+            out[key + '.slot_ids'] = np.asarray(chosen_ids, np.int64)
+        mask = F.interpolate(mask.float(), size=(image.shape[2] // 8, image.shape[3] // 8), mode='nearest')     # him.py:172-173
+        out[key + '.image'], out[key + '.alpha'], out[key + '.mask'] = image.numpy(), alpha.float().numpy(), mask.float().numpy()
+    np.savez_compressed(os.path.join(HERE, 'preprocess_pinned.npz'), **out)
+    print('wrote preprocess_pinned.npz', {k: v.shape for k, v in out.items()})
+
+
+def metric_fixture():
+    """The reference's own metric classes (maggie/utils/metric.py: SAD, MSE, MAD, Grad on CPU, dtSSD) on seeded planes. The module
+    imports cv2 / skimage.measure at the top for Conn / MESSDdt only: empty stand-ins are enough to import it."""
+    import importlib, sys, types
+    for name in ('cv2', 'skimage', 'skimage.measure'):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules['skimage'].measure = sys.modules['skimage.measure']
+    stub = sys.modules.get('maggie.utils.metric')
+    if stub is not None and not hasattr(stub, 'SAD'):                 # postprocess_fixture's reshape2D-only stand-in
+        del sys.modules['maggie.utils.metric']
+    M = importlib.import_module('maggie.utils.metric')
+    out = {}
+    for key, (shape, seed, with_tri) in {'image': ((2, 3, 48, 40), 31, True), 'no_trimap': ((1, 2, 33, 57), 32, False),
+                                         'clip': ((4, 2, 32, 32), 33, True)}.items():
+        rs = np.random.RandomState(seed)
+        pred = rs.rand(*shape).astype(np.float32)
+        gt = np.clip(pred + rs.normal(0, 0.1, size=shape), 0, 1).astype(np.float32)
+        tri = rs.randint(0, 3, size=shape).astype(np.float32) if with_tri else None
+        for name in ('SAD', 'MSE', 'MAD', 'Grad'):
+            m = getattr(M, name)()
+            r = m.update(pred, gt, tri, device='cpu')
+            out['%s.%s' % (key, name)] = np.asarray([r, m.score, m.count, m.average()], np.float64)
+        m = M.dtSSD()
+        r = m.update(pred, gt, tri)
+        out['%s.dtSSD' % key] = np.asarray([r, m.score, m.count, m.average()], np.float64)
+    np.savez_compressed(os.path.join(HERE, 'metric_pinned.npz'), **out)
+    print('wrote metric_pinned.npz', {k: v.tolist() for k, v in out.items()})
+
+
 def main():
     ns = ref_loader.load_reference()
     postprocess_fixture()
+    preprocess_fixture()
+    metric_fixture()
     layout_fixture(ns)
     dense_fixture(ns)
     model_fixture(ns, 'image', False, 1, 1, 2, 128, 0, None, 'model_image_eval.npz')

@@ -51,3 +51,32 @@ def reference_layout_state_dict(kind='image', seed=WSEED, requires_grad=False):
 
 def model_cfg(kind):
     return copy.deepcopy(config.MODEL_IMAGE if kind == 'image' else config.MODEL_VIDEO)
+
+
+PREPROCESS_CASES = {'image_train': (1, 3, 64, 96, 10, 5), 'video_eval': (3, 2, 40, 56, None, 6), 'odd_size': (1, 1, 36, 52, 10, 7)}
+
+
+def preprocess_inputs(key):
+    """The seeded uint8 inputs tests/golden/make_golden.py:preprocess_fixture fed to the reference (same draws, same order)."""
+    import numpy as np
+    n_f, n_i, H, W, max_inst, seed = PREPROCESS_CASES[key]
+    rs = np.random.RandomState(seed)
+    frames = rs.randint(0, 256, size=(n_f, H, W, 3)).astype(np.uint8)
+    alphas = rs.randint(0, 256, size=(n_f * n_i, H, W)).astype(np.uint8)
+    alphas[rs.rand(*alphas.shape) < 0.3] = rs.randint(0, 8)
+    masks = (rs.rand(n_f * n_i, H, W) < 0.5).astype(np.uint8) * 255
+    return frames, alphas.reshape(n_f, n_i, H, W), masks.reshape(n_f, n_i, H, W), max_inst
+
+
+METRIC_CASES = {'image': ((2, 3, 48, 40), 31, True), 'no_trimap': ((1, 2, 33, 57), 32, False), 'clip': ((4, 2, 32, 32), 33, True)}
+
+
+def metric_inputs(key):
+    """The seeded planes tests/golden/make_golden.py:metric_fixture fed to the reference's metric classes."""
+    import numpy as np
+    shape, seed, with_tri = METRIC_CASES[key]
+    rs = np.random.RandomState(seed)
+    pred = rs.rand(*shape).astype(np.float32)
+    gt = np.clip(pred + rs.normal(0, 0.1, size=shape), 0, 1).astype(np.float32)
+    tri = rs.randint(0, 3, size=shape).astype(np.float32) if with_tri else None
+    return pred, gt, tri

@@ -493,3 +493,78 @@ def test_bias_act_bwd(dtype, M, C):
     assert g2 is dy and torch.allclose(db2, dy.double().sum(0).float(), rtol=1e-4, atol=1e-3 * max(1.0, M ** 0.5))
     g3, db3 = K.bias_act_bwd(dy, y, False)
     assert db3 is None and torch.equal(g3, ref)
+
+
+@pytest.mark.gpu
+def test_device_preprocessor_matches_reference_fixture_and_oracle():
+    """maggie_amd.utils.preprocess (mg_preprocess_image / mg_preprocess_planes) against the reference's own outputs
+    (tests/golden/preprocess_pinned.npz) and, at the bench geometry, against the oracle: bit-exact."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import load_golden, preprocess_inputs, PREPROCESS_CASES
+    from maggie_amd.utils.preprocess import DevicePreprocessor, normalize_frames, scale_planes
+    from oracle import preprocess as pre
+    dev = _dev()
+    gold = load_golden('preprocess_pinned.npz')
+    for key in PREPROCESS_CASES:
+        frames, alphas, masks, max_inst = preprocess_inputs(key)
+        ids = None if max_inst is None else [int(i) for i in gold[key + '.slot_ids']]
+        out = DevicePreprocessor(max_inst=10, device=dev)(frames, alphas, masks, slot_ids=ids)
+        for name in ('image', 'alpha', 'mask'):
+            got = out[name].cpu().numpy()
+            assert got.shape == gold['%s.%s' % (key, name)].shape, (key, name)
+            assert np.array_equal(got, gold['%s.%s' % (key, name)]), (key, name)
+    rs = np.random.RandomState(0)
+    frames = rs.randint(0, 256, size=(4, 1, 512, 512, 3)).astype(np.uint8)                # (b, n_f, H, W, 3)
+    planes = rs.randint(0, 256, size=(4, 2, 512, 512)).astype(np.uint8)
+    img = normalize_frames(frames, device=dev)
+    assert img.shape == (4, 1, 3, 512, 512)
+    assert np.array_equal(img.cpu().numpy(), pre.normalize_frames(frames, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)))
+    ids = [7, 2]
+    for size, thresh in ((None, 5), ((64, 64), 0), ((37, 91), 0)):
+        got = scale_planes(planes, 10, ids, size, thresh, device=dev).cpu().numpy()
+        assert np.array_equal(got, pre.scale_planes(planes, 10, ids, size, thresh)), (size, thresh)
+    with pytest.raises(ValueError):
+        scale_planes(planes, 10, [1, 1], device=dev)
+    with pytest.raises(TypeError):
+        normalize_frames(frames.astype(np.float32), device=dev)
+
+
+@pytest.mark.gpu
+def test_device_metrics_match_reference_fixture_and_oracle():
+    """maggie_amd.utils.metric (mg_metric_plane_sums / mg_metric_grad / mg_metric_dtssd) against the reference's own metric classes
+    (tests/golden/metric_pinned.npz) and, at 512x512, against the oracle. fp32 planes, fp64 accumulation: rtol 2e-5."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import load_golden, metric_inputs, METRIC_CASES
+    from maggie_amd.utils import metric as dm
+    from oracle import metric as om
+    dev = _dev()
+    gold = load_golden('metric_pinned.npz')
+    T = lambda a: None if a is None else torch.from_numpy(a).to(dev)        # noqa: E731
+    for key in METRIC_CASES:
+        pred, gt, tri = metric_inputs(key)
+        ms = dm.build_metric(['SAD', 'MSE', 'MAD', 'Grad', 'dtSSD'])
+        for name, m in ms.items():
+            r = m.update(T(pred), T(gt), T(tri))
+            ref = gold['%s.%s' % (key, name)]                      # [update() return, score, count, average()]
+            assert m.count == ref[2], (key, name)
+            assert abs(m.score - ref[1]) <= 2e-5 * abs(ref[1]) + 1e-9, (key, name, m.score, ref[1])
+            assert abs(r - ref[0]) <= 2e-5 * abs(ref[0]) + 1e-9 and abs(m.average() - ref[3]) <= 2e-5 * abs(ref[3]) + 1e-9
+            m.update(T(pred), T(gt), T(tri))                       # accumulates like the reference
+            assert m.count == 2 * ref[2] and abs(m.score - 2 * ref[1]) <= 4e-5 * abs(ref[1]) + 1e-9
+            m.reset()
+            assert m.score == 0 and m.count == 0
+    rs = np.random.RandomState(9)
+    shape = (3, 2, 512, 512)                                       # (T, n_i, H, W): one clip of the bench geometry
+    pred = rs.rand(*shape).astype(np.float32)
+    gt = np.clip(pred + rs.normal(0, 0.05, size=shape), 0, 1).astype(np.float32)
+    tri = rs.randint(0, 3, size=shape).astype(np.float32)
+    for name, fn in (('SAD', om.sad), ('MSE', om.mse), ('MAD', om.mad), ('Grad', om.grad), ('dtSSD', om.dtssd)):
+        for t in (tri, None):
+            m = dm.build_metric([name])[name]
+            m.update(T(pred), T(gt), T(t))
+            score, count = fn(pred, gt, t)
+            assert m.count == count and abs(m.score - score) <= 5e-5 * abs(score) + 1e-9, (name, t is None, m.score, score)
+    with pytest.raises(NotImplementedError):
+        dm.build_metric(['Conn'])

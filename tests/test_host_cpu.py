@@ -168,3 +168,81 @@ def test_flat_clip_grad_norm_matches_torch():
             assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=0)
         assert ours[5].grad is None
         assert float(part[10:].min()) == 1e9
+
+
+def test_checkpoint_bridge_round_trips_reference_formats(tmp_path):
+    """maggie_amd.utils.checkpoint: .pth / .safetensors / hub-snapshot directory round trips with the reference's keys
+    (tests/golden/state_dict_layout_image.json), DDP `module.` prefix, legacy spconv (kh,kw,Cin,Cout) weights, the
+    (missing, unexpected, mismatch) report of maggie/engine/train.py:80-96, and the last_model.pth / last_opt.pth resume pair."""
+    import json
+    import torch
+    from maggie_amd.network import build_model
+    from maggie_amd.utils import checkpoint as ck, config, synth
+    layout = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'state_dict_layout_image.json')))['state_dict']
+
+    def fresh(seed):
+        m, _ = build_model(config.model_config('image'))
+        sd = m.state_dict()
+        synth.fill_state_dict_(sd, seed)
+        m.load_state_dict(sd)
+        return m
+
+    src, ref_sd = fresh(3), None
+    ref_sd = {k: v.clone() for k, v in src.state_dict().items()}
+    assert set(ref_sd) == set(layout)
+    for name in ('m.pth', 'm.safetensors'):
+        path = str(tmp_path / name)
+        ck.save_model(src, path)
+        stored = ck.read_state_dict(path)
+        assert set(stored) == set(layout) and all(list(stored[k].shape) == list(layout[k][0]) for k in layout)
+        dst = fresh(4)
+        assert ck.load_pretrained(dst, path) == ([], [], [])
+        assert all(torch.equal(v, ref_sd[k]) for k, v in dst.state_dict().items())
+    # hub snapshot directory
+    hub = tmp_path / 'snapshot'
+    hub.mkdir()
+    ck.save_model(src, str(hub / 'model.safetensors'))
+    dst = fresh(5)
+    ck.load_pretrained(dst, str(hub))
+    assert torch.equal(dst.state_dict()['decoder.refine_OS1.3.weight'], ref_sd['decoder.refine_OS1.3.weight'])
+    # DDP prefix + legacy spconv layout + a wrong shape + a foreign key + a missing key
+    odd = {'module.' + k: v for k, v in ref_sd.items()}
+    w = odd['module.decoder.layer3.3.weight']
+    assert w.shape == (64, 3, 3, 64)
+    odd['module.decoder.guidance_layer.0.weight'] = ref_sd['decoder.guidance_layer.0.weight'].permute(1, 2, 3, 0).contiguous()   # (1,1,128,64)
+    odd['module.encoder.bn1.weight'] = torch.zeros(7)
+    odd['module.not_a_parameter'] = torch.zeros(1)
+    del odd['module.decoder.refine_OS4.3.bias']
+    dst = fresh(6)
+    before = dst.state_dict()['encoder.bn1.weight'].clone()
+    missing, unexpected, mismatch = ck.load_state_dict(dst, odd)
+    assert missing == ['decoder.refine_OS4.3.bias'] and unexpected == ['not_a_parameter'] and mismatch == ['encoder.bn1.weight']
+    got = dst.state_dict()
+    assert torch.equal(got['decoder.guidance_layer.0.weight'], ref_sd['decoder.guidance_layer.0.weight'])
+    assert torch.equal(got['encoder.bn1.weight'], before)
+    import pytest
+    with pytest.raises(RuntimeError):
+        ck.load_pretrained(fresh(7), _write(tmp_path, odd))
+    # resume pair
+    params = [p for p in src.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-4)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=10)
+    for p in params[:3]:
+        p.grad = torch.ones_like(p)
+    opt.step(); sched.step()
+    ck.save_training_state(str(tmp_path / 'run'), src, opt, sched, 123, 0.5)
+    assert sorted(os.listdir(tmp_path / 'run')) == ['last_model.pth', 'last_opt.pth']
+    dst = fresh(8)
+    opt2 = torch.optim.AdamW([p for p in dst.parameters() if p.requires_grad], lr=1e-4)
+    sched2 = torch.optim.lr_scheduler.OneCycleLR(opt2, max_lr=1e-3, total_steps=10)
+    assert ck.load_resume_model(dst, opt2, sched2, str(tmp_path / 'run'), 'cpu') == (123, 0.5)
+    assert sched2.last_epoch == 1 and len(opt2.state_dict()['state']) == 3
+    with pytest.raises(ValueError):
+        ck.load_resume_model(dst, opt2, sched2, str(tmp_path / 'nowhere'), 'cpu')
+
+
+def _write(tmp_path, sd):
+    import torch
+    path = str(tmp_path / 'odd.pth')
+    torch.save(sd, path)
+    return path

@@ -138,3 +138,38 @@ def test_postprocess_oracle_matches_reference_fixture():
         assert np.abs(y - gold[key]).max() <= 1e-6, key
     a = pp.snap_alpha(np.array([0.0, 1 / 255.0, 0.004, 0.5, 254 / 255.0, 0.9999], np.float32))
     assert a.tolist() == [0.0, 0.0, np.float32(0.004), 0.5, 1.0, 1.0]
+
+
+def test_preprocess_oracle_matches_reference_fixture():
+    """oracle/preprocess.py against tests/golden/preprocess_pinned.npz (outputs of the reference's own ToTensor / Normalize and of
+    the him.py item-assembly statements on seeded uint8 inputs): bit-exact."""
+    import numpy as np
+    from helpers import load_golden, preprocess_inputs, PREPROCESS_CASES
+    from oracle import preprocess as pre
+    gold = load_golden('preprocess_pinned.npz')
+    for key in PREPROCESS_CASES:
+        frames, alphas, masks, max_inst = preprocess_inputs(key)
+        ids = None if max_inst is None else [int(i) for i in gold[key + '.slot_ids']]
+        H, W = frames.shape[1:3]
+        img = pre.normalize_frames(frames, (0.485, 0.456, 0.406), (0.229, 0.224, 0.225))
+        a = pre.scale_planes(alphas, max_inst, ids, None, 5)
+        m = pre.scale_planes(masks, max_inst, ids, (H // 8, W // 8), 0)
+        assert np.array_equal(img, gold[key + '.image']), key
+        assert np.array_equal(a, gold[key + '.alpha']), key
+        assert np.array_equal(m, gold[key + '.mask']), key
+        assert float(a[(a > 0)].min()) >= 5 / 255.0 - 1e-7
+
+
+def test_metric_oracle_matches_reference_fixture():
+    """oracle/metric.py against tests/golden/metric_pinned.npz (the reference's own SAD / MSE / MAD / Grad / dtSSD classes)."""
+    import numpy as np
+    from helpers import load_golden, metric_inputs, METRIC_CASES
+    from oracle import metric as om
+    gold = load_golden('metric_pinned.npz')
+    for key in METRIC_CASES:
+        pred, gt, tri = metric_inputs(key)
+        for name, fn in (('SAD', om.sad), ('MSE', om.mse), ('MAD', om.mad), ('Grad', om.grad), ('dtSSD', om.dtssd)):
+            score, count = fn(pred, gt, tri)
+            ref = gold['%s.%s' % (key, name)]                      # [update() return, score, count, average()]
+            assert count == ref[2], (key, name)
+            assert abs(score - ref[1]) <= 2e-5 * abs(ref[1]) + 1e-9, (key, name, score, ref[1])
