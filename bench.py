@@ -47,7 +47,9 @@ def parse():
     ap.add_argument('--layers', action='store_true', help='print the per-shape conv kernel table to stderr')
     ap.add_argument('--ddp', action='store_true', help='all-reduce gradients with torch DistributedDataParallel (like the reference) instead of '
                                                       'maggie_amd.parallel.GradSync (flat-buffer RCCL all-reduce, the default for N > 1)')
-    ap.add_argument('--foreach-adamw', action='store_true', help='torch.optim.AdamW default (foreach) implementation instead of fused=True')
+    ap.add_argument('--optimizer', default='flat', choices=['flat', 'fused', 'foreach'],
+                    help='flat: maggie_amd.optim.FlatAdamW (one flat buffer, clip folded into the update; default); fused / foreach: '
+                         'torch.optim.AdamW implementations after maggie_amd.parallel.clip_grad_norm_')
     ap.add_argument('--video', action='store_true', help='maggie_video.yaml, T=3 (BASELINE configs[3]); not the headline line')
     return ap.parse_args()
 
@@ -101,8 +103,11 @@ def main():
     # AdamW as maggie_image.yaml:90-98; lr = max_lr / 25 = the first value of the reference's OneCycleLR schedule
     # (engine/optim.py:117-118, default div_factor) -- a full max_lr step on random-init weights makes the detail region
     # (and therefore the sparse workload) drift wildly between the few timed steps.
-    # fused=True: the same update as one multi-tensor kernel instead of ~10 foreach passes over every state tensor
-    opt = torch.optim.AdamW(params, lr=1.5e-4 / 25, betas=(0.9, 0.999), weight_decay=0.01, fused=not args.foreach_adamw)
+    if args.optimizer == 'flat':                              # same update rule, one HBM pass (tests: test_flat_adamw_matches_torch_adamw)
+        from maggie_amd.optim import FlatAdamW
+        opt = FlatAdamW(params, lr=1.5e-4 / 25, betas=(0.9, 0.999), weight_decay=0.01, max_grad_norm=0.01)      # clip: engine/train.py:274
+    else:
+        opt = torch.optim.AdamW(params, lr=1.5e-4 / 25, betas=(0.9, 0.999), weight_decay=0.01, fused=args.optimizer == 'fused')
 
     batch = synth.synthetic_batch(b, n_f, args.instances, args.size, args.size, seed=1234 + rank, train=True, it=args.iter, max_inst=10)
     batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
@@ -125,7 +130,8 @@ def main():
         if grad_sync is not None:
             grad_sync()
         t.append(time.perf_counter())
-        parallel.clip_grad_norm_(params, 0.01)                                          # engine/train.py:274, over the flat grad buffers
+        if args.optimizer != 'flat':
+            parallel.clip_grad_norm_(params, 0.01)                                      # engine/train.py:274, over the flat grad buffers
         opt.step()
         t.append(time.perf_counter())
         if host_t is not None:
@@ -246,7 +252,7 @@ def main():
             'per_gpu': round(value / world, 3),
             'config': {'workload': 'maggie_%s.yaml train step: %dx%d, %d instances (10 slots), batch %d frames/GPU x %d frame(s), iter=%d, '
                                    'fwd+loss+bwd+clip+AdamW' % (kind, args.size, args.size, args.instances, b, n_f, args.iter),
-                       'global_batch': b * world, 'parallelism': 'dp%d' % world, 'sync_bn': bool(args.sync_bn and world > 1), 'optimizer': 'AdamW(%s) + flat-buffer grad-norm clip' % ('foreach' if args.foreach_adamw else 'fused'),
+                       'global_batch': b * world, 'parallelism': 'dp%d' % world, 'sync_bn': bool(args.sync_bn and world > 1), 'optimizer': 'FlatAdamW (clip 0.01 folded in)' if args.optimizer == 'flat' else 'torch AdamW(%s) + flat-buffer grad-norm clip' % args.optimizer,
                        'grad_allreduce': None if world == 1 and not force_ddp else ('torch DDP' if args.ddp else 'GradSync (flat-buffer RCCL all-reduce)'),
                        'active_ratio': round(active_ratio, 4), 'active_ratio_per_timed_step': [round(float(v), 3) for v in stats['active_hist'][-args.steps - 2:-2]] if not args.no_roofline else None, 'active_pixels_per_step_per_gpu': int(active_px), 'loss_total': round(loss_val, 4)},
             'roofline': roofline, 'cpu_baseline': cpu_baseline,

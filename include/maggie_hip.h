@@ -295,6 +295,20 @@ int mg_weight_bank(const mg_wb_entry* entries, int n, int backward, void* stream
 int mg_bias_act_bwd(const void* dy, const void* y, void* g, int dtype, int M, int C, float* db, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Optimizer step of the measured train step (maggie/engine/train.py:274-276: clip_grad_norm_(0.01), AdamW of engine/optim.py)
+ * over ONE flat fp32 buffer holding every trainable parameter (p, g, m, v: n floats each, n % 4 == 0, 16-byte aligned).
+ * sumsq_scratch != NULL: the squared gradient norm is reduced into it first (1 device double) and, with max_norm > 0, gradients
+ * are scaled by min(1, max_norm / (norm + 1e-6)) inside the update (no separate scaling pass); norm_out (or NULL) receives the norm.
+ * bias_correction1 = 1 - beta1^t, bias_correction2_sqrt = sqrt(1 - beta2^t) for step t (computed by the host mirror).
+ * phases: bit 0 = reduce the norm of g[0:n] into sumsq_scratch, bit 1 = update [0:n] (3 = both). Parameters that got no gradient
+ * this step are skipped like torch does: the host reduces the norm over the whole buffer once (phases 1), then updates each
+ * contiguous run of parameters that have one (phases 2, same scratch).
+ * ------------------------------------------------------------------------------------------------------------- */
+int mg_adamw_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                  float bias_correction1, float bias_correction2_sqrt, double* sumsq_scratch, float max_norm, float* norm_out, int phases,
+                  void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Input side: the tensor work of the reference's DataLoader after decoding, from uint8 buffers.
  *   mg_preprocess_image : ToTensor + Normalize (maggie/dataloader/transforms.py:720-778): in uint8 [frames][HW][3] ->
  *                         out fp32 [frames][3][HW] = (x / 255 - mean[c]) / std[c]  (IEEE divisions: bit-exact). HW % 4 == 0.

@@ -1,0 +1,148 @@
+"""Optimizer step of the train step on the MI355X: AdamW over one flat parameter buffer, gradient-norm clip folded in.
+
+`FlatAdamW(params, lr, betas, eps, weight_decay, max_grad_norm)` is torch.optim.AdamW (what maggie/engine/optim.py builds) for the
+case the hot path has -- one parameter group, fp32 parameters on one GPU -- restructured for HBM:
+
+  * on construction every trainable parameter is re-homed into ONE flat fp32 buffer (`p.data` becomes a view; 256-byte aligned
+    slots), and so are the two moment buffers;
+  * `step()` gathers the gradients into a flat buffer of the same layout (a multi-tensor copy; the hipGraph trunk already hands
+    its ~150 gradients over as one flat tensor), then ONE pass `mg_adamw_flat` reduces the gradient norm, scales by
+    min(1, max_norm / (norm + 1e-6)) (`clip_grad_norm_` of maggie/engine/train.py:274) and applies the AdamW update:
+    28 bytes per parameter of HBM traffic in total, instead of 9 fused multi-tensor launches + 3 norm + 3 scale launches.
+
+`state_dict()` / `load_state_dict()` use torch.optim.AdamW's format (per-parameter `step`, `exp_avg`, `exp_avg_sq`), so the
+reference's `last_opt.pth` resumes here and vice versa; torch LR schedulers (OneCycleLR) drive `param_groups[0]['lr']` as usual."""
+import math
+
+import torch
+
+from . import hip
+from .hip import c_long, c_float, c_int
+
+_ALIGN = 64                                                       # floats: 256-byte slots
+
+
+class FlatAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None):
+        params = [p for p in params if p.requires_grad]
+        if not params:
+            raise ValueError('no trainable parameters')
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if len(self.param_groups) != 1:
+            raise ValueError('FlatAdamW handles one parameter group')
+        self.max_grad_norm = max_grad_norm
+        self._t = 0
+        self._steps = [0] * len(params)
+        self.last_grad_norm = None
+        self._build()
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _build(self):
+        ps = self.param_groups[0]['params']
+        dev = ps[0].device
+        hip.need_cuda(ps[0])
+        for p in ps:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise TypeError('FlatAdamW expects fp32 parameters on one device')
+        self._offsets, total = [], 0
+        for p in ps:
+            self._offsets.append(total)
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self._n = total
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._scratch = torch.zeros(1, dtype=torch.float64, device=dev)
+        self._norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        view = lambda flat, o, p: flat[o:o + p.numel()].view(p.shape)      # noqa: E731
+        self._g_views = [view(self.flat_g, o, p) for o, p in zip(self._offsets, ps)]
+        with torch.no_grad():
+            for i, (o, p) in enumerate(zip(self._offsets, ps)):
+                v = view(self.flat_p, o, p)
+                v.copy_(p.data)
+                p.data = v                                        # the parameter now lives in the flat buffer
+                st = self.state[p]
+                old_m, old_v = st.get('exp_avg'), st.get('exp_avg_sq')
+                st['exp_avg'], st['exp_avg_sq'] = view(self.flat_m, o, p), view(self.flat_v, o, p)
+                if old_m is not None:
+                    st['exp_avg'].copy_(old_m)
+                    st['exp_avg_sq'].copy_(old_v)
+                st['step'] = torch.tensor(float(self._steps[i]))
+        self._ptrs = [p.data_ptr() for p in ps]
+
+    def _intact(self):
+        ps = self.param_groups[0]['params']
+        return all(p.data_ptr() == a for p, a in zip(ps, self._ptrs))
+
+    # ------------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if not self._intact():                                    # model.to(...) / .float() moved the parameters: re-home them
+            self._build()
+        g = self.param_groups[0]
+        ps = g['params']
+        grads, views, have = [], [], []
+        for p, gv in zip(ps, self._g_views):
+            have.append(p.grad is not None)
+            if p.grad is not None:
+                grads.append(p.grad)
+                views.append(gv)
+        if not grads:
+            return loss
+        if len(grads) != len(ps):
+            self.flat_g.zero_()                                   # absent gradients must not count in the norm
+        torch._foreach_copy_(views, grads)
+        b1, b2 = g['betas']
+        clip = self.max_grad_norm is not None
+        args = (c_float(g['lr']), c_float(b1), c_float(b2), c_float(g['eps']), c_float(g['weight_decay']))
+        tail = (hip.ptr(self._scratch), c_float(float(self.max_grad_norm) if clip else 0.0), hip.ptr(self._norm))
+
+        def launch(lo, hi, t, phases):
+            off = 4 * lo
+            hip.call('mg_adamw_flat', hip.ctypes.c_void_p(self.flat_p.data_ptr() + off), hip.ctypes.c_void_p(self.flat_g.data_ptr() + off),
+                     hip.ctypes.c_void_p(self.flat_m.data_ptr() + off), hip.ctypes.c_void_p(self.flat_v.data_ptr() + off), c_long(hi - lo), *args,
+                     c_float(1.0 - b1 ** t), c_float(math.sqrt(1.0 - b2 ** t)), *tail, c_int(phases), hip.stream())
+
+        steps = self._steps
+        if all(have) and min(steps) == max(steps):                # the usual case: one launch pair over everything
+            t = steps[0] + 1
+            launch(0, self._n, t, 3)
+            self._steps = [t] * len(ps)
+        else:
+            # torch.optim.AdamW skips a parameter without a gradient (no decay, no moment update, its own step count): update each
+            # contiguous run of parameters that do have one and share a step count; the norm is taken over the whole buffer first
+            launch(0, self._n, 1, 1)
+            ends = self._offsets[1:] + [self._n]
+            i = 0
+            while i < len(ps):
+                if not have[i]:
+                    i += 1
+                    continue
+                j = i
+                while j + 1 < len(ps) and have[j + 1] and steps[j + 1] == steps[i]:
+                    j += 1
+                launch(self._offsets[i], ends[j], steps[i] + 1, 2)
+                for k in range(i, j + 1):
+                    steps[k] += 1
+                i = j + 1
+        self._t = max(self._steps)
+        self.last_grad_norm = self._norm                          # device scalar (no sync): total gradient norm before clipping
+        return loss
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def state_dict(self):
+        for p, t in zip(self.param_groups[0]['params'], self._steps):
+            self.state[p]['step'] = torch.tensor(float(t))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)                       # replaces the moment tensors by loaded copies ...
+        ps = self.param_groups[0]['params']
+        self._steps = [int(float(self.state[p]['step'])) if 'step' in self.state[p] else 0 for p in ps]
+        self._t = max(self._steps) if self._steps else 0
+        self._build()                                             # ... which _build copies back into the flat buffers

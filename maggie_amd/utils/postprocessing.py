@@ -28,18 +28,23 @@ def reverse_transform_tensor(img, transform_info, snap=False):
     shape = list(img.shape)
     x = img.reshape(-1, shape[-2], shape[-1]).float().contiguous()
     crop_h, crop_w = x.shape[-2:]
-    ran = False
+    ops = []
     for tr in transform_info[::-1]:
         name = tr['name'][0] if isinstance(tr['name'], list) else tr['name']
         if name == 'padding':
-            ph, pw = (_scalar(v) for v in tr['pad_size'])
-            crop_h, crop_w = crop_h - ph, crop_w - pw
+            ops.append(('pad',) + tuple(_scalar(v) for v in tr['pad_size']))
         elif name == 'resize':
-            h, w = (_scalar(v) for v in tr['ori_size'])
-            x = _run(x, crop_h, crop_w, h, w, False)
-            crop_h, crop_w = h, w
-            ran = True
-    if snap or not ran or (crop_h, crop_w) != tuple(x.shape[-2:]):
-        x = _run(x, crop_h, crop_w, crop_h, crop_w, snap)                  # pending crop and/or snapping (exact copy: scale 1)
+            ops.append(('resize',) + tuple(_scalar(v) for v in tr['ori_size']))
+    snapped = False
+    for i, (name, a, b) in enumerate(ops):
+        if name == 'pad':
+            crop_h, crop_w = crop_h - a, crop_w - b
+        else:
+            last = snap and i == len(ops) - 1                     # the snapping rides on the last resize: no extra pass
+            x = _run(x, crop_h, crop_w, a, b, last)
+            crop_h, crop_w = a, b
+            snapped = snapped or last
+    if (snap and not snapped) or (crop_h, crop_w) != tuple(x.shape[-2:]):
+        x = _run(x, crop_h, crop_w, crop_h, crop_w, snap and not snapped)      # pending crop and/or snapping (exact copy: scale 1)
     shape[-2:] = crop_h, crop_w
     return x.reshape(shape)

@@ -568,3 +568,47 @@ def test_device_metrics_match_reference_fixture_and_oracle():
             assert m.count == count and abs(m.score - score) <= 5e-5 * abs(score) + 1e-9, (name, t is None, m.score, score)
     with pytest.raises(NotImplementedError):
         dm.build_metric(['Conn'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('max_norm', [None, 0.01, 1e6])
+def test_flat_adamw_matches_torch_adamw(max_norm):
+    """maggie_amd.optim.FlatAdamW (mg_adamw_flat) == torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW, step for step, including a
+    OneCycleLR schedule, a parameter that gets no gradient on some steps, and a state_dict round trip into torch's own AdamW."""
+    from maggie_amd.optim import FlatAdamW
+    dev = _dev()
+    torch.manual_seed(0)
+    shapes = [(64, 3, 3, 32), (128,), (17, 5), (1,), (256, 256), (33,)]
+    mk = lambda: [torch.nn.Parameter(torch.randn(s, device=dev, generator=None) * 0.1) for s in shapes]     # noqa: E731
+    ours = mk()
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ours]
+    kw = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    o_opt, r_opt = FlatAdamW(ours, max_grad_norm=max_norm, **kw), torch.optim.AdamW(ref, **kw)
+    o_s = torch.optim.lr_scheduler.OneCycleLR(o_opt, max_lr=5e-3, total_steps=12, cycle_momentum=False)
+    r_s = torch.optim.lr_scheduler.OneCycleLR(r_opt, max_lr=5e-3, total_steps=12, cycle_momentum=False)
+    assert all(p.data_ptr() >= o_opt.flat_p.data_ptr() for p in ours) and ours[0].data_ptr() == o_opt.flat_p.data_ptr()
+    for it in range(8):
+        for i, (a, b) in enumerate(zip(ours, ref)):
+            if i == 3 and it % 2:                                  # no gradient this step
+                a.grad = b.grad = None
+                continue
+            g = torch.randn_like(a) * (10.0 if it == 5 else 0.01)
+            a.grad, b.grad = g.clone(), g.clone()
+        if max_norm is not None:
+            total = torch.nn.utils.clip_grad_norm_([p for p in ref if p.grad is not None], max_norm)
+        o_opt.step(); r_opt.step(); o_s.step(); r_s.step()
+        if max_norm is not None:
+            assert torch.allclose(o_opt.last_grad_norm[0], total, rtol=1e-5)
+        for i, (a, b) in enumerate(zip(ours, ref)):                # incl. the parameter torch skips on odd steps (own step count)
+            assert torch.allclose(a, b, rtol=2e-5, atol=2e-7), (it, i, float((a - b).abs().max()))
+    assert o_opt._steps[3] == 4 and o_opt._steps[0] == 8
+    # torch's AdamW resumes from our state
+    sd = o_opt.state_dict()
+    t_opt = torch.optim.AdamW([torch.nn.Parameter(p.detach().clone()) for p in ours], **kw)
+    t_opt.load_state_dict(sd)
+    assert float(t_opt.state[t_opt.param_groups[0]['params'][0]]['step']) == 8 and float(t_opt.state[t_opt.param_groups[0]['params'][3]]['step']) == 4
+    assert torch.equal(t_opt.state[t_opt.param_groups[0]['params'][4]]['exp_avg'], o_opt.state[ours[4]]['exp_avg'])
+    # and we resume from torch's
+    o2 = FlatAdamW([torch.nn.Parameter(p.detach().clone()) for p in ref if True], max_grad_norm=max_norm, **kw)
+    o2.load_state_dict(r_opt.state_dict())
+    assert o2._t == 8 and torch.allclose(o2.flat_m[:o2.param_groups[0]['params'][0].numel()], r_opt.state[ref[0]]['exp_avg'].reshape(-1))

@@ -3,6 +3,7 @@ import sys, os, time, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from maggie_amd.network import build_model
+from maggie_amd import parallel
 from maggie_amd.utils import config, synth
 from maggie_amd import graphs as G
 it = int(sys.argv[sys.argv.index('--iter') + 1]) if '--iter' in sys.argv else 100
@@ -14,7 +15,7 @@ batch = synth.synthetic_batch(4, 1, 2, 512, 512, seed=1234, train=True, it=it, m
 batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
 np.random.seed(1); random.seed(1); torch.manual_seed(1)
 params = [p for p in model.parameters() if p.requires_grad]
-opt = torch.optim.AdamW(params, lr=1.5e-4 / 25, weight_decay=0.01)
+opt = torch.optim.AdamW(params, lr=1.5e-4 / 25, weight_decay=0.01, fused=True)       # as bench.py
 ev = {}
 def mark(name):
     e = torch.cuda.Event(enable_timing=True); e.record(); ev.setdefault(name, []).append(e)
@@ -33,7 +34,7 @@ def step():
         out, loss = model(batch)
     loss['total'].backward()
     mark('backward_end')
-    torch.nn.utils.clip_grad_norm_(params, 0.01)
+    parallel.clip_grad_norm_(params, 0.01)
     opt.step()
     mark('step_end')
 for _ in range(5): step()
