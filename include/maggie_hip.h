@@ -295,7 +295,7 @@ int mg_weight_bank(const mg_wb_entry* entries, int n, int backward, void* stream
 int mg_bias_act_bwd(const void* dy, const void* y, void* g, int dtype, int M, int C, float* db, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
- * Optimizer step of the measured train step (maggie/engine/train.py:274-276: clip_grad_norm_(0.01), AdamW of engine/optim.py)
+ * Optimizer step of the measured train step (maggie/engine/train.py:274,281: clip_grad_norm_(0.01), AdamW of engine/optim.py:110-118)
  * over ONE flat fp32 buffer holding every trainable parameter (p, g, m, v: n floats each, n % 4 == 0, 16-byte aligned).
  * sumsq_scratch != NULL: the squared gradient norm is reduced into it first (1 device double) and, with max_norm > 0, gradients
  * are scaled by min(1, max_norm / (norm + 1e-6)) inside the update (no separate scaling pass); norm_out (or NULL) receives the norm.

@@ -404,7 +404,7 @@ extern "C" int mg_bias_act_bwd(const void* dy, const void* y, void* g, int dtype
     const int ce = dtype == MG_BF16 ? 8 : 4;
     if (C % ce) return -3;
     if (y && !g) return -3;
-    const ColGeom gm = col_geom(M, C, ce, 64);
+    const ColGeom gm = col_geom(M, C, ce, 512);          // like MG_BN_RB: enough blocks to stream at HBM rate, few enough atomics per channel
     const size_t lds = (size_t)gm.ty * gm.tx * ce * sizeof(float);
     if (dtype == MG_BF16) hipLaunchKernelGGL(bias_act_bwd_kernel<bf16raw>, dim3(gm.rb, gm.groups), dim3(NT), lds, st, (const bf16raw*)dy, (const bf16raw*)y, (bf16raw*)g, M, C, db, gm.rpb, gm.tx, gm.ty);
     else hipLaunchKernelGGL(bias_act_bwd_kernel<float>, dim3(gm.rb, gm.groups), dim3(NT), lds, st, (const float*)dy, (const float*)y, (float*)g, M, C, db, gm.rpb, gm.tx, gm.ty);

@@ -1,6 +1,6 @@
 """Optimizer step of the train step on the MI355X: AdamW over one flat parameter buffer, gradient-norm clip folded in.
 
-`FlatAdamW(params, lr, betas, eps, weight_decay, max_grad_norm)` is torch.optim.AdamW (what maggie/engine/optim.py builds) for the
+`FlatAdamW(params, lr, betas, eps, weight_decay, max_grad_norm)` is torch.optim.AdamW (what maggie/engine/optim.py:110-118 builds) for the
 case the hot path has -- one parameter group, fp32 parameters on one GPU -- restructured for HBM:
 
   * on construction every trainable parameter is re-homed into ONE flat fp32 buffer (`p.data` becomes a view; 256-byte aligned
