@@ -257,9 +257,18 @@ def main():
                        'active_ratio': round(active_ratio, 4), 'active_ratio_per_timed_step': [round(float(v), 3) for v in stats['active_hist'][-args.steps - 2:-2]] if not args.no_roofline else None, 'active_pixels_per_step_per_gpu': int(active_px), 'loss_total': round(loss_val, 4)},
             'roofline': roofline, 'cpu_baseline': cpu_baseline,
         }
-        print(json.dumps(line))
     if world > 1 or force_ddp:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE JSON line goes out last: anything native libraries (RCCL's version banner) left in the C stdio buffer first
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.write(json.dumps(line) + '\n')
+        sys.stdout.flush()
 
 
 def cpu_baseline_subprocess(args, limit_s=150):
