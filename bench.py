@@ -95,17 +95,20 @@ def main():
             from torch.nn.parallel import DistributedDataParallel as DDP
             net = DDP(model, device_ids=[local_rank], find_unused_parameters=True, gradient_as_bucket_view=True)
         else:
-            # same start on every rank (DDP broadcasts rank 0's state at construction), then flat-buffer gradient all-reduce
+            # same start on every rank (DDP broadcasts rank 0's state at construction), then flat-buffer gradient all-reduce:
+            # inside FlatAdamW.step() (one collective over its flat gradient buffer) or, with a torch optimizer, parallel.GradSync
             for t_ in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t_.data, 0)
-            grad_sync = parallel.GradSync(model)
+            if args.optimizer != 'flat':
+                grad_sync = parallel.GradSync(model)
     params = [p for p in model.parameters() if p.requires_grad]
     # AdamW as maggie_image.yaml:90-98; lr = max_lr / 25 = the first value of the reference's OneCycleLR schedule
     # (engine/optim.py:117-118, default div_factor) -- a full max_lr step on random-init weights makes the detail region
     # (and therefore the sparse workload) drift wildly between the few timed steps.
     if args.optimizer == 'flat':                              # same update rule, one HBM pass (tests: test_flat_adamw_matches_torch_adamw)
         from maggie_amd.optim import FlatAdamW
-        opt = FlatAdamW(params, lr=1.5e-4 / 25, betas=(0.9, 0.999), weight_decay=0.01, max_grad_norm=0.01)      # clip: engine/train.py:274
+        opt = FlatAdamW(params, lr=1.5e-4 / 25, betas=(0.9, 0.999), weight_decay=0.01, max_grad_norm=0.01,           # clip: engine/train.py:274
+                        sync_group=True if ((world > 1 or force_ddp) and not args.ddp) else None)
     else:
         opt = torch.optim.AdamW(params, lr=1.5e-4 / 25, betas=(0.9, 0.999), weight_decay=0.01, fused=args.optimizer == 'fused')
 
@@ -253,7 +256,7 @@ def main():
             'config': {'workload': 'maggie_%s.yaml train step: %dx%d, %d instances (10 slots), batch %d frames/GPU x %d frame(s), iter=%d, '
                                    'fwd+loss+bwd+clip+AdamW' % (kind, args.size, args.size, args.instances, b, n_f, args.iter),
                        'global_batch': b * world, 'parallelism': 'dp%d' % world, 'sync_bn': bool(args.sync_bn and world > 1), 'optimizer': 'FlatAdamW (clip 0.01 folded in)' if args.optimizer == 'flat' else 'torch AdamW(%s) + flat-buffer grad-norm clip' % args.optimizer,
-                       'grad_allreduce': None if world == 1 and not force_ddp else ('torch DDP' if args.ddp else 'GradSync (flat-buffer RCCL all-reduce)'),
+                       'grad_allreduce': None if world == 1 and not force_ddp else ('torch DDP' if args.ddp else ('one RCCL all-reduce of the flat gradient buffer inside FlatAdamW.step' if args.optimizer == 'flat' else 'GradSync (flat-buffer RCCL all-reduce)')),
                        'active_ratio': round(active_ratio, 4), 'active_ratio_per_timed_step': [round(float(v), 3) for v in stats['active_hist'][-args.steps - 2:-2]] if not args.no_roofline else None, 'active_pixels_per_step_per_gpu': int(active_px), 'loss_total': round(loss_val, 4)},
             'roofline': roofline, 'cpu_baseline': cpu_baseline,
         }

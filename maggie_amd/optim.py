@@ -10,6 +10,9 @@ case the hot path has -- one parameter group, fp32 parameters on one GPU -- rest
     min(1, max_norm / (norm + 1e-6)) (`clip_grad_norm_` of maggie/engine/train.py:274) and applies the AdamW update:
     28 bytes per parameter of HBM traffic in total, instead of 9 fused multi-tensor launches + 3 norm + 3 scale launches.
 
+`sync_group=True` (or a process group) makes `step()` average the flat gradient buffer over the ranks first -- the whole data-parallel exchange
+of the train step as one RCCL all-reduce, instead of DDP's hooks and buckets (call neither DDP nor `parallel.GradSync` then).
+
 `state_dict()` / `load_state_dict()` use torch.optim.AdamW's format (per-parameter `step`, `exp_avg`, `exp_avg_sq`), so the
 reference's `last_opt.pth` resumes here and vice versa; torch LR schedulers (OneCycleLR) drive `param_groups[0]['lr']` as usual."""
 import math
@@ -23,7 +26,7 @@ _ALIGN = 64                                                       # floats: 256-
 
 
 class FlatAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None, sync_group=None):
         params = [p for p in params if p.requires_grad]
         if not params:
             raise ValueError('no trainable parameters')
@@ -31,6 +34,7 @@ class FlatAdamW(torch.optim.Optimizer):
         if len(self.param_groups) != 1:
             raise ValueError('FlatAdamW handles one parameter group')
         self.max_grad_norm = max_grad_norm
+        self.sync_group = sync_group                              # see step(): data-parallel gradient averaging on the flat buffer
         self._t = 0
         self._steps = [0] * len(params)
         self.last_grad_norm = None
@@ -92,11 +96,20 @@ class FlatAdamW(torch.optim.Optimizer):
             if p.grad is not None:
                 grads.append(p.grad)
                 views.append(gv)
-        if not grads:
+        sync = self.sync_group is not None
+        if not grads and not sync:
             return loss
         if len(grads) != len(ps):
             self.flat_g.zero_()                                   # absent gradients must not count in the norm
-        torch._foreach_copy_(views, grads)
+        if grads:
+            torch._foreach_copy_(views, grads)
+        if sync:
+            # data parallel: ONE all-reduce (mean) of the whole flat gradient buffer over RCCL -- same size and layout on every
+            # rank whatever each rank's autograd produced; a parameter without a local gradient contributes zeros, as under DDP
+            import torch.distributed as dist
+            grp = None if self.sync_group is True else self.sync_group
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.AVG, group=grp)
+            have = [True] * len(ps)
         b1, b2 = g['betas']
         clip = self.max_grad_norm is not None
         args = (c_float(g['lr']), c_float(b1), c_float(b2), c_float(g['eps']), c_float(g['weight_decay']))

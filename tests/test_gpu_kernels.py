@@ -612,3 +612,36 @@ def test_flat_adamw_matches_torch_adamw(max_norm):
     o2 = FlatAdamW([torch.nn.Parameter(p.detach().clone()) for p in ref if True], max_grad_norm=max_norm, **kw)
     o2.load_state_dict(r_opt.state_dict())
     assert o2._t == 8 and torch.allclose(o2.flat_m[:o2.param_groups[0]['params'][0].numel()], r_opt.state[ref[0]]['exp_avg'].reshape(-1))
+
+
+@pytest.mark.gpu
+def test_flat_adamw_sync_group_single_rank_rccl():
+    """FlatAdamW(sync_group=True): the gradient exchange is one RCCL all-reduce (mean) of the flat buffer. With one rank the mean is the
+    identity: same parameters as without the group; a parameter without a local gradient is updated with zeros (DDP semantics)."""
+    import os
+    import torch.distributed as dist
+    from maggie_amd.optim import FlatAdamW
+    dev = _dev()
+    if dist.is_initialized():
+        pytest.skip('a process group already exists in this process')
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29541', RANK='0', WORLD_SIZE='1')
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        torch.manual_seed(1)
+        a = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in ((40, 9), (7,), (3, 3))]
+        b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+        oa = FlatAdamW(a, lr=1e-3, max_grad_norm=0.01, sync_group=True)
+        ob = FlatAdamW(b, lr=1e-3, max_grad_norm=0.01)
+        for it in range(3):
+            for x, y in zip(a, b):
+                g = torch.randn_like(x)
+                x.grad, y.grad = g.clone(), g.clone()
+            oa.step(); ob.step()
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+        before = a[1].detach().clone()
+        a[1].grad = None
+        oa.step()
+        assert oa._steps == [4, 4, 4] and not torch.equal(a[1], before)      # decayed / moment-driven update, like a zero gradient under DDP
+    finally:
+        dist.destroy_process_group()
