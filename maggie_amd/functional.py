@@ -492,6 +492,20 @@ class BNAct(torch.autograd.Function):
         x2 = x.contiguous().view(-1, C)
         M = x2.shape[0]
         H, W_ = (shape[1], shape[2]) if x.dim() == 4 else (1, 1)
+        if training and group is None and gamma.dtype == torch.float32 and gamma.numel() == C and M > 0 and \
+                (running_mean is None or running_mean.numel() == C):
+            # the common case (local statistics, unpadded channels) in one C call: statistics, finalize, apply
+            exact = M <= EXACT_STATS_ROWS
+            if exact and stats is not None and stats.dim() != 1:
+                stats = None                                      # replicas from a conv epilogue: the exact path recomputes
+            r2 = None if res is None else res.contiguous().view(-1, C)
+            y, pack = K.bn_train_fwd(x2, gamma, beta, running_mean, running_var, momentum, eps, act, LRELU_SLOPE, r2, res_mode, H, W_,
+                                     stats, exact)
+            ctx.save_for_backward(x2, y, pack)
+            ctx.fast = True
+            ctx.meta = (shape, M, C, act, res is not None, res_mode, training, group, mask_x_pos, C, res.shape if res is not None else None)
+            return y.view(shape)
+        ctx.fast = False
         g32 = pad_vec(gamma.float(), C)
         b32 = pad_vec(beta.float(), C)
         count = float(M)
@@ -533,6 +547,13 @@ class BNAct(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.fast:
+            x2, y, pack = ctx.saved_tensors
+            shape, M, C, act, has_res, res_mode, training, group, mask_x_pos, nch, res_shape = ctx.meta
+            dx, dres, sums = K.bn_train_bwd(dy.contiguous().view(-1, C), y, x2, pack, act, LRELU_SLOPE, has_res, mask_x_pos)
+            if has_res:
+                dres = K.pool2x2(dres, 1, shape[0], shape[1] // 2, shape[2] // 2).view(res_shape) if res_mode == 2 else dres.view(res_shape)
+            return dx.view(shape), sums[C:], sums[:C], dres, None, None, None, None, None, None, None, None, None, None
         x2, y, scale, mean, invstd, cnt_t = ctx.saved_tensors
         shape, M, C, act, has_res, res_mode, training, group, mask_x_pos, nch, res_shape = ctx.meta
         dy2 = dy.contiguous().view(-1, C)

@@ -645,3 +645,42 @@ def test_flat_adamw_sync_group_single_rank_rccl():
         assert oa._steps == [4, 4, 4] and not torch.equal(a[1], before)      # decayed / moment-driven update, like a zero gradient under DDP
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('M,with_res,act', [(1000, True, 2), (50000, False, 2), (40000, True, 1), (8, False, 0)])
+def test_batch_norm_act_one_call_path_matches_torch(dtype, M, with_res, act):
+    """functional.batch_norm_act (mg_bn_train_fwd / mg_bn_train_bwd: statistics, finalize, apply behind one call each way) against
+    torch.nn.functional.batch_norm on the CPU -- both the exact two-pass branch (M <= 32768) and the replica-accumulator branch."""
+    from maggie_amd import functional as MF
+    dev = _dev()
+    rs = np.random.RandomState(M)
+    C = 32
+    q = _q(dtype)
+    x = q(torch.from_numpy(rs.normal(0.5, 2.0, (M, C)).astype(np.float32))).requires_grad_(True)
+    res = q(torch.from_numpy(rs.normal(size=(M, C)).astype(np.float32))).requires_grad_(True) if with_res else None
+    bn_ref = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        bn_ref.weight.copy_(torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32)))
+        bn_ref.bias.copy_(torch.from_numpy(rs.normal(size=C).astype(np.float32)))
+    bn = torch.nn.BatchNorm1d(C).to(dev)
+    bn.load_state_dict(bn_ref.state_dict())
+    y_ref = bn_ref(x) if res is None else bn_ref(x) + res
+    y_ref = [lambda t: t, F.relu, lambda t: F.leaky_relu(t, 0.2)][act](y_ref)
+    gy = q(torch.from_numpy(rs.normal(size=(M, C)).astype(np.float32)))
+    y_ref.backward(gy)
+    xd = x.detach().to(dev, dtype).requires_grad_(True)
+    rd = None if res is None else res.detach().to(dev, dtype).requires_grad_(True)
+    MF.ARENA.reset(dev)
+    y = MF.batch_norm_act(xd, bn, act, res=rd)
+    y.backward(gy.to(dev, dtype))
+    tol = _tol(dtype)
+    assert (y.detach().float().cpu() - y_ref.detach()).abs().max() <= tol * y_ref.abs().max() + 1e-6
+    assert torch.allclose(bn.running_mean.cpu(), bn_ref.running_mean, atol=1e-4) and torch.allclose(bn.running_var.cpu(), bn_ref.running_var, rtol=1e-3, atol=1e-4)
+    assert int(bn.num_batches_tracked) == 1
+    assert (xd.grad.float().cpu() - x.grad).abs().max() <= max(tol, 2e-4) * x.grad.abs().max() * 2
+    if res is not None:
+        assert (rd.grad.float().cpu() - res.grad).abs().max() <= tol * res.grad.abs().max() + 1e-6
+    for got, ref in ((bn.bias.grad, bn_ref.bias.grad), (bn.weight.grad, bn_ref.weight.grad)):
+        assert torch.allclose(got.cpu(), ref, rtol=2e-2, atol=2e-2 * ref.abs().max().item())
