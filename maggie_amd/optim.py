@@ -106,9 +106,8 @@ class FlatAdamW(torch.optim.Optimizer):
         if sync:
             # data parallel: ONE all-reduce (mean) of the whole flat gradient buffer over RCCL -- same size and layout on every
             # rank whatever each rank's autograd produced; a parameter without a local gradient contributes zeros, as under DDP
-            import torch.distributed as dist
-            grp = None if self.sync_group is True else self.sync_group
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.AVG, group=grp)
+            from .parallel import all_reduce_mean
+            all_reduce_mean(self.flat_g, None if self.sync_group is True else self.sync_group)
             have = [True] * len(ps)
         b1, b2 = g['betas']
         clip = self.max_grad_norm is not None

@@ -46,6 +46,16 @@ def wrap_ddp(model, device_index):
     return DDP(model, device_ids=[device_index], find_unused_parameters=False, gradient_as_bucket_view=True)
 
 
+def all_reduce_mean(flat, group=None):
+    """In-place mean over the process group: one `all_reduce(AVG)` on RCCL ("nccl"); gloo has no AVG, so SUM then divide."""
+    if dist.get_backend(group) == 'nccl':
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
+    else:
+        dist.all_reduce(flat, group=group)
+        flat.div_(dist.get_world_size(group))
+    return flat
+
+
 def grad_buffers(params, fill_missing=False):
     """Tensors that together hold every gradient of `params` exactly once: a flat 1-D base buffer where all of it is covered
     by gradient views (the hipGraph trunk's export: ~150 gradients = ONE tensor), the gradients themselves otherwise."""
@@ -102,11 +112,7 @@ class GradSync:
         self.avg = dist.is_available() and dist.is_initialized() and dist.get_backend(group) == 'nccl'
 
     def _all_reduce(self, flat):
-        if self.avg:
-            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
-        else:                                                     # gloo has no AVG
-            dist.all_reduce(flat, group=self.group)
-            flat.div_(self.world)
+        all_reduce_mean(flat, self.group)
 
     def __call__(self):
         if self.world <= 1 and not (dist.is_available() and dist.is_initialized()):

@@ -126,6 +126,10 @@ for p in ps[:4]:
     assert torch.allclose(p.grad, exp), (p.grad, exp); o += p.numel()
 assert torch.allclose(ps[4].grad, torch.full_like(ps[4], 15.0))
 assert torch.allclose(ps[5].grad, torch.full_like(ps[5], 2.0))
+# the exchange FlatAdamW(sync_group=...) performs on its flat gradient buffer (one mean all-reduce, identical layout on every rank)
+fg = torch.arange(10, dtype=torch.float32) * (r + 1)
+parallel.all_reduce_mean(fg)
+assert torch.allclose(fg, torch.arange(10, dtype=torch.float32) * 1.5)
 dist.destroy_process_group()
 print('OK', dist.get_rank() if False else '')
 '''
