@@ -187,7 +187,7 @@ def main():
     if not args.no_roofline:
         # Per-launch HIP-event timing needs every conv launched individually: the instrumented extra steps run the trunk
         # eagerly (the timed steps above replay it from hipGraphs, where the same kernels run back to back).
-        names = ['mg_conv_fprop', 'mg_conv_wgrad_ws']
+        names = ['mg_conv_fprop', 'mg_conv_fprop_ws', 'mg_conv_wgrad_ws']        # _ws: the split-K form of the same fprop family
         graphs_flag = model.__dict__.get('hip_graphs')
         model.hip_graphs = False
         hip.enable_timing(names)
@@ -200,7 +200,7 @@ def main():
         fam = {}
         for n in names:
             for s, e, work, tag in rec[n]:
-                key = '%s/%s' % (n, tag[0])
+                key = '%s/%s' % ('mg_conv_fprop' if n == 'mg_conv_fprop_ws' else n, tag[0])
                 d = fam.setdefault(key, [0.0, 0.0, 0])
                 d[0] += s.elapsed_time(e) * 1e-3
                 d[1] += work

@@ -67,6 +67,11 @@ typedef struct mg_conv_params {
 } mg_conv_params;
 
 int mg_conv_fprop(const mg_conv_params* p, void* stream);
+/* Same, allowed to split the K dimension over several blocks per tile for deep layers with few output rows (M <= 8192,
+ * K >= ~1152, Cout >= 64): mg_conv_fprop_workspace(p) = floats of scratch that plan needs (0: no split, identical to
+ * mg_conv_fprop); partial tiles go to the workspace, a second kernel sums them and applies the epilogue (deterministic). */
+long mg_conv_fprop_workspace(const mg_conv_params* p);
+int mg_conv_fprop_ws(const mg_conv_params* p, float* workspace, long workspace_floats, void* stream);
 
 /* Weight gradient:  dW[co, tap, ci] (+)= sum_m dY[m, co] * X[src(m,tap), ci]   (fp32 accumulate, atomics across
  * row splits; dW must be pre-zeroed fp32 [Cout, R*S, Cin]). Same geometry struct; `y` = dY (read), `res` unused,

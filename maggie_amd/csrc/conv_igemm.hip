@@ -51,8 +51,12 @@ static inline unsigned xcd_grid(long L) { return (unsigned)(((L + NXCD - 1) / NX
 // publishes stage s and stay in flight under its KS*FM*FN MFMAs; one LDS buffer, two barriers per stage. KS = 4 is used for
 // K-heavy layers (few, fat memory round trips: these GEMMs are small, so exposed load latency -- not bandwidth or MFMA rate --
 // is what bounds them), KS = 1 for the thin-K high-resolution layers.
-template <typename T, int BM, int BN, int KS, int MODE>
-__global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p) {
+// SPLIT (deep layers with few rows: M <= ~4096, K >= 1152): the K stages are divided over `splits` blocks per tile, each writing its
+// raw fp32 partial tile to its own slab of `ws` ([splits][M][Cout]); splitk_finish_kernel sums the slabs and applies the epilogue.
+// These layers could only fill the chip with 64x32 tiles (21 FLOP per byte staged through L2/LDS: ~100-220 TFLOP/s whatever the
+// shape); with the K split, 128x128 tiles (64 FLOP/B) reach the same block count.
+template <typename T, int BM, int BN, int KS, int MODE, bool SPLIT = false>
+__global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p, float* __restrict__ ws, int splits) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE, EPS = TR::EPS;
     constexpr int WAVES_M = TileCfg<BM, BN>::WAVES_M, WAVES_N = TileCfg<BM, BN>::WAVES_N;
@@ -69,13 +73,21 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
     const int lane = t & 63, wave = t >> 6;
     const int ntn = (p.Cout + BN - 1) / BN;
     int work;
-    if (!xcd_order(((p.M + BM - 1) / BM) * ntn, work)) return;
+    if (!xcd_order(((p.M + BM - 1) / BM) * ntn * (SPLIT ? splits : 1), work)) return;
+    int sp = 0;
+    if constexpr (SPLIT) { sp = work % splits; work /= splits; }
     const int mt = work / ntn;                   // channel tiles of one row tile are consecutive: they share the A rows
     const int m0 = mt * BM, n0 = (work - mt * ntn) * BN;
     const int taps = p.R * p.S;
     const int Ktot = taps * p.Cin;
     const int nslab = (Ktot + EPS - 1) / EPS;
-    const int nstage = (nslab + KS - 1) / KS;
+    const int nstage_all = (nslab + KS - 1) / KS;
+    int s_beg = 0, nstage = nstage_all;          // this block walks stages [s_beg, nstage)
+    if constexpr (SPLIT) {
+        const int per = (nstage_all + splits - 1) / splits;
+        s_beg = sp * per;
+        nstage = min(nstage_all, s_beg + per);
+    }
     const char* __restrict__ xb = (const char*)p.x;
     const char* __restrict__ wb = (const char*)p.w;
 
@@ -97,7 +109,7 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
             rc[i].n = m; rc[i].ho = 0; rc[i].wo = 0;
         }
     }
-    int a_k = a_c * CE;                    // running k index of this thread's chunk in slab 0 of the current stage
+    int a_k = s_beg * KS * EPS + a_c * CE; // running k index of this thread's chunk in slab 0 of the current stage
     int a_tap = a_k / p.Cin;
     int a_ci = a_k - a_tap * p.Cin;
 
@@ -177,7 +189,8 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
         bptr[i] = wb + ((long)(n0 + (bok[i] ? co : 0)) * Ktot + c * CE) * (long)sizeof(T);
     }
     const int spt = p.Cin / EPS;             // slabs per tap (aligned path)
-    int q_slab = 0, q_sub = 0, q_ky = 0, q_kx = 0, q_tap = 0;
+    int q_slab = s_beg * KS, q_sub = 0, q_ky = 0, q_kx = 0, q_tap = 0;
+    if (SPLIT && al && !c8) { q_tap = q_slab / spt; q_sub = q_slab - q_tap * spt; q_ky = q_tap / p.S; q_kx = q_tap - q_ky * p.S; }
     auto load_stage_al = [&](int u) {
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
@@ -245,8 +258,8 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
     const char* b_base = sB + (wn * WN + lr) * ROWB + lg * 16;
 #pragma unroll
     for (int u = 0; u < PF; ++u)
-        if (u < nstage) { if (al) load_stage_al(u); else load_stage(u, u); }
-    for (int s0 = 0; s0 < nstage; s0 += PF) {
+        if (s_beg + u < nstage) { if (al) load_stage_al(u); else load_stage(s_beg + u, u); }
+    for (int s0 = s_beg; s0 < nstage; s0 += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {                 // fully unrolled: `u` is a compile-time register-bank index
             const int s = s0 + u;
@@ -280,6 +293,20 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
         }
     }
 
+    if constexpr (SPLIT) {
+        // raw partial tile -> this split's slab (16 lanes = 16 consecutive channels = one 64-byte segment per row)
+        float* slab = ws + (long)sp * p.M * p.Cout;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int m = m0 + wm * WM + i * 16 + lg * 4 + e, c = n0 + wn * WN + j * 16 + lr;
+                    if (m < p.M && c < p.Cout) slab[(long)m * p.Cout + c] = acc[i][j][e];
+                }
+        return;
+    }
     // ---------------- epilogue: accumulators -> fp32 LDS tile -> vectorised global stores ----------------
     // (large tiles run two half-height passes so the fp32 tile stays within the staging buffers' LDS footprint)
     constexpr int EP = ep_passes<BM, BN>();
@@ -411,9 +438,9 @@ int launch_fprop(const mg_conv_params& p, hipStream_t st) {
         attr_set = true;
     }
     switch (p.mode) {
-        case MG_MODE_CONV: hipLaunchKernelGGL((igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_CONV>), grid, dim3(256), lds, st, p); break;
-        case MG_MODE_TCONV: hipLaunchKernelGGL((igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_TCONV>), grid, dim3(256), lds, st, p); break;
-        case MG_MODE_GATHER: hipLaunchKernelGGL((igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_GATHER>), grid, dim3(256), lds, st, p); break;
+        case MG_MODE_CONV: hipLaunchKernelGGL((igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_CONV>), grid, dim3(256), lds, st, p, (float*)nullptr, 1); break;
+        case MG_MODE_TCONV: hipLaunchKernelGGL((igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_TCONV>), grid, dim3(256), lds, st, p, (float*)nullptr, 1); break;
+        case MG_MODE_GATHER: hipLaunchKernelGGL((igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_GATHER>), grid, dim3(256), lds, st, p, (float*)nullptr, 1); break;
         default: return -2;
     }
     MG_CHECK_LAUNCH();
@@ -442,6 +469,165 @@ int dispatch_fprop_ks(const mg_conv_params& p, hipStream_t st) {
     return launch_fprop<T, 128, 16, KS>(p, st);
 }
 
+// ---- split-K: sum the partial slabs, then the SAME epilogue arithmetic as igemm_fprop_kernel (pre-activation, scale/shift,
+// residual, activation, post residual, rounding to T) and the BatchNorm statistics of the rounded values ----------------------
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const mg_conv_params p, const float* __restrict__ ws, int splits, int rows_per_block) {
+    using TR = ElemTraits<T>;
+    constexpr int CE = TR::CE;
+    __shared__ float sred[256 * 2 * CE];
+    const int cpr = (p.Cout + CE - 1) / CE;                // 16-byte chunks per row
+    const int tx = cpr < 32 ? cpr : 32;                    // chunk columns per block (cpr is a multiple of tx or handled by the guard)
+    const int ty = 256 / tx;
+    const int ix = threadIdx.x % tx, iy = threadIdx.x / tx;
+    const int cc = blockIdx.y * tx + ix;
+    const int cbase = cc * CE;
+    const bool active = iy < ty && cbase < p.Cout;
+    float sc[CE], sh[CE], s1[CE], s2[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+        const int c = cbase + e;
+        sc[e] = (p.scale && c < p.Cout) ? p.scale[c] : 1.f;
+        sh[e] = (p.shift && c < p.Cout) ? p.shift[c] : 0.f;
+        s1[e] = 0.f; s2[e] = 0.f;
+    }
+    const bool full_vec = (cbase + CE <= p.Cout);
+    T* __restrict__ yb = (T*)p.y;
+    const T* __restrict__ r1b = (const T*)p.res;
+    const T* __restrict__ r2b = (const T*)p.res2;
+    const long slab = (long)p.M * p.Cout;
+    const int mbeg = blockIdx.x * rows_per_block, mend = min(p.M, mbeg + rows_per_block);
+    if (active) {
+        for (int m = mbeg + iy; m < mend; m += ty) {
+            float v[CE];
+#pragma unroll
+            for (int e = 0; e < CE; ++e) v[e] = 0.f;
+            const float* src = ws + (long)m * p.Cout + cbase;
+            for (int s = 0; s < splits; ++s) {
+                if (full_vec && (p.Cout % 4) == 0) {
+#pragma unroll
+                    for (int q = 0; q < CE / 4; ++q) {
+                        const float4 a = *(const float4*)(src + s * slab + q * 4);
+                        v[q * 4 + 0] += a.x; v[q * 4 + 1] += a.y; v[q * 4 + 2] += a.z; v[q * 4 + 3] += a.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < CE; ++e) if (cbase + e < p.Cout) v[e] += src[s * slab + e];
+                }
+            }
+            long rrow = m;
+            if (p.res_mode == 2) {
+                const int hw = p.Hout * p.Wout;
+                const int n = m / hw, rem = m - n * hw, ho = rem / p.Wout, wo = rem - ho * p.Wout;
+                rrow = ((long)n * (p.Hout >> 1) + (ho >> 1)) * (p.Wout >> 1) + (wo >> 1);
+            }
+            float rv[CE], rv2[CE];
+#pragma unroll
+            for (int e = 0; e < CE; ++e) { rv[e] = 0.f; rv2[e] = 0.f; }
+            if (r1b) {
+#pragma unroll
+                for (int e = 0; e < CE; ++e) if (cbase + e < p.Cout) rv[e] = TR::ld(r1b + rrow * p.ldr + cbase + e);
+            }
+            if (r2b) {
+#pragma unroll
+                for (int e = 0; e < CE; ++e) if (cbase + e < p.Cout) rv2[e] = TR::ld(r2b + (long)m * p.ldr2 + cbase + e);
+            }
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
+                float x = v[e];
+                if (p.pre_act) x = apply_act(x, p.act, p.slope);
+                x = x * sc[e] + sh[e];
+                x += rv[e];
+                if (!p.pre_act) x = apply_act(x, p.act, p.slope);
+                x += rv2[e];
+                x = TR::rnd(x);
+                v[e] = x;
+                s1[e] += x; s2[e] += x * x;
+            }
+            T* dst = yb + (long)m * p.ldy + p.yoff + cbase;
+            if (full_vec) *(uint4*)dst = TR::pack(v);
+            else {
+#pragma unroll
+                for (int e = 0; e < CE; ++e) if (cbase + e < p.Cout) TR::st(dst + e, v[e]);
+            }
+        }
+    }
+    if (p.stats) {                                          // uniform per launch: every thread reaches the barrier
+        const int width = tx * 2 * CE;
+        if (active) {
+#pragma unroll
+            for (int e = 0; e < CE; ++e) { sred[iy * width + ix * 2 * CE + e] = s1[e]; sred[iy * width + ix * 2 * CE + CE + e] = s2[e]; }
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < width; j += 256) {
+            float a = 0.f;
+            for (int r = 0; r < ty; ++r) a += sred[r * width + j];
+            const int cx = j / (2 * CE), k = j - cx * 2 * CE, sq = k / CE, e = k - sq * CE;
+            const int c = (blockIdx.y * tx + cx) * CE + e;
+            if (c < p.Cout) {
+                if (p.stat_mode == 1) { if (!sq) atomicAdd(&p.stats[c], a); }
+                else atomicAdd(&p.stats[(size_t)(blockIdx.x & (MG_STAT_REPLICAS - 1)) * 2 * p.Cout + (sq ? p.Cout : 0) + c], a);
+            }
+        }
+    }
+}
+
+struct SplitPlan { int bn, splits; };
+// Which layers: dense convs whose 64x64 tiling yields too few blocks (they run 64x32 tiles today) and whose K is deep enough
+// (>= 18 stages of 4 slabs). MG_FPROP_SPLITK=0 switches the path off.
+template <typename T>
+static SplitPlan plan_splitk(const mg_conv_params& p) {
+    SplitPlan sp{0, 1};
+    static const int enabled = [] { const char* e = getenv("MG_FPROP_SPLITK"); return e ? atoi(e) : 1; }();
+    static const long want_small = [] { const char* e = getenv("MG_FPROP_BLOCKS_SMALL"); return e ? atol(e) : 300l; }();
+    if (!enabled || p.mode == MG_MODE_GATHER || p.Cout < 64 || p.M > 8192) return sp;
+    constexpr int EPS = ElemTraits<T>::EPS;
+    const int nslab = (p.R * p.S * p.Cin + EPS - 1) / EPS;
+    const int nstage = (nslab + 3) / 4;
+    auto blocks = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn); };
+    static const int min_stages = [] { const char* e = getenv("MG_SPLITK_MIN_K_STAGES"); return e ? atoi(e) : 18; }();   // K >= 2304 (bf16). Stand-alone launches: 48 -> 30 us
+    // at 16x16x512 (K 4608), 53 -> 34 us at 32x32 512->256, even at K = 2304, a loss at K = 1152; inside the captured graphs (no host
+    // cost for the extra launch) the forward + backward graphs take 13.60 / 13.43 / 13.25 / 13.40 ms for off / 24 / 18 / 9 stages
+    if (nstage < min_stages || blocks(64, 64) >= want_small) return sp;
+    sp.bn = p.Cout >= 128 ? 128 : 64;
+    const long tiles = blocks(128, sp.bn);
+    static const long target = [] { const char* e = getenv("MG_SPLITK_BLOCKS"); return e ? atol(e) : 512l; }();
+    static const long smax = [] { const char* e = getenv("MG_SPLITK_MAX"); return e ? atol(e) : 8l; }();
+    static const long smin_stages = [] { const char* e = getenv("MG_SPLITK_MIN_STAGES"); return e ? atol(e) : 3l; }();
+    long s = (target + tiles - 1) / tiles;
+    if (s > nstage / smin_stages) s = nstage / smin_stages;
+    if (s > smax) s = smax;
+    if (s < 2) { sp.bn = 0; return sp; }
+    sp.splits = (int)s;
+    return sp;
+}
+
+template <typename T, int BN>
+static int launch_fprop_split(const mg_conv_params& p, float* ws, int splits, hipStream_t st) {
+    constexpr int BM = 128, KS = 4;
+    dim3 grid(xcd_grid((long)((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN) * splits));
+    constexpr size_t lds = lds_bytes<BM, BN, KS>();
+    static bool attr_set = false;
+    if (lds > 65536 && !attr_set) {
+        hipFuncSetAttribute((const void*)igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_CONV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_TCONV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    if (p.mode == MG_MODE_CONV) hipLaunchKernelGGL((igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_CONV, true>), grid, dim3(256), lds, st, p, ws, splits);
+    else hipLaunchKernelGGL((igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_TCONV, true>), grid, dim3(256), lds, st, p, ws, splits);
+    MG_CHECK_LAUNCH();
+    constexpr int CE = ElemTraits<T>::CE;
+    const int cpr = (p.Cout + CE - 1) / CE, tx = cpr < 32 ? cpr : 32, ty = 256 / tx;
+    const int groups = (cpr + tx - 1) / tx;
+    int rb = (p.M + ty * 2 - 1) / (ty * 2);
+    if (rb < 1) rb = 1;
+    if (rb > 512) rb = 512;
+    const int rpb = (p.M + rb - 1) / rb;
+    hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3((p.M + rpb - 1) / rpb, groups), dim3(256), 0, st, p, (const float*)ws, splits, rpb);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
 template <typename T>
 int dispatch_fprop(const mg_conv_params& p, hipStream_t st) {
     const int eps = sizeof(T) == 2 ? 32 : 16;
@@ -456,14 +642,47 @@ int dispatch_fprop(const mg_conv_params& p, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int mg_conv_fprop(const mg_conv_params* pp, void* stream) {
-    if (!pp) return -1;
-    const mg_conv_params& p = *pp;
+extern "C" long mg_conv_fprop_workspace(const mg_conv_params* pp) {
+    if (!pp || pp->M <= 0) return 0;
+    const SplitPlan sp = pp->dtype == MG_BF16 ? plan_splitk<bf16raw>(*pp) : plan_splitk<float>(*pp);
+    return sp.bn ? (long)sp.splits * pp->M * pp->Cout : 0;
+}
+
+static int conv_fprop_check(const mg_conv_params& p) {
     const int ce = p.dtype == MG_BF16 ? 8 : 4;
-    if (p.M <= 0) return 0;
     if (p.Cin % ce != 0 || p.ldx % ce != 0) return -3;                 // K chunks must not straddle taps / be 16-B aligned
     if (p.Cout >= ce && (p.ldy % ce != 0 || p.yoff % ce != 0)) return -4;
     if (p.mode == MG_MODE_GATHER && !p.nbr) return -5;
+    return 0;
+}
+
+extern "C" int mg_conv_fprop(const mg_conv_params* pp, void* stream);
+
+extern "C" int mg_conv_fprop_ws(const mg_conv_params* pp, float* workspace, long workspace_floats, void* stream) {
+    if (!pp) return -1;
+    const mg_conv_params& p = *pp;
+    if (p.M <= 0) return 0;
+    const long need = mg_conv_fprop_workspace(pp);
+    if (!need || !workspace || workspace_floats < need) return mg_conv_fprop(pp, stream);
+    int rc = conv_fprop_check(p); if (rc) return rc;
+    if (p.Cout % (p.dtype == MG_BF16 ? 8 : 4)) return mg_conv_fprop(pp, stream);
+    hipStream_t st = (hipStream_t)stream;
+    if (p.dtype == MG_BF16) {
+        const SplitPlan sp = plan_splitk<bf16raw>(p);
+        return sp.bn == 128 ? launch_fprop_split<bf16raw, 128>(p, workspace, sp.splits, st) : launch_fprop_split<bf16raw, 64>(p, workspace, sp.splits, st);
+    }
+    if (p.dtype == MG_F32) {
+        const SplitPlan sp = plan_splitk<float>(p);
+        return sp.bn == 128 ? launch_fprop_split<float, 128>(p, workspace, sp.splits, st) : launch_fprop_split<float, 64>(p, workspace, sp.splits, st);
+    }
+    return -6;
+}
+
+extern "C" int mg_conv_fprop(const mg_conv_params* pp, void* stream) {
+    if (!pp) return -1;
+    const mg_conv_params& p = *pp;
+    if (p.M <= 0) return 0;
+    { int rc = conv_fprop_check(p); if (rc) return rc; }
     hipStream_t st = (hipStream_t)stream;
     if (p.dtype == MG_BF16) return dispatch_fprop<bf16raw>(p, st);
     if (p.dtype == MG_F32) return dispatch_fprop<float>(p, st);

@@ -74,9 +74,27 @@ def conv_fprop(x, w, *, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=None, Wout=None,
     p = _conv_params(x, w, out, mode, N, Hin, Win, Hout, Wout, R, S, stride, pad, dil, M, Cin, Cout, nbr, scale, shift,
                      res, res_mode, res2, act, pre_act, slope, stats, yoff)
     p.stat_mode = stat_mode
-    hip.call('mg_conv_fprop', ctypes.byref(p), hip.stream(), work=2.0 * M * Cout * R * S * Cin,
-             tag=('bf16' if x.dtype == torch.bfloat16 else 'f32', mode, Cout, R * S * Cin, M))
+    work, tag = 2.0 * M * Cout * R * S * Cin, ('bf16' if x.dtype == torch.bfloat16 else 'f32', mode, Cout, R * S * Cin, M)
+    if mode != MODE_GATHER and 0 < M <= 8192 and Cout >= 64:
+        # deep layers with few rows: the library may split K over several blocks per tile (mg_conv_fprop_ws)
+        need = _fprop_workspace_fn()(ctypes.byref(p))
+        if need > 0:
+            ws = _wgrad_workspace(need, x.device)
+            hip.call('mg_conv_fprop_ws', ctypes.byref(p), hip.ptr(ws), ctypes.c_long(need), hip.stream(), work=work, tag=tag)
+            return out
+    hip.call('mg_conv_fprop', ctypes.byref(p), hip.stream(), work=work, tag=tag)
     return out
+
+
+_FPROP_WS_FN = []
+
+
+def _fprop_workspace_fn():
+    if not _FPROP_WS_FN:
+        fn = hip.lib().mg_conv_fprop_workspace
+        fn.restype = ctypes.c_long
+        _FPROP_WS_FN.append(fn)
+    return _FPROP_WS_FN[0]
 
 
 def conv_wgrad(x, dy, *, cout, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=1, Wout=1, R=1, S=1, stride=1, pad=0, dil=1,

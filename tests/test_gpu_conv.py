@@ -158,3 +158,74 @@ def test_gather_conv(dtype):
     dw = K.conv_wgrad(feat.to(dev, dtype), gy.to(dev, dtype), cout=Cout, mode=K.MODE_GATHER,
                       nbr=torch.from_numpy(nbr).to(dev), R=3, S=3)
     assert (dw.cpu().reshape(Cout, 3, 3, Cin) - w_.grad).abs().max().item() <= _tol(dtype) * w_.grad.abs().max().item()
+
+
+SPLITK_CASES = [
+    # N, Cin, Cout, H, W, k, stride, pad, dil   -- deep K, few output rows: the split-K plan of mg_conv_fprop_ws
+    (2, 256, 256, 16, 16, 3, 1, 1, 1),          # K 2304 (the shallowest K that splits), M 512
+    (1, 512, 128, 16, 16, 3, 1, 2, 2),          # dilated (ASPP-like), Cout 128
+    (1, 392, 72, 12, 20, 3, 1, 1, 1),           # unaligned Cin (generic tap walk), ragged Cout / M
+    (4, 512, 512, 8, 8, 3, 1, 1, 1),            # M 256, 8 splits
+    (1, 4096, 64, 8, 8, 1, 1, 0, 1),            # 1x1, K 4096, Cout 64 tile
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', SPLITK_CASES)
+def test_conv_fprop_split_k(case, dtype):
+    """Layers the library runs with the K dimension split over several blocks per tile (partial slabs + finishing kernel):
+    forward with the full epilogue (scale/shift, half-resolution residual, LeakyReLU, post residual, BN statistics in both
+    accumulator layouts) and the data gradient (TCONV mode), against torch on the CPU; and bit-identical to the unsplit kernel."""
+    import ctypes, os
+    from maggie_amd import kernels as K, hip
+    dev = _dev()
+    N, Cin, Cout, H, W, k, stride, pad, dil = case
+    rs = np.random.RandomState(sum(case))
+    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    x = q(torch.from_numpy(rs.normal(size=(N, Cin, H, W)).astype(np.float32))).requires_grad_(True)
+    w = q(torch.from_numpy((rs.normal(size=(Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)))
+    scale = torch.from_numpy(rs.uniform(0.5, 1.5, Cout).astype(np.float32))
+    shift = torch.from_numpy(rs.normal(size=Cout).astype(np.float32))
+    y0 = F.conv2d(x, w, None, stride, pad, dil)
+    Ho, Wo = y0.shape[-2:]
+    even = Ho % 2 == 0 and Wo % 2 == 0
+    res = q(torch.from_numpy(rs.normal(size=(N, Cout, Ho // 2, Wo // 2) if even else (N, Cout, Ho, Wo)).astype(np.float32)))
+    res2 = q(torch.from_numpy(rs.normal(size=(N, Cout, Ho, Wo)).astype(np.float32)))
+    y_ref = y0 * scale[None, :, None, None] + shift[None, :, None, None]
+    y_ref = F.leaky_relu(y_ref + (F.interpolate(res, scale_factor=2, mode='nearest') if even else res), 0.2) + res2
+    gy = q(torch.from_numpy(rs.normal(size=tuple(y0.shape)).astype(np.float32)))
+    y0.backward(gy)
+
+    xd, wd = _nhwc(x.detach()).to(dev, dtype), _krsc(w).to(dev, dtype)
+    geo = dict(N=N, Hin=H, Win=W, R=k, S=k, stride=stride, pad=pad, dil=dil)
+    # the plan really splits these layers
+    p = K._conv_params(xd.view(-1, Cin), wd, torch.empty((N * Ho * Wo, Cout), dtype=dtype, device=dev), K.MODE_CONV, N, H, W, Ho, Wo, k, k, stride,
+                       pad, dil, N * Ho * Wo, Cin, Cout)
+    assert K._fprop_workspace_fn()(ctypes.byref(p)) >= 2 * N * Ho * Wo * Cout
+    for stat_rows in (K.STAT_REPLICAS, 1):
+        stats = torch.zeros((stat_rows, 2 * Cout), device=dev) if stat_rows > 1 else torch.zeros(2 * Cout, device=dev)
+        y = K.conv_fprop(xd.view(-1, Cin), wd, scale=scale.to(dev), shift=shift.to(dev), res=_nhwc(res).to(dev, dtype).view(-1, Cout),
+                         res_mode=2 if even else 1, res2=_nhwc(res2).to(dev, dtype).view(-1, Cout), act=K.ACT_LRELU, slope=0.2, stats=stats, **geo)
+        yf = y.float().cpu().reshape(N, Ho, Wo, Cout).permute(0, 3, 1, 2)
+        assert (yf - y_ref.detach()).abs().max().item() <= _tol(dtype) * y_ref.abs().max().item()
+        s = stats.sum(0).cpu() if stat_rows > 1 else stats.cpu()
+        assert torch.allclose(s[:Cout], yf.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
+        if stat_rows > 1:
+            assert torch.allclose(s[Cout:], (yf * yf).sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
+        else:
+            assert float(s[Cout:].abs().max()) == 0                       # stat_mode 1: column sums only
+    # same result as the unsplit kernel up to fp32 summation order (bf16: at most one rounding step on a few elements)
+    y_split = K.conv_fprop(xd.view(-1, Cin), wd, **geo)
+    p.y = hip.ptr(torch.empty_like(y_split))
+    y_plain = torch.empty_like(y_split)
+    p.y = hip.ptr(y_plain)
+    hip.call('mg_conv_fprop', ctypes.byref(p), hip.stream())
+    d = (y_split.float() - y_plain.float()).abs().max().item()
+    assert d <= (2e-5 if dtype == torch.float32 else 1.6e-2) * y_plain.float().abs().max().item()
+    # dgrad: TCONV mode over the same geometry (K = taps * Cout)
+    if Cout % 8 == 0:
+        wt = w.permute(1, 2, 3, 0).reshape(Cin, k * k, Cout).contiguous().to(dev, dtype)
+        dx = K.conv_fprop(_nhwc(gy).to(dev, dtype).view(-1, Cout), wt, mode=K.MODE_TCONV, N=N, Hin=Ho, Win=Wo, Hout=H, Wout=W, R=k, S=k,
+                          stride=stride, pad=pad, dil=dil)
+        dx = dx.float().cpu().reshape(N, H, W, Cin).permute(0, 3, 1, 2)
+        assert (dx - x.grad).abs().max().item() <= _tol(dtype) * x.grad.abs().max().item()

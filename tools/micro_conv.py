@@ -11,6 +11,9 @@ def bench(fn, it=30):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / it * 1e3
 shapes = [(4, 128, 128, 64, 3), (4, 256, 256, 32, 3), (4, 64, 64, 128, 3), (4, 512, 512, 16, 3), (4, 32, 32, 512, 3)]
+if os.environ.get('MICRO_DEEP'):
+    shapes = [(4, 512, 512, 16, 3), (4, 256, 256, 32, 3), (4, 512, 256, 32, 3), (4, 256, 512, 32, 3), (4, 1280, 512, 16, 1), (4, 512, 256, 16, 3),
+              (4, 256, 512, 16, 3), (4, 256, 256, 16, 3), (4, 2048, 256, 16, 1), (4, 128, 128, 32, 3), (4, 512, 512, 32, 3)]
 for (N, Cin, Cout, HW, k) in shapes:
     x = torch.randn(N * HW * HW, Cin, device=dev).bfloat16()
     dy = torch.randn(N * HW * HW, Cout, device=dev).bfloat16()
