@@ -226,13 +226,13 @@ def main():
         # separate runs of this command, corrected per MI355X_MICROARCH.md; tools/pmc_traffic.py) -- only for the config they
         # were collected on
         traffic = None
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic_default_eager.json')
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic_final_eager.json')
         if os.path.isfile(pmc_path) and not args.video and args.size == 512 and args.batch == 4 and args.iter == 10000 and use_bf16:
             fam_key = 'igemm_fprop' if 'fprop' in dom[0] else 'igemm_wgrad'
             traffic = json.load(open(pmc_path)).get(fam_key, {}).get('hbm_bytes_per_launch')
         roofline = {
             'bound': 'mfma', 'kernel': 'igemm ' + dom[0], 'achieved': round(ach, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(ach / PEAK_BF16_TFLOPS, 5), 'traffic': traffic, 'traffic_unit': 'HBM-side bytes per launch (PMC, profiles/r01_pmc_traffic_default_eager.json)',
+            'frac': round(ach / PEAK_BF16_TFLOPS, 5), 'traffic': traffic, 'traffic_unit': 'HBM-side bytes per launch (PMC, profiles/r01_pmc_traffic_final_eager.json)',
             'launches_per_step': dom[1][2] // n_prof, 'avg_launch_us': round(1e6 * dom[1][0] / dom[1][2], 2),
             'alg_gflop_per_launch': round(dom[1][1] / dom[1][2] / 1e9, 4),
             'conv_family_ms_per_step': round(1e3 * tot_t / n_prof, 3), 'conv_family_tflops': round(tot_w / tot_t / 1e12, 2),
