@@ -120,14 +120,17 @@ int mg_bn_finalize(const float* stats, int nrep, const float* count_ptr, float c
                    float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
                    float* mean_out, float* invstd_out, void* stream);
 /* Training BatchNorm(+residual+activation) behind one entry point each way (same kernels as the calls above; local statistics only):
- *   mg_bn_train_fwd: p: x, y, res*, act, slope, H, W, dtype, M, C, ld*; pack: (2*MG_STAT_REPLICAS + 4)*C floats of scratch whose
- *                    last 4C receive scale | shift | mean | invstd (kept for the backward); stats_in (or NULL): statistics already
- *                    accumulated by the producing conv's epilogue -- stats_in_rows replicas of [2C], or with `exact` one row of
- *                    column sums; `exact`: two-pass variance (few rows per channel). Updates running_mean / running_var (or NULL).
- *   mg_bn_train_bwd: p: dy, y, x, scale, mean, invstd, dx, dres, sums [2C] (zeroed here; = dbeta | dgamma afterwards). */
-int mg_bn_train_fwd(const mg_rowwise_params* p, float* pack, const float* stats_in, int stats_in_rows, int exact, const float* gamma,
-                    const float* beta, float* running_mean, float* running_var, float momentum, float eps, void* stream);
-int mg_bn_train_bwd(const mg_rowwise_params* p, void* stream);
+ *   mg_bn_train_fwd: p: x, y, res*, act, slope, H, W, dtype, M, C, ld*; stats_ws: statistics scratch, [2C] floats with `exact`, else
+ *                    [MG_STAT_REPLICAS][2C] (ws_zeroed != 0: the caller hands it over zeroed, e.g. a slice of a per-step zero arena;
+ *                    else it is zeroed here); outs: 4C floats receiving scale | shift | mean | invstd (kept for the backward);
+ *                    stats_in (or NULL): statistics already accumulated by the producing conv's epilogue -- stats_in_rows replicas
+ *                    of [2C], or with `exact` one row of column sums; `exact`: two-pass variance (few rows per channel).
+ *                    Updates running_mean / running_var (or NULL).
+ *   mg_bn_train_bwd: p: dy, y, x, scale, mean, invstd, dx, dres, sums [2C] (zeroed here unless sums_zeroed; = dbeta | dgamma after). */
+int mg_bn_train_fwd(const mg_rowwise_params* p, float* stats_ws, int ws_zeroed, float* outs, const float* stats_in, int stats_in_rows,
+                    int exact, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                    void* stream);
+int mg_bn_train_bwd(const mg_rowwise_params* p, int sums_zeroed, void* stream);
 /* eval mode: fold running statistics into scale/shift */
 int mg_bn_fold(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                float eps, float* scale, float* shift, void* stream);

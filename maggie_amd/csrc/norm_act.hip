@@ -494,25 +494,25 @@ extern "C" int mg_bn_bwd_apply(const mg_rowwise_params* p, void* stream) {
 // ---- one-call training BatchNorm (the four / two launches above behind ONE entry point: the per-call host cost of the Python
 // binding -- argument marshalling, allocations, autograd bookkeeping -- is paid once instead of per kernel; this matters for the
 // host-paced sparse head, where a BatchNorm forward cost 51 us of host time for ~15 us of kernels) ------------------------------
-extern "C" int mg_bn_train_fwd(const mg_rowwise_params* p_in, float* pack, const float* stats_in, int stats_in_rows, int exact,
-                               const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
-                               float eps, void* stream) {
+extern "C" int mg_bn_train_fwd(const mg_rowwise_params* p_in, float* stats_ws, int ws_zeroed, float* outs, const float* stats_in,
+                               int stats_in_rows, int exact, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, float momentum, float eps, void* stream) {
     int rc = rowwise_check(p_in); if (rc) return rc;
     mg_rowwise_params p = *p_in;
     const int C = p.C;
     hipStream_t st = (hipStream_t)stream;
-    float* own = pack;                                   // [MG_STAT_REPLICAS][2C] statistics scratch
-    float* outs = pack + (size_t)MG_STAT_REPLICAS * 2 * C; // scale | shift | mean | invstd
+    float* own = stats_ws;                               // [2C] (exact) or [MG_STAT_REPLICAS][2C] statistics scratch; outs: scale | shift | mean | invstd
+    if (!stats_in && !own) return -3;
     const float* stats = stats_in;
     int nrep = stats_in_rows, centered = 0;
     if (exact) {
         // two-pass variance; a 1-row stats_in already carries the column sums from the producing conv's epilogue
         float* row = stats_in ? (float*)stats_in : own;
-        if (!stats_in) { hipError_t e = mg_zero_words(own, 2 * C, st); if (e != hipSuccess) return (int)e; }
+        if (!stats_in && !ws_zeroed) { hipError_t e = mg_zero_words(own, 2 * C, st); if (e != hipSuccess) return (int)e; }
         rc = mg_colstats_centered(p.x, p.dtype, p.M, C, p.ldx, row, stats_in ? 1 : 0, stream); if (rc) return rc;
         stats = row; nrep = 1; centered = 1;
     } else if (!stats_in) {
-        hipError_t e = mg_zero_words(own, (long)MG_STAT_REPLICAS * 2 * C, st); if (e != hipSuccess) return (int)e;
+        if (!ws_zeroed) { hipError_t e = mg_zero_words(own, (long)MG_STAT_REPLICAS * 2 * C, st); if (e != hipSuccess) return (int)e; }
         rc = mg_colstats(p.x, p.dtype, p.M, C, p.ldx, own, stream); if (rc) return rc;
         stats = own; nrep = MG_STAT_REPLICAS;
     }
@@ -523,10 +523,12 @@ extern "C" int mg_bn_train_fwd(const mg_rowwise_params* p_in, float* pack, const
     return mg_affine_act(&p, stream);
 }
 
-extern "C" int mg_bn_train_bwd(const mg_rowwise_params* p, void* stream) {
+extern "C" int mg_bn_train_bwd(const mg_rowwise_params* p, int sums_zeroed, void* stream) {
     int rc = rowwise_check(p); if (rc) return rc;
-    hipError_t e = mg_zero_words(p->sums, 2 * p->C, (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
+    if (!sums_zeroed) {
+        hipError_t e = mg_zero_words(p->sums, 2 * p->C, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+    }
     rc = mg_bn_bwd_reduce(p, stream); if (rc) return rc;
     return mg_bn_bwd_apply(p, stream);
 }

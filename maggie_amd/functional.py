@@ -499,8 +499,10 @@ class BNAct(torch.autograd.Function):
             if exact and stats is not None and stats.dim() != 1:
                 stats = None                                      # replicas from a conv epilogue: the exact path recomputes
             r2 = None if res is None else res.contiguous().view(-1, C)
+            own = stats is None
+            ws = ARENA.take((2 if exact else 2 * K.STAT_REPLICAS) * C, x.device) if own else None      # zeroed once per step / per graph
             y, pack = K.bn_train_fwd(x2, gamma, beta, running_mean, running_var, momentum, eps, act, LRELU_SLOPE, r2, res_mode, H, W_,
-                                     stats, exact)
+                                     stats, exact, ws)
             ctx.save_for_backward(x2, y, pack)
             ctx.fast = True
             ctx.meta = (shape, M, C, act, res is not None, res_mode, training, group, mask_x_pos, C, res.shape if res is not None else None)
@@ -550,7 +552,10 @@ class BNAct(torch.autograd.Function):
         if ctx.fast:
             x2, y, pack = ctx.saved_tensors
             shape, M, C, act, has_res, res_mode, training, group, mask_x_pos, nch, res_shape = ctx.meta
-            dx, dres, sums = K.bn_train_bwd(dy.contiguous().view(-1, C), y, x2, pack, act, LRELU_SLOPE, has_res, mask_x_pos)
+            # inside a graph capture the accumulator is a slice of the graph's own zero arena (no fill kernel per layer); eagerly the
+            # sums leave as gradients and must outlive the step's arena, so they get their own (zeroed in the call)
+            sums = ARENA.take(2 * C, dy.device) if torch.cuda.is_current_stream_capturing() else None
+            dx, dres, sums = K.bn_train_bwd(dy.contiguous().view(-1, C), y, x2, pack, act, LRELU_SLOPE, has_res, mask_x_pos, sums)
             if has_res:
                 dres = K.pool2x2(dres, 1, shape[0], shape[1] // 2, shape[2] // 2).view(res_shape) if res_mode == 2 else dres.view(res_shape)
             return dx.view(shape), sums[C:], sums[:C], dres, None, None, None, None, None, None, None, None, None, None

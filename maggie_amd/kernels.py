@@ -259,32 +259,38 @@ def bn_backward(dy, y, x, scale, mean, invstd, count, act=ACT_NONE, slope=0.2, w
 
 
 def bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, act, slope, res=None, res_mode=1, H=1, W=1, stats=None,
-                 exact=False):
-    """Training BatchNorm forward in ONE C call (statistics -> finalize -> apply): -> y, pack; pack[-4C:] = scale|shift|mean|invstd."""
+                 exact=False, stats_ws=None):
+    """Training BatchNorm forward in ONE C call (statistics -> finalize -> apply): -> y, outs = scale|shift|mean|invstd (4C).
+    `stats_ws`: zeroed scratch for the statistics ([2C] with `exact`, else [STAT_REPLICAS * 2C]); None: allocated and zeroed here."""
     M, C = x.shape[0], x.shape[-1]
     y = torch.empty((M, C), dtype=x.dtype, device=x.device)
-    pack = torch.empty((2 * STAT_REPLICAS + 4) * C, dtype=torch.float32, device=x.device)
+    outs = torch.empty(4 * C, dtype=torch.float32, device=x.device)
+    zeroed = stats_ws is not None
+    if stats_ws is None and stats is None:
+        stats_ws = torch.empty((2 if exact else 2 * STAT_REPLICAS) * C, dtype=torch.float32, device=x.device)
     p = _rowwise(x, M, C)
     p.y, p.ldy, p.yoff = hip.ptr(y), C, 0
     if res is not None:
         p.res, p.ldr, p.res_mode = hip.ptr(res), _ld(res), res_mode
     p.act, p.slope, p.H, p.W = act, slope, H, W
     rows = 0 if stats is None else (stats.shape[0] if stats.dim() == 2 else 1)
-    hip.call('mg_bn_train_fwd', ctypes.byref(p), hip.ptr(pack), hip.ptr(stats), c_int(rows), c_int(int(exact)), hip.ptr(gamma), hip.ptr(beta),
-             hip.ptr(running_mean), hip.ptr(running_var), c_float(momentum), c_float(eps), hip.stream())
-    return y, pack
+    hip.call('mg_bn_train_fwd', ctypes.byref(p), hip.ptr(stats_ws), c_int(int(zeroed)), hip.ptr(outs), hip.ptr(stats), c_int(rows), c_int(int(exact)),
+             hip.ptr(gamma), hip.ptr(beta), hip.ptr(running_mean), hip.ptr(running_var), c_float(momentum), c_float(eps), hip.stream())
+    return y, outs
 
 
-def bn_train_bwd(dy, y, x, pack, act, slope, want_dres=False, mask_x_pos=False):
-    """Training BatchNorm backward in ONE C call (reduce + apply): -> dx, dres, sums [2C] = dbeta | dgamma."""
+def bn_train_bwd(dy, y, x, outs, act, slope, want_dres=False, mask_x_pos=False, sums=None):
+    """Training BatchNorm backward in ONE C call (reduce + apply): -> dx, dres, sums [2C] = dbeta | dgamma.
+    `sums`: zeroed [2C] accumulator (None: allocated and zeroed here)."""
     M, C = x.shape[0], x.shape[-1]
-    o = 2 * STAT_REPLICAS * C
     p = _rowwise(x, M, C)
     p.dy, p.lddy = hip.ptr(dy), _ld(dy)
     p.y, p.ldy, p.yoff = hip.ptr(y), C, 0
-    base = pack.data_ptr() + 4 * o
+    base = outs.data_ptr()
     p.scale, p.mean, p.invstd = ctypes.c_void_p(base), ctypes.c_void_p(base + 8 * C), ctypes.c_void_p(base + 12 * C)
-    sums = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    zeroed = sums is not None
+    if sums is None:
+        sums = torch.empty(2 * C, dtype=torch.float32, device=x.device)
     p.sums, p.count = hip.ptr(sums), float(M)
     p.act, p.slope, p.mask_x_pos = act, slope, int(mask_x_pos)
     dx = torch.empty((M, C), dtype=x.dtype, device=x.device)
@@ -293,7 +299,7 @@ def bn_train_bwd(dy, y, x, pack, act, slope, want_dres=False, mask_x_pos=False):
     if want_dres:
         dres = torch.empty((M, C), dtype=x.dtype, device=x.device)
         p.dres, p.lddres = hip.ptr(dres), C
-    hip.call('mg_bn_train_bwd', ctypes.byref(p), hip.stream())
+    hip.call('mg_bn_train_bwd', ctypes.byref(p), c_int(int(zeroed)), hip.stream())
     return dx, dres, sums
 
 
