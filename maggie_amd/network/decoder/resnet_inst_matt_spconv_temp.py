@@ -50,18 +50,37 @@ class ResShortCut_InstMattSpconv_BiTempSpar_Dec(ResShortCut_InstMattSpconv_Dec):
         x = MF.conv2d(x, MF.weight_oihw_to_krsc(m[6].weight, dt, None, 8), None, 3, 3, 1, 1, 1)
         return MF.upsample_tanh(x, 1, 8, True, apply_tanh=False)
 
-    def bidirectional_fusion(self, feat, preds):
-        """feat (b, n_f, h, w, 64) NHWC (detached); preds (b, n_f, n_i, H, W) fp32."""
+    def frame_diffs(self, feat):
+        """The 2*(n_f-1) difference maps of bidirectional_fusion (:35-52), in the reference's call order (forward pairs, then
+        backward pairs -- BatchNorm running statistics and SpectralNorm iterations advance per call). They depend only on the
+        (detached) OS8 features, i.e. they are static-shape work: dense_stage() computes them so that they are part of the captured
+        trunk graphs. feat (b, n_f, h, w, C) NHWC -> (2*(n_f-1), b, 1, H, W) fp32 logits."""
         n_f = feat.shape[1]
+        pairs = [(i - 1, i) for i in range(1, n_f)] + [(i, i - 1) for i in range(n_f - 1, 0, -1)]
+        return torch.stack([self._diff(torch.cat([feat[:, a], feat[:, b]], dim=-1)) for a, b in pairs], 0)
+
+    def dense_stage(self, x, mid_fea, b, n_f, n_i, masks, gt_alphas, mem_feat=None):
+        out = super().dense_stage(x, mid_fea, b, n_f, n_i, masks, gt_alphas, mem_feat)
+        if n_f < 2:
+            return out
+        feat = out[1]
+        return tuple(out) + (self.frame_diffs(feat.view(b, n_f, *feat.shape[1:]).detach()),)
+
+    def bidirectional_fusion(self, feat, preds, diffs=None):
+        """feat (b, n_f, h, w, 64) NHWC (detached); preds (b, n_f, n_i, H, W) fp32; diffs: frame_diffs(feat) when the trunk already
+        computed them."""
+        n_f = feat.shape[1]
+        if diffs is None:
+            diffs = self.frame_diffs(feat)
         forward_diffs, backward_diffs = [], []
         forward_preds, backward_preds = [preds[:, 0]], [preds[:, n_f - 1]]
         for i in range(1, n_f):
-            diff = self._diff(torch.cat([feat[:, i - 1], feat[:, i]], dim=-1))
+            diff = diffs[i - 1]
             forward_diffs.append(diff)
             forward_preds.append(forward_preds[-1] * (1 - diff.sigmoid()) + preds[:, i] * diff.sigmoid())
         forward_diffs = torch.stack([torch.zeros_like(forward_diffs[0])] + forward_diffs, dim=1)
-        for i in range(n_f - 1, 0, -1):
-            diff = self._diff(torch.cat([feat[:, i], feat[:, i - 1]], dim=-1))
+        for j, i in enumerate(range(n_f - 1, 0, -1)):
+            diff = diffs[n_f - 1 + j]
             backward_diffs.append(diff)
             backward_preds.append(backward_preds[-1] * (1 - diff.sigmoid()) + preds[:, i - 1] * diff.sigmoid())
         backward_preds = backward_preds[::-1]
@@ -78,14 +97,15 @@ class ResShortCut_InstMattSpconv_BiTempSpar_Dec(ResShortCut_InstMattSpconv_Dec):
         return forward_diffs, backward_diffs, torch.stack(fuse_preds, dim=1)
 
     def dense_modules(self):
-        return super().dense_modules() + [self.os8_temp_module]
+        return super().dense_modules() + [self.os8_temp_module, self.diff_module]
 
     def _refine_os8(self, x, masks, gt_masks, n_f, mem_feat):
         prop = partial(self.os8_temp_module.propagate_features, n_f=n_f, prev_h_state=mem_feat, temp_method=self.temp_method)
         return self.refine_OS8(x, masks, use_mask_atten=False, gt_mask=gt_masks, aggregate_mem_fn=prop)
 
     def detail_stage(self, dense, image, b, n_f, n_i, iter, gt_alphas, mem_feat=None, spar_gt=None, **kwargs):
-        x_os8, x, queries, loss_max_atten, hidden_state, fea1, fea2, fea3 = dense
+        x_os8, x, queries, loss_max_atten, hidden_state, fea1, fea2, fea3 = dense[:8]
+        diffs = dense[8] if len(dense) > 8 else None
         h, w = image.shape[-2:]
         mem_feat = hidden_state
         feat_os8 = x.view(b, n_f, *x.shape[1:]).detach()
@@ -139,7 +159,7 @@ class ResShortCut_InstMattSpconv_BiTempSpar_Dec(ResShortCut_InstMattSpconv_Dec):
         ret['weight_os4'] = weight_os4
         ret['weight_os1'] = weight_os1
         temp_alpha = alpha_pred.view(b, n_f, *alpha_pred.shape[1:])
-        diff_forward, diff_backward, temp_fused_alpha = self.bidirectional_fusion(feat_os8, temp_alpha)
+        diff_forward, diff_backward, temp_fused_alpha = self.bidirectional_fusion(feat_os8, temp_alpha, diffs)
         if (not self.training and self.use_fusion) or self.training:
             ret['temp_alpha'] = temp_fused_alpha
             ret['diff_forward'] = diff_forward.sigmoid()

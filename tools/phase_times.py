@@ -8,10 +8,11 @@ from maggie_amd.utils import config, synth
 from maggie_amd import graphs as G
 it = int(sys.argv[sys.argv.index('--iter') + 1]) if '--iter' in sys.argv else 100
 dev = torch.device('cuda:0')
-model, _ = build_model(config.model_config('image'))
+VIDEO = '--video' in sys.argv
+model, _ = build_model(config.model_config('video' if VIDEO else 'image'))
 sd = model.state_dict(); synth.fill_state_dict_(sd, 1234); model.load_state_dict(sd)
 model.to(dev).train()
-batch = synth.synthetic_batch(4, 1, 2, 512, 512, seed=1234, train=True, it=it, max_inst=10)
+batch = synth.synthetic_batch(1 if VIDEO else 4, 3 if VIDEO else 1, 2, 512, 512, seed=1234, train=True, it=it, max_inst=10)
 batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
 np.random.seed(1); random.seed(1); torch.manual_seed(1)
 params = [p for p in model.parameters() if p.requires_grad]
