@@ -83,6 +83,40 @@ __global__ __launch_bounds__(256) void unpack_u8_kernel(const u64* __restrict__ 
     }
 }
 
+// ---- progressive refinement blend (maggie/network/decoder/resnet_inst_matt_spconv.py:272-290): alpha = a * w + b * (1 - w) with
+// w = the unknown-region bit plane, i.e. a per-pixel select. Reads the bit plane itself: no uint8/float weight tensor, one pass.
+__global__ __launch_bounds__(256) void select_kernel(const u64* __restrict__ bits, const float* __restrict__ a, const float* __restrict__ b,
+                                                     float* __restrict__ out, long nwords, int W, int Ww) {
+    const int lane = threadIdx.x & 63;
+    long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long stride = (long)gridDim.x * 4;
+    for (; w < nwords; w += stride) {
+        const long row = w / Ww; const int wj = (int)(w - row * Ww);
+        const int x = wj * 64 + lane;
+        if (x < W) {
+            const long i = row * W + x;
+            out[i] = ((bits[w] >> lane) & 1ull) ? a[i] : b[i];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void select_bwd_kernel(const u64* __restrict__ bits, const float* __restrict__ dy, float* __restrict__ da,
+                                                         float* __restrict__ db, long nwords, int W, int Ww) {
+    const int lane = threadIdx.x & 63;
+    long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long stride = (long)gridDim.x * 4;
+    for (; w < nwords; w += stride) {
+        const long row = w / Ww; const int wj = (int)(w - row * Ww);
+        const int x = wj * 64 + lane;
+        if (x < W) {
+            const long i = row * W + x;
+            const bool on = (bits[w] >> lane) & 1ull;
+            const float g = dy[i];
+            if (da) da[i] = on ? g : 0.f;
+            if (db) db[i] = on ? 0.f : g;
+        }
+    }
+}
+
 // ---- dilation ----------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ u64 span_or(u64 prev, u64 cur, u64 next, int lo, int hi) {
     // out bit j = OR_{t=lo..hi} src(x0 + j + t);  U bit i <-> pixel x0 - 32 + i
@@ -275,6 +309,24 @@ extern "C" int mg_bits_unpack_u8(const void* bits, uint8_t* out, int P, int H, i
     long nwords = (long)P * H * Ww;
     if (nwords <= 0) return 0;
     hipLaunchKernelGGL(unpack_u8_kernel, dim3(grid_for(nwords, 4)), dim3(256), 0, (hipStream_t)stream, (const u64*)bits, out, nwords, W, Ww);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_bits_select(const void* bits, const float* a, const float* b, float* out, int P, int H, int W, void* stream) {
+    const int Ww = (W + 63) / 64;
+    const long nwords = (long)P * H * Ww;
+    if (nwords <= 0) return 0;
+    hipLaunchKernelGGL(select_kernel, dim3(grid_for(nwords, 4)), dim3(256), 0, (hipStream_t)stream, (const u64*)bits, a, b, out, nwords, W, Ww);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_bits_select_bwd(const void* bits, const float* dy, float* da, float* db, int P, int H, int W, void* stream) {
+    const int Ww = (W + 63) / 64;
+    const long nwords = (long)P * H * Ww;
+    if (nwords <= 0) return 0;
+    hipLaunchKernelGGL(select_bwd_kernel, dim3(grid_for(nwords, 4)), dim3(256), 0, (hipStream_t)stream, (const u64*)bits, dy, da, db, nwords, W, Ww);
     MG_CHECK_LAUNCH();
     return 0;
 }

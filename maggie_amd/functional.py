@@ -684,6 +684,27 @@ def gather_conv(x, w, nbr, nbr_t, reverse_taps, ksize=3, bias=None, stats=None, 
     return GatherConv.apply(x, w, bias, nbr, nbr_t, reverse_taps, ksize, stats, act)
 
 
+class BitsSelect(torch.autograd.Function):
+    """out = a where the bit plane is set, b elsewhere (the blend a*w + b*(1-w) of `fuse` for a 0/1 weight plane), fp32 planes."""
+
+    @staticmethod
+    def forward(ctx, bits, a, b, W):
+        a, b = a.float().contiguous(), b.float().contiguous()
+        ctx.save_for_backward(bits)
+        ctx.W = W
+        return K.bits_select(bits, a, b, W)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (bits,) = ctx.saved_tensors
+        da, db = K.bits_select_bwd(bits, dy.contiguous(), ctx.W, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        return None, da, db, None
+
+
+def bits_select(bits, a, b, W):
+    return BitsSelect.apply(bits, a, b, W)
+
+
 class GatherRows(torch.autograd.Function):
     """rows[r] = dense[frame(r), y, x] (* tokens[frame, inst]).  `bits`/`wordoff`: the level's bit planes and ranks (used by the
     atomic-free backward)."""

@@ -339,6 +339,23 @@ def bits_pack(a, mode=0, lo=LOWER_THRES, hi=UPPER_THRES):
     return bits
 
 
+def bits_select(bits, a, b, W):
+    """out = bit ? a : b over fp32 planes shaped like a (numel = P*H*W of the bit planes)."""
+    P, H, Ww = bits.shape
+    hip.need_cuda(bits, a, b)
+    out = torch.empty_like(a)
+    hip.call('mg_bits_select', hip.ptr(bits), hip.ptr(a), hip.ptr(b), hip.ptr(out), c_int(P), c_int(H), c_int(W), hip.stream())
+    return out
+
+
+def bits_select_bwd(bits, dy, W, want_a=True, want_b=True):
+    P, H, Ww = bits.shape
+    da = torch.empty_like(dy) if want_a else None
+    db = torch.empty_like(dy) if want_b else None
+    hip.call('mg_bits_select_bwd', hip.ptr(bits), hip.ptr(dy), hip.ptr(da), hip.ptr(db), c_int(P), c_int(H), c_int(W), hip.stream())
+    return da, db
+
+
 def bits_unpack_u8(bits, W, shape=None):
     P, H, Ww = bits.shape
     out = torch.empty((P, H, W), dtype=torch.uint8, device=bits.device)

@@ -257,10 +257,13 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
         a1, a4, a8 = pred['alpha_os1'], pred['alpha_os4'], pred['alpha_os8']
         H, W = a8.shape[-2:]
         alpha = a8
-        w4 = K.bits_unpack_u8(MF.unknown_bits(alpha, 27, self.training, andmask=detail_bits), W, a8.shape).to(alpha.dtype)
-        alpha = a4.type(alpha.dtype) * w4 + alpha * (1 - w4)
-        w1 = K.bits_unpack_u8(MF.unknown_bits(alpha, 15, self.training, andmask=detail_bits), W, a8.shape).to(alpha.dtype)
-        alpha = a1.type(alpha.dtype) * w1 + alpha * (1 - w1)
+        # a*w + alpha*(1-w) with a 0/1 weight plane is a per-pixel select: done straight from the bit planes (one pass each way)
+        bits4 = MF.unknown_bits(alpha, 27, self.training, andmask=detail_bits)
+        alpha = MF.bits_select(bits4, a4, alpha, W)
+        bits1 = MF.unknown_bits(alpha, 15, self.training, andmask=detail_bits)
+        alpha = MF.bits_select(bits1, a1, alpha, W)
+        w4 = K.bits_unpack_u8(bits4, W, a8.shape).to(alpha.dtype)
+        w1 = K.bits_unpack_u8(bits1, W, a8.shape).to(alpha.dtype)
         return alpha, w4, w1
 
     def os32_to_os8(self, x, mid_fea, b, n_f, n_i, masks, gt_alphas):

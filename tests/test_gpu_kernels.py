@@ -684,3 +684,26 @@ def test_batch_norm_act_one_call_path_matches_torch(dtype, M, with_res, act):
         assert (rd.grad.float().cpu() - res.grad).abs().max() <= tol * res.grad.abs().max() + 1e-6
     for got, ref in ((bn.bias.grad, bn_ref.bias.grad), (bn.weight.grad, bn_ref.weight.grad)):
         assert torch.allclose(got.cpu(), ref, rtol=2e-2, atol=2e-2 * ref.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_bits_select_is_the_fuse_blend():
+    """mg_bits_select{,_bwd}: out = a*w + b*(1-w) for the 0/1 weight plane a bit plane encodes (fuse(),
+    maggie/network/decoder/resnet_inst_matt_spconv.py:272-290), forward and both gradients, bit-exact; ragged width (W % 64 != 0)."""
+    from maggie_amd import functional as MF, kernels as K
+    dev = _dev()
+    torch.manual_seed(2)
+    for P, H, W in ((6, 40, 200), (3, 17, 64), (2, 9, 70)):
+        a = torch.randn(P, H, W, device=dev, requires_grad=True)
+        b = torch.randn(P, H, W, device=dev, requires_grad=True)
+        w8 = (torch.rand(P, H, W, device=dev) < 0.4).to(torch.uint8)
+        bits = K.bits_pack(w8, mode=1)
+        assert torch.equal(K.bits_unpack_u8(bits, W), w8)
+        w = w8.float()
+        ref = a * w + b * (1 - w)
+        out = MF.bits_select(bits, a, b, W)
+        assert torch.equal(out, ref)
+        g = torch.randn_like(ref)
+        ga, gb = torch.autograd.grad(out, (a, b), g)
+        ra, rb = torch.autograd.grad(ref, (a, b), g)
+        assert torch.equal(ga, ra) and torch.equal(gb, rb)
