@@ -42,6 +42,24 @@ __global__ __launch_bounds__(NT) void plane_flags_kernel(const float* __restrict
     if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(&flags[p], 1);
 }
 
+// loss weight of the OS8 prediction (maggie/network/arch/maggie.py:271-281): w = [plane has ground truth] + [pixel is in the unknown band
+// (1/255 <= v <= 254/255) of the ground truth or of the prediction]; ~12 elementwise passes over the planes in the torch formulation
+__global__ __launch_bounds__(NT) void os8_weight_kernel(const float* __restrict__ gt, const float* __restrict__ a8, const int* __restrict__ flags,
+                                                        long HW, int reweight, float* __restrict__ out) {
+    const int p = blockIdx.y;
+    const float valid = flags[p] ? 1.f : 0.f;
+    const long base = (long)p * HW;
+    const float lo = 1.0f / 255.0f, hi = 254.0f / 255.0f;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < HW; i += (long)gridDim.x * NT) {
+        float w = valid;
+        if (reweight) {
+            const float g = gt[base + i], a = a8[base + i];
+            if ((g <= hi && g >= lo) || (a <= hi && a >= lo)) w += 1.f;
+        }
+        out[base + i] = w;
+    }
+}
+
 __device__ __forceinline__ float sobel_mag(const float* __restrict__ a, const float* __restrict__ w, int y, int x, int H, int W, float& gx,
                                            float& gy) {
     float v[3][3];
@@ -339,6 +357,16 @@ extern "C" int mg_plane_flags(const float* w, int P, int HW, int32_t* flags, voi
     dim3 g = grid2(HW, P);
     if (g.x > 64) g.x = 64;
     hipLaunchKernelGGL(plane_flags_kernel, g, dim3(NT), 0, st, w, HW, flags);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_os8_weight(const float* gt, const float* a8, int P, long HW, int reweight, int32_t* flags_scratch, float* out, void* stream) {
+    if (P <= 0 || HW <= 0) return 0;
+    int rc = mg_plane_flags(gt, P, (int)HW, flags_scratch, stream);
+    if (rc) return rc;
+    dim3 g = grid2(HW, P);
+    hipLaunchKernelGGL(os8_weight_kernel, g, dim3(NT), 0, (hipStream_t)stream, gt, a8, (const int*)flags_scratch, HW, reweight, out);
     MG_CHECK_LAUNCH();
     return 0;
 }

@@ -920,6 +920,18 @@ class MattingLosses(torch.autograd.Function):
         return dp.view(ctx.shape), None, None
 
 
+def os8_weight(alphas, a8, reweight=True):
+    """Loss weight of the OS8 prediction (arch/maggie.py:271-281): [plane has ground truth] + [pixel in the unknown band of gt or a8]."""
+    gt, a = alphas.detach().contiguous(), a8.detach().contiguous()
+    H, W_ = gt.shape[-2:]
+    P = gt.numel() // (H * W_)
+    out = torch.empty_like(a)
+    flags = torch.empty(P, dtype=torch.int32, device=gt.device)
+    K.hip.call('mg_os8_weight', K.hip.ptr(gt), K.hip.ptr(a), K.c_int(P), K.c_long(H * W_), K.c_int(int(bool(reweight))), K.hip.ptr(flags),
+               K.hip.ptr(out), K.hip.stream())
+    return out
+
+
 def matting_losses(pred, target, weight):
     """-> (rec, lap, grad) scalars."""
     out = MattingLosses.apply(pred, target, weight.expand_as(pred) if weight.shape != pred.shape else weight)

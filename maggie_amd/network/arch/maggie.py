@@ -316,13 +316,16 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
     def compute_loss(self, pred, weight_os4, weight_os1, alphas, trans_gt, alpha_shape, reweight_os8=True):
         a1, a4, a8 = pred.get('alpha_os1', None), pred.get('alpha_os4', None), pred['alpha_os8']
         loss_dict = {}
-        weight_os8 = torch.ones_like(a8)
-        valid_mask = alphas.sum((2, 3), keepdim=True) > 0
-        weight_os8 = weight_os8 * valid_mask
-        if reweight_os8:
-            unknown_gt = (alphas <= 254.0 / 255.0) & (alphas >= 1.0 / 255.0)
-            unknown_pred_os8 = (a8 <= 254.0 / 255.0) & (a8 >= 1.0 / 255.0)
-            weight_os8 = (unknown_gt | unknown_pred_os8).type(weight_os8.dtype) + weight_os8
+        if alphas.shape == a8.shape and alphas.dtype == torch.float32 and a8.dtype == torch.float32 and alphas.is_cuda:
+            weight_os8 = MF.os8_weight(alphas, a8, reweight_os8)             # the statements below in one pass (mg_os8_weight)
+        else:
+            weight_os8 = torch.ones_like(a8)
+            valid_mask = alphas.sum((2, 3), keepdim=True) > 0
+            weight_os8 = weight_os8 * valid_mask
+            if reweight_os8:
+                unknown_gt = (alphas <= 254.0 / 255.0) & (alphas >= 1.0 / 255.0)
+                unknown_pred_os8 = (a8 <= 254.0 / 255.0) & (a8 >= 1.0 / 255.0)
+                weight_os8 = (unknown_gt | unknown_pred_os8).type(weight_os8.dtype) + weight_os8
         n_i = alphas.shape[1]
         if self.num_masks - n_i > 0:
             padding = torch.zeros((alphas.shape[0], self.num_masks - n_i, *alphas.shape[-2:]), device=alphas.device)

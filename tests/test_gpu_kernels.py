@@ -707,3 +707,25 @@ def test_bits_select_is_the_fuse_blend():
         ga, gb = torch.autograd.grad(out, (a, b), g)
         ra, rb = torch.autograd.grad(ref, (a, b), g)
         assert torch.equal(ga, ra) and torch.equal(gb, rb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('reweight', [True, False])
+def test_os8_weight_matches_reference_statements(reweight):
+    """mg_os8_weight == the weight_os8 statements of compute_loss (maggie/network/arch/maggie.py:271-281), bit-exact, incl. an empty plane
+    and values exactly on the 1/255 and 254/255 thresholds."""
+    from maggie_amd import functional as MF
+    dev = _dev()
+    torch.manual_seed(4)
+    alphas = torch.rand(3, 10, 64, 72, device=dev)
+    alphas[alphas < 0.3] = 0
+    alphas[alphas > 0.8] = 1
+    alphas[:, 4] = 0                                              # an empty instance slot
+    alphas[0, 0, 0, :4] = torch.tensor([1 / 255.0, 254 / 255.0, 0.0039, 0.9962], device=dev)
+    a8 = torch.rand(3, 10, 64, 72, device=dev)
+    a8[a8 < 0.2] = 0
+    a8[0, 1, 0, :2] = torch.tensor([1 / 255.0, 254 / 255.0], device=dev)
+    w = torch.ones_like(a8) * (alphas.sum((2, 3), keepdim=True) > 0)
+    if reweight:
+        w = (((alphas <= 254.0 / 255.0) & (alphas >= 1.0 / 255.0)) | ((a8 <= 254.0 / 255.0) & (a8 >= 1.0 / 255.0))).type(w.dtype) + w
+    assert torch.equal(MF.os8_weight(alphas, a8, reweight), w)
