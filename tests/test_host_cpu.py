@@ -250,3 +250,29 @@ def _write(tmp_path, sd):
     path = str(tmp_path / 'odd.pth')
     torch.save(sd, path)
     return path
+
+
+def test_video_window_matches_reference_bookkeeping():
+    """maggie_amd.utils.video_window.VideoWindow == the window bookkeeping of eval_video (maggie/engine/test.py:237-286, restated in
+    oracle/video_window.py) over a 5-clip video, a 1-clip video (first and last at once) and a second video after a reset."""
+    import numpy as np
+    import torch
+    from maggie_amd.utils.video_window import VideoWindow
+    from oracle.video_window import Window
+    rs = np.random.RandomState(0)
+    ours, ref = VideoWindow(), Window()
+    for n_clips in (5, 1, 2):
+        for c in range(n_clips):
+            a, g, t = (rs.rand(1, 3, 2, 6, 5).astype(np.float32) for _ in range(3))
+            names = ['v/f%02d.jpg' % (c + k) for k in range(3)]
+            first, last = c == 0, c == n_clips - 1
+            o = ours.push(torch.from_numpy(a), torch.from_numpy(g), torch.from_numpy(t), names, first, last)
+            r = ref.push(a, g, t, names, first, last)
+            assert o['save'][0] == r['save'][0] and np.array_equal(o['save'][1].numpy(), r['save'][1])
+            for key in ('current', 'previous'):
+                if r[key] is None:
+                    assert o[key] is None
+                    continue
+                for x, y in zip(o[key], r[key]):
+                    assert x.shape == y.shape and np.array_equal(x.numpy(), y), (n_clips, c, key)
+        assert ours.preds.shape[0] <= 3
