@@ -270,7 +270,9 @@ typedef struct mg_sn_desc {
     int64_t out_off;     /* element offset of this conv's (Cout, taps, pad_in) block in the output    */
     int64_t work_off;    /* float offset of this conv's [v (B*taps) | u (A) | scratch (4)] block      */
     int64_t dw_off;      /* float offset of this conv's gradient block (backward)                     */
-    int32_t A, B, taps, transposed, pad_in, reserved;
+    int32_t A, B, taps, transposed, pad_in;
+    int32_t plain;       /* != 0: an ordinary (not spectrally normalised) conv weight: converted / transposed with sigma = 1, u and v unused;
+                            its gradient comes back unchanged in the parameter's layout                      */
 } mg_sn_desc;
 int mg_spectral_norm_batched(const mg_sn_desc* descs, int n_conv, const int32_t* items_k1, int n1, const int32_t* items_k2, int n2,
                              const int32_t* items_k3, int n3, float* work_base, long work_floats, void* out_base, void* out_t_base,

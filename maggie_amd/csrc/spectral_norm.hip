@@ -229,10 +229,13 @@ __global__ __launch_bounds__(NT) void snb_finish_kernel(const mg_sn_desc* __rest
     const mg_sn_desc d = descs[it.x];
     const int Wd = d.B * d.taps;
     const float* scratch = work_base + d.work_off + Wd + d.A;
-    const float nt = sqrtf(scratch[0]);
-    const float sv = 1.f / (nt + SN_EPS);
-    const float ns = sqrtf(scratch[1]) * sv;
-    const float sigma = ns * ns / (ns + SN_EPS);
+    float sigma = 1.f;                                       // d.plain: an ordinary conv weight riding along for the layout conversion only
+    if (!d.plain) {
+        const float nt = sqrtf(scratch[0]);
+        const float sv = 1.f / (nt + SN_EPS);
+        const float ns = sqrtf(scratch[1]) * sv;
+        sigma = ns * ns / (ns + SN_EPS);
+    }
     const SnTile t = sn_tile(d, it);
     sn_load_param_tile(d, t, 1.f / sigma, sT);
     __syncthreads();
@@ -277,6 +280,7 @@ __global__ __launch_bounds__(NT) void snb_vectors_kernel(const mg_sn_desc* __res
     const int c = blockIdx.x;
     if (c >= n) return;
     const mg_sn_desc d = descs[c];
+    if (d.plain) return;
     const int Wd = d.B * d.taps;
     float* t = work_base + d.work_off;
     float* s = t + Wd;
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(NT) void snb_bwd_dot_kernel(const mg_sn_desc* __res
     const int4 it = items[blockIdx.x];                       // (conv, a tile, b tile, -)
     const mg_sn_desc d = descs[it.x];
     const T* G = (const T*)Gptrs[it.x];
-    if (!G) return;
+    if (!G || d.plain) return;
     const SnTile t = sn_tile(d, it);
     sn_load_grad_tile<T>(d, t, G, sT);
     __syncthreads();
@@ -357,6 +361,13 @@ __global__ __launch_bounds__(NT) void snb_bwd_apply_kernel(const mg_sn_desc* __r
     }
     sn_load_grad_tile<T>(d, t, G, sT);
     __syncthreads();
+    if (d.plain) {                                           // plain conv: the gradient itself, back in the parameter's layout
+        for (int i = threadIdx.x; i < t.na * run; i += NT) {
+            const int al = i / run, r = i - al * run;
+            dW[((long)(t.a0 + al) * d.B + t.b0) * d.taps + r] = sT[al * SN_PITCH + r];
+        }
+        return;
+    }
     const float inv_sigma = 1.f / scratch[3];
     const float coef = scratch[2] * inv_sigma * inv_sigma;
     for (int i = threadIdx.x; i < t.na * run; i += NT) {

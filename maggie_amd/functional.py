@@ -32,7 +32,10 @@ class ZeroArena:
         self.cap_buf = None
         self.cap_off = 0
 
+    epoch = 0                                                     # bumped once per model forward: stamps per-step prepared weights
+
     def reset(self, device):
+        self.epoch += 1
         self.need = max(self.need, self.used + (1 << 16))
         if self.buf is None or self.buf.device != device or self.buf.numel() < self.need:
             self.buf = torch.zeros(self.need, dtype=torch.float32, device=device)
@@ -272,6 +275,15 @@ def spectral_norm_weight(w_bar, u, v, transposed, dtype, pad_in):
     return SpectralNormWeight.apply(w_bar, u.data, v.data, transposed, dtype, pad_in)
 
 
+def _weight_source(m):
+    """(W, u, v, transposed, in_channels, plain) of one entry of the batched weight pipeline: a SpectralNorm wrapper, or an ordinary
+    conv holder (nn.Conv2d-like: OIHW `weight`, `in_channels`) that rides along for the layout / dtype conversion only."""
+    inner = getattr(m, 'module', None)
+    if inner is not None and hasattr(inner, 'weight_bar'):
+        return inner.weight_bar, inner.weight_u, inner.weight_v, int(inner.transposed), inner.in_channels, 0
+    return m.weight, None, None, 0, m.in_channels, 1
+
+
 class SpectralNormPlan:
     """Descriptor table + work lists for the batched SpectralNorm kernels (built once per model / dtype / device)."""
 
@@ -280,35 +292,35 @@ class SpectralNormPlan:
         import numpy as np
         self.modules = modules
         self.dtype = dtype
-        dev = modules[0].module.weight_bar.device
+        self.sources = [_weight_source(m) for m in modules]
+        dev = self.sources[0][0].device
         n = len(modules)
         descs = (K.hip.SnDesc * n)()
         out_off = work_off = dw_off = 0
         k1, k2, k3 = [], [], []
         self.shapes, self.out_slices, self.dw_slices = [], [], []
-        for c, m in enumerate(modules):
-            w = m.module.weight_bar
+        for c, (w, u, v, transposed, cin, plain) in enumerate(self.sources):
             A, B, kh, kw = w.shape
             taps = kh * kw
             if taps > 16:
                 raise K.hip.MaggieHipError(f'batched SpectralNorm tiles hold up to 16 taps (SN_MAXTAPS), got a {kh}x{kw} kernel')
-            transposed = int(m.module.transposed)
-            pad_in = pad8(m.module.in_channels)
+            pad_in = pad8(cin)
             cout = B if transposed else A
             d = descs[c]
-            d.W, d.u, d.v = w.data_ptr(), m.module.weight_u.data_ptr(), m.module.weight_v.data_ptr()
+            d.W, d.u, d.v = w.data_ptr(), (None if plain else u.data_ptr()), (None if plain else v.data_ptr())
             d.out_off, d.work_off, d.dw_off = out_off, work_off, dw_off
-            d.A, d.B, d.taps, d.transposed, d.pad_in = A, B, taps, transposed, pad_in
+            d.A, d.B, d.taps, d.transposed, d.pad_in, d.plain = A, B, taps, transposed, pad_in, plain
             Wd = B * taps
             n_out = cout * taps * pad_in
             self.shapes.append((cout, taps, pad_in, tuple(w.shape)))
             self.out_slices.append((out_off, n_out))
             self.dw_slices.append((dw_off, w.numel()))
-            for cb in range((Wd + 255) // 256):
-                for rb in range((A + 31) // 32):
-                    k1.append((c, cb, rb, 0))
-            for rg in range((A + 3) // 4):
-                k2.append((c, rg, 0, 0))
+            if not plain:                                         # power iteration work items
+                for cb in range((Wd + 255) // 256):
+                    for rb in range((A + 31) // 32):
+                        k1.append((c, cb, rb, 0))
+                for rg in range((A + 3) // 4):
+                    k2.append((c, rg, 0, 0))
             for at in range((A + 15) // 16):                      # (SN_TA x SN_TB) parameter tiles, csrc/spectral_norm.hip
                 for bt in range((B + 31) // 32):
                     k3.append((c, at, bt, 0))
@@ -323,7 +335,7 @@ class SpectralNormPlan:
         self.ptr_key = self._ptrs()
 
     def _ptrs(self):
-        return tuple((m.module.weight_bar.data_ptr(), m.module.weight_u.data_ptr(), m.module.weight_v.data_ptr()) for m in self.modules)
+        return tuple((w.data_ptr(), 0 if u is None else u.data_ptr(), 0 if v is None else v.data_ptr()) for w, u, v, *_ in self.sources)
 
     def valid(self, dtype):
         return dtype == self.dtype and self._ptrs() == self.ptr_key
@@ -350,8 +362,8 @@ class SpectralNormBatch(torch.autograd.Function):
             t_._mg_side_wgrad = True                              # every dW of these weights meets again in backward() below: the join point
         if out_t is not None:
             # (Cin_pad, taps, Cout) twins for the data-gradient convolution ride along as a Python attribute of each weight
-            for t_, (o, n), sh, m in zip(outs, plan.out_slices, plan.shapes, plan.modules):
-                if not m.module.transposed:
+            for t_, (o, n), sh, src in zip(outs, plan.out_slices, plan.shapes, plan.sources):
+                if not src[3]:
                     t_._mg_wt = out_t[o:o + n].view(sh[2], sh[1], sh[0])
         return outs
 
@@ -389,9 +401,20 @@ def spectral_norm_prepare(modules, dtype, cache):
     if plan is None or not plan.valid(dtype):
         plan = SpectralNormPlan(modules, dtype)
         cache['plan'] = plan
-    outs = SpectralNormBatch.apply(plan, *[m.module.weight_bar for m in modules])
+    outs = SpectralNormBatch.apply(plan, *[src[0] for src in plan.sources])
     for m, o in zip(modules, outs):
-        m._prepared = o
+        m.__dict__['_prepared'] = o
+        m.__dict__['_prepared_epoch'] = ARENA.epoch
+
+
+def plain_krsc(conv, dtype, keep=False):
+    """(Cout, taps, Cin_pad) weight of an ordinary conv holder: the tensor the batched weight pipeline prepared for this step (with its
+    dgrad twin attached) when there is one, else converted here. keep=True leaves it in place for further calls of the same step
+    (ConvGRU cells)."""
+    w = conv.__dict__.get('_prepared') if keep else conv.__dict__.pop('_prepared', None)
+    if w is not None and conv.__dict__.get('_prepared_epoch') == ARENA.epoch and w.dtype == dtype and w.shape[-1] == pad8(conv.in_channels):
+        return w
+    return weight_oihw_to_krsc(conv.weight, dtype)
 
 
 def pad_vec(v, n):

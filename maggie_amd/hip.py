@@ -152,4 +152,4 @@ class WbEntry(ctypes.Structure):
 class SnDesc(ctypes.Structure):
     _fields_ = [('W', ctypes.c_void_p), ('u', ctypes.c_void_p), ('v', ctypes.c_void_p), ('out_off', ctypes.c_int64),
                 ('work_off', ctypes.c_int64), ('dw_off', ctypes.c_int64), ('A', ctypes.c_int32), ('B', ctypes.c_int32),
-                ('taps', ctypes.c_int32), ('transposed', ctypes.c_int32), ('pad_in', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+                ('taps', ctypes.c_int32), ('transposed', ctypes.c_int32), ('pad_in', ctypes.c_int32), ('plain', ctypes.c_int32)]

@@ -57,7 +57,9 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             trunk_roots = [self.encoder, self.aspp] + list(self.decoder.dense_modules())
             trunk_ids = {id(m) for r in trunk_roots for m in r.modules() if isinstance(m, SpectralNorm)}
             allm = [m for m in self.modules() if isinstance(m, SpectralNorm)]
-            groups = {'all': allm, 'trunk': [m for m in allm if id(m) in trunk_ids],
+            # ordinary conv holders of the trunk ride along in the same batched kernels (layout / dtype conversion only)
+            plain = list(self.aspp.plain_convs()) + list(self.decoder.plain_trunk_convs())
+            groups = {'all': allm + plain, 'trunk': [m for m in allm if id(m) in trunk_ids] + plain,
                       'detail': [m for m in allm if id(m) not in trunk_ids]}
             self.__dict__['_sn_groups_cache'] = groups
             self.__dict__['_sn_cache'] = {k: {} for k in groups}

@@ -350,6 +350,10 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
         """Sub-modules whose parameters are touched by dense_stage only."""
         return [self.layer1, self.layer2, self.refine_OS8]
 
+    def plain_trunk_convs(self):
+        """Ordinary (not spectrally normalised) conv holders of the dense stage, converted with the batched weight pipeline."""
+        return self.refine_OS8.plain_convs()
+
     def _refine_os8(self, x, masks, gt_masks, n_f, mem_feat):
         return self.refine_OS8(x, masks, use_mask_atten=False, gt_mask=gt_masks)
 

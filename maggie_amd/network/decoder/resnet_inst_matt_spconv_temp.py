@@ -99,6 +99,9 @@ class ResShortCut_InstMattSpconv_BiTempSpar_Dec(ResShortCut_InstMattSpconv_Dec):
     def dense_modules(self):
         return super().dense_modules() + [self.os8_temp_module, self.diff_module]
 
+    def plain_trunk_convs(self):
+        return super().plain_trunk_convs() + self.os8_temp_module.plain_convs()
+
     def _refine_os8(self, x, masks, gt_masks, n_f, mem_feat):
         prop = partial(self.os8_temp_module.propagate_features, n_f=n_f, prev_h_state=mem_feat, temp_method=self.temp_method)
         return self.refine_OS8(x, masks, use_mask_atten=False, gt_mask=gt_masks, aggregate_mem_fn=prop)

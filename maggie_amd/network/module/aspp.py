@@ -21,18 +21,22 @@ class ASPP(nn.Module):
         self.conv2 = ConvWeight(mid * 5, out_channel, 1, 1, 0, 1)
         self.bn2 = norm(out_channel)
 
+    def plain_convs(self):
+        """Conv holders whose per-step layout / dtype conversion rides on the batched weight pipeline (functional.plain_krsc)."""
+        return [self.aspp1, self.aspp2, self.aspp3, self.aspp4, self.aspp5, self.conv2]
+
     def forward(self, x):
         """x: (N, H, W, 512) NHWC."""
         dt = x.dtype
         outs = []
         for conv, bn in ((self.aspp1, self.aspp1_bn), (self.aspp2, self.aspp2_bn), (self.aspp3, self.aspp3_bn), (self.aspp4, self.aspp4_bn)):
-            w = MF.weight_oihw_to_krsc(conv.weight, dt)
+            w = MF.plain_krsc(conv, dt)
             outs.append(MF.conv_bn_act(x, w, bn, MF.ACT_RELU, conv.kernel_size, conv.kernel_size, 1, conv.padding, conv.dilation))
         N, H, W_, C = x.shape
         pooled = x.float().mean((1, 2), keepdim=True).to(dt)                       # AdaptiveAvgPool2d(1)
-        w5 = MF.weight_oihw_to_krsc(self.aspp5.weight, dt)
+        w5 = MF.plain_krsc(self.aspp5, dt)
         x5 = MF.conv_bn_act(pooled, w5, self.aspp5_bn, MF.ACT_RELU, 1, 1, 1, 0, 1)
         outs.append(x5.expand(N, H, W_, x5.shape[-1]))                             # nearest upsample of a 1x1 map
         y = torch.cat(outs, -1)
-        w2 = MF.weight_oihw_to_krsc(self.conv2.weight, dt)
+        w2 = MF.plain_krsc(self.conv2, dt)
         return MF.conv_bn_act(y, w2, self.bn2, MF.ACT_RELU, 1, 1, 1, 0, 1)

@@ -22,8 +22,11 @@ class ConvGRU(nn.Module):
     @staticmethod
     def _gate_conv(seq, inp):
         conv = seq[0]
-        return MF.conv2d(inp, MF.weight_oihw_to_krsc(conv.weight, inp.dtype), conv.bias.float(), conv.kernel_size, conv.kernel_size, 1,
-                         conv.padding, conv.dilation)
+        return MF.conv2d(inp, MF.plain_krsc(conv, inp.dtype, keep=True), conv.bias.float(), conv.kernel_size, conv.kernel_size, 1,
+                         conv.padding, conv.dilation)                    # keep: one cell per frame and direction, same weights
+
+    def plain_convs(self):
+        return [self.ih[0], self.hh[0]]
 
     def cell(self, x, h):
         rz = self._gate_conv(self.ih, torch.cat((x, h), -1))             # pre-activation [r | z]

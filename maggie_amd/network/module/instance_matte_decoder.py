@@ -62,8 +62,11 @@ class InstanceMatteDecoder(nn.Module):
 
     def _smooth(self, x):
         c0, bn0, _, c1, bn1, _ = self.conv
-        x = MF.conv_bn_act(x, MF.weight_oihw_to_krsc(c0.weight, x.dtype), bn0, MF.ACT_LRELU, 3, 3, 1, 1, 1)
-        return MF.conv_bn_act(x, MF.weight_oihw_to_krsc(c1.weight, x.dtype), bn1, MF.ACT_LRELU, 1, 1, 1, 0, 1)
+        x = MF.conv_bn_act(x, MF.plain_krsc(c0, x.dtype, keep=True), bn0, MF.ACT_LRELU, 3, 3, 1, 1, 1)    # keep: applied twice per video forward
+        return MF.conv_bn_act(x, MF.plain_krsc(c1, x.dtype, keep=True), bn1, MF.ACT_LRELU, 1, 1, 1, 0, 1)
+
+    def plain_convs(self):
+        return [self.conv[0], self.conv[3]]
 
     def forward(self, ori_feat, mask, use_mask_atten=False, gt_mask=None, aggregate_mem_fn=None):
         assert not use_mask_atten
