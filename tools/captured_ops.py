@@ -13,10 +13,12 @@ batch = synth.synthetic_batch(4, 1, 2, 512, 512, seed=1234, train=True, it=100, 
 batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
 np.random.seed(1); random.seed(1); torch.manual_seed(1)
 agg = collections.Counter()
+ALL = '--all' in sys.argv
+VIEWS = ('view', 'reshape', 'expand', 'permute', 'transpose', 'slice', 'select', 'unsqueeze', 'squeeze', 't.default', 'detach', 'alias', 'as_strided', 'unbind', 'split', 'empty', 'size', 'stride', 'is_', 'sym_', '_unsafe', 'lift', 'unfold', 'narrow', 'chunk', 'flatten')
 class Spy(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = str(func).replace('aten.', '')
-        if torch.cuda.is_current_stream_capturing() and any(w in name for w in ('clone', 'copy_', 'contiguous', 'fill_', 'zeros', 'zero_', 'add.Tensor', 'add_.Tensor', 'sum')):
+        if torch.cuda.is_current_stream_capturing() and (ALL or any(w in name for w in ('clone', 'copy_', 'contiguous', 'fill_', 'zeros', 'zero_', 'add.Tensor', 'add_.Tensor', 'sum'))) and not any(v in name for v in VIEWS):
             frame = 'autograd/other'
             for fs in reversed(traceback.extract_stack(limit=30)):
                 if 'maggie_amd' in fs.filename and not fs.filename.endswith('hip.py'):
@@ -34,5 +36,13 @@ torch.autograd.set_multithreading_enabled(False)
 step()
 with Spy():
     step()
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:60]:
-    print(v, k)
+if ALL:
+    by = collections.Counter()
+    for (name, dts, frame, contig), v in agg.items():
+        by[(name, frame.split(':')[0])] += v
+    print('kernel-launching aten ops inside the captured graphs:', sum(by.values()))
+    for k, v in by.most_common(45):
+        print(v, k)
+else:
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:60]:
+        print(v, k)
