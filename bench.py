@@ -141,7 +141,7 @@ def main():
             host_t.append([1e3 * (t[i + 1] - t[i]) for i in range(3)])
         stats['active_px'] = out['detail_mask']
         stats['loss'] = loss['total']
-        stats.setdefault('active_hist', []).append(out['detail_mask'].float().mean() * 5.0)      # 2 of 10 slots are real
+        stats.setdefault('active_hist', []).append(out['detail_mask'].sum())           # one reduction launch; normalised when reported
 
     def sync():
         torch.cuda.synchronize()
@@ -257,7 +257,7 @@ def main():
                                    'fwd+loss+bwd+clip+AdamW' % (kind, args.size, args.size, args.instances, b, n_f, args.iter),
                        'global_batch': b * world, 'parallelism': 'dp%d' % world, 'sync_bn': bool(args.sync_bn and world > 1), 'optimizer': 'FlatAdamW (clip 0.01 folded in)' if args.optimizer == 'flat' else 'torch AdamW(%s) + flat-buffer grad-norm clip' % args.optimizer,
                        'grad_allreduce': None if world == 1 and not force_ddp else ('torch DDP' if args.ddp else ('one RCCL all-reduce of the flat gradient buffer inside FlatAdamW.step' if args.optimizer == 'flat' else 'GradSync (flat-buffer RCCL all-reduce)')),
-                       'active_ratio': round(active_ratio, 4), 'active_ratio_per_timed_step': [round(float(v), 3) for v in stats['active_hist'][-args.steps - 2:-2]] if not args.no_roofline else None, 'active_pixels_per_step_per_gpu': int(active_px), 'loss_total': round(loss_val, 4)},
+                       'active_ratio': round(active_ratio, 4), 'active_ratio_per_timed_step': [round(float(v) / (b * n_f * args.instances * args.size * args.size), 3) for v in stats['active_hist'][-args.steps - 2:-2]] if not args.no_roofline else None, 'active_pixels_per_step_per_gpu': int(active_px), 'loss_total': round(loss_val, 4)},
             'roofline': roofline, 'cpu_baseline': cpu_baseline,
         }
     if world > 1 or force_ddp:

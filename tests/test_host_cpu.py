@@ -276,3 +276,18 @@ def test_video_window_matches_reference_bookkeeping():
                 for x, y in zip(o[key], r[key]):
                     assert x.shape == y.shape and np.array_equal(x.numpy(), y), (n_clips, c, key)
         assert ours.preds.shape[0] <= 3
+
+
+def test_vectorised_width_draw_equals_reference_scalar_draws():
+    """functional.unknown_bits draws the P random dilation widths of compute_unknown (maggie/utils/utils.py:47: one
+    np.random.randint(1, k) per slice) with ONE vectorised call: same values, same generator state afterwards."""
+    import numpy as np
+    for seed in range(10):
+        for k in (15, 27, 30):
+            np.random.seed(seed)
+            a = [np.random.randint(1, k) for _ in range(40)]
+            x = np.random.rand()
+            np.random.seed(seed)
+            b = np.random.randint(1, k, size=40).astype(np.int32)
+            y = np.random.rand()
+            assert list(b) == a and x == y
