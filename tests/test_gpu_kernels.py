@@ -729,3 +729,61 @@ def test_os8_weight_matches_reference_statements(reweight):
     if reweight:
         w = (((alphas <= 254.0 / 255.0) & (alphas >= 1.0 / 255.0)) | ((a8 <= 254.0 / 255.0) & (a8 >= 1.0 / 255.0))).type(w.dtype) + w
     assert torch.equal(MF.os8_weight(alphas, a8, reweight), w)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_batched_weight_pipeline_mixes_spectral_norm_and_plain_convs(dtype):
+    """functional.spectral_norm_prepare over a list that mixes SpectralNorm wrappers with ordinary conv holders (`plain` descriptors):
+    the plain weights come out as the exact per-tensor conversion (KRSC + dgrad twin) and their gradient returns unchanged in OIHW; the
+    SpectralNorm entries equal the per-conv kernel path (weight, u/v update, gradient)."""
+    from maggie_amd import functional as MF
+    from maggie_amd.network.module import SpectralNorm, ConvWeight
+    dev = _dev()
+    torch.manual_seed(7)
+    mk_sn = lambda ci, co, k: SpectralNorm(ConvWeight(ci, co, k, 1, k // 2, 1)).to(dev)          # noqa: E731
+    mods = [mk_sn(40, 64, 3), ConvWeight(136, 72, 3, 1, 1, 1).to(dev), mk_sn(64, 32, 1), ConvWeight(512, 256, 1).to(dev), ConvWeight(8, 24, 3, 1, 2, 2).to(dev)]
+    twins = [SpectralNorm(ConvWeight(40, 64, 3, 1, 1, 1)).to(dev), SpectralNorm(ConvWeight(64, 32, 1)).to(dev)]
+    for a, b in zip((mods[0], mods[2]), twins):
+        b.load_state_dict(a.state_dict())
+    MF.ARENA.reset(dev)
+    cache = {}
+    MF.spectral_norm_prepare(mods, dtype, cache)
+    outs = []
+    for m in mods:
+        w = m.__dict__['_prepared']
+        outs.append(w)
+        if isinstance(m, SpectralNorm):
+            continue
+        co, ci, k, _ = m.weight.shape
+        ref = MF.weight_oihw_to_krsc(m.weight.detach(), dtype)
+        assert w.shape == ref.shape and torch.equal(w, ref)
+        assert torch.equal(w._mg_wt, ref.permute(2, 1, 0).contiguous())
+        assert MF.plain_krsc(m, dtype) is w and MF.plain_krsc(m, dtype) is not w          # handed out once per step
+    # SpectralNorm entries: same weight and the same advanced u, v as the per-conv path
+    for m, t, w in ((mods[0], twins[0], outs[0]), (mods[2], twins[1], outs[2])):
+        ref = t.krsc(dtype)
+        tol = 1e-6 if dtype == torch.float32 else 8e-3
+        assert (w.float() - ref.float()).abs().max() <= tol * ref.float().abs().max()
+        assert torch.allclose(m.module.weight_u, t.module.weight_u, atol=1e-6) and torch.allclose(m.module.weight_v, t.module.weight_v, atol=1e-6)
+    # gradients: plain = identity back to OIHW; SpectralNorm = the per-conv backward
+    grads = [torch.randn_like(o) for o in outs]
+    params = [m.module.weight_bar if isinstance(m, SpectralNorm) else m.weight for m in mods]
+    got = torch.autograd.grad(outs, params, grads)
+    for m, g_out, g in zip(mods, grads, got):
+        if isinstance(m, SpectralNorm):
+            continue
+        co, ci, k, _ = m.weight.shape
+        ref = g_out.float()[:, :, :ci].reshape(co, k, k, ci).permute(0, 3, 1, 2)
+        assert g.dtype == torch.float32 and torch.equal(g, ref)
+    for idx in (0, 2):
+        # u, v have advanced: compare against autograd of the reference formula W / sigma with the advanced vectors held fixed
+        wbar = mods[idx].module.weight_bar
+        u, v = mods[idx].module.weight_u.detach(), mods[idx].module.weight_v.detach()
+        wb = wbar.detach().clone().requires_grad_(True)
+        sigma = u.dot(wb.reshape(wb.shape[0], -1).mv(v))
+        wn = (wb / sigma).permute(0, 2, 3, 1).reshape(wb.shape[0], -1, wb.shape[1])
+        gk = grads[idx].float()[:, :, :wb.shape[1]]
+        (ref,) = torch.autograd.grad(wn, wb, gk)
+        tol = 2e-5 if dtype == torch.float32 else 2e-2
+        assert (got[idx] - ref).abs().max() <= tol * ref.abs().max() + 1e-7
