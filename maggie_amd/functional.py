@@ -292,7 +292,7 @@ class SpectralNormPlan:
         import numpy as np
         self.modules = modules
         self.dtype = dtype
-        self.sources = [_weight_source(m) for m in modules]
+        self.sources = [_weight_source(m) for m in modules]                # used below only; tensors are dropped at the end
         dev = self.sources[0][0].device
         n = len(modules)
         descs = (K.hip.SnDesc * n)()
@@ -333,9 +333,16 @@ class SpectralNormPlan:
         mk = lambda lst: torch.from_numpy(np.asarray(lst, np.int32).reshape(-1, 4)).to(dev)
         self.k1, self.k2, self.k3 = mk(k1), mk(k2), mk(k3)
         self.ptr_key = self._ptrs()
+        self.sources = [(None, None, None) + tuple(src[3:]) for src in self.sources]      # metadata only: never hand out a stale tensor
 
     def _ptrs(self):
-        return tuple((w.data_ptr(), 0 if u is None else u.data_ptr(), 0 if v is None else v.data_ptr()) for w, u, v, *_ in self.sources)
+        # LIVE tensors of the modules (not the ones seen when the plan was built): parameters may have been re-allocated or re-homed
+        # since, and during a graph capture the modules hold stand-ins
+        out = []
+        for m in self.modules:
+            w, u, v = _weight_source(m)[:3]
+            out.append((w.data_ptr(), 0 if u is None else u.data_ptr(), 0 if v is None else v.data_ptr()))
+        return tuple(out)
 
     def valid(self, dtype):
         return dtype == self.dtype and self._ptrs() == self.ptr_key
@@ -401,7 +408,9 @@ def spectral_norm_prepare(modules, dtype, cache):
     if plan is None or not plan.valid(dtype):
         plan = SpectralNormPlan(modules, dtype)
         cache['plan'] = plan
-    outs = SpectralNormBatch.apply(plan, *[src[0] for src in plan.sources])
+    # the weight tensors are looked up NOW, not taken from the plan: while a graph is being captured the modules hold stand-in
+    # parameters (graphs._ParamAliases) and the captured backward must be differentiated with respect to those
+    outs = SpectralNormBatch.apply(plan, *[_weight_source(m)[0] for m in modules])
     for m, o in zip(modules, outs):
         m.__dict__['_prepared'] = o
         m.__dict__['_prepared_epoch'] = ARENA.epoch

@@ -131,3 +131,38 @@ def test_graphs_are_dropped_when_parameters_move():
     assert any(not isinstance(v, (int, str)) for v in model._trunk_graphs.values())
     for r in (first, replay):
         assert float((r['alpha'] - eager['alpha']).abs().max()) <= 1e-4 and torch.equal(r['mask'], eager['mask'])
+
+
+def test_flat_adamw_rehoming_with_graphs():
+    """FlatAdamW moves every trainable parameter into one flat buffer. Graphs captured before that must be dropped (addresses
+    changed), the re-captured ones must read the re-homed parameters (an optimizer step changes what the next replay computes),
+    and a replayed step must still equal the eager step from the same state."""
+    from maggie_amd.optim import FlatAdamW
+    from maggie_amd.utils import synth
+    dev = _dev()
+    model, _ = _build('image', dev, True)
+    batch = _to(synth.synthetic_batch(2, 1, 2, 64, 64, seed=DSEED, train=True, max_inst=10, it=10000), dev)
+    state = copy.deepcopy(model.state_dict())
+    for _ in range(3):
+        _one_step(model, state, batch, True, True, False)
+    assert any(not isinstance(v, (int, str)) for v in model._trunk_graphs.values())
+    opt = FlatAdamW(model.parameters(), lr=1e-3, weight_decay=0.01, max_grad_norm=0.01)
+    p0 = model.get_parameter('encoder.layer1.0.conv1.module.weight_bar')
+    assert opt.flat_p.data_ptr() <= p0.data_ptr() < opt.flat_p.data_ptr() + 4 * opt.flat_p.numel()
+    first = _one_step(model, state, batch, True, True, False)          # eager again: the old graphs are gone
+    assert all(isinstance(v, (int, str)) for v in model._trunk_graphs.values())
+    eager = _one_step(model, state, batch, False, True, False)
+    _one_step(model, state, batch, True, True, False)                  # capture on the flat buffer
+    replay = _one_step(model, state, batch, True, True, False)
+    assert any(not isinstance(v, (int, str)) for v in model._trunk_graphs.values())
+    for r in (first, replay):
+        assert abs(r['loss'] - eager['loss']) <= 2e-3 * max(1.0, abs(eager['loss']))
+        assert float((r['os8'] - eager['os8']).abs().mean()) <= 1e-4
+    before = p0.detach().clone()
+    opt.step()                                                         # gradients of the replayed step
+    assert float(opt.last_grad_norm) > 0 and not torch.equal(p0, before)
+    moved = copy.deepcopy(model.state_dict())
+    after = _one_step(model, moved, batch, True, True, False)          # the graph reads the updated flat buffer
+    after_eager = _one_step(model, moved, batch, False, True, False)
+    assert abs(after['loss'] - after_eager['loss']) <= 2e-3 * max(1.0, abs(after_eager['loss']))
+    assert abs(after['loss'] - replay['loss']) > 0                     # ... and not the pre-update weights
