@@ -166,3 +166,32 @@ def test_flat_adamw_rehoming_with_graphs():
     after_eager = _one_step(model, moved, batch, False, True, False)
     assert abs(after['loss'] - after_eager['loss']) <= 2e-3 * max(1.0, abs(after_eager['loss']))
     assert abs(after['loss'] - replay['loss']) > 0                     # ... and not the pre-update weights
+
+
+@pytest.mark.parametrize('kind', ['image', 'video'])
+def test_every_parameter_trains_under_graphs(kind):
+    """bench.py's order (optimizer first, graphs captured afterwards): on every replayed step each trainable parameter receives a
+    gradient and is moved by the optimizer -- nothing is silently cut out of the captured backward."""
+    from maggie_amd.optim import FlatAdamW
+    from maggie_amd.utils import synth
+    dev = _dev()
+    model, _ = _build(kind, dev, True)
+    model.hip_graphs = True
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = FlatAdamW(params, lr=1e-4, weight_decay=0.01, max_grad_norm=0.01)
+    n_f = 3 if kind == 'video' else 1
+    batch = _to(synth.synthetic_batch(2 if kind == 'image' else 1, n_f, 2, 64, 64, seed=DSEED, train=True, max_inst=10, it=10000), dev)
+    seed_all(3)
+    for i in range(4):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            out, loss = model(batch)
+        loss['total'].backward()
+        missing = [n for n, p in model.named_parameters() if p.requires_grad and p.grad is None]
+        assert not missing, (i, missing[:5])
+        before = opt.flat_p.clone()
+        opt.step()
+        still = [j for j, (p, o) in enumerate(zip(params, opt._offsets)) if torch.equal(p.detach().reshape(-1), before[o:o + p.numel()])]
+        assert not still, (i, len(still))
+    assert any(not isinstance(v, (int, str)) for v in model._trunk_graphs.values())
+    assert set(opt._steps) == {4}
