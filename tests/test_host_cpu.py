@@ -174,6 +174,28 @@ def test_flat_clip_grad_norm_matches_torch():
         assert float(part[10:].min()) == 1e9
 
 
+def test_checkpoint_bridge_video_layout(tmp_path):
+    """The video model's keys / shapes (tests/golden/state_dict_layout_video.json: ConvGRU `ih.0` / `hh.0`, `diff_module`) survive a
+    safetensors round trip and load back without a single missing / unexpected / mismatched entry."""
+    import json
+    import torch
+    from maggie_amd.network import build_model
+    from maggie_amd.utils import checkpoint as ck, config, synth
+    layout = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'state_dict_layout_video.json')))['state_dict']
+    src, _ = build_model(config.model_config('video'))
+    sd = src.state_dict()
+    synth.fill_state_dict_(sd, 11)
+    src.load_state_dict(sd)
+    path = str(tmp_path / 'video.safetensors')
+    ck.save_model(src, path)
+    stored = ck.read_state_dict(path)
+    assert set(stored) == set(layout) and all(list(stored[k].shape) == list(layout[k][0]) for k in layout)
+    assert any('os8_temp_module.ih.0.weight' in k for k in stored) and any('diff_module' in k for k in stored)
+    dst, _ = build_model(config.model_config('video'))
+    assert ck.load_pretrained(dst, path) == ([], [], [])
+    assert all(torch.equal(v, sd[k]) for k, v in dst.state_dict().items())
+
+
 def test_checkpoint_bridge_round_trips_reference_formats(tmp_path):
     """maggie_amd.utils.checkpoint: .pth / .safetensors / hub-snapshot directory round trips with the reference's keys
     (tests/golden/state_dict_layout_image.json), DDP `module.` prefix, legacy spconv (kh,kw,Cin,Cout) weights, the
