@@ -27,12 +27,17 @@ _ALIGN = 64                                                       # floats: 256-
 
 class FlatAdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None, sync_group=None):
-        params = [p for p in params if p.requires_grad]
-        if not params:
+        # Like torch.optim.AdamW(model.parameters()) (maggie/engine/optim.py:117): EVERY parameter handed in stays in
+        # param_groups[0]['params'] -- frozen ones too (SpectralNorm's weight_u / weight_v, dummy_downscale) -- so that the index
+        # space of state_dict() is the reference's and its last_opt.pth resumes here (and vice versa). Only the trainable
+        # ones live in the flat buffers and are ever updated; torch never creates state for a parameter without a gradient either.
+        params = list(params)
+        if not any(p.requires_grad for p in params):
             raise ValueError('no trainable parameters')
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         if len(self.param_groups) != 1:
             raise ValueError('FlatAdamW handles one parameter group')
+        params = self._active()
         self.max_grad_norm = max_grad_norm
         self.sync_group = sync_group                              # see step(): data-parallel gradient averaging on the flat buffer
         self._t = 0
@@ -41,8 +46,13 @@ class FlatAdamW(torch.optim.Optimizer):
         self._build()
 
     # ------------------------------------------------------------------------------------------------------------------
+    def _active(self):
+        return [p for p in self.param_groups[0]['params'] if p.requires_grad]
+
     def _build(self):
-        ps = self.param_groups[0]['params']
+        ps = self._active()
+        if len(ps) != len(self._steps):                           # requires_grad flags changed since construction
+            self._steps = [self._t] * len(ps)
         dev = ps[0].device
         hip.need_cuda(ps[0])
         for p in ps:
@@ -76,8 +86,8 @@ class FlatAdamW(torch.optim.Optimizer):
         self._ptrs = [p.data_ptr() for p in ps]
 
     def _intact(self):
-        ps = self.param_groups[0]['params']
-        return all(p.data_ptr() == a for p, a in zip(ps, self._ptrs))
+        ps = self._active()
+        return len(ps) == len(self._ptrs) and all(p.data_ptr() == a for p, a in zip(ps, self._ptrs))
 
     # ------------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -89,7 +99,7 @@ class FlatAdamW(torch.optim.Optimizer):
         if not self._intact():                                    # model.to(...) / .float() moved the parameters: re-home them
             self._build()
         g = self.param_groups[0]
-        ps = g['params']
+        ps = self._active()
         grads, views, have = [], [], []
         for p, gv in zip(ps, self._g_views):
             have.append(p.grad is not None)
@@ -148,13 +158,16 @@ class FlatAdamW(torch.optim.Optimizer):
 
     # ------------------------------------------------------------------------------------------------------------------
     def state_dict(self):
-        for p, t in zip(self.param_groups[0]['params'], self._steps):
+        for p, t in zip(self._active(), self._steps):
             self.state[p]['step'] = torch.tensor(float(t))
-        return super().state_dict()
+        sd = super().state_dict()
+        # torch.optim.AdamW holds no state for a parameter it never stepped (no gradient yet): same here
+        sd['state'] = {k: v for k, v in sd['state'].items() if float(v.get('step', 0)) > 0}
+        return sd
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)                       # replaces the moment tensors by loaded copies ...
-        ps = self.param_groups[0]['params']
+        ps = self._active()
         self._steps = [int(float(self.state[p]['step'])) if 'step' in self.state[p] else 0 for p in ps]
         self._t = max(self._steps) if self._steps else 0
         self._build()                                             # ... which _build copies back into the flat buffers

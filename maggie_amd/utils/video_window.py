@@ -35,9 +35,11 @@ class VideoWindow:
         out = {'save': (self.names[:end_idx], self.preds[None, :end_idx])}
         previous = None
         if n > 3:
-            # (:266-270; the reference slices [-4:-3] while the clip is not the last one, and everything before the final three at the end)
-            end_prev = -3 if not is_last else n
-            previous = (self.preds[-4:end_prev], self.trimaps[-4:end_prev], self.gts[-4:end_prev])
+            # (:266-270) the reference slices [-4:-3] while the clip is not the last one; on the last clip its end index is
+            # `len(prev_preds)` of the PREVIOUS iteration (= 1 whenever that iteration had 4 stored frames), i.e. [-4:1] of 4 frames:
+            # the same single frame. (On a video of exactly two clips the reference raises -- len(None) -- and a single
+            # first-and-last clip has n == 3; both corner cases get the single frame / None here.)
+            previous = (self.preds[-4:-3], self.trimaps[-4:-3], self.gts[-4:-3])
         end_all = -2 if not is_last else n
         out['current'] = (self.preds[-3:end_all], self.trimaps[-3:end_all], self.gts[-3:end_all])
         out['previous'] = previous

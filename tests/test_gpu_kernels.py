@@ -615,6 +615,50 @@ def test_flat_adamw_matches_torch_adamw(max_norm):
 
 
 @pytest.mark.gpu
+def test_flat_adamw_real_model_state_dict_cross_resume():
+    """The reference builds torch.optim.AdamW(model.parameters()) (maggie/engine/optim.py:117) -- frozen parameters (SpectralNorm weight_u /
+    weight_v, dummy_downscale here) included in param_groups. FlatAdamW keeps the same index space: its state_dict loads into torch's AdamW
+    over the same model and torch's loads into FlatAdamW (`last_opt.pth` cross-resume, engine/train.py:98-113,335-343)."""
+    from maggie_amd.network import build_model
+    from maggie_amd.utils import config
+    from maggie_amd.optim import FlatAdamW
+    dev = _dev()
+    torch.manual_seed(0)
+    model, _ = build_model(config.model_config('image'))
+    model.to(dev)
+    twin, _ = build_model(config.model_config('image'))
+    twin.load_state_dict(model.state_dict())
+    twin.to(dev)
+    for a, b in zip(model.parameters(), twin.parameters()):
+        b.requires_grad_(a.requires_grad)
+    kw = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    ours, ref = FlatAdamW(model.parameters(), **kw), torch.optim.AdamW(twin.parameters(), **kw)
+    n_all = len(list(model.parameters()))
+    assert len(ours.param_groups[0]['params']) == n_all == len(ref.param_groups[0]['params'])
+    assert any(not p.requires_grad for p in model.parameters())
+    for _ in range(2):
+        for a, b in zip(model.parameters(), twin.parameters()):
+            if a.requires_grad:
+                g = torch.randn_like(a) * 0.01
+                a.grad, b.grad = g.clone(), g.clone()
+        ours.step(); ref.step()
+    for a, b in zip(model.parameters(), twin.parameters()):
+        assert torch.allclose(a, b, rtol=2e-5, atol=2e-7)
+    sd_o, sd_r = ours.state_dict(), ref.state_dict()
+    assert sd_o['param_groups'][0]['params'] == sd_r['param_groups'][0]['params'] == list(range(n_all))
+    assert sorted(sd_o['state'].keys()) == sorted(sd_r['state'].keys())          # no state for a parameter that was never stepped
+    k = sorted(sd_r['state'].keys())[len(sd_r['state']) // 2]
+    assert torch.allclose(sd_o['state'][k]['exp_avg'], sd_r['state'][k]['exp_avg'], rtol=1e-5, atol=1e-9)
+    torch.optim.AdamW(twin.parameters(), **kw).load_state_dict(sd_o)              # reference side resumes from ours
+    o2 = FlatAdamW(model.parameters(), **kw)
+    o2.load_state_dict(sd_r)                                                     # we resume from the reference's
+    assert o2._t == 2
+    p0 = next(p for p in model.parameters() if p.requires_grad)
+    i0 = [i for i, p in enumerate(model.parameters()) if p is p0][0]
+    assert torch.allclose(o2.state[p0]['exp_avg'], sd_r['state'][i0]['exp_avg'])
+
+
+@pytest.mark.gpu
 def test_flat_adamw_sync_group_single_rank_rccl():
     """FlatAdamW(sync_group=True): the gradient exchange is one RCCL all-reduce (mean) of the flat buffer. With one rank the mean is the
     identity: same parameters as without the group; a parameter without a local gradient is updated with zeros (DDP semantics)."""

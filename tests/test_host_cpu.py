@@ -297,6 +297,9 @@ def test_video_window_matches_reference_bookkeeping():
                     continue
                 for x, y in zip(o[key], r[key]):
                     assert x.shape == y.shape and np.array_equal(x.numpy(), y), (n_clips, c, key)
+            if o['previous'] is not None:
+                # as executed by the reference (test.py:266-268): ONE frame, also on the last clip (end index = len(prev_preds) = 1)
+                assert o['previous'][0].shape[0] == 1
         assert ours.preds.shape[0] <= 3
 
 
