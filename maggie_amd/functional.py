@@ -86,6 +86,14 @@ def compute_dtype():
     """bf16 inside torch.autocast(device_type='cuda') (the reference's --precision 16 path uses fp16 autocast,
     engine/train.py:208,227-229; bf16 is this build's choice), fp32 otherwise."""
     if torch.is_autocast_enabled():
+        dt = torch.get_autocast_dtype('cuda') if hasattr(torch, 'get_autocast_dtype') else torch.get_autocast_gpu_dtype()
+        if dt != torch.bfloat16:
+            # the unchanged harness with `--precision 16` (fp16 autocast + GradScaler) must not silently compute in bf16 under a
+            # loss scaler: there is no fp16 kernel family in this build -- say so
+            raise K.hip.MaggieHipError(
+                'MaGGIe (MI355X build): autocast dtype %s is not supported -- the HIP kernels compute in bf16 (fp32 accumulate) or fp32. '
+                'Use torch.autocast("cuda", dtype=torch.bfloat16) and drop the GradScaler (bf16 needs no loss scaling), or run without '
+                'autocast for fp32.' % dt)
         return torch.bfloat16
     return torch.float32
 
@@ -557,8 +565,8 @@ class BNAct(torch.autograd.Function):
                 stats = K.colstats(x2)
             if group is not None:
                 flat = stats.sum(0) if stats.dim() == 2 else stats
-                pack = torch.cat([flat[:2 * C], torch.full((1,), float(M), device=x.device)])
-                dist.all_reduce(pack, group=group)
+                from .parallel import syncbn_exchange_forward
+                pack = syncbn_exchange_forward(torch.cat([flat[:2 * C], torch.full((1,), float(M), device=x.device)]), group)
                 stats, cnt_t = pack[:2 * C], pack[2 * C:]
             rm = running_mean if running_mean.numel() == C else None
             rv = running_var if running_var.numel() == C else None
@@ -597,13 +605,17 @@ class BNAct(torch.autograd.Function):
         if training:
             _, _, sums = K.bn_backward(dy2, y, x2, scale, mean, invstd, M, act=act, slope=LRELU_SLOPE, reduce_only=True,
                                        sums=ARENA.take(2 * C, dy.device))
+            local = sums
             if group is not None:
-                dist.all_reduce(sums, group=group)
-            dx, dres, sums = K.bn_backward(dy2, y, x2, scale, mean, invstd, M, act=act, slope=LRELU_SLOPE, want_dres=has_res,
-                                           mask_x_pos=mask_x_pos, sums=sums, apply_only=True, count_ptr=cnt_t)
+                # SyncBN: dx needs the sums over ALL ranks' rows; dgamma / dbeta stay LOCAL (nn.SyncBatchNorm semantics -- the
+                # data-parallel gradient averaging that follows would otherwise count them world_size times)
+                from .parallel import syncbn_exchange_backward
+                sums, local = syncbn_exchange_backward(sums, group)
+            dx, dres, _ = K.bn_backward(dy2, y, x2, scale, mean, invstd, M, act=act, slope=LRELU_SLOPE, want_dres=has_res,
+                                        mask_x_pos=mask_x_pos, sums=sums, apply_only=True, count_ptr=cnt_t)
             if not torch.cuda.is_current_stream_capturing():
-                sums = sums.clone()              # the arena slice dies with the step; inside a graph it is the graph's own
-            dgamma, dbeta = sums[C:2 * C][:nch], sums[:C][:nch]
+                local = local.clone()            # the arena slice dies with the step; inside a graph it is the graph's own
+            dgamma, dbeta = local[C:2 * C][:nch], local[:C][:nch]
         else:
             # eval statistics are constants: dx = g * scale
             zeros = torch.zeros(2 * C, dtype=torch.float32, device=dy.device)

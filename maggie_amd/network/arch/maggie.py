@@ -20,7 +20,7 @@ from ... import kernels as K
 from ..module import ASPP
 from ..encoder import *      # noqa: F401,F403  (factory names are resolved by eval(), like the reference)
 from ..decoder import *      # noqa: F401,F403
-from ..loss import LapLoss, loss_dtSSD, GradientLoss
+from ..loss import loss_dtSSD
 
 
 class MaGGIe(nn.Module, PyTorchModelHubMixin):
@@ -39,8 +39,6 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         self.loss_atten_w = cfg.loss_atten_w
         self.reweight_os8 = cfg.loss_reweight_os8
         self.loss_dtSSD_w = cfg.loss_dtSSD_w
-        self.lap_loss = LapLoss()
-        self.grad_loss = GradientLoss()
         for module in [self.aspp, self.decoder]:
             for name, p in module.named_parameters():
                 if "context_token" in name:
@@ -296,87 +294,44 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         return masks, alphas, trans_gt, n_i, chosen_ids, enc_masks
 
     # ------------------------------------------------------------------------------------------------ losses
-    @staticmethod
-    def regression_loss(logit, target, loss_type='l1', weight=None, topk=-1):
-        if weight is None:
-            if loss_type == 'l1':
-                return F.l1_loss(logit, target)
-            elif loss_type == 'l2':
-                return F.mse_loss(logit, target)
-            raise NotImplementedError("NotImplemented loss type {}".format(loss_type))
-        if loss_type == 'l1':
-            loss = F.l1_loss(logit * weight, target * weight, reduction='none')
-            if topk > 0:
-                topk = int(weight.sum() * 0.5)
-                loss, _ = torch.topk(loss.view(-1), topk)
-                return loss.sum() / (topk + 1e-8)
-            return loss.sum() / (torch.sum(weight) + 1e-8)
-        elif loss_type == 'l2':
-            return F.mse_loss(logit * weight, target * weight, reduction='sum') / (torch.sum(weight) + 1e-8)
-        raise NotImplementedError("NotImplemented loss type {}".format(loss_type))
-
     def compute_loss(self, pred, weight_os4, weight_os1, alphas, trans_gt, alpha_shape, reweight_os8=True):
+        """arch/maggie.py:268-368: weighted L1 + Laplacian-pyramid L1 + Sobel-gradient L1 at OS1 (x2) / OS4 / OS8 (+ dtSSD for video), same
+        loss names. Every term is a fused HIP pipeline (csrc/losses.hip) -- there is no torch fallback: what the kernels do not cover is
+        rejected loudly (`loss_alpha_type` other than the 'l1' of maggie_{image,video}.yaml; sizes that are not multiples of 8)."""
         a1, a4, a8 = pred.get('alpha_os1', None), pred.get('alpha_os4', None), pred['alpha_os8']
+        lt = self.cfg.loss_alpha_type
+        if lt not in ('l1', 'l2'):
+            raise NotImplementedError("NotImplemented loss type {}".format(lt))          # arch/maggie.py:253,266
+        if lt != 'l1' or a1 is None or a8.shape[-1] % 8 or a8.shape[-2] % 8 or not alphas.is_cuda:
+            raise K.hip.MaggieHipError(
+                "MaGGIe (MI355X build): the fused HIP loss kernels implement loss_alpha_type='l1' (configs/maggie_{image,video}.yaml) on "
+                "CUDA planes whose height and width are multiples of 8; got type %r, size %dx%d. There is no torch fallback."
+                % (lt, a8.shape[-2], a8.shape[-1]))
         loss_dict = {}
-        if alphas.shape == a8.shape and alphas.dtype == torch.float32 and a8.dtype == torch.float32 and alphas.is_cuda:
-            weight_os8 = MF.os8_weight(alphas, a8, reweight_os8)             # the statements below in one pass (mg_os8_weight)
-        else:
-            weight_os8 = torch.ones_like(a8)
-            valid_mask = alphas.sum((2, 3), keepdim=True) > 0
-            weight_os8 = weight_os8 * valid_mask
-            if reweight_os8:
-                unknown_gt = (alphas <= 254.0 / 255.0) & (alphas >= 1.0 / 255.0)
-                unknown_pred_os8 = (a8 <= 254.0 / 255.0) & (a8 >= 1.0 / 255.0)
-                weight_os8 = (unknown_gt | unknown_pred_os8).type(weight_os8.dtype) + weight_os8
+        alphas = alphas.float()
+        weight_os8 = MF.os8_weight(alphas, a8.float(), reweight_os8)             # arch/maggie.py:271-281 in one pass (mg_os8_weight)
         n_i = alphas.shape[1]
         if self.num_masks - n_i > 0:
             padding = torch.zeros((alphas.shape[0], self.num_masks - n_i, *alphas.shape[-2:]), device=alphas.device)
             alphas = torch.cat([alphas, padding], dim=1)
             trans_gt = torch.cat([trans_gt, padding], dim=1)
         total_loss = 0
-        lt = self.cfg.loss_alpha_type
-        fused = (a1 is not None and lt == 'l1' and a8.shape[-1] % 8 == 0 and a8.shape[-2] % 8 == 0)
-        if fused:
-            # one fused HIP pipeline per scale: weighted L1 + Laplacian-pyramid L1 + Sobel-gradient L1 (fwd sums + exact bwd)
-            r1, l1_, g1 = MF.matting_losses(a1, alphas, weight_os1)
-            r4, l4_, g4 = MF.matting_losses(a4, alphas, weight_os4)
-            r8, l8_, g8 = MF.matting_losses(a8, alphas, weight_os8)
+        # one fused HIP pipeline per scale: weighted L1 + Laplacian-pyramid L1 + Sobel-gradient L1 (fwd sums + exact bwd)
+        r1, l1_, g1 = MF.matting_losses(a1, alphas, weight_os1)
+        r4, l4_, g4 = MF.matting_losses(a4, alphas, weight_os4)
+        r8, l8_, g8 = MF.matting_losses(a8, alphas, weight_os8)
         if self.loss_alpha_w > 0:
-            ref_alpha_loss = 0
-            if a1 is not None:
-                if not fused:
-                    r1 = self.regression_loss(a1, alphas, loss_type=lt, weight=weight_os1)
-                    r4 = self.regression_loss(a4, alphas, loss_type=lt, weight=weight_os4)
-                    r8 = self.regression_loss(a8, alphas, loss_type=lt, weight=weight_os8)
-                ref_alpha_loss = ref_alpha_loss + r1 * 2 + r4 + r8
-                loss_dict['loss_rec_os1'], loss_dict['loss_rec_os4'], loss_dict['loss_rec_os8'] = r1, r4, r8
-            loss_dict['loss_rec'] = ref_alpha_loss
-            total_loss = total_loss + ref_alpha_loss * self.loss_alpha_w
+            loss_dict['loss_rec_os1'], loss_dict['loss_rec_os4'], loss_dict['loss_rec_os8'] = r1, r4, r8
+            loss_dict['loss_rec'] = r1 * 2 + r4 + r8
+            total_loss = total_loss + loss_dict['loss_rec'] * self.loss_alpha_w
         if self.loss_alpha_lap_w > 0:
-            logging.debug("Computing lap loss")
-            h, w = a8.shape[-2:]
-            lap_loss = 0
-            if a1 is not None:
-                if not fused:
-                    v = lambda t: t.reshape(-1, 1, h, w)
-                    l1_ = self.lap_loss(v(a1), v(alphas), v(weight_os1))
-                    l4_ = self.lap_loss(v(a4), v(alphas), v(weight_os4))
-                    l8_ = self.lap_loss(v(a8), v(alphas), v(weight_os8))
-                loss_dict['loss_lap_os1'], loss_dict['loss_lap_os4'], loss_dict['loss_lap_os8'] = l1_, l4_, l8_
-                lap_loss = lap_loss + l1_ * 2 + l4_ + l8_
-            loss_dict['loss_lap'] = lap_loss
-            total_loss = total_loss + lap_loss * self.loss_alpha_lap_w
+            loss_dict['loss_lap_os1'], loss_dict['loss_lap_os4'], loss_dict['loss_lap_os8'] = l1_, l4_, l8_
+            loss_dict['loss_lap'] = l1_ * 2 + l4_ + l8_
+            total_loss = total_loss + loss_dict['loss_lap'] * self.loss_alpha_lap_w
         if self.loss_alpha_grad_w > 0:
-            grad_loss = 0
-            if a1 is not None:
-                if not fused:
-                    g1 = self.grad_loss(a1, alphas, weight_os1)
-                    g4 = self.grad_loss(a4, alphas, weight_os4)
-                    g8 = self.grad_loss(a8, alphas, weight_os8)
-                grad_loss = grad_loss + g1 * 2 + g4 + g8
-                loss_dict['loss_grad_os1'], loss_dict['loss_grad_os4'], loss_dict['loss_grad_os8'] = g1, g4, g8
-            loss_dict['loss_grad'] = grad_loss
-            total_loss = total_loss + grad_loss * self.loss_alpha_grad_w
+            loss_dict['loss_grad_os1'], loss_dict['loss_grad_os4'], loss_dict['loss_grad_os8'] = g1, g4, g8
+            loss_dict['loss_grad'] = g1 * 2 + g4 + g8
+            total_loss = total_loss + loss_dict['loss_grad'] * self.loss_alpha_grad_w
         if self.loss_dtSSD_w > 0:
             rs = lambda t: t.reshape(*alpha_shape)
             d1 = loss_dtSSD(rs(a1), rs(alphas), rs(weight_os1))

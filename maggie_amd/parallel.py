@@ -25,6 +25,25 @@ def reduce_bn_stats(pack, C, group):
     return mean, var, n
 
 
+def syncbn_exchange_forward(local_pack, group):
+    """Forward statistics exchange of SyncBatchNorm as functional.BNAct does it: local_pack = [sum x (C), sum x^2 (C), rows] of this
+    rank's rows -> the same pack summed over the group (a copy; variable row counts per rank are fine: the count rides along).
+    torch's SyncBatchNorm all-gathers (mean, invstd, count) instead (engine/train.py:160-161); the pooled moments are the same numbers."""
+    pack = local_pack.clone()
+    dist.all_reduce(pack, group=group)
+    return pack
+
+
+def syncbn_exchange_backward(local_sums, group):
+    """Backward exchange: local_sums = [sum g (C), sum g * xhat (C)] of this rank's rows -> (global sums for the dx formula, the LOCAL sums
+    untouched). torch's SyncBatchNorm all-reduces these two vectors for dx only and keeps grad_weight / grad_bias local (DDP then averages
+    them over the ranks); returning the all-reduced sums as dgamma / dbeta would make every BN parameter gradient world_size times too
+    large."""
+    glob = local_sums.clone()
+    dist.all_reduce(glob, group=group)
+    return glob, local_sums
+
+
 def shard_items(n_items, rank, world):
     """Weak-scaling item assignment: rank r owns items r, r+world, ..."""
     return list(range(rank, n_items, world))

