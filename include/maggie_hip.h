@@ -288,7 +288,7 @@ int mg_spectral_norm_batched_bwd(const mg_sn_desc* descs, int n_conv, const int3
  *   mg_gru_out_bwd  : from dhn: drz[:, C:], dc_pre, dh_part = dhn * (1 - z)
  *   mg_gru_gate_bwd : from dxrh: dx = dxrh[:, :C], drz[:, :C], dh_part = dxrh[:, C:] * r
  *   mg_temporal_fuse: eval-time alpha-level aggregation over frames (t-1, t, t+1) of maggie/network/arch/maggie_temp.py:34-77,
- *                     in place on fp32 planes (3, P, H*W): thresholds the difference maps at 0.5, propagates t-1 -> t and t+1 -> t,
+ *                     in place on fp32 planes (n_frames >= 3, P, H*W; t+1 = the LAST frame, :48, frames 1 and 2 are rewritten): thresholds the difference maps at 0.5, propagates t-1 -> t and t+1 -> t,
  *                     keeps the model's own prediction where the two disagree, then propagates t -> t+1.
  * ------------------------------------------------------------------------------------------------------------- */
 int mg_gru_gate_fwd(const void* rz, const void* x, const void* h, int dtype, int M, int C, void* xrh, void* stream);
@@ -296,7 +296,7 @@ int mg_gru_gate_bwd(const void* dxrh, const void* rz, const void* h, int dtype, 
 int mg_gru_out_fwd(const void* rz, const void* cpre, const void* h, int dtype, int M, int C, void* hn, void* stream);
 int mg_gru_out_bwd(const void* dhn, const void* rz, const void* cpre, const void* h, int dtype, int M, int C, void* drz, void* dc_pre,
                    void* dh_part, void* stream);
-int mg_temporal_fuse(float* alphas, const float* prev, const float* df, const float* db, long plane_elems, void* stream);
+int mg_temporal_fuse(float* alphas, const float* prev, const float* df, const float* db, long plane_elems, int n_frames, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Sparse refinement head, parameter side (maggie/network/decoder/resnet_inst_matt_spconv.py:69-130: the spconv layers' weights

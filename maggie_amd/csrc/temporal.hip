@@ -118,9 +118,10 @@ __global__ __launch_bounds__(NT) void gru_out_bwd_kernel(const T* __restrict__ d
 // alphas: (3, P, HW) fp32 frames t-1, t, t+1 (frame stride fs); prev: (P, HW) or NULL (= frame 0); df / db: forward / backward
 // difference maps (3, P, HW) with the same strides. Writes frames 1 and 2 in place.
 __global__ __launch_bounds__(NT) void temporal_fuse_kernel(float* __restrict__ alphas, const float* __restrict__ prev, const float* __restrict__ df,
-                                                           const float* __restrict__ db, long fs, long n) {
+                                                           const float* __restrict__ db, long fs, long n, long last) {
+    // `last` = offset of the clip's final frame (alphas[:, -1] of maggie_temp.py:48): frame 2 for the 3-frame evaluation window
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
-        const float a0 = alphas[i], a1 = alphas[fs + i], a2 = alphas[2 * fs + i];
+        const float a0 = alphas[i], a1 = alphas[fs + i], a2 = alphas[last + i];
         const float pv = prev ? prev[i] : a0;
         const float f1 = df[fs + i] > 0.5f ? 1.f : 0.f, f2 = df[2 * fs + i] > 0.5f ? 1.f : 0.f, b1 = db[fs + i] > 0.5f ? 1.f : 0.f;
         float fwd = pv * (1.f - f1) + a1 * f1;                       // t-1 -> t
@@ -185,9 +186,11 @@ extern "C" int mg_gru_out_bwd(const void* dhn, const void* rz, const void* cpre,
 }
 
 // alphas (3, P, H*W) fp32 contiguous frames (t-1, t, t+1), updated in place (frames 1 and 2); prev (P, H*W) or NULL; df / db (3, P, H*W)
-extern "C" int mg_temporal_fuse(float* alphas, const float* prev, const float* df, const float* db, long plane_elems, void* stream) {
+extern "C" int mg_temporal_fuse(float* alphas, const float* prev, const float* df, const float* db, long plane_elems, int n_frames, void* stream) {
     if (plane_elems <= 0) return 0;
-    hipLaunchKernelGGL(temporal_fuse_kernel, dim3(grid_for(plane_elems)), dim3(NT), 0, (hipStream_t)stream, alphas, prev, df, db, plane_elems, plane_elems);
+    if (n_frames < 3) return -3;
+    hipLaunchKernelGGL(temporal_fuse_kernel, dim3(grid_for(plane_elems)), dim3(NT), 0, (hipStream_t)stream, alphas, prev, df, db, plane_elems, plane_elems,
+                       (long)(n_frames - 1) * plane_elems);
     MG_CHECK_LAUNCH();
     return 0;
 }

@@ -626,8 +626,9 @@ def gru_out_bwd(dhn, rz, cpre, h):
 
 
 def temporal_fuse_(alphas3, prev, df3, db3):
-    """In place on alphas3 (3, ...) fp32 contiguous: frames (t-1, t, t+1); prev (...) or None; df3 / db3 like alphas3."""
+    """In place on alphas3 (n_f >= 3, ...) fp32 contiguous: frames (t-1, t, ..., last = the reference's t+1); prev (...) or None;
+    df3 / db3 like alphas3. Frames 1 and 2 are rewritten (maggie_temp.py:71,75)."""
     assert alphas3.is_contiguous() and df3.is_contiguous() and db3.is_contiguous() and alphas3.dtype == torch.float32
     n = alphas3[0].numel()
-    hip.call('mg_temporal_fuse', hip.ptr(alphas3), hip.ptr(prev), hip.ptr(df3), hip.ptr(db3), c_long(n), hip.stream())
+    hip.call('mg_temporal_fuse', hip.ptr(alphas3), hip.ptr(prev), hip.ptr(df3), hip.ptr(db3), c_long(n), c_int(alphas3.shape[0]), hip.stream())
     return alphas3

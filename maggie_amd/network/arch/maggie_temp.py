@@ -31,9 +31,10 @@ class MaGGIe_Temp(MaGGIe):
         output = super().forward(batch, **kwargs)
         if self.training:
             return output
-        # window aggregation (hard-wired to frames 0, 1, 2 like the reference): refined_masks[:, 1:3] are rewritten in place
-        alphas = output['refined_masks']                                        # (1, 3, n_i, H, W)
-        assert alphas.shape[0] == 1 and alphas.shape[1] == 3, 'the eval-time aggregation works on one 3-frame window'
+        # window aggregation (maggie_temp.py:34-77): frames 1 and 2 of refined_masks are rewritten in place; "t+1" is the clip's LAST frame
+        # (alphas[:, -1], :48) -- frame 2 for the 3-frame evaluation window of engine/test.py, any n_f >= 3 works like the reference
+        alphas = output['refined_masks']                                        # (1, n_f, n_i, H, W)
+        assert alphas.shape[0] == 1 and alphas.shape[1] >= 3, 'the eval-time aggregation works on one window of >= 3 frames'
         prev = kwargs.get('prev_pred')                                          # fused t-1 of the previous window, else frame 0
         if prev is not None:
             prev = prev.to(alphas.device).float().contiguous()

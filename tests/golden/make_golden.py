@@ -59,10 +59,13 @@ def pack(t):
     return t.float().numpy()
 
 
-def model_fixture(ns, kind, train, b, n_f, n_inst, hw, it, max_inst, name):
+def model_fixture(ns, kind, train, b, n_f, n_inst, hw, it, max_inst, name, keep=None):
+    """`hw`: int (square) or (h, w). `keep`: output names to store (None = all) -- the larger-geometry fixtures keep the final matte, the
+    coarse matte and the index map only."""
     m = build(ns, kind)
     m.train(train)
-    batch = synth.synthetic_batch(b, n_f, n_inst, hw, hw, seed=DSEED, train=train, it=it, max_inst=max_inst)
+    h_, w_ = (hw, hw) if isinstance(hw, int) else hw
+    batch = synth.synthetic_batch(b, n_f, n_inst, h_, w_, seed=DSEED, train=train, it=it, max_inst=max_inst)
     seed_all(RSEED)
     out = {}
     if train:
@@ -84,12 +87,12 @@ def model_fixture(ns, kind, train, b, n_f, n_inst, hw, it, max_inst, name):
         with torch.no_grad():
             o = m(batch)
     for k, v in o.items():
-        if torch.is_tensor(v):
+        if torch.is_tensor(v) and (keep is None or k in keep):
             out['out/' + k] = pack(v)
             out['shape/' + k] = np.array(v.shape)
     sd = m.state_dict()
     out['sn/encoder.conv1.module.weight_u'] = sd['encoder.conv1.module.weight_u'].numpy()
-    out['meta'] = np.array([b, n_f, n_inst, hw, it, -1 if max_inst is None else max_inst, WSEED, DSEED, RSEED])
+    out['meta'] = np.array([b, n_f, n_inst, h_, it, -1 if max_inst is None else max_inst, WSEED, DSEED, RSEED] + ([] if isinstance(hw, int) else [w_]))
     np.savez_compressed(os.path.join(HERE, name), **out)
     print('wrote', name, {k: (v.shape if hasattr(v, 'shape') else v) for k, v in list(out.items())[:4]})
 
@@ -274,6 +277,8 @@ def metric_fixture():
 
 def main():
     ns = ref_loader.load_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == '--new-geometries':          # only the round-2 additions (the others are unchanged)
+        return new_geometry_fixtures(ns)
     postprocess_fixture()
     preprocess_fixture()
     metric_fixture()
@@ -284,6 +289,16 @@ def main():
     model_fixture(ns, 'image', True, 2, 1, 2, 128, 100, None, 'model_image_train_warmup.npz')
     model_fixture(ns, 'video', False, 1, 3, 2, 128, 0, None, 'model_video_eval.npz')
     model_fixture(ns, 'video', True, 1, 3, 2, 128, 10000, 10, 'model_video_train.npz')
+    new_geometry_fixtures(ns)
+
+
+def new_geometry_fixtures(ns):
+    # BASELINE configs[2] geometry (image, 4 instances, batch 4 per GPU) and configs[4] geometry (video, T = 5, 3 instances), small sizes
+    keep = ('refined_masks', 'alpha_os8', 'detail_mask')
+    model_fixture(ns, 'image', False, 1, 1, 4, 128, 0, None, 'model_image_eval_4inst.npz', keep)
+    model_fixture(ns, 'image', True, 4, 1, 4, 128, 10000, 10, 'model_image_train_4inst_b4.npz', keep)
+    model_fixture(ns, 'video', False, 1, 5, 3, (96, 128), 0, None, 'model_video_eval_t5.npz', keep + ('temp_alpha',))
+    model_fixture(ns, 'video', True, 1, 5, 3, 96, 10000, 10, 'model_video_train_t5.npz', keep)      # square: the reference's LapLoss upsample (loss.py:138) breaks on H != W
 
 
 if __name__ == '__main__':

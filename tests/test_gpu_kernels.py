@@ -427,6 +427,17 @@ def test_temporal_fuse_kernel():
         p12 = p01 * (1 - f[2]) + al[2] * f[2]
         out = K.temporal_fuse_(a.clone().to(dev), None if prev is None else prev.to(dev), df.to(dev), db.to(dev)).cpu()
         assert torch.equal(out[0], a[0]) and torch.allclose(out[1], p01, atol=1e-7) and torch.allclose(out[2], p12, atol=1e-7)
+    # a 5-frame clip (BASELINE configs[4] geometry): "t+1" is the LAST frame (maggie_temp.py:48), frames 1 and 2 are rewritten
+    a5 = torch.from_numpy(rs.uniform(size=(5, 2, 8, 24)).astype(np.float32))
+    df5, db5 = (torch.from_numpy(rs.uniform(size=(5, 2, 8, 24)).astype(np.float32)) for _ in range(2))
+    f, bk = (df5 > 0.5).float(), (db5 > 0.5).float()
+    p01 = a5[0] * (1 - f[1]) + a5[1] * f[1]
+    p21 = a5[4] * (1 - bk[1]) + a5[1] * bk[1]
+    p01 = torch.where((p01 - p21).abs() > 0, a5[1], p01)
+    p12 = p01 * (1 - f[2]) + a5[4] * f[2]
+    out = K.temporal_fuse_(a5.clone().to(dev), None, df5.to(dev), db5.to(dev)).cpu()
+    assert torch.equal(out[0], a5[0]) and torch.equal(out[3], a5[3]) and torch.equal(out[4], a5[4])
+    assert torch.allclose(out[1], p01, atol=1e-7) and torch.allclose(out[2], p12, atol=1e-7)
 
 
 @pytest.mark.gpu

@@ -114,6 +114,42 @@ def test_full_model_train_vs_reference_glue():
     assert _close(sd['encoder.bn1.running_mean'].detach(), gold['bn/encoder.bn1.running_mean'], 1e-6)
 
 
+NEW_GEOMETRIES = {
+    # BASELINE configs[2] geometry: image, 4 instances (batch 4 per GPU in training); configs[4] geometry: video, T = 5, 3 instances
+    'image_eval_4inst': ('image', False, 1, 1, 4, (128, 128), 0, None, 'model_image_eval_4inst.npz'),
+    'image_train_4inst_b4': ('image', True, 4, 1, 4, (128, 128), 10000, 10, 'model_image_train_4inst_b4.npz'),
+    'video_eval_t5': ('video', False, 1, 5, 3, (96, 128), 0, None, 'model_video_eval_t5.npz'),
+    'video_train_t5': ('video', True, 1, 5, 3, (96, 96), 10000, 10, 'model_video_train_t5.npz'),
+}
+
+
+@pytest.mark.parametrize('case', sorted(NEW_GEOMETRIES))
+def test_oracle_matches_reference_glue_on_config2_and_config4_geometries(case):
+    """oracle/refmodel.py against the reference's own forward (+ backward) at the instance / frame counts of BASELINE configs[2] and
+    configs[4] (tests/golden/make_golden.py --new-geometries): mattes, index map, every loss, gradient norms."""
+    kind, train, b, n_f, n_inst, (h, w), it, max_inst, name = NEW_GEOMETRIES[case]
+    gold = load_golden(name)
+    sd = reference_layout_state_dict(kind, requires_grad=train)
+    batch = synth.synthetic_batch(b, n_f, n_inst, h, w, seed=DSEED, train=train, it=it, max_inst=max_inst)
+    seed_all(RSEED)
+    if train:
+        out, loss = refmodel.maggie_forward(sd, model_cfg(kind), batch, True)
+        loss['total'].backward()
+        for k, v in loss.items():
+            assert abs(float(v) - float(gold['loss/' + k])) <= 5e-5 * max(1.0, abs(float(v))), k
+        norms = dict(zip([str(n) for n in gold['grad_norm_names']], gold['grad_norms']))
+        bad = [n for n, t in sd.items() if t.grad is not None and n in norms and norms[n] > 1e-6
+               and abs(float(t.grad.double().norm()) - norms[n]) > 5e-3 * norms[n]]
+        assert not bad, bad[:5]
+    else:
+        with torch.no_grad():
+            out = refmodel.maggie_forward(sd, model_cfg(kind), batch, False)
+    for k in ('alpha_os8', 'refined_masks') + (('temp_alpha',) if 'out/temp_alpha' in gold.files else ()):
+        assert _close(out[k].detach(), gold['out/' + k], 5e-5), k
+    dm = out['detail_mask'].numpy()
+    assert np.array_equal(dm.reshape(-1), unpack_bits(gold['out/detail_mask'], dm.shape).reshape(-1))
+
+
 def test_postprocess_oracle_matches_reference_fixture():
     """oracle/postprocess.py against tests/golden/postprocess_pinned.npz (outputs of the reference's own
     maggie/utils/postprocessing.py:reverse_transform_tensor on seeded planes; generator: tests/golden/make_golden.py)."""
