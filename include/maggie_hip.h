@@ -64,6 +64,10 @@ typedef struct mg_conv_params {
     int32_t dw_dtype;    /* mg_conv_wgrad_ws only: dtype dW is written in (MG_F32 = 0 default, MG_BF16 needs a workspace) */
     int32_t stat_mode;   /* mg_conv_fprop `stats`: 0 = [MG_STAT_REPLICAS][2*Cout] sum and sum of squares (default);
                             1 = ONE row [2*Cout], column sums only (small layers: feeds the exact two-pass variance) */
+    const int32_t* m_dev; /* optional DEVICE row count (sparse head): the kernels run over min(*m_dev, M) rows, M is then the
+                            capacity the buffers were sized for. The launch is a fixed, persistent grid (tiles are walked
+                            grid-stride), so no host code ever needs the count: the detail stage stays free of device->host
+                            reads and its launches can be captured into a hipGraph. NULL: M is the row count (dense layers). */
 } mg_conv_params;
 
 int mg_conv_fprop(const mg_conv_params* p, void* stream);
@@ -108,6 +112,8 @@ typedef struct mg_rowwise_params {
     int32_t ldx, ldy, yoff, ldr, ldr2, lddy, lddx, lddres;
     int32_t act, res_mode, mask_x_pos;
     float slope, count;
+    const int32_t* m_dev; /* optional DEVICE row count (see mg_conv_params.m_dev): rows = min(*m_dev, M); BatchNorm then uses it as
+                             the sample count (exact two-pass variance), NULL: M rows */
 } mg_rowwise_params;
 
 /* stats[rep][c] += sum_m x[m,c], stats[rep][C+c] += sum_m x[m,c]^2 (fp32 [MG_STAT_REPLICAS][2C], pre-zeroed) */
@@ -369,6 +375,48 @@ int mg_metric_dtssd(const float* pred, const float* gt, const float* trimap, int
  * ------------------------------------------------------------------------------------------------------------- */
 int mg_postprocess_alpha(const float* in, int P, int Hin, int Win, int crop_h, int crop_w, int Hout, int Wout, int snap, float* out,
                          void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Sparse refinement head with a DEVICE row count (round 2).
+ * The reference's detail stage (maggie/network/decoder/resnet_inst_matt_spconv.py:196-270) sizes every spconv feature matrix from
+ * `torch.nonzero` (:206) -- a device->host read per forward, after which ~430 small launches are paced by the host. Here the site
+ * counts of the index pyramid stay in device words (mg_bits_rank: rowoff[P*H]); feature matrices are (capacity x C) buffers and
+ * every kernel below runs over min(*rows_dev, capacity) rows from a fixed grid (mg_conv_params.m_dev / mg_rowwise_params.m_dev for
+ * the implicit-GEMM and BatchNorm entry points). `*_dev` = the entry point of the same name with the extra `rows_dev` argument
+ * (NULL: identical to the plain one).
+ * ------------------------------------------------------------------------------------------------------------- */
+int mg_gather_rows_dev(const void* dense, int dtype, const int32_t* coords, int R, int n_i, int Hd, int Wd, int C, const float* mul,
+                       int mul_ninst, void* out, int ldo, int yoff, const int32_t* rows_dev, void* stream);
+int mg_gather_rows_bwd_dev(const void* dout, int dtype, int ldo, int yoff, const int32_t* coords, int R, int n_i, int Hd, int Wd, int C,
+                           const float* mul, int mul_ninst, const void* dense, float* ddense, float* dmul, const int32_t* rows_dev, void* stream);
+int mg_scatter_plane_dev(const void* vals, int dtype, int ldv, int col, const int32_t* coords, int R, int P, int H, int W, float fill,
+                         float* plane, const int32_t* rows_dev, void* stream);
+/* zero_rest != 0: the other ldv - 1 columns of every live row are zeroed (gradient of a 1-channel output padded to a 16-byte row) */
+int mg_gather_plane_dev(const float* plane, const int32_t* coords, int R, int H, int W, void* vals, int dtype, int ldv, int col,
+                        const int32_t* rows_dev, int zero_rest, void* stream);
+int mg_gather_table_dev(const int32_t* coords, int R, int ksize, int kind, const void* src_bits, const int32_t* src_wordoff, int Hs,
+                        int Ws, int32_t* nbr, const int32_t* rows_dev, void* stream);
+int mg_colstats_dev(const void* x, int dtype, int M, int C, int ld, float* stats, const int32_t* rows_dev, void* stream);
+int mg_colstats_centered_dev(const void* x, int dtype, int M, int C, int ld, float* stats, int have_sum, const int32_t* rows_dev, void* stream);
+int mg_bias_act_bwd_dev(const void* dy, const void* y, void* g, int dtype, int M, int C, float* db, const int32_t* rows_dev, void* stream);
+/* out = a * sigmoid(g): instance-specific guidance, `detail * guidance` of resnet_inst_matt_spconv.py:188-193 (a may be a channel slice
+ * of a wider buffer: row pitch lda); backward da = dout * s, dg = dout * a * s * (1 - s) */
+int mg_rows_sigmoid_mul_fwd(const void* a, int lda, const void* g, void* out, int dtype, int M, int C, const int32_t* rows_dev, void* stream);
+int mg_rows_sigmoid_mul_bwd(const void* dout, const void* a, int lda, const void* g, void* da, void* dg, int dtype, int M, int C,
+                            const int32_t* rows_dev, void* stream);
+/* out = a + b over the live rows (gradient of a feature matrix with two consumers) */
+int mg_rows_add(const void* a, int lda, const void* b, int ldb, void* out, int ldo, int dtype, int M, int C, const int32_t* rows_dev, void* stream);
+/* nn.Dropout(p) of FFNLayer (maggie/network/module/mask_attention.py:170-182) with a counter-based mask: keep = hash(state, salt, element)
+ * >= p; `state` = device int64[2] (seed, step). The backward calls the same entry point on the gradient (same state and salt). */
+int mg_rows_dropout(const void* x, void* y, int dtype, int M, int C, float p, const int64_t* state, int salt, const int32_t* rows_dev, void* stream);
+/* y = LayerNorm(x + r) * gamma + beta per row (post-norm residual of FFNLayer, mask_attention.py:176-181); rstat [M][2] = (mean, rstd).
+ * Backward: dz (= dx = dr), dgamma / dbeta [C] (zeroed here, fp32). C / (8 bf16 | 4 fp32) must be a power of two <= 64. */
+int mg_rows_add_layernorm_fwd(const void* x, const void* r, const float* gamma, const float* beta, float eps, void* y, float* rstat, int dtype,
+                              int M, int C, const int32_t* rows_dev, void* stream);
+int mg_rows_add_layernorm_bwd(const void* dy, const void* x, const void* r, const float* gamma, const float* rstat, void* dz, float* dgamma,
+                              float* dbeta, int dtype, int M, int C, const int32_t* rows_dev, void* stream);
+/* resnet_inst_matt_spconv.py:347-348 ("dummy code to prevent all zeros"): if *count == 0, set bits [y0:y1, x0:x1] of every plane */
+int mg_bits_patch_if_empty(void* bits, const int32_t* count, int P, int H, int W, int y0, int y1, int x0, int x1, void* stream);
 
 #ifdef __cplusplus
 }

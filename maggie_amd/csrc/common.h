@@ -60,6 +60,13 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     return v;
 }
 
+// Row count of a sparse-head launch: the device word when given (clamped to the capacity the buffers were sized for), else the host value.
+__device__ __forceinline__ int dev_rows(const int32_t* __restrict__ m_dev, int cap) {
+    if (!m_dev) return cap;
+    const int v = *m_dev;
+    return v < 0 ? 0 : (v < cap ? v : cap);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

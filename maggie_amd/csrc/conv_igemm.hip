@@ -56,7 +56,7 @@ static inline unsigned xcd_grid(long L) { return (unsigned)(((L + NXCD - 1) / NX
 // These layers could only fill the chip with 64x32 tiles (21 FLOP per byte staged through L2/LDS: ~100-220 TFLOP/s whatever the
 // shape); with the K split, 128x128 tiles (64 FLOP/B) reach the same block count.
 template <typename T, int BM, int BN, int KS, int MODE, bool SPLIT = false>
-__global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p, float* __restrict__ ws, int splits) {
+__device__ __forceinline__ void igemm_fprop_tile(const mg_conv_params& p, const int M, int work, float* __restrict__ ws, int splits, char* smem) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE, EPS = TR::EPS;
     constexpr int WAVES_M = TileCfg<BM, BN>::WAVES_M, WAVES_N = TileCfg<BM, BN>::WAVES_N;
@@ -65,15 +65,12 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
     constexpr int B_ITERS = (BN * 4 + 255) / 256;   // B chunks per thread (per slab)
     constexpr int ROWB = rowb<KS>();
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;                       // [BM][ROWB]
     char* sB = smem + BM * ROWB;           // [BN][ROWB]
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int ntn = (p.Cout + BN - 1) / BN;
-    int work;
-    if (!xcd_order(((p.M + BM - 1) / BM) * ntn * (SPLIT ? splits : 1), work)) return;
     int sp = 0;
     if constexpr (SPLIT) { sp = work % splits; work /= splits; }
     const int mt = work / ntn;                   // channel tiles of one row tile are consecutive: they share the A rows
@@ -97,7 +94,7 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
         int m = m0 + (t >> 2) + i * 64;
-        rc[i].ok = m < p.M;
+        rc[i].ok = m < M;
         if (MODE != MG_MODE_GATHER) {
             int hw = p.Hout * p.Wout;
             int mm = rc[i].ok ? m : 0;
@@ -295,7 +292,7 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
 
     if constexpr (SPLIT) {
         // raw partial tile -> this split's slab (16 lanes = 16 consecutive channels = one 64-byte segment per row)
-        float* slab = ws + (long)sp * p.M * p.Cout;
+        float* slab = ws + (long)sp * M * p.Cout;
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -303,7 +300,7 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int m = m0 + wm * WM + i * 16 + lg * 4 + e, c = n0 + wn * WN + j * 16 + lr;
-                    if (m < p.M && c < p.Cout) slab[(long)m * p.Cout + c] = acc[i][j][e];
+                    if (m < M && c < p.Cout) slab[(long)m * p.Cout + c] = acc[i][j][e];
                 }
         return;
     }
@@ -346,7 +343,7 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
         __syncthreads();
         for (int r = rr; r < PR; r += RPP) {
             int m = m0 + ep * PR + r;
-            if (m >= p.M || cbase >= p.Cout) continue;
+            if (m >= M || cbase >= p.Cout) continue;
             float v[CE];
 #pragma unroll
             for (int e = 0; e < CE; ++e) v[e] = sC[r * LDC + cc * CE + e];
@@ -426,6 +423,33 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
     }
 }
 
+
+// one tile per workgroup (dense layers: the row count is a host value)
+template <typename T, int BM, int BN, int KS, int MODE, bool SPLIT = false>
+__global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p, float* __restrict__ ws, int splits) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ntn = (p.Cout + BN - 1) / BN;
+    int work;
+    if (!xcd_order(((p.M + BM - 1) / BM) * ntn * (SPLIT ? splits : 1), work)) return;
+    igemm_fprop_tile<T, BM, BN, KS, MODE, SPLIT>(p, p.M, work, ws, splits, smem);
+}
+
+// Persistent form for the sparse head (p.m_dev): the row count lives in a device word, the grid is fixed (a multiple of 8 workgroups,
+// a few per CU) and every workgroup walks tiles grid-stride in the same XCD-contiguous order. No host code depends on the count.
+template <typename T, int BM, int BN, int KS, int MODE>
+__global__ __launch_bounds__(256) void igemm_fprop_persistent_kernel(const mg_conv_params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int M = dev_rows(p.m_dev, p.M);
+    const int ntn = (p.Cout + BN - 1) / BN;
+    const int L = ((M + BM - 1) / BM) * ntn;
+    const int chunk = (L + NXCD - 1) / NXCD;
+    for (int vb = blockIdx.x; vb / NXCD < chunk; vb += gridDim.x) {          // gridDim.x % 8 == 0: vb stays on this workgroup's XCD
+        const int work = (vb % NXCD) * chunk + vb / NXCD;
+        if (work < L) igemm_fprop_tile<T, BM, BN, KS, MODE, false>(p, M, work, nullptr, 1, smem);
+        __syncthreads();                                                      // the next tile's staging reuses the epilogue's LDS
+    }
+}
+
 template <typename T, int BM, int BN, int KS>
 int launch_fprop(const mg_conv_params& p, hipStream_t st) {
     dim3 grid(xcd_grid((long)((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN)));
@@ -436,6 +460,23 @@ int launch_fprop(const mg_conv_params& p, hipStream_t st) {
         hipFuncSetAttribute((const void*)igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_TCONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute((const void*)igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
+    }
+    if (p.m_dev) {
+        // fixed persistent grid: enough workgroups to fill the chip (8 per CU at most), never more than the capacity needs
+        long cap_tiles = (long)((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
+        long g = cap_tiles < 2048 ? cap_tiles : 2048;
+        dim3 pg(xcd_grid(g < 1 ? 1 : g));
+        static bool attr_set_p = false;
+        if (lds > 65536 && !attr_set_p) {
+            hipFuncSetAttribute((const void*)igemm_fprop_persistent_kernel<T, BM, BN, KS, MG_MODE_CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipFuncSetAttribute((const void*)igemm_fprop_persistent_kernel<T, BM, BN, KS, MG_MODE_GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set_p = true;
+        }
+        if (p.mode == MG_MODE_CONV) hipLaunchKernelGGL((igemm_fprop_persistent_kernel<T, BM, BN, KS, MG_MODE_CONV>), pg, dim3(256), lds, st, p);
+        else if (p.mode == MG_MODE_GATHER) hipLaunchKernelGGL((igemm_fprop_persistent_kernel<T, BM, BN, KS, MG_MODE_GATHER>), pg, dim3(256), lds, st, p);
+        else return -2;
+        MG_CHECK_LAUNCH();
+        return 0;
     }
     switch (p.mode) {
         case MG_MODE_CONV: hipLaunchKernelGGL((igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_CONV>), grid, dim3(256), lds, st, p, (float*)nullptr, 1); break;
@@ -580,7 +621,7 @@ static SplitPlan plan_splitk(const mg_conv_params& p) {
     SplitPlan sp{0, 1};
     static const int enabled = [] { const char* e = getenv("MG_FPROP_SPLITK"); return e ? atoi(e) : 1; }();
     static const long want_small = [] { const char* e = getenv("MG_FPROP_BLOCKS_SMALL"); return e ? atol(e) : 300l; }();
-    if (!enabled || p.mode == MG_MODE_GATHER || p.Cout < 64 || p.M > 8192) return sp;
+    if (!enabled || p.mode == MG_MODE_GATHER || p.Cout < 64 || p.M > 8192 || p.m_dev) return sp;
     constexpr int EPS = ElemTraits<T>::EPS;
     const int nslab = (p.R * p.S * p.Cin + EPS - 1) / EPS;
     const int nstage = (nslab + 3) / 4;
@@ -704,7 +745,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 
 template <typename T, int TCO, int TCI, int MODE>
-__global__ __launch_bounds__(256) void igemm_wgrad_kernel(const mg_conv_params p, const int rows_per_block, float* __restrict__ ws) {
+__global__ __launch_bounds__(256) void igemm_wgrad_kernel(const mg_conv_params p, int rows_per_block, float* __restrict__ ws) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
     constexpr bool BF = sizeof(T) == 2;
@@ -728,7 +769,13 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const mg_conv_params p
     // work order: (tap, ci tile) fastest, then the co tile, then the row split -- every block of one row split reads the same
     // rows of x and dY, so they run back to back on one XCD
     const int nco = (p.Cout + TCO - 1) / TCO;
-    const int nsplit = (p.M + rows_per_block - 1) / rows_per_block;
+    int nsplit = (p.M + rows_per_block - 1) / rows_per_block;        // from the capacity when the row count is a device word
+    const int M = dev_rows(p.m_dev, p.M);
+    if (p.m_dev) {
+        // same number of row splits (one workspace slab each), the rows actually present divided evenly between them
+        rows_per_block = (((M + nsplit - 1) / nsplit + KSTEP - 1) / KSTEP) * KSTEP;
+        if (rows_per_block < KSTEP) rows_per_block = KSTEP;
+    }
     int work;
     if (!xcd_order(nsplit * taps * nci * nco, work)) return;
     const int tc = work % (taps * nci);
@@ -738,8 +785,8 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const mg_conv_params p
     const int ci0 = (tc - tap * nci) * TCI;
     const int co0 = (rest - split * nco) * TCO;
     const int mbeg = split * rows_per_block;
-    const int mend = min(p.M, mbeg + rows_per_block);
-    if (mbeg >= mend) return;
+    const int mend = min(M, mbeg + rows_per_block);
+    if (mbeg >= mend && !p.m_dev) return;                            // device row count: an empty split still writes its (zero) slab
     const int ky = tap / p.S, kx = tap - ky * p.S;
     const FastDiv div_hw(MODE == MG_MODE_GATHER ? 1 : p.Hout * p.Wout), div_w(MODE == MG_MODE_GATHER ? 1 : p.Wout);
     const int sshift = p.stride == 1 ? 0 : (p.stride == 2 ? 1 : (p.stride == 4 ? 2 : -1));

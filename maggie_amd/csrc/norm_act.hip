@@ -56,10 +56,11 @@ __device__ __forceinline__ void col_block_reduce(float* sred, const float* part,
 // column statistics: stats[c] += sum_m x[m,c]; stats[C+c] += sum_m x[m,c]^2
 template <typename T>
 __global__ __launch_bounds__(NT) void colstats_kernel(const T* __restrict__ x, int M, int C, int ld, float* __restrict__ stats,
-                                                      int rows_per_block, int nrep, int only_sum, int tx, int ty) {
+                                                      int rows_per_block, int nrep, int only_sum, int tx, int ty, const int32_t* __restrict__ m_dev) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
     extern __shared__ float sred[];
+    if (m_dev) { M = dev_rows(m_dev, M); rows_per_block = (M + (int)gridDim.x - 1) / (int)gridDim.x; }
     const int ix = threadIdx.x % tx, iy = threadIdx.x / tx;
     const int cc = blockIdx.y * tx + ix;
     const bool active = iy < ty && cc * CE < C;
@@ -93,10 +94,11 @@ __global__ __launch_bounds__(NT) void colstats_kernel(const T* __restrict__ x, i
 // db[c] = sum_m g[m,c] in one pass (the torch formulation was compare + cast + multiply + cast + sum: 5 launches)
 template <typename T>
 __global__ __launch_bounds__(NT) void bias_act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ g, int M, int C,
-                                                          float* __restrict__ db, int rows_per_block, int tx, int ty) {
+                                                          float* __restrict__ db, int rows_per_block, int tx, int ty, const int32_t* __restrict__ m_dev) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
     extern __shared__ float sred[];
+    if (m_dev) { M = dev_rows(m_dev, M); rows_per_block = (M + (int)gridDim.x - 1) / (int)gridDim.x; }
     const int ix = threadIdx.x % tx, iy = threadIdx.x / tx;
     const int cc = blockIdx.y * tx + ix;
     const bool active = iy < ty && cc * CE < C;
@@ -126,15 +128,16 @@ __global__ __launch_bounds__(NT) void bias_act_bwd_kernel(const T* __restrict__ 
 // second pass of the exact two-pass variance: stats[C+c] += sum_m (x[m,c] - stats[c]/M)^2   (stats[0:C] = column sums)
 template <typename T>
 __global__ __launch_bounds__(NT) void colstats_centered_kernel(const T* __restrict__ x, int M, int C, int ld, float* __restrict__ stats,
-                                                               int rows_per_block, int tx, int ty) {
+                                                               int rows_per_block, int tx, int ty, const int32_t* __restrict__ m_dev) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
     extern __shared__ float sred[];
+    if (m_dev) { M = dev_rows(m_dev, M); rows_per_block = (M + (int)gridDim.x - 1) / (int)gridDim.x; }
     const int ix = threadIdx.x % tx, iy = threadIdx.x / tx;
     const int cc = blockIdx.y * tx + ix;
     const bool active = iy < ty && cc * CE < C;
     float part[CE], mu[CE];
-    const float inv_m = 1.f / (float)M;
+    const float inv_m = M > 0 ? 1.f / (float)M : 0.f;
 #pragma unroll
     for (int e = 0; e < CE; ++e) { part[e] = 0.f; mu[e] = active ? stats[cc * CE + e] * inv_m : 0.f; }
     const int mbeg = blockIdx.x * rows_per_block, mend = min(M, mbeg + rows_per_block);
@@ -164,10 +167,18 @@ __global__ __launch_bounds__(NT) void colstats_centered_kernel(const T* __restri
 __global__ void bn_finalize_kernel(const float* __restrict__ stats, int nrep, const float* __restrict__ count_ptr, float count, int C, int centered,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
                                    float* running_var, float momentum, float eps, float* __restrict__ scale,
-                                   float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ invstd_out) {
+                                   float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                   const int32_t* __restrict__ m_dev) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float n = count_ptr ? *count_ptr : count;
+    if (m_dev) {
+        n = (float)dev_rows(m_dev, (int)count);
+        if (n <= 0.f) {                                   // no active row at all: identity statistics, running stats untouched
+            scale[c] = gamma ? gamma[c] : 1.f; shift[c] = beta ? beta[c] : 0.f; mean_out[c] = 0.f; invstd_out[c] = 1.f;
+            return;
+        }
+    }
     float s1 = 0.f, s2 = 0.f;
     for (int r = 0; r < nrep; ++r) { s1 += stats[(size_t)r * 2 * C + c]; s2 += stats[(size_t)r * 2 * C + C + c]; }
     float mean = s1 / n;
@@ -205,7 +216,7 @@ __global__ __launch_bounds__(NT) void affine_act_kernel(const mg_rowwise_params 
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
     const int cpr = p.C / CE;
-    const long total = (long)p.M * cpr;
+    const long total = (long)dev_rows(p.m_dev, p.M) * cpr;
     const T* __restrict__ x = (const T*)p.x;
     const T* __restrict__ r1 = (const T*)p.res;
     const T* __restrict__ r2 = (const T*)p.res2;
@@ -290,6 +301,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const mg_rowwise_para
     constexpr int CE = TR::CE;
     extern __shared__ float sred[];
     const int C = p.C;
+    const int M = dev_rows(p.m_dev, p.M);
+    if (p.m_dev) rows_per_block = (M + (int)gridDim.x - 1) / (int)gridDim.x;
     const int ix = threadIdx.x % tx, iy = threadIdx.x / tx;
     const int cc = blockIdx.y * tx + ix;
     const bool active = iy < ty && cc * CE < C;
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const mg_rowwise_para
         part[e] = 0.f; part[CE + e] = 0.f;
         mu[e] = active ? p.mean[c0 + e] : 0.f; is[e] = active ? p.invstd[c0 + e] : 0.f;
     }
-    const int mbeg = blockIdx.x * rows_per_block, mend = min(p.M, mbeg + rows_per_block);
+    const int mbeg = blockIdx.x * rows_per_block, mend = min(M, mbeg + rows_per_block);
     if (active) {
         int m = mbeg + iy;
         for (; m + ty < mend; m += 2 * ty) {                 // two independent row groups in flight
@@ -331,8 +344,10 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const mg_rowwise_param
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
     const int cpr = p.C / CE;
-    const long total = (long)p.M * cpr;
-    const float inv_n = 1.f / (p.count_ptr ? *p.count_ptr : p.count);
+    const int Mrows = dev_rows(p.m_dev, p.M);
+    const long total = (long)Mrows * cpr;
+    // sample count: the SyncBN global count when given, else the live rows of this rank (device word), else the host value
+    const float inv_n = p.count_ptr ? 1.f / *p.count_ptr : (p.m_dev ? (Mrows > 0 ? 1.f / (float)Mrows : 0.f) : 1.f / p.count);
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
         int m = (int)(i / cpr), cc = (int)(i - (long)m * cpr);
         int c0 = cc * CE;
@@ -404,20 +419,28 @@ inline int grid_for(long total) {
 
 }  // namespace
 
-extern "C" int mg_colstats(const void* x, int dtype, int M, int C, int ld, float* stats, void* stream) {
+extern "C" int mg_colstats_dev(const void* x, int dtype, int M, int C, int ld, float* stats, const int32_t* m_dev, void* stream) {
     if (M <= 0) return 0;
     const int ce = dtype == MG_BF16 ? 8 : 4;
     if (C % ce || ld % ce) return -3;
     const ColGeom g = col_geom(M, C, ce, 1024);
     const size_t lds = (size_t)g.ty * g.tx * 2 * ce * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MG_BF16) hipLaunchKernelGGL(colstats_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const bf16raw*)x, M, C, ld, stats, g.rpb, MG_STAT_REPLICAS, 0, g.tx, g.ty);
-    else hipLaunchKernelGGL(colstats_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const float*)x, M, C, ld, stats, g.rpb, MG_STAT_REPLICAS, 0, g.tx, g.ty);
+    if (dtype == MG_BF16) hipLaunchKernelGGL(colstats_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const bf16raw*)x, M, C, ld, stats, g.rpb, MG_STAT_REPLICAS, 0, g.tx, g.ty, m_dev);
+    else hipLaunchKernelGGL(colstats_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const float*)x, M, C, ld, stats, g.rpb, MG_STAT_REPLICAS, 0, g.tx, g.ty, m_dev);
     MG_CHECK_LAUNCH();
     return 0;
 }
 
+extern "C" int mg_colstats(const void* x, int dtype, int M, int C, int ld, float* stats, void* stream) {
+    return mg_colstats_dev(x, dtype, M, C, ld, stats, nullptr, stream);
+}
+
+extern "C" int mg_bias_act_bwd_dev(const void* dy, const void* y, void* g, int dtype, int M, int C, float* db, const int32_t* m_dev, void* stream);
 extern "C" int mg_bias_act_bwd(const void* dy, const void* y, void* g, int dtype, int M, int C, float* db, void* stream) {
+    return mg_bias_act_bwd_dev(dy, y, g, dtype, M, C, db, nullptr, stream);
+}
+extern "C" int mg_bias_act_bwd_dev(const void* dy, const void* y, void* g, int dtype, int M, int C, float* db, const int32_t* m_dev, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (db) { hipError_t e = mg_zero_words(db, C, st); if (e != hipSuccess) return (int)e; }
     if (M <= 0) return 0;
@@ -426,13 +449,17 @@ extern "C" int mg_bias_act_bwd(const void* dy, const void* y, void* g, int dtype
     if (y && !g) return -3;
     const ColGeom gm = col_geom(M, C, ce, 512);          // like MG_BN_RB: enough blocks to stream at HBM rate, few enough atomics per channel
     const size_t lds = (size_t)gm.ty * gm.tx * ce * sizeof(float);
-    if (dtype == MG_BF16) hipLaunchKernelGGL(bias_act_bwd_kernel<bf16raw>, dim3(gm.rb, gm.groups), dim3(NT), lds, st, (const bf16raw*)dy, (const bf16raw*)y, (bf16raw*)g, M, C, db, gm.rpb, gm.tx, gm.ty);
-    else hipLaunchKernelGGL(bias_act_bwd_kernel<float>, dim3(gm.rb, gm.groups), dim3(NT), lds, st, (const float*)dy, (const float*)y, (float*)g, M, C, db, gm.rpb, gm.tx, gm.ty);
+    if (dtype == MG_BF16) hipLaunchKernelGGL(bias_act_bwd_kernel<bf16raw>, dim3(gm.rb, gm.groups), dim3(NT), lds, st, (const bf16raw*)dy, (const bf16raw*)y, (bf16raw*)g, M, C, db, gm.rpb, gm.tx, gm.ty, m_dev);
+    else hipLaunchKernelGGL(bias_act_bwd_kernel<float>, dim3(gm.rb, gm.groups), dim3(NT), lds, st, (const float*)dy, (const float*)y, (float*)g, M, C, db, gm.rpb, gm.tx, gm.ty, m_dev);
     MG_CHECK_LAUNCH();
     return 0;
 }
 
+extern "C" int mg_colstats_centered_dev(const void* x, int dtype, int M, int C, int ld, float* stats, int have_sum, const int32_t* m_dev, void* stream);
 extern "C" int mg_colstats_centered(const void* x, int dtype, int M, int C, int ld, float* stats, int have_sum, void* stream) {
+    return mg_colstats_centered_dev(x, dtype, M, C, ld, stats, have_sum, nullptr, stream);
+}
+extern "C" int mg_colstats_centered_dev(const void* x, int dtype, int M, int C, int ld, float* stats, int have_sum, const int32_t* m_dev, void* stream) {
     if (M <= 0) return 0;
     const int ce = dtype == MG_BF16 ? 8 : 4;
     if (C % ce || ld % ce) return -3;
@@ -442,12 +469,21 @@ extern "C" int mg_colstats_centered(const void* x, int dtype, int M, int C, int 
     // `stats` must arrive zeroed (the caller hands out slices of a per-step zero arena): pass 1 adds the column sums only
     // (skipped when the producing conv's epilogue already did: have_sum), pass 2 the centred second moments
     if (dtype == MG_BF16) {
-        if (!have_sum) hipLaunchKernelGGL(colstats_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const bf16raw*)x, M, C, ld, stats, g.rpb, 1, 1, g.tx, g.ty);
-        hipLaunchKernelGGL(colstats_centered_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const bf16raw*)x, M, C, ld, stats, g.rpb, g.tx, g.ty);
+        if (!have_sum) hipLaunchKernelGGL(colstats_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const bf16raw*)x, M, C, ld, stats, g.rpb, 1, 1, g.tx, g.ty, m_dev);
+        hipLaunchKernelGGL(colstats_centered_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const bf16raw*)x, M, C, ld, stats, g.rpb, g.tx, g.ty, m_dev);
     } else {
-        if (!have_sum) hipLaunchKernelGGL(colstats_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const float*)x, M, C, ld, stats, g.rpb, 1, 1, g.tx, g.ty);
-        hipLaunchKernelGGL(colstats_centered_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const float*)x, M, C, ld, stats, g.rpb, g.tx, g.ty);
+        if (!have_sum) hipLaunchKernelGGL(colstats_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const float*)x, M, C, ld, stats, g.rpb, 1, 1, g.tx, g.ty, m_dev);
+        hipLaunchKernelGGL(colstats_centered_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const float*)x, M, C, ld, stats, g.rpb, g.tx, g.ty, m_dev);
     }
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+static int bn_finalize_launch(const float* stats, int nrep, const float* count_ptr, float count, int C, int centered, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
+                              float* mean_out, float* invstd_out, const int32_t* m_dev, void* stream) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, nrep, count_ptr, count, C, centered, gamma,
+                       beta, running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out, m_dev);
     MG_CHECK_LAUNCH();
     return 0;
 }
@@ -455,10 +491,8 @@ extern "C" int mg_colstats_centered(const void* x, int dtype, int M, int C, int 
 extern "C" int mg_bn_finalize(const float* stats, int nrep, const float* count_ptr, float count, int C, int centered, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
                               float* mean_out, float* invstd_out, void* stream) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, nrep, count_ptr, count, C, centered, gamma,
-                       beta, running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out);
-    MG_CHECK_LAUNCH();
-    return 0;
+    return bn_finalize_launch(stats, nrep, count_ptr, count, C, centered, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, mean_out,
+                              invstd_out, nullptr, stream);
 }
 
 extern "C" int mg_bn_fold(int C, const float* gamma, const float* beta, const float* running_mean, const float* running_var,
@@ -525,6 +559,18 @@ extern "C" int mg_bn_train_fwd(const mg_rowwise_params* p_in, float* stats_ws, i
     if (!stats_in && !own) return -3;
     const float* stats = stats_in;
     int nrep = stats_in_rows, centered = 0;
+    if (p.m_dev) {
+        // sparse head: the row count is a device word -> always the exact two-pass variance over min(*m_dev, M) rows (no host knowledge of
+        // the count is needed to choose a path), statistics in `own` [2C]
+        if (!own) return -3;
+        if (!ws_zeroed) { hipError_t e = mg_zero_words(own, 2 * C, st); if (e != hipSuccess) return (int)e; }
+        if (p.M > 0) { rc = mg_colstats_centered_dev(p.x, p.dtype, p.M, C, p.ldx, own, 0, p.m_dev, stream); if (rc) return rc; }
+        rc = bn_finalize_launch(own, 1, nullptr, (float)p.M, C, 1, gamma, beta, running_mean, running_var, momentum, eps, outs, outs + C, outs + 2 * C,
+                                outs + 3 * C, p.m_dev, stream);
+        if (rc) return rc;
+        p.scale = outs; p.shift = outs + C;
+        return mg_affine_act(&p, stream);
+    }
     if (exact) {
         // two-pass variance; a 1-row stats_in already carries the column sums from the producing conv's epilogue
         float* row = stats_in ? (float*)stats_in : own;

@@ -258,7 +258,9 @@ __device__ __forceinline__ int rank_of(const u64* __restrict__ bits, const int* 
 // tap (ky,kx) valid iff (y+1-ky) even ...);  KIND 2: strided gather (rows = coarse sites, source = fine level, i = 2o-1+k)
 template <int KIND>
 __global__ __launch_bounds__(256) void table_kernel(const int* __restrict__ coords, int R, int ksize, const u64* __restrict__ sbits,
-                                                    const int* __restrict__ swordoff, int Hs, int Ws, int Wws, int* __restrict__ nbr) {
+                                                    const int* __restrict__ swordoff, int Hs, int Ws, int Wws, int* __restrict__ nbr,
+                                                    const int32_t* __restrict__ r_dev) {
+    R = dev_rows(r_dev, R);
     const int taps = ksize * ksize;
     const int total = R * taps;
     const int c = ksize / 2;
@@ -378,8 +380,14 @@ extern "C" int mg_bits_coords(const void* bits, const int32_t* wordoff, int P, i
     return 0;
 }
 
+extern "C" int mg_gather_table_dev(const int32_t* coords, int R, int ksize, int kind, const void* src_bits, const int32_t* src_wordoff, int Hs,
+                                   int Ws, int32_t* nbr, const int32_t* r_dev, void* stream);
 extern "C" int mg_gather_table(const int32_t* coords, int R, int ksize, int kind, const void* src_bits, const int32_t* src_wordoff, int Hs,
                                int Ws, int32_t* nbr, void* stream) {
+    return mg_gather_table_dev(coords, R, ksize, kind, src_bits, src_wordoff, Hs, Ws, nbr, nullptr, stream);
+}
+extern "C" int mg_gather_table_dev(const int32_t* coords, int R, int ksize, int kind, const void* src_bits, const int32_t* src_wordoff, int Hs,
+                                   int Ws, int32_t* nbr, const int32_t* r_dev, void* stream) {
     if (R <= 0) return 0;
     if (kind < 0 || kind > 2) return -2;
     long total = (long)R * ksize * ksize;
@@ -387,9 +395,9 @@ extern "C" int mg_gather_table(const int32_t* coords, int R, int ksize, int kind
     dim3 g(grid_for(total, 256)), b(256);
     hipStream_t st = (hipStream_t)stream;
     const int Wws = (Ws + 63) / 64;
-    if (kind == 0) hipLaunchKernelGGL(table_kernel<0>, g, b, 0, st, coords, R, ksize, (const u64*)src_bits, src_wordoff, Hs, Ws, Wws, nbr);
-    else if (kind == 1) hipLaunchKernelGGL(table_kernel<1>, g, b, 0, st, coords, R, ksize, (const u64*)src_bits, src_wordoff, Hs, Ws, Wws, nbr);
-    else hipLaunchKernelGGL(table_kernel<2>, g, b, 0, st, coords, R, ksize, (const u64*)src_bits, src_wordoff, Hs, Ws, Wws, nbr);
+    if (kind == 0) hipLaunchKernelGGL(table_kernel<0>, g, b, 0, st, coords, R, ksize, (const u64*)src_bits, src_wordoff, Hs, Ws, Wws, nbr, r_dev);
+    else if (kind == 1) hipLaunchKernelGGL(table_kernel<1>, g, b, 0, st, coords, R, ksize, (const u64*)src_bits, src_wordoff, Hs, Ws, Wws, nbr, r_dev);
+    else hipLaunchKernelGGL(table_kernel<2>, g, b, 0, st, coords, R, ksize, (const u64*)src_bits, src_wordoff, Hs, Ws, Wws, nbr, r_dev);
     MG_CHECK_LAUNCH();
     return 0;
 }

@@ -17,10 +17,11 @@ inline int grid_for(long total) { long b = (total + NT - 1) / NT; return (int)(b
 template <typename T>
 __global__ __launch_bounds__(NT) void gather_rows_kernel(const T* __restrict__ dense, const int* __restrict__ coords, int R, int n_i, int Hd,
                                                          int Wd, int C, const float* __restrict__ mul, int mul_ninst, T* __restrict__ out,
-                                                         int ldo, int yoff) {
+                                                         int ldo, int yoff, const int32_t* __restrict__ r_dev) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
     const int cpr = C / CE;
+    R = dev_rows(r_dev, R);
     const long total = (long)R * cpr;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
         int r = (int)(i / cpr), cc = (int)(i - (long)r * cpr);
@@ -68,10 +69,11 @@ template <typename T>
 __global__ __launch_bounds__(NT) void gather_rows_bwd_kernel(const T* __restrict__ dout, int ldo, int yoff, const int* __restrict__ coords,
                                                              int R, int n_i, int Hd, int Wd, int C, const float* __restrict__ mul,
                                                              int mul_ninst, const T* __restrict__ dense, float* __restrict__ ddense,
-                                                             float* __restrict__ dmul) {
+                                                             float* __restrict__ dmul, const int32_t* __restrict__ r_dev) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
     const int cpr = C / CE;
+    R = dev_rows(r_dev, R);
     const int tid = blockIdx.x * NT + threadIdx.x;
     const int nthreads = gridDim.x * NT;
     const int cc = tid % cpr;
@@ -160,7 +162,8 @@ __global__ __launch_bounds__(NT) void gather_rows_bwd_dense_kernel(const T* __re
 // plane[p, y, x] = vals[r, col]  (plane pre-filled by the caller's fill kernel)
 template <typename T>
 __global__ __launch_bounds__(NT) void scatter_plane_kernel(const T* __restrict__ vals, int ldv, int col, const int* __restrict__ coords,
-                                                           int R, int H, int W, float* __restrict__ plane) {
+                                                           int R, int H, int W, float* __restrict__ plane, const int32_t* __restrict__ r_dev) {
+    R = dev_rows(r_dev, R);
     for (int r = blockIdx.x * NT + threadIdx.x; r < R; r += gridDim.x * NT) {
         int p = coords[(long)r * 3], y = coords[(long)r * 3 + 1], x = coords[(long)r * 3 + 2];
         plane[((long)p * H + y) * W + x] = ElemTraits<T>::ld(vals + (long)r * ldv + col);
@@ -169,9 +172,14 @@ __global__ __launch_bounds__(NT) void scatter_plane_kernel(const T* __restrict__
 
 template <typename T>
 __global__ __launch_bounds__(NT) void gather_plane_kernel(const float* __restrict__ plane, const int* __restrict__ coords, int R, int H, int W,
-                                                          T* __restrict__ vals, int ldv, int col) {
+                                                          T* __restrict__ vals, int ldv, int col, const int32_t* __restrict__ r_dev,
+                                                          int zero_rest) {
+    R = dev_rows(r_dev, R);
     for (int r = blockIdx.x * NT + threadIdx.x; r < R; r += gridDim.x * NT) {
         int p = coords[(long)r * 3], y = coords[(long)r * 3 + 1], x = coords[(long)r * 3 + 2];
+        if (zero_rest) {                                    // the other (padding) columns of the row carry no gradient
+            for (int c = 0; c < ldv; ++c) if (c != col) ElemTraits<T>::st(vals + (long)r * ldv + c, 0.f);
+        }
         ElemTraits<T>::st(vals + (long)r * ldv + col, plane[((long)p * H + y) * W + x]);
     }
 }
@@ -357,28 +365,40 @@ __global__ __launch_bounds__(NT) void upsample_tanh_bwd_tile_kernel(const float*
 
 }  // namespace
 
+extern "C" int mg_gather_rows_dev(const void* dense, int dtype, const int32_t* coords, int R, int n_i, int Hd, int Wd, int C, const float* mul,
+                                  int mul_ninst, void* out, int ldo, int yoff, const int32_t* r_dev, void* stream);
 extern "C" int mg_gather_rows(const void* dense, int dtype, const int32_t* coords, int R, int n_i, int Hd, int Wd, int C, const float* mul,
                               int mul_ninst, void* out, int ldo, int yoff, void* stream) {
+    return mg_gather_rows_dev(dense, dtype, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, out, ldo, yoff, nullptr, stream);
+}
+extern "C" int mg_gather_rows_dev(const void* dense, int dtype, const int32_t* coords, int R, int n_i, int Hd, int Wd, int C, const float* mul,
+                                  int mul_ninst, void* out, int ldo, int yoff, const int32_t* r_dev, void* stream) {
     if (R <= 0) return 0;
     const int ce = dtype == MG_BF16 ? 8 : 4;
     if (C % ce || ldo % ce || yoff % ce) return -3;
     long total = (long)R * (C / ce);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MG_BF16) hipLaunchKernelGGL(gather_rows_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const bf16raw*)dense, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, (bf16raw*)out, ldo, yoff);
-    else hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, st, (const float*)dense, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, (float*)out, ldo, yoff);
+    if (dtype == MG_BF16) hipLaunchKernelGGL(gather_rows_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const bf16raw*)dense, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, (bf16raw*)out, ldo, yoff, r_dev);
+    else hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, st, (const float*)dense, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, (float*)out, ldo, yoff, r_dev);
     MG_CHECK_LAUNCH();
     return 0;
 }
 
+extern "C" int mg_gather_rows_bwd_dev(const void* dout, int dtype, int ldo, int yoff, const int32_t* coords, int R, int n_i, int Hd, int Wd, int C,
+                                      const float* mul, int mul_ninst, const void* dense, float* ddense, float* dmul, const int32_t* r_dev, void* stream);
 extern "C" int mg_gather_rows_bwd(const void* dout, int dtype, int ldo, int yoff, const int32_t* coords, int R, int n_i, int Hd, int Wd, int C,
                                   const float* mul, int mul_ninst, const void* dense, float* ddense, float* dmul, void* stream) {
+    return mg_gather_rows_bwd_dev(dout, dtype, ldo, yoff, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, dense, ddense, dmul, nullptr, stream);
+}
+extern "C" int mg_gather_rows_bwd_dev(const void* dout, int dtype, int ldo, int yoff, const int32_t* coords, int R, int n_i, int Hd, int Wd, int C,
+                                      const float* mul, int mul_ninst, const void* dense, float* ddense, float* dmul, const int32_t* r_dev, void* stream) {
     if (R <= 0) return 0;
     const int ce = dtype == MG_BF16 ? 8 : 4;
     if (C % ce || ldo % ce || yoff % ce) return -3;
     long total = (long)R * (C / ce);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MG_BF16) hipLaunchKernelGGL(gather_rows_bwd_kernel<bf16raw>, dim3(grid_for(total) > 512 ? 512 : grid_for(total)), dim3(NT), 0, st, (const bf16raw*)dout, ldo, yoff, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, (const bf16raw*)dense, ddense, dmul);
-    else hipLaunchKernelGGL(gather_rows_bwd_kernel<float>, dim3(grid_for(total) > 512 ? 512 : grid_for(total)), dim3(NT), 0, st, (const float*)dout, ldo, yoff, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, (const float*)dense, ddense, dmul);
+    if (dtype == MG_BF16) hipLaunchKernelGGL(gather_rows_bwd_kernel<bf16raw>, dim3(grid_for(total) > 512 ? 512 : grid_for(total)), dim3(NT), 0, st, (const bf16raw*)dout, ldo, yoff, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, (const bf16raw*)dense, ddense, dmul, r_dev);
+    else hipLaunchKernelGGL(gather_rows_bwd_kernel<float>, dim3(grid_for(total) > 512 ? 512 : grid_for(total)), dim3(NT), 0, st, (const float*)dout, ldo, yoff, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, (const float*)dense, ddense, dmul, r_dev);
     MG_CHECK_LAUNCH();
     return 0;
 }
@@ -396,26 +416,38 @@ extern "C" int mg_gather_rows_bwd_dense(const void* dout, int dtype, int ldo, in
     return 0;
 }
 
+extern "C" int mg_scatter_plane_dev(const void* vals, int dtype, int ldv, int col, const int32_t* coords, int R, int P, int H, int W, float fill,
+                                    float* plane, const int32_t* r_dev, void* stream);
 extern "C" int mg_scatter_plane(const void* vals, int dtype, int ldv, int col, const int32_t* coords, int R, int P, int H, int W, float fill,
                                 float* plane, void* stream) {
+    return mg_scatter_plane_dev(vals, dtype, ldv, col, coords, R, P, H, W, fill, plane, nullptr, stream);
+}
+extern "C" int mg_scatter_plane_dev(const void* vals, int dtype, int ldv, int col, const int32_t* coords, int R, int P, int H, int W, float fill,
+                                    float* plane, const int32_t* r_dev, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     long n = (long)P * H * W;
     if (n <= 0) return 0;
     hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(NT), 0, st, plane, n, fill);
     if (R > 0) {
-        if (dtype == MG_BF16) hipLaunchKernelGGL(scatter_plane_kernel<bf16raw>, dim3(grid_for(R)), dim3(NT), 0, st, (const bf16raw*)vals, ldv, col, coords, R, H, W, plane);
-        else hipLaunchKernelGGL(scatter_plane_kernel<float>, dim3(grid_for(R)), dim3(NT), 0, st, (const float*)vals, ldv, col, coords, R, H, W, plane);
+        if (dtype == MG_BF16) hipLaunchKernelGGL(scatter_plane_kernel<bf16raw>, dim3(grid_for(R)), dim3(NT), 0, st, (const bf16raw*)vals, ldv, col, coords, R, H, W, plane, r_dev);
+        else hipLaunchKernelGGL(scatter_plane_kernel<float>, dim3(grid_for(R)), dim3(NT), 0, st, (const float*)vals, ldv, col, coords, R, H, W, plane, r_dev);
     }
     MG_CHECK_LAUNCH();
     return 0;
 }
 
+extern "C" int mg_gather_plane_dev(const float* plane, const int32_t* coords, int R, int H, int W, void* vals, int dtype, int ldv, int col,
+                                   const int32_t* r_dev, int zero_rest, void* stream);
 extern "C" int mg_gather_plane(const float* plane, const int32_t* coords, int R, int H, int W, void* vals, int dtype, int ldv, int col,
                                void* stream) {
+    return mg_gather_plane_dev(plane, coords, R, H, W, vals, dtype, ldv, col, nullptr, 0, stream);
+}
+extern "C" int mg_gather_plane_dev(const float* plane, const int32_t* coords, int R, int H, int W, void* vals, int dtype, int ldv, int col,
+                                   const int32_t* r_dev, int zero_rest, void* stream) {
     if (R <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MG_BF16) hipLaunchKernelGGL(gather_plane_kernel<bf16raw>, dim3(grid_for(R)), dim3(NT), 0, st, plane, coords, R, H, W, (bf16raw*)vals, ldv, col);
-    else hipLaunchKernelGGL(gather_plane_kernel<float>, dim3(grid_for(R)), dim3(NT), 0, st, plane, coords, R, H, W, (float*)vals, ldv, col);
+    if (dtype == MG_BF16) hipLaunchKernelGGL(gather_plane_kernel<bf16raw>, dim3(grid_for(R)), dim3(NT), 0, st, plane, coords, R, H, W, (bf16raw*)vals, ldv, col, r_dev, zero_rest);
+    else hipLaunchKernelGGL(gather_plane_kernel<float>, dim3(grid_for(R)), dim3(NT), 0, st, plane, coords, R, H, W, (float*)vals, ldv, col, r_dev, zero_rest);
     MG_CHECK_LAUNCH();
     return 0;
 }

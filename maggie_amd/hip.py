@@ -36,6 +36,7 @@ class ConvParams(ctypes.Structure):
         ('ldr2', ctypes.c_int32),
         ('act', ctypes.c_int32), ('pre_act', ctypes.c_int32), ('res_mode', ctypes.c_int32),
         ('slope', ctypes.c_float), ('dw_dtype', ctypes.c_int32), ('stat_mode', ctypes.c_int32),
+        ('m_dev', ctypes.c_void_p),
     ]
 
 
@@ -135,6 +136,7 @@ class RowwiseParams(ctypes.Structure):
         ('ldr2', ctypes.c_int32), ('lddy', ctypes.c_int32), ('lddx', ctypes.c_int32), ('lddres', ctypes.c_int32),
         ('act', ctypes.c_int32), ('res_mode', ctypes.c_int32), ('mask_x_pos', ctypes.c_int32),
         ('slope', ctypes.c_float), ('count', ctypes.c_float),
+        ('m_dev', ctypes.c_void_p),
     ]
 
 

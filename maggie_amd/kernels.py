@@ -42,7 +42,7 @@ def _conv_params(x, w, y, mode, N, Hin, Win, Hout, Wout, R, S, stride, pad, dil,
 
 def conv_fprop(x, w, *, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=None, Wout=None, R=1, S=1, stride=1, pad=0, dil=1,
                M=None, nbr=None, scale=None, shift=None, res=None, res_mode=1, res2=None, act=ACT_NONE, pre_act=False,
-               slope=0.2, stats=None, out=None, yoff=0, cout=None):
+               slope=0.2, stats=None, out=None, yoff=0, cout=None, rows=None):
     """Y = epilogue(implicit GEMM). x: (..., Cin) channel-contiguous; w: (Cout, R*S, Cin) same dtype.
     Dense modes: rows of x are (n, h, w) of an (N, Hin, Win) map; gather mode: rows of x are sparse sites, `nbr` (M, R*S).
     `out`/`yoff` let the result land in a channel slice of a wider buffer (zero-copy concat)."""
@@ -74,8 +74,9 @@ def conv_fprop(x, w, *, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=None, Wout=None,
     p = _conv_params(x, w, out, mode, N, Hin, Win, Hout, Wout, R, S, stride, pad, dil, M, Cin, Cout, nbr, scale, shift,
                      res, res_mode, res2, act, pre_act, slope, stats, yoff)
     p.stat_mode = stat_mode
+    p.m_dev = hip.ptr(rows)                    # device row count (sparse head): M is then the capacity, the launch a persistent grid
     work, tag = 2.0 * M * Cout * R * S * Cin, ('bf16' if x.dtype == torch.bfloat16 else 'f32', mode, Cout, R * S * Cin, M)
-    if mode != MODE_GATHER and 0 < M <= 8192 and Cout >= 64:
+    if mode != MODE_GATHER and 0 < M <= 8192 and Cout >= 64 and rows is None:
         # deep layers with few rows: the library may split K over several blocks per tile (mg_conv_fprop_ws)
         need = _fprop_workspace_fn()(ctypes.byref(p))
         if need > 0:
@@ -98,7 +99,7 @@ def _fprop_workspace_fn():
 
 
 def conv_wgrad(x, dy, *, cout, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=1, Wout=1, R=1, S=1, stride=1, pad=0, dil=1,
-               M=None, nbr=None, yoff=0, out=None, out_dtype=torch.float32):
+               M=None, nbr=None, yoff=0, out=None, out_dtype=torch.float32, rows=None):
     """dW[co, tap, ci] = sum_m dY[m, co] X[src(m,tap), ci]; (Cout, R*S, Cin) accumulated in fp32 and written as
     `out_dtype` (fp32 / bf16 -- the converting reduce saves a separate cast pass). `dy` may be a channel slice (yoff) of
     a wider buffer."""
@@ -112,6 +113,7 @@ def conv_wgrad(x, dy, *, cout, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=1, Wout=1
     if out is not None:
         out_dtype = out.dtype
     p.dw_dtype = hip.BF16 if out_dtype == torch.bfloat16 else hip.F32
+    p.m_dev = hip.ptr(rows)
     lib = hip.lib()
     lib.mg_conv_wgrad_workspace.restype = ctypes.c_long
     need = lib.mg_conv_wgrad_workspace(ctypes.byref(p)) if M > 0 else 0
@@ -161,13 +163,14 @@ def colstats(x, stats=None):
     return stats
 
 
-def bias_act_bwd(dy, y, want_db):
-    """g = dy * (y > 0) (y None: g = dy) and db = g.sum(0) in fp32 (None unless want_db) -- one pass (mg_bias_act_bwd)."""
+def bias_act_bwd(dy, y, want_db, rows=None):
+    """g = dy * (y > 0) (y None: g = dy) and db = g.sum(0) in fp32 (None unless want_db) -- one pass (mg_bias_act_bwd).
+    `rows`: device row count (int32 tensor), dy.shape[0] is then the capacity."""
     M, C = dy.shape
     g = torch.empty_like(dy) if y is not None else dy
     db = torch.empty(C, dtype=torch.float32, device=dy.device) if want_db else None
-    hip.call('mg_bias_act_bwd', hip.ptr(dy), hip.ptr(y), hip.ptr(g if y is not None else None), c_int(hip.dtype_code(dy)), c_int(M), c_int(C),
-             hip.ptr(db), hip.stream())
+    hip.call('mg_bias_act_bwd_dev', hip.ptr(dy), hip.ptr(y), hip.ptr(g if y is not None else None), c_int(hip.dtype_code(dy)), c_int(M), c_int(C),
+             hip.ptr(db), hip.ptr(rows), hip.stream())
     return g, db
 
 
@@ -212,7 +215,7 @@ def _rowwise(x, M, C):
     return p
 
 
-def affine_act(x, scale=None, shift=None, res=None, res_mode=1, res2=None, act=ACT_NONE, slope=0.2, H=1, W=1, out=None, yoff=0):
+def affine_act(x, scale=None, shift=None, res=None, res_mode=1, res2=None, act=ACT_NONE, slope=0.2, H=1, W=1, out=None, yoff=0, rows=None):
     """y = act(x*scale + shift + res) + res2 over rows x channels."""
     M, C = x.shape[0], x.shape[-1]
     if out is None:
@@ -224,12 +227,13 @@ def affine_act(x, scale=None, shift=None, res=None, res_mode=1, res2=None, act=A
     p.res, p.ldr, p.res_mode = hip.ptr(res), (_ld(res) if res is not None else 0), (res_mode if res is not None else 0)
     p.res2, p.ldr2 = hip.ptr(res2), (_ld(res2) if res2 is not None else 0)
     p.act, p.slope, p.H, p.W = act, slope, H, W
+    p.m_dev = hip.ptr(rows)
     hip.call('mg_affine_act', ctypes.byref(p), hip.stream())
     return out
 
 
 def bn_backward(dy, y, x, scale, mean, invstd, count, act=ACT_NONE, slope=0.2, want_dres=False, mask_x_pos=False, yoff=0,
-                count_ptr=None, sums=None, want_dx=True, reduce_only=False, apply_only=False):
+                count_ptr=None, sums=None, want_dx=True, reduce_only=False, apply_only=False, rows=None):
     """BatchNorm(+activation) backward over rows x channels.
     Returns (dx, dres, sums) with sums = [sum g, sum g*xhat] (= dbeta, dgamma)."""
     M, C = x.shape[0], x.shape[-1]
@@ -243,6 +247,7 @@ def bn_backward(dy, y, x, scale, mean, invstd, count, act=ACT_NONE, slope=0.2, w
     p.sums = hip.ptr(sums)
     p.count, p.count_ptr = float(count), hip.ptr(count_ptr)
     p.act, p.slope, p.mask_x_pos = act, slope, int(mask_x_pos)
+    p.m_dev = hip.ptr(rows)
     dx = dres = None
     if not apply_only:
         hip.call('mg_bn_bwd_reduce', ctypes.byref(p), hip.stream())
@@ -259,7 +264,7 @@ def bn_backward(dy, y, x, scale, mean, invstd, count, act=ACT_NONE, slope=0.2, w
 
 
 def bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, act, slope, res=None, res_mode=1, H=1, W=1, stats=None,
-                 exact=False, stats_ws=None):
+                 exact=False, stats_ws=None, rows=None):
     """Training BatchNorm forward in ONE C call (statistics -> finalize -> apply): -> y, outs = scale|shift|mean|invstd (4C).
     `stats_ws`: zeroed scratch for the statistics ([2C] with `exact`, else [STAT_REPLICAS * 2C]); None: allocated and zeroed here."""
     M, C = x.shape[0], x.shape[-1]
@@ -273,13 +278,14 @@ def bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, act, 
     if res is not None:
         p.res, p.ldr, p.res_mode = hip.ptr(res), _ld(res), res_mode
     p.act, p.slope, p.H, p.W = act, slope, H, W
-    rows = 0 if stats is None else (stats.shape[0] if stats.dim() == 2 else 1)
-    hip.call('mg_bn_train_fwd', ctypes.byref(p), hip.ptr(stats_ws), c_int(int(zeroed)), hip.ptr(outs), hip.ptr(stats), c_int(rows), c_int(int(exact)),
+    p.m_dev = hip.ptr(rows)                    # device row count: always the exact two-pass variance over the live rows
+    srows = 0 if stats is None else (stats.shape[0] if stats.dim() == 2 else 1)
+    hip.call('mg_bn_train_fwd', ctypes.byref(p), hip.ptr(stats_ws), c_int(int(zeroed)), hip.ptr(outs), hip.ptr(stats), c_int(srows), c_int(int(exact)),
              hip.ptr(gamma), hip.ptr(beta), hip.ptr(running_mean), hip.ptr(running_var), c_float(momentum), c_float(eps), hip.stream())
     return y, outs
 
 
-def bn_train_bwd(dy, y, x, outs, act, slope, want_dres=False, mask_x_pos=False, sums=None):
+def bn_train_bwd(dy, y, x, outs, act, slope, want_dres=False, mask_x_pos=False, sums=None, rows=None):
     """Training BatchNorm backward in ONE C call (reduce + apply): -> dx, dres, sums [2C] = dbeta | dgamma.
     `sums`: zeroed [2C] accumulator (None: allocated and zeroed here)."""
     M, C = x.shape[0], x.shape[-1]
@@ -293,6 +299,7 @@ def bn_train_bwd(dy, y, x, outs, act, slope, want_dres=False, mask_x_pos=False, 
         sums = torch.empty(2 * C, dtype=torch.float32, device=x.device)
     p.sums, p.count = hip.ptr(sums), float(M)
     p.act, p.slope, p.mask_x_pos = act, slope, int(mask_x_pos)
+    p.m_dev = hip.ptr(rows)
     dx = torch.empty((M, C), dtype=x.dtype, device=x.device)
     p.dx, p.lddx = hip.ptr(dx), C
     dres = None
@@ -400,19 +407,19 @@ def bits_coords(bits, wordoff, W, R):
     return coords
 
 
-def gather_table(coords, ksize, kind, src_bits, src_wordoff, Hs, Ws):
+def gather_table(coords, ksize, kind, src_bits, src_wordoff, Hs, Ws, rows=None):
     R = coords.shape[0]
     nbr = torch.empty((R, ksize * ksize), dtype=torch.int32, device=coords.device)
     if R > 0:
-        hip.call('mg_gather_table', hip.ptr(coords), c_int(R), c_int(ksize), c_int(kind), hip.ptr(src_bits), hip.ptr(src_wordoff),
-                 c_int(Hs), c_int(Ws), hip.ptr(nbr), hip.stream())
+        hip.call('mg_gather_table_dev', hip.ptr(coords), c_int(R), c_int(ksize), c_int(kind), hip.ptr(src_bits), hip.ptr(src_wordoff),
+                 c_int(Hs), c_int(Ws), hip.ptr(nbr), hip.ptr(rows), hip.stream())
     return nbr
 
 
 # ------------------------------------------------------------------------------------------------------------------
 # dense <-> sparse, alpha planes, input packing
 # ------------------------------------------------------------------------------------------------------------------
-def gather_rows(dense, coords, n_i, mul=None, out=None, yoff=0):
+def gather_rows(dense, coords, n_i, mul=None, out=None, yoff=0, rows=None):
     """dense: (N, Hd, Wd, C) NHWC contiguous; coords (R,3) at that level; mul: fp32 (N, n_tok, C) or None."""
     N, Hd, Wd, C = dense.shape
     R = coords.shape[0]
@@ -422,19 +429,20 @@ def gather_rows(dense, coords, n_i, mul=None, out=None, yoff=0):
     hip.need_cuda(dense, coords, mul, out)
     if mul is not None:
         assert mul.dtype == torch.float32 and mul.is_contiguous() and mul.shape[-1] == C
-    hip.call('mg_gather_rows', hip.ptr(dense), c_int(hip.dtype_code(dense)), hip.ptr(coords), c_int(R), c_int(n_i), c_int(Hd), c_int(Wd),
-             c_int(C), hip.ptr(mul), c_int(mul.shape[1] if mul is not None else 0), hip.ptr(out), c_int(_ld(out)), c_int(yoff), hip.stream())
+    hip.call('mg_gather_rows_dev', hip.ptr(dense), c_int(hip.dtype_code(dense)), hip.ptr(coords), c_int(R), c_int(n_i), c_int(Hd), c_int(Wd),
+             c_int(C), hip.ptr(mul), c_int(mul.shape[1] if mul is not None else 0), hip.ptr(out), c_int(_ld(out)), c_int(yoff), hip.ptr(rows),
+             hip.stream())
     return out
 
 
-def gather_rows_bwd(dout, coords, n_i, dense_shape, mul=None, dense=None, yoff=0, want_ddense=True, want_dmul=False):
+def gather_rows_bwd(dout, coords, n_i, dense_shape, mul=None, dense=None, yoff=0, want_ddense=True, want_dmul=False, rows=None):
     N, Hd, Wd, C = dense_shape
     R = coords.shape[0]
     ddense = torch.zeros(dense_shape, dtype=torch.float32, device=dout.device) if want_ddense else None
     dmul = torch.zeros_like(mul) if (want_dmul and mul is not None) else None
-    hip.call('mg_gather_rows_bwd', hip.ptr(dout), c_int(hip.dtype_code(dout)), c_int(_ld(dout)), c_int(yoff), hip.ptr(coords), c_int(R),
+    hip.call('mg_gather_rows_bwd_dev', hip.ptr(dout), c_int(hip.dtype_code(dout)), c_int(_ld(dout)), c_int(yoff), hip.ptr(coords), c_int(R),
              c_int(n_i), c_int(Hd), c_int(Wd), c_int(C), hip.ptr(mul), c_int(mul.shape[1] if mul is not None else 0), hip.ptr(dense),
-             hip.ptr(ddense), hip.ptr(dmul), hip.stream())
+             hip.ptr(ddense), hip.ptr(dmul), hip.ptr(rows), hip.stream())
     return ddense, dmul
 
 
@@ -448,22 +456,22 @@ def gather_rows_bwd_dense(dout, bits, wordoff, n_i, dense_shape, mul=None, yoff=
     return ddense
 
 
-def scatter_plane(vals, col, coords, P, H, W, fill=-99.0):
+def scatter_plane(vals, col, coords, P, H, W, fill=-99.0, rows=None):
     R = coords.shape[0]
     plane = torch.empty((P, H, W), dtype=torch.float32, device=coords.device)
-    hip.call('mg_scatter_plane', hip.ptr(vals), c_int(hip.dtype_code(vals) if vals is not None else 0),
+    hip.call('mg_scatter_plane_dev', hip.ptr(vals), c_int(hip.dtype_code(vals) if vals is not None else 0),
              c_int(_ld(vals) if vals is not None and R > 0 else 1), c_int(col), hip.ptr(coords), c_int(R), c_int(P), c_int(H), c_int(W),
-             c_float(fill), hip.ptr(plane), hip.stream())
+             c_float(fill), hip.ptr(plane), hip.ptr(rows), hip.stream())
     return plane
 
 
-def gather_plane(plane, coords, like):
-    """-> (R, 1) tensor of dtype like.dtype with plane values at the sites."""
+def gather_plane(plane, coords, like, width=1, rows=None):
+    """-> (R, width) tensor of dtype `like` with the plane values at the sites in column 0 (the other columns zero)."""
     R = coords.shape[0]
     P, H, W = plane.shape
-    out = torch.empty((R, 1), dtype=like, device=plane.device)
-    hip.call('mg_gather_plane', hip.ptr(plane), hip.ptr(coords), c_int(R), c_int(H), c_int(W), hip.ptr(out),
-             c_int(hip.BF16 if like == torch.bfloat16 else hip.F32), c_int(1), c_int(0), hip.stream())
+    out = torch.empty((R, width), dtype=like, device=plane.device)
+    hip.call('mg_gather_plane_dev', hip.ptr(plane), hip.ptr(coords), c_int(R), c_int(H), c_int(W), hip.ptr(out),
+             c_int(hip.BF16 if like == torch.bfloat16 else hip.F32), c_int(width), c_int(0), hip.ptr(rows), c_int(int(width > 1)), hip.stream())
     return out
 
 
@@ -632,3 +640,72 @@ def temporal_fuse_(alphas3, prev, df3, db3):
     n = alphas3[0].numel()
     hip.call('mg_temporal_fuse', hip.ptr(alphas3), hip.ptr(prev), hip.ptr(df3), hip.ptr(db3), c_long(n), c_int(alphas3.shape[0]), hip.stream())
     return alphas3
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# row kernels of the sparse head with a device row count (maggie_amd/csrc/rows.hip)
+# ------------------------------------------------------------------------------------------------------------------
+def rows_sigmoid_mul(a, g, rows=None):
+    """a * sigmoid(g); `a` may be a channel slice (view) of a wider row buffer."""
+    M, C = g.shape
+    out = torch.empty_like(g)
+    hip.call('mg_rows_sigmoid_mul_fwd', hip.ptr(a), c_int(_ld(a)), hip.ptr(g), hip.ptr(out), c_int(hip.dtype_code(g)), c_int(M), c_int(C), hip.ptr(rows),
+             hip.stream())
+    return out
+
+
+def rows_sigmoid_mul_bwd(dout, a, g, rows=None):
+    M, C = g.shape
+    da, dg = torch.empty_like(g), torch.empty_like(g)
+    hip.call('mg_rows_sigmoid_mul_bwd', hip.ptr(dout), hip.ptr(a), c_int(_ld(a)), hip.ptr(g), hip.ptr(da), hip.ptr(dg), c_int(hip.dtype_code(g)),
+             c_int(M), c_int(C), hip.ptr(rows), hip.stream())
+    return da, dg
+
+
+def rows_add(a, b, out=None, rows=None):
+    """a + b over the live rows; a / b / out may be channel slices of wider buffers (out=a: in place)."""
+    M, C = a.shape
+    if out is None:
+        out = torch.empty((M, C), dtype=a.dtype, device=a.device)
+    hip.call('mg_rows_add', hip.ptr(a), c_int(_ld(a)), hip.ptr(b), c_int(_ld(b)), hip.ptr(out), c_int(_ld(out)), c_int(hip.dtype_code(a)), c_int(M),
+             c_int(C), hip.ptr(rows), hip.stream())
+    return out
+
+
+def rows_dropout(x, p, state, salt, rows=None):
+    """x * keep / (1 - p) with the counter-based mask of (state = device int64 [seed, step], salt); its own backward."""
+    M, C = x.shape
+    assert x.is_contiguous() and state.dtype == torch.int64 and state.numel() >= 2
+    y = torch.empty_like(x)
+    hip.call('mg_rows_dropout', hip.ptr(x), hip.ptr(y), c_int(hip.dtype_code(x)), c_int(M), c_int(C), c_float(float(p)), hip.ptr(state), c_int(int(salt)),
+             hip.ptr(rows), hip.stream())
+    return y
+
+
+def rows_add_layernorm(x, r, gamma, beta, eps, rows=None):
+    """LayerNorm(x + r) * gamma + beta per row -> y, rstat (M, 2) fp32 = (mean, rstd)."""
+    M, C = x.shape
+    assert x.is_contiguous() and r.is_contiguous() and gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    y = torch.empty_like(x)
+    rstat = torch.empty((M, 2), dtype=torch.float32, device=x.device)
+    hip.call('mg_rows_add_layernorm_fwd', hip.ptr(x), hip.ptr(r), hip.ptr(gamma), hip.ptr(beta), c_float(float(eps)), hip.ptr(y), hip.ptr(rstat),
+             c_int(hip.dtype_code(x)), c_int(M), c_int(C), hip.ptr(rows), hip.stream())
+    return y, rstat
+
+
+def rows_add_layernorm_bwd(dy, x, r, gamma, rstat, rows=None):
+    """-> dz (gradient of both x and r), dgamma, dbeta (fp32 [C])."""
+    M, C = x.shape
+    dz = torch.empty_like(x)
+    dgb = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    hip.call('mg_rows_add_layernorm_bwd', hip.ptr(dy), hip.ptr(x), hip.ptr(r), hip.ptr(gamma), hip.ptr(rstat), hip.ptr(dz), hip.ptr(dgb[:C]),
+             hip.ptr(dgb[C:]), c_int(hip.dtype_code(x)), c_int(M), c_int(C), hip.ptr(rows), hip.stream())
+    return dz, dgb[:C], dgb[C:]
+
+
+def bits_patch_if_empty_(bits, count, H, W, y0, y1, x0, x1):
+    """In place: if the device word `count` is 0, set bits [y0:y1, x0:x1] of every plane."""
+    P = bits.shape[0]
+    hip.call('mg_bits_patch_if_empty', hip.ptr(bits), hip.ptr(count), c_int(P), c_int(H), c_int(W), c_int(y0), c_int(y1), c_int(x0), c_int(x1),
+             hip.stream())
+    return bits

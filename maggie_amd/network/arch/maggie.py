@@ -84,7 +84,6 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             self.__dict__.get('_trunk_graphs', {}).clear()
             self.__dict__.pop('_bn_counters', None)
             self.__dict__['_addr_sig'] = sig
-        self.decoder.drop_prefetched()                            # a step that died half way must not leak converted weights
         if self._defer_bn_counters():
             ctr = self.__dict__.get('_bn_counters')
             if ctr is None or any(c.device != device for c in ctr):
@@ -154,13 +153,9 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
                 graphs[key] = (entry or 0) + 1
             self._prepare_spectral_norm('all')
             out = self._trunk(geom, False, *inputs, mem_feat=mem_feat)
-            if torch.is_grad_enabled() == self.training:
-                self.decoder.prefetch_detail_weights(MF.compute_dtype())
         else:
             self._prepare_spectral_norm('detail')
             out = entry(*inputs)
-            if torch.is_grad_enabled() == self.training:          # same autograd mode as the detail stage that will consume them
-                self.decoder.prefetch_detail_weights(MF.compute_dtype())
             from ..module.instance_matte_decoder import check_tokens
             check_tokens(out[2])
             out = (out[0].clone(),) + tuple(out[1:])              # alpha_os8 is handed to the caller: never alias graph memory

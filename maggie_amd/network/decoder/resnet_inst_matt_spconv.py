@@ -15,6 +15,7 @@ from ... import kernels as K
 from .resnet import BasicBlock
 from ..module import SpectralNorm, conv1x1, InstanceMatteDecoder, Marker
 from ..module.mask_attention import FFNLayer
+from ...sparse_head import DevicePyramid, DeviceRng, SparseHead
 
 
 class SparseConvWeight(nn.Module):
@@ -31,15 +32,9 @@ class SparseConvWeight(nn.Module):
             self.register_parameter('bias', None)
 
     def krsc(self, dtype):
-        pre = self.__dict__.pop('_pre_w', None)
-        if pre is not None and pre[0] == dtype:
-            return pre[1]
         return MF.weight_krsc_param(self.weight, dtype, None, MF.pad8(self.out_channels))
 
     def bias32(self):
-        pre = self.__dict__.pop('_pre_b', None)
-        if pre is not None:
-            return pre
         return None if self.bias is None else MF.pad_vec(self.bias.float(), MF.pad8(self.out_channels))
 
 
@@ -53,50 +48,6 @@ def SparseConv2d(i, o, kernel_size, stride=2, padding=1, bias=True, indice_key=N
 
 def SparseInverseConv2d(i, o, kernel_size, bias=True, indice_key=None):
     return SparseConvWeight(i, o, kernel_size, bias, 'inverse', indice_key)
-
-
-class SiteLevel:
-    """Active sites of one resolution level: bit planes, ranks, sorted coords and the gather tables built on demand."""
-
-    def __init__(self, bits, H, W):
-        self.bits, self.H, self.W = bits, H, W
-        self.rowoff, self.wordoff = K.bits_rank(bits, W)
-        self.count = None
-        self.coords = None
-        self._subm = None
-
-    def finalize(self, count):
-        self.count = count
-        self.coords = K.bits_coords(self.bits, self.wordoff, self.W, count)
-
-    def subm_table(self):
-        if self._subm is None:
-            self._subm = K.gather_table(self.coords, 3, 0, self.bits, self.wordoff, self.H, self.W)
-        return self._subm
-
-
-class ActivePyramid:
-    """Index pyramid OS1 -> OS2 -> OS4 -> OS8 of the detail region (spconv SparseConv2d(k3,s2,p1) output rule). One host sync:
-    the four site counts needed to size the feature matrices."""
-
-    def __init__(self, roi_bits, H, W):
-        lv = [SiteLevel(roi_bits, H, W)]
-        for _ in range(3):
-            b, h, w = K.bits_downsample(lv[-1].bits, lv[-1].W)
-            lv.append(SiteLevel(b, h, w))
-        counts = torch.stack([l.rowoff[-1] for l in lv]).tolist()          # the single device->host read
-        for l, c in zip(lv, counts):
-            l.finalize(int(c))
-        self.levels = lv                                                   # [OS1, OS2, OS4, OS8]
-        self._inv, self._down = {}, {}
-
-    def inverse_tables(self, fine):
-        """(fine<-coarse gather table, coarse<-fine table for the input gradient) of SparseInverseConv2d at level `fine`."""
-        if fine not in self._inv:
-            f, c = self.levels[fine], self.levels[fine + 1]
-            self._inv[fine] = K.gather_table(f.coords, 3, 1, c.bits, c.wordoff, c.H, c.W)
-            self._down[fine] = K.gather_table(c.coords, 3, 2, f.bits, f.wordoff, f.H, f.W)
-        return self._inv[fine], self._down[fine]
 
 
 class ResShortCut_InstMattSpconv_Dec(nn.Module):
@@ -165,92 +116,54 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
         return nn.Sequential(*layers)
 
     # ------------------------------------------------------------------ sparse refinement head
-    @staticmethod
-    def _bn_rows(x, bn, act=MF.ACT_NONE, stats=None):
-        if x.shape[0] == 0:
-            return x
-        return MF.batch_norm_act(x, bn, act, stats=stats)
+    _HEAD_BNS = ('layer3.1', 'guidance_layer.1', 'layer3_smooth.2', 'refine_OS4.1', 'layer4.1', 'layer4_smooth.2', 'layer5.1',
+                 'layer5_smooth.2', 'refine_OS1.1')
 
-    def _subm3(self, x, conv, lvl, stats=None, act=MF.ACT_NONE):
-        t = lvl.subm_table()
-        return MF.gather_conv(x, conv.krsc(x.dtype), t, t, True, 3, conv.bias32(), stats, act)
-
-    def _inverse(self, x, conv, pyr, fine, stats=None):
-        t, tt = pyr.inverse_tables(fine)
-        return MF.gather_conv(x, conv.krsc(x.dtype), t, tt, False, 3, conv.bias32(), stats)
-
-    @staticmethod
-    def _lin(x, conv, stats=None, pre_relu=False):
-        return MF.linear_rows(x, conv.krsc(x.dtype), conv.bias32(), pre_relu, stats)
-
-    def _stats(self, bn, x):
-        return MF.new_stats(x.shape[-1], x.device) if (bn.training and False) else None
+    def _head_env(self, pyr, n_i, dtype):
+        """Everything SparseHead needs besides the dense inputs: the pyramid, the converted weights (ONE weight-bank launch each way) and
+        the BatchNorm / LayerNorm parameters, as one flat `params` list with name -> position tables."""
+        plan, slots = self._weight_bank_plan()
+        names = self.__dict__.get('_head_names')
+        if names is None:
+            by_id = {id(m): n for n, m in self.named_modules()}
+            ffn = self.inst_spec_layer
+            by_id[id(ffn.linear1)], by_id[id(ffn.linear2)] = 'ffn1', 'ffn2'
+            names = self.__dict__['_head_names'] = [(by_id[id(m)], what) for m, what in slots]
+        outs = MF.weight_bank(plan, dtype)
+        env = type('HeadEnv', (), {})()
+        env.dec, env.pyr, env.n_i = self, pyr, n_i
+        env.w_index = {n: i for i, (n, what) in enumerate(names) if what == 'w'}
+        env.b_index = {n: i for i, (n, what) in enumerate(names) if what == 'b'}
+        params = list(outs)
+        env.bn_index = {}
+        for n in self._HEAD_BNS:
+            mod, idx = n.split('.')
+            bn = getattr(self, mod)[int(idx)]
+            env.bn_index[n] = len(params)
+            params += [bn.weight, bn.bias]
+        env.ln_index = len(params)
+        params += [self.inst_spec_layer.norm.weight, self.inst_spec_layer.norm.bias]
+        env.n_params, env.params = len(params), params
+        env.rng_state = None
+        if self.inst_spec_layer.training and self.inst_spec_layer.dropout.p > 0:
+            rng = self.__dict__.get('_head_rng')
+            if rng is None or rng.state.device != outs[0].device:
+                rng = self.__dict__['_head_rng'] = DeviceRng(outs[0].device)
+            env.rng_state = rng.snapshot()
+        return env
 
     def predict_details(self, os8_feat, roi_bits, n_i, inst_guidance_os8, dense_features, H, W):
-        """os8_feat (N,h8,w8,64) NHWC; roi_bits (N*n_i, H, Ww) bit planes; inst_guidance_os8 (N,10,64);
-        dense_features = fea1 (N,H,W,32), fea2 (N,H/2,W/2,32), fea3 (N,H/4,W/4,64).
-        Returns fp32 planes (N*n_i, H/4, W/4) and (N*n_i, H, W) with -99 outside the active sites, and the pyramid."""
+        """os8_feat (N,h8,w8,64) NHWC; roi_bits (N*n_i, H, Ww) bit planes (patched IN PLACE when empty in training, :347-348);
+        inst_guidance_os8 (N,10,64); dense_features = fea1 (N,H,W,32), fea2 (N,H/2,W/2,32), fea3 (N,H/4,W/4,64).
+        Returns fp32 planes (N*n_i, H/4, W/4) and (N*n_i, H, W) with -99 outside the active sites, and the pyramid.
+        No site count ever reaches the host (maggie_amd/sparse_head.py)."""
         fea1, fea2, fea3 = dense_features
-        P = roi_bits.shape[0]
-        pyr = ActivePyramid(roi_bits, H, W)
-        l1, l2, l4, l8 = pyr.levels
-        # OS8 gather * instance guidance -> FFN (inst_spec_layer)  (:221-232)
-        x = MF.gather_rows(os8_feat, l8, n_i, mul=inst_guidance_os8)
-        x = self._inst_spec(x) if x.shape[0] > 0 else x
-        # layer3: inverse conv OS8->OS4, BN, LeakyReLU, SubM 3x3
-        x = self._inverse(x, self.layer3[0], pyr, 2)
-        x = self._bn_rows(x, self.layer3[1], MF.ACT_LRELU)
-        x = self._subm3(x, self.layer3[3], l4)
-        # instance_spec_guidance with fea3 (:172-194)
-        detail = MF.gather_rows(fea3, l4, n_i)
-        g = self._lin(torch.cat([detail, x], 1), self.guidance_layer[0])
-        g = self._bn_rows(g, self.guidance_layer[1], MF.ACT_LRELU)
-        g = torch.sigmoid(self._subm3(g, self.guidance_layer[3], l4).float()).to(detail.dtype)
-        x = detail * g
-        # layer3_smooth, refine_OS4
-        x = self._lin(x, self.layer3_smooth[0], pre_relu=True)
-        x = self._bn_rows(x, self.layer3_smooth[2])
-        o4 = self._subm3(x, self.refine_OS4[0], l4)
-        o4 = self._bn_rows(o4, self.refine_OS4[1], MF.ACT_LRELU)
-        o4 = self._subm3(o4, self.refine_OS4[3], l4)
-        x_os4 = MF.scatter_plane(o4, l4.coords, P, l4.H, l4.W, -99.0)
-        # layer4 (OS4->OS2), fea2, layer4_smooth
-        x = self._inverse(x, self.layer4[0], pyr, 1)
-        x = self._bn_rows(x, self.layer4[1], MF.ACT_LRELU)
-        x = self._lin(x, self.layer4[3])
-        x = torch.cat([MF.gather_rows(fea2, l2, n_i), x], 1)
-        x = self._lin(x, self.layer4_smooth[0], pre_relu=True)
-        x = self._bn_rows(x, self.layer4_smooth[2])
-        # layer5 (OS2->OS1), fea1, layer5_smooth, refine_OS1
-        x = self._inverse(x, self.layer5[0], pyr, 0)
-        x = self._bn_rows(x, self.layer5[1], MF.ACT_LRELU)
-        x = self._subm3(x, self.layer5[3], l1)
-        x = torch.cat([MF.gather_rows(fea1, l1, n_i), x], 1)
-        x = self._lin(x, self.layer5_smooth[0], pre_relu=True)
-        x = self._bn_rows(x, self.layer5_smooth[2])
-        o1 = self._subm3(x, self.refine_OS1[0], l1)
-        o1 = self._bn_rows(o1, self.refine_OS1[1], MF.ACT_LRELU)
-        o1 = self._subm3(o1, self.refine_OS1[3], l1)
-        x_os1 = MF.scatter_plane(o1, l1.coords, P, H, W, -99.0)
+        patch = (200, 250, 200, 250) if (self.training and H > 200 and W > 200) else None      # "dummy code to prevent all zeros"
+        pyr = DevicePyramid(roi_bits, H, W, patch)
+        env = self._head_env(pyr, n_i, os8_feat.dtype)
+        x_os4, x_os1 = SparseHead.apply(env, os8_feat.contiguous(), inst_guidance_os8, fea1.contiguous(), fea2.contiguous(), fea3.contiguous(),
+                                        *env.params)
         return x_os4, x_os1, pyr
-
-    @staticmethod
-    def _banked_linear(lin, dt):
-        pre_w, pre_b = lin.__dict__.pop('_pre_w', None), lin.__dict__.pop('_pre_b', None)
-        if pre_w is not None and pre_w[0] == dt and pre_b is not None:
-            return pre_w[1], pre_b
-        return MF._pad_krsc(lin.weight[:, None, :], dt, None, None), lin.bias.float()
-
-    def _inst_spec(self, x):
-        """inst_spec_layer = FFNLayer(64, 64, dropout 0.1) over the gathered OS8 rows (:228-232; mask_attention.py:170-182): both 64x64
-        linears on the implicit-GEMM kernel (bias / ReLU in the epilogue), the two dropouts in the reference's order (they consume
-        the torch RNG), residual + LayerNorm in fp32."""
-        ffn = self.inst_spec_layer
-        dt = x.dtype
-        (w1, b1), (w2, b2) = (self._banked_linear(lin, dt) for lin in (ffn.linear1, ffn.linear2))
-        hid = ffn.dropout(MF.linear_rows(x, w1, b1, pre_relu=True))
-        out = ffn.dropout(MF.linear_rows(hid, w2, b2))
-        return ffn.norm(x.float() + out.float()).to(dt)
 
     def fuse(self, pred, detail_bits):
         """Progressive refinement (:272-290) with the two compute_unknown calls on device bit planes."""
@@ -287,16 +200,9 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
         H, W = image.shape[-2:]
         N = b * n_f
         queries = queries[:, None].expand(-1, n_f, -1, -1).reshape(N, *queries.shape[1:]).contiguous()
+        # an empty region needs no host decision: in training the device patches it (predict_details), in eval every plane stays at
+        # -99 and (tanh(-99) + 1) / 2 is exactly 0 -- the zeros of :350-352
         x_os4, x_os1, pyr = self.predict_details(x, detail_bits, n_i, queries, [fea1, fea2, fea3], H, W)
-        if pyr.levels[0].count == 0:
-            if self.training and H > 200 and W > 200:                       # "dummy code to prevent all zeros" (:347-348)
-                patch = torch.zeros((N * n_i, H, W), dtype=torch.uint8, device=image.device)
-                patch[:, 200:250, 200:250] = 1
-                detail_bits = K.bits_pack(patch, mode=1)
-                x_os4, x_os1, pyr = self.predict_details(x, detail_bits, n_i, queries, [fea1, fea2, fea3], H, W)
-            elif not self.training:
-                z = torch.zeros((N, n_i, H, W), device=image.device)
-                return z, torch.zeros_like(z), detail_bits
         x_os4 = MF.upsample_tanh(x_os4.view(N, n_i, H // 4, W // 4), n_i, 4, False)
         x_os1 = MF.upsample_tanh(x_os1.view(N, n_i, H, W), n_i, 1, False)
         return x_os4, x_os1, detail_bits
@@ -327,24 +233,6 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
                 slots.append((lin, 'b'))
             plan = self.__dict__['_wb_plan'] = (MF.WeightBankPlan(items), slots)
         return plan
-
-    def prefetch_detail_weights(self, dtype):
-        """Layout / dtype conversion of every sparse-stage parameter in ONE launch (functional.WeightBank), issued right after the
-        trunk graph launch when there is one; each result waits on its module for the next krsc() / bias32() call."""
-        plan, slots = self._weight_bank_plan()
-        outs = MF.weight_bank(plan, dtype)
-        for (m, what), t in zip(slots, outs):
-            if what == 'w':
-                m.__dict__['_pre_w'] = (dtype, t)
-            else:
-                m.__dict__['_pre_b'] = t
-
-    def drop_prefetched(self):
-        plan = self.__dict__.get('_wb_plan')
-        if plan is not None:
-            for m, _ in plan[1]:
-                m.__dict__.pop('_pre_w', None)
-                m.__dict__.pop('_pre_b', None)
 
     def dense_modules(self):
         """Sub-modules whose parameters are touched by dense_stage only."""
