@@ -79,6 +79,7 @@ def capture_table(n):
         raise RuntimeError('capture table exhausted')
     CAPTURE_TABLE[1] = off + n
     return buf[off:off + n]
+EAGER_TOKEN_CHECK = True       # InstanceMatteDecoder checks its tokens for NaN itself (a host sync) unless MaGGIe.forward, which reads all step flags at once, clears this
 DEFER_BN_COUNTERS = False      # set by MaGGIe.forward: num_batches_tracked of all BN layers is bumped by one foreach op per step
 
 
@@ -257,8 +258,11 @@ class WeightBank(torch.autograd.Function):
         return (None, None) + tuple(outs)
 
 
-def weight_bank(plan, dtype):
-    return WeightBank.apply(plan, dtype, *[it[0] for it in plan.items])
+def weight_bank(plan, dtype, params=None):
+    """`params`: the LIVE parameter tensors in plan order (default: the ones seen when the plan was built). Callers that may run inside a
+    graph capture pass them: the modules then hold stand-in leaves (graphs._ParamAliases) and the captured backward must be
+    differentiated with respect to those."""
+    return WeightBank.apply(plan, dtype, *(params if params is not None else [it[0] for it in plan.items]))
 
 
 class SpectralNormWeight(torch.autograd.Function):
@@ -875,9 +879,17 @@ def avg_pool2x2(x):
 # region ops (no gradients: integer / boolean work on bit planes)
 # ----------------------------------------------------------------------------------------------------------------------
 
-def unknown_bits(alpha, k_size=30, is_train=False, andmask=None):
+def draw_widths(P, k_size):
+    """The P per-slice dilation widths of compute_unknown(is_train=True) (maggie/utils/utils.py:47: one np.random.randint(1, k) per slice)
+    as ONE vectorised draw = the same values and the same generator state afterwards (tests/test_host_cpu.py), a tenth of the host time."""
+    import numpy as np
+    return np.random.randint(1, k_size, size=P).astype(np.int32)
+
+
+def unknown_bits(alpha, k_size=30, is_train=False, andmask=None, widths=None):
     """compute_unknown (maggie/utils/utils.py:28-55) on fp32 planes (..., H, W) -> bit planes (P, H, Ww).
-    Train mode draws one np.random.randint(1, k_size) per slice from the GLOBAL numpy RNG (reference order)."""
+    Train mode draws one np.random.randint(1, k_size) per slice from the GLOBAL numpy RNG (reference order) -- unless the caller
+    already drew them (`widths`: device int32 [P]; the captured detail stage gets them as a graph input)."""
     import numpy as np
     a = alpha.detach()
     if a.dtype != torch.float32:
@@ -887,10 +899,7 @@ def unknown_bits(alpha, k_size=30, is_train=False, andmask=None):
     P = a.numel() // (H * W_)
     bits = K.bits_pack(a, mode=0)
     if is_train:
-        # one vectorised draw = the same values and the same generator state afterwards as the reference's P scalar draws
-        # (utils/utils.py:47, checked in tests/test_host_cpu.py), at a tenth of the host time
-        widths = np.random.randint(1, k_size, size=P).astype(np.int32)
-        wd = torch.from_numpy(widths).to(a.device, non_blocking=True)
+        wd = widths if widths is not None else torch.from_numpy(draw_widths(P, k_size)).to(a.device, non_blocking=True)
         return K.bits_dilate(bits, W_, widths=wd, andmask=andmask)
     return K.bits_dilate(bits, W_, width=k_size // 2, andmask=andmask)
 

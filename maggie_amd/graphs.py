@@ -26,8 +26,11 @@ CAPTURE_MODE = 'thread_local'
 
 
 class _Replay(torch.autograd.Function):
+    """forward(g, *differentiable inputs, *parameters): the live differentiable inputs are only there so that autograd routes their
+    gradients (their values were copied into the graph's static inputs by GraphedCallable.__call__)."""
+
     @staticmethod
-    def forward(ctx, g, *params):
+    def forward(ctx, g, *tensors):
         g.fwd.replay()
         ctx.g = g
         outs = tuple(o.detach() for o in g.static_outputs)
@@ -38,15 +41,23 @@ class _Replay(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, *grads):
         g = ctx.g
-        src, dst = [], []
+        src, dst, zero = [], [], []
         for s, gr in zip(g.static_grad_outputs, grads):
-            if s is not None and gr is not None and s.data_ptr() != gr.data_ptr():
+            if s is None:
+                continue
+            if gr is None:
+                zero.append(s)                                    # this output took no part in the loss: its slot must not keep a stale gradient
+            elif s.data_ptr() != gr.data_ptr():
                 src.append(gr.to(s.dtype) if gr.dtype != s.dtype else gr)
                 dst.append(s)
+        if zero:
+            torch._foreach_zero_(zero)
         if dst:
             torch._foreach_copy_(dst, src)
         g.bwd.replay()
-        return (None,) + g.export_param_grads()
+        # gradients of the differentiable inputs are handed over as the graph's own buffers: their consumer (the producing graph's
+        # backward, or autograd's accumulation) reads them during this backward pass, before any further replay can overwrite them
+        return (None,) + tuple(g.static_input_grads) + g.export_param_grads()
 
 
 class _ParamAliases:
@@ -87,10 +98,16 @@ class GraphedCallable:
     """fn(*inputs) -> tuple of tensors, captured for fixed input shapes. `module`: the nn.Module whose parameters fn reads
     (requires_grad ones get gradients). `mutable`: tensors fn mutates in place (rolled back after warm-up)."""
 
-    def __init__(self, fn, inputs, module, mutable, training, warmup=2):
+    def __init__(self, fn, inputs, module, mutable, training, warmup=2, grad_inputs=()):
+        """`grad_inputs`: indices of `inputs` whose gradient the caller needs back (a graph fed by another graph's outputs)."""
         dev = inputs[0].device
         self.training = training
+        self.grad_idx = [i for i in grad_inputs if training and inputs[i].is_floating_point()]
         self.static_inputs = [i.detach().clone() for i in inputs]
+        for i in self.grad_idx:
+            self.static_inputs[i].requires_grad_(True)
+        gin = [self.static_inputs[i] for i in self.grad_idx]
+        self.static_input_grads = []
         snap = [m.detach().clone() for m in mutable]
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
@@ -102,8 +119,8 @@ class GraphedCallable:
                 if training:
                     req = [o for o in outs if o.requires_grad]
                     with torch.autocast('cuda', enabled=False):      # backward never runs under autocast (see below)
-                        gr = torch.autograd.grad(req, cap_params, [torch.ones_like(o) for o in req], allow_unused=True)
-                    used = [x is not None for x in gr]
+                        gr = torch.autograd.grad(req, cap_params + gin, [torch.ones_like(o) for o in req], allow_unused=True)
+                    used = [x is not None for x in gr[:len(cap_params)]]
                     MF.join_side()
                     del gr
                 del outs
@@ -130,9 +147,11 @@ class GraphedCallable:
                     with torch.cuda.graph(self.bwd, pool=self.pool, stream=side, capture_error_mode=CAPTURE_MODE), \
                             torch.autocast('cuda', enabled=False):
                         MF.ARENA.begin_capture(dev)
-                        self.static_param_grads = torch.autograd.grad(
-                            [o for o in self.static_outputs if o.requires_grad], cap_params,
+                        allg = torch.autograd.grad(
+                            [o for o in self.static_outputs if o.requires_grad], cap_params + gin,
                             [g for g in self.static_grad_outputs if g is not None], allow_unused=True)
+                        self.static_param_grads = allg[:len(cap_params)]
+                        self.static_input_grads = list(allg[len(cap_params):])
                         MF.join_side()                            # every forked branch must be back before the capture ends
                         self._pack_grads()
             finally:
@@ -174,8 +193,9 @@ class GraphedCallable:
                 src.append(i if i.dtype == s.dtype else i.to(s.dtype))
                 dst.append(s)
         if dst:
-            torch._foreach_copy_(dst, src)
+            with torch.no_grad():                                 # static inputs the graph differentiates through are leaves that require grad
+                torch._foreach_copy_(dst, src)
         if self.training:
-            return _Replay.apply(self, *self.params)
+            return _Replay.apply(self, *[inputs[i] for i in self.grad_idx], *self.params)
         self.fwd.replay()
         return tuple(o.detach() for o in self.static_outputs)

@@ -82,6 +82,7 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         sig = tuple(p.data_ptr() for p in sentinel)
         if self.__dict__.get('_addr_sig') != sig:
             self.__dict__.get('_trunk_graphs', {}).clear()
+            self.__dict__.get('_detail_graphs', {}).clear()
             self.__dict__.pop('_bn_counters', None)
             self.__dict__['_addr_sig'] = sig
         if self._defer_bn_counters():
@@ -103,10 +104,12 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             raise K.hip.MaggieHipError('MaGGIe (MI355X build) runs on the GPU only: move the batch to cuda (no CPU fallback)')
         self._begin_step(batch['image'].device)
         MF.DEFER_BN_COUNTERS = self._defer_bn_counters()
+        MF.EAGER_TOKEN_CHECK = False                                  # read together with the other step flags in _forward_impl
         try:
             return self._forward_impl(batch, **kwargs)
         finally:
             MF.DEFER_BN_COUNTERS = False
+            MF.EAGER_TOKEN_CHECK = True
 
     # ------------------------------------------------------------------------------------------------ dense trunk
     def _trunk(self, geom, prepare_sn, x, enc_masks, masks, gt_alphas=None, mem_feat=None):
@@ -156,8 +159,6 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         else:
             self._prepare_spectral_norm('detail')
             out = entry(*inputs)
-            from ..module.instance_matte_decoder import check_tokens
-            check_tokens(out[2])
             out = (out[0].clone(),) + tuple(out[1:])              # alpha_os8 is handed to the caller: never alias graph memory
         out = list(out)
         if not has_hidden:
@@ -178,17 +179,52 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
     def _forward_impl(self, batch, **kwargs):
         masks, alphas, trans_gt, b, n_f, h, w, n_i, chosen_ids, x, enc_masks = self.forward_inputs(batch)
         dense = self._run_trunk((b, n_f, n_i), x, enc_masks, masks, alphas, kwargs.get('mem_feat'))
-        pred = self.decoder.detail_stage(dense, x, b, n_f, n_i, batch.get('iter', 0), alphas, spar_gt=trans_gt,
-                                         **{k: v for k, v in kwargs.items() if k != 'mem_feat'})
-        if isinstance(pred, tuple):
-            pred = pred[0]
+        # ---- the ONE device->host read of the step: NaN instance tokens (mask_attention.py:95-98 raises) and, in training, whether the
+        # coarse alpha is identically zero (resnet_inst_matt_spconv.py:314: the ground truth then guides the detail region). Everything
+        # else the detail stage needs from the host is drawn below, in the reference's order; no site count is ever read back.
+        x_os8 = dense[0]
+        fl = [torch.isnan(dense[2]).any()] + ([x_os8.sum() == 0] if self.training else [])
+        flags = torch.stack(fl).tolist()
+        if flags[0]:
+            raise ValueError("Mask is empty")
+        P = b * n_f * (x_os8.shape[1] if self.training else n_i)
+        plan = self.decoder.detail_plan(batch.get('iter', 0), bool(self.training and flags[1]), P, x.device)
+        use_fuse_w = bool(self.training and np.random.rand() < 0.75)            # arch/maggie.py:99-101
+        names, tensors = self._run_detail(dense, (b, n_f, n_i, h, w), plan, use_fuse_w, alphas, trans_gt)
+        res = dict(zip(names, tensors))
+        output = {k[4:]: v for k, v in res.items() if k.startswith('out/')}
+        if self.training:
+            loss_dict = {k[5:]: v for k, v in res.items() if k.startswith('loss/')}
+            if chosen_ids is not None:
+                for k, v in output.items():
+                    output[k] = v[:, :, chosen_ids, :, :]
+            return output, loss_dict
+        return output
+
+    # ------------------------------------------------------------------------------------------------ detail stage + losses
+    def _detail_and_loss(self, geom, plan, n_dense, *tensors):
+        """Static-shape tail of the step as a function of tensors only: detail region -> sparse refinement -> fusion -> output dict
+        (-> losses). `tensors` = the trunk's outputs, then [ground-truth alphas, transition maps, fuse-weight flag] in training.
+        -> (names, tensors): 'out/<key>' entries (detached) and, in training, 'loss/<name>' entries ('loss/total' differentiable)."""
+        b, n_f, n_i, h, w = geom
+        dense = list(tensors[:n_dense])
+        if not hasattr(self.decoder, 'os8_temp_module'):
+            dense.insert(4, None)                                 # the image decoder has no recurrent hidden state
+        alphas = trans_gt = use_w = None
+        if self.training:
+            alphas, trans_gt, use_w = tensors[n_dense:n_dense + 3]
+        pred = self.decoder.detail_stage(dense, (h, w), b, n_f, n_i, plan, alphas, spar_gt=trans_gt)
         alpha_pred = pred.pop("refined_masks")
         weight_os4 = pred["detail_mask"].type(alpha_pred.dtype)
         weight_os1 = weight_os4
-        if self.training and 'weight_os4' in pred and np.random.rand() < 0.75:
-            weight_os4 = pred.pop("weight_os4")
-            weight_os1 = pred.pop("weight_os1")
+        if self.training and 'weight_os4' in pred:
+            # `np.random.rand() < 0.75` (arch/maggie.py:99-101) was drawn by the caller: a device flag selects the weight planes, so one
+            # captured graph serves both outcomes
+            pick = use_w.bool()
+            weight_os4 = torch.where(pick, pred.pop("weight_os4").type(alpha_pred.dtype), weight_os4)
+            weight_os1 = torch.where(pick, pred.pop("weight_os1").type(alpha_pred.dtype), weight_os1)
         output = self.transform_output(b, n_f, h, w, n_i, pred, alpha_pred)
+        names, outs = [], []
         if self.training:
             alphas = alphas.view(-1, n_i, h, w)
             trans_gt = trans_gt.view(-1, n_i, h, w)
@@ -202,16 +238,66 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             loss_dict = self.compute_loss(pred, weight_os4, weight_os1, alphas, trans_gt, (b, n_f, self.num_masks, h, w),
                                           reweight_os8=self.reweight_os8)
             self.update_additional_decoder_loss(pred, loss_dict)
-            if chosen_ids is not None:
-                for k, v in output.items():
-                    output[k] = v[:, :, chosen_ids, :, :]
-            return output, loss_dict
+            for k, v in loss_dict.items():
+                names.append('loss/' + k)
+                outs.append(v if k == 'total' else v.detach())          # the caller back-propagates loss['total'] (engine/train.py:265-268)
+        else:
+            for k, v in output.items():
+                output[k] = v[:, :, :n_i]
+            for k in pred:
+                if k.startswith("mem_"):
+                    output[k] = pred[k]
         for k, v in output.items():
-            output[k] = v[:, :, :n_i]
-        for k in pred:
-            if k.startswith("mem_"):
-                output[k] = pred[k]
-        return output
+            names.append('out/' + k)
+            outs.append(v.detach())
+        return names, tuple(outs)
+
+    def _run_detail(self, dense, geom, plan, use_fuse_w, alphas, trans_gt):
+        """The detail stage eagerly the first time a (geometry, mode) is seen, from its own pair of hipGraphs afterwards; its differentiable
+        inputs are the trunk's outputs, so backward chains detail graph -> trunk graph."""
+        dense = [t for t in dense if t is not None]
+        n_dense = len(dense)
+        extra = []
+        if self.training:
+            extra = [alphas, trans_gt, torch.tensor([int(use_fuse_w)], dtype=torch.int32).to(dense[0].device, non_blocking=True)]
+        host_w = [plan['widths']] if plan['widths'] is not None else []
+        inputs = list(dense) + extra + host_w
+        static_plan = {'use_gt': plan['use_gt'], 'with_atten': plan['with_atten']}
+
+        def fn(*t):
+            p = dict(static_plan, widths=t[n_dense + len(extra)] if host_w else None)
+            names, outs = self._detail_and_loss(geom, p, n_dense, *t)
+            fn.names = names
+            return outs
+
+        graphs = self.__dict__.setdefault('_detail_graphs', {})
+        key = None
+        if self._graph_policy():
+            key = (geom, self.training, MF.compute_dtype(), plan['use_gt'], plan['with_atten'], tuple((tuple(t.shape), t.dtype) for t in inputs))
+        entry = graphs.get(key) if key is not None else None
+        if isinstance(entry, int) and entry >= 1:
+            entry = self._capture_detail(fn, inputs, n_dense)
+            graphs[key] = entry
+            while len(graphs) > 4:
+                graphs.pop(next(iter(graphs)))
+        if entry is None or isinstance(entry, int) or entry == 'failed':
+            if key is not None and entry != 'failed':
+                graphs[key] = (entry or 0) + 1
+            outs = fn(*inputs)
+            return fn.names, outs
+        g, names = entry
+        return names, g(*inputs)
+
+    def _capture_detail(self, fn, inputs, n_dense):
+        from ... import graphs
+        mutable = [t for t in self.buffers()] + [p for p in self.parameters() if not p.requires_grad] + self.decoder.head_state()
+        try:
+            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=torch.is_autocast_enabled(), cache_enabled=False):
+                g = graphs.GraphedCallable(fn, inputs, self, mutable, self.training, grad_inputs=range(n_dense))
+            return g, fn.names
+        except Exception as e:                                    # pragma: no cover - capture is an optimisation, never fatal
+            logging.warning('hipGraph capture of the MaGGIe detail stage failed (%s: %s); staying eager', type(e).__name__, e)
+            return 'failed'
 
     def update_additional_decoder_loss(self, pred, loss_dict):
         if 'loss_max_atten' in pred and self.loss_atten_w > 0:

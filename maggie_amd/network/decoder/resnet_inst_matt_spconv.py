@@ -129,7 +129,7 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
             ffn = self.inst_spec_layer
             by_id[id(ffn.linear1)], by_id[id(ffn.linear2)] = 'ffn1', 'ffn2'
             names = self.__dict__['_head_names'] = [(by_id[id(m)], what) for m, what in slots]
-        outs = MF.weight_bank(plan, dtype)
+        outs = MF.weight_bank(plan, dtype, [m.weight if what == 'w' else m.bias for m, what in slots])     # live tensors (capture aliases)
         env = type('HeadEnv', (), {})()
         env.dec, env.pyr, env.n_i = self, pyr, n_i
         env.w_index = {n: i for i, (n, what) in enumerate(names) if what == 'w'}
@@ -149,7 +149,7 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
             rng = self.__dict__.get('_head_rng')
             if rng is None or rng.state.device != outs[0].device:
                 rng = self.__dict__['_head_rng'] = DeviceRng(outs[0].device)
-            env.rng_state = rng.snapshot()
+            env.rng_state = rng.snapshot()                        # device ops only: same sequence eagerly and from a replayed graph
         return env
 
     def predict_details(self, os8_feat, roi_bits, n_i, inst_guidance_os8, dense_features, H, W):
@@ -165,15 +165,17 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
                                         *env.params)
         return x_os4, x_os1, pyr
 
-    def fuse(self, pred, detail_bits):
-        """Progressive refinement (:272-290) with the two compute_unknown calls on device bit planes."""
+    def fuse(self, pred, detail_bits, widths=None):
+        """Progressive refinement (:272-290) with the two compute_unknown calls on device bit planes. `widths` (2, P) device int32: the
+        train-mode dilation widths for k = 27 and k = 15 when the caller already drew them (detail_plan)."""
         a1, a4, a8 = pred['alpha_os1'], pred['alpha_os4'], pred['alpha_os8']
         H, W = a8.shape[-2:]
         alpha = a8
+        w27, w15 = (widths[0], widths[1]) if widths is not None else (None, None)
         # a*w + alpha*(1-w) with a 0/1 weight plane is a per-pixel select: done straight from the bit planes (one pass each way)
-        bits4 = MF.unknown_bits(alpha, 27, self.training, andmask=detail_bits)
+        bits4 = MF.unknown_bits(alpha, 27, self.training, andmask=detail_bits, widths=w27)
         alpha = MF.bits_select(bits4, a4, alpha, W)
-        bits1 = MF.unknown_bits(alpha, 15, self.training, andmask=detail_bits)
+        bits1 = MF.unknown_bits(alpha, 15, self.training, andmask=detail_bits, widths=w15)
         alpha = MF.bits_select(bits1, a1, alpha, W)
         w4 = K.bits_unpack_u8(bits4, W, a8.shape).to(alpha.dtype)
         w1 = K.bits_unpack_u8(bits1, W, a8.shape).to(alpha.dtype)
@@ -195,9 +197,9 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
         h, w = image.shape[-2:]
         return x, masks, valid_masks, gt_masks, fea1, fea2, fea3, image, h, w
 
-    def process_os4_os1(self, x, b, n_f, fea1, fea2, fea3, image, x_os8, queries, n_i, detail_bits):
+    def process_os4_os1(self, x, b, n_f, fea1, fea2, fea3, hw, x_os8, queries, n_i, detail_bits):
         """:346-366. Returns alpha_os4, alpha_os1 (N, n_i, H, W) fp32 and the (possibly patched) detail bit planes."""
-        H, W = image.shape[-2:]
+        H, W = hw
         N = b * n_f
         queries = queries[:, None].expand(-1, n_f, -1, -1).reshape(N, *queries.shape[1:]).contiguous()
         # an empty region needs no host decision: in training the device patches it (predict_details), in eval every plane stays at
@@ -234,6 +236,11 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
             plan = self.__dict__['_wb_plan'] = (MF.WeightBankPlan(items), slots)
         return plan
 
+    def head_state(self):
+        """Device state the detail stage mutates besides module buffers (rolled back after a capture's warm-up runs): the dropout counter."""
+        rng = self.__dict__.get('_head_rng')
+        return [rng.state] if rng is not None else []
+
     def dense_modules(self):
         """Sub-modules whose parameters are touched by dense_stage only."""
         return [self.layer1, self.layer2, self.refine_OS8]
@@ -259,33 +266,54 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
 
     def forward(self, x, mid_fea, b, n_f, n_i, masks, iter, gt_alphas, **kwargs):
         dense = self.dense_stage(x, mid_fea, b, n_f, n_i, masks, gt_alphas, kwargs.get('mem_feat'))
-        return self.detail_stage(dense, mid_fea['image'], b, n_f, n_i, iter, gt_alphas, **kwargs)
+        x_os8 = dense[0]
+        flags = torch.stack([torch.isnan(dense[2]).any(), x_os8.sum() == 0]).tolist()
+        if flags[0]:
+            raise ValueError("Mask is empty")
+        P = x_os8.shape[0] * (x_os8.shape[1] if self.training else n_i)
+        plan = self.detail_plan(iter, bool(flags[1]), P, x_os8.device)
+        return self.detail_stage(dense, mid_fea['image'].shape[-2:], b, n_f, n_i, plan, gt_alphas, spar_gt=kwargs.get('spar_gt'))
 
-    def detail_stage(self, dense, image, b, n_f, n_i, iter, gt_alphas, **kwargs):
-        x_os8, x, queries, loss_max_atten, _, fea1, fea2, fea3 = dense
-        h, w = image.shape[-2:]
+    def detail_plan(self, iter, coarse_is_zero, P, device):
+        """Everything the detail stage needs from the HOST, consumed in the reference's order (:312-316 `random.random()`, then the per-slice
+        `np.random.randint` widths of compute_unknown(is_train=True): fuse k = 27, k = 15 (:276,282), then -- only when the ground truth
+        guides the region -- k = 30, k = 15 (:326-327)). -> dict(use_gt, with_atten, widths (4, P) device int32 | None)."""
+        use_gt = bool(self.training and (iter < self.warmup_detail_iter or coarse_is_zero
+                                         or (iter < self.warmup_detail_iter * 3 and random.random() < 0.5)))
+        widths = None
+        if self.inst_spec_layer.training and self.inst_spec_layer.dropout.p > 0:          # created here, never inside a capture
+            rng = self.__dict__.get('_head_rng')
+            if rng is None or rng.state.device != device:
+                self.__dict__['_head_rng'] = DeviceRng(device)
+        if self.training:
+            import numpy as np
+            rows = [MF.draw_widths(P, 27), MF.draw_widths(P, 15)]
+            rows += [MF.draw_widths(P, 30), MF.draw_widths(P, 15)] if use_gt else [np.ones(P, np.int32)] * 2
+            widths = torch.from_numpy(np.stack(rows)).to(device, non_blocking=True)
+        return {'use_gt': use_gt, 'with_atten': bool(self.training and iter >= self.warmup_mask_atten_iter), 'widths': widths}
+
+    def detail_stage(self, dense, hw, b, n_f, n_i, plan, gt_alphas, spar_gt=None):
+        """Tensors in, tensors out, static shapes, no host read (graph-capturable): detail region -> sparse refinement -> fusion."""
+        x_os8, x, queries, loss_max_atten, _, fea1, fea2, fea3 = dense[:8]
+        h, w = hw
         if not self.training:
             x_os8 = x_os8[:, :n_i].contiguous()
-        guided = x_os8
-        is_use_alphas_gt = False
-        if self.training and (iter < self.warmup_detail_iter or bool(x_os8.sum() == 0)
-                              or (iter < self.warmup_detail_iter * 3 and random.random() < 0.5)):
-            guided = gt_alphas
-            is_use_alphas_gt = True
+        use_gt, widths = plan['use_gt'], plan['widths']
+        guided = gt_alphas if use_gt else x_os8
         n_cur = guided.shape[1]
         detail_bits = MF.unknown_bits(guided, 30, False)                                   # (N*n_cur, H, Ww)
-        x_os4, x_os1, detail_bits = self.process_os4_os1(x, b, n_f, fea1, fea2, fea3, image, x_os8, queries, n_cur, detail_bits)
+        x_os4, x_os1, detail_bits = self.process_os4_os1(x, b, n_f, fea1, fea2, fea3, hw, x_os8, queries, n_cur, detail_bits)
         ret = {'alpha_os1': x_os1, 'alpha_os4': x_os4, 'alpha_os8': x_os8}
-        alpha_pred, weight_os4, weight_os1 = self.fuse(ret, detail_bits)
+        alpha_pred, weight_os4, weight_os1 = self.fuse(ret, detail_bits, widths)
         ret['refined_masks'] = alpha_pred
         unknown_os8 = K.bits_unpack_u8(detail_bits, w, x_os8.shape)
-        if is_use_alphas_gt:
-            weight_os4 = K.bits_unpack_u8(MF.unknown_bits(gt_alphas, 30, self.training, andmask=detail_bits), w, x_os8.shape)
-            weight_os1 = K.bits_unpack_u8(MF.unknown_bits(gt_alphas, 15, self.training, andmask=detail_bits), w, x_os8.shape)
+        if use_gt:
+            weight_os4 = K.bits_unpack_u8(MF.unknown_bits(gt_alphas, 30, self.training, andmask=detail_bits, widths=widths[2]), w, x_os8.shape)
+            weight_os1 = K.bits_unpack_u8(MF.unknown_bits(gt_alphas, 15, self.training, andmask=detail_bits, widths=widths[3]), w, x_os8.shape)
         ret['weight_os4'] = weight_os4
         ret['weight_os1'] = weight_os1
         ret['detail_mask'] = unknown_os8
-        if self.training and iter >= self.warmup_mask_atten_iter:
+        if plan['with_atten']:
             ret['loss_max_atten'] = loss_max_atten
         return ret
 

@@ -1,8 +1,6 @@
 """MaGGIe video decoder: adds ConvGRU feature propagation at OS8, the feature-difference module and bidirectional alpha
 fusion -- mirrors maggie/network/decoder/resnet_inst_matt_spconv_temp.py:14-206."""
 from functools import partial
-import random
-
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -106,20 +104,17 @@ class ResShortCut_InstMattSpconv_BiTempSpar_Dec(ResShortCut_InstMattSpconv_Dec):
         prop = partial(self.os8_temp_module.propagate_features, n_f=n_f, prev_h_state=mem_feat, temp_method=self.temp_method)
         return self.refine_OS8(x, masks, use_mask_atten=False, gt_mask=gt_masks, aggregate_mem_fn=prop)
 
-    def detail_stage(self, dense, image, b, n_f, n_i, iter, gt_alphas, mem_feat=None, spar_gt=None, **kwargs):
+    def detail_stage(self, dense, hw, b, n_f, n_i, plan, gt_alphas, spar_gt=None):
+        """Tensors in, tensors out, static shapes, no host read (see the image decoder)."""
         x_os8, x, queries, loss_max_atten, hidden_state, fea1, fea2, fea3 = dense[:8]
         diffs = dense[8] if len(dense) > 8 else None
-        h, w = image.shape[-2:]
+        h, w = hw
         mem_feat = hidden_state
         feat_os8 = x.view(b, n_f, *x.shape[1:]).detach()
         if not self.training:
             x_os8 = x_os8[:, :n_i].contiguous()
-        guided = x_os8
-        is_use_alphas_gt = False
-        if self.training and (iter < self.warmup_detail_iter or bool(x_os8.sum() == 0)
-                              or (iter < self.warmup_detail_iter * 3 and random.random() < 0.5)):
-            guided = gt_alphas
-            is_use_alphas_gt = True
+        use_gt, widths = plan['use_gt'], plan['widths']
+        guided = gt_alphas if use_gt else x_os8
         if not self.training:
             x_os8 = torch.where(x_os8 >= 0.95, torch.ones_like(x_os8), x_os8)
             guided = x_os8
@@ -127,7 +122,7 @@ class ResShortCut_InstMattSpconv_BiTempSpar_Dec(ResShortCut_InstMattSpconv_Dec):
         detail_bits = MF.unknown_bits(guided, 30, False)
         if not self.training:
             # ignore everything outside each instance's padded bounding box (:121-142), on device without host loops
-            H, W = image.shape[-2:]
+            H, W = hw
             smooth = gaussian_smoothing(x_os8, 3) > 0.1                              # (N, n_i, H, W) bool
             rows = smooth.any(-1)
             cols = smooth.any(-2)
@@ -149,16 +144,16 @@ class ResShortCut_InstMattSpconv_BiTempSpar_Dec(ResShortCut_InstMattSpconv_Dec):
             x_os8 = x_os8 * box
             detail_bits = detail_bits & K.bits_pack(box.to(torch.uint8).contiguous(), mode=1)
             guided = x_os8
-        x_os4, x_os1, detail_bits = self.process_os4_os1(x, b, n_f, fea1, fea2, fea3, image, x_os8, queries, n_cur, detail_bits)
+        x_os4, x_os1, detail_bits = self.process_os4_os1(x, b, n_f, fea1, fea2, fea3, hw, x_os8, queries, n_cur, detail_bits)
         ret = {'alpha_os1': x_os1, 'alpha_os4': x_os4, 'alpha_os8': x_os8}
-        alpha_pred, weight_os4, weight_os1 = self.fuse(ret, detail_bits)
+        alpha_pred, weight_os4, weight_os1 = self.fuse(ret, detail_bits, widths)
         ret['refined_masks'] = alpha_pred
         ret['detail_mask'] = K.bits_unpack_u8(detail_bits, w, x_os8.shape)
         if self.use_temp:
             ret['mem_feat'] = mem_feat
-        if is_use_alphas_gt:
-            weight_os4 = K.bits_unpack_u8(MF.unknown_bits(gt_alphas, 30, self.training, andmask=detail_bits), w, x_os8.shape)
-            weight_os1 = K.bits_unpack_u8(MF.unknown_bits(gt_alphas, 15, self.training, andmask=detail_bits), w, x_os8.shape)
+        if use_gt:
+            weight_os4 = K.bits_unpack_u8(MF.unknown_bits(gt_alphas, 30, self.training, andmask=detail_bits, widths=widths[2]), w, x_os8.shape)
+            weight_os1 = K.bits_unpack_u8(MF.unknown_bits(gt_alphas, 15, self.training, andmask=detail_bits, widths=widths[3]), w, x_os8.shape)
         ret['weight_os4'] = weight_os4
         ret['weight_os1'] = weight_os1
         temp_alpha = alpha_pred.view(b, n_f, *alpha_pred.shape[1:])

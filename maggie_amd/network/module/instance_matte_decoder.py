@@ -127,8 +127,8 @@ class InstanceMatteDecoder(nn.Module):
             if self.training:
                 max_loss = max_loss + self.compute_atten_loss(b, n_f, guidance_mask, att)
             max_loss = max_loss / (self.n_block + 1)
-        if not torch.cuda.is_current_stream_capturing():          # captured runs are checked by the graph owner after replay
-            check_tokens(tokens)
+        if MF.EAGER_TOKEN_CHECK and not torch.cuda.is_current_stream_capturing():
+            check_tokens(tokens)                                  # direct module use; MaGGIe.forward reads all its flags in ONE device->host copy
 
         feat = feat.to(dt).view(N, h, w, -1)
         hidden_state = None
