@@ -37,7 +37,15 @@ def parse():
     ap.add_argument('--batch', type=int, default=4, help='frames per GPU')
     ap.add_argument('--instances', type=int, default=2)
     ap.add_argument('--size', type=int, default=512)
-    ap.add_argument('--iter', type=int, default=10000, help="batch['iter'] (past every warm-up of the reference)")
+    ap.add_argument('--workload', default='gt', choices=['gt', 'pred'],
+                    help="gt (default): the detail region is guided by the ground-truth alphas (the reference's first warmup_detail_iter = 3000 "
+                         "iterations, resnet_inst_matt_spconv.py:312-316) with a soft edge sized for the realistic active ratio of 0.15 (SURVEY 8d) -- "
+                         "constant over steps and rounds; pred: iter = 10000, region from the model's own coarse alpha (random-init weights: 3-5x "
+                         "the realistic ratio, drifting as AdamW trains)")
+    ap.add_argument('--iter', type=int, default=None, help="batch['iter'] (default: 100 for --workload gt, 10000 for pred)")
+    ap.add_argument('--edge', type=float, default=40.0, help='soft-edge width (px at 512) of the synthetic alphas: 40 -> active ratio ~0.15 with --workload gt')
+    ap.add_argument('--no-trace', action='store_true', help='skip the rocprofv3 kernel trace of the graph-replayed steps (roofline.graph_replay)')
+    ap.add_argument('--cpu-baseline-full', action='store_true', help='cpu_baseline with 2 warm-ups + 5 timed steps per leg (several minutes)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--sync-bn', action='store_true', help='nn.SyncBatchNorm like configs/maggie_image.yaml:33 (N > 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -56,8 +64,10 @@ def parse():
 
 def main():
     args = parse()
+    if args.iter is None:
+        args.iter = 100 if args.workload == 'gt' else 10000
     if args.cpu_baseline_worker:
-        print('CPU_BASELINE ' + json.dumps(run_cpu_baseline('video' if args.video else 'image', args)))
+        run_cpu_baseline('video' if args.video else 'image', args)
         return
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -112,7 +122,8 @@ def main():
     else:
         opt = torch.optim.AdamW(params, lr=1.5e-4 / 25, betas=(0.9, 0.999), weight_decay=0.01, fused=args.optimizer == 'fused')
 
-    batch = synth.synthetic_batch(b, n_f, args.instances, args.size, args.size, seed=1234 + rank, train=True, it=args.iter, max_inst=10)
+    batch = synth.synthetic_batch(b, n_f, args.instances, args.size, args.size, seed=1234 + rank, train=True, it=args.iter, max_inst=10,
+                                  edge=args.edge * args.size / 512.0)
     batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
     np.random.seed(1234 + rank)
     import random
@@ -185,8 +196,11 @@ def main():
 
     roofline = None
     if not args.no_roofline:
-        # Per-launch HIP-event timing needs every conv launched individually: the instrumented extra steps run the trunk
-        # eagerly (the timed steps above replay it from hipGraphs, where the same kernels run back to back).
+        # (1) live HIP events: per-launch timing needs every conv launched individually, so two extra instrumented steps run eagerly (the
+        #     timed steps above replay the same kernels, same launch configurations, back to back from hipGraphs);
+        # (2) the graph-replayed steps themselves: a rocprofv3 --kernel-trace child of this same command (fewer steps) gives the average
+        #     duration of the same kernels inside the replayed graphs -- `frac` is computed from (2) when the tracer is available.
+        # FLOPs are ALGORITHMIC (kernels.py): existing taps of transposed / strided data-gradient convs, unpadded channels.
         names = ['mg_conv_fprop', 'mg_conv_fprop_ws', 'mg_conv_wgrad_ws']        # _ws: the split-K form of the same fprop family
         graphs_flag = model.__dict__.get('hip_graphs')
         model.hip_graphs = False
@@ -197,24 +211,26 @@ def main():
         torch.cuda.synchronize()
         rec = hip.disable_timing()['records']
         model.__dict__['hip_graphs'] = graphs_flag
-        fam = {}
+        fam, sparse_t = {}, {}
         for n in names:
-            for s, e, work, tag in rec[n]:
+            for s_, e_, work, tag in rec[n]:
                 key = '%s/%s' % ('mg_conv_fprop' if n == 'mg_conv_fprop_ws' else n, tag[0])
-                d = fam.setdefault(key, [0.0, 0.0, 0])
-                d[0] += s.elapsed_time(e) * 1e-3
-                d[1] += work
-                d[2] += 1
+                dt_ = s_.elapsed_time(e_) * 1e-3
+                if work is None:                                   # sparse head (device row count): time only
+                    d = sparse_t.setdefault(key, [0.0, 0]); d[0] += dt_; d[1] += 1
+                    continue
+                d = fam.setdefault(key, [0.0, 0.0, 0, 0.0])
+                d[0] += dt_; d[1] += work; d[2] += 1; d[3] += tag[5]
         if args.layers and rank == 0:
             per = {}
             for n in names:
                 for s_, e_, work, tag in rec[n]:
-                    k_ = (n,) + tuple(tag)
-                    d_ = per.setdefault(k_, [0.0, 0.0, 0])
-                    d_[0] += s_.elapsed_time(e_) * 1e-3; d_[1] += work; d_[2] += 1
-            sys.stderr.write('%-14s %-5s %4s %5s %6s %8s %6s %9s %8s\n' % ('entry', 'dtype', 'mode', 'Cout', 'K', 'M', 'calls', 'us/call', 'TFLOP/s'))
+                    k_ = (n,) + tuple(tag[:5])
+                    d_ = per.setdefault(k_, [0.0, 0.0, 0, 0.0])
+                    d_[0] += s_.elapsed_time(e_) * 1e-3; d_[1] += work or 0.0; d_[2] += 1; d_[3] += tag[5]
+            sys.stderr.write('%-14s %-5s %4s %5s %6s %8s %6s %9s %9s %9s\n' % ('entry', 'dtype', 'mode', 'Cout', 'K', 'M', 'calls', 'us/call', 'alg TF/s', 'exec TF/s'))
             for k_, d_ in sorted(per.items(), key=lambda kv: -kv[1][0]):
-                sys.stderr.write('%-14s %-5s %4d %5d %6d %8d %6d %9.1f %8.1f\n' % (k_[0], k_[1], k_[2], k_[3], k_[4], k_[5], d_[2] // n_prof, 1e6 * d_[0] / d_[2], d_[1] / d_[0] / 1e12))
+                sys.stderr.write('%-14s %-5s %4d %5d %6d %8d %6d %9.1f %9.1f %9.1f\n' % (k_[0], k_[1], k_[2], k_[3], k_[4], k_[5], d_[2] // n_prof, 1e6 * d_[0] / d_[2], d_[1] / d_[0] / 1e12, d_[3] / d_[0] / 1e12))
         dom = max(fam.items(), key=lambda kv: kv[1][0])
         tot_t = sum(v[0] for v in fam.values())
         tot_w = sum(v[1] for v in fam.values())
@@ -222,22 +238,41 @@ def main():
         frames_s = b * n_f * args.steps / elapsed
         scale = (args.size / 512.0) ** 2
         step_tflops = (frames_s * DENSE_GFLOP_PER_FRAME_FWD * 3 * scale * 1e9 + (active_px / ms_per_step * 1e3) * SPARSE_KFLOP_PER_ACTIVE_PX_FWD * 3e3) / 1e12
-        # HBM-side traffic of the same kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-        # separate runs of this command, corrected per MI355X_MICROARCH.md; tools/pmc_traffic.py) -- only for the config they
-        # were collected on
-        traffic = None
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic_final_eager.json')
-        if os.path.isfile(pmc_path) and not args.video and args.size == 512 and args.batch == 4 and args.iter == 10000 and use_bf16:
-            fam_key = 'igemm_fprop' if 'fprop' in dom[0] else 'igemm_wgrad'
-            traffic = json.load(open(pmc_path)).get(fam_key, {}).get('hbm_bytes_per_launch')
+        replay = None
+        if rank == 0 and world == 1 and not args.no_trace:
+            replay = trace_graph_replay(args, {k: (v[1] / n_prof, v[2] // n_prof) for k, v in fam.items()})
+        src = 'HIP events, eager instrumented steps'
+        if replay and replay.get('fprop_ms_per_step'):
+            # same launches, same algorithmic FLOPs per step; durations from inside the replayed graphs
+            fp_w = sum(v[1] for k, v in fam.items() if 'fprop' in k) / n_prof
+            ach = fp_w / (replay['fprop_ms_per_step'] * 1e-3) / 1e12
+            src = 'rocprofv3 kernel trace of the graph-replayed steps (child run of this command)'
+        # HBM-side traffic of the dominant family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
+        # corrected per MI355X_MICROARCH.md; tools/pmc_traffic.py) -- only for the configuration they were collected on
+        traffic, traffic_src = None, None
+        for cand in ('r02_pmc_traffic.json', 'r01_pmc_traffic_final_eager.json'):
+            pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', cand)
+            if os.path.isfile(pmc_path) and not args.video and args.size == 512 and args.batch == 4 and use_bf16:
+                traffic = json.load(open(pmc_path)).get('igemm_fprop', {}).get('hbm_bytes_per_launch')
+                traffic_src = 'profiles/' + cand
+                break
+        fp = {k: v for k, v in fam.items() if 'fprop' in k}
+        fp_launches = sum(v[2] for v in fp.values()) // n_prof
         roofline = {
-            'bound': 'mfma', 'kernel': 'igemm ' + dom[0], 'achieved': round(ach, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(ach / PEAK_BF16_TFLOPS, 5), 'traffic': traffic, 'traffic_unit': 'HBM-side bytes per launch (PMC, profiles/r01_pmc_traffic_final_eager.json)',
-            'launches_per_step': dom[1][2] // n_prof, 'avg_launch_us': round(1e6 * dom[1][0] / dom[1][2], 2),
-            'alg_gflop_per_launch': round(dom[1][1] / dom[1][2] / 1e9, 4),
-            'conv_family_ms_per_step': round(1e3 * tot_t / n_prof, 3), 'conv_family_tflops': round(tot_w / tot_t / 1e12, 2),
-            'families': {k: {'ms_per_step': round(1e3 * v[0] / n_prof, 3), 'tflops': round(v[1] / v[0] / 1e12, 2), 'launches': v[2] // n_prof}
-                         for k, v in fam.items()},
+            'bound': 'mfma', 'kernel': 'igemm_fprop (dense conv fprop / dgrad family), ' + dom[0].split('/')[1], 'achieved': round(ach, 2),
+            'peak': PEAK_BF16_TFLOPS if use_bf16 else 157.3, 'unit': 'TFLOP/s',
+            'frac': round(ach / (PEAK_BF16_TFLOPS if use_bf16 else 157.3), 5), 'traffic': traffic,
+            'traffic_unit': 'HBM-side bytes per launch (PMC, %s)' % traffic_src, 'achieved_source': src,
+            'launches_per_step': fp_launches,
+            'alg_gflop_per_launch': round(sum(v[1] for v in fp.values()) / max(1, sum(v[2] for v in fp.values())) / 1e9, 4),
+            'alg_gflop_per_step': round(sum(v[1] for v in fp.values()) / n_prof / 1e9, 2),
+            'executed_gflop_per_step': round(sum(v[3] for v in fp.values()) / n_prof / 1e9, 2),
+            'eager_events': {k: {'ms_per_step': round(1e3 * v[0] / n_prof, 3), 'alg_tflops': round(v[1] / v[0] / 1e12, 2),
+                                 'executed_tflops': round(v[3] / v[0] / 1e12, 2), 'launches': v[2] // n_prof,
+                                 'avg_launch_us': round(1e6 * v[0] / v[2], 2)} for k, v in fam.items()},
+            'sparse_head_eager_ms_per_step': {k: round(1e3 * v[0] / n_prof, 3) for k, v in sparse_t.items()},
+            'graph_replay': replay,
+            'conv_family_alg_tflops_eager': round(tot_w / tot_t / 1e12, 2),
             'step_algorithmic_tflops_per_gpu': round(step_tflops, 2), 'step_frac_of_mfma_peak': round(step_tflops / PEAK_BF16_TFLOPS, 5),
             'hip_graphs': bool(getattr(model, '_trunk_graphs', None)) and any(not isinstance(v, (int, str)) for v in model._trunk_graphs.values()),
         }
@@ -253,8 +288,10 @@ def main():
             'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
             'per_gpu': round(value / world, 3),
-            'config': {'workload': 'maggie_%s.yaml train step: %dx%d, %d instances (10 slots), batch %d frames/GPU x %d frame(s), iter=%d, '
-                                   'fwd+loss+bwd+clip+AdamW' % (kind, args.size, args.size, args.instances, b, n_f, args.iter),
+            'config': {'workload': 'maggie_%s.yaml train step: %dx%d, %d instances (10 slots), batch %d frames/GPU x %d frame(s), iter=%d (%s), '
+                                   'fwd+loss+bwd+clip+AdamW' % (kind, args.size, args.size, args.instances, b, n_f, args.iter,
+                                                                'detail region guided by the ground-truth alphas, soft edge %g px: constant active ratio' % args.edge
+                                                                if args.workload == 'gt' else 'detail region from the predicted coarse alpha: drifts with the random-init weights'),
                        'global_batch': b * world, 'parallelism': 'dp%d' % world, 'sync_bn': bool(args.sync_bn and world > 1), 'optimizer': 'FlatAdamW (clip 0.01 folded in)' if args.optimizer == 'flat' else 'torch AdamW(%s) + flat-buffer grad-norm clip' % args.optimizer,
                        'grad_allreduce': None if world == 1 and not force_ddp else ('torch DDP' if args.ddp else ('one RCCL all-reduce of the flat gradient buffer inside FlatAdamW.step' if args.optimizer == 'flat' else 'GradSync (flat-buffer RCCL all-reduce)')),
                        'active_ratio': round(active_ratio, 4), 'active_ratio_per_timed_step': [round(float(v) / (b * n_f * args.instances * args.size * args.size), 3) for v in stats['active_hist'][-args.steps - 2:-2]] if not args.no_roofline else None, 'active_pixels_per_step_per_gpu': int(active_px), 'loss_total': round(loss_val, 4)},
@@ -274,25 +311,90 @@ def main():
         sys.stdout.flush()
 
 
-def cpu_baseline_subprocess(args, limit_s=150):
-    """Run the CPU oracle leg in a child process with a hard time limit so the default bench always finishes in minutes."""
+def trace_graph_replay(args, fam_alg):
+    """rocprofv3 --kernel-trace over a short child run of THIS command: average durations of the conv kernels inside the replayed hipGraphs
+    (HIP events cannot bracket a kernel inside a graph). -> dict or None when the tracer is unavailable / failed."""
+    import csv
+    import glob
+    import shutil
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--size', str(args.size), '--instances', str(args.instances),
-           '--iter', str(args.iter), '--cpu-threads', str(args.cpu_threads)] + (['--video'] if args.video else [])
-    env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+    import tempfile
+    prof = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.isfile('/opt/rocm/bin/rocprofv3') else None)
+    if prof is None:
+        return None
+    n_steps = 6
+    out_dir = tempfile.mkdtemp(prefix='mg_trace_', dir='/tmp')
+    cmd = [prof, '--kernel-trace', '--output-format', 'csv', '-d', out_dir, '--', sys.executable, os.path.abspath(__file__), '--steps', str(n_steps),
+           '--warmup', '2', '--no-roofline', '--no-cpu-baseline', '--batch', str(args.batch), '--instances', str(args.instances), '--size', str(args.size),
+           '--workload', args.workload, '--iter', str(args.iter), '--edge', str(args.edge), '--dtype', args.dtype] + (['--video'] if args.video else [])
     try:
-        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=limit_s, env=env).stdout.decode()
-        for line in out.splitlines():
-            if line.startswith('CPU_BASELINE '):
-                return json.loads(line[len('CPU_BASELINE '):])
-        return {'value': None, 'unit': 'instance-frames/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': 'failed: ' + out[-300:]}
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'))
+        line = [l for l in res.stdout.decode(errors='replace').splitlines() if l.startswith('{"metric"')]
+        files = glob.glob(os.path.join(out_dir, '**', '*kernel_trace.csv'), recursive=True)
+        if not line or not files:
+            return None
+        ms = json.loads(line[-1])['ms_per_step']
+        rows = []
+        with open(files[0]) as f:
+            for r in csv.DictReader(f):
+                rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']))
+        rows.sort()
+        # the last (n_steps - 1) steps of the timed region: whole steps, all replayed from graphs
+        k = n_steps - 1
+        t_end = rows[-1][1]
+        win = [r for r in rows if r[0] >= t_end - k * ms * 1e6]
+        acc = {}
+        for s_, e_, nm in win:
+            fam = 'fprop' if ('igemm_fprop_kernel' in nm or 'splitk_finish' in nm) else 'wgrad' if ('igemm_wgrad' in nm or 'wgrad_reduce' in nm) else \
+                'sparse' if 'igemm_fprop_persistent' in nm else None
+            if fam:
+                d = acc.setdefault(fam, [0, 0, 0])
+                d[0] += e_ - s_
+                d[1] += 1
+                d[2] += int('igemm_fprop_kernel' in nm or 'igemm_wgrad_kernel' in nm)
+        busy = sum(e_ - s_ for s_, e_, _ in win)
+        span = win[-1][1] - win[0][0]
+        out = {'steps_in_window': k, 'traced_ms_per_step': ms, 'launches_per_step': round(len(win) / k, 1), 'gpu_busy_frac': round(busy / span, 4)}
+        for fam, (t, c, cm) in acc.items():
+            out[fam + '_ms_per_step'] = round(t / 1e6 / k, 4)
+            out[fam + '_launches_per_step'] = round(c / k, 1)
+            out[fam + '_avg_kernel_us'] = round(t / 1e3 / max(cm, 1), 2)          # per igemm launch (split-K finish / reduce time included)
+        return out
+    except Exception as e:                                          # the trace is evidence, never a reason to fail the bench
+        return {'error': '%s: %s' % (type(e).__name__, e)}
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+
+
+def cpu_baseline_subprocess(args):
+    """Run the CPU oracle legs in a child process with a hard time limit so the default bench always finishes in minutes."""
+    import subprocess
+    limit_s = 900 if args.cpu_baseline_full else 330
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--size', str(args.size), '--instances', str(args.instances),
+           '--batch', str(args.batch), '--iter', str(args.iter), '--edge', str(args.edge), '--workload', args.workload,
+           '--cpu-threads', str(args.cpu_threads)] + (['--video'] if args.video else []) + (['--cpu-baseline-full'] if args.cpu_baseline_full else [])
+    env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+    part = None
+    try:
+        pr = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
+        out, _ = pr.communicate(timeout=limit_s)
+        out = out.decode(errors='replace')
     except subprocess.TimeoutExpired:
-        return {'value': None, 'unit': 'instance-frames/s', 'cores': os.cpu_count(), 'kind': 'port',
-                'sample': 'oracle train step at %dx%d did not finish within %d s' % (args.size, args.size, limit_s)}
+        pr.kill()
+        out = pr.communicate()[0].decode(errors='replace')
+    for line in out.splitlines():                                   # the worker prints a (growing) result line after every timed step
+        if line.startswith('CPU_BASELINE '):
+            part = json.loads(line[len('CPU_BASELINE '):])
+    if part is not None:
+        return part
+    return {'value': None, 'unit': 'instance-frames/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': 'failed: ' + out[-300:]}
 
 
 def run_cpu_baseline(kind, args):
-    """The CPU oracle (a port of the reference path, test infrastructure) timed on this host: one bounded train step."""
+    """The CPU oracle (oracle/refmodel.py: a port of the reference path -- test infrastructure, never the product; the reference's own
+    Python cannot run on this box) timed on the host cores on the SAME workload as the GPU line: same batch, instances, size, soft edge and
+    detail-region guidance. Two legs: train forward + loss + backward (= `value`), and eval forward. Each leg: warm-up steps, then
+    timed steps, median reported; a result line is printed after every timed step so that the parent always has the latest median."""
     import copy
     from maggie_amd.network import build_model
     from maggie_amd.utils import config, synth
@@ -301,27 +403,54 @@ def run_cpu_baseline(kind, args):
     threads = args.cpu_threads if args.cpu_threads > 0 else min(cores, 32)      # beyond ~32 threads the many small ops regress
     torch.set_num_threads(threads)
     model, _ = build_model(config.model_config(kind))
-    sd = model.state_dict()
-    synth.fill_state_dict_(sd, 1234)
-    sd = {k: v.clone() for k, v in sd.items()}
-    for k, v in sd.items():
-        if v.is_floating_point() and not k.endswith(('_u', '_v', 'running_mean', 'running_var')):
-            v.requires_grad_(True)
+    sd0 = model.state_dict()
+    synth.fill_state_dict_(sd0, 1234)
     n_f = 3 if kind == 'video' else 1
-    b = 1 if kind == 'video' else 2
-    size = min(args.size, 512)
-    batch = synth.synthetic_batch(b, n_f, args.instances, size, size, seed=1234, train=True, it=args.iter, max_inst=10)
+    b = 1 if kind == 'video' else args.batch
+    size = args.size
     mcfg = copy.deepcopy(config.MODEL_VIDEO if kind == 'video' else config.MODEL_IMAGE)
-    np.random.seed(0)
-    t0 = time.perf_counter()
-    out, loss = refmodel.maggie_forward(sd, mcfg, batch, True)
-    loss['total'].backward()
-    dt = time.perf_counter() - t0
-    ratio = float(out['detail_mask'].float().mean()) * 10.0 / args.instances
-    return {'value': round(b * n_f * args.instances / dt, 4), 'unit': 'instance-frames/s', 'cores': threads, 'kind': 'port',
-            'sample': 'oracle/refmodel.py fp32 train step (fwd+loss+bwd, no optimizer), %dx%d, batch %d x %d frame(s), %d instances, '
-                      'active ratio %.2f, one timed step (no warm-up) = %.1f s on %d of %d host cores' % (size, size, b, n_f, args.instances,
-                                                                                                       ratio, dt, threads, cores)}
+    n_warm, n_timed = (2, 5) if args.cpu_baseline_full else (1, 3)
+    res = {'unit': 'instance-frames/s', 'cores': threads, 'host_cores': cores, 'kind': 'port'}
+    inst = b * n_f * args.instances
+
+    def emit():
+        tr, ev = res.get('train_s', []), res.get('eval_s', [])
+        res['value'] = round(inst / float(np.median(tr)), 4) if tr else None
+        res['eval_forward_value'] = round(inst / float(np.median(ev)), 4) if ev else None
+        res['sample'] = ('oracle/refmodel.py fp32 on %d of %d host cores (torch threads), same workload as the GPU line: %dx%d, batch %d x %d frame(s), %d '
+                         'instances, %s-guided detail region, active ratio %.3f; train leg = forward + losses + backward (no optimizer): %d warm-up + %d '
+                         'timed steps, median %.2f s/step; eval-forward leg: %d timed, median %.2f s' % (
+                             threads, cores, size, size, b, n_f, args.instances, 'ground-truth' if args.workload == 'gt' else 'prediction',
+                             res.get('active_ratio', float('nan')), n_warm, len(tr), float(np.median(tr)) if tr else float('nan'), len(ev),
+                             float(np.median(ev)) if ev else float('nan')))
+        print('CPU_BASELINE ' + json.dumps({k: v for k, v in res.items() if k not in ('train_s', 'eval_s')}), flush=True)
+
+    batch = synth.synthetic_batch(b, n_f, args.instances, size, size, seed=1234, train=True, it=args.iter, max_inst=10, edge=args.edge * size / 512.0)
+    ev_batch = {k: (v[:, :, :args.instances] if k == 'mask' else v) for k, v in batch.items() if k in ('image', 'mask')}
+    for i in range(n_warm + n_timed):
+        sd = {k: v.clone() for k, v in sd0.items()}
+        for k, v in sd.items():
+            if v.is_floating_point() and not k.endswith(('_u', '_v', 'running_mean', 'running_var')):
+                v.requires_grad_(True)
+        np.random.seed(i)
+        t0 = time.perf_counter()
+        out, loss = refmodel.maggie_forward(sd, mcfg, batch, True)
+        loss['total'].backward()
+        dt = time.perf_counter() - t0
+        res['active_ratio'] = round(float(out['detail_mask'].float().mean()) * 10.0 / args.instances, 4)
+        if i >= n_warm:
+            res.setdefault('train_s', []).append(dt)
+            emit()
+    for i in range(n_warm + n_timed):
+        sd = {k: v.clone() for k, v in sd0.items()}
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            refmodel.maggie_forward(sd, mcfg, ev_batch, False)
+        dt = time.perf_counter() - t0
+        if i >= n_warm:
+            res.setdefault('eval_s', []).append(dt)
+            emit()
+    return {k: v for k, v in res.items() if k not in ('train_s', 'eval_s')}
 
 
 if __name__ == '__main__':

@@ -377,8 +377,9 @@ class SpectralNormBatch(torch.autograd.Function):
         ctx.plan = plan
         ctx.save_for_backward(work)
         outs = tuple(out[o:o + n].view(sh[0], sh[1], sh[2]) for (o, n), sh in zip(plan.out_slices, plan.shapes))
-        for t_ in outs:
+        for t_, src in zip(outs, plan.sources):
             t_._mg_side_wgrad = True                              # every dW of these weights meets again in backward() below: the join point
+            t_._mg_cin = src[4]                                   # real (unpadded) input channels: algorithmic-FLOP accounting of the bench
         if out_t is not None:
             # (Cin_pad, taps, Cout) twins for the data-gradient convolution ride along as a Python attribute of each weight
             for t_, (o, n), sh, src in zip(outs, plan.out_slices, plan.shapes, plan.sources):
@@ -460,9 +461,10 @@ class ConvRaw(torch.autograd.Function):
         mode = MODE_TCONV if transposed else MODE_CONV
         Ho = K.conv_out_size(mode, H, R, stride, pad, dil)
         Wo = K.conv_out_size(mode, W_, S, stride, pad, dil)
+        ctx.cin_real = getattr(w, '_mg_cin', None)
         y = K.conv_fprop(x.view(-1, Cin), w, mode=mode, N=N, Hin=H, Win=W_, Hout=Ho, Wout=Wo, R=R, S=S, stride=stride,
                          pad=pad, dil=dil, shift=bias, act=ACT_RELU if pre_relu else ACT_NONE, pre_act=False,
-                         stats=stats)
+                         stats=stats, alg_cin=ctx.cin_real)
         y = y.view(N, Ho, Wo, Cout)
         ctx.wt = getattr(w, '_mg_wt', None)                       # pre-transposed weights from the batched SpectralNorm kernel
         ctx.side = SIDE_WGRAD and getattr(w, '_mg_side_wgrad', False) and not transposed
@@ -483,7 +485,7 @@ class ConvRaw(torch.autograd.Function):
             wt = ctx.wt if (ctx.wt is not None and not transposed) else w.permute(2, 1, 0).contiguous()      # (Cin, taps, Cout)
             dmode = MODE_CONV if transposed else MODE_TCONV
             dx = K.conv_fprop(dy2, wt, mode=dmode, N=N, Hin=Ho, Win=Wo, Hout=H, Wout=W_, R=R, S=S, stride=stride, pad=pad,
-                              dil=dil).view(N, H, W_, Cin)
+                              dil=dil, alg_cout=ctx.cin_real).view(N, H, W_, Cin)
         if ctx.needs_input_grad[1]:
             if ctx.side:
                 side, main = fork_side(dy2.device)
@@ -495,7 +497,7 @@ class ConvRaw(torch.autograd.Function):
                 dw.record_stream(main)
             elif not transposed:
                 dw = K.conv_wgrad(x.view(-1, Cin), dy2, cout=Cout, mode=MODE_CONV, N=N, Hin=H, Win=W_, Hout=Ho, Wout=Wo,
-                                  R=R, S=S, stride=stride, pad=pad, dil=dil, out_dtype=w.dtype)
+                                  R=R, S=S, stride=stride, pad=pad, dil=dil, out_dtype=w.dtype, alg_cin=ctx.cin_real)
             else:
                 # dW[ci, tap, co] = sum_o x[o, ci] * dy[2o - pad + k, co]  (roles of x and dy swapped)
                 dwt = K.conv_wgrad(dy2, x.view(-1, Cin), cout=Cin, mode=MODE_CONV, N=N, Hin=Ho, Win=Wo, Hout=H, Wout=W_,

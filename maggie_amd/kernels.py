@@ -42,7 +42,7 @@ def _conv_params(x, w, y, mode, N, Hin, Win, Hout, Wout, R, S, stride, pad, dil,
 
 def conv_fprop(x, w, *, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=None, Wout=None, R=1, S=1, stride=1, pad=0, dil=1,
                M=None, nbr=None, scale=None, shift=None, res=None, res_mode=1, res2=None, act=ACT_NONE, pre_act=False,
-               slope=0.2, stats=None, out=None, yoff=0, cout=None, rows=None):
+               slope=0.2, stats=None, out=None, yoff=0, cout=None, rows=None, alg_cin=None, alg_cout=None):
     """Y = epilogue(implicit GEMM). x: (..., Cin) channel-contiguous; w: (Cout, R*S, Cin) same dtype.
     Dense modes: rows of x are (n, h, w) of an (N, Hin, Win) map; gather mode: rows of x are sparse sites, `nbr` (M, R*S).
     `out`/`yoff` let the result land in a channel slice of a wider buffer (zero-copy concat)."""
@@ -75,7 +75,14 @@ def conv_fprop(x, w, *, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=None, Wout=None,
                      res, res_mode, res2, act, pre_act, slope, stats, yoff)
     p.stat_mode = stat_mode
     p.m_dev = hip.ptr(rows)                    # device row count (sparse head): M is then the capacity, the launch a persistent grid
-    work, tag = 2.0 * M * Cout * R * S * Cin, ('bf16' if x.dtype == torch.bfloat16 else 'f32', mode, Cout, R * S * Cin, M)
+    # bench accounting: `work` = ALGORITHMIC FLOPs -- the taps that exist (a stride-s transposed / data-gradient conv touches
+    # R*S/s^2 taps per output row on average; the rest of what MG_MODE_TCONV multiplies are structural zeros) and the real, unpadded
+    # channel counts; the executed FLOPs ride along in the tag. A device row count (sparse head) makes the work unknown here: None.
+    executed = 2.0 * M * Cout * R * S * Cin
+    work = None
+    if rows is None:
+        work = executed * ((alg_cin or Cin) / Cin) * ((alg_cout or Cout) / Cout) / (stride * stride if mode == MODE_TCONV else 1)
+    tag = ('bf16' if x.dtype == torch.bfloat16 else 'f32', mode, Cout, R * S * Cin, M, executed, rows is not None)
     if mode != MODE_GATHER and 0 < M <= 8192 and Cout >= 64 and rows is None:
         # deep layers with few rows: the library may split K over several blocks per tile (mg_conv_fprop_ws)
         need = _fprop_workspace_fn()(ctypes.byref(p))
@@ -99,7 +106,7 @@ def _fprop_workspace_fn():
 
 
 def conv_wgrad(x, dy, *, cout, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=1, Wout=1, R=1, S=1, stride=1, pad=0, dil=1,
-               M=None, nbr=None, yoff=0, out=None, out_dtype=torch.float32, rows=None):
+               M=None, nbr=None, yoff=0, out=None, out_dtype=torch.float32, rows=None, alg_cin=None, alg_cout=None):
     """dW[co, tap, ci] = sum_m dY[m, co] X[src(m,tap), ci]; (Cout, R*S, Cin) accumulated in fp32 and written as
     `out_dtype` (fp32 / bf16 -- the converting reduce saves a separate cast pass). `dy` may be a channel slice (yoff) of
     a wider buffer."""
@@ -123,8 +130,10 @@ def conv_wgrad(x, dy, *, cout, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=1, Wout=1
             torch.zeros((cout, R * S, Cin), dtype=out_dtype, device=x.device)
     ws = _wgrad_workspace(need, x.device) if need > 0 else None
     p.stats = hip.ptr(out)
+    executed = 2.0 * M * cout * R * S * Cin
+    work = None if rows is not None else executed * ((alg_cin or Cin) / Cin) * ((alg_cout or cout) / cout) / (stride * stride if mode == MODE_TCONV else 1)
     hip.call('mg_conv_wgrad_ws', ctypes.byref(p), hip.ptr(ws), ctypes.c_long(need if ws is not None else 0), hip.stream(),
-             work=2.0 * M * cout * R * S * Cin, tag=('bf16' if x.dtype == torch.bfloat16 else 'f32', mode, cout, R * S * Cin, M))
+             work=work, tag=('bf16' if x.dtype == torch.bfloat16 else 'f32', mode, cout, R * S * Cin, M, executed, rows is not None))
     return out
 
 
