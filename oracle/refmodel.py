@@ -86,7 +86,7 @@ def resize_any_shape(x, scale_factor, use_max_pool=False, use_avg_pool_binary=Fa
 
 def compute_unknown(masks, k_size=30, is_train=False):
     """maggie/utils/utils.py:28-55; returns a uint8 tensor shaped like `masks`."""
-    out = region.compute_unknown(masks.detach().cpu().numpy(), k_size, is_train)
+    out = region.compute_unknown(masks.detach().float().cpu().numpy(), k_size, is_train)      # .float(): also usable under CPU bf16 autocast (bf16 yardstick runs)
     return torch.from_numpy(out)
 
 
