@@ -345,13 +345,15 @@ def trace_graph_replay(args, fam_alg):
         win = [r for r in rows if r[0] >= t_end - k * ms * 1e6]
         acc = {}
         for s_, e_, nm in win:
-            fam = 'fprop' if ('igemm_fprop_kernel' in nm or 'splitk_finish' in nm) else 'wgrad' if ('igemm_wgrad' in nm or 'wgrad_reduce' in nm) else \
-                'sparse' if 'igemm_fprop_persistent' in nm else None
+            # dense fprop family = every igemm_fprop_* kernel that is not the persistent (sparse-head) form: the register-staged im2col loop,
+            # the direct-to-LDS im2col ring, the spatial halo-tile kernel, split-K + its finishing kernel
+            fam = 'sparse' if ('igemm_fprop' in nm and 'persistent' in nm) else 'fprop' if ('igemm_fprop' in nm or 'splitk_finish' in nm) else \
+                'wgrad' if ('igemm_wgrad' in nm or 'wgrad_reduce' in nm) else None
             if fam:
                 d = acc.setdefault(fam, [0, 0, 0])
                 d[0] += e_ - s_
                 d[1] += 1
-                d[2] += int('igemm_fprop_kernel' in nm or 'igemm_wgrad_kernel' in nm or 'igemm_fprop_persistent' in nm)
+                d[2] += int('igemm_fprop' in nm or 'igemm_wgrad_kernel' in nm)
         busy = sum(e_ - s_ for s_, e_, _ in win)
         span = win[-1][1] - win[0][0]
         out = {'steps_in_window': k, 'traced_ms_per_step': ms, 'launches_per_step': round(len(win) / k, 1), 'gpu_busy_frac': round(busy / span, 4)}

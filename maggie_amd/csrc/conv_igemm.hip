@@ -17,6 +17,7 @@
 #include "common.h"
 #include "../../include/maggie_hip.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -450,6 +451,689 @@ __global__ __launch_bounds__(256) void igemm_fprop_persistent_kernel(const mg_co
     }
 }
 
+// =====================================================================================================================
+// Direct-to-LDS ("async copy") form of the tile loop for the channel-aligned bf16 layers (Cin % 32 == 0: every 64-byte K slab
+// lies inside one filter tap; Cout > 32). The register-staged loop above is latency-bound: one stage of loads in flight per
+// block, two barriers per stage, global -> VGPR -> LDS (PMC: waves parked ~42 % of the time). Here `global_load_lds_dwordx4`
+// writes the tile straight into LDS, so the staging registers disappear and a ring of NS stage buffers keeps NS - 1 stages of
+// loads in flight per block behind ONE barrier per stage:
+//     wait vmcnt(loads of the younger stages) -> s_barrier -> issue stage s + NS - 1 -> MFMAs of stage s
+// LDS image: per slab [rows][64 B] unpadded (an LDS-DMA instruction writes wave-uniform base + lane * 16 B, so 64 lanes = 16
+// rows x 4 chunks land contiguously); bank conflicts of the ds_read_b128 fragment reads are removed by an XOR swizzle applied on
+// the SOURCE side (which lane fetches which 16-byte chunk is free, the global address is per lane): slot = chunk ^ (row & 8 ? 3 : 0)
+// -- the 16 lanes of each ds_read_b128 service group then hit 16 different 16-byte slots of the 256-byte bank row.
+// Out-of-image taps / rows beyond M read a 16-byte zero page instead (an LDS-DMA lane cannot be masked to zero).
+// =====================================================================================================================
+__device__ uint4 mg_zero_page[4];        // zero-initialised device memory
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
+
+template <int BM, int BN, int KS, int NS> constexpr int async_stage_bytes() { return KS * (BM + BN) * 64; }
+template <int BM, int BN, int KS, int NS> constexpr int async_lds_bytes() {
+    return NS * async_stage_bytes<BM, BN, KS, NS>() > ctile_bytes<BM, BN>() ? NS * async_stage_bytes<BM, BN, KS, NS>() : ctile_bytes<BM, BN>();
+}
+
+template <int BM, int BN, int KS, int NS, int MODE>
+__device__ __forceinline__ void igemm_fprop_async_tile(const mg_conv_params& p, const int M, int work, char* smem) {
+    using T = bf16raw;
+    using TR = ElemTraits<T>;
+    constexpr int CE = 8, EPS = 32;
+    constexpr int WAVES_M = TileCfg<BM, BN>::WAVES_M, WAVES_N = TileCfg<BM, BN>::WAVES_N;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, FM = WM / 16, FN = WN / 16;
+    constexpr int AG = BM / 64, BG = BN / 64;               // 16-row groups each wave fetches per slab (A, B)
+    constexpr int SLAB_A = BM * 64, SLAB_B = BN * 64;       // bytes per slab
+    constexpr int STAGE = KS * (SLAB_A + SLAB_B);
+    constexpr int L = KS * (AG + BG);                       // LDS-DMA instructions per wave per stage
+    static_assert(BN >= 64 && NS >= 2 && L * (NS - 1) <= 60, "tile / ring not supported");
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int ntn = (p.Cout + BN - 1) / BN;
+    const int mt = work / ntn;
+    const int m0 = mt * BM, n0 = (work - mt * ntn) * BN;
+    const int taps = p.R * p.S;
+    const int Ktot = taps * p.Cin;
+    const int nslab = Ktot / EPS;
+    const int nstage = (nslab + KS - 1) / KS;
+    const char* __restrict__ xb = (const char*)p.x;
+    const char* __restrict__ wb = (const char*)p.w;
+    const char* zpage = (const char*)mg_zero_page;
+    const int sshift = p.stride == 1 ? 0 : (p.stride == 2 ? 1 : 2);
+
+    // this lane's slot in every 16-row x 4-chunk DMA instruction, and the chunk it fetches into it (swizzle on the source side)
+    const int lrow = lane >> 2;                              // row inside the 16-row group
+    const int lch = (lane & 3) ^ (((lane >> 5) & 1) * 3);    // chunk of the 64-byte slab this lane fetches
+    int hb[AG], wbs[AG], rbase[AG];
+    bool rok[AG];
+#pragma unroll
+    for (int i = 0; i < AG; ++i) {
+        const int m = m0 + (wave + 4 * i) * 16 + lrow;
+        rok[i] = m < M;
+        const int mm = rok[i] ? m : 0;
+        if (MODE != MG_MODE_GATHER) {
+            const int hw = p.Hout * p.Wout;
+            const int n = mm / hw, rem = mm - n * hw, ho = rem / p.Wout, wo = rem - ho * p.Wout;
+            if (MODE == MG_MODE_CONV) { hb[i] = ho * p.stride - p.pad; wbs[i] = wo * p.stride - p.pad; }
+            else { hb[i] = ho + p.pad; wbs[i] = wo + p.pad; }
+            rbase[i] = n * p.Hin;
+        } else {
+            hb[i] = 0; wbs[i] = 0; rbase[i] = mm * taps;
+        }
+    }
+    const char* bptr[BG];
+    bool bok[BG];
+#pragma unroll
+    for (int i = 0; i < BG; ++i) {
+        const int co = n0 + (wave + 4 * i) * 16 + lrow;
+        bok[i] = co < p.Cout;
+        bptr[i] = wb + ((long)(bok[i] ? co : 0) * Ktot + lch * CE) * 2l;
+    }
+    const int spt = p.Cin / EPS;
+    int q_slab = 0, q_sub = 0, q_ky = 0, q_kx = 0, q_tap = 0;
+    const long xpitch = (long)p.ldx * 2l;
+
+    auto issue_stage = [&](int buf) {
+        char* sbase = smem + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            const bool live = q_slab < nslab;
+            const int dh = q_ky * p.dil, dw = q_kx * p.dil;
+            const long coff = ((long)q_sub * EPS + lch * CE) * 2l;
+#pragma unroll
+            for (int i = 0; i < AG; ++i) {
+                long src = -1;
+                if (MODE == MG_MODE_CONV) {
+                    const int hi = hb[i] + dh, wi = wbs[i] + dw;
+                    if ((unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win) src = (long)(rbase[i] + hi) * p.Win + wi;
+                } else if (MODE == MG_MODE_TCONV) {
+                    const int th = hb[i] - dh, tw = wbs[i] - dw;
+                    const int hi = th >> sshift, wi = tw >> sshift;
+                    if (th >= 0 && tw >= 0 && ((th | tw) & (p.stride - 1)) == 0 && hi < p.Hin && wi < p.Win)
+                        src = (long)(rbase[i] + hi) * p.Win + wi;
+                } else {
+                    if (rok[i] && live) src = p.nbr[(long)rbase[i] + q_tap];
+                }
+                const char* g = (src >= 0 && rok[i] && live) ? xb + src * xpitch + coff : zpage;
+                char* dst = sbase + j * SLAB_A + (wave + 4 * i) * 1024;             // wave-uniform; the hardware adds lane * 16
+                __builtin_amdgcn_global_load_lds((gbl_void_ptr)g, (lds_void_ptr)dst, 16, 0, 0);
+            }
+            const long boff = (long)q_slab * EPS * 2l;
+#pragma unroll
+            for (int i = 0; i < BG; ++i) {
+                const char* g = (bok[i] && live) ? bptr[i] + boff : zpage;
+                char* dst = sbase + KS * SLAB_A + j * SLAB_B + (wave + 4 * i) * 1024;
+                __builtin_amdgcn_global_load_lds((gbl_void_ptr)g, (lds_void_ptr)dst, 16, 0, 0);
+            }
+            ++q_slab;
+            if (++q_sub == spt) { q_sub = 0; ++q_tap; if (++q_kx == p.S) { q_kx = 0; ++q_ky; } }
+        }
+    };
+
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int lgs = lg ^ (((lr >> 3) & 1) * 3);              // slot of k-chunk lg in this fragment row (row & 8 == lr & 8)
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int a_off = (wm * WM + lr) * 64 + lgs * 16;
+    const int b_off = KS * SLAB_A + (wn * WN + lr) * 64 + lgs * 16;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;      // LDS byte address of the ring
+
+#pragma unroll
+    for (int u = 0; u < NS - 1; ++u)
+        if (u < nstage) issue_stage(u);
+    for (int s = 0; s < nstage; ++s) {
+        // this wave's loads of stage s have landed once at most the younger stages' loads are outstanding
+        const int younger = min(NS - 2, nstage - 1 - s);
+        if (NS == 2 || younger == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * L) : "memory");
+        __builtin_amdgcn_s_barrier();                        // everyone's stage s is in LDS; everyone is done reading stage s - 1
+        asm volatile("" ::: "memory");
+        if (s + NS - 1 < nstage) issue_stage((s + NS - 1) % NS);
+        // Fragment reads as inline asm: hipcc's waitcnt pass treats every LDS-DMA in flight as a possible writer of whatever a
+        // ds_read it can see reads, and puts `s_waitcnt vmcnt(0)` in front of it -- which would drain the ring every stage.
+        // The ordering these reads need is exactly the counted wait + barrier above.
+        const unsigned sb = lds_base + (unsigned)((s % NS) * STAGE);
+        u32x4 fa[KS][FM], fb[KS][FN];
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[j][i]) : "v"(sb + (unsigned)a_off), "n"(j * SLAB_A + i * 1024) : "memory");
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[j][i]) : "v"(sb + (unsigned)b_off), "n"(j * SLAB_B + i * 1024) : "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            // slab j's FM + FN reads are complete once at most the later slabs' reads are outstanding
+            if (j == KS - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else if (j == KS - 2) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FM + FN) : "memory");
+            else if (j == KS - 3) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((2 * (FM + FN)) > 15 ? 15 : 2 * (FM + FN)) : "memory");
+            else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((3 * (FM + FN)) > 15 ? 15 : 3 * (FM + FN)) : "memory");
+            __builtin_amdgcn_sched_barrier(0);               // the MFMAs below must not be hoisted above the wait
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int jj = 0; jj < FN; ++jj)
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&fa[j][i], *(const bf16x8*)&fb[j][jj], acc[i][jj], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                         // all fragment reads done before the epilogue reuses the buffers
+
+    // ---------------- epilogue (identical arithmetic to igemm_fprop_tile) ----------------
+    constexpr int EP = ep_passes<BM, BN>();
+    constexpr int PR = BM / EP;
+    constexpr int LDC = BN + 4;
+    float* sC = (float*)smem;
+    float* sStat = (float*)(smem + PR * LDC * 4);
+    constexpr int CPR = BN / CE;
+    constexpr int RPP = 256 / CPR;
+    const int cc = t % CPR, rr = t / CPR;
+    const int cbase = n0 + cc * CE;
+    float sc[CE], sh[CE], s1[CE], s2[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+        int c = cbase + e;
+        sc[e] = (p.scale && c < p.Cout) ? p.scale[c] : 1.f;
+        sh[e] = (p.shift && c < p.Cout) ? p.shift[c] : 0.f;
+        s1[e] = 0.f; s2[e] = 0.f;
+    }
+    const bool full_vec = (cbase + CE <= p.Cout);
+    T* __restrict__ yb = (T*)p.y;
+    const T* __restrict__ r1b = (const T*)p.res;
+    const T* __restrict__ r2b = (const T*)p.res2;
+#pragma unroll
+    for (int ep = 0; ep < EP; ++ep) {
+        if (ep > 0) __syncthreads();
+        if ((wm * WM) / PR == ep) {
+            const int rb0 = wm * WM - ep * PR;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        sC[(rb0 + i * 16 + lg * 4 + e) * LDC + wn * WN + j * 16 + lr] = acc[i][j][e];
+        }
+        __syncthreads();
+        for (int r = rr; r < PR; r += RPP) {
+            int m = m0 + ep * PR + r;
+            if (m >= M || cbase >= p.Cout) continue;
+            float v[CE];
+#pragma unroll
+            for (int e = 0; e < CE; ++e) v[e] = sC[r * LDC + cc * CE + e];
+            long rrow = m;
+            if (p.res_mode == 2) {
+                int hw = p.Hout * p.Wout;
+                int n = m / hw; int rem = m - n * hw; int ho = rem / p.Wout; int wo = rem - ho * p.Wout;
+                rrow = ((long)n * (p.Hout >> 1) + (ho >> 1)) * (p.Wout >> 1) + (wo >> 1);
+            }
+            float rv[CE], rv2[CE];
+#pragma unroll
+            for (int e = 0; e < CE; ++e) { rv[e] = 0.f; rv2[e] = 0.f; }
+            if (r1b) {
+                if (full_vec) { uint4 q = *(const uint4*)(r1b + rrow * p.ldr + cbase); TR::unpack(q, rv); }
+                else {
+#pragma unroll
+                    for (int e = 0; e < CE; ++e) if (cbase + e < p.Cout) rv[e] = TR::ld(r1b + rrow * p.ldr + cbase + e);
+                }
+            }
+            if (r2b) {
+                if (full_vec) { uint4 q = *(const uint4*)(r2b + (long)m * p.ldr2 + cbase); TR::unpack(q, rv2); }
+                else {
+#pragma unroll
+                    for (int e = 0; e < CE; ++e) if (cbase + e < p.Cout) rv2[e] = TR::ld(r2b + (long)m * p.ldr2 + cbase + e);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
+                float x = v[e];
+                if (p.pre_act) x = apply_act(x, p.act, p.slope);
+                x = x * sc[e] + sh[e];
+                x += rv[e];
+                if (!p.pre_act) x = apply_act(x, p.act, p.slope);
+                x += rv2[e];
+                x = TR::rnd(x);
+                v[e] = x;
+                s1[e] += x; s2[e] += x * x;
+            }
+            T* dst = yb + (long)m * p.ldy + p.yoff + cbase;
+            if (full_vec) *(uint4*)dst = TR::pack(v);
+            else {
+#pragma unroll
+                for (int e = 0; e < CE; ++e) if (cbase + e < p.Cout) TR::st(dst + e, v[e]);
+            }
+        }
+    }
+    if (p.stats) {
+        static_assert((CPR & (CPR - 1)) == 0 && CPR <= 32, "channel chunks per tile row must be a power of two");
+#pragma unroll
+        for (int o = CPR; o < 64; o <<= 1) {
+#pragma unroll
+            for (int e = 0; e < CE; ++e) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+        }
+        if (lane < CPR) {
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
+                sStat[wave * 2 * BN + lane * CE + e] = s1[e];
+                sStat[wave * 2 * BN + BN + lane * CE + e] = s2[e];
+            }
+        }
+        __syncthreads();
+        if (t < 2 * BN) {
+            const int c = t < BN ? t : t - BN;
+            if (n0 + c < p.Cout) {
+                const float v = (sStat[t] + sStat[2 * BN + t]) + (sStat[4 * BN + t] + sStat[6 * BN + t]);
+                if (p.stat_mode == 1) {
+                    if (t < BN) atomicAdd(&p.stats[n0 + c], v);
+                } else {
+                    float* st = p.stats + (size_t)(mt & (MG_STAT_REPLICAS - 1)) * 2 * p.Cout;
+                    atomicAdd(&st[(t < BN ? 0 : p.Cout) + n0 + c], v);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int KS, int NS, int MODE>
+__global__ __launch_bounds__(256) void igemm_fprop_async_kernel(const mg_conv_params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ntn = (p.Cout + BN - 1) / BN;
+    int work;
+    if (!xcd_order(((p.M + BM - 1) / BM) * ntn, work)) return;
+    igemm_fprop_async_tile<BM, BN, KS, NS, MODE>(p, p.M, work, smem);
+}
+
+template <int BM, int BN, int KS, int NS, int MODE>
+__global__ __launch_bounds__(256) void igemm_fprop_async_persistent_kernel(const mg_conv_params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int M = dev_rows(p.m_dev, p.M);
+    const int ntn = (p.Cout + BN - 1) / BN;
+    const int L = ((M + BM - 1) / BM) * ntn;
+    const int chunk = (L + NXCD - 1) / NXCD;
+    for (int vb = blockIdx.x; vb / NXCD < chunk; vb += gridDim.x) {
+        const int work = (vb % NXCD) * chunk + vb / NXCD;
+        if (work < L) igemm_fprop_async_tile<BM, BN, KS, NS, MODE>(p, M, work, smem);
+        __syncthreads();
+    }
+}
+
+// =====================================================================================================================
+// Spatial halo-tile form for the 3x3 / stride 1 / pad 1 layers with Cin % 32 == 0 (bf16): the encoder's BasicBlocks and the
+// decoder convs, forward and data gradient -- the bulk of the trunk's FLOPs (north_star: "LDS-staged 3x3 tiles").
+// The im2col loops above re-fetch every input pixel once per filter tap: a 64 x 64 tile moves 32 FLOP per byte it pulls from
+// L2, and the kernels sit at ~240 TFLOP/s = ~7.5 TB/s of L2 -> LDS traffic whatever the shape (measured; larger tiles leave CUs
+// idle on these small layers). Here a workgroup owns TH x 16 output pixels x 64 output channels; per 32-channel slab it
+// stages the (TH+2) x 18 input halo ONCE (direct-to-LDS) plus the nine 64 x 32 weight slabs, and forms the nine taps from LDS
+// at constant offsets: 2.5-3x fewer bytes per FLOP. The data gradient of such a layer is the same convolution with the taps
+// mirrored (MG_MODE_TCONV).
+// LDS image of the halo: [TH+2][24 pixels][64 B] (pitch 24 px so that the bank swizzle slot = chunk ^ 2*((pixel>>2)&1) depends on
+// x + kx only), weights per tap [64 rows][64 B] swizzled as in the im2col ring. NS = 3 stages in flight, one barrier per stage.
+// =====================================================================================================================
+template <int TH, int BN, int NS> struct HaloCfg {
+    static constexpr int TW = 16, BM = TH * TW, PW = 24, HH = TH + 2;
+    static constexpr int A_INSTR = (HH * PW + 15) / 16, A_PER_WAVE = (A_INSTR + 3) / 4, A_BYTES = A_PER_WAVE * 4 * 1024;
+    static constexpr int B_GRP = BN / 16, B_INSTR = 9 * B_GRP, B_PER_WAVE = (B_INSTR + 3) / 4, B_BYTES = 9 * BN * 64;
+    static constexpr int STAGE = A_BYTES + B_BYTES, L = A_PER_WAVE + B_PER_WAVE;
+    static constexpr int LDS = NS * STAGE > ctile_bytes<BM, BN>() ? NS * STAGE : ctile_bytes<BM, BN>();
+};
+
+template <int TH, int BN, int NS, int MODE>
+__device__ __forceinline__ void igemm_fprop_halo_tile(const mg_conv_params& p, int work, char* smem) {
+    using T = bf16raw;
+    using TR = ElemTraits<T>;
+    using HC = HaloCfg<TH, BN, NS>;
+    constexpr int CE = 8, EPS = 32, TW = HC::TW, BM = HC::BM, PW = HC::PW, HH = HC::HH;
+    constexpr int WAVES_M = 2, WAVES_N = 2;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, FM = WM / 16, FN = WN / 16;
+    constexpr int STAGE = HC::STAGE, L = HC::L, A_BYTES = HC::A_BYTES;
+    static_assert(BN == 64 && (TH == 8 || TH == 4) && 2 * L <= 60, "halo tile configuration");
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int H = p.Hout, W = p.Wout;                        // stride 1, pad 1: input and output share the geometry
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int ntn = (p.Cout + BN - 1) / BN;
+    const int mt = work / ntn;
+    const int n0 = (work - mt * ntn) * BN;
+    const int img = mt / (tiles_y * tiles_x);
+    const int trem = mt - img * tiles_y * tiles_x;
+    const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+    const int Ktot = 9 * p.Cin;
+    const int nstage = p.Cin / EPS;                          // one stage = one 32-channel slab, all nine taps
+    const char* __restrict__ xb = (const char*)p.x;
+    const char* __restrict__ wb = (const char*)p.w;
+    const char* zpage = (const char*)mg_zero_page;
+    const long xpitch = (long)p.ldx * 2l;
+
+    // ---- what this lane fetches: A = halo pixels (A_PER_WAVE instructions per wave and stage), B = weight rows ----------------------
+    const char* asrc[HC::A_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < HC::A_PER_WAVE; ++i) {
+        const int a = wave + 4 * i;
+        const int q = a * 16 + (lane >> 2);                  // pixel slot of the linear [HH][PW] halo image
+        const int hy = q / PW, hx = q - hy * PW;
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const bool ok = a < HC::A_INSTR && hy < HH && hx < TW + 2 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        const int ach = (lane & 3) ^ (((lane >> 4) & 1) * 2);  // chunk landing in this lane's slot: slot = chunk ^ 2*((q>>2)&1)
+        asrc[i] = ok ? xb + ((long)(img * H + iy) * W + ix) * xpitch + ach * 16 : nullptr;
+    }
+    const char* bsrc[HC::B_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < HC::B_PER_WAVE; ++i) {
+        const int bi = wave + 4 * i;
+        const int tap = bi / HC::B_GRP, grp = bi - tap * HC::B_GRP;
+        const int co = n0 + grp * 16 + (lane >> 2);
+        const int bch = (lane & 3) ^ (((lane >> 5) & 1) * 3);
+        const bool ok = bi < HC::B_INSTR && co < p.Cout;
+        bsrc[i] = ok ? wb + ((long)co * Ktot + (long)tap * p.Cin) * 2l + bch * 16 : nullptr;
+    }
+    auto issue_stage = [&](int s, int buf) {
+        char* sbase = smem + buf * STAGE;
+        const long coff = (long)s * EPS * 2l;
+#pragma unroll
+        for (int i = 0; i < HC::A_PER_WAVE; ++i) {
+            const char* g = asrc[i] ? asrc[i] + coff : zpage;
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)g, (lds_void_ptr)(sbase + (wave + 4 * i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < HC::B_PER_WAVE; ++i) {
+            const char* g = bsrc[i] ? bsrc[i] + coff : zpage;
+            const int bi = wave + 4 * i;
+            // instruction bi = (tap, 16-row group): its 1 KiB lands at tap * BN * 64 + group * 1024 = bi * 1024 (B_GRP groups per tap)
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)g, (lds_void_ptr)(sbase + A_BYTES + bi * 1024), 16, 0, 0);
+        }
+    };
+
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int lr = lane & 15, lg = lane >> 4;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    // A fragment row i of this wave = tile row ty = wm * FM + i, pixel tx = lr; tap (aky, akx) reads halo pixel (ty + aky, lr + akx)
+    unsigned a_lane[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int px = lr + kx;
+        a_lane[kx] = (unsigned)((wm * FM * PW + px) * 64 + ((lg ^ (((px >> 2) & 1) * 2)) << 4));
+    }
+    const unsigned b_lane = (unsigned)(A_BYTES + (wn * WN + lr) * 64 + ((lg ^ (((lr >> 3) & 1) * 3)) << 4));
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int u = 0; u < NS - 1; ++u)
+        if (u < nstage) issue_stage(u, u);
+    for (int s = 0; s < nstage; ++s) {
+        const int younger = min(NS - 2, nstage - 1 - s);
+        if (NS == 2 || younger == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (s + NS - 1 < nstage) issue_stage(s + NS - 1, (s + NS - 1) % NS);
+        const unsigned sb = lds_base + (unsigned)((s % NS) * STAGE);
+        u32x4 fa[2][FM], fb[2][FN];
+        // taps are software-pipelined: the reads of tap t + 1 are issued before the MFMAs of tap t (fragment row i of the wave sits
+        // i halo rows further down: a literal offset)
+        auto read_tap = [&](auto tap_c, auto buf_c) {
+            constexpr int TAP = decltype(tap_c)::value, BUF = decltype(buf_c)::value;
+            constexpr int ky_ = TAP / 3, kx_ = TAP % 3;
+            constexpr int aky_ = MODE == MG_MODE_TCONV ? 2 - ky_ : ky_, akx_ = MODE == MG_MODE_TCONV ? 2 - kx_ : kx_;
+            const unsigned aaddr = sb + a_lane[akx_];
+            const unsigned baddr = sb + b_lane;
+            if constexpr (FM >= 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[BUF][0]) : "v"(aaddr), "n"((aky_ + 0) * PW * 64) : "memory");
+            if constexpr (FM >= 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[BUF][1]) : "v"(aaddr), "n"((aky_ + 1) * PW * 64) : "memory");
+            if constexpr (FM >= 3) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[BUF][2]) : "v"(aaddr), "n"((aky_ + 2) * PW * 64) : "memory");
+            if constexpr (FM >= 4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[BUF][3]) : "v"(aaddr), "n"((aky_ + 3) * PW * 64) : "memory");
+            if constexpr (FN >= 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[BUF][0]) : "v"(baddr), "n"(TAP * BN * 64 + 0 * 1024) : "memory");
+            if constexpr (FN >= 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[BUF][1]) : "v"(baddr), "n"(TAP * BN * 64 + 1 * 1024) : "memory");
+        };
+        auto mma_tap = [&](auto buf_c) {
+            constexpr int BUF = decltype(buf_c)::value;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int jj = 0; jj < FN; ++jj)
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&fa[BUF][i], *(const bf16x8*)&fb[BUF][jj], acc[i][jj], 0, 0, 0);
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+#define MG_TAP_STEP(T_, CUR, NXT)                                                                       \
+        read_tap(std::integral_constant<int, (T_) + 1>{}, NXT{});                                         \
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(FM + FN) : "memory");                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        mma_tap(CUR{});
+        read_tap(I0{}, I0{});
+        MG_TAP_STEP(0, I0, I1) MG_TAP_STEP(1, I1, I0) MG_TAP_STEP(2, I0, I1) MG_TAP_STEP(3, I1, I0)
+        MG_TAP_STEP(4, I0, I1) MG_TAP_STEP(5, I1, I0) MG_TAP_STEP(6, I0, I1) MG_TAP_STEP(7, I1, I0)
+#undef MG_TAP_STEP
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tap(I0{});
+    }
+    __syncthreads();
+
+    // ---------------- epilogue: same arithmetic as the im2col tiles; row r of the tile = pixel (y0 + r / 16, x0 + r % 16) ----------------
+    constexpr int EP = ep_passes<BM, BN>();
+    constexpr int PR = BM / EP;
+    constexpr int LDC = BN + 4;
+    float* sC = (float*)smem;
+    float* sStat = (float*)(smem + PR * LDC * 4);
+    constexpr int CPR = BN / CE;
+    constexpr int RPP = 256 / CPR;
+    const int cc = t % CPR, rr = t / CPR;
+    const int cbase = n0 + cc * CE;
+    float sc[CE], sh[CE], s1[CE], s2[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+        int c = cbase + e;
+        sc[e] = (p.scale && c < p.Cout) ? p.scale[c] : 1.f;
+        sh[e] = (p.shift && c < p.Cout) ? p.shift[c] : 0.f;
+        s1[e] = 0.f; s2[e] = 0.f;
+    }
+    const bool full_vec = (cbase + CE <= p.Cout);
+    T* __restrict__ yb = (T*)p.y;
+    const T* __restrict__ r1b = (const T*)p.res;
+    const T* __restrict__ r2b = (const T*)p.res2;
+#pragma unroll
+    for (int ep = 0; ep < EP; ++ep) {
+        if (ep > 0) __syncthreads();
+        if ((wm * WM) / PR == ep) {
+            const int rb0 = wm * WM - ep * PR;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        sC[(rb0 + i * 16 + lg * 4 + e) * LDC + wn * WN + j * 16 + lr] = acc[i][j][e];
+        }
+        __syncthreads();
+        for (int r = rr; r < PR; r += RPP) {
+            const int rt = ep * PR + r;
+            const int y = y0 + rt / TW, x = x0 + (rt % TW);
+            if (y >= H || x >= W || cbase >= p.Cout) continue;
+            const long m = ((long)img * H + y) * W + x;
+            float v[CE];
+#pragma unroll
+            for (int e = 0; e < CE; ++e) v[e] = sC[r * LDC + cc * CE + e];
+            long rrow = m;
+            if (p.res_mode == 2) rrow = ((long)img * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1);
+            float rv[CE], rv2[CE];
+#pragma unroll
+            for (int e = 0; e < CE; ++e) { rv[e] = 0.f; rv2[e] = 0.f; }
+            if (r1b) {
+                if (full_vec) { uint4 q = *(const uint4*)(r1b + rrow * p.ldr + cbase); TR::unpack(q, rv); }
+                else {
+#pragma unroll
+                    for (int e = 0; e < CE; ++e) if (cbase + e < p.Cout) rv[e] = TR::ld(r1b + rrow * p.ldr + cbase + e);
+                }
+            }
+            if (r2b) {
+                if (full_vec) { uint4 q = *(const uint4*)(r2b + m * p.ldr2 + cbase); TR::unpack(q, rv2); }
+                else {
+#pragma unroll
+                    for (int e = 0; e < CE; ++e) if (cbase + e < p.Cout) rv2[e] = TR::ld(r2b + m * p.ldr2 + cbase + e);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
+                float xv = v[e];
+                if (p.pre_act) xv = apply_act(xv, p.act, p.slope);
+                xv = xv * sc[e] + sh[e];
+                xv += rv[e];
+                if (!p.pre_act) xv = apply_act(xv, p.act, p.slope);
+                xv += rv2[e];
+                xv = TR::rnd(xv);
+                v[e] = xv;
+                s1[e] += xv; s2[e] += xv * xv;
+            }
+            T* dst = yb + m * p.ldy + p.yoff + cbase;
+            if (full_vec) *(uint4*)dst = TR::pack(v);
+            else {
+#pragma unroll
+                for (int e = 0; e < CE; ++e) if (cbase + e < p.Cout) TR::st(dst + e, v[e]);
+            }
+        }
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int o = CPR; o < 64; o <<= 1) {
+#pragma unroll
+            for (int e = 0; e < CE; ++e) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+        }
+        if (lane < CPR) {
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
+                sStat[wave * 2 * BN + lane * CE + e] = s1[e];
+                sStat[wave * 2 * BN + BN + lane * CE + e] = s2[e];
+            }
+        }
+        __syncthreads();
+        if (t < 2 * BN) {
+            const int c = t < BN ? t : t - BN;
+            if (n0 + c < p.Cout) {
+                const float v = (sStat[t] + sStat[2 * BN + t]) + (sStat[4 * BN + t] + sStat[6 * BN + t]);
+                if (p.stat_mode == 1) {
+                    if (t < BN) atomicAdd(&p.stats[n0 + c], v);
+                } else {
+                    float* st = p.stats + (size_t)(mt & (MG_STAT_REPLICAS - 1)) * 2 * p.Cout;
+                    atomicAdd(&st[(t < BN ? 0 : p.Cout) + n0 + c], v);
+                }
+            }
+        }
+    }
+}
+
+template <int TH, int BN, int NS, int MODE>
+__global__ __launch_bounds__(256) void igemm_fprop_halo_kernel(const mg_conv_params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles = p.N * ((p.Hout + TH - 1) / TH) * ((p.Wout + 15) / 16) * ((p.Cout + BN - 1) / BN);
+    int work;
+    if (!xcd_order(tiles, work)) return;
+    igemm_fprop_halo_tile<TH, BN, NS, MODE>(p, work, smem);
+}
+
+static inline bool halo_eligible(const mg_conv_params& p) {
+    static const int enabled = [] { const char* e = getenv("MG_FPROP_HALO"); return e ? atoi(e) : 1; }();
+    if (!enabled || p.dtype != MG_BF16 || p.m_dev || p.mode == MG_MODE_GATHER) return false;
+    // Cin >= 96: with fewer than three 32-channel stages the ring's prologue dominates (C64 128x128: 22.5 us against 20.5 us im2col)
+    if (p.R != 3 || p.S != 3 || p.stride != 1 || p.dil != 1 || p.pad != 1 || p.Cin % 32 != 0 || p.Cin < 96 || p.Cout < 64) return false;
+    if (p.Hin != p.Hout || p.Win != p.Wout || p.Wout < 16 || p.Hout < 4) return false;
+    return true;
+}
+
+template <int TH>
+static int launch_fprop_halo(const mg_conv_params& p, hipStream_t st) {
+    constexpr int BN = 64, NS = 3;
+    constexpr size_t lds = HaloCfg<TH, BN, NS>::LDS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)igemm_fprop_halo_kernel<TH, BN, NS, MG_MODE_CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)igemm_fprop_halo_kernel<TH, BN, NS, MG_MODE_TCONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const long tiles = (long)p.N * ((p.Hout + TH - 1) / TH) * ((p.Wout + 15) / 16) * ((p.Cout + BN - 1) / BN);
+    dim3 grid(xcd_grid(tiles));
+    if (p.mode == MG_MODE_CONV) hipLaunchKernelGGL((igemm_fprop_halo_kernel<TH, BN, NS, MG_MODE_CONV>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((igemm_fprop_halo_kernel<TH, BN, NS, MG_MODE_TCONV>), grid, dim3(256), lds, st, p);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+static int dispatch_fprop_halo(const mg_conv_params& p, hipStream_t st) {
+    // 8 x 16 pixel tiles when they still give about one workgroup per CU (a workgroup holds a whole CU's LDS), else 4 x 16
+    static const long want = [] { const char* e = getenv("MG_HALO_BLOCKS"); return e ? atol(e) : 200l; }();
+    const long t8 = (long)p.N * ((p.Hout + 7) / 8) * ((p.Wout + 15) / 16) * ((p.Cout + 63) / 64);
+    if (t8 >= want && p.Hout >= 8) return launch_fprop_halo<8>(p, st);
+    return launch_fprop_halo<4>(p, st);
+}
+
+static inline bool async_eligible(const mg_conv_params& p) {
+    // 1 (default): the 1x1 layers and the sparse gather convs (measured: 1x1 C128->64 15.6 -> 10.5 us; neutral or slightly slower than the
+    // register-staged loop on the dense 3x3 shapes that the halo kernel does not take); 2: every aligned layer; 0: off
+    static const int enabled = [] { const char* e = getenv("MG_FPROP_ASYNC"); return e ? atoi(e) : 1; }();
+    if (!enabled || p.dtype != MG_BF16 || p.Cin % 32 != 0 || p.Cout <= 32) return false;
+    if (enabled == 1 && !(p.R * p.S == 1 || p.mode == MG_MODE_GATHER)) return false;
+    if (p.mode == MG_MODE_TCONV && !(p.stride == 1 || p.stride == 2 || p.stride == 4)) return false;
+    if ((long)p.R * p.S * p.Cin * 2l >= (1l << 31)) return false;
+    return true;
+}
+
+template <int BM, int BN, int KS, int NS>
+int launch_fprop_async(const mg_conv_params& p, hipStream_t st) {
+    constexpr size_t lds = async_lds_bytes<BM, BN, KS, NS>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)igemm_fprop_async_kernel<BM, BN, KS, NS, MG_MODE_CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)igemm_fprop_async_kernel<BM, BN, KS, NS, MG_MODE_TCONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)igemm_fprop_async_kernel<BM, BN, KS, NS, MG_MODE_GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)igemm_fprop_async_persistent_kernel<BM, BN, KS, NS, MG_MODE_CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)igemm_fprop_async_persistent_kernel<BM, BN, KS, NS, MG_MODE_GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const long tiles = (long)((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
+    if (p.m_dev) {
+        const long g = tiles < 2048 ? tiles : 2048;
+        dim3 pg(xcd_grid(g < 1 ? 1 : g));
+        if (p.mode == MG_MODE_CONV) hipLaunchKernelGGL((igemm_fprop_async_persistent_kernel<BM, BN, KS, NS, MG_MODE_CONV>), pg, dim3(256), lds, st, p);
+        else if (p.mode == MG_MODE_GATHER) hipLaunchKernelGGL((igemm_fprop_async_persistent_kernel<BM, BN, KS, NS, MG_MODE_GATHER>), pg, dim3(256), lds, st, p);
+        else return -2;
+        MG_CHECK_LAUNCH();
+        return 0;
+    }
+    dim3 grid(xcd_grid(tiles));
+    switch (p.mode) {
+        case MG_MODE_CONV: hipLaunchKernelGGL((igemm_fprop_async_kernel<BM, BN, KS, NS, MG_MODE_CONV>), grid, dim3(256), lds, st, p); break;
+        case MG_MODE_TCONV: hipLaunchKernelGGL((igemm_fprop_async_kernel<BM, BN, KS, NS, MG_MODE_TCONV>), grid, dim3(256), lds, st, p); break;
+        case MG_MODE_GATHER: hipLaunchKernelGGL((igemm_fprop_async_kernel<BM, BN, KS, NS, MG_MODE_GATHER>), grid, dim3(256), lds, st, p); break;
+        default: return -2;
+    }
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+// tile choice as in dispatch_fprop_ks (largest tile that still fills the chip); ring depth / stage width by K and tile
+static int dispatch_fprop_async(const mg_conv_params& p, hipStream_t st) {
+    static const long want = [] { const char* e = getenv("MG_FPROP_BLOCKS"); return e ? atol(e) : 768l; }();
+    auto blocks = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn); };
+    static const int ns_small = [] { const char* e = getenv("MG_ASYNC_NS"); return e ? atoi(e) : 4; }();
+    if (p.Cout > 64) {
+        if (blocks(128, 128) >= want) return launch_fprop_async<128, 128, 2, 3>(p, st);
+        if (blocks(128, 64) >= want) return ns_small >= 4 ? launch_fprop_async<128, 64, 2, 4>(p, st) : launch_fprop_async<128, 64, 2, 3>(p, st);
+        return ns_small >= 4 ? launch_fprop_async<64, 64, 2, 4>(p, st) : launch_fprop_async<64, 64, 2, 3>(p, st);
+    }
+    if (blocks(128, 64) >= want) return ns_small >= 4 ? launch_fprop_async<128, 64, 2, 4>(p, st) : launch_fprop_async<128, 64, 2, 3>(p, st);
+    return ns_small >= 4 ? launch_fprop_async<64, 64, 2, 4>(p, st) : launch_fprop_async<64, 64, 2, 3>(p, st);
+}
+
 template <typename T, int BM, int BN, int KS>
 int launch_fprop(const mg_conv_params& p, hipStream_t st) {
     dim3 grid(xcd_grid((long)((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN)));
@@ -622,6 +1306,7 @@ static SplitPlan plan_splitk(const mg_conv_params& p) {
     static const int enabled = [] { const char* e = getenv("MG_FPROP_SPLITK"); return e ? atoi(e) : 1; }();
     static const long want_small = [] { const char* e = getenv("MG_FPROP_BLOCKS_SMALL"); return e ? atol(e) : 300l; }();
     if (!enabled || p.mode == MG_MODE_GATHER || p.Cout < 64 || p.M > 8192 || p.m_dev) return sp;
+    if (halo_eligible(p)) return sp;             // the halo-tile kernel beats split-K on the deep 3x3 layers (C256 32x32: 30 -> 14 us)
     constexpr int EPS = ElemTraits<T>::EPS;
     const int nslab = (p.R * p.S * p.Cin + EPS - 1) / EPS;
     const int nstage = (nslab + 3) / 4;
@@ -671,6 +1356,8 @@ static int launch_fprop_split(const mg_conv_params& p, float* ws, int splits, hi
 
 template <typename T>
 int dispatch_fprop(const mg_conv_params& p, hipStream_t st) {
+    if (sizeof(T) == 2 && halo_eligible(p)) return dispatch_fprop_halo(p, st);
+    if (sizeof(T) == 2 && async_eligible(p)) return dispatch_fprop_async(p, st);
     const int eps = sizeof(T) == 2 ? 32 : 16;
     const int nslab = (p.R * p.S * p.Cin + eps - 1) / eps;
     // stage width: 4 slabs (256 B of K per row) for the K-heavy layers, 2 slabs for K <= 576 (C32 / C64 3x3 layers: half the LDS

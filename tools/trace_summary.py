@@ -14,8 +14,10 @@ win = [r for r in rows if r[0] >= t_end - steps * ms * 1e6]
 
 
 def family(nm):
-    if 'igemm_fprop_persistent' in nm: return 'maggie: igemm_fprop_persistent (sparse head)'
-    if 'igemm_fprop' in nm: return 'maggie: igemm_fprop (conv fprop/dgrad)'
+    if 'igemm_fprop' in nm and 'persistent' in nm: return 'maggie: igemm_fprop persistent (sparse head)'
+    if 'igemm_fprop_halo' in nm: return 'maggie: igemm_fprop_halo (3x3 s1 halo tiles)'
+    if 'igemm_fprop_async' in nm: return 'maggie: igemm_fprop_async (direct-to-LDS im2col)'
+    if 'igemm_fprop' in nm: return 'maggie: igemm_fprop (register-staged im2col)'
     if 'igemm_wgrad' in nm or 'wgrad_reduce' in nm: return 'maggie: igemm_wgrad'
     if 'anonymous namespace' in nm and 'at::native' not in nm and 'ck::' not in nm and 'Cat' not in nm and 'multi_tensor' not in nm \
             and 'layer_norm' not in nm and 'GammaBeta' not in nm and 'cuCompute' not in nm and 'reflection' not in nm:
