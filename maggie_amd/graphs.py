@@ -165,11 +165,17 @@ class GraphedCallable:
             for m, s in zip(mutable, snap):
                 m.copy_(s)
 
+    grad_hook = None         # callable(list of fresh flat gradient buffers, list of parameters): data-parallel exchange (parallel.OverlappedGradSync)
+
     def export_param_grads(self):
         """Fresh copies of the parameter gradients. The backward graph ends by concatenating them into one flat buffer per
-        dtype (`_pack_grads`, captured), so leaving the graph costs ONE device copy per dtype plus views."""
+        dtype (`_pack_grads`, captured), so leaving the graph costs ONE device copy per dtype plus views. With a `grad_hook` the
+        fresh buffers are handed to it first: the gradient all-reduce of THIS graph's parameters starts (on a side stream) while the
+        next backward graph of the step is still to run."""
         out = []
         fresh = {dt: flat.clone() for dt, flat in self.flat_grads.items()}
+        if self.grad_hook is not None:
+            self.grad_hook(list(fresh.values()), self.params)
         for dt, off, n, shape in self.grad_slots:
             out.append(fresh[dt][off:off + n].view(shape))
         return tuple(out)

@@ -57,8 +57,12 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             allm = [m for m in self.modules() if isinstance(m, SpectralNorm)]
             # ordinary conv holders of the trunk ride along in the same batched kernels (layout / dtype conversion only)
             plain = list(self.aspp.plain_convs()) + list(self.decoder.plain_trunk_convs())
+            enc_ids = {id(m) for m in self.encoder.modules() if isinstance(m, SpectralNorm)}
             groups = {'all': allm + plain, 'trunk': [m for m in allm if id(m) in trunk_ids] + plain,
-                      'detail': [m for m in allm if id(m) not in trunk_ids]}
+                      'detail': [m for m in allm if id(m) not in trunk_ids],
+                      # the trunk as two graphs (data parallel: the decoder's gradients are exchanged while the encoder's backward runs)
+                      'enc': [m for m in allm if id(m) in enc_ids],
+                      'dec': [m for m in allm if id(m) in trunk_ids and id(m) not in enc_ids] + plain}
             self.__dict__['_sn_groups_cache'] = groups
             self.__dict__['_sn_cache'] = {k: {} for k in groups}
         return groups
@@ -81,8 +85,8 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             sentinel = self.__dict__['_addr_sentinels'] = [ps[0], ps[len(ps) // 2], ps[-1]]
         sig = tuple(p.data_ptr() for p in sentinel)
         if self.__dict__.get('_addr_sig') != sig:
-            self.__dict__.get('_trunk_graphs', {}).clear()
-            self.__dict__.get('_detail_graphs', {}).clear()
+            for store in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs', '_detail_names'):
+                self.__dict__.get(store, {}).clear()
             self.__dict__.pop('_bn_counters', None)
             self.__dict__['_addr_sig'] = sig
         if self._defer_bn_counters():
@@ -137,44 +141,109 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             return False                  # SyncBN all-reduces inside the trunk: collectives are not captured
         return True
 
-    def _run_trunk(self, geom, x, enc_masks, masks, gt_alphas, mem_feat):
-        """Eager the first time a batch geometry is seen, captured into hipGraphs from the second time on."""
-        inputs = [x, enc_masks, masks] + ([gt_alphas] if (self.training and gt_alphas is not None) else [])
-        has_hidden = hasattr(self.decoder, 'os8_temp_module')
-        graphs = self.__dict__.setdefault('_trunk_graphs', {})
-        key = None
-        if mem_feat is None and self._graph_policy():
-            key = (geom, self.training, MF.compute_dtype(), tuple((tuple(t.shape), t.dtype) for t in inputs))
+    def _trunk_enc(self, prepare_sn, x, enc_masks):
+        """First half of the trunk as its own graph: mask embedding + encoder -> (embedding, fea1..fea5)."""
+        if prepare_sn:
+            self._prepare_spectral_norm('enc')
+        embedding, mid_fea = self.encoder(x, enc_masks)
+        return (embedding,) + tuple(mid_fea['shortcut'])
+
+    def _trunk_dec(self, geom, prepare_sn, image_shape, embedding, f1, f2, f3, f4, f5, masks, gt_alphas=None):
+        """Second half: ASPP + dense decoder stage (+ instance matte decoder) on the encoder graph's outputs."""
+        b, n_f, n_i = geom
+        if prepare_sn:
+            self._prepare_spectral_norm('dec')
+        embedding = self.aspp(embedding)
+        mid_fea = {'shortcut': (f1, f2, f3, f4, f5), 'image': type('ImageShape', (), {'shape': image_shape})}
+        dense = self.decoder.dense_stage(embedding, mid_fea, b, n_f, n_i, masks, gt_alphas, None)
+        return tuple(t for t in dense if t is not None)
+
+    def _split_trunk(self):
+        """Trunk as two graph pairs (encoder | ASPP + dense decoder) instead of one: only useful for the overlapped gradient exchange of
+        data-parallel runs (parallel.OverlappedGradSync). Attribute `split_trunk`, env MAGGIE_SPLIT_TRUNK=0/1, default: world size > 1."""
+        flag = self.__dict__.get('split_trunk')
+        if flag is None:
+            import os
+            env = os.environ.get('MAGGIE_SPLIT_TRUNK')
+            if env is not None:
+                flag = env != '0'
+            else:
+                flag = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        return bool(flag) and self.training
+
+    def _graphed(self, store, key, fn, inputs, grad_inputs=()):
+        """fn(*inputs) eagerly the first time `key` is seen, captured into hipGraphs (forward + backward) the second time, replayed from
+        then on. -> (outputs, replayed?). `key` None: always eager."""
+        graphs = self.__dict__.setdefault(store, {})
         entry = graphs.get(key) if key is not None else None
         if isinstance(entry, int) and entry >= 1:
-            entry = self._capture_trunk(geom, inputs)
+            entry = self._capture(fn, inputs, grad_inputs)
             graphs[key] = entry
             while len(graphs) > 4:                                # bounded: each graph pins its own activation pool
                 graphs.pop(next(iter(graphs)))
         if entry is None or isinstance(entry, int) or entry == 'failed':
             if key is not None and entry != 'failed':
                 graphs[key] = (entry or 0) + 1
-            self._prepare_spectral_norm('all')
-            out = self._trunk(geom, False, *inputs, mem_feat=mem_feat)
+            return None, False
+        return entry(*inputs), True
+
+    def _capture(self, fn, inputs, grad_inputs=()):
+        from ... import graphs
+        mutable = [t for t in self.buffers()] + [p for p in self.parameters() if not p.requires_grad] + self.decoder.head_state()
+        try:
+            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=torch.is_autocast_enabled(), cache_enabled=False):
+                g = graphs.GraphedCallable(fn, inputs, self, mutable, self.training, grad_inputs=grad_inputs)
+            overlap = self.__dict__.get('_grad_overlap')
+            if overlap is not None:
+                g.grad_hook = overlap.reduce_async
+            return g
+        except Exception as e:
+            if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+                raise                  # data parallel: every rank must take the same path (same collectives in the same order)
+            logging.warning('hipGraph capture of a MaGGIe stage failed (%s: %s); staying eager', type(e).__name__, e)
+            return 'failed'
+
+    def _run_trunk(self, geom, x, enc_masks, masks, gt_alphas, mem_feat):
+        """Eager the first time a batch geometry is seen, captured into hipGraphs from the second time on."""
+        extra = [gt_alphas] if (self.training and gt_alphas is not None) else []
+        inputs = [x, enc_masks, masks] + extra
+        has_hidden = hasattr(self.decoder, 'os8_temp_module')
+        key, from_graph = None, False
+        if mem_feat is None and self._graph_policy():
+            key = (geom, self.training, MF.compute_dtype(), tuple((tuple(t.shape), t.dtype) for t in inputs))
+        if key is not None and self._split_trunk():
+            enc, r1 = self._graphed('_trunk_enc_graphs', key, lambda *t: self._trunk_enc(True, *t), [x, enc_masks])
+            if r1:
+                dec_in = list(enc) + [masks] + extra
+                out, r2 = self._graphed('_trunk_graphs', ('dec',) + key, lambda *t: self._trunk_dec(geom, True, x.shape, *t), dec_in,
+                                        grad_inputs=range(len(enc)))
+                from_graph = r2
+                if not r2:                                        # decoder graph not there yet: run it eagerly on the encoder graph's outputs
+                    self._prepare_spectral_norm('dec')
+                    out = self._trunk_dec(geom, False, x.shape, *dec_in)
+                self._prepare_spectral_norm('detail')
+            else:
+                self.__dict__.setdefault('_trunk_graphs', {}).setdefault(('dec',) + key, 0)
+                g = self.__dict__['_trunk_graphs']
+                if isinstance(g[('dec',) + key], int):
+                    g[('dec',) + key] += 1                        # both halves are captured at the same (second) sight of the geometry
+                self._prepare_spectral_norm('all')
+                out = self._trunk(geom, False, *inputs, mem_feat=mem_feat)
         else:
-            self._prepare_spectral_norm('detail')
-            out = entry(*inputs)
-            out = (out[0].clone(),) + tuple(out[1:])              # alpha_os8 is handed to the caller: never alias graph memory
-        out = list(out)
+            out, replayed = self._graphed('_trunk_graphs', key, lambda *t: self._trunk(geom, True, *t), inputs)
+            from_graph = replayed
+            if not replayed:
+                self._prepare_spectral_norm('all')
+                out = self._trunk(geom, False, *inputs, mem_feat=mem_feat)
+            else:
+                self._prepare_spectral_norm('detail')
+        if not isinstance(out, list):
+            out = list(out)
+        if from_graph:
+            out[0] = out[0].clone()                               # alpha_os8 is handed to the caller: never alias graph memory
         if not has_hidden:
             out.insert(4, None)
         return tuple(out)
-
-    def _capture_trunk(self, geom, inputs):
-        from ... import graphs
-        mutable = [t for t in self.buffers()] + [p for p in self.parameters() if not p.requires_grad]
-        fn = lambda *t: self._trunk(geom, True, *t)               # noqa: E731
-        try:
-            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=torch.is_autocast_enabled(), cache_enabled=False):
-                return graphs.GraphedCallable(fn, inputs, self, mutable, self.training)
-        except Exception as e:                                    # pragma: no cover - capture is an optimisation, never fatal
-            logging.warning('hipGraph capture of the MaGGIe trunk failed (%s: %s); staying eager', type(e).__name__, e)
-            return 'failed'
 
     def _forward_impl(self, batch, **kwargs):
         masks, alphas, trans_gt, b, n_f, h, w, n_i, chosen_ids, x, enc_masks = self.forward_inputs(batch)
@@ -270,34 +339,17 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             fn.names = names
             return outs
 
-        graphs = self.__dict__.setdefault('_detail_graphs', {})
         key = None
         if self._graph_policy():
             key = (geom, self.training, MF.compute_dtype(), plan['use_gt'], plan['with_atten'], tuple((tuple(t.shape), t.dtype) for t in inputs))
-        entry = graphs.get(key) if key is not None else None
-        if isinstance(entry, int) and entry >= 1:
-            entry = self._capture_detail(fn, inputs, n_dense)
-            graphs[key] = entry
-            while len(graphs) > 4:
-                graphs.pop(next(iter(graphs)))
-        if entry is None or isinstance(entry, int) or entry == 'failed':
-            if key is not None and entry != 'failed':
-                graphs[key] = (entry or 0) + 1
-            outs = fn(*inputs)
-            return fn.names, outs
-        g, names = entry
-        return names, g(*inputs)
-
-    def _capture_detail(self, fn, inputs, n_dense):
-        from ... import graphs
-        mutable = [t for t in self.buffers()] + [p for p in self.parameters() if not p.requires_grad] + self.decoder.head_state()
-        try:
-            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=torch.is_autocast_enabled(), cache_enabled=False):
-                g = graphs.GraphedCallable(fn, inputs, self, mutable, self.training, grad_inputs=range(n_dense))
-            return g, fn.names
-        except Exception as e:                                    # pragma: no cover - capture is an optimisation, never fatal
-            logging.warning('hipGraph capture of the MaGGIe detail stage failed (%s: %s); staying eager', type(e).__name__, e)
-            return 'failed'
+        names_key = ('names', key)
+        outs, replayed = self._graphed('_detail_graphs', key, fn, inputs, grad_inputs=range(n_dense))
+        store = self.__dict__.setdefault('_detail_names', {})
+        if replayed:
+            return store[names_key], outs
+        outs = fn(*inputs)
+        store[names_key] = fn.names
+        return fn.names, outs
 
     def update_additional_decoder_loss(self, pred, loss_dict):
         if 'loss_max_atten' in pred and self.loss_atten_w > 0:

@@ -40,6 +40,7 @@ class FlatAdamW(torch.optim.Optimizer):
         params = self._active()
         self.max_grad_norm = max_grad_norm
         self.sync_group = sync_group                              # see step(): data-parallel gradient averaging on the flat buffer
+        self.overlap = None                                       # parallel.OverlappedGradSync: chunks already reduced during backward
         self._t = 0
         self._steps = [0] * len(params)
         self.last_grad_norm = None
@@ -107,6 +108,8 @@ class FlatAdamW(torch.optim.Optimizer):
                 grads.append(p.grad)
                 views.append(gv)
         sync = self.sync_group is not None
+        # gradient chunks that were all-reduced on the side stream during backward: the main stream must not read them earlier
+        done = self.overlap.wait() if (sync and self.overlap is not None) else set()
         if not grads and not sync:
             return loss
         if len(grads) != len(ps):
@@ -114,10 +117,18 @@ class FlatAdamW(torch.optim.Optimizer):
         if grads:
             torch._foreach_copy_(views, grads)
         if sync:
-            # data parallel: ONE all-reduce (mean) of the whole flat gradient buffer over RCCL -- same size and layout on every
-            # rank whatever each rank's autograd produced; a parameter without a local gradient contributes zeros, as under DDP
             from .parallel import all_reduce_mean
-            all_reduce_mean(self.flat_g, None if self.sync_group is True else self.sync_group)
+            grp = None if self.sync_group is True else self.sync_group
+            if not done:
+                # data parallel: ONE all-reduce (mean) of the whole flat gradient buffer over RCCL -- same size and layout on every
+                # rank whatever each rank's autograd produced; a parameter without a local gradient contributes zeros, as under DDP
+                all_reduce_mean(self.flat_g, grp)
+            else:
+                # the captured backward graphs already exchanged their chunks on the side stream while backward was running
+                # (parallel.OverlappedGradSync); what is left -- parameters outside the graphs this step -- goes in contiguous runs of the
+                # flat buffer (same runs on every rank: the ranks see the same geometries in the same order)
+                from .parallel import reduce_remaining_runs
+                reduce_remaining_runs(self.flat_g, ps, self._offsets, self._n, done, grp)
             have = [True] * len(ps)
         b1, b2 = g['betas']
         clip = self.max_grad_norm is not None

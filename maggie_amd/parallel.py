@@ -75,6 +75,82 @@ def all_reduce_mean(flat, group=None):
     return flat
 
 
+class OverlappedGradSync:
+    """Gradient all-reduce overlapped with backward on a side HIP stream (north_star; what DDP's bucket hooks give the reference,
+    engine/train.py:163-164), MI355X-first: the unit is not a 25 MiB bucket but the flat gradient buffer of one captured backward graph.
+
+    A training step's backward is three hipGraphs in reverse-autograd order -- detail stage (sparse head, ~0.3 M parameters), dense
+    decoder + ASPP (~14 M), encoder (~16 M). Each graph ends by packing its parameter gradients into one flat buffer; when a graph
+    finishes, its buffer is handed to `reduce_async`, which all-reduces (mean) it over RCCL on a side stream while the NEXT graph runs on
+    the main stream. Only the encoder's chunk (the last, ~63 MB: one large ring all-reduce, what point-to-point xGMI wants) is exposed,
+    and the optimizer waits for it with `wait()`. `reduced` = ids of the parameters whose gradient already went through a collective
+    this step; the optimizer reduces the rest itself (eager steps before a geometry's graphs exist). The collective sequence is the same
+    on every rank because every rank sees the same geometries in the same order (a failed capture is fatal in distributed runs)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.stream = None
+        self.events = []
+        self.reduced = set()
+
+    def attach(self, model):
+        """Route the gradient buffers of every captured graph of `model` (present and future) through this object."""
+        model.__dict__['_grad_overlap'] = self
+        for store in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs'):
+            for entry in model.__dict__.get(store, {}).values():
+                g = entry[0] if isinstance(entry, tuple) else entry
+                if hasattr(g, 'grad_hook'):
+                    g.grad_hook = self.reduce_async
+        return self
+
+    def reduce_async(self, flats, params):
+        if not flats[0].is_cuda:                                  # CPU tensors (gloo tests of the bookkeeping): nothing to overlap with
+            for f in flats:
+                all_reduce_mean(f, self.group)
+            self.reduced.update(id(p) for p in params)
+            return
+        main = torch.cuda.current_stream()
+        if self.stream is None:
+            self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(main)                             # the fresh buffers were filled on the main stream
+        with torch.cuda.stream(self.stream):
+            for f in flats:
+                all_reduce_mean(f, self.group)
+                f.record_stream(self.stream)
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        self.events.append(ev)
+        self.reduced.update(id(p) for p in params)
+
+    def wait(self):
+        """The current stream waits for every exchange started since the last wait; -> the ids of the parameters already reduced."""
+        if self.events:
+            main = torch.cuda.current_stream()
+            for ev in self.events:
+                main.wait_event(ev)
+        done, self.events, self.reduced = self.reduced, [], set()
+        return done
+
+
+def reduce_remaining_runs(flat, params, offsets, total, done, group=None):
+    """All-reduce (mean) the slices of the optimizer's flat gradient buffer that belong to parameters NOT in `done` (ids), one collective
+    per contiguous run of such parameters. `offsets[i]` = start of parameter i in `flat`, `total` = its length. Every rank computes the
+    same runs because every rank's graphs cover the same parameters. -> number of collectives issued."""
+    ends = list(offsets[1:]) + [total]
+    n, i = 0, 0
+    while i < len(params):
+        if id(params[i]) in done:
+            i += 1
+            continue
+        j = i
+        while j + 1 < len(params) and id(params[j + 1]) not in done:
+            j += 1
+        all_reduce_mean(flat[offsets[i]:ends[j]], group)
+        n += 1
+        i = j + 1
+    return n
+
+
 def grad_buffers(params, fill_missing=False):
     """Tensors that together hold every gradient of `params` exactly once: a flat 1-D base buffer where all of it is covered
     by gradient views (the hipGraph trunk's export: ~150 gradients = ONE tensor), the gradients themselves otherwise."""

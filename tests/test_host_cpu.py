@@ -263,6 +263,63 @@ def test_syncbn_exchange_world_size_2_gloo(tmp_path):
         assert p.returncode == 0, out.decode()
 
 
+_OVERLAP_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+dist.init_process_group('gloo', rank=int(os.environ['RANK']), world_size=2)
+from maggie_amd import parallel
+r = dist.get_rank()
+# six parameters in optimizer order; the flat gradient buffer of the optimizer (FlatAdamW layout: 64-float aligned slots)
+shapes = [(5,), (3, 4), (7,), (2, 2), (6,), (9,)]
+ps = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+offsets, total = [], 0
+for p in ps:
+    offsets.append(total); total += (p.numel() + 63) // 64 * 64
+g = torch.Generator().manual_seed(100 + r)
+grads = [torch.randn(s, generator=g) for s in shapes]
+g0, g1 = torch.Generator().manual_seed(100), torch.Generator().manual_seed(101)
+both = [torch.randn(s, generator=g0) for s in shapes], [torch.randn(s, generator=g1) for s in shapes]      # both ranks' gradients
+sync = parallel.OverlappedGradSync()
+# backward graph A (runs first: the detail stage) owns parameters 4, 5; graph B (decoder) owns 1, 2: each hands over ONE flat buffer
+def graph_export(idx):
+    flat = torch.cat([grads[i].reshape(-1) for i in idx]).clone()
+    sync.reduce_async([flat], [ps[i] for i in idx])            # what GraphedCallable.export_param_grads does through grad_hook
+    o = 0
+    for i in idx:
+        ps[i].grad = flat[o:o + ps[i].numel()].view(shapes[i]); o += ps[i].numel()
+graph_export([4, 5]); graph_export([1, 2])
+ps[0].grad, ps[3].grad = grads[0].clone(), grads[3].clone()   # loose gradients (parameters outside the graphs this step)
+# optimizer side (FlatAdamW.step): wait, gather into the flat buffer, reduce what is left in contiguous runs
+done = sync.wait()
+assert done == {id(ps[i]) for i in (1, 2, 4, 5)} and not sync.reduced and not sync.events
+flat_g = torch.zeros(total)
+for p, o in zip(ps, offsets):
+    flat_g[o:o + p.numel()].copy_(p.grad.reshape(-1))
+n = parallel.reduce_remaining_runs(flat_g, ps, offsets, total, done)
+assert n == 2                                                  # runs [0] and [3]
+for i, (p, o) in enumerate(zip(ps, offsets)):
+    exp = (both[0][i] + both[1][i]) / 2
+    assert torch.allclose(flat_g[o:o + p.numel()].view(shapes[i]), exp, atol=1e-6), i
+# a step without any graph (first sights of a geometry): nothing in `done` -> the caller all-reduces the whole buffer
+assert sync.wait() == set()
+dist.destroy_process_group()
+"""
+
+
+def test_overlapped_grad_sync_world_size_2_gloo(tmp_path):
+    """parallel.OverlappedGradSync + reduce_remaining_runs (the data-parallel exchange of FlatAdamW(sync_group) with gradient chunks handed
+    over by the backward graphs) on 2 gloo ranks: every parameter's gradient ends up averaged exactly once."""
+    script = tmp_path / 'ov.py'
+    script.write_text(_OVERLAP_WORKER % ROOT)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29619')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=120)
+        assert p.returncode == 0, out.decode()
+
+
 def test_flat_clip_grad_norm_matches_torch():
     """parallel.clip_grad_norm_ == torch.nn.utils.clip_grad_norm_ (the call of engine/train.py:274) for gradients that are
     views of a flat buffer (fully and partially covered) mixed with ordinary ones, and for a missing gradient."""
