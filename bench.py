@@ -303,6 +303,10 @@ def main():
             'roofline': roofline, 'cpu_baseline': cpu_baseline,
         }
     if world > 1 or force_ddp:
+        # graphs that captured RCCL collectives (SyncBN statistics) must go before the communicator does
+        for store in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs'):
+            model.__dict__.get(store, {}).clear()
+        torch.cuda.synchronize()
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -418,6 +418,29 @@ int mg_rows_add_layernorm_bwd(const void* dy, const void* x, const void* r, cons
 /* resnet_inst_matt_spconv.py:347-348 ("dummy code to prevent all zeros"): if *count == 0, set bits [y0:y1, x0:x1] of every plane */
 int mg_bits_patch_if_empty(void* bits, const int32_t* count, int P, int H, int W, int y0, int y1, int x0, int x1, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Temporal-consistency tail of the video model (maggie_amd/csrc/temporal2.hip), fp32 planes.
+ *   mg_bifuse_fwd/_bwd : bidirectional alpha fusion of maggie/network/decoder/resnet_inst_matt_spconv_temp.py:35-79 over the T frames
+ *                        of a clip. preds / fused (B,T,NI,HW); diffs (2(T-1), B, HW) = the difference logits in the reference's call
+ *                        order (forward pairs, then backward pairs); fdiff / bdiff (B,T,HW) = the reference's forward_diffs /
+ *                        backward_diffs (zero-padded), fsig / bsig their sigmoids. Backward: dpreds, ddiffs (summed over instances).
+ *   mg_dtssd_fwd/_bwd  : loss_dtSSD (maggie/network/loss.py:7-16): sums[0] / sums[1]; p, g, m hold T frames of E elements per batch
+ *                        item with batch strides *bs (frame slices of a wider tensor need no copy); sig != 0: p = sigmoid(logits)
+ *                        (loss_temporal_sparsity, :183-203); m NULL = ones. Backward: dp = gout / sums[1] * d(numerator)/dp.
+ *   mg_bce_logits_*    : F.binary_cross_entropy_with_logits(reduction='mean') of the difference logits (:189-190), same strides.
+ *   mg_temporal_crop   : eval-time bounding-box crop (:115-142 with utils/utils.py:61-83): in place on alpha [P,H,W] and on the
+ *                        detail bit planes [P,H,Ww]; scratch [P,H,W] floats, box int32[P][4].
+ * ------------------------------------------------------------------------------------------------------------- */
+int mg_bifuse_fwd(const float* preds, const float* diffs, int B, int T, int NI, long HW, float* fused, float* fdiff, float* bdiff, float* fsig,
+                  float* bsig, void* stream);
+int mg_bifuse_bwd(const float* dfused, const float* preds, const float* diffs, int B, int T, int NI, long HW, float* dpreds, float* ddiffs, void* stream);
+int mg_dtssd_fwd(const float* p, long pbs, const float* g, long gbs, const float* m, long mbs, int B, int T, long E, int sig, float* sums, void* stream);
+int mg_dtssd_bwd(const float* p, long pbs, const float* g, long gbs, const float* m, long mbs, int B, int T, long E, int sig, const float* sums,
+                 const float* gout, float* dp, long dbs, void* stream);
+int mg_bce_logits_fwd(const float* x, long xbs, const float* y, long ybs, int B, long TE, float* sum, void* stream);
+int mg_bce_logits_bwd(const float* x, long xbs, const float* y, long ybs, int B, long TE, const float* gout, float* dx, long dbs, void* stream);
+int mg_temporal_crop(float* alpha, void* bits, int P, int H, int W, float sigma, float thr, int pad, float* scratch, int32_t* box, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -520,8 +520,11 @@ def linear_rows(x2d, w, bias=None, pre_relu=False, stats=None):
 # BatchNorm (+ residual + activation), training (batch statistics, running-stat update, SyncBN) and eval
 # ----------------------------------------------------------------------------------------------------------------------
 
+SYNCBN_WORLD1 = os.environ.get('MAGGIE_SYNCBN_WORLD1', '0') == '1'   # test hook: run the SyncBN exchange code also in a 1-rank process group
+
+
 def _sync_group(bn):
-    if isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or SYNCBN_WORLD1):
         return bn.process_group if bn.process_group is not None else dist.group.WORLD
     return None
 
@@ -1079,3 +1082,120 @@ class GruOut(torch.autograd.Function):
     def backward(ctx, dhn):
         rz, cpre, h = ctx.saved_tensors
         return K.gru_out_bwd(dhn.contiguous(), rz, cpre, h)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# temporal-consistency tail of the video model (maggie_amd/csrc/temporal2.hip)
+# ----------------------------------------------------------------------------------------------------------------------
+
+class BiFuse(torch.autograd.Function):
+    """bidirectional_fusion (resnet_inst_matt_spconv_temp.py:35-79) given the 2(T-1) difference logits: preds (B,T,NI,H,W) fp32,
+    diffs (2(T-1), B, 1, H, W) fp32 -> fused (B,T,NI,H,W), forward / backward difference logits (B,T,1,H,W) and their sigmoids."""
+
+    @staticmethod
+    def forward(ctx, preds, diffs):
+        preds, diffs = preds.float().contiguous(), diffs.float().contiguous()
+        B, T, NI, H, W = preds.shape
+        HW = H * W
+        fused = torch.empty_like(preds)
+        aux = torch.empty((4, B, T, 1, H, W), dtype=torch.float32, device=preds.device)
+        K.hip.call('mg_bifuse_fwd', K.hip.ptr(preds), K.hip.ptr(diffs), K.c_int(B), K.c_int(T), K.c_int(NI), K.c_long(HW), K.hip.ptr(fused),
+                   K.hip.ptr(aux[0]), K.hip.ptr(aux[1]), K.hip.ptr(aux[2]), K.hip.ptr(aux[3]), K.hip.stream())
+        ctx.save_for_backward(preds, diffs)
+        ctx.mark_non_differentiable(aux)
+        return fused, aux
+
+    @staticmethod
+    def backward(ctx, dfused, _daux):
+        preds, diffs = ctx.saved_tensors
+        B, T, NI, H, W = preds.shape
+        dp, dd = torch.empty_like(preds), torch.empty_like(diffs)
+        K.hip.call('mg_bifuse_bwd', K.hip.ptr(dfused.float().contiguous()), K.hip.ptr(preds), K.hip.ptr(diffs), K.c_int(B), K.c_int(T), K.c_int(NI),
+                   K.c_long(H * W), K.hip.ptr(dp), K.hip.ptr(dd), K.hip.stream())
+        return dp, dd
+
+
+def _frames(t):
+    """(B, T, ...) fp32 tensor whose frames are contiguous blocks -> (tensor, batch stride, T, elements per frame); a slice along T
+    (x[:, 1:], x[:, :-1]) is used in place: only the batch stride differs."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    E = 1
+    for d in t.shape[2:]:
+        E *= d
+    inner_ok = t[0, 0].is_contiguous() and (t.shape[1] == 1 or t.stride(1) == E)
+    if not inner_ok:
+        t = t.contiguous()
+    return t, (t.stride(0) if t.shape[0] > 1 else t.shape[1] * E), t.shape[1], E
+
+
+class DtSSD(torch.autograd.Function):
+    """loss_dtSSD (maggie/network/loss.py:7-16); sig: pred = sigmoid(logits) (loss_temporal_sparsity); mask None = ones."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, mask, sig):
+        p, pbs, T, E = _frames(pred)
+        g, gbs, _, _ = _frames(gt.detach())
+        m, mbs = (None, 0) if mask is None else _frames(mask.detach())[:2]
+        B = p.shape[0]
+        sums = torch.empty(2, dtype=torch.float32, device=p.device)
+        K.hip.call('mg_dtssd_fwd', K.hip.ptr(p), K.c_long(pbs), K.hip.ptr(g), K.c_long(gbs), K.hip.ptr(m), K.c_long(mbs), K.c_int(B), K.c_int(T),
+                   K.c_long(E), K.c_int(int(sig)), K.hip.ptr(sums), K.hip.stream())
+        ctx.save_for_backward(p, g, m, sums)
+        ctx.meta = (pbs, gbs, mbs, B, T, E, int(sig), pred.shape)
+        return sums[0] / sums[1]
+
+    @staticmethod
+    def backward(ctx, gout):
+        p, g, m, sums = ctx.saved_tensors
+        pbs, gbs, mbs, B, T, E, sig, shape = ctx.meta
+        dp = torch.empty(shape, dtype=torch.float32, device=p.device)
+        K.hip.call('mg_dtssd_bwd', K.hip.ptr(p), K.c_long(pbs), K.hip.ptr(g), K.c_long(gbs), K.hip.ptr(m), K.c_long(mbs), K.c_int(B), K.c_int(T),
+                   K.c_long(E), K.c_int(sig), K.hip.ptr(sums), K.hip.ptr(gout.float().contiguous().view(1)), K.hip.ptr(dp), K.c_long(T * E), K.hip.stream())
+        return dp, None, None, None
+
+
+def dtssd_loss(pred, gt, mask=None, sig=False):
+    return DtSSD.apply(pred, gt, mask, sig)
+
+
+class BCELogitsMean(torch.autograd.Function):
+    """F.binary_cross_entropy_with_logits(x, y, reduction='mean') over (B, T, ...) frame slices without copies."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        xx, xbs, T, E = _frames(x)
+        yy, ybs, _, _ = _frames(y.detach())
+        B = xx.shape[0]
+        s = torch.empty(1, dtype=torch.float32, device=xx.device)
+        K.hip.call('mg_bce_logits_fwd', K.hip.ptr(xx), K.c_long(xbs), K.hip.ptr(yy), K.c_long(ybs), K.c_int(B), K.c_long(T * E), K.hip.ptr(s), K.hip.stream())
+        ctx.save_for_backward(xx, yy)
+        ctx.meta = (xbs, ybs, B, T * E, x.shape)
+        return s[0] / float(B * T * E)
+
+    @staticmethod
+    def backward(ctx, gout):
+        xx, yy = ctx.saved_tensors
+        xbs, ybs, B, TE, shape = ctx.meta
+        dx = torch.empty(shape, dtype=torch.float32, device=xx.device)
+        K.hip.call('mg_bce_logits_bwd', K.hip.ptr(xx), K.c_long(xbs), K.hip.ptr(yy), K.c_long(ybs), K.c_int(B), K.c_long(TE),
+                   K.hip.ptr(gout.float().contiguous().view(1)), K.hip.ptr(dx), K.c_long(TE), K.hip.stream())
+        return dx, None
+
+
+def bce_logits_mean(x, y):
+    return BCELogitsMean.apply(x, y)
+
+
+def temporal_crop_(alpha, bits, sigma=3, thr=0.1, pad=30):
+    """Eval-time bounding-box crop of the video decoder (resnet_inst_matt_spconv_temp.py:115-142): in place on the coarse alpha planes
+    (N, n_i, H, W) fp32 and on the detail bit planes (N*n_i, H, Ww)."""
+    a = alpha.contiguous()
+    assert a.dtype == torch.float32 and a.data_ptr() == alpha.data_ptr()
+    H, W_ = a.shape[-2:]
+    P = a.numel() // (H * W_)
+    scratch = torch.empty_like(a)
+    box = torch.empty((P, 4), dtype=torch.int32, device=a.device)
+    K.hip.call('mg_temporal_crop', K.hip.ptr(a), K.hip.ptr(bits), K.c_int(P), K.c_int(H), K.c_int(W_), K.c_float(float(sigma)), K.c_float(float(thr)),
+               K.c_int(int(pad)), K.hip.ptr(scratch), K.hip.ptr(box), K.hip.stream())
+    return alpha, bits

@@ -20,7 +20,6 @@ from ... import kernels as K
 from ..module import ASPP
 from ..encoder import *      # noqa: F401,F403  (factory names are resolved by eval(), like the reference)
 from ..decoder import *      # noqa: F401,F403
-from ..loss import loss_dtSSD
 
 
 class MaGGIe(nn.Module, PyTorchModelHubMixin):
@@ -137,8 +136,12 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         if self.training != torch.is_grad_enabled():
             return False
         if self.training and torch.distributed.is_available() and torch.distributed.is_initialized() \
-                and torch.distributed.get_world_size() > 1 and any(isinstance(m, nn.SyncBatchNorm) for m in self.modules()):
-            return False                  # SyncBN all-reduces inside the trunk: collectives are not captured
+                and (torch.distributed.get_world_size() > 1 or MF.SYNCBN_WORLD1) and any(isinstance(m, nn.SyncBatchNorm) for m in self.modules()):
+            # SyncBN exchanges batch statistics layer by layer (each layer's normalisation needs the global moments of ITS input, so the
+            # ~142 small collectives of a step cannot be merged). Capturing RCCL collectives into the hipGraphs is opt-in
+            # (MAGGIE_SYNCBN_GRAPHS=1): it could only be verified in a 1-rank process group here.
+            import os
+            return os.environ.get('MAGGIE_SYNCBN_GRAPHS', '0') == '1'
         return True
 
     def _trunk_enc(self, prepare_sn, x, enc_masks):
@@ -467,9 +470,9 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             total_loss = total_loss + loss_dict['loss_grad'] * self.loss_alpha_grad_w
         if self.loss_dtSSD_w > 0:
             rs = lambda t: t.reshape(*alpha_shape)
-            d1 = loss_dtSSD(rs(a1), rs(alphas), rs(weight_os1))
-            d4 = loss_dtSSD(rs(a4), rs(alphas), rs(weight_os4))
-            d8 = loss_dtSSD(rs(a8), rs(alphas), rs(weight_os8))
+            d1 = MF.dtssd_loss(rs(a1), rs(alphas), rs(weight_os1))       # loss.py:7-16 as a fused HIP reduction (mg_dtssd_fwd / _bwd)
+            d4 = MF.dtssd_loss(rs(a4), rs(alphas), rs(weight_os4))
+            d8 = MF.dtssd_loss(rs(a8), rs(alphas), rs(weight_os8))
             dt = d1 * 2 + d4 + d8
             loss_dict['loss_dtSSD_os1'], loss_dict['loss_dtSSD_os4'], loss_dict['loss_dtSSD_os8'] = d1, d4, d8
             loss_dict['loss_dtSSD'] = dt

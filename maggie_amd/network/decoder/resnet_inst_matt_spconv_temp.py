@@ -9,22 +9,7 @@ from ... import functional as MF
 from ... import kernels as K
 from .resnet import BasicBlock
 from .resnet_inst_matt_spconv import ResShortCut_InstMattSpconv_Dec
-from ..loss import loss_dtSSD
 from ..module import SpectralNorm, conv1x1, conv3x3, ConvGRU, Marker
-
-
-def gaussian_smoothing(x, sigma):
-    """maggie/utils/utils.py:61-83 on fp32 planes (N, C, H, W), including its kernel quirk (g*g broadcast over rows)."""
-    ks = sigma * 2 + 1
-    pad = ks // 2
-    xp = F.pad(x, (pad, pad, pad, pad), mode='constant', value=0)
-    grid = torch.arange(ks, device=x.device).float() - ks // 2
-    g = torch.exp(-grid ** 2 / (2 * sigma ** 2))
-    g = g / g.sum()
-    k = (g.view(1, 1, -1) * g.view(1, 1, -1)).expand(x.shape[1], 1, ks, ks).type_as(x)
-    sm = F.conv2d(xp, k, stride=1, padding=0, groups=x.shape[1])
-    sm = sm[:, :, pad:-pad, pad:-pad]
-    return F.interpolate(sm, size=x.shape[-2:], mode='bilinear', align_corners=False)
 
 
 class ResShortCut_InstMattSpconv_BiTempSpar_Dec(ResShortCut_InstMattSpconv_Dec):
@@ -66,33 +51,19 @@ class ResShortCut_InstMattSpconv_BiTempSpar_Dec(ResShortCut_InstMattSpconv_Dec):
 
     def bidirectional_fusion(self, feat, preds, diffs=None):
         """feat (b, n_f, h, w, 64) NHWC (detached); preds (b, n_f, n_i, H, W) fp32; diffs: frame_diffs(feat) when the trunk already
-        computed them."""
-        n_f = feat.shape[1]
+        computed them. The two recursions pred = prev * (1 - sigmoid(d)) + cur * sigmoid(d) (:53-67), their average (:69-78) and the
+        zero-padded difference stacks are ONE HIP kernel each way (mg_bifuse_fwd / _bwd).
+        -> forward_diffs, backward_diffs (b, n_f, 1, H, W) logits, fused (b, n_f, n_i, H, W), sigmoid(forward_diffs), sigmoid(backward_diffs)."""
         if diffs is None:
             diffs = self.frame_diffs(feat)
-        forward_diffs, backward_diffs = [], []
-        forward_preds, backward_preds = [preds[:, 0]], [preds[:, n_f - 1]]
-        for i in range(1, n_f):
-            diff = diffs[i - 1]
-            forward_diffs.append(diff)
-            forward_preds.append(forward_preds[-1] * (1 - diff.sigmoid()) + preds[:, i] * diff.sigmoid())
-        forward_diffs = torch.stack([torch.zeros_like(forward_diffs[0])] + forward_diffs, dim=1)
-        for j, i in enumerate(range(n_f - 1, 0, -1)):
-            diff = diffs[n_f - 1 + j]
-            backward_diffs.append(diff)
-            backward_preds.append(backward_preds[-1] * (1 - diff.sigmoid()) + preds[:, i - 1] * diff.sigmoid())
-        backward_preds = backward_preds[::-1]
-        backward_diffs = backward_diffs[::-1]
-        backward_diffs = torch.stack(backward_diffs + [torch.zeros_like(backward_diffs[-1])], dim=1)
-        fuse_preds = []
-        for i in range(n_f):
-            if i == 0:
-                fuse_preds.append(forward_preds[i])
-            elif i == n_f - 1:
-                fuse_preds.append(backward_preds[i])
-            else:
-                fuse_preds.append((forward_preds[i] + backward_preds[i]) / 2)
-        return forward_diffs, backward_diffs, torch.stack(fuse_preds, dim=1)
+        fused, aux = MF.BiFuse.apply(preds, diffs)
+        # aux = [forward logits, backward logits, their sigmoids]: the logits are `diffs` re-arranged, so gradients (the temporal losses)
+        # flow through a differentiable re-arrangement of `diffs` rather than through the kernel's copy
+        n_f = preds.shape[1]
+        zero = torch.zeros_like(diffs[0])
+        fwd = torch.stack([zero] + [diffs[i - 1] for i in range(1, n_f)], dim=1)
+        bwd = torch.stack([diffs[2 * n_f - 3 - k] for k in range(n_f - 1)] + [zero], dim=1)
+        return fwd, bwd, fused, aux[2], aux[3]
 
     def dense_modules(self):
         return super().dense_modules() + [self.os8_temp_module, self.diff_module]
@@ -121,28 +92,10 @@ class ResShortCut_InstMattSpconv_BiTempSpar_Dec(ResShortCut_InstMattSpconv_Dec):
         n_cur = guided.shape[1]
         detail_bits = MF.unknown_bits(guided, 30, False)
         if not self.training:
-            # ignore everything outside each instance's padded bounding box (:121-142), on device without host loops
-            H, W = hw
-            smooth = gaussian_smoothing(x_os8, 3) > 0.1                              # (N, n_i, H, W) bool
-            rows = smooth.any(-1)
-            cols = smooth.any(-2)
-            ar_h = torch.arange(H, device=x.device)
-            ar_w = torch.arange(W, device=x.device)
-            big = 10 ** 6
-            y_min = torch.where(rows, ar_h, big).amin(-1)
-            y_max = torch.where(rows, ar_h, -big).amax(-1)
-            x_min = torch.where(cols, ar_w, big).amin(-1)
-            x_max = torch.where(cols, ar_w, -big).amax(-1)
-            has = rows.any(-1)
-            y0 = (y_min - 30).clamp(min=0)
-            y1 = (y_max + 30).clamp(max=H)
-            x0 = (x_min - 30).clamp(min=0)
-            x1 = (x_max + 30).clamp(max=W)
-            box = ((ar_h[None, None, :, None] >= y0[..., None, None]) & (ar_h[None, None, :, None] < y1[..., None, None])
-                   & (ar_w[None, None, None, :] >= x0[..., None, None]) & (ar_w[None, None, None, :] < x1[..., None, None]))
-            box = box | ~has[..., None, None]                                        # `continue` when the instance is empty
-            x_os8 = x_os8 * box
-            detail_bits = detail_bits & K.bits_pack(box.to(torch.uint8).contiguous(), mode=1)
+            # ignore everything outside each instance's padded bounding box (:121-142): smoothing, resize, threshold, per-plane bounding box
+            # and its application to the coarse alpha and the detail bit planes in four small HIP kernels (mg_temporal_crop)
+            x_os8 = x_os8.contiguous()
+            MF.temporal_crop_(x_os8, detail_bits, sigma=3, thr=0.1, pad=30)
             guided = x_os8
         x_os4, x_os1, detail_bits = self.process_os4_os1(x, b, n_f, fea1, fea2, fea3, hw, x_os8, queries, n_cur, detail_bits)
         ret = {'alpha_os1': x_os1, 'alpha_os4': x_os4, 'alpha_os8': x_os8}
@@ -157,25 +110,28 @@ class ResShortCut_InstMattSpconv_BiTempSpar_Dec(ResShortCut_InstMattSpconv_Dec):
         ret['weight_os4'] = weight_os4
         ret['weight_os1'] = weight_os1
         temp_alpha = alpha_pred.view(b, n_f, *alpha_pred.shape[1:])
-        diff_forward, diff_backward, temp_fused_alpha = self.bidirectional_fusion(feat_os8, temp_alpha, diffs)
+        diff_forward, diff_backward, temp_fused_alpha, sig_f, sig_b = self.bidirectional_fusion(feat_os8, temp_alpha, diffs)
         if (not self.training and self.use_fusion) or self.training:
             ret['temp_alpha'] = temp_fused_alpha
-            ret['diff_forward'] = diff_forward.sigmoid()
-            ret['diff_backward'] = diff_backward.sigmoid()
+            ret['diff_forward'] = sig_f
+            ret['diff_backward'] = sig_b
         if self.training:
             ret['loss_max_atten'] = loss_max_atten
             ret.update(self.loss_temporal_sparsity(diff_forward, diff_backward, spar_gt))
         return ret
 
     def loss_temporal_sparsity(self, diff_forward, diff_backward, spar_gt):
+        """:183-203 -- BCE-with-logits of the difference maps against the transition maps of frames 1.. plus the temporal-derivative loss of
+        their sigmoids, x 0.25; every term a fused HIP reduction with an exact backward kernel (mg_bce_logits_*, mg_dtssd_*), on frame
+        slices in place (no copies)."""
         loss = {}
         spar_gt = spar_gt.view(diff_forward.shape[0], -1, *spar_gt.shape[1:])
-        bce_f = F.binary_cross_entropy_with_logits(diff_forward[:, 1:, 0], spar_gt[:, 1:, 0], reduction='mean')
-        bce_b = F.binary_cross_entropy_with_logits(diff_backward[:, :-1, 0], spar_gt[:, 1:, 0], reduction='mean')
+        tgt = spar_gt[:, 1:, 0:1]                                             # (b, n_f - 1, 1, H, W)
+        bce_f = MF.bce_logits_mean(diff_forward[:, 1:], tgt)
+        bce_b = MF.bce_logits_mean(diff_backward[:, :-1], tgt)
         loss['loss_temp_bce'] = bce_f + bce_b
-        ones = torch.ones_like(spar_gt[:, 1:, 0:1])
-        dt_f = loss_dtSSD(diff_forward[:, 1:].sigmoid(), spar_gt[:, 1:, 0:1], ones)
-        dt_b = loss_dtSSD(diff_backward[:, :-1].sigmoid(), spar_gt[:, 1:, 0:1], ones)
+        dt_f = MF.dtssd_loss(diff_forward[:, 1:], tgt, None, sig=True)
+        dt_b = MF.dtssd_loss(diff_backward[:, :-1], tgt, None, sig=True)
         loss['loss_temp_dtssd'] = dt_f + dt_b
         loss['loss_temp'] = (loss['loss_temp_bce'] + dt_f + dt_b) * 0.25
         return loss

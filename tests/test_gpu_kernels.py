@@ -835,3 +835,88 @@ def test_batched_weight_pipeline_mixes_spectral_norm_and_plain_convs(dtype):
         (ref,) = torch.autograd.grad(wn, wb, gk)
         tol = 2e-5 if dtype == torch.float32 else 2e-2
         assert (got[idx] - ref).abs().max() <= tol * ref.abs().max() + 1e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('T', [2, 3, 5])
+def test_bidirectional_fusion_kernel_matches_torch_restatement(T):
+    """mg_bifuse_fwd / _bwd against the statement-by-statement torch form of bidirectional_fusion's blend
+    (maggie/network/decoder/resnet_inst_matt_spconv_temp.py:53-78) for given difference logits: fused alphas, the zero-padded difference
+    stacks, their sigmoids, and the gradients w.r.t. predictions and logits."""
+    from maggie_amd import functional as MF
+    dev = _dev()
+    rs = np.random.RandomState(T)
+    B, NI, H, W = 2, 3, 8, 24
+    preds = torch.from_numpy(rs.uniform(size=(B, T, NI, H, W)).astype(np.float32)).requires_grad_(True)
+    diffs = torch.from_numpy(rs.normal(size=(2 * (T - 1), B, 1, H, W)).astype(np.float32)).requires_grad_(True)
+    fw, bw = [preds[:, 0]], [preds[:, T - 1]]
+    fd, bd = [], []
+    for i in range(1, T):
+        d = diffs[i - 1]; fd.append(d)
+        fw.append(fw[-1] * (1 - d.sigmoid()) + preds[:, i] * d.sigmoid())
+    for j, i in enumerate(range(T - 1, 0, -1)):
+        d = diffs[T - 1 + j]; bd.append(d)
+        bw.append(bw[-1] * (1 - d.sigmoid()) + preds[:, i - 1] * d.sigmoid())
+    bw, bd = bw[::-1], bd[::-1]
+    fused_ref = torch.stack([fw[i] if i == 0 else bw[i] if i == T - 1 else (fw[i] + bw[i]) / 2 for i in range(T)], 1)
+    fd_ref = torch.stack([torch.zeros_like(fd[0])] + fd, 1)
+    bd_ref = torch.stack(bd + [torch.zeros_like(bd[-1])], 1)
+    wgt = torch.from_numpy(rs.normal(size=fused_ref.shape).astype(np.float32))
+    (fused_ref * wgt).sum().backward()
+    p2 = preds.detach().to(dev).requires_grad_(True)
+    d2 = diffs.detach().to(dev).requires_grad_(True)
+    fused, aux = MF.BiFuse.apply(p2, d2)
+    (fused * wgt.to(dev)).sum().backward()
+    assert torch.allclose(fused.cpu(), fused_ref.detach(), atol=1e-6)
+    assert torch.allclose(aux[0].cpu(), fd_ref.detach(), atol=0) and torch.allclose(aux[1].cpu(), bd_ref.detach(), atol=0)
+    assert torch.allclose(aux[2].cpu(), fd_ref.detach().sigmoid(), atol=1e-6) and torch.allclose(aux[3].cpu(), bd_ref.detach().sigmoid(), atol=1e-6)
+    assert torch.allclose(p2.grad.cpu(), preds.grad, atol=1e-5), float((p2.grad.cpu() - preds.grad).abs().max())
+    dref = diffs.grad if diffs.grad is not None else torch.zeros_like(diffs)       # T = 2: the fused frames are the predictions themselves
+    assert torch.allclose(d2.grad.cpu(), dref, atol=1e-5), float((d2.grad.cpu() - dref).abs().max())
+
+
+@pytest.mark.gpu
+def test_dtssd_and_bce_loss_kernels_match_torch():
+    """mg_dtssd_* (loss_dtSSD, maggie/network/loss.py:7-16, pinned value in dense_pinned.npz) and mg_bce_logits_* against torch: full
+    tensors, frame slices used in place (loss_temporal_sparsity's [:, 1:] / [:, :-1]), sigmoid-of-logits form, absent mask; values + gradients."""
+    from maggie_amd import functional as MF
+    from helpers import load_golden
+    dev = _dev()
+    rs = np.random.RandomState(9)
+    # the pinned value of the reference's own loss_dtSSD (same draws as tests/golden/make_golden.py:dense_fixture)
+    _ = rs.normal(size=(1, 3, 128, 8, 8)); _ = rs.normal(size=(1, 3, 64, 8, 8)); _ = rs.uniform(size=(1, 3, 2, 64, 64))
+    a = torch.from_numpy(rs.uniform(size=(2, 3, 32, 32)).astype(np.float32))
+    g = torch.from_numpy(rs.uniform(size=(2, 3, 32, 32)).astype(np.float32))
+    wgt = torch.from_numpy((rs.uniform(size=(2, 3, 32, 32)) > 0.5).astype(np.float32))
+    r5 = lambda t: t.reshape(1, 2, 3, 32, 32).to(dev)       # noqa: E731
+    assert abs(float(MF.dtssd_loss(r5(a), r5(g), r5(wgt))) - float(load_golden('dense_pinned.npz')['loss/dtssd'])) < 1e-6
+
+    def ref_dtssd(pred, gt, mask):
+        dadt, dgdt = pred[:, 1:] - pred[:, :-1], gt[:, 1:] - gt[:, :-1]
+        return torch.sum((dadt - dgdt) ** 2 * mask[:, 1:]) / torch.sum(mask[:, 1:] + 1e-6)
+
+    B, T, NI, H, W = 2, 4, 3, 8, 16
+    x = torch.from_numpy(rs.normal(size=(B, T, NI, H, W)).astype(np.float32))
+    y = torch.from_numpy(rs.uniform(size=(B, T, NI, H, W)).astype(np.float32))
+    m = torch.from_numpy((rs.uniform(size=(B, T, NI, H, W)) > 0.3).astype(np.float32))
+    for sl, sig, use_m in ((slice(None), False, True), (slice(1, None), True, False), (slice(None, -1), True, False), (slice(1, None), False, True)):
+        xr = x.clone().requires_grad_(True)
+        pr = xr[:, sl].sigmoid() if sig else xr[:, sl]
+        lr = ref_dtssd(pr, y[:, 1:] if sl != slice(None) else y, (m[:, 1:] if sl != slice(None) else m) if use_m else torch.ones_like(pr))
+        lr.backward()
+        xg = x.clone().to(dev).requires_grad_(True)
+        yy = (y[:, 1:] if sl != slice(None) else y).to(dev)
+        mm = ((m[:, 1:] if sl != slice(None) else m).to(dev)) if use_m else None
+        lg = MF.dtssd_loss(xg[:, sl], yy, mm, sig=sig)
+        lg.backward()
+        assert abs(float(lg) - float(lr)) <= 1e-5 * max(1.0, abs(float(lr))), (sl, sig)
+        assert torch.allclose(xg.grad.cpu(), xr.grad, atol=1e-6, rtol=1e-4), (sl, sig, float((xg.grad.cpu() - xr.grad).abs().max()))
+        # binary cross entropy with logits on the same slices
+        xr2 = x.clone().requires_grad_(True)
+        tgt = ((y[:, 1:] if sl != slice(None) else y) > 0.5).float()
+        lb = F.binary_cross_entropy_with_logits(xr2[:, sl], tgt, reduction='mean')
+        lb.backward()
+        xg2 = x.clone().to(dev).requires_grad_(True)
+        lh = MF.bce_logits_mean(xg2[:, sl], tgt.to(dev))
+        lh.backward()
+        assert abs(float(lh) - float(lb)) <= 1e-5 and torch.allclose(xg2.grad.cpu(), xr2.grad, atol=1e-7, rtol=1e-4)
