@@ -441,6 +441,26 @@ int mg_bce_logits_fwd(const float* x, long xbs, const float* y, long ybs, int B,
 int mg_bce_logits_bwd(const float* x, long xbs, const float* y, long ybs, int B, long TE, const float* gout, float* dx, long dbs, void* stream);
 int mg_temporal_crop(float* alpha, void* bits, int P, int H, int W, float sigma, float thr, int pad, float* scratch, int32_t* box, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Token side of the instance matte decoder (maggie_amd/csrc/token_side.hip): the (batch x 10 tokens) x 128 operations of
+ * maggie/network/module/mask_attention.py:9-206 -- projections, FFN / MLP layers, post-norm residual LayerNorms (SelfAttentionLayer
+ * :9-60, CrossAttentionLayer :63-133 token side, FFNLayer :170-182, MLP :185-206) -- fp32, single-workgroup kernels.
+ *   mg_token_linear_fwd: y[R,N] = LN( res + act( (x + xadd)[R,K] W[N,K]^T + bias ) ); xadd / bias / res / gamma,beta (LayerNorm) may be
+ *                        NULL, relu 0/1. With a LayerNorm: z[R,N] (its input) and rstat[R][2] = (mean, rstd) are kept for the backward.
+ *   mg_token_linear_bwd: from dy: dx[R,K] (also the gradient of xadd), dW[N,K], db[N], dres[R,N], dgamma / dbeta[N] (NULL when absent);
+ *                        yout = the forward output (ReLU mask; only read when relu); dz_scratch [R,N] floats.
+ *   mg_token_sa_fwd/bwd: out[b] = softmax(q[b] k[b]^T * scale, keys with pad[b][j] != 0 masked) v[b], prob [B,T,T] kept; T <= 16.
+ * ------------------------------------------------------------------------------------------------------------- */
+int mg_token_linear_fwd(const float* x, const float* xadd, const float* W, const float* bias, const float* res, int relu, const float* gamma,
+                        const float* beta, float eps, float* y, float* z, float* rstat, int R, int K, int N, void* stream);
+int mg_token_linear_bwd(const float* dy, const float* x, const float* xadd, const float* W, const float* yout, int relu, const float* gamma,
+                        const float* z, const float* rstat, float* dx, float* dW, float* db, float* dres, float* dgamma, float* dbeta, float* dz_scratch,
+                        int R, int K, int N, void* stream);
+int mg_token_sa_fwd(const float* q, const float* k, const float* v, const unsigned char* pad, float scale, int B, int T, int D, float* out, float* prob,
+                    void* stream);
+int mg_token_sa_bwd(const float* dout, const float* q, const float* k, const float* v, const float* prob, float scale, int B, int T, int D, float* dq,
+                    float* dk, float* dv, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

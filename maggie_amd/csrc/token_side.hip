@@ -1,0 +1,348 @@
+// Token side of the instance matte decoder (maggie/network/module/mask_attention.py:9-206, instance_matte_decoder.py:219-299): every
+// operation on the (batch x 10 instance tokens) x 128 matrices -- query / key / value projections, the out-projections, FFN and MLP
+// layers, post-norm residual LayerNorms, the 10 x 10 token self-attention. The reference runs them as ~150 cuBLAS + ~250 elementwise
+// launches per training step on tensors of 40 rows; here each layer is one fused launch forward and two backward (rows in LDS, W in L2):
+//   mg_token_linear_fwd : y = LN( res + act( (x + xadd) W^T + b ) )   [xadd, b, res, ReLU, LayerNorm each optional]
+//   mg_token_linear_bwd : dx (= dxadd), dW, db, dres, dgamma, dbeta of the above (a row-parallel and a column-parallel launch)
+//   mg_token_sa_fwd/bwd : softmax(q k^T / sqrt(d), key padding mask) v for the T tokens of each batch element
+// fp32 throughout (the reference keeps these tiny operands in fp32 too). Any row count; K a multiple of 4.
+#include "common.h"
+#include "../../include/maggie_hip.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ float block_row_sum(float v, float* red) {      // sum over the 256 threads of the block
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// Row-parallel forward: a workgroup owns RB = 4 rows and all N columns. W (<= 64 KB) is staged into LDS once per workgroup with
+// coalesced loads (transposed, pitch N + 1: conflict-free both ways) -- reading it per thread straight from L2 made the kernel a chain
+// of exposed round trips (9 us per layer); the row block of x sits in LDS too (broadcast reads). The LayerNorm of a row is finished
+// inside the same workgroup.
+constexpr int RB = 4;
+
+__global__ __launch_bounds__(NT) void token_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ xadd, const float* __restrict__ W,
+                                                              const float* __restrict__ bias, const float* __restrict__ res, int relu,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                              float* __restrict__ y, float* __restrict__ z_out, float* __restrict__ rstat, int R, int K,
+                                                              int N) {
+    extern __shared__ float sm[];
+    float* sx = sm;                      // [RB][K]  x + xadd
+    float* sy = sm + RB * K;             // [RB][N]  pre-LayerNorm values
+    float* sw = sy + RB * N;             // [K][N + 1]  W transposed
+    const int t = threadIdx.x;
+    const int r0 = blockIdx.x * RB;
+    const int nr = min(RB, R - r0);
+    const int P = N + 1;
+    {   // W -> LDS transposed; 8 x 16-byte loads in flight per thread (a load-store-load chain costs a round trip per element)
+        const int total4 = N * K / 4;
+        for (int base = t; base < total4; base += NT * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i4 = base + u * NT; if (i4 < total4) v[u] = ((const float4*)W)[i4]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i4 = base + u * NT;
+                if (i4 < total4) {
+                    const int i = i4 * 4, n = i / K, k = i - n * K;
+                    sw[k * P + n] = v[u].x; sw[(k + 1) * P + n] = v[u].y; sw[(k + 2) * P + n] = v[u].z; sw[(k + 3) * P + n] = v[u].w;
+                }
+            }
+        }
+    }
+    for (int i = t; i < RB * K; i += NT) sx[i] = i < nr * K ? x[(size_t)r0 * K + i] + (xadd ? xadd[(size_t)r0 * K + i] : 0.f) : 0.f;
+    __syncthreads();
+    // thread -> (column n, row pair): with N >= 128 two row pairs run side by side, narrower layers use fewer threads
+    const int cols = N < 128 ? N : 128;
+    const int c = t % cols, h = t / cols;            // h-th group of rows
+    const int groups = NT / cols;                    // row groups in flight
+    for (int n = c; n < N; n += cols) {
+        for (int rl0 = h; rl0 < RB; rl0 += groups) {
+            float acc = 0.f;
+            const float* xr = sx + rl0 * K;
+#pragma unroll 8
+            for (int k = 0; k < K; ++k) acc += sw[k * P + n] * xr[k];
+            if (rl0 >= nr) continue;
+            float v = acc + (bias ? bias[n] : 0.f);
+            if (relu) v = v > 0.f ? v : 0.f;
+            if (res) v += res[(size_t)(r0 + rl0) * N + n];
+            if (gamma) sy[rl0 * N + n] = v;
+            else y[(size_t)(r0 + rl0) * N + n] = v;
+        }
+    }
+    if (!gamma) return;
+    __syncthreads();
+    const int lane = t & 63, wave = t >> 6;          // LayerNorm: wave w normalises row w of the block
+    for (int rl = wave; rl < nr; rl += 4) {
+        float s = 0.f;
+        for (int n = lane; n < N; n += 64) s += sy[rl * N + n];
+        const float mean = wave_sum(s) / (float)N;
+        float q = 0.f;
+        for (int n = lane; n < N; n += 64) { const float d = sy[rl * N + n] - mean; q += d * d; }
+        const float rstd = rsqrtf(wave_sum(q) / (float)N + eps);
+        for (int n = lane; n < N; n += 64) {
+            const float v = sy[rl * N + n];
+            if (z_out) z_out[(size_t)(r0 + rl) * N + n] = v;
+            y[(size_t)(r0 + rl) * N + n] = (v - mean) * rstd * gamma[n] + beta[n];
+        }
+        if (lane == 0 && rstat) { rstat[2 * (r0 + rl)] = mean; rstat[2 * (r0 + rl) + 1] = rstd; }
+    }
+}
+
+// Backward, kernel A (row-parallel, RB rows per workgroup): dz = gradient at the pre-LayerNorm point (= dres), ReLU mask, and
+// dx[r][k] = sum_n dz[r][n] W[n][k] with W staged row-major in LDS (thread per input column k: conflict-free).
+__global__ __launch_bounds__(NT) void token_linear_bwd_rows_kernel(const float* __restrict__ dy, const float* __restrict__ W, const float* __restrict__ yout,
+                                                                   int relu, const float* __restrict__ gamma, const float* __restrict__ z,
+                                                                   const float* __restrict__ rstat, float* __restrict__ dx, float* __restrict__ dz_out,
+                                                                   float* __restrict__ dres, int R, int K, int N) {
+    extern __shared__ float sm[];
+    float* sdz = sm;                     // [RB][N]
+    float* sw = sm + RB * N;             // [N][K]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r0 = blockIdx.x * RB;
+    const int nr = min(RB, R - r0);
+    if (dx) {
+        const int total4 = N * K / 4;
+        for (int base = t; base < total4; base += NT * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i4 = base + u * NT; if (i4 < total4) v[u] = ((const float4*)W)[i4]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i4 = base + u * NT; if (i4 < total4) ((float4*)sw)[i4] = v[u]; }
+        }
+    }
+    for (int rl = wave; rl < RB; rl += 4) {
+        if (rl >= nr) { for (int n = lane; n < N; n += 64) sdz[rl * N + n] = 0.f; continue; }
+        const size_t ro = (size_t)(r0 + rl) * N;
+        if (gamma) {
+            const float mean = rstat[2 * (r0 + rl)], rstd = rstat[2 * (r0 + rl) + 1];
+            float s1 = 0.f, s2 = 0.f;
+            for (int n = lane; n < N; n += 64) {
+                const float gg = dy[ro + n] * gamma[n], xh = (z[ro + n] - mean) * rstd;
+                s1 += gg; s2 += gg * xh;
+            }
+            s1 = wave_sum(s1) / (float)N; s2 = wave_sum(s2) / (float)N;
+            for (int n = lane; n < N; n += 64) {
+                const float xh = (z[ro + n] - mean) * rstd;
+                sdz[rl * N + n] = rstd * (dy[ro + n] * gamma[n] - s1 - xh * s2);
+            }
+        } else {
+            for (int n = lane; n < N; n += 64) sdz[rl * N + n] = dy[ro + n];
+        }
+        for (int n = lane; n < N; n += 64) {
+            float g = sdz[rl * N + n];
+            if (dres) dres[ro + n] = g;                               // the residual enters after the activation
+            if (relu && !(yout[ro + n] > 0.f)) g = 0.f;
+            sdz[rl * N + n] = g;
+            dz_out[ro + n] = g;
+        }
+    }
+    __syncthreads();
+    if (!dx) return;
+    const int cols = K < 128 ? K : 128;
+    const int c = t % cols, h = t / cols, groups = NT / cols;
+    for (int k = c; k < K; k += cols) {
+        for (int rl = h; rl < nr; rl += groups) {
+            float acc = 0.f;
+            const float* g = sdz + rl * N;
+#pragma unroll 8
+            for (int n = 0; n < N; ++n) acc += g[n] * sw[n * K + k];
+            dx[(size_t)(r0 + rl) * K + k] = acc;
+        }
+    }
+}
+
+// Backward, kernel B (column-parallel, CB = 4 output columns per workgroup): dW[n][k] = sum_r dz[r][n] x'[r][k], db[n] = sum_r dz[r][n],
+// dgamma[n] = sum_r dy[r][n] xhat[r][n], dbeta[n] = sum_r dy[r][n]; x' = x + xadd staged in LDS in row chunks of 32.
+constexpr int CB = 4;
+
+__global__ __launch_bounds__(NT) void token_linear_bwd_cols_kernel(const float* __restrict__ dz, const float* __restrict__ dy, const float* __restrict__ x,
+                                                                   const float* __restrict__ xadd, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ z, const float* __restrict__ rstat, float* __restrict__ dW,
+                                                                   float* __restrict__ db, float* __restrict__ dgamma, float* __restrict__ dbeta, int R,
+                                                                   int K, int N) {
+    extern __shared__ float sm[];
+    constexpr int RC = 32;               // rows staged per pass
+    float* sg = sm;                      // [RC][CB] dz of this block's columns
+    float* sx = sm + RC * CB;            // [RC][K]
+    const int t = threadIdx.x;
+    const int n0 = blockIdx.x * CB;
+    const int nc = min(CB, N - n0);
+    const int cols = K < 128 ? K : 128;
+    const int c = t % cols, h = t / cols, groups = NT / cols;          // thread -> (k, column group)
+    // this thread's (k, column) pairs: k = c + ki * cols (ki < 2: K <= 256), column = h + cj * groups (cj < 2: groups >= 2)
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    float sb = 0.f, ag = 0.f, ab = 0.f;
+    for (int rb = 0; rb < R; rb += RC) {
+        const int nrow = min(RC, R - rb);
+        __syncthreads();
+        for (int i = t; i < nrow * CB; i += NT) { const int r = i / CB, cc = i - r * CB; sg[i] = cc < nc ? dz[(size_t)(rb + r) * N + n0 + cc] : 0.f; }
+        for (int i = t; i < nrow * K; i += NT) sx[i] = x[(size_t)rb * K + i] + (xadd ? xadd[(size_t)rb * K + i] : 0.f);
+        __syncthreads();
+#pragma unroll
+        for (int ki = 0; ki < 2; ++ki) {
+            const int k = c + ki * cols;
+            if (k >= K) continue;
+#pragma unroll
+            for (int cj = 0; cj < 2; ++cj) {
+                const int ci = h + cj * groups;
+                if (ci >= CB) continue;
+                float a = 0.f;
+#pragma unroll 8
+                for (int r = 0; r < nrow; ++r) a += sg[r * CB + ci] * sx[r * K + k];
+                acc[ki][cj] += a;
+            }
+        }
+        if (t < nc) {
+            for (int r = 0; r < nrow; ++r) {
+                sb += sg[r * CB + t];
+                if (gamma) {
+                    const float d = dy[(size_t)(rb + r) * N + n0 + t];
+                    ag += d * (z[(size_t)(rb + r) * N + n0 + t] - rstat[2 * (rb + r)]) * rstat[2 * (rb + r) + 1];
+                    ab += d;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int ki = 0; ki < 2; ++ki)
+#pragma unroll
+        for (int cj = 0; cj < 2; ++cj) {
+            const int k = c + ki * cols, ci = h + cj * groups;
+            if (k < K && ci < nc) dW[(size_t)(n0 + ci) * K + k] = acc[ki][cj];
+        }
+    if (t < nc) {
+        if (db) db[n0 + t] = sb;
+        if (gamma) { dgamma[n0 + t] = ag; dbeta[n0 + t] = ab; }
+    }
+}
+
+// ---- token self-attention core: one workgroup per batch element, T <= 16 tokens, D <= 256 -------------------------------------------------
+__global__ __launch_bounds__(NT) void token_sa_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                          const unsigned char* __restrict__ pad, float scale, int T, int D, float* __restrict__ out,
+                                                          float* __restrict__ prob) {
+    __shared__ float sp[16 * 16];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float* qb = q + (size_t)b * T * D; const float* kb = k + (size_t)b * T * D; const float* vb = v + (size_t)b * T * D;
+    if (t < T * T) {
+        const int i = t / T, j = t - i * T;
+        float s = 0.f;
+        for (int d = 0; d < D; ++d) s += qb[i * D + d] * kb[j * D + d];
+        s *= scale;
+        if (pad && pad[b * T + j]) s = -INFINITY;
+        sp[i * 16 + j] = s;
+    }
+    __syncthreads();
+    if (t < T) {
+        float m = -INFINITY;
+        for (int j = 0; j < T; ++j) m = fmaxf(m, sp[t * 16 + j]);
+        float sum = 0.f;
+        for (int j = 0; j < T; ++j) { const float e = __expf(sp[t * 16 + j] - m); sp[t * 16 + j] = e; sum += e; }
+        const float inv = 1.f / sum;
+        for (int j = 0; j < T; ++j) { sp[t * 16 + j] *= inv; prob[((size_t)b * T + t) * T + j] = sp[t * 16 + j]; }
+    }
+    __syncthreads();
+    for (int i = t; i < T * D; i += NT) {
+        const int r = i / D, d = i - r * D;
+        float a = 0.f;
+        for (int j = 0; j < T; ++j) a += sp[r * 16 + j] * vb[j * D + d];
+        out[(size_t)b * T * D + i] = a;
+    }
+}
+
+__global__ __launch_bounds__(NT) void token_sa_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ q, const float* __restrict__ k,
+                                                          const float* __restrict__ v, const float* __restrict__ prob, float scale, int T, int D,
+                                                          float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv) {
+    __shared__ float sp[16 * 16], sds[16 * 16];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const size_t o = (size_t)b * T * D;
+    if (t < T * T) {
+        const int i = t / T, j = t - i * T;
+        sp[i * 16 + j] = prob[((size_t)b * T + i) * T + j];
+        float a = 0.f;                                               // dP[i][j] = dout[i] . v[j]
+        for (int d = 0; d < D; ++d) a += dout[o + i * D + d] * v[o + j * D + d];
+        sds[i * 16 + j] = a;
+    }
+    __syncthreads();
+    if (t < T) {                                                     // softmax backward per row, then the 1/sqrt(d) factor
+        float dot = 0.f;
+        for (int j = 0; j < T; ++j) dot += sp[t * 16 + j] * sds[t * 16 + j];
+        for (int j = 0; j < T; ++j) sds[t * 16 + j] = sp[t * 16 + j] * (sds[t * 16 + j] - dot) * scale;
+    }
+    __syncthreads();
+    for (int i = t; i < T * D; i += NT) {
+        const int r = i / D, d = i - r * D;
+        float aq = 0.f, ak = 0.f, av = 0.f;
+        for (int j = 0; j < T; ++j) {
+            aq += sds[r * 16 + j] * k[o + j * D + d];                 // dq[r] = sum_j dS[r][j] k[j]
+            ak += sds[j * 16 + r] * q[o + j * D + d];                 // dk[r] = sum_i dS[i][r] q[i]
+            av += sp[j * 16 + r] * dout[o + j * D + d];               // dv[r] = sum_i P[i][r] dout[i]
+        }
+        dq[o + i] = aq; dk[o + i] = ak; dv[o + i] = av;
+    }
+}
+
+}  // namespace
+
+static int tl_check(int R, int K, int N) {
+    if (R <= 0 || K <= 0 || K > 256 || N <= 0 || N > 256 || (K & 3)) return -3;
+    return 0;
+}
+
+extern "C" int mg_token_linear_fwd(const float* x, const float* xadd, const float* W, const float* bias, const float* res, int relu, const float* gamma,
+                                   const float* beta, float eps, float* y, float* z, float* rstat, int R, int K, int N, void* stream) {
+    int rc = tl_check(R, K, N); if (rc) return rc;
+    if (gamma && (!beta || !z || !rstat)) return -2;
+    const size_t lds = ((size_t)RB * (K + N) + (size_t)K * (N + 1)) * sizeof(float);
+    if (lds > 150 * 1024) return -3;
+    static bool attr_f = false;
+    if (!attr_f) { (void)hipFuncSetAttribute((const void*)token_linear_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_f = true; }
+    hipLaunchKernelGGL(token_linear_fwd_kernel, dim3((R + RB - 1) / RB), dim3(NT), lds, (hipStream_t)stream, x, xadd, W, bias, res, relu, gamma, beta, eps, y, z,
+                       rstat, R, K, N);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+// `dz` [R,N] scratch = gradient w.r.t. the linear output (after LayerNorm backward and the ReLU mask); dres may alias nothing (NULL when absent)
+extern "C" int mg_token_linear_bwd(const float* dy, const float* x, const float* xadd, const float* W, const float* yout, int relu, const float* gamma,
+                                   const float* z, const float* rstat, float* dx, float* dW, float* db, float* dres, float* dgamma, float* dbeta,
+                                   float* dz, int R, int K, int N, void* stream) {
+    int rc = tl_check(R, K, N); if (rc) return rc;
+    if (gamma && (!z || !rstat || !dgamma || !dbeta)) return -2;
+    if ((relu && !yout) || !dz) return -2;
+    const size_t lds_r = ((size_t)RB * N + (size_t)N * K) * sizeof(float);
+    if (lds_r > 150 * 1024) return -3;
+    static bool attr_b = false;
+    if (!attr_b) { (void)hipFuncSetAttribute((const void*)token_linear_bwd_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_b = true; }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(token_linear_bwd_rows_kernel, dim3((R + RB - 1) / RB), dim3(NT), lds_r, st, dy, W, yout, relu, gamma, z, rstat, dx,
+                       dz, dres, R, K, N);
+    hipLaunchKernelGGL(token_linear_bwd_cols_kernel, dim3((N + CB - 1) / CB), dim3(NT), (size_t)32 * (CB + K) * sizeof(float), st, (const float*)dz, dy, x, xadd, gamma, z,
+                       rstat, dW, db, dgamma, dbeta, R, K, N);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_token_sa_fwd(const float* q, const float* k, const float* v, const unsigned char* pad, float scale, int B, int T, int D, float* out,
+                               float* prob, void* stream) {
+    if (B <= 0) return 0;
+    if (T <= 0 || T > 16 || D <= 0) return -3;
+    hipLaunchKernelGGL(token_sa_fwd_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, q, k, v, pad, scale, T, D, out, prob);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_token_sa_bwd(const float* dout, const float* q, const float* k, const float* v, const float* prob, float scale, int B, int T, int D,
+                               float* dq, float* dk, float* dv, void* stream) {
+    if (B <= 0) return 0;
+    if (T <= 0 || T > 16 || D <= 0) return -3;
+    hipLaunchKernelGGL(token_sa_bwd_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, dout, q, k, v, prob, scale, T, D, dq, dk, dv);
+    MG_CHECK_LAUNCH();
+    return 0;
+}

@@ -1199,3 +1199,123 @@ def temporal_crop_(alpha, bits, sigma=3, thr=0.1, pad=30):
     K.hip.call('mg_temporal_crop', K.hip.ptr(a), K.hip.ptr(bits), K.c_int(P), K.c_int(H), K.c_int(W_), K.c_float(float(sigma)), K.c_float(float(thr)),
                K.c_int(int(pad)), K.hip.ptr(scratch), K.hip.ptr(box), K.hip.stream())
     return alpha, bits
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# token side of the instance matte decoder (maggie_amd/csrc/token_side.hip)
+# ----------------------------------------------------------------------------------------------------------------------
+
+class TokenLinear(torch.autograd.Function):
+    """y = LN( res + act( (x + xadd) W^T + b ) ) over (..., K) -> (..., N) fp32; every optional piece may be None. One HIP launch each way
+    (the reference: up to 2 adds + cuBLAS + bias + ReLU + add + LayerNorm forward, twice that backward)."""
+
+    @staticmethod
+    def forward(ctx, x, xadd, W, b, res, relu, gamma, beta, eps):
+        if relu and (res is not None or gamma is not None):
+            raise K.hip.MaggieHipError('TokenLinear: ReLU is only fused for a plain linear layer (no residual / LayerNorm behind it)')
+        shape = x.shape
+        Kd, N = shape[-1], W.shape[0]
+        f = lambda t: None if t is None else t.detach().float().contiguous()       # noqa: E731
+        x2, xa, W_, b_, r_, g_, be_ = f(x).view(-1, Kd), f(xadd), f(W), f(b), f(res), f(gamma), f(beta)
+        if xa is not None:
+            xa = xa.expand(shape).contiguous().view(-1, Kd) if xa.shape != shape else xa.view(-1, Kd)
+        if r_ is not None:
+            r_ = r_.view(-1, N)
+        R = x2.shape[0]
+        y = torch.empty((R, N), dtype=torch.float32, device=x.device)
+        z = torch.empty((R, N), dtype=torch.float32, device=x.device) if g_ is not None else None
+        rstat = torch.empty((R, 2), dtype=torch.float32, device=x.device) if g_ is not None else None
+        K.hip.call('mg_token_linear_fwd', K.hip.ptr(x2), K.hip.ptr(xa), K.hip.ptr(W_), K.hip.ptr(b_), K.hip.ptr(r_), K.c_int(int(bool(relu))),
+                   K.hip.ptr(g_), K.hip.ptr(be_), K.c_float(float(eps)), K.hip.ptr(y), K.hip.ptr(z), K.hip.ptr(rstat), K.c_int(R), K.c_int(Kd),
+                   K.c_int(N), K.hip.stream())
+        ctx.save_for_backward(x2, xa, W_, y if relu else None, g_, z, rstat)
+        ctx.meta = (shape, R, Kd, N, bool(relu), b is not None, res is not None, None if xadd is None else xadd.shape)
+        return y.view(*shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, xa, W_, yout, g_, z, rstat = ctx.saved_tensors
+        shape, R, Kd, N, relu, has_b, has_res, xadd_shape = ctx.meta
+        dev = dy.device
+        dy2 = dy.float().contiguous().view(R, N)
+        need_dx = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        dx = torch.empty((R, Kd), dtype=torch.float32, device=dev) if need_dx else None
+        dW = torch.empty((N, Kd), dtype=torch.float32, device=dev)
+        db = torch.empty(N, dtype=torch.float32, device=dev) if has_b else None
+        dres = torch.empty((R, N), dtype=torch.float32, device=dev) if has_res else None
+        dgb = torch.empty(2 * N, dtype=torch.float32, device=dev) if g_ is not None else None
+        dz = torch.empty((R, N), dtype=torch.float32, device=dev)
+        K.hip.call('mg_token_linear_bwd', K.hip.ptr(dy2), K.hip.ptr(x2), K.hip.ptr(xa), K.hip.ptr(W_), K.hip.ptr(yout), K.c_int(int(relu)), K.hip.ptr(g_),
+                   K.hip.ptr(z), K.hip.ptr(rstat), K.hip.ptr(dx), K.hip.ptr(dW), K.hip.ptr(db), K.hip.ptr(dres),
+                   K.hip.ptr(None if dgb is None else dgb[:N]), K.hip.ptr(None if dgb is None else dgb[N:]), K.hip.ptr(dz), K.c_int(R), K.c_int(Kd),
+                   K.c_int(N), K.hip.stream())
+        dxv = None if dx is None else dx.view(shape)
+        dxadd = None
+        if xadd_shape is not None and ctx.needs_input_grad[1]:
+            dxadd = dxv if tuple(xadd_shape) == tuple(shape) else dxv.sum_to_size(xadd_shape)
+        return (dxv if ctx.needs_input_grad[0] else None, dxadd, dW, db, None if dres is None else dres.view(*shape[:-1], N), None,
+                None if dgb is None else dgb[:N], None if dgb is None else dgb[N:], None)
+
+
+def token_linear(x, W, b=None, xadd=None, res=None, relu=False, ln=None):
+    """`ln`: an nn.LayerNorm (weight, bias, eps) applied to (res + linear output)."""
+    g, be, eps = (ln.weight, ln.bias, ln.eps) if ln is not None else (None, None, 0.0)
+    return TokenLinear.apply(x, xadd, W, b, res, relu, g, be, eps)
+
+
+class TokenSelfAttention(torch.autograd.Function):
+    """softmax(q k^T / sqrt(d), key padding) v for (B, T <= 16, D) fp32 tokens: one workgroup per batch element each way."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, pad):
+        q, k, v = q.float().contiguous(), k.float().contiguous(), v.float().contiguous()
+        B, T, D = q.shape
+        pd = None if pad is None else pad.to(torch.uint8).contiguous()
+        out = torch.empty_like(q)
+        prob = torch.empty((B, T, T), dtype=torch.float32, device=q.device)
+        scale = 1.0 / (D ** 0.5)
+        K.hip.call('mg_token_sa_fwd', K.hip.ptr(q), K.hip.ptr(k), K.hip.ptr(v), K.hip.ptr(pd), K.c_float(scale), K.c_int(B), K.c_int(T), K.c_int(D),
+                   K.hip.ptr(out), K.hip.ptr(prob), K.hip.stream())
+        ctx.save_for_backward(q, k, v, prob)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, prob = ctx.saved_tensors
+        B, T, D = q.shape
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        K.hip.call('mg_token_sa_bwd', K.hip.ptr(dout.float().contiguous()), K.hip.ptr(q), K.hip.ptr(k), K.hip.ptr(v), K.hip.ptr(prob), K.c_float(ctx.scale),
+                   K.c_int(B), K.c_int(T), K.c_int(D), K.hip.ptr(dq), K.hip.ptr(dk), K.hip.ptr(dv), K.hip.stream())
+        return dq, dk, dv, None
+
+
+def token_self_attention(q, k, v, pad=None):
+    return TokenSelfAttention.apply(q, k, v, pad)
+
+
+class RowsAddLayerNorm(torch.autograd.Function):
+    """LayerNorm(x + r) over the channels of (rows, C) matrices (the post-norm residual of the feature-side cross attention over all
+    b * L feature rows, mask_attention.py:128-133): mg_rows_add_layernorm_fwd / _bwd."""
+
+    @staticmethod
+    def forward(ctx, x, r, gamma, beta, eps):
+        shape = x.shape
+        C = shape[-1]
+        x2, r2 = x.contiguous().view(-1, C), r.contiguous().view(-1, C)
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        y, rstat = K.rows_add_layernorm(x2, r2, g, b, eps)
+        ctx.save_for_backward(x2, r2, g, rstat)
+        ctx.shape = shape
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, r2, g, rstat = ctx.saved_tensors
+        dz, dg, db = K.rows_add_layernorm_bwd(dy.contiguous().view(x2.shape), x2, r2, g, rstat)
+        dz = dz.view(ctx.shape)
+        return dz, dz, dg, db, None
+
+
+def rows_add_layernorm(x, r, ln):
+    return RowsAddLayerNorm.apply(x, r, ln.weight, ln.bias, ln.eps)

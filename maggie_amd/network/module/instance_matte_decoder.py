@@ -143,7 +143,7 @@ class InstanceMatteDecoder(nn.Module):
             out_feat = feat
 
         with torch.autocast('cuda', enabled=False):
-            tokens = self.decoder_norm(self.final_mlp(tokens))                                # (b, 10, c_out) fp32
+            tokens = self.final_mlp(tokens, ln=self.decoder_norm)                               # (b, 10, c_out) fp32
         # einsum('bqc,btchw->btqhw'): a per-batch-element 1x1 conv whose weights are the tokens (padded to 16 outputs)
         cq = MF.pad8(n_i) if MF.pad8(n_i) >= 16 else 16
         logits = []

@@ -48,18 +48,14 @@ class SelfAttentionLayer(nn.Module):
                 nn.init.xavier_uniform_(p)
 
     def forward(self, tgt, tgt_key_padding_mask=None, query_pos=None):
-        """tgt: (b, T, d) tokens; key padding mask (b, T) True = ignore."""
+        """tgt: (b, T, d) tokens; key padding mask (b, T) True = ignore. Five HIP launches: three projections (position added inside),
+        the T x T attention core, out-projection + residual + LayerNorm (mg_token_linear_*, mg_token_sa_*)."""
         (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.self_attn)
-        qk = tgt if query_pos is None else tgt + query_pos
-        q = F.linear(qk, wq, bq)
-        k = F.linear(qk, wk, bk)
-        v = F.linear(tgt, wv, bv)
-        s = torch.matmul(q, k.transpose(1, 2)) / math.sqrt(q.shape[-1])
-        if tgt_key_padding_mask is not None:
-            s = s.masked_fill(tgt_key_padding_mask[:, None, :], float('-inf'))
-        p = torch.softmax(s, -1)
-        out = self.self_attn.out_proj(torch.matmul(p, v))
-        return self.norm(tgt + out)
+        q = MF.token_linear(tgt, wq, bq, xadd=query_pos)
+        k = MF.token_linear(tgt, wk, bk, xadd=query_pos)
+        v = MF.token_linear(tgt, wv, bv)
+        ctx = MF.token_self_attention(q, k, v, tgt_key_padding_mask)
+        return MF.token_linear(ctx, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, res=tgt, ln=self.norm)
 
 
 class CrossAttentionLayer(nn.Module):
@@ -75,37 +71,33 @@ class CrossAttentionLayer(nn.Module):
     def tokens_from_features(self, tokens, token_pos, feat, feat_ids, id_table):
         """tokens (b,T,d) <- feat (b,L,d) with key position = id_table[feat_ids] ((b,L) int32). Returns new tokens and the
         attention matrix (b,T,L). The pass over the feature rows (scores, softmax over L, context) is one HIP pipeline
-        (mg_attn_tok_fwd / _bwd); the 10-token projections around it are small fp32 torch ops."""
+        (mg_attn_tok_fwd / _bwd); the 10-token projections around it are fused HIP linears (mg_token_linear_*)."""
         (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.multihead_attn)
         d = tokens.shape[-1]
-        q = F.linear(tokens if token_pos is None else tokens + token_pos, wq, bq)            # (b,T,d)
-        qk = torch.matmul(q, wk)                                                             # fold Wk into the queries
-        qb = (q * bk).sum(-1, keepdim=True)
-        if id_table is not None:
-            tbl = torch.matmul(q, (F.linear(id_table, wk)).t()) + qb                         # (b,T,n_id)
-        else:
-            tbl = qb                                                                         # (b,T,1); feat_ids are all 0
+        q = MF.token_linear(tokens, wq, bq, xadd=token_pos)                                  # (b,T,d)
+        qk = MF.token_linear(q, wk.t().contiguous())                                         # q Wk: fold Wk into the queries
+        # score bias of a feature row with position id: q . (E[id] Wk^T + bk)  (id_table None: every row has id 0 and no embedding)
+        key_pos = MF.token_linear(id_table, wk, bk) if id_table is not None else bk[None, :]
+        tbl = MF.token_linear(q, key_pos)                                                    # (b,T,n_id)
         if _hip_attention(tokens.shape[1], d):
             p, ctx = MF.attn_tokens_from_features(qk, tbl, feat, feat_ids, 1.0 / math.sqrt(d))
         else:                                                                                # other widths: plain torch
             s = torch.matmul(qk, feat.transpose(1, 2)) + torch.gather(tbl, 2, feat_ids.long()[:, None, :].expand(-1, q.shape[1], -1))
             p = torch.softmax(s / math.sqrt(d), -1)
             ctx = torch.matmul(p, feat)                                                      # (b,T,d)
-        out = self.multihead_attn.out_proj(F.linear(ctx, wv, bv))
-        return self.norm(tokens + out), p
+        h = MF.token_linear(ctx, wv, bv)
+        return MF.token_linear(h, self.multihead_attn.out_proj.weight, self.multihead_attn.out_proj.bias, res=tokens, ln=self.norm), p
 
     def features_from_tokens(self, feat, feat_ids, id_table, tokens, token_pos, token_padding_mask):
         """feat (b,L,d) <- tokens (b,T,d); query position = id_table[feat_ids]. Scores, masked softmax over the T tokens and
-        the value mix are one HIP kernel per direction (mg_attn_feat_fwd / _bwd)."""
+        the value mix are one HIP kernel per direction (mg_attn_feat_fwd / _bwd); residual + LayerNorm over the b * L rows one more."""
         (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.multihead_attn)
         d = feat.shape[-1]
-        k = F.linear(tokens if token_pos is None else tokens + token_pos, wk, bk)            # (b,T,d)
-        vp = F.linear(F.linear(tokens, wv, bv), self.multihead_attn.out_proj.weight)         # (b,T,d): rows of (Wo V^T)^T
-        kq = torch.matmul(k, wq)                                                             # (b,T,d): fold Wq into the keys
-        if id_table is not None:
-            tbl = torch.matmul(F.linear(id_table, wq, bq), k.transpose(1, 2))                # (b,n_id,T)
-        else:
-            tbl = torch.matmul(k, bq)[:, None, :]                                            # (b,1,T)
+        k = MF.token_linear(tokens, wk, bk, xadd=token_pos)                                  # (b,T,d)
+        vp = MF.token_linear(MF.token_linear(tokens, wv, bv), self.multihead_attn.out_proj.weight)      # (b,T,d): rows of (Wo V^T)^T
+        kq = MF.token_linear(k, wq.t().contiguous())                                         # (b,T,d): fold Wq into the keys
+        qry_pos = MF.token_linear(id_table, wq, bq) if id_table is not None else bq[None, :]  # (n_id, d)
+        tbl = MF.token_linear(k, qry_pos).transpose(1, 2).contiguous()                       # (b,n_id,T)
         if _hip_attention(tokens.shape[1], d):
             out = MF.attn_features_from_tokens(feat, kq, tbl, vp, self.multihead_attn.out_proj.bias, token_padding_mask, feat_ids,
                                                1.0 / math.sqrt(d))
@@ -115,7 +107,7 @@ class CrossAttentionLayer(nn.Module):
             if token_padding_mask is not None:
                 s = s.masked_fill(token_padding_mask[:, None, :], float('-inf'))
             out = torch.matmul(torch.softmax(s, -1), vp) + self.multihead_attn.out_proj.bias
-        return self.norm(feat + out)
+        return MF.rows_add_layernorm(feat, out, self.norm)
 
 
 class FFNLayer(nn.Module):
@@ -131,8 +123,12 @@ class FFNLayer(nn.Module):
                 nn.init.xavier_uniform_(p)
 
     def forward(self, tgt):
-        tgt2 = self.linear2(self.dropout(F.relu(self.linear1(tgt))))
-        return self.norm(tgt + self.dropout(tgt2))
+        """Token rows (b, T, d): two fused HIP launches (linear + ReLU; linear + residual + LayerNorm). The instance-specific FFN of
+        the sparse head (dropout 0.1, row counts in a device word) runs inside maggie_amd.sparse_head instead."""
+        if self.dropout.p > 0 and self.training:
+            raise MF.K.hip.MaggieHipError('FFNLayer with dropout on token rows is not part of maggie_{image,video}.yaml (see sparse_head)')
+        h = MF.token_linear(tgt, self.linear1.weight, self.linear1.bias, relu=True)
+        return MF.token_linear(h, self.linear2.weight, self.linear2.bias, res=tgt, ln=self.norm)
 
 
 class MLP(nn.Module):
@@ -144,7 +140,13 @@ class MLP(nn.Module):
         h = [hidden_dim] * (num_layers - 1)
         self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
 
-    def forward(self, x):
+    def forward(self, x, ln=None):
+        """`ln`: a LayerNorm fused behind the last layer (InstanceMatteDecoder: decoder_norm(final_mlp(tokens)))."""
+        if x.dim() == 3 and x.shape[0] * x.shape[1] <= 128 and x.dtype == torch.float32:      # token rows: fused HIP linears
+            for i, layer in enumerate(self.layers):
+                last = i == self.num_layers - 1
+                x = MF.token_linear(x, layer.weight, layer.bias, relu=not last, ln=ln if last else None)
+            return x
         for i, layer in enumerate(self.layers):
             x = F.relu(layer(x)) if i < self.num_layers - 1 else layer(x)
-        return x
+        return x if ln is None else ln(x)

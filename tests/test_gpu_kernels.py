@@ -920,3 +920,77 @@ def test_dtssd_and_bce_loss_kernels_match_torch():
         lh = MF.bce_logits_mean(xg2[:, sl], tgt.to(dev))
         lh.backward()
         assert abs(float(lh) - float(lb)) <= 1e-5 and torch.allclose(xg2.grad.cpu(), xr2.grad, atol=1e-7, rtol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('R,Kd,N,xadd,bias,res,relu,ln', [
+    (40, 128, 128, True, True, True, False, True),      # projection + residual + LayerNorm (attention out-projection, FFN second layer)
+    (40, 128, 128, False, True, False, True, False),    # linear + ReLU (FFN first layer)
+    (40, 128, 11, False, False, False, False, False),   # score-bias table (N not a multiple of 4)
+    (11, 128, 128, False, True, False, False, False),   # ID-embedding rows through a projection
+    (10, 128, 64, False, True, False, False, True),     # final MLP + decoder_norm (batch 1), LayerNorm without residual
+    (80, 128, 1, True, False, False, False, False),     # batch 8, one output column
+])
+def test_token_linear_matches_torch(R, Kd, N, xadd, bias, res, relu, ln):
+    """mg_token_linear_fwd / _bwd: y = LN(res + act((x + xadd) W^T + b)) and every gradient against torch autograd."""
+    from maggie_amd import functional as MF
+    dev = _dev()
+    g = torch.Generator().manual_seed(R * 1000 + N)
+    mk = lambda *s: torch.randn(*s, generator=g)                      # noqa: E731
+    x, W = mk(R, Kd), mk(N, Kd) / Kd ** 0.5
+    xa = mk(R, Kd) if xadd else None
+    b = mk(N) if bias else None
+    r = mk(R, N) if res else None
+    norm = torch.nn.LayerNorm(N) if ln else None
+    if ln:
+        with torch.no_grad():
+            norm.weight.copy_(mk(N)); norm.bias.copy_(mk(N))
+    leaves = [t for t in (x, xa, W, b, r) if t is not None]
+    for t in leaves:
+        t.requires_grad_(True)
+    h = F.linear(x + xa if xadd else x, W, b)
+    if relu:
+        h = F.relu(h)
+    if res:
+        h = h + r
+    y_ref = norm(h) if ln else h
+    wgt = mk(R, N)
+    (y_ref * wgt).sum().backward()
+    dl = [None if t is None else t.detach().clone().to(dev).requires_grad_(True) for t in (x, xa, W, b, r)]
+    nd = None
+    if ln:
+        nd = torch.nn.LayerNorm(N).to(dev)
+        nd.load_state_dict(norm.state_dict())
+    y = MF.token_linear(dl[0], dl[2], dl[3], xadd=dl[1], res=dl[4], relu=relu, ln=nd)
+    (y * wgt.to(dev)).sum().backward()
+    tol = dict(atol=2e-5, rtol=2e-5)
+    assert torch.allclose(y.detach().cpu(), y_ref.detach(), **tol), float((y.detach().cpu() - y_ref.detach()).abs().max())
+    for name, a, c in zip(('x', 'xadd', 'W', 'b', 'res'), dl, (x, xa, W, b, r)):
+        if c is not None:
+            assert torch.allclose(a.grad.cpu(), c.grad, atol=5e-5, rtol=5e-5), (name, float((a.grad.cpu() - c.grad).abs().max()))
+    if ln:
+        assert torch.allclose(nd.weight.grad.cpu(), norm.weight.grad, atol=5e-5, rtol=5e-5) and torch.allclose(nd.bias.grad.cpu(), norm.bias.grad, atol=5e-5, rtol=5e-5)
+
+
+@pytest.mark.gpu
+def test_token_self_attention_matches_torch():
+    """mg_token_sa_fwd / _bwd: softmax(q k^T / sqrt(d), key padding mask) v for 10 tokens per batch element, against torch autograd."""
+    from maggie_amd import functional as MF
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    B, T, D = 4, 10, 128
+    q, k, v = (torch.randn(B, T, D, generator=g).requires_grad_(True) for _ in range(3))
+    pad = torch.zeros(B, T, dtype=torch.bool)
+    pad[:, 2:] = True
+    pad[1, :5] = False
+    s = torch.matmul(q, k.transpose(1, 2)) / D ** 0.5
+    s = s.masked_fill(pad[:, None, :], float('-inf'))
+    out_ref = torch.matmul(torch.softmax(s, -1), v)
+    wgt = torch.randn(B, T, D, generator=g)
+    (out_ref * wgt).sum().backward()
+    qd, kd, vd = (t.detach().clone().to(dev).requires_grad_(True) for t in (q, k, v))
+    out = MF.token_self_attention(qd, kd, vd, pad.to(dev))
+    (out * wgt.to(dev)).sum().backward()
+    assert torch.allclose(out.detach().cpu(), out_ref.detach(), atol=2e-5, rtol=2e-5)
+    for a, c in ((qd, q), (kd, k), (vd, v)):
+        assert torch.allclose(a.grad.cpu(), c.grad, atol=5e-5, rtol=5e-5), float((a.grad.cpu() - c.grad).abs().max())
