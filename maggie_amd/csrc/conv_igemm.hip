@@ -1655,6 +1655,207 @@ __global__ __launch_bounds__(256) void wgrad_reduce_wave_kernel(const float* __r
     }
 }
 
+// many splits: 32 consecutive elements x 8 split groups per block -- 128-byte coalesced rows, splits/8 loads per thread, LDS finish
+template <typename TO>
+__global__ __launch_bounds__(256) void wgrad_reduce_tile_kernel(const float* __restrict__ ws, int splits, long n, TO* __restrict__ dw) {
+    __shared__ float part[8][33];
+    const int e = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    const long i = (long)blockIdx.x * 32 + e;
+    float a0 = 0.f, a1 = 0.f;
+    if (i < n) {
+        int s = sg;
+        for (; s + 8 < splits; s += 16) { a0 += ws[(long)s * n + i]; a1 += ws[(long)(s + 8) * n + i]; }
+        if (s < splits) a0 += ws[(long)s * n + i];
+    }
+    part[sg][e] = a0 + a1;
+    __syncthreads();
+    if (sg == 0 && i < n)
+        ElemTraits<TO>::st(dw + i, ((part[0][e] + part[1][e]) + (part[2][e] + part[3][e])) + ((part[4][e] + part[5][e]) + (part[6][e] + part[7][e])));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Halo-tile weight gradient for the 3x3 / stride 1 / pad 1 layers (bf16): one block = one (co tile, ci tile) of ALL nine taps over a
+// range of 8x16-pixel spatial tiles. The dY tile (128 px) and the x halo tile (10x18 px) are staged once per spatial tile and serve
+// nine MFMA sweeps -- the per-tap kernel above re-reads dY nine times and x nine times from L2 (32 FLOP per byte staged; that, not
+// MFMA rate, bounded it at ~100 TFLOP/s). The reduction dimension is the pixel index: both operands are read transposed from
+// row-major LDS tiles with ds_read_b64_tr_b16, the x rows shifted by the tap's (ky, kx) inside the halo tile. Waves own the four
+// quadrants of the block tile (no cross-wave reduction); accumulators leave the registers as fp32 partials, one slab per spatial split.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int FM, int FN>
+__global__ __launch_bounds__(256) void igemm_wgrad_halo_kernel(const mg_conv_params p, int tiles_per_block, float* __restrict__ ws) {
+    constexpr int TCO = 32 * FM, TCI = 32 * FN;
+    constexpr int TH = 8, TW = 16, HW_ = TW + 2, HH = TH + 2;
+    constexpr int PY = TCO + 16, PX = TCI + 16;                  // row pitches (elements): 96 / 160 bytes, conflict-free for the 4-row transpose reads
+    constexpr int CPY = TCO / 8, CPX = TCI / 8;
+    constexpr int NY = TH * TW * CPY, NX = HH * HW_ * CPX;
+    constexpr int ITY = (NY + 255) / 256, ITX = (NX + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16raw* sY = (bf16raw*)smem;                                // [TH*TW][PY]
+    bf16raw* sX = sY + TH * TW * PY;                             // [HH*HW_][PX]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int wco = (wave >> 1) * FM * 16, wci = (wave & 1) * FN * 16;
+    const int nci = p.Cin / TCI, nco = p.Cout / TCO;
+    const int tiles_x = (p.Wout + TW - 1) / TW, tiles_y = (p.Hout + TH - 1) / TH;
+    const int S = p.N * tiles_y * tiles_x;
+    const int nsplit = (S + tiles_per_block - 1) / tiles_per_block;
+    int work;
+    if (!xcd_order(nsplit * nco * nci, work)) return;
+    const int cc = work % (nco * nci), split = work / (nco * nci);
+    const int co0 = (cc / nci) * TCO, ci0 = (cc % nci) * TCI;
+    const int s_beg = split * tiles_per_block, s_end = min(S, s_beg + tiles_per_block);
+    const bf16raw* __restrict__ yb = (const bf16raw*)p.y;
+    const bf16raw* __restrict__ xb = (const bf16raw*)p.x;
+
+    uint4 ry[ITY], rx[ITX];
+    auto load_tile = [&](int s) {
+        const int n = s / (tiles_y * tiles_x);
+        const int r = s - n * tiles_y * tiles_x;
+        const int y0 = (r / tiles_x) * TH, x0 = (r % tiles_x) * TW;
+#pragma unroll
+        for (int i = 0; i < ITY; ++i) {
+            const int idx = t + i * 256;
+            const int px = idx / CPY, c = idx - px * CPY;
+            const int oy = y0 + px / TW, ox = x0 + px % TW;
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if (idx < NY && oy < p.Hout && ox < p.Wout)
+                q = *(const uint4*)(yb + ((long)(n * p.Hout + oy) * p.Wout + ox) * p.ldy + p.yoff + co0 + c * 8);
+            ry[i] = q;
+        }
+#pragma unroll
+        for (int i = 0; i < ITX; ++i) {
+            const int idx = t + i * 256;
+            const int px = idx / CPX, c = idx - px * CPX;
+            const int iy = y0 - 1 + px / HW_, ix = x0 - 1 + px % HW_;
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if (idx < NX && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win)
+                q = *(const uint4*)(xb + ((long)(n * p.Hin + iy) * p.Win + ix) * p.ldx + ci0 + c * 8);
+            rx[i] = q;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < ITY; ++i) {
+            const int idx = t + i * 256;
+            const int px = idx / CPY, c = idx - px * CPY;
+            if (idx < NY) *(uint4*)(sY + px * PY + c * 8) = ry[i];
+        }
+#pragma unroll
+        for (int i = 0; i < ITX; ++i) {
+            const int idx = t + i * 256;
+            const int px = idx / CPX, c = idx - px * CPX;
+            if (idx < NX) *(uint4*)(sX + px * PX + c * 8) = rx[i];
+        }
+    };
+
+    f32x4 acc[9][FM][FN];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[tp][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int q = g * 4 + (li >> 2), cq = (li & 3) * 4;          // this lane's pixel column inside a 16-px tile row, and its 4-channel group
+    if (s_beg < s_end) load_tile(s_beg);
+    for (int s = s_beg; s < s_end; ++s) {
+        store_tile();
+        __syncthreads();
+        if (s + 1 < s_end) load_tile(s + 1);
+#pragma unroll
+        for (int kc = 0; kc < TH / 2; ++kc) {                    // 32 pixels (two tile rows) per MFMA K step
+            s16x4 a[FM][2];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                a[i][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sY + ((2 * kc) * TW + q) * PY + wco + i * 16 + cq));
+                a[i][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sY + ((2 * kc + 1) * TW + q) * PY + wco + i * 16 + cq));
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    s16x4 b[FN][2];
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        b[j][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sX + ((2 * kc + ky) * HW_ + q + kx) * PX + wci + j * 16 + cq));
+                        b[j][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sX + ((2 * kc + 1 + ky) * HW_ + q + kx) * PX + wci + j * 16 + cq));
+                    }
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j) {
+                            union { s16x4 h[2]; bf16x8 v; } ua, ub;
+                            ua.h[0] = a[i][0]; ua.h[1] = a[i][1]; ub.h[0] = b[j][0]; ub.h[1] = b[j][1];
+                            acc[ky * 3 + kx][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc[ky * 3 + kx][i][j], 0, 0, 0);
+                        }
+                }
+        }
+        __syncthreads();
+    }
+    float* __restrict__ slab = ws + (long)split * p.Cout * 9 * p.Cin;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    slab[((long)(co0 + wco + i * 16 + g * 4 + e) * 9 + tp) * p.Cin + ci0 + wci + j * 16 + li] = acc[tp][i][j][e];
+}
+
+static inline bool wgrad_halo_eligible(const mg_conv_params& p) {
+    static const int on = [] { const char* e = getenv("MG_WGRAD_HALO"); return e ? atoi(e) : 1; }();
+    return on && p.dtype == MG_BF16 && p.mode == MG_MODE_CONV && !p.m_dev && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad == 1 && p.dil == 1 &&
+           p.Hout == p.Hin && p.Wout == p.Win && p.Cin % 32 == 0 && p.Cout % 32 == 0 && p.ldx % 8 == 0 && p.ldy % 8 == 0 && p.yoff % 8 == 0 &&
+           p.Wout >= 16 && p.Hout >= 8 && (long)p.Cout * 9 * p.Cin <= (16l << 20);
+}
+
+struct WgradHaloPlan { long splits; int tpb; };
+
+static WgradHaloPlan plan_wgrad_halo(const mg_conv_params& p) {
+    const long cc = (long)(p.Cin / 32) * (p.Cout / 32);
+    const long S = (long)p.N * ((p.Hout + 7) / 8) * ((p.Wout + 15) / 16);
+    static const long target = [] { const char* e = getenv("MG_WGRAD_HALO_BLOCKS"); return e ? atol(e) : 512l; }();
+    const long n = (long)p.Cout * 9 * p.Cin;
+    long splits = (target + cc - 1) / cc;
+    if (splits > S) splits = S;
+    if (splits > (16l << 20) / n) splits = (16l << 20) / n;
+    if (splits < 1) splits = 1;
+    const int tpb = (int)((S + splits - 1) / splits);
+    splits = (S + tpb - 1) / tpb;
+    return {splits, tpb};
+}
+
+static int launch_wgrad_halo(const mg_conv_params& p, float* ws, long ws_floats, hipStream_t st) {
+    const WgradHaloPlan pl = plan_wgrad_halo(p);
+    const long n = (long)p.Cout * 9 * p.Cin;
+    const bool out_bf16 = p.dw_dtype == MG_BF16;
+    float* use_ws = nullptr;
+    if ((pl.splits > 1 || out_bf16) && ws && ws_floats >= pl.splits * n) use_ws = ws;
+    if (out_bf16 && !use_ws) return -4;
+    if (pl.splits > 1 && !use_ws) return -4;                       // the halo form has no atomic fallback: callers size the workspace first
+    if (pl.splits == 1 && !out_bf16) use_ws = p.stats;
+    const long cc = (long)(p.Cin / 32) * (p.Cout / 32);
+    dim3 grid(xcd_grid(pl.splits * cc));
+    const size_t lds = (size_t)(8 * 16 * (32 + 16) + 10 * 18 * (32 + 16)) * sizeof(bf16raw);
+    hipLaunchKernelGGL((igemm_wgrad_halo_kernel<1, 1>), grid, dim3(256), lds, st, p, pl.tpb, use_ws);
+    if (use_ws != p.stats) {
+        if (pl.splits >= 8) {
+            const long b = (n + 31) / 32;
+            if (out_bf16) hipLaunchKernelGGL(wgrad_reduce_tile_kernel<bf16raw>, dim3((unsigned)b), dim3(256), 0, st, use_ws, (int)pl.splits, n, (bf16raw*)p.stats);
+            else hipLaunchKernelGGL(wgrad_reduce_tile_kernel<float>, dim3((unsigned)b), dim3(256), 0, st, use_ws, (int)pl.splits, n, p.stats);
+        } else {
+            long b = (n + 255) / 256; if (b > 2048) b = 2048;
+            if (out_bf16) hipLaunchKernelGGL(wgrad_reduce_kernel<bf16raw>, dim3((unsigned)b), dim3(256), 0, st, use_ws, (int)pl.splits, n, (bf16raw*)p.stats);
+            else hipLaunchKernelGGL(wgrad_reduce_kernel<float>, dim3((unsigned)b), dim3(256), 0, st, use_ws, (int)pl.splits, n, p.stats);
+        }
+    }
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
 struct WgradPlan { long splits; int rpb; };
 
 template <typename T, int TCO, int TCI>
@@ -1729,6 +1930,11 @@ template <typename T>
 int dispatch_wgrad(const mg_conv_params& p, float* ws, long ws_floats, long* need, hipStream_t st) {
     const bool small_co = p.Cout <= 32, small_ci = p.Cin <= 32;
     const long n = (long)p.Cout * p.R * p.S * p.Cin;
+    if (sizeof(T) == 2 && wgrad_halo_eligible(p)) {
+        if (need) { const WgradHaloPlan pl = plan_wgrad_halo(p); *need = (pl.splits > 1 || p.dw_dtype == MG_BF16) ? pl.splits * n : 0; return 0; }
+        const WgradHaloPlan pl = plan_wgrad_halo(p);
+        if (pl.splits == 1 || (ws && ws_floats >= pl.splits * n)) return launch_wgrad_halo(p, ws, ws_floats, st);
+    }
 #define MG_WG(TCO, TCI)                                                                             \
     do {                                                                                            \
         if (need) { WgradPlan pl = plan_wgrad<T, TCO, TCI>(p); *need = (pl.splits > 1 || p.dw_dtype == MG_BF16) ? pl.splits * n : 0; return 0; } \

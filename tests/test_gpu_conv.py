@@ -45,6 +45,7 @@ CASES = [
     (1, 32, 64, 16, 16, 3, 1, 1, 1),
     (1, 96, 192, 5, 33, 3, 1, 1, 1),
     (1, 64, 128, 20, 20, 3, 2, 1, 1),
+    (2, 32, 32, 40, 24, 3, 1, 1, 1),                 # halo-tile weight gradient at one 32 x 32 channel tile, ragged spatial tiles
     (2, 128, 64, 14, 14, 1, 1, 0, 1),
 ]
 
