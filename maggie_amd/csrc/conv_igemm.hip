@@ -794,7 +794,7 @@ __device__ __forceinline__ void igemm_fprop_halo_tile(const mg_conv_params& p, i
     constexpr int WAVES_M = 2, WAVES_N = 2;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, FM = WM / 16, FN = WN / 16;
     constexpr int STAGE = HC::STAGE, L = HC::L, A_BYTES = HC::A_BYTES;
-    static_assert(BN == 64 && (TH == 8 || TH == 4) && 2 * L <= 60, "halo tile configuration");
+    static_assert((BN == 64 || BN == 32) && (TH == 8 || TH == 4) && 2 * L <= 60, "halo tile configuration");
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -873,12 +873,22 @@ __device__ __forceinline__ void igemm_fprop_halo_tile(const mg_conv_params& p, i
     for (int u = 0; u < NS - 1; ++u)
         if (u < nstage) issue_stage(u, u);
     for (int s = 0; s < nstage; ++s) {
-        const int younger = min(NS - 2, nstage - 1 - s);
-        if (NS == 2 || younger == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (s + NS - 1 < nstage) issue_stage(s + NS - 1, (s + NS - 1) % NS);
+        if constexpr (NS == 1) {
+            // one or two 32-channel slabs (the C32 / C64 high-resolution layers): no ring -- a single 48 KiB (BN = 64) stage lets three
+            // workgroups share a CU and overlap each other's load / MFMA / epilogue phases instead
+            if (s > 0) __builtin_amdgcn_s_barrier();
+            issue_stage(s, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        } else {
+            const int younger = min(NS - 2, nstage - 1 - s);
+            if (NS == 2 || younger == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (s + NS - 1 < nstage) issue_stage(s + NS - 1, (s + NS - 1) % NS);
+        }
         const unsigned sb = lds_base + (unsigned)((s % NS) * STAGE);
         u32x4 fa[2][FM], fb[2][FN];
         // taps are software-pipelined: the reads of tap t + 1 are issued before the MFMAs of tap t (fragment row i of the wave sits
@@ -1044,15 +1054,16 @@ __global__ __launch_bounds__(256) void igemm_fprop_halo_kernel(const mg_conv_par
 static inline bool halo_eligible(const mg_conv_params& p) {
     static const int enabled = [] { const char* e = getenv("MG_FPROP_HALO"); return e ? atoi(e) : 1; }();
     if (!enabled || p.dtype != MG_BF16 || p.m_dev || p.mode == MG_MODE_GATHER) return false;
-    // Cin >= 96: with fewer than three 32-channel stages the ring's prologue dominates (C64 128x128: 22.5 us against 20.5 us im2col)
-    if (p.R != 3 || p.S != 3 || p.stride != 1 || p.dil != 1 || p.pad != 1 || p.Cin % 32 != 0 || p.Cin < 96 || p.Cout < 64) return false;
+    // Cin >= 96: three-stage ring over the 32-channel slabs; Cin 32 / 64: single-stage form (halo_small)
+    static const int small = [] { const char* e = getenv("MG_FPROP_HALO_SMALL"); return e ? atoi(e) : 1; }();
+    if (p.R != 3 || p.S != 3 || p.stride != 1 || p.dil != 1 || p.pad != 1 || p.Cin % 32 != 0) return false;
+    if (p.Cin < 96 ? (!small || p.Cout < 32) : p.Cout < 64) return false;
     if (p.Hin != p.Hout || p.Win != p.Wout || p.Wout < 16 || p.Hout < 4) return false;
     return true;
 }
 
-template <int TH>
+template <int TH, int BN = 64, int NS = 3>
 static int launch_fprop_halo(const mg_conv_params& p, hipStream_t st) {
-    constexpr int BN = 64, NS = 3;
     constexpr size_t lds = HaloCfg<TH, BN, NS>::LDS;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1071,6 +1082,10 @@ static int launch_fprop_halo(const mg_conv_params& p, hipStream_t st) {
 static int dispatch_fprop_halo(const mg_conv_params& p, hipStream_t st) {
     // 8 x 16 pixel tiles when they still give about one workgroup per CU (a workgroup holds a whole CU's LDS), else 4 x 16
     static const long want = [] { const char* e = getenv("MG_HALO_BLOCKS"); return e ? atol(e) : 200l; }();
+    if (p.Cin < 96) {
+        if (p.Cout <= 32) return p.Hout >= 8 ? launch_fprop_halo<8, 32, 1>(p, st) : launch_fprop_halo<4, 32, 1>(p, st);
+        return p.Hout >= 8 ? launch_fprop_halo<8, 64, 1>(p, st) : launch_fprop_halo<4, 64, 1>(p, st);
+    }
     const long t8 = (long)p.N * ((p.Hout + 7) / 8) * ((p.Wout + 15) / 16) * ((p.Cout + 63) / 64);
     if (t8 >= want && p.Hout >= 8) return launch_fprop_halo<8>(p, st);
     return launch_fprop_halo<4>(p, st);

@@ -13,7 +13,8 @@ from . import kernels as K
 from .kernels import MODE_CONV, MODE_TCONV, MODE_GATHER, ACT_NONE, ACT_RELU, ACT_LRELU  # noqa: F401
 
 LRELU_SLOPE = 0.2
-EXACT_STATS_ROWS = 32768      # BatchNorm layers with at most this many rows use the exact two-pass variance
+import os as _os
+EXACT_STATS_ROWS = int(_os.environ.get('MAGGIE_EXACT_STATS_ROWS', '32768'))      # BatchNorm layers with at most this many rows use the exact two-pass variance
 
 
 class ZeroArena:

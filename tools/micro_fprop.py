@@ -17,7 +17,7 @@ def bench(fn, it=50):
 
 
 # (N, Cin, Cout, H, k, mode, stride): encoder stages at 512x512 batch 4, decoder, ASPP-like, dgrad (mode 1)
-shapes = [(4, 64, 64, 128, 3, 0, 1), (4, 128, 128, 64, 3, 0, 1), (4, 256, 256, 32, 3, 0, 1), (4, 512, 512, 16, 3, 0, 1), (4, 512, 256, 32, 3, 0, 1),
+shapes = [(4, 32, 32, 512, 3, 0, 1), (4, 32, 32, 512, 3, 1, 1), (4, 32, 32, 256, 3, 0, 1), (4, 32, 64, 128, 3, 0, 1), (4, 64, 64, 128, 3, 0, 1), (4, 128, 128, 64, 3, 0, 1), (4, 256, 256, 32, 3, 0, 1), (4, 512, 512, 16, 3, 0, 1), (4, 512, 256, 32, 3, 0, 1),
           (4, 256, 128, 64, 3, 0, 1), (4, 128, 128, 64, 3, 1, 1), (4, 64, 64, 128, 3, 1, 1), (4, 1280, 512, 16, 1, 0, 1), (4, 128, 64, 64, 1, 0, 1)]
 tot = 0.0
 for (N, Cin, Cout, HW, k, mode, stride) in shapes:
