@@ -48,6 +48,31 @@ __device__ __forceinline__ bool xcd_order(int L, int& v) {
 }
 static inline unsigned xcd_grid(long L) { return (unsigned)(((L + NXCD - 1) / NXCD) * NXCD); }
 
+// Phase decomposition of the stride-2 transposed walk (ConvTranspose k4 s2 p1, and the data gradient of a stride-2 3x3 / 1x1 conv): an
+// output pixel (ho, wo) only meets the filter taps with ky = (ho + pad) mod 2, kx = (wo + pad) mod 2 -- a quarter of them. The rows of the
+// GEMM are therefore ordered phase-major (4 sub-lattices (ho & 1, wo & 1), each [N][Hout/2][Wout/2], padded to whole row tiles) and every
+// tile walks only its phase's taps: executed FLOPs == algorithmic FLOPs instead of 4x (k4) / 4x (k3) / 4x (k1) of them.
+__host__ __device__ __forceinline__ bool tconv_phased(const mg_conv_params& p) {
+    const int eps = p.dtype == MG_BF16 ? 32 : 16;
+    return p.mode == MG_MODE_TCONV && p.stride == 2 && p.dil == 1 && !p.m_dev && p.Cin % eps == 0 && !(p.Hout & 1) && !(p.Wout & 1) &&
+           p.R >= 1 && p.S >= 1;
+}
+__host__ __device__ __forceinline__ long row_tiles(const mg_conv_params& p, int M, int bm) {
+    if (tconv_phased(p)) return 4l * ((M / 4 + bm - 1) / bm);
+    return (M + bm - 1) / bm;
+}
+// phase-major GEMM row -> output pixel row. `pm` = row inside the phase.
+struct PhaseMap {
+    int H2, W2, py, px, Mp;
+    __device__ __forceinline__ PhaseMap(const mg_conv_params& p, int phase) : H2(p.Hout >> 1), W2(p.Wout >> 1), py(phase >> 1), px(phase & 1), Mp(p.N * (p.Hout >> 1) * (p.Wout >> 1)) {}
+    __device__ __forceinline__ void decode(int pm, int& n, int& ho, int& wo) const {
+        n = pm / (H2 * W2);
+        const int rem = pm - n * H2 * W2;
+        const int i = rem / W2;
+        ho = 2 * i + py; wo = 2 * (rem - i * W2) + px;
+    }
+};
+
 // K is walked in STAGES of KS slabs (KS*64 bytes per row). The loads of stage s+1 are issued right after the barrier that
 // publishes stage s and stay in flight under its KS*FM*FN MFMAs; one LDS buffer, two barriers per stage. KS = 4 is used for
 // K-heavy layers (few, fat memory round trips: these GEMMs are small, so exposed load latency -- not bandwidth or MFMA rate --
@@ -75,10 +100,23 @@ __device__ __forceinline__ void igemm_fprop_tile(const mg_conv_params& p, const 
     int sp = 0;
     if constexpr (SPLIT) { sp = work % splits; work /= splits; }
     const int mt = work / ntn;                   // channel tiles of one row tile are consecutive: they share the A rows
-    const int m0 = mt * BM, n0 = (work - mt * ntn) * BN;
+    int m0 = mt * BM;
+    const int n0 = (work - mt * ntn) * BN;
     const int taps = p.R * p.S;
     const int Ktot = taps * p.Cin;
-    const int nslab = (Ktot + EPS - 1) / EPS;
+    int nslab = (Ktot + EPS - 1) / EPS;
+    // phase-major rows + phase tap walk (tconv_phased): this tile belongs to ONE of the four output sub-lattices
+    const bool ph = !SPLIT && MODE == MG_MODE_TCONV && tconv_phased(p);
+    const int tpp = ph ? (M / 4 + BM - 1) / BM : 1;                  // row tiles per phase
+    const PhaseMap pmap(p, ph ? mt / tpp : 0);
+    int ky0 = 0, kx0 = 0, kstep = 1;
+    if (ph) {
+        m0 = (mt - (mt / tpp) * tpp) * BM;                           // row offset inside the phase
+        ky0 = (pmap.py + p.pad) & 1; kx0 = (pmap.px + p.pad) & 1; kstep = 2;
+        const int nky = (p.R - ky0 + 1) >> 1, nkx = (p.S - kx0 + 1) >> 1;
+        nslab = nky * nkx * (p.Cin / EPS);
+    }
+    const int Mrows = ph ? pmap.Mp : M;                              // rows of this tile's row space
     const int nstage_all = (nslab + KS - 1) / KS;
     int s_beg = 0, nstage = nstage_all;          // this block walks stages [s_beg, nstage)
     if constexpr (SPLIT) {
@@ -95,8 +133,10 @@ __device__ __forceinline__ void igemm_fprop_tile(const mg_conv_params& p, const 
 #pragma unroll
     for (int i = 0; i < A_ROWS; ++i) {
         int m = m0 + (t >> 2) + i * 64;
-        rc[i].ok = m < M;
-        if (MODE != MG_MODE_GATHER) {
+        rc[i].ok = m < Mrows;
+        if (ph) {
+            pmap.decode(rc[i].ok ? m : 0, rc[i].n, rc[i].ho, rc[i].wo);
+        } else if (MODE != MG_MODE_GATHER) {
             int hw = p.Hout * p.Wout;
             int mm = rc[i].ok ? m : 0;
             rc[i].n = mm / hw;
@@ -187,7 +227,7 @@ __device__ __forceinline__ void igemm_fprop_tile(const mg_conv_params& p, const 
         bptr[i] = wb + ((long)(n0 + (bok[i] ? co : 0)) * Ktot + c * CE) * (long)sizeof(T);
     }
     const int spt = p.Cin / EPS;             // slabs per tap (aligned path)
-    int q_slab = s_beg * KS, q_sub = 0, q_ky = 0, q_kx = 0, q_tap = 0;
+    int q_slab = s_beg * KS, q_sub = 0, q_ky = ky0, q_kx = kx0, q_tap = 0;
     if (SPLIT && al && !c8) { q_tap = q_slab / spt; q_sub = q_slab - q_tap * spt; q_ky = q_tap / p.S; q_kx = q_tap - q_ky * p.S; }
     auto load_stage_al = [&](int u) {
 #pragma unroll
@@ -218,15 +258,15 @@ __device__ __forceinline__ void igemm_fprop_tile(const mg_conv_params& p, const 
                 if (src >= 0 && rc[i].ok && live) ra[u][j][i] = *(const uint4*)(xb + src * ((long)p.ldx * (long)sizeof(T)) + coff);
                 else ra[u][j][i] = make_uint4(0, 0, 0, 0);
             }
-            const long boff = (long)q_slab * EPS * (long)sizeof(T);
+            const long boff = ph ? ((long)(q_ky * p.S + q_kx) * p.Cin + (long)q_sub * EPS) * (long)sizeof(T) : (long)q_slab * EPS * (long)sizeof(T);
 #pragma unroll
             for (int i = 0; i < B_ITERS; ++i) {
-                const bool blive = q_slab * EPS + ((t + i * 256) & 3) * CE < Ktot;
+                const bool blive = ph ? live : q_slab * EPS + ((t + i * 256) & 3) * CE < Ktot;
                 if (bok[i] && blive) rb[u][j][i] = *(const uint4*)(bptr[i] + boff);
                 else rb[u][j][i] = make_uint4(0, 0, 0, 0);
             }
             ++q_slab;
-            if (++q_sub == spt) { q_sub = 0; ++q_tap; if (++q_kx == p.S) { q_kx = 0; ++q_ky; } }
+            if (++q_sub == spt) { q_sub = 0; ++q_tap; q_kx += kstep; if (q_kx >= p.S) { q_kx = kx0; q_ky += kstep; } }
         }
     };
 
@@ -344,7 +384,8 @@ __device__ __forceinline__ void igemm_fprop_tile(const mg_conv_params& p, const 
         __syncthreads();
         for (int r = rr; r < PR; r += RPP) {
             int m = m0 + ep * PR + r;
-            if (m >= M || cbase >= p.Cout) continue;
+            if (m >= Mrows || cbase >= p.Cout) continue;
+            if (ph) { int n_, ho_, wo_; pmap.decode(m, n_, ho_, wo_); m = (n_ * p.Hout + ho_) * p.Wout + wo_; }
             float v[CE];
 #pragma unroll
             for (int e = 0; e < CE; ++e) v[e] = sC[r * LDC + cc * CE + e];
@@ -431,7 +472,7 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ntn = (p.Cout + BN - 1) / BN;
     int work;
-    if (!xcd_order(((p.M + BM - 1) / BM) * ntn * (SPLIT ? splits : 1), work)) return;
+    if (!xcd_order((int)(SPLIT ? (long)((p.M + BM - 1) / BM) * ntn * splits : row_tiles(p, p.M, BM) * ntn), work)) return;
     igemm_fprop_tile<T, BM, BN, KS, MODE, SPLIT>(p, p.M, work, ws, splits, smem);
 }
 
@@ -1151,7 +1192,7 @@ static int dispatch_fprop_async(const mg_conv_params& p, hipStream_t st) {
 
 template <typename T, int BM, int BN, int KS>
 int launch_fprop(const mg_conv_params& p, hipStream_t st) {
-    dim3 grid(xcd_grid((long)((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN)));
+    dim3 grid(xcd_grid(row_tiles(p, p.M, BM) * ((p.Cout + BN - 1) / BN)));
     constexpr size_t lds = lds_bytes<BM, BN, KS>();
     static bool attr_set = false;
     if (lds > 65536 && !attr_set) {
@@ -1192,7 +1233,7 @@ int dispatch_fprop_ks(const mg_conv_params& p, hipStream_t st) {
     // Largest tile that still yields >= `want` blocks: these GEMMs are small, so exposed load latency is hidden by having
     // several co-resident blocks per CU (256 CUs), not by a deeper per-block pipeline.
     static const long want = [] { const char* e = getenv("MG_FPROP_BLOCKS"); return e ? atol(e) : 768l; }();
-    auto blocks = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn); };
+    auto blocks = [&](int bm, int bn) { return row_tiles(p, p.M, bm) * ((p.Cout + bn - 1) / bn); };
     static const long want_small = [] { const char* e = getenv("MG_FPROP_BLOCKS_SMALL"); return e ? atol(e) : 300l; }();   // below this many 64x64 blocks, 64x32 tiles (C512 16x16: +11 %, C256 32x32: +4 %)
     if (p.Cout > 64) {
         if (blocks(128, 128) >= want) return launch_fprop<T, 128, 128, KS>(p, st);
@@ -1321,6 +1362,7 @@ static SplitPlan plan_splitk(const mg_conv_params& p) {
     static const int enabled = [] { const char* e = getenv("MG_FPROP_SPLITK"); return e ? atoi(e) : 1; }();
     static const long want_small = [] { const char* e = getenv("MG_FPROP_BLOCKS_SMALL"); return e ? atol(e) : 300l; }();
     if (!enabled || p.mode == MG_MODE_GATHER || p.Cout < 64 || p.M > 8192 || p.m_dev) return sp;
+    if (tconv_phased(p)) return sp;              // a quarter of the taps per phase: the K walk is short again
     if (halo_eligible(p)) return sp;             // the halo-tile kernel beats split-K on the deep 3x3 layers (C256 32x32: 30 -> 14 us)
     constexpr int EPS = ElemTraits<T>::EPS;
     const int nslab = (p.R * p.S * p.Cin + EPS - 1) / EPS;
@@ -1372,8 +1414,14 @@ static int launch_fprop_split(const mg_conv_params& p, float* ws, int splits, hi
 template <typename T>
 int dispatch_fprop(const mg_conv_params& p, hipStream_t st) {
     if (sizeof(T) == 2 && halo_eligible(p)) return dispatch_fprop_halo(p, st);
-    if (sizeof(T) == 2 && async_eligible(p)) return dispatch_fprop_async(p, st);
     const int eps = sizeof(T) == 2 ? 32 : 16;
+    if (tconv_phased(p)) {                       // stage width by the longest phase walk (ceil(R/2) * ceil(S/2) taps)
+        const int nsl = ((p.R + 1) / 2) * ((p.S + 1) / 2) * (p.Cin / eps);
+        if (nsl >= 8 && nsl <= 18) return dispatch_fprop_ks<T, 2>(p, st);
+        if (nsl >= 8) return dispatch_fprop_ks<T, 4>(p, st);
+        return dispatch_fprop_ks<T, 1>(p, st);
+    }
+    if (sizeof(T) == 2 && async_eligible(p)) return dispatch_fprop_async(p, st);
     const int nslab = (p.R * p.S * p.Cin + eps - 1) / eps;
     // stage width: 4 slabs (256 B of K per row) for the K-heavy layers, 2 slabs for K <= 576 (C32 / C64 3x3 layers: half the LDS
     // and staging registers -> more co-resident blocks; measured +31 % on the 512x512 C32 layers, +8 % on C64), 1 for tiny K

@@ -82,6 +82,9 @@ def conv_fprop(x, w, *, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=None, Wout=None,
     work = None
     if rows is None:
         work = executed * ((alg_cin or Cin) / Cin) * ((alg_cout or Cout) / Cout) / (stride * stride if mode == MODE_TCONV else 1)
+    if mode == MODE_TCONV and stride == 2 and dil == 1 and rows is None and Cin % (32 if x.dtype == torch.bfloat16 else 16) == 0 \
+            and Hout % 2 == 0 and Wout % 2 == 0:
+        executed /= 4.0                         # phase-decomposed walk (csrc/conv_igemm.hip: tconv_phased): only the taps that exist
     tag = ('bf16' if x.dtype == torch.bfloat16 else 'f32', mode, Cout, R * S * Cin, M, executed, rows is not None)
     if mode != MODE_GATHER and 0 < M <= 8192 and Cout >= 64 and rows is None:
         # deep layers with few rows: the library may split K over several blocks per tile (mg_conv_fprop_ws)

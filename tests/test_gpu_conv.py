@@ -45,7 +45,9 @@ CASES = [
     (1, 32, 64, 16, 16, 3, 1, 1, 1),
     (1, 96, 192, 5, 33, 3, 1, 1, 1),
     (1, 64, 128, 20, 20, 3, 2, 1, 1),
-    (2, 32, 32, 40, 24, 3, 1, 1, 1),                 # halo-tile weight gradient at one 32 x 32 channel tile, ragged spatial tiles
+    (2, 32, 32, 40, 24, 3, 1, 1, 1),
+    (2, 64, 128, 16, 24, 1, 2, 0, 1),                # stride-2 1x1 (downsample): its data gradient is the phase walk with three empty phases
+    (2, 32, 64, 24, 40, 3, 2, 1, 1),                 # stride-2 3x3: phase-decomposed data gradient (1 / 2 / 2 / 4 taps), ragged phase tiles                 # halo-tile weight gradient at one 32 x 32 channel tile, ragged spatial tiles
     (2, 128, 64, 14, 14, 1, 1, 0, 1),
 ]
 
@@ -142,6 +144,34 @@ def test_conv_transpose_k4s2(dtype):
                      stride=2, pad=1)
     y = y.float().cpu().reshape(N, 2 * H, 2 * W, Cout).permute(0, 3, 1, 2)
     assert (y - y_ref).abs().max().item() <= _tol(dtype) * y_ref.abs().max().item()
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_conv_transpose_phased_epilogue(dtype):
+    """The phase-major row order of the stride-2 transposed walk must be invisible to the epilogue: scale / shift, post residual, channel
+    slice of a wider buffer and the BatchNorm statistics, on a geometry whose phases are not whole row tiles (Mp = 480)."""
+    from maggie_amd import kernels as K
+    dev = _dev()
+    N, Cin, Cout, H, W = 2, 64, 64, 12, 20
+    rs = np.random.RandomState(14)
+    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    x = q(torch.from_numpy(rs.normal(size=(N, Cin, H, W)).astype(np.float32)))
+    w = q(torch.from_numpy((rs.normal(size=(Cin, Cout, 4, 4)) / 20).astype(np.float32)))
+    res2 = q(torch.from_numpy(rs.normal(size=(N, Cout, 2 * H, 2 * W)).astype(np.float32)))
+    scale = torch.from_numpy(rs.uniform(0.5, 1.5, Cout).astype(np.float32))
+    shift = torch.from_numpy(rs.normal(size=Cout).astype(np.float32))
+    y_ref = F.relu(F.conv_transpose2d(x, w, None, 2, 1) * scale[None, :, None, None] + shift[None, :, None, None]) + res2
+    wk = w.permute(1, 2, 3, 0).reshape(Cout, 16, Cin).contiguous().to(dev, dtype)
+    stats = torch.zeros((K.STAT_REPLICAS, 2 * Cout), device=dev)
+    big = torch.zeros((N * 4 * H * W, 2 * Cout), device=dev, dtype=dtype)
+    K.conv_fprop(_nhwc(x).to(dev, dtype), wk, mode=K.MODE_TCONV, N=N, Hin=H, Win=W, Hout=2 * H, Wout=2 * W, R=4, S=4, stride=2, pad=1,
+                 scale=scale.to(dev), shift=shift.to(dev), res2=_nhwc(res2).to(dev, dtype), act=K.ACT_RELU, stats=stats, out=big, yoff=Cout)
+    y = big[:, Cout:].float().cpu().reshape(N, 2 * H, 2 * W, Cout).permute(0, 3, 1, 2)
+    assert big[:, :Cout].abs().max().item() == 0
+    assert (y - y_ref).abs().max().item() <= _tol(dtype) * y_ref.abs().max().item()
+    s = stats.sum(0).cpu()
+    assert torch.allclose(s[:Cout], y.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
+    assert torch.allclose(s[Cout:], (y * y).sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
