@@ -15,12 +15,16 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef uint16_t bf16raw;
 
 __device__ __forceinline__ float bf2f(bf16raw v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16raw f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16raw)((u >> 16) | 0x40u);   // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);                                           // round to nearest even
-    return (bf16raw)(u >> 16);
+// fp32 -> bf16, round to nearest even: gfx950 has it in hardware (v_cvt_pk_bf16_f32, two values per instruction). The integer sequence
+// this replaces (NaN test, +0x7fff + lsb, shift: ~8 VALU per value) made the conv epilogues VALU-bound: 13.4 k of the 26 k cycles of a
+// C128 64x64 halo tile were the 32 outputs per thread being rounded twice (tools/halo_timeline.py).
+typedef __attribute__((ext_vector_type(2))) float mg_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 mg_bf16x2;
+__device__ __forceinline__ uint32_t f2bf_pk(float lo, float hi) {
+    const mg_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, mg_bf16x2));
 }
+__device__ __forceinline__ bf16raw f2bf(float f) { return (bf16raw)(f2bf_pk(f, 0.f) & 0xffffu); }
 
 template <typename T> struct ElemTraits;
 template <> struct ElemTraits<float> {
@@ -49,8 +53,7 @@ template <> struct ElemTraits<bf16raw> {
         f[6] = __uint_as_float(q.w << 16); f[7] = __uint_as_float(q.w & 0xffff0000u);
     }
     __device__ static __forceinline__ uint4 pack(const float* f) {
-        return make_uint4((uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16), (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16),
-                          (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16), (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16));
+        return make_uint4(f2bf_pk(f[0], f[1]), f2bf_pk(f[2], f[3]), f2bf_pk(f[4], f[5]), f2bf_pk(f[6], f[7]));
     }
 };
 

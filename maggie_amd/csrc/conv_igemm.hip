@@ -73,6 +73,178 @@ struct PhaseMap {
     }
 };
 
+// =====================================================================================================================
+// Tile epilogue shared by the fprop kernels: accumulators -> fp32 LDS tile -> y = act?(acc) * scale + shift (+ res) -> act? (+ res2),
+// rounded to T, 16-byte global stores; optional BatchNorm statistics (column sums / sums of squares of the ROUNDED values).
+// `rowmap(rt)` maps tile row rt to the output row index (or -1: outside the tensor).
+// Shape of the code (a workgroup usually owns a whole CU, one wave per SIMD, so every instruction is exposed): the residual-free /
+// full-vector case is a separate instantiation without per-element branches; the activation is branch-free
+// (act(x) = max(x, x * slope) covers none (slope 1), ReLU (0) and LeakyReLU); all LDS reads of a pass are issued before the first
+// use; fp32 -> bf16 is the packed hardware conversion. (Before: ~1600 static instructions with ~170 branches, 8-12 k cycles per
+// 128 x 64 tile -- as long as the whole K loop of a C128 3x3 layer, tools/halo_timeline.py.)
+// =====================================================================================================================
+template <typename T, int BM, int BN, int FM, int FN, bool RES, typename RowMap>
+__device__ __forceinline__ void tile_epilogue_impl(const mg_conv_params& p, f32x4 (&acc)[FM][FN], int wm, int wn, int WM, int WN, int n0, int stat_slot,
+                                                   char* smem, const RowMap& rowmap) {
+    using TR = ElemTraits<T>;
+    constexpr int CE = TR::CE;
+    constexpr int EP = ep_passes<BM, BN>();
+    constexpr int PR = BM / EP;
+    constexpr int LDC = BN + 4;
+    constexpr int CPR = BN / CE;
+    constexpr int RPP = 256 / CPR;
+    constexpr int NIT = (PR + RPP - 1) / RPP;
+    static_assert((CPR & (CPR - 1)) == 0 && CPR <= 32, "channel chunks per tile row must be a power of two");
+    float* sC = (float*)smem;                         // [PR][LDC]
+    float* sStat = (float*)(smem + PR * LDC * 4);     // [4 waves][2][BN]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int cc = t % CPR, rr = t / CPR;
+    const int cbase = n0 + cc * CE;
+    const bool col_ok = cbase < p.Cout;
+    const bool full_vec = cbase + CE <= p.Cout;
+    float sc[CE], sh[CE], s1[CE], s2[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { sc[e] = 1.f; sh[e] = 0.f; s1[e] = 0.f; s2[e] = 0.f; }
+    if (full_vec) {                                    // vector loads, in flight under the LDS tile write below
+        if (p.scale) {
+#pragma unroll
+            for (int e = 0; e < CE; e += 4) *(float4*)&sc[e] = *(const float4*)(p.scale + cbase + e);
+        }
+        if (p.shift) {
+#pragma unroll
+            for (int e = 0; e < CE; e += 4) *(float4*)&sh[e] = *(const float4*)(p.shift + cbase + e);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < CE; ++e) {
+            const int c = cbase + e;
+            if (p.scale && c < p.Cout) sc[e] = p.scale[c];
+            if (p.shift && c < p.Cout) sh[e] = p.shift[c];
+        }
+    }
+    // act(x) = max(x, x * slope): none -> 1, ReLU -> 0, LeakyReLU -> slope; applied before or after the affine part
+    const float sl = p.act == MG_ACT_NONE ? 1.f : (p.act == MG_ACT_RELU ? 0.f : p.slope);
+    const float sl_pre = p.pre_act ? sl : 1.f, sl_post = p.pre_act ? 1.f : sl;
+    T* __restrict__ yb = (T*)p.y;
+    const T* __restrict__ r1b = (const T*)p.res;
+    const T* __restrict__ r2b = (const T*)p.res2;
+    const bool stats = p.stats != nullptr;
+#pragma unroll
+    for (int ep = 0; ep < EP; ++ep) {
+        if (ep > 0) __syncthreads();
+        if ((wm * WM) / PR == ep) {
+            const int rb0 = wm * WM - ep * PR;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        sC[(rb0 + i * 16 + lg * 4 + e) * LDC + wn * WN + j * 16 + lr] = acc[i][j][e];
+        }
+        __syncthreads();
+        float v[NIT][CE];
+        long mrow[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int r = rr + k * RPP;
+            mrow[k] = (r < PR && col_ok) ? rowmap(ep * PR + r) : -1l;
+#pragma unroll
+            for (int e = 0; e < CE; e += 4) *(float4*)&v[k][e] = *(const float4*)&sC[(r < PR ? r : 0) * LDC + cc * CE + e];
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const long m = mrow[k];
+            if (m < 0) continue;
+            float rv[CE], rv2[CE];
+            if constexpr (RES) {
+#pragma unroll
+                for (int e = 0; e < CE; ++e) { rv[e] = 0.f; rv2[e] = 0.f; }
+                if (r1b) {
+                    long rrow = m;
+                    if (p.res_mode == 2) {                    // residual lives at half resolution (nearest x2 upsample)
+                        const int hw = p.Hout * p.Wout;
+                        const int n = (int)(m / hw); const int rem = (int)(m - (long)n * hw); const int ho = rem / p.Wout; const int wo = rem - ho * p.Wout;
+                        rrow = ((long)n * (p.Hout >> 1) + (ho >> 1)) * (p.Wout >> 1) + (wo >> 1);
+                    }
+                    if (full_vec) { const uint4 q = *(const uint4*)(r1b + rrow * p.ldr + cbase); TR::unpack(q, rv); }
+                    else {
+#pragma unroll
+                        for (int e = 0; e < CE; ++e) if (cbase + e < p.Cout) rv[e] = TR::ld(r1b + rrow * p.ldr + cbase + e);
+                    }
+                }
+                if (r2b) {
+                    if (full_vec) { const uint4 q = *(const uint4*)(r2b + m * p.ldr2 + cbase); TR::unpack(q, rv2); }
+                    else {
+#pragma unroll
+                        for (int e = 0; e < CE; ++e) if (cbase + e < p.Cout) rv2[e] = TR::ld(r2b + m * p.ldr2 + cbase + e);
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
+                float x = v[k][e];
+                x = fmaxf(x, x * sl_pre);
+                x = x * sc[e] + sh[e];
+                if constexpr (RES) x += rv[e];
+                x = fmaxf(x, x * sl_post);
+                if constexpr (RES) x += rv2[e];
+                v[k][e] = x;
+            }
+            const uint4 packed = TR::pack(v[k]);               // rounded once; the statistics are those of the rounded values
+            if (stats) {
+                TR::unpack(packed, v[k]);
+#pragma unroll
+                for (int e = 0; e < CE; ++e) { s1[e] += v[k][e]; s2[e] += v[k][e] * v[k][e]; }
+            }
+            T* dst = yb + m * p.ldy + p.yoff + cbase;
+            if (full_vec) *(uint4*)dst = packed;
+            else {
+#pragma unroll
+                for (int e = 0; e < CE; ++e) if (cbase + e < p.Cout) TR::st(dst + e, v[k][e]);
+            }
+        }
+    }
+    if (stats) {
+        // lanes t, t+CPR, t+2*CPR, ... of a wave hold the same channel chunk: butterfly over them (CPR is a power of two <= 32),
+        // one LDS row per wave, then one global atomic per channel per block into 1 of 32 replicas. (LDS float atomics here
+        // serialised 64-way on the narrow tiles and doubled the kernel time of the 512x512 layers.)
+#pragma unroll
+        for (int o = CPR; o < 64; o <<= 1) {
+#pragma unroll
+            for (int e = 0; e < CE; ++e) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+        }
+        if (lane < CPR) {
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
+                sStat[wave * 2 * BN + lane * CE + e] = s1[e];
+                sStat[wave * 2 * BN + BN + lane * CE + e] = s2[e];
+            }
+        }
+        __syncthreads();
+        if (t < 2 * BN) {
+            const int c = t < BN ? t : t - BN;
+            if (n0 + c < p.Cout) {
+                const float val = (sStat[t] + sStat[2 * BN + t]) + (sStat[4 * BN + t] + sStat[6 * BN + t]);
+                if (p.stat_mode == 1) {                                       // one row, sums only
+                    if (t < BN) atomicAdd(&p.stats[n0 + c], val);
+                } else {
+                    float* st = p.stats + (size_t)(stat_slot & (MG_STAT_REPLICAS - 1)) * 2 * p.Cout;   // spread same-address atomics
+                    atomicAdd(&st[(t < BN ? 0 : p.Cout) + n0 + c], val);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int FM, int FN, typename RowMap>
+__device__ __forceinline__ void tile_epilogue(const mg_conv_params& p, f32x4 (&acc)[FM][FN], int wm, int wn, int WM, int WN, int n0, int stat_slot,
+                                              char* smem, const RowMap& rowmap) {
+    if (p.res || p.res2) tile_epilogue_impl<T, BM, BN, FM, FN, true>(p, acc, wm, wn, WM, WN, n0, stat_slot, smem, rowmap);
+    else tile_epilogue_impl<T, BM, BN, FM, FN, false>(p, acc, wm, wn, WM, WN, n0, stat_slot, smem, rowmap);
+}
+
 // K is walked in STAGES of KS slabs (KS*64 bytes per row). The loads of stage s+1 are issued right after the barrier that
 // publishes stage s and stay in flight under its KS*FM*FN MFMAs; one LDS buffer, two barriers per stage. KS = 4 is used for
 // K-heavy layers (few, fat memory round trips: these GEMMs are small, so exposed load latency -- not bandwidth or MFMA rate --
@@ -345,124 +517,14 @@ __device__ __forceinline__ void igemm_fprop_tile(const mg_conv_params& p, const 
                 }
         return;
     }
-    // ---------------- epilogue: accumulators -> fp32 LDS tile -> vectorised global stores ----------------
-    // (large tiles run two half-height passes so the fp32 tile stays within the staging buffers' LDS footprint)
-    constexpr int EP = ep_passes<BM, BN>();
-    constexpr int PR = BM / EP;                       // tile rows per pass
-    constexpr int LDC = BN + 4;
-    float* sC = (float*)smem;                         // [PR][LDC]
-    float* sStat = (float*)(smem + PR * LDC * 4);     // [4 waves][2][BN]
-    constexpr int CPR = BN / CE;                      // 16-byte chunks per tile row
-    constexpr int RPP = 256 / CPR;                    // rows per sweep
-    const int cc = t % CPR, rr = t / CPR;
-    const int cbase = n0 + cc * CE;
-    float sc[CE], sh[CE], s1[CE], s2[CE];
-#pragma unroll
-    for (int e = 0; e < CE; ++e) {
-        int c = cbase + e;
-        sc[e] = (p.scale && c < p.Cout) ? p.scale[c] : 1.f;
-        sh[e] = (p.shift && c < p.Cout) ? p.shift[c] : 0.f;
-        s1[e] = 0.f; s2[e] = 0.f;
-    }
-    const bool full_vec = (cbase + CE <= p.Cout);
-    T* __restrict__ yb = (T*)p.y;
-    const T* __restrict__ r1b = (const T*)p.res;
-    const T* __restrict__ r2b = (const T*)p.res2;
-#pragma unroll
-    for (int ep = 0; ep < EP; ++ep) {
-        if (ep > 0) __syncthreads();
-        if ((wm * WM) / PR == ep) {
-            const int rbase = wm * WM - ep * PR;
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        sC[(rbase + i * 16 + lg * 4 + e) * LDC + wn * WN + j * 16 + lr] = acc[i][j][e];
-        }
-        __syncthreads();
-        for (int r = rr; r < PR; r += RPP) {
-            int m = m0 + ep * PR + r;
-            if (m >= Mrows || cbase >= p.Cout) continue;
-            if (ph) { int n_, ho_, wo_; pmap.decode(m, n_, ho_, wo_); m = (n_ * p.Hout + ho_) * p.Wout + wo_; }
-            float v[CE];
-#pragma unroll
-            for (int e = 0; e < CE; ++e) v[e] = sC[r * LDC + cc * CE + e];
-            long rrow = m;
-            if (p.res_mode == 2) {                    // residual lives at half resolution (nearest x2 upsample)
-                int hw = p.Hout * p.Wout;
-                int n = m / hw; int rem = m - n * hw; int ho = rem / p.Wout; int wo = rem - ho * p.Wout;
-                rrow = ((long)n * (p.Hout >> 1) + (ho >> 1)) * (p.Wout >> 1) + (wo >> 1);
-            }
-            float rv[CE], rv2[CE];
-#pragma unroll
-            for (int e = 0; e < CE; ++e) { rv[e] = 0.f; rv2[e] = 0.f; }
-            if (r1b) {
-                if (full_vec) { uint4 q = *(const uint4*)(r1b + rrow * p.ldr + cbase); TR::unpack(q, rv); }
-                else {
-#pragma unroll
-                    for (int e = 0; e < CE; ++e) if (cbase + e < p.Cout) rv[e] = TR::ld(r1b + rrow * p.ldr + cbase + e);
-                }
-            }
-            if (r2b) {
-                if (full_vec) { uint4 q = *(const uint4*)(r2b + (long)m * p.ldr2 + cbase); TR::unpack(q, rv2); }
-                else {
-#pragma unroll
-                    for (int e = 0; e < CE; ++e) if (cbase + e < p.Cout) rv2[e] = TR::ld(r2b + (long)m * p.ldr2 + cbase + e);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < CE; ++e) {
-                float x = v[e];
-                if (p.pre_act) x = apply_act(x, p.act, p.slope);
-                x = x * sc[e] + sh[e];
-                x += rv[e];
-                if (!p.pre_act) x = apply_act(x, p.act, p.slope);
-                x += rv2[e];
-                x = TR::rnd(x);
-                v[e] = x;
-                s1[e] += x; s2[e] += x * x;
-            }
-            T* dst = yb + (long)m * p.ldy + p.yoff + cbase;
-            if (full_vec) *(uint4*)dst = TR::pack(v);
-            else {
-#pragma unroll
-                for (int e = 0; e < CE; ++e) if (cbase + e < p.Cout) TR::st(dst + e, v[e]);
-            }
-        }
-    }
-    if (p.stats) {
-        // lanes t, t+CPR, t+2*CPR, ... of a wave hold the same channel chunk: butterfly over them (CPR is a power of two <= 32),
-        // one LDS row per wave, then one global atomic per channel per block into 1 of 32 replicas. (LDS float atomics here
-        // serialised 64-way on the narrow tiles and doubled the kernel time of the 512x512 layers.)
-        static_assert((CPR & (CPR - 1)) == 0 && CPR <= 32, "channel chunks per tile row must be a power of two");
-#pragma unroll
-        for (int o = CPR; o < 64; o <<= 1) {
-#pragma unroll
-            for (int e = 0; e < CE; ++e) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
-        }
-        if (lane < CPR) {
-#pragma unroll
-            for (int e = 0; e < CE; ++e) {
-                sStat[wave * 2 * BN + lane * CE + e] = s1[e];
-                sStat[wave * 2 * BN + BN + lane * CE + e] = s2[e];
-            }
-        }
-        __syncthreads();
-        if (t < 2 * BN) {
-            const int c = t < BN ? t : t - BN;
-            if (n0 + c < p.Cout) {
-                const float v = (sStat[t] + sStat[2 * BN + t]) + (sStat[4 * BN + t] + sStat[6 * BN + t]);
-                if (p.stat_mode == 1) {                                       // one row, sums only
-                    if (t < BN) atomicAdd(&p.stats[n0 + c], v);
-                } else {
-                    float* st = p.stats + (size_t)(mt & (MG_STAT_REPLICAS - 1)) * 2 * p.Cout;   // spread same-address atomics
-                    atomicAdd(&st[(t < BN ? 0 : p.Cout) + n0 + c], v);
-                }
-            }
-        }
-    }
+    // ---------------- epilogue (tile_epilogue): accumulators -> fp32 LDS tile -> vectorised global stores ----------------
+    auto rowmap = [&](int rt) -> long {
+        int m = m0 + rt;
+        if (m >= Mrows) return -1l;
+        if (ph) { int n_, ho_, wo_; pmap.decode(m, n_, ho_, wo_); m = (n_ * p.Hout + ho_) * p.Wout + wo_; }
+        return (long)m;
+    };
+    tile_epilogue<T, BM, BN, FM, FN>(p, acc, wm, wn, WM, WN, n0, mt, smem, rowmap);
 }
 
 
@@ -668,119 +730,9 @@ __device__ __forceinline__ void igemm_fprop_async_tile(const mg_conv_params& p, 
     }
     __syncthreads();                                         // all fragment reads done before the epilogue reuses the buffers
 
-    // ---------------- epilogue (identical arithmetic to igemm_fprop_tile) ----------------
-    constexpr int EP = ep_passes<BM, BN>();
-    constexpr int PR = BM / EP;
-    constexpr int LDC = BN + 4;
-    float* sC = (float*)smem;
-    float* sStat = (float*)(smem + PR * LDC * 4);
-    constexpr int CPR = BN / CE;
-    constexpr int RPP = 256 / CPR;
-    const int cc = t % CPR, rr = t / CPR;
-    const int cbase = n0 + cc * CE;
-    float sc[CE], sh[CE], s1[CE], s2[CE];
-#pragma unroll
-    for (int e = 0; e < CE; ++e) {
-        int c = cbase + e;
-        sc[e] = (p.scale && c < p.Cout) ? p.scale[c] : 1.f;
-        sh[e] = (p.shift && c < p.Cout) ? p.shift[c] : 0.f;
-        s1[e] = 0.f; s2[e] = 0.f;
-    }
-    const bool full_vec = (cbase + CE <= p.Cout);
-    T* __restrict__ yb = (T*)p.y;
-    const T* __restrict__ r1b = (const T*)p.res;
-    const T* __restrict__ r2b = (const T*)p.res2;
-#pragma unroll
-    for (int ep = 0; ep < EP; ++ep) {
-        if (ep > 0) __syncthreads();
-        if ((wm * WM) / PR == ep) {
-            const int rb0 = wm * WM - ep * PR;
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        sC[(rb0 + i * 16 + lg * 4 + e) * LDC + wn * WN + j * 16 + lr] = acc[i][j][e];
-        }
-        __syncthreads();
-        for (int r = rr; r < PR; r += RPP) {
-            int m = m0 + ep * PR + r;
-            if (m >= M || cbase >= p.Cout) continue;
-            float v[CE];
-#pragma unroll
-            for (int e = 0; e < CE; ++e) v[e] = sC[r * LDC + cc * CE + e];
-            long rrow = m;
-            if (p.res_mode == 2) {
-                int hw = p.Hout * p.Wout;
-                int n = m / hw; int rem = m - n * hw; int ho = rem / p.Wout; int wo = rem - ho * p.Wout;
-                rrow = ((long)n * (p.Hout >> 1) + (ho >> 1)) * (p.Wout >> 1) + (wo >> 1);
-            }
-            float rv[CE], rv2[CE];
-#pragma unroll
-            for (int e = 0; e < CE; ++e) { rv[e] = 0.f; rv2[e] = 0.f; }
-            if (r1b) {
-                if (full_vec) { uint4 q = *(const uint4*)(r1b + rrow * p.ldr + cbase); TR::unpack(q, rv); }
-                else {
-#pragma unroll
-                    for (int e = 0; e < CE; ++e) if (cbase + e < p.Cout) rv[e] = TR::ld(r1b + rrow * p.ldr + cbase + e);
-                }
-            }
-            if (r2b) {
-                if (full_vec) { uint4 q = *(const uint4*)(r2b + (long)m * p.ldr2 + cbase); TR::unpack(q, rv2); }
-                else {
-#pragma unroll
-                    for (int e = 0; e < CE; ++e) if (cbase + e < p.Cout) rv2[e] = TR::ld(r2b + (long)m * p.ldr2 + cbase + e);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < CE; ++e) {
-                float x = v[e];
-                if (p.pre_act) x = apply_act(x, p.act, p.slope);
-                x = x * sc[e] + sh[e];
-                x += rv[e];
-                if (!p.pre_act) x = apply_act(x, p.act, p.slope);
-                x += rv2[e];
-                x = TR::rnd(x);
-                v[e] = x;
-                s1[e] += x; s2[e] += x * x;
-            }
-            T* dst = yb + (long)m * p.ldy + p.yoff + cbase;
-            if (full_vec) *(uint4*)dst = TR::pack(v);
-            else {
-#pragma unroll
-                for (int e = 0; e < CE; ++e) if (cbase + e < p.Cout) TR::st(dst + e, v[e]);
-            }
-        }
-    }
-    if (p.stats) {
-        static_assert((CPR & (CPR - 1)) == 0 && CPR <= 32, "channel chunks per tile row must be a power of two");
-#pragma unroll
-        for (int o = CPR; o < 64; o <<= 1) {
-#pragma unroll
-            for (int e = 0; e < CE; ++e) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
-        }
-        if (lane < CPR) {
-#pragma unroll
-            for (int e = 0; e < CE; ++e) {
-                sStat[wave * 2 * BN + lane * CE + e] = s1[e];
-                sStat[wave * 2 * BN + BN + lane * CE + e] = s2[e];
-            }
-        }
-        __syncthreads();
-        if (t < 2 * BN) {
-            const int c = t < BN ? t : t - BN;
-            if (n0 + c < p.Cout) {
-                const float v = (sStat[t] + sStat[2 * BN + t]) + (sStat[4 * BN + t] + sStat[6 * BN + t]);
-                if (p.stat_mode == 1) {
-                    if (t < BN) atomicAdd(&p.stats[n0 + c], v);
-                } else {
-                    float* st = p.stats + (size_t)(mt & (MG_STAT_REPLICAS - 1)) * 2 * p.Cout;
-                    atomicAdd(&st[(t < BN ? 0 : p.Cout) + n0 + c], v);
-                }
-            }
-        }
-    }
+    // ---------------- epilogue (tile_epilogue, shared with igemm_fprop_tile) ----------------
+    auto rowmap = [&](int rt) -> long { const int m = m0 + rt; return m < M ? (long)m : -1l; };
+    tile_epilogue<T, BM, BN, FM, FN>(p, acc, wm, wn, WM, WN, n0, mt, smem, rowmap);
 }
 
 template <int BM, int BN, int KS, int NS, int MODE>
@@ -825,6 +777,14 @@ template <int TH, int BN, int NS> struct HaloCfg {
     static constexpr int STAGE = A_BYTES + B_BYTES, L = A_PER_WAVE + B_PER_WAVE;
     static constexpr int LDS = NS * STAGE > ctile_bytes<BM, BN>() ? NS * STAGE : ctile_bytes<BM, BN>();
 };
+
+#ifdef MG_HALO_TIMING
+__device__ long long mg_dbg[32 * 24];
+#define MG_STAMP(i) do { if ((threadIdx.x & 63) == 0 && (work & 63) == 0 && work / 64 < 32 && (threadIdx.x >> 6) == 0) mg_dbg[(work / 64) * 24 + (i)] = clock64(); } while (0)
+extern "C" int mg_debug_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mg_dbg), sizeof(mg_dbg)); }
+#else
+#define MG_STAMP(i)
+#endif
 
 template <int TH, int BN, int NS, int MODE>
 __device__ __forceinline__ void igemm_fprop_halo_tile(const mg_conv_params& p, int work, char* smem) {
@@ -910,10 +870,13 @@ __device__ __forceinline__ void igemm_fprop_halo_tile(const mg_conv_params& p, i
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    MG_STAMP(0);
 #pragma unroll
     for (int u = 0; u < NS - 1; ++u)
         if (u < nstage) issue_stage(u, u);
+    MG_STAMP(1);
     for (int s = 0; s < nstage; ++s) {
+        if (s < 6) MG_STAMP(2 + 2 * s);
         if constexpr (NS == 1) {
             // one or two 32-channel slabs (the C32 / C64 high-resolution layers): no ring -- a single 48 KiB (BN = 64) stage lets three
             // workgroups share a CU and overlap each other's load / MFMA / epilogue phases instead
@@ -930,6 +893,7 @@ __device__ __forceinline__ void igemm_fprop_halo_tile(const mg_conv_params& p, i
             asm volatile("" ::: "memory");
             if (s + NS - 1 < nstage) issue_stage(s + NS - 1, (s + NS - 1) % NS);
         }
+        if (s < 6) MG_STAMP(3 + 2 * s);
         const unsigned sb = lds_base + (unsigned)((s % NS) * STAGE);
         u32x4 fa[2][FM], fb[2][FN];
         // taps are software-pipelined: the reads of tap t + 1 are issued before the MFMAs of tap t (fragment row i of the wave sits
@@ -969,118 +933,16 @@ __device__ __forceinline__ void igemm_fprop_halo_tile(const mg_conv_params& p, i
         __builtin_amdgcn_sched_barrier(0);
         mma_tap(I0{});
     }
+    MG_STAMP(14);
     __syncthreads();
 
-    // ---------------- epilogue: same arithmetic as the im2col tiles; row r of the tile = pixel (y0 + r / 16, x0 + r % 16) ----------------
-    constexpr int EP = ep_passes<BM, BN>();
-    constexpr int PR = BM / EP;
-    constexpr int LDC = BN + 4;
-    float* sC = (float*)smem;
-    float* sStat = (float*)(smem + PR * LDC * 4);
-    constexpr int CPR = BN / CE;
-    constexpr int RPP = 256 / CPR;
-    const int cc = t % CPR, rr = t / CPR;
-    const int cbase = n0 + cc * CE;
-    float sc[CE], sh[CE], s1[CE], s2[CE];
-#pragma unroll
-    for (int e = 0; e < CE; ++e) {
-        int c = cbase + e;
-        sc[e] = (p.scale && c < p.Cout) ? p.scale[c] : 1.f;
-        sh[e] = (p.shift && c < p.Cout) ? p.shift[c] : 0.f;
-        s1[e] = 0.f; s2[e] = 0.f;
-    }
-    const bool full_vec = (cbase + CE <= p.Cout);
-    T* __restrict__ yb = (T*)p.y;
-    const T* __restrict__ r1b = (const T*)p.res;
-    const T* __restrict__ r2b = (const T*)p.res2;
-#pragma unroll
-    for (int ep = 0; ep < EP; ++ep) {
-        if (ep > 0) __syncthreads();
-        if ((wm * WM) / PR == ep) {
-            const int rb0 = wm * WM - ep * PR;
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        sC[(rb0 + i * 16 + lg * 4 + e) * LDC + wn * WN + j * 16 + lr] = acc[i][j][e];
-        }
-        __syncthreads();
-        for (int r = rr; r < PR; r += RPP) {
-            const int rt = ep * PR + r;
-            const int y = y0 + rt / TW, x = x0 + (rt % TW);
-            if (y >= H || x >= W || cbase >= p.Cout) continue;
-            const long m = ((long)img * H + y) * W + x;
-            float v[CE];
-#pragma unroll
-            for (int e = 0; e < CE; ++e) v[e] = sC[r * LDC + cc * CE + e];
-            long rrow = m;
-            if (p.res_mode == 2) rrow = ((long)img * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1);
-            float rv[CE], rv2[CE];
-#pragma unroll
-            for (int e = 0; e < CE; ++e) { rv[e] = 0.f; rv2[e] = 0.f; }
-            if (r1b) {
-                if (full_vec) { uint4 q = *(const uint4*)(r1b + rrow * p.ldr + cbase); TR::unpack(q, rv); }
-                else {
-#pragma unroll
-                    for (int e = 0; e < CE; ++e) if (cbase + e < p.Cout) rv[e] = TR::ld(r1b + rrow * p.ldr + cbase + e);
-                }
-            }
-            if (r2b) {
-                if (full_vec) { uint4 q = *(const uint4*)(r2b + m * p.ldr2 + cbase); TR::unpack(q, rv2); }
-                else {
-#pragma unroll
-                    for (int e = 0; e < CE; ++e) if (cbase + e < p.Cout) rv2[e] = TR::ld(r2b + m * p.ldr2 + cbase + e);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < CE; ++e) {
-                float xv = v[e];
-                if (p.pre_act) xv = apply_act(xv, p.act, p.slope);
-                xv = xv * sc[e] + sh[e];
-                xv += rv[e];
-                if (!p.pre_act) xv = apply_act(xv, p.act, p.slope);
-                xv += rv2[e];
-                xv = TR::rnd(xv);
-                v[e] = xv;
-                s1[e] += xv; s2[e] += xv * xv;
-            }
-            T* dst = yb + m * p.ldy + p.yoff + cbase;
-            if (full_vec) *(uint4*)dst = TR::pack(v);
-            else {
-#pragma unroll
-                for (int e = 0; e < CE; ++e) if (cbase + e < p.Cout) TR::st(dst + e, v[e]);
-            }
-        }
-    }
-    if (p.stats) {
-#pragma unroll
-        for (int o = CPR; o < 64; o <<= 1) {
-#pragma unroll
-            for (int e = 0; e < CE; ++e) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
-        }
-        if (lane < CPR) {
-#pragma unroll
-            for (int e = 0; e < CE; ++e) {
-                sStat[wave * 2 * BN + lane * CE + e] = s1[e];
-                sStat[wave * 2 * BN + BN + lane * CE + e] = s2[e];
-            }
-        }
-        __syncthreads();
-        if (t < 2 * BN) {
-            const int c = t < BN ? t : t - BN;
-            if (n0 + c < p.Cout) {
-                const float v = (sStat[t] + sStat[2 * BN + t]) + (sStat[4 * BN + t] + sStat[6 * BN + t]);
-                if (p.stat_mode == 1) {
-                    if (t < BN) atomicAdd(&p.stats[n0 + c], v);
-                } else {
-                    float* st = p.stats + (size_t)(mt & (MG_STAT_REPLICAS - 1)) * 2 * p.Cout;
-                    atomicAdd(&st[(t < BN ? 0 : p.Cout) + n0 + c], v);
-                }
-            }
-        }
-    }
+    // ---------------- epilogue (tile_epilogue): row r of the tile = pixel (y0 + r / 16, x0 + r % 16) ----------------
+    auto rowmap = [&](int rt) -> long {
+        const int y = y0 + rt / TW, x = x0 + (rt % TW);
+        return (y < H && x < W) ? ((long)img * H + y) * W + x : -1l;
+    };
+    tile_epilogue<T, BM, BN, FM, FN>(p, acc, wm, wn, WM, WN, n0, mt, smem, rowmap);
+    MG_STAMP(15);
 }
 
 template <int TH, int BN, int NS, int MODE>
@@ -1321,12 +1183,16 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const mg_conv_params
                 x += rv[e];
                 if (!p.pre_act) x = apply_act(x, p.act, p.slope);
                 x += rv2[e];
-                x = TR::rnd(x);
                 v[e] = x;
-                s1[e] += x; s2[e] += x * x;
+            }
+            const uint4 packed = TR::pack(v);                  // rounded once; the statistics are those of the rounded values
+            if (p.stats) {
+                TR::unpack(packed, v);
+#pragma unroll
+                for (int e = 0; e < CE; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
             }
             T* dst = yb + (long)m * p.ldy + p.yoff + cbase;
-            if (full_vec) *(uint4*)dst = TR::pack(v);
+            if (full_vec) *(uint4*)dst = packed;
             else {
 #pragma unroll
                 for (int e = 0; e < CE; ++e) if (cbase + e < p.Cout) TR::st(dst + e, v[e]);
