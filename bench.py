@@ -420,7 +420,7 @@ def run_cpu_baseline(kind, args):
     b = 1 if kind == 'video' else args.batch
     size = args.size
     mcfg = copy.deepcopy(config.MODEL_VIDEO if kind == 'video' else config.MODEL_IMAGE)
-    n_warm, n_timed = (2, 5) if args.cpu_baseline_full else (1, 3)
+    n_warm, n_timed = (2, 9) if args.cpu_baseline_full else (2, 5)
     res = {'unit': 'instance-frames/s', 'cores': threads, 'host_cores': cores, 'kind': 'port'}
     inst = b * n_f * args.instances
 

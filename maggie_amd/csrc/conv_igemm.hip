@@ -48,6 +48,14 @@ __device__ __forceinline__ bool xcd_order(int L, int& v) {
 }
 static inline unsigned xcd_grid(long L) { return (unsigned)(((L + NXCD - 1) / NXCD) * NXCD); }
 
+#ifdef MG_HALO_TIMING
+__device__ long long mg_dbg[32 * 24];
+#define MG_STAMP(i) do { if ((threadIdx.x & 63) == 0 && (work & 63) == 0 && work / 64 < 32 && work >= 0 && (threadIdx.x >> 6) == 0) mg_dbg[(work / 64) * 24 + (i)] = clock64(); } while (0)
+extern "C" int mg_debug_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mg_dbg), sizeof(mg_dbg)); }
+#else
+#define MG_STAMP(i)
+#endif
+
 // Phase decomposition of the stride-2 transposed walk (ConvTranspose k4 s2 p1, and the data gradient of a stride-2 3x3 / 1x1 conv): an
 // output pixel (ho, wo) only meets the filter taps with ky = (ho + pad) mod 2, kx = (wo + pad) mod 2 -- a quarter of them. The rows of the
 // GEMM are therefore ordered phase-major (4 sub-lattices (ho & 1, wo & 1), each [N][Hout/2][Wout/2], padded to whole row tiles) and every
@@ -778,13 +786,6 @@ template <int TH, int BN, int NS> struct HaloCfg {
     static constexpr int LDS = NS * STAGE > ctile_bytes<BM, BN>() ? NS * STAGE : ctile_bytes<BM, BN>();
 };
 
-#ifdef MG_HALO_TIMING
-__device__ long long mg_dbg[32 * 24];
-#define MG_STAMP(i) do { if ((threadIdx.x & 63) == 0 && (work & 63) == 0 && work / 64 < 32 && (threadIdx.x >> 6) == 0) mg_dbg[(work / 64) * 24 + (i)] = clock64(); } while (0)
-extern "C" int mg_debug_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mg_dbg), sizeof(mg_dbg)); }
-#else
-#define MG_STAMP(i)
-#endif
 
 template <int TH, int BN, int NS, int MODE>
 __device__ __forceinline__ void igemm_fprop_halo_tile(const mg_conv_params& p, int work, char* smem) {
@@ -1637,29 +1638,40 @@ __global__ __launch_bounds__(256) void igemm_wgrad_halo_kernel(const mg_conv_par
     const bf16raw* __restrict__ yb = (const bf16raw*)p.y;
     const bf16raw* __restrict__ xb = (const bf16raw*)p.x;
 
+    // what this thread stages per spatial tile: ITY chunks of dY, ITX chunks of the x halo. The position of a chunk inside the tile is the
+    // same for every tile, so its (row, column, element offset) are computed once; per tile only the origin and two bound checks remain.
+    int y_ty[ITY], y_tx[ITY], y_off[ITY], x_hy[ITX], x_hx[ITX], x_off[ITX];
+#pragma unroll
+    for (int i = 0; i < ITY; ++i) {
+        const int idx = t + i * 256;
+        const int px = idx / CPY, c = idx - px * CPY;
+        y_ty[i] = idx < NY ? px / TW : (1 << 20); y_tx[i] = px % TW;
+        y_off[i] = idx < NY ? (y_ty[i] * p.Wout + y_tx[i]) * p.ldy + c * 8 : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < ITX; ++i) {
+        const int idx = t + i * 256;
+        const int px = idx / CPX, c = idx - px * CPX;
+        x_hy[i] = idx < NX ? px / HW_ - 1 : (1 << 20); x_hx[i] = px % HW_ - 1;
+        x_off[i] = idx < NX ? (x_hy[i] * p.Win + x_hx[i]) * p.ldx + c * 8 : 0;
+    }
     uint4 ry[ITY], rx[ITX];
     auto load_tile = [&](int s) {
         const int n = s / (tiles_y * tiles_x);
         const int r = s - n * tiles_y * tiles_x;
         const int y0 = (r / tiles_x) * TH, x0 = (r % tiles_x) * TW;
+        const bf16raw* ybase = yb + ((long)(n * p.Hout + y0) * p.Wout + x0) * p.ldy + p.yoff + co0;
+        const bf16raw* xbase = xb + ((long)(n * p.Hin + y0) * p.Win + x0) * p.ldx + ci0;
 #pragma unroll
         for (int i = 0; i < ITY; ++i) {
-            const int idx = t + i * 256;
-            const int px = idx / CPY, c = idx - px * CPY;
-            const int oy = y0 + px / TW, ox = x0 + px % TW;
             uint4 q = make_uint4(0, 0, 0, 0);
-            if (idx < NY && oy < p.Hout && ox < p.Wout)
-                q = *(const uint4*)(yb + ((long)(n * p.Hout + oy) * p.Wout + ox) * p.ldy + p.yoff + co0 + c * 8);
+            if (y0 + y_ty[i] < p.Hout && x0 + y_tx[i] < p.Wout) q = *(const uint4*)(ybase + y_off[i]);
             ry[i] = q;
         }
 #pragma unroll
         for (int i = 0; i < ITX; ++i) {
-            const int idx = t + i * 256;
-            const int px = idx / CPX, c = idx - px * CPX;
-            const int iy = y0 - 1 + px / HW_, ix = x0 - 1 + px % HW_;
             uint4 q = make_uint4(0, 0, 0, 0);
-            if (idx < NX && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win)
-                q = *(const uint4*)(xb + ((long)(n * p.Hin + iy) * p.Win + ix) * p.ldx + ci0 + c * 8);
+            if ((unsigned)(y0 + x_hy[i]) < (unsigned)p.Hin && (unsigned)(x0 + x_hx[i]) < (unsigned)p.Win) q = *(const uint4*)(xbase + x_off[i]);
             rx[i] = q;
         }
     };
@@ -1687,10 +1699,14 @@ __global__ __launch_bounds__(256) void igemm_wgrad_halo_kernel(const mg_conv_par
             for (int j = 0; j < FN; ++j) acc[tp][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int q = g * 4 + (li >> 2), cq = (li & 3) * 4;          // this lane's pixel column inside a 16-px tile row, and its 4-channel group
+    MG_STAMP(0);
     if (s_beg < s_end) load_tile(s_beg);
+    MG_STAMP(1);
     for (int s = s_beg; s < s_end; ++s) {
+        if (s - s_beg < 6) MG_STAMP(2 + 2 * (s - s_beg));
         store_tile();
         __syncthreads();
+        if (s - s_beg < 6) MG_STAMP(3 + 2 * (s - s_beg));
         if (s + 1 < s_end) load_tile(s + 1);
 #pragma unroll
         for (int kc = 0; kc < TH / 2; ++kc) {                    // 32 pixels (two tile rows) per MFMA K step
@@ -1722,6 +1738,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_halo_kernel(const mg_conv_par
         }
         __syncthreads();
     }
+    MG_STAMP(14);
     float* __restrict__ slab = ws + (long)split * p.Cout * 9 * p.Cin;
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp)
@@ -1732,6 +1749,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_halo_kernel(const mg_conv_par
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     slab[((long)(co0 + wco + i * 16 + g * 4 + e) * 9 + tp) * p.Cin + ci0 + wci + j * 16 + li] = acc[tp][i][j][e];
+    MG_STAMP(15);
 }
 
 static inline bool wgrad_halo_eligible(const mg_conv_params& p) {

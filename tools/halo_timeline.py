@@ -7,11 +7,16 @@ from maggie_amd import hip
 hip.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_dbg', 'libmaggie_dbg.so')
 from maggie_amd import kernels as K
 N, Cin, Cout, HW = map(int, sys.argv[1:5])
+wgrad = len(sys.argv) > 5 and sys.argv[5] == 'wgrad' 
 dev = torch.device('cuda:0')
 x = torch.randn(N * HW * HW, Cin, device=dev).bfloat16()
 w = torch.randn(Cout, 9, Cin, device=dev).bfloat16()
+gy = torch.randn(N * HW * HW, Cout, device=dev).bfloat16()
 for _ in range(5):
-    K.conv_fprop(x, w, mode=K.MODE_CONV, N=N, Hin=HW, Win=HW, R=3, S=3, stride=1, pad=1, dil=1)
+    if wgrad:
+        K.conv_wgrad(x, gy, cout=Cout, mode=K.MODE_CONV, N=N, Hin=HW, Win=HW, Hout=HW, Wout=HW, R=3, S=3, stride=1, pad=1, dil=1)
+    else:
+        K.conv_fprop(x, w, mode=K.MODE_CONV, N=N, Hin=HW, Win=HW, R=3, S=3, stride=1, pad=1, dil=1)
 torch.cuda.synchronize()
 buf = (ctypes.c_longlong * 768)()
 assert hip.lib().mg_debug_read(buf) == 0
