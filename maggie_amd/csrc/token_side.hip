@@ -97,54 +97,50 @@ __global__ __launch_bounds__(NT) void token_linear_fwd_kernel(const float* __res
 
 // Backward, kernel A (row-parallel, RB rows per workgroup): dz = gradient at the pre-LayerNorm point (= dres), ReLU mask, and
 // dx[r][k] = sum_n dz[r][n] W[n][k] with W staged row-major in LDS (thread per input column k: conflict-free).
-__global__ __launch_bounds__(NT) void token_linear_bwd_rows_kernel(const float* __restrict__ dy, const float* __restrict__ W, const float* __restrict__ yout,
-                                                                   int relu, const float* __restrict__ gamma, const float* __restrict__ z,
-                                                                   const float* __restrict__ rstat, float* __restrict__ dx, float* __restrict__ dz_out,
-                                                                   float* __restrict__ dres, int R, int K, int N) {
-    extern __shared__ float sm[];
+__global__ __launch_bounds__(NT) void token_linear_dz_kernel(const float* __restrict__ dy, const float* __restrict__ yout, int relu,
+                                                            const float* __restrict__ gamma, const float* __restrict__ z, const float* __restrict__ rstat,
+                                                            float* __restrict__ dz_out, float* __restrict__ dres, int R, int N) {
+    // one wave per row: LayerNorm backward (two row reductions), residual gradient, ReLU mask -> dz
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= R) return;
+    const size_t ro = (size_t)r * N;
+    float s1 = 0.f, s2 = 0.f, mean = 0.f, rstd = 1.f;
+    if (gamma) {
+        mean = rstat[2 * r]; rstd = rstat[2 * r + 1];
+        for (int n = lane; n < N; n += 64) {
+            const float gg = dy[ro + n] * gamma[n], xh = (z[ro + n] - mean) * rstd;
+            s1 += gg; s2 += gg * xh;
+        }
+        s1 = wave_sum(s1) / (float)N; s2 = wave_sum(s2) / (float)N;
+    }
+    for (int n = lane; n < N; n += 64) {
+        float g = dy[ro + n];
+        if (gamma) { const float xh = (z[ro + n] - mean) * rstd; g = rstd * (g * gamma[n] - s1 - xh * s2); }
+        if (dres) dres[ro + n] = g;                                   // the residual enters after the activation
+        if (relu && !(yout[ro + n] > 0.f)) g = 0.f;
+        dz_out[ro + n] = g;
+    }
+}
+
+// dx[r][k] = sum_n dz[r][n] W[n][k]: RB rows per workgroup, W staged once in LDS (the row-parallel half of the main backward launch)
+__device__ __forceinline__ void token_linear_bwd_rows(float* sm, int rblock, const float* __restrict__ dz, const float* __restrict__ W,
+                                                      float* __restrict__ dx, int R, int K, int N) {
     float* sdz = sm;                     // [RB][N]
     float* sw = sm + RB * N;             // [N][K]
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int r0 = blockIdx.x * RB;
+    const int t = threadIdx.x;
+    const int r0 = rblock * RB;
     const int nr = min(RB, R - r0);
-    if (dx) {
-        const int total4 = N * K / 4;
-        for (int base = t; base < total4; base += NT * 8) {
-            float4 v[8];
+    const int total4 = N * K / 4;
+    for (int base = t; base < total4; base += NT * 8) {
+        float4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int i4 = base + u * NT; if (i4 < total4) v[u] = ((const float4*)W)[i4]; }
+        for (int u = 0; u < 8; ++u) { const int i4 = base + u * NT; if (i4 < total4) v[u] = ((const float4*)W)[i4]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int i4 = base + u * NT; if (i4 < total4) ((float4*)sw)[i4] = v[u]; }
-        }
+        for (int u = 0; u < 8; ++u) { const int i4 = base + u * NT; if (i4 < total4) ((float4*)sw)[i4] = v[u]; }
     }
-    for (int rl = wave; rl < RB; rl += 4) {
-        if (rl >= nr) { for (int n = lane; n < N; n += 64) sdz[rl * N + n] = 0.f; continue; }
-        const size_t ro = (size_t)(r0 + rl) * N;
-        if (gamma) {
-            const float mean = rstat[2 * (r0 + rl)], rstd = rstat[2 * (r0 + rl) + 1];
-            float s1 = 0.f, s2 = 0.f;
-            for (int n = lane; n < N; n += 64) {
-                const float gg = dy[ro + n] * gamma[n], xh = (z[ro + n] - mean) * rstd;
-                s1 += gg; s2 += gg * xh;
-            }
-            s1 = wave_sum(s1) / (float)N; s2 = wave_sum(s2) / (float)N;
-            for (int n = lane; n < N; n += 64) {
-                const float xh = (z[ro + n] - mean) * rstd;
-                sdz[rl * N + n] = rstd * (dy[ro + n] * gamma[n] - s1 - xh * s2);
-            }
-        } else {
-            for (int n = lane; n < N; n += 64) sdz[rl * N + n] = dy[ro + n];
-        }
-        for (int n = lane; n < N; n += 64) {
-            float g = sdz[rl * N + n];
-            if (dres) dres[ro + n] = g;                               // the residual enters after the activation
-            if (relu && !(yout[ro + n] > 0.f)) g = 0.f;
-            sdz[rl * N + n] = g;
-            dz_out[ro + n] = g;
-        }
-    }
+    for (int i = t; i < RB * N; i += NT) { const int rl = i / N; sdz[i] = rl < nr ? dz[(size_t)r0 * N + i] : 0.f; }
     __syncthreads();
-    if (!dx) return;
     const int cols = K < 128 ? K : 128;
     const int c = t % cols, h = t / cols, groups = NT / cols;
     for (int k = c; k < K; k += cols) {
@@ -162,17 +158,15 @@ __global__ __launch_bounds__(NT) void token_linear_bwd_rows_kernel(const float* 
 // dgamma[n] = sum_r dy[r][n] xhat[r][n], dbeta[n] = sum_r dy[r][n]; x' = x + xadd staged in LDS in row chunks of 32.
 constexpr int CB = 4;
 
-__global__ __launch_bounds__(NT) void token_linear_bwd_cols_kernel(const float* __restrict__ dz, const float* __restrict__ dy, const float* __restrict__ x,
-                                                                   const float* __restrict__ xadd, const float* __restrict__ gamma,
-                                                                   const float* __restrict__ z, const float* __restrict__ rstat, float* __restrict__ dW,
-                                                                   float* __restrict__ db, float* __restrict__ dgamma, float* __restrict__ dbeta, int R,
-                                                                   int K, int N) {
-    extern __shared__ float sm[];
+__device__ __forceinline__ void token_linear_bwd_cols(float* sm, int cblock, const float* __restrict__ dz, const float* __restrict__ dy,
+                                                      const float* __restrict__ x, const float* __restrict__ xadd, const float* __restrict__ gamma,
+                                                      const float* __restrict__ z, const float* __restrict__ rstat, float* __restrict__ dW,
+                                                      float* __restrict__ db, float* __restrict__ dgamma, float* __restrict__ dbeta, int R, int K, int N) {
     constexpr int RC = 32;               // rows staged per pass
     float* sg = sm;                      // [RC][CB] dz of this block's columns
     float* sx = sm + RC * CB;            // [RC][K]
     const int t = threadIdx.x;
-    const int n0 = blockIdx.x * CB;
+    const int n0 = cblock * CB;
     const int nc = min(CB, N - n0);
     const int cols = K < 128 ? K : 128;
     const int c = t % cols, h = t / cols, groups = NT / cols;          // thread -> (k, column group)
@@ -221,6 +215,18 @@ __global__ __launch_bounds__(NT) void token_linear_bwd_cols_kernel(const float* 
         if (db) db[n0 + t] = sb;
         if (gamma) { dgamma[n0 + t] = ag; dbeta[n0 + t] = ab; }
     }
+}
+
+// The main backward launch: workgroups [0, nrb) produce dx (row-parallel), the rest dW / db / dgamma / dbeta (column-parallel) -- both halves
+// only read dz (token_linear_dz_kernel), so they share the chip instead of running back to back (two ~12 us latency-bound launches before).
+__global__ __launch_bounds__(NT) void token_linear_bwd_main_kernel(int nrb, const float* __restrict__ dz, const float* __restrict__ dy,
+                                                                   const float* __restrict__ x, const float* __restrict__ xadd, const float* __restrict__ W,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ z,
+                                                                   const float* __restrict__ rstat, float* __restrict__ dx, float* __restrict__ dW,
+                                                                   float* __restrict__ db, float* __restrict__ dgamma, float* __restrict__ dbeta, int R, int K, int N) {
+    extern __shared__ float sm[];
+    if ((int)blockIdx.x < nrb) token_linear_bwd_rows(sm, blockIdx.x, dz, W, dx, R, K, N);
+    else token_linear_bwd_cols(sm, blockIdx.x - nrb, dz, dy, x, xadd, gamma, z, rstat, dW, db, dgamma, dbeta, R, K, N);
 }
 
 // ---- token self-attention core: one workgroup per batch element, T <= 16 tokens, D <= 256 -------------------------------------------------
@@ -317,14 +323,15 @@ extern "C" int mg_token_linear_bwd(const float* dy, const float* x, const float*
     if (gamma && (!z || !rstat || !dgamma || !dbeta)) return -2;
     if ((relu && !yout) || !dz) return -2;
     const size_t lds_r = ((size_t)RB * N + (size_t)N * K) * sizeof(float);
+    const size_t lds_c = (size_t)32 * (CB + K) * sizeof(float);
     if (lds_r > 150 * 1024) return -3;
     static bool attr_b = false;
-    if (!attr_b) { (void)hipFuncSetAttribute((const void*)token_linear_bwd_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_b = true; }
+    if (!attr_b) { (void)hipFuncSetAttribute((const void*)token_linear_bwd_main_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_b = true; }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(token_linear_bwd_rows_kernel, dim3((R + RB - 1) / RB), dim3(NT), lds_r, st, dy, W, yout, relu, gamma, z, rstat, dx,
-                       dz, dres, R, K, N);
-    hipLaunchKernelGGL(token_linear_bwd_cols_kernel, dim3((N + CB - 1) / CB), dim3(NT), (size_t)32 * (CB + K) * sizeof(float), st, (const float*)dz, dy, x, xadd, gamma, z,
-                       rstat, dW, db, dgamma, dbeta, R, K, N);
+    hipLaunchKernelGGL(token_linear_dz_kernel, dim3((R + 3) / 4), dim3(NT), 0, st, dy, yout, relu, gamma, z, rstat, dz, dres, R, N);
+    const int nrb = dx ? (R + RB - 1) / RB : 0;
+    hipLaunchKernelGGL(token_linear_bwd_main_kernel, dim3(nrb + (N + CB - 1) / CB), dim3(NT), dx ? (lds_r > lds_c ? lds_r : lds_c) : lds_c, st, nrb,
+                       (const float*)dz, dy, x, xadd, W, gamma, z, rstat, dx, dW, db, dgamma, dbeta, R, K, N);
     MG_CHECK_LAUNCH();
     return 0;
 }
