@@ -1826,6 +1826,13 @@ WgradPlan plan_wgrad(const mg_conv_params& p) {
     if (splits > 2048 / tiles) splits = 2048 / tiles;
     if (splits > 512) splits = 512;
     if (splits > (16l << 20) / n) splits = (16l << 20) / n;
+    if (p.m_dev) {
+        // sparse head: M is the CAPACITY (every site of the frame); the live rows are typically 10-20 % of it and are divided evenly over the
+        // splits in-kernel, so a capacity-sized split count only buys zero slabs (33 MB written + 33 MB re-read per C64 launch; step time 15.20 / 15.10 / 15.10 / 15.18 ms at 512 / 128 / 64 / 32)
+        static const long dev_splits = [] { const char* e = getenv("MG_WGRAD_DEV_SPLITS"); return e ? atol(e) : 128l; }();
+        const long cap = (dev_splits * 9 + tiles - 1) / tiles;            // ~dev_splits row ranges for a 3x3 layer's 9 tap tiles
+        if (splits > cap) splits = cap;
+    }
     if (splits < 1) splits = 1;
     int rpb = (int)((p.M + splits - 1) / splits);
     rpb = ((rpb + KSTEP - 1) / KSTEP) * KSTEP;
