@@ -442,6 +442,19 @@ int mg_bce_logits_bwd(const float* x, long xbs, const float* y, long ybs, int B,
 int mg_temporal_crop(float* alpha, void* bits, int P, int H, int W, float sigma, float thr, int pad, float* scratch, int32_t* box, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Loss bookkeeping (maggie_amd/csrc/losses.hip)
+ *   mg_atten_loss_fwd/_bwd : compute_atten_loss of maggie/network/module/instance_matte_decoder.py (guidance_mask [rows, L], attention
+ *                            matrix [rows, L], rows = batch * instance slots): out[0] = scale * sum_rows((sum_l gm != 0) - sum_l gm * att);
+ *                            terms [rows] scratch. Backward: datt = -scale * gout[0] * gm.
+ *   mg_scalar_lincomb/_bwd : out[0] = sum_i coef[i] * ptrs[i][0] over n <= 16 device scalars (ptrs / coef are HOST arrays, passed by value
+ *                            into the launch): the loss sums of arch/maggie.py:283-300; backward gin[i] = coef[i] * gout[0].
+ * ------------------------------------------------------------------------------------------------------------- */
+int mg_atten_loss_fwd(const float* gm, const float* att, int rows, long L, float scale, float* terms, float* out, void* stream);
+int mg_atten_loss_bwd(const float* gm, const float* gout, float scale, long n, float* datt, void* stream);
+int mg_scalar_lincomb(const float* const* ptrs, const float* coef, int n, float* out, void* stream);
+int mg_scalar_lincomb_bwd(const float* coef, int n, const float* gout, float* gin, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Token side of the instance matte decoder (maggie_amd/csrc/token_side.hip): the (batch x 10 tokens) x 128 operations of
  * maggie/network/module/mask_attention.py:9-206 -- projections, FFN / MLP layers, post-norm residual LayerNorms (SelfAttentionLayer
  * :9-60, CrossAttentionLayer :63-133 token side, FFNLayer :170-182, MLP :185-206) -- fp32, single-workgroup kernels.

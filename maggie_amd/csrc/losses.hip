@@ -418,3 +418,78 @@ extern "C" int mg_loss_point_bwd(const float* p, const float* t, const float* w,
     MG_CHECK_LAUNCH();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Attention guidance loss of the instance matte decoder (maggie/network/module/instance_matte_decoder.py: compute_atten_loss):
+//   loss = scale * sum_rows [ (sum_l gm[row, l] != 0) - sum_l gm[row, l] * att[row, l] ],  d att = -scale * gout * gm.
+// One workgroup per row writes its term, a second tiny kernel sums the rows: two launches, no atomics, deterministic (the torch expression was 8 launches forward + 5 backward per call, three calls per step).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void atten_loss_rows_kernel(const float* __restrict__ gm, const float* __restrict__ att, long L, float* __restrict__ terms) {
+    __shared__ float sh[2 * (NT / 64)];
+    const long base = (long)blockIdx.x * L;
+    float sv = 0.f, sg = 0.f;
+    for (long i = threadIdx.x; i < L; i += NT) { const float g = gm[base + i]; sv += g * att[base + i]; sg += g; }
+    sv = wave_sum(sv); sg = wave_sum(sg);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sh[wave] = sv; sh[NT / 64 + wave] = sg; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, b = 0.f;
+        for (int w = 0; w < NT / 64; ++w) { a += sh[w]; b += sh[NT / 64 + w]; }
+        terms[blockIdx.x] = (b != 0.f ? 1.f : 0.f) - a;
+    }
+}
+__global__ void atten_loss_sum_kernel(const float* __restrict__ terms, int rows, float scale, float* __restrict__ out) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < rows; i += 64) s += terms[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) out[0] = s * scale;
+}
+__global__ __launch_bounds__(NT) void atten_loss_bwd_kernel(const float* __restrict__ gm, const float* __restrict__ gout, float scale, long n, float* __restrict__ datt) {
+    const float c = -scale * gout[0];
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) datt[i] = c * gm[i];
+}
+
+extern "C" int mg_atten_loss_fwd(const float* gm, const float* att, int rows, long L, float scale, float* terms, float* out, void* stream) {
+    if (rows <= 0 || L <= 0) return -3;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(atten_loss_rows_kernel, dim3(rows), dim3(NT), 0, st, gm, att, L, terms);
+    hipLaunchKernelGGL(atten_loss_sum_kernel, dim3(1), dim3(64), 0, st, (const float*)terms, rows, scale, out);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int mg_atten_loss_bwd(const float* gm, const float* gout, float scale, long n, float* datt, void* stream) {
+    if (n <= 0) return 0;
+    long b = (n + NT - 1) / NT; if (b > 1024) b = 1024;
+    hipLaunchKernelGGL(atten_loss_bwd_kernel, dim3((unsigned)b), dim3(NT), 0, (hipStream_t)stream, gm, gout, scale, n, datt);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weighted sum of up to 16 device scalars (the loss bookkeeping of arch/maggie.py:283-300: loss_rec = 2 r1 + r4 + r8, ..., total = sum_k w_k L_k)
+// and its backward gin[i] = c[i] * gout: one launch each instead of a dozen 1-element torch kernels forward and as many backward.
+// ---------------------------------------------------------------------------------------------------------------------
+struct ScalarTerms { const float* p[16]; float c[16]; int n; };
+__global__ void scalar_lincomb_kernel(const ScalarTerms t, float* __restrict__ out) {
+    if (threadIdx.x == 0) { float s = 0.f; for (int i = 0; i < t.n; ++i) s += t.c[i] * t.p[i][0]; out[0] = s; }
+}
+__global__ void scalar_lincomb_bwd_kernel(const ScalarTerms t, const float* __restrict__ gout, float* __restrict__ gin) {
+    if ((int)threadIdx.x < t.n) gin[threadIdx.x] = t.c[threadIdx.x] * gout[0];
+}
+extern "C" int mg_scalar_lincomb(const float* const* ptrs, const float* coef, int n, float* out, void* stream) {
+    if (n <= 0 || n > 16) return -3;
+    ScalarTerms t; t.n = n;
+    for (int i = 0; i < 16; ++i) { t.p[i] = i < n ? ptrs[i] : nullptr; t.c[i] = i < n ? coef[i] : 0.f; }
+    hipLaunchKernelGGL(scalar_lincomb_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t, out);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int mg_scalar_lincomb_bwd(const float* coef, int n, const float* gout, float* gin, void* stream) {
+    if (n <= 0 || n > 16) return -3;
+    ScalarTerms t; t.n = n;
+    for (int i = 0; i < 16; ++i) { t.p[i] = nullptr; t.c[i] = i < n ? coef[i] : 0.f; }
+    hipLaunchKernelGGL(scalar_lincomb_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t, gout, gin);
+    MG_CHECK_LAUNCH();
+    return 0;
+}

@@ -1160,6 +1160,75 @@ def dtssd_loss(pred, gt, mask=None, sig=False):
     return DtSSD.apply(pred, gt, mask, sig)
 
 
+class AttenGuidanceLoss(torch.autograd.Function):
+    """compute_atten_loss (maggie/network/module/instance_matte_decoder.py): scale * sum((sum_l gm != 0) - sum_l gm * att) over the (b, slot) rows;
+    two HIP launches forward, one backward (mg_atten_loss_*)."""
+
+    @staticmethod
+    def forward(ctx, gm, att, scale):
+        gm2 = gm.detach().float().contiguous()
+        a2 = att.float().contiguous()
+        L = gm2.shape[-1]
+        rows = gm2.numel() // L
+        out = torch.empty(1, dtype=torch.float32, device=a2.device)
+        terms = torch.empty(rows, dtype=torch.float32, device=a2.device)
+        K.hip.need_cuda(a2)
+        K.hip.call('mg_atten_loss_fwd', K.hip.ptr(gm2), K.hip.ptr(a2), K.c_int(rows), K.c_long(L), K.c_float(float(scale)), K.hip.ptr(terms),
+                   K.hip.ptr(out), K.hip.stream())
+        ctx.save_for_backward(gm2)
+        ctx.meta = (float(scale), att.shape, att.dtype)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        gm2, = ctx.saved_tensors
+        scale, shape, dtype = ctx.meta
+        datt = torch.empty(shape, dtype=torch.float32, device=gm2.device)
+        K.hip.call('mg_atten_loss_bwd', K.hip.ptr(gm2), K.hip.ptr(gout.float().contiguous().view(1)), K.c_float(scale), K.c_long(gm2.numel()),
+                   K.hip.ptr(datt), K.hip.stream())
+        return None, datt if dtype == torch.float32 else datt.to(dtype), None
+
+
+def atten_guidance_loss(gm, att, scale):
+    return AttenGuidanceLoss.apply(gm, att, scale)
+
+
+class ScalarLinComb(torch.autograd.Function):
+    """sum_i coef[i] * t_i over up to 16 one-element CUDA tensors in ONE launch (and one for the backward): the loss sums of arch/maggie.py:283-300."""
+
+    @staticmethod
+    def forward(ctx, coefs, *terms):
+        n = len(terms)
+        ts = [t.detach().float().reshape(1) for t in terms]
+        out = torch.empty(1, dtype=torch.float32, device=ts[0].device)
+        K.hip.need_cuda(ts[0])
+        ptrs = (K.ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+        cf = (K.ctypes.c_float * n)(*[float(c) for c in coefs])
+        K.hip.call('mg_scalar_lincomb', ptrs, cf, K.c_int(n), K.hip.ptr(out), K.hip.stream())
+        ctx.coefs = tuple(float(c) for c in coefs)
+        ctx.shapes = [t.shape for t in terms]
+        ctx.keep = ts                                   # the launch read them through raw pointers
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        n = len(ctx.coefs)
+        gin = torch.empty(n, dtype=torch.float32, device=gout.device)
+        cf = (K.ctypes.c_float * n)(*ctx.coefs)
+        K.hip.call('mg_scalar_lincomb_bwd', cf, K.c_int(n), K.hip.ptr(gout.float().contiguous().view(1)), K.hip.ptr(gin), K.hip.stream())
+        return (None,) + tuple(g.view(sh) for g, sh in zip(gin.unbind(0), ctx.shapes))
+
+
+def scalar_lincomb(terms, coefs):
+    """Weighted sum of one-element tensors; python numbers among `terms` are folded on the host."""
+    const = sum(float(t) * float(c) for t, c in zip(terms, coefs) if not torch.is_tensor(t))
+    tt = [(t, c) for t, c in zip(terms, coefs) if torch.is_tensor(t)]
+    if not tt:
+        return const
+    out = ScalarLinComb.apply([c for _, c in tt], *[t for t, _ in tt])
+    return out + const if const else out
+
+
 class BCELogitsMean(torch.autograd.Function):
     """F.binary_cross_entropy_with_logits(x, y, reduction='mean') over (B, T, ...) frame slices without copies."""
 

@@ -308,8 +308,9 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
                     continue        # the reference multiplies these too (:114-117) but never reads them again
                 pred[k] = v * valid_masks
             loss_dict = self.compute_loss(pred, weight_os4, weight_os1, alphas, trans_gt, (b, n_f, self.num_masks, h, w),
-                                          reweight_os8=self.reweight_os8)
+                                          reweight_os8=self.reweight_os8, defer_total=True)
             self.update_additional_decoder_loss(pred, loss_dict)
+            self._finish_total(loss_dict)
             for k, v in loss_dict.items():
                 names.append('loss/' + k)
                 outs.append(v if k == 'total' else v.detach())          # the caller back-propagates loss['total'] (engine/train.py:265-268)
@@ -354,10 +355,23 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         store[names_key] = fn.names
         return fn.names, outs
 
+    @staticmethod
+    def _add_to_total(loss_dict, term, coef):
+        if '_total_terms' in loss_dict:
+            loss_dict['_total_terms'][0].append(term)
+            loss_dict['_total_terms'][1].append(coef)
+        else:
+            loss_dict['total'] = loss_dict['total'] + term * coef
+
+    @staticmethod
+    def _finish_total(loss_dict):
+        terms, coefs = loss_dict.pop('_total_terms')
+        loss_dict['total'] = MF.scalar_lincomb(terms, coefs) if terms else 0
+
     def update_additional_decoder_loss(self, pred, loss_dict):
         if 'loss_max_atten' in pred and self.loss_atten_w > 0:
             loss_dict['loss_max_atten'] = pred['loss_max_atten']
-            loss_dict['total'] += loss_dict['loss_max_atten'] * self.loss_atten_w
+            self._add_to_total(loss_dict, loss_dict['loss_max_atten'], self.loss_atten_w)
 
     def transform_output(self, b, n_f, h, w, n_i, pred, alpha_pred):
         output = {}
@@ -430,7 +444,7 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         return masks, alphas, trans_gt, n_i, chosen_ids, enc_masks
 
     # ------------------------------------------------------------------------------------------------ losses
-    def compute_loss(self, pred, weight_os4, weight_os1, alphas, trans_gt, alpha_shape, reweight_os8=True):
+    def compute_loss(self, pred, weight_os4, weight_os1, alphas, trans_gt, alpha_shape, reweight_os8=True, defer_total=False):
         """arch/maggie.py:268-368: weighted L1 + Laplacian-pyramid L1 + Sobel-gradient L1 at OS1 (x2) / OS4 / OS8 (+ dtSSD for video), same
         loss names. Every term is a fused HIP pipeline (csrc/losses.hip) -- there is no torch fallback: what the kernels do not cover is
         rejected loudly (`loss_alpha_type` other than the 'l1' of maggie_{image,video}.yaml; sizes that are not multiples of 8)."""
@@ -451,31 +465,36 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             padding = torch.zeros((alphas.shape[0], self.num_masks - n_i, *alphas.shape[-2:]), device=alphas.device)
             alphas = torch.cat([alphas, padding], dim=1)
             trans_gt = torch.cat([trans_gt, padding], dim=1)
-        total_loss = 0
         # one fused HIP pipeline per scale: weighted L1 + Laplacian-pyramid L1 + Sobel-gradient L1 (fwd sums + exact bwd)
         r1, l1_, g1 = MF.matting_losses(a1, alphas, weight_os1)
         r4, l4_, g4 = MF.matting_losses(a4, alphas, weight_os4)
         r8, l8_, g8 = MF.matting_losses(a8, alphas, weight_os8)
+        # The sums of arch/maggie.py:283-300 (loss_x = 2 * os1 + os4 + os8, total = sum_x w_x * loss_x): the per-family values are for the log
+        # (no gradient flows through them -- only through `total`), `total` is ONE weighted sum of the nine (twelve) scale terms
+        # (mg_scalar_lincomb: one launch forward, one backward, instead of ~12 + ~14 one-element torch kernels)
+        terms, coefs = [], []
+
+        def family(name, w, t1, t4, t8):
+            loss_dict[name + '_os1'], loss_dict[name + '_os4'], loss_dict[name + '_os8'] = t1, t4, t8
+            with torch.no_grad():
+                loss_dict[name] = MF.scalar_lincomb([t1, t4, t8], [2.0, 1.0, 1.0])
+            terms.extend([t1, t4, t8])
+            coefs.extend([2.0 * w, w, w])
+
         if self.loss_alpha_w > 0:
-            loss_dict['loss_rec_os1'], loss_dict['loss_rec_os4'], loss_dict['loss_rec_os8'] = r1, r4, r8
-            loss_dict['loss_rec'] = r1 * 2 + r4 + r8
-            total_loss = total_loss + loss_dict['loss_rec'] * self.loss_alpha_w
+            family('loss_rec', self.loss_alpha_w, r1, r4, r8)
         if self.loss_alpha_lap_w > 0:
-            loss_dict['loss_lap_os1'], loss_dict['loss_lap_os4'], loss_dict['loss_lap_os8'] = l1_, l4_, l8_
-            loss_dict['loss_lap'] = l1_ * 2 + l4_ + l8_
-            total_loss = total_loss + loss_dict['loss_lap'] * self.loss_alpha_lap_w
+            family('loss_lap', self.loss_alpha_lap_w, l1_, l4_, l8_)
         if self.loss_alpha_grad_w > 0:
-            loss_dict['loss_grad_os1'], loss_dict['loss_grad_os4'], loss_dict['loss_grad_os8'] = g1, g4, g8
-            loss_dict['loss_grad'] = g1 * 2 + g4 + g8
-            total_loss = total_loss + loss_dict['loss_grad'] * self.loss_alpha_grad_w
+            family('loss_grad', self.loss_alpha_grad_w, g1, g4, g8)
         if self.loss_dtSSD_w > 0:
             rs = lambda t: t.reshape(*alpha_shape)
             d1 = MF.dtssd_loss(rs(a1), rs(alphas), rs(weight_os1))       # loss.py:7-16 as a fused HIP reduction (mg_dtssd_fwd / _bwd)
             d4 = MF.dtssd_loss(rs(a4), rs(alphas), rs(weight_os4))
             d8 = MF.dtssd_loss(rs(a8), rs(alphas), rs(weight_os8))
-            dt = d1 * 2 + d4 + d8
-            loss_dict['loss_dtSSD_os1'], loss_dict['loss_dtSSD_os4'], loss_dict['loss_dtSSD_os8'] = d1, d4, d8
-            loss_dict['loss_dtSSD'] = dt
-            total_loss = total_loss + dt * self.loss_dtSSD_w
-        loss_dict['total'] = total_loss
+            family('loss_dtSSD', self.loss_dtSSD_w, d1, d4, d8)
+        if defer_total:
+            loss_dict['_total_terms'] = (terms, coefs)       # update_additional_decoder_loss appends the decoder's terms; _finish_total sums once
+        else:
+            loss_dict['total'] = MF.scalar_lincomb(terms, coefs) if terms else 0
         return loss_dict

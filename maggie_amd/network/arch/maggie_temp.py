@@ -24,7 +24,7 @@ class MaGGIe_Temp(MaGGIe):
         super().update_additional_decoder_loss(pred, loss_dict)
         if 'loss_temp' in pred:                                                 # BCE + dtSSD on the difference maps, already weighted
             loss_dict['loss_temp_bce'], loss_dict['loss_temp'] = pred['loss_temp_bce'], pred['loss_temp']
-            loss_dict['total'] += pred['loss_temp']
+            self._add_to_total(loss_dict, pred['loss_temp'], 1.0)
         loss_dict.update({k: pred[k] for k in _EXTRA_LOSSES if k in pred})
 
     def forward(self, batch, **kwargs):

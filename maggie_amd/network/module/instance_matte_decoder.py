@@ -56,9 +56,8 @@ class InstanceMatteDecoder(nn.Module):
                 nn.init.xavier_uniform_(m.weight)
 
     def compute_atten_loss(self, b, n_f, guidance_mask, atten_mat):
-        atten_values = (guidance_mask * atten_mat).sum(2)
-        atten_gt = (guidance_mask.sum(2) != 0).to(atten_values.dtype)
-        return (atten_gt - atten_values).sum() / (n_f * b)
+        """((guidance.sum(2) != 0) - (guidance * atten).sum(2)).sum() / (n_f * b) as one fused HIP reduction (mg_atten_loss_fwd / _bwd)."""
+        return MF.atten_guidance_loss(guidance_mask, atten_mat, 1.0 / (n_f * b))
 
     def _smooth(self, x):
         c0, bn0, _, c1, bn1, _ = self.conv
@@ -103,7 +102,7 @@ class InstanceMatteDecoder(nn.Module):
                 gm = torch.cat([gm, gm.new_zeros((b, n_f, n_i - gm.shape[2], h * w))], 2)
             guidance_mask = (gm > 0).permute(0, 2, 1, 3).reshape(b, n_i, n_f * h * w).float()
 
-        max_loss = 0
+        max_loss, atten_terms = 0, []
         valid_tokens = m8.sum((1, 3, 4)) > 0
         if valid_tokens.shape[1] < n_i:
             valid_tokens = torch.cat([valid_tokens, valid_tokens.new_zeros((b, n_i - valid_tokens.shape[1]))], 1)
@@ -119,14 +118,15 @@ class InstanceMatteDecoder(nn.Module):
             for i in range(self.n_block):
                 tokens, att = self.token_feat_ca_layers[i].tokens_from_features(tokens, pos_t, feat, feat_ids, tbl)
                 if self.training:
-                    max_loss = max_loss + self.compute_atten_loss(b, n_f, guidance_mask, att)
+                    atten_terms.append(self.compute_atten_loss(b, n_f, guidance_mask, att))
                 tokens = self.mlp_layers[i](tokens)
                 tokens = self.sa_layers[i](tokens, tgt_key_padding_mask=token_padding_mask, query_pos=token_pos)
                 feat = self.feat_token_ca_layers[i].features_from_tokens(feat, feat_ids, tbl, tokens, pos_t, token_padding_mask)
             tokens, att = self.final_token_feat_ca.tokens_from_features(tokens, token_pos, feat, feat_ids, id_table)
             if self.training:
-                max_loss = max_loss + self.compute_atten_loss(b, n_f, guidance_mask, att)
-            max_loss = max_loss / (self.n_block + 1)
+                atten_terms.append(self.compute_atten_loss(b, n_f, guidance_mask, att))
+            if atten_terms:                                       # mean over the n_block + 1 attention maps: one launch (mg_scalar_lincomb)
+                max_loss = MF.scalar_lincomb(atten_terms, [1.0 / (self.n_block + 1)] * len(atten_terms))
         if MF.EAGER_TOKEN_CHECK and not torch.cuda.is_current_stream_capturing():
             check_tokens(tokens)                                  # direct module use; MaGGIe.forward reads all its flags in ONE device->host copy
 

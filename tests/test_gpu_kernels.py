@@ -994,3 +994,36 @@ def test_token_self_attention_matches_torch():
     assert torch.allclose(out.detach().cpu(), out_ref.detach(), atol=2e-5, rtol=2e-5)
     for a, c in ((qd, q), (kd, k), (vd, v)):
         assert torch.allclose(a.grad.cpu(), c.grad, atol=5e-5, rtol=5e-5), float((a.grad.cpu() - c.grad).abs().max())
+
+
+@pytest.mark.gpu
+def test_atten_guidance_loss_and_scalar_lincomb_match_torch():
+    """compute_atten_loss (instance_matte_decoder.py) and the loss sums of arch/maggie.py:283-300 as fused HIP launches: value and gradients
+    against the torch expressions they replace."""
+    from maggie_amd import functional as MF
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    b, n_i, L, n_f = 3, 10, 777, 1
+    gm = (torch.rand(b, n_i, L, generator=g) > 0.7).float()
+    gm[1, 4] = 0                                                     # an instance slot without guidance: contributes 0 - 0
+    att = torch.rand(b, n_i, L, generator=g).softmax(-1)
+    a_ref = att.clone().requires_grad_(True)
+    ref = ((gm.sum(2) != 0).float() - (gm * a_ref).sum(2)).sum() / (n_f * b)
+    (ref * 1.7).backward()
+    a = att.to(dev).requires_grad_(True)
+    out = MF.atten_guidance_loss(gm.to(dev), a, 1.0 / (n_f * b))
+    (out * 1.7).backward()
+    assert abs(float(out) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    assert (a.grad.cpu() - a_ref.grad).abs().max().item() <= 1e-6
+
+    ts = [torch.randn((), generator=g) for _ in range(9)]
+    cs = [2.0, 1.0, 1.0, 0.5, 0.25, 0.25, 3.0, 1.5, 1.5]
+    tr = [t.clone().requires_grad_(True) for t in ts]
+    ref = sum(c * t for c, t in zip(cs, tr)) + 0.125 * 2.0
+    ref.backward()
+    td = [t.to(dev).requires_grad_(True) for t in ts]
+    out = MF.scalar_lincomb(td + [0.125], cs + [2.0])               # a python number among the terms is folded on the host
+    out.backward()
+    assert abs(float(out) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref)))
+    for t, r, c in zip(td, tr, cs):
+        assert abs(float(t.grad) - float(r.grad)) <= 1e-7 and abs(float(t.grad) - c) <= 1e-7
