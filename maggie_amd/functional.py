@@ -455,7 +455,7 @@ class ConvRaw(torch.autograd.Function):
     ConvTranspose2d(k, stride, pad). `stats` (fp32 [2*Cout(+1)], zeroed) receives the BN batch statistics of y."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, R, S, stride, pad, dil, transposed, pre_relu, stats):
+    def forward(ctx, x, w, bias, R, S, stride, pad, dil, transposed, pre_relu, stats, carry=False):
         N, H, W_, Cin = x.shape
         Cout = w.shape[0]
         x = x.contiguous()
@@ -471,10 +471,15 @@ class ConvRaw(torch.autograd.Function):
         ctx.side = SIDE_WGRAD and getattr(w, '_mg_side_wgrad', False) and not transposed
         ctx.save_for_backward(x, w, y if pre_relu else None)
         ctx.geom = (N, H, W_, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, transposed, pre_relu, bias is not None)
+        if carry:
+            # `carry`: the input is handed back as a second output for the caller's skip connection. Its gradient then arrives HERE (d_carry)
+            # and is added inside the data-gradient kernel's epilogue (res2) -- instead of autograd summing the two branches of x with a
+            # separate feature-map-sized add kernel per residual block.
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, d_carry=None):
         x, w, y = ctx.saved_tensors
         N, H, W_, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, transposed, pre_relu, has_bias = ctx.geom
         dy2 = dy.contiguous().view(-1, Cout)
@@ -485,8 +490,11 @@ class ConvRaw(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt = ctx.wt if (ctx.wt is not None and not transposed) else w.permute(2, 1, 0).contiguous()      # (Cin, taps, Cout)
             dmode = MODE_CONV if transposed else MODE_TCONV
+            r2 = None if d_carry is None else d_carry.to(dy2.dtype).contiguous().view(-1, Cin)
             dx = K.conv_fprop(dy2, wt, mode=dmode, N=N, Hin=Ho, Win=Wo, Hout=H, Wout=W_, R=R, S=S, stride=stride, pad=pad,
-                              dil=dil, alg_cout=ctx.cin_real).view(N, H, W_, Cin)
+                              dil=dil, alg_cout=ctx.cin_real, res2=r2).view(N, H, W_, Cin)
+        elif d_carry is not None:
+            dx = d_carry
         if ctx.needs_input_grad[1]:
             if ctx.side:
                 side, main = fork_side(dy2.device)
@@ -504,11 +512,11 @@ class ConvRaw(torch.autograd.Function):
                 dwt = K.conv_wgrad(dy2, x.view(-1, Cin), cout=Cin, mode=MODE_CONV, N=N, Hin=Ho, Win=Wo, Hout=H, Wout=W_,
                                    R=R, S=S, stride=stride, pad=pad, dil=dil, out_dtype=w.dtype)
                 dw = dwt.permute(2, 1, 0).contiguous()
-        return dx, dw, db, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
-def conv2d(x, w, bias=None, R=3, S=3, stride=1, pad=1, dil=1, transposed=False, pre_relu=False, stats=None):
-    return ConvRaw.apply(x, w, bias, R, S, stride, pad, dil, transposed, pre_relu, stats)
+def conv2d(x, w, bias=None, R=3, S=3, stride=1, pad=1, dil=1, transposed=False, pre_relu=False, stats=None, carry=False):
+    return ConvRaw.apply(x, w, bias, R, S, stride, pad, dil, transposed, pre_relu, stats, carry)
 
 
 def linear_rows(x2d, w, bias=None, pre_relu=False, stats=None):
@@ -662,7 +670,7 @@ def new_stats(channels, device, rows=None, bn=None):
 
 
 def conv_bn_act(x, w, bn, act=ACT_NONE, R=3, S=3, stride=1, pad=1, dil=1, transposed=False, res=None, res_mode=1, res2=None,
-                relu_before_bn=False, bias=None):
+                relu_before_bn=False, bias=None, carry=False):
     """conv -> BN -> (+res) -> act (-> +res2).  In inference (no grad, eval BN) this is ONE fused kernel; in training the
     conv epilogue accumulates the batch statistics and a second HBM pass applies them."""
     Cout = w.shape[0]
@@ -681,17 +689,21 @@ def conv_bn_act(x, w, bn, act=ACT_NONE, R=3, S=3, stride=1, pad=1, dil=1, transp
                          res=None if res is None else res.contiguous().view(-1, Cout), res_mode=res_mode,
                          res2=None if res2 is None else res2.contiguous().view(-1, Cout),
                          act=ACT_RELU if relu_before_bn else act, pre_act=relu_before_bn, slope=LRELU_SLOPE)
-        return y.view(N, Ho, Wo, Cout)
+        return (y.view(N, Ho, Wo, Cout), x) if carry else y.view(N, Ho, Wo, Cout)
     stats = None
     if bn.training:
         mode_ = MODE_TCONV if transposed else MODE_CONV
         rows = x.shape[0] * K.conv_out_size(mode_, x.shape[1], R, stride, pad, dil) * K.conv_out_size(mode_, x.shape[2], S, stride, pad, dil)
         stats = new_stats(Cout, x.device, rows, bn)
-    y = conv2d(x, w, bias, R, S, stride, pad, dil, transposed, relu_before_bn, stats)
+    xc = None
+    if carry and torch.is_grad_enabled() and x.requires_grad:
+        y, xc = conv2d(x, w, bias, R, S, stride, pad, dil, transposed, relu_before_bn, stats, True)
+    else:
+        y = conv2d(x, w, bias, R, S, stride, pad, dil, transposed, relu_before_bn, stats)
     y = batch_norm_act(y, bn, ACT_NONE if relu_before_bn else act, res=res, stats=stats, res_mode=res_mode)
     if res2 is not None:
         y = y + res2
-    return y
+    return (y, x if xc is None else xc) if carry else y
 
 
 # ----------------------------------------------------------------------------------------------------------------------

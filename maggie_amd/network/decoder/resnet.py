@@ -26,10 +26,11 @@ class BasicBlock(nn.Module):
         """`post_add` (the encoder shortcut feature) is added after the block's activation; fused into the last kernel in
         inference."""
         dt = x.dtype
+        # `carry`: the skip branch takes x back from the first conv, whose data-gradient kernel then adds the skip gradient in its epilogue
         if self.stride > 1:
-            out = MF.conv_bn_act(x, self.conv1.krsc(dt, x.shape[-1]), self.bn1, MF.ACT_LRELU, 4, 4, 2, 1, 1, transposed=True)
+            out, x = MF.conv_bn_act(x, self.conv1.krsc(dt, x.shape[-1]), self.bn1, MF.ACT_LRELU, 4, 4, 2, 1, 1, transposed=True, carry=True)
         else:
-            out = MF.conv_bn_act(x, self.conv1.krsc(dt, x.shape[-1]), self.bn1, MF.ACT_LRELU, 3, 3, 1, 1, 1)
+            out, x = MF.conv_bn_act(x, self.conv1.krsc(dt, x.shape[-1]), self.bn1, MF.ACT_LRELU, 3, 3, 1, 1, 1, carry=True)
         identity, res_mode = x, 1
         if self.upsample is not None:
             u = self.upsample

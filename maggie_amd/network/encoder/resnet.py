@@ -23,7 +23,9 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         dt = x.dtype
-        out = MF.conv_bn_act(x, self.conv1.krsc(dt, x.shape[-1]), self.bn1, MF.ACT_RELU, 3, 3, self.stride, 1, 1)
+        # the skip branch takes x back FROM the first conv (`carry`): in backward the skip gradient is added inside that conv's
+        # data-gradient kernel instead of by a separate add over the feature map
+        out, x = MF.conv_bn_act(x, self.conv1.krsc(dt, x.shape[-1]), self.bn1, MF.ACT_RELU, 3, 3, self.stride, 1, 1, carry=True)
         identity = x
         if self.downsample is not None:
             d = self.downsample

@@ -82,8 +82,9 @@ class InstanceMatteDecoder(nn.Module):
         ids = torch.arange(1, n_in + 1, device=mask.device, dtype=torch.float32)[None, None, :, None, None]
         feat_ids = (m8 * ids).amax(2).to(torch.int32).reshape(b, n_f * h * w).contiguous()  # (b, L), l = f*hw + p
         id_table = self.id_embedding.weight.float() if self.use_id_pe else None
-        token_pos = self.id_embedding.weight[1:self.max_inst + 1].float()[None].expand(b, -1, -1)
-        tokens = self.query_feat.weight.float()[None].expand(b, -1, -1)
+        # materialised once: every token-side launch below wants dense (b, 10, d) operands (an expanded view would be copied per use)
+        token_pos = self.id_embedding.weight[1:self.max_inst + 1].float()[None].expand(b, -1, -1).contiguous()
+        tokens = self.query_feat.weight.float()[None].expand(b, -1, -1).contiguous()
 
         # feature projection (Linear 128->128 over all rows) on the implicit-GEMM kernel
         lin = self.feat_proj.layers[0]
