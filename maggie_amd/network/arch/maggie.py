@@ -78,11 +78,12 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         MF.ARENA.reset(device)
         # Everything cached by address (captured graphs, the BatchNorm counter list) is dropped when the parameters were
         # re-allocated: model.to(...) / .half() / .float() / a re-assigned .data
-        sentinel = self.__dict__.get('_addr_sentinels')
-        if sentinel is None:
-            ps = list(self.parameters())
-            sentinel = self.__dict__['_addr_sentinels'] = [ps[0], ps[len(ps) // 2], ps[-1]]
-        sig = tuple(p.data_ptr() for p in sentinel)
+        # (every parameter and buffer, not a few sentinels: re-homing a subset -- FlatAdamW moves only the trainable ones, a per-layer
+        # `p.data = ...` re-initialisation, SpectralNorm's fallback reassigning u / v -- must also drop the graphs; ~0.1 ms of host time)
+        tensors = self.__dict__.get('_addr_tensors')
+        if tensors is None:
+            tensors = self.__dict__['_addr_tensors'] = list(self.parameters()) + list(self.buffers())
+        sig = tuple([t.data_ptr() for t in tensors])
         if self.__dict__.get('_addr_sig') != sig:
             for store in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs', '_detail_names'):
                 self.__dict__.get(store, {}).clear()
@@ -181,13 +182,21 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         entry = graphs.get(key) if key is not None else None
         if isinstance(entry, int) and entry >= 1:
             entry = self._capture(fn, inputs, grad_inputs)
-            graphs[key] = entry
-            while len(graphs) > 4:                                # bounded: each graph pins its own activation pool
-                graphs.pop(next(iter(graphs)))
+            graphs.pop(key, None)
+            graphs[key] = entry                                   # most recently used = last
+            # bounded: each captured graph pins its own activation pool. Evict the least recently USED graph (never the one just
+            # captured); sighting counters of geometries that were never captured are bounded separately
+            captured = [k for k, v in graphs.items() if not isinstance(v, int)]
+            for k in captured[:max(0, len(captured) - 4)]:
+                graphs.pop(k)
+            counters = [k for k, v in graphs.items() if isinstance(v, int)]
+            for k in counters[:max(0, len(counters) - 16)]:
+                graphs.pop(k)
         if entry is None or isinstance(entry, int) or entry == 'failed':
             if key is not None and entry != 'failed':
                 graphs[key] = (entry or 0) + 1
             return None, False
+        graphs[key] = graphs.pop(key)                             # LRU order: a replayed graph moves to the end
         return entry(*inputs), True
 
     def _capture(self, fn, inputs, grad_inputs=()):

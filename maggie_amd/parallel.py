@@ -195,16 +195,19 @@ class GradSync:
     """Average the gradients of `model` over the process group after backward(): `sync = GradSync(model)` once, then
     `loss.backward(); sync(); optimizer.step()`.
 
-    Gradients that are views of one flat 1-D buffer (the hipGraph trunk's export) are reduced in place through that buffer;
-    the rest are coalesced into one temporary flat tensor per dtype. Every rank must call it every step with the same set of
-    trainable parameters: a parameter without a gradient on this rank contributes zeros, so the collectives always have the
-    same shape on every rank (no hang when one rank's detail region is empty)."""
+    The collective layout is RANK-INVARIANT: every trainable parameter, in `model.parameters()` order, has a fixed slot in one flat fp32
+    buffer; gradients are gathered into it with one multi-tensor copy (a parameter without a gradient on this rank contributes zeros),
+    ONE all-reduce averages the buffer, one multi-tensor copy hands the results back. Whether a rank's gradients happen to be views of a
+    hipGraph's exported flat buffer or loose tensors (a rank whose capture failed, an evicted graph, a different geometry history) no
+    longer changes what is sent -- the earlier per-buffer scheme could issue collectives of different sizes on different ranks.
+    (`FlatAdamW(sync_group=True)` does the same inside its own flat buffer and is the faster path; this class serves torch optimizers.)"""
 
     def __init__(self, model, group=None):
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.avg = dist.is_available() and dist.is_initialized() and dist.get_backend(group) == 'nccl'
+        self._flat = None
 
     def _all_reduce(self, flat):
         all_reduce_mean(flat, self.group)
@@ -212,17 +215,23 @@ class GradSync:
     def __call__(self):
         if self.world <= 1 and not (dist.is_available() and dist.is_initialized()):
             return
-        whole, rest = grad_buffers(self.params, fill_missing=True)
-        for b in whole:                                           # the buffer holds gradients and nothing else
-            self._all_reduce(b)
-        loose = {}
-        for g in rest:
-            loose.setdefault(g.dtype, []).append(g)
-        for dt, gs in loose.items():
-            flat = torch.cat([g.reshape(-1) for g in gs])
-            self._all_reduce(flat)
-            outs, o = [], 0
-            for g in gs:
-                outs.append(flat[o:o + g.numel()].view(g.shape))
-                o += g.numel()
-            torch._foreach_copy_(gs, outs)
+        ps = self.params
+        n = sum(p.numel() for p in ps)
+        dev = ps[0].device
+        if self._flat is None or self._flat.numel() != n or self._flat.device != dev:
+            self._flat = torch.zeros(n, dtype=torch.float32, device=dev)
+            self._views, o = [], 0
+            for p in ps:
+                self._views.append(self._flat[o:o + p.numel()].view(p.shape))
+                o += p.numel()
+        have = [(v, p.grad) for v, p in zip(self._views, ps) if p.grad is not None]
+        if len(have) != len(ps):
+            self._flat.zero_()
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        self._all_reduce(self._flat)
+        with torch.no_grad():
+            for v, p in zip(self._views, ps):
+                if p.grad is None:
+                    p.grad = v.clone()
+            torch._foreach_copy_([p.grad for _, p in zip(self._views, ps)], self._views)
