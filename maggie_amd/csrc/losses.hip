@@ -270,8 +270,11 @@ __global__ __launch_bounds__(NT) void point_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ coef_grad, const float* __restrict__ dd,
                                                        const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ dp) {
     const int pl = blockIdx.y;
-    if (!flags[pl]) return;
     const long off = (long)pl * H * W;
+    if (!flags[pl]) {                                   // a plane without weight: its gradient is zero (written here: dp needs no pre-fill)
+        for (int idx = blockIdx.x * NT + threadIdx.x; idx < H * W; idx += gridDim.x * NT) dp[off + idx] = 0.f;
+        return;
+    }
     const float cr = coef_rec[0], cg = coef_grad[0];
     const float kx[3][3] = {{-1.f, 0.f, 1.f}, {-2.f, 0.f, 2.f}, {-1.f, 0.f, 1.f}};
     for (int idx = blockIdx.x * NT + threadIdx.x; idx < H * W; idx += gridDim.x * NT) {

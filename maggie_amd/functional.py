@@ -987,7 +987,7 @@ class MattingLosses(torch.autograd.Function):
         dd0 = new(H, W_)
         hipc('mg_pyr_downT', ptr(r0), ptr(G0), ptr(c0), ptr(flags), c_int(P), c_int(H), c_int(W_), ptr(dd0), st())
         A, B = new(H, W_), new(H, W_)
-        dp = torch.zeros((P, H, W_), dtype=torch.float32, device=dev)
+        dp = torch.empty((P, H, W_), dtype=torch.float32, device=dev)          # planes without weight are zeroed by the kernel
         hipc('mg_loss_point_bwd', ptr(p), ptr(t), ptr(w), ptr(flags), c_int(P), c_int(H), c_int(W_), ptr(c_rec), ptr(c_grad), ptr(dd0),
              ptr(A), ptr(B), ptr(dp), st())
         return dp.view(ctx.shape), None, None
