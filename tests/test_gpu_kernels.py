@@ -1027,3 +1027,41 @@ def test_atten_guidance_loss_and_scalar_lincomb_match_torch():
     assert abs(float(out) - float(ref)) <= 1e-6 * max(1.0, abs(float(ref)))
     for t, r, c in zip(td, tr, cs):
         assert abs(float(t.grad) - float(r.grad)) <= 1e-7 and abs(float(t.grad) - c) <= 1e-7
+
+
+@pytest.mark.gpu
+def test_temporal_crop_matches_oracle_restatement():
+    """Eval bounding-box crop of the video decoder (resnet_inst_matt_spconv_temp.py:115-142): smoothing with the reference's kernel quirk, crop,
+    bilinear resize, threshold 0.1, box +-30 px, applied to the alpha planes and to the detail bit planes -- against the oracle's restatement
+    (oracle/refmodel.py:gaussian_smoothing + the box loop) on planes with separated blobs, an empty plane and a plane touching the border."""
+    from maggie_amd import functional as MF, kernels as K
+    from oracle import refmodel as rm
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    N, n_i, H, W = 2, 3, 96, 160
+    a = torch.zeros(N, n_i, H, W)
+    a[0, 0, 20:40, 30:70] = torch.rand(20, 40, generator=g) * 0.8 + 0.2
+    a[0, 1, 0:12, 100:160] = 0.9                                     # touches the top / right border
+    a[1, 0, 60:90, 5:25] = 0.5
+    a[1, 0, 10:14, 120:126] = 0.05                                   # faint: stays below the 0.1 threshold after smoothing
+    a[1, 2, 40:44, 80:84] = 1.0                                      # tiny blob
+    unk = (torch.rand(N, n_i, H, W, generator=g) > 0.5)
+    sm = rm.gaussian_smoothing(a, 3)
+    ref_a, ref_u = a.clone(), unk.clone()
+    for i in range(N):
+        for j in range(n_i):
+            ys, xs = torch.nonzero(sm[i, j] > 0.1, as_tuple=True)
+            if len(ys) == 0:
+                continue
+            y0, y1 = max(0, int(ys.min()) - 30), min(int(ys.max()) + 30, H)
+            x0, x1 = max(0, int(xs.min()) - 30), min(int(xs.max()) + 30, W)
+            tm = torch.zeros(H, W, dtype=torch.bool)
+            tm[y0:y1, x0:x1] = True
+            ref_a[i, j] = ref_a[i, j] * tm
+            ref_u[i, j] = ref_u[i, j] & tm
+    ad = a.to(dev).contiguous()
+    bits = K.bits_pack(unk.reshape(N * n_i, H, W).to(torch.uint8).to(dev), mode=1)
+    MF.temporal_crop_(ad, bits)
+    assert torch.equal(ad.cpu(), ref_a)
+    got_u = K.bits_unpack_u8(bits, W, (N * n_i, H, W)).cpu().bool().reshape(N, n_i, H, W)
+    assert torch.equal(got_u, ref_u)
