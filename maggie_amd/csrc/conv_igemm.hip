@@ -781,7 +781,10 @@ __global__ __launch_bounds__(256) void igemm_fprop_async_persistent_kernel(const
 template <int TH, int BN, int NS> struct HaloCfg {
     static constexpr int TW = 16, BM = TH * TW, PW = 24, HH = TH + 2;
     static constexpr int A_INSTR = (HH * PW + 15) / 16, A_PER_WAVE = (A_INSTR + 3) / 4, A_BYTES = A_PER_WAVE * 4 * 1024;
-    static constexpr int B_GRP = BN / 16, B_INSTR = 9 * B_GRP, B_PER_WAVE = (B_INSTR + 3) / 4, B_BYTES = 9 * BN * 64;
+    // every wave issues B_PER_WAVE weight instructions per stage (the counted vmcnt waits rely on it): the B region is sized for ALL of them.
+    // With BN = 32 the 18 real instructions round up to 20; sized as 9 * BN * 64 the two spare ones (zero-page loads) landed 2 KiB past the
+    // stage -- in the NEXT ring buffer's halo rows while it was being read (Cin 96 with the two-slab ring: 20 % errors).
+    static constexpr int B_GRP = BN / 16, B_INSTR = 9 * B_GRP, B_PER_WAVE = (B_INSTR + 3) / 4, B_BYTES = B_PER_WAVE * 4 * 1024;
     static constexpr int STAGE = A_BYTES + B_BYTES, L = A_PER_WAVE + B_PER_WAVE;
     static constexpr int LDS = NS * STAGE > ctile_bytes<BM, BN>() ? NS * STAGE : ctile_bytes<BM, BN>();
 };

@@ -44,6 +44,8 @@ CASES = [
     (4, 64, 128, 32, 32, 3, 1, 1, 1),
     (1, 32, 64, 16, 16, 3, 1, 1, 1),
     (1, 96, 192, 5, 33, 3, 1, 1, 1),
+    (2, 96, 64, 16, 24, 3, 1, 1, 1),                 # odd number of 32-channel slabs through the two-slab ring of the 32-wide halo form
+    (1, 160, 96, 8, 16, 3, 1, 1, 1),                 # five slabs, Cout not a multiple of 64
     (1, 64, 128, 20, 20, 3, 2, 1, 1),
     (2, 32, 32, 40, 24, 3, 1, 1, 1),
     (2, 64, 128, 16, 24, 1, 2, 0, 1),                # stride-2 1x1 (downsample): its data gradient is the phase walk with three empty phases
