@@ -998,7 +998,7 @@ static int dispatch_fprop_halo(const mg_conv_params& p, hipStream_t st) {
     // 64-wide three-slab form owns the whole CU). Costs 30 % more halo traffic; measured C512->256 32x32 18.0 -> 15.5 us, C256->128 64x64
     // 15.2 -> 14.1 us, C128 / C256 unchanged, step 14.91 -> 14.74 ms. MG_HALO_NARROW=0 selects the wide form.
     static const int narrow = [] { const char* e = getenv("MG_HALO_NARROW"); return e ? atoi(e) : 1; }();
-    if (narrow && p.Hout >= 8) return launch_fprop_halo<8, 32, 2>(p, st);
+    if (narrow && p.Hout >= 8) return launch_fprop_halo<8, 32, 2>(p, st);      // (4 x 16 tiles for the layers with < 300 workgroups: no gain, measured)
     if (t8 >= want && p.Hout >= 8) return launch_fprop_halo<8>(p, st);
     return launch_fprop_halo<4>(p, st);
 }
