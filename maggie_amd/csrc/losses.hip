@@ -138,17 +138,30 @@ __global__ __launch_bounds__(NT) void pyr_lap_fwd_kernel(const float* __restrict
     for (int o = blockIdx.x * NT + threadIdx.x; o < h * w; o += gridDim.x * NT) {
         int y = o / w, xx = o - y * w;
         float up = 0.f;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            int yy = refl(y + i - 2, h);
-            if (yy & 1) continue;
-            float r = 0.f;
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                int xs = refl(xx + j - 2, w);
-                if (!(xs & 1)) r += c_g1[j] * dp[(yy >> 1) * wd + (xs >> 1)];
+        if (y >= 2 && y < h - 2 && xx >= 2 && xx < w - 2) {
+            // interior: no reflection; only the taps that hit an even (stuffed) position contribute -- i = y mod 2 (+2, +4), same for j.
+            // Same terms in the same order as the general walk below (which spends most of its time skipping the other 16-21 taps).
+            const float g1[5] = {1.f / 16.f, 4.f / 16.f, 6.f / 16.f, 4.f / 16.f, 1.f / 16.f};
+            const int i0 = y & 1, j0 = xx & 1;
+            const float* row = dp + ((y + i0 - 2) >> 1) * wd + ((xx + j0 - 2) >> 1);
+            if (j0 == 0) {
+                for (int i = i0; i < 5; i += 2, row += wd) up += g1[i] * (g1[0] * row[0] + g1[2] * row[1] + g1[4] * row[2]);
+            } else {
+                for (int i = i0; i < 5; i += 2, row += wd) up += g1[i] * (g1[1] * row[0] + g1[3] * row[1]);
             }
-            up += c_g1[i] * r;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                int yy = refl(y + i - 2, h);
+                if (yy & 1) continue;
+                float r = 0.f;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    int xs = refl(xx + j - 2, w);
+                    if (!(xs & 1)) r += c_g1[j] * dp[(yy >> 1) * wd + (xs >> 1)];
+                }
+                up += c_g1[i] * r;
+            }
         }
         float L = xp[o] - 4.f * up;
         float wl = wp[(long)(y << lvl) * W0 + (xx << lvl)];
