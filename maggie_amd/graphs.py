@@ -54,6 +54,7 @@ class _Replay(torch.autograd.Function):
             torch._foreach_zero_(zero)
         if dst:
             torch._foreach_copy_(dst, src)
+        g.prepare_sink_replay()
         g.bwd.replay()
         # gradients of the differentiable inputs are handed over as the graph's own buffers: their consumer (the producing graph's
         # backward, or autograd's accumulation) reads them during this backward pass, before any further replay can overwrite them
@@ -98,10 +99,15 @@ class GraphedCallable:
     """fn(*inputs) -> tuple of tensors, captured for fixed input shapes. `module`: the nn.Module whose parameters fn reads
     (requires_grad ones get gradients). `mutable`: tensors fn mutates in place (rolled back after warm-up)."""
 
-    def __init__(self, fn, inputs, module, mutable, training, warmup=2, grad_inputs=()):
-        """`grad_inputs`: indices of `inputs` whose gradient the caller needs back (a graph fed by another graph's outputs)."""
+    def __init__(self, fn, inputs, module, mutable, training, warmup=2, grad_inputs=(), grad_sink=None):
+        """`grad_inputs`: indices of `inputs` whose gradient the caller needs back (a graph fed by another graph's outputs).
+        `grad_sink(params) -> list of fp32 tensors | None`: where the parameter gradients should be written (FlatAdamW.grad_views: slices of
+        the optimizer's flat gradient buffer). The captured backward then ends by copying the gradients THERE, `.grad` becomes a view of the
+        optimizer's buffer and neither the export copy nor the optimizer's gather copy runs (two passes over ~120 MB per step)."""
         dev = inputs[0].device
         self.training = training
+        self.grad_sink = grad_sink
+        self.sink_views = None
         self.grad_idx = [i for i in grad_inputs if training and inputs[i].is_floating_point()]
         self.static_inputs = [i.detach().clone() for i in inputs]
         for i in self.grad_idx:
@@ -166,12 +172,16 @@ class GraphedCallable:
                 m.copy_(s)
 
     grad_hook = None         # callable(list of fresh flat gradient buffers, list of parameters): data-parallel exchange (parallel.OverlappedGradSync)
+    _sink_saved = None
 
     def export_param_grads(self):
         """Fresh copies of the parameter gradients. The backward graph ends by concatenating them into one flat buffer per
         dtype (`_pack_grads`, captured), so leaving the graph costs ONE device copy per dtype plus views. With a `grad_hook` the
         fresh buffers are handed to it first: the gradient all-reduce of THIS graph's parameters starts (on a side stream) while the
-        next backward graph of the step is still to run."""
+        next backward graph of the step is still to run. With a gradient sink (see __init__) the graph already wrote into the
+        optimizer's buffer: fresh VIEWS of it are returned (no copy)."""
+        if self.sink_views is not None:
+            return self._export_to_sink()
         out = []
         fresh = {dt: flat.clone() for dt, flat in self.flat_grads.items()}
         if self.grad_hook is not None:
@@ -180,8 +190,40 @@ class GraphedCallable:
             out.append(fresh[dt][off:off + n].view(shape))
         return tuple(out)
 
+    def prepare_sink_replay(self):
+        """Called right BEFORE the backward graph is replayed. The replay overwrites the sink slots; a gradient that is already there
+        (accumulation over several backward passes: `.grad` is set and is a view of the slot) is saved so that it can be added back."""
+        self._sink_saved = None
+        if self.sink_views is None:
+            return
+        acc = [(v, p.grad) for v, p in zip(self.sink_views, self.params) if p.grad is not None and p.grad.data_ptr() == v.data_ptr()]
+        if acc:
+            self._sink_saved = ([v for v, _ in acc], [g.clone() for _, g in acc])
+
+    def _export_to_sink(self):
+        if self._sink_saved is not None:
+            torch._foreach_add_(self._sink_saved[0], self._sink_saved[1])     # slot = earlier gradient + this backward's
+            self._sink_saved = None
+        out = []
+        for v, p in zip(self.sink_views, self.params):
+            if p.grad is None:
+                out.append(v.view(v.shape))                       # a fresh view object: AccumulateGrad adopts it, `.grad` aliases the slot
+            elif p.grad.data_ptr() == v.data_ptr():
+                out.append(None)                                  # `.grad` IS the slot and already holds the sum
+            else:
+                out.append(v.clone())                             # a foreign `.grad` tensor: autograd adds a private copy to it
+        return tuple(out)
+
     def _pack_grads(self):
         """Called INSIDE the backward capture."""
+        if self.grad_sink is not None and self.grad_hook is None:
+            views = self.grad_sink(self.params)
+            if views is not None and all(v is not None and v.dtype == g.dtype and v.shape == g.shape
+                                         for v, g in zip(views, self.static_param_grads)):
+                torch._foreach_copy_(list(views), list(self.static_param_grads))
+                self.sink_views = list(views)
+                self.flat_grads, self.grad_slots = {}, []
+                return
         by_dt = {}
         for g in self.static_param_grads:
             by_dt.setdefault(g.dtype, []).append(g)

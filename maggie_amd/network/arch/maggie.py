@@ -204,7 +204,8 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         mutable = [t for t in self.buffers()] + [p for p in self.parameters() if not p.requires_grad] + self.decoder.head_state()
         try:
             with torch.autocast('cuda', dtype=torch.bfloat16, enabled=torch.is_autocast_enabled(), cache_enabled=False):
-                g = graphs.GraphedCallable(fn, inputs, self, mutable, self.training, grad_inputs=grad_inputs)
+                g = graphs.GraphedCallable(fn, inputs, self, mutable, self.training, grad_inputs=grad_inputs,
+                                           grad_sink=self.__dict__.get('grad_sink') if self.__dict__.get('_grad_overlap') is None else None)
             overlap = self.__dict__.get('_grad_overlap')
             if overlap is not None:
                 g.grad_hook = overlap.reduce_async

@@ -86,6 +86,22 @@ class FlatAdamW(torch.optim.Optimizer):
                 st['step'] = torch.tensor(float(self._steps[i]))
         self._ptrs = [p.data_ptr() for p in ps]
 
+    def grad_views(self, params):
+        """Gradient sink for the captured backward graphs (graphs.GraphedCallable(grad_sink=...), `model.grad_sink = opt.grad_views`): fresh
+        views of the flat gradient buffer for `params`, or None when one of them is not managed here. The graphs then write the gradients
+        straight into this buffer and step() finds `.grad` already in place."""
+        if not self._intact():
+            self._build()
+        index = {id(p): i for i, p in enumerate(self._active())}
+        out = []
+        for p in params:
+            i = index.get(id(p))
+            if i is None:
+                return None
+            o = self._offsets[i]
+            out.append(self.flat_g[o:o + p.numel()].view(p.shape))
+        return out
+
     def _intact(self):
         ps = self._active()
         return len(ps) == len(self._ptrs) and all(p.data_ptr() == a for p, a in zip(ps, self._ptrs))
@@ -101,19 +117,21 @@ class FlatAdamW(torch.optim.Optimizer):
             self._build()
         g = self.param_groups[0]
         ps = self._active()
-        grads, views, have = [], [], []
+        grads, views, have, absent = [], [], [], []
         for p, gv in zip(ps, self._g_views):
             have.append(p.grad is not None)
-            if p.grad is not None:
-                grads.append(p.grad)
+            if p.grad is None:
+                absent.append(gv)
+            elif p.grad.data_ptr() != gv.data_ptr() or p.grad.dtype != torch.float32:
+                grads.append(p.grad)                              # (a gradient written into its slot by a graph's gradient sink needs no copy)
                 views.append(gv)
         sync = self.sync_group is not None
         # gradient chunks that were all-reduced on the side stream during backward: the main stream must not read them earlier
         done = self.overlap.wait() if (sync and self.overlap is not None) else set()
-        if not grads and not sync:
+        if not any(have) and not sync:
             return loss
-        if len(grads) != len(ps):
-            self.flat_g.zero_()                                   # absent gradients must not count in the norm
+        if absent:
+            torch._foreach_zero_(absent)                          # absent gradients must not count in the norm
         if grads:
             torch._foreach_copy_(views, grads)
         if sync:
