@@ -545,6 +545,195 @@ extern "C" int mg_bn_bwd_apply(const mg_rowwise_params* p, void* stream) {
     return 0;
 }
 
+// =====================================================================================================================
+// Small BatchNorm layers in ONE launch per direction (M <= 4096 rows: the OS16 / OS32 layers, ~30 of the 71 per step).
+// A workgroup OWNS one 16-byte channel chunk (8 bf16 / 4 fp32 channels) over all rows: every thread keeps its <= 16 rows of the chunk in
+// registers, so x is read once, the exact two-pass variance comes from registers, and -- because no other workgroup touches these
+// channels -- there are no atomics, no zeroed accumulators and no cross-workgroup ordering: statistics, finalize (scale / shift / mean /
+// invstd, running statistics) and apply are one kernel (were 4 launches, ~25 us at the ~5 us latency floor each); backward: reduce + apply
+// in one (were 2). The strided 16-byte column reads are served from L2 (these tensors are <= 4 MB).
+// =====================================================================================================================
+template <int CE>
+__device__ __forceinline__ void block_sum_vec(float* v, float* sred) {            // sum of v[0..CE) over the 256 threads, result in every thread
+#pragma unroll
+    for (int e = 0; e < CE; ++e) v[e] = wave_sum(v[e]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();                                                              // sred may still be read from the previous reduction
+    if (lane == 0) {
+#pragma unroll
+        for (int e = 0; e < CE; ++e) sred[wave * CE + e] = v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < CE; ++e) v[e] = (sred[e] + sred[CE + e]) + (sred[2 * CE + e] + sred[3 * CE + e]);
+}
+
+template <typename T, int RPT>
+__global__ __launch_bounds__(NT) void bn_small_fwd_kernel(const mg_rowwise_params p, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* running_mean, float* running_var, float momentum, float eps, float* __restrict__ outs) {
+    using TR = ElemTraits<T>;
+    constexpr int CE = TR::CE;
+    __shared__ float sred[4 * CE];
+    const int c0 = blockIdx.x * CE, t = threadIdx.x, M = p.M, C = p.C;
+    const T* __restrict__ x = (const T*)p.x;
+    uint4 q[RPT];
+    float s[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int m = t + k * NT;
+        q[k] = m < M ? *(const uint4*)(x + (long)m * p.ldx + c0) : make_uint4(0, 0, 0, 0);
+        float f[CE];
+        TR::unpack(q[k], f);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) s[e] += f[e];                               // rows beyond M hold zeros
+    }
+    block_sum_vec<CE>(s, sred);
+    const float inv_n = 1.f / (float)M;
+    float mean[CE], var[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { mean[e] = s[e] * inv_n; var[e] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        if (t + k * NT < M) {
+            float f[CE];
+            TR::unpack(q[k], f);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) { const float d = f[e] - mean[e]; var[e] += d * d; }
+        }
+    }
+    block_sum_vec<CE>(var, sred);
+    float sc[CE], sh[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+        var[e] = fmaxf(var[e] * inv_n, 0.f);
+        const float invstd = rsqrtf(var[e] + eps);
+        const float g = gamma ? gamma[c0 + e] : 1.f, b = beta ? beta[c0 + e] : 0.f;
+        sc[e] = g * invstd; sh[e] = b - mean[e] * g * invstd;
+        if (t == 0) {
+            const int c = c0 + e;
+            outs[c] = sc[e]; outs[C + c] = sh[e]; outs[2 * C + c] = mean[e]; outs[3 * C + c] = invstd;
+            if (running_mean) {
+                const float n = (float)M, unbiased = n > 1.f ? var[e] * n / (n - 1.f) : var[e];
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean[e];
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+            }
+        }
+    }
+    const T* __restrict__ r1 = (const T*)p.res;
+    const T* __restrict__ r2 = (const T*)p.res2;
+    T* __restrict__ y = (T*)p.y;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int m = t + k * NT;
+        if (m >= M) continue;
+        float f[CE], a[CE], b[CE];
+        TR::unpack(q[k], f);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) { a[e] = 0.f; b[e] = 0.f; }
+        if (r1) {
+            long rrow = m;
+            if (p.res_mode == 2) {
+                const int hw = p.H * p.W; const int n = m / hw; const int rem = m - n * hw; const int ho = rem / p.W; const int wo = rem - ho * p.W;
+                rrow = ((long)n * (p.H >> 1) + (ho >> 1)) * (p.W >> 1) + (wo >> 1);
+            }
+            TR::unpack(*(const uint4*)(r1 + rrow * p.ldr + c0), a);
+        }
+        if (r2) TR::unpack(*(const uint4*)(r2 + (long)m * p.ldr2 + c0), b);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) f[e] = apply_act(f[e] * sc[e] + sh[e] + a[e], p.act, p.slope) + b[e];
+        *(uint4*)(y + (long)m * p.ldy + p.yoff + c0) = TR::pack(f);
+    }
+}
+
+template <typename T, int RPT>
+__global__ __launch_bounds__(NT) void bn_small_bwd_kernel(const mg_rowwise_params p) {
+    using TR = ElemTraits<T>;
+    constexpr int CE = TR::CE;
+    __shared__ float sred[4 * CE];
+    const int c0 = blockIdx.x * CE, t = threadIdx.x, M = p.M, C = p.C;
+    float mu[CE], is[CE], sg[CE], sgx[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { mu[e] = p.mean[c0 + e]; is[e] = p.invstd[c0 + e]; sg[e] = 0.f; sgx[e] = 0.f; }
+    float g[RPT][CE];
+    uint4 qx[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int m = t + k * NT;
+        if (m < M) {
+            load_g<T>(p, m, c0, g[k]);
+            qx[k] = *(const uint4*)((const T*)p.x + (long)m * p.ldx + c0);
+            float xv[CE];
+            TR::unpack(qx[k], xv);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) { sg[e] += g[k][e]; sgx[e] += g[k][e] * (xv[e] - mu[e]) * is[e]; }
+        } else {
+            qx[k] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) g[k][e] = 0.f;
+        }
+    }
+    block_sum_vec<CE>(sg, sred);
+    block_sum_vec<CE>(sgx, sred);
+    if (t == 0) {
+#pragma unroll
+        for (int e = 0; e < CE; ++e) { p.sums[c0 + e] = sg[e]; p.sums[C + c0 + e] = sgx[e]; }
+    }
+    const float inv_n = 1.f / p.count;
+    float sc[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) sc[e] = p.scale[c0 + e];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int m = t + k * NT;
+        if (m >= M) continue;
+        if (p.dres) *(uint4*)((T*)p.dres + (long)m * p.lddres + c0) = TR::pack(g[k]);
+        if (p.dx) {
+            float xv[CE], o[CE];
+            TR::unpack(qx[k], xv);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
+                const float xh = (xv[e] - mu[e]) * is[e];
+                float v = sc[e] * (g[k][e] - sg[e] * inv_n - xh * sgx[e] * inv_n);
+                if (p.mask_x_pos && !(xv[e] > 0.f)) v = 0.f;
+                o[e] = v;
+            }
+            *(uint4*)((T*)p.dx + (long)m * p.lddx + c0) = TR::pack(o);
+        }
+    }
+}
+
+static bool bn_small_ok(const mg_rowwise_params& p) {
+    // rows up to which the one-launch form is used: a workgroup reads its 16-byte column slice with a row stride, i.e. one cache line per
+    // lane -- at 4096 rows x 32 workgroups that costs as much as the four coalesced launches it replaces (24.8 us forward, 33.7 us backward
+    // against ~25 / ~17 us); at 1024 rows (64 workgroups x 4 rows per thread) it is 12 us each way. MG_BN_SMALL_ROWS=0 switches it off.
+    static const int max_rows = [] { const char* e = getenv("MG_BN_SMALL_ROWS"); return e ? atoi(e) : 1024; }();
+    const int ce = p.dtype == MG_BF16 ? 8 : 4;
+    return !p.m_dev && !p.count_ptr && p.M > 1 && p.M <= max_rows && p.M <= 16 * NT && p.C % ce == 0 && p.ldx % ce == 0;
+}
+template <typename T>
+static int bn_small_fwd_launch(const mg_rowwise_params& p, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                               float eps, float* outs, hipStream_t st) {
+    const int ce = ElemTraits<T>::CE;
+    dim3 grid(p.C / ce);
+    if (p.M <= 4 * NT) hipLaunchKernelGGL((bn_small_fwd_kernel<T, 4>), grid, dim3(NT), 0, st, p, gamma, beta, running_mean, running_var, momentum, eps, outs);
+    else if (p.M <= 8 * NT) hipLaunchKernelGGL((bn_small_fwd_kernel<T, 8>), grid, dim3(NT), 0, st, p, gamma, beta, running_mean, running_var, momentum, eps, outs);
+    else hipLaunchKernelGGL((bn_small_fwd_kernel<T, 16>), grid, dim3(NT), 0, st, p, gamma, beta, running_mean, running_var, momentum, eps, outs);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+template <typename T>
+static int bn_small_bwd_launch(const mg_rowwise_params& p, hipStream_t st) {
+    const int ce = ElemTraits<T>::CE;
+    dim3 grid(p.C / ce);
+    if (p.M <= 4 * NT) hipLaunchKernelGGL((bn_small_bwd_kernel<T, 4>), grid, dim3(NT), 0, st, p);
+    else if (p.M <= 8 * NT) hipLaunchKernelGGL((bn_small_bwd_kernel<T, 8>), grid, dim3(NT), 0, st, p);
+    else hipLaunchKernelGGL((bn_small_bwd_kernel<T, 16>), grid, dim3(NT), 0, st, p);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- one-call training BatchNorm (the four / two launches above behind ONE entry point: the per-call host cost of the Python
 // binding -- argument marshalling, allocations, autograd bookkeeping -- is paid once instead of per kernel; this matters for the
 // host-paced sparse head, where a BatchNorm forward cost 51 us of host time for ~15 us of kernels) ------------------------------
@@ -557,6 +746,9 @@ extern "C" int mg_bn_train_fwd(const mg_rowwise_params* p_in, float* stats_ws, i
     hipStream_t st = (hipStream_t)stream;
     float* own = stats_ws;                               // [2C] (exact) or [MG_STAT_REPLICAS][2C] statistics scratch; outs: scale | shift | mean | invstd
     if (!stats_in && !own) return -3;
+    if (exact && bn_small_ok(p))                         // one launch: the statistics never leave the registers (stats_in / stats_ws unused)
+        return p.dtype == MG_BF16 ? bn_small_fwd_launch<bf16raw>(p, gamma, beta, running_mean, running_var, momentum, eps, outs, st)
+                                  : bn_small_fwd_launch<float>(p, gamma, beta, running_mean, running_var, momentum, eps, outs, st);
     const float* stats = stats_in;
     int nrep = stats_in_rows, centered = 0;
     if (p.m_dev) {
@@ -591,6 +783,8 @@ extern "C" int mg_bn_train_fwd(const mg_rowwise_params* p_in, float* stats_ws, i
 
 extern "C" int mg_bn_train_bwd(const mg_rowwise_params* p, int sums_zeroed, void* stream) {
     int rc = rowwise_check(p); if (rc) return rc;
+    if (bn_small_ok(*p) && p->lddy % (p->dtype == MG_BF16 ? 8 : 4) == 0)
+        return p->dtype == MG_BF16 ? bn_small_bwd_launch<bf16raw>(*p, (hipStream_t)stream) : bn_small_bwd_launch<float>(*p, (hipStream_t)stream);
     if (!sums_zeroed) {
         hipError_t e = mg_zero_words(p->sums, 2 * p->C, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
