@@ -1760,6 +1760,177 @@ __global__ __launch_bounds__(256) void igemm_wgrad_halo_kernel(const mg_conv_par
     MG_STAMP(15);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// All-taps weight gradient of the sparse head's 3x3 gather convolutions (MG_MODE_GATHER, bf16): one block = one (co tile, 32-channel ci
+// tile) of all NINE taps over a range of active rows. Per 64-row stage the dY rows are staged ONCE and the nine neighbour rows of x are
+// gathered through the neighbour table into nine LDS tiles; the per-tap kernel above re-reads dY nine times (it is L2-bandwidth bound:
+// 370 MB per C64 launch). Same MFMA structure as the halo kernel (transposed LDS reads, waves own quadrants, fp32 slabs per row split); the
+// row count is a device word: the fixed grid divides the live rows evenly, empty splits write zero slabs.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int FM>
+__global__ __launch_bounds__(256) void igemm_wgrad_gather9_kernel(const mg_conv_params p, int nsplit, float* __restrict__ ws) {
+    constexpr int FN = 1, TCO = 32 * FM, TCI = 32, RC = 64;
+    constexpr int PY = TCO + 16, PX = TCI + 16;
+    constexpr int CPY = TCO / 8, CPX = TCI / 8;
+    constexpr int NY = RC * CPY, NX = 9 * RC * CPX;
+    constexpr int ITY = (NY + 255) / 256, ITX = NX / 256;        // 9 * 64 * 4 / 256 = 9
+    static_assert(NX % 256 == 0, "gather staging");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16raw* sY = (bf16raw*)smem;                                // [RC][PY]
+    bf16raw* sX = sY + RC * PY;                                  // [9][RC][PX]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int wco = (wave >> 1) * FM * 16, wci = (wave & 1) * FN * 16;
+    const int nci = p.Cin / TCI, nco = p.Cout / TCO;
+    int work;
+    if (!xcd_order(nsplit * nco * nci, work)) return;
+    const int cc = work % (nco * nci), split = work / (nco * nci);
+    const int co0 = (cc / nci) * TCO, ci0 = (cc % nci) * TCI;
+    const int M = dev_rows(p.m_dev, p.M);
+    const int rps = (((M + nsplit - 1) / nsplit + RC - 1) / RC) * RC;
+    const int mbeg = split * rps, mend = min(M, mbeg + rps);
+    const bf16raw* __restrict__ yb = (const bf16raw*)p.y;
+    const bf16raw* __restrict__ xb = (const bf16raw*)p.x;
+
+    uint4 ry[ITY], rx[ITX];
+    auto load_stage = [&](int mb) {
+#pragma unroll
+        for (int i = 0; i < ITY; ++i) {
+            const int idx = t + i * 256;
+            const int row = idx / CPY, c = idx - row * CPY;
+            const int m = mb + row;
+            ry[i] = (idx < NY && m < mend) ? *(const uint4*)(yb + (long)m * p.ldy + p.yoff + co0 + c * 8) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < ITX; ++i) {
+            const int idx = t + i * 256;                         // (tap, row, chunk): chunk fastest, then row, then tap
+            const int c = idx % CPX, row = (idx / CPX) % RC, tap = idx / (CPX * RC);
+            const int m = mb + row;
+            int src = -1;
+            if (m < mend) src = p.nbr[(long)m * 9 + tap];
+            rx[i] = src >= 0 ? *(const uint4*)(xb + (long)src * p.ldx + ci0 + c * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < ITY; ++i) {
+            const int idx = t + i * 256;
+            const int row = idx / CPY, c = idx - row * CPY;
+            if (idx < NY) *(uint4*)(sY + row * PY + c * 8) = ry[i];
+        }
+#pragma unroll
+        for (int i = 0; i < ITX; ++i) {
+            const int idx = t + i * 256;
+            const int c = idx % CPX, row = (idx / CPX) % RC, tap = idx / (CPX * RC);
+            *(uint4*)(sX + (tap * RC + row) * PX + c * 8) = rx[i];
+        }
+    };
+
+    f32x4 acc[9][FM][FN];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[tp][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int q = g * 4 + (li >> 2), cq = (li & 3) * 4;
+    if (mbeg < mend) load_stage(mbeg);
+    for (int mb = mbeg; mb < mend; mb += RC) {
+        store_stage();
+        __syncthreads();
+        if (mb + RC < mend) load_stage(mb + RC);
+#pragma unroll
+        for (int kc = 0; kc < RC / 32; ++kc) {
+            s16x4 a[FM][2];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                a[i][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sY + (kc * 32 + q) * PY + wco + i * 16 + cq));
+                a[i][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sY + (kc * 32 + 16 + q) * PY + wco + i * 16 + cq));
+            }
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                s16x4 b[FN][2];
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    b[j][0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sX + (tp * RC + kc * 32 + q) * PX + wci + j * 16 + cq));
+                    b[j][1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sX + (tp * RC + kc * 32 + 16 + q) * PX + wci + j * 16 + cq));
+                }
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        union { s16x4 h[2]; bf16x8 v; } ua, ub;
+                        ua.h[0] = a[i][0]; ua.h[1] = a[i][1]; ub.h[0] = b[j][0]; ub.h[1] = b[j][1];
+                        acc[tp][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc[tp][i][j], 0, 0, 0);
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    float* __restrict__ slab = ws + (long)split * p.Cout * 9 * p.Cin;
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    slab[((long)(co0 + wco + i * 16 + g * 4 + e) * 9 + tp) * p.Cin + ci0 + wci + j * 16 + li] = acc[tp][i][j][e];
+}
+
+static inline bool wgrad_gather9_eligible(const mg_conv_params& p) {
+    static const int on = [] { const char* e = getenv("MG_WGRAD_GATHER9"); return e ? atoi(e) : 1; }();
+    // Cin >= 64 only: at Cin 32 (the OS1 level: ~20 stages of 64 rows per block, 18 MFMAs per stage) the kernel is bound by the gather latency
+    // of its short stages and the per-tap kernel's 128-row steps win (measured 52 -> 64 us); at Cin 64: 55 -> 27, 54 -> 41, 32 -> 23 us
+    return on && p.dtype == MG_BF16 && p.mode == MG_MODE_GATHER && p.nbr && p.R * p.S == 9 && p.Cin % 64 == 0 && p.Cout % 32 == 0 &&
+           p.ldx % 8 == 0 && p.ldy % 8 == 0 && p.yoff % 8 == 0 && (long)p.Cout * 9 * p.Cin <= (16l << 20) && p.M >= 256;
+}
+static long plan_wgrad_gather9(const mg_conv_params& p) {
+    // ~512 workgroups (two fit a CU), bounded by ~20 MB of fp32 partial slabs (written once, read once by the reduce)
+    static const long target = [] { const char* e = getenv("MG_WGRAD_GATHER_BLOCKS"); return e ? atol(e) : 512l; }();
+    static const long ws_cap = [] { const char* e = getenv("MG_WGRAD_GATHER_WS_MB"); return (e ? atol(e) : 20l) << 18; }();   // floats
+    const int tco = p.Cout % 64 == 0 ? 64 : 32;
+    const long cc = (long)(p.Cout / tco) * (p.Cin / 32);
+    const long n = (long)p.Cout * 9 * p.Cin;
+    long splits = (target + cc - 1) / cc;
+    const long by_rows = (p.M + 127) / 128;
+    if (splits > by_rows) splits = by_rows;
+    if (splits > ws_cap / n) splits = ws_cap / n;
+    return splits < 1 ? 1 : splits;
+}
+static int launch_wgrad_gather9(const mg_conv_params& p, float* ws, long ws_floats, hipStream_t st) {
+    const long splits = plan_wgrad_gather9(p);
+    const long n = (long)p.Cout * 9 * p.Cin;
+    const bool out_bf16 = p.dw_dtype == MG_BF16;
+    if (!ws || ws_floats < splits * n) return -4;
+    const int tco = p.Cout % 64 == 0 ? 64 : 32;
+    const long cc = (long)(p.Cout / tco) * (p.Cin / 32);
+    dim3 grid(xcd_grid(splits * cc));
+    const size_t lds = (size_t)(64 * (tco + 16) + 9 * 64 * (32 + 16)) * sizeof(bf16raw);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)igemm_wgrad_gather9_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)igemm_wgrad_gather9_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr_set = true;
+    }
+    if (tco == 64) hipLaunchKernelGGL((igemm_wgrad_gather9_kernel<2>), grid, dim3(256), lds, st, p, (int)splits, ws);
+    else hipLaunchKernelGGL((igemm_wgrad_gather9_kernel<1>), grid, dim3(256), lds, st, p, (int)splits, ws);
+    if (splits >= 8) {
+        const long b = (n + 31) / 32;
+        if (out_bf16) hipLaunchKernelGGL(wgrad_reduce_tile_kernel<bf16raw>, dim3((unsigned)b), dim3(256), 0, st, ws, (int)splits, n, (bf16raw*)p.stats);
+        else hipLaunchKernelGGL(wgrad_reduce_tile_kernel<float>, dim3((unsigned)b), dim3(256), 0, st, ws, (int)splits, n, p.stats);
+    } else {
+        long b = (n + 255) / 256; if (b > 2048) b = 2048;
+        if (out_bf16) hipLaunchKernelGGL(wgrad_reduce_kernel<bf16raw>, dim3((unsigned)b), dim3(256), 0, st, ws, (int)splits, n, (bf16raw*)p.stats);
+        else hipLaunchKernelGGL(wgrad_reduce_kernel<float>, dim3((unsigned)b), dim3(256), 0, st, ws, (int)splits, n, p.stats);
+    }
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
 static inline bool wgrad_halo_eligible(const mg_conv_params& p) {
     static const int on = [] { const char* e = getenv("MG_WGRAD_HALO"); return e ? atoi(e) : 1; }();
     return on && p.dtype == MG_BF16 && p.mode == MG_MODE_CONV && !p.m_dev && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad == 1 && p.dil == 1 &&
@@ -1892,6 +2063,11 @@ template <typename T>
 int dispatch_wgrad(const mg_conv_params& p, float* ws, long ws_floats, long* need, hipStream_t st) {
     const bool small_co = p.Cout <= 32, small_ci = p.Cin <= 32;
     const long n = (long)p.Cout * p.R * p.S * p.Cin;
+    if (sizeof(T) == 2 && wgrad_gather9_eligible(p)) {
+        const long splits = plan_wgrad_gather9(p);
+        if (need) { *need = splits * n; return 0; }
+        if (ws && ws_floats >= splits * n) return launch_wgrad_gather9(p, ws, ws_floats, st);
+    }
     if (sizeof(T) == 2 && wgrad_halo_eligible(p)) {
         if (need) { const WgradHaloPlan pl = plan_wgrad_halo(p); *need = (pl.splits > 1 || p.dw_dtype == MG_BF16) ? pl.splits * n : 0; return 0; }
         const WgradHaloPlan pl = plan_wgrad_halo(p);
