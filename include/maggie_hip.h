@@ -248,7 +248,9 @@ int mg_plane_flags(const float* w, int P, int HW, int32_t* flags, void* stream);
 /* loss weight of the OS8 prediction (arch/maggie.py:271-281): out = [plane p of gt has a positive pixel] + (reweight && (gt or a8 in
  * [1/255, 254/255])); fp32 planes [P][HW]; flags_scratch: P int32 */
 int mg_os8_weight(const float* gt, const float* a8, int P, long HW, int reweight, int32_t* flags_scratch, float* out, void* stream);
-/* sums[9] = [l1, grad, w, lap0, w0, lap1, w1, lap2, w2] (accumulated by mg_loss_point_fwd / mg_pyr_lap_fwd) -> out3 = (rec, lap, grad)
+/* sums = 32 replicas x 16 floats (512 zeroed floats; a workgroup adds to replica `its index mod 32`: same-address atomics were the kernels' bound),
+ * each replica [l1, grad, w, lap0, w0, lap1, w1, lap2, w2, ...] (accumulated by mg_loss_point_fwd / mg_pyr_lap_fwd; mg_pyr_lap_fwd takes
+ * `sums + 3 + 2 * level`); the replicas are summed here -> out3 = (rec, lap, grad)
  * with the reference's normalisations (arch/maggie.py:237-262: eps 1e-8 on the L1 term; loss.py:137-191: eps 1e-6, 3-fold LapLoss);
  * mg_loss_coef: upstream gradient g3 of those three -> the five per-term coefficients the backward kernels take. */
 int mg_loss_finish(const float* sums, float* out3, void* stream);

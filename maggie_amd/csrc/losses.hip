@@ -20,6 +20,11 @@ __device__ __constant__ float c_g1[5] = {1.f / 16.f, 4.f / 16.f, 6.f / 16.f, 4.f
 __device__ __forceinline__ int refl(int k, int n) { return k < 0 ? -k : (k >= n ? 2 * (n - 1) - k : k); }
 __device__ __forceinline__ int clampi(int k, int n) { return k < 0 ? 0 : (k >= n ? n - 1 : k); }
 
+// The loss accumulators are REPLICATED: [LOSS_REPLICAS][LOSS_STRIDE] floats, a workgroup adds to replica (its index mod 32). With one copy every
+// workgroup of a launch ended in 2-3 same-address atomics, and those -- not the stencils -- set the kernel time (point_fwd 36 -> 52 -> 86 us
+// at 48 / 128 / 256 workgroups per plane); loss_finish / loss_coef sum the replicas.
+constexpr int LOSS_REPLICAS = 32, LOSS_STRIDE = 16;
+
 __device__ __forceinline__ void block_add(float v, float* dst, float* sh) {
     v = wave_sum(v);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -39,7 +44,8 @@ __global__ __launch_bounds__(NT) void plane_flags_kernel(const float* __restrict
     const float* wp = w + (long)p * HW;
     int any = 0;
     for (int i = blockIdx.x * NT + threadIdx.x; i < HW; i += gridDim.x * NT) any |= (wp[i] > 0.f);
-    if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(&flags[p], 1);
+    // every writer stores the same value: a plain store (no read-modify-write) is enough, and one per workgroup instead of one atomic per wave
+    if (__syncthreads_or(any) && threadIdx.x == 0) flags[p] = 1;
 }
 
 // loss weight of the OS8 prediction (maggie/network/arch/maggie.py:271-281): w = [plane has ground truth] + [pixel is in the unknown band
@@ -96,9 +102,10 @@ __global__ __launch_bounds__(NT) void point_fwd_kernel(const float* __restrict__
         float mt = sobel_mag(tp, wp, y, x, H, W, gx, gy);
         s1 += fabsf(mp - mt);
     }
-    block_add(s0, &sums[0], sh);
-    block_add(s1, &sums[1], sh);
-    block_add(s2, &sums[2], sh);
+    float* srep = sums + ((blockIdx.y * gridDim.x + blockIdx.x) & (LOSS_REPLICAS - 1)) * LOSS_STRIDE;   // spread the same-address atomics
+    block_add(s0, &srep[0], sh);
+    block_add(s1, &srep[1], sh);
+    block_add(s2, &srep[2], sh);
 }
 
 // out[P, h/2, w/2] = (gauss5 * x)(2y, 2x), reflect padding
@@ -135,7 +142,14 @@ __global__ __launch_bounds__(NT) void pyr_lap_fwd_kernel(const float* __restrict
     const float* dp = down + (long)pl * hd * wd;
     const float* wp = w0 + (long)pl * H0 * W0;
     float s0 = 0.f, s1 = 0.f;
-    for (int o = blockIdx.x * NT + threadIdx.x; o < h * w; o += gridDim.x * NT) {
+    // four pixels per trip (independent chains: the plane is walked by few workgroups -- their count is bounded by the two same-address
+    // atomics each ends with -- so a thread's ~20 pixels were ~20 exposed memory round trips)
+    const int stride = gridDim.x * NT;
+    for (int o4 = blockIdx.x * NT + threadIdx.x; o4 < h * w; o4 += 4 * stride)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int o = o4 + u * stride;
+        if (o >= h * w) break;
         int y = o / w, xx = o - y * w;
         float up = 0.f;
         if (y >= 2 && y < h - 2 && xx >= 2 && xx < w - 2) {
@@ -169,8 +183,9 @@ __global__ __launch_bounds__(NT) void pyr_lap_fwd_kernel(const float* __restrict
         s1 += wl;
         G[(long)pl * h * w + o] = L > 0.f ? wl : (L < 0.f ? -wl : 0.f);
     }
-    block_add(s0, &sums[0], sh);
-    block_add(s1, &sums[1], sh);
+    float* srep = sums + ((blockIdx.y * gridDim.x + blockIdx.x) & (LOSS_REPLICAS - 1)) * LOSS_STRIDE;
+    block_add(s0, &srep[0], sh);
+    block_add(s1, &srep[1], sh);
 }
 
 // r[P, h/2, w/2] = add - coef * U^T(q),  U = 4 * gauss5 * zero_stuff (reflect); q: [P, h, w]
@@ -329,11 +344,21 @@ inline dim3 grid2(long per_plane, int P, long max_blocks = 1024) {
 }
 // kernels that end with one atomicAdd per sum per block: every block hits the same 2-3 addresses, so keep the block count low
 // (8 planes x 1024 blocks x 3 same-address atomics cost more than the stencil itself)
-constexpr long REDUCING_BLOCKS_PER_PLANE = 48;
+static const long REDUCING_BLOCKS_PER_PLANE = [] { const char* e = getenv("MG_LOSS_BLOCKS"); return e ? atol(e) : 256l; }();
 
 // sums = [l1, grad, w, lap0, w0, lap1, w1, lap2, w2] -> (rec, lap, grad) exactly as arch/maggie.py:237-262 / loss.py:67-191
 // normalise them (eps 1e-8 for the L1 term, 1e-6 for the others; LapLoss is the 3-fold channel sum)
-__global__ void loss_finish_kernel(const float* __restrict__ sums, float* __restrict__ out) {
+__device__ __forceinline__ void loss_sum_replicas(const float* __restrict__ rep, float* s) {      // 64 threads; result in s[0..16) (shared)
+    if (threadIdx.x < LOSS_STRIDE) {
+        float a = 0.f;
+        for (int r = 0; r < LOSS_REPLICAS; ++r) a += rep[r * LOSS_STRIDE + threadIdx.x];
+        s[threadIdx.x] = a;
+    }
+    __syncthreads();
+}
+__global__ void loss_finish_kernel(const float* __restrict__ rep, float* __restrict__ out) {
+    __shared__ float sums[LOSS_STRIDE];
+    loss_sum_replicas(rep, sums);
     if (threadIdx.x == 0) {
         out[0] = sums[0] / (sums[2] + 1e-8f);
         out[1] = 3.0f * (sums[3] / (sums[4] + 1e-6f) + sums[5] / (sums[6] + 1e-6f) + sums[7] / (sums[8] + 1e-6f));
@@ -341,7 +366,9 @@ __global__ void loss_finish_kernel(const float* __restrict__ sums, float* __rest
     }
 }
 // upstream gradient (d rec, d lap, d grad) -> the five per-term coefficients of the backward kernels
-__global__ void loss_coef_kernel(const float* __restrict__ g, const float* __restrict__ sums, float* __restrict__ coef) {
+__global__ void loss_coef_kernel(const float* __restrict__ g, const float* __restrict__ rep, float* __restrict__ coef) {
+    __shared__ float sums[LOSS_STRIDE];
+    loss_sum_replicas(rep, sums);
     if (threadIdx.x == 0) {
         coef[0] = g[0] / (sums[2] + 1e-8f);
         coef[1] = g[2] / (sums[2] + 1e-6f);

@@ -943,7 +943,7 @@ class MattingLosses(torch.autograd.Function):
         ptr, st = K.hip.ptr, K.hip.stream
         flags = torch.empty(P, dtype=torch.int32, device=dev)
         hipc('mg_plane_flags', ptr(w), c_int(P), c_int(H * W_), ptr(flags), st())
-        sums = torch.zeros(9, dtype=torch.float32, device=dev)          # [l1, grad, w, lap0, w0, lap1, w1, lap2, w2]
+        sums = torch.zeros(32 * 16, dtype=torch.float32, device=dev)    # 32 replicas x [l1, grad, w, lap0, w0, lap1, w1, lap2, w2, pad]: see mg_loss_finish
         d = torch.empty((P, H, W_), dtype=torch.float32, device=dev)
         hipc('mg_loss_point_fwd', ptr(p), ptr(t), ptr(w), ptr(flags), c_int(P), c_int(H), c_int(W_), ptr(d), ptr(sums), st())
         x, h, ww = d, H, W_
