@@ -525,7 +525,11 @@ extern "C" int mg_bn_bwd_reduce(const mg_rowwise_params* p, void* stream) {
     int rc = rowwise_check(p); if (rc) return rc;
     if (p->M <= 0) return 0;
     const int ce = p->dtype == MG_BF16 ? 8 : 4;
-    static const int max_rb = [] { const char* e = getenv("MG_BN_RB"); return e ? atoi(e) : 512; }();
+    // row blocks: every block ends with one atomic per channel, all blocks on the same 2C addresses -- past ~256 blocks those serialise into a
+    // tail longer than what the extra parallelism buys, except on the largest tensors (measured, us at 128 / 256 / 512 / 1024 row blocks:
+    // 1M x 32: 109 / 60 / 45 / 52; 262144 x 64: 56 / 35 / 31 / 43; 262144 x 32: 29 / 21.5 / 24 / 36; 65536 x 64: 19 / 13 / 19 / 19)
+    static const int env_rb = [] { const char* e = getenv("MG_BN_RB"); return e ? atoi(e) : 0; }();
+    const int max_rb = env_rb > 0 ? env_rb : ((long)p->M * p->C >= (16l << 20) ? 512 : 256);
     const ColGeom g = col_geom(p->M, p->C, ce, max_rb);
     const size_t lds = (size_t)g.ty * g.tx * 2 * ce * sizeof(float);
     if (p->dtype == MG_BF16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty);
