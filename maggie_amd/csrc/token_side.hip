@@ -328,7 +328,10 @@ extern "C" int mg_token_linear_bwd(const float* dy, const float* x, const float*
     static bool attr_b = false;
     if (!attr_b) { (void)hipFuncSetAttribute((const void*)token_linear_bwd_main_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_b = true; }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(token_linear_dz_kernel, dim3((R + 3) / 4), dim3(NT), 0, st, dy, yout, relu, gamma, z, rstat, dz, dres, R, N);
+    // a plain linear layer (no LayerNorm, no ReLU) has dz == dy: the caller passes dz = dy (and takes dy as the residual gradient) and the dz
+    // kernel is skipped
+    if (gamma || relu || dz != dy || dres)
+        hipLaunchKernelGGL(token_linear_dz_kernel, dim3((R + 3) / 4), dim3(NT), 0, st, dy, yout, relu, gamma, z, rstat, dz, dres, R, N);
     const int nrb = dx ? (R + RB - 1) / RB : 0;
     hipLaunchKernelGGL(token_linear_bwd_main_kernel, dim3(nrb + (N + CB - 1) / CB), dim3(NT), dx ? (lds_r > lds_c ? lds_r : lds_c) : lds_c, st, nrb,
                        (const float*)dz, dy, x, xadd, W, gamma, z, rstat, dx, dW, db, dgamma, dbeta, R, K, N);

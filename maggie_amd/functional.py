@@ -1324,9 +1324,10 @@ class TokenLinear(torch.autograd.Function):
         dx = torch.empty((R, Kd), dtype=torch.float32, device=dev) if need_dx else None
         dW = torch.empty((N, Kd), dtype=torch.float32, device=dev)
         db = torch.empty(N, dtype=torch.float32, device=dev) if has_b else None
-        dres = torch.empty((R, N), dtype=torch.float32, device=dev) if has_res else None
+        plain = g_ is None and not relu                      # dz == dy: no dz kernel, the residual gradient IS dy
+        dres = torch.empty((R, N), dtype=torch.float32, device=dev) if (has_res and not plain) else None
         dgb = torch.empty(2 * N, dtype=torch.float32, device=dev) if g_ is not None else None
-        dz = torch.empty((R, N), dtype=torch.float32, device=dev)
+        dz = dy2 if plain else torch.empty((R, N), dtype=torch.float32, device=dev)
         K.hip.call('mg_token_linear_bwd', K.hip.ptr(dy2), K.hip.ptr(x2), K.hip.ptr(xa), K.hip.ptr(W_), K.hip.ptr(yout), K.c_int(int(relu)), K.hip.ptr(g_),
                    K.hip.ptr(z), K.hip.ptr(rstat), K.hip.ptr(dx), K.hip.ptr(dW), K.hip.ptr(db), K.hip.ptr(dres),
                    K.hip.ptr(None if dgb is None else dgb[:N]), K.hip.ptr(None if dgb is None else dgb[N:]), K.hip.ptr(dz), K.c_int(R), K.c_int(Kd),
@@ -1335,6 +1336,8 @@ class TokenLinear(torch.autograd.Function):
         dxadd = None
         if xadd_shape is not None and ctx.needs_input_grad[1]:
             dxadd = dxv if tuple(xadd_shape) == tuple(shape) else dxv.sum_to_size(xadd_shape)
+        if plain and has_res:
+            dres = dy2
         return (dxv if ctx.needs_input_grad[0] else None, dxadd, dW, db, None if dres is None else dres.view(*shape[:-1], N), None,
                 None if dgb is None else dgb[:N], None if dgb is None else dgb[N:], None)
 
