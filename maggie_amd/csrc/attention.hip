@@ -404,6 +404,22 @@ constexpr int TT = 10;
 
 }  // namespace
 
+// zero n buffers, merging runs that are adjacent in memory (in the given order) into one fill launch
+static int zero_adjacent(float* const* bufs, const long* words, int n, hipStream_t st) {
+    int i = 0;
+    while (i < n) {
+        if (!bufs[i] || words[i] <= 0) { ++i; continue; }
+        float* base = bufs[i];
+        long total = words[i];
+        int j = i + 1;
+        while (j < n && bufs[j] && words[j] > 0 && bufs[j] == base + total) { total += words[j]; ++j; }
+        hipError_t e = mg_zero_words(base, total, st);
+        if (e != hipSuccess) return (int)e;
+        i = j;
+    }
+    return 0;
+}
+
 extern "C" int mg_attn_tok_fwd(const float* qk, const float* btab, const float* feat, const int32_t* ids, int B, int T, int L, int Dm, int NID,
                                float scale, float* p, float* ctx, void* stream) {
     int rc = attn_check(B, T, L, Dm, NID); if (rc) return rc;
@@ -421,9 +437,11 @@ extern "C" int mg_attn_tok_bwd(const float* p, const float* feat, const float* q
                                void* stream) {
     int rc = attn_check(B, T, L, Dm, NID); if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = mg_zero_words(rowdot, (long)B * T, st); if (e != hipSuccess) return (int)e;
-    e = mg_zero_words(dqk, (long)B * T * Dm, st); if (e != hipSuccess) return (int)e;
-    e = mg_zero_words(dbtab, (long)B * T * NID, st); if (e != hipSuccess) return (int)e;
+    {   // accumulators that sit back to back in memory (the Python binding carves them from one allocation) are zeroed by one fill launch
+        float* bufs[3] = {rowdot, dqk, dbtab};
+        const long words[3] = {(long)B * T, (long)B * T * Dm, (long)B * T * NID};
+        int rcz = zero_adjacent(bufs, words, 3, st); if (rcz) return rcz;
+    }
     hipLaunchKernelGGL(tok_bwd1_kernel<TT>, row_grid(L, B), dim3(NT), 0, st, p, feat, dctx, dp, L, gbuf, rowdot);
     const size_t lds = (size_t)(6 * TT * D + TT * NID) * sizeof(float);
     hipLaunchKernelGGL(tok_bwd2_kernel<TT>, row_grid(L, B), dim3(NT), lds, st, p, feat, qk, dctx, ids, gbuf, rowdot, L, NID, scale, dfeat, dqk, dbtab);
@@ -443,10 +461,11 @@ extern "C" int mg_attn_feat_bwd(const float* dout, const float* p, const float* 
                                 int L, int Dm, int NID, float scale, float* dfeat, float* dkq, float* dvp, float* db2, float* dobias, void* stream) {
     int rc = attn_check(B, T, L, Dm, NID); if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = mg_zero_words(dkq, (long)B * T * Dm, st); if (e != hipSuccess) return (int)e;
-    e = mg_zero_words(dvp, (long)B * T * Dm, st); if (e != hipSuccess) return (int)e;
-    e = mg_zero_words(db2, (long)B * NID * T, st); if (e != hipSuccess) return (int)e;
-    if (dobias) { e = mg_zero_words(dobias, (long)Dm, st); if (e != hipSuccess) return (int)e; }
+    {
+        float* bufs[4] = {dkq, dvp, db2, dobias};
+        const long words[4] = {(long)B * T * Dm, (long)B * T * Dm, (long)B * NID * T, dobias ? (long)Dm : 0l};
+        int rcz = zero_adjacent(bufs, words, 4, st); if (rcz) return rcz;
+    }
     const size_t lds = (size_t)(6 * TT * D + TT * NID) * sizeof(float);
     hipLaunchKernelGGL(feat_bwd_kernel<TT>, row_grid(L, B), dim3(NT), lds, st, dout, p, feat, kq, vp, ids, L, NID, scale, dfeat, dkq, dvp, db2, dobias);
     MG_CHECK_LAUNCH();

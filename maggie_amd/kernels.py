@@ -575,9 +575,11 @@ def attn_tok_bwd(p, feat, qk, ids, dctx, dp, scale, NID):
     T = qk.shape[1]
     dev = feat.device
     gbuf = torch.empty((B, T, L), dtype=torch.float32, device=dev)
-    rowdot = torch.empty((B, T), dtype=torch.float32, device=dev)
-    dqk = torch.empty((B, T, D), dtype=torch.float32, device=dev)
-    dbtab = torch.empty((B, T, NID), dtype=torch.float32, device=dev)
+    # the three atomic accumulators are carved from ONE buffer: the C side zeroes adjacent buffers with a single fill launch
+    acc = torch.empty(B * T * (1 + D + NID), dtype=torch.float32, device=dev)
+    rowdot = acc[:B * T].view(B, T)
+    dqk = acc[B * T:B * T * (1 + D)].view(B, T, D)
+    dbtab = acc[B * T * (1 + D):].view(B, T, NID)
     dfeat = torch.empty((B, L, D), dtype=torch.float32, device=dev)
     hip.call('mg_attn_tok_bwd', hip.ptr(p), hip.ptr(feat), hip.ptr(qk), hip.ptr(ids), hip.ptr(dctx), hip.ptr(dp), c_int(B), c_int(T), c_int(L),
              c_int(D), c_int(NID), c_float(scale), hip.ptr(gbuf), hip.ptr(rowdot), hip.ptr(dqk), hip.ptr(dbtab), hip.ptr(dfeat), hip.stream())
@@ -601,10 +603,12 @@ def attn_feat_bwd(dout, p, feat, kq, vp, ids, scale, NID, want_bias):
     T = kq.shape[1]
     dev = feat.device
     dfeat = torch.empty((B, L, D), dtype=torch.float32, device=dev)
-    dkq = torch.empty((B, T, D), dtype=torch.float32, device=dev)
-    dvp = torch.empty((B, T, D), dtype=torch.float32, device=dev)
-    db2 = torch.empty((B, NID, T), dtype=torch.float32, device=dev)
-    dob = torch.empty((D,), dtype=torch.float32, device=dev) if want_bias else None
+    n1, n2 = B * T * D, B * NID * T
+    acc = torch.empty(2 * n1 + n2 + (D if want_bias else 0), dtype=torch.float32, device=dev)      # one buffer, one fill launch (see attn_tok_bwd)
+    dkq = acc[:n1].view(B, T, D)
+    dvp = acc[n1:2 * n1].view(B, T, D)
+    db2 = acc[2 * n1:2 * n1 + n2].view(B, NID, T)
+    dob = acc[2 * n1 + n2:] if want_bias else None
     hip.call('mg_attn_feat_bwd', hip.ptr(dout), hip.ptr(p), hip.ptr(feat), hip.ptr(kq), hip.ptr(vp), hip.ptr(ids), c_int(B), c_int(T), c_int(L),
              c_int(D), c_int(NID), c_float(scale), hip.ptr(dfeat), hip.ptr(dkq), hip.ptr(dvp), hip.ptr(db2), hip.ptr(dob), hip.stream())
     return dfeat, dkq, dvp, db2, dob
