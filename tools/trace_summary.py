@@ -19,6 +19,7 @@ def family(nm):
     if 'igemm_fprop_async' in nm: return 'maggie: igemm_fprop_async (direct-to-LDS im2col)'
     if 'igemm_fprop' in nm: return 'maggie: igemm_fprop (register-staged im2col)'
     if 'igemm_wgrad_halo' in nm: return 'maggie: igemm_wgrad_halo (3x3 s1, all taps per tile)'
+    if 'igemm_wgrad_gather9' in nm: return 'maggie: igemm_wgrad_gather9 (sparse head, all taps per tile)'
     if 'wgrad_reduce' in nm: return 'maggie: wgrad_reduce (split slabs -> dW)'
     if 'igemm_wgrad' in nm: return 'maggie: igemm_wgrad (per-tap tiles)'
     if 'anonymous namespace' in nm and 'at::native' not in nm and 'ck::' not in nm and 'Cat' not in nm and 'multi_tensor' not in nm \
