@@ -796,10 +796,10 @@ __device__ __forceinline__ void igemm_fprop_halo_tile(const mg_conv_params& p, i
     using TR = ElemTraits<T>;
     using HC = HaloCfg<TH, BN, NS>;
     constexpr int CE = 8, EPS = 32, TW = HC::TW, BM = HC::BM, PW = HC::PW, HH = HC::HH;
-    constexpr int WAVES_M = 2, WAVES_N = 2;
+    constexpr int WAVES_N = BN >= 32 ? 2 : 1, WAVES_M = 4 / WAVES_N;   // BN = 16 (an 8-channel output, padded to one MFMA column tile): the four waves split the rows
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, FM = WM / 16, FN = WN / 16;
     constexpr int STAGE = HC::STAGE, L = HC::L, A_BYTES = HC::A_BYTES;
-    static_assert((BN == 64 || BN == 32) && (TH == 8 || TH == 4) && 2 * L <= 60, "halo tile configuration");
+    static_assert((BN == 64 || BN == 32 || BN == 16) && (TH == 8 || TH == 4) && 2 * L <= 60, "halo tile configuration");
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -964,7 +964,7 @@ static inline bool halo_eligible(const mg_conv_params& p) {
     // Cin >= 96: three-stage ring over the 32-channel slabs; Cin 32 / 64: single-stage form (halo_small)
     static const int small = [] { const char* e = getenv("MG_FPROP_HALO_SMALL"); return e ? atoi(e) : 1; }();
     if (p.R != 3 || p.S != 3 || p.stride != 1 || p.dil != 1 || p.pad != 1 || p.Cin % 32 != 0) return false;
-    if (p.Cin < 96 ? (!small || p.Cout < 32) : p.Cout < 64) return false;
+    if (p.Cin < 96 ? (!small || p.Cout < 8 || p.Cout % 8 != 0) : p.Cout < 64) return false;
     if (p.Hin != p.Hout || p.Win != p.Wout || p.Wout < 16 || p.Hout < 4) return false;
     return true;
 }
@@ -990,6 +990,7 @@ static int dispatch_fprop_halo(const mg_conv_params& p, hipStream_t st) {
     // 8 x 16 pixel tiles when they still give about one workgroup per CU (a workgroup holds a whole CU's LDS), else 4 x 16
     static const long want = [] { const char* e = getenv("MG_HALO_BLOCKS"); return e ? atol(e) : 200l; }();
     if (p.Cin < 96) {
+        if (p.Cout <= 16) return p.Hout >= 8 ? launch_fprop_halo<8, 16, 1>(p, st) : launch_fprop_halo<4, 16, 1>(p, st);   // the 8-channel network input's data gradient
         if (p.Cout <= 32) return p.Hout >= 8 ? launch_fprop_halo<8, 32, 1>(p, st) : launch_fprop_halo<4, 32, 1>(p, st);
         return p.Hout >= 8 ? launch_fprop_halo<8, 64, 1>(p, st) : launch_fprop_halo<4, 64, 1>(p, st);
     }

@@ -48,6 +48,8 @@ CASES = [
     (1, 160, 96, 8, 16, 3, 1, 1, 1),                 # five slabs, Cout not a multiple of 64
     (1, 64, 128, 20, 20, 3, 2, 1, 1),
     (2, 32, 32, 40, 24, 3, 1, 1, 1),
+    (1, 32, 16, 16, 24, 3, 1, 1, 1),                 # 16-wide halo tiles (the four waves split the rows); the (2, 8, 32, ...) case above runs them as its data gradient
+    (2, 64, 8, 9, 33, 3, 1, 1, 1),                   # 8 output channels, two slabs, ragged tiles
     (2, 64, 128, 16, 24, 1, 2, 0, 1),                # stride-2 1x1 (downsample): its data gradient is the phase walk with three empty phases
     (2, 32, 64, 24, 40, 3, 2, 1, 1),                 # stride-2 3x3: phase-decomposed data gradient (1 / 2 / 2 / 4 taps), ragged phase tiles                 # halo-tile weight gradient at one 32 x 32 channel tile, ragged spatial tiles
     (2, 128, 64, 14, 14, 1, 1, 0, 1),
