@@ -1932,6 +1932,135 @@ static int launch_wgrad_gather9(const mg_conv_params& p, float* ws, long ws_floa
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the 3x3 / stride 1 convs that read the 8-CHANNEL network input (Cin == 8: 16 bytes per pixel), bf16. The layer is
+// HBM-bound (1 M pixels: 64 MB of dY + 16 MB of x against 0.15 GFLOP), the per-tap kernel re-read both nine times (110 us). Here a block stages
+// a dY tile (8x16 px x 32 co) and the x halo tile (10x18 px x 16 B) once; the GEMM's N dimension is (tap, ci): sixteen columns = the 8 channels
+// of two horizontally adjacent taps = 32 contiguous bytes of the halo row, so the transposed LDS read of the halo image yields the operand
+// directly. Wave w owns output-channel tile (w & 1) and tap pair (w >> 1) of all three filter rows (kx = 2 of pair 1 has a junk second half).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void igemm_wgrad_c8_kernel(const mg_conv_params p, int tiles_per_block, float* __restrict__ ws) {
+    constexpr int TCO = 32, TH = 8, TW = 16, HW_ = TW + 2, HH = TH + 2;
+    constexpr int PY = TCO + 16;
+    constexpr int NY = TH * TW * (TCO / 8), NX = HH * HW_;
+    constexpr int ITY = NY / 256;                                // 2
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16raw* sY = (bf16raw*)smem;                                // [TH*TW][PY]
+    bf16raw* sX = sY + TH * TW * PY;                             // [HH*HW_ + 4][8]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, g = lane >> 4;
+    const int mt = wave & 1, pair = wave >> 1;
+    const int nco = p.Cout / TCO;
+    const int tiles_x = (p.Wout + TW - 1) / TW, tiles_y = (p.Hout + TH - 1) / TH;
+    const int S = p.N * tiles_y * tiles_x;
+    const int nsplit = (S + tiles_per_block - 1) / tiles_per_block;
+    int work;
+    if (!xcd_order(nsplit * nco, work)) return;
+    const int co0 = (work % nco) * TCO, split = work / nco;
+    const int s_beg = split * tiles_per_block, s_end = min(S, s_beg + tiles_per_block);
+    const bf16raw* __restrict__ yb = (const bf16raw*)p.y;
+    const bf16raw* __restrict__ xb = (const bf16raw*)p.x;
+
+    int y_ty[ITY], y_tx[ITY], y_off[ITY];
+#pragma unroll
+    for (int i = 0; i < ITY; ++i) {
+        const int idx = t + i * 256;
+        const int px = idx >> 2, c = idx & 3;
+        y_ty[i] = px / TW; y_tx[i] = px % TW;
+        y_off[i] = (y_ty[i] * p.Wout + y_tx[i]) * p.ldy + c * 8;
+    }
+    const int x_hy = t < NX ? t / HW_ - 1 : (1 << 20), x_hx = t % HW_ - 1;
+    const int x_off = t < NX ? (x_hy * p.Win + x_hx) * p.ldx : 0;
+    if (t < 4) *(uint4*)(sX + (NX + t) * 8) = make_uint4(0, 0, 0, 0);       // the pad pixels behind the halo image (read by the junk half of pair 1)
+    uint4 ry[ITY], rx;
+    auto load_tile = [&](int s) {
+        const int n = s / (tiles_y * tiles_x);
+        const int r = s - n * tiles_y * tiles_x;
+        const int y0 = (r / tiles_x) * TH, x0 = (r % tiles_x) * TW;
+        const bf16raw* ybase = yb + ((long)(n * p.Hout + y0) * p.Wout + x0) * p.ldy + p.yoff + co0;
+        const bf16raw* xbase = xb + ((long)(n * p.Hin + y0) * p.Win + x0) * p.ldx;
+#pragma unroll
+        for (int i = 0; i < ITY; ++i)
+            ry[i] = (y0 + y_ty[i] < p.Hout && x0 + y_tx[i] < p.Wout) ? *(const uint4*)(ybase + y_off[i]) : make_uint4(0, 0, 0, 0);
+        rx = ((unsigned)(y0 + x_hy) < (unsigned)p.Hin && (unsigned)(x0 + x_hx) < (unsigned)p.Win) ? *(const uint4*)(xbase + x_off) : make_uint4(0, 0, 0, 0);
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < ITY; ++i) {
+            const int idx = t + i * 256;
+            *(uint4*)(sY + (idx >> 2) * PY + (idx & 3) * 8) = ry[i];
+        }
+        if (t < NX) *(uint4*)(sX + t * 8) = rx;
+    };
+
+    f32x4 acc[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) acc[ky] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int q = g * 4 + (li >> 2), cq = (li & 3) * 4;
+    if (s_beg < s_end) load_tile(s_beg);
+    for (int s = s_beg; s < s_end; ++s) {
+        store_tile();
+        __syncthreads();
+        if (s + 1 < s_end) load_tile(s + 1);
+#pragma unroll
+        for (int kc = 0; kc < TH / 2; ++kc) {
+            union { s16x4 h[2]; bf16x8 v; } ua, ub;
+            ua.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sY + ((2 * kc) * TW + q) * PY + mt * 16 + cq));
+            ua.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sY + ((2 * kc + 1) * TW + q) * PY + mt * 16 + cq));
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                ub.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sX + ((2 * kc + ky) * HW_ + q + 2 * pair) * 8 + cq));
+                ub.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sX + ((2 * kc + 1 + ky) * HW_ + q + 2 * pair) * 8 + cq));
+                acc[ky] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc[ky], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    float* __restrict__ slab = ws + (long)split * p.Cout * 72;
+    const int kx = 2 * pair + (li >> 3), ci = li & 7;
+    if (kx < 3) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                slab[((long)(co0 + mt * 16 + g * 4 + e) * 9 + ky * 3 + kx) * 8 + ci] = acc[ky][e];
+    }
+}
+
+static inline bool wgrad_c8_eligible(const mg_conv_params& p) {
+    static const int on = [] { const char* e = getenv("MG_WGRAD_C8"); return e ? atoi(e) : 1; }();
+    return on && p.dtype == MG_BF16 && p.mode == MG_MODE_CONV && !p.m_dev && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad == 1 && p.dil == 1 &&
+           p.Hout == p.Hin && p.Wout == p.Win && p.Cin == 8 && p.Cout % 32 == 0 && p.ldx % 8 == 0 && p.ldy % 8 == 0 && p.yoff % 8 == 0 &&
+           p.Wout >= 16 && p.Hout >= 8;
+}
+static long plan_wgrad_c8(const mg_conv_params& p, int* tpb_out) {
+    const long S = (long)p.N * ((p.Hout + 7) / 8) * ((p.Wout + 15) / 16);
+    const long nco = p.Cout / 32;
+    long splits = (512 + nco - 1) / nco;
+    if (splits > S) splits = S;
+    if (splits < 1) splits = 1;
+    const int tpb = (int)((S + splits - 1) / splits);
+    splits = (S + tpb - 1) / tpb;
+    if (tpb_out) *tpb_out = tpb;
+    return splits;
+}
+static int launch_wgrad_c8(const mg_conv_params& p, float* ws, long ws_floats, hipStream_t st) {
+    int tpb = 1;
+    const long splits = plan_wgrad_c8(p, &tpb);
+    const long n = (long)p.Cout * 72;
+    const bool out_bf16 = p.dw_dtype == MG_BF16;
+    if (!ws || ws_floats < splits * n) return -4;
+    dim3 grid(xcd_grid(splits * (p.Cout / 32)));
+    const size_t lds = (size_t)(8 * 16 * (32 + 16) + (10 * 18 + 4) * 8) * sizeof(bf16raw);
+    hipLaunchKernelGGL(igemm_wgrad_c8_kernel, grid, dim3(256), lds, st, p, tpb, ws);
+    const long b = (n + 31) / 32;
+    if (out_bf16) hipLaunchKernelGGL(wgrad_reduce_tile_kernel<bf16raw>, dim3((unsigned)b), dim3(256), 0, st, ws, (int)splits, n, (bf16raw*)p.stats);
+    else hipLaunchKernelGGL(wgrad_reduce_tile_kernel<float>, dim3((unsigned)b), dim3(256), 0, st, ws, (int)splits, n, p.stats);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
 static inline bool wgrad_halo_eligible(const mg_conv_params& p) {
     static const int on = [] { const char* e = getenv("MG_WGRAD_HALO"); return e ? atoi(e) : 1; }();
     return on && p.dtype == MG_BF16 && p.mode == MG_MODE_CONV && !p.m_dev && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad == 1 && p.dil == 1 &&
@@ -2064,6 +2193,11 @@ template <typename T>
 int dispatch_wgrad(const mg_conv_params& p, float* ws, long ws_floats, long* need, hipStream_t st) {
     const bool small_co = p.Cout <= 32, small_ci = p.Cin <= 32;
     const long n = (long)p.Cout * p.R * p.S * p.Cin;
+    if (sizeof(T) == 2 && wgrad_c8_eligible(p)) {
+        const long splits = plan_wgrad_c8(p, nullptr);
+        if (need) { *need = splits * n; return 0; }
+        if (ws && ws_floats >= splits * n) return launch_wgrad_c8(p, ws, ws_floats, st);
+    }
     if (sizeof(T) == 2 && wgrad_gather9_eligible(p)) {
         const long splits = plan_wgrad_gather9(p);
         if (need) { *need = splits * n; return 0; }
