@@ -1287,8 +1287,100 @@ static int launch_fprop_split(const mg_conv_params& p, float* ws, int splits, hi
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 forward conv over the 8-CHANNEL network input (Cin == 8, Cout <= 32; bf16): HBM-bound (16 B in, 64 B out per pixel). One
+// block = an 8x16-pixel tile (16x16 measured slower: 36 vs 30 us at 512x512): the halo image (16 B per pixel) is staged once; K = 9 taps x 8 channels is walked as three 32-wide MFMA
+// steps whose A fragment of lane (pixel, k-group) IS one halo pixel (the 8 channels of tap 4*step + k-group: a 16-byte LDS read at a constant
+// offset; taps 9..11 read a zero pixel); the weights (72 x Cout) live in registers. The im2col kernel re-read the input nine times through L2 (40 us isolated, 63 us in the step with the statistics epilogue; now 30 / 51).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int TH>
+__global__ __launch_bounds__(256) void igemm_fprop_c8_kernel(const mg_conv_params p) {
+    using T = bf16raw;
+    constexpr int TW = 16, HP = 18, BM = TH * TW, BN = 32, FM = TH / 4, FN = 2, WM = BM / 4, WN = 32;
+    constexpr int NH = (TH + 2) * HP;                             // halo pixels (+ 1 zero pixel)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4* sH = (uint4*)(smem + ctile_bytes<BM, BN>());           // behind the epilogue's fp32 tile: no overlay hazards
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int H = p.Hout, W = p.Wout;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    int work;
+    if (!xcd_order(p.N * tiles_y * tiles_x, work)) return;
+    const int img = work / (tiles_y * tiles_x);
+    const int trem = work - img * tiles_y * tiles_x;
+    const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+    const T* __restrict__ xb = (const T*)p.x;
+    const T* __restrict__ wb = (const T*)p.w;
+
+    u32x4 fb[3][FN];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int tap = s * 4 + lg, co = j * 16 + lr;
+            fb[s][j] = (tap < 9 && co < p.Cout) ? *(const u32x4*)(wb + ((long)co * 9 + tap) * 8) : (u32x4){0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int idx = t + r * 256;
+        if (idx < NH) {
+            const int hy = idx / HP, hx = idx - hy * HP;
+            const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+            sH[idx] = ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? *(const uint4*)(xb + ((long)(img * H + iy) * W + ix) * p.ldx)
+                                                                                 : make_uint4(0, 0, 0, 0);
+        } else if (idx == NH) sH[NH] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int wm = wave;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int tap = s * 4 + lg;
+        const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int ty = wm * FM + i;
+            const int px = tap < 9 ? (ty + ky) * HP + lr + kx : NH;
+            const u32x4 fa = *(const u32x4*)&sH[px];
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&fa, *(const bf16x8*)&fb[s][j], acc[i][j], 0, 0, 0);
+        }
+    }
+    auto rowmap = [&](int rt) -> long {
+        const int y = y0 + rt / TW, x = x0 + (rt % TW);
+        return (y < H && x < W) ? ((long)img * H + y) * W + x : -1l;
+    };
+    tile_epilogue<T, BM, BN, FM, FN>(p, acc, wm, 0, WM, WN, 0, work, smem, rowmap);
+}
+
+static inline bool fprop_c8_eligible(const mg_conv_params& p) {
+    static const int on = [] { const char* e = getenv("MG_FPROP_C8"); return e ? atoi(e) : 1; }();
+    return on && p.dtype == MG_BF16 && p.mode == MG_MODE_CONV && !p.m_dev && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad == 1 && p.dil == 1 &&
+           p.Hout == p.Hin && p.Wout == p.Win && p.Cin == 8 && p.Cout <= 32 && p.ldx % 8 == 0;
+}
+static int launch_fprop_c8(const mg_conv_params& p, hipStream_t st) {
+    static const int th = [] { const char* e = getenv("MG_FPROP_C8_TH"); return e ? atoi(e) : 8; }();
+    if (th == 16) {
+        const long tiles = (long)p.N * ((p.Hout + 15) / 16) * ((p.Wout + 15) / 16);
+        const size_t lds = (size_t)ctile_bytes<256, 32>() + (18 * 18 + 1) * 16;
+        hipLaunchKernelGGL(igemm_fprop_c8_kernel<16>, dim3(xcd_grid(tiles)), dim3(256), lds, st, p);
+    } else {
+        const long tiles = (long)p.N * ((p.Hout + 7) / 8) * ((p.Wout + 15) / 16);
+        const size_t lds = (size_t)ctile_bytes<128, 32>() + (10 * 18 + 1) * 16;
+        hipLaunchKernelGGL(igemm_fprop_c8_kernel<8>, dim3(xcd_grid(tiles)), dim3(256), lds, st, p);
+    }
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
 template <typename T>
 int dispatch_fprop(const mg_conv_params& p, hipStream_t st) {
+    if (sizeof(T) == 2 && fprop_c8_eligible(p)) return launch_fprop_c8(p, st);
     if (sizeof(T) == 2 && halo_eligible(p)) return dispatch_fprop_halo(p, st);
     const int eps = sizeof(T) == 2 ? 32 : 16;
     if (tconv_phased(p)) {                       // stage width by the longest phase walk (ceil(R/2) * ceil(S/2) taps)

@@ -48,6 +48,7 @@ CASES = [
     (1, 160, 96, 8, 16, 3, 1, 1, 1),                 # five slabs, Cout not a multiple of 64
     (1, 64, 128, 20, 20, 3, 2, 1, 1),
     (2, 32, 32, 40, 24, 3, 1, 1, 1),
+    (1, 8, 16, 33, 17, 3, 1, 1, 1),                  # the 8-channel-input kernels (16x16-pixel halo tiles, taps x channels as K), ragged tiles, Cout 16
     (1, 32, 16, 16, 24, 3, 1, 1, 1),                 # 16-wide halo tiles (the four waves split the rows); the (2, 8, 32, ...) case above runs them as its data gradient
     (2, 64, 8, 9, 33, 3, 1, 1, 1),                   # 8 output channels, two slabs, ragged tiles
     (2, 64, 128, 16, 24, 1, 2, 0, 1),                # stride-2 1x1 (downsample): its data gradient is the phase walk with three empty phases
