@@ -14,6 +14,9 @@ from .kernels import MODE_CONV, MODE_TCONV, MODE_GATHER, ACT_NONE, ACT_RELU, ACT
 
 LRELU_SLOPE = 0.2
 import os as _os
+# conv layers with at least this many output rows leave the BatchNorm statistics to the column-statistics kernel (4.5 TB/s, 15 us at 1 M x 32)
+# instead of the conv epilogue: there the per-element statistics + butterfly of 8192 small tiles cost more than the extra read (step 13.89 -> 13.72 ms)
+UNFUSED_STATS_ROWS = int(_os.environ.get('MAGGIE_UNFUSED_STATS_ROWS', str(1 << 19)))
 EXACT_STATS_ROWS = int(_os.environ.get('MAGGIE_EXACT_STATS_ROWS', '32768'))      # BatchNorm layers with at most this many rows use the exact two-pass variance
 
 
@@ -694,7 +697,8 @@ def conv_bn_act(x, w, bn, act=ACT_NONE, R=3, S=3, stride=1, pad=1, dil=1, transp
     if bn.training:
         mode_ = MODE_TCONV if transposed else MODE_CONV
         rows = x.shape[0] * K.conv_out_size(mode_, x.shape[1], R, stride, pad, dil) * K.conv_out_size(mode_, x.shape[2], S, stride, pad, dil)
-        stats = new_stats(Cout, x.device, rows, bn)
+        # fused statistics in the conv epilogue -- except on the largest, thinnest tensors (UNFUSED_STATS_ROWS)
+        stats = new_stats(Cout, x.device, rows, bn) if rows < UNFUSED_STATS_ROWS else None
     xc = None
     if carry and torch.is_grad_enabled() and x.requires_grad:
         y, xc = conv2d(x, w, bias, R, S, stride, pad, dil, transposed, relu_before_bn, stats, True)
