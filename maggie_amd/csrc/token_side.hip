@@ -193,16 +193,25 @@ __device__ __forceinline__ void token_linear_bwd_cols(float* sm, int cblock, con
                 acc[ki][cj] += a;
             }
         }
-        if (t < nc) {
-            for (int r = 0; r < nrow; ++r) {
-                sb += sg[r * CB + t];
-                if (gamma) {
-                    const float d = dy[(size_t)(rb + r) * N + n0 + t];
-                    ag += d * (z[(size_t)(rb + r) * N + n0 + t] - rstat[2 * (rb + r)]) * rstat[2 * (rb + r) + 1];
-                    ab += d;
+        if (t < 64) {
+            // column sums (db, dgamma, dbeta): the first wave, lane = (row group, column) -- 16 row groups, so the dependent global loads of
+            // the LayerNorm terms form chains of 2 instead of 32 (four threads walking all rows serially cost ~10 us per LayerNorm layer)
+            const int cc = t & (CB - 1);
+            for (int r = t / CB; r < nrow; r += 64 / CB) {
+                if (cc < nc) {
+                    sb += sg[r * CB + cc];
+                    if (gamma) {
+                        const float d = dy[(size_t)(rb + r) * N + n0 + cc];
+                        ag += d * (z[(size_t)(rb + r) * N + n0 + cc] - rstat[2 * (rb + r)]) * rstat[2 * (rb + r) + 1];
+                        ab += d;
+                    }
                 }
             }
         }
+    }
+    if (t < 64) {
+#pragma unroll
+        for (int o = CB; o < 64; o <<= 1) { sb += __shfl_xor(sb, o, 64); ag += __shfl_xor(ag, o, 64); ab += __shfl_xor(ab, o, 64); }
     }
 #pragma unroll
     for (int ki = 0; ki < 2; ++ki)
