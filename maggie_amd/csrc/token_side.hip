@@ -177,7 +177,24 @@ __device__ __forceinline__ void token_linear_bwd_cols(float* sm, int cblock, con
         const int nrow = min(RC, R - rb);
         __syncthreads();
         for (int i = t; i < nrow * CB; i += NT) { const int r = i / CB, cc = i - r * CB; sg[i] = cc < nc ? dz[(size_t)(rb + r) * N + n0 + cc] : 0.f; }
-        for (int i = t; i < nrow * K; i += NT) sx[i] = x[(size_t)rb * K + i] + (xadd ? xadd[(size_t)rb * K + i] : 0.f);
+        {   // K % 4 == 0 (tl_check): 16-byte loads, all of a thread's loads in flight before the first LDS store
+            const int n4 = nrow * K / 4;
+            const float4* x4 = (const float4*)(x + (size_t)rb * K);
+            const float4* a4 = xadd ? (const float4*)(xadd + (size_t)rb * K) : nullptr;
+            for (int base = t; base < n4; base += NT * 4) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = base + u * NT;
+                    if (i < n4) {
+                        v[u] = x4[i];
+                        if (a4) { const float4 w = a4[i]; v[u].x += w.x; v[u].y += w.y; v[u].z += w.z; v[u].w += w.w; }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int i = base + u * NT; if (i < n4) ((float4*)sx)[i] = v[u]; }
+            }
+        }
         __syncthreads();
 #pragma unroll
         for (int ki = 0; ki < 2; ++ki) {
