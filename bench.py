@@ -124,8 +124,9 @@ def main():
             # captured backward graph hands its flat gradient chunk to RCCL as soon as it has run (parallel.OverlappedGradSync)
             model.split_trunk = True
             opt.overlap = parallel.OverlappedGradSync().attach(model)
-        elif os.environ.get('MAGGIE_GRAD_SINK', '1') != '0' and not (world > 1 or force_ddp):
-            # single process: the backward graphs write the gradients straight into the optimizer's flat buffer (no export / gather copies)
+        if os.environ.get('MAGGIE_GRAD_SINK', '1') != '0' and not args.ddp:
+            # the backward graphs write the gradients straight into the optimizer's flat buffer (no export / gather copies); with the overlapped
+            # exchange the all-reduce then runs in place on that buffer's stretches
             model.grad_sink = opt.grad_views
     else:
         opt = torch.optim.AdamW(params, lr=1.5e-4 / 25, betas=(0.9, 0.999), weight_decay=0.01, fused=args.optimizer == 'fused')

@@ -108,6 +108,7 @@ class GraphedCallable:
         self.training = training
         self.grad_sink = grad_sink
         self.sink_views = None
+        self.sink_runs = None
         self.grad_idx = [i for i in grad_inputs if training and inputs[i].is_floating_point()]
         self.static_inputs = [i.detach().clone() for i in inputs]
         for i in self.grad_idx:
@@ -202,8 +203,15 @@ class GraphedCallable:
 
     def _export_to_sink(self):
         if self._sink_saved is not None:
+            if self.grad_hook is not None:
+                raise MF.K.hip.MaggieHipError('gradient accumulation (a second backward before zero_grad) is not supported together with the overlapped '
+                                              'gradient exchange writing into the optimizer buffer: unset model.grad_sink or MAGGIE_GRAD_OVERLAP=0')
             torch._foreach_add_(self._sink_saved[0], self._sink_saved[1])     # slot = earlier gradient + this backward's
             self._sink_saved = None
+        if self.grad_hook is not None:
+            # data parallel: THIS graph's slots of the optimizer buffer are all-reduced in place on the side stream while the next backward
+            # graph (which writes other slots) runs; no staging copy at all
+            self.grad_hook(self.sink_runs, self.params)
         out = []
         for v, p in zip(self.sink_views, self.params):
             if p.grad is None:
@@ -216,12 +224,15 @@ class GraphedCallable:
 
     def _pack_grads(self):
         """Called INSIDE the backward capture."""
-        if self.grad_sink is not None and self.grad_hook is None:
+        if self.grad_sink is not None:
             views = self.grad_sink(self.params)
+            owner = getattr(self.grad_sink, '__self__', None)
+            runs = owner.grad_runs(self.params) if (views is not None and hasattr(owner, 'grad_runs')) else None
             if views is not None and all(v is not None and v.dtype == g.dtype and v.shape == g.shape
                                          for v, g in zip(views, self.static_param_grads)):
                 torch._foreach_copy_(list(views), list(self.static_param_grads))
                 self.sink_views = list(views)
+                self.sink_runs = runs if runs is not None else list(views)    # contiguous stretches of the sink covering these parameters
                 self.flat_grads, self.grad_slots = {}, []
                 return
         by_dt = {}

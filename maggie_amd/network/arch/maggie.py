@@ -205,7 +205,7 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         try:
             with torch.autocast('cuda', dtype=torch.bfloat16, enabled=torch.is_autocast_enabled(), cache_enabled=False):
                 g = graphs.GraphedCallable(fn, inputs, self, mutable, self.training, grad_inputs=grad_inputs,
-                                           grad_sink=self.__dict__.get('grad_sink') if self.__dict__.get('_grad_overlap') is None else None)
+                                           grad_sink=self.__dict__.get('grad_sink'))
             overlap = self.__dict__.get('_grad_overlap')
             if overlap is not None:
                 g.grad_hook = overlap.reduce_async

@@ -102,6 +102,21 @@ class FlatAdamW(torch.optim.Optimizer):
             out.append(self.flat_g[o:o + p.numel()].view(p.shape))
         return out
 
+    def grad_runs(self, params):
+        """The contiguous stretches of the flat gradient buffer that hold `params` (consecutive parameters of the optimizer's order share a
+        stretch, alignment padding included: it stays zero) -- what an in-place all-reduce of a graph's gradients operates on."""
+        index = {id(p): i for i, p in enumerate(self._active())}
+        idx = sorted(index[id(p)] for p in params if id(p) in index)
+        ends = list(self._offsets[1:]) + [self._n]
+        runs, k = [], 0
+        while k < len(idx):
+            j = k
+            while j + 1 < len(idx) and idx[j + 1] == idx[j] + 1:
+                j += 1
+            runs.append(self.flat_g[self._offsets[idx[k]]:ends[idx[j]]])
+            k = j + 1
+        return runs
+
     def _intact(self):
         ps = self._active()
         return len(ps) == len(self._ptrs) and all(p.data_ptr() == a for p, a in zip(ps, self._ptrs))

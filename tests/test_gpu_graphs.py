@@ -255,3 +255,55 @@ def test_gradient_sink_is_zero_copy_and_equivalent():
         # 1e-2 p95 / 0.1 worst through the order of fp32 atomics; a gradient in the wrong slot, lost or stale would show as a deviation of ~1
         assert len(devs) >= 280 and devs[len(devs) // 2] <= 2e-2 and devs[int(0.95 * len(devs))] <= 0.15, (i, devs[len(devs) // 2], devs[int(0.95 * len(devs))], devs[-1])
         assert abs(runs[False][1][i] - runs[True][1][i]) <= 5e-2 * runs[False][1][i]
+
+
+@pytest.mark.gpu
+def test_overlapped_exchange_in_place_on_the_optimizer_buffer_single_rank_rccl():
+    """Data-parallel configuration of bench.py in a 1-rank RCCL group: split trunk (three backward graphs), parallel.OverlappedGradSync, and the
+    gradient sink -- each graph's stretches of FlatAdamW's flat gradient buffer are all-reduced in place on the side stream. With one rank the
+    mean is the identity, so the gradients of every step must equal those of the plain single-process configuration (lr = 0: same state), every
+    trainable parameter must have been through a collective on the replayed steps, and `.grad` must alias the optimizer buffer (no copies)."""
+    import os
+    import torch.distributed as dist
+    from maggie_amd import parallel
+    from maggie_amd.optim import FlatAdamW
+    from maggie_amd.utils import synth
+    dev = _dev()
+    if dist.is_initialized():
+        pytest.skip('a process group already exists in this process')
+    batch = _to(synth.synthetic_batch(2, 1, 2, 64, 64, seed=DSEED, train=True, max_inst=10, it=100), dev)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29543', RANK='0', WORLD_SIZE='1')
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        runs = {}
+        for ddp in (False, True):
+            model, _ = _build('image', dev, True)
+            model.decoder.inst_spec_layer.dropout.p = 0.0
+            model.hip_graphs = True
+            params = [p for p in model.parameters() if p.requires_grad]
+            opt = FlatAdamW(params, lr=0.0, weight_decay=0.0, max_grad_norm=0.01, sync_group=True if ddp else None)
+            if ddp:
+                model.split_trunk = True
+                opt.overlap = parallel.OverlappedGradSync().attach(model)
+            model.grad_sink = opt.grad_views
+            grads = []
+            for i in range(4):
+                seed_all(100 + i)
+                opt.zero_grad(set_to_none=True)
+                out, loss = model(batch)
+                loss['total'].backward()
+                if ddp and i >= 2:
+                    reduced = set(opt.overlap.reduced)
+                    assert sum(id(p) in reduced for p in params if p.grad is not None) >= 280
+                    lo, hi = opt.flat_g.data_ptr(), opt.flat_g.data_ptr() + 4 * opt.flat_g.numel()
+                    assert all(lo <= p.grad.data_ptr() < hi for p in params if p.grad is not None and id(p) in reduced)
+                torch.cuda.synchronize()
+                grads.append([None if p.grad is None else p.grad.detach().clone() for p in params])
+                opt.step()
+            runs[ddp] = grads
+            del model, opt
+        for i in range(4):
+            devs = sorted(float((a - b).abs().max() / (a.abs().max() + 1e-12)) for a, b in zip(runs[False][i], runs[True][i]) if a is not None and b is not None)
+            assert len(devs) >= 280 and devs[len(devs) // 2] <= 2e-2 and devs[int(0.95 * len(devs))] <= 0.15, (i, devs[len(devs) // 2], devs[-1])
+    finally:
+        dist.destroy_process_group()
