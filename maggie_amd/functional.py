@@ -72,6 +72,20 @@ class ZeroArena:
         return v
 
 
+def flush_bn_count_log(log):
+    """num_batches_tracked += (number of calls) for every logged BatchNorm: one foreach launch per distinct multiplicity (the temporal decoder
+    calls some layers two or more times per forward; 81 one-element add kernels per video step otherwise)."""
+    counts, tensors = {}, {}
+    for t in log:
+        counts[id(t)] = counts.get(id(t), 0) + 1
+        tensors[id(t)] = t
+    by_c = {}
+    for k, c in counts.items():
+        by_c.setdefault(c, []).append(tensors[k])
+    for c, ts in by_c.items():
+        torch._foreach_add_(ts, c)
+
+
 ARENA = ZeroArena()
 CAPTURE_FIXUPS = []            # (slice of CAPTURE_TABLE, host tensor to upload once the capture has ended)
 CAPTURE_TABLE = [None, 0]      # [int64 device buffer owned by the graph being captured, bump offset]
@@ -85,6 +99,7 @@ def capture_table(n):
     return buf[off:off + n]
 EAGER_TOKEN_CHECK = True       # InstanceMatteDecoder checks its tokens for NaN itself (a host sync) unless MaGGIe.forward, which reads all step flags at once, clears this
 DEFER_BN_COUNTERS = False      # set by MaGGIe.forward: num_batches_tracked of all BN layers is bumped by one foreach op per step
+BN_COUNT_LOG = None            # a list while a stage of the video model runs: BatchNorm calls are logged, the stage bumps the counters with one foreach op per multiplicity
 
 
 def compute_dtype():
@@ -658,7 +673,10 @@ def batch_norm_act(x, bn, act=ACT_NONE, res=None, stats=None, res_mode=1, mask_x
     """`bn` is an nn.BatchNorm{1,2}d / nn.SyncBatchNorm used as the parameter + running-stat holder."""
     training = bn.training or (bn.running_mean is None)
     if training and bn.num_batches_tracked is not None and not DEFER_BN_COUNTERS:
-        bn.num_batches_tracked.add_(1)
+        if BN_COUNT_LOG is not None:
+            BN_COUNT_LOG.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked.add_(1)
     mom = 0.1 if bn.momentum is None else bn.momentum
     return BNAct.apply(x, bn.weight, bn.bias, res, bn.running_mean, bn.running_var, training, mom, bn.eps, act, stats, res_mode,
                        _sync_group(bn) if training else None, mask_x_pos)

@@ -22,6 +22,26 @@ from ..encoder import *      # noqa: F401,F403  (factory names are resolved by e
 from ..decoder import *      # noqa: F401,F403
 
 
+def _bn_counted(method):
+    """Stage methods of the VIDEO model (its BatchNorm layers are called a varying number of times per forward, so the image model's
+    one-foreach-per-step counter bump does not apply): BatchNorm calls inside the stage are logged and the counters bumped at its end with
+    one foreach launch per multiplicity -- inside the stage, so it is captured with it."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapper(self, *a, **k):
+        if not self.training or MF.DEFER_BN_COUNTERS or MF.BN_COUNT_LOG is not None:
+            return method(self, *a, **k)
+        MF.BN_COUNT_LOG = log = []
+        try:
+            out = method(self, *a, **k)
+        finally:
+            MF.BN_COUNT_LOG = None
+        MF.flush_bn_count_log(log)
+        return out
+    return wrapper
+
+
 class MaGGIe(nn.Module, PyTorchModelHubMixin):
     def __init__(self, cfg):
         super().__init__()
@@ -116,6 +136,7 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             MF.EAGER_TOKEN_CHECK = True
 
     # ------------------------------------------------------------------------------------------------ dense trunk
+    @_bn_counted
     def _trunk(self, geom, prepare_sn, x, enc_masks, masks, gt_alphas=None, mem_feat=None):
         """Static-shape part of the step: mask embedding + encoder + ASPP + dense decoder stage. Tensors in, tensors out."""
         b, n_f, n_i = geom
@@ -145,6 +166,7 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             return os.environ.get('MAGGIE_SYNCBN_GRAPHS', '0') == '1'
         return True
 
+    @_bn_counted
     def _trunk_enc(self, prepare_sn, x, enc_masks):
         """First half of the trunk as its own graph: mask embedding + encoder -> (embedding, fea1..fea5)."""
         if prepare_sn:
@@ -152,6 +174,7 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         embedding, mid_fea = self.encoder(x, enc_masks)
         return (embedding,) + tuple(mid_fea['shortcut'])
 
+    @_bn_counted
     def _trunk_dec(self, geom, prepare_sn, image_shape, embedding, f1, f2, f3, f4, f5, masks, gt_alphas=None):
         """Second half: ASPP + dense decoder stage (+ instance matte decoder) on the encoder graph's outputs."""
         b, n_f, n_i = geom
@@ -284,6 +307,7 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         return output
 
     # ------------------------------------------------------------------------------------------------ detail stage + losses
+    @_bn_counted
     def _detail_and_loss(self, geom, plan, n_dense, *tensors):
         """Static-shape tail of the step as a function of tensors only: detail region -> sparse refinement -> fusion -> output dict
         (-> losses). `tensors` = the trunk's outputs, then [ground-truth alphas, transition maps, fuse-weight flag] in training.

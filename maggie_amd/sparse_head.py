@@ -121,7 +121,10 @@ class _BN:
         self.group = MF._sync_group(bn) if self.training else None
         if self.training:
             if bn.num_batches_tracked is not None and not MF.DEFER_BN_COUNTERS:
-                bn.num_batches_tracked.add_(1)
+                if MF.BN_COUNT_LOG is not None:
+                    MF.BN_COUNT_LOG.append(bn.num_batches_tracked)
+                else:
+                    bn.num_batches_tracked.add_(1)
             mom = 0.1 if bn.momentum is None else bn.momentum
             if self.group is None:
                 self.y, self.pack = K.bn_train_fwd(x, gamma, beta, bn.running_mean, bn.running_var, mom, bn.eps, self.act, SLOPE,
