@@ -230,7 +230,9 @@ class GraphedCallable:
             runs = owner.grad_runs(self.params) if (views is not None and hasattr(owner, 'grad_runs')) else None
             if views is not None and all(v is not None and v.dtype == g.dtype and v.shape == g.shape
                                          for v, g in zip(views, self.static_param_grads)):
-                torch._foreach_copy_(list(views), list(self.static_param_grads))
+                # one multi-tensor launch: torch falls back to ONE COPY PER TENSOR for the whole list as soon as a single source is not
+                # contiguous (the video model's ConvGRU weight gradients are permuted views: 305 memcpy nodes per backward graph)
+                torch._foreach_copy_(list(views), [g if g.is_contiguous() else g.contiguous() for g in self.static_param_grads])
                 self.sink_views = list(views)
                 self.sink_runs = runs if runs is not None else list(views)    # contiguous stretches of the sink covering these parameters
                 self.flat_grads, self.grad_slots = {}, []

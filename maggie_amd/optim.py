@@ -148,7 +148,8 @@ class FlatAdamW(torch.optim.Optimizer):
         if absent:
             torch._foreach_zero_(absent)                          # absent gradients must not count in the norm
         if grads:
-            torch._foreach_copy_(views, grads)
+            # (contiguous sources keep torch on its one-launch multi-tensor route; a single strided gradient would turn the call into one copy per tensor)
+            torch._foreach_copy_(views, [g_ if g_.is_contiguous() else g_.contiguous() for g_ in grads])
         if sync:
             from .parallel import all_reduce_mean
             grp = None if self.sync_group is True else self.sync_group

@@ -18,10 +18,11 @@ from maggie_amd.optim import FlatAdamW
 from maggie_amd.utils import config, synth
 
 dev = torch.device('cuda:0')
-model, _ = build_model(config.model_config('image'))
+KIND = os.environ.get('KIND', 'image')
+model, _ = build_model(config.model_config(KIND))
 sd = model.state_dict(); synth.fill_state_dict_(sd, 1234); model.load_state_dict(sd)
 model.to(dev).train()
-batch = synth.synthetic_batch(4, 1, 2, 512, 512, seed=1234, train=True, it=100, max_inst=10, edge=40.0)
+batch = synth.synthetic_batch(1 if KIND == 'video' else 4, 3 if KIND == 'video' else 1, 2, 512, 512, seed=1234, train=True, it=100, max_inst=10, edge=40.0)
 batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
 np.random.seed(1); random.seed(1); torch.manual_seed(1)
 params = [p for p in model.parameters() if p.requires_grad]
