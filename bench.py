@@ -161,7 +161,11 @@ def main():
             host_t.append([1e3 * (t[i + 1] - t[i]) for i in range(3)])
         stats['active_px'] = out['detail_mask']
         stats['loss'] = loss['total']
-        stats.setdefault('active_hist', []).append(out['detail_mask'].sum())           # one reduction launch; normalised when reported
+        # per-step active ratio: only a reference to the step's own mask is kept here (outputs of a replayed step are private copies);
+        # the reductions run after the timed region
+        hist = stats.setdefault('active_masks', [])
+        hist.append(out['detail_mask'])
+        del hist[:-(args.steps + 2)]
 
     def sync():
         torch.cuda.synchronize()
@@ -200,6 +204,7 @@ def main():
     value = inst_frames_per_step * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
     active_px = float(stats['active_px'].float().sum().item())
+    stats['active_hist'] = [m.sum() for m in stats.pop('active_masks')[-args.steps:]]      # the timed steps (the instrumented ones come later)
     active_ratio = active_px / (b * n_f * args.instances * args.size * args.size)
     loss_val = float(stats['loss'].item())
 
@@ -303,7 +308,7 @@ def main():
                                                                 if args.workload == 'gt' else 'detail region from the predicted coarse alpha: drifts with the random-init weights'),
                        'global_batch': b * world, 'parallelism': 'dp%d' % world, 'sync_bn': bool(args.sync_bn and world > 1), 'optimizer': 'FlatAdamW (clip 0.01 folded in)' if args.optimizer == 'flat' else 'torch AdamW(%s) + flat-buffer grad-norm clip' % args.optimizer,
                        'grad_allreduce': None if world == 1 and not force_ddp else ('torch DDP' if args.ddp else ('RCCL all-reduce (mean) of each of the three backward graphs\' stretches of the optimizer\'s flat gradient buffer, in place on a side stream, overlapped with the rest of backward (parallel.OverlappedGradSync + FlatAdamW gradient sink)' if (args.optimizer == 'flat' and os.environ.get('MAGGIE_GRAD_OVERLAP', '1') != '0') else 'one RCCL all-reduce of the flat gradient buffer inside FlatAdamW.step' if args.optimizer == 'flat' else 'GradSync (flat-buffer RCCL all-reduce)')),
-                       'active_ratio': round(active_ratio, 4), 'active_ratio_per_timed_step': [round(float(v) / (b * n_f * args.instances * args.size * args.size), 3) for v in stats['active_hist'][-args.steps - 2:-2]] if not args.no_roofline else None, 'active_pixels_per_step_per_gpu': int(active_px), 'loss_total': round(loss_val, 4)},
+                       'active_ratio': round(active_ratio, 4), 'active_ratio_per_timed_step': [round(float(v) / (b * n_f * args.instances * args.size * args.size), 3) for v in stats['active_hist']] if not args.no_roofline else None, 'active_pixels_per_step_per_gpu': int(active_px), 'loss_total': round(loss_val, 4)},
             'roofline': roofline, 'cpu_baseline': cpu_baseline,
         }
     if world > 1 or force_ddp:

@@ -68,6 +68,16 @@ typedef struct mg_conv_params {
                             capacity the buffers were sized for. The launch is a fixed, persistent grid (tiles are walked
                             grid-stride), so no host code ever needs the count: the detail stage stays free of device->host
                             reads and its launches can be captured into a hipGraph. NULL: M is the row count (dense layers). */
+    /* mg_conv_fprop, optional (bnb_x != NULL): this launch computes the gradient dz arriving at the OUTPUT z = act(BN(x) [+ res]) of a
+     * training BatchNorm layer (maggie/network/encoder/resnet.py:28-39 backward). The epilogue then writes g = dz * act'(z) to `y` and
+     * accumulates that layer's backward reductions into `stats` (stat_mode 0 layout): stats[c] += sum g, stats[Cout + c] += sum g * xhat,
+     * xhat = (x - mean) * invstd -- the separate mg_bn_bwd_reduce pass disappears. bnb_y / bnb_x: [M, bnb_ld] rows of z (NULL when the
+     * layer has no activation) and x in the launch dtype; bnb_act: the layer's activation (its LeakyReLU slope is `slope`). */
+    const void* bnb_y;
+    const void* bnb_x;
+    const float* bnb_mean;
+    const float* bnb_invstd;
+    int32_t bnb_act, bnb_ld;
 } mg_conv_params;
 
 int mg_conv_fprop(const mg_conv_params* p, void* stream);
@@ -145,6 +155,10 @@ int mg_affine_act(const mg_rowwise_params* p, void* stream);
 /* BatchNorm backward: reduce (sums) then apply (dx, dres) */
 int mg_bn_bwd_reduce(const mg_rowwise_params* p, void* stream);
 int mg_bn_bwd_apply(const mg_rowwise_params* p, void* stream);
+/* apply pass for a layer whose reductions rode on the consumer conv's data-gradient epilogue (mg_conv_params.bnb_*): p->dy holds
+ * g = dy * act'(y) already, sums_rep = nrep replicas of [2C] (summed here); sums_out [2C] receives dbeta | dgamma. Needs a power-of-two
+ * number of 16-byte channel chunks per row (-3 otherwise). */
+int mg_bn_bwd_apply_linked(const mg_rowwise_params* p, const float* sums_rep, int nrep, float* sums_out, void* stream);
 /* op 0: 2x2 average pool, 1: 2x2 sum pool (out Ho x Wo from 2Ho x 2Wo); 2: 0.25*nearest-upsample, 3: nearest-upsample
  * (out Ho x Wo from Ho/2 x Wo/2) */
 int mg_pool2x2(const void* in, void* out, int dtype, int op, int N, int Ho, int Wo, int C, void* stream);

@@ -91,7 +91,7 @@ struct PhaseMap {
 // use; fp32 -> bf16 is the packed hardware conversion. (Before: ~1600 static instructions with ~170 branches, 8-12 k cycles per
 // 128 x 64 tile -- as long as the whole K loop of a C128 3x3 layer, tools/halo_timeline.py.)
 // =====================================================================================================================
-template <typename T, int BM, int BN, int FM, int FN, bool RES, typename RowMap>
+template <typename T, int BM, int BN, int FM, int FN, bool RES, bool BNB, typename RowMap>
 __device__ __forceinline__ void tile_epilogue_impl(const mg_conv_params& p, f32x4 (&acc)[FM][FN], int wm, int wn, int WM, int WN, int n0, int stat_slot,
                                                    char* smem, const RowMap& rowmap) {
     using TR = ElemTraits<T>;
@@ -114,6 +114,18 @@ __device__ __forceinline__ void tile_epilogue_impl(const mg_conv_params& p, f32x
     float sc[CE], sh[CE], s1[CE], s2[CE];
 #pragma unroll
     for (int e = 0; e < CE; ++e) { sc[e] = 1.f; sh[e] = 0.f; s1[e] = 0.f; s2[e] = 0.f; }
+    // BNB (round 3): this launch is the data gradient arriving at the OUTPUT of a training BatchNorm(+activation) layer. The epilogue
+    // then writes g = dz * act'(z) and accumulates that layer's backward sums (sum g, sum g * xhat) -- the whole bn_bwd_reduce pass
+    // (59 launches, three tensor reads each per step) rides on tiles that are in registers anyway.
+    [[maybe_unused]] float bmu[CE], bis[CE];
+    if constexpr (BNB) {
+#pragma unroll
+        for (int e = 0; e < CE; ++e) {
+            const int c = cbase + e;
+            bmu[e] = c < p.Cout ? p.bnb_mean[c] : 0.f;
+            bis[e] = c < p.Cout ? p.bnb_invstd[c] : 0.f;
+        }
+    }
     if (full_vec) {                                    // vector loads, in flight under the LDS tile write below
         if (p.scale) {
 #pragma unroll
@@ -138,6 +150,9 @@ __device__ __forceinline__ void tile_epilogue_impl(const mg_conv_params& p, f32x
     const T* __restrict__ r1b = (const T*)p.res;
     const T* __restrict__ r2b = (const T*)p.res2;
     const bool stats = p.stats != nullptr;
+    [[maybe_unused]] const T* __restrict__ bxb = (const T*)p.bnb_x;
+    [[maybe_unused]] const T* __restrict__ byb = (const T*)p.bnb_y;
+    [[maybe_unused]] const float bsl = p.bnb_act == MG_ACT_NONE ? 1.f : (p.bnb_act == MG_ACT_RELU ? 0.f : p.slope);
 #pragma unroll
     for (int ep = 0; ep < EP; ++ep) {
         if (ep > 0) __syncthreads();
@@ -160,6 +175,17 @@ __device__ __forceinline__ void tile_epilogue_impl(const mg_conv_params& p, f32x
             mrow[k] = (r < PR && col_ok) ? rowmap(ep * PR + r) : -1l;
 #pragma unroll
             for (int e = 0; e < CE; e += 4) *(float4*)&v[k][e] = *(const float4*)&sC[(r < PR ? r : 0) * LDC + cc * CE + e];
+        }
+        [[maybe_unused]] uint4 qbx[NIT], qby[NIT];
+        if constexpr (BNB) {                                   // the BatchNorm layer's input and output rows of this tile: all loads in flight at once
+#pragma unroll
+            for (int k = 0; k < NIT; ++k) {
+                qbx[k] = make_uint4(0, 0, 0, 0); qby[k] = make_uint4(0, 0, 0, 0);
+                if (mrow[k] >= 0 && full_vec) {
+                    qbx[k] = *(const uint4*)(bxb + mrow[k] * p.bnb_ld + cbase);
+                    if (byb) qby[k] = *(const uint4*)(byb + mrow[k] * p.bnb_ld + cbase);
+                }
+            }
         }
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
@@ -200,11 +226,33 @@ __device__ __forceinline__ void tile_epilogue_impl(const mg_conv_params& p, f32x
                 if constexpr (RES) x += rv2[e];
                 v[k][e] = x;
             }
+            [[maybe_unused]] float bxv[CE];
+            if constexpr (BNB) {
+                float byv[CE];
+                if (full_vec) { TR::unpack(qbx[k], bxv); TR::unpack(qby[k], byv); }
+                else {
+#pragma unroll
+                    for (int e = 0; e < CE; ++e) {
+                        const bool ok = cbase + e < p.Cout;
+                        bxv[e] = ok ? TR::ld(bxb + m * p.bnb_ld + cbase + e) : 0.f;
+                        byv[e] = (ok && byb) ? TR::ld(byb + m * p.bnb_ld + cbase + e) : 1.f;
+                    }
+                }
+                if (byb) {
+#pragma unroll
+                    for (int e = 0; e < CE; ++e) v[k][e] = byv[e] > 0.f ? v[k][e] : v[k][e] * bsl;
+                }
+            }
             const uint4 packed = TR::pack(v[k]);               // rounded once; the statistics are those of the rounded values
             if (stats) {
                 TR::unpack(packed, v[k]);
+                if constexpr (BNB) {
 #pragma unroll
-                for (int e = 0; e < CE; ++e) { s1[e] += v[k][e]; s2[e] += v[k][e] * v[k][e]; }
+                    for (int e = 0; e < CE; ++e) { s1[e] += v[k][e]; s2[e] += v[k][e] * (bxv[e] - bmu[e]) * bis[e]; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < CE; ++e) { s1[e] += v[k][e]; s2[e] += v[k][e] * v[k][e]; }
+                }
             }
             T* dst = yb + m * p.ldy + p.yoff + cbase;
             if (full_vec) *(uint4*)dst = packed;
@@ -246,11 +294,14 @@ __device__ __forceinline__ void tile_epilogue_impl(const mg_conv_params& p, f32x
     }
 }
 
-template <typename T, int BM, int BN, int FM, int FN, typename RowMap>
+// BNB is a compile-time property of the KERNEL: as a run-time branch the BatchNorm-backward path put its registers into every fprop kernel
+// (occupancy 3 -> 2, 4 -> 3, 7 -> 4 across the family, -Rpass-analysis=kernel-resource-usage; the step lost 0.4 ms).
+template <typename T, int BM, int BN, int FM, int FN, bool BNB = false, typename RowMap>
 __device__ __forceinline__ void tile_epilogue(const mg_conv_params& p, f32x4 (&acc)[FM][FN], int wm, int wn, int WM, int WN, int n0, int stat_slot,
                                               char* smem, const RowMap& rowmap) {
-    if (p.res || p.res2) tile_epilogue_impl<T, BM, BN, FM, FN, true>(p, acc, wm, wn, WM, WN, n0, stat_slot, smem, rowmap);
-    else tile_epilogue_impl<T, BM, BN, FM, FN, false>(p, acc, wm, wn, WM, WN, n0, stat_slot, smem, rowmap);
+    if constexpr (BNB) tile_epilogue_impl<T, BM, BN, FM, FN, true, true>(p, acc, wm, wn, WM, WN, n0, stat_slot, smem, rowmap);
+    else if (p.res || p.res2) tile_epilogue_impl<T, BM, BN, FM, FN, true, false>(p, acc, wm, wn, WM, WN, n0, stat_slot, smem, rowmap);
+    else tile_epilogue_impl<T, BM, BN, FM, FN, false, false>(p, acc, wm, wn, WM, WN, n0, stat_slot, smem, rowmap);
 }
 
 // K is walked in STAGES of KS slabs (KS*64 bytes per row). The loads of stage s+1 are issued right after the barrier that
@@ -261,7 +312,7 @@ __device__ __forceinline__ void tile_epilogue(const mg_conv_params& p, f32x4 (&a
 // raw fp32 partial tile to its own slab of `ws` ([splits][M][Cout]); splitk_finish_kernel sums the slabs and applies the epilogue.
 // These layers could only fill the chip with 64x32 tiles (21 FLOP per byte staged through L2/LDS: ~100-220 TFLOP/s whatever the
 // shape); with the K split, 128x128 tiles (64 FLOP/B) reach the same block count.
-template <typename T, int BM, int BN, int KS, int MODE, bool SPLIT = false>
+template <typename T, int BM, int BN, int KS, int MODE, bool SPLIT = false, bool BNB = false>
 __device__ __forceinline__ void igemm_fprop_tile(const mg_conv_params& p, const int M, int work, float* __restrict__ ws, int splits, char* smem) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE, EPS = TR::EPS;
@@ -532,18 +583,18 @@ __device__ __forceinline__ void igemm_fprop_tile(const mg_conv_params& p, const 
         if (ph) { int n_, ho_, wo_; pmap.decode(m, n_, ho_, wo_); m = (n_ * p.Hout + ho_) * p.Wout + wo_; }
         return (long)m;
     };
-    tile_epilogue<T, BM, BN, FM, FN>(p, acc, wm, wn, WM, WN, n0, mt, smem, rowmap);
+    tile_epilogue<T, BM, BN, FM, FN, BNB>(p, acc, wm, wn, WM, WN, n0, mt, smem, rowmap);
 }
 
 
 // one tile per workgroup (dense layers: the row count is a host value)
-template <typename T, int BM, int BN, int KS, int MODE, bool SPLIT = false>
+template <typename T, int BM, int BN, int KS, int MODE, bool SPLIT = false, bool BNB = false>
 __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p, float* __restrict__ ws, int splits) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ntn = (p.Cout + BN - 1) / BN;
     int work;
     if (!xcd_order((int)(SPLIT ? (long)((p.M + BM - 1) / BM) * ntn * splits : row_tiles(p, p.M, BM) * ntn), work)) return;
-    igemm_fprop_tile<T, BM, BN, KS, MODE, SPLIT>(p, p.M, work, ws, splits, smem);
+    igemm_fprop_tile<T, BM, BN, KS, MODE, SPLIT, BNB>(p, p.M, work, ws, splits, smem);
 }
 
 // Persistent form for the sparse head (p.m_dev): the row count lives in a device word, the grid is fixed (a multiple of 8 workgroups,
@@ -586,7 +637,7 @@ template <int BM, int BN, int KS, int NS> constexpr int async_lds_bytes() {
     return NS * async_stage_bytes<BM, BN, KS, NS>() > ctile_bytes<BM, BN>() ? NS * async_stage_bytes<BM, BN, KS, NS>() : ctile_bytes<BM, BN>();
 }
 
-template <int BM, int BN, int KS, int NS, int MODE>
+template <int BM, int BN, int KS, int NS, int MODE, bool BNB = false>
 __device__ __forceinline__ void igemm_fprop_async_tile(const mg_conv_params& p, const int M, int work, char* smem) {
     using T = bf16raw;
     using TR = ElemTraits<T>;
@@ -740,16 +791,16 @@ __device__ __forceinline__ void igemm_fprop_async_tile(const mg_conv_params& p, 
 
     // ---------------- epilogue (tile_epilogue, shared with igemm_fprop_tile) ----------------
     auto rowmap = [&](int rt) -> long { const int m = m0 + rt; return m < M ? (long)m : -1l; };
-    tile_epilogue<T, BM, BN, FM, FN>(p, acc, wm, wn, WM, WN, n0, mt, smem, rowmap);
+    tile_epilogue<T, BM, BN, FM, FN, BNB>(p, acc, wm, wn, WM, WN, n0, mt, smem, rowmap);
 }
 
-template <int BM, int BN, int KS, int NS, int MODE>
+template <int BM, int BN, int KS, int NS, int MODE, bool BNB = false>
 __global__ __launch_bounds__(256) void igemm_fprop_async_kernel(const mg_conv_params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ntn = (p.Cout + BN - 1) / BN;
     int work;
     if (!xcd_order(((p.M + BM - 1) / BM) * ntn, work)) return;
-    igemm_fprop_async_tile<BM, BN, KS, NS, MODE>(p, p.M, work, smem);
+    igemm_fprop_async_tile<BM, BN, KS, NS, MODE, BNB>(p, p.M, work, smem);
 }
 
 template <int BM, int BN, int KS, int NS, int MODE>
@@ -790,7 +841,7 @@ template <int TH, int BN, int NS> struct HaloCfg {
 };
 
 
-template <int TH, int BN, int NS, int MODE>
+template <int TH, int BN, int NS, int MODE, bool BNB = false>
 __device__ __forceinline__ void igemm_fprop_halo_tile(const mg_conv_params& p, int work, char* smem) {
     using T = bf16raw;
     using TR = ElemTraits<T>;
@@ -945,17 +996,17 @@ __device__ __forceinline__ void igemm_fprop_halo_tile(const mg_conv_params& p, i
         const int y = y0 + rt / TW, x = x0 + (rt % TW);
         return (y < H && x < W) ? ((long)img * H + y) * W + x : -1l;
     };
-    tile_epilogue<T, BM, BN, FM, FN>(p, acc, wm, wn, WM, WN, n0, mt, smem, rowmap);
+    tile_epilogue<T, BM, BN, FM, FN, BNB>(p, acc, wm, wn, WM, WN, n0, mt, smem, rowmap);
     MG_STAMP(15);
 }
 
-template <int TH, int BN, int NS, int MODE>
+template <int TH, int BN, int NS, int MODE, bool BNB = false>
 __global__ __launch_bounds__(256) void igemm_fprop_halo_kernel(const mg_conv_params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tiles = p.N * ((p.Hout + TH - 1) / TH) * ((p.Wout + 15) / 16) * ((p.Cout + BN - 1) / BN);
     int work;
     if (!xcd_order(tiles, work)) return;
-    igemm_fprop_halo_tile<TH, BN, NS, MODE>(p, work, smem);
+    igemm_fprop_halo_tile<TH, BN, NS, MODE, BNB>(p, work, smem);
 }
 
 static inline bool halo_eligible(const mg_conv_params& p) {
@@ -976,11 +1027,15 @@ static int launch_fprop_halo(const mg_conv_params& p, hipStream_t st) {
     if (!attr_set) {
         hipFuncSetAttribute((const void*)igemm_fprop_halo_kernel<TH, BN, NS, MG_MODE_CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute((const void*)igemm_fprop_halo_kernel<TH, BN, NS, MG_MODE_TCONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)igemm_fprop_halo_kernel<TH, BN, NS, MG_MODE_TCONV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const long tiles = (long)p.N * ((p.Hout + TH - 1) / TH) * ((p.Wout + 15) / 16) * ((p.Cout + BN - 1) / BN);
     dim3 grid(xcd_grid(tiles));
-    if (p.mode == MG_MODE_CONV) hipLaunchKernelGGL((igemm_fprop_halo_kernel<TH, BN, NS, MG_MODE_CONV>), grid, dim3(256), lds, st, p);
+    if (p.bnb_x) {                                           // the data gradient of a 3x3 / stride 1 conv behind a BatchNorm layer
+        if (p.mode != MG_MODE_TCONV) return -2;
+        hipLaunchKernelGGL((igemm_fprop_halo_kernel<TH, BN, NS, MG_MODE_TCONV, true>), grid, dim3(256), lds, st, p);
+    } else if (p.mode == MG_MODE_CONV) hipLaunchKernelGGL((igemm_fprop_halo_kernel<TH, BN, NS, MG_MODE_CONV>), grid, dim3(256), lds, st, p);
     else hipLaunchKernelGGL((igemm_fprop_halo_kernel<TH, BN, NS, MG_MODE_TCONV>), grid, dim3(256), lds, st, p);
     MG_CHECK_LAUNCH();
     return 0;
@@ -1025,9 +1080,16 @@ int launch_fprop_async(const mg_conv_params& p, hipStream_t st) {
         hipFuncSetAttribute((const void*)igemm_fprop_async_kernel<BM, BN, KS, NS, MG_MODE_GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute((const void*)igemm_fprop_async_persistent_kernel<BM, BN, KS, NS, MG_MODE_CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute((const void*)igemm_fprop_async_persistent_kernel<BM, BN, KS, NS, MG_MODE_GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)igemm_fprop_async_kernel<BM, BN, KS, NS, MG_MODE_TCONV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const long tiles = (long)((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
+    if (p.bnb_x) {                                           // data gradient of a 1x1 conv behind a BatchNorm layer
+        if (p.m_dev || p.mode != MG_MODE_TCONV) return -2;
+        hipLaunchKernelGGL((igemm_fprop_async_kernel<BM, BN, KS, NS, MG_MODE_TCONV, true>), dim3(xcd_grid(tiles)), dim3(256), lds, st, p);
+        MG_CHECK_LAUNCH();
+        return 0;
+    }
     if (p.m_dev) {
         const long g = tiles < 2048 ? tiles : 2048;
         dim3 pg(xcd_grid(g < 1 ? 1 : g));
@@ -1071,7 +1133,17 @@ int launch_fprop(const mg_conv_params& p, hipStream_t st) {
         hipFuncSetAttribute((const void*)igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute((const void*)igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_TCONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute((const void*)igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_CONV, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_TCONV, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
+    }
+    if (p.bnb_x) {                                           // a data-gradient launch that also accumulates a BatchNorm layer's backward sums
+        if (p.m_dev) return -2;
+        if (p.mode == MG_MODE_CONV) hipLaunchKernelGGL((igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_CONV, false, true>), grid, dim3(256), lds, st, p, (float*)nullptr, 1);
+        else if (p.mode == MG_MODE_TCONV) hipLaunchKernelGGL((igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_TCONV, false, true>), grid, dim3(256), lds, st, p, (float*)nullptr, 1);
+        else return -2;
+        MG_CHECK_LAUNCH();
+        return 0;
     }
     if (p.m_dev) {
         // fixed persistent grid: enough workgroups to fill the chip (8 per CU at most), never more than the capacity needs
@@ -1195,11 +1267,27 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const mg_conv_params
                 x += rv2[e];
                 v[e] = x;
             }
+            float bxv[CE];
+            if (p.bnb_x) {                                     // BatchNorm-backward sums ride on the data-gradient tile (see tile_epilogue_impl)
+                const T* bxb = (const T*)p.bnb_x; const T* byb = (const T*)p.bnb_y;
+                const float bsl = p.bnb_act == MG_ACT_NONE ? 1.f : (p.bnb_act == MG_ACT_RELU ? 0.f : p.slope);
+#pragma unroll
+                for (int e = 0; e < CE; ++e) {
+                    const bool ok = cbase + e < p.Cout;
+                    bxv[e] = ok ? (TR::ld(bxb + (long)m * p.bnb_ld + cbase + e) - p.bnb_mean[cbase + e]) * p.bnb_invstd[cbase + e] : 0.f;
+                    if (byb && ok && !(TR::ld(byb + (long)m * p.bnb_ld + cbase + e) > 0.f)) v[e] *= bsl;
+                }
+            }
             const uint4 packed = TR::pack(v);                  // rounded once; the statistics are those of the rounded values
             if (p.stats) {
                 TR::unpack(packed, v);
+                if (p.bnb_x) {
 #pragma unroll
-                for (int e = 0; e < CE; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
+                    for (int e = 0; e < CE; ++e) { s1[e] += v[e]; s2[e] += v[e] * bxv[e]; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < CE; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
+                }
             }
             T* dst = yb + (long)m * p.ldy + p.yoff + cbase;
             if (full_vec) *(uint4*)dst = packed;
@@ -1380,7 +1468,7 @@ static int launch_fprop_c8(const mg_conv_params& p, hipStream_t st) {
 
 template <typename T>
 int dispatch_fprop(const mg_conv_params& p, hipStream_t st) {
-    if (sizeof(T) == 2 && fprop_c8_eligible(p)) return launch_fprop_c8(p, st);
+    if (sizeof(T) == 2 && !p.bnb_x && fprop_c8_eligible(p)) return launch_fprop_c8(p, st);
     if (sizeof(T) == 2 && halo_eligible(p)) return dispatch_fprop_halo(p, st);
     const int eps = sizeof(T) == 2 ? 32 : 16;
     if (tconv_phased(p)) {                       // stage width by the longest phase walk (ceil(R/2) * ceil(S/2) taps)

@@ -172,12 +172,10 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int nrep, co
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float n = count_ptr ? *count_ptr : count;
-    if (m_dev) {
-        n = (float)dev_rows(m_dev, (int)count);
-        if (n <= 0.f) {                                   // no active row at all: identity statistics, running stats untouched
-            scale[c] = gamma ? gamma[c] : 1.f; shift[c] = beta ? beta[c] : 0.f; mean_out[c] = 0.f; invstd_out[c] = 1.f;
-            return;
-        }
+    if (m_dev) n = (float)dev_rows(m_dev, (int)count);
+    if ((m_dev || count_ptr) && n <= 0.f) {               // no active row at all (on any rank, for SyncBN): identity statistics, running stats untouched
+        scale[c] = gamma ? gamma[c] : 1.f; shift[c] = beta ? beta[c] : 0.f; mean_out[c] = 0.f; invstd_out[c] = 1.f;
+        return;
     }
     float s1 = 0.f, s2 = 0.f;
     for (int r = 0; r < nrep; ++r) { s1 += stats[(size_t)r * 2 * C + c]; s2 += stats[(size_t)r * 2 * C + C + c]; }
@@ -270,6 +268,102 @@ __global__ __launch_bounds__(NT) void affine_act_kernel(const mg_rowwise_params 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Training BatchNorm, last forward pass: finalize + apply in ONE launch (round 3). Every workgroup re-derives scale / shift for
+// its own channels from the accumulated statistics (the replicas are summed through LDS by the first 2C threads -- at most 32
+// independent L2 loads per thread, then 2 * CE LDS reads per thread), workgroup 0 also writes scale | shift | mean | invstd for the backward
+// and updates the running statistics. Same arithmetic, in the same order, as bn_finalize_kernel + affine_act_kernel; what goes
+// away is a 6 us launch at the latency floor per BatchNorm layer (59 per step) and its dependent boundary.
+// Requires a fixed thread -> channel-chunk mapping (NT % (C / CE) == 0: every power-of-two channel count).
+// ---------------------------------------------------------------------------------------------------
+struct BnFin {
+    const float* stats; int nrep; int centered;
+    const float* gamma; const float* beta; float* running_mean; float* running_var;
+    float momentum, eps; float* outs;
+};
+
+template <typename T>
+__global__ __launch_bounds__(NT) void bn_apply_fused_kernel(const mg_rowwise_params p, const BnFin f) {
+    using TR = ElemTraits<T>;
+    constexpr int CE = TR::CE;
+    extern __shared__ float ssum[];                            // [2C] statistics summed over the replicas
+    const int C = p.C, cpr = C / CE;
+    const int Mrows = dev_rows(p.m_dev, p.M);
+    const long i0 = (long)blockIdx.x * NT + threadIdx.x;
+    int m = (int)(i0 / cpr);
+    const int cc = (int)(i0 - (long)m * cpr), c0 = cc * CE;
+    const int m_step = (int)(((long)gridDim.x * NT) / cpr);
+    const T* __restrict__ x = (const T*)p.x;
+    const T* __restrict__ r1 = (const T*)p.res;
+    const T* __restrict__ r2 = (const T*)p.res2;
+    T* __restrict__ y = (T*)p.y;
+    auto res_row = [&](int mm) -> long {
+        if (p.res_mode != 2) return mm;
+        const int hw = p.H * p.W; const int nn = mm / hw; const int rem = mm - nn * hw; const int ho = rem / p.W; const int wo = rem - ho * p.W;
+        return ((long)nn * (p.H >> 1) + (ho >> 1)) * (p.W >> 1) + (wo >> 1);
+    };
+    // the first row's operands are requested BEFORE the statistics are touched: most launches give a thread one or two rows, so the
+    // statistics round trip (L2 miss on words just written by atomics) and the tensor round trip overlap instead of adding up
+    uint4 qx = make_uint4(0, 0, 0, 0), qa = qx, qb = qx;
+    if (m < Mrows) {
+        qx = *(const uint4*)(x + (long)m * p.ldx + c0);
+        if (r1) qa = *(const uint4*)(r1 + res_row(m) * p.ldr + c0);
+        if (r2) qb = *(const uint4*)(r2 + (long)m * p.ldr2 + c0);
+    }
+    const float n = p.count_ptr ? *p.count_ptr : (p.m_dev ? (float)Mrows : p.count);
+    for (int j = threadIdx.x; j < 2 * C; j += NT) {
+        float a = 0.f;
+        for (int r = 0; r < f.nrep; ++r) a += f.stats[(size_t)r * 2 * C + j];
+        ssum[j] = a;
+    }
+    __syncthreads();
+    const bool ident = (p.m_dev || p.count_ptr) && n <= 0.f;  // no live row anywhere: identity statistics, running stats untouched
+    const bool writer = blockIdx.x == 0 && threadIdx.x < cpr;
+    float sc[CE], sh[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+        const int c = c0 + e;
+        const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
+        float mean = 0.f, invstd = 1.f, var = 0.f;
+        if (!ident) {
+            const float s1 = ssum[c], s2 = ssum[C + c];
+            mean = s1 / n;
+            var = f.centered ? s2 / n : s2 / n - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            invstd = rsqrtf(var + f.eps);
+        }
+        sc[e] = ident ? g : g * invstd;
+        sh[e] = ident ? b : b - mean * g * invstd;
+        if (writer) {
+            f.outs[c] = sc[e]; f.outs[C + c] = sh[e]; f.outs[2 * C + c] = mean; f.outs[3 * C + c] = invstd;
+            if (f.running_mean && !ident) {
+                const float unbiased = n > 1.f ? var * n / (n - 1.f) : var;
+                f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * mean;
+                f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * unbiased;
+            }
+        }
+    }
+    while (m < Mrows) {
+        const int mn = m + m_step;
+        uint4 nx = make_uint4(0, 0, 0, 0), na = nx, nb = nx;
+        if (mn < Mrows) {                                      // next row in flight under this row's arithmetic and store
+            nx = *(const uint4*)(x + (long)mn * p.ldx + c0);
+            if (r1) na = *(const uint4*)(r1 + res_row(mn) * p.ldr + c0);
+            if (r2) nb = *(const uint4*)(r2 + (long)mn * p.ldr2 + c0);
+        }
+        float v[CE], a[CE], b[CE];
+        TR::unpack(qx, v);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) { a[e] = 0.f; b[e] = 0.f; }
+        if (r1) TR::unpack(qa, a);
+        if (r2) TR::unpack(qb, b);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) v[e] = apply_act(v[e] * sc[e] + sh[e] + a[e], p.act, p.slope) + b[e];
+        *(uint4*)(y + (long)m * p.ldy + p.yoff + c0) = TR::pack(v);
+        m = mn; qx = nx; qa = na; qb = nb;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // BN backward, pass 1: sums[c] += sum_m g, sums[C+c] += sum_m g*xhat,  g = dy * act'(y) (y = post-activation output)
 // BN backward, pass 2: dx = scale_c * (g - sum_g/n - xhat * sum_gx/n)   [ * (x > 0) for the ReLU-before-BN shortcut ]
 //                      dres = g (optional, gradient of the pre-activation residual)
@@ -347,7 +441,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const mg_rowwise_param
     const int Mrows = dev_rows(p.m_dev, p.M);
     const long total = (long)Mrows * cpr;
     // sample count: the SyncBN global count when given, else the live rows of this rank (device word), else the host value
-    const float inv_n = p.count_ptr ? 1.f / *p.count_ptr : (p.m_dev ? (Mrows > 0 ? 1.f / (float)Mrows : 0.f) : 1.f / p.count);
+    const float inv_n = p.count_ptr ? (*p.count_ptr > 0.f ? 1.f / *p.count_ptr : 0.f) : (p.m_dev ? (Mrows > 0 ? 1.f / (float)Mrows : 0.f) : 1.f / p.count);
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
         int m = (int)(i / cpr), cc = (int)(i - (long)m * cpr);
         int c0 = cc * CE;
@@ -370,6 +464,73 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const mg_rowwise_param
 }
 
 // dgamma[c] = sums[C+c], dbeta[c] = sums[c] are read directly by the host side (fp32 tensors).
+
+// Pass 2 with a fixed thread -> channel-chunk mapping (round 3; NT % (C / CE) == 0): the per-channel constants (mean, invstd, scale, the two
+// sums) live in registers for the whole grid-stride walk instead of five parameter loads and a 64-bit division per 16-byte chunk. The
+// sums may arrive as `nrep` replicas of [2C] (accumulated by the consumer conv's data-gradient epilogue, mg_conv_params.bnb_*): they are
+// reduced through LDS here, workgroup 0 writes the totals to `sums_out` (= dbeta | dgamma). `premasked`: p.dy already holds
+// g = dy * act'(y) (written by that epilogue), so y is not read again.
+template <typename T>
+__global__ __launch_bounds__(NT) void bn_bwd_apply_fixed_kernel(const mg_rowwise_params p, const float* __restrict__ sums_rep, int nrep, int premasked,
+                                                                float* __restrict__ sums_out) {
+    using TR = ElemTraits<T>;
+    constexpr int CE = TR::CE;
+    extern __shared__ float ssum[];                            // [2C]
+    const int C = p.C, cpr = C / CE;
+    const int Mrows = dev_rows(p.m_dev, p.M);
+    const long i0 = (long)blockIdx.x * NT + threadIdx.x;
+    int m = (int)(i0 / cpr);
+    const int cc = (int)(i0 - (long)m * cpr), c0 = cc * CE;
+    const int m_step = (int)(((long)gridDim.x * NT) / cpr);
+    // first row's operands in flight before the sums are touched (see bn_apply_fused_kernel)
+    float g[CE];
+    uint4 qx = make_uint4(0, 0, 0, 0);
+    if (m < Mrows) {
+        if (premasked) TR::unpack(*(const uint4*)((const T*)p.dy + (long)m * p.lddy + c0), g);
+        else load_g<T>(p, m, c0, g);
+        qx = *(const uint4*)((const T*)p.x + (long)m * p.ldx + c0);
+    }
+    for (int j = threadIdx.x; j < 2 * C; j += NT) {
+        float a = 0.f;
+        for (int r = 0; r < nrep; ++r) a += sums_rep[(size_t)r * 2 * C + j];
+        ssum[j] = a;
+        if (sums_out && blockIdx.x == 0) sums_out[j] = a;
+    }
+    __syncthreads();
+    const float inv_n = p.count_ptr ? (*p.count_ptr > 0.f ? 1.f / *p.count_ptr : 0.f) : (p.m_dev ? (Mrows > 0 ? 1.f / (float)Mrows : 0.f) : 1.f / p.count);
+    float mu[CE], is[CE], sc[CE], sg[CE], sgx[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+        mu[e] = p.mean[c0 + e]; is[e] = p.invstd[c0 + e]; sc[e] = p.scale[c0 + e];
+        sg[e] = ssum[c0 + e] * inv_n; sgx[e] = ssum[C + c0 + e] * inv_n;
+    }
+    while (m < Mrows) {
+        const int mn = m + m_step;
+        float gn[CE];
+        uint4 nx = make_uint4(0, 0, 0, 0);
+        if (mn < Mrows) {
+            if (premasked) TR::unpack(*(const uint4*)((const T*)p.dy + (long)mn * p.lddy + c0), gn);
+            else load_g<T>(p, mn, c0, gn);
+            nx = *(const uint4*)((const T*)p.x + (long)mn * p.ldx + c0);
+        }
+        if (p.dres) *(uint4*)((T*)p.dres + (long)m * p.lddres + c0) = TR::pack(g);
+        if (p.dx) {
+            float xv[CE], o[CE];
+            TR::unpack(qx, xv);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
+                const float xh = (xv[e] - mu[e]) * is[e];
+                float v = sc[e] * (g[e] - sg[e] - xh * sgx[e]);
+                if (p.mask_x_pos && !(xv[e] > 0.f)) v = 0.f;
+                o[e] = v;
+            }
+            *(uint4*)((T*)p.dx + (long)m * p.lddx + c0) = TR::pack(o);
+        }
+        m = mn; qx = nx;
+#pragma unroll
+        for (int e = 0; e < CE; ++e) g[e] = gn[e];
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------
 // 2x2 average pool (AvgPool2d(2,2), encoder/resnet.py:113), its backward, 2x2 sum (nearest-upsample backward)
@@ -538,9 +699,36 @@ extern "C" int mg_bn_bwd_reduce(const mg_rowwise_params* p, void* stream) {
     return 0;
 }
 
+static bool bn_fixed_ok(const mg_rowwise_params& p) {
+    static const int on = [] { const char* e = getenv("MG_BN_FIXED_APPLY"); return e ? atoi(e) : 1; }();
+    const int ce = p.dtype == MG_BF16 ? 8 : 4;
+    const int cpr = p.C / ce;
+    return on && p.M > 0 && cpr > 0 && cpr <= NT && (NT % cpr) == 0 && p.ldx % ce == 0 && p.lddy % ce == 0 && (!p.dx || p.lddx % ce == 0) &&
+           (!p.dres || p.lddres % ce == 0);
+}
+static int bn_bwd_apply_fixed_launch(const mg_rowwise_params& p, const float* sums_rep, int nrep, int premasked, float* sums_out, hipStream_t st) {
+    const int ce = p.dtype == MG_BF16 ? 8 : 4;
+    const long total = (long)p.M * (p.C / ce);
+    const size_t lds = (size_t)2 * p.C * sizeof(float);
+    if (p.dtype == MG_BF16) hipLaunchKernelGGL(bn_bwd_apply_fixed_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), lds, st, p, sums_rep, nrep, premasked, sums_out);
+    else hipLaunchKernelGGL(bn_bwd_apply_fixed_kernel<float>, dim3(grid_for(total)), dim3(NT), lds, st, p, sums_rep, nrep, premasked, sums_out);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+/* BatchNorm backward, apply pass only, for a layer whose reductions were accumulated by the consumer conv's data-gradient epilogue
+ * (mg_conv_params.bnb_*): p->dy = g (already dy * act'(y)), sums_rep = nrep replicas of [2C]; sums_out [2C] receives dbeta | dgamma. */
+extern "C" int mg_bn_bwd_apply_linked(const mg_rowwise_params* p, const float* sums_rep, int nrep, float* sums_out, void* stream) {
+    int rc = rowwise_check(p); if (rc) return rc;
+    if (!sums_rep || nrep < 1 || !sums_out) return -2;
+    if (!bn_fixed_ok(*p)) return -3;
+    return bn_bwd_apply_fixed_launch(*p, sums_rep, nrep, 1, sums_out, (hipStream_t)stream);
+}
+
 extern "C" int mg_bn_bwd_apply(const mg_rowwise_params* p, void* stream) {
     int rc = rowwise_check(p); if (rc) return rc;
     if (p->M <= 0) return 0;
+    if (bn_fixed_ok(*p)) return bn_bwd_apply_fixed_launch(*p, p->sums, 1, 0, nullptr, (hipStream_t)stream);
     const int ce = p->dtype == MG_BF16 ? 8 : 4;
     long total = (long)p->M * (p->C / ce);
     if (p->dtype == MG_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, *p);
@@ -738,6 +926,24 @@ static int bn_small_bwd_launch(const mg_rowwise_params& p, hipStream_t st) {
     return 0;
 }
 
+static bool bn_fused_ok(const mg_rowwise_params& p) {
+    static const int on = [] { const char* e = getenv("MG_BN_FUSED_APPLY"); return e ? atoi(e) : 1; }();
+    const int ce = p.dtype == MG_BF16 ? 8 : 4;
+    const int cpr = p.C / ce;
+    return on && p.M > 0 && cpr > 0 && cpr <= NT && (NT % cpr) == 0 && p.ldx % ce == 0;
+}
+static int bn_apply_fused_launch(const mg_rowwise_params& p, const float* stats, int nrep, int centered, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, float momentum, float eps, float* outs, hipStream_t st) {
+    const int ce = p.dtype == MG_BF16 ? 8 : 4;
+    const long total = (long)p.M * (p.C / ce);
+    BnFin f{stats, nrep, centered, gamma, beta, running_mean, running_var, momentum, eps, outs};
+    const size_t lds = (size_t)2 * p.C * sizeof(float);
+    if (p.dtype == MG_BF16) hipLaunchKernelGGL(bn_apply_fused_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), lds, st, p, f);
+    else hipLaunchKernelGGL(bn_apply_fused_kernel<float>, dim3(grid_for(total)), dim3(NT), lds, st, p, f);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- one-call training BatchNorm (the four / two launches above behind ONE entry point: the per-call host cost of the Python
 // binding -- argument marshalling, allocations, autograd bookkeeping -- is paid once instead of per kernel; this matters for the
 // host-paced sparse head, where a BatchNorm forward cost 51 us of host time for ~15 us of kernels) ------------------------------
@@ -761,6 +967,7 @@ extern "C" int mg_bn_train_fwd(const mg_rowwise_params* p_in, float* stats_ws, i
         if (!own) return -3;
         if (!ws_zeroed) { hipError_t e = mg_zero_words(own, 2 * C, st); if (e != hipSuccess) return (int)e; }
         if (p.M > 0) { rc = mg_colstats_centered_dev(p.x, p.dtype, p.M, C, p.ldx, own, 0, p.m_dev, stream); if (rc) return rc; }
+        if (bn_fused_ok(p)) return bn_apply_fused_launch(p, own, 1, 1, gamma, beta, running_mean, running_var, momentum, eps, outs, st);
         rc = bn_finalize_launch(own, 1, nullptr, (float)p.M, C, 1, gamma, beta, running_mean, running_var, momentum, eps, outs, outs + C, outs + 2 * C,
                                 outs + 3 * C, p.m_dev, stream);
         if (rc) return rc;
@@ -778,6 +985,8 @@ extern "C" int mg_bn_train_fwd(const mg_rowwise_params* p_in, float* stats_ws, i
         rc = mg_colstats(p.x, p.dtype, p.M, C, p.ldx, own, stream); if (rc) return rc;
         stats = own; nrep = MG_STAT_REPLICAS;
     }
+    p.count = (float)p.M;
+    if (bn_fused_ok(p)) return bn_apply_fused_launch(p, stats, nrep, centered, gamma, beta, running_mean, running_var, momentum, eps, outs, st);
     rc = mg_bn_finalize(stats, nrep, nullptr, (float)p.M, C, centered, gamma, beta, running_mean, running_var, momentum, eps, outs, outs + C,
                         outs + 2 * C, outs + 3 * C, stream);
     if (rc) return rc;

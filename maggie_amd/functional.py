@@ -468,15 +468,41 @@ def pad_vec(v, n):
 # dense convolution (implicit GEMM) with optional bias / ReLU-before-BN epilogue and fused BN statistics
 # ----------------------------------------------------------------------------------------------------------------------
 
+BN_SMALL_ROWS = int(_os.environ.get('MG_BN_SMALL_ROWS', '1024'))     # layers up to this many rows run BatchNorm as one launch per direction (csrc/norm_act.hip)
+BN_LINK = _os.environ.get('MAGGIE_BN_LINK', '1') != '0'
+
+
+class BnLink:
+    """Hand-over between a training BatchNorm(+activation) layer and the ONE convolution that consumes its output z (round 3).
+
+    Backward of such a pair used to be: conv data-gradient kernel -> dz in HBM -> bn_bwd_reduce (reads dz, z, x) -> bn_bwd_apply (reads them
+    again). With a link the data-gradient kernel's epilogue -- which holds the dz tile in registers -- writes g = dz * act'(z) and accumulates
+    the layer's two reductions (sum g, sum g * xhat) itself (mg_conv_params.bnb_*), so only the apply pass is left: 59 launches and ~1.5 GB of
+    reads per step gone. The producer (`conv_bn_act(..., link_out=True)`) promises that z has no other consumer than one conv2d / conv_bn_act
+    call (a skip connection taken back through that conv's `carry` output is fine: its gradient is added inside the same epilogue)."""
+    __slots__ = ('x2', 'y', 'pack', 'act', 'C', 'M', 'consumers', 'sums', 'g')
+
+    def __init__(self):
+        self.x2 = self.y = self.pack = self.sums = self.g = None
+        self.act, self.C, self.M, self.consumers = ACT_NONE, 0, 0, 0
+
+    def ready(self):
+        return self.x2 is not None and self.consumers == 1
+
+    def clear(self):
+        self.x2 = self.y = self.pack = self.sums = self.g = None
+
+
 class ConvRaw(torch.autograd.Function):
     """y = [relu]( conv(x, w) + bias ).  x: (N,H,W,Cin) NHWC; w: (Cout, R*S, Cin) KRSC; transposed=True is
     ConvTranspose2d(k, stride, pad). `stats` (fp32 [2*Cout(+1)], zeroed) receives the BN batch statistics of y."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, R, S, stride, pad, dil, transposed, pre_relu, stats, carry=False):
+    def forward(ctx, x, w, bias, R, S, stride, pad, dil, transposed, pre_relu, stats, carry=False, link=None, mask_upstream=False):
         N, H, W_, Cin = x.shape
         Cout = w.shape[0]
         x = x.contiguous()
+        ctx.link, ctx.mask_upstream = link, bool(mask_upstream and pre_relu)
         mode = MODE_TCONV if transposed else MODE_CONV
         Ho = K.conv_out_size(mode, H, R, stride, pad, dil)
         Wo = K.conv_out_size(mode, W_, S, stride, pad, dil)
@@ -487,7 +513,8 @@ class ConvRaw(torch.autograd.Function):
         y = y.view(N, Ho, Wo, Cout)
         ctx.wt = getattr(w, '_mg_wt', None)                       # pre-transposed weights from the batched SpectralNorm kernel
         ctx.side = SIDE_WGRAD and getattr(w, '_mg_side_wgrad', False) and not transposed
-        ctx.save_for_backward(x, w, y if pre_relu else None)
+        # mask_upstream: the BatchNorm behind this conv's ReLU applies the ReLU mask in its own backward pass (mask_x_pos), y is not needed
+        ctx.save_for_backward(x, w, y if (pre_relu and not ctx.mask_upstream) else None)
         ctx.geom = (N, H, W_, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, transposed, pre_relu, bias is not None)
         if carry:
             # `carry`: the input is handed back as a second output for the caller's skip connection. Its gradient then arrives HERE (d_carry)
@@ -503,14 +530,23 @@ class ConvRaw(torch.autograd.Function):
         dy2 = dy.contiguous().view(-1, Cout)
         dx = dw = db = None
         want_db = has_bias and ctx.needs_input_grad[2]
-        if pre_relu or want_db:                                   # ReLU mask and bias gradient in one pass
-            dy2, db = K.bias_act_bwd(dy2, y.view(-1, Cout) if pre_relu else None, want_db)
+        mask_here = pre_relu and not ctx.mask_upstream
+        if mask_here or want_db:                                  # ReLU mask and bias gradient in one pass
+            dy2, db = K.bias_act_bwd(dy2, y.view(-1, Cout) if mask_here else None, want_db)
         if ctx.needs_input_grad[0]:
             wt = ctx.wt if (ctx.wt is not None and not transposed) else w.permute(2, 1, 0).contiguous()      # (Cin, taps, Cout)
             dmode = MODE_CONV if transposed else MODE_TCONV
             r2 = None if d_carry is None else d_carry.to(dy2.dtype).contiguous().view(-1, Cin)
+            link, bnb, sums_rep = ctx.link, None, None
+            if link is not None and link.ready() and link.C == Cin and link.M == N * H * W_ and link.x2.dtype == dy2.dtype:
+                # x is the output of a training BatchNorm layer with no other consumer: its backward reductions ride on this kernel's epilogue
+                Cb = link.C
+                sums_rep = ARENA.take(K.STAT_REPLICAS * 2 * Cb, dy2.device).view(K.STAT_REPLICAS, 2 * Cb)
+                bnb = (link.y if link.act != ACT_NONE else None, link.x2, link.pack[2 * Cb:3 * Cb], link.pack[3 * Cb:4 * Cb], link.act)
             dx = K.conv_fprop(dy2, wt, mode=dmode, N=N, Hin=Ho, Win=Wo, Hout=H, Wout=W_, R=R, S=S, stride=stride, pad=pad,
-                              dil=dil, alg_cout=ctx.cin_real, res2=r2).view(N, H, W_, Cin)
+                              dil=dil, alg_cout=ctx.cin_real, res2=r2, stats=sums_rep, bnb=bnb, slope=LRELU_SLOPE).view(N, H, W_, Cin)
+            if bnb is not None:
+                link.sums, link.g = sums_rep, dx
         elif d_carry is not None:
             dx = d_carry
         if ctx.needs_input_grad[1]:
@@ -530,11 +566,14 @@ class ConvRaw(torch.autograd.Function):
                 dwt = K.conv_wgrad(dy2, x.view(-1, Cin), cout=Cin, mode=MODE_CONV, N=N, Hin=Ho, Win=Wo, Hout=H, Wout=W_,
                                    R=R, S=S, stride=stride, pad=pad, dil=dil, out_dtype=w.dtype)
                 dw = dwt.permute(2, 1, 0).contiguous()
-        return dx, dw, db, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
 
 
-def conv2d(x, w, bias=None, R=3, S=3, stride=1, pad=1, dil=1, transposed=False, pre_relu=False, stats=None, carry=False):
-    return ConvRaw.apply(x, w, bias, R, S, stride, pad, dil, transposed, pre_relu, stats, carry)
+def conv2d(x, w, bias=None, R=3, S=3, stride=1, pad=1, dil=1, transposed=False, pre_relu=False, stats=None, carry=False, mask_upstream=False):
+    link = getattr(x, '_mg_bnlink', None) if (BN_LINK and torch.is_grad_enabled()) else None
+    if link is not None:
+        link.consumers += 1                                       # a link seen by two convolutions is void (BnLink.ready)
+    return ConvRaw.apply(x, w, bias, R, S, stride, pad, dil, transposed, pre_relu, stats, carry, link, mask_upstream)
 
 
 def linear_rows(x2d, w, bias=None, pre_relu=False, stats=None):
@@ -562,7 +601,8 @@ class BNAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, res, running_mean, running_var, training, momentum, eps, act, stats, res_mode, group,
-                mask_x_pos):
+                mask_x_pos, link=None):
+        ctx.link = None
         shape = x.shape
         C = shape[-1]
         x2 = x.contiguous().view(-1, C)
@@ -582,6 +622,11 @@ class BNAct(torch.autograd.Function):
             ctx.save_for_backward(x2, y, pack)
             ctx.fast = True
             ctx.meta = (shape, M, C, act, res is not None, res_mode, training, group, mask_x_pos, C, res.shape if res is not None else None)
+            if link is not None and M > BN_SMALL_ROWS and (C * x2.element_size()) % 16 == 0 and ((C * x2.element_size()) // 16 & ((C * x2.element_size()) // 16 - 1)) == 0:
+                # (layers up to BN_SMALL_ROWS rows already run their backward as ONE launch; the linked apply kernel wants a power-of-two
+                # number of 16-byte chunks per row)
+                link.x2, link.y, link.pack, link.act, link.C, link.M = x2, y, pack, act, C, M
+                ctx.link = link
             return y.view(shape)
         ctx.fast = False
         g32 = pad_vec(gamma.float(), C)
@@ -628,13 +673,24 @@ class BNAct(torch.autograd.Function):
         if ctx.fast:
             x2, y, pack = ctx.saved_tensors
             shape, M, C, act, has_res, res_mode, training, group, mask_x_pos, nch, res_shape = ctx.meta
+            link = ctx.link
+            if link is not None and link.g is not None and link.sums is not None and link.g.data_ptr() == dy.data_ptr() and dy.is_contiguous():
+                # the consumer conv's data-gradient epilogue already produced g = dy * act'(y) (in `dy`) and the two reductions
+                dx, sums = K.bn_bwd_apply_linked(dy.view(-1, C), x2, pack, link.sums, M, mask_x_pos)
+                dres = dy.view(-1, C) if has_res else None
+                link.clear()
+                if has_res:
+                    dres = K.pool2x2(dres, 1, shape[0], shape[1] // 2, shape[2] // 2).view(res_shape) if res_mode == 2 else dres.view(res_shape)
+                return dx.view(shape), sums[C:], sums[:C], dres, None, None, None, None, None, None, None, None, None, None, None
+            if link is not None:
+                link.clear()
             # inside a graph capture the accumulator is a slice of the graph's own zero arena (no fill kernel per layer); eagerly the
             # sums leave as gradients and must outlive the step's arena, so they get their own (zeroed in the call)
             sums = ARENA.take(2 * C, dy.device) if torch.cuda.is_current_stream_capturing() else None
             dx, dres, sums = K.bn_train_bwd(dy.contiguous().view(-1, C), y, x2, pack, act, LRELU_SLOPE, has_res, mask_x_pos, sums)
             if has_res:
                 dres = K.pool2x2(dres, 1, shape[0], shape[1] // 2, shape[2] // 2).view(res_shape) if res_mode == 2 else dres.view(res_shape)
-            return dx.view(shape), sums[C:], sums[:C], dres, None, None, None, None, None, None, None, None, None, None
+            return dx.view(shape), sums[C:], sums[:C], dres, None, None, None, None, None, None, None, None, None, None, None
         x2, y, scale, mean, invstd, cnt_t = ctx.saved_tensors
         shape, M, C, act, has_res, res_mode, training, group, mask_x_pos, nch, res_shape = ctx.meta
         dy2 = dy.contiguous().view(-1, C)
@@ -666,10 +722,10 @@ class BNAct(torch.autograd.Function):
                 dres = K.pool2x2(dres, 1, N, H // 2, W_ // 2).view(res_shape)
             else:
                 dres = dres.view(res_shape)
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None
 
 
-def batch_norm_act(x, bn, act=ACT_NONE, res=None, stats=None, res_mode=1, mask_x_pos=False):
+def batch_norm_act(x, bn, act=ACT_NONE, res=None, stats=None, res_mode=1, mask_x_pos=False, link=None):
     """`bn` is an nn.BatchNorm{1,2}d / nn.SyncBatchNorm used as the parameter + running-stat holder."""
     training = bn.training or (bn.running_mean is None)
     if training and bn.num_batches_tracked is not None and not DEFER_BN_COUNTERS:
@@ -679,7 +735,7 @@ def batch_norm_act(x, bn, act=ACT_NONE, res=None, stats=None, res_mode=1, mask_x
             bn.num_batches_tracked.add_(1)
     mom = 0.1 if bn.momentum is None else bn.momentum
     return BNAct.apply(x, bn.weight, bn.bias, res, bn.running_mean, bn.running_var, training, mom, bn.eps, act, stats, res_mode,
-                       _sync_group(bn) if training else None, mask_x_pos)
+                       _sync_group(bn) if training else None, mask_x_pos, link)
 
 
 def new_stats(channels, device, rows=None, bn=None):
@@ -691,9 +747,10 @@ def new_stats(channels, device, rows=None, bn=None):
 
 
 def conv_bn_act(x, w, bn, act=ACT_NONE, R=3, S=3, stride=1, pad=1, dil=1, transposed=False, res=None, res_mode=1, res2=None,
-                relu_before_bn=False, bias=None, carry=False):
+                relu_before_bn=False, bias=None, carry=False, link_out=False):
     """conv -> BN -> (+res) -> act (-> +res2).  In inference (no grad, eval BN) this is ONE fused kernel; in training the
-    conv epilogue accumulates the batch statistics and a second HBM pass applies them."""
+    conv epilogue accumulates the batch statistics and a second HBM pass applies them.
+    `link_out`: the caller guarantees that the returned activation is consumed by exactly ONE conv2d / conv_bn_act call (see BnLink)."""
     Cout = w.shape[0]
     fused = (not bn.training) and (not torch.is_grad_enabled())
     if fused:
@@ -718,11 +775,17 @@ def conv_bn_act(x, w, bn, act=ACT_NONE, R=3, S=3, stride=1, pad=1, dil=1, transp
         # fused statistics in the conv epilogue -- except on the largest, thinnest tensors (UNFUSED_STATS_ROWS)
         stats = new_stats(Cout, x.device, rows, bn) if rows < UNFUSED_STATS_ROWS else None
     xc = None
+    # ReLU-before-BN (encoder shortcuts): the BatchNorm's backward applies the ReLU mask itself (mask_x_pos: its input IS the ReLU output),
+    # so the conv's backward needs neither its saved output nor a masking pass over the gradient
+    mask_up = bool(relu_before_bn and bn.training and bias is None)
     if carry and torch.is_grad_enabled() and x.requires_grad:
-        y, xc = conv2d(x, w, bias, R, S, stride, pad, dil, transposed, relu_before_bn, stats, True)
+        y, xc = conv2d(x, w, bias, R, S, stride, pad, dil, transposed, relu_before_bn, stats, True, mask_upstream=mask_up)
     else:
-        y = conv2d(x, w, bias, R, S, stride, pad, dil, transposed, relu_before_bn, stats)
-    y = batch_norm_act(y, bn, ACT_NONE if relu_before_bn else act, res=res, stats=stats, res_mode=res_mode)
+        y = conv2d(x, w, bias, R, S, stride, pad, dil, transposed, relu_before_bn, stats, mask_upstream=mask_up)
+    link = BnLink() if (link_out and BN_LINK and bn.training and res2 is None and torch.is_grad_enabled()) else None
+    y = batch_norm_act(y, bn, ACT_NONE if relu_before_bn else act, res=res, stats=stats, res_mode=res_mode, mask_x_pos=mask_up, link=link)
+    if link is not None and link.x2 is not None:
+        y._mg_bnlink = link
     if res2 is not None:
         y = y + res2
     return (y, x if xc is None else xc) if carry else y

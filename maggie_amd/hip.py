@@ -37,6 +37,8 @@ class ConvParams(ctypes.Structure):
         ('act', ctypes.c_int32), ('pre_act', ctypes.c_int32), ('res_mode', ctypes.c_int32),
         ('slope', ctypes.c_float), ('dw_dtype', ctypes.c_int32), ('stat_mode', ctypes.c_int32),
         ('m_dev', ctypes.c_void_p),
+        ('bnb_y', ctypes.c_void_p), ('bnb_x', ctypes.c_void_p), ('bnb_mean', ctypes.c_void_p), ('bnb_invstd', ctypes.c_void_p),
+        ('bnb_act', ctypes.c_int32), ('bnb_ld', ctypes.c_int32),
     ]
 
 

@@ -42,7 +42,7 @@ def _conv_params(x, w, y, mode, N, Hin, Win, Hout, Wout, R, S, stride, pad, dil,
 
 def conv_fprop(x, w, *, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=None, Wout=None, R=1, S=1, stride=1, pad=0, dil=1,
                M=None, nbr=None, scale=None, shift=None, res=None, res_mode=1, res2=None, act=ACT_NONE, pre_act=False,
-               slope=0.2, stats=None, out=None, yoff=0, cout=None, rows=None, alg_cin=None, alg_cout=None):
+               slope=0.2, stats=None, out=None, yoff=0, cout=None, rows=None, alg_cin=None, alg_cout=None, bnb=None):
     """Y = epilogue(implicit GEMM). x: (..., Cin) channel-contiguous; w: (Cout, R*S, Cin) same dtype.
     Dense modes: rows of x are (n, h, w) of an (N, Hin, Win) map; gather mode: rows of x are sparse sites, `nbr` (M, R*S).
     `out`/`yoff` let the result land in a channel slice of a wider buffer (zero-copy concat)."""
@@ -75,6 +75,15 @@ def conv_fprop(x, w, *, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=None, Wout=None,
                      res, res_mode, res2, act, pre_act, slope, stats, yoff)
     p.stat_mode = stat_mode
     p.m_dev = hip.ptr(rows)                    # device row count (sparse head): M is then the capacity, the launch a persistent grid
+    if bnb is not None:
+        # this launch produces the gradient at the OUTPUT of a training BatchNorm layer: its epilogue writes g = dz * act'(z) and accumulates
+        # that layer's backward sums into `stats` (replicated layout) -- bnb = (z | None, x, mean, invstd, act), rows x Cout like `out`
+        bz, bx, bmean, binv, bact = bnb
+        assert stats is not None and stat_mode == 0 and bx.dtype == x.dtype and bx.shape[-1] == Cout and _ld(bx) == Cout
+        assert bz is None or (bz.dtype == x.dtype and _ld(bz) == Cout)
+        hip.need_cuda(bx, bmean, binv)
+        p.bnb_y, p.bnb_x, p.bnb_mean, p.bnb_invstd = hip.ptr(bz), hip.ptr(bx), hip.ptr(bmean), hip.ptr(binv)
+        p.bnb_act, p.bnb_ld = bact, Cout
     # bench accounting: `work` = ALGORITHMIC FLOPs -- the taps that exist (a stride-s transposed / data-gradient conv touches
     # R*S/s^2 taps per output row on average; the rest of what MG_MODE_TCONV multiplies are structural zeros) and the real, unpadded
     # channel counts; the executed FLOPs ride along in the tag. A device row count (sparse head) makes the work unknown here: None.
@@ -273,6 +282,25 @@ def bn_backward(dy, y, x, scale, mean, invstd, count, act=ACT_NONE, slope=0.2, w
         p.dres, p.lddres = hip.ptr(dres), C
     hip.call('mg_bn_bwd_apply', ctypes.byref(p), hip.stream())
     return dx, dres, sums
+
+
+def bn_bwd_apply_linked(g, x, outs, sums_rep, count, mask_x_pos=False, rows=None):
+    """BatchNorm backward, apply pass only: `g` = dy * act'(y) and `sums_rep` ([nrep, 2C] replicas of sum g | sum g * xhat) were produced by
+    the consumer conv's data-gradient epilogue (conv_fprop(bnb=...)). -> dx, sums [2C] = dbeta | dgamma. The residual gradient of the layer
+    IS g."""
+    M, C = x.shape[0], x.shape[-1]
+    p = _rowwise(x, M, C)
+    p.dy, p.lddy = hip.ptr(g), _ld(g)
+    base = outs.data_ptr()
+    p.scale, p.mean, p.invstd = ctypes.c_void_p(base), ctypes.c_void_p(base + 8 * C), ctypes.c_void_p(base + 12 * C)
+    p.count, p.mask_x_pos = float(count), int(mask_x_pos)
+    p.m_dev = hip.ptr(rows)
+    dx = torch.empty((M, C), dtype=x.dtype, device=x.device)
+    p.dx, p.lddx = hip.ptr(dx), C
+    sums = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    hip.call('mg_bn_bwd_apply_linked', ctypes.byref(p), hip.ptr(sums_rep), c_int(sums_rep.shape[0] if sums_rep.dim() == 2 else 1), hip.ptr(sums),
+             hip.stream())
+    return dx, sums
 
 
 def bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, act, slope, res=None, res_mode=1, H=1, W=1, stats=None,

@@ -198,6 +198,19 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
                 flag = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
         return bool(flag) and self.training
 
+    def _rank_safe_graphs(self):
+        """Must every rank replay the same graphs whatever its data? Attribute `rank_safe_graphs`, env MAGGIE_RANK_SAFE_GRAPHS=0/1, default:
+        world size > 1 (the graphs then carry the overlapped gradient exchange, parallel.OverlappedGradSync)."""
+        flag = self.__dict__.get('rank_safe_graphs')
+        if flag is None:
+            import os
+            env = os.environ.get('MAGGIE_RANK_SAFE_GRAPHS')
+            if env is not None:
+                flag = env != '0'
+            else:
+                flag = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+        return bool(flag)
+
     def _graphed(self, store, key, fn, inputs, grad_inputs=()):
         """fn(*inputs) eagerly the first time `key` is seen, captured into hipGraphs (forward + backward) the second time, replayed from
         then on. -> (outputs, replayed?). `key` None: always eager."""
@@ -318,7 +331,10 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             dense.insert(4, None)                                 # the image decoder has no recurrent hidden state
         alphas = trans_gt = use_w = None
         if self.training:
-            alphas, trans_gt, use_w = tensors[n_dense:n_dense + 3]
+            alphas, trans_gt, step_flags = tensors[n_dense:n_dense + 3]      # step_flags: int32 [use the fuse weights, ground truth guides the region]
+            use_w = step_flags[:1]
+            if plan.get('use_gt') is None:
+                plan = dict(plan, use_gt_dev=step_flags[1:2])
         pred = self.decoder.detail_stage(dense, (h, w), b, n_f, n_i, plan, alphas, spar_gt=trans_gt)
         alpha_pred = pred.pop("refined_masks")
         weight_os4 = pred["detail_mask"].type(alpha_pred.dtype)
@@ -365,11 +381,14 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         dense = [t for t in dense if t is not None]
         n_dense = len(dense)
         extra = []
+        rank_safe = self.training and self._rank_safe_graphs()
         if self.training:
-            extra = [alphas, trans_gt, torch.tensor([int(use_fuse_w)], dtype=torch.int32).to(dense[0].device, non_blocking=True)]
+            extra = [alphas, trans_gt, torch.tensor([int(use_fuse_w), int(plan['use_gt'])], dtype=torch.int32).to(dense[0].device, non_blocking=True)]
         host_w = [plan['widths']] if plan['widths'] is not None else []
         inputs = list(dense) + extra + host_w
-        static_plan = {'use_gt': plan['use_gt'], 'with_atten': plan['with_atten']}
+        # rank_safe: `use_gt` is per-rank data (random.random(), x_os8.sum() == 0): as part of the static plan / graph key it would let the
+        # ranks of a data-parallel job replay DIFFERENT graphs -- i.e. issue different gradient collectives. It travels as a device flag then.
+        static_plan = {'use_gt': None if rank_safe else plan['use_gt'], 'with_atten': plan['with_atten']}
 
         def fn(*t):
             p = dict(static_plan, widths=t[n_dense + len(extra)] if host_w else None)
@@ -377,17 +396,35 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             fn.names = names
             return outs
 
-        key = None
-        if self._graph_policy():
-            key = (geom, self.training, MF.compute_dtype(), plan['use_gt'], plan['with_atten'], tuple((tuple(t.shape), t.dtype) for t in inputs))
+        key = self._detail_key(geom, static_plan, inputs) if self._graph_policy() else None
         names_key = ('names', key)
         outs, replayed = self._graphed('_detail_graphs', key, fn, inputs, grad_inputs=range(n_dense))
         store = self.__dict__.setdefault('_detail_names', {})
         if replayed:
-            return store[names_key], outs
+            return store[names_key], self._own_outputs(store[names_key], outs)
         outs = fn(*inputs)
         store[names_key] = fn.names
         return fn.names, outs
+
+    def _detail_key(self, geom, static_plan, inputs):
+        """What selects a captured detail graph: geometry, mode, dtype, the STATIC part of the plan and the input signature -- never per-rank
+        data when `static_plan['use_gt']` is None (rank-safe mode: the guidance choice is a device flag among `inputs`)."""
+        return (geom, self.training, MF.compute_dtype(), static_plan['use_gt'], static_plan['with_atten'],
+                tuple((tuple(t.shape), t.dtype) for t in inputs))
+
+    @staticmethod
+    def _own_outputs(names, outs):
+        """A replayed graph hands back views of ITS static output buffers, which the next forward with the same geometry overwrites.
+        Everything the caller receives (alphas, detail mask, memory features, logged loss scalars) is copied out with one multi-tensor
+        launch, so outputs held across calls (VideoWindow, metric / demo code) keep their values -- as they do on the eager path."""
+        outs = list(outs)
+        idx = [i for i, (n, t) in enumerate(zip(names, outs)) if not t.requires_grad]
+        if idx:
+            fresh = [torch.empty_like(outs[i]) for i in idx]
+            torch._foreach_copy_(fresh, [outs[i] for i in idx])
+            for i, f in zip(idx, fresh):
+                outs[i] = f
+        return tuple(t.clone() if t.requires_grad else t for t in outs)        # 'loss/total': a differentiable one-element copy
 
     @staticmethod
     def _add_to_total(loss_dict, term, coef):

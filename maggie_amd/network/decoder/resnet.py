@@ -22,15 +22,15 @@ class BasicBlock(nn.Module):
         self.bn2 = norm_layer(planes)
         self.upsample = upsample
 
-    def forward(self, x, post_add=None):
+    def forward(self, x, post_add=None, link_out=False):
         """`post_add` (the encoder shortcut feature) is added after the block's activation; fused into the last kernel in
-        inference."""
+        inference. `link_out`: the caller feeds the result to the next block's first conv and to nothing else (functional.BnLink)."""
         dt = x.dtype
         # `carry`: the skip branch takes x back from the first conv, whose data-gradient kernel then adds the skip gradient in its epilogue
         if self.stride > 1:
-            out, x = MF.conv_bn_act(x, self.conv1.krsc(dt, x.shape[-1]), self.bn1, MF.ACT_LRELU, 4, 4, 2, 1, 1, transposed=True, carry=True)
+            out, x = MF.conv_bn_act(x, self.conv1.krsc(dt, x.shape[-1]), self.bn1, MF.ACT_LRELU, 4, 4, 2, 1, 1, transposed=True, carry=True, link_out=True)
         else:
-            out, x = MF.conv_bn_act(x, self.conv1.krsc(dt, x.shape[-1]), self.bn1, MF.ACT_LRELU, 3, 3, 1, 1, 1, carry=True)
+            out, x = MF.conv_bn_act(x, self.conv1.krsc(dt, x.shape[-1]), self.bn1, MF.ACT_LRELU, 3, 3, 1, 1, 1, carry=True, link_out=True)
         identity, res_mode = x, 1
         if self.upsample is not None:
             u = self.upsample
@@ -41,4 +41,4 @@ class BasicBlock(nn.Module):
             else:
                 identity = MF.conv_bn_act(x, u[0].krsc(dt, x.shape[-1]), u[1], MF.ACT_NONE, 1, 1, 1, 0, 1)
         return MF.conv_bn_act(out, self.conv2.krsc(dt, out.shape[-1]), self.bn2, MF.ACT_LRELU, 3, 3, 1, 1, 1, res=identity,
-                              res_mode=res_mode, res2=post_add)
+                              res_mode=res_mode, res2=post_add, link_out=link_out and post_add is None)

@@ -158,16 +158,19 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
         Returns fp32 planes (N*n_i, H/4, W/4) and (N*n_i, H, W) with -99 outside the active sites, and the pyramid.
         No site count ever reaches the host (maggie_amd/sparse_head.py)."""
         fea1, fea2, fea3 = dense_features
-        patch = (200, 250, 200, 250) if (self.training and H > 200 and W > 200) else None      # "dummy code to prevent all zeros"
+        # "dummy code to prevent all zeros" (:347-348): `unknown_os8[:, :, 200:250, 200:250] = 1` -- a slice assignment, so the square
+        # is clipped to the plane (and is a no-op on planes of 200 pixels or less)
+        patch = (200, min(250, H), 200, min(250, W)) if (self.training and H > 200 and W > 200) else None
         pyr = DevicePyramid(roi_bits, H, W, patch)
         env = self._head_env(pyr, n_i, os8_feat.dtype)
         x_os4, x_os1 = SparseHead.apply(env, os8_feat.contiguous(), inst_guidance_os8, fea1.contiguous(), fea2.contiguous(), fea3.contiguous(),
                                         *env.params)
         return x_os4, x_os1, pyr
 
-    def fuse(self, pred, detail_bits, widths=None):
+    def fuse(self, pred, detail_bits, widths=None, want_bits=False):
         """Progressive refinement (:272-290) with the two compute_unknown calls on device bit planes. `widths` (2, P) device int32: the
-        train-mode dilation widths for k = 27 and k = 15 when the caller already drew them (detail_plan)."""
+        train-mode dilation widths for k = 27 and k = 15 when the caller already drew them (detail_plan). `want_bits`: return the two
+        weight planes as bit planes (the caller selects between them and the ground-truth-guided ones on the device, then unpacks once)."""
         a1, a4, a8 = pred['alpha_os1'], pred['alpha_os4'], pred['alpha_os8']
         H, W = a8.shape[-2:]
         alpha = a8
@@ -177,6 +180,8 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
         alpha = MF.bits_select(bits4, a4, alpha, W)
         bits1 = MF.unknown_bits(alpha, 15, self.training, andmask=detail_bits, widths=w15)
         alpha = MF.bits_select(bits1, a1, alpha, W)
+        if want_bits:
+            return alpha, bits4, bits1
         w4 = K.bits_unpack_u8(bits4, W, a8.shape).to(alpha.dtype)
         w1 = K.bits_unpack_u8(bits1, W, a8.shape).to(alpha.dtype)
         return alpha, w4, w1
@@ -189,10 +194,10 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
             gt_masks = (gt_alphas > 0).reshape(b, n_f, n_i, gt_alphas.shape[2], gt_alphas.shape[3])
         fea1, fea2, fea3, fea4, fea5 = mid_fea['shortcut']
         image = mid_fea['image']
-        x = self.layer1[0](x)
+        x = self.layer1[0](x, link_out=True)
         x = self.layer1[1](x, post_add=fea5)
-        x = self.layer2[0](x)
-        x = self.layer2[1](x)
+        x = self.layer2[0](x, link_out=True)
+        x = self.layer2[1](x, link_out=True)
         x = self.layer2[2](x, post_add=fea4)
         h, w = image.shape[-2:]
         return x, masks, valid_masks, gt_masks, fea1, fea2, fea3, image, h, w
@@ -299,15 +304,32 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
         if not self.training:
             x_os8 = x_os8[:, :n_i].contiguous()
         use_gt, widths = plan['use_gt'], plan['widths']
-        guided = gt_alphas if use_gt else x_os8
-        n_cur = guided.shape[1]
-        detail_bits = MF.unknown_bits(guided, 30, False)                                   # (N*n_cur, H, Ww)
+        gt_dev = plan.get('use_gt_dev')
+        if gt_dev is not None:
+            # Data-parallel runs (arch/maggie.py:_rank_safe_graphs): whether the ground truth guides the detail region is a PER-RANK decision
+            # (random.random(), `x_os8.sum() == 0`), and it must not select a different captured graph on different ranks -- the graphs carry
+            # the gradient collectives. Both guidance sources have the same static shape, so both are evaluated (bit planes: 1/64 of the
+            # alpha planes) and the device flag selects between them word by word.
+            sel = gt_dev.bool()
+            detail_bits = torch.where(sel, MF.unknown_bits(gt_alphas, 30, False), MF.unknown_bits(x_os8, 30, False))
+            n_cur = x_os8.shape[1]
+        else:
+            guided = gt_alphas if use_gt else x_os8
+            n_cur = guided.shape[1]
+            detail_bits = MF.unknown_bits(guided, 30, False)                               # (N*n_cur, H, Ww)
         x_os4, x_os1, detail_bits = self.process_os4_os1(x, b, n_f, fea1, fea2, fea3, hw, x_os8, queries, n_cur, detail_bits)
         ret = {'alpha_os1': x_os1, 'alpha_os4': x_os4, 'alpha_os8': x_os8}
-        alpha_pred, weight_os4, weight_os1 = self.fuse(ret, detail_bits, widths)
+        if gt_dev is not None:
+            alpha_pred, bits4, bits1 = self.fuse(ret, detail_bits, widths, want_bits=True)
+            g4 = MF.unknown_bits(gt_alphas, 30, self.training, andmask=detail_bits, widths=widths[2])
+            g1 = MF.unknown_bits(gt_alphas, 15, self.training, andmask=detail_bits, widths=widths[3])
+            weight_os4 = K.bits_unpack_u8(torch.where(sel, g4, bits4), w, x_os8.shape)
+            weight_os1 = K.bits_unpack_u8(torch.where(sel, g1, bits1), w, x_os8.shape)
+        else:
+            alpha_pred, weight_os4, weight_os1 = self.fuse(ret, detail_bits, widths)
         ret['refined_masks'] = alpha_pred
         unknown_os8 = K.bits_unpack_u8(detail_bits, w, x_os8.shape)
-        if use_gt:
+        if use_gt and gt_dev is None:
             weight_os4 = K.bits_unpack_u8(MF.unknown_bits(gt_alphas, 30, self.training, andmask=detail_bits, widths=widths[2]), w, x_os8.shape)
             weight_os1 = K.bits_unpack_u8(MF.unknown_bits(gt_alphas, 15, self.training, andmask=detail_bits, widths=widths[3]), w, x_os8.shape)
         ret['weight_os4'] = weight_os4

@@ -28,8 +28,8 @@ class ResShortCut_InstMattSpconv_BiTempSpar_Dec(ResShortCut_InstMattSpconv_Dec):
         """x: (b, h, w, 128) NHWC -> fp32 logits upsampled x8: (b, 1, H, W)."""
         m = self.diff_module
         dt = x.dtype
-        x = MF.conv_bn_act(x, m[0].krsc(dt, x.shape[-1]), m[1], MF.ACT_RELU, 1, 1, 1, 0, 1)
-        x = MF.conv_bn_act(x, m[3].krsc(dt, x.shape[-1]), m[4], MF.ACT_RELU, 3, 3, 1, 1, 1)
+        x = MF.conv_bn_act(x, m[0].krsc(dt, x.shape[-1]), m[1], MF.ACT_RELU, 1, 1, 1, 0, 1, link_out=True)
+        x = MF.conv_bn_act(x, m[3].krsc(dt, x.shape[-1]), m[4], MF.ACT_RELU, 3, 3, 1, 1, 1, link_out=True)
         x = MF.conv2d(x, MF.weight_oihw_to_krsc(m[6].weight, dt, None, 8), None, 3, 3, 1, 1, 1)
         return MF.upsample_tanh(x, 1, 8, True, apply_tanh=False)
 
@@ -85,12 +85,18 @@ class ResShortCut_InstMattSpconv_BiTempSpar_Dec(ResShortCut_InstMattSpconv_Dec):
         if not self.training:
             x_os8 = x_os8[:, :n_i].contiguous()
         use_gt, widths = plan['use_gt'], plan['widths']
-        guided = gt_alphas if use_gt else x_os8
-        if not self.training:
-            x_os8 = torch.where(x_os8 >= 0.95, torch.ones_like(x_os8), x_os8)
-            guided = x_os8
-        n_cur = guided.shape[1]
-        detail_bits = MF.unknown_bits(guided, 30, False)
+        gt_dev = plan.get('use_gt_dev') if self.training else None      # data parallel: the guidance source is a device-side select (image decoder)
+        if gt_dev is not None:
+            sel = gt_dev.bool()
+            detail_bits = torch.where(sel, MF.unknown_bits(gt_alphas, 30, False), MF.unknown_bits(x_os8, 30, False))
+            n_cur = x_os8.shape[1]
+        else:
+            guided = gt_alphas if use_gt else x_os8
+            if not self.training:
+                x_os8 = torch.where(x_os8 >= 0.95, torch.ones_like(x_os8), x_os8)
+                guided = x_os8
+            n_cur = guided.shape[1]
+            detail_bits = MF.unknown_bits(guided, 30, False)
         if not self.training:
             # ignore everything outside each instance's padded bounding box (:121-142): smoothing, resize, threshold, per-plane bounding box
             # and its application to the coarse alpha and the detail bit planes in four small HIP kernels (mg_temporal_crop)
@@ -99,12 +105,19 @@ class ResShortCut_InstMattSpconv_BiTempSpar_Dec(ResShortCut_InstMattSpconv_Dec):
             guided = x_os8
         x_os4, x_os1, detail_bits = self.process_os4_os1(x, b, n_f, fea1, fea2, fea3, hw, x_os8, queries, n_cur, detail_bits)
         ret = {'alpha_os1': x_os1, 'alpha_os4': x_os4, 'alpha_os8': x_os8}
-        alpha_pred, weight_os4, weight_os1 = self.fuse(ret, detail_bits, widths)
+        if gt_dev is not None:
+            alpha_pred, bits4, bits1 = self.fuse(ret, detail_bits, widths, want_bits=True)
+            g4 = MF.unknown_bits(gt_alphas, 30, self.training, andmask=detail_bits, widths=widths[2])
+            g1 = MF.unknown_bits(gt_alphas, 15, self.training, andmask=detail_bits, widths=widths[3])
+            weight_os4 = K.bits_unpack_u8(torch.where(sel, g4, bits4), w, x_os8.shape)
+            weight_os1 = K.bits_unpack_u8(torch.where(sel, g1, bits1), w, x_os8.shape)
+        else:
+            alpha_pred, weight_os4, weight_os1 = self.fuse(ret, detail_bits, widths)
         ret['refined_masks'] = alpha_pred
         ret['detail_mask'] = K.bits_unpack_u8(detail_bits, w, x_os8.shape)
         if self.use_temp:
             ret['mem_feat'] = mem_feat
-        if use_gt:
+        if use_gt and gt_dev is None:
             weight_os4 = K.bits_unpack_u8(MF.unknown_bits(gt_alphas, 30, self.training, andmask=detail_bits, widths=widths[2]), w, x_os8.shape)
             weight_os1 = K.bits_unpack_u8(MF.unknown_bits(gt_alphas, 15, self.training, andmask=detail_bits, widths=widths[3]), w, x_os8.shape)
         ret['weight_os4'] = weight_os4

@@ -20,12 +20,13 @@ class BasicBlock(nn.Module):
         self.bn2 = norm_layer(planes)
         self.downsample = downsample
         self.stride = stride
+        self.link_out = False        # set by ResNet_D: this block's output feeds the next block's conv1 and nothing else (functional.BnLink)
 
     def forward(self, x):
         dt = x.dtype
         # the skip branch takes x back FROM the first conv (`carry`): in backward the skip gradient is added inside that conv's
         # data-gradient kernel instead of by a separate add over the feature map
-        out, x = MF.conv_bn_act(x, self.conv1.krsc(dt, x.shape[-1]), self.bn1, MF.ACT_RELU, 3, 3, self.stride, 1, 1, carry=True)
+        out, x = MF.conv_bn_act(x, self.conv1.krsc(dt, x.shape[-1]), self.bn1, MF.ACT_RELU, 3, 3, self.stride, 1, 1, carry=True, link_out=True)
         identity = x
         if self.downsample is not None:
             d = self.downsample
@@ -34,7 +35,7 @@ class BasicBlock(nn.Module):
                 identity = MF.conv_bn_act(identity, d[1].krsc(dt, identity.shape[-1]), d[2], MF.ACT_NONE, 1, 1, 1, 0, 1)
             else:
                 identity = MF.conv_bn_act(x, d[0].krsc(dt, x.shape[-1]), d[1], MF.ACT_NONE, 1, 1, self.stride, 0, 1)
-        return MF.conv_bn_act(out, self.conv2.krsc(dt, out.shape[-1]), self.bn2, MF.ACT_RELU, 3, 3, 1, 1, 1, res=identity)
+        return MF.conv_bn_act(out, self.conv2.krsc(dt, out.shape[-1]), self.bn2, MF.ACT_RELU, 3, 3, 1, 1, 1, res=identity, link_out=self.link_out)
 
 
 class ResNet_D(nn.Module):
@@ -84,6 +85,8 @@ class ResNet_D(nn.Module):
         self.inplanes = planes * block.expansion
         for _ in range(1, blocks):
             layers.append(block(self.inplanes, planes, norm_layer=norm_layer))
+        for blk in layers[:-1]:
+            blk.link_out = True          # the last block's output also feeds a shortcut branch / the ASPP: several consumers
         return nn.Sequential(*layers)
 
 
@@ -105,15 +108,15 @@ class ResShortCut_D(ResNet_D):
     @staticmethod
     def _run_shortcut(seq, x):
         dt = x.dtype
-        x = MF.conv_bn_act(x, seq[0].krsc(dt, x.shape[-1]), seq[2], MF.ACT_NONE, 3, 3, 1, 1, 1, relu_before_bn=True)
+        x = MF.conv_bn_act(x, seq[0].krsc(dt, x.shape[-1]), seq[2], MF.ACT_NONE, 3, 3, 1, 1, 1, relu_before_bn=True, link_out=True)
         return MF.conv_bn_act(x, seq[3].krsc(dt, x.shape[-1]), seq[5], MF.ACT_NONE, 3, 3, 1, 1, 1, relu_before_bn=True)
 
     def forward_features(self, x):
         """x: (N, H, W, 8) NHWC (RGB + 3 embedding channels + 2 zero pad)."""
         dt = x.dtype
-        out = MF.conv_bn_act(x, self.conv1.krsc(dt, 8), self.bn1, MF.ACT_RELU, 3, 3, self.start_stride[0], 1, 1)
-        x1 = MF.conv_bn_act(out, self.conv2.krsc(dt), self.bn2, MF.ACT_RELU, 3, 3, self.start_stride[1], 1, 1)
-        out = MF.conv_bn_act(x1, self.conv3.krsc(dt), self.bn3, MF.ACT_RELU, 3, 3, self.start_stride[2], 1, 1)
+        out = MF.conv_bn_act(x, self.conv1.krsc(dt, 8), self.bn1, MF.ACT_RELU, 3, 3, self.start_stride[0], 1, 1, link_out=True)
+        x1 = MF.conv_bn_act(out, self.conv2.krsc(dt), self.bn2, MF.ACT_RELU, 3, 3, self.start_stride[1], 1, 1)       # x1 also feeds shortcut[1]
+        out = MF.conv_bn_act(x1, self.conv3.krsc(dt), self.bn3, MF.ACT_RELU, 3, 3, self.start_stride[2], 1, 1, link_out=True)
         x2 = self.layer1(out)
         x3 = self.layer2(x2)
         x4 = self.layer3(x3)

@@ -39,4 +39,4 @@ class ASPP(nn.Module):
         outs.append(x5.expand(N, H, W_, x5.shape[-1]))                             # nearest upsample of a 1x1 map
         y = torch.cat(outs, -1)
         w2 = MF.plain_krsc(self.conv2, dt)
-        return MF.conv_bn_act(y, w2, self.bn2, MF.ACT_RELU, 1, 1, 1, 0, 1)
+        return MF.conv_bn_act(y, w2, self.bn2, MF.ACT_RELU, 1, 1, 1, 0, 1, link_out=True)     # sole consumer: the decoder's first (transposed) conv

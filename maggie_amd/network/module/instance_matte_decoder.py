@@ -61,7 +61,7 @@ class InstanceMatteDecoder(nn.Module):
 
     def _smooth(self, x):
         c0, bn0, _, c1, bn1, _ = self.conv
-        x = MF.conv_bn_act(x, MF.plain_krsc(c0, x.dtype, keep=True), bn0, MF.ACT_LRELU, 3, 3, 1, 1, 1)    # keep: applied twice per video forward
+        x = MF.conv_bn_act(x, MF.plain_krsc(c0, x.dtype, keep=True), bn0, MF.ACT_LRELU, 3, 3, 1, 1, 1, link_out=True)    # keep: applied twice per video forward
         return MF.conv_bn_act(x, MF.plain_krsc(c1, x.dtype, keep=True), bn1, MF.ACT_LRELU, 1, 1, 1, 0, 1)
 
     def plain_convs(self):

@@ -21,14 +21,16 @@ import math
 
 import torch
 from torch import nn
-from torch.nn import functional as F
 
 from ... import functional as MF
 
 
-def _hip_attention(n_tokens, d):
-    """The HIP attention kernels are built for the configuration of maggie_{image,video}.yaml (10 instance tokens, width 128)."""
-    return n_tokens == 10 and d == 128
+def _need_hip_attention(n_tokens, d):
+    """The HIP attention kernels are built for the configuration of maggie_{image,video}.yaml (10 instance tokens, width 128). Anything
+    else is rejected: there is no torch fallback anywhere in this build (maggie_amd/hip.py)."""
+    if n_tokens != 10 or d != 128:
+        raise MF.K.hip.MaggieHipError('MaGGIe (MI355X build): the cross-attention kernels are built for max_inst = 10 tokens of width 128 '
+                                      '(configs/maggie_{image,video}.yaml); got %d tokens of width %d' % (n_tokens, d))
 
 
 def _split_in_proj(mha):
@@ -79,12 +81,8 @@ class CrossAttentionLayer(nn.Module):
         # score bias of a feature row with position id: q . (E[id] Wk^T + bk)  (id_table None: every row has id 0 and no embedding)
         key_pos = MF.token_linear(id_table, wk, bk) if id_table is not None else bk[None, :]
         tbl = MF.token_linear(q, key_pos)                                                    # (b,T,n_id)
-        if _hip_attention(tokens.shape[1], d):
-            p, ctx = MF.attn_tokens_from_features(qk, tbl, feat, feat_ids, 1.0 / math.sqrt(d))
-        else:                                                                                # other widths: plain torch
-            s = torch.matmul(qk, feat.transpose(1, 2)) + torch.gather(tbl, 2, feat_ids.long()[:, None, :].expand(-1, q.shape[1], -1))
-            p = torch.softmax(s / math.sqrt(d), -1)
-            ctx = torch.matmul(p, feat)                                                      # (b,T,d)
+        _need_hip_attention(tokens.shape[1], d)
+        p, ctx = MF.attn_tokens_from_features(qk, tbl, feat, feat_ids, 1.0 / math.sqrt(d))
         h = MF.token_linear(ctx, wv, bv)
         return MF.token_linear(h, self.multihead_attn.out_proj.weight, self.multihead_attn.out_proj.bias, res=tokens, ln=self.norm), p
 
@@ -98,15 +96,9 @@ class CrossAttentionLayer(nn.Module):
         kq = MF.token_linear(k, wq.t().contiguous())                                         # (b,T,d): fold Wq into the keys
         qry_pos = MF.token_linear(id_table, wq, bq) if id_table is not None else bq[None, :]  # (n_id, d)
         tbl = MF.token_linear(k, qry_pos).transpose(1, 2).contiguous()                       # (b,n_id,T)
-        if _hip_attention(tokens.shape[1], d):
-            out = MF.attn_features_from_tokens(feat, kq, tbl, vp, self.multihead_attn.out_proj.bias, token_padding_mask, feat_ids,
-                                               1.0 / math.sqrt(d))
-        else:
-            s = torch.matmul(feat, kq.transpose(1, 2)) + torch.gather(tbl, 1, feat_ids.long()[:, :, None].expand(-1, -1, k.shape[1]))
-            s = s / math.sqrt(d)
-            if token_padding_mask is not None:
-                s = s.masked_fill(token_padding_mask[:, None, :], float('-inf'))
-            out = torch.matmul(torch.softmax(s, -1), vp) + self.multihead_attn.out_proj.bias
+        _need_hip_attention(tokens.shape[1], d)
+        out = MF.attn_features_from_tokens(feat, kq, tbl, vp, self.multihead_attn.out_proj.bias, token_padding_mask, feat_ids,
+                                           1.0 / math.sqrt(d))
         return MF.rows_add_layernorm(feat, out, self.norm)
 
 
@@ -142,11 +134,10 @@ class MLP(nn.Module):
 
     def forward(self, x, ln=None):
         """`ln`: a LayerNorm fused behind the last layer (InstanceMatteDecoder: decoder_norm(final_mlp(tokens)))."""
-        if x.dim() == 3 and x.shape[0] * x.shape[1] <= 128 and x.dtype == torch.float32:      # token rows: fused HIP linears
-            for i, layer in enumerate(self.layers):
-                last = i == self.num_layers - 1
-                x = MF.token_linear(x, layer.weight, layer.bias, relu=not last, ln=ln if last else None)
-            return x
+        if not x.is_cuda:
+            raise MF.K.hip.MaggieHipError('MaGGIe (MI355X build) runs on the GPU only (MLP got a %s tensor)' % x.device.type)
+        # token rows of any count (mg_token_linear_* tile over rows): per-process batches beyond 12 stay on the HIP kernels too
         for i, layer in enumerate(self.layers):
-            x = F.relu(layer(x)) if i < self.num_layers - 1 else layer(x)
-        return x if ln is None else ln(x)
+            last = i == self.num_layers - 1
+            x = MF.token_linear(x, layer.weight, layer.bias, relu=not last, ln=ln if last else None)
+        return x

@@ -258,6 +258,9 @@ class SparseHead(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, d_os4, d_os1):
         s = ctx.s
+        if s is None:
+            raise K.hip.MaggieHipError('SparseHead: a second backward through the same forward (retain_graph=True) is not supported -- the head '
+                                       'releases its saved row buffers after the first one')
         env, dt = s.env, s.dt
         pyr, n_i = env.pyr, env.n_i
         l1, l2, l4, l8 = pyr.levels

@@ -635,6 +635,31 @@ def loss_temporal_sparsity(diff_forward, diff_backward, spar_gt):
     return loss
 
 
+def video_eval_region(x_os8, n_i, h, w):
+    """Region ops of the video decoder at inference, resnet_inst_matt_spconv_temp.py:115-142: snap the coarse alpha (>= 0.95 -> 1), the
+    unknown band of the snapped alpha, then per plane the padded bounding box of (gaussian-smoothed alpha > 0.1) applied to both.
+    -> (cropped coarse alpha, detail mask). A function of x_os8 alone, so a test can feed it the product's own coarse alpha."""
+    x_os8 = torch.where(x_os8 >= 0.95, torch.ones_like(x_os8), x_os8)
+    unknown_os8 = compute_unknown(x_os8, 30)
+    smooth = gaussian_smoothing(x_os8, 3)
+    x_os8 = x_os8.clone()
+    for i in range(smooth.shape[0]):
+        for j in range(n_i):
+            coarse = smooth[i, j] > 0.1
+            ys, xs = torch.nonzero(coarse, as_tuple=True)
+            if len(ys) == 0:
+                continue
+            y0 = max(0, int(ys.min()) - 30)
+            y1 = min(int(ys.max()) + 30, h)
+            x0 = max(0, int(xs.min()) - 30)
+            x1 = min(int(xs.max()) + 30, w)
+            tm = torch.zeros_like(coarse)
+            tm[y0:y1, x0:x1] = 1
+            unknown_os8[i, j] = unknown_os8[i, j] * tm
+            x_os8[i, j] = x_os8[i, j] * tm
+    return x_os8, unknown_os8
+
+
 def decoder_video(sd, p, x, mid_fea, b, n_f, n_i, masks, it, gt_alphas, training, dcfg, mem_feat=None, spar_gt=None):
     """ResShortCut_InstMattSpconv_BiTempSpar_Dec.forward -- resnet_inst_matt_spconv_temp.py:81-181."""
     temp_method_full = dcfg.get('temp_method', 'bi')
@@ -661,28 +686,10 @@ def decoder_video(sd, p, x, mid_fea, b, n_f, n_i, masks, it, gt_alphas, training
         guided = gt_alphas.clone()
         use_gt = True
     if not training:
-        x_os8 = torch.where(x_os8 >= 0.95, torch.ones_like(x_os8), x_os8)
+        x_os8, unknown_os8 = video_eval_region(x_os8, n_i, *image.shape[-2:])
         guided = x_os8
-    unknown_os8 = compute_unknown(guided, 30)
-    if not training:
-        h, w = image.shape[-2:]
-        smooth = gaussian_smoothing(x_os8, 3)
-        x_os8 = x_os8.clone()
-        for i in range(smooth.shape[0]):
-            for j in range(n_i):
-                coarse = smooth[i, j] > 0.1
-                ys, xs = torch.nonzero(coarse, as_tuple=True)
-                if len(ys) == 0:
-                    continue
-                y0 = max(0, int(ys.min()) - 30)
-                y1 = min(int(ys.max()) + 30, h)
-                x0 = max(0, int(xs.min()) - 30)
-                x1 = min(int(xs.max()) + 30, w)
-                tm = torch.zeros_like(coarse)
-                tm[y0:y1, x0:x1] = 1
-                unknown_os8[i, j] = unknown_os8[i, j] * tm
-                x_os8[i, j] = x_os8[i, j] * tm
-        guided = x_os8
+    else:
+        unknown_os8 = compute_unknown(guided, 30)
     x_os4, x_os1 = process_os4_os1(sd, p, x, b, n_f, fea1, fea2, fea3, image, x_os8, queries, guided, unknown_os8, training)
     ret = {'alpha_os1': x_os1, 'alpha_os4': x_os4, 'alpha_os8': x_os8}
     alpha, w4, w1 = dec_fuse(ret, unknown_os8, training)

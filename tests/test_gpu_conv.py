@@ -278,3 +278,90 @@ def test_conv_fprop_split_k(case, dtype):
                           stride=stride, pad=pad, dil=dil)
         dx = dx.float().cpu().reshape(N, H, W, Cin).permute(0, 3, 1, 2)
         assert (dx - x.grad).abs().max().item() <= _tol(dtype) * x.grad.abs().max().item()
+
+
+LINK_CASES = [
+    # N, C0, C1, C2, H, W, (k2, stride2, pad2, transposed2), act of the BatchNorm layer, residual into the BatchNorm, carry through conv 2
+    (2, 32, 64, 64, 40, 48, (3, 1, 1, False), 1, False, False),      # 3x3 s1 consumer: halo-tile data gradient (bf16), im2col (fp32)
+    (2, 32, 64, 32, 40, 48, (3, 1, 1, False), 2, True, True),        # LeakyReLU + residual + skip gradient added in the same epilogue (carry)
+    (2, 16, 32, 64, 48, 40, (3, 2, 1, False), 1, False, False),      # stride-2 consumer: phase-decomposed data gradient, ragged phase tiles
+    (4, 64, 128, 64, 24, 24, (1, 1, 0, False), 0, False, False),     # BatchNorm without activation, 1x1 consumer
+    (2, 64, 64, 32, 20, 28, (4, 2, 1, True), 2, False, True),        # transposed consumer (decoder): its data gradient is a stride-2 conv
+    (1, 256, 256, 256, 34, 34, (3, 1, 1, False), 1, False, False),   # deep layer with few rows
+    (1, 512, 512, 256, 40, 40, (1, 1, 0, False), 1, False, False),   # K = 512 1x1: im2col ring
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('case', LINK_CASES)
+def test_bn_backward_sums_in_the_consumer_dgrad_epilogue(case, dtype):
+    """Round 3 (functional.BnLink, mg_conv_params.bnb_*): conv -> BN(+res, act) -> conv. The second conv's data-gradient epilogue writes
+    g = dz * act'(z) and accumulates the BatchNorm layer's backward sums; only the apply pass is left. Against torch on the CPU, and against
+    the unlinked path (separate reduce pass) of this build."""
+    from maggie_amd import functional as MF
+    dev = _dev()
+    N, C0, C1, C2, H, W, (k2, s2, p2, tr2), act, with_res, carry = case
+    rs = np.random.RandomState(sum(case[:6]))
+    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    x = q(torch.from_numpy(rs.normal(size=(N, C0, H, W)).astype(np.float32))).requires_grad_(True)
+    w1 = q(torch.from_numpy((rs.normal(size=(C1, C0, 3, 3)) / np.sqrt(C0 * 9)).astype(np.float32))).requires_grad_(True)
+    w2s = (C1, C2, k2, k2) if tr2 else (C2, C1, k2, k2)
+    w2 = q(torch.from_numpy((rs.normal(size=w2s) / np.sqrt(C1 * k2 * k2)).astype(np.float32))).requires_grad_(True)
+    res = q(torch.from_numpy(rs.normal(size=(N, C1, H, W)).astype(np.float32))).requires_grad_(True) if with_res else None
+    gamma = torch.from_numpy(rs.uniform(0.5, 1.5, C1).astype(np.float32)).requires_grad_(True)
+    beta = torch.from_numpy(rs.normal(size=C1).astype(np.float32)).requires_grad_(True)
+    actf = [lambda t: t, F.relu, lambda t: F.leaky_relu(t, 0.2)][act]
+
+    y1 = F.conv2d(x, w1, None, 1, 1)
+    z = F.batch_norm(y1, None, None, gamma, beta, True, 0.1, 1e-5)
+    z = actf(z if res is None else z + res)
+    y2 = F.conv_transpose2d(z, w2, None, s2, p2) if tr2 else F.conv2d(z, w2, None, s2, p2)
+    gy = q(torch.from_numpy(rs.normal(size=tuple(y2.shape)).astype(np.float32)))
+    gz = q(torch.from_numpy(rs.normal(size=tuple(z.shape)).astype(np.float32)))          # the skip branch's gradient (carry)
+    (y2 * gy).sum().backward() if not carry else ((y2 * gy).sum() + (z * gz).sum()).backward()
+
+    def run(link):
+        MF.BN_LINK = link
+        try:
+            MF.ARENA.reset(dev)
+            bn = torch.nn.BatchNorm2d(C1).to(dev)
+            with torch.no_grad():
+                bn.weight.copy_(gamma.detach()); bn.bias.copy_(beta.detach())
+            xd = _nhwc(x.detach()).to(dev, dtype).requires_grad_(True)
+            w1d = _krsc(w1.detach()).to(dev, dtype).requires_grad_(True)
+            w2k = w2.detach().permute(1, 2, 3, 0) if tr2 else w2.detach().permute(0, 2, 3, 1)
+            w2d = w2k.reshape(C2, k2 * k2, C1).contiguous().to(dev, dtype).requires_grad_(True)
+            rd = None if res is None else _nhwc(res.detach()).to(dev, dtype).requires_grad_(True)
+            zd = MF.conv_bn_act(xd, w1d, bn, act, 3, 3, 1, 1, 1, res=rd, link_out=True)
+            linked = getattr(zd, '_mg_bnlink', None) is not None
+            if carry:
+                y2d, zc = MF.conv2d(zd, w2d, None, k2, k2, s2, p2, 1, tr2, carry=True)
+                loss = (y2d.float() * _nhwc(gy).to(dev)).sum() + (zc.float() * _nhwc(gz).to(dev)).sum()
+            else:
+                y2d = MF.conv2d(zd, w2d, None, k2, k2, s2, p2, 1, tr2)
+                loss = (y2d.float() * _nhwc(gy).to(dev)).sum()
+            loss.backward()
+            out = {'dx': xd.grad.float().cpu().permute(0, 3, 1, 2), 'dgamma': bn.weight.grad.cpu(), 'dbeta': bn.bias.grad.cpu(),
+                   'dw1': w1d.grad.float().cpu().reshape(C1, 3, 3, C0).permute(0, 3, 1, 2), 'y2': y2d.detach().float().cpu().permute(0, 3, 1, 2)}
+            if rd is not None:
+                out['dres'] = rd.grad.float().cpu().permute(0, 3, 1, 2)
+            return out, linked
+        finally:
+            MF.BN_LINK = True
+
+    got, linked = run(True)
+    base, base_linked = run(False)
+    assert linked and not base_linked, 'the link must be taken in the first run and not in the second'
+    ref = {'dx': x.grad, 'dgamma': gamma.grad, 'dbeta': beta.grad, 'dw1': w1.grad, 'y2': y2.detach()}
+    if res is not None:
+        ref['dres'] = res.grad
+    for k_, r_ in ref.items():
+        sc_ = r_.abs().max().item()
+        # against torch in the L2 sense: a pre-activation value within rounding distance of zero (fp32: summation order; bf16: the conv output
+        # entering the BatchNorm is rounded here and not on the CPU) lands on the other side of the ReLU / LeakyReLU kink and moves its
+        # gradient by O(1). The element-wise comparison is made against the unlinked path below, which shares the activations.
+        rel = ((got[k_] - r_).norm() / r_.norm().clamp_min(1e-12)).item()
+        assert rel <= (1e-3 if dtype == torch.float32 else 3e-2), (k_, rel)
+        # linked vs unlinked path of this build: same arithmetic up to the order of the fp32 reductions (and, in bf16, one rounding of g
+        # where the unlinked path rounds dz and re-derives g in fp32)
+        assert (got[k_] - base[k_]).abs().max().item() <= (2e-5 if dtype == torch.float32 else 2e-2) * sc_, ('vs unlinked', k_)

@@ -163,16 +163,18 @@ def test_bf16_full_size_step_matches_fp32_step():
     assert np.isfinite(g16) and abs(g16 - g32) <= 0.5 * g32
 
 
-def test_bf16_step_at_the_reference_autocast_noise_floor():
+@pytest.mark.parametrize('size', [128, 512])
+def test_bf16_step_at_the_reference_autocast_noise_floor(size):
     """How far may a bf16 step be from the fp32 one? Yardstick: the oracle (the reference's torch ops) run under CPU bf16 AUTOCAST -- what the
-    reference's own mixed-precision mode does to the dense path -- against the fp32 oracle, same weights and inputs (4 x 128x128, train-mode
+    reference's own mixed-precision mode does to the dense path -- against the fp32 oracle, same weights and inputs (4 x size^2, train-mode
     BatchNorm). The HIP bf16 path must deviate from the fp32 oracle by no more than 2x that (coarse alpha, mean-abs and the fraction of
-    pixels beyond 0.05)."""
+    pixels beyond 0.05). size = 512 is the headline geometry (BASELINE configs[1]): the bar of the full-size bf16 run is what the reference's
+    own arithmetic does at that size, measured here, not a constant."""
     from maggie_amd.utils import synth
     import oracle.refmodel as rm
     from helpers import reference_layout_state_dict, model_cfg, RSEED
     dev = _dev()
-    batch = synth.synthetic_batch(4, 1, 2, 128, 128, seed=DSEED, train=True, max_inst=10, it=10000)
+    batch = synth.synthetic_batch(4, 1, 2, size, size, seed=DSEED, train=True, max_inst=10, it=10000)
 
     class _Got(Exception):
         pass

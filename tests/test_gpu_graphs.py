@@ -6,6 +6,7 @@ Random-init training BN over a handful of samples is chaotic from one step to th
 apart after a single optimizer step), so every comparison here restarts from one saved state; what is left is the
 run-to-run noise of fp32 atomics, measured by comparing two eager runs and used as the yardstick."""
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -109,6 +110,39 @@ def test_graph_grads_do_not_alias_static_buffers():
     one()
     double = model.get_parameter(name).grad
     assert float((double - 2 * single).abs().max()) <= 0.05 * float(single.abs().max())
+
+
+@pytest.mark.parametrize('train', [False, True])
+def test_outputs_of_a_replayed_step_do_not_alias_graph_memory(train):
+    """everything the caller receives from a replayed step (alphas, detail mask, logged loss scalars) must be its own memory --
+    a second forward with the same geometry (VideoWindow keeps frames of the previous clip, metric code keeps outputs) must not rewrite it."""
+    from maggie_amd.utils import synth
+    dev = _dev()
+    model, _ = _build('image', dev, train)
+    model.hip_graphs = True
+    batches = [_to(synth.synthetic_batch(2, 1, 2, 64, 64, seed=DSEED + i, train=train, max_inst=10, it=100), dev) for i in range(4)]
+
+    def run(bt):
+        seed_all(5)
+        if train:
+            out, loss = model(bt)
+            return out, loss
+        with torch.no_grad():
+            return model(bt), {}
+
+    for bt in batches[:2]:                                            # first sight: eager; second: capture + replay
+        run(bt)
+    out_a, loss_a = run(batches[2])                                   # pure replay
+    n_graphs = sum(1 for v in model.__dict__.get('_detail_graphs', {}).values() if not isinstance(v, (int, str)))
+    assert n_graphs >= 1, 'the detail stage must be running from a captured graph for this test to mean anything'
+    keep = {k: v.clone() for k, v in out_a.items()}
+    keep_l = {k: v.detach().clone() for k, v in loss_a.items() if torch.is_tensor(v)}
+    out_b, _ = run(batches[3])                                        # another replay of the same graphs, different data
+    assert any(not torch.equal(out_b[k], keep[k]) for k in keep), 'the second batch must produce different outputs'
+    for k, v in keep.items():
+        assert torch.equal(out_a[k], v), 'output %r of the first call was rewritten by the second call' % k
+    for k, v in keep_l.items():
+        assert torch.equal(loss_a[k].detach(), v), 'loss entry %r of the first call was rewritten by the second call' % k
 
 
 def test_graphs_are_dropped_when_parameters_move():
@@ -307,3 +341,91 @@ def test_overlapped_exchange_in_place_on_the_optimizer_buffer_single_rank_rccl()
             assert len(devs) >= 280 and devs[len(devs) // 2] <= 2e-2 and devs[int(0.95 * len(devs))] <= 0.15, (i, devs[len(devs) // 2], devs[-1])
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rank_safe_graphs_one_detail_graph_serves_both_guidance_sources():
+    """`use_gt` (random.random() / `x_os8.sum() == 0`, per-rank data) must not choose between captured graphs in a
+    data-parallel job -- the graphs carry the gradient collectives. In rank-safe mode it is a device flag: ONE detail graph, and its results
+    equal the plain mode's (where the flag is part of the graph key) for both values of the flag."""
+    import random
+    from maggie_amd.utils import synth
+    dev = _dev()
+    model, _ = _build('image', dev, True)
+    model.decoder.inst_spec_layer.dropout.p = 0.0            # the dropout counter advances per forward: the two runs below would draw different masks
+    state = copy.deepcopy(model.state_dict())
+    # iter 5000: between warmup_detail_iter (3000) and 3x: `random.random() < 0.5` decides (resnet_inst_matt_spconv.py:312-316)
+    batch = _to(synth.synthetic_batch(2, 1, 2, 64, 64, seed=DSEED, train=True, max_inst=10, it=5000), dev)
+
+    def run(rank_safe, rnd_seed, steps):
+        model.__dict__['rank_safe_graphs'] = rank_safe
+        for store in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs', '_detail_names'):
+            model.__dict__.get(store, {}).clear()
+        outs = []
+        for s_ in range(steps):
+            model.load_state_dict(state)
+            model.hip_graphs = True
+            model.zero_grad(set_to_none=True)
+            seed_all(5)
+            random.seed(rnd_seed[s_])
+            out, loss = model(batch)
+            loss['total'].backward()
+            g = torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None])
+            outs.append((float(loss['total']), out['refined_masks'].float().cpu().clone(), out['detail_mask'].cpu().clone(), g.float().cpu()))
+        n = sum(1 for v in model.__dict__.get('_detail_graphs', {}).values() if not isinstance(v, (int, str)))
+        return outs, n
+
+    # python seeds whose first random.random() is < 0.5 / >= 0.5
+    lo = next(s_ for s_ in range(100) if random.Random(s_).random() < 0.5)
+    hi = next(s_ for s_ in range(100) if random.Random(s_).random() >= 0.5)
+    seeds = [lo, lo, lo, hi, hi, hi, lo]
+    safe, n_safe = run(True, seeds, len(seeds))
+    plain, n_plain = run(False, seeds, len(seeds))
+    assert n_safe == 1, 'rank-safe mode must serve both guidance sources from ONE captured detail graph (got %d)' % n_safe
+    assert n_plain == 2, 'plain mode keys the detail graph by use_gt (got %d graphs)' % n_plain
+    assert not torch.equal(safe[2][2], safe[5][2]), 'the two guidance sources must give different detail regions for this test to mean anything'
+    for i, (a, b_) in enumerate(zip(safe, plain)):
+        assert abs(a[0] - b_[0]) <= 2e-4 * max(1.0, abs(b_[0])), (i, a[0], b_[0])
+        assert torch.equal(a[2], b_[2]), 'detail mask, step %d' % i
+        assert (a[1] - b_[1]).abs().max().item() <= 1e-4, i
+        assert (a[3] - b_[3]).norm().item() <= 2e-2 * b_[3].norm().item(), i
+
+
+def _syncbn_worker(mode, port):
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    pr = subprocess.run([sys.executable, os.path.join(here, 'syncbn_worker.py'), mode, str(port)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                        timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'))
+    out, err = pr.stdout.decode(errors='replace'), pr.stderr.decode(errors='replace')
+    line = [l for l in out.splitlines() if l.startswith('RESULT ')]
+    if pr.returncode != 0 or not line:
+        if 'CapturedEvent' in err or 'operation not permitted when stream is capturing' in err:
+            pytest.skip('known ROCm 7.2 flake: the process-group watchdog queried an event during capture (DESIGN.md section 6)')
+        raise AssertionError('syncbn worker %s failed (rc %d):\n%s' % (mode, pr.returncode, err[-3000:]))
+    return json.loads(line[-1][7:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['sync_eager', 'sync_graphs'])
+def test_syncbn_single_rank_rccl_matches_local_batchnorm(mode):
+    """`sync_bn: true` (configs/maggie_{image,video}.yaml, engine/train.py:159-161) through a REAL RCCL process
+    group of one rank -- the eager path (host-launched collectives, the default for SyncBN) and MAGGIE_SYNCBN_GRAPHS=1 (collectives captured
+    into the hipGraphs) -- against local BatchNorm. A 1-rank all-reduce is the identity, so only the statistics kernels differ
+    (E[x^2] - E[x]^2 over pooled moments instead of the local exact two-pass variance)."""
+    _dev()
+    ref = _syncbn_worker('local', 29561)
+    got = _syncbn_worker(mode, 29562 if mode == 'sync_eager' else 29563)
+    assert got['sync_layers'] >= 60 and ref['sync_layers'] == 0
+    assert (got['graphs'] >= 2) == (mode == 'sync_graphs'), got['graphs']
+    for i, (a, b) in enumerate(zip(got['steps'], ref['steps'])):
+        assert a['n_grads'] == b['n_grads']
+        assert abs(a['loss'] - b['loss']) <= 2e-3 * max(1.0, abs(b['loss'])), (i, a['loss'], b['loss'])
+        assert abs(a['alpha_mean'] - b['alpha_mean']) <= 2e-3, (i, a['alpha_mean'], b['alpha_mean'])
+        assert abs(a['active'] - b['active']) <= 0.02 * max(b['active'], 1), (i, a['active'], b['active'])
+        assert abs(a['bn_mean'] - b['bn_mean']) <= 1e-3 * max(1.0, abs(b['bn_mean'])) and abs(a['bn_var'] - b['bn_var']) <= 1e-3 * abs(b['bn_var'])
+        d8 = max(abs(x - y) for x, y in zip(a['alpha_os8_sample'], b['alpha_os8_sample']))
+        assert d8 <= 5e-3, (i, d8)
+        rel = sorted(abs(a['grad_norms'][n] - b['grad_norms'][n]) / max(b['grad_norms'][n], 1e-12) for n in b['grad_norms'])
+        assert rel[len(rel) // 2] <= 5e-2, (i, rel[len(rel) // 2])

@@ -1065,3 +1065,46 @@ def test_temporal_crop_matches_oracle_restatement():
     assert torch.equal(ad.cpu(), ref_a)
     got_u = K.bits_unpack_u8(bits, W, (N * n_i, H, W)).cpu().bool().reshape(N, n_i, H, W)
     assert torch.equal(got_u, ref_u)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_rows_dropout_mask_statistics_and_backward_reuse(dtype):
+    """inst_spec_layer's dropout (mask_attention.py:170-182, p = 0.1; resnet_inst_matt_spconv.py:226-232) as the counter-based row kernel:
+    keep rate within 3 sigma of 1 - p, kept values scaled by exactly 1 / (1 - p), the backward call with the same (state, salt) re-creates
+    the forward's mask (checked against torch given the extracted mask), another salt / step gives another mask, p = 0 is the identity, and
+    only the first `rows` rows of a capacity-sized buffer are touched."""
+    from maggie_amd import kernels as K
+    from maggie_amd.sparse_head import DeviceRng
+    dev = _dev()
+    torch.manual_seed(11)
+    M, C, p = 40000, 32, 0.1
+    rng = DeviceRng(dev)
+    state = rng.snapshot()
+    x = (torch.rand(M, C, device=dev) + 0.5).to(dtype)                 # strictly positive: a zero in the output IS a dropped element
+    live = torch.tensor([M - 1000], dtype=torch.int32, device=dev)
+    y = K.rows_dropout(x, p, state, 1, rows=live)
+    yl, xl = y[:M - 1000].float(), x[:M - 1000].float()
+    keep = yl != 0
+    n = keep.numel()
+    rate = keep.float().mean().item()
+    sigma = (p * (1 - p) / n) ** 0.5
+    assert abs(rate - (1 - p)) <= 3 * sigma, (rate, sigma)
+    # per-channel and per-row keep rates are unbiased too (a hash that correlates with the row or channel index would fail here)
+    assert (keep.float().mean(0) - (1 - p)).abs().max().item() <= 5 * (p * (1 - p) / keep.shape[0]) ** 0.5
+    assert abs(keep.float().mean(1).std().item() - (p * (1 - p) / C) ** 0.5) <= 0.1 * (p * (1 - p) / C) ** 0.5
+    tol = 0 if dtype == torch.float32 else 2 ** -8
+    ref = xl * (1.0 / (1.0 - p))
+    assert ((yl - ref * keep).abs() <= tol * ref.abs() + (1e-6 if dtype == torch.float32 else 0)).all()
+    # backward: same (state, salt) on the upstream gradient = torch's dropout backward with the forward's mask
+    g = torch.randn(M, C, device=dev).to(dtype)
+    gx = K.rows_dropout(g, p, state, 1, rows=live)
+    gref = g[:M - 1000].float() * keep * (1.0 / (1.0 - p))
+    assert ((gx[:M - 1000].float() - gref).abs() <= tol * gref.abs() + 1e-6).all()
+    # a second dropout site of the same forward (salt 2) and the next step draw different masks
+    k2 = K.rows_dropout(x, p, state, 2, rows=live)[:M - 1000] != 0
+    k3 = K.rows_dropout(x, p, rng.snapshot(), 1, rows=live)[:M - 1000] != 0
+    for other in (k2, k3):
+        agree = (other == keep).float().mean().item()                 # independent masks agree on (1-p)^2 + p^2 = 0.82 of the elements
+        assert abs(agree - ((1 - p) ** 2 + p ** 2)) < 0.01, agree
+    assert torch.equal(K.rows_dropout(x, 0.0, state, 1, rows=live)[:M - 1000], x[:M - 1000])

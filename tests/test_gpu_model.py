@@ -326,3 +326,80 @@ def test_empty_guidance_mask_raises_like_the_reference():
         for _ in range(3):                               # eager, capture step, replay
             with pytest.raises(ValueError, match='Mask is empty'):
                 model(_to(batch, dev))
+
+
+@pytest.mark.parametrize('n_f,n_inst,h,w', [(3, 2, 128, 128), (5, 3, 96, 128)])
+def test_video_region_ops_bit_exact_given_the_same_coarse_alpha(n_f, n_inst, h, w):
+    """end to end the video model's index map may differ from the oracle's at the `x_os8 >= 0.95 -> 1` float
+    discontinuity (a 1e-6 difference in the coarse alpha flips a pixel). Here the region ops themselves are pinned: the product's OWN
+    coarse alpha is handed to the oracle's restatement of resnet_inst_matt_spconv_temp.py:115-142 (snap, unknown band, smoothed bounding-box
+    crop) and the product's `detail_mask` and cropped `alpha_os8` must then be identical bit for bit."""
+    from maggie_amd.utils import synth
+    from oracle import refmodel
+    dev = _dev()
+    model, _ = _build('video', dev, False)
+    model.hip_graphs = False
+    seen = {}
+    orig = model.decoder.detail_stage
+
+    def spy(dense, *a, **k):
+        seen['x_os8'] = dense[0].detach().float().cpu().clone()
+        return orig(dense, *a, **k)
+
+    model.decoder.detail_stage = spy
+    batch = synth.synthetic_batch(1, n_f, n_inst, h, w, seed=DSEED, train=False)
+    with torch.no_grad():
+        out = model(_to(batch, dev))
+    x8 = seen['x_os8'][:, :n_inst]
+    assert float(((x8 > 0.9) & (x8 < 1.0)).float().mean()) > 0 or float((x8 >= 0.95).float().mean()) > 0, 'the snap must have something to do'
+    ref_a8, ref_mask = refmodel.video_eval_region(x8, n_inst, h, w)
+    dm = out['detail_mask'].cpu().reshape(-1, n_inst, h, w)
+    assert dm.float().sum() > 0
+    assert torch.equal(dm.float(), ref_mask.float()), 'detail mask: %d pixels differ' % int((dm.float() != ref_mask.float()).sum())
+    a8 = out['alpha_os8'].float().cpu().reshape(-1, n_inst, h, w)
+    assert torch.equal(a8, ref_a8), 'cropped coarse alpha: max diff %g' % float((a8 - ref_a8).abs().max())
+
+
+def test_video_consecutive_windows_with_prev_pred_match_oracle():
+    """engine/test.py:219-224: the video model runs on overlapping 3-frame windows and hands frame t of each window's fused output to the
+    next call as `prev_pred` (arch/maggie_temp.py:43-46). Two consecutive windows of a 4-frame clip through the product (HIP post-fusion,
+    mg_temporal_fuse) and the oracle, each with its OWN previous output, then stitched by VideoWindow / the oracle's window bookkeeping."""
+    from maggie_amd.utils import synth
+    from maggie_amd.utils.video_window import VideoWindow
+    from oracle import refmodel
+    from oracle.video_window import Window
+    dev = _dev()
+    model, sd = _build('video', dev, False)
+    n_i, h, w = 2, 128, 128
+    clip = synth.synthetic_batch(1, 4, n_i, h, w, seed=DSEED + 1, train=True, motion=0.03)
+    frames = lambda i: {k: v[:, i:i + 3].contiguous() for k, v in clip.items() if k in ('image', 'mask')}        # noqa: E731
+    gts = [clip['alpha'][:, i:i + 3] for i in range(2)]
+    tri = [clip['transition'][:, i:i + 3] for i in range(2)]
+    names = [['f%d' % (i + j) for j in range(3)] for i in range(2)]
+    ref_sd = {k: v.clone() for k, v in sd.items()}                     # ONE state for both oracle calls: SpectralNorm's u / v advance per forward
+    ours, theirs = VideoWindow(), Window()
+    prev = ref_prev = None
+    stitched, ref_stitched = [], []
+    for i in range(2):
+        with torch.no_grad():
+            out = model(_to(frames(i), dev), mem_feat=None, prev_pred=prev)
+            ref = refmodel.maggie_forward(ref_sd, model_cfg('video'), frames(i), False, prev_pred=ref_prev)
+        alpha, ref_alpha = out['refined_masks'].float().cpu(), ref['refined_masks']
+        bad = float(((alpha - ref_alpha).abs() > ALPHA_TOL).float().mean())
+        print('window', i, 'max diff %.3g, frac > tol %.2e' % (float((alpha - ref_alpha).abs().max()), bad))
+        assert bad <= 5e-4, 'window %d' % i
+        if i == 1:
+            # the second window's frame 1 depends on prev_pred: it must differ from what the same window gives without it
+            with torch.no_grad():
+                ref_no_prev = refmodel.maggie_forward({k: v.clone() for k, v in ref_sd.items()}, model_cfg('video'), frames(i), False)
+            assert float((ref_no_prev['refined_masks'][:, 1] - ref_alpha[:, 1]).abs().max()) > 0 or \
+                float((ref_prev - ref_alpha[:, 0]).abs().max()) == 0, 'prev_pred had no effect in the oracle: the test would be vacuous'
+        prev, ref_prev = out['refined_masks'][:, 1].cpu(), ref_alpha[:, 1].clone()       # engine/test.py:222
+        o = ours.push(out['refined_masks'], gts[i].to(dev), tri[i].to(dev), names[i], i == 0, i == 1)
+        r = theirs.push(ref_alpha.numpy(), gts[i].numpy(), tri[i].numpy(), names[i], i == 0, i == 1)
+        assert list(o['save'][0]) == list(r['save'][0])
+        stitched.append(o['save'][1].float().cpu())
+        ref_stitched.append(torch.from_numpy(np.asarray(r['save'][1])))
+    got, want = torch.cat(stitched, 1), torch.cat(ref_stitched, 1)
+    assert got.shape == want.shape and got.shape[1] >= 4, got.shape                     # every frame of the clip reaches the saving callback
+    assert float(((got - want).abs() > ALPHA_TOL).float().mean()) <= 5e-4

@@ -489,3 +489,26 @@ def test_vectorised_width_draw_equals_reference_scalar_draws():
             b = np.random.randint(1, k, size=40).astype(np.int32)
             y = np.random.rand()
             assert list(b) == a and x == y
+
+
+def test_detail_graph_key_ignores_per_rank_guidance_choice_in_rank_safe_mode():
+    """The key that selects a captured detail graph (maggie_amd/network/arch/maggie.py:_detail_key) must be identical on every rank of a
+    data-parallel job whatever a rank's own data decided (`use_gt`: random.random(), x_os8.sum() == 0) -- in rank-safe mode the choice
+    travels as a device flag among the graph inputs, so two ranks that disagree on it still look up the same graph."""
+    import torch
+    from maggie_amd.network import build_model
+    from maggie_amd.utils import config
+    model, _ = build_model(config.model_config('image'))
+    model.train()
+    inputs = [torch.zeros(2, 10, 64, 64), torch.zeros(2, 8, 8, 64), torch.zeros(2, dtype=torch.int32)]
+    geom = (2, 1, 10, 64, 64)
+    rank0 = model._detail_key(geom, {'use_gt': None, 'with_atten': False}, inputs)        # rank 0 drew use_gt = True
+    rank1 = model._detail_key(geom, {'use_gt': None, 'with_atten': False}, inputs)        # rank 1 saw x_os8.sum() == 0 -> True as well / False
+    assert rank0 == rank1
+    plain_t = model._detail_key(geom, {'use_gt': True, 'with_atten': False}, inputs)
+    plain_f = model._detail_key(geom, {'use_gt': False, 'with_atten': False}, inputs)
+    assert plain_t != plain_f and rank0 not in (plain_t, plain_f)
+    # default policy: rank-safe exactly when a process group with more than one rank exists (none here)
+    assert model._rank_safe_graphs() is False
+    model.rank_safe_graphs = True
+    assert model._rank_safe_graphs() is True

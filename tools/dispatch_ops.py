@@ -32,6 +32,7 @@ SKIP = ('view', 'reshape', 'expand', 'permute', 'transpose', 'unsqueeze', 'squee
         'unbind', 'split', 'empty', 'size', 'stride', 'is_', '_unsafe_view', 'lift_fresh', 'unfold', 'narrow', 'flatten', 'record_stream', 'chunk',
         '_local_scalar_dense', 'sym_', 'resize_', 'set_', 'item')
 hits = collections.Counter()
+SHAPES = os.environ.get('SHAPES', '0') == '1'
 
 
 class Mode(TorchDispatchMode):
@@ -48,6 +49,10 @@ class Mode(TorchDispatchMode):
                     if ('maggie_amd' in fs.filename or 'dispatch_ops' in fs.filename) and fs.name != '__torch_dispatch__':
                         where = '%s:%d %s' % (fs.filename.split('repo/')[-1], fs.lineno, fs.name)
                         break
+                if SHAPES and where.startswith('autograd engine'):
+                    # ops run by built-in autograd nodes (gradient accumulation of a tensor with several consumers, casts of gradients):
+                    # which tensors? -> shapes and dtypes of the operands
+                    where += '  ' + ' '.join('%s%s' % (str(a.dtype).replace('torch.', ''), list(a.shape)) for a in args if torch.is_tensor(a))
                 hits[(name.replace('aten.', ''), where)] += 1
         return func(*args, **(kwargs or {}))
 
@@ -70,4 +75,4 @@ torch.cuda.synchronize()
 top = int(sys.argv[1]) if len(sys.argv) > 1 else 80
 print('ATen ops touching CUDA tensors in one eager step: %d' % sum(hits.values()))
 for (name, where), n in hits.most_common(top):
-    print('%4d  %-34s %s' % (n, name[:34], where))
+    print('%4d  %-34s %s' % (n, name[:34], where[:200]))
