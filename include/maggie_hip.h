@@ -219,6 +219,13 @@ int mg_upsample_tanh(const void* in, int dtype, long sn, long sc, long sy, long 
                      int apply_tanh, float* out, void* stream);
 int mg_upsample_tanh_bwd(const float* dout, const float* out, long sn, long sc, long sy, long sx, int N, int C, int h, int w,
                          int scale, int apply_tanh, float* din, void* stream);
+/* The same with a 0 / 1 scale per output plane (`pscale` [N*C] or NULL: `x_os8 * valid_masks`, resnet_inst_matt_spconv.py:331, without a second
+ * pass over the planes) and `any_nonzero` (or NULL; a pre-zeroed int32 set to 1 when any output element is non-zero: the `x_os8.sum() == 0` test
+ * of :314 without a reduction over the planes). The backward masks the gradient of the planes scaled by 0. */
+int mg_upsample_tanh_ex(const void* in, int dtype, long sn, long sc, long sy, long sx, int N, int C, int h, int w, int scale,
+                        int apply_tanh, float* out, const float* pscale, int32_t* any_nonzero, void* stream);
+int mg_upsample_tanh_bwd_ex(const float* dout, const float* out, long sn, long sc, long sy, long sx, int N, int C, int h, int w,
+                            int scale, int apply_tanh, float* din, const float* pscale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * SpectralNorm weight preparation (maggie/network/module/spectral_norm.py:22-35,73-80): one power iteration on every
@@ -262,6 +269,9 @@ int mg_plane_flags(const float* w, int P, int HW, int32_t* flags, void* stream);
 /* loss weight of the OS8 prediction (arch/maggie.py:271-281): out = [plane p of gt has a positive pixel] + (reweight && (gt or a8 in
  * [1/255, 254/255])); fp32 planes [P][HW]; flags_scratch: P int32 */
 int mg_os8_weight(const float* gt, const float* a8, int P, long HW, int reweight, int32_t* flags_scratch, float* out, void* stream);
+/* the same with a8 standing for a8 * pvalid[plane] (pvalid: int32 [P] 0 / 1 or NULL) */
+int mg_os8_weight_ex(const float* gt, const float* a8, int P, long HW, int reweight, int32_t* flags_scratch, float* out, const int32_t* pvalid,
+                     void* stream);
 /* sums = 32 replicas x 16 floats (512 zeroed floats; a workgroup adds to replica `its index mod 32`: same-address atomics were the kernels' bound),
  * each replica [l1, grad, w, lap0, w0, lap1, w1, lap2, w2, ...] (accumulated by mg_loss_point_fwd / mg_pyr_lap_fwd; mg_pyr_lap_fwd takes
  * `sums + 3 + 2 * level`); the replicas are summed here -> out3 = (rec, lap, grad)
@@ -269,9 +279,10 @@ int mg_os8_weight(const float* gt, const float* a8, int P, long HW, int reweight
  * mg_loss_coef: upstream gradient g3 of those three -> the five per-term coefficients the backward kernels take. */
 int mg_loss_finish(const float* sums, float* out3, void* stream);
 int mg_loss_coef(const float* g3, const float* sums, float* coef5, void* stream);
-/* d = p - t; sums[0] += w|d|, sums[1] += |sobel(p*w) - sobel(t*w)|, sums[2] += w */
+/* d = p - t; sums[0] += w|d|, sums[1] += |sobel(p*w) - sobel(t*w)|, sums[2] += w. `pvalid` (int32 [P] or NULL): planes with pvalid == 0 are
+ * evaluated with p = 0 (`pred * valid_masks`, arch/maggie.py:112-118, folded into the loss kernels; their gradient is zero) */
 int mg_loss_point_fwd(const float* p, const float* t, const float* w, const int32_t* flags, int P, int H, int W, float* d,
-                      float* sums, void* stream);
+                      float* sums, const int32_t* pvalid, void* stream);
 /* out[P,h/2,w/2] = (gauss5 (reflect) * x)[::2, ::2] */
 int mg_pyr_down(const float* x, const int32_t* flags, int P, int h, int w, float* out, void* stream);
 /* L = x - 4*gauss5*zero_stuff(down); sums[0] += |L|*wl, sums[1] += wl, G = wl*sign(L); wl = w0[y<<lvl, x<<lvl] */
@@ -282,7 +293,7 @@ int mg_pyr_upT(const float* q, const float* coef, const float* add, const int32_
 int mg_pyr_downT(const float* r, const float* q, const float* coef, const int32_t* flags, int P, int h, int w, float* dd, void* stream);
 /* dp = coef_rec*w*sign(p-t) + dd + coef_grad*w*SobelAdjoint(...)  (A, B: [P,H,W] scratch) */
 int mg_loss_point_bwd(const float* p, const float* t, const float* w, const int32_t* flags, int P, int H, int W, const float* coef_rec,
-                      const float* coef_grad, const float* dd, float* A, float* B, float* dp, void* stream);
+                      const float* coef_grad, const float* dd, float* A, float* B, float* dp, const int32_t* pvalid, void* stream);
 
 /* Batched SpectralNorm: all wrapped convolutions of a model in five launches. `descs` lives in device memory. */
 typedef struct mg_sn_desc {

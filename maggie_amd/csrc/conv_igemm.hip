@@ -155,6 +155,23 @@ __device__ __forceinline__ void tile_epilogue_impl(const mg_conv_params& p, f32x
     [[maybe_unused]] const float bsl = p.bnb_act == MG_ACT_NONE ? 1.f : (p.bnb_act == MG_ACT_RELU ? 0.f : p.slope);
 #pragma unroll
     for (int ep = 0; ep < EP; ++ep) {
+        long mrow[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int r = rr + k * RPP;
+            mrow[k] = (r < PR && col_ok) ? rowmap(ep * PR + r) : -1l;
+        }
+        [[maybe_unused]] uint4 qbx[NIT], qby[NIT];
+        if constexpr (BNB) {                                   // the BatchNorm layer's input and output rows of this tile: requested before the
+#pragma unroll                                                 // accumulators go through LDS, so the HBM round trip overlaps the tile dump
+            for (int k = 0; k < NIT; ++k) {
+                qbx[k] = make_uint4(0, 0, 0, 0); qby[k] = make_uint4(0, 0, 0, 0);
+                if (mrow[k] >= 0 && full_vec) {
+                    qbx[k] = *(const uint4*)(bxb + mrow[k] * p.bnb_ld + cbase);
+                    if (byb) qby[k] = *(const uint4*)(byb + mrow[k] * p.bnb_ld + cbase);
+                }
+            }
+        }
         if (ep > 0) __syncthreads();
         if ((wm * WM) / PR == ep) {
             const int rb0 = wm * WM - ep * PR;
@@ -168,24 +185,11 @@ __device__ __forceinline__ void tile_epilogue_impl(const mg_conv_params& p, f32x
         }
         __syncthreads();
         float v[NIT][CE];
-        long mrow[NIT];
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
             const int r = rr + k * RPP;
-            mrow[k] = (r < PR && col_ok) ? rowmap(ep * PR + r) : -1l;
 #pragma unroll
             for (int e = 0; e < CE; e += 4) *(float4*)&v[k][e] = *(const float4*)&sC[(r < PR ? r : 0) * LDC + cc * CE + e];
-        }
-        [[maybe_unused]] uint4 qbx[NIT], qby[NIT];
-        if constexpr (BNB) {                                   // the BatchNorm layer's input and output rows of this tile: all loads in flight at once
-#pragma unroll
-            for (int k = 0; k < NIT; ++k) {
-                qbx[k] = make_uint4(0, 0, 0, 0); qby[k] = make_uint4(0, 0, 0, 0);
-                if (mrow[k] >= 0 && full_vec) {
-                    qbx[k] = *(const uint4*)(bxb + mrow[k] * p.bnb_ld + cbase);
-                    if (byb) qby[k] = *(const uint4*)(byb + mrow[k] * p.bnb_ld + cbase);
-                }
-            }
         }
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {

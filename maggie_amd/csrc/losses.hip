@@ -51,15 +51,16 @@ __global__ __launch_bounds__(NT) void plane_flags_kernel(const float* __restrict
 // loss weight of the OS8 prediction (maggie/network/arch/maggie.py:271-281): w = [plane has ground truth] + [pixel is in the unknown band
 // (1/255 <= v <= 254/255) of the ground truth or of the prediction]; ~12 elementwise passes over the planes in the torch formulation
 __global__ __launch_bounds__(NT) void os8_weight_kernel(const float* __restrict__ gt, const float* __restrict__ a8, const int* __restrict__ flags,
-                                                        long HW, int reweight, float* __restrict__ out) {
+                                                        long HW, int reweight, float* __restrict__ out, const int* __restrict__ pvalid) {
     const int p = blockIdx.y;
     const float valid = flags[p] ? 1.f : 0.f;
+    const float pv = (pvalid && !pvalid[p]) ? 0.f : 1.f;          // a8 stands for `a8 * valid_masks` (arch/maggie.py:112-118)
     const long base = (long)p * HW;
     const float lo = 1.0f / 255.0f, hi = 254.0f / 255.0f;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < HW; i += (long)gridDim.x * NT) {
         float w = valid;
         if (reweight) {
-            const float g = gt[base + i], a = a8[base + i];
+            const float g = gt[base + i], a = a8[base + i] * pv;
             if ((g <= hi && g >= lo) || (a <= hi && a >= lo)) w += 1.f;
         }
         out[base + i] = w;
@@ -67,14 +68,14 @@ __global__ __launch_bounds__(NT) void os8_weight_kernel(const float* __restrict_
 }
 
 __device__ __forceinline__ float sobel_mag(const float* __restrict__ a, const float* __restrict__ w, int y, int x, int H, int W, float& gx,
-                                           float& gy) {
+                                           float& gy, float as = 1.f) {
     float v[3][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             int yy = clampi(y + i - 1, H), xx = clampi(x + j - 1, W);
-            v[i][j] = a[yy * W + xx] * w[yy * W + xx];
+            v[i][j] = a[yy * W + xx] * as * w[yy * W + xx];
         }
     gx = ((v[0][2] - v[0][0]) + 2.f * (v[1][2] - v[1][0]) + (v[2][2] - v[2][0])) * 0.125f;
     gy = ((v[2][0] - v[0][0]) + 2.f * (v[2][1] - v[0][1]) + (v[2][2] - v[0][2])) * 0.125f;
@@ -84,21 +85,24 @@ __device__ __forceinline__ float sobel_mag(const float* __restrict__ a, const fl
 // d = p - t ; sums[0] += w|d| ; sums[1] += |sobel(p w) - sobel(t w)| ; sums[2] += w
 __global__ __launch_bounds__(NT) void point_fwd_kernel(const float* __restrict__ p, const float* __restrict__ t, const float* __restrict__ w,
                                                        const int* __restrict__ flags, int H, int W, float* __restrict__ d,
-                                                       float* __restrict__ sums) {
+                                                       float* __restrict__ sums, const int* __restrict__ pvalid) {
     __shared__ float sh[NT / 64];
     const int pl = blockIdx.y;
     if (!flags[pl]) return;
+    // pvalid (0 / 1 per plane): `pred * valid_masks` of arch/maggie.py:112-118 -- the prediction of a plane without ground-truth transition
+    // region counts as zero -- applied on the fly instead of by three multiplies over the (N, 10, H, W) planes (and three in backward)
+    const float pv = (pvalid && !pvalid[pl]) ? 0.f : 1.f;
     const long off = (long)pl * H * W;
     const float *pp = p + off, *tp = t + off, *wp = w + off;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     for (int i = blockIdx.x * NT + threadIdx.x; i < H * W; i += gridDim.x * NT) {
         int y = i / W, x = i - y * W;
-        float dv = pp[i] - tp[i], wv = wp[i];
+        float dv = pp[i] * pv - tp[i], wv = wp[i];
         d[off + i] = dv;
         s0 += wv * fabsf(dv);
         s2 += wv;
         float gx, gy;
-        float mp = sobel_mag(pp, wp, y, x, H, W, gx, gy);
+        float mp = sobel_mag(pp, wp, y, x, H, W, gx, gy, pv);
         float mt = sobel_mag(tp, wp, y, x, H, W, gx, gy);
         s1 += fabsf(mp - mt);
     }
@@ -276,9 +280,11 @@ __global__ __launch_bounds__(NT) void pyr_downT_kernel(const float* __restrict__
 
 // Sobel backward pass 1: A = s * gx / mag, B = s * gy / mag with s = sign(mag_p - mag_t)   (coef applied in pass 2)
 __global__ __launch_bounds__(NT) void sobel_bwd1_kernel(const float* __restrict__ p, const float* __restrict__ t, const float* __restrict__ w,
-                                                        const int* __restrict__ flags, int H, int W, float* __restrict__ A, float* __restrict__ B) {
+                                                        const int* __restrict__ flags, int H, int W, float* __restrict__ A, float* __restrict__ B,
+                                                        const int* __restrict__ pvalid) {
     const int pl = blockIdx.y;
     if (!flags[pl]) return;
+    if (pvalid && !pvalid[pl]) return;                  // masked prediction: point_bwd writes a zero gradient without reading A / B
     const long off = (long)pl * H * W;
     const float *pp = p + off, *tp = t + off, *wp = w + off;
     for (int i = blockIdx.x * NT + threadIdx.x; i < H * W; i += gridDim.x * NT) {
@@ -296,10 +302,11 @@ __global__ __launch_bounds__(NT) void sobel_bwd1_kernel(const float* __restrict_
 __global__ __launch_bounds__(NT) void point_bwd_kernel(const float* __restrict__ p, const float* __restrict__ t, const float* __restrict__ w,
                                                        const int* __restrict__ flags, int H, int W, const float* __restrict__ coef_rec,
                                                        const float* __restrict__ coef_grad, const float* __restrict__ dd,
-                                                       const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ dp) {
+                                                       const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ dp,
+                                                       const int* __restrict__ pvalid) {
     const int pl = blockIdx.y;
     const long off = (long)pl * H * W;
-    if (!flags[pl]) {                                   // a plane without weight: its gradient is zero (written here: dp needs no pre-fill)
+    if (!flags[pl] || (pvalid && !pvalid[pl])) {        // a plane without weight, or a masked prediction (d(p * 0)/dp = 0): zero gradient, written here
         for (int idx = blockIdx.x * NT + threadIdx.x; idx < H * W; idx += gridDim.x * NT) dp[off + idx] = 0.f;
         return;
     }
@@ -404,20 +411,26 @@ extern "C" int mg_plane_flags(const float* w, int P, int HW, int32_t* flags, voi
     return 0;
 }
 
+extern "C" int mg_os8_weight_ex(const float* gt, const float* a8, int P, long HW, int reweight, int32_t* flags_scratch, float* out, const int32_t* pvalid,
+                                void* stream);
 extern "C" int mg_os8_weight(const float* gt, const float* a8, int P, long HW, int reweight, int32_t* flags_scratch, float* out, void* stream) {
+    return mg_os8_weight_ex(gt, a8, P, HW, reweight, flags_scratch, out, nullptr, stream);
+}
+extern "C" int mg_os8_weight_ex(const float* gt, const float* a8, int P, long HW, int reweight, int32_t* flags_scratch, float* out, const int32_t* pvalid,
+                                void* stream) {
     if (P <= 0 || HW <= 0) return 0;
     int rc = mg_plane_flags(gt, P, (int)HW, flags_scratch, stream);
     if (rc) return rc;
     dim3 g = grid2(HW, P);
-    hipLaunchKernelGGL(os8_weight_kernel, g, dim3(NT), 0, (hipStream_t)stream, gt, a8, (const int*)flags_scratch, HW, reweight, out);
+    hipLaunchKernelGGL(os8_weight_kernel, g, dim3(NT), 0, (hipStream_t)stream, gt, a8, (const int*)flags_scratch, HW, reweight, out, pvalid);
     MG_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int mg_loss_point_fwd(const float* p, const float* t, const float* w, const int32_t* flags, int P, int H, int W, float* d,
-                                 float* sums, void* stream) {
+                                 float* sums, const int32_t* pvalid, void* stream) {
     if (P <= 0) return 0;
-    hipLaunchKernelGGL(point_fwd_kernel, grid2((long)H * W, P, REDUCING_BLOCKS_PER_PLANE), dim3(NT), 0, (hipStream_t)stream, p, t, w, flags, H, W, d, sums);
+    hipLaunchKernelGGL(point_fwd_kernel, grid2((long)H * W, P, REDUCING_BLOCKS_PER_PLANE), dim3(NT), 0, (hipStream_t)stream, p, t, w, flags, H, W, d, sums, pvalid);
     MG_CHECK_LAUNCH();
     return 0;
 }
@@ -453,11 +466,11 @@ extern "C" int mg_pyr_downT(const float* r, const float* q, const float* coef, c
 }
 
 extern "C" int mg_loss_point_bwd(const float* p, const float* t, const float* w, const int32_t* flags, int P, int H, int W, const float* coef_rec,
-                                 const float* coef_grad, const float* dd, float* A, float* B, float* dp, void* stream) {
+                                 const float* coef_grad, const float* dd, float* A, float* B, float* dp, const int32_t* pvalid, void* stream) {
     if (P <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(sobel_bwd1_kernel, grid2((long)H * W, P), dim3(NT), 0, st, p, t, w, flags, H, W, A, B);
-    hipLaunchKernelGGL(point_bwd_kernel, grid2((long)H * W, P), dim3(NT), 0, st, p, t, w, flags, H, W, coef_rec, coef_grad, dd, A, B, dp);
+    hipLaunchKernelGGL(sobel_bwd1_kernel, grid2((long)H * W, P), dim3(NT), 0, st, p, t, w, flags, H, W, A, B, pvalid);
+    hipLaunchKernelGGL(point_bwd_kernel, grid2((long)H * W, P), dim3(NT), 0, st, p, t, w, flags, H, W, coef_rec, coef_grad, dd, A, B, dp, pvalid);
     MG_CHECK_LAUNCH();
     return 0;
 }

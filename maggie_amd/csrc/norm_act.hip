@@ -275,6 +275,62 @@ __global__ __launch_bounds__(NT) void affine_act_kernel(const mg_rowwise_params 
 // away is a 6 us launch at the latency floor per BatchNorm layer (59 per step) and its dependent boundary.
 // Requires a fixed thread -> channel-chunk mapping (NT % (C / CE) == 0: every power-of-two channel count).
 // ---------------------------------------------------------------------------------------------------
+// Sum of `nrep` replicas of a [2C] fp32 statistics row for THIS thread's CE channels: s1[e] = sum_r st[r][c0 + e], s2[e] = sum_r st[r][C + c0 + e].
+// nrep == 1 (exact two-pass layers, the sparse head): two 16-byte loads per 4 channels straight into registers, no barrier. nrep > 1 (the
+// 32 replicas a conv epilogue spreads its atomics over): the WORKGROUP reads the nrep x 2C words once, every thread a few INDEPENDENT loads
+// (thread -> (replica group, column); a serial `a += st[r]` loop was 32 dependent L2 round trips, and every thread reading all replicas of
+// its own channels moved 2 GB through L2 per launch), partial sums meet in LDS. `lds`: 256 floats + 2C floats.
+template <int CE>
+__device__ __forceinline__ void replica_sums(const float* __restrict__ st, int nrep, int C, int c0, float* s1, float* s2, float* lds) {
+    if (nrep == 1) {
+#pragma unroll
+        for (int q = 0; q < CE / 4; ++q) {
+            const float4 a = *(const float4*)(st + c0 + q * 4);
+            const float4 b = *(const float4*)(st + C + c0 + q * 4);
+            s1[q * 4 + 0] = a.x; s1[q * 4 + 1] = a.y; s1[q * 4 + 2] = a.z; s1[q * 4 + 3] = a.w;
+            s2[q * 4 + 0] = b.x; s2[q * 4 + 1] = b.y; s2[q * 4 + 2] = b.z; s2[q * 4 + 3] = b.w;
+        }
+        return;
+    }
+    // columns 2C <= 256 (every layer that accumulates replicas has C <= 128): thread t -> column t % W2, replica group t / W2
+    const int W2 = 2 * C;
+    float* part = lds;                // [NT]
+    float* tot = lds + NT;            // [2C]
+    if (W2 <= NT) {
+        const int groups = NT / W2;                           // replica groups in flight (power of two: C is)
+        const int col = threadIdx.x % W2, grp = threadIdx.x / W2;
+        float a = 0.f;
+        if (grp < groups) {
+            float v[8];
+            int r = grp;
+            for (; r + 7 * groups < nrep; r += 8 * groups) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = st[(size_t)(r + u * groups) * W2 + col];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += v[u];
+            }
+            for (; r < nrep; r += groups) a += st[(size_t)r * W2 + col];
+        }
+        part[threadIdx.x] = a;
+        __syncthreads();
+        if (threadIdx.x < W2) {
+            float t = 0.f;
+            for (int g = 0; g < groups; ++g) t += part[g * W2 + threadIdx.x];
+            tot[threadIdx.x] = t;
+        }
+        __syncthreads();
+    } else {
+        for (int j = threadIdx.x; j < W2; j += NT) {
+            float t = 0.f;
+            for (int r = 0; r < nrep; ++r) t += st[(size_t)r * W2 + j];
+            tot[j] = t;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { s1[e] = tot[c0 + e]; s2[e] = tot[C + c0 + e]; }
+}
+
 struct BnFin {
     const float* stats; int nrep; int centered;
     const float* gamma; const float* beta; float* running_mean; float* running_var;
@@ -285,7 +341,7 @@ template <typename T>
 __global__ __launch_bounds__(NT) void bn_apply_fused_kernel(const mg_rowwise_params p, const BnFin f) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
-    extern __shared__ float ssum[];                            // [2C] statistics summed over the replicas
+    extern __shared__ float slds[];                           // [NT + 2C] (replica_sums)
     const int C = p.C, cpr = C / CE;
     const int Mrows = dev_rows(p.m_dev, p.M);
     const long i0 = (long)blockIdx.x * NT + threadIdx.x;
@@ -310,22 +366,20 @@ __global__ __launch_bounds__(NT) void bn_apply_fused_kernel(const mg_rowwise_par
         if (r2) qb = *(const uint4*)(r2 + (long)m * p.ldr2 + c0);
     }
     const float n = p.count_ptr ? *p.count_ptr : (p.m_dev ? (float)Mrows : p.count);
-    for (int j = threadIdx.x; j < 2 * C; j += NT) {
-        float a = 0.f;
-        for (int r = 0; r < f.nrep; ++r) a += f.stats[(size_t)r * 2 * C + j];
-        ssum[j] = a;
-    }
-    __syncthreads();
+    float gam[CE], bet[CE], t1[CE], t2[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { gam[e] = f.gamma ? f.gamma[c0 + e] : 1.f; bet[e] = f.beta ? f.beta[c0 + e] : 0.f; }
+    replica_sums<CE>(f.stats, f.nrep, C, c0, t1, t2, slds);
     const bool ident = (p.m_dev || p.count_ptr) && n <= 0.f;  // no live row anywhere: identity statistics, running stats untouched
     const bool writer = blockIdx.x == 0 && threadIdx.x < cpr;
     float sc[CE], sh[CE];
 #pragma unroll
     for (int e = 0; e < CE; ++e) {
         const int c = c0 + e;
-        const float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
+        const float g = gam[e], b = bet[e];
         float mean = 0.f, invstd = 1.f, var = 0.f;
         if (!ident) {
-            const float s1 = ssum[c], s2 = ssum[C + c];
+            const float s1 = t1[e], s2 = t2[e];
             mean = s1 / n;
             var = f.centered ? s2 / n : s2 / n - mean * mean;
             var = var > 0.f ? var : 0.f;
@@ -475,7 +529,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_fixed_kernel(const mg_rowwise
                                                                 float* __restrict__ sums_out) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
-    extern __shared__ float ssum[];                            // [2C]
+    extern __shared__ float slds[];                           // [NT + 2C] (replica_sums)
     const int C = p.C, cpr = C / CE;
     const int Mrows = dev_rows(p.m_dev, p.M);
     const long i0 = (long)blockIdx.x * NT + threadIdx.x;
@@ -490,20 +544,17 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_fixed_kernel(const mg_rowwise
         else load_g<T>(p, m, c0, g);
         qx = *(const uint4*)((const T*)p.x + (long)m * p.ldx + c0);
     }
-    for (int j = threadIdx.x; j < 2 * C; j += NT) {
-        float a = 0.f;
-        for (int r = 0; r < nrep; ++r) a += sums_rep[(size_t)r * 2 * C + j];
-        ssum[j] = a;
-        if (sums_out && blockIdx.x == 0) sums_out[j] = a;
-    }
-    __syncthreads();
-    const float inv_n = p.count_ptr ? (*p.count_ptr > 0.f ? 1.f / *p.count_ptr : 0.f) : (p.m_dev ? (Mrows > 0 ? 1.f / (float)Mrows : 0.f) : 1.f / p.count);
     float mu[CE], is[CE], sc[CE], sg[CE], sgx[CE];
 #pragma unroll
-    for (int e = 0; e < CE; ++e) {
-        mu[e] = p.mean[c0 + e]; is[e] = p.invstd[c0 + e]; sc[e] = p.scale[c0 + e];
-        sg[e] = ssum[c0 + e] * inv_n; sgx[e] = ssum[C + c0 + e] * inv_n;
+    for (int e = 0; e < CE; ++e) { mu[e] = p.mean[c0 + e]; is[e] = p.invstd[c0 + e]; sc[e] = p.scale[c0 + e]; }
+    replica_sums<CE>(sums_rep, nrep, C, c0, sg, sgx, slds);
+    if (sums_out && blockIdx.x == 0 && threadIdx.x < cpr) {
+#pragma unroll
+        for (int e = 0; e < CE; ++e) { sums_out[c0 + e] = sg[e]; sums_out[C + c0 + e] = sgx[e]; }
     }
+    const float inv_n = p.count_ptr ? (*p.count_ptr > 0.f ? 1.f / *p.count_ptr : 0.f) : (p.m_dev ? (Mrows > 0 ? 1.f / (float)Mrows : 0.f) : 1.f / p.count);
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { sg[e] *= inv_n; sgx[e] *= inv_n; }
     while (m < Mrows) {
         const int mn = m + m_step;
         float gn[CE];
@@ -699,8 +750,16 @@ extern "C" int mg_bn_bwd_reduce(const mg_rowwise_params* p, void* stream) {
     return 0;
 }
 
+static bool bn_fixed_shape_ok(const mg_rowwise_params& p) {
+    const int ce = p.dtype == MG_BF16 ? 8 : 4;
+    const int cpr = p.C / ce;
+    return p.M > 0 && cpr > 0 && cpr <= NT && (NT % cpr) == 0 && p.ldx % ce == 0 && p.lddy % ce == 0 && (!p.dx || p.lddx % ce == 0) &&
+           (!p.dres || p.lddres % ce == 0);
+}
 static bool bn_fixed_ok(const mg_rowwise_params& p) {
-    static const int on = [] { const char* e = getenv("MG_BN_FIXED_APPLY"); return e ? atoi(e) : 1; }();
+    // the general apply pass stays on the simple grid-stride kernel (8.0 us average against 8.9 us for this one at nrep = 1: more registers,
+    // fewer waves in flight); this kernel serves the linked path (replicated sums). MG_BN_FIXED_APPLY=1 uses it everywhere.
+    static const int on = [] { const char* e = getenv("MG_BN_FIXED_APPLY"); return e ? atoi(e) : 0; }();
     const int ce = p.dtype == MG_BF16 ? 8 : 4;
     const int cpr = p.C / ce;
     return on && p.M > 0 && cpr > 0 && cpr <= NT && (NT % cpr) == 0 && p.ldx % ce == 0 && p.lddy % ce == 0 && (!p.dx || p.lddx % ce == 0) &&
@@ -709,9 +768,8 @@ static bool bn_fixed_ok(const mg_rowwise_params& p) {
 static int bn_bwd_apply_fixed_launch(const mg_rowwise_params& p, const float* sums_rep, int nrep, int premasked, float* sums_out, hipStream_t st) {
     const int ce = p.dtype == MG_BF16 ? 8 : 4;
     const long total = (long)p.M * (p.C / ce);
-    const size_t lds = (size_t)2 * p.C * sizeof(float);
-    if (p.dtype == MG_BF16) hipLaunchKernelGGL(bn_bwd_apply_fixed_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), lds, st, p, sums_rep, nrep, premasked, sums_out);
-    else hipLaunchKernelGGL(bn_bwd_apply_fixed_kernel<float>, dim3(grid_for(total)), dim3(NT), lds, st, p, sums_rep, nrep, premasked, sums_out);
+    if (p.dtype == MG_BF16) hipLaunchKernelGGL(bn_bwd_apply_fixed_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), (size_t)(NT + 2 * p.C) * sizeof(float), st, p, sums_rep, nrep, premasked, sums_out);
+    else hipLaunchKernelGGL(bn_bwd_apply_fixed_kernel<float>, dim3(grid_for(total)), dim3(NT), (size_t)(NT + 2 * p.C) * sizeof(float), st, p, sums_rep, nrep, premasked, sums_out);
     MG_CHECK_LAUNCH();
     return 0;
 }
@@ -721,7 +779,7 @@ static int bn_bwd_apply_fixed_launch(const mg_rowwise_params& p, const float* su
 extern "C" int mg_bn_bwd_apply_linked(const mg_rowwise_params* p, const float* sums_rep, int nrep, float* sums_out, void* stream) {
     int rc = rowwise_check(p); if (rc) return rc;
     if (!sums_rep || nrep < 1 || !sums_out) return -2;
-    if (!bn_fixed_ok(*p)) return -3;
+    if (!bn_fixed_shape_ok(*p)) return -3;
     return bn_bwd_apply_fixed_launch(*p, sums_rep, nrep, 1, sums_out, (hipStream_t)stream);
 }
 
@@ -927,7 +985,10 @@ static int bn_small_bwd_launch(const mg_rowwise_params& p, hipStream_t st) {
 }
 
 static bool bn_fused_ok(const mg_rowwise_params& p) {
-    static const int on = [] { const char* e = getenv("MG_BN_FUSED_APPLY"); return e ? atoi(e) : 1; }();
+    // off by default: 0.89 ms per step against 0.98 ms for finalize + apply in the kernel trace, but nothing on the step's wall clock (13.48 vs
+    // 13.43-13.50 ms over 60-step runs): its register footprint (per-channel constants + the prefetched row) costs the streaming part what the
+    // removed launch saved. MG_BN_FUSED_APPLY=1 switches it on.
+    static const int on = [] { const char* e = getenv("MG_BN_FUSED_APPLY"); return e ? atoi(e) : 0; }();
     const int ce = p.dtype == MG_BF16 ? 8 : 4;
     const int cpr = p.C / ce;
     return on && p.M > 0 && cpr > 0 && cpr <= NT && (NT % cpr) == 0 && p.ldx % ce == 0;
@@ -937,9 +998,8 @@ static int bn_apply_fused_launch(const mg_rowwise_params& p, const float* stats,
     const int ce = p.dtype == MG_BF16 ? 8 : 4;
     const long total = (long)p.M * (p.C / ce);
     BnFin f{stats, nrep, centered, gamma, beta, running_mean, running_var, momentum, eps, outs};
-    const size_t lds = (size_t)2 * p.C * sizeof(float);
-    if (p.dtype == MG_BF16) hipLaunchKernelGGL(bn_apply_fused_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), lds, st, p, f);
-    else hipLaunchKernelGGL(bn_apply_fused_kernel<float>, dim3(grid_for(total)), dim3(NT), lds, st, p, f);
+    if (p.dtype == MG_BF16) hipLaunchKernelGGL(bn_apply_fused_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), (size_t)(NT + 2 * p.C) * sizeof(float), st, p, f);
+    else hipLaunchKernelGGL(bn_apply_fused_kernel<float>, dim3(grid_for(total)), dim3(NT), (size_t)(NT + 2 * p.C) * sizeof(float), st, p, f);
     MG_CHECK_LAUNCH();
     return 0;
 }

@@ -264,12 +264,21 @@ __device__ __forceinline__ void bil_src(int d, int scale, int in_size, int& i0, 
 // (tanh(v) + 1) / 2 == sigmoid(2 v) = 1 / (1 + exp(-2 v)) through the fast exponential -- the kernel was VALU-bound (46 us for 42 MB).
 template <typename T>
 __global__ __launch_bounds__(NT) void upsample_tanh_kernel(const T* __restrict__ in, long sn, long sc, long sy, long sx, int N, int C, int h,
-                                                           int w, int scale, int apply_tanh, float* __restrict__ out) {
+                                                           int w, int scale, int apply_tanh, float* __restrict__ out,
+                                                           const float* __restrict__ pscale, int* __restrict__ any_nonzero) {
     const int H = h * scale, W = w * scale;
     const int pl = blockIdx.y;
     const int n = pl / C, c = pl - n * C;
     const T* base = in + n * sn + c * sc;
     float* op = out + (long)pl * H * W;
+    // `pscale` (0 / 1 per plane): `x_os8 * valid_masks` of resnet_inst_matt_spconv.py:331 without a second pass over the planes; `any_nonzero`:
+    // the "coarse alpha is identically zero" test of :314 (`x_os8.sum() == 0`, values are >= 0) without a 42 MB reduction
+    const float ps = pscale ? pscale[pl] : 1.f;
+    int nz = 0;
+    if (pscale && ps == 0.f) {
+        for (int i = blockIdx.x * NT + threadIdx.x; i < H * W; i += gridDim.x * NT) op[i] = 0.f;
+        return;
+    }
     for (int i = blockIdx.x * NT + threadIdx.x; i < H * W; i += gridDim.x * NT) {
         const int Y = i / W, X = i - Y * W;
         float v;
@@ -283,14 +292,17 @@ __global__ __launch_bounds__(NT) void upsample_tanh_kernel(const T* __restrict__
             float v10 = ElemTraits<T>::ld(base + y1 * sy + x0 * sx), v11 = ElemTraits<T>::ld(base + y1 * sy + x1 * sx);
             v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
         }
-        op[i] = apply_tanh ? 1.f / (1.f + __expf(-2.f * v)) : v;
+        const float o = (apply_tanh ? 1.f / (1.f + __expf(-2.f * v)) : v) * ps;
+        op[i] = o;
+        nz |= (o != 0.f);
     }
+    if (any_nonzero && __syncthreads_or(nz) && threadIdx.x == 0) *any_nonzero = 1;      // every writer stores the same value
 }
 
 // backward: din(n,c,y,x) (fp32, same strides, pre-zeroed) += bilinear^T( dout * (1 - t^2)/2 ), t = 2*out - 1
 __global__ __launch_bounds__(NT) void upsample_tanh_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out, long sn, long sc,
                                                                long sy, long sx, int N, int C, int h, int w, int scale, int apply_tanh,
-                                                               float* __restrict__ din) {
+                                                               float* __restrict__ din, const float* __restrict__ pscale) {
     const int H = h * scale, W = w * scale;
     const long total = (long)N * C * H * W;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
@@ -298,6 +310,7 @@ __global__ __launch_bounds__(NT) void upsample_tanh_bwd_kernel(const float* __re
         if (apply_tanh) { float t = 2.f * out[i] - 1.f; g *= 0.5f * (1.f - t * t); }
         if (g == 0.f) continue;
         int X = (int)(i % W); long r = i / W; int Y = (int)(r % H); r /= H; int c = (int)(r % C); int n = (int)(r / C);
+        if (pscale && pscale[n * C + c] == 0.f) continue;                     // a 0 / 1 plane scale: masked planes pass no gradient
         float* base = din + n * sn + c * sc;
         if (scale == 1) { base[Y * sy + X * sx] += g; continue; }             // one writer per element
         int y0, y1, x0, x1; float ly, lx;
@@ -316,18 +329,19 @@ __global__ __launch_bounds__(NT) void upsample_tanh_bwd_kernel(const float* __re
 template <int SCALE>
 __global__ __launch_bounds__(NT) void upsample_tanh_bwd_tile_kernel(const float* __restrict__ dout, const float* __restrict__ out, long sn, long sc,
                                                                     long sy, long sx, int C, int h, int w, int apply_tanh,
-                                                                    float* __restrict__ din) {
+                                                                    float* __restrict__ din, const float* __restrict__ pscale) {
     constexpr int TS = 8, R = (TS + 2) * SCALE;                   // LDS tile edge in output pixels
     __shared__ float sg[R * R];
     const int H = h * SCALE, W = w * SCALE;
     const int plane = blockIdx.z, n = plane / C, c = plane - n * C;
+    const bool masked = pscale && pscale[plane] == 0.f;           // 0 / 1 plane scale of the forward: a masked plane passes no gradient
     const int y_src0 = blockIdx.y * TS, x_src0 = blockIdx.x * TS;
     const int Y0 = (y_src0 - 1) * SCALE, X0 = (x_src0 - 1) * SCALE;
     const long pbase = (long)plane * H * W;
     for (int i = threadIdx.x; i < R * R; i += NT) {
         const int ry = i / R, rx = i - ry * R, Y = Y0 + ry, X = X0 + rx;
         float g = 0.f;
-        if (Y >= 0 && Y < H && X >= 0 && X < W) {
+        if (!masked && Y >= 0 && Y < H && X >= 0 && X < W) {
             g = dout[pbase + (long)Y * W + X];
             if (apply_tanh) { const float t = 2.f * out[pbase + (long)Y * W + X] - 1.f; g *= 0.5f * (1.f - t * t); }
         }
@@ -481,31 +495,43 @@ extern "C" int mg_mask_embed_bwd(const void* dx, int dtype, const float* masks, 
     return 0;
 }
 
+extern "C" int mg_upsample_tanh_ex(const void* in, int dtype, long sn, long sc, long sy, long sx, int N, int C, int h, int w, int scale,
+                                   int apply_tanh, float* out, const float* pscale, int32_t* any_nonzero, void* stream);
 extern "C" int mg_upsample_tanh(const void* in, int dtype, long sn, long sc, long sy, long sx, int N, int C, int h, int w, int scale,
                                 int apply_tanh, float* out, void* stream) {
+    return mg_upsample_tanh_ex(in, dtype, sn, sc, sy, sx, N, C, h, w, scale, apply_tanh, out, nullptr, nullptr, stream);
+}
+extern "C" int mg_upsample_tanh_ex(const void* in, int dtype, long sn, long sc, long sy, long sx, int N, int C, int h, int w, int scale,
+                                   int apply_tanh, float* out, const float* pscale, int32_t* any_nonzero, void* stream) {
     long total = (long)N * C * h * w * scale * scale;
     if (total <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     const long hw = (long)h * w * scale * scale;
     long bx = (hw + NT - 1) / NT; if (bx > 64) bx = 64;
     dim3 grid((unsigned)bx, (unsigned)(N * C));
-    if (dtype == MG_BF16) hipLaunchKernelGGL(upsample_tanh_kernel<bf16raw>, grid, dim3(NT), 0, st, (const bf16raw*)in, sn, sc, sy, sx, N, C, h, w, scale, apply_tanh, out);
-    else hipLaunchKernelGGL(upsample_tanh_kernel<float>, grid, dim3(NT), 0, st, (const float*)in, sn, sc, sy, sx, N, C, h, w, scale, apply_tanh, out);
+    if (dtype == MG_BF16) hipLaunchKernelGGL(upsample_tanh_kernel<bf16raw>, grid, dim3(NT), 0, st, (const bf16raw*)in, sn, sc, sy, sx, N, C, h, w, scale, apply_tanh, out, pscale, any_nonzero);
+    else hipLaunchKernelGGL(upsample_tanh_kernel<float>, grid, dim3(NT), 0, st, (const float*)in, sn, sc, sy, sx, N, C, h, w, scale, apply_tanh, out, pscale, any_nonzero);
     MG_CHECK_LAUNCH();
     return 0;
 }
 
+extern "C" int mg_upsample_tanh_bwd_ex(const float* dout, const float* out, long sn, long sc, long sy, long sx, int N, int C, int h, int w,
+                                       int scale, int apply_tanh, float* din, const float* pscale, void* stream);
 extern "C" int mg_upsample_tanh_bwd(const float* dout, const float* out, long sn, long sc, long sy, long sx, int N, int C, int h, int w,
                                     int scale, int apply_tanh, float* din, void* stream) {
+    return mg_upsample_tanh_bwd_ex(dout, out, sn, sc, sy, sx, N, C, h, w, scale, apply_tanh, din, nullptr, stream);
+}
+extern "C" int mg_upsample_tanh_bwd_ex(const float* dout, const float* out, long sn, long sc, long sy, long sx, int N, int C, int h, int w,
+                                       int scale, int apply_tanh, float* din, const float* pscale, void* stream) {
     long total = (long)N * C * h * w * scale * scale;
     if (total <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     if (scale == 4 && h % 8 == 0 && w % 8 == 0)
-        hipLaunchKernelGGL(upsample_tanh_bwd_tile_kernel<4>, dim3(w / 8, h / 8, N * C), dim3(NT), 0, st, dout, out, sn, sc, sy, sx, C, h, w, apply_tanh, din);
+        hipLaunchKernelGGL(upsample_tanh_bwd_tile_kernel<4>, dim3(w / 8, h / 8, N * C), dim3(NT), 0, st, dout, out, sn, sc, sy, sx, C, h, w, apply_tanh, din, pscale);
     else if (scale == 8 && h % 8 == 0 && w % 8 == 0)
-        hipLaunchKernelGGL(upsample_tanh_bwd_tile_kernel<8>, dim3(w / 8, h / 8, N * C), dim3(NT), 0, st, dout, out, sn, sc, sy, sx, C, h, w, apply_tanh, din);
+        hipLaunchKernelGGL(upsample_tanh_bwd_tile_kernel<8>, dim3(w / 8, h / 8, N * C), dim3(NT), 0, st, dout, out, sn, sc, sy, sx, C, h, w, apply_tanh, din, pscale);
     else
-        hipLaunchKernelGGL(upsample_tanh_bwd_kernel, dim3(grid_for(total)), dim3(NT), 0, st, dout, out, sn, sc, sy, sx, N, C, h, w, scale, apply_tanh, din);
+        hipLaunchKernelGGL(upsample_tanh_bwd_kernel, dim3(grid_for(total)), dim3(NT), 0, st, dout, out, sn, sc, sy, sx, N, C, h, w, scale, apply_tanh, din, pscale);
     MG_CHECK_LAUNCH();
     return 0;
 }

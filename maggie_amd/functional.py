@@ -194,6 +194,39 @@ def join_side():
         del _FORKED[:]
 
 
+def parallel_branches(fns, device, tag=''):
+    """Run independent launch sequences concurrently: fns[0] on the current stream, the others on side streams forked from it, all joined
+    before returning. -> list of results. The chains this is used for (the three scales of the matting losses, the ASPP branches) are
+    strings of small kernels at the latency floor of a launch: one after the other their floors add up, side by side they overlap --
+    inside a captured hipGraph they become parallel branches. Tensors produced on a side stream are registered with the caching
+    allocator for the current stream (they are consumed there after the join). MAGGIE_BRANCHES=0 runs them in sequence."""
+    if len(fns) < 2 or not (PAR_BRANCHES == '1' or (tag and tag in PAR_BRANCHES.split(','))):
+        return [f() for f in fns]
+    main = torch.cuda.current_stream(device)
+    sides = []
+    for i in range(1, len(fns)):
+        sd = side_stream(device, 8 + i)
+        sd.wait_stream(main)
+        sides.append(sd)
+    outs = [None] * len(fns)
+    for i, sd in enumerate(sides, 1):
+        with torch.cuda.stream(sd):
+            outs[i] = fns[i]()
+    outs[0] = fns[0]()
+    for i, sd in enumerate(sides, 1):
+        main.wait_stream(sd)
+        r = outs[i]
+        for t in (r if isinstance(r, (tuple, list)) else (r,)):
+            if torch.is_tensor(t):
+                t.record_stream(main)
+    return outs
+
+
+# Off by default: measured on the frozen workload (round 3), the three loss scales + the five ASPP branches as parallel graph branches
+# made the step 2.0 ms SLOWER (14.45 -> 16.44 ms) -- fork / join edges of a replayed hipGraph cost far more than the launch floors they hide.
+PAR_BRANCHES = os.environ.get('MAGGIE_BRANCHES', '0')        # '0' | '1' | comma list of tags ('loss', 'aspp')
+
+
 class WeightBankPlan:
     """Static description of a set of small parameters converted together (csrc/weight_bank.hip). `items`: list of
     (parameter, (cout, taps, cin), cout_pad, cin_pad, flip_t, is_bias); a bias is (1, 1, C) and stays fp32."""
@@ -469,7 +502,11 @@ def pad_vec(v, n):
 # ----------------------------------------------------------------------------------------------------------------------
 
 BN_SMALL_ROWS = int(_os.environ.get('MG_BN_SMALL_ROWS', '1024'))     # layers up to this many rows run BatchNorm as one launch per direction (csrc/norm_act.hip)
-BN_LINK = _os.environ.get('MAGGIE_BN_LINK', '1') != '0'
+# Off by default (round 3, measured on the frozen workload): the reduce pass it removes (35 launches, 0.44 ms) is paid back by the slower
+# data-gradient epilogues (+0.17 ms over 30 launches: two more HBM tiles per output tile at one workgroup per CU) and the replica reduction
+# in front of the apply pass (+0.3 ms) -- 13.42 / 13.60 ms with the link against 13.43 / 13.44 ms without. Kept for the tests and as the
+# starting point of a register-staged variant; MAGGIE_BN_LINK=1 switches it on.
+BN_LINK = _os.environ.get('MAGGIE_BN_LINK', '0') != '0'
 
 
 class BnLink:
@@ -917,7 +954,7 @@ class UpsampleTanh(torch.autograd.Function):
     `nhwc`, else fp32 planes (N, C, h, w)."""
 
     @staticmethod
-    def forward(ctx, x, C, scale, nhwc, apply_tanh):
+    def forward(ctx, x, C, scale, nhwc, apply_tanh, pscale=None, want_flag=False):
         x = x.contiguous()
         if nhwc:
             N, h, w, Cp = x.shape
@@ -925,22 +962,29 @@ class UpsampleTanh(torch.autograd.Function):
         else:
             N, _, h, w = x.shape
             strides = (C * h * w, h * w, w, 1)
-        out = K.upsample_tanh(x, strides, N, C, h, w, scale, apply_tanh)
-        ctx.save_for_backward(out)
+        ps = None if pscale is None else pscale.detach().float().reshape(-1).contiguous()
+        flag = torch.zeros(1, dtype=torch.int32, device=x.device) if want_flag else None
+        out = K.upsample_tanh(x, strides, N, C, h, w, scale, apply_tanh, ps, flag)
+        ctx.save_for_backward(out, ps)
         ctx.meta = (x.shape, x.dtype, strides, N, C, h, w, scale, apply_tanh)
+        if want_flag:
+            ctx.mark_non_differentiable(flag)
+            return out, flag
         return out
 
     @staticmethod
-    def backward(ctx, dout):
-        (out,) = ctx.saved_tensors
+    def backward(ctx, dout, _dflag=None):
+        out, ps = ctx.saved_tensors
         xshape, xdtype, strides, N, C, h, w, scale, apply_tanh = ctx.meta
         din = torch.zeros(xshape, dtype=torch.float32, device=dout.device)
-        K.upsample_tanh_bwd(dout.contiguous(), out, strides, N, C, h, w, scale, din, apply_tanh)
-        return din.to(xdtype), None, None, None, None
+        K.upsample_tanh_bwd(dout.contiguous(), out, strides, N, C, h, w, scale, din, apply_tanh, ps)
+        return din.to(xdtype), None, None, None, None, None, None
 
 
-def upsample_tanh(x, C, scale, nhwc, apply_tanh=True):
-    return UpsampleTanh.apply(x, C, scale, nhwc, apply_tanh)
+def upsample_tanh(x, C, scale, nhwc, apply_tanh=True, pscale=None, want_flag=False):
+    """`pscale` (N*C values in {0, 1}): per-plane scale of the output (`* valid_masks`); `want_flag`: also return an int32 [1] tensor that is 1
+    when any output element is non-zero."""
+    return UpsampleTanh.apply(x, C, scale, nhwc, apply_tanh, pscale, want_flag)
 
 
 class MaskEmbed(torch.autograd.Function):
@@ -1016,7 +1060,7 @@ class MattingLosses(torch.autograd.Function):
     Returns a 3-vector; backward yields d/dpred only (target and weight are constants of the loss)."""
 
     @staticmethod
-    def forward(ctx, pred, target, weight):
+    def forward(ctx, pred, target, weight, pvalid=None):
         H, W_ = pred.shape[-2:]
         assert H % 8 == 0 and W_ % 8 == 0
         p = pred.detach().float().contiguous()
@@ -1030,7 +1074,9 @@ class MattingLosses(torch.autograd.Function):
         hipc('mg_plane_flags', ptr(w), c_int(P), c_int(H * W_), ptr(flags), st())
         sums = torch.zeros(32 * 16, dtype=torch.float32, device=dev)    # 32 replicas x [l1, grad, w, lap0, w0, lap1, w1, lap2, w2, pad]: see mg_loss_finish
         d = torch.empty((P, H, W_), dtype=torch.float32, device=dev)
-        hipc('mg_loss_point_fwd', ptr(p), ptr(t), ptr(w), ptr(flags), c_int(P), c_int(H), c_int(W_), ptr(d), ptr(sums), st())
+        if pvalid is not None:
+            assert pvalid.dtype == torch.int32 and pvalid.numel() == P and pvalid.is_contiguous()
+        hipc('mg_loss_point_fwd', ptr(p), ptr(t), ptr(w), ptr(flags), c_int(P), c_int(H), c_int(W_), ptr(d), ptr(sums), ptr(pvalid), st())
         x, h, ww = d, H, W_
         Gs = []
         for lvl in range(3):
@@ -1044,6 +1090,7 @@ class MattingLosses(torch.autograd.Function):
         out = torch.empty(3, dtype=torch.float32, device=dev)                   # (rec, lap, grad)
         hipc('mg_loss_finish', ptr(sums), ptr(out), st())
         ctx.save_for_backward(p, t, w, flags, sums, *Gs)
+        ctx.pvalid = pvalid
         ctx.shape = pred.shape
         return out
 
@@ -1074,25 +1121,25 @@ class MattingLosses(torch.autograd.Function):
         A, B = new(H, W_), new(H, W_)
         dp = torch.empty((P, H, W_), dtype=torch.float32, device=dev)          # planes without weight are zeroed by the kernel
         hipc('mg_loss_point_bwd', ptr(p), ptr(t), ptr(w), ptr(flags), c_int(P), c_int(H), c_int(W_), ptr(c_rec), ptr(c_grad), ptr(dd0),
-             ptr(A), ptr(B), ptr(dp), st())
-        return dp.view(ctx.shape), None, None
+             ptr(A), ptr(B), ptr(dp), ptr(ctx.pvalid), st())
+        return dp.view(ctx.shape), None, None, None
 
 
-def os8_weight(alphas, a8, reweight=True):
+def os8_weight(alphas, a8, reweight=True, pvalid=None):
     """Loss weight of the OS8 prediction (arch/maggie.py:271-281): [plane has ground truth] + [pixel in the unknown band of gt or a8]."""
     gt, a = alphas.detach().contiguous(), a8.detach().contiguous()
     H, W_ = gt.shape[-2:]
     P = gt.numel() // (H * W_)
     out = torch.empty_like(a)
     flags = torch.empty(P, dtype=torch.int32, device=gt.device)
-    K.hip.call('mg_os8_weight', K.hip.ptr(gt), K.hip.ptr(a), K.c_int(P), K.c_long(H * W_), K.c_int(int(bool(reweight))), K.hip.ptr(flags),
-               K.hip.ptr(out), K.hip.stream())
+    K.hip.call('mg_os8_weight_ex', K.hip.ptr(gt), K.hip.ptr(a), K.c_int(P), K.c_long(H * W_), K.c_int(int(bool(reweight))), K.hip.ptr(flags),
+               K.hip.ptr(out), K.hip.ptr(pvalid), K.hip.stream())
     return out
 
 
-def matting_losses(pred, target, weight):
-    """-> (rec, lap, grad) scalars."""
-    out = MattingLosses.apply(pred, target, weight.expand_as(pred) if weight.shape != pred.shape else weight)
+def matting_losses(pred, target, weight, pvalid=None):
+    """-> (rec, lap, grad) scalars. `pvalid` (int32 [planes]): planes with 0 are evaluated as if pred were zero there (`pred * valid_masks`)."""
+    out = MattingLosses.apply(pred, target, weight.expand_as(pred) if weight.shape != pred.shape else weight, pvalid)
     return out.unbind(0)
 
 

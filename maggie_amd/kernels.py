@@ -536,22 +536,35 @@ def mask_embed_bwd(dx, masks, table_shape):
     return dtable
 
 
-def upsample_tanh(x, strides, N, C, h, w, scale, apply_tanh=True):
-    """x addressed as (n, c, y, x) with element strides -> fp32 (N, C, h*scale, w*scale) = (tanh(bilinear(x)) + 1)/2."""
+def upsample_tanh(x, strides, N, C, h, w, scale, apply_tanh=True, pscale=None, any_nonzero=None):
+    """x addressed as (n, c, y, x) with element strides -> fp32 (N, C, h*scale, w*scale) = (tanh(bilinear(x)) + 1)/2.
+    `pscale`: fp32 [N*C] 0 / 1 plane scale; `any_nonzero`: zeroed int32 [1], set to 1 when any output element is non-zero."""
     out = torch.empty((N, C, h * scale, w * scale), dtype=torch.float32, device=x.device)
     sn, sc, sy, sx = strides
-    hip.need_cuda(x)
-    hip.call('mg_upsample_tanh', hip.ptr(x), c_int(hip.dtype_code(x)), c_long(sn), c_long(sc), c_long(sy), c_long(sx), c_int(N), c_int(C),
-             c_int(h), c_int(w), c_int(scale), c_int(int(apply_tanh)), hip.ptr(out), hip.stream())
+    hip.need_cuda(x, pscale, any_nonzero)
+    assert pscale is None or (pscale.dtype == torch.float32 and pscale.numel() == N * C and pscale.is_contiguous())
+    hip.call('mg_upsample_tanh_ex', hip.ptr(x), c_int(hip.dtype_code(x)), c_long(sn), c_long(sc), c_long(sy), c_long(sx), c_int(N), c_int(C),
+             c_int(h), c_int(w), c_int(scale), c_int(int(apply_tanh)), hip.ptr(out), hip.ptr(pscale), hip.ptr(any_nonzero), hip.stream())
     return out
 
 
-def upsample_tanh_bwd(dout, out, strides, N, C, h, w, scale, din, apply_tanh=True):
+def upsample_tanh_bwd(dout, out, strides, N, C, h, w, scale, din, apply_tanh=True, pscale=None):
     """din: fp32 buffer with the input's strides (pre-zeroed), accumulated atomically."""
     sn, sc, sy, sx = strides
-    hip.call('mg_upsample_tanh_bwd', hip.ptr(dout), hip.ptr(out), c_long(sn), c_long(sc), c_long(sy), c_long(sx), c_int(N), c_int(C), c_int(h),
-             c_int(w), c_int(scale), c_int(int(apply_tanh)), hip.ptr(din), hip.stream())
+    hip.call('mg_upsample_tanh_bwd_ex', hip.ptr(dout), hip.ptr(out), c_long(sn), c_long(sc), c_long(sy), c_long(sx), c_int(N), c_int(C), c_int(h),
+             c_int(w), c_int(scale), c_int(int(apply_tanh)), hip.ptr(din), hip.ptr(pscale), hip.stream())
     return din
+
+
+def plane_flags(planes):
+    """int32 [P]: 1 where a (.., H, W) fp32 plane holds any value > 0 (mg_plane_flags)."""
+    H, W = planes.shape[-2:]
+    P = planes.numel() // (H * W)
+    flags = torch.empty(P, dtype=torch.int32, device=planes.device)
+    hip.need_cuda(planes)
+    assert planes.dtype == torch.float32 and planes.is_contiguous()
+    hip.call('mg_plane_flags', hip.ptr(planes), c_int(P), c_int(H * W), hip.ptr(flags), hip.stream())
+    return flags
 
 
 # ------------------------------------------------------------------------------------------------------------------

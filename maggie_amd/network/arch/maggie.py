@@ -296,12 +296,12 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
 
     def _forward_impl(self, batch, **kwargs):
         masks, alphas, trans_gt, b, n_f, h, w, n_i, chosen_ids, x, enc_masks = self.forward_inputs(batch)
-        dense = self._run_trunk((b, n_f, n_i), x, enc_masks, masks, alphas, kwargs.get('mem_feat'))
+        dense, nonzero = self.decoder.split_dense_flag(self._run_trunk((b, n_f, n_i), x, enc_masks, masks, alphas, kwargs.get('mem_feat')))
         # ---- the ONE device->host read of the step: NaN instance tokens (mask_attention.py:95-98 raises) and, in training, whether the
         # coarse alpha is identically zero (resnet_inst_matt_spconv.py:314: the ground truth then guides the detail region). Everything
         # else the detail stage needs from the host is drawn below, in the reference's order; no site count is ever read back.
         x_os8 = dense[0]
-        fl = [torch.isnan(dense[2]).any()] + ([x_os8.sum() == 0] if self.training else [])
+        fl = [torch.isnan(dense[2]).any()] + ([nonzero[0] == 0] if self.training else [])      # (the flag is written by the up-sampling kernel)
         flags = torch.stack(fl).tolist()
         if flags[0]:
             raise ValueError("Mask is empty")
@@ -350,15 +350,24 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         if self.training:
             alphas = alphas.view(-1, n_i, h, w)
             trans_gt = trans_gt.view(-1, n_i, h, w)
-            valid_masks = (trans_gt.sum((2, 3), keepdim=True) > 0).float()
+            # `pred[k] = v * valid_masks` (:112-118; valid = the plane has a ground-truth transition region). Where only the fused matting
+            # losses read the three alpha planes (image model), the per-plane 0 / 1 factor is handed to the loss kernels instead: no
+            # reduction over trans_gt, no three multiplies over (N, 10, H, W) planes forward and backward.
+            fold = self.loss_dtSSD_w <= 0 and n_i == self.num_masks and trans_gt.dtype == torch.float32
+            pvalid = K.plane_flags(trans_gt.contiguous()) if fold else None
+            valid_masks = None if fold else (trans_gt.sum((2, 3), keepdim=True) > 0).float()
             for k, v in list(pred.items()):
                 if 'loss' in k or 'mem_' in k:
                     continue
                 if k in ('detail_mask', 'weight_os4', 'weight_os1'):
                     continue        # the reference multiplies these too (:114-117) but never reads them again
+                if fold and k in ('alpha_os1', 'alpha_os4', 'alpha_os8'):
+                    continue
+                if valid_masks is None:
+                    valid_masks = pvalid.view(-1, n_i, 1, 1).float()
                 pred[k] = v * valid_masks
             loss_dict = self.compute_loss(pred, weight_os4, weight_os1, alphas, trans_gt, (b, n_f, self.num_masks, h, w),
-                                          reweight_os8=self.reweight_os8, defer_total=True)
+                                          reweight_os8=self.reweight_os8, defer_total=True, pvalid=pvalid)
             self.update_additional_decoder_loss(pred, loss_dict)
             self._finish_total(loss_dict)
             for k, v in loss_dict.items():
@@ -468,10 +477,17 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             raise K.hip.MaggieHipError('MaGGIe (MI355X build) runs on the GPU only: move the batch to cuda (no CPU fallback)')
         x = x.reshape(-1, 3, h, w).float()
         masks_lr = masks.flatten(0, 1).float()                      # kept at its own resolution for the packing kernel
-        if masks.shape[-1] != w:
-            masks = F.interpolate(masks_lr, size=(h, w), mode="nearest")
-        else:
+        hm, wm = masks.shape[-2:]
+        if wm == w and hm == h:
             masks = masks_lr
+        elif w % wm == 0 and h % hm == 0 and w // wm == h // hm and 8 % (w // wm) == 0:
+            # The reference up-scales the guidance masks to (h, w) (nearest, arch/maggie.py:176-178) only to reduce them again: the instance
+            # matte decoder average-pools them to OS8 and thresholds (> 0), `valid_masks` is (sum > 0) per plane. For an integer down-scale
+            # that divides 8 both are functions of the low-resolution mask alone (every OS8 cell is a whole number of mask pixels), so the
+            # 40 MB full-resolution copy, its reduction and its pooling are skipped: the decoder receives the mask as it came.
+            masks = masks_lr
+        else:
+            masks = F.interpolate(masks_lr, size=(h, w), mode="nearest")
         masks, alphas, trans_gt, n_i, chosen_ids, enc_masks = self.prepare_input(x, masks, masks_lr, alphas, trans_gt, b, n_f, h, w, n_i)
         if alphas is not None:
             alphas = alphas.reshape(-1, n_i, h, w)
@@ -500,7 +516,7 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
                 chosen_ids = np.random.choice(self.num_masks, n_i, replace=False)
                 enc_masks = masks_lr.new_zeros((b * n_f, self.num_masks, hm, wm))
                 enc_masks[:, chosen_ids] = masks_lr
-                new_masks = masks.new_zeros((b * n_f, self.num_masks, h, w))
+                new_masks = masks.new_zeros((b * n_f, self.num_masks, *masks.shape[-2:]))
                 new_masks[:, chosen_ids] = masks
                 masks = new_masks
                 if alphas is not None:
@@ -515,7 +531,7 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         return masks, alphas, trans_gt, n_i, chosen_ids, enc_masks
 
     # ------------------------------------------------------------------------------------------------ losses
-    def compute_loss(self, pred, weight_os4, weight_os1, alphas, trans_gt, alpha_shape, reweight_os8=True, defer_total=False):
+    def compute_loss(self, pred, weight_os4, weight_os1, alphas, trans_gt, alpha_shape, reweight_os8=True, defer_total=False, pvalid=None):
         """arch/maggie.py:268-368: weighted L1 + Laplacian-pyramid L1 + Sobel-gradient L1 at OS1 (x2) / OS4 / OS8 (+ dtSSD for video), same
         loss names. Every term is a fused HIP pipeline (csrc/losses.hip) -- there is no torch fallback: what the kernels do not cover is
         rejected loudly (`loss_alpha_type` other than the 'l1' of maggie_{image,video}.yaml; sizes that are not multiples of 8)."""
@@ -530,16 +546,17 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
                 % (lt, a8.shape[-2], a8.shape[-1]))
         loss_dict = {}
         alphas = alphas.float()
-        weight_os8 = MF.os8_weight(alphas, a8.float(), reweight_os8)             # arch/maggie.py:271-281 in one pass (mg_os8_weight)
+        weight_os8 = MF.os8_weight(alphas, a8.float(), reweight_os8, pvalid)     # arch/maggie.py:271-281 in one pass (mg_os8_weight)
         n_i = alphas.shape[1]
         if self.num_masks - n_i > 0:
             padding = torch.zeros((alphas.shape[0], self.num_masks - n_i, *alphas.shape[-2:]), device=alphas.device)
             alphas = torch.cat([alphas, padding], dim=1)
             trans_gt = torch.cat([trans_gt, padding], dim=1)
         # one fused HIP pipeline per scale: weighted L1 + Laplacian-pyramid L1 + Sobel-gradient L1 (fwd sums + exact bwd)
-        r1, l1_, g1 = MF.matting_losses(a1, alphas, weight_os1)
-        r4, l4_, g4 = MF.matting_losses(a4, alphas, weight_os4)
-        r8, l8_, g8 = MF.matting_losses(a8, alphas, weight_os8)
+        # (the three scales are independent strings of ~15 small launches each way: side by side as parallel branches of the graph)
+        (r1, l1_, g1), (r4, l4_, g4), (r8, l8_, g8) = MF.parallel_branches(
+            [lambda: MF.matting_losses(a1, alphas, weight_os1, pvalid), lambda: MF.matting_losses(a4, alphas, weight_os4, pvalid),
+             lambda: MF.matting_losses(a8, alphas, weight_os8, pvalid)], alphas.device, 'loss')
         # The sums of arch/maggie.py:283-300 (loss_x = 2 * os1 + os4 + os8, total = sum_x w_x * loss_x): the per-family values are for the log
         # (no gradient flows through them -- only through `total`), `total` is ONE weighted sum of the nine (twelve) scale terms
         # (mg_scalar_lincomb: one launch forward, one backward, instead of ~12 + ~14 one-element torch kernels)

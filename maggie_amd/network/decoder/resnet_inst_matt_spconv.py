@@ -191,7 +191,8 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
         valid_masks = masks.flatten(0, 1).sum((2, 3), keepdim=True) > 0
         gt_masks = None
         if self.training:
-            gt_masks = (gt_alphas > 0).reshape(b, n_f, n_i, gt_alphas.shape[2], gt_alphas.shape[3])
+            # (gt_alphas > 0) of :322 is applied AFTER the decoder's max-pooling to OS8 (max > 0 <=> any > 0): no full-resolution compare pass
+            gt_masks = gt_alphas.reshape(b, n_f, n_i, gt_alphas.shape[2], gt_alphas.shape[3])
         fea1, fea2, fea3, fea4, fea5 = mid_fea['shortcut']
         image = mid_fea['image']
         x = self.layer1[0](x, link_out=True)
@@ -259,20 +260,29 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
 
     def dense_stage(self, x, mid_fea, b, n_f, n_i, masks, gt_alphas, mem_feat=None):
         """:318-339. Returns (alpha_os8 (N, 10, H, W) fp32 [train: times valid_masks], OS8 features, queries, loss_max_atten,
-        hidden_state | None, fea1, fea2, fea3)."""
+        hidden_state | None, fea1, fea2, fea3) and, in training, as LAST element an int32 [1] device flag: 1 when alpha_os8 has a non-zero
+        element (split_dense_flag() takes it off again)."""
         x, masks, valid_masks, gt_masks, fea1, fea2, fea3, image, h, w = self.os32_to_os8(x, mid_fea, b, n_f, n_i, masks, gt_alphas)
         x_os8, x, queries, loss_max_atten, hidden_state = self._refine_os8(x, masks, gt_masks, n_f, mem_feat)
-        x_os8 = MF.upsample_tanh(x_os8, self.max_inst, h // x_os8.shape[1], True)          # (N, 10, H, W) fp32
         if self.training:
-            x_os8 = x_os8 * valid_masks
+            # `x_os8 * valid_masks` (:331) and the `x_os8.sum() == 0` test of :314 ride on the up-sampling kernel: a 0 / 1 scale per plane and
+            # a "some element is non-zero" flag, instead of a multiply and a reduction over the (N, 10, H, W) planes (and a multiply in backward)
+            x_os8, nonzero = MF.upsample_tanh(x_os8, self.max_inst, h // x_os8.shape[1], True, pscale=valid_masks, want_flag=True)
+        else:
+            x_os8, nonzero = MF.upsample_tanh(x_os8, self.max_inst, h // x_os8.shape[1], True), None          # (N, 10, H, W) fp32
         if not torch.is_tensor(loss_max_atten):
             loss_max_atten = x_os8.new_zeros(())
-        return x_os8, x, queries, loss_max_atten, hidden_state, fea1, fea2, fea3
+        out = (x_os8, x, queries, loss_max_atten, hidden_state, fea1, fea2, fea3)
+        return out + (nonzero,) if self.training else out
+
+    def split_dense_flag(self, dense):
+        """dense_stage()'s tuple -> (tuple without the trailing flag, flag | None)."""
+        return (tuple(dense[:-1]), dense[-1]) if self.training else (tuple(dense), None)
 
     def forward(self, x, mid_fea, b, n_f, n_i, masks, iter, gt_alphas, **kwargs):
-        dense = self.dense_stage(x, mid_fea, b, n_f, n_i, masks, gt_alphas, kwargs.get('mem_feat'))
+        dense, nonzero = self.split_dense_flag(self.dense_stage(x, mid_fea, b, n_f, n_i, masks, gt_alphas, kwargs.get('mem_feat')))
         x_os8 = dense[0]
-        flags = torch.stack([torch.isnan(dense[2]).any(), x_os8.sum() == 0]).tolist()
+        flags = torch.stack([torch.isnan(dense[2]).any(), (nonzero[0] == 0) if nonzero is not None else (x_os8.sum() == 0)]).tolist()
         if flags[0]:
             raise ValueError("Mask is empty")
         P = x_os8.shape[0] * (x_os8.shape[1] if self.training else n_i)

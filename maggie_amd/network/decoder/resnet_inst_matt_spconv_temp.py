@@ -46,8 +46,9 @@ class ResShortCut_InstMattSpconv_BiTempSpar_Dec(ResShortCut_InstMattSpconv_Dec):
         out = super().dense_stage(x, mid_fea, b, n_f, n_i, masks, gt_alphas, mem_feat)
         if n_f < 2:
             return out
-        feat = out[1]
-        return tuple(out) + (self.frame_diffs(feat.view(b, n_f, *feat.shape[1:]).detach()),)
+        core, flag = self.split_dense_flag(out)                  # the training flag stays the LAST element
+        feat = core[1]
+        return core + (self.frame_diffs(feat.view(b, n_f, *feat.shape[1:]).detach()),) + ((flag,) if flag is not None else ())
 
     def bidirectional_fusion(self, feat, preds, diffs=None):
         """feat (b, n_f, h, w, 64) NHWC (detached); preds (b, n_f, n_i, H, W) fp32; diffs: frame_diffs(feat) when the trunk already

@@ -28,15 +28,24 @@ class ASPP(nn.Module):
     def forward(self, x):
         """x: (N, H, W, 512) NHWC."""
         dt = x.dtype
-        outs = []
-        for conv, bn in ((self.aspp1, self.aspp1_bn), (self.aspp2, self.aspp2_bn), (self.aspp3, self.aspp3_bn), (self.aspp4, self.aspp4_bn)):
-            w = MF.plain_krsc(conv, dt)
-            outs.append(MF.conv_bn_act(x, w, bn, MF.ACT_RELU, conv.kernel_size, conv.kernel_size, 1, conv.padding, conv.dilation))
         N, H, W_, C = x.shape
-        pooled = x.float().mean((1, 2), keepdim=True).to(dt)                       # AdaptiveAvgPool2d(1)
+
+        def branch(conv, bn):
+            w = MF.plain_krsc(conv, dt)                           # (looked up on the calling stream: host-side only)
+            return lambda: MF.conv_bn_act(x, w, bn, MF.ACT_RELU, conv.kernel_size, conv.kernel_size, 1, conv.padding, conv.dilation)
+
+        def pooled_branch():
+            pooled = x.float().mean((1, 2), keepdim=True).to(dt)                   # AdaptiveAvgPool2d(1)
+            return MF.conv_bn_act(pooled, w5, self.aspp5_bn, MF.ACT_RELU, 1, 1, 1, 0, 1)
+
         w5 = MF.plain_krsc(self.aspp5, dt)
-        x5 = MF.conv_bn_act(pooled, w5, self.aspp5_bn, MF.ACT_RELU, 1, 1, 1, 0, 1)
-        outs.append(x5.expand(N, H, W_, x5.shape[-1]))                             # nearest upsample of a 1x1 map
+        # five independent conv + BatchNorm strings over a (N, 16, 16) map: every kernel under-fills the chip, so they run as parallel
+        # branches (functional.parallel_branches) -- forward and, through autograd's per-node streams, backward
+        fns = [branch(c, b) for c, b in ((self.aspp1, self.aspp1_bn), (self.aspp2, self.aspp2_bn), (self.aspp3, self.aspp3_bn),
+                                         (self.aspp4, self.aspp4_bn))] + [pooled_branch]
+        outs = MF.parallel_branches(fns, x.device, 'aspp')
+        x5 = outs[4]
+        outs = list(outs[:4]) + [x5.expand(N, H, W_, x5.shape[-1])]                # nearest upsample of a 1x1 map
         y = torch.cat(outs, -1)
         w2 = MF.plain_krsc(self.conv2, dt)
         return MF.conv_bn_act(y, w2, self.bn2, MF.ACT_RELU, 1, 1, 1, 0, 1, link_out=True)     # sole consumer: the decoder's first (transposed) conv

@@ -76,8 +76,8 @@ class InstanceMatteDecoder(nn.Module):
         stride = mask.shape[-1] // w
         m8 = mask.reshape(b * n_f, n_in, mask.shape[-2], mask.shape[-1]).float()
         if stride > 1:
-            m8 = (F.avg_pool2d(m8, stride, stride) > 0).float()
-        m8 = m8.view(b, n_f, n_in, h, w)
+            m8 = F.avg_pool2d(m8, stride, stride)
+        m8 = (m8 > 0).float().view(b, n_f, n_in, h, w)             # (also for a mask that arrives at OS8: the reference pools its up-scaled copy)
         # ID position of every feature pixel = max over instances of id*mask (:150-153)
         ids = torch.arange(1, n_in + 1, device=mask.device, dtype=torch.float32)[None, None, :, None, None]
         feat_ids = (m8 * ids).amax(2).to(torch.int32).reshape(b, n_f * h * w).contiguous()  # (b, L), l = f*hw + p

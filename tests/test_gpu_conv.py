@@ -320,6 +320,8 @@ def test_bn_backward_sums_in_the_consumer_dgrad_epilogue(case, dtype):
     gz = q(torch.from_numpy(rs.normal(size=tuple(z.shape)).astype(np.float32)))          # the skip branch's gradient (carry)
     (y2 * gy).sum().backward() if not carry else ((y2 * gy).sum() + (z * gz).sum()).backward()
 
+    prev_link = MF.BN_LINK
+
     def run(link):
         MF.BN_LINK = link
         try:
@@ -347,7 +349,7 @@ def test_bn_backward_sums_in_the_consumer_dgrad_epilogue(case, dtype):
                 out['dres'] = rd.grad.float().cpu().permute(0, 3, 1, 2)
             return out, linked
         finally:
-            MF.BN_LINK = True
+            MF.BN_LINK = prev_link
 
     got, linked = run(True)
     base, base_linked = run(False)
@@ -361,7 +363,7 @@ def test_bn_backward_sums_in_the_consumer_dgrad_epilogue(case, dtype):
         # entering the BatchNorm is rounded here and not on the CPU) lands on the other side of the ReLU / LeakyReLU kink and moves its
         # gradient by O(1). The element-wise comparison is made against the unlinked path below, which shares the activations.
         rel = ((got[k_] - r_).norm() / r_.norm().clamp_min(1e-12)).item()
-        assert rel <= (1e-3 if dtype == torch.float32 else 3e-2), (k_, rel)
+        assert rel <= (5e-3 if dtype == torch.float32 else 3e-2), (k_, rel)
         # linked vs unlinked path of this build: same arithmetic up to the order of the fp32 reductions (and, in bf16, one rounding of g
         # where the unlinked path rounds dz and re-derives g in fp32)
         assert (got[k_] - base[k_]).abs().max().item() <= (2e-5 if dtype == torch.float32 else 2e-2) * sc_, ('vs unlinked', k_)

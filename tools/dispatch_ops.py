@@ -49,7 +49,7 @@ class Mode(TorchDispatchMode):
                     if ('maggie_amd' in fs.filename or 'dispatch_ops' in fs.filename) and fs.name != '__torch_dispatch__':
                         where = '%s:%d %s' % (fs.filename.split('repo/')[-1], fs.lineno, fs.name)
                         break
-                if SHAPES and where.startswith('autograd engine'):
+                if SHAPES and ('dispatch_ops' in where or where.startswith('autograd engine')):
                     # ops run by built-in autograd nodes (gradient accumulation of a tensor with several consumers, casts of gradients):
                     # which tensors? -> shapes and dtypes of the operands
                     where += '  ' + ' '.join('%s%s' % (str(a.dtype).replace('torch.', ''), list(a.shape)) for a in args if torch.is_tensor(a))
