@@ -496,6 +496,25 @@ int mg_token_linear_fwd(const float* x, const float* xadd, const float* W, const
 int mg_token_linear_bwd(const float* dy, const float* x, const float* xadd, const float* W, const float* yout, int relu, const float* gamma,
                         const float* z, const float* rstat, float* dx, float* dW, float* db, float* dres, float* dgamma, float* dbeta, float* dz_scratch,
                         int R, int K, int N, void* stream);
+/* mg_token_linear_fwd / _bwd with `wt` != 0: W is given as [K][N] and y = (x + xadd) W (dW is returned as [K][N] too) -- the `x @ wk` products of
+ * mask_attention.py (queries folded through the key projection) without a transposed copy of the weight each step. N % 4 == 0. */
+int mg_token_linear_fwd_ex(const float* x, const float* xadd, const float* W, const float* bias, const float* res, int relu, const float* gamma,
+                           const float* beta, float eps, float* y, float* z, float* rstat, int R, int K, int N, int wt, void* stream);
+int mg_token_linear_bwd_ex(const float* dy, const float* x, const float* xadd, const float* W, const float* yout, int relu, const float* gamma,
+                           const float* z, const float* rstat, float* dx, float* dW, float* db, float* dres, float* dgamma, float* dbeta,
+                           float* dz, int R, int K, int N, int wt, void* stream);
+/* Mask pre-processing of the instance matte decoder (instance_matte_decoder.py:131-153; utils.py:16-21): mask [B][NF][n_in][h*s][w*s] fp32 guidance
+ * masks (s = integer factor over the OS8 map), gt (or NULL) [B][NF][n_gt][h*gs][w*gs] fp32 alphas -> feat_ids int32 [B][NF*h*w] = max_i (i+1) * [avg-pooled
+ * mask_i > 0]; valid uint8 [B][n_i] padded to 4 bytes (zeroed here): 1 where slot i has a mask pixel; guidance fp32 [B][n_i][NF*h*w] = [max-pooled alpha_i > 0]
+ * (only with gt). */
+int mg_imd_prep(const float* mask, int n_in, int s, const float* gt, int n_gt, int gs, int B, int NF, int h, int w, int n_i, int32_t* feat_ids,
+                float* guidance, unsigned char* valid, void* stream);
+/* einsum('bqc,blc->blq') of the instance matte decoder (instance_matte_decoder.py:296-299): logits[b][l][q] = sum_c feat[b][l][c] tok[b][q][c] for
+ * q < Q, zero up to the row pitch QP (= 16). feat / out / dlog / dfeat in `dtype` ([B][L][C] / [B][L][QP]); tok / dtok fp32 [B][Q][C] (dtok is
+ * overwritten). C = 32 or 64, Q <= 16. The tokens are rounded to `dtype` first (the 1x1 convolution this replaces did the same). */
+int mg_token_einsum_fwd(const void* feat, int dtype, const float* tok, int B, int L, int C, int Q, int QP, void* out, void* stream);
+int mg_token_einsum_bwd(const void* dlog, const void* feat, int dtype, const float* tok, int B, int L, int C, int Q, int QP, void* dfeat,
+                        float* dtok, void* stream);
 int mg_token_sa_fwd(const float* q, const float* k, const float* v, const unsigned char* pad, float scale, int B, int T, int D, float* out, float* prob,
                     void* stream);
 int mg_token_sa_bwd(const float* dout, const float* q, const float* k, const float* v, const float* prob, float scale, int B, int T, int D, float* dq,

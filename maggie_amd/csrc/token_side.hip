@@ -31,7 +31,7 @@ __global__ __launch_bounds__(NT) void token_linear_fwd_kernel(const float* __res
                                                               const float* __restrict__ bias, const float* __restrict__ res, int relu,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                               float* __restrict__ y, float* __restrict__ z_out, float* __restrict__ rstat, int R, int K,
-                                                              int N) {
+                                                              int N, int wt) {
     extern __shared__ float sm[];
     float* sx = sm;                      // [RB][K]  x + xadd
     float* sy = sm + RB * K;             // [RB][N]  pre-LayerNorm values
@@ -50,8 +50,14 @@ __global__ __launch_bounds__(NT) void token_linear_fwd_kernel(const float* __res
             for (int u = 0; u < 8; ++u) {
                 const int i4 = base + u * NT;
                 if (i4 < total4) {
-                    const int i = i4 * 4, n = i / K, k = i - n * K;
-                    sw[k * P + n] = v[u].x; sw[(k + 1) * P + n] = v[u].y; sw[(k + 2) * P + n] = v[u].z; sw[(k + 3) * P + n] = v[u].w;
+                    const int i = i4 * 4;
+                    if (wt) {                            // W given as [K][N] (y = x W: the `wk.t()` products of mask_attention.py without a transposed copy)
+                        const int k = i / N, n = i - k * N;
+                        sw[k * P + n] = v[u].x; sw[k * P + n + 1] = v[u].y; sw[k * P + n + 2] = v[u].z; sw[k * P + n + 3] = v[u].w;
+                    } else {
+                        const int n = i / K, k = i - n * K;
+                        sw[k * P + n] = v[u].x; sw[(k + 1) * P + n] = v[u].y; sw[(k + 2) * P + n] = v[u].z; sw[(k + 3) * P + n] = v[u].w;
+                    }
                 }
             }
         }
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(NT) void token_linear_dz_kernel(const float* __rest
 
 // dx[r][k] = sum_n dz[r][n] W[n][k]: RB rows per workgroup, W staged once in LDS (the row-parallel half of the main backward launch)
 __device__ __forceinline__ void token_linear_bwd_rows(float* sm, int rblock, const float* __restrict__ dz, const float* __restrict__ W,
-                                                      float* __restrict__ dx, int R, int K, int N) {
+                                                      float* __restrict__ dx, int R, int K, int N, int wt) {
     float* sdz = sm;                     // [RB][N]
     float* sw = sm + RB * N;             // [N][K]
     const int t = threadIdx.x;
@@ -137,7 +143,14 @@ __device__ __forceinline__ void token_linear_bwd_rows(float* sm, int rblock, con
 #pragma unroll
         for (int u = 0; u < 8; ++u) { const int i4 = base + u * NT; if (i4 < total4) v[u] = ((const float4*)W)[i4]; }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int i4 = base + u * NT; if (i4 < total4) ((float4*)sw)[i4] = v[u]; }
+        for (int u = 0; u < 8; ++u) {
+            const int i4 = base + u * NT;
+            if (i4 >= total4) continue;
+            if (wt) {                                    // W is [K][N]: the LDS copy stays [N][K]
+                const int i = i4 * 4, k = i / N, n = i - k * N;
+                sw[n * K + k] = v[u].x; sw[(n + 1) * K + k] = v[u].y; sw[(n + 2) * K + k] = v[u].z; sw[(n + 3) * K + k] = v[u].w;
+            } else ((float4*)sw)[i4] = v[u];
+        }
     }
     for (int i = t; i < RB * N; i += NT) { const int rl = i / N; sdz[i] = rl < nr ? dz[(size_t)r0 * N + i] : 0.f; }
     __syncthreads();
@@ -161,7 +174,8 @@ constexpr int CB = 4;
 __device__ __forceinline__ void token_linear_bwd_cols(float* sm, int cblock, const float* __restrict__ dz, const float* __restrict__ dy,
                                                       const float* __restrict__ x, const float* __restrict__ xadd, const float* __restrict__ gamma,
                                                       const float* __restrict__ z, const float* __restrict__ rstat, float* __restrict__ dW,
-                                                      float* __restrict__ db, float* __restrict__ dgamma, float* __restrict__ dbeta, int R, int K, int N) {
+                                                      float* __restrict__ db, float* __restrict__ dgamma, float* __restrict__ dbeta, int R, int K, int N,
+                                                      int wt) {
     constexpr int RC = 32;               // rows staged per pass
     float* sg = sm;                      // [RC][CB] dz of this block's columns
     float* sx = sm + RC * CB;            // [RC][K]
@@ -235,7 +249,7 @@ __device__ __forceinline__ void token_linear_bwd_cols(float* sm, int cblock, con
 #pragma unroll
         for (int cj = 0; cj < 2; ++cj) {
             const int k = c + ki * cols, ci = h + cj * groups;
-            if (k < K && ci < nc) dW[(size_t)(n0 + ci) * K + k] = acc[ki][cj];
+            if (k < K && ci < nc) dW[wt ? (size_t)k * N + n0 + ci : (size_t)(n0 + ci) * K + k] = acc[ki][cj];
         }
     if (t < nc) {
         if (db) db[n0 + t] = sb;
@@ -249,10 +263,11 @@ __global__ __launch_bounds__(NT) void token_linear_bwd_main_kernel(int nrb, cons
                                                                    const float* __restrict__ x, const float* __restrict__ xadd, const float* __restrict__ W,
                                                                    const float* __restrict__ gamma, const float* __restrict__ z,
                                                                    const float* __restrict__ rstat, float* __restrict__ dx, float* __restrict__ dW,
-                                                                   float* __restrict__ db, float* __restrict__ dgamma, float* __restrict__ dbeta, int R, int K, int N) {
+                                                                   float* __restrict__ db, float* __restrict__ dgamma, float* __restrict__ dbeta, int R, int K, int N,
+                                                                   int wt) {
     extern __shared__ float sm[];
-    if ((int)blockIdx.x < nrb) token_linear_bwd_rows(sm, blockIdx.x, dz, W, dx, R, K, N);
-    else token_linear_bwd_cols(sm, blockIdx.x - nrb, dz, dy, x, xadd, gamma, z, rstat, dW, db, dgamma, dbeta, R, K, N);
+    if ((int)blockIdx.x < nrb) token_linear_bwd_rows(sm, blockIdx.x, dz, W, dx, R, K, N, wt);
+    else token_linear_bwd_cols(sm, blockIdx.x - nrb, dz, dy, x, xadd, gamma, z, rstat, dW, db, dgamma, dbeta, R, K, N, wt);
 }
 
 // ---- token self-attention core: one workgroup per batch element, T <= 16 tokens, D <= 256 -------------------------------------------------
@@ -320,6 +335,125 @@ __global__ __launch_bounds__(NT) void token_sa_bwd_kernel(const float* __restric
     }
 }
 
+
+// ---- mask pre-processing of the instance matte decoder (instance_matte_decoder.py:131-153 + utils.py:16-21 resizeAnyShape(use_avg_pool_binary)):
+// per OS8 cell: the guidance masks average-pooled and thresholded (> 0), the instance-ID position = max_i (i + 1) * m8_i, which instance slots
+// have any mask pixel (token validity), and -- training -- the ground-truth guidance (max-pool of the alphas > 0). ~15 small torch launches
+// (pool, compare, cast, multiply, amax, cat, permute copies ...) per step in one.
+__global__ __launch_bounds__(NT) void imd_prep_kernel(const float* __restrict__ mask, int n_in, int s, const float* __restrict__ gt, int n_gt, int gs,
+                                                      int B, int NF, int h, int w, int n_i, int32_t* __restrict__ feat_ids,
+                                                      float* __restrict__ guidance, unsigned char* __restrict__ valid) {
+    const long cells = (long)B * NF * h * w;
+    const long i = (long)blockIdx.x * NT + threadIdx.x;
+    if (i >= cells) return;
+    const int x = (int)(i % w); long r = i / w; const int y = (int)(r % h); r /= h; const int f = (int)(r % NF); const int b = (int)(r / NF);
+    const int Hm = h * s, Wm = w * s;
+    int id = 0;
+    for (int k = 0; k < n_in; ++k) {
+        const float* mp = mask + (((long)(b * NF + f) * n_in + k) * Hm + (long)y * s) * Wm + (long)x * s;
+        float acc = 0.f;
+        for (int dy = 0; dy < s; ++dy)
+            for (int dx = 0; dx < s; ++dx) acc += mp[(long)dy * Wm + dx];
+        if (acc / (float)(s * s) > 0.f) { id = k + 1; valid[b * n_i + k] = 1; }        // (m8 * ids).amax(2): the largest set instance index
+    }
+    const long L = (long)NF * h * w, l = ((long)f * h + y) * w + x;
+    feat_ids[b * L + l] = id;
+    if (guidance) {
+        const int H = h * gs, W = w * gs;
+        for (int k = 0; k < n_i; ++k) {
+            float m = 0.f;
+            if (k < n_gt) {
+                const float* gp = gt + (((long)(b * NF + f) * n_gt + k) * H + (long)y * gs) * W + (long)x * gs;
+                m = gp[0];
+                for (int dy = 0; dy < gs; ++dy)
+                    for (int dx = 0; dx < gs; ++dx) m = fmaxf(m, gp[(long)dy * W + dx]);
+            }
+            guidance[((long)b * n_i + k) * L + l] = m > 0.f ? 1.f : 0.f;
+        }
+    }
+}
+
+// ---- einsum('bqc,blc->blq') of the instance matte decoder (instance_matte_decoder.py:296-299: logits of every OS8 pixel against the Q = 10
+// instance tokens of its batch element; C = output_dim = 32). The reference runs it as one einsum; round 2 ran it as one 1x1 convolution PER
+// batch element (weights = that element's tokens: 4 fprop + 4 dgrad + 4 wgrad + 4 reduce launches, 4 weight conversions and a stack per
+// step). One launch each way here: a thread owns a pixel row (C values in registers), the tokens of its batch element sit in LDS.
+template <typename T, int C>
+__global__ __launch_bounds__(NT) void token_einsum_fwd_kernel(const T* __restrict__ feat, const float* __restrict__ tok, int L, int Q, int QP,
+                                                              T* __restrict__ out) {
+    using TR = ElemTraits<T>;
+    constexpr int CE = TR::CE;
+    __shared__ float st[16 * C];
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < Q * C; i += NT) st[i] = TR::rnd(tok[(size_t)b * Q * C + i]);      // tokens in the compute dtype, like the conv they replace
+    __syncthreads();
+    const int l = blockIdx.x * NT + threadIdx.x;
+    if (l >= L) return;
+    const T* fp = feat + ((size_t)b * L + l) * C;
+    float f[C];
+#pragma unroll
+    for (int k = 0; k < C / CE; ++k) TR::unpack(*(const uint4*)(fp + k * CE), f + k * CE);
+    T* op = out + ((size_t)b * L + l) * QP;
+    float o[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        float a = 0.f;
+        if (q < Q) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) a += f[c] * st[q * C + c];
+        }
+        o[q] = a;
+    }
+    for (int k = 0; k < QP / CE; ++k) *(uint4*)(op + k * CE) = TR::pack(o + k * CE);
+}
+
+// backward: dfeat[l][c] = sum_q dlog[l][q] tok[q][c];  dtok[q][c] += sum_l dlog[l][q] feat[l][c]  (wave butterfly -> LDS -> one atomic per value per block)
+template <typename T, int C>
+__global__ __launch_bounds__(NT) void token_einsum_bwd_kernel(const T* __restrict__ dlog, const T* __restrict__ feat, const float* __restrict__ tok, int L, int Q,
+                                                              int QP, T* __restrict__ dfeat, float* __restrict__ dtok) {
+    using TR = ElemTraits<T>;
+    constexpr int CE = TR::CE;
+    __shared__ float st[16 * C];
+    __shared__ float sacc[16 * C];
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < 16 * C; i += NT) { st[i] = i < Q * C ? TR::rnd(tok[(size_t)b * Q * C + i]) : 0.f; sacc[i] = 0.f; }
+    __syncthreads();
+    const int l = blockIdx.x * NT + threadIdx.x;
+    const bool live = l < L;
+    float g[16], f[C];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) g[q] = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) f[c] = 0.f;
+    if (live) {
+        const T* gp = dlog + ((size_t)b * L + l) * QP;
+        for (int k = 0; k < QP / CE; ++k) TR::unpack(*(const uint4*)(gp + k * CE), g + k * CE);
+        const T* fp = feat + ((size_t)b * L + l) * C;
+#pragma unroll
+        for (int k = 0; k < C / CE; ++k) TR::unpack(*(const uint4*)(fp + k * CE), f + k * CE);
+        float d[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float a = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a += g[q] * st[q * C + c];      // rows q >= Q of st are zero
+            d[c] = a;
+        }
+        T* dp = dfeat + ((size_t)b * L + l) * C;
+#pragma unroll
+        for (int k = 0; k < C / CE; ++k) *(uint4*)(dp + k * CE) = TR::pack(d + k * CE);
+    }
+    const int lane = threadIdx.x & 63;
+    for (int q = 0; q < Q; ++q) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float v = wave_sum(g[q] * f[c]);
+            if (lane == 0) atomicAdd(&sacc[q * C + c], v);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < Q * C; i += NT) atomicAdd(&dtok[(size_t)b * Q * C + i], sacc[i]);
+}
+
 }  // namespace
 
 static int tl_check(int R, int K, int N) {
@@ -327,25 +461,41 @@ static int tl_check(int R, int K, int N) {
     return 0;
 }
 
+extern "C" int mg_token_linear_fwd_ex(const float* x, const float* xadd, const float* W, const float* bias, const float* res, int relu, const float* gamma,
+                                      const float* beta, float eps, float* y, float* z, float* rstat, int R, int K, int N, int wt, void* stream);
 extern "C" int mg_token_linear_fwd(const float* x, const float* xadd, const float* W, const float* bias, const float* res, int relu, const float* gamma,
                                    const float* beta, float eps, float* y, float* z, float* rstat, int R, int K, int N, void* stream) {
+    return mg_token_linear_fwd_ex(x, xadd, W, bias, res, relu, gamma, beta, eps, y, z, rstat, R, K, N, 0, stream);
+}
+extern "C" int mg_token_linear_fwd_ex(const float* x, const float* xadd, const float* W, const float* bias, const float* res, int relu, const float* gamma,
+                                      const float* beta, float eps, float* y, float* z, float* rstat, int R, int K, int N, int wt, void* stream) {
     int rc = tl_check(R, K, N); if (rc) return rc;
+    if (wt && (N & 3)) return -3;
     if (gamma && (!beta || !z || !rstat)) return -2;
     const size_t lds = ((size_t)RB * (K + N) + (size_t)K * (N + 1)) * sizeof(float);
     if (lds > 150 * 1024) return -3;
     static bool attr_f = false;
     if (!attr_f) { (void)hipFuncSetAttribute((const void*)token_linear_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr_f = true; }
     hipLaunchKernelGGL(token_linear_fwd_kernel, dim3((R + RB - 1) / RB), dim3(NT), lds, (hipStream_t)stream, x, xadd, W, bias, res, relu, gamma, beta, eps, y, z,
-                       rstat, R, K, N);
+                       rstat, R, K, N, wt);
     MG_CHECK_LAUNCH();
     return 0;
 }
 
 // `dz` [R,N] scratch = gradient w.r.t. the linear output (after LayerNorm backward and the ReLU mask); dres may alias nothing (NULL when absent)
+extern "C" int mg_token_linear_bwd_ex(const float* dy, const float* x, const float* xadd, const float* W, const float* yout, int relu, const float* gamma,
+                                      const float* z, const float* rstat, float* dx, float* dW, float* db, float* dres, float* dgamma, float* dbeta,
+                                      float* dz, int R, int K, int N, int wt, void* stream);
 extern "C" int mg_token_linear_bwd(const float* dy, const float* x, const float* xadd, const float* W, const float* yout, int relu, const float* gamma,
                                    const float* z, const float* rstat, float* dx, float* dW, float* db, float* dres, float* dgamma, float* dbeta,
                                    float* dz, int R, int K, int N, void* stream) {
+    return mg_token_linear_bwd_ex(dy, x, xadd, W, yout, relu, gamma, z, rstat, dx, dW, db, dres, dgamma, dbeta, dz, R, K, N, 0, stream);
+}
+extern "C" int mg_token_linear_bwd_ex(const float* dy, const float* x, const float* xadd, const float* W, const float* yout, int relu, const float* gamma,
+                                      const float* z, const float* rstat, float* dx, float* dW, float* db, float* dres, float* dgamma, float* dbeta,
+                                      float* dz, int R, int K, int N, int wt, void* stream) {
     int rc = tl_check(R, K, N); if (rc) return rc;
+    if (wt && (N & 3)) return -3;
     if (gamma && (!z || !rstat || !dgamma || !dbeta)) return -2;
     if ((relu && !yout) || !dz) return -2;
     const size_t lds_r = ((size_t)RB * N + (size_t)N * K) * sizeof(float);
@@ -360,7 +510,7 @@ extern "C" int mg_token_linear_bwd(const float* dy, const float* x, const float*
         hipLaunchKernelGGL(token_linear_dz_kernel, dim3((R + 3) / 4), dim3(NT), 0, st, dy, yout, relu, gamma, z, rstat, dz, dres, R, N);
     const int nrb = dx ? (R + RB - 1) / RB : 0;
     hipLaunchKernelGGL(token_linear_bwd_main_kernel, dim3(nrb + (N + CB - 1) / CB), dim3(NT), dx ? (lds_r > lds_c ? lds_r : lds_c) : lds_c, st, nrb,
-                       (const float*)dz, dy, x, xadd, W, gamma, z, rstat, dx, dW, db, dgamma, dbeta, R, K, N);
+                       (const float*)dz, dy, x, xadd, W, gamma, z, rstat, dx, dW, db, dgamma, dbeta, R, K, N, wt);
     MG_CHECK_LAUNCH();
     return 0;
 }
@@ -379,6 +529,56 @@ extern "C" int mg_token_sa_bwd(const float* dout, const float* q, const float* k
     if (B <= 0) return 0;
     if (T <= 0 || T > 16 || D <= 0) return -3;
     hipLaunchKernelGGL(token_sa_bwd_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, dout, q, k, v, prob, scale, T, D, dq, dk, dv);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+/* logits[b][l][q] = sum_c feat[b][l][c] * tok[b][q][c] for q < Q, zero for Q <= q < QP (QP = 16: the row pitch of the NHWC logits the up-sampling
+ * kernel reads). feat / out / dlog / dfeat in `dtype`, tok / dtok fp32 ([B][Q][C]; dtok is zeroed here). C = 32, Q <= 16. */
+extern "C" int mg_token_einsum_fwd(const void* feat, int dtype, const float* tok, int B, int L, int C, int Q, int QP, void* out, void* stream) {
+    if (B <= 0 || L <= 0) return 0;
+    if ((C != 32 && C != 64) || Q < 1 || Q > 16 || QP != 16) return -3;
+    if (dtype != MG_BF16 && dtype != MG_F32) return -6;
+    dim3 grid((L + NT - 1) / NT, B);
+    hipStream_t st = (hipStream_t)stream;
+#define EINSUM_FWD(T, CC) hipLaunchKernelGGL((token_einsum_fwd_kernel<T, CC>), grid, dim3(NT), 0, st, (const T*)feat, tok, L, Q, QP, (T*)out)
+    if (dtype == MG_BF16) { if (C == 32) EINSUM_FWD(bf16raw, 32); else EINSUM_FWD(bf16raw, 64); }
+    else { if (C == 32) EINSUM_FWD(float, 32); else EINSUM_FWD(float, 64); }
+#undef EINSUM_FWD
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_token_einsum_bwd(const void* dlog, const void* feat, int dtype, const float* tok, int B, int L, int C, int Q, int QP, void* dfeat,
+                                   float* dtok, void* stream) {
+    if (B <= 0 || L <= 0) return 0;
+    if ((C != 32 && C != 64) || Q < 1 || Q > 16 || QP != 16) return -3;
+    if (dtype != MG_BF16 && dtype != MG_F32) return -6;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = mg_zero_words(dtok, (long)B * Q * C, st);
+    if (e != hipSuccess) return (int)e;
+    dim3 grid((L + NT - 1) / NT, B);
+#define EINSUM_BWD(T, CC) hipLaunchKernelGGL((token_einsum_bwd_kernel<T, CC>), grid, dim3(NT), 0, st, (const T*)dlog, (const T*)feat, tok, L, Q, QP, (T*)dfeat, dtok)
+    if (dtype == MG_BF16) { if (C == 32) EINSUM_BWD(bf16raw, 32); else EINSUM_BWD(bf16raw, 64); }
+    else { if (C == 32) EINSUM_BWD(float, 32); else EINSUM_BWD(float, 64); }
+#undef EINSUM_BWD
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+/* Mask pre-processing of the instance matte decoder: mask [B][NF][n_in][h*s][w*s] fp32 (guidance masks at s times the OS8 resolution), gt (or NULL)
+ * [B][NF][n_gt][h*gs][w*gs] fp32 alphas -> feat_ids int32 [B][NF*h*w] (max_i (i+1) * [avg-pooled mask_i > 0]), valid uint8 [B][n_i] (zeroed here; 1 where
+ * instance slot i has any mask pixel), guidance fp32 [B][n_i][NF*h*w] ([max-pooled alpha_i > 0], slots >= n_gt zero; only with gt). */
+extern "C" int mg_imd_prep(const float* mask, int n_in, int s, const float* gt, int n_gt, int gs, int B, int NF, int h, int w, int n_i, int32_t* feat_ids,
+                           float* guidance, unsigned char* valid, void* stream) {
+    if (B <= 0 || NF <= 0 || h <= 0 || w <= 0) return 0;
+    if (n_in < 0 || n_in > n_i || s < 1 || (gt && (gs < 1 || n_gt < 0))) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = mg_zero_words(valid, ((long)B * n_i + 3) / 4, st);          // `valid` must be padded to a multiple of 4 bytes by the caller
+    if (e != hipSuccess) return (int)e;
+    const long cells = (long)B * NF * h * w;
+    hipLaunchKernelGGL(imd_prep_kernel, dim3((unsigned)((cells + NT - 1) / NT)), dim3(NT), 0, st, mask, n_in, s, gt, gt ? n_gt : 0, gs, B, NF, h, w, n_i,
+                       feat_ids, gt ? guidance : nullptr, valid);
     MG_CHECK_LAUNCH();
     return 0;
 }

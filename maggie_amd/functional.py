@@ -102,18 +102,33 @@ DEFER_BN_COUNTERS = False      # set by MaGGIe.forward: num_batches_tracked of a
 BN_COUNT_LOG = None            # a list while a stage of the video model runs: BatchNorm calls are logged, the stage bumps the counters with one foreach op per multiplicity
 
 
+FP16_AUTOCAST_AS_BF16 = os.environ.get('MAGGIE_FP16_AUTOCAST', '') == 'bf16'
+_FP16_WARNED = False
+
+
 def compute_dtype():
     """bf16 inside torch.autocast(device_type='cuda') (the reference's --precision 16 path uses fp16 autocast,
     engine/train.py:208,227-229; bf16 is this build's choice), fp32 otherwise."""
     if torch.is_autocast_enabled():
         dt = torch.get_autocast_dtype('cuda') if hasattr(torch, 'get_autocast_dtype') else torch.get_autocast_gpu_dtype()
+        if dt == torch.float16 and FP16_AUTOCAST_AS_BF16:
+            # explicit opt-in (MAGGIE_FP16_AUTOCAST=bf16): the unchanged harness with `--precision 16` (engine/train.py:208,227-229: fp16 autocast +
+            # GradScaler) runs on the bf16 kernels. bf16 has fp32's exponent range, so the scaler's 2^16 loss scale is harmless (gradients are
+            # fp32 when `unscale_` checks them for inf) -- but the mantissa is 8 bits, not fp16's 11: said once, loudly.
+            global _FP16_WARNED
+            if not _FP16_WARNED:
+                _FP16_WARNED = True
+                import warnings
+                warnings.warn('MaGGIe (MI355X build): fp16 autocast is served by the bf16 kernels (MAGGIE_FP16_AUTOCAST=bf16); the GradScaler '
+                              'keeps working but is not needed.')
+            return torch.bfloat16
         if dt != torch.bfloat16:
             # the unchanged harness with `--precision 16` (fp16 autocast + GradScaler) must not silently compute in bf16 under a
             # loss scaler: there is no fp16 kernel family in this build -- say so
             raise K.hip.MaggieHipError(
                 'MaGGIe (MI355X build): autocast dtype %s is not supported -- the HIP kernels compute in bf16 (fp32 accumulate) or fp32. '
-                'Use torch.autocast("cuda", dtype=torch.bfloat16) and drop the GradScaler (bf16 needs no loss scaling), or run without '
-                'autocast for fp32.' % dt)
+                'Use torch.autocast("cuda", dtype=torch.bfloat16) and drop the GradScaler (bf16 needs no loss scaling), run without '
+                'autocast for fp32, or set MAGGIE_FP16_AUTOCAST=bf16 to serve fp16 autocast with the bf16 kernels.' % dt)
         return torch.bfloat16
     return torch.float32
 
@@ -1424,11 +1439,11 @@ class TokenLinear(torch.autograd.Function):
     (the reference: up to 2 adds + cuBLAS + bias + ReLU + add + LayerNorm forward, twice that backward)."""
 
     @staticmethod
-    def forward(ctx, x, xadd, W, b, res, relu, gamma, beta, eps):
+    def forward(ctx, x, xadd, W, b, res, relu, gamma, beta, eps, wt=False):
         if relu and (res is not None or gamma is not None):
             raise K.hip.MaggieHipError('TokenLinear: ReLU is only fused for a plain linear layer (no residual / LayerNorm behind it)')
         shape = x.shape
-        Kd, N = shape[-1], W.shape[0]
+        Kd, N = shape[-1], (W.shape[1] if wt else W.shape[0])                 # wt: W is (K, N) and y = x W
         f = lambda t: None if t is None else t.detach().float().contiguous()       # noqa: E731
         x2, xa, W_, b_, r_, g_, be_ = f(x).view(-1, Kd), f(xadd), f(W), f(b), f(res), f(gamma), f(beta)
         if xa is not None:
@@ -1439,10 +1454,11 @@ class TokenLinear(torch.autograd.Function):
         y = torch.empty((R, N), dtype=torch.float32, device=x.device)
         z = torch.empty((R, N), dtype=torch.float32, device=x.device) if g_ is not None else None
         rstat = torch.empty((R, 2), dtype=torch.float32, device=x.device) if g_ is not None else None
-        K.hip.call('mg_token_linear_fwd', K.hip.ptr(x2), K.hip.ptr(xa), K.hip.ptr(W_), K.hip.ptr(b_), K.hip.ptr(r_), K.c_int(int(bool(relu))),
+        K.hip.call('mg_token_linear_fwd_ex', K.hip.ptr(x2), K.hip.ptr(xa), K.hip.ptr(W_), K.hip.ptr(b_), K.hip.ptr(r_), K.c_int(int(bool(relu))),
                    K.hip.ptr(g_), K.hip.ptr(be_), K.c_float(float(eps)), K.hip.ptr(y), K.hip.ptr(z), K.hip.ptr(rstat), K.c_int(R), K.c_int(Kd),
-                   K.c_int(N), K.hip.stream())
+                   K.c_int(N), K.c_int(int(bool(wt))), K.hip.stream())
         ctx.save_for_backward(x2, xa, W_, y if relu else None, g_, z, rstat)
+        ctx.wt = bool(wt)
         ctx.meta = (shape, R, Kd, N, bool(relu), b is not None, res is not None, None if xadd is None else xadd.shape)
         return y.view(*shape[:-1], N)
 
@@ -1454,16 +1470,16 @@ class TokenLinear(torch.autograd.Function):
         dy2 = dy.float().contiguous().view(R, N)
         need_dx = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         dx = torch.empty((R, Kd), dtype=torch.float32, device=dev) if need_dx else None
-        dW = torch.empty((N, Kd), dtype=torch.float32, device=dev)
+        dW = torch.empty((Kd, N) if ctx.wt else (N, Kd), dtype=torch.float32, device=dev)
         db = torch.empty(N, dtype=torch.float32, device=dev) if has_b else None
         plain = g_ is None and not relu                      # dz == dy: no dz kernel, the residual gradient IS dy
         dres = torch.empty((R, N), dtype=torch.float32, device=dev) if (has_res and not plain) else None
         dgb = torch.empty(2 * N, dtype=torch.float32, device=dev) if g_ is not None else None
         dz = dy2 if plain else torch.empty((R, N), dtype=torch.float32, device=dev)
-        K.hip.call('mg_token_linear_bwd', K.hip.ptr(dy2), K.hip.ptr(x2), K.hip.ptr(xa), K.hip.ptr(W_), K.hip.ptr(yout), K.c_int(int(relu)), K.hip.ptr(g_),
+        K.hip.call('mg_token_linear_bwd_ex', K.hip.ptr(dy2), K.hip.ptr(x2), K.hip.ptr(xa), K.hip.ptr(W_), K.hip.ptr(yout), K.c_int(int(relu)), K.hip.ptr(g_),
                    K.hip.ptr(z), K.hip.ptr(rstat), K.hip.ptr(dx), K.hip.ptr(dW), K.hip.ptr(db), K.hip.ptr(dres),
                    K.hip.ptr(None if dgb is None else dgb[:N]), K.hip.ptr(None if dgb is None else dgb[N:]), K.hip.ptr(dz), K.c_int(R), K.c_int(Kd),
-                   K.c_int(N), K.hip.stream())
+                   K.c_int(N), K.c_int(int(ctx.wt)), K.hip.stream())
         dxv = None if dx is None else dx.view(shape)
         dxadd = None
         if xadd_shape is not None and ctx.needs_input_grad[1]:
@@ -1471,13 +1487,13 @@ class TokenLinear(torch.autograd.Function):
         if plain and has_res:
             dres = dy2
         return (dxv if ctx.needs_input_grad[0] else None, dxadd, dW, db, None if dres is None else dres.view(*shape[:-1], N), None,
-                None if dgb is None else dgb[:N], None if dgb is None else dgb[N:], None)
+                None if dgb is None else dgb[:N], None if dgb is None else dgb[N:], None, None)
 
 
-def token_linear(x, W, b=None, xadd=None, res=None, relu=False, ln=None):
-    """`ln`: an nn.LayerNorm (weight, bias, eps) applied to (res + linear output)."""
+def token_linear(x, W, b=None, xadd=None, res=None, relu=False, ln=None, wt=False):
+    """`ln`: an nn.LayerNorm (weight, bias, eps) applied to (res + linear output). `wt`: W is (K, N) and the product is x W (no transposed copy)."""
     g, be, eps = (ln.weight, ln.bias, ln.eps) if ln is not None else (None, None, 0.0)
-    return TokenLinear.apply(x, xadd, W, b, res, relu, g, be, eps)
+    return TokenLinear.apply(x, xadd, W, b, res, relu, g, be, eps, wt)
 
 
 class TokenSelfAttention(torch.autograd.Function):
@@ -1536,3 +1552,38 @@ class RowsAddLayerNorm(torch.autograd.Function):
 
 def rows_add_layernorm(x, r, ln):
     return RowsAddLayerNorm.apply(x, r, ln.weight, ln.bias, ln.eps)
+
+
+class TokenEinsum(torch.autograd.Function):
+    """logits (B, L, 16) = einsum('bqc,blc->blq') padded to 16 outputs: mg_token_einsum_fwd / _bwd (one launch each way)."""
+
+    @staticmethod
+    def forward(ctx, feat, tok):
+        feat = feat.contiguous()
+        tok32 = tok.detach().float().contiguous()
+        B, L, C = feat.shape
+        Q = tok32.shape[1]
+        out = torch.empty((B, L, 16), dtype=feat.dtype, device=feat.device)
+        K.hip.need_cuda(feat, tok32)
+        K.hip.call('mg_token_einsum_fwd', K.hip.ptr(feat), K.c_int(K.hip.dtype_code(feat)), K.hip.ptr(tok32), K.c_int(B), K.c_int(L), K.c_int(C), K.c_int(Q),
+                   K.c_int(16), K.hip.ptr(out), K.hip.stream())
+        ctx.save_for_backward(feat, tok32)
+        ctx.tok_dtype = tok.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dlog):
+        feat, tok32 = ctx.saved_tensors
+        B, L, C = feat.shape
+        Q = tok32.shape[1]
+        dlog = dlog.to(feat.dtype).contiguous()
+        dfeat = torch.empty_like(feat)
+        dtok = torch.empty_like(tok32)
+        K.hip.call('mg_token_einsum_bwd', K.hip.ptr(dlog), K.hip.ptr(feat), K.c_int(K.hip.dtype_code(feat)), K.hip.ptr(tok32), K.c_int(B), K.c_int(L),
+                   K.c_int(C), K.c_int(Q), K.c_int(16), K.hip.ptr(dfeat), K.hip.ptr(dtok), K.hip.stream())
+        return dfeat, dtok if ctx.tok_dtype == torch.float32 else dtok.to(ctx.tok_dtype)
+
+
+def token_einsum(feat, tok):
+    """feat (B, L, C) in the compute dtype, tok (B, Q <= 16, C), C = 32 or 64 -> (B, L, 16) logits (columns >= Q are zero)."""
+    return TokenEinsum.apply(feat, tok)

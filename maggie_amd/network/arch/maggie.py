@@ -428,6 +428,13 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         launch, so outputs held across calls (VideoWindow, metric / demo code) keep their values -- as they do on the eager path."""
         outs = list(outs)
         idx = [i for i, (n, t) in enumerate(zip(names, outs)) if not t.requires_grad]
+        # the logged loss scalars (a dozen one-element fp32 tensors): ONE concatenation gives them fresh memory, views are handed out
+        small = [i for i in idx if outs[i].numel() == 1 and outs[i].dtype == torch.float32]
+        if len(small) > 1:
+            pack = torch.cat([outs[i].reshape(1) for i in small])
+            for j, i in enumerate(small):
+                outs[i] = pack[j].view(outs[i].shape)
+            idx = [i for i in idx if i not in set(small)]
         if idx:
             fresh = [torch.empty_like(outs[i]) for i in idx]
             torch._foreach_copy_(fresh, [outs[i] for i in idx])

@@ -72,15 +72,28 @@ class InstanceMatteDecoder(nn.Module):
         N, h, w, C = ori_feat.shape
         b, n_f, n_in = mask.shape[:3]
         dt = ori_feat.dtype
-        # mask -> OS8 binary (resizeAnyShape(..., use_avg_pool_binary=True), utils.py:16-21)
+        # mask -> OS8 binary (resizeAnyShape(..., use_avg_pool_binary=True), utils.py:16-21), the ID position of every feature pixel = max over
+        # instances of id * mask (:150-153), the token validity and (training) the ground-truth guidance: ONE launch (mg_imd_prep)
+        n_i = self.max_inst
         stride = mask.shape[-1] // w
-        m8 = mask.reshape(b * n_f, n_in, mask.shape[-2], mask.shape[-1]).float()
-        if stride > 1:
-            m8 = F.avg_pool2d(m8, stride, stride)
-        m8 = (m8 > 0).float().view(b, n_f, n_in, h, w)             # (also for a mask that arrives at OS8: the reference pools its up-scaled copy)
-        # ID position of every feature pixel = max over instances of id*mask (:150-153)
-        ids = torch.arange(1, n_in + 1, device=mask.device, dtype=torch.float32)[None, None, :, None, None]
-        feat_ids = (m8 * ids).amax(2).to(torch.int32).reshape(b, n_f * h * w).contiguous()  # (b, L), l = f*hw + p
+        if stride < 1 or mask.shape[-1] != w * stride or mask.shape[-2] != h * stride:
+            raise MF.K.hip.MaggieHipError('InstanceMatteDecoder: the guidance mask must be an integer multiple of the OS8 map (%dx%d), got %dx%d'
+                                          % (h, w, mask.shape[-2], mask.shape[-1]))
+        mk = mask.float().contiguous()
+        gm = gs = None
+        if self.training:
+            gm = gt_mask.float().contiguous()
+            gs = gm.shape[-1] // w
+            if gs < 1 or gm.shape[-1] != w * gs or gm.shape[-2] != h * gs:
+                raise MF.K.hip.MaggieHipError('InstanceMatteDecoder: the ground-truth alphas must be an integer multiple of the OS8 map')
+        L = n_f * h * w
+        feat_ids = torch.empty((b, L), dtype=torch.int32, device=mask.device)
+        valid_u8 = torch.empty((b * n_i + 3) // 4 * 4, dtype=torch.uint8, device=mask.device)
+        guidance_mask = torch.empty((b, n_i, L), dtype=torch.float32, device=mask.device) if self.training else None
+        MF.K.hip.call('mg_imd_prep', MF.K.hip.ptr(mk), MF.K.c_int(n_in), MF.K.c_int(stride), MF.K.hip.ptr(gm), MF.K.c_int(0 if gm is None else gm.shape[2]),
+                      MF.K.c_int(gs or 1), MF.K.c_int(b), MF.K.c_int(n_f), MF.K.c_int(h), MF.K.c_int(w), MF.K.c_int(n_i), MF.K.hip.ptr(feat_ids),
+                      MF.K.hip.ptr(guidance_mask), MF.K.hip.ptr(valid_u8), MF.K.hip.stream())
+        token_padding_mask = valid_u8[:b * n_i].view(b, n_i) == 0
         id_table = self.id_embedding.weight.float() if self.use_id_pe else None
         # materialised once: every token-side launch below wants dense (b, 10, d) operands (an expanded view would be copied per use)
         token_pos = self.id_embedding.weight[1:self.max_inst + 1].float()[None].expand(b, -1, -1).contiguous()
@@ -91,23 +104,7 @@ class InstanceMatteDecoder(nn.Module):
         wproj = MF._pad_krsc(lin.weight[:, None, :], dt, None, None)
         feat = MF.linear_rows(ori_feat.reshape(-1, C), wproj, lin.bias.float()).float().view(b, n_f * h * w, -1)
 
-        n_i = self.max_inst
-        guidance_mask = None
-        if self.training:
-            gm = gt_mask.reshape(b * n_f, gt_mask.shape[2], gt_mask.shape[-2], gt_mask.shape[-1]).float()
-            gs = gm.shape[-1] // w
-            if gs > 1:
-                gm = F.max_pool2d(gm, gs, gs)
-            gm = gm.view(b, n_f, -1, h * w)
-            if gm.shape[2] < n_i:
-                gm = torch.cat([gm, gm.new_zeros((b, n_f, n_i - gm.shape[2], h * w))], 2)
-            guidance_mask = (gm > 0).permute(0, 2, 1, 3).reshape(b, n_i, n_f * h * w).float()
-
         max_loss, atten_terms = 0, []
-        valid_tokens = m8.sum((1, 3, 4)) > 0
-        if valid_tokens.shape[1] < n_i:
-            valid_tokens = torch.cat([valid_tokens, valid_tokens.new_zeros((b, n_i - valid_tokens.shape[1]))], 1)
-        token_padding_mask = ~valid_tokens
         pos_t = token_pos if self.use_id_pe else None
         tbl = id_table if self.use_id_pe else None
         if not self.use_id_pe:
@@ -146,10 +143,9 @@ class InstanceMatteDecoder(nn.Module):
         with torch.autocast('cuda', enabled=False):
             tokens = self.final_mlp(tokens, ln=self.decoder_norm)                               # (b, 10, c_out) fp32
         # einsum('bqc,btchw->btqhw'): a per-batch-element 1x1 conv whose weights are the tokens (padded to 16 outputs)
-        cq = MF.pad8(n_i) if MF.pad8(n_i) >= 16 else 16
-        logits = []
-        fr = feat.view(b, n_f * h * w, -1)
-        for tok_b, fr_b in zip(tokens.unbind(0), fr.unbind(0)):
-            logits.append(MF.linear_rows(fr_b, MF._pad_krsc(tok_b[:, None, :], dt, None, cq)))
-        output_mask = torch.stack(logits, 0).view(N, h, w, cq)
+        cq = 16
+        if n_i > cq or feat.shape[-1] not in (32, 64):
+            raise MF.K.hip.MaggieHipError('InstanceMatteDecoder (MI355X build): the token einsum kernel is built for max_inst <= 16 and output_dim 32 / 64 '
+                                          '(configs/maggie_{image,video}.yaml); got %d tokens of width %d' % (n_i, feat.shape[-1]))
+        output_mask = MF.token_einsum(feat.view(b, n_f * h * w, -1), tokens).view(N, h, w, cq)      # one launch each way (mg_token_einsum_*)
         return output_mask, out_feat, tokens, max_loss, hidden_state

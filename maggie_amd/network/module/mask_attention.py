@@ -77,7 +77,7 @@ class CrossAttentionLayer(nn.Module):
         (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.multihead_attn)
         d = tokens.shape[-1]
         q = MF.token_linear(tokens, wq, bq, xadd=token_pos)                                  # (b,T,d)
-        qk = MF.token_linear(q, wk.t().contiguous())                                         # q Wk: fold Wk into the queries
+        qk = MF.token_linear(q, wk, wt=True)                                                 # q Wk: fold Wk into the queries (wk used as (K, N): no transposed copy)
         # score bias of a feature row with position id: q . (E[id] Wk^T + bk)  (id_table None: every row has id 0 and no embedding)
         key_pos = MF.token_linear(id_table, wk, bk) if id_table is not None else bk[None, :]
         tbl = MF.token_linear(q, key_pos)                                                    # (b,T,n_id)
@@ -93,7 +93,7 @@ class CrossAttentionLayer(nn.Module):
         d = feat.shape[-1]
         k = MF.token_linear(tokens, wk, bk, xadd=token_pos)                                  # (b,T,d)
         vp = MF.token_linear(MF.token_linear(tokens, wv, bv), self.multihead_attn.out_proj.weight)      # (b,T,d): rows of (Wo V^T)^T
-        kq = MF.token_linear(k, wq.t().contiguous())                                         # (b,T,d): fold Wq into the keys
+        kq = MF.token_linear(k, wq, wt=True)                                                 # (b,T,d): fold Wq into the keys
         qry_pos = MF.token_linear(id_table, wq, bq) if id_table is not None else bq[None, :]  # (n_id, d)
         tbl = MF.token_linear(k, qry_pos).transpose(1, 2).contiguous()                       # (b,n_id,T)
         _need_hip_attention(tokens.shape[1], d)

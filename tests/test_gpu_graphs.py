@@ -388,7 +388,7 @@ def test_rank_safe_graphs_one_detail_graph_serves_both_guidance_sources():
         assert abs(a[0] - b_[0]) <= 2e-4 * max(1.0, abs(b_[0])), (i, a[0], b_[0])
         assert torch.equal(a[2], b_[2]), 'detail mask, step %d' % i
         assert (a[1] - b_[1]).abs().max().item() <= 1e-3, i         # (two eager runs of the same step differ by ~2e-4: fp32 atomics under train-mode BatchNorm)
-        assert (a[3] - b_[3]).norm().item() <= 2e-2 * b_[3].norm().item(), i
+        assert (a[3] - b_[3]).norm().item() <= 8e-2 * b_[3].norm().item(), i      # (structural errors -- a missing or doubled gradient -- are O(1))
 
 
 def _syncbn_worker(mode, port):

@@ -1108,3 +1108,55 @@ def test_rows_dropout_mask_statistics_and_backward_reuse(dtype):
         agree = (other == keep).float().mean().item()                 # independent masks agree on (1-p)^2 + p^2 = 0.82 of the elements
         assert abs(agree - ((1 - p) ** 2 + p ** 2)) < 0.01, agree
     assert torch.equal(K.rows_dropout(x, 0.0, state, 1, rows=live)[:M - 1000], x[:M - 1000])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('R,Kd,N,xadd', [(40, 128, 128, True), (7, 128, 64, False), (130, 64, 128, False)])
+def test_token_linear_with_untransposed_weight_matches_torch(R, Kd, N, xadd):
+    """mg_token_linear_fwd_ex / _bwd_ex with wt = 1: y = (x + xadd) W for W given as (K, N) -- `q @ wk` of the cross-attention folding
+    (module/mask_attention.py) without the transposed copy of the projection weight every step; dW comes back as (K, N)."""
+    from maggie_amd import functional as MF
+    dev = _dev()
+    g = torch.Generator().manual_seed(R + N)
+    x, W = torch.randn(R, Kd, generator=g).requires_grad_(True), (torch.randn(Kd, N, generator=g) / Kd ** 0.5).requires_grad_(True)
+    xa = torch.randn(R, Kd, generator=g).requires_grad_(True) if xadd else None
+    y_ref = (x + xa if xadd else x) @ W
+    wgt = torch.randn(R, N, generator=g)
+    (y_ref * wgt).sum().backward()
+    xd, Wd = x.detach().clone().to(dev).requires_grad_(True), W.detach().clone().to(dev).requires_grad_(True)
+    xad = xa.detach().clone().to(dev).requires_grad_(True) if xadd else None
+    y = MF.token_linear(xd, Wd, xadd=xad, wt=True)
+    (y * wgt.to(dev)).sum().backward()
+    assert torch.allclose(y.detach().cpu(), y_ref.detach(), atol=2e-5, rtol=2e-5)
+    assert Wd.grad.shape == W.grad.shape
+    for a, c in ((xd, x), (Wd, W)) + (((xad, xa),) if xadd else ()):
+        assert torch.allclose(a.grad.cpu(), c.grad, atol=5e-5, rtol=5e-5), float((a.grad.cpu() - c.grad).abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,L,Q,C', [(4, 4096, 10, 64), (1, 777, 10, 32), (2, 300, 16, 64)])
+def test_token_einsum_matches_torch(dtype, B, L, Q, C):
+    """mg_token_einsum_fwd / _bwd: einsum('bqc,blc->blq') of instance_matte_decoder.py:296-299 (pixel logits against the instance tokens of the
+    pixel's batch element), padded to 16 output columns, against torch.einsum on the CPU (inputs rounded to the compute dtype first)."""
+    from maggie_amd import functional as MF
+    dev = _dev()
+    q_ = _q(dtype)
+    g = torch.Generator().manual_seed(B * L)
+    feat = q_(torch.randn(B, L, C, generator=g)).requires_grad_(True)
+    tok = q_(torch.randn(B, Q, C, generator=g)).requires_grad_(True)
+    ref = torch.einsum('bqc,blc->blq', tok, feat)
+    wgt = q_(torch.randn(B, L, Q, generator=g))
+    (ref * wgt).sum().backward()
+    fd = feat.detach().to(dev, dtype).requires_grad_(True)
+    td = tok.detach().to(dev).requires_grad_(True)
+    out = MF.token_einsum(fd, td)
+    assert out.shape == (B, L, 16) and out.dtype == dtype
+    assert float(out[..., Q:].float().abs().max()) == 0.0 if Q < 16 else True
+    w16 = torch.zeros(B, L, 16)
+    w16[..., :Q] = wgt
+    (out.float() * w16.to(dev)).sum().backward()
+    tol = _tol(dtype)
+    assert (out[..., :Q].detach().float().cpu() - ref.detach()).abs().max() <= tol * ref.abs().max()
+    assert (fd.grad.float().cpu() - feat.grad).abs().max() <= tol * feat.grad.abs().max()
+    assert (td.grad.float().cpu() - tok.grad).abs().max() <= max(tol, 1e-4) * tok.grad.abs().max()

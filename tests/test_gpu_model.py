@@ -403,3 +403,53 @@ def test_video_consecutive_windows_with_prev_pred_match_oracle():
     got, want = torch.cat(stitched, 1), torch.cat(ref_stitched, 1)
     assert got.shape == want.shape and got.shape[1] >= 4, got.shape                     # every frame of the clip reaches the saving callback
     assert float(((got - want).abs() > ALPHA_TOL).float().mean()) <= 5e-4
+
+
+def test_fp16_autocast_opt_in_runs_the_unchanged_harness_recipe():
+    """INTEGRATION.md section 1 / VERDICT round 2 next #7 (the cheap half): the reference's `--precision 16` recipe (engine/train.py:208,227-229,265-281:
+    fp16 autocast, GradScaler.scale(loss).backward(), unscale_, clip 0.01, scaler.step, scaler.update) runs unchanged when the caller opts in with
+    MAGGIE_FP16_AUTOCAST=bf16 -- on the bf16 kernels, results equal to a bf16-autocast run of the same steps -- and raises loudly without the opt-in."""
+    import warnings
+    from maggie_amd import functional as MF
+    from maggie_amd.hip import MaggieHipError
+    from maggie_amd.utils import synth
+    dev = _dev()
+    batch = _to(synth.synthetic_batch(2, 1, 2, 64, 64, seed=DSEED, train=True, max_inst=10, it=100), dev)
+
+    def steps(dtype, scaler_on):
+        model, _ = _build('image', dev, True)
+        model.decoder.inst_spec_layer.dropout.p = 0.0
+        model.hip_graphs = False
+        opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-5)
+        scaler = torch.amp.GradScaler('cuda', enabled=scaler_on)
+        losses = []
+        for i in range(3):
+            seed_all(50 + i)
+            opt.zero_grad()
+            with torch.autocast('cuda', dtype=dtype):
+                out, loss = model(batch)
+            scaler.scale(loss['total']).backward()
+            scaler.unscale_(opt)
+            torch.nn.utils.clip_grad_norm_(model.parameters(), 0.01)
+            scaler.step(opt)
+            scaler.update()
+            losses.append(float(loss['total']))
+        return losses, scaler.get_scale() if scaler_on else None
+
+    prev = MF.FP16_AUTOCAST_AS_BF16
+    try:
+        MF.FP16_AUTOCAST_AS_BF16 = False
+        with pytest.raises(MaggieHipError):
+            steps(torch.float16, True)
+        MF.FP16_AUTOCAST_AS_BF16 = True
+        MF._FP16_WARNED = False
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            l16, scale = steps(torch.float16, True)
+        assert any('bf16 kernels' in str(x.message) for x in w)
+        lbf, _ = steps(torch.bfloat16, False)
+    finally:
+        MF.FP16_AUTOCAST_AS_BF16 = prev
+    assert all(np.isfinite(v) for v in l16) and scale == 65536.0          # no step was skipped: the scale never backed off
+    for a, b in zip(l16, lbf):
+        assert abs(a - b) <= 0.15 * abs(b), (l16, lbf)                    # same kernels; two bf16 runs of this tiny train-mode-BatchNorm problem differ by up to ~10 % (tests/test_gpu_graphs.py uses the same floor)
