@@ -34,6 +34,9 @@ extern "C" {
 #define MG_MODE_GATHER 2 /* src(m,tap) = nbr[m*taps + tap]  (-1 = no neighbour): sparse convolutions               */
 
 int mg_abi_version(void);
+/* Declare [base, base + bytes) zero-filled with every part handed to at most one accumulator (NULL, 0: no such range). Entry points that clear an
+ * accumulator with a fill launch of their own skip it for buffers inside the range -- the host's per-graph zero arena (one memset node per replay). */
+int mg_set_zeroed_range(void* base, long bytes);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution (MFMA):  Y[m, yoff+co] = epi( sum_{tap,ci} X[src(m,tap), ci] * W[co, tap, ci] )

@@ -97,8 +97,14 @@ static __global__ void mg_zero_words_kernel(uint32_t* __restrict__ p, long n) {
     const long step = (long)gridDim.x * blockDim.x;
     for (; i < n; i += step) p[i] = 0u;
 }
+// Accumulators carved from a buffer the caller has ALREADY zeroed (the per-graph zero arena: one memset node at the head of every replay,
+// maggie_amd/functional.py ZeroArena) need no fill launch of their own: the host registers the arena's address range
+// (mg_set_zeroed_range) and promises to hand every slice out once. ~60 fill launches of ~4.7 us per step disappear from the captured graphs.
+extern "C" char* mg_zeroed_lo;
+extern "C" char* mg_zeroed_hi;
 static inline hipError_t mg_zero_words(void* p, long n_words, hipStream_t st) {
     if (n_words <= 0) return hipSuccess;
+    if ((char*)p >= mg_zeroed_lo && (char*)p + 4 * n_words <= mg_zeroed_hi) return hipSuccess;
     long blocks = (n_words + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(mg_zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint32_t*)p, n_words);

@@ -308,11 +308,11 @@ __global__ __launch_bounds__(NT) void upsample_tanh_bwd_kernel(const float* __re
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
         float g = dout[i];
         if (apply_tanh) { float t = 2.f * out[i] - 1.f; g *= 0.5f * (1.f - t * t); }
-        if (g == 0.f) continue;
         int X = (int)(i % W); long r = i / W; int Y = (int)(r % H); r /= H; int c = (int)(r % C); int n = (int)(r / C);
-        if (pscale && pscale[n * C + c] == 0.f) continue;                     // a 0 / 1 plane scale: masked planes pass no gradient
+        if (pscale && pscale[n * C + c] == 0.f) g = 0.f;                      // a 0 / 1 plane scale: masked planes pass no gradient
         float* base = din + n * sn + c * sc;
-        if (scale == 1) { base[Y * sy + X * sx] += g; continue; }             // one writer per element
+        if (scale == 1) { base[Y * sy + X * sx] = g; continue; }              // one writer per element: plain store, no pre-zeroed buffer needed
+        if (g == 0.f) continue;
         int y0, y1, x0, x1; float ly, lx;
         bil_src(Y, scale, h, y0, y1, ly);
         bil_src(X, scale, w, x0, x1, lx);
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(NT) void upsample_tanh_bwd_tile_kernel(const float*
     }
     acc += __shfl_xor(acc, 1, 64);
     acc += __shfl_xor(acc, 2, 64);
-    if (part == 0) din[n * sn + c * sc + ys * sy + xs * sx] += acc;
+    if (part == 0) din[n * sn + c * sc + ys * sy + xs * sx] = acc;            // one writer per element: no pre-zeroed buffer needed for the planes it covers
 }
 
 }  // namespace

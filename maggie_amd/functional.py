@@ -52,9 +52,27 @@ class ZeroArena:
         """Called by the graph builder right after capture starts (forward graph and backward graph each get their own)."""
         self.cap_buf = torch.zeros(max(self.need, 1 << 20), dtype=torch.float32, device=device)
         self.cap_off = 0
+        # the library skips its own fill launches for accumulators inside this (zeroed once per replay) buffer: csrc/common.h mg_zero_words
+        K.hip.lib().mg_set_zeroed_range(K.ctypes.c_void_p(self.cap_buf.data_ptr()), K.ctypes.c_long(4 * self.cap_buf.numel()))
 
     def end_capture(self):
         self.cap_buf = None
+        K.hip.lib().mg_set_zeroed_range(None, K.ctypes.c_long(0))
+
+    def acc(self, n, device, dtype=torch.float32):
+        """An accumulator of n 4-byte words the callee will clear itself: inside a capture a slice of the graph's zero arena (the callee's fill
+        launch is then skipped, mg_set_zeroed_range), else fresh uninitialised memory."""
+        if self.cap_buf is not None and torch.cuda.is_current_stream_capturing():
+            v = self.take(n, device)
+            return v if dtype == torch.float32 else v.view(dtype)
+        return torch.empty(n, dtype=dtype, device=device)
+
+    def zeros(self, n, device, dtype=torch.float32):
+        """Zero-initialised scratch of n 4-byte words: an arena slice inside a capture, torch.zeros otherwise."""
+        if self.cap_buf is not None and torch.cuda.is_current_stream_capturing():
+            v = self.take(n, device)
+            return v if dtype == torch.float32 else v.view(dtype)
+        return torch.zeros(n, dtype=dtype, device=device)
 
     def take(self, n, device):
         n_al = (n + 63) // 64 * 64
@@ -87,6 +105,7 @@ def flush_bn_count_log(log):
 
 
 ARENA = ZeroArena()
+K.ACC = ARENA.acc                 # kernels.py allocates the accumulators its callees clear through the arena (no fill launch inside a capture)
 CAPTURE_FIXUPS = []            # (slice of CAPTURE_TABLE, host tensor to upload once the capture has ended)
 CAPTURE_TABLE = [None, 0]      # [int64 device buffer owned by the graph being captured, bump offset]
 
@@ -978,7 +997,7 @@ class UpsampleTanh(torch.autograd.Function):
             N, _, h, w = x.shape
             strides = (C * h * w, h * w, w, 1)
         ps = None if pscale is None else pscale.detach().float().reshape(-1).contiguous()
-        flag = torch.zeros(1, dtype=torch.int32, device=x.device) if want_flag else None
+        flag = ARENA.zeros(1, x.device, torch.int32) if want_flag else None
         out = K.upsample_tanh(x, strides, N, C, h, w, scale, apply_tanh, ps, flag)
         ctx.save_for_backward(out, ps)
         ctx.meta = (x.shape, x.dtype, strides, N, C, h, w, scale, apply_tanh)
@@ -991,7 +1010,10 @@ class UpsampleTanh(torch.autograd.Function):
     def backward(ctx, dout, _dflag=None):
         out, ps = ctx.saved_tensors
         xshape, xdtype, strides, N, C, h, w, scale, apply_tanh = ctx.meta
-        din = torch.zeros(xshape, dtype=torch.float32, device=dout.device)
+        # scale 1 and the tiled x4 / x8 kernels write every element of the C planes exactly once: only padded NHWC channels (and the atomic
+        # fallback of other scales) need a zeroed buffer -- the OS1 planes alone were a 42 MB fill per step
+        covers = (scale == 1 or (scale in (4, 8) and h % 8 == 0 and w % 8 == 0)) and (len(xshape) != 4 or strides[1] != 1 or xshape[-1] == C)
+        din = (torch.empty if covers else torch.zeros)(xshape, dtype=torch.float32, device=dout.device)
         K.upsample_tanh_bwd(dout.contiguous(), out, strides, N, C, h, w, scale, din, apply_tanh, ps)
         return din.to(xdtype), None, None, None, None, None, None
 
@@ -1085,9 +1107,9 @@ class MattingLosses(torch.autograd.Function):
         dev = p.device
         hipc, c_int = K.hip.call, K.c_int
         ptr, st = K.hip.ptr, K.hip.stream
-        flags = torch.empty(P, dtype=torch.int32, device=dev)
+        flags = ARENA.acc(P, dev, torch.int32)
         hipc('mg_plane_flags', ptr(w), c_int(P), c_int(H * W_), ptr(flags), st())
-        sums = torch.zeros(32 * 16, dtype=torch.float32, device=dev)    # 32 replicas x [l1, grad, w, lap0, w0, lap1, w1, lap2, w2, pad]: see mg_loss_finish
+        sums = ARENA.zeros(32 * 16, dev)                                # 32 replicas x [l1, grad, w, lap0, w0, lap1, w1, lap2, w2, pad]: see mg_loss_finish
         d = torch.empty((P, H, W_), dtype=torch.float32, device=dev)
         if pvalid is not None:
             assert pvalid.dtype == torch.int32 and pvalid.numel() == P and pvalid.is_contiguous()
@@ -1578,7 +1600,7 @@ class TokenEinsum(torch.autograd.Function):
         Q = tok32.shape[1]
         dlog = dlog.to(feat.dtype).contiguous()
         dfeat = torch.empty_like(feat)
-        dtok = torch.empty_like(tok32)
+        dtok = ARENA.acc(tok32.numel(), tok32.device).view_as(tok32)
         K.hip.call('mg_token_einsum_bwd', K.hip.ptr(dlog), K.hip.ptr(feat), K.c_int(K.hip.dtype_code(feat)), K.hip.ptr(tok32), K.c_int(B), K.c_int(L),
                    K.c_int(C), K.c_int(Q), K.c_int(16), K.hip.ptr(dfeat), K.hip.ptr(dtok), K.hip.stream())
         return dfeat, dtok if ctx.tok_dtype == torch.float32 else dtok.to(ctx.tok_dtype)

@@ -38,6 +38,14 @@ class _Replay(torch.autograd.Function):
         return outs
 
     @staticmethod
+    def mark_static(outs):
+        """Outputs of a replay live at fixed addresses for the life of the graph: a graph captured downstream may take them as its static
+        inputs in place (GraphedCallable.__init__: no per-step copy of the trunk's features into the detail graph)."""
+        for o in outs:
+            o._mg_static = True
+        return outs
+
+    @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, *grads):
         g = ctx.g
@@ -110,7 +118,10 @@ class GraphedCallable:
         self.sink_views = None
         self.sink_runs = None
         self.grad_idx = [i for i in grad_inputs if training and inputs[i].is_floating_point()]
-        self.static_inputs = [i.detach().clone() for i in inputs]
+        # an input that is another graph's static output (marked by _Replay.mark_static) is adopted in place: it has the same address on every
+        # step, so __call__ finds nothing to copy (the trunk graph's outputs -- 135 MB of features and the 42 MB coarse alpha at the headline
+        # geometry -- were copied into the detail graph's own input buffers every step)
+        self.static_inputs = [i.detach() if getattr(i, '_mg_static', False) else i.detach().clone() for i in inputs]
         for i in self.grad_idx:
             self.static_inputs[i].requires_grad_(True)
         gin = [self.static_inputs[i] for i in self.grad_idx]
@@ -257,6 +268,6 @@ class GraphedCallable:
             with torch.no_grad():                                 # static inputs the graph differentiates through are leaves that require grad
                 torch._foreach_copy_(dst, src)
         if self.training:
-            return _Replay.apply(self, *[inputs[i] for i in self.grad_idx], *self.params)
+            return _Replay.mark_static(_Replay.apply(self, *[inputs[i] for i in self.grad_idx], *self.params))
         self.fwd.replay()
-        return tuple(o.detach() for o in self.static_outputs)
+        return _Replay.mark_static(tuple(o.detach() for o in self.static_outputs))

@@ -174,6 +174,11 @@ from .hip import RowwiseParams, c_int, c_float, c_long  # noqa: E402
 STAT_REPLICAS = 32
 
 
+def ACC(n, device, dtype=torch.float32):
+    """Accumulator the callee clears itself; functional.py re-points this at its zero arena (ZeroArena.acc)."""
+    return torch.empty(n, dtype=dtype, device=device)
+
+
 def colstats(x, stats=None):
     """stats[STAT_REPLICAS][2C] (fp32) += column sum / sum of squares of x (M, C), spread over replicas."""
     M, C = x.shape[0], x.shape[-1]
@@ -189,7 +194,7 @@ def bias_act_bwd(dy, y, want_db, rows=None):
     `rows`: device row count (int32 tensor), dy.shape[0] is then the capacity."""
     M, C = dy.shape
     g = torch.empty_like(dy) if y is not None else dy
-    db = torch.empty(C, dtype=torch.float32, device=dy.device) if want_db else None
+    db = ACC(C, dy.device) if want_db else None
     hip.call('mg_bias_act_bwd_dev', hip.ptr(dy), hip.ptr(y), hip.ptr(g if y is not None else None), c_int(hip.dtype_code(dy)), c_int(M), c_int(C),
              hip.ptr(db), hip.ptr(rows), hip.stream())
     return g, db
@@ -560,7 +565,7 @@ def plane_flags(planes):
     """int32 [P]: 1 where a (.., H, W) fp32 plane holds any value > 0 (mg_plane_flags)."""
     H, W = planes.shape[-2:]
     P = planes.numel() // (H * W)
-    flags = torch.empty(P, dtype=torch.int32, device=planes.device)
+    flags = ACC(P, planes.device, torch.int32)
     hip.need_cuda(planes)
     assert planes.dtype == torch.float32 and planes.is_contiguous()
     hip.call('mg_plane_flags', hip.ptr(planes), c_int(P), c_int(H * W), hip.ptr(flags), hip.stream())
@@ -605,7 +610,7 @@ def attn_tok_fwd(qk, btab, feat, ids, scale):
     B, L, D = feat.shape
     T, NID = qk.shape[1], btab.shape[2]
     p = torch.empty((B, T, L), dtype=torch.float32, device=feat.device)
-    ctx = torch.empty((B, T, D), dtype=torch.float32, device=feat.device)
+    ctx = ACC(B * T * D, feat.device).view(B, T, D)
     hip.call('mg_attn_tok_fwd', hip.ptr(qk), hip.ptr(btab), hip.ptr(feat), hip.ptr(ids), c_int(B), c_int(T), c_int(L), c_int(D), c_int(NID),
              c_float(scale), hip.ptr(p), hip.ptr(ctx), hip.stream())
     return p, ctx
@@ -617,7 +622,7 @@ def attn_tok_bwd(p, feat, qk, ids, dctx, dp, scale, NID):
     dev = feat.device
     gbuf = torch.empty((B, T, L), dtype=torch.float32, device=dev)
     # the three atomic accumulators are carved from ONE buffer: the C side zeroes adjacent buffers with a single fill launch
-    acc = torch.empty(B * T * (1 + D + NID), dtype=torch.float32, device=dev)
+    acc = ACC(B * T * (1 + D + NID), dev)
     rowdot = acc[:B * T].view(B, T)
     dqk = acc[B * T:B * T * (1 + D)].view(B, T, D)
     dbtab = acc[B * T * (1 + D):].view(B, T, NID)
@@ -645,7 +650,7 @@ def attn_feat_bwd(dout, p, feat, kq, vp, ids, scale, NID, want_bias):
     dev = feat.device
     dfeat = torch.empty((B, L, D), dtype=torch.float32, device=dev)
     n1, n2 = B * T * D, B * NID * T
-    acc = torch.empty(2 * n1 + n2 + (D if want_bias else 0), dtype=torch.float32, device=dev)      # one buffer, one fill launch (see attn_tok_bwd)
+    acc = ACC(2 * n1 + n2 + (D if want_bias else 0), dev)                                           # one buffer, one fill launch (see attn_tok_bwd)
     dkq = acc[:n1].view(B, T, D)
     dvp = acc[n1:2 * n1].view(B, T, D)
     db2 = acc[2 * n1:2 * n1 + n2].view(B, NID, T)
@@ -754,7 +759,7 @@ def rows_add_layernorm_bwd(dy, x, r, gamma, rstat, rows=None):
     """-> dz (gradient of both x and r), dgamma, dbeta (fp32 [C])."""
     M, C = x.shape
     dz = torch.empty_like(x)
-    dgb = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    dgb = ACC(2 * C, x.device)
     hip.call('mg_rows_add_layernorm_bwd', hip.ptr(dy), hip.ptr(x), hip.ptr(r), hip.ptr(gamma), hip.ptr(rstat), hip.ptr(dz), hip.ptr(dgb[:C]),
              hip.ptr(dgb[C:]), c_int(hip.dtype_code(x)), c_int(M), c_int(C), hip.ptr(rows), hip.stream())
     return dz, dgb[:C], dgb[C:]

@@ -288,8 +288,7 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
                 self._prepare_spectral_norm('detail')
         if not isinstance(out, list):
             out = list(out)
-        if from_graph:
-            out[0] = out[0].clone()                               # alpha_os8 is handed to the caller: never alias graph memory
+        self.__dict__['_trunk_replayed'] = bool(from_graph)       # _run_detail: outputs of an EAGER detail stage may alias the trunk graph's buffers
         if not has_hidden:
             out.insert(4, None)
         return tuple(out)
@@ -413,6 +412,10 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             return store[names_key], self._own_outputs(store[names_key], outs)
         outs = fn(*inputs)
         store[names_key] = fn.names
+        if self.__dict__.get('_trunk_replayed'):
+            # eager detail stage on a replayed trunk (the first two sightings of a geometry): what it passes through (alpha_os8, the recurrent
+            # feature) is the trunk graph's own memory -- the caller gets private copies, as from a replayed detail graph
+            outs = tuple(o.clone() if (getattr(o, '_mg_static', False) or any(o.data_ptr() == d.data_ptr() for d in dense)) else o for o in outs)
         return fn.names, outs
 
     def _detail_key(self, geom, static_plan, inputs):

@@ -88,7 +88,7 @@ class InstanceMatteDecoder(nn.Module):
                 raise MF.K.hip.MaggieHipError('InstanceMatteDecoder: the ground-truth alphas must be an integer multiple of the OS8 map')
         L = n_f * h * w
         feat_ids = torch.empty((b, L), dtype=torch.int32, device=mask.device)
-        valid_u8 = torch.empty((b * n_i + 3) // 4 * 4, dtype=torch.uint8, device=mask.device)
+        valid_u8 = MF.ARENA.acc((b * n_i + 3) // 4, mask.device).view(torch.uint8)               # zeroed by the callee (or the graph's zero arena)
         guidance_mask = torch.empty((b, n_i, L), dtype=torch.float32, device=mask.device) if self.training else None
         MF.K.hip.call('mg_imd_prep', MF.K.hip.ptr(mk), MF.K.c_int(n_in), MF.K.c_int(stride), MF.K.hip.ptr(gm), MF.K.c_int(0 if gm is None else gm.shape[2]),
                       MF.K.c_int(gs or 1), MF.K.c_int(b), MF.K.c_int(n_f), MF.K.c_int(h), MF.K.c_int(w), MF.K.c_int(n_i), MF.K.hip.ptr(feat_ids),
