@@ -82,6 +82,8 @@ def main():
         dist.init_process_group('nccl')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    if os.environ.get('MAGGIE_MEM_FRACTION'):                 # a bound on the caching allocator: an over-sized configuration raises instead of taking the box down
+        torch.cuda.set_per_process_memory_fraction(float(os.environ['MAGGIE_MEM_FRACTION']), dev)
 
     from maggie_amd.network import build_model
     from maggie_amd.utils import config, synth
@@ -308,7 +310,7 @@ def main():
                                                                 if args.workload == 'gt' else 'detail region from the predicted coarse alpha: drifts with the random-init weights'),
                        'global_batch': b * world, 'parallelism': 'dp%d' % world, 'sync_bn': bool(args.sync_bn and world > 1), 'optimizer': 'FlatAdamW (clip 0.01 folded in)' if args.optimizer == 'flat' else 'torch AdamW(%s) + flat-buffer grad-norm clip' % args.optimizer,
                        'grad_allreduce': None if world == 1 and not force_ddp else ('torch DDP' if args.ddp else ('RCCL all-reduce (mean) of each of the three backward graphs\' stretches of the optimizer\'s flat gradient buffer, in place on a side stream, overlapped with the rest of backward (parallel.OverlappedGradSync + FlatAdamW gradient sink)' if (args.optimizer == 'flat' and os.environ.get('MAGGIE_GRAD_OVERLAP', '1') != '0') else 'one RCCL all-reduce of the flat gradient buffer inside FlatAdamW.step' if args.optimizer == 'flat' else 'GradSync (flat-buffer RCCL all-reduce)')),
-                       'active_ratio': round(active_ratio, 4), 'active_ratio_per_timed_step': [round(float(v) / (b * n_f * args.instances * args.size * args.size), 3) for v in stats['active_hist']] if not args.no_roofline else None, 'active_pixels_per_step_per_gpu': int(active_px), 'loss_total': round(loss_val, 4)},
+                       'peak_hbm_gb': round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1), 'active_ratio': round(active_ratio, 4), 'active_ratio_per_timed_step': [round(float(v) / (b * n_f * args.instances * args.size * args.size), 3) for v in stats['active_hist']] if not args.no_roofline else None, 'active_pixels_per_step_per_gpu': int(active_px), 'loss_total': round(loss_val, 4)},
             'roofline': roofline, 'cpu_baseline': cpu_baseline,
         }
     if world > 1 or force_ddp:

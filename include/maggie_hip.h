@@ -176,6 +176,7 @@ int mg_pool2x2(const void* in, void* out, int dtype, int op, int N, int Ho, int 
 /* mode 0: bit = (lo < a < hi); mode 1: bit = (a > 0). `a` is [P,H,W] planes of dtype MG_F32 or MG_U8. */
 int mg_bits_pack(const void* a, int dtype, void* bits, int P, int H, int W, int mode, float lo, float hi, void* stream);
 int mg_bits_unpack_u8(const void* bits, uint8_t* out, int P, int H, int W, void* stream);
+int mg_bits_unpack_f32(const void* bits, float* out, int P, int H, int W, void* stream);   /* the same as 0.f / 1.f planes (loss weights) */
 /* progressive refinement blend of `fuse` (resnet_inst_matt_spconv.py:272-290): out = bit ? a : b over fp32 planes [P][H][W] (= a*w + b*(1-w)
  * for the 0/1 weight plane the bits encode), and its backward da = bit ? dy : 0, db = bit ? 0 : dy (either may be NULL) */
 int mg_bits_select(const void* bits, const float* a, const float* b, float* out, int P, int H, int W, void* stream);

@@ -83,6 +83,18 @@ __global__ __launch_bounds__(256) void unpack_u8_kernel(const u64* __restrict__ 
     }
 }
 
+// the same straight to fp32 planes (loss weights: the uint8 planes were unpacked, then cast to fp32 by a second pass over 42 MB)
+__global__ __launch_bounds__(256) void unpack_f32_kernel(const u64* __restrict__ bits, float* __restrict__ out, long nwords, int W, int Ww) {
+    const int lane = threadIdx.x & 63;
+    long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long stride = (long)gridDim.x * 4;
+    for (; w < nwords; w += stride) {
+        long row = w / Ww; int wj = (int)(w - row * Ww);
+        int x = wj * 64 + lane;
+        if (x < W) out[row * W + x] = (float)((bits[w] >> lane) & 1ull);
+    }
+}
+
 // ---- progressive refinement blend (maggie/network/decoder/resnet_inst_matt_spconv.py:272-290): alpha = a * w + b * (1 - w) with
 // w = the unknown-region bit plane, i.e. a per-pixel select. Reads the bit plane itself: no uint8/float weight tensor, one pass.
 __global__ __launch_bounds__(256) void select_kernel(const u64* __restrict__ bits, const float* __restrict__ a, const float* __restrict__ b,
@@ -311,6 +323,15 @@ extern "C" int mg_bits_unpack_u8(const void* bits, uint8_t* out, int P, int H, i
     long nwords = (long)P * H * Ww;
     if (nwords <= 0) return 0;
     hipLaunchKernelGGL(unpack_u8_kernel, dim3(grid_for(nwords, 4)), dim3(256), 0, (hipStream_t)stream, (const u64*)bits, out, nwords, W, Ww);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_bits_unpack_f32(const void* bits, float* out, int P, int H, int W, void* stream) {
+    const int Ww = (W + 63) / 64;
+    long nwords = (long)P * H * Ww;
+    if (nwords <= 0) return 0;
+    hipLaunchKernelGGL(unpack_f32_kernel, dim3(grid_for(nwords, 4)), dim3(256), 0, (hipStream_t)stream, (const u64*)bits, out, nwords, W, Ww);
     MG_CHECK_LAUNCH();
     return 0;
 }

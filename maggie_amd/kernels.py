@@ -415,6 +415,13 @@ def bits_unpack_u8(bits, W, shape=None):
     return out if shape is None else out.view(*shape)
 
 
+def bits_unpack_f32(bits, W, shape=None):
+    P, H, Ww = bits.shape
+    out = torch.empty((P, H, W), dtype=torch.float32, device=bits.device)
+    hip.call('mg_bits_unpack_f32', hip.ptr(bits), hip.ptr(out), c_int(P), c_int(H), c_int(W), hip.stream())
+    return out if shape is None else out.view(*shape)
+
+
 def bits_dilate(bits, W, width=None, widths=None, andmask=None):
     """Binary dilation with OpenCV's ellipse of the given width (scalar) or per-plane device int32 `widths`."""
     P, H, Ww = bits.shape

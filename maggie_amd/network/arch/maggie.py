@@ -336,14 +336,18 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
                 plan = dict(plan, use_gt_dev=step_flags[1:2])
         pred = self.decoder.detail_stage(dense, (h, w), b, n_f, n_i, plan, alphas, spar_gt=trans_gt)
         alpha_pred = pred.pop("refined_masks")
-        weight_os4 = pred["detail_mask"].type(alpha_pred.dtype)
-        weight_os1 = weight_os4
-        if self.training and 'weight_os4' in pred:
+        detail_bits = pred.pop('detail_bits', None)
+        if self.training and 'weight_os4_bits' in pred and detail_bits is not None:
             # `np.random.rand() < 0.75` (arch/maggie.py:99-101) was drawn by the caller: a device flag selects the weight planes, so one
-            # captured graph serves both outcomes
+            # captured graph serves both outcomes -- on the BIT planes, unpacked once straight to fp32
             pick = use_w.bool()
-            weight_os4 = torch.where(pick, pred.pop("weight_os4").type(alpha_pred.dtype), weight_os4)
-            weight_os1 = torch.where(pick, pred.pop("weight_os1").type(alpha_pred.dtype), weight_os1)
+            shape = pred['detail_mask'].shape
+            weight_os4 = K.bits_unpack_f32(torch.where(pick, pred.pop('weight_os4_bits'), detail_bits), w, shape)
+            weight_os1 = K.bits_unpack_f32(torch.where(pick, pred.pop('weight_os1_bits'), detail_bits), w, shape)
+        else:
+            pred.pop('weight_os4_bits', None), pred.pop('weight_os1_bits', None)
+            weight_os4 = pred["detail_mask"].type(alpha_pred.dtype)
+            weight_os1 = weight_os4
         output = self.transform_output(b, n_f, h, w, n_i, pred, alpha_pred)
         names, outs = [], []
         if self.training:

@@ -329,21 +329,23 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
             detail_bits = MF.unknown_bits(guided, 30, False)                               # (N*n_cur, H, Ww)
         x_os4, x_os1, detail_bits = self.process_os4_os1(x, b, n_f, fea1, fea2, fea3, hw, x_os8, queries, n_cur, detail_bits)
         ret = {'alpha_os1': x_os1, 'alpha_os4': x_os4, 'alpha_os8': x_os8}
+        # the two loss-weight planes leave as BIT planes (1/64 of the bytes): the caller selects between them and the detail mask word by word
+        # and unpacks once, straight to fp32 (was: unpack to uint8, cast to fp32, torch.where over 42 MB planes -- per weight plane)
         if gt_dev is not None:
             alpha_pred, bits4, bits1 = self.fuse(ret, detail_bits, widths, want_bits=True)
             g4 = MF.unknown_bits(gt_alphas, 30, self.training, andmask=detail_bits, widths=widths[2])
             g1 = MF.unknown_bits(gt_alphas, 15, self.training, andmask=detail_bits, widths=widths[3])
-            weight_os4 = K.bits_unpack_u8(torch.where(sel, g4, bits4), w, x_os8.shape)
-            weight_os1 = K.bits_unpack_u8(torch.where(sel, g1, bits1), w, x_os8.shape)
+            wbits4, wbits1 = torch.where(sel, g4, bits4), torch.where(sel, g1, bits1)
         else:
-            alpha_pred, weight_os4, weight_os1 = self.fuse(ret, detail_bits, widths)
+            alpha_pred, wbits4, wbits1 = self.fuse(ret, detail_bits, widths, want_bits=True)
         ret['refined_masks'] = alpha_pred
         unknown_os8 = K.bits_unpack_u8(detail_bits, w, x_os8.shape)
         if use_gt and gt_dev is None:
-            weight_os4 = K.bits_unpack_u8(MF.unknown_bits(gt_alphas, 30, self.training, andmask=detail_bits, widths=widths[2]), w, x_os8.shape)
-            weight_os1 = K.bits_unpack_u8(MF.unknown_bits(gt_alphas, 15, self.training, andmask=detail_bits, widths=widths[3]), w, x_os8.shape)
-        ret['weight_os4'] = weight_os4
-        ret['weight_os1'] = weight_os1
+            wbits4 = MF.unknown_bits(gt_alphas, 30, self.training, andmask=detail_bits, widths=widths[2])
+            wbits1 = MF.unknown_bits(gt_alphas, 15, self.training, andmask=detail_bits, widths=widths[3])
+        ret['weight_os4_bits'] = wbits4
+        ret['weight_os1_bits'] = wbits1
+        ret['detail_bits'] = detail_bits
         ret['detail_mask'] = unknown_os8
         if plan['with_atten']:
             ret['loss_max_atten'] = loss_max_atten
