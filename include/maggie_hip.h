@@ -188,6 +188,9 @@ int mg_bits_dilate(const void* in, void* out, const void* andmask, int P, int H,
 int mg_bits_downsample(const void* fine, void* coarse, int P, int Hf, int Wf, void* stream);
 /* per-row exclusive scan: rowoff[P*H + 1] (rowoff[P*H] = number of active sites), wordoff[P*H*Ww] = rank of each word */
 int mg_bits_rank(const void* bits, int P, int H, int W, int32_t* counts_tmp, int32_t* rowoff, int32_t* wordoff, void* stream);
+/* Bounded sparse-head capacity: keep at most `cap` active sites of a level in rank order (bits cleared in place, *count clamped, *overflow set to 1
+ * when sites were dropped; wordoff stays valid for the kept sites). The host raises on the sticky overflow flag at its next flag read. */
+int mg_bits_truncate(void* bits, const int32_t* wordoff, int P, int H, int W, int cap, int32_t* count, int32_t* overflow, void* stream);
 /* coords[R,3] = (plane, y, x) of the active sites in sorted order (== torch.nonzero) */
 int mg_bits_coords(const void* bits, const int32_t* wordoff, int P, int H, int W, int32_t* coords, void* stream);
 /* gather tables [R, k*k] into the (src_bits, src_wordoff) level. kind 0: submanifold k x k; kind 1: inverse conv

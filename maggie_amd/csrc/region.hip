@@ -299,6 +299,28 @@ __global__ __launch_bounds__(256) void table_kernel(const int* __restrict__ coor
     }
 }
 
+// Bounded capacity of the sparse head (round 3): when a level has more active sites than the row buffers were sized for, the sites of rank
+// >= cap are REMOVED from the bit planes (so every later kernel sees a consistent, smaller active set: no rank ever points past a buffer),
+// the level's count word is clamped and a sticky device flag is raised -- the host raises on it at its next (already existing) flag read.
+__global__ __launch_bounds__(256) void truncate_kernel(u64* __restrict__ bits, const int* __restrict__ wordoff, long nwords, int cap,
+                                                       int* __restrict__ count, int* __restrict__ overflow) {
+    if (*count <= cap) return;                            // (uniform: every thread reads the same word before anyone clamps it -- see the launcher)
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (long)gridDim.x * 256) {
+        const u64 m = bits[i];
+        if (!m) continue;
+        const int off = wordoff[i];
+        if (off >= cap) { bits[i] = 0ull; continue; }
+        int keep = cap - off;                             // >= 1
+        if (__popcll(m) <= keep) continue;
+        u64 r = m, out = 0ull;
+        while (keep-- > 0) { const u64 low = r & (~r + 1ull); out |= low; r ^= low; }
+        bits[i] = out;
+    }
+}
+__global__ void truncate_finish_kernel(int cap, int* __restrict__ count, int* __restrict__ overflow) {
+    if (*count > cap) { *count = cap; *overflow = 1; }
+}
+
 inline int grid_for(long total, int per_block) {
     long b = (total + per_block - 1) / per_block;
     return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -397,6 +419,19 @@ extern "C" int mg_bits_coords(const void* bits, const int32_t* wordoff, int P, i
     if (nwords <= 0) return 0;
     hipLaunchKernelGGL(emit_coords_kernel, dim3(grid_for(nwords, 256)), dim3(256), 0, (hipStream_t)stream, (const u64*)bits, wordoff, nwords,
                        H, Ww, coords);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+/* Keep at most `cap` active sites of a level (in rank order): clears the bits of the others in place, clamps *count (the level's site count,
+ * = rowoff[P*H] of mg_bits_rank) and sets *overflow = 1 when anything was dropped. wordoff stays valid for the kept sites. */
+extern "C" int mg_bits_truncate(void* bits, const int32_t* wordoff, int P, int H, int W, int cap, int32_t* count, int32_t* overflow, void* stream) {
+    const int Ww = (W + 63) / 64;
+    const long nwords = (long)P * H * Ww;
+    if (nwords <= 0 || cap < 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(truncate_kernel, dim3(grid_for(nwords, 256)), dim3(256), 0, st, (u64*)bits, wordoff, nwords, cap, count, overflow);
+    hipLaunchKernelGGL(truncate_finish_kernel, dim3(1), dim3(1), 0, st, cap, count, overflow);      // after every block has read the unclamped count
     MG_CHECK_LAUNCH();
     return 0;
 }

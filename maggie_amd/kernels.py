@@ -451,6 +451,14 @@ def bits_rank(bits, W):
     return rowoff, wordoff
 
 
+def bits_truncate_(bits, wordoff, W, cap, count, overflow):
+    """In place: at most `cap` sites of the level stay active (rank order); `count` (int32 [1] view of the rank table) is clamped and the sticky
+    int32 [1] `overflow` flag raised when sites were dropped."""
+    P, H, Ww = bits.shape
+    hip.call('mg_bits_truncate', hip.ptr(bits), hip.ptr(wordoff), c_int(P), c_int(H), c_int(W), c_int(int(cap)), hip.ptr(count), hip.ptr(overflow),
+             hip.stream())
+
+
 def bits_coords(bits, wordoff, W, R):
     P, H, Ww = bits.shape
     coords = torch.empty((R, 3), dtype=torch.int32, device=bits.device)

@@ -301,9 +301,18 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         # else the detail stage needs from the host is drawn below, in the reference's order; no site count is ever read back.
         x_os8 = dense[0]
         fl = [torch.isnan(dense[2]).any()] + ([nonzero[0] == 0] if self.training else [])      # (the flag is written by the up-sampling kernel)
+        ovf = self.decoder.__dict__.get('_sparse_overflow') if self.decoder.sparse_capacity() < 1.0 else None
+        if ovf is not None:
+            fl.append(ovf[0] != 0)                                    # sticky: raised by an EARLIER step's detail stage (sparse_head.DeviceLevel)
         flags = torch.stack(fl).tolist()
         if flags[0]:
             raise ValueError("Mask is empty")
+        if ovf is not None and flags[-1]:
+            ovf.zero_()
+            raise K.hip.MaggieHipError(
+                'MaGGIe (MI355X build): the detail region of a previous step had more active sites than the sparse head was sized for '
+                '(sparse_capacity = %.2f of all sites); the sites beyond the capacity were dropped, i.e. that step\'s refinement and gradients are '
+                'incomplete. Raise model.decoder.sparse_capacity_frac / MAGGIE_SPARSE_CAPACITY (1.0 cannot overflow).' % self.decoder.sparse_capacity())
         P = b * n_f * (x_os8.shape[1] if self.training else n_i)
         plan = self.decoder.detail_plan(batch.get('iter', 0), bool(self.training and flags[1]), P, x.device)
         use_fuse_w = bool(self.training and np.random.rand() < 0.75)            # arch/maggie.py:99-101

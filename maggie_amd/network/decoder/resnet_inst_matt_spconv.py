@@ -161,11 +161,28 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
         # "dummy code to prevent all zeros" (:347-348): `unknown_os8[:, :, 200:250, 200:250] = 1` -- a slice assignment, so the square
         # is clipped to the plane (and is a no-op on planes of 200 pixels or less)
         patch = (200, min(250, H), 200, min(250, W)) if (self.training and H > 200 and W > 200) else None
-        pyr = DevicePyramid(roi_bits, H, W, patch)
+        pyr = DevicePyramid(roi_bits, H, W, patch, self.sparse_capacity(), self.sparse_overflow_flag(roi_bits.device))
         env = self._head_env(pyr, n_i, os8_feat.dtype)
         x_os4, x_os1 = SparseHead.apply(env, os8_feat.contiguous(), inst_guidance_os8, fea1.contiguous(), fea2.contiguous(), fea3.contiguous(),
                                         *env.params)
         return x_os4, x_os1, pyr
+
+    def sparse_capacity(self):
+        """Fraction of "every site active" the sparse head's row buffers are sized for: attribute `sparse_capacity`, env MAGGIE_SPARSE_CAPACITY,
+        default 1.0 (cannot overflow). With a smaller value a step whose detail region exceeds it raises MaggieHipError (after the fact: at the next
+        forward's flag read) instead of silently refining fewer sites."""
+        v = self.__dict__.get('sparse_capacity_frac')
+        if v is None:
+            import os
+            v = float(os.environ.get('MAGGIE_SPARSE_CAPACITY', '1.0'))
+        return float(v)
+
+    def sparse_overflow_flag(self, device):
+        """Sticky int32 [1] device flag: 1 once any level of any step dropped sites (created once: its address is baked into the captured graphs)."""
+        f = self.__dict__.get('_sparse_overflow')
+        if f is None or f.device != device:
+            f = self.__dict__['_sparse_overflow'] = torch.zeros(1, dtype=torch.int32, device=device)
+        return f
 
     def fuse(self, pred, detail_bits, widths=None, want_bits=False):
         """Progressive refinement (:272-290) with the two compute_unknown calls on device bit planes. `widths` (2, P) device int32: the
@@ -245,7 +262,7 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
     def head_state(self):
         """Device state the detail stage mutates besides module buffers (rolled back after a capture's warm-up runs): the dropout counter."""
         rng = self.__dict__.get('_head_rng')
-        return [rng.state] if rng is not None else []
+        return ([rng.state] if rng is not None else []) + ([self.__dict__['_sparse_overflow']] if '_sparse_overflow' in self.__dict__ else [])
 
     def dense_modules(self):
         """Sub-modules whose parameters are touched by dense_stage only."""

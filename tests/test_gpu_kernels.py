@@ -1160,3 +1160,29 @@ def test_token_einsum_matches_torch(dtype, B, L, Q, C):
     assert (out[..., :Q].detach().float().cpu() - ref.detach()).abs().max() <= tol * ref.abs().max()
     assert (fd.grad.float().cpu() - feat.grad).abs().max() <= tol * feat.grad.abs().max()
     assert (td.grad.float().cpu() - tok.grad).abs().max() <= max(tol, 1e-4) * tok.grad.abs().max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cap', [0, 1, 777, 5000, 10 ** 9])
+def test_bits_truncate_keeps_the_first_cap_sites(cap):
+    """mg_bits_truncate (bounded sparse-head capacity): the first `cap` active sites in torch.nonzero order survive, the count word is clamped
+    and the sticky overflow flag says whether anything was dropped -- against numpy."""
+    from maggie_amd import kernels as K
+    dev = _dev()
+    rs = np.random.RandomState(5)
+    P, H, W = 3, 37, 150
+    dense = (rs.rand(P, H, W) < 0.3)
+    a = torch.from_numpy(dense.astype(np.float32)).to(dev)
+    bits = K.bits_pack(a, mode=1)
+    rowoff, wordoff = K.bits_rank(bits, W)
+    count = rowoff[-1:]
+    total = int(dense.sum())
+    assert int(count) == total
+    ovf = torch.zeros(1, dtype=torch.int32, device=dev)
+    K.bits_truncate_(bits, wordoff, W, cap, count, ovf)
+    got = K.bits_unpack_u8(bits, W).cpu().numpy().astype(bool)
+    want = np.zeros_like(dense)
+    idx = np.argwhere(dense)[:cap]
+    want[idx[:, 0], idx[:, 1], idx[:, 2]] = True
+    assert np.array_equal(got, want)
+    assert int(count) == min(total, cap) and int(ovf) == int(total > cap)

