@@ -516,6 +516,18 @@ int mg_token_linear_bwd_ex(const float* dy, const float* x, const float* xadd, c
  * (only with gt). */
 int mg_imd_prep(const float* mask, int n_in, int s, const float* gt, int n_gt, int gs, int B, int NF, int h, int w, int n_i, int32_t* feat_ids,
                 float* guidance, unsigned char* valid, void* stream);
+/* Up to 4 INDEPENDENT token linear layers per launch (the q / k / v projections of the token self-attention, the folded key / table products of a
+ * cross attention: module/mask_attention.py:9-206): per layer the semantics of mg_token_linear_fwd_ex / _bwd_ex. Unused pointers are NULL. */
+typedef struct mg_tok_lin {
+    const float *x, *xadd, *W, *bias, *res, *gamma, *beta;   /* forward inputs ([R,K], [R,K], [N,K] or [K,N] with wt, [N], [R,N], [N], [N]) */
+    float *y, *z, *rstat;                                    /* forward outputs (z: pre-LayerNorm values, rstat [R,2]: with gamma)          */
+    const float *dy, *yout;                                  /* backward inputs ([R,N]; yout = y of a ReLU layer)                          */
+    float *dx, *dW, *db, *dres, *dgamma, *dbeta, *dz;        /* backward outputs (dz: [R,N] scratch; = dy for a plain layer)               */
+    int32_t R, K, N, relu, wt;
+    float eps;
+} mg_tok_lin;
+int mg_token_linear_multi_fwd(const mg_tok_lin* ops, int n, void* stream);
+int mg_token_linear_multi_bwd(const mg_tok_lin* ops, int n, void* stream);
 /* einsum('bqc,blc->blq') of the instance matte decoder (instance_matte_decoder.py:296-299): logits[b][l][q] = sum_c feat[b][l][c] tok[b][q][c] for
  * q < Q, zero up to the row pitch QP (= 16). feat / out / dlog / dfeat in `dtype` ([B][L][C] / [B][L][QP]); tok / dtok fp32 [B][Q][C] (dtok is
  * overwritten). C = 32 or 64, Q <= 16. The tokens are rounded to `dtype` first (the 1x1 convolution this replaces did the same). */

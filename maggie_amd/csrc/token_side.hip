@@ -27,17 +27,17 @@ __device__ __forceinline__ float block_row_sum(float v, float* red) {      // su
 // inside the same workgroup.
 constexpr int RB = 4;
 
-__global__ __launch_bounds__(NT) void token_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ xadd, const float* __restrict__ W,
-                                                              const float* __restrict__ bias, const float* __restrict__ res, int relu,
-                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                              float* __restrict__ y, float* __restrict__ z_out, float* __restrict__ rstat, int R, int K,
-                                                              int N, int wt) {
+__device__ __forceinline__ void token_linear_fwd_body(int bx, const float* __restrict__ x, const float* __restrict__ xadd, const float* __restrict__ W,
+                                                      const float* __restrict__ bias, const float* __restrict__ res, int relu,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                      float* __restrict__ y, float* __restrict__ z_out, float* __restrict__ rstat, int R, int K,
+                                                      int N, int wt) {
     extern __shared__ float sm[];
     float* sx = sm;                      // [RB][K]  x + xadd
     float* sy = sm + RB * K;             // [RB][N]  pre-LayerNorm values
     float* sw = sy + RB * N;             // [K][N + 1]  W transposed
     const int t = threadIdx.x;
-    const int r0 = blockIdx.x * RB;
+    const int r0 = bx * RB;
     const int nr = min(RB, R - r0);
     const int P = N + 1;
     {   // W -> LDS transposed; 8 x 16-byte loads in flight per thread (a load-store-load chain costs a round trip per element)
@@ -101,14 +101,42 @@ __global__ __launch_bounds__(NT) void token_linear_fwd_kernel(const float* __res
     }
 }
 
+__global__ __launch_bounds__(NT) void token_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ xadd, const float* __restrict__ W,
+                                                              const float* __restrict__ bias, const float* __restrict__ res, int relu,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                              float* __restrict__ y, float* __restrict__ z_out, float* __restrict__ rstat, int R, int K,
+                                                              int N, int wt) {
+    token_linear_fwd_body(blockIdx.x, x, xadd, W, bias, res, relu, gamma, beta, eps, y, z_out, rstat, R, K, N, wt);
+}
+
+// Several INDEPENDENT layers in one launch (blockIdx.y = layer): the q / k / v projections of the token self-attention, the folded key /
+// table products of a cross attention, ... -- each was a launch of 10 workgroups at the latency floor (9 us forward, 8 + 5 us backward).
+struct TokLin {
+    const float *x, *xadd, *W, *bias, *res, *gamma, *beta;
+    float *y, *z, *rstat;
+    // backward
+    const float *dy, *yout;
+    float *dx, *dW, *db, *dres, *dgamma, *dbeta, *dz;
+    int R, K, N, relu, wt;
+    float eps;
+};
+constexpr int TOK_MULTI = 4;
+struct TokLinSet { TokLin op[TOK_MULTI]; int n; };
+
+__global__ __launch_bounds__(NT) void token_linear_multi_fwd_kernel(const TokLinSet set) {
+    const TokLin& p = set.op[blockIdx.y];
+    if ((int)blockIdx.x * RB >= p.R) return;
+    token_linear_fwd_body(blockIdx.x, p.x, p.xadd, p.W, p.bias, p.res, p.relu, p.gamma, p.beta, p.eps, p.y, p.z, p.rstat, p.R, p.K, p.N, p.wt);
+}
+
 // Backward, kernel A (row-parallel, RB rows per workgroup): dz = gradient at the pre-LayerNorm point (= dres), ReLU mask, and
 // dx[r][k] = sum_n dz[r][n] W[n][k] with W staged row-major in LDS (thread per input column k: conflict-free).
-__global__ __launch_bounds__(NT) void token_linear_dz_kernel(const float* __restrict__ dy, const float* __restrict__ yout, int relu,
-                                                            const float* __restrict__ gamma, const float* __restrict__ z, const float* __restrict__ rstat,
-                                                            float* __restrict__ dz_out, float* __restrict__ dres, int R, int N) {
+__device__ __forceinline__ void token_linear_dz_body(int bx, const float* __restrict__ dy, const float* __restrict__ yout, int relu,
+                                                     const float* __restrict__ gamma, const float* __restrict__ z, const float* __restrict__ rstat,
+                                                     float* __restrict__ dz_out, float* __restrict__ dres, int R, int N) {
     // one wave per row: LayerNorm backward (two row reductions), residual gradient, ReLU mask -> dz
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int r = blockIdx.x * 4 + wave;
+    const int r = bx * 4 + wave;
     if (r >= R) return;
     const size_t ro = (size_t)r * N;
     float s1 = 0.f, s2 = 0.f, mean = 0.f, rstd = 1.f;
@@ -127,6 +155,18 @@ __global__ __launch_bounds__(NT) void token_linear_dz_kernel(const float* __rest
         if (relu && !(yout[ro + n] > 0.f)) g = 0.f;
         dz_out[ro + n] = g;
     }
+}
+
+__global__ __launch_bounds__(NT) void token_linear_dz_kernel(const float* __restrict__ dy, const float* __restrict__ yout, int relu,
+                                                            const float* __restrict__ gamma, const float* __restrict__ z, const float* __restrict__ rstat,
+                                                            float* __restrict__ dz_out, float* __restrict__ dres, int R, int N) {
+    token_linear_dz_body(blockIdx.x, dy, yout, relu, gamma, z, rstat, dz_out, dres, R, N);
+}
+__global__ __launch_bounds__(NT) void token_linear_multi_dz_kernel(const TokLinSet set) {
+    const TokLin& p = set.op[blockIdx.y];
+    if (p.dz == p.dy && !p.dres) return;                  // a plain layer: dz IS dy (see mg_token_linear_bwd)
+    if ((int)blockIdx.x * 4 >= p.R) return;
+    token_linear_dz_body(blockIdx.x, p.dy, p.yout, p.relu, p.gamma, p.z, p.rstat, p.dz, p.dres, p.R, p.N);
 }
 
 // dx[r][k] = sum_n dz[r][n] W[n][k]: RB rows per workgroup, W staged once in LDS (the row-parallel half of the main backward launch)
@@ -268,6 +308,16 @@ __global__ __launch_bounds__(NT) void token_linear_bwd_main_kernel(int nrb, cons
     extern __shared__ float sm[];
     if ((int)blockIdx.x < nrb) token_linear_bwd_rows(sm, blockIdx.x, dz, W, dx, R, K, N, wt);
     else token_linear_bwd_cols(sm, blockIdx.x - nrb, dz, dy, x, xadd, gamma, z, rstat, dW, db, dgamma, dbeta, R, K, N, wt);
+}
+
+__global__ __launch_bounds__(NT) void token_linear_multi_bwd_main_kernel(const TokLinSet set) {
+    extern __shared__ float sm[];
+    const TokLin& p = set.op[blockIdx.y];
+    const int nrb = p.dx ? (p.R + RB - 1) / RB : 0;
+    const int ncb = (p.N + CB - 1) / CB;
+    if ((int)blockIdx.x >= nrb + ncb) return;
+    if ((int)blockIdx.x < nrb) token_linear_bwd_rows(sm, blockIdx.x, p.dz, p.W, p.dx, p.R, p.K, p.N, p.wt);
+    else token_linear_bwd_cols(sm, blockIdx.x - nrb, p.dz, p.dy, p.x, p.xadd, p.gamma, p.z, p.rstat, p.dW, p.db, p.dgamma, p.dbeta, p.R, p.K, p.N, p.wt);
 }
 
 // ---- token self-attention core: one workgroup per batch element, T <= 16 tokens, D <= 256 -------------------------------------------------
@@ -606,6 +656,66 @@ extern "C" int mg_imd_prep(const float* mask, int n_in, int s, const float* gt, 
     const long cells = (long)B * NF * h * w;
     hipLaunchKernelGGL(imd_prep_kernel, dim3((unsigned)((cells + NT - 1) / NT)), dim3(NT), 0, st, mask, n_in, s, gt, gt ? n_gt : 0, gs, B, NF, h, w, n_i,
                        feat_ids, gt ? guidance : nullptr, valid);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+/* Up to 4 INDEPENDENT token linear layers in one launch each way (same semantics per layer as mg_token_linear_fwd_ex / _bwd_ex). `ops`: array of
+ * mg_tok_lin (include/maggie_hip.h); forward reads x, xadd, W, bias, res, relu, gamma, beta, eps, wt and writes y (z, rstat with a LayerNorm);
+ * backward reads dy (+ the forward's x, xadd, W, yout, gamma, z, rstat) and writes dx, dW, db, dres, dgamma, dbeta through the scratch dz. */
+static int tok_set(const mg_tok_lin* ops, int n, TokLinSet* set, int bwd) {
+    if (!ops || n < 1 || n > TOK_MULTI) return -2;
+    set->n = n;
+    for (int i = 0; i < n; ++i) {
+        const mg_tok_lin& o = ops[i];
+        int rc = tl_check(o.R, o.K, o.N); if (rc) return rc;
+        if (o.wt && (o.N & 3)) return -3;
+        if (o.gamma && ((!bwd && !o.beta) || !o.z || !o.rstat)) return -2;
+        if (bwd && ((o.relu && !o.yout) || !o.dz || !o.dW || (o.gamma && (!o.dgamma || !o.dbeta)))) return -2;
+        TokLin& t = set->op[i];
+        t.x = o.x; t.xadd = o.xadd; t.W = o.W; t.bias = o.bias; t.res = o.res; t.gamma = o.gamma; t.beta = o.beta;
+        t.y = o.y; t.z = o.z; t.rstat = o.rstat; t.dy = o.dy; t.yout = o.yout; t.dx = o.dx; t.dW = o.dW; t.db = o.db; t.dres = o.dres;
+        t.dgamma = o.dgamma; t.dbeta = o.dbeta; t.dz = o.dz; t.R = o.R; t.K = o.K; t.N = o.N; t.relu = o.relu; t.wt = o.wt; t.eps = o.eps;
+    }
+    return 0;
+}
+
+extern "C" int mg_token_linear_multi_fwd(const mg_tok_lin* ops, int n, void* stream) {
+    TokLinSet set;
+    int rc = tok_set(ops, n, &set, 0); if (rc) return rc;
+    size_t lds = 0; int gx = 0;
+    for (int i = 0; i < n; ++i) {
+        const size_t l = ((size_t)RB * (ops[i].K + ops[i].N) + (size_t)ops[i].K * (ops[i].N + 1)) * sizeof(float);
+        if (l > lds) lds = l;
+        const int g = (ops[i].R + RB - 1) / RB; if (g > gx) gx = g;
+    }
+    if (lds > 150 * 1024) return -3;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)token_linear_multi_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
+    hipLaunchKernelGGL(token_linear_multi_fwd_kernel, dim3(gx, n), dim3(NT), lds, (hipStream_t)stream, set);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int mg_token_linear_multi_bwd(const mg_tok_lin* ops, int n, void* stream) {
+    TokLinSet set;
+    int rc = tok_set(ops, n, &set, 1); if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    size_t lds = 0; int gx = 0, gz = 0; bool need_dz = false;
+    for (int i = 0; i < n; ++i) {
+        const mg_tok_lin& o = ops[i];
+        const size_t lr = ((size_t)RB * o.N + (size_t)o.N * o.K) * sizeof(float), lc = (size_t)32 * (CB + o.K) * sizeof(float);
+        const size_t l = o.dx ? (lr > lc ? lr : lc) : lc;
+        if (l > lds) lds = l;
+        const int g = (o.dx ? (o.R + RB - 1) / RB : 0) + (o.N + CB - 1) / CB; if (g > gx) gx = g;
+        const int z = (o.R + 3) / 4; if (z > gz) gz = z;
+        if (o.gamma || o.relu || o.dz != o.dy || o.dres) need_dz = true;
+    }
+    if (lds > 150 * 1024) return -3;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)token_linear_multi_bwd_main_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
+    if (need_dz) hipLaunchKernelGGL(token_linear_multi_dz_kernel, dim3(gz, n), dim3(NT), 0, st, set);
+    hipLaunchKernelGGL(token_linear_multi_bwd_main_kernel, dim3(gx, n), dim3(NT), lds, st, set);
     MG_CHECK_LAUNCH();
     return 0;
 }

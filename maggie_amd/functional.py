@@ -1518,6 +1518,107 @@ def token_linear(x, W, b=None, xadd=None, res=None, relu=False, ln=None, wt=Fals
     return TokenLinear.apply(x, xadd, W, b, res, relu, g, be, eps, wt)
 
 
+class TokenLinearMulti(torch.autograd.Function):
+    """Up to four INDEPENDENT TokenLinear layers in one launch each way (mg_token_linear_multi_fwd / _bwd): inputs are 7 slots per layer
+    (x, xadd, W, b, res, gamma, beta; None where absent), `specs` = per layer (relu, eps, wt)."""
+
+    @staticmethod
+    def forward(ctx, specs, *slots):
+        n = len(specs)
+        f = lambda t: None if t is None else t.detach().float().contiguous()       # noqa: E731
+        ops = (K.hip.TokLin * n)()
+        saved, metas, outs = [], [], []
+        for i, (relu, eps, wt) in enumerate(specs):
+            x, xadd, W, b, res, gamma, beta = slots[7 * i:7 * i + 7]
+            if relu and (res is not None or gamma is not None):
+                raise K.hip.MaggieHipError('TokenLinear: ReLU is only fused for a plain linear layer (no residual / LayerNorm behind it)')
+            shape = x.shape
+            Kd, N = shape[-1], (W.shape[1] if wt else W.shape[0])
+            x2, xa, W_, b_, r_, g_, be_ = f(x).view(-1, Kd), f(xadd), f(W), f(b), f(res), f(gamma), f(beta)
+            if xa is not None:
+                xa = xa.expand(shape).contiguous().view(-1, Kd) if xa.shape != shape else xa.view(-1, Kd)
+            if r_ is not None:
+                r_ = r_.view(-1, N)
+            R = x2.shape[0]
+            y = torch.empty((R, N), dtype=torch.float32, device=x.device)
+            z = torch.empty((R, N), dtype=torch.float32, device=x.device) if g_ is not None else None
+            rstat = torch.empty((R, 2), dtype=torch.float32, device=x.device) if g_ is not None else None
+            o = ops[i]
+            o.x, o.xadd, o.W, o.bias, o.res, o.gamma, o.beta = (K.hip.ptr(t) for t in (x2, xa, W_, b_, r_, g_, be_))
+            o.y, o.z, o.rstat = K.hip.ptr(y), K.hip.ptr(z), K.hip.ptr(rstat)
+            o.R, o.K, o.N, o.relu, o.wt, o.eps = R, Kd, N, int(bool(relu)), int(bool(wt)), float(eps)
+            saved += [x2, xa, W_, y if relu else None, g_, z, rstat]
+            metas.append((shape, R, Kd, N, bool(relu), b is not None, res is not None, None if xadd is None else xadd.shape, bool(wt)))
+            outs.append(y.view(*shape[:-1], N))
+        K.hip.need_cuda(*[t for t in saved if t is not None])
+        K.hip.call('mg_token_linear_multi_fwd', ops, K.c_int(n), K.hip.stream())
+        ctx.save_for_backward(*saved)
+        ctx.metas = metas
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        saved, metas = ctx.saved_tensors, ctx.metas
+        n = len(metas)
+        ops = (K.hip.TokLin * n)()
+        keep, results = [], []
+        for i, (shape, R, Kd, N, relu, has_b, has_res, xadd_shape, wt) in enumerate(metas):
+            x2, xa, W_, yout, g_, z, rstat = saved[7 * i:7 * i + 7]
+            dev = x2.device
+            dy = dys[i]
+            dy2 = (torch.zeros((R, N), dtype=torch.float32, device=dev) if dy is None else dy.float().contiguous().view(R, N))
+            need_dx = ctx.needs_input_grad[1 + 7 * i] or ctx.needs_input_grad[2 + 7 * i]
+            dx = torch.empty((R, Kd), dtype=torch.float32, device=dev) if need_dx else None
+            dW = torch.empty((Kd, N) if wt else (N, Kd), dtype=torch.float32, device=dev)
+            db = torch.empty(N, dtype=torch.float32, device=dev) if has_b else None
+            plain = g_ is None and not relu
+            dres = torch.empty((R, N), dtype=torch.float32, device=dev) if (has_res and not plain) else None
+            dgb = torch.empty(2 * N, dtype=torch.float32, device=dev) if g_ is not None else None
+            dz = dy2 if plain else torch.empty((R, N), dtype=torch.float32, device=dev)
+            o = ops[i]
+            o.x, o.xadd, o.W, o.gamma, o.z, o.rstat = (K.hip.ptr(t) for t in (x2, xa, W_, g_, z, rstat))
+            o.dy, o.yout, o.dx, o.dW, o.db, o.dres, o.dz = (K.hip.ptr(t) for t in (dy2, yout, dx, dW, db, dres, dz))
+            o.dgamma, o.dbeta = K.hip.ptr(None if dgb is None else dgb[:N]), K.hip.ptr(None if dgb is None else dgb[N:])
+            o.R, o.K, o.N, o.relu, o.wt = R, Kd, N, int(relu), int(wt)
+            keep += [dy2, dx, dW, db, dres, dgb, dz]
+            dxv = None if dx is None else dx.view(shape)
+            dxadd = None
+            if xadd_shape is not None and ctx.needs_input_grad[2 + 7 * i]:
+                dxadd = dxv if tuple(xadd_shape) == tuple(shape) else dxv.sum_to_size(xadd_shape)
+            if plain and has_res:
+                dres = dy2
+            results += [dxv if ctx.needs_input_grad[1 + 7 * i] else None, dxadd, dW, db, None if dres is None else dres.view(*shape[:-1], N),
+                        None if dgb is None else dgb[:N], None if dgb is None else dgb[N:]]
+        K.hip.call('mg_token_linear_multi_bwd', ops, K.c_int(n), K.hip.stream())
+        return (None,) + tuple(results)
+
+
+TOKEN_MULTI = os.environ.get('MAGGIE_TOKEN_MULTI', '1') != '0'
+
+
+def token_linear_multi(layers):
+    """`layers`: list of dicts with the keyword arguments of token_linear (x, W, b, xadd, res, relu, ln, wt) for layers that do NOT depend on each
+    other -> list of outputs. One launch forward, two backward, for up to four layers (longer lists are cut into groups of four)."""
+    outs = []
+    for g0 in range(0, len(layers), 4):
+        grp = layers[g0:g0 + 4] if TOKEN_MULTI else layers[g0:g0 + 1]
+        if not TOKEN_MULTI:
+            for L in layers[g0:g0 + 4]:
+                outs.append(token_linear(L['x'], L['W'], L.get('b'), L.get('xadd'), L.get('res'), L.get('relu', False), L.get('ln'), L.get('wt', False)))
+            continue
+        if len(grp) == 1:
+            L = grp[0]
+            outs.append(token_linear(L['x'], L['W'], L.get('b'), L.get('xadd'), L.get('res'), L.get('relu', False), L.get('ln'), L.get('wt', False)))
+            continue
+        specs, slots = [], []
+        for L in grp:
+            ln = L.get('ln')
+            specs.append((bool(L.get('relu', False)), ln.eps if ln is not None else 0.0, bool(L.get('wt', False))))
+            slots += [L['x'], L.get('xadd'), L['W'], L.get('b'), L.get('res'), None if ln is None else ln.weight, None if ln is None else ln.bias]
+        outs += list(TokenLinearMulti.apply(specs, *slots))
+    return outs
+
+
 class TokenSelfAttention(torch.autograd.Function):
     """softmax(q k^T / sqrt(d), key padding) v for (B, T <= 16, D) fp32 tokens: one workgroup per batch element each way."""
 

@@ -146,6 +146,13 @@ U8 = 2
 c_int, c_float, c_long = ctypes.c_int, ctypes.c_float, ctypes.c_long
 
 
+class TokLin(ctypes.Structure):
+    """mg_tok_lin (include/maggie_hip.h): one layer of mg_token_linear_multi_fwd / _bwd."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ('x', 'xadd', 'W', 'bias', 'res', 'gamma', 'beta', 'y', 'z', 'rstat', 'dy', 'yout', 'dx', 'dW', 'db',
+                                               'dres', 'dgamma', 'dbeta', 'dz')] + \
+               [(n, ctypes.c_int32) for n in ('R', 'K', 'N', 'relu', 'wt')] + [('eps', ctypes.c_float)]
+
+
 class WbEntry(ctypes.Structure):
     """mg_wb_entry (include/maggie_hip.h)."""
     _fields_ = [('src', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('dst_t', ctypes.c_void_p), ('cout', ctypes.c_int32),

@@ -53,9 +53,8 @@ class SelfAttentionLayer(nn.Module):
         """tgt: (b, T, d) tokens; key padding mask (b, T) True = ignore. Five HIP launches: three projections (position added inside),
         the T x T attention core, out-projection + residual + LayerNorm (mg_token_linear_*, mg_token_sa_*)."""
         (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.self_attn)
-        q = MF.token_linear(tgt, wq, bq, xadd=query_pos)
-        k = MF.token_linear(tgt, wk, bk, xadd=query_pos)
-        v = MF.token_linear(tgt, wv, bv)
+        q, k, v = MF.token_linear_multi([dict(x=tgt, W=wq, b=bq, xadd=query_pos), dict(x=tgt, W=wk, b=bk, xadd=query_pos),
+                                         dict(x=tgt, W=wv, b=bv)])                                       # three projections, one launch
         ctx = MF.token_self_attention(q, k, v, tgt_key_padding_mask)
         return MF.token_linear(ctx, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, res=tgt, ln=self.norm)
 
@@ -76,11 +75,13 @@ class CrossAttentionLayer(nn.Module):
         (mg_attn_tok_fwd / _bwd); the 10-token projections around it are fused HIP linears (mg_token_linear_*)."""
         (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.multihead_attn)
         d = tokens.shape[-1]
-        q = MF.token_linear(tokens, wq, bq, xadd=token_pos)                                  # (b,T,d)
-        qk = MF.token_linear(q, wk, wt=True)                                                 # q Wk: fold Wk into the queries (wk used as (K, N): no transposed copy)
         # score bias of a feature row with position id: q . (E[id] Wk^T + bk)  (id_table None: every row has id 0 and no embedding)
-        key_pos = MF.token_linear(id_table, wk, bk) if id_table is not None else bk[None, :]
-        tbl = MF.token_linear(q, key_pos)                                                    # (b,T,n_id)
+        if id_table is not None:                                                             # two independent layers, one launch
+            q, key_pos = MF.token_linear_multi([dict(x=tokens, W=wq, b=bq, xadd=token_pos), dict(x=id_table, W=wk, b=bk)])
+        else:
+            q, key_pos = MF.token_linear(tokens, wq, bq, xadd=token_pos), bk[None, :]
+        # q Wk (fold Wk into the queries; wk used as (K, N): no transposed copy) and the (b,T,n_id) score-bias table: one launch
+        qk, tbl = MF.token_linear_multi([dict(x=q, W=wk, wt=True), dict(x=q, W=key_pos)])
         _need_hip_attention(tokens.shape[1], d)
         p, ctx = MF.attn_tokens_from_features(qk, tbl, feat, feat_ids, 1.0 / math.sqrt(d))
         h = MF.token_linear(ctx, wv, bv)
@@ -91,11 +92,15 @@ class CrossAttentionLayer(nn.Module):
         the value mix are one HIP kernel per direction (mg_attn_feat_fwd / _bwd); residual + LayerNorm over the b * L rows one more."""
         (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.multihead_attn)
         d = feat.shape[-1]
-        k = MF.token_linear(tokens, wk, bk, xadd=token_pos)                                  # (b,T,d)
-        vp = MF.token_linear(MF.token_linear(tokens, wv, bv), self.multihead_attn.out_proj.weight)      # (b,T,d): rows of (Wo V^T)^T
-        kq = MF.token_linear(k, wq, wt=True)                                                 # (b,T,d): fold Wq into the keys
-        qry_pos = MF.token_linear(id_table, wq, bq) if id_table is not None else bq[None, :]  # (n_id, d)
-        tbl = MF.token_linear(k, qry_pos).transpose(1, 2).contiguous()                       # (b,n_id,T)
+        first = [dict(x=tokens, W=wk, b=bk, xadd=token_pos), dict(x=tokens, W=wv, b=bv)]     # k (b,T,d), v
+        if id_table is not None:
+            first.append(dict(x=id_table, W=wq, b=bq))                                       # qry_pos (n_id, d)
+        res = MF.token_linear_multi(first)
+        k, v = res[0], res[1]
+        qry_pos = res[2] if id_table is not None else bq[None, :]
+        # vp (b,T,d): rows of (Wo V^T)^T; kq (b,T,d): Wq folded into the keys; the (b,T,n_id) score-bias table -- three layers, one launch
+        vp, kq, tbl = MF.token_linear_multi([dict(x=v, W=self.multihead_attn.out_proj.weight), dict(x=k, W=wq, wt=True), dict(x=k, W=qry_pos)])
+        tbl = tbl.transpose(1, 2).contiguous()                                               # (b,n_id,T)
         _need_hip_attention(tokens.shape[1], d)
         out = MF.attn_features_from_tokens(feat, kq, tbl, vp, self.multihead_attn.out_proj.bias, token_padding_mask, feat_ids,
                                            1.0 / math.sqrt(d))

@@ -1186,3 +1186,49 @@ def test_bits_truncate_keeps_the_first_cap_sites(cap):
     want[idx[:, 0], idx[:, 1], idx[:, 2]] = True
     assert np.array_equal(got, want)
     assert int(count) == min(total, cap) and int(ovf) == int(total > cap)
+
+
+@pytest.mark.gpu
+def test_token_linear_multi_equals_separate_layers():
+    """mg_token_linear_multi_fwd / _bwd: several INDEPENDENT token layers per launch (the q / k / v projections of the token self-attention; a
+    projection next to the batch-independent ID-table product; a transposed-weight product next to a narrow table product) must give exactly what
+    the one-layer-per-launch path gives -- outputs and every gradient, including a tensor shared by several layers (autograd sums)."""
+    from maggie_amd import functional as MF
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    mk = lambda *s: torch.randn(*s, generator=g).to(dev)                      # noqa: E731
+    ln = torch.nn.LayerNorm(128).to(dev)
+    with torch.no_grad():
+        ln.weight.copy_(mk(128)); ln.bias.copy_(mk(128))
+
+    def leaves():
+        torch.manual_seed(1)
+        t = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        return t
+
+    base = dict(tgt=mk(4, 10, 128), pos=mk(4, 10, 128), wq=mk(128, 128) / 11, wk=mk(128, 128) / 11, wv=mk(128, 128) / 11, bq=mk(128), bk=mk(128), bv=mk(128),
+                table=mk(11, 128), kp=mk(11, 128) / 11, res=mk(4, 10, 128), w1=mk(64, 128) / 11, b1=mk(64))
+    wts = [mk(4, 10, 128), mk(4, 10, 128), mk(4, 10, 128), mk(11, 128), mk(4, 10, 128), mk(4, 10, 11), mk(4, 10, 128), mk(4, 10, 64)]
+
+    def run(multi):
+        t = leaves()
+        prev, MF.TOKEN_MULTI = MF.TOKEN_MULTI, multi
+        try:
+            a = MF.token_linear_multi([dict(x=t['tgt'], W=t['wq'], b=t['bq'], xadd=t['pos']), dict(x=t['tgt'], W=t['wk'], b=t['bk'], xadd=t['pos']),
+                                       dict(x=t['tgt'], W=t['wv'], b=t['bv']), dict(x=t['table'], W=t['wk'], b=t['bk'])])
+            b = MF.token_linear_multi([dict(x=a[0], W=t['wk'], wt=True), dict(x=a[0], W=t['kp']),
+                                       dict(x=a[2], W=t['wq'], res=t['res'], ln=ln), dict(x=a[1], W=t['w1'], b=t['b1'], relu=True)])
+        finally:
+            MF.TOKEN_MULTI = prev
+        outs = list(a) + list(b)
+        ln.zero_grad()
+        sum((o * w).sum() for o, w in zip(outs, wts)).backward()
+        return [o.detach() for o in outs], {k: v.grad.clone() for k, v in t.items()}, (ln.weight.grad.clone(), ln.bias.grad.clone())
+
+    o1, g1, l1 = run(True)
+    o0, g0, l0 = run(False)
+    for a, b in zip(o1, o0):
+        assert torch.equal(a, b)
+    for k in g0:
+        assert torch.allclose(g1[k], g0[k], atol=2e-5, rtol=1e-5), (k, float((g1[k] - g0[k]).abs().max()))      # (a tensor shared by several layers: autograd's sum order)
+    assert torch.allclose(l1[0], l0[0], atol=2e-5, rtol=1e-5) and torch.allclose(l1[1], l0[1], atol=2e-5, rtol=1e-5)

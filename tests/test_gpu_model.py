@@ -458,28 +458,37 @@ def test_fp16_autocast_opt_in_runs_the_unchanged_harness_recipe():
 def test_bounded_sparse_capacity_raises_instead_of_refining_fewer_sites():
     """VERDICT round 2, weak #8 / ADVICE: the sparse head's row buffers may be sized for a FRACTION of "every site active"
     (decoder.sparse_capacity_frac / MAGGIE_SPARSE_CAPACITY). A step whose detail region exceeds it must not read or write past a buffer, and the
-    model must say so (MaggieHipError at its next flag read) rather than silently refine fewer sites; with enough capacity results are unchanged."""
+    model must say so (MaggieHipError at its next flag read) rather than silently refine fewer sites; with enough capacity results are unchanged.
+    Training-mode forward with the ground-truth-guided detail region (iter 100): a deterministic region of a few percent of the 10 x H x W sites."""
     from maggie_amd.hip import MaggieHipError
     from maggie_amd.utils import synth
     dev = _dev()
-    batch = _to(synth.synthetic_batch(1, 1, 2, 128, 128, seed=DSEED, train=False), dev)
-    model, _ = _build('image', dev, False)
+    batch = _to(synth.synthetic_batch(2, 1, 2, 128, 128, seed=DSEED, train=True, max_inst=10, it=100), dev)
+    model, _ = _build('image', dev, True)
+    model.decoder.inst_spec_layer.dropout.p = 0.0
     model.hip_graphs = False
-    with torch.no_grad():
-        ref = model(batch)
-        active = float(ref['detail_mask'].float().mean())
-        assert active > 0.02
-        model.decoder.sparse_capacity_frac = min(0.9, active * 2)                       # roomy (OS1 fraction; coarser levels get 2x per level): same result
-        out = model(batch)
-        assert torch.equal(out['detail_mask'], ref['detail_mask'])
-        assert float((out['refined_masks'] - ref['refined_masks']).abs().max()) <= 1e-5
-        model(batch)                                                                    # and no complaint on the next read
-        model.decoder.sparse_capacity_frac = active / 8                                 # too small: the step runs (safely) ...
-        small = model(batch)
-        assert torch.isfinite(small['refined_masks']).all()
-        assert 0 < float(small['detail_mask'].float().mean()) < active                  # ... on fewer sites
-        with pytest.raises(MaggieHipError, match='sparse_capacity'):
-            model(batch)                                                                # ... and the next forward refuses to go on
-        model.decoder.sparse_capacity_frac = 1.0
-        again = model(batch)
-        assert torch.equal(again['detail_mask'], ref['detail_mask'])
+    state = copy.deepcopy(model.state_dict())
+
+    def run():
+        model.load_state_dict(state)
+        seed_all(5)
+        with torch.no_grad():
+            return model(batch)[0]
+
+    ref = run()
+    active = float(ref['detail_mask'].float().mean())
+    assert 0.005 < active < 0.2, active
+    model.decoder.sparse_capacity_frac = active * 3                                     # roomy (OS1 fraction; coarser levels get 2x per level): same result
+    out = run()
+    assert torch.equal(out['detail_mask'], ref['detail_mask'])
+    assert float((out['refined_masks'] - ref['refined_masks']).abs().max()) <= 2e-3       # (train-mode BatchNorm: fp32 atomics order between two runs)
+    run()                                                                               # and no complaint on the next read
+    model.decoder.sparse_capacity_frac = active / 8                                     # too small: the step runs (safely) ...
+    small = run()
+    assert torch.isfinite(small['refined_masks']).all()
+    assert 0 < float(small['detail_mask'].float().mean()) < active                      # ... on fewer sites
+    with pytest.raises(MaggieHipError, match='sparse_capacity'):
+        run()                                                                           # ... and the next forward refuses to go on
+    model.decoder.sparse_capacity_frac = 1.0
+    again = run()
+    assert torch.equal(again['detail_mask'], ref['detail_mask'])

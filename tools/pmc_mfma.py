@@ -11,6 +11,9 @@ for r in csv.DictReader(open(sys.argv[1])):
     if f:
         acc[f][r['Counter_Name']] += float(r['Counter_Value'])
         if r['Counter_Name'] == 'GRBM_GUI_ACTIVE': n[f] += 1
+NXCD = 8     # rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs of an MI355X: the device's active cycles are value / 8
 for f, c in acc.items():
-    util = c['SQ_VALU_MFMA_BUSY_CYCLES'] / max(c['GRBM_GUI_ACTIVE'] * 256 * 4, 1)
-    print('%-12s launches %d  MFMA busy cycles %.3g  GPU active cycles %.3g  MfmaUtil %.2f %%' % (f, n[f], c['SQ_VALU_MFMA_BUSY_CYCLES'], c['GRBM_GUI_ACTIVE'], 100 * util))
+    active = c['GRBM_GUI_ACTIVE'] / NXCD
+    util = c['SQ_VALU_MFMA_BUSY_CYCLES'] / max(active * 256 * 4, 1)
+    print('%-12s launches %d  MFMA busy cycles %.3g  device active cycles %.3g (GRBM_GUI_ACTIVE / %d XCDs)  MfmaUtil %.2f %%'
+          % (f, n[f], c['SQ_VALU_MFMA_BUSY_CYCLES'], active, NXCD, 100 * util))
