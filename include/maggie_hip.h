@@ -302,6 +302,16 @@ int mg_pyr_downT(const float* r, const float* q, const float* coef, const int32_
 int mg_loss_point_bwd(const float* p, const float* t, const float* w, const int32_t* flags, int P, int H, int W, const float* coef_rec,
                       const float* coef_grad, const float* dd, float* A, float* B, float* dp, const int32_t* pvalid, void* stream);
 
+/* The whole fused-loss pipeline of S (<= 3) output scales per call (alpha_os1 / os4 / os8 of arch/maggie.py:283-300 share shape and target): scale s
+ * reads p[s] and w[s] ([P][H][W] fp32 each) against the shared target t; pvalid as in mg_loss_point_fwd. Scratch buffers hold S * P planes,
+ * scale-major: flags [S*P], d / G0 / dd0 / A / B / dp at (H, W), down0 / G1 / r0 / dd1 at (H/2, W/2), down1 / G2 / r1 / dd2 at (H/4, W/4), down2 / r2 at
+ * (H/8, W/8); sums [S][512] accumulators, out [S][3] = (rec, lap, grad) per scale, g [S][3] their upstream gradients, coef [S][5]. H, W multiples of 8. */
+int mg_matting_losses_fwd(const float* const* p, const float* t, const float* const* w, const int32_t* pvalid, int S, int P, int H, int W, int32_t* flags,
+                          float* d, float* down0, float* down1, float* down2, float* G0, float* G1, float* G2, float* sums, float* out, void* stream);
+int mg_matting_losses_bwd(const float* g, const float* sums, const float* const* p, const float* t, const float* const* w, const int32_t* pvalid,
+                          const int32_t* flags, int S, int P, int H, int W, const float* G0, const float* G1, const float* G2, float* coef, float* r2,
+                          float* dd2, float* r1, float* dd1, float* r0, float* dd0, float* A, float* B, float* dp, void* stream);
+
 /* Batched SpectralNorm: all wrapped convolutions of a model in five launches. `descs` lives in device memory. */
 typedef struct mg_sn_desc {
     const float* W;      /* fp32 parameter weight_bar, [A][B][taps]                                   */

@@ -24,6 +24,11 @@ __device__ __forceinline__ int clampi(int k, int n) { return k < 0 ? 0 : (k >= n
 // workgroup of a launch ended in 2-3 same-address atomics, and those -- not the stencils -- set the kernel time (point_fwd 36 -> 52 -> 86 us
 // at 48 / 128 / 256 workgroups per plane); loss_finish / loss_coef sum the replicas.
 constexpr int LOSS_REPLICAS = 32, LOSS_STRIDE = 16;
+// The three output scales of the model (alpha_os1 / os4 / os8: same (P, H, W) shape, same target, their own weight planes) run through ONE set of
+// launches (round 3): plane index pl = scale * Pper + q; the predictions and weights of the scales are separate tensors (P3), the pyramid
+// scratch is one (S * Pper)-plane buffer, the accumulators of scale s start at sums + s * LOSS_SUMS. Pper == total planes: a single scale.
+struct P3 { const float* a[3]; };
+constexpr int LOSS_SUMS = LOSS_REPLICAS * LOSS_STRIDE;
 
 __device__ __forceinline__ void block_add(float v, float* dst, float* sh) {
     v = wave_sum(v);
@@ -45,6 +50,14 @@ __global__ __launch_bounds__(NT) void plane_flags_kernel(const float* __restrict
     int any = 0;
     for (int i = blockIdx.x * NT + threadIdx.x; i < HW; i += gridDim.x * NT) any |= (wp[i] > 0.f);
     // every writer stores the same value: a plain store (no read-modify-write) is enough, and one per workgroup instead of one atomic per wave
+    if (__syncthreads_or(any) && threadIdx.x == 0) flags[p] = 1;
+}
+
+__global__ __launch_bounds__(NT) void plane_flags3_kernel(const P3 w, int Pper, int HW, int* __restrict__ flags) {
+    const int p = blockIdx.y, sc = p / Pper;
+    const float* wp = w.a[sc] + (long)(p - sc * Pper) * HW;
+    int any = 0;
+    for (int i = blockIdx.x * NT + threadIdx.x; i < HW; i += gridDim.x * NT) any |= (wp[i] > 0.f);
     if (__syncthreads_or(any) && threadIdx.x == 0) flags[p] = 1;
 }
 
@@ -83,17 +96,18 @@ __device__ __forceinline__ float sobel_mag(const float* __restrict__ a, const fl
 }
 
 // d = p - t ; sums[0] += w|d| ; sums[1] += |sobel(p w) - sobel(t w)| ; sums[2] += w
-__global__ __launch_bounds__(NT) void point_fwd_kernel(const float* __restrict__ p, const float* __restrict__ t, const float* __restrict__ w,
+__global__ __launch_bounds__(NT) void point_fwd_kernel(const P3 p, const float* __restrict__ t, const P3 w,
                                                        const int* __restrict__ flags, int H, int W, float* __restrict__ d,
-                                                       float* __restrict__ sums, const int* __restrict__ pvalid) {
+                                                       float* __restrict__ sums, const int* __restrict__ pvalid, int Pper) {
     __shared__ float sh[NT / 64];
     const int pl = blockIdx.y;
     if (!flags[pl]) return;
+    const int sc = pl / Pper, pq = pl - sc * Pper;
     // pvalid (0 / 1 per plane): `pred * valid_masks` of arch/maggie.py:112-118 -- the prediction of a plane without ground-truth transition
     // region counts as zero -- applied on the fly instead of by three multiplies over the (N, 10, H, W) planes (and three in backward)
-    const float pv = (pvalid && !pvalid[pl]) ? 0.f : 1.f;
-    const long off = (long)pl * H * W;
-    const float *pp = p + off, *tp = t + off, *wp = w + off;
+    const float pv = (pvalid && !pvalid[pq]) ? 0.f : 1.f;
+    const long off = (long)pl * H * W, offq = (long)pq * H * W;
+    const float *pp = p.a[sc] + offq, *tp = t + offq, *wp = w.a[sc] + offq;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     for (int i = blockIdx.x * NT + threadIdx.x; i < H * W; i += gridDim.x * NT) {
         int y = i / W, x = i - y * W;
@@ -106,7 +120,7 @@ __global__ __launch_bounds__(NT) void point_fwd_kernel(const float* __restrict__
         float mt = sobel_mag(tp, wp, y, x, H, W, gx, gy);
         s1 += fabsf(mp - mt);
     }
-    float* srep = sums + ((blockIdx.y * gridDim.x + blockIdx.x) & (LOSS_REPLICAS - 1)) * LOSS_STRIDE;   // spread the same-address atomics
+    float* srep = sums + sc * LOSS_SUMS + ((blockIdx.y * gridDim.x + blockIdx.x) & (LOSS_REPLICAS - 1)) * LOSS_STRIDE;   // spread the same-address atomics
     block_add(s0, &srep[0], sh);
     block_add(s1, &srep[1], sh);
     block_add(s2, &srep[2], sh);
@@ -135,16 +149,17 @@ __global__ __launch_bounds__(NT) void pyr_down_kernel(const float* __restrict__ 
 }
 
 // L = x - 4 * gauss5 * zero_stuff(down);  sums[0] += |L| wl ; sums[1] += wl ; G = wl * sign(L);  wl = w0[(y << lvl), (x << lvl)]
-__global__ __launch_bounds__(NT) void pyr_lap_fwd_kernel(const float* __restrict__ x, const float* __restrict__ down, const float* __restrict__ w0,
+__global__ __launch_bounds__(NT) void pyr_lap_fwd_kernel(const float* __restrict__ x, const float* __restrict__ down, const P3 w0,
                                                          int lvl, int H0, int W0, const int* __restrict__ flags, int h, int w,
-                                                         float* __restrict__ G, float* __restrict__ sums) {
+                                                         float* __restrict__ G, float* __restrict__ sums, int Pper) {
     __shared__ float sh[NT / 64];
     const int pl = blockIdx.y;
     if (!flags[pl]) return;
+    const int sc = pl / Pper;
     const int hd = h >> 1, wd = w >> 1;
     const float* xp = x + (long)pl * h * w;
     const float* dp = down + (long)pl * hd * wd;
-    const float* wp = w0 + (long)pl * H0 * W0;
+    const float* wp = w0.a[sc] + (long)(pl - sc * Pper) * H0 * W0;
     float s0 = 0.f, s1 = 0.f;
     // four pixels per trip (independent chains: the plane is walked by few workgroups -- their count is bounded by the two same-address
     // atomics each ends with -- so a thread's ~20 pixels were ~20 exposed memory round trips)
@@ -187,19 +202,19 @@ __global__ __launch_bounds__(NT) void pyr_lap_fwd_kernel(const float* __restrict
         s1 += wl;
         G[(long)pl * h * w + o] = L > 0.f ? wl : (L < 0.f ? -wl : 0.f);
     }
-    float* srep = sums + ((blockIdx.y * gridDim.x + blockIdx.x) & (LOSS_REPLICAS - 1)) * LOSS_STRIDE;
+    float* srep = sums + sc * LOSS_SUMS + ((blockIdx.y * gridDim.x + blockIdx.x) & (LOSS_REPLICAS - 1)) * LOSS_STRIDE;
     block_add(s0, &srep[0], sh);
     block_add(s1, &srep[1], sh);
 }
 
 // r[P, h/2, w/2] = add - coef * U^T(q),  U = 4 * gauss5 * zero_stuff (reflect); q: [P, h, w]
 __global__ __launch_bounds__(NT) void pyr_upT_kernel(const float* __restrict__ q, const float* __restrict__ coef, const float* __restrict__ add,
-                                                     const int* __restrict__ flags, int h, int w, float* __restrict__ r) {
+                                                     const int* __restrict__ flags, int h, int w, float* __restrict__ r, int Pper) {
     const int pl = blockIdx.y;
     if (!flags[pl]) return;
     const int hd = h >> 1, wd = w >> 1;
     const float* qp = q + (long)pl * h * w;
-    const float c = coef[0];
+    const float c = coef[(pl / Pper) * 5];               // coefficient of this plane's scale (coef5 rows, see loss_coef_kernel)
     for (int o = blockIdx.x * NT + threadIdx.x; o < hd * wd; o += gridDim.x * NT) {
         int a = o / wd, b = o - a * wd;
         float acc = 0.f;
@@ -236,12 +251,12 @@ __global__ __launch_bounds__(NT) void pyr_upT_kernel(const float* __restrict__ q
 
 // dd[P, h, w] = coef * q + D^T(r),  D = decimate2(gauss5 * . ) (reflect); r: [P, h/2, w/2]
 __global__ __launch_bounds__(NT) void pyr_downT_kernel(const float* __restrict__ r, const float* __restrict__ q, const float* __restrict__ coef,
-                                                       const int* __restrict__ flags, int h, int w, float* __restrict__ dd) {
+                                                       const int* __restrict__ flags, int h, int w, float* __restrict__ dd, int Pper) {
     const int pl = blockIdx.y;
     if (!flags[pl]) return;
     const int hd = h >> 1, wd = w >> 1;
     const float* rp = r + (long)pl * hd * wd;
-    const float c = coef[0];
+    const float c = coef[(pl / Pper) * 5];
     for (int o = blockIdx.x * NT + threadIdx.x; o < h * w; o += gridDim.x * NT) {
         int Y = o / w, X = o - Y * w;
         float acc = 0.f;
@@ -279,14 +294,15 @@ __global__ __launch_bounds__(NT) void pyr_downT_kernel(const float* __restrict__
 }
 
 // Sobel backward pass 1: A = s * gx / mag, B = s * gy / mag with s = sign(mag_p - mag_t)   (coef applied in pass 2)
-__global__ __launch_bounds__(NT) void sobel_bwd1_kernel(const float* __restrict__ p, const float* __restrict__ t, const float* __restrict__ w,
+__global__ __launch_bounds__(NT) void sobel_bwd1_kernel(const P3 p, const float* __restrict__ t, const P3 w,
                                                         const int* __restrict__ flags, int H, int W, float* __restrict__ A, float* __restrict__ B,
-                                                        const int* __restrict__ pvalid) {
+                                                        const int* __restrict__ pvalid, int Pper) {
     const int pl = blockIdx.y;
     if (!flags[pl]) return;
-    if (pvalid && !pvalid[pl]) return;                  // masked prediction: point_bwd writes a zero gradient without reading A / B
-    const long off = (long)pl * H * W;
-    const float *pp = p + off, *tp = t + off, *wp = w + off;
+    const int sc = pl / Pper, pq = pl - sc * Pper;
+    if (pvalid && !pvalid[pq]) return;                  // masked prediction: point_bwd writes a zero gradient without reading A / B
+    const long off = (long)pl * H * W, offq = (long)pq * H * W;
+    const float *pp = p.a[sc] + offq, *tp = t + offq, *wp = w.a[sc] + offq;
     for (int i = blockIdx.x * NT + threadIdx.x; i < H * W; i += gridDim.x * NT) {
         int y = i / W, x = i - y * W;
         float gx, gy, tx, ty;
@@ -299,23 +315,27 @@ __global__ __launch_bounds__(NT) void sobel_bwd1_kernel(const float* __restrict_
 }
 
 // dpred = coef_rec * w * sign(p - t) + dd_lap + coef_grad * w * SobelAdjoint(A, B)   (replicate padding adjoint)
-__global__ __launch_bounds__(NT) void point_bwd_kernel(const float* __restrict__ p, const float* __restrict__ t, const float* __restrict__ w,
+__global__ __launch_bounds__(NT) void point_bwd_kernel(const P3 p, const float* __restrict__ t, const P3 w,
                                                        const int* __restrict__ flags, int H, int W, const float* __restrict__ coef_rec,
                                                        const float* __restrict__ coef_grad, const float* __restrict__ dd,
                                                        const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ dp,
-                                                       const int* __restrict__ pvalid) {
+                                                       const int* __restrict__ pvalid, int Pper) {
     const int pl = blockIdx.y;
-    const long off = (long)pl * H * W;
-    if (!flags[pl] || (pvalid && !pvalid[pl])) {        // a plane without weight, or a masked prediction (d(p * 0)/dp = 0): zero gradient, written here
+    const int sc = pl / Pper, pq = pl - sc * Pper;
+    const long off = (long)pl * H * W, offq = (long)pq * H * W;
+    if (!flags[pl] || (pvalid && !pvalid[pq])) {        // a plane without weight, or a masked prediction (d(p * 0)/dp = 0): zero gradient, written here
         for (int idx = blockIdx.x * NT + threadIdx.x; idx < H * W; idx += gridDim.x * NT) dp[off + idx] = 0.f;
         return;
     }
-    const float cr = coef_rec[0], cg = coef_grad[0];
+    const float cr = coef_rec[sc * 5], cg = coef_grad[sc * 5];
+    const float* __restrict__ pp = p.a[sc] + offq;
+    const float* __restrict__ tp = t + offq;
+    const float* __restrict__ wp = w.a[sc] + offq;
     const float kx[3][3] = {{-1.f, 0.f, 1.f}, {-2.f, 0.f, 2.f}, {-1.f, 0.f, 1.f}};
     for (int idx = blockIdx.x * NT + threadIdx.x; idx < H * W; idx += gridDim.x * NT) {
         int Y = idx / W, X = idx - Y * W;
-        float dv = p[off + idx] - t[off + idx];
-        float wv = w[off + idx];
+        float dv = pp[idx] - tp[idx];
+        float wv = wp[idx];
         float g = cr * wv * (dv > 0.f ? 1.f : (dv < 0.f ? -1.f : 0.f));
         if (dd) g += dd[off + idx];
         float acc = 0.f;
@@ -363,8 +383,9 @@ __device__ __forceinline__ void loss_sum_replicas(const float* __restrict__ rep,
     }
     __syncthreads();
 }
-__global__ void loss_finish_kernel(const float* __restrict__ rep, float* __restrict__ out) {
+__global__ void loss_finish_kernel(const float* __restrict__ rep, float* __restrict__ out) {      // one workgroup per scale
     __shared__ float sums[LOSS_STRIDE];
+    rep += blockIdx.x * LOSS_SUMS; out += blockIdx.x * 3;
     loss_sum_replicas(rep, sums);
     if (threadIdx.x == 0) {
         out[0] = sums[0] / (sums[2] + 1e-8f);
@@ -373,8 +394,9 @@ __global__ void loss_finish_kernel(const float* __restrict__ rep, float* __restr
     }
 }
 // upstream gradient (d rec, d lap, d grad) -> the five per-term coefficients of the backward kernels
-__global__ void loss_coef_kernel(const float* __restrict__ g, const float* __restrict__ rep, float* __restrict__ coef) {
+__global__ void loss_coef_kernel(const float* __restrict__ g, const float* __restrict__ rep, float* __restrict__ coef) {   // one workgroup per scale
     __shared__ float sums[LOSS_STRIDE];
+    rep += blockIdx.x * LOSS_SUMS; g += blockIdx.x * 3; coef += blockIdx.x * 5;
     loss_sum_replicas(rep, sums);
     if (threadIdx.x == 0) {
         coef[0] = g[0] / (sums[2] + 1e-8f);
@@ -430,7 +452,7 @@ extern "C" int mg_os8_weight_ex(const float* gt, const float* a8, int P, long HW
 extern "C" int mg_loss_point_fwd(const float* p, const float* t, const float* w, const int32_t* flags, int P, int H, int W, float* d,
                                  float* sums, const int32_t* pvalid, void* stream) {
     if (P <= 0) return 0;
-    hipLaunchKernelGGL(point_fwd_kernel, grid2((long)H * W, P, REDUCING_BLOCKS_PER_PLANE), dim3(NT), 0, (hipStream_t)stream, p, t, w, flags, H, W, d, sums, pvalid);
+    hipLaunchKernelGGL(point_fwd_kernel, grid2((long)H * W, P, REDUCING_BLOCKS_PER_PLANE), dim3(NT), 0, (hipStream_t)stream, P3{{p, nullptr, nullptr}}, t, P3{{w, nullptr, nullptr}}, flags, H, W, d, sums, pvalid, P);
     MG_CHECK_LAUNCH();
     return 0;
 }
@@ -446,21 +468,21 @@ extern "C" int mg_pyr_down(const float* x, const int32_t* flags, int P, int h, i
 extern "C" int mg_pyr_lap_fwd(const float* x, const float* down, const float* w0, int lvl, int H0, int W0, const int32_t* flags, int P, int h,
                               int w, float* G, float* sums, void* stream) {
     if (P <= 0) return 0;
-    hipLaunchKernelGGL(pyr_lap_fwd_kernel, grid2((long)h * w, P, REDUCING_BLOCKS_PER_PLANE), dim3(NT), 0, (hipStream_t)stream, x, down, w0, lvl, H0, W0, flags, h, w, G, sums);
+    hipLaunchKernelGGL(pyr_lap_fwd_kernel, grid2((long)h * w, P, REDUCING_BLOCKS_PER_PLANE), dim3(NT), 0, (hipStream_t)stream, x, down, P3{{w0, nullptr, nullptr}}, lvl, H0, W0, flags, h, w, G, sums, P);
     MG_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int mg_pyr_upT(const float* q, const float* coef, const float* add, const int32_t* flags, int P, int h, int w, float* r, void* stream) {
     if (P <= 0) return 0;
-    hipLaunchKernelGGL(pyr_upT_kernel, grid2((long)(h / 2) * (w / 2), P), dim3(NT), 0, (hipStream_t)stream, q, coef, add, flags, h, w, r);
+    hipLaunchKernelGGL(pyr_upT_kernel, grid2((long)(h / 2) * (w / 2), P), dim3(NT), 0, (hipStream_t)stream, q, coef, add, flags, h, w, r, P);
     MG_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int mg_pyr_downT(const float* r, const float* q, const float* coef, const int32_t* flags, int P, int h, int w, float* dd, void* stream) {
     if (P <= 0) return 0;
-    hipLaunchKernelGGL(pyr_downT_kernel, grid2((long)h * w, P), dim3(NT), 0, (hipStream_t)stream, r, q, coef, flags, h, w, dd);
+    hipLaunchKernelGGL(pyr_downT_kernel, grid2((long)h * w, P), dim3(NT), 0, (hipStream_t)stream, r, q, coef, flags, h, w, dd, P);
     MG_CHECK_LAUNCH();
     return 0;
 }
@@ -469,8 +491,62 @@ extern "C" int mg_loss_point_bwd(const float* p, const float* t, const float* w,
                                  const float* coef_grad, const float* dd, float* A, float* B, float* dp, const int32_t* pvalid, void* stream) {
     if (P <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(sobel_bwd1_kernel, grid2((long)H * W, P), dim3(NT), 0, st, p, t, w, flags, H, W, A, B, pvalid);
-    hipLaunchKernelGGL(point_bwd_kernel, grid2((long)H * W, P), dim3(NT), 0, st, p, t, w, flags, H, W, coef_rec, coef_grad, dd, A, B, dp, pvalid);
+    const P3 pp{{p, nullptr, nullptr}}, ww{{w, nullptr, nullptr}};
+    hipLaunchKernelGGL(sobel_bwd1_kernel, grid2((long)H * W, P), dim3(NT), 0, st, pp, t, ww, flags, H, W, A, B, pvalid, P);
+    hipLaunchKernelGGL(point_bwd_kernel, grid2((long)H * W, P), dim3(NT), 0, st, pp, t, ww, flags, H, W, coef_rec, coef_grad, dd, A, B, dp, pvalid, P);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- the whole loss pipeline of S (<= 3) output scales in one call each way (round 3). Scale s reads prediction p[s] and weight w[s] ([P][H][W]
+// each), all share the target t; every scratch buffer holds S * P planes (scale-major). Forward: 9 launches whatever S is (was 9 per scale).
+extern "C" int mg_matting_losses_fwd(const float* const* p, const float* t, const float* const* w, const int32_t* pvalid, int S, int P, int H, int W,
+                                     int32_t* flags, float* d, float* down0, float* down1, float* down2, float* G0, float* G1, float* G2, float* sums,
+                                     float* out, void* stream) {
+    if (S < 1 || S > 3 || P <= 0) return -2;
+    if ((H & 7) || (W & 7) || H < 16 || W < 16) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    P3 pp{{nullptr, nullptr, nullptr}}, ww{{nullptr, nullptr, nullptr}};
+    for (int i = 0; i < S; ++i) { pp.a[i] = p[i]; ww.a[i] = w[i]; }
+    const int SP = S * P;
+    hipError_t e = mg_zero_words(flags, (long)SP, st); if (e != hipSuccess) return (int)e;
+    e = mg_zero_words(sums, (long)S * LOSS_SUMS, st); if (e != hipSuccess) return (int)e;
+    { dim3 g = grid2((long)H * W, SP); if (g.x > 64) g.x = 64; hipLaunchKernelGGL(plane_flags3_kernel, g, dim3(NT), 0, st, ww, P, H * W, flags); }
+    hipLaunchKernelGGL(point_fwd_kernel, grid2((long)H * W, SP, REDUCING_BLOCKS_PER_PLANE), dim3(NT), 0, st, pp, t, ww, flags, H, W, d, sums, pvalid, P);
+    const float* x = d; float* downs[3] = {down0, down1, down2}; float* Gs[3] = {G0, G1, G2};
+    int h = H, wd = W;
+    for (int lvl = 0; lvl < 3; ++lvl) {
+        hipLaunchKernelGGL(pyr_down_kernel, grid2((long)(h / 2) * (wd / 2), SP), dim3(NT), 0, st, x, flags, h, wd, downs[lvl]);
+        hipLaunchKernelGGL(pyr_lap_fwd_kernel, grid2((long)h * wd, SP, REDUCING_BLOCKS_PER_PLANE), dim3(NT), 0, st, x, (const float*)downs[lvl], ww, lvl, H, W,
+                           flags, h, wd, Gs[lvl], sums + 3 + 2 * lvl, P);
+        x = downs[lvl]; h >>= 1; wd >>= 1;
+    }
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(S), dim3(64), 0, st, (const float*)sums, out);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+/* backward of the above: g [S][3] upstream gradients of (rec, lap, grad) -> dp [S*P][H][W]. Scratch: coef [S][5], r2 (H/8), dd2 (H/4), r1 (H/4), dd1
+ * (H/2), r0 (H/2), dd0 (H), A, B (H): S*P planes each. */
+extern "C" int mg_matting_losses_bwd(const float* g, const float* sums, const float* const* p, const float* t, const float* const* w,
+                                     const int32_t* pvalid, const int32_t* flags, int S, int P, int H, int W, const float* G0, const float* G1,
+                                     const float* G2, float* coef, float* r2, float* dd2, float* r1, float* dd1, float* r0, float* dd0, float* A, float* B,
+                                     float* dp, void* stream) {
+    if (S < 1 || S > 3 || P <= 0) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    P3 pp{{nullptr, nullptr, nullptr}}, ww{{nullptr, nullptr, nullptr}};
+    for (int i = 0; i < S; ++i) { pp.a[i] = p[i]; ww.a[i] = w[i]; }
+    const int SP = S * P;
+    hipLaunchKernelGGL(loss_coef_kernel, dim3(S), dim3(64), 0, st, g, sums, coef);
+    hipLaunchKernelGGL(pyr_upT_kernel, grid2((long)(H / 8) * (W / 8), SP), dim3(NT), 0, st, G2, (const float*)(coef + 4), (const float*)nullptr, flags, H / 4, W / 4, r2, P);
+    hipLaunchKernelGGL(pyr_downT_kernel, grid2((long)(H / 4) * (W / 4), SP), dim3(NT), 0, st, (const float*)r2, G2, (const float*)(coef + 4), flags, H / 4, W / 4, dd2, P);
+    hipLaunchKernelGGL(pyr_upT_kernel, grid2((long)(H / 4) * (W / 4), SP), dim3(NT), 0, st, G1, (const float*)(coef + 3), (const float*)dd2, flags, H / 2, W / 2, r1, P);
+    hipLaunchKernelGGL(pyr_downT_kernel, grid2((long)(H / 2) * (W / 2), SP), dim3(NT), 0, st, (const float*)r1, G1, (const float*)(coef + 3), flags, H / 2, W / 2, dd1, P);
+    hipLaunchKernelGGL(pyr_upT_kernel, grid2((long)(H / 2) * (W / 2), SP), dim3(NT), 0, st, G0, (const float*)(coef + 2), (const float*)dd1, flags, H, W, r0, P);
+    hipLaunchKernelGGL(pyr_downT_kernel, grid2((long)H * W, SP), dim3(NT), 0, st, (const float*)r0, G0, (const float*)(coef + 2), flags, H, W, dd0, P);
+    hipLaunchKernelGGL(sobel_bwd1_kernel, grid2((long)H * W, SP), dim3(NT), 0, st, pp, t, ww, flags, H, W, A, B, pvalid, P);
+    hipLaunchKernelGGL(point_bwd_kernel, grid2((long)H * W, SP), dim3(NT), 0, st, pp, t, ww, flags, H, W, (const float*)coef, (const float*)(coef + 1),
+                       (const float*)dd0, (const float*)A, (const float*)B, dp, pvalid, P);
     MG_CHECK_LAUNCH();
     return 0;
 }

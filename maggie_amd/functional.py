@@ -1162,6 +1162,74 @@ class MattingLosses(torch.autograd.Function):
         return dp.view(ctx.shape), None, None, None
 
 
+class MattingLossesMulti(torch.autograd.Function):
+    """The fused loss pipeline of up to three output scales in ONE set of launches each way (mg_matting_losses_fwd / _bwd): preds and weights
+    are S tensors of the same (.., H, W) shape, the target is shared. -> (S, 3) tensor of (rec, lap, grad) per scale; backward yields d/dpred."""
+
+    @staticmethod
+    def forward(ctx, target, pvalid, *pw):
+        S = len(pw) // 2
+        preds, weights = pw[:S], pw[S:]
+        H, W_ = preds[0].shape[-2:]
+        assert H % 8 == 0 and W_ % 8 == 0
+        ps = [x.detach().float().contiguous() for x in preds]
+        ws = [(x.expand_as(preds[0]) if x.shape != preds[0].shape else x).detach().float().contiguous() for x in weights]
+        t = target.detach().float().contiguous()
+        P = ps[0].numel() // (H * W_)
+        dev = t.device
+        K.hip.need_cuda(t, *ps, *ws)
+        if pvalid is not None:
+            assert pvalid.dtype == torch.int32 and pvalid.numel() == P and pvalid.is_contiguous()
+        SP = S * P
+        new = lambda hh, ww: torch.empty((SP, hh, ww), dtype=torch.float32, device=dev)      # noqa: E731
+        flags = ARENA.acc(SP, dev, torch.int32)
+        sums = ARENA.acc(S * 512, dev)
+        d, downs = new(H, W_), [new(H >> 1, W_ >> 1), new(H >> 2, W_ >> 2), new(H >> 3, W_ >> 3)]
+        Gs = [new(H, W_), new(H >> 1, W_ >> 1), new(H >> 2, W_ >> 2)]
+        out = torch.empty((S, 3), dtype=torch.float32, device=dev)
+        parr = (K.ctypes.c_void_p * S)(*[x.data_ptr() for x in ps])
+        warr = (K.ctypes.c_void_p * S)(*[x.data_ptr() for x in ws])
+        ptr = K.hip.ptr
+        K.hip.call('mg_matting_losses_fwd', parr, ptr(t), warr, ptr(pvalid), K.c_int(S), K.c_int(P), K.c_int(H), K.c_int(W_), ptr(flags), ptr(d),
+                   ptr(downs[0]), ptr(downs[1]), ptr(downs[2]), ptr(Gs[0]), ptr(Gs[1]), ptr(Gs[2]), ptr(sums), ptr(out), K.hip.stream())
+        ctx.save_for_backward(t, flags, sums, *Gs, *ps, *ws)
+        ctx.pvalid, ctx.S, ctx.shape = pvalid, S, preds[0].shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        S = ctx.S
+        saved = ctx.saved_tensors
+        t, flags, sums, G0, G1, G2 = saved[:6]
+        ps, ws = saved[6:6 + S], saved[6 + S:6 + 2 * S]
+        SP, H, W_ = G0.shape
+        P = SP // S
+        dev = t.device
+        new = lambda hh, ww: torch.empty((SP, hh, ww), dtype=torch.float32, device=dev)      # noqa: E731
+        coef = torch.empty((S, 5), dtype=torch.float32, device=dev)
+        r2, dd2, r1, dd1 = new(H >> 3, W_ >> 3), new(H >> 2, W_ >> 2), new(H >> 2, W_ >> 2), new(H >> 1, W_ >> 1)
+        r0, dd0, A, B, dp = new(H >> 1, W_ >> 1), new(H, W_), new(H, W_), new(H, W_), new(H, W_)
+        parr = (K.ctypes.c_void_p * S)(*[x.data_ptr() for x in ps])
+        warr = (K.ctypes.c_void_p * S)(*[x.data_ptr() for x in ws])
+        ptr = K.hip.ptr
+        K.hip.call('mg_matting_losses_bwd', ptr(g.float().contiguous()), ptr(sums), parr, ptr(t), warr, ptr(ctx.pvalid), ptr(flags), K.c_int(S), K.c_int(P),
+                   K.c_int(H), K.c_int(W_), ptr(G0), ptr(G1), ptr(G2), ptr(coef), ptr(r2), ptr(dd2), ptr(r1), ptr(dd1), ptr(r0), ptr(dd0), ptr(A), ptr(B),
+                   ptr(dp), K.hip.stream())
+        dps = tuple(dp[i * P:(i + 1) * P].view(ctx.shape) for i in range(S))
+        return (None, None) + dps + (None,) * S
+
+
+def matting_losses_multi(preds, target, weights, pvalid=None):
+    """[(rec, lap, grad)] per prediction: the scales' loss pipelines as one batched set of launches."""
+    if not LOSS_MULTI or len(preds) == 1 or len(preds) > 3:
+        return [matting_losses(p_, target, w_, pvalid) for p_, w_ in zip(preds, weights)]
+    out = MattingLossesMulti.apply(target, pvalid, *preds, *weights)
+    return [row.unbind(0) for row in out.unbind(0)]
+
+
+LOSS_MULTI = os.environ.get('MAGGIE_LOSS_MULTI', '1') != '0'
+
+
 def os8_weight(alphas, a8, reweight=True, pvalid=None):
     """Loss weight of the OS8 prediction (arch/maggie.py:271-281): [plane has ground truth] + [pixel in the unknown band of gt or a8]."""
     gt, a = alphas.detach().contiguous(), a8.detach().contiguous()

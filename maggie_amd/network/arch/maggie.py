@@ -576,10 +576,8 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             alphas = torch.cat([alphas, padding], dim=1)
             trans_gt = torch.cat([trans_gt, padding], dim=1)
         # one fused HIP pipeline per scale: weighted L1 + Laplacian-pyramid L1 + Sobel-gradient L1 (fwd sums + exact bwd)
-        # (the three scales are independent strings of ~15 small launches each way: side by side as parallel branches of the graph)
-        (r1, l1_, g1), (r4, l4_, g4), (r8, l8_, g8) = MF.parallel_branches(
-            [lambda: MF.matting_losses(a1, alphas, weight_os1, pvalid), lambda: MF.matting_losses(a4, alphas, weight_os4, pvalid),
-             lambda: MF.matting_losses(a8, alphas, weight_os8, pvalid)], alphas.device, 'loss')
+        # the three scales share shape and target: ONE batched pipeline (9 launches forward, 9 backward, whatever the number of scales)
+        (r1, l1_, g1), (r4, l4_, g4), (r8, l8_, g8) = MF.matting_losses_multi([a1, a4, a8], alphas, [weight_os1, weight_os4, weight_os8], pvalid)
         # The sums of arch/maggie.py:283-300 (loss_x = 2 * os1 + os4 + os8, total = sum_x w_x * loss_x): the per-family values are for the log
         # (no gradient flows through them -- only through `total`), `total` is ONE weighted sum of the nine (twelve) scale terms
         # (mg_scalar_lincomb: one launch forward, one backward, instead of ~12 + ~14 one-element torch kernels)

@@ -1232,3 +1232,48 @@ def test_token_linear_multi_equals_separate_layers():
     for k in g0:
         assert torch.allclose(g1[k], g0[k], atol=2e-5, rtol=1e-5), (k, float((g1[k] - g0[k]).abs().max()))      # (a tensor shared by several layers: autograd's sum order)
     assert torch.allclose(l1[0], l0[0], atol=2e-5, rtol=1e-5) and torch.allclose(l1[1], l0[1], atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('with_valid', [False, True])
+def test_matting_losses_of_three_scales_in_one_pipeline(with_valid):
+    """mg_matting_losses_fwd / _bwd: the loss pipelines of alpha_os1 / os4 / os8 (arch/maggie.py:283-300: same shape, same target, their own weights)
+    as ONE batched set of launches must equal three single-scale pipelines (values and gradients), also with the per-plane validity of
+    `pred * valid_masks` (:112-118) folded in -- which itself must equal multiplying the predictions first."""
+    from maggie_amd import functional as MF
+    dev = _dev()
+    rs = np.random.RandomState(21)
+    P, H, W = (2, 5), 48, 72
+    mk = lambda: torch.from_numpy(rs.uniform(size=P + (H, W)).astype(np.float32)).to(dev)       # noqa: E731
+    preds = [mk() for _ in range(3)]
+    tgt = mk()
+    wts = [(mk() > t_).float() * s_ for t_, s_ in ((0.4, 1.0), (0.7, 1.0), (0.2, 2.0))]
+    wts[0][:, 1] = 0
+    wts[1][:, 1] = 0
+    wts[2][:, 3] = 0
+    pvalid = torch.tensor([1, 1, 0, 1, 1, 1, 1, 1, 0, 1], dtype=torch.int32, device=dev) if with_valid else None
+    coefs = torch.tensor([[1.3, 0.7, 2.1], [0.4, 1.9, 0.6], [1.0, 1.0, 1.0]], device=dev)
+
+    def run(multi):
+        prev, MF.LOSS_MULTI = MF.LOSS_MULTI, multi
+        try:
+            ps = [p_.clone().requires_grad_(True) for p_ in preds]
+            out = torch.stack([torch.stack(r) for r in MF.matting_losses_multi(ps, tgt, wts, pvalid)])
+            (out * coefs).sum().backward()
+            return out.detach(), [p_.grad.clone() for p_ in ps]
+        finally:
+            MF.LOSS_MULTI = prev
+
+    o1, g1 = run(True)
+    o0, g0 = run(False)
+    assert torch.allclose(o1, o0, rtol=2e-6, atol=1e-7), (o1, o0)
+    for a, b in zip(g1, g0):
+        assert (a - b).abs().max().item() <= 1e-6 * max(b.abs().max().item(), 1e-12) + 1e-9
+    if with_valid:
+        # the folded validity == multiplying the predictions by the 0 / 1 plane factor before the loss
+        vm = pvalid.float().view(2, 5, 1, 1)
+        ps = [(p_ * vm).requires_grad_(True) for p_ in preds]
+        ref = torch.stack([torch.stack(r) for r in MF.matting_losses_multi(ps, tgt, wts, None)])
+        assert torch.allclose(o1, ref, rtol=2e-6, atol=1e-7)
+        for g_ in g1:
+            assert float(g_.view(10, H, W)[2].abs().max()) == 0.0 and float(g_.view(10, H, W)[8].abs().max()) == 0.0
