@@ -21,14 +21,14 @@ constexpr int NT = 256;
 struct ColGeom {
     int tx, ty, groups, rb, rpb;
 };
-static inline ColGeom col_geom(int M, int C, int ce, int max_rb) {
+static inline ColGeom col_geom(int M, int C, int ce, int max_rb, int nt = NT, int rpt = 4) {
     ColGeom g;
     const int cpr = C / ce;
     g.tx = cpr < 8 ? cpr : 8;
-    g.ty = NT / g.tx;
+    g.ty = nt / g.tx;
     g.groups = (cpr + g.tx - 1) / g.tx;
     int want = 1024 / g.groups; if (want < 1) want = 1; if (want > max_rb) want = max_rb;
-    int rb = (M + g.ty * 4 - 1) / (g.ty * 4); if (rb < 1) rb = 1; if (rb > want) rb = want;
+    int rb = (M + g.ty * rpt - 1) / (g.ty * rpt); if (rb < 1) rb = 1; if (rb > want) rb = want;
     g.rpb = (M + rb - 1) / rb;
     g.rb = (M + g.rpb - 1) / g.rpb;
     return g;
@@ -44,12 +44,39 @@ __device__ __forceinline__ void col_block_reduce(float* sred, const float* part,
         for (int k = 0; k < NV; ++k) sred[iy * width + ix * NV + k] = part[k];
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < width; j += NT) {
+    for (int j = threadIdx.x; j < width; j += (int)blockDim.x) {
         float acc = 0.f;
         for (int r = 0; r < ty; ++r) acc += sred[r * width + j];
         const int cx = j / NV, k = j - cx * NV, a = k / ce, e = k - a * ce;
         const int c = c_base + cx * ce + e;
         if (c < C) atomicAdd((a == 0 ? dst0 : dst1) + c, acc);
+    }
+}
+
+// the same reduction for the 1024-thread blocks (tx a power of two): rows of a wave first meet in registers (butterfly over the lanes that share a
+// channel chunk), so LDS holds one row per WAVE instead of one per thread row (64 KB -> 8 KB at 1024 threads)
+template <int NV>
+__device__ __forceinline__ void col_block_reduce_wave(float* sred, float* part, int tx, int ix, bool active,
+                                                      float* __restrict__ dst0, float* __restrict__ dst1, int c_base, int C, int ce) {
+    const int width = tx * NV;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
+    for (int off = tx; off < 64; off <<= 1) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) part[k] += __shfl_xor(part[k], off);
+    }
+    if (lane < tx && active) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) sred[wave * width + ix * NV + k] = part[k];
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < width; j += (int)blockDim.x) {
+        const int cx = j / NV, k = j - cx * NV, a = k / ce, e = k - a * ce;
+        const int c = c_base + cx * ce + e;
+        if (c < C) {
+            float acc = 0.f;
+            for (int r = 0; r < nw; ++r) acc += sred[r * width + j];
+            atomicAdd((a == 0 ? dst0 : dst1) + c, acc);
+        }
     }
 }
 
@@ -443,8 +470,8 @@ __device__ __forceinline__ void load_g(const mg_rowwise_params& p, int m, int c0
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const mg_rowwise_params p, int rows_per_block, int tx, int ty) {
+template <typename T, int BT = NT>
+__global__ __launch_bounds__(BT) void bn_bwd_reduce_kernel(const mg_rowwise_params p, int rows_per_block, int tx, int ty) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
     extern __shared__ float sred[];
@@ -484,7 +511,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const mg_rowwise_para
             for (int e = 0; e < CE; ++e) { part[e] += g0[e]; part[CE + e] += g0[e] * (x0[e] - mu[e]) * is[e]; }
         }
     }
-    col_block_reduce<2 * CE>(sred, part, tx, ty, ix, iy, active, p.sums, p.sums + C, blockIdx.y * tx * CE, C, CE);
+    if (BT > NT) col_block_reduce_wave<2 * CE>(sred, part, tx, ix, active, p.sums, p.sums + C, blockIdx.y * tx * CE, C, CE);
+    else col_block_reduce<2 * CE>(sred, part, tx, ty, ix, iy, active, p.sums, p.sums + C, blockIdx.y * tx * CE, C, CE);
 }
 
 template <typename T>
@@ -742,9 +770,17 @@ extern "C" int mg_bn_bwd_reduce(const mg_rowwise_params* p, void* stream) {
     // 1M x 32: 109 / 60 / 45 / 52; 262144 x 64: 56 / 35 / 31 / 43; 262144 x 32: 29 / 21.5 / 24 / 36; 65536 x 64: 19 / 13 / 19 / 19)
     static const int env_rb = [] { const char* e = getenv("MG_BN_RB"); return e ? atoi(e) : 0; }();
     const int max_rb = env_rb > 0 ? env_rb : ((long)p->M * p->C >= (16l << 20) ? 512 : 256);
-    const ColGeom g = col_geom(p->M, p->C, ce, max_rb);
-    const size_t lds = (size_t)g.ty * g.tx * 2 * ce * sizeof(float);
-    if (p->dtype == MG_BF16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty);
+    ColGeom g = col_geom(p->M, p->C, ce, max_rb);
+    // the row-block count is capped by the atomics, not by the work: when a block still walks >= 256 rows, 1024-thread blocks put four times the
+    // waves (loads in flight) behind the same number of atomics (65536 x 64..128: 18.6 us with 4 waves per CU, the tensor is 16-32 MB)
+    static const int wide_on = [] { const char* e = getenv("MG_BN_WIDE"); return e ? atoi(e) : 1; }();
+    const bool wide = wide_on && !p->m_dev && max_rb == 256 && g.rpb >= 256 && (g.tx & (g.tx - 1)) == 0;      // (the >= 16 M element layers: 25 -> 36 us)
+    if (wide) g = col_geom(p->M, p->C, ce, max_rb, 1024, 2);
+    const size_t lds = wide ? (size_t)16 * g.tx * 2 * ce * sizeof(float) : (size_t)g.ty * g.tx * 2 * ce * sizeof(float);
+    if (wide) {
+        if (p->dtype == MG_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16raw, 1024>), dim3(g.rb, g.groups), dim3(1024), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty);
+        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 1024>), dim3(g.rb, g.groups), dim3(1024), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty);
+    } else if (p->dtype == MG_BF16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty);
     else hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty);
     MG_CHECK_LAUNCH();
     return 0;

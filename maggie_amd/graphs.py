@@ -33,6 +33,9 @@ class _Replay(torch.autograd.Function):
     def forward(ctx, g, *tensors):
         g.fwd.replay()
         ctx.g = g
+        # no zero tensors for outputs that took no part in the loss (the detail graph hands back four 42 MB alpha planes, the detail mask and a
+        # dozen logged loss scalars next to loss/total: autograd would fill a zero gradient for each of them on every step)
+        ctx.set_materialize_grads(False)
         outs = tuple(o.detach() for o in g.static_outputs)
         ctx.mark_non_differentiable(*[o for o, s in zip(outs, g.static_outputs) if not s.requires_grad])
         return outs
@@ -50,14 +53,20 @@ class _Replay(torch.autograd.Function):
     def backward(ctx, *grads):
         g = ctx.g
         src, dst, zero = [], [], []
-        for s, gr in zip(g.static_grad_outputs, grads):
+        clean = g.__dict__.setdefault('_grad_out_clean', set())  # slots known to hold zeros (nothing has been copied into them since the last fill)
+        for k, (s, gr) in enumerate(zip(g.static_grad_outputs, grads)):
             if s is None:
                 continue
             if gr is None:
-                zero.append(s)                                    # this output took no part in the loss: its slot must not keep a stale gradient
+                if k not in clean:
+                    zero.append(s)                                # this output took no part in the loss: its slot must not keep a stale gradient
+                    clean.add(k)
             elif s.data_ptr() != gr.data_ptr():
                 src.append(gr.to(s.dtype) if gr.dtype != s.dtype else gr)
                 dst.append(s)
+                clean.discard(k)
+            else:
+                clean.discard(k)
         if zero:
             torch._foreach_zero_(zero)
         if dst:

@@ -7,11 +7,15 @@ import random
 import sys
 import traceback
 
-os.environ['MAGGIE_HIP_GRAPHS'] = '0'
+REPLAY = os.environ.get('GRAPHS', '0') == '2'          # 2: the ops issued AROUND the graph replays of a steady-state step
+GRAPHS = os.environ.get('GRAPHS', '0') == '1'      # 1: count the ops recorded INTO the hipGraphs (first step = warm-up + capture; only ops issued while capturing)
+if not GRAPHS and not REPLAY:
+    os.environ['MAGGIE_HIP_GRAPHS'] = '0'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from torch.utils._python_dispatch import TorchDispatchMode
+from torch.utils._pytree import tree_leaves
 
 from maggie_amd.network import build_model
 from maggie_amd.optim import FlatAdamW
@@ -38,23 +42,22 @@ SHAPES = os.environ.get('SHAPES', '0') == '1'
 class Mode(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = str(func)
+        out = func(*args, **(kwargs or {}))
         if not any(s in name for s in SKIP):
-            big = 0
-            for a in list(args) + list((kwargs or {}).values()):
-                if torch.is_tensor(a) and a.is_cuda:
-                    big = max(big, a.numel())
-            if big > 0:
+            # operands AND results, lists flattened (cat / stack / _foreach_* take lists; zeros / full have no tensor operand at all)
+            leaves = [a for a in tree_leaves((args, kwargs or {}, out)) if torch.is_tensor(a) and a.is_cuda]
+            if leaves and (not GRAPHS or torch.cuda.is_current_stream_capturing()):
                 where = 'autograd engine / no maggie_amd frame'
                 for fs in reversed(traceback.extract_stack(limit=40)):
                     if ('maggie_amd' in fs.filename or 'dispatch_ops' in fs.filename) and fs.name != '__torch_dispatch__':
                         where = '%s:%d %s' % (fs.filename.split('repo/')[-1], fs.lineno, fs.name)
                         break
-                if SHAPES and ('dispatch_ops' in where or where.startswith('autograd engine')):
+                if SHAPES and ('dispatch_ops' in where or where.startswith('autograd engine') or 'graphs.py' in where):
                     # ops run by built-in autograd nodes (gradient accumulation of a tensor with several consumers, casts of gradients):
                     # which tensors? -> shapes and dtypes of the operands
-                    where += '  ' + ' '.join('%s%s' % (str(a.dtype).replace('torch.', ''), list(a.shape)) for a in args if torch.is_tensor(a))
+                    where += '  ' + ' '.join('%s%s' % (str(a.dtype).replace('torch.', ''), list(a.shape)) for a in leaves[:3])
                 hits[(name.replace('aten.', ''), where)] += 1
-        return func(*args, **(kwargs or {}))
+        return out
 
 
 def step():
@@ -65,7 +68,7 @@ def step():
     opt.step()
 
 
-for _ in range(3):
+for _ in range(1 if GRAPHS else 4):
     step()
 torch.cuda.synchronize()
 torch.autograd.set_multithreading_enabled(False)
