@@ -46,7 +46,8 @@ def parse():
     ap.add_argument('--edge', type=float, default=40.0, help='soft-edge width (px at 512) of the synthetic alphas: 40 -> active ratio ~0.15 with --workload gt')
     ap.add_argument('--no-trace', action='store_true', help='skip the rocprofv3 kernel trace of the graph-replayed steps (roofline.graph_replay)')
     ap.add_argument('--cpu-baseline-full', action='store_true', help='cpu_baseline with 2 warm-ups + 5 timed steps per leg (several minutes)')
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'fp16'],
+                    help="fp16 = the reference's --precision 16 recipe: fp16 autocast + GradScaler (engine/train.py:208,227-229,265-281)")
     ap.add_argument('--sync-bn', action='store_true', help='nn.SyncBatchNorm like configs/maggie_image.yaml:33 (N > 1)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -140,7 +141,9 @@ def main():
     import random
     random.seed(1234 + rank)
     torch.manual_seed(1234 + rank)
-    use_bf16 = args.dtype == 'bf16'
+    use_bf16 = args.dtype in ('bf16', 'fp16')                 # a 16-bit kernel family (same MFMA rate)
+    amp_dtype = torch.float16 if args.dtype == 'fp16' else torch.bfloat16
+    scaler = torch.amp.GradScaler('cuda') if args.dtype == 'fp16' else None
     stats = {}
 
     host_t = [] if os.environ.get('MAGGIE_HOST_TIMES') == '1' else None     # host-side (launch) time per phase, no device syncs
@@ -148,16 +151,25 @@ def main():
     def step():
         t = [time.perf_counter()]
         opt.zero_grad(set_to_none=True)
-        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=use_bf16):
+        with torch.autocast('cuda', dtype=amp_dtype, enabled=use_bf16):
             out, loss = net(batch)
         t.append(time.perf_counter())
-        loss['total'].backward()
+        if scaler is not None:
+            scaler.scale(loss['total']).backward()                                      # engine/train.py:265-266
+        else:
+            loss['total'].backward()
         if grad_sync is not None:
             grad_sync()
         t.append(time.perf_counter())
+        if scaler is not None:
+            scaler.unscale_(opt)                                                        # :271-272 (before the 0.01 clip)
         if args.optimizer != 'flat':
             parallel.clip_grad_norm_(params, 0.01)                                      # engine/train.py:274, over the flat grad buffers
-        opt.step()
+        if scaler is not None:
+            scaler.step(opt)                                                            # :277-279 (skips the update on inf / nan gradients)
+            scaler.update()
+        else:
+            opt.step()
         t.append(time.perf_counter())
         if host_t is not None:
             host_t.append([1e3 * (t[i + 1] - t[i]) for i in range(3)])

@@ -8,7 +8,7 @@
  *
  * Conventions
  *   - all pointers are DEVICE pointers (HBM), 16-byte aligned, unless the name says host;
- *   - activations are NHWC ("rows x channels": row = (n*H + h)*W + w) in `dtype` = MG_F32 or MG_BF16;
+ *   - activations are NHWC ("rows x channels": row = (n*H + h)*W + w) in `dtype` = MG_F32, MG_BF16 or MG_F16 (every `dtype` argument below);
  *     sparse feature matrices are rows x channels with row = active-site id (sorted (batch,y,x) order);
  *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); kernels are asynchronous;
  *   - return value 0 = launched, <0 = argument error, >0 = hipError_t.
@@ -22,6 +22,7 @@ extern "C" {
 
 #define MG_F32 0
 #define MG_BF16 1
+#define MG_F16 3 /* IEEE half storage, fp32 accumulate: the reference's `--precision 16` (torch.cuda.amp fp16 autocast + GradScaler, engine/train.py:208,227-229) */
 
 #define MG_ACT_NONE 0
 #define MG_ACT_RELU 1
@@ -64,7 +65,7 @@ typedef struct mg_conv_params {
     int32_t ldx, ldy, yoff, ldr, ldr2;
     int32_t act, pre_act, res_mode; /* res_mode: 1 = same rows, 2 = residual at half resolution (nearest x2) */
     float slope;
-    int32_t dw_dtype;    /* mg_conv_wgrad_ws only: dtype dW is written in (MG_F32 = 0 default, MG_BF16 needs a workspace) */
+    int32_t dw_dtype;    /* mg_conv_wgrad_ws only: dtype dW is written in (MG_F32 = 0 default; MG_BF16 / MG_F16 = the activations' 16-bit type, needs a workspace) */
     int32_t stat_mode;   /* mg_conv_fprop `stats`: 0 = [MG_STAT_REPLICAS][2*Cout] sum and sum of squares (default);
                             1 = ONE row [2*Cout], column sums only (small layers: feeds the exact two-pass variance) */
     const int32_t* m_dev; /* optional DEVICE row count (sparse head): the kernels run over min(*m_dev, M) rows, M is then the

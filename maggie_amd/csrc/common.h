@@ -5,6 +5,7 @@
 
 #define MG_F32 0
 #define MG_BF16 1
+#define MG_F16 3
 
 #define MG_ACT_NONE 0
 #define MG_ACT_RELU 1
@@ -13,6 +14,12 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef uint16_t bf16raw;
+// IEEE half storage (the reference's `--precision 16`: fp16 autocast + GradScaler, engine/train.py:208,227-229). A distinct 2-byte type so that
+// every kernel templated on its 16-bit storage type gets an fp16 instantiation next to the bf16 one; same vector widths, same MFMA shape
+// (v_mfma_f32_16x16x32_f16 runs at the bf16 rate on gfx950), fp32 accumulation everywhere.
+struct f16raw { uint16_t v; };
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 mg_f16x2;
 
 __device__ __forceinline__ float bf2f(bf16raw v) { return __uint_as_float(((uint32_t)v) << 16); }
 // fp32 -> bf16, round to nearest even: gfx950 has it in hardware (v_cvt_pk_bf16_f32, two values per instruction). The integer sequence
@@ -56,6 +63,42 @@ template <> struct ElemTraits<bf16raw> {
         return make_uint4(f2bf_pk(f[0], f[1]), f2bf_pk(f[2], f[3]), f2bf_pk(f[4], f[5]), f2bf_pk(f[6], f[7]));
     }
 };
+
+__device__ __forceinline__ uint32_t f2h_pk(float lo, float hi) {
+    const mg_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, mg_f16x2));      // v_cvt_pk_f16_f32: round to nearest even, overflow -> inf
+}
+__device__ __forceinline__ void h2f_pk(uint32_t w, float& lo, float& hi) {
+    const mg_f32x2 v = __builtin_convertvector(__builtin_bit_cast(mg_f16x2, w), mg_f32x2);
+    lo = v[0]; hi = v[1];
+}
+template <> struct ElemTraits<f16raw> {
+    static constexpr int CE = 8;
+    static constexpr int EPS = 32;
+    __device__ static __forceinline__ float ld(const f16raw* p) { return (float)__builtin_bit_cast(_Float16, p->v); }
+    __device__ static __forceinline__ void st(f16raw* p, float v) { p->v = __builtin_bit_cast(uint16_t, (_Float16)v); }
+    __device__ static __forceinline__ float rnd(float v) { return (float)(_Float16)v; }
+    __device__ static __forceinline__ void unpack(const uint4& q, float* f) {
+        h2f_pk(q.x, f[0], f[1]); h2f_pk(q.y, f[2], f[3]); h2f_pk(q.z, f[4], f[5]); h2f_pk(q.w, f[6], f[7]);
+    }
+    __device__ static __forceinline__ uint4 pack(const float* f) {
+        return make_uint4(f2h_pk(f[0], f[1]), f2h_pk(f[2], f[3]), f2h_pk(f[4], f[5]), f2h_pk(f[6], f[7]));
+    }
+};
+
+// one 16x16x32 MFMA step on 16-byte fragments (any 16-byte register type) of the 16-bit storage type T, fp32 accumulate
+template <typename T> struct IsF16 { static constexpr bool value = false; };
+template <> struct IsF16<f16raw> { static constexpr bool value = true; };
+template <typename T, typename V>
+__device__ __forceinline__ f32x4 mfma16(const V& a, const V& b, const f32x4& c) {
+    static_assert(sizeof(V) == 16, "MFMA operand fragments are 16 bytes");
+    if constexpr (IsF16<T>::value) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else if constexpr (sizeof(T) == 2) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else return c;                                            // fp32 storage: the callers use the 16x16x4 f32 MFMA instead
+}
+
+// 16-bit activation / weight storage (bf16 or IEEE half): same vector widths and tile shapes
+#define MG_IS16(code) ((code) == MG_BF16 || (code) == MG_F16)
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     if (act == MG_ACT_RELU) return v > 0.f ? v : 0.f;

@@ -61,7 +61,7 @@ extern "C" int mg_debug_read(long long* out) { return (int)hipMemcpyFromSymbol(o
 // GEMM are therefore ordered phase-major (4 sub-lattices (ho & 1, wo & 1), each [N][Hout/2][Wout/2], padded to whole row tiles) and every
 // tile walks only its phase's taps: executed FLOPs == algorithmic FLOPs instead of 4x (k4) / 4x (k3) / 4x (k1) of them.
 __host__ __device__ __forceinline__ bool tconv_phased(const mg_conv_params& p) {
-    const int eps = p.dtype == MG_BF16 ? 32 : 16;
+    const int eps = MG_IS16(p.dtype) ? 32 : 16;
     return p.mode == MG_MODE_TCONV && p.stride == 2 && p.dil == 1 && !p.m_dev && p.Cin % eps == 0 && !(p.Hout & 1) && !(p.Wout & 1) &&
            p.R >= 1 && p.S >= 1;
 }
@@ -552,7 +552,7 @@ __device__ __forceinline__ void igemm_fprop_tile(const mg_conv_params& p, const 
         #pragma unroll
                         for (int jj = 0; jj < FN; ++jj) {
                             if constexpr (sizeof(T) == 2) {
-                                acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&fa[i], *(const bf16x8*)&fb[jj], acc[i][jj], 0, 0, 0);
+                                acc[i][jj] = mfma16<T>(fa[i], fb[jj], acc[i][jj]);
                             } else {
                                 acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i].x), __uint_as_float(fb[jj].x), acc[i][jj], 0, 0, 0);
                                 acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(fa[i].y), __uint_as_float(fb[jj].y), acc[i][jj], 0, 0, 0);
@@ -641,9 +641,8 @@ template <int BM, int BN, int KS, int NS> constexpr int async_lds_bytes() {
     return NS * async_stage_bytes<BM, BN, KS, NS>() > ctile_bytes<BM, BN>() ? NS * async_stage_bytes<BM, BN, KS, NS>() : ctile_bytes<BM, BN>();
 }
 
-template <int BM, int BN, int KS, int NS, int MODE, bool BNB = false>
+template <int BM, int BN, int KS, int NS, int MODE, bool BNB = false, typename T = bf16raw>
 __device__ __forceinline__ void igemm_fprop_async_tile(const mg_conv_params& p, const int M, int work, char* smem) {
-    using T = bf16raw;
     using TR = ElemTraits<T>;
     constexpr int CE = 8, EPS = 32;
     constexpr int WAVES_M = TileCfg<BM, BN>::WAVES_M, WAVES_N = TileCfg<BM, BN>::WAVES_N;
@@ -788,7 +787,7 @@ __device__ __forceinline__ void igemm_fprop_async_tile(const mg_conv_params& p, 
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int jj = 0; jj < FN; ++jj)
-                    acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&fa[j][i], *(const bf16x8*)&fb[j][jj], acc[i][jj], 0, 0, 0);
+                    acc[i][jj] = mfma16<T>(fa[j][i], fb[j][jj], acc[i][jj]);
         }
     }
     __syncthreads();                                         // all fragment reads done before the epilogue reuses the buffers
@@ -798,16 +797,16 @@ __device__ __forceinline__ void igemm_fprop_async_tile(const mg_conv_params& p, 
     tile_epilogue<T, BM, BN, FM, FN, BNB>(p, acc, wm, wn, WM, WN, n0, mt, smem, rowmap);
 }
 
-template <int BM, int BN, int KS, int NS, int MODE, bool BNB = false>
+template <int BM, int BN, int KS, int NS, int MODE, bool BNB = false, typename T = bf16raw>
 __global__ __launch_bounds__(256) void igemm_fprop_async_kernel(const mg_conv_params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ntn = (p.Cout + BN - 1) / BN;
     int work;
     if (!xcd_order(((p.M + BM - 1) / BM) * ntn, work)) return;
-    igemm_fprop_async_tile<BM, BN, KS, NS, MODE, BNB>(p, p.M, work, smem);
+    igemm_fprop_async_tile<BM, BN, KS, NS, MODE, BNB, T>(p, p.M, work, smem);
 }
 
-template <int BM, int BN, int KS, int NS, int MODE>
+template <int BM, int BN, int KS, int NS, int MODE, typename T = bf16raw>
 __global__ __launch_bounds__(256) void igemm_fprop_async_persistent_kernel(const mg_conv_params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int M = dev_rows(p.m_dev, p.M);
@@ -816,7 +815,7 @@ __global__ __launch_bounds__(256) void igemm_fprop_async_persistent_kernel(const
     const int chunk = (L + NXCD - 1) / NXCD;
     for (int vb = blockIdx.x; vb / NXCD < chunk; vb += gridDim.x) {
         const int work = (vb % NXCD) * chunk + vb / NXCD;
-        if (work < L) igemm_fprop_async_tile<BM, BN, KS, NS, MODE>(p, M, work, smem);
+        if (work < L) igemm_fprop_async_tile<BM, BN, KS, NS, MODE, false, T>(p, M, work, smem);
         __syncthreads();
     }
 }
@@ -845,9 +844,8 @@ template <int TH, int BN, int NS> struct HaloCfg {
 };
 
 
-template <int TH, int BN, int NS, int MODE, bool BNB = false>
+template <int TH, int BN, int NS, int MODE, bool BNB = false, typename T = bf16raw>
 __device__ __forceinline__ void igemm_fprop_halo_tile(const mg_conv_params& p, int work, char* smem) {
-    using T = bf16raw;
     using TR = ElemTraits<T>;
     using HC = HaloCfg<TH, BN, NS>;
     constexpr int CE = 8, EPS = 32, TW = HC::TW, BM = HC::BM, PW = HC::PW, HH = HC::HH;
@@ -976,7 +974,7 @@ __device__ __forceinline__ void igemm_fprop_halo_tile(const mg_conv_params& p, i
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int jj = 0; jj < FN; ++jj)
-                    acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&fa[BUF][i], *(const bf16x8*)&fb[BUF][jj], acc[i][jj], 0, 0, 0);
+                    acc[i][jj] = mfma16<T>(fa[BUF][i], fb[BUF][jj], acc[i][jj]);
         };
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
 #define MG_TAP_STEP(T_, CUR, NXT)                                                                       \
@@ -1004,18 +1002,18 @@ __device__ __forceinline__ void igemm_fprop_halo_tile(const mg_conv_params& p, i
     MG_STAMP(15);
 }
 
-template <int TH, int BN, int NS, int MODE, bool BNB = false>
+template <int TH, int BN, int NS, int MODE, bool BNB = false, typename T = bf16raw>
 __global__ __launch_bounds__(256) void igemm_fprop_halo_kernel(const mg_conv_params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tiles = p.N * ((p.Hout + TH - 1) / TH) * ((p.Wout + 15) / 16) * ((p.Cout + BN - 1) / BN);
     int work;
     if (!xcd_order(tiles, work)) return;
-    igemm_fprop_halo_tile<TH, BN, NS, MODE, BNB>(p, work, smem);
+    igemm_fprop_halo_tile<TH, BN, NS, MODE, BNB, T>(p, work, smem);
 }
 
 static inline bool halo_eligible(const mg_conv_params& p) {
     static const int enabled = [] { const char* e = getenv("MG_FPROP_HALO"); return e ? atoi(e) : 1; }();
-    if (!enabled || p.dtype != MG_BF16 || p.m_dev || p.mode == MG_MODE_GATHER) return false;
+    if (!enabled || !MG_IS16(p.dtype) || p.m_dev || p.mode == MG_MODE_GATHER) return false;
     // Cin >= 96: three-stage ring over the 32-channel slabs; Cin 32 / 64: single-stage form (halo_small)
     static const int small = [] { const char* e = getenv("MG_FPROP_HALO_SMALL"); return e ? atoi(e) : 1; }();
     if (p.R != 3 || p.S != 3 || p.stride != 1 || p.dil != 1 || p.pad != 1 || p.Cin % 32 != 0) return false;
@@ -1024,90 +1022,91 @@ static inline bool halo_eligible(const mg_conv_params& p) {
     return true;
 }
 
-template <int TH, int BN = 64, int NS = 3>
+template <typename T, int TH, int BN = 64, int NS = 3>
 static int launch_fprop_halo(const mg_conv_params& p, hipStream_t st) {
     constexpr size_t lds = HaloCfg<TH, BN, NS>::LDS;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)igemm_fprop_halo_kernel<TH, BN, NS, MG_MODE_CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)igemm_fprop_halo_kernel<TH, BN, NS, MG_MODE_TCONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)igemm_fprop_halo_kernel<TH, BN, NS, MG_MODE_TCONV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)igemm_fprop_halo_kernel<TH, BN, NS, MG_MODE_CONV, false, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)igemm_fprop_halo_kernel<TH, BN, NS, MG_MODE_TCONV, false, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)igemm_fprop_halo_kernel<TH, BN, NS, MG_MODE_TCONV, true, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const long tiles = (long)p.N * ((p.Hout + TH - 1) / TH) * ((p.Wout + 15) / 16) * ((p.Cout + BN - 1) / BN);
     dim3 grid(xcd_grid(tiles));
     if (p.bnb_x) {                                           // the data gradient of a 3x3 / stride 1 conv behind a BatchNorm layer
         if (p.mode != MG_MODE_TCONV) return -2;
-        hipLaunchKernelGGL((igemm_fprop_halo_kernel<TH, BN, NS, MG_MODE_TCONV, true>), grid, dim3(256), lds, st, p);
-    } else if (p.mode == MG_MODE_CONV) hipLaunchKernelGGL((igemm_fprop_halo_kernel<TH, BN, NS, MG_MODE_CONV>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((igemm_fprop_halo_kernel<TH, BN, NS, MG_MODE_TCONV>), grid, dim3(256), lds, st, p);
+        hipLaunchKernelGGL((igemm_fprop_halo_kernel<TH, BN, NS, MG_MODE_TCONV, true, T>), grid, dim3(256), lds, st, p);
+    } else if (p.mode == MG_MODE_CONV) hipLaunchKernelGGL((igemm_fprop_halo_kernel<TH, BN, NS, MG_MODE_CONV, false, T>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((igemm_fprop_halo_kernel<TH, BN, NS, MG_MODE_TCONV, false, T>), grid, dim3(256), lds, st, p);
     MG_CHECK_LAUNCH();
     return 0;
 }
 
+template <typename T>
 static int dispatch_fprop_halo(const mg_conv_params& p, hipStream_t st) {
     // 8 x 16 pixel tiles when they still give about one workgroup per CU (a workgroup holds a whole CU's LDS), else 4 x 16
     static const long want = [] { const char* e = getenv("MG_HALO_BLOCKS"); return e ? atol(e) : 200l; }();
     if (p.Cin < 96) {
-        if (p.Cout <= 16) return p.Hout >= 8 ? launch_fprop_halo<8, 16, 1>(p, st) : launch_fprop_halo<4, 16, 1>(p, st);   // the 8-channel network input's data gradient
-        if (p.Cout <= 32) return p.Hout >= 8 ? launch_fprop_halo<8, 32, 1>(p, st) : launch_fprop_halo<4, 32, 1>(p, st);
-        return p.Hout >= 8 ? launch_fprop_halo<8, 64, 1>(p, st) : launch_fprop_halo<4, 64, 1>(p, st);
+        if (p.Cout <= 16) return p.Hout >= 8 ? launch_fprop_halo<T, 8, 16, 1>(p, st) : launch_fprop_halo<T, 4, 16, 1>(p, st);   // the 8-channel network input's data gradient
+        if (p.Cout <= 32) return p.Hout >= 8 ? launch_fprop_halo<T, 8, 32, 1>(p, st) : launch_fprop_halo<T, 4, 32, 1>(p, st);
+        return p.Hout >= 8 ? launch_fprop_halo<T, 8, 64, 1>(p, st) : launch_fprop_halo<T, 4, 64, 1>(p, st);
     }
     const long t8 = (long)p.N * ((p.Hout + 7) / 8) * ((p.Wout + 15) / 16) * ((p.Cout + 63) / 64);
     // 32-channel-wide tiles with a two-slab ring: 66 KiB of LDS -> TWO workgroups per CU, whose load / MFMA / epilogue phases overlap (the
     // 64-wide three-slab form owns the whole CU). Costs 30 % more halo traffic; measured C512->256 32x32 18.0 -> 15.5 us, C256->128 64x64
     // 15.2 -> 14.1 us, C128 / C256 unchanged, step 14.91 -> 14.74 ms. MG_HALO_NARROW=0 selects the wide form.
     static const int narrow = [] { const char* e = getenv("MG_HALO_NARROW"); return e ? atoi(e) : 1; }();
-    if (narrow && p.Hout >= 8) return launch_fprop_halo<8, 32, 2>(p, st);      // (4 x 16 tiles for the layers with < 300 workgroups: no gain, measured)
-    if (t8 >= want && p.Hout >= 8) return launch_fprop_halo<8>(p, st);
-    return launch_fprop_halo<4>(p, st);
+    if (narrow && p.Hout >= 8) return launch_fprop_halo<T, 8, 32, 2>(p, st);      // (4 x 16 tiles for the layers with < 300 workgroups: no gain, measured)
+    if (t8 >= want && p.Hout >= 8) return launch_fprop_halo<T, 8>(p, st);
+    return launch_fprop_halo<T, 4>(p, st);
 }
 
 static inline bool async_eligible(const mg_conv_params& p) {
     // 1 (default): the 1x1 layers and the sparse gather convs (measured: 1x1 C128->64 15.6 -> 10.5 us; neutral or slightly slower than the
     // register-staged loop on the dense 3x3 shapes that the halo kernel does not take); 2: every aligned layer; 0: off
     static const int enabled = [] { const char* e = getenv("MG_FPROP_ASYNC"); return e ? atoi(e) : 1; }();
-    if (!enabled || p.dtype != MG_BF16 || p.Cin % 32 != 0 || p.Cout <= 32) return false;
+    if (!enabled || !MG_IS16(p.dtype) || p.Cin % 32 != 0 || p.Cout <= 32) return false;
     if (enabled == 1 && !(p.R * p.S == 1 || p.mode == MG_MODE_GATHER)) return false;
     if (p.mode == MG_MODE_TCONV && !(p.stride == 1 || p.stride == 2 || p.stride == 4)) return false;
     if ((long)p.R * p.S * p.Cin * 2l >= (1l << 31)) return false;
     return true;
 }
 
-template <int BM, int BN, int KS, int NS>
+template <typename T, int BM, int BN, int KS, int NS>
 int launch_fprop_async(const mg_conv_params& p, hipStream_t st) {
     constexpr size_t lds = async_lds_bytes<BM, BN, KS, NS>();
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)igemm_fprop_async_kernel<BM, BN, KS, NS, MG_MODE_CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)igemm_fprop_async_kernel<BM, BN, KS, NS, MG_MODE_TCONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)igemm_fprop_async_kernel<BM, BN, KS, NS, MG_MODE_GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)igemm_fprop_async_persistent_kernel<BM, BN, KS, NS, MG_MODE_CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)igemm_fprop_async_persistent_kernel<BM, BN, KS, NS, MG_MODE_GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute((const void*)igemm_fprop_async_kernel<BM, BN, KS, NS, MG_MODE_TCONV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)igemm_fprop_async_kernel<BM, BN, KS, NS, MG_MODE_CONV, false, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)igemm_fprop_async_kernel<BM, BN, KS, NS, MG_MODE_TCONV, false, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)igemm_fprop_async_kernel<BM, BN, KS, NS, MG_MODE_GATHER, false, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)igemm_fprop_async_persistent_kernel<BM, BN, KS, NS, MG_MODE_CONV, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)igemm_fprop_async_persistent_kernel<BM, BN, KS, NS, MG_MODE_GATHER, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)igemm_fprop_async_kernel<BM, BN, KS, NS, MG_MODE_TCONV, true, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     const long tiles = (long)((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
     if (p.bnb_x) {                                           // data gradient of a 1x1 conv behind a BatchNorm layer
         if (p.m_dev || p.mode != MG_MODE_TCONV) return -2;
-        hipLaunchKernelGGL((igemm_fprop_async_kernel<BM, BN, KS, NS, MG_MODE_TCONV, true>), dim3(xcd_grid(tiles)), dim3(256), lds, st, p);
+        hipLaunchKernelGGL((igemm_fprop_async_kernel<BM, BN, KS, NS, MG_MODE_TCONV, true, T>), dim3(xcd_grid(tiles)), dim3(256), lds, st, p);
         MG_CHECK_LAUNCH();
         return 0;
     }
     if (p.m_dev) {
         const long g = tiles < 2048 ? tiles : 2048;
         dim3 pg(xcd_grid(g < 1 ? 1 : g));
-        if (p.mode == MG_MODE_CONV) hipLaunchKernelGGL((igemm_fprop_async_persistent_kernel<BM, BN, KS, NS, MG_MODE_CONV>), pg, dim3(256), lds, st, p);
-        else if (p.mode == MG_MODE_GATHER) hipLaunchKernelGGL((igemm_fprop_async_persistent_kernel<BM, BN, KS, NS, MG_MODE_GATHER>), pg, dim3(256), lds, st, p);
+        if (p.mode == MG_MODE_CONV) hipLaunchKernelGGL((igemm_fprop_async_persistent_kernel<BM, BN, KS, NS, MG_MODE_CONV, T>), pg, dim3(256), lds, st, p);
+        else if (p.mode == MG_MODE_GATHER) hipLaunchKernelGGL((igemm_fprop_async_persistent_kernel<BM, BN, KS, NS, MG_MODE_GATHER, T>), pg, dim3(256), lds, st, p);
         else return -2;
         MG_CHECK_LAUNCH();
         return 0;
     }
     dim3 grid(xcd_grid(tiles));
     switch (p.mode) {
-        case MG_MODE_CONV: hipLaunchKernelGGL((igemm_fprop_async_kernel<BM, BN, KS, NS, MG_MODE_CONV>), grid, dim3(256), lds, st, p); break;
-        case MG_MODE_TCONV: hipLaunchKernelGGL((igemm_fprop_async_kernel<BM, BN, KS, NS, MG_MODE_TCONV>), grid, dim3(256), lds, st, p); break;
-        case MG_MODE_GATHER: hipLaunchKernelGGL((igemm_fprop_async_kernel<BM, BN, KS, NS, MG_MODE_GATHER>), grid, dim3(256), lds, st, p); break;
+        case MG_MODE_CONV: hipLaunchKernelGGL((igemm_fprop_async_kernel<BM, BN, KS, NS, MG_MODE_CONV, false, T>), grid, dim3(256), lds, st, p); break;
+        case MG_MODE_TCONV: hipLaunchKernelGGL((igemm_fprop_async_kernel<BM, BN, KS, NS, MG_MODE_TCONV, false, T>), grid, dim3(256), lds, st, p); break;
+        case MG_MODE_GATHER: hipLaunchKernelGGL((igemm_fprop_async_kernel<BM, BN, KS, NS, MG_MODE_GATHER, false, T>), grid, dim3(256), lds, st, p); break;
         default: return -2;
     }
     MG_CHECK_LAUNCH();
@@ -1115,17 +1114,18 @@ int launch_fprop_async(const mg_conv_params& p, hipStream_t st) {
 }
 
 // tile choice as in dispatch_fprop_ks (largest tile that still fills the chip); ring depth / stage width by K and tile
+template <typename T>
 static int dispatch_fprop_async(const mg_conv_params& p, hipStream_t st) {
     static const long want = [] { const char* e = getenv("MG_FPROP_BLOCKS"); return e ? atol(e) : 768l; }();
     auto blocks = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn); };
     static const int ns_small = [] { const char* e = getenv("MG_ASYNC_NS"); return e ? atoi(e) : 4; }();
     if (p.Cout > 64) {
-        if (blocks(128, 128) >= want) return launch_fprop_async<128, 128, 2, 3>(p, st);
-        if (blocks(128, 64) >= want) return ns_small >= 4 ? launch_fprop_async<128, 64, 2, 4>(p, st) : launch_fprop_async<128, 64, 2, 3>(p, st);
-        return ns_small >= 4 ? launch_fprop_async<64, 64, 2, 4>(p, st) : launch_fprop_async<64, 64, 2, 3>(p, st);
+        if (blocks(128, 128) >= want) return launch_fprop_async<T, 128, 128, 2, 3>(p, st);
+        if (blocks(128, 64) >= want) return ns_small >= 4 ? launch_fprop_async<T, 128, 64, 2, 4>(p, st) : launch_fprop_async<T, 128, 64, 2, 3>(p, st);
+        return ns_small >= 4 ? launch_fprop_async<T, 64, 64, 2, 4>(p, st) : launch_fprop_async<T, 64, 64, 2, 3>(p, st);
     }
-    if (blocks(128, 64) >= want) return ns_small >= 4 ? launch_fprop_async<128, 64, 2, 4>(p, st) : launch_fprop_async<128, 64, 2, 3>(p, st);
-    return ns_small >= 4 ? launch_fprop_async<64, 64, 2, 4>(p, st) : launch_fprop_async<64, 64, 2, 3>(p, st);
+    if (blocks(128, 64) >= want) return ns_small >= 4 ? launch_fprop_async<T, 128, 64, 2, 4>(p, st) : launch_fprop_async<T, 128, 64, 2, 3>(p, st);
+    return ns_small >= 4 ? launch_fprop_async<T, 64, 64, 2, 4>(p, st) : launch_fprop_async<T, 64, 64, 2, 3>(p, st);
 }
 
 template <typename T, int BM, int BN, int KS>
@@ -1385,9 +1385,8 @@ static int launch_fprop_split(const mg_conv_params& p, float* ws, int splits, hi
 // steps whose A fragment of lane (pixel, k-group) IS one halo pixel (the 8 channels of tap 4*step + k-group: a 16-byte LDS read at a constant
 // offset; taps 9..11 read a zero pixel); the weights (72 x Cout) live in registers. The im2col kernel re-read the input nine times through L2 (40 us isolated, 63 us in the step with the statistics epilogue; now 30 / 51).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int TH>
+template <int TH, typename T = bf16raw>
 __global__ __launch_bounds__(256) void igemm_fprop_c8_kernel(const mg_conv_params p) {
-    using T = bf16raw;
     constexpr int TW = 16, HP = 18, BM = TH * TW, BN = 32, FM = TH / 4, FN = 2, WM = BM / 4, WN = 32;
     constexpr int NH = (TH + 2) * HP;                             // halo pixels (+ 1 zero pixel)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1440,7 +1439,7 @@ __global__ __launch_bounds__(256) void igemm_fprop_c8_kernel(const mg_conv_param
             const u32x4 fa = *(const u32x4*)&sH[px];
 #pragma unroll
             for (int j = 0; j < FN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8*)&fa, *(const bf16x8*)&fb[s][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = mfma16<T>(fa, fb[s][j], acc[i][j]);
         }
     }
     auto rowmap = [&](int rt) -> long {
@@ -1452,19 +1451,20 @@ __global__ __launch_bounds__(256) void igemm_fprop_c8_kernel(const mg_conv_param
 
 static inline bool fprop_c8_eligible(const mg_conv_params& p) {
     static const int on = [] { const char* e = getenv("MG_FPROP_C8"); return e ? atoi(e) : 1; }();
-    return on && p.dtype == MG_BF16 && p.mode == MG_MODE_CONV && !p.m_dev && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad == 1 && p.dil == 1 &&
+    return on && MG_IS16(p.dtype) && p.mode == MG_MODE_CONV && !p.m_dev && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad == 1 && p.dil == 1 &&
            p.Hout == p.Hin && p.Wout == p.Win && p.Cin == 8 && p.Cout <= 32 && p.ldx % 8 == 0;
 }
+template <typename T>
 static int launch_fprop_c8(const mg_conv_params& p, hipStream_t st) {
     static const int th = [] { const char* e = getenv("MG_FPROP_C8_TH"); return e ? atoi(e) : 8; }();
     if (th == 16) {
         const long tiles = (long)p.N * ((p.Hout + 15) / 16) * ((p.Wout + 15) / 16);
         const size_t lds = (size_t)ctile_bytes<256, 32>() + (18 * 18 + 1) * 16;
-        hipLaunchKernelGGL(igemm_fprop_c8_kernel<16>, dim3(xcd_grid(tiles)), dim3(256), lds, st, p);
+        hipLaunchKernelGGL((igemm_fprop_c8_kernel<16, T>), dim3(xcd_grid(tiles)), dim3(256), lds, st, p);
     } else {
         const long tiles = (long)p.N * ((p.Hout + 7) / 8) * ((p.Wout + 15) / 16);
         const size_t lds = (size_t)ctile_bytes<128, 32>() + (10 * 18 + 1) * 16;
-        hipLaunchKernelGGL(igemm_fprop_c8_kernel<8>, dim3(xcd_grid(tiles)), dim3(256), lds, st, p);
+        hipLaunchKernelGGL((igemm_fprop_c8_kernel<8, T>), dim3(xcd_grid(tiles)), dim3(256), lds, st, p);
     }
     MG_CHECK_LAUNCH();
     return 0;
@@ -1472,8 +1472,10 @@ static int launch_fprop_c8(const mg_conv_params& p, hipStream_t st) {
 
 template <typename T>
 int dispatch_fprop(const mg_conv_params& p, hipStream_t st) {
-    if (sizeof(T) == 2 && !p.bnb_x && fprop_c8_eligible(p)) return launch_fprop_c8(p, st);
-    if (sizeof(T) == 2 && halo_eligible(p)) return dispatch_fprop_halo(p, st);
+    if constexpr (sizeof(T) == 2) {
+        if (!p.bnb_x && fprop_c8_eligible(p)) return launch_fprop_c8<T>(p, st);
+        if (halo_eligible(p)) return dispatch_fprop_halo<T>(p, st);
+    }
     const int eps = sizeof(T) == 2 ? 32 : 16;
     if (tconv_phased(p)) {                       // stage width by the longest phase walk (ceil(R/2) * ceil(S/2) taps)
         const int nsl = ((p.R + 1) / 2) * ((p.S + 1) / 2) * (p.Cin / eps);
@@ -1481,7 +1483,9 @@ int dispatch_fprop(const mg_conv_params& p, hipStream_t st) {
         if (nsl >= 8) return dispatch_fprop_ks<T, 4>(p, st);
         return dispatch_fprop_ks<T, 1>(p, st);
     }
-    if (sizeof(T) == 2 && async_eligible(p)) return dispatch_fprop_async(p, st);
+    if constexpr (sizeof(T) == 2) {
+        if (async_eligible(p)) return dispatch_fprop_async<T>(p, st);
+    }
     const int nslab = (p.R * p.S * p.Cin + eps - 1) / eps;
     // stage width: 4 slabs (256 B of K per row) for the K-heavy layers, 2 slabs for K <= 576 (C32 / C64 3x3 layers: half the LDS
     // and staging registers -> more co-resident blocks; measured +31 % on the 512x512 C32 layers, +8 % on C64), 1 for tiny K
@@ -1495,12 +1499,12 @@ int dispatch_fprop(const mg_conv_params& p, hipStream_t st) {
 
 extern "C" long mg_conv_fprop_workspace(const mg_conv_params* pp) {
     if (!pp || pp->M <= 0) return 0;
-    const SplitPlan sp = pp->dtype == MG_BF16 ? plan_splitk<bf16raw>(*pp) : plan_splitk<float>(*pp);
+    const SplitPlan sp = MG_IS16(pp->dtype) ? plan_splitk<bf16raw>(*pp) : plan_splitk<float>(*pp);
     return sp.bn ? (long)sp.splits * pp->M * pp->Cout : 0;
 }
 
 static int conv_fprop_check(const mg_conv_params& p) {
-    const int ce = p.dtype == MG_BF16 ? 8 : 4;
+    const int ce = MG_IS16(p.dtype) ? 8 : 4;
     if (p.Cin % ce != 0 || p.ldx % ce != 0) return -3;                 // K chunks must not straddle taps / be 16-B aligned
     if (p.Cout >= ce && (p.ldy % ce != 0 || p.yoff % ce != 0)) return -4;
     if (p.mode == MG_MODE_GATHER && !p.nbr) return -5;
@@ -1516,11 +1520,15 @@ extern "C" int mg_conv_fprop_ws(const mg_conv_params* pp, float* workspace, long
     const long need = mg_conv_fprop_workspace(pp);
     if (!need || !workspace || workspace_floats < need) return mg_conv_fprop(pp, stream);
     int rc = conv_fprop_check(p); if (rc) return rc;
-    if (p.Cout % (p.dtype == MG_BF16 ? 8 : 4)) return mg_conv_fprop(pp, stream);
+    if (p.Cout % (MG_IS16(p.dtype) ? 8 : 4)) return mg_conv_fprop(pp, stream);
     hipStream_t st = (hipStream_t)stream;
     if (p.dtype == MG_BF16) {
         const SplitPlan sp = plan_splitk<bf16raw>(p);
         return sp.bn == 128 ? launch_fprop_split<bf16raw, 128>(p, workspace, sp.splits, st) : launch_fprop_split<bf16raw, 64>(p, workspace, sp.splits, st);
+    }
+    if (p.dtype == MG_F16) {
+        const SplitPlan sp = plan_splitk<f16raw>(p);
+        return sp.bn == 128 ? launch_fprop_split<f16raw, 128>(p, workspace, sp.splits, st) : launch_fprop_split<f16raw, 64>(p, workspace, sp.splits, st);
     }
     if (p.dtype == MG_F32) {
         const SplitPlan sp = plan_splitk<float>(p);
@@ -1536,6 +1544,7 @@ extern "C" int mg_conv_fprop(const mg_conv_params* pp, void* stream) {
     { int rc = conv_fprop_check(p); if (rc) return rc; }
     hipStream_t st = (hipStream_t)stream;
     if (p.dtype == MG_BF16) return dispatch_fprop<bf16raw>(p, st);
+    if (p.dtype == MG_F16) return dispatch_fprop<f16raw>(p, st);
     if (p.dtype == MG_F32) return dispatch_fprop<float>(p, st);
     return -6;
 }
@@ -1697,9 +1706,9 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const mg_conv_params p
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
-                    union { s16x4 h[2]; bf16x8 v; } ua, ub;
+                    union { s16x4 h[2]; uint4 v; } ua, ub;
                     ua.h[0] = a[i][0]; ua.h[1] = a[i][1]; ub.h[0] = b[j][0]; ub.h[1] = b[j][1];
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma16<T>(ua.v, ub.v, acc[i][j]);
                 }
         } else {
 #pragma unroll
@@ -1796,6 +1805,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_tile_kernel(const float* __r
         ElemTraits<TO>::st(dw + i, ((part[0][e] + part[1][e]) + (part[2][e] + part[3][e])) + ((part[4][e] + part[5][e]) + (part[6][e] + part[7][e])));
 }
 
+
+// split slabs -> dW in the weight-gradient dtype (fp32, bf16 or fp16)
+#define MG_REDUCE_LAUNCH(KERN, B, WS, SPLITS)                                                                                                          \
+    do {                                                                                                                                               \
+        if (p.dw_dtype == MG_BF16) hipLaunchKernelGGL(KERN<bf16raw>, dim3((unsigned)(B)), dim3(256), 0, st, WS, (int)(SPLITS), n, (bf16raw*)p.stats);  \
+        else if (p.dw_dtype == MG_F16) hipLaunchKernelGGL(KERN<f16raw>, dim3((unsigned)(B)), dim3(256), 0, st, WS, (int)(SPLITS), n, (f16raw*)p.stats); \
+        else hipLaunchKernelGGL(KERN<float>, dim3((unsigned)(B)), dim3(256), 0, st, WS, (int)(SPLITS), n, p.stats);                                    \
+    } while (0)
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Halo-tile weight gradient for the 3x3 / stride 1 / pad 1 layers (bf16): one block = one (co tile, ci tile) of ALL nine taps over a
 // range of 8x16-pixel spatial tiles. The dY tile (128 px) and the x halo tile (10x18 px) are staged once per spatial tile and serve
@@ -1804,7 +1822,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_tile_kernel(const float* __r
 // row-major LDS tiles with ds_read_b64_tr_b16, the x rows shifted by the tap's (ky, kx) inside the halo tile. Waves own the four
 // quadrants of the block tile (no cross-wave reduction); accumulators leave the registers as fp32 partials, one slab per spatial split.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int FM, int FN>
+template <int FM, int FN, typename T = bf16raw>
 __global__ __launch_bounds__(256) void igemm_wgrad_halo_kernel(const mg_conv_params p, int tiles_per_block, float* __restrict__ ws) {
     constexpr int TCO = 32 * FM, TCI = 32 * FN;
     constexpr int TH = 8, TW = 16, HW_ = TW + 2, HH = TH + 2;
@@ -1923,9 +1941,9 @@ __global__ __launch_bounds__(256) void igemm_wgrad_halo_kernel(const mg_conv_par
                     for (int i = 0; i < FM; ++i)
 #pragma unroll
                         for (int j = 0; j < FN; ++j) {
-                            union { s16x4 h[2]; bf16x8 v; } ua, ub;
+                            union { s16x4 h[2]; uint4 v; } ua, ub;
                             ua.h[0] = a[i][0]; ua.h[1] = a[i][1]; ub.h[0] = b[j][0]; ub.h[1] = b[j][1];
-                            acc[ky * 3 + kx][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc[ky * 3 + kx][i][j], 0, 0, 0);
+                            acc[ky * 3 + kx][i][j] = mfma16<T>(ua.v, ub.v, acc[ky * 3 + kx][i][j]);
                         }
                 }
         }
@@ -1952,7 +1970,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_halo_kernel(const mg_conv_par
 // 370 MB per C64 launch). Same MFMA structure as the halo kernel (transposed LDS reads, waves own quadrants, fp32 slabs per row split); the
 // row count is a device word: the fixed grid divides the live rows evenly, empty splits write zero slabs.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int FM>
+template <int FM, typename T = bf16raw>
 __global__ __launch_bounds__(256) void igemm_wgrad_gather9_kernel(const mg_conv_params p, int nsplit, float* __restrict__ ws) {
     constexpr int FN = 1, TCO = 32 * FM, TCI = 32, RC = 64;
     constexpr int PY = TCO + 16, PX = TCI + 16;
@@ -2046,9 +2064,9 @@ __global__ __launch_bounds__(256) void igemm_wgrad_gather9_kernel(const mg_conv_
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
                     for (int j = 0; j < FN; ++j) {
-                        union { s16x4 h[2]; bf16x8 v; } ua, ub;
+                        union { s16x4 h[2]; uint4 v; } ua, ub;
                         ua.h[0] = a[i][0]; ua.h[1] = a[i][1]; ub.h[0] = b[j][0]; ub.h[1] = b[j][1];
-                        acc[tp][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc[tp][i][j], 0, 0, 0);
+                        acc[tp][i][j] = mfma16<T>(ua.v, ub.v, acc[tp][i][j]);
                     }
             }
         }
@@ -2070,7 +2088,7 @@ static inline bool wgrad_gather9_eligible(const mg_conv_params& p) {
     static const int on = [] { const char* e = getenv("MG_WGRAD_GATHER9"); return e ? atoi(e) : 1; }();
     // Cin >= 64 only: at Cin 32 (the OS1 level: ~20 stages of 64 rows per block, 18 MFMAs per stage) the kernel is bound by the gather latency
     // of its short stages and the per-tap kernel's 128-row steps win (measured 52 -> 64 us); at Cin 64: 55 -> 27, 54 -> 41, 32 -> 23 us
-    return on && p.dtype == MG_BF16 && p.mode == MG_MODE_GATHER && p.nbr && p.R * p.S == 9 && p.Cin % 64 == 0 && p.Cout % 32 == 0 &&
+    return on && MG_IS16(p.dtype) && p.mode == MG_MODE_GATHER && p.nbr && p.R * p.S == 9 && p.Cin % 64 == 0 && p.Cout % 32 == 0 &&
            p.ldx % 8 == 0 && p.ldy % 8 == 0 && p.yoff % 8 == 0 && (long)p.Cout * 9 * p.Cin <= (16l << 20) && p.M >= 256;
 }
 static long plan_wgrad_gather9(const mg_conv_params& p) {
@@ -2089,7 +2107,7 @@ static long plan_wgrad_gather9(const mg_conv_params& p) {
 static int launch_wgrad_gather9(const mg_conv_params& p, float* ws, long ws_floats, hipStream_t st) {
     const long splits = plan_wgrad_gather9(p);
     const long n = (long)p.Cout * 9 * p.Cin;
-    const bool out_bf16 = p.dw_dtype == MG_BF16;
+    const bool out_bf16 = MG_IS16(p.dw_dtype);
     if (!ws || ws_floats < splits * n) return -4;
     const int tco = p.Cout % 64 == 0 ? 64 : 32;
     const long cc = (long)(p.Cout / tco) * (p.Cin / 32);
@@ -2099,18 +2117,21 @@ static int launch_wgrad_gather9(const mg_conv_params& p, float* ws, long ws_floa
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)igemm_wgrad_gather9_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute((const void*)igemm_wgrad_gather9_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)igemm_wgrad_gather9_kernel<1, f16raw>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)igemm_wgrad_gather9_kernel<2, f16raw>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         attr_set = true;
     }
-    if (tco == 64) hipLaunchKernelGGL((igemm_wgrad_gather9_kernel<2>), grid, dim3(256), lds, st, p, (int)splits, ws);
+    if (p.dtype == MG_F16) {
+        if (tco == 64) hipLaunchKernelGGL((igemm_wgrad_gather9_kernel<2, f16raw>), grid, dim3(256), lds, st, p, (int)splits, ws);
+        else hipLaunchKernelGGL((igemm_wgrad_gather9_kernel<1, f16raw>), grid, dim3(256), lds, st, p, (int)splits, ws);
+    } else if (tco == 64) hipLaunchKernelGGL((igemm_wgrad_gather9_kernel<2>), grid, dim3(256), lds, st, p, (int)splits, ws);
     else hipLaunchKernelGGL((igemm_wgrad_gather9_kernel<1>), grid, dim3(256), lds, st, p, (int)splits, ws);
     if (splits >= 8) {
         const long b = (n + 31) / 32;
-        if (out_bf16) hipLaunchKernelGGL(wgrad_reduce_tile_kernel<bf16raw>, dim3((unsigned)b), dim3(256), 0, st, ws, (int)splits, n, (bf16raw*)p.stats);
-        else hipLaunchKernelGGL(wgrad_reduce_tile_kernel<float>, dim3((unsigned)b), dim3(256), 0, st, ws, (int)splits, n, p.stats);
+        MG_REDUCE_LAUNCH(wgrad_reduce_tile_kernel, b, ws, splits);
     } else {
         long b = (n + 255) / 256; if (b > 2048) b = 2048;
-        if (out_bf16) hipLaunchKernelGGL(wgrad_reduce_kernel<bf16raw>, dim3((unsigned)b), dim3(256), 0, st, ws, (int)splits, n, (bf16raw*)p.stats);
-        else hipLaunchKernelGGL(wgrad_reduce_kernel<float>, dim3((unsigned)b), dim3(256), 0, st, ws, (int)splits, n, p.stats);
+        MG_REDUCE_LAUNCH(wgrad_reduce_kernel, b, ws, splits);
     }
     MG_CHECK_LAUNCH();
     return 0;
@@ -2123,6 +2144,7 @@ static int launch_wgrad_gather9(const mg_conv_params& p, float* ws, long ws_floa
 // of two horizontally adjacent taps = 32 contiguous bytes of the halo row, so the transposed LDS read of the halo image yields the operand
 // directly. Wave w owns output-channel tile (w & 1) and tap pair (w >> 1) of all three filter rows (kx = 2 of pair 1 has a junk second half).
 // ---------------------------------------------------------------------------------------------------------------------
+template <typename T = bf16raw>
 __global__ __launch_bounds__(256) void igemm_wgrad_c8_kernel(const mg_conv_params p, int tiles_per_block, float* __restrict__ ws) {
     constexpr int TCO = 32, TH = 8, TW = 16, HW_ = TW + 2, HH = TH + 2;
     constexpr int PY = TCO + 16;
@@ -2189,14 +2211,14 @@ __global__ __launch_bounds__(256) void igemm_wgrad_c8_kernel(const mg_conv_param
         if (s + 1 < s_end) load_tile(s + 1);
 #pragma unroll
         for (int kc = 0; kc < TH / 2; ++kc) {
-            union { s16x4 h[2]; bf16x8 v; } ua, ub;
+            union { s16x4 h[2]; uint4 v; } ua, ub;
             ua.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sY + ((2 * kc) * TW + q) * PY + mt * 16 + cq));
             ua.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sY + ((2 * kc + 1) * TW + q) * PY + mt * 16 + cq));
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 ub.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sX + ((2 * kc + ky) * HW_ + q + 2 * pair) * 8 + cq));
                 ub.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sX + ((2 * kc + 1 + ky) * HW_ + q + 2 * pair) * 8 + cq));
-                acc[ky] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc[ky], 0, 0, 0);
+                acc[ky] = mfma16<T>(ua.v, ub.v, acc[ky]);
             }
         }
         __syncthreads();
@@ -2214,7 +2236,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_c8_kernel(const mg_conv_param
 
 static inline bool wgrad_c8_eligible(const mg_conv_params& p) {
     static const int on = [] { const char* e = getenv("MG_WGRAD_C8"); return e ? atoi(e) : 1; }();
-    return on && p.dtype == MG_BF16 && p.mode == MG_MODE_CONV && !p.m_dev && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad == 1 && p.dil == 1 &&
+    return on && MG_IS16(p.dtype) && p.mode == MG_MODE_CONV && !p.m_dev && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad == 1 && p.dil == 1 &&
            p.Hout == p.Hin && p.Wout == p.Win && p.Cin == 8 && p.Cout % 32 == 0 && p.ldx % 8 == 0 && p.ldy % 8 == 0 && p.yoff % 8 == 0 &&
            p.Wout >= 16 && p.Hout >= 8;
 }
@@ -2233,21 +2255,21 @@ static int launch_wgrad_c8(const mg_conv_params& p, float* ws, long ws_floats, h
     int tpb = 1;
     const long splits = plan_wgrad_c8(p, &tpb);
     const long n = (long)p.Cout * 72;
-    const bool out_bf16 = p.dw_dtype == MG_BF16;
+    const bool out_bf16 = MG_IS16(p.dw_dtype);
     if (!ws || ws_floats < splits * n) return -4;
     dim3 grid(xcd_grid(splits * (p.Cout / 32)));
     const size_t lds = (size_t)(8 * 16 * (32 + 16) + (10 * 18 + 4) * 8) * sizeof(bf16raw);
-    hipLaunchKernelGGL(igemm_wgrad_c8_kernel, grid, dim3(256), lds, st, p, tpb, ws);
+    if (p.dtype == MG_F16) hipLaunchKernelGGL(igemm_wgrad_c8_kernel<f16raw>, grid, dim3(256), lds, st, p, tpb, ws);
+    else hipLaunchKernelGGL(igemm_wgrad_c8_kernel<bf16raw>, grid, dim3(256), lds, st, p, tpb, ws);
     const long b = (n + 31) / 32;
-    if (out_bf16) hipLaunchKernelGGL(wgrad_reduce_tile_kernel<bf16raw>, dim3((unsigned)b), dim3(256), 0, st, ws, (int)splits, n, (bf16raw*)p.stats);
-    else hipLaunchKernelGGL(wgrad_reduce_tile_kernel<float>, dim3((unsigned)b), dim3(256), 0, st, ws, (int)splits, n, p.stats);
+    MG_REDUCE_LAUNCH(wgrad_reduce_tile_kernel, b, ws, splits);
     MG_CHECK_LAUNCH();
     return 0;
 }
 
 static inline bool wgrad_halo_eligible(const mg_conv_params& p) {
     static const int on = [] { const char* e = getenv("MG_WGRAD_HALO"); return e ? atoi(e) : 1; }();
-    return on && p.dtype == MG_BF16 && p.mode == MG_MODE_CONV && !p.m_dev && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad == 1 && p.dil == 1 &&
+    return on && MG_IS16(p.dtype) && p.mode == MG_MODE_CONV && !p.m_dev && p.R == 3 && p.S == 3 && p.stride == 1 && p.pad == 1 && p.dil == 1 &&
            p.Hout == p.Hin && p.Wout == p.Win && p.Cin % 32 == 0 && p.Cout % 32 == 0 && p.ldx % 8 == 0 && p.ldy % 8 == 0 && p.yoff % 8 == 0 &&
            p.Wout >= 16 && p.Hout >= 8 && (long)p.Cout * 9 * p.Cin <= (16l << 20);
 }
@@ -2271,7 +2293,7 @@ static WgradHaloPlan plan_wgrad_halo(const mg_conv_params& p) {
 static int launch_wgrad_halo(const mg_conv_params& p, float* ws, long ws_floats, hipStream_t st) {
     const WgradHaloPlan pl = plan_wgrad_halo(p);
     const long n = (long)p.Cout * 9 * p.Cin;
-    const bool out_bf16 = p.dw_dtype == MG_BF16;
+    const bool out_bf16 = MG_IS16(p.dw_dtype);
     float* use_ws = nullptr;
     if ((pl.splits > 1 || out_bf16) && ws && ws_floats >= pl.splits * n) use_ws = ws;
     if (out_bf16 && !use_ws) return -4;
@@ -2280,16 +2302,15 @@ static int launch_wgrad_halo(const mg_conv_params& p, float* ws, long ws_floats,
     const long cc = (long)(p.Cin / 32) * (p.Cout / 32);
     dim3 grid(xcd_grid(pl.splits * cc));
     const size_t lds = (size_t)(8 * 16 * (32 + 16) + 10 * 18 * (32 + 16)) * sizeof(bf16raw);
-    hipLaunchKernelGGL((igemm_wgrad_halo_kernel<1, 1>), grid, dim3(256), lds, st, p, pl.tpb, use_ws);
+    if (p.dtype == MG_F16) hipLaunchKernelGGL((igemm_wgrad_halo_kernel<1, 1, f16raw>), grid, dim3(256), lds, st, p, pl.tpb, use_ws);
+    else hipLaunchKernelGGL((igemm_wgrad_halo_kernel<1, 1>), grid, dim3(256), lds, st, p, pl.tpb, use_ws);
     if (use_ws != p.stats) {
         if (pl.splits >= 8) {
             const long b = (n + 31) / 32;
-            if (out_bf16) hipLaunchKernelGGL(wgrad_reduce_tile_kernel<bf16raw>, dim3((unsigned)b), dim3(256), 0, st, use_ws, (int)pl.splits, n, (bf16raw*)p.stats);
-            else hipLaunchKernelGGL(wgrad_reduce_tile_kernel<float>, dim3((unsigned)b), dim3(256), 0, st, use_ws, (int)pl.splits, n, p.stats);
+            MG_REDUCE_LAUNCH(wgrad_reduce_tile_kernel, b, use_ws, pl.splits);
         } else {
             long b = (n + 255) / 256; if (b > 2048) b = 2048;
-            if (out_bf16) hipLaunchKernelGGL(wgrad_reduce_kernel<bf16raw>, dim3((unsigned)b), dim3(256), 0, st, use_ws, (int)pl.splits, n, (bf16raw*)p.stats);
-            else hipLaunchKernelGGL(wgrad_reduce_kernel<float>, dim3((unsigned)b), dim3(256), 0, st, use_ws, (int)pl.splits, n, p.stats);
+            MG_REDUCE_LAUNCH(wgrad_reduce_kernel, b, use_ws, pl.splits);
         }
     }
     MG_CHECK_LAUNCH();
@@ -2342,7 +2363,7 @@ int launch_wgrad(const mg_conv_params& p, float* ws, long ws_floats, hipStream_t
     const int nci = (p.Cin + TCI - 1) / TCI, nco = (p.Cout + TCO - 1) / TCO;
     WgradPlan pl = plan_wgrad<T, TCO, TCI>(p);
     const long n = (long)p.Cout * taps * p.Cin;
-    const bool out_bf16 = p.dw_dtype == MG_BF16;                   // dW in bf16: always partials -> (converting) reduce
+    const bool out_bf16 = MG_IS16(p.dw_dtype);                   // dW in bf16: always partials -> (converting) reduce
     float* use_ws = nullptr;
     if ((pl.splits > 1 || out_bf16) && ws && ws_floats >= pl.splits * n) use_ws = ws;
     if (out_bf16 && !use_ws) return -4;
@@ -2361,12 +2382,10 @@ int launch_wgrad(const mg_conv_params& p, float* ws, long ws_floats, hipStream_t
     if (use_ws && (pl.splits > 1 || out_bf16)) {
         if (pl.splits > 32 && n <= (1l << 16)) {
             long b = (n + 3) / 4; if (b > 8192) b = 8192;
-            if (out_bf16) hipLaunchKernelGGL(wgrad_reduce_wave_kernel<bf16raw>, dim3((unsigned)b), dim3(256), 0, st, use_ws, (int)pl.splits, n, (bf16raw*)p.stats);
-            else hipLaunchKernelGGL(wgrad_reduce_wave_kernel<float>, dim3((unsigned)b), dim3(256), 0, st, use_ws, (int)pl.splits, n, p.stats);
+            MG_REDUCE_LAUNCH(wgrad_reduce_wave_kernel, b, use_ws, pl.splits);
         } else {
             long b = (n + 255) / 256; if (b > 2048) b = 2048;
-            if (out_bf16) hipLaunchKernelGGL(wgrad_reduce_kernel<bf16raw>, dim3((unsigned)b), dim3(256), 0, st, use_ws, (int)pl.splits, n, (bf16raw*)p.stats);
-            else hipLaunchKernelGGL(wgrad_reduce_kernel<float>, dim3((unsigned)b), dim3(256), 0, st, use_ws, (int)pl.splits, n, p.stats);
+            MG_REDUCE_LAUNCH(wgrad_reduce_kernel, b, use_ws, pl.splits);
         }
     }
     MG_CHECK_LAUNCH();
@@ -2388,13 +2407,13 @@ int dispatch_wgrad(const mg_conv_params& p, float* ws, long ws_floats, long* nee
         if (ws && ws_floats >= splits * n) return launch_wgrad_gather9(p, ws, ws_floats, st);
     }
     if (sizeof(T) == 2 && wgrad_halo_eligible(p)) {
-        if (need) { const WgradHaloPlan pl = plan_wgrad_halo(p); *need = (pl.splits > 1 || p.dw_dtype == MG_BF16) ? pl.splits * n : 0; return 0; }
+        if (need) { const WgradHaloPlan pl = plan_wgrad_halo(p); *need = (pl.splits > 1 || MG_IS16(p.dw_dtype)) ? pl.splits * n : 0; return 0; }
         const WgradHaloPlan pl = plan_wgrad_halo(p);
         if (pl.splits == 1 || (ws && ws_floats >= pl.splits * n)) return launch_wgrad_halo(p, ws, ws_floats, st);
     }
 #define MG_WG(TCO, TCI)                                                                             \
     do {                                                                                            \
-        if (need) { WgradPlan pl = plan_wgrad<T, TCO, TCI>(p); *need = (pl.splits > 1 || p.dw_dtype == MG_BF16) ? pl.splits * n : 0; return 0; } \
+        if (need) { WgradPlan pl = plan_wgrad<T, TCO, TCI>(p); *need = (pl.splits > 1 || MG_IS16(p.dw_dtype)) ? pl.splits * n : 0; return 0; } \
         return launch_wgrad<T, TCO, TCI>(p, ws, ws_floats, st);                                     \
     } while (0)
     if (small_co && small_ci) MG_WG(32, 32);
@@ -2407,10 +2426,11 @@ int dispatch_wgrad(const mg_conv_params& p, float* ws, long ws_floats, long* nee
 int wgrad_check(const mg_conv_params* pp) {
     if (!pp) return -1;
     const mg_conv_params& p = *pp;
-    const int ce = p.dtype == MG_BF16 ? 8 : 4;
+    const int ce = MG_IS16(p.dtype) ? 8 : 4;
     if (p.Cin % ce != 0 || p.ldx % ce != 0) return -3;
     if (p.mode == MG_MODE_GATHER && !p.nbr) return -5;
-    if (p.dtype != MG_BF16 && p.dtype != MG_F32) return -6;
+    if (!MG_IS16(p.dtype) && p.dtype != MG_F32) return -6;
+    if (MG_IS16(p.dw_dtype) && p.dw_dtype != p.dtype) return -6;           // 16-bit dW comes in the activations' own 16-bit type
     return 0;
 }
 
@@ -2420,7 +2440,7 @@ int wgrad_check(const mg_conv_params* pp) {
 extern "C" long mg_conv_wgrad_workspace(const mg_conv_params* pp) {
     if (wgrad_check(pp) || pp->M <= 0) return 0;
     long need = 0;
-    if (pp->dtype == MG_BF16) dispatch_wgrad<bf16raw>(*pp, nullptr, 0, &need, nullptr);
+    if (MG_IS16(pp->dtype)) dispatch_wgrad<bf16raw>(*pp, nullptr, 0, &need, nullptr);
     else dispatch_wgrad<float>(*pp, nullptr, 0, &need, nullptr);
     return need;
 }
@@ -2434,6 +2454,7 @@ extern "C" int mg_conv_wgrad_ws(const mg_conv_params* pp, float* workspace, long
     if (pp->M <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     if (pp->dtype == MG_BF16) return dispatch_wgrad<bf16raw>(*pp, workspace, workspace_floats, nullptr, st);
+    if (pp->dtype == MG_F16) return dispatch_wgrad<f16raw>(*pp, workspace, workspace_floats, nullptr, st);
     return dispatch_wgrad<float>(*pp, workspace, workspace_floats, nullptr, st);
 }
 

@@ -661,12 +661,13 @@ inline int grid_for(long total) {
 
 extern "C" int mg_colstats_dev(const void* x, int dtype, int M, int C, int ld, float* stats, const int32_t* m_dev, void* stream) {
     if (M <= 0) return 0;
-    const int ce = dtype == MG_BF16 ? 8 : 4;
+    const int ce = MG_IS16(dtype) ? 8 : 4;
     if (C % ce || ld % ce) return -3;
     const ColGeom g = col_geom(M, C, ce, 1024);
     const size_t lds = (size_t)g.ty * g.tx * 2 * ce * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MG_BF16) hipLaunchKernelGGL(colstats_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const bf16raw*)x, M, C, ld, stats, g.rpb, MG_STAT_REPLICAS, 0, g.tx, g.ty, m_dev);
+    else if (dtype == MG_F16) hipLaunchKernelGGL(colstats_kernel<f16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const f16raw*)x, M, C, ld, stats, g.rpb, MG_STAT_REPLICAS, 0, g.tx, g.ty, m_dev);
     else hipLaunchKernelGGL(colstats_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const float*)x, M, C, ld, stats, g.rpb, MG_STAT_REPLICAS, 0, g.tx, g.ty, m_dev);
     MG_CHECK_LAUNCH();
     return 0;
@@ -684,12 +685,13 @@ extern "C" int mg_bias_act_bwd_dev(const void* dy, const void* y, void* g, int d
     hipStream_t st = (hipStream_t)stream;
     if (db) { hipError_t e = mg_zero_words(db, C, st); if (e != hipSuccess) return (int)e; }
     if (M <= 0) return 0;
-    const int ce = dtype == MG_BF16 ? 8 : 4;
+    const int ce = MG_IS16(dtype) ? 8 : 4;
     if (C % ce) return -3;
     if (y && !g) return -3;
     const ColGeom gm = col_geom(M, C, ce, 512);          // like MG_BN_RB: enough blocks to stream at HBM rate, few enough atomics per channel
     const size_t lds = (size_t)gm.ty * gm.tx * ce * sizeof(float);
     if (dtype == MG_BF16) hipLaunchKernelGGL(bias_act_bwd_kernel<bf16raw>, dim3(gm.rb, gm.groups), dim3(NT), lds, st, (const bf16raw*)dy, (const bf16raw*)y, (bf16raw*)g, M, C, db, gm.rpb, gm.tx, gm.ty, m_dev);
+    else if (dtype == MG_F16) hipLaunchKernelGGL(bias_act_bwd_kernel<f16raw>, dim3(gm.rb, gm.groups), dim3(NT), lds, st, (const f16raw*)dy, (const f16raw*)y, (f16raw*)g, M, C, db, gm.rpb, gm.tx, gm.ty, m_dev);
     else hipLaunchKernelGGL(bias_act_bwd_kernel<float>, dim3(gm.rb, gm.groups), dim3(NT), lds, st, (const float*)dy, (const float*)y, (float*)g, M, C, db, gm.rpb, gm.tx, gm.ty, m_dev);
     MG_CHECK_LAUNCH();
     return 0;
@@ -701,7 +703,7 @@ extern "C" int mg_colstats_centered(const void* x, int dtype, int M, int C, int 
 }
 extern "C" int mg_colstats_centered_dev(const void* x, int dtype, int M, int C, int ld, float* stats, int have_sum, const int32_t* m_dev, void* stream) {
     if (M <= 0) return 0;
-    const int ce = dtype == MG_BF16 ? 8 : 4;
+    const int ce = MG_IS16(dtype) ? 8 : 4;
     if (C % ce || ld % ce) return -3;
     const ColGeom g = col_geom(M, C, ce, 256);
     const size_t lds = (size_t)g.ty * g.tx * 2 * ce * sizeof(float);
@@ -711,6 +713,9 @@ extern "C" int mg_colstats_centered_dev(const void* x, int dtype, int M, int C, 
     if (dtype == MG_BF16) {
         if (!have_sum) hipLaunchKernelGGL(colstats_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const bf16raw*)x, M, C, ld, stats, g.rpb, 1, 1, g.tx, g.ty, m_dev);
         hipLaunchKernelGGL(colstats_centered_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const bf16raw*)x, M, C, ld, stats, g.rpb, g.tx, g.ty, m_dev);
+    } else if (dtype == MG_F16) {
+        if (!have_sum) hipLaunchKernelGGL(colstats_kernel<f16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const f16raw*)x, M, C, ld, stats, g.rpb, 1, 1, g.tx, g.ty, m_dev);
+        hipLaunchKernelGGL(colstats_centered_kernel<f16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const f16raw*)x, M, C, ld, stats, g.rpb, g.tx, g.ty, m_dev);
     } else {
         if (!have_sum) hipLaunchKernelGGL(colstats_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const float*)x, M, C, ld, stats, g.rpb, 1, 1, g.tx, g.ty, m_dev);
         hipLaunchKernelGGL(colstats_centered_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const float*)x, M, C, ld, stats, g.rpb, g.tx, g.ty, m_dev);
@@ -745,7 +750,7 @@ extern "C" int mg_bn_fold(int C, const float* gamma, const float* beta, const fl
 
 static int rowwise_check(const mg_rowwise_params* p) {
     if (!p) return -1;
-    const int ce = p->dtype == MG_BF16 ? 8 : 4;
+    const int ce = MG_IS16(p->dtype) ? 8 : 4;
     if (p->C % ce) return -3;
     return 0;
 }
@@ -753,9 +758,10 @@ static int rowwise_check(const mg_rowwise_params* p) {
 extern "C" int mg_affine_act(const mg_rowwise_params* p, void* stream) {
     int rc = rowwise_check(p); if (rc) return rc;
     if (p->M <= 0) return 0;
-    const int ce = p->dtype == MG_BF16 ? 8 : 4;
+    const int ce = MG_IS16(p->dtype) ? 8 : 4;
     long total = (long)p->M * (p->C / ce);
     if (p->dtype == MG_BF16) hipLaunchKernelGGL(affine_act_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, *p);
+    else if (p->dtype == MG_F16) hipLaunchKernelGGL(affine_act_kernel<f16raw>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, *p);
     else hipLaunchKernelGGL(affine_act_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, *p);
     MG_CHECK_LAUNCH();
     return 0;
@@ -764,7 +770,7 @@ extern "C" int mg_affine_act(const mg_rowwise_params* p, void* stream) {
 extern "C" int mg_bn_bwd_reduce(const mg_rowwise_params* p, void* stream) {
     int rc = rowwise_check(p); if (rc) return rc;
     if (p->M <= 0) return 0;
-    const int ce = p->dtype == MG_BF16 ? 8 : 4;
+    const int ce = MG_IS16(p->dtype) ? 8 : 4;
     // row blocks: every block ends with one atomic per channel, all blocks on the same 2C addresses -- past ~256 blocks those serialise into a
     // tail longer than what the extra parallelism buys, except on the largest tensors (measured, us at 128 / 256 / 512 / 1024 row blocks:
     // 1M x 32: 109 / 60 / 45 / 52; 262144 x 64: 56 / 35 / 31 / 43; 262144 x 32: 29 / 21.5 / 24 / 36; 65536 x 64: 19 / 13 / 19 / 19)
@@ -779,15 +785,17 @@ extern "C" int mg_bn_bwd_reduce(const mg_rowwise_params* p, void* stream) {
     const size_t lds = wide ? (size_t)16 * g.tx * 2 * ce * sizeof(float) : (size_t)g.ty * g.tx * 2 * ce * sizeof(float);
     if (wide) {
         if (p->dtype == MG_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16raw, 1024>), dim3(g.rb, g.groups), dim3(1024), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty);
+        else if (p->dtype == MG_F16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<f16raw, 1024>), dim3(g.rb, g.groups), dim3(1024), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty);
         else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 1024>), dim3(g.rb, g.groups), dim3(1024), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty);
     } else if (p->dtype == MG_BF16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty);
+    else if (p->dtype == MG_F16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<f16raw>, dim3(g.rb, g.groups), dim3(NT), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty);
     else hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty);
     MG_CHECK_LAUNCH();
     return 0;
 }
 
 static bool bn_fixed_shape_ok(const mg_rowwise_params& p) {
-    const int ce = p.dtype == MG_BF16 ? 8 : 4;
+    const int ce = MG_IS16(p.dtype) ? 8 : 4;
     const int cpr = p.C / ce;
     return p.M > 0 && cpr > 0 && cpr <= NT && (NT % cpr) == 0 && p.ldx % ce == 0 && p.lddy % ce == 0 && (!p.dx || p.lddx % ce == 0) &&
            (!p.dres || p.lddres % ce == 0);
@@ -796,15 +804,16 @@ static bool bn_fixed_ok(const mg_rowwise_params& p) {
     // the general apply pass stays on the simple grid-stride kernel (8.0 us average against 8.9 us for this one at nrep = 1: more registers,
     // fewer waves in flight); this kernel serves the linked path (replicated sums). MG_BN_FIXED_APPLY=1 uses it everywhere.
     static const int on = [] { const char* e = getenv("MG_BN_FIXED_APPLY"); return e ? atoi(e) : 0; }();
-    const int ce = p.dtype == MG_BF16 ? 8 : 4;
+    const int ce = MG_IS16(p.dtype) ? 8 : 4;
     const int cpr = p.C / ce;
     return on && p.M > 0 && cpr > 0 && cpr <= NT && (NT % cpr) == 0 && p.ldx % ce == 0 && p.lddy % ce == 0 && (!p.dx || p.lddx % ce == 0) &&
            (!p.dres || p.lddres % ce == 0);
 }
 static int bn_bwd_apply_fixed_launch(const mg_rowwise_params& p, const float* sums_rep, int nrep, int premasked, float* sums_out, hipStream_t st) {
-    const int ce = p.dtype == MG_BF16 ? 8 : 4;
+    const int ce = MG_IS16(p.dtype) ? 8 : 4;
     const long total = (long)p.M * (p.C / ce);
     if (p.dtype == MG_BF16) hipLaunchKernelGGL(bn_bwd_apply_fixed_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), (size_t)(NT + 2 * p.C) * sizeof(float), st, p, sums_rep, nrep, premasked, sums_out);
+    else if (p.dtype == MG_F16) hipLaunchKernelGGL(bn_bwd_apply_fixed_kernel<f16raw>, dim3(grid_for(total)), dim3(NT), (size_t)(NT + 2 * p.C) * sizeof(float), st, p, sums_rep, nrep, premasked, sums_out);
     else hipLaunchKernelGGL(bn_bwd_apply_fixed_kernel<float>, dim3(grid_for(total)), dim3(NT), (size_t)(NT + 2 * p.C) * sizeof(float), st, p, sums_rep, nrep, premasked, sums_out);
     MG_CHECK_LAUNCH();
     return 0;
@@ -823,9 +832,10 @@ extern "C" int mg_bn_bwd_apply(const mg_rowwise_params* p, void* stream) {
     int rc = rowwise_check(p); if (rc) return rc;
     if (p->M <= 0) return 0;
     if (bn_fixed_ok(*p)) return bn_bwd_apply_fixed_launch(*p, p->sums, 1, 0, nullptr, (hipStream_t)stream);
-    const int ce = p->dtype == MG_BF16 ? 8 : 4;
+    const int ce = MG_IS16(p->dtype) ? 8 : 4;
     long total = (long)p->M * (p->C / ce);
     if (p->dtype == MG_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, *p);
+    else if (p->dtype == MG_F16) hipLaunchKernelGGL(bn_bwd_apply_kernel<f16raw>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, *p);
     else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, *p);
     MG_CHECK_LAUNCH();
     return 0;
@@ -995,7 +1005,7 @@ static bool bn_small_ok(const mg_rowwise_params& p) {
     // lane -- at 4096 rows x 32 workgroups that costs as much as the four coalesced launches it replaces (24.8 us forward, 33.7 us backward
     // against ~25 / ~17 us); at 1024 rows (64 workgroups x 4 rows per thread) it is 12 us each way. MG_BN_SMALL_ROWS=0 switches it off.
     static const int max_rows = [] { const char* e = getenv("MG_BN_SMALL_ROWS"); return e ? atoi(e) : 1024; }();
-    const int ce = p.dtype == MG_BF16 ? 8 : 4;
+    const int ce = MG_IS16(p.dtype) ? 8 : 4;
     return !p.m_dev && !p.count_ptr && p.M > 1 && p.M <= max_rows && p.M <= 16 * NT && p.C % ce == 0 && p.ldx % ce == 0;
 }
 template <typename T>
@@ -1025,16 +1035,17 @@ static bool bn_fused_ok(const mg_rowwise_params& p) {
     // 13.43-13.50 ms over 60-step runs): its register footprint (per-channel constants + the prefetched row) costs the streaming part what the
     // removed launch saved. MG_BN_FUSED_APPLY=1 switches it on.
     static const int on = [] { const char* e = getenv("MG_BN_FUSED_APPLY"); return e ? atoi(e) : 0; }();
-    const int ce = p.dtype == MG_BF16 ? 8 : 4;
+    const int ce = MG_IS16(p.dtype) ? 8 : 4;
     const int cpr = p.C / ce;
     return on && p.M > 0 && cpr > 0 && cpr <= NT && (NT % cpr) == 0 && p.ldx % ce == 0;
 }
 static int bn_apply_fused_launch(const mg_rowwise_params& p, const float* stats, int nrep, int centered, const float* gamma, const float* beta,
                                  float* running_mean, float* running_var, float momentum, float eps, float* outs, hipStream_t st) {
-    const int ce = p.dtype == MG_BF16 ? 8 : 4;
+    const int ce = MG_IS16(p.dtype) ? 8 : 4;
     const long total = (long)p.M * (p.C / ce);
     BnFin f{stats, nrep, centered, gamma, beta, running_mean, running_var, momentum, eps, outs};
     if (p.dtype == MG_BF16) hipLaunchKernelGGL(bn_apply_fused_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), (size_t)(NT + 2 * p.C) * sizeof(float), st, p, f);
+    else if (p.dtype == MG_F16) hipLaunchKernelGGL(bn_apply_fused_kernel<f16raw>, dim3(grid_for(total)), dim3(NT), (size_t)(NT + 2 * p.C) * sizeof(float), st, p, f);
     else hipLaunchKernelGGL(bn_apply_fused_kernel<float>, dim3(grid_for(total)), dim3(NT), (size_t)(NT + 2 * p.C) * sizeof(float), st, p, f);
     MG_CHECK_LAUNCH();
     return 0;
@@ -1054,7 +1065,8 @@ extern "C" int mg_bn_train_fwd(const mg_rowwise_params* p_in, float* stats_ws, i
     if (!stats_in && !own) return -3;
     if (exact && bn_small_ok(p))                         // one launch: the statistics never leave the registers (stats_in / stats_ws unused)
         return p.dtype == MG_BF16 ? bn_small_fwd_launch<bf16raw>(p, gamma, beta, running_mean, running_var, momentum, eps, outs, st)
-                                  : bn_small_fwd_launch<float>(p, gamma, beta, running_mean, running_var, momentum, eps, outs, st);
+               : p.dtype == MG_F16 ? bn_small_fwd_launch<f16raw>(p, gamma, beta, running_mean, running_var, momentum, eps, outs, st)
+                                   : bn_small_fwd_launch<float>(p, gamma, beta, running_mean, running_var, momentum, eps, outs, st);
     const float* stats = stats_in;
     int nrep = stats_in_rows, centered = 0;
     if (p.m_dev) {
@@ -1092,8 +1104,8 @@ extern "C" int mg_bn_train_fwd(const mg_rowwise_params* p_in, float* stats_ws, i
 
 extern "C" int mg_bn_train_bwd(const mg_rowwise_params* p, int sums_zeroed, void* stream) {
     int rc = rowwise_check(p); if (rc) return rc;
-    if (bn_small_ok(*p) && p->lddy % (p->dtype == MG_BF16 ? 8 : 4) == 0)
-        return p->dtype == MG_BF16 ? bn_small_bwd_launch<bf16raw>(*p, (hipStream_t)stream) : bn_small_bwd_launch<float>(*p, (hipStream_t)stream);
+    if (bn_small_ok(*p) && p->lddy % (MG_IS16(p->dtype) ? 8 : 4) == 0)
+        return p->dtype == MG_BF16 ? bn_small_bwd_launch<bf16raw>(*p, (hipStream_t)stream) : p->dtype == MG_F16 ? bn_small_bwd_launch<f16raw>(*p, (hipStream_t)stream) : bn_small_bwd_launch<float>(*p, (hipStream_t)stream);
     if (!sums_zeroed) {
         hipError_t e = mg_zero_words(p->sums, 2 * p->C, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
@@ -1103,7 +1115,7 @@ extern "C" int mg_bn_train_bwd(const mg_rowwise_params* p, int sums_zeroed, void
 }
 
 extern "C" int mg_pool2x2(const void* in, void* out, int dtype, int op, int N, int Ho, int Wo, int C, void* stream) {
-    const int ce = dtype == MG_BF16 ? 8 : 4;
+    const int ce = MG_IS16(dtype) ? 8 : 4;
     if (C % ce) return -3;
     long total = (long)N * Ho * Wo * (C / ce);
     if (total <= 0) return 0;
@@ -1113,6 +1125,8 @@ extern "C" int mg_pool2x2(const void* in, void* out, int dtype, int op, int N, i
 #define POOL_CASE(T, OP) hipLaunchKernelGGL((pool2x2_kernel<T, OP>), g, b, 0, st, (const T*)in, (T*)out, N, Ho, Wo, C, Hi, Wi)
     if (dtype == MG_BF16) {
         switch (op) { case 0: POOL_CASE(bf16raw, 0); break; case 1: POOL_CASE(bf16raw, 1); break; case 2: POOL_CASE(bf16raw, 2); break; case 3: POOL_CASE(bf16raw, 3); break; default: return -2; }
+    } else if (dtype == MG_F16) {
+        switch (op) { case 0: POOL_CASE(f16raw, 0); break; case 1: POOL_CASE(f16raw, 1); break; case 2: POOL_CASE(f16raw, 2); break; case 3: POOL_CASE(f16raw, 3); break; default: return -2; }
     } else {
         switch (op) { case 0: POOL_CASE(float, 0); break; case 1: POOL_CASE(float, 1); break; case 2: POOL_CASE(float, 2); break; case 3: POOL_CASE(float, 3); break; default: return -2; }
     }

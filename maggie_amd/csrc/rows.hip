@@ -234,8 +234,8 @@ __global__ void patch_if_empty_kernel(unsigned long long* __restrict__ bits, con
 }  // namespace
 
 static int rows_check(int dtype, int C) {
-    if (dtype != MG_BF16 && dtype != MG_F32) return -6;
-    const int ce = dtype == MG_BF16 ? 8 : 4;
+    if (!MG_IS16(dtype) && dtype != MG_F32) return -6;
+    const int ce = MG_IS16(dtype) ? 8 : 4;
     if (C % ce) return -3;
     return 0;
 }
@@ -243,9 +243,10 @@ static int rows_check(int dtype, int C) {
 extern "C" int mg_rows_sigmoid_mul_fwd(const void* a, int lda, const void* g, void* out, int dtype, int M, int C, const int32_t* m_dev, void* stream) {
     int rc = rows_check(dtype, C); if (rc) return rc;
     if (M <= 0) return 0;
-    const long total = (long)M * (C / (dtype == MG_BF16 ? 8 : 4));
+    const long total = (long)M * (C / (MG_IS16(dtype) ? 8 : 4));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MG_BF16) hipLaunchKernelGGL(sigmul_fwd_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const bf16raw*)a, lda, (const bf16raw*)g, (bf16raw*)out, M, C, m_dev);
+    else if (dtype == MG_F16) hipLaunchKernelGGL(sigmul_fwd_kernel<f16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const f16raw*)a, lda, (const f16raw*)g, (f16raw*)out, M, C, m_dev);
     else hipLaunchKernelGGL(sigmul_fwd_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, st, (const float*)a, lda, (const float*)g, (float*)out, M, C, m_dev);
     MG_CHECK_LAUNCH();
     return 0;
@@ -255,9 +256,10 @@ extern "C" int mg_rows_sigmoid_mul_bwd(const void* dout, const void* a, int lda,
                                        const int32_t* m_dev, void* stream) {
     int rc = rows_check(dtype, C); if (rc) return rc;
     if (M <= 0) return 0;
-    const long total = (long)M * (C / (dtype == MG_BF16 ? 8 : 4));
+    const long total = (long)M * (C / (MG_IS16(dtype) ? 8 : 4));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MG_BF16) hipLaunchKernelGGL(sigmul_bwd_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const bf16raw*)dout, (const bf16raw*)a, lda, (const bf16raw*)g, (bf16raw*)da, (bf16raw*)dg, M, C, m_dev);
+    else if (dtype == MG_F16) hipLaunchKernelGGL(sigmul_bwd_kernel<f16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const f16raw*)dout, (const f16raw*)a, lda, (const f16raw*)g, (f16raw*)da, (f16raw*)dg, M, C, m_dev);
     else hipLaunchKernelGGL(sigmul_bwd_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, st, (const float*)dout, (const float*)a, lda, (const float*)g, (float*)da, (float*)dg, M, C, m_dev);
     MG_CHECK_LAUNCH();
     return 0;
@@ -266,9 +268,10 @@ extern "C" int mg_rows_sigmoid_mul_bwd(const void* dout, const void* a, int lda,
 extern "C" int mg_rows_add(const void* a, int lda, const void* b, int ldb, void* out, int ldo, int dtype, int M, int C, const int32_t* m_dev, void* stream) {
     int rc = rows_check(dtype, C); if (rc) return rc;
     if (M <= 0) return 0;
-    const long total = (long)M * (C / (dtype == MG_BF16 ? 8 : 4));
+    const long total = (long)M * (C / (MG_IS16(dtype) ? 8 : 4));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MG_BF16) hipLaunchKernelGGL(rows_add_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const bf16raw*)a, lda, (const bf16raw*)b, ldb, (bf16raw*)out, ldo, M, C, m_dev);
+    else if (dtype == MG_F16) hipLaunchKernelGGL(rows_add_kernel<f16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const f16raw*)a, lda, (const f16raw*)b, ldb, (f16raw*)out, ldo, M, C, m_dev);
     else hipLaunchKernelGGL(rows_add_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, st, (const float*)a, lda, (const float*)b, ldb, (float*)out, ldo, M, C, m_dev);
     MG_CHECK_LAUNCH();
     return 0;
@@ -278,9 +281,10 @@ extern "C" int mg_rows_dropout(const void* x, void* y, int dtype, int M, int C, 
     int rc = rows_check(dtype, C); if (rc) return rc;
     if (M <= 0) return 0;
     if (!state || p < 0.f || p > 1.f) return -2;
-    const long total = (long)M * (C / (dtype == MG_BF16 ? 8 : 4));
+    const long total = (long)M * (C / (MG_IS16(dtype) ? 8 : 4));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MG_BF16) hipLaunchKernelGGL(rows_dropout_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const bf16raw*)x, (bf16raw*)y, M, C, p, state, (uint32_t)salt, m_dev);
+    else if (dtype == MG_F16) hipLaunchKernelGGL(rows_dropout_kernel<f16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const f16raw*)x, (f16raw*)y, M, C, p, state, (uint32_t)salt, m_dev);
     else hipLaunchKernelGGL(rows_dropout_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, st, (const float*)x, (float*)y, M, C, p, state, (uint32_t)salt, m_dev);
     MG_CHECK_LAUNCH();
     return 0;
@@ -288,7 +292,7 @@ extern "C" int mg_rows_dropout(const void* x, void* y, int dtype, int M, int C, 
 
 static int ln_check(int dtype, int C) {
     int rc = rows_check(dtype, C); if (rc) return rc;
-    const int lpr = C / (dtype == MG_BF16 ? 8 : 4);
+    const int lpr = C / (MG_IS16(dtype) ? 8 : 4);
     if (lpr < 1 || lpr > 64 || (lpr & (lpr - 1))) return -3;          // a row = a power-of-two group of lanes
     return 0;
 }
@@ -297,10 +301,11 @@ extern "C" int mg_rows_add_layernorm_fwd(const void* x, const void* r, const flo
                                          int M, int C, const int32_t* m_dev, void* stream) {
     int rc = ln_check(dtype, C); if (rc) return rc;
     if (M <= 0) return 0;
-    const int lpr = C / (dtype == MG_BF16 ? 8 : 4), rpb = NT / lpr;
+    const int lpr = C / (MG_IS16(dtype) ? 8 : 4), rpb = NT / lpr;
     long blocks = ((long)M + rpb - 1) / rpb; if (blocks > 2048) blocks = 2048;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MG_BF16) hipLaunchKernelGGL(add_layernorm_fwd_kernel<bf16raw>, dim3((unsigned)blocks), dim3(NT), 0, st, (const bf16raw*)x, (const bf16raw*)r, gamma, beta, eps, (bf16raw*)y, rstat, M, C, m_dev);
+    else if (dtype == MG_F16) hipLaunchKernelGGL(add_layernorm_fwd_kernel<f16raw>, dim3((unsigned)blocks), dim3(NT), 0, st, (const f16raw*)x, (const f16raw*)r, gamma, beta, eps, (f16raw*)y, rstat, M, C, m_dev);
     else hipLaunchKernelGGL(add_layernorm_fwd_kernel<float>, dim3((unsigned)blocks), dim3(NT), 0, st, (const float*)x, (const float*)r, gamma, beta, eps, (float*)y, rstat, M, C, m_dev);
     MG_CHECK_LAUNCH();
     return 0;
@@ -312,9 +317,10 @@ extern "C" int mg_rows_add_layernorm_bwd(const void* dy, const void* x, const vo
     hipStream_t st = (hipStream_t)stream;
     { hipError_t e = mg_zero_words(dgamma, C, st); if (e != hipSuccess) return (int)e; e = mg_zero_words(dbeta, C, st); if (e != hipSuccess) return (int)e; }
     if (M <= 0) return 0;
-    const int lpr = C / (dtype == MG_BF16 ? 8 : 4), rpb = NT / lpr;
+    const int lpr = C / (MG_IS16(dtype) ? 8 : 4), rpb = NT / lpr;
     long blocks = ((long)M + rpb - 1) / rpb; if (blocks > 512) blocks = 512;
     if (dtype == MG_BF16) hipLaunchKernelGGL(add_layernorm_bwd_kernel<bf16raw>, dim3((unsigned)blocks), dim3(NT), 0, st, (const bf16raw*)dy, (const bf16raw*)x, (const bf16raw*)r, gamma, rstat, (bf16raw*)dz, dgamma, dbeta, M, C, m_dev);
+    else if (dtype == MG_F16) hipLaunchKernelGGL(add_layernorm_bwd_kernel<f16raw>, dim3((unsigned)blocks), dim3(NT), 0, st, (const f16raw*)dy, (const f16raw*)x, (const f16raw*)r, gamma, rstat, (f16raw*)dz, dgamma, dbeta, M, C, m_dev);
     else hipLaunchKernelGGL(add_layernorm_bwd_kernel<float>, dim3((unsigned)blocks), dim3(NT), 0, st, (const float*)dy, (const float*)x, (const float*)r, gamma, rstat, (float*)dz, dgamma, dbeta, M, C, m_dev);
     MG_CHECK_LAUNCH();
     return 0;

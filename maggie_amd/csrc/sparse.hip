@@ -215,7 +215,7 @@ __global__ __launch_bounds__(NT) void mask_embed_kernel(const float* __restrict_
         float inv = 1.f / (cnt + 1e-6f);
         f[3] = e[0] * inv; f[4] = e[1] * inv; f[5] = e[2] * inv; f[6] = 0.f; f[7] = 0.f;
         T* dst = out + i * 8;
-        if (sizeof(T) == 2) *(uint4*)dst = ElemTraits<bf16raw>::pack(f);
+        if constexpr (sizeof(T) == 2) *(uint4*)dst = ElemTraits<T>::pack(f);
         else { *(uint4*)dst = ElemTraits<float>::pack(f); *(uint4*)((float*)dst + 4) = ElemTraits<float>::pack(f + 4); }
     }
 }
@@ -392,11 +392,12 @@ extern "C" int mg_gather_rows(const void* dense, int dtype, const int32_t* coord
 extern "C" int mg_gather_rows_dev(const void* dense, int dtype, const int32_t* coords, int R, int n_i, int Hd, int Wd, int C, const float* mul,
                                   int mul_ninst, void* out, int ldo, int yoff, const int32_t* r_dev, void* stream) {
     if (R <= 0) return 0;
-    const int ce = dtype == MG_BF16 ? 8 : 4;
+    const int ce = MG_IS16(dtype) ? 8 : 4;
     if (C % ce || ldo % ce || yoff % ce) return -3;
     long total = (long)R * (C / ce);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MG_BF16) hipLaunchKernelGGL(gather_rows_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const bf16raw*)dense, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, (bf16raw*)out, ldo, yoff, r_dev);
+    else if (dtype == MG_F16) hipLaunchKernelGGL(gather_rows_kernel<f16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const f16raw*)dense, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, (f16raw*)out, ldo, yoff, r_dev);
     else hipLaunchKernelGGL(gather_rows_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, st, (const float*)dense, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, (float*)out, ldo, yoff, r_dev);
     MG_CHECK_LAUNCH();
     return 0;
@@ -411,11 +412,12 @@ extern "C" int mg_gather_rows_bwd(const void* dout, int dtype, int ldo, int yoff
 extern "C" int mg_gather_rows_bwd_dev(const void* dout, int dtype, int ldo, int yoff, const int32_t* coords, int R, int n_i, int Hd, int Wd, int C,
                                       const float* mul, int mul_ninst, const void* dense, float* ddense, float* dmul, const int32_t* r_dev, void* stream) {
     if (R <= 0) return 0;
-    const int ce = dtype == MG_BF16 ? 8 : 4;
+    const int ce = MG_IS16(dtype) ? 8 : 4;
     if (C % ce || ldo % ce || yoff % ce) return -3;
     long total = (long)R * (C / ce);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MG_BF16) hipLaunchKernelGGL(gather_rows_bwd_kernel<bf16raw>, dim3(grid_for(total) > 512 ? 512 : grid_for(total)), dim3(NT), 0, st, (const bf16raw*)dout, ldo, yoff, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, (const bf16raw*)dense, ddense, dmul, r_dev);
+    else if (dtype == MG_F16) hipLaunchKernelGGL(gather_rows_bwd_kernel<f16raw>, dim3(grid_for(total) > 512 ? 512 : grid_for(total)), dim3(NT), 0, st, (const f16raw*)dout, ldo, yoff, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, (const f16raw*)dense, ddense, dmul, r_dev);
     else hipLaunchKernelGGL(gather_rows_bwd_kernel<float>, dim3(grid_for(total) > 512 ? 512 : grid_for(total)), dim3(NT), 0, st, (const float*)dout, ldo, yoff, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, (const float*)dense, ddense, dmul, r_dev);
     MG_CHECK_LAUNCH();
     return 0;
@@ -423,12 +425,13 @@ extern "C" int mg_gather_rows_bwd_dev(const void* dout, int dtype, int ldo, int 
 
 extern "C" int mg_gather_rows_bwd_dense(const void* dout, int dtype, int ldo, int yoff, const void* bits, const int32_t* wordoff, int n_i, int N,
                                         int Hd, int Wd, int C, const float* mul, int mul_ninst, void* ddense, void* stream) {
-    const int ce = dtype == MG_BF16 ? 8 : 4;
+    const int ce = MG_IS16(dtype) ? 8 : 4;
     if (C % ce || ldo % ce || yoff % ce) return -3;
     long total = (long)N * Hd * Wd * (C / ce);
     if (total <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MG_BF16) hipLaunchKernelGGL(gather_rows_bwd_dense_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const bf16raw*)dout, ldo, yoff, (const unsigned long long*)bits, wordoff, n_i, N, Hd, Wd, C, mul, mul_ninst, (bf16raw*)ddense);
+    else if (dtype == MG_F16) hipLaunchKernelGGL(gather_rows_bwd_dense_kernel<f16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const f16raw*)dout, ldo, yoff, (const unsigned long long*)bits, wordoff, n_i, N, Hd, Wd, C, mul, mul_ninst, (f16raw*)ddense);
     else hipLaunchKernelGGL(gather_rows_bwd_dense_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, st, (const float*)dout, ldo, yoff, (const unsigned long long*)bits, wordoff, n_i, N, Hd, Wd, C, mul, mul_ninst, (float*)ddense);
     MG_CHECK_LAUNCH();
     return 0;
@@ -448,6 +451,7 @@ extern "C" int mg_scatter_plane_dev(const void* vals, int dtype, int ldv, int co
     hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(NT), 0, st, plane, n, fill);
     if (R > 0) {
         if (dtype == MG_BF16) hipLaunchKernelGGL(scatter_plane_kernel<bf16raw>, dim3(grid_for(R)), dim3(NT), 0, st, (const bf16raw*)vals, ldv, col, coords, R, H, W, plane, r_dev);
+        else if (dtype == MG_F16) hipLaunchKernelGGL(scatter_plane_kernel<f16raw>, dim3(grid_for(R)), dim3(NT), 0, st, (const f16raw*)vals, ldv, col, coords, R, H, W, plane, r_dev);
         else hipLaunchKernelGGL(scatter_plane_kernel<float>, dim3(grid_for(R)), dim3(NT), 0, st, (const float*)vals, ldv, col, coords, R, H, W, plane, r_dev);
     }
     MG_CHECK_LAUNCH();
@@ -465,6 +469,7 @@ extern "C" int mg_gather_plane_dev(const float* plane, const int32_t* coords, in
     if (R <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MG_BF16) hipLaunchKernelGGL(gather_plane_kernel<bf16raw>, dim3(grid_for(R)), dim3(NT), 0, st, plane, coords, R, H, W, (bf16raw*)vals, ldv, col, r_dev, zero_rest);
+    else if (dtype == MG_F16) hipLaunchKernelGGL(gather_plane_kernel<f16raw>, dim3(grid_for(R)), dim3(NT), 0, st, plane, coords, R, H, W, (f16raw*)vals, ldv, col, r_dev, zero_rest);
     else hipLaunchKernelGGL(gather_plane_kernel<float>, dim3(grid_for(R)), dim3(NT), 0, st, plane, coords, R, H, W, (float*)vals, ldv, col, r_dev, zero_rest);
     MG_CHECK_LAUNCH();
     return 0;
@@ -477,6 +482,7 @@ extern "C" int mg_mask_embed(const float* image, const float* masks, const float
     if (H % Hm || W % Wm || n_embed > 3) return -2;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MG_BF16) hipLaunchKernelGGL(mask_embed_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), 0, st, image, masks, table, N, H, W, n_m, Hm, Wm, n_embed, (bf16raw*)out);
+    else if (dtype == MG_F16) hipLaunchKernelGGL(mask_embed_kernel<f16raw>, dim3(grid_for(total)), dim3(NT), 0, st, image, masks, table, N, H, W, n_m, Hm, Wm, n_embed, (f16raw*)out);
     else hipLaunchKernelGGL(mask_embed_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, st, image, masks, table, N, H, W, n_m, Hm, Wm, n_embed, (float*)out);
     MG_CHECK_LAUNCH();
     return 0;
@@ -490,6 +496,7 @@ extern "C" int mg_mask_embed_bwd(const void* dx, int dtype, const float* masks, 
     hipStream_t st = (hipStream_t)stream;
     int g = grid_for(total); if (g > 1024) g = 1024;
     if (dtype == MG_BF16) hipLaunchKernelGGL(mask_embed_bwd_kernel<bf16raw>, dim3(g), dim3(NT), 0, st, (const bf16raw*)dx, masks, N, H, W, n_m, Hm, Wm, n_embed, dtable);
+    else if (dtype == MG_F16) hipLaunchKernelGGL(mask_embed_bwd_kernel<f16raw>, dim3(g), dim3(NT), 0, st, (const f16raw*)dx, masks, N, H, W, n_m, Hm, Wm, n_embed, dtable);
     else hipLaunchKernelGGL(mask_embed_bwd_kernel<float>, dim3(g), dim3(NT), 0, st, (const float*)dx, masks, N, H, W, n_m, Hm, Wm, n_embed, dtable);
     MG_CHECK_LAUNCH();
     return 0;
@@ -510,6 +517,7 @@ extern "C" int mg_upsample_tanh_ex(const void* in, int dtype, long sn, long sc, 
     long bx = (hw + NT - 1) / NT; if (bx > 64) bx = 64;
     dim3 grid((unsigned)bx, (unsigned)(N * C));
     if (dtype == MG_BF16) hipLaunchKernelGGL(upsample_tanh_kernel<bf16raw>, grid, dim3(NT), 0, st, (const bf16raw*)in, sn, sc, sy, sx, N, C, h, w, scale, apply_tanh, out, pscale, any_nonzero);
+    else if (dtype == MG_F16) hipLaunchKernelGGL(upsample_tanh_kernel<f16raw>, grid, dim3(NT), 0, st, (const f16raw*)in, sn, sc, sy, sx, N, C, h, w, scale, apply_tanh, out, pscale, any_nonzero);
     else hipLaunchKernelGGL(upsample_tanh_kernel<float>, grid, dim3(NT), 0, st, (const float*)in, sn, sc, sy, sx, N, C, h, w, scale, apply_tanh, out, pscale, any_nonzero);
     MG_CHECK_LAUNCH();
     return 0;

@@ -132,6 +132,7 @@ extern "C" int mg_spectral_norm(const float* W, float* u, float* v, int A, int B
     int blocks = grid_for(need);
     if ((long)blocks * NT < (Wd > A ? Wd : A)) blocks = (int)(((Wd > A ? Wd : A) + NT - 1) / NT);
     if (out_dtype == MG_BF16) hipLaunchKernelGGL(sn_finish_kernel<bf16raw>, dim3(blocks), dim3(NT), 0, st, W, t, s, scratch, A, B, taps, transposed, pad_in, u, v, (bf16raw*)out);
+    else if (out_dtype == MG_F16) hipLaunchKernelGGL(sn_finish_kernel<f16raw>, dim3(blocks), dim3(NT), 0, st, W, t, s, scratch, A, B, taps, transposed, pad_in, u, v, (f16raw*)out);
     else hipLaunchKernelGGL(sn_finish_kernel<float>, dim3(blocks), dim3(NT), 0, st, W, t, s, scratch, A, B, taps, transposed, pad_in, u, v, (float*)out);
     MG_CHECK_LAUNCH();
     return 0;
@@ -389,6 +390,7 @@ extern "C" int mg_spectral_norm_batched(const mg_sn_desc* descs, int n_conv, con
     hipLaunchKernelGGL(snb_wt_u_kernel, dim3(n1), dim3(NT), 0, st, descs, (const int4*)items_k1, work_base);
     hipLaunchKernelGGL(snb_w_t_kernel, dim3(n2), dim3(NT), 0, st, descs, (const int4*)items_k2, work_base);
     if (out_dtype == MG_BF16) hipLaunchKernelGGL(snb_finish_kernel<bf16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, work_base, (bf16raw*)out_base, (bf16raw*)out_t_base);
+    else if (out_dtype == MG_F16) hipLaunchKernelGGL(snb_finish_kernel<f16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, work_base, (f16raw*)out_base, (f16raw*)out_t_base);
     else hipLaunchKernelGGL(snb_finish_kernel<float>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, work_base, (float*)out_base, (float*)out_t_base);
     hipLaunchKernelGGL(snb_vectors_kernel, dim3(n_conv), dim3(NT), 0, st, descs, n_conv, work_base);
     MG_CHECK_LAUNCH();
@@ -404,6 +406,9 @@ extern "C" int mg_spectral_norm_batched_bwd(const mg_sn_desc* descs, int n_conv,
     if (g_dtype == MG_BF16) {
         hipLaunchKernelGGL(snb_bwd_dot_kernel<bf16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, work_base);
         hipLaunchKernelGGL(snb_bwd_apply_kernel<bf16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, work_base, dW_base);
+    } else if (g_dtype == MG_F16) {
+        hipLaunchKernelGGL(snb_bwd_dot_kernel<f16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, work_base);
+        hipLaunchKernelGGL(snb_bwd_apply_kernel<f16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, work_base, dW_base);
     } else {
         hipLaunchKernelGGL(snb_bwd_dot_kernel<float>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, work_base);
         hipLaunchKernelGGL(snb_bwd_apply_kernel<float>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, work_base, dW_base);

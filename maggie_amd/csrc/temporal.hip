@@ -135,8 +135,8 @@ __global__ __launch_bounds__(NT) void temporal_fuse_kernel(float* __restrict__ a
 }  // namespace
 
 static inline int gru_check(int dtype, int M, int C, long* total) {
-    const int ce = dtype == MG_BF16 ? 8 : 4;
-    if (dtype != MG_BF16 && dtype != MG_F32) return -6;
+    const int ce = MG_IS16(dtype) ? 8 : 4;
+    if (!MG_IS16(dtype) && dtype != MG_F32) return -6;
     if (C % ce) return -3;
     *total = (long)M * (C / ce);
     return 0;
@@ -147,6 +147,7 @@ extern "C" int mg_gru_gate_fwd(const void* rz, const void* x, const void* h, int
     if (M <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MG_BF16) hipLaunchKernelGGL(gru_gate_fwd_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const bf16raw*)rz, (const bf16raw*)x, (const bf16raw*)h, M, C, (bf16raw*)xrh);
+    else if (dtype == MG_F16) hipLaunchKernelGGL(gru_gate_fwd_kernel<f16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const f16raw*)rz, (const f16raw*)x, (const f16raw*)h, M, C, (f16raw*)xrh);
     else hipLaunchKernelGGL(gru_gate_fwd_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, st, (const float*)rz, (const float*)x, (const float*)h, M, C, (float*)xrh);
     MG_CHECK_LAUNCH();
     return 0;
@@ -158,6 +159,7 @@ extern "C" int mg_gru_gate_bwd(const void* dxrh, const void* rz, const void* h, 
     if (M <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MG_BF16) hipLaunchKernelGGL(gru_gate_bwd_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const bf16raw*)dxrh, (const bf16raw*)rz, (const bf16raw*)h, M, C, (bf16raw*)dx, (bf16raw*)drz, 2 * C, (bf16raw*)dh_part);
+    else if (dtype == MG_F16) hipLaunchKernelGGL(gru_gate_bwd_kernel<f16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const f16raw*)dxrh, (const f16raw*)rz, (const f16raw*)h, M, C, (f16raw*)dx, (f16raw*)drz, 2 * C, (f16raw*)dh_part);
     else hipLaunchKernelGGL(gru_gate_bwd_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, st, (const float*)dxrh, (const float*)rz, (const float*)h, M, C, (float*)dx, (float*)drz, 2 * C, (float*)dh_part);
     MG_CHECK_LAUNCH();
     return 0;
@@ -168,6 +170,7 @@ extern "C" int mg_gru_out_fwd(const void* rz, const void* cpre, const void* h, i
     if (M <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MG_BF16) hipLaunchKernelGGL(gru_out_fwd_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const bf16raw*)rz, (const bf16raw*)cpre, (const bf16raw*)h, M, C, (bf16raw*)hn);
+    else if (dtype == MG_F16) hipLaunchKernelGGL(gru_out_fwd_kernel<f16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const f16raw*)rz, (const f16raw*)cpre, (const f16raw*)h, M, C, (f16raw*)hn);
     else hipLaunchKernelGGL(gru_out_fwd_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, st, (const float*)rz, (const float*)cpre, (const float*)h, M, C, (float*)hn);
     MG_CHECK_LAUNCH();
     return 0;
@@ -180,6 +183,7 @@ extern "C" int mg_gru_out_bwd(const void* dhn, const void* rz, const void* cpre,
     if (M <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MG_BF16) hipLaunchKernelGGL(gru_out_bwd_kernel<bf16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const bf16raw*)dhn, (const bf16raw*)rz, (const bf16raw*)cpre, (const bf16raw*)h, M, C, (bf16raw*)drz + C, 2 * C, (bf16raw*)dc_pre, (bf16raw*)dh_part);
+    else if (dtype == MG_F16) hipLaunchKernelGGL(gru_out_bwd_kernel<f16raw>, dim3(grid_for(total)), dim3(NT), 0, st, (const f16raw*)dhn, (const f16raw*)rz, (const f16raw*)cpre, (const f16raw*)h, M, C, (f16raw*)drz + C, 2 * C, (f16raw*)dc_pre, (f16raw*)dh_part);
     else hipLaunchKernelGGL(gru_out_bwd_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, st, (const float*)dhn, (const float*)rz, (const float*)cpre, (const float*)h, M, C, (float*)drz + C, 2 * C, (float*)dc_pre, (float*)dh_part);
     MG_CHECK_LAUNCH();
     return 0;

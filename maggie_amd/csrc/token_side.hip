@@ -615,11 +615,12 @@ extern "C" int mg_token_sa_bwd(const float* dout, const float* q, const float* k
 extern "C" int mg_token_einsum_fwd(const void* feat, int dtype, const float* tok, int B, int L, int C, int Q, int QP, void* out, void* stream) {
     if (B <= 0 || L <= 0) return 0;
     if ((C != 32 && C != 64) || Q < 1 || Q > 16 || QP != 16) return -3;
-    if (dtype != MG_BF16 && dtype != MG_F32) return -6;
+    if (!MG_IS16(dtype) && dtype != MG_F32) return -6;
     dim3 grid((L + NT - 1) / NT, B);
     hipStream_t st = (hipStream_t)stream;
 #define EINSUM_FWD(T, CC) hipLaunchKernelGGL((token_einsum_fwd_kernel<T, CC>), grid, dim3(NT), 0, st, (const T*)feat, tok, L, Q, QP, (T*)out)
     if (dtype == MG_BF16) { if (C == 32) EINSUM_FWD(bf16raw, 32); else EINSUM_FWD(bf16raw, 64); }
+    else if (dtype == MG_F16) { if (C == 32) EINSUM_FWD(f16raw, 32); else EINSUM_FWD(f16raw, 64); }
     else { if (C == 32) EINSUM_FWD(float, 32); else EINSUM_FWD(float, 64); }
 #undef EINSUM_FWD
     MG_CHECK_LAUNCH();
@@ -630,13 +631,14 @@ extern "C" int mg_token_einsum_bwd(const void* dlog, const void* feat, int dtype
                                    float* dtok, void* stream) {
     if (B <= 0 || L <= 0) return 0;
     if ((C != 32 && C != 64) || Q < 1 || Q > 16 || QP != 16) return -3;
-    if (dtype != MG_BF16 && dtype != MG_F32) return -6;
+    if (!MG_IS16(dtype) && dtype != MG_F32) return -6;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = mg_zero_words(dtok, (long)B * Q * C, st);
     if (e != hipSuccess) return (int)e;
     dim3 grid((L + NT - 1) / NT, B);
 #define EINSUM_BWD(T, CC) hipLaunchKernelGGL((token_einsum_bwd_kernel<T, CC>), grid, dim3(NT), 0, st, (const T*)dlog, (const T*)feat, tok, L, Q, QP, (T*)dfeat, dtok)
     if (dtype == MG_BF16) { if (C == 32) EINSUM_BWD(bf16raw, 32); else EINSUM_BWD(bf16raw, 64); }
+    else if (dtype == MG_F16) { if (C == 32) EINSUM_BWD(f16raw, 32); else EINSUM_BWD(f16raw, 64); }
     else { if (C == 32) EINSUM_BWD(float, 32); else EINSUM_BWD(float, 64); }
 #undef EINSUM_BWD
     MG_CHECK_LAUNCH();

@@ -13,9 +13,11 @@ namespace {
 
 struct WbArgs { mg_wb_entry e[MG_WB_MAX_ENTRIES]; };
 
-__device__ __forceinline__ float wb_ld(const void* p, long i, int dt) { return dt == MG_BF16 ? bf2f(((const bf16raw*)p)[i]) : ((const float*)p)[i]; }
+__device__ __forceinline__ float wb_ld(const void* p, long i, int dt) {
+    return dt == MG_BF16 ? bf2f(((const bf16raw*)p)[i]) : dt == MG_F16 ? ElemTraits<f16raw>::ld((const f16raw*)p + i) : ((const float*)p)[i];
+}
 __device__ __forceinline__ void wb_st(void* p, long i, int dt, float v) {
-    if (dt == MG_BF16) ((bf16raw*)p)[i] = f2bf(v); else ((float*)p)[i] = v;
+    if (dt == MG_BF16) ((bf16raw*)p)[i] = f2bf(v); else if (dt == MG_F16) ElemTraits<f16raw>::st((f16raw*)p + i, v); else ((float*)p)[i] = v;
 }
 
 __global__ __launch_bounds__(256) void wb_fwd_kernel(const WbArgs a) {

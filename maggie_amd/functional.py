@@ -126,14 +126,15 @@ _FP16_WARNED = False
 
 
 def compute_dtype():
-    """bf16 inside torch.autocast(device_type='cuda') (the reference's --precision 16 path uses fp16 autocast,
-    engine/train.py:208,227-229; bf16 is this build's choice), fp32 otherwise."""
+    """The kernels' 16-bit storage type inside torch.autocast(device_type='cuda'): bf16 (this build's choice, BASELINE north_star) or fp16 (the
+    reference's `--precision 16`: torch.cuda.amp fp16 autocast + GradScaler, engine/train.py:208,227-229 -- served by the fp16 instantiations
+    of the same kernels, v_mfma_f32_16x16x32_f16, fp32 accumulate); fp32 otherwise. MAGGIE_FP16_AUTOCAST=bf16 serves fp16 autocast with the
+    bf16 kernels instead (fp32's exponent range: the loss scaler keeps working but is not needed; 8 mantissa bits instead of 11)."""
     if torch.is_autocast_enabled():
         dt = torch.get_autocast_dtype('cuda') if hasattr(torch, 'get_autocast_dtype') else torch.get_autocast_gpu_dtype()
-        if dt == torch.float16 and FP16_AUTOCAST_AS_BF16:
-            # explicit opt-in (MAGGIE_FP16_AUTOCAST=bf16): the unchanged harness with `--precision 16` (engine/train.py:208,227-229: fp16 autocast +
-            # GradScaler) runs on the bf16 kernels. bf16 has fp32's exponent range, so the scaler's 2^16 loss scale is harmless (gradients are
-            # fp32 when `unscale_` checks them for inf) -- but the mantissa is 8 bits, not fp16's 11: said once, loudly.
+        if dt == torch.float16:
+            if not FP16_AUTOCAST_AS_BF16:
+                return torch.float16
             global _FP16_WARNED
             if not _FP16_WARNED:
                 _FP16_WARNED = True
@@ -142,12 +143,8 @@ def compute_dtype():
                               'keeps working but is not needed.')
             return torch.bfloat16
         if dt != torch.bfloat16:
-            # the unchanged harness with `--precision 16` (fp16 autocast + GradScaler) must not silently compute in bf16 under a
-            # loss scaler: there is no fp16 kernel family in this build -- say so
-            raise K.hip.MaggieHipError(
-                'MaGGIe (MI355X build): autocast dtype %s is not supported -- the HIP kernels compute in bf16 (fp32 accumulate) or fp32. '
-                'Use torch.autocast("cuda", dtype=torch.bfloat16) and drop the GradScaler (bf16 needs no loss scaling), run without '
-                'autocast for fp32, or set MAGGIE_FP16_AUTOCAST=bf16 to serve fp16 autocast with the bf16 kernels.' % dt)
+            raise K.hip.MaggieHipError('MaGGIe (MI355X build): autocast dtype %s is not supported -- the HIP kernels compute in bf16 or fp16 '
+                                       '(fp32 accumulate) under autocast, fp32 without.' % dt)
         return torch.bfloat16
     return torch.float32
 
@@ -296,8 +293,8 @@ class WeightBank(torch.autograd.Function):
     def forward(ctx, plan, dtype, *params):
         dev = params[0].device
         want_t = any(ctx.needs_input_grad[2:])
-        code = K.hip.BF16 if dtype == torch.bfloat16 else K.hip.F32
-        esz = 2 if dtype == torch.bfloat16 else 4
+        code = K.hip.code_of(dtype)
+        esz = 4 if dtype == torch.float32 else 2
         w = torch.empty(plan.total_w, dtype=dtype, device=dev)
         wt = torch.empty(plan.total_w, dtype=dtype, device=dev) if want_t else None
         b = torch.empty(max(plan.total_b, 1), dtype=torch.float32, device=dev)
@@ -492,7 +489,7 @@ class SpectralNormBatch(torch.autograd.Function):
             ptrs = host_ptrs.to(dev, non_blocking=True)
         dW = torch.empty(plan.total_dw, dtype=torch.float32, device=dev)
         K.hip.call('mg_spectral_norm_batched_bwd', K.hip.ptr(plan.descs), K.c_int(plan.n), K.hip.ptr(plan.k3), K.c_int(plan.k3.shape[0]),
-                   K.hip.ptr(ptrs), K.c_int(K.hip.BF16 if plan.dtype == torch.bfloat16 else K.hip.F32), K.hip.ptr(work), K.hip.ptr(dW),
+                   K.hip.ptr(ptrs), K.c_int(K.hip.code_of(plan.dtype)), K.hip.ptr(work), K.hip.ptr(dW),
                    K.hip.stream())
         outs = tuple(dW[o:o + n].view(sh[3]) for (o, n), sh in zip(plan.dw_slices, plan.shapes))
         return (None,) + outs

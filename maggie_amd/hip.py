@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libmaggie_hip.so')
 _LIB = None
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 3          # MG_F32 / MG_BF16 / MG_F16 (2 is MG_U8, mask planes only)
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 MODE_CONV, MODE_TCONV, MODE_GATHER = 0, 1, 2
 
@@ -55,11 +55,24 @@ def lib():
     return _LIB
 
 
+def code_of(dtype):
+    """torch dtype -> MG_* code (fp32, bf16, fp16)."""
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    if dtype == torch.float16:
+        return F16
+    raise MaggieHipError('unsupported dtype %s' % dtype)
+
+
 def dtype_code(t):
     if t.dtype == torch.float32:
         return F32
     if t.dtype == torch.bfloat16:
         return BF16
+    if t.dtype == torch.float16:
+        return F16
     raise MaggieHipError('unsupported dtype %s' % t.dtype)
 
 

@@ -10,6 +10,8 @@ import torch
 from . import hip
 from .hip import ConvParams, MODE_CONV, MODE_TCONV, MODE_GATHER, ACT_NONE, ACT_RELU, ACT_LRELU  # noqa: F401
 
+_DT_TAG = {torch.float32: 'f32', torch.bfloat16: 'bf16', torch.float16: 'f16'}
+
 
 def _ld(t):
     """Row pitch (elements) of a channel-contiguous tensor."""
@@ -91,10 +93,10 @@ def conv_fprop(x, w, *, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=None, Wout=None,
     work = None
     if rows is None:
         work = executed * ((alg_cin or Cin) / Cin) * ((alg_cout or Cout) / Cout) / (stride * stride if mode == MODE_TCONV else 1)
-    if mode == MODE_TCONV and stride == 2 and dil == 1 and rows is None and Cin % (32 if x.dtype == torch.bfloat16 else 16) == 0 \
+    if mode == MODE_TCONV and stride == 2 and dil == 1 and rows is None and Cin % (16 if x.dtype == torch.float32 else 32) == 0 \
             and Hout % 2 == 0 and Wout % 2 == 0:
         executed /= 4.0                         # phase-decomposed walk (csrc/conv_igemm.hip: tconv_phased): only the taps that exist
-    tag = ('bf16' if x.dtype == torch.bfloat16 else 'f32', mode, Cout, R * S * Cin, M, executed, rows is not None)
+    tag = (_DT_TAG[x.dtype], mode, Cout, R * S * Cin, M, executed, rows is not None)
     if mode != MODE_GATHER and 0 < M <= 8192 and Cout >= 64 and rows is None:
         # deep layers with few rows: the library may split K over several blocks per tile (mg_conv_fprop_ws)
         need = _fprop_workspace_fn()(ctypes.byref(p))
@@ -131,7 +133,7 @@ def conv_wgrad(x, dy, *, cout, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=1, Wout=1
     p = _conv_params(x, None, dy, mode, N, Hin, Win, Hout, Wout, R, S, stride, pad, dil, M, Cin, cout, nbr, yoff=yoff)
     if out is not None:
         out_dtype = out.dtype
-    p.dw_dtype = hip.BF16 if out_dtype == torch.bfloat16 else hip.F32
+    p.dw_dtype = hip.code_of(out_dtype)
     p.m_dev = hip.ptr(rows)
     lib = hip.lib()
     lib.mg_conv_wgrad_workspace.restype = ctypes.c_long
@@ -145,7 +147,7 @@ def conv_wgrad(x, dy, *, cout, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=1, Wout=1
     executed = 2.0 * M * cout * R * S * Cin
     work = None if rows is not None else executed * ((alg_cin or Cin) / Cin) * ((alg_cout or cout) / cout) / (stride * stride if mode == MODE_TCONV else 1)
     hip.call('mg_conv_wgrad_ws', ctypes.byref(p), hip.ptr(ws), ctypes.c_long(need if ws is not None else 0), hip.stream(),
-             work=work, tag=('bf16' if x.dtype == torch.bfloat16 else 'f32', mode, cout, R * S * Cin, M, executed, rows is not None))
+             work=work, tag=(_DT_TAG[x.dtype], mode, cout, R * S * Cin, M, executed, rows is not None))
     return out
 
 
@@ -531,7 +533,7 @@ def gather_plane(plane, coords, like, width=1, rows=None):
     P, H, W = plane.shape
     out = torch.empty((R, width), dtype=like, device=plane.device)
     hip.call('mg_gather_plane_dev', hip.ptr(plane), hip.ptr(coords), c_int(R), c_int(H), c_int(W), hip.ptr(out),
-             c_int(hip.BF16 if like == torch.bfloat16 else hip.F32), c_int(width), c_int(0), hip.ptr(rows), c_int(int(width > 1)), hip.stream())
+             c_int(hip.code_of(like)), c_int(width), c_int(0), hip.ptr(rows), c_int(int(width > 1)), hip.stream())
     return out
 
 

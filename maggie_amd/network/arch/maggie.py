@@ -239,7 +239,9 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         from ... import graphs
         mutable = [t for t in self.buffers()] + [p for p in self.parameters() if not p.requires_grad] + self.decoder.head_state()
         try:
-            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=torch.is_autocast_enabled(), cache_enabled=False):
+            amp_dt = (torch.get_autocast_dtype('cuda') if hasattr(torch, 'get_autocast_dtype') else torch.get_autocast_gpu_dtype()) \
+                if torch.is_autocast_enabled() else torch.bfloat16
+            with torch.autocast('cuda', dtype=amp_dt, enabled=torch.is_autocast_enabled(), cache_enabled=False):
                 g = graphs.GraphedCallable(fn, inputs, self, mutable, self.training, grad_inputs=grad_inputs,
                                            grad_sink=self.__dict__.get('grad_sink'))
             overlap = self.__dict__.get('_grad_overlap')

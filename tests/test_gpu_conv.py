@@ -24,8 +24,11 @@ def _krsc(w):                         # (Cout, Cin, R, S) -> (Cout, R*S, Cin)
     return w.permute(0, 2, 3, 1).reshape(co, r * s, ci).contiguous()
 
 
+DTYPES = [torch.float32, torch.bfloat16, torch.float16]      # fp16: the reference's `--precision 16` storage type (same kernels, v_mfma_f32_16x16x32_f16)
+
+
 def _tol(dtype):
-    return 2e-4 if dtype == torch.float32 else 2.5e-2
+    return {torch.float32: 2e-4, torch.bfloat16: 2.5e-2, torch.float16: 4e-3}[dtype]
 
 
 CASES = [
@@ -57,7 +60,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('case', CASES)
 def test_conv_fprop_dgrad_wgrad(case, dtype):
     from maggie_amd import kernels as K
@@ -66,15 +69,15 @@ def test_conv_fprop_dgrad_wgrad(case, dtype):
     rs = np.random.RandomState(hash(case) % 1000)
     x = torch.from_numpy(rs.normal(size=(N, Cin, H, W)).astype(np.float32))
     w = torch.from_numpy((rs.normal(size=(Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32))
-    if dtype == torch.bfloat16:
-        x, w = x.bfloat16().float(), w.bfloat16().float()
+    if dtype != torch.float32:
+        x, w = x.to(dtype).float(), w.to(dtype).float()
     x.requires_grad_(True)
     w.requires_grad_(True)
     y_ref = F.conv2d(x, w, None, stride, pad, dil)
     Ho, Wo = y_ref.shape[-2:]
     gy = torch.from_numpy(rs.normal(size=tuple(y_ref.shape)).astype(np.float32))
-    if dtype == torch.bfloat16:
-        gy = gy.bfloat16().float()
+    if dtype != torch.float32:
+        gy = gy.to(dtype).float()
     y_ref.backward(gy)
 
     xd = _nhwc(x.detach()).to(dev, dtype)
@@ -97,21 +100,21 @@ def test_conv_fprop_dgrad_wgrad(case, dtype):
                       pad=pad, dil=dil)
     dw = dw.cpu().reshape(Cout, k, k, Cin).permute(0, 3, 1, 2)
     assert (dw - w.grad).abs().max().item() <= _tol(dtype) * w.grad.abs().max().item()
-    if dtype == torch.bfloat16:                       # converting reduce: dW written directly in bf16
+    if dtype != torch.float32:                        # converting reduce: dW written directly in the 16-bit type
         dwb = K.conv_wgrad(xd, gyd, cout=Cout, mode=K.MODE_CONV, N=N, Hin=H, Win=W, Hout=Ho, Wout=Wo, R=k, S=k, stride=stride,
-                           pad=pad, dil=dil, out_dtype=torch.bfloat16)
-        assert dwb.dtype == torch.bfloat16
+                           pad=pad, dil=dil, out_dtype=dtype)
+        assert dwb.dtype == dtype
         dwb = dwb.float().cpu().reshape(Cout, k, k, Cin).permute(0, 3, 1, 2)
         assert (dwb - dw).abs().max().item() <= 1e-2 * dw.abs().max().item()
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_conv_epilogue_and_stats(dtype):
     from maggie_amd import kernels as K
     dev = _dev()
     N, Cin, Cout, H, W = 2, 32, 64, 16, 16
     rs = np.random.RandomState(3)
-    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    q = (lambda t: t.to(dtype).float()) if dtype != torch.float32 else (lambda t: t)
     x = q(torch.from_numpy(rs.normal(size=(N, Cin, H, W)).astype(np.float32)))
     w = q(torch.from_numpy((rs.normal(size=(Cout, Cin, 3, 3)) / 17).astype(np.float32)))
     res = q(torch.from_numpy(rs.normal(size=(N, Cout, H // 2, W // 2)).astype(np.float32)))
@@ -133,14 +136,14 @@ def test_conv_epilogue_and_stats(dtype):
     assert torch.allclose(s[Cout:], (y * y).sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_conv_transpose_k4s2(dtype):
     """ConvTranspose2d(k=4, s=2, p=1) forward == TCONV-mode implicit GEMM (decoder/resnet.py:20)."""
     from maggie_amd import kernels as K
     dev = _dev()
     N, Cin, Cout, H, W = 2, 64, 48, 7, 9
     rs = np.random.RandomState(4)
-    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    q = (lambda t: t.to(dtype).float()) if dtype != torch.float32 else (lambda t: t)
     x = q(torch.from_numpy(rs.normal(size=(N, Cin, H, W)).astype(np.float32)))
     w = q(torch.from_numpy((rs.normal(size=(Cin, Cout, 4, 4)) / 20).astype(np.float32)))
     y_ref = F.conv_transpose2d(x, w, None, 2, 1)
@@ -151,7 +154,7 @@ def test_conv_transpose_k4s2(dtype):
     assert (y - y_ref).abs().max().item() <= _tol(dtype) * y_ref.abs().max().item()
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_conv_transpose_phased_epilogue(dtype):
     """The phase-major row order of the stride-2 transposed walk must be invisible to the epilogue: scale / shift, post residual, channel
     slice of a wider buffer and the BatchNorm statistics, on a geometry whose phases are not whole row tiles (Mp = 480)."""
@@ -159,7 +162,7 @@ def test_conv_transpose_phased_epilogue(dtype):
     dev = _dev()
     N, Cin, Cout, H, W = 2, 64, 64, 12, 20
     rs = np.random.RandomState(14)
-    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    q = (lambda t: t.to(dtype).float()) if dtype != torch.float32 else (lambda t: t)
     x = q(torch.from_numpy(rs.normal(size=(N, Cin, H, W)).astype(np.float32)))
     w = q(torch.from_numpy((rs.normal(size=(Cin, Cout, 4, 4)) / 20).astype(np.float32)))
     res2 = q(torch.from_numpy(rs.normal(size=(N, Cout, 2 * H, 2 * W)).astype(np.float32)))
@@ -179,7 +182,7 @@ def test_conv_transpose_phased_epilogue(dtype):
     assert torch.allclose(s[Cout:], (y * y).sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', DTYPES)
 def test_gather_conv(dtype):
     """MG_MODE_GATHER against the oracle's gather restatement (submanifold 3x3 over a random active set)."""
     from maggie_amd import kernels as K
@@ -189,7 +192,7 @@ def test_gather_conv(dtype):
     act = rs.uniform(size=(3, 24, 20)) > 0.6
     nbr = region.subm_neighbors(act)
     R_, Cin, Cout = nbr.shape[0], 64, 32
-    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    q = (lambda t: t.to(dtype).float()) if dtype != torch.float32 else (lambda t: t)
     feat = q(torch.from_numpy(rs.normal(size=(R_, Cin)).astype(np.float32)))
     w = q(torch.from_numpy((rs.normal(size=(Cout, 3, 3, Cin)) / 24).astype(np.float32)))
     bias = torch.from_numpy(rs.normal(size=Cout).astype(np.float32))
@@ -215,7 +218,7 @@ SPLITK_CASES = [
 ]
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('case', SPLITK_CASES)
 def test_conv_fprop_split_k(case, dtype):
     """Layers the library runs with the K dimension split over several blocks per tile (partial slabs + finishing kernel):
@@ -226,7 +229,7 @@ def test_conv_fprop_split_k(case, dtype):
     dev = _dev()
     N, Cin, Cout, H, W, k, stride, pad, dil = case
     rs = np.random.RandomState(sum(case))
-    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    q = (lambda t: t.to(dtype).float()) if dtype != torch.float32 else (lambda t: t)
     x = q(torch.from_numpy(rs.normal(size=(N, Cin, H, W)).astype(np.float32))).requires_grad_(True)
     w = q(torch.from_numpy((rs.normal(size=(Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)))
     scale = torch.from_numpy(rs.uniform(0.5, 1.5, Cout).astype(np.float32))
@@ -247,7 +250,7 @@ def test_conv_fprop_split_k(case, dtype):
     # split-K there); the full-epilogue checks below then exercise the halo kernel's epilogue
     p = K._conv_params(xd.view(-1, Cin), wd, torch.empty((N * Ho * Wo, Cout), dtype=dtype, device=dev), K.MODE_CONV, N, H, W, Ho, Wo, k, k, stride,
                        pad, dil, N * Ho * Wo, Cin, Cout)
-    halo = (dtype == torch.bfloat16 and k == 3 and stride == 1 and pad == 1 and dil == 1 and Cin % 32 == 0 and Cin >= 96 and Cout >= 64
+    halo = (dtype != torch.float32 and k == 3 and stride == 1 and pad == 1 and dil == 1 and Cin % 32 == 0 and Cin >= 96 and Cout >= 64
             and W >= 16 and H >= 4)
     need = K._fprop_workspace_fn()(ctypes.byref(p))
     assert need == 0 if halo else need >= 2 * N * Ho * Wo * Cout
@@ -292,7 +295,7 @@ LINK_CASES = [
 ]
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', DTYPES)
 @pytest.mark.parametrize('case', LINK_CASES)
 def test_bn_backward_sums_in_the_consumer_dgrad_epilogue(case, dtype):
     """Round 3 (functional.BnLink, mg_conv_params.bnb_*): conv -> BN(+res, act) -> conv. The second conv's data-gradient epilogue writes
@@ -302,7 +305,7 @@ def test_bn_backward_sums_in_the_consumer_dgrad_epilogue(case, dtype):
     dev = _dev()
     N, C0, C1, C2, H, W, (k2, s2, p2, tr2), act, with_res, carry = case
     rs = np.random.RandomState(sum(case[:6]))
-    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    q = (lambda t: t.to(dtype).float()) if dtype != torch.float32 else (lambda t: t)
     x = q(torch.from_numpy(rs.normal(size=(N, C0, H, W)).astype(np.float32))).requires_grad_(True)
     w1 = q(torch.from_numpy((rs.normal(size=(C1, C0, 3, 3)) / np.sqrt(C0 * 9)).astype(np.float32))).requires_grad_(True)
     w2s = (C1, C2, k2, k2) if tr2 else (C2, C1, k2, k2)

@@ -15,14 +15,14 @@ def _dev():
 
 
 def _q(dtype):
-    return (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    return (lambda t: t.to(dtype).float()) if dtype != torch.float32 else (lambda t: t)
 
 
 def _tol(dtype):
     return 1e-5 if dtype == torch.float32 else 1.6e-2
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('act', [0, 1, 2])
 def test_bn_train_forward_backward(dtype, act):
     from maggie_amd import kernels as K
@@ -150,7 +150,7 @@ def test_active_pyramid_and_tables_bit_exact(hw):
         assert np.array_equal(down, chk)
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 def test_gather_scatter_rows_and_planes(dtype):
     from maggie_amd import kernels as K
     from oracle import region
@@ -212,7 +212,7 @@ def test_upsample_tanh(scale, h, w):
     assert torch.allclose(din[..., :C].cpu().permute(0, 3, 1, 2), xin.grad, atol=1e-5)
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 def test_mask_embed(dtype):
     from maggie_amd import kernels as K
     from oracle import refmodel
@@ -383,13 +383,13 @@ def test_postprocess_alpha_matches_reference_fixture_and_oracle():
     assert abs(float(y[0, 0, 0, 0, 0]) - float(x0)) <= 1e-6
 
 
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 def test_conv_gru_gate_kernels(dtype):
     """mg_gru_gate_{fwd,bwd} / mg_gru_out_{fwd,bwd} against the torch formulas of conv_gru.py:22-27 (autograd on the CPU)."""
     from maggie_amd import functional as MF
     dev = _dev()
     rs = np.random.RandomState(8)
-    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    q = (lambda t: t.to(dtype).float()) if dtype != torch.float32 else (lambda t: t)
     t = lambda *sh: q(torch.from_numpy(rs.normal(size=sh).astype(np.float32)))
     b, H, W, C = 2, 5, 6, 16
     rz, x, h, cp, g1, g2 = t(b, H, W, 2 * C), t(b, H, W, C), t(b, H, W, C), t(b, H, W, C), t(b, H, W, 2 * C), t(b, H, W, C)
@@ -441,7 +441,7 @@ def test_temporal_fuse_kernel():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])
 def test_weight_bank_matches_per_parameter_conversion(dtype):
     """One-launch conversion of all sparse-head parameters (mg_weight_bank) == the per-parameter cast/pad/permute/flip chains,
     bit for bit, forward (kernel layout + input-gradient twin) and backward (gradient back in the parameter's layout)."""
@@ -481,7 +481,7 @@ def test_weight_bank_matches_per_parameter_conversion(dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize('M,C', [(0, 32), (1, 8), (777, 64), (20000, 32)])
 def test_bias_act_bwd(dtype, M, C):
     from maggie_amd import kernels as K
@@ -696,7 +696,7 @@ def test_flat_adamw_sync_group_single_rank_rccl():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('M,with_res,act', [(1000, True, 2), (50000, False, 2), (40000, True, 1), (8, False, 0)])
 def test_batch_norm_act_one_call_path_matches_torch(dtype, M, with_res, act):
     """functional.batch_norm_act (mg_bn_train_fwd / mg_bn_train_bwd: statistics, finalize, apply behind one call each way) against
@@ -780,7 +780,7 @@ def test_os8_weight_matches_reference_statements(reweight):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])
 def test_batched_weight_pipeline_mixes_spectral_norm_and_plain_convs(dtype):
     """functional.spectral_norm_prepare over a list that mixes SpectralNorm wrappers with ordinary conv holders (`plain` descriptors):
     the plain weights come out as the exact per-tensor conversion (KRSC + dgrad twin) and their gradient returns unchanged in OIHW; the
@@ -1068,7 +1068,7 @@ def test_temporal_crop_matches_oracle_restatement():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 def test_rows_dropout_mask_statistics_and_backward_reuse(dtype):
     """inst_spec_layer's dropout (mask_attention.py:170-182, p = 0.1; resnet_inst_matt_spconv.py:226-232) as the counter-based row kernel:
     keep rate within 3 sigma of 1 - p, kept values scaled by exactly 1 / (1 - p), the backward call with the same (state, salt) re-creates
@@ -1134,7 +1134,7 @@ def test_token_linear_with_untransposed_weight_matches_torch(R, Kd, N, xadd):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('B,L,Q,C', [(4, 4096, 10, 64), (1, 777, 10, 32), (2, 300, 16, 64)])
 def test_token_einsum_matches_torch(dtype, B, L, Q, C):
     """mg_token_einsum_fwd / _bwd: einsum('bqc,blc->blq') of instance_matte_decoder.py:296-299 (pixel logits against the instance tokens of the

@@ -405,13 +405,14 @@ def test_video_consecutive_windows_with_prev_pred_match_oracle():
     assert float(((got - want).abs() > ALPHA_TOL).float().mean()) <= 5e-4
 
 
-def test_fp16_autocast_opt_in_runs_the_unchanged_harness_recipe():
-    """INTEGRATION.md section 1 / VERDICT round 2 next #7 (the cheap half): the reference's `--precision 16` recipe (engine/train.py:208,227-229,265-281:
-    fp16 autocast, GradScaler.scale(loss).backward(), unscale_, clip 0.01, scaler.step, scaler.update) runs unchanged when the caller opts in with
-    MAGGIE_FP16_AUTOCAST=bf16 -- on the bf16 kernels, results equal to a bf16-autocast run of the same steps -- and raises loudly without the opt-in."""
+def test_fp16_autocast_runs_the_unchanged_harness_recipe_on_the_fp16_kernels():
+    """VERDICT round 2 missing #2 / next #7: the reference's `--precision 16` recipe (engine/train.py:208,227-229,265-281: fp16 autocast,
+    GradScaler.scale(loss).backward(), unscale_, clip 0.01, scaler.step, scaler.update) runs unchanged on the fp16 instantiations of the HIP
+    kernels (IEEE half storage, v_mfma_f32_16x16x32_f16, fp32 accumulate). Held against an fp32 run of the same steps; fp16 has three mantissa
+    bits more than bf16, so it must sit at least as close to fp32 as the bf16 family does. MAGGIE_FP16_AUTOCAST=bf16 still maps fp16 autocast
+    onto the bf16 kernels (with a warning)."""
     import warnings
     from maggie_amd import functional as MF
-    from maggie_amd.hip import MaggieHipError
     from maggie_amd.utils import synth
     dev = _dev()
     batch = _to(synth.synthetic_batch(2, 1, 2, 64, 64, seed=DSEED, train=True, max_inst=10, it=100), dev)
@@ -421,12 +422,16 @@ def test_fp16_autocast_opt_in_runs_the_unchanged_harness_recipe():
         model.decoder.inst_spec_layer.dropout.p = 0.0
         model.hip_graphs = False
         opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-5)
-        scaler = torch.amp.GradScaler('cuda', enabled=scaler_on)
-        losses = []
+        # init_scale 2^7 instead of the default 2^16: this random-init problem has weight gradients up to ~140 (fp32 run), so any scale beyond ~470
+        # overflows the fp16 weight gradient of the stem conv -- as it does under torch's own fp16 autocast -- and the scaler spends its first steps
+        # backing off (inf gradients -> skipped updates, engine/train.py:277-279); three steps would then compare nothing but forwards
+        scaler = torch.amp.GradScaler('cuda', init_scale=128.0, enabled=scaler_on)
+        losses, seen = [], set()
         for i in range(3):
             seed_all(50 + i)
             opt.zero_grad()
-            with torch.autocast('cuda', dtype=dtype):
+            with torch.autocast('cuda', dtype=dtype, enabled=dtype != torch.float32):
+                seen.add(MF.compute_dtype())
                 out, loss = model(batch)
             scaler.scale(loss['total']).backward()
             scaler.unscale_(opt)
@@ -434,25 +439,58 @@ def test_fp16_autocast_opt_in_runs_the_unchanged_harness_recipe():
             scaler.step(opt)
             scaler.update()
             losses.append(float(loss['total']))
-        return losses, scaler.get_scale() if scaler_on else None
+        return losses, scaler.get_scale() if scaler_on else None, seen
 
     prev = MF.FP16_AUTOCAST_AS_BF16
     try:
         MF.FP16_AUTOCAST_AS_BF16 = False
-        with pytest.raises(MaggieHipError):
-            steps(torch.float16, True)
+        l16, scale, seen = steps(torch.float16, True)
+        assert seen == {torch.float16}
+        l32, _, _ = steps(torch.float32, False)
+        lbf, _, _ = steps(torch.bfloat16, False)
         MF.FP16_AUTOCAST_AS_BF16 = True
         MF._FP16_WARNED = False
         with warnings.catch_warnings(record=True) as w:
             warnings.simplefilter('always')
-            l16, scale = steps(torch.float16, True)
-        assert any('bf16 kernels' in str(x.message) for x in w)
-        lbf, _ = steps(torch.bfloat16, False)
+            lmap, mscale, mseen = steps(torch.float16, True)
+        assert any('bf16 kernels' in str(x.message) for x in w) and mseen == {torch.bfloat16} and mscale == 128.0
     finally:
         MF.FP16_AUTOCAST_AS_BF16 = prev
-    assert all(np.isfinite(v) for v in l16) and scale == 65536.0          # no step was skipped: the scale never backed off
-    for a, b in zip(l16, lbf):
-        assert abs(a - b) <= 0.15 * abs(b), (l16, lbf)                    # same kernels; two bf16 runs of this tiny train-mode-BatchNorm problem differ by up to ~10 % (tests/test_gpu_graphs.py uses the same floor)
+    assert all(np.isfinite(v) for v in l16) and scale == 128.0, (l16, scale)       # no step was skipped
+    # the first step is a pure forward comparison (same weights). On this tiny problem (train-mode BatchNorm over 2-32 samples per channel) repeated
+    # runs of ONE dtype already differ by ~1 % (atomics order), fp16 measures 6.34-6.41 and bf16 6.48-6.67 against fp32's 6.478: bound 4 %.
+    # (The kernel-level fp16 bars are in test_gpu_conv.py / test_gpu_kernels.py: 4e-3 against bf16's 2.5e-2.)
+    d16 = abs(l16[0] - l32[0]) / abs(l32[0])
+    assert d16 <= 0.04, (l16, lbf, l32)
+    for a, b in zip(l16, l32):
+        assert abs(a - b) <= 0.2 * abs(b), (l16, l32)                      # later steps: the problem's own floor (see test_gpu_graphs.py); the loss must FALL like fp32's
+    assert l16[2] < l16[0] - 0.5
+    for a, b in zip(lmap, lbf):
+        assert abs(a - b) <= 0.15 * abs(b), (lmap, lbf)
+
+
+def test_fp16_eval_forward_sits_closer_to_fp32_than_bf16():
+    """Eval forward (running-statistics BatchNorm) of the image model under fp16 and bf16 autocast against fp32: the fp16
+    kernel family must be the closer one (11 against 8 mantissa bits) and keep the detail region essentially unchanged."""
+    from maggie_amd.utils import synth
+    dev = _dev()
+    batch = _to(synth.synthetic_batch(1, 1, 3, 128, 128, seed=DSEED, train=False, max_inst=10), dev)
+    model, _ = _build('image', dev, False)
+    model.hip_graphs = False
+    outs = {}
+    for dt in (torch.float32, torch.float16, torch.bfloat16):
+        with torch.no_grad(), torch.autocast('cuda', dtype=dt, enabled=dt != torch.float32):
+            o = model(batch)
+        outs[dt] = (o['refined_masks'].float().clone(), o['detail_mask'].clone())
+    ref, refm = outs[torch.float32]
+    e16 = (outs[torch.float16][0] - ref).abs().mean().item()
+    ebf = (outs[torch.bfloat16][0] - ref).abs().mean().item()
+    flip16 = (outs[torch.float16][1] != refm).float().mean().item()
+    assert torch.isfinite(outs[torch.float16][0]).all()
+    # (random-init weights with identity running statistics: the eval network amplifies rounding far more than a trained one -- bf16 sits ~0.15
+    # mean-abs from fp32 here; the claim under test is the ORDER of the two families, and a bound well inside bf16's distance)
+    assert e16 <= 0.75 * ebf, (e16, ebf)
+    assert flip16 <= 2e-2, flip16
 
 
 def test_bounded_sparse_capacity_raises_instead_of_refining_fewer_sites():

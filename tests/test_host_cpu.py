@@ -131,18 +131,24 @@ print('SHIM_OK')
 
 
 @pytest.mark.gpu
-def test_fp16_autocast_is_rejected_loudly():
-    """engine/train.py:208,227-229 runs fp16 autocast + GradScaler under `--precision 16`. This build has bf16 and fp32 kernels: fp16
-    autocast must raise, not silently compute in bf16 under a loss scaler."""
+def test_autocast_dtype_selects_the_kernel_family():
+    """engine/train.py:208,227-229 runs fp16 autocast + GradScaler under `--precision 16`: served by the fp16 kernel family (not silently by
+    bf16 under a loss scaler); bf16 autocast -> the bf16 family; MAGGIE_FP16_AUTOCAST=bf16 is the explicit mapping of fp16 autocast onto bf16."""
     import torch
     from maggie_amd import functional as MF
-    from maggie_amd.hip import MaggieHipError
     assert MF.compute_dtype() == torch.float32
     with torch.autocast('cuda', dtype=torch.bfloat16):
         assert MF.compute_dtype() == torch.bfloat16
-    with torch.autocast('cuda', dtype=torch.float16):
-        with pytest.raises(MaggieHipError, match='bf16'):
-            MF.compute_dtype()
+    prev = MF.FP16_AUTOCAST_AS_BF16
+    try:
+        MF.FP16_AUTOCAST_AS_BF16 = False
+        with torch.autocast('cuda', dtype=torch.float16):
+            assert MF.compute_dtype() == torch.float16
+        MF.FP16_AUTOCAST_AS_BF16 = True
+        with torch.autocast('cuda', dtype=torch.float16):
+            assert MF.compute_dtype() == torch.bfloat16
+    finally:
+        MF.FP16_AUTOCAST_AS_BF16 = prev
 
 
 _GLOO_WORKER = r'''
