@@ -222,13 +222,30 @@ class GraphedCallable:
             self._sink_saved = ([v for v, _ in acc], [g.clone() for _, g in acc])
 
     def _export_to_sink(self):
+        hooked = False
         if self._sink_saved is not None:
+            saved, self._sink_saved = self._sink_saved, None
             if self.grad_hook is not None:
-                raise MF.K.hip.MaggieHipError('gradient accumulation (a second backward before zero_grad) is not supported together with the overlapped '
-                                              'gradient exchange writing into the optimizer buffer: unset model.grad_sink or MAGGIE_GRAD_OVERLAP=0')
-            torch._foreach_add_(self._sink_saved[0], self._sink_saved[1])     # slot = earlier gradient + this backward's
-            self._sink_saved = None
-        if self.grad_hook is not None:
+                # gradient accumulation under the overlapped exchange (DDP semantics: every backward's gradient is averaged over the ranks, then
+                # added to `.grad`): THIS backward's gradients are all-reduced in place on the side stream, and the earlier sum is added back
+                # on that same stream behind the collective -- never on the main stream, where the add would race the in-place reduce
+                self.grad_hook(self.sink_runs, self.params)
+                hooked = True
+                owner = getattr(self.grad_hook, '__self__', None)
+                side = getattr(owner, 'stream', None)
+                if side is not None and saved[0][0].is_cuda:
+                    with torch.cuda.stream(side):
+                        torch._foreach_add_(saved[0], saved[1])
+                        for t in saved[1]:
+                            t.record_stream(side)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    owner.events.append(ev)                       # the optimizer's wait() covers the add as well
+                else:
+                    torch._foreach_add_(saved[0], saved[1])
+            else:
+                torch._foreach_add_(saved[0], saved[1])           # slot = earlier gradient + this backward's
+        if self.grad_hook is not None and not hooked:
             # data parallel: THIS graph's slots of the optimizer buffer are all-reduced in place on the side stream while the next backward
             # graph (which writes other slots) runs; no staging copy at all
             self.grad_hook(self.sink_runs, self.params)

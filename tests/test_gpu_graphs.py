@@ -334,6 +334,28 @@ def test_overlapped_exchange_in_place_on_the_optimizer_buffer_single_rank_rccl()
                 torch.cuda.synchronize()
                 grads.append([None if p.grad is None else p.grad.detach().clone() for p in params])
                 opt.step()
+            # gradient accumulation (a second backward before zero_grad, torch / DDP semantics): the slots keep the earlier sum -- under the overlapped
+            # exchange the add-back runs on the side stream behind the in-place all-reduce (was: a MaggieHipError in the middle of backward)
+            seed_all(200)
+            opt.zero_grad(set_to_none=True)
+            for _ in range(2):
+                out, loss = model(batch)
+                loss['total'].backward()
+            if ddp:
+                opt.overlap.wait()
+            torch.cuda.synchronize()
+            grads.append([None if p.grad is None else p.grad.detach().clone() for p in params])
+            seed_all(200)
+            opt.zero_grad(set_to_none=True)
+            out, loss = model(batch)
+            loss['total'].backward()
+            if ddp:
+                opt.overlap.wait()
+            torch.cuda.synchronize()
+            single = [None if p.grad is None else p.grad.detach().clone() for p in params]
+            ratios = sorted(float(a.norm() / b.norm().clamp_min(1e-20)) for a, b in zip(grads[-1], single) if a is not None and b is not None and float(b.norm()) > 0)
+            assert 1.5 <= ratios[len(ratios) // 2] <= 2.5, ratios[len(ratios) // 2]      # two backward passes of (almost) the same step: about twice one
+            grads.pop()
             runs[ddp] = grads
             del model, opt
         for i in range(4):

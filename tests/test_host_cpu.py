@@ -518,3 +518,46 @@ def test_detail_graph_key_ignores_per_rank_guidance_choice_in_rank_safe_mode():
     assert model._rank_safe_graphs() is False
     model.rank_safe_graphs = True
     assert model._rank_safe_graphs() is True
+
+
+_RANKSAFE_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+dist.init_process_group('gloo', rank=int(os.environ['RANK']), world_size=2)
+from maggie_amd.network import build_model
+from maggie_amd.utils import config
+model, _ = build_model(config.model_config('image'))
+model.train()
+r = dist.get_rank()
+# what _run_detail does with the step's plan: rank 1 ALONE saw x_os8.sum() == 0 (or drew random.random() < 0.5): its plan says use_gt
+plan = {'use_gt': r == 1, 'with_atten': False}
+inputs = [torch.zeros(2, 10, 64, 64), torch.zeros(2, 8, 8, 64), torch.tensor([0, int(plan['use_gt'])], dtype=torch.int32)]
+geom = (2, 1, 10, 64, 64)
+assert model._rank_safe_graphs() is True                   # a process group with more than one rank switches it on
+rank_safe = model.training and model._rank_safe_graphs()
+key = model._detail_key(geom, {'use_gt': None if rank_safe else plan['use_gt'], 'with_atten': plan['with_atten']}, inputs)
+keys = [None, None]
+dist.all_gather_object(keys, key)
+assert keys[0] == keys[1], keys                            # same graph looked up on both ranks -> same collectives in the same order
+unsafe = model._detail_key(geom, {'use_gt': plan['use_gt'], 'with_atten': plan['with_atten']}, inputs)
+ukeys = [None, None]
+dist.all_gather_object(ukeys, unsafe)
+assert ukeys[0] != ukeys[1]                                # the single-process key (guidance choice baked into the graph) would have diverged here
+dist.destroy_process_group()
+"""
+
+
+def test_world_size_2_ranks_that_disagree_on_the_guidance_source_look_up_the_same_detail_graph(tmp_path):
+    """`use_gt` is per-rank data (x_os8.sum() == 0, random.random()). With more than one rank the detail-graph key
+    must not contain it (it travels as a device flag), or ranks would replay different graphs and issue different gradient collectives. Two gloo
+    ranks, rank 1 alone takes the ground-truth guidance: the keys agree; the single-process key would not."""
+    script = tmp_path / 'rs.py'
+    script.write_text(_RANKSAFE_WORKER % ROOT)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29619')
+        env.pop('MAGGIE_RANK_SAFE_GRAPHS', None)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=180)
+        assert p.returncode == 0, out.decode()
