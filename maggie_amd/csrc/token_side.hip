@@ -120,7 +120,7 @@ struct TokLin {
     int R, K, N, relu, wt;
     float eps;
 };
-constexpr int TOK_MULTI = 4;
+constexpr int TOK_MULTI = 6;
 struct TokLinSet { TokLin op[TOK_MULTI]; int n; };
 
 __global__ __launch_bounds__(NT) void token_linear_multi_fwd_kernel(const TokLinSet set) {
@@ -662,7 +662,7 @@ extern "C" int mg_imd_prep(const float* mask, int n_in, int s, const float* gt, 
     return 0;
 }
 
-/* Up to 4 INDEPENDENT token linear layers in one launch each way (same semantics per layer as mg_token_linear_fwd_ex / _bwd_ex). `ops`: array of
+/* Up to 6 INDEPENDENT token linear layers in one launch each way (same semantics per layer as mg_token_linear_fwd_ex / _bwd_ex). `ops`: array of
  * mg_tok_lin (include/maggie_hip.h); forward reads x, xadd, W, bias, res, relu, gamma, beta, eps, wt and writes y (z, rstat with a LayerNorm);
  * backward reads dy (+ the forward's x, xadd, W, yout, gamma, z, rstat) and writes dx, dW, db, dres, dgamma, dbeta through the scratch dz. */
 static int tok_set(const mg_tok_lin* ops, int n, TokLinSet* set, int bwd) {

@@ -1584,7 +1584,7 @@ def token_linear(x, W, b=None, xadd=None, res=None, relu=False, ln=None, wt=Fals
 
 
 class TokenLinearMulti(torch.autograd.Function):
-    """Up to four INDEPENDENT TokenLinear layers in one launch each way (mg_token_linear_multi_fwd / _bwd): inputs are 7 slots per layer
+    """Up to six INDEPENDENT TokenLinear layers in one launch each way (mg_token_linear_multi_fwd / _bwd): inputs are 7 slots per layer
     (x, xadd, W, b, res, gamma, beta; None where absent), `specs` = per layer (relu, eps, wt)."""
 
     @staticmethod
@@ -1661,19 +1661,19 @@ class TokenLinearMulti(torch.autograd.Function):
 TOKEN_MULTI = os.environ.get('MAGGIE_TOKEN_MULTI', '1') != '0'
 
 
+TOKEN_MULTI_MAX = 6            # csrc/token_side.hip: TOK_MULTI
+TOKEN_XBLOCK = os.environ.get('MAGGIE_TOKEN_XBLOCK', '1') != '0'      # instance matte decoder: token-side levels of consecutive blocks in one launch
+
+
 def token_linear_multi(layers):
     """`layers`: list of dicts with the keyword arguments of token_linear (x, W, b, xadd, res, relu, ln, wt) for layers that do NOT depend on each
-    other -> list of outputs. One launch forward, two backward, for up to four layers (longer lists are cut into groups of four)."""
+    other -> list of outputs. One launch forward, two backward, for up to six layers (longer lists are cut into groups of six)."""
     outs = []
-    for g0 in range(0, len(layers), 4):
-        grp = layers[g0:g0 + 4] if TOKEN_MULTI else layers[g0:g0 + 1]
-        if not TOKEN_MULTI:
-            for L in layers[g0:g0 + 4]:
+    for g0 in range(0, len(layers), TOKEN_MULTI_MAX):
+        grp = layers[g0:g0 + TOKEN_MULTI_MAX]
+        if not TOKEN_MULTI or len(grp) == 1:
+            for L in grp:
                 outs.append(token_linear(L['x'], L['W'], L.get('b'), L.get('xadd'), L.get('res'), L.get('relu', False), L.get('ln'), L.get('wt', False)))
-            continue
-        if len(grp) == 1:
-            L = grp[0]
-            outs.append(token_linear(L['x'], L['W'], L.get('b'), L.get('xadd'), L.get('res'), L.get('relu', False), L.get('ln'), L.get('wt', False)))
             continue
         specs, slots = [], []
         for L in grp:

@@ -113,14 +113,29 @@ class InstanceMatteDecoder(nn.Module):
         # The attention blocks run in fp32 with autocast OFF: every operand is a small fp32 tensor (10 tokens per sample, one
         # (L x 128) feature matrix), so autocast would only add a cast kernel per operand per op (~250 launches per step)
         with torch.autocast('cuda', enabled=False):
+            pre = None                                            # (qk, tbl) of the NEXT tokens <- features block, computed one block early
             for i in range(self.n_block):
-                tokens, att = self.token_feat_ca_layers[i].tokens_from_features(tokens, pos_t, feat, feat_ids, tbl)
+                tokens, att = self.token_feat_ca_layers[i].tokens_from_features(tokens, pos_t, feat, feat_ids, tbl, pre=pre)
                 if self.training:
                     atten_terms.append(self.compute_atten_loss(b, n_f, guidance_mask, att))
                 tokens = self.mlp_layers[i](tokens)
                 tokens = self.sa_layers[i](tokens, tgt_key_padding_mask=token_padding_mask, query_pos=token_pos)
-                feat = self.feat_token_ca_layers[i].features_from_tokens(feat, feat_ids, tbl, tokens, pos_t, token_padding_mask)
-            tokens, att = self.final_token_feat_ca.tokens_from_features(tokens, token_pos, feat, feat_ids, id_table)
+                # both cross attentions that follow start from THESE tokens (the features <- tokens block does not change them): their two
+                # levels of token-side linears run as ONE launch per level (5 independent layers each) instead of two
+                fft = self.feat_token_ca_layers[i]
+                if not MF.TOKEN_XBLOCK:
+                    feat = fft.features_from_tokens(feat, feat_ids, tbl, tokens, pos_t, token_padding_mask)
+                    continue
+                last = i + 1 == self.n_block
+                nxt = self.final_token_feat_ca if last else self.token_feat_ca_layers[i + 1]
+                nxt_pos, nxt_tbl = (token_pos, id_table) if last else (pos_t, tbl)
+                l1a, l1b = fft.fft_level1(tokens, pos_t, tbl), nxt.tff_level1(tokens, nxt_pos, nxt_tbl)
+                r1 = MF.token_linear_multi(l1a + l1b)
+                l2a, l2b = fft.fft_level2(r1[:len(l1a)], tbl), nxt.tff_level2(r1[len(l1a):], nxt_tbl)
+                r2 = MF.token_linear_multi(l2a + l2b)
+                feat = fft.features_from_tokens(feat, feat_ids, tbl, tokens, pos_t, token_padding_mask, pre=r2[:len(l2a)])
+                pre = r2[len(l2a):]
+            tokens, att = self.final_token_feat_ca.tokens_from_features(tokens, token_pos, feat, feat_ids, id_table, pre=pre)
             if self.training:
                 atten_terms.append(self.compute_atten_loss(b, n_f, guidance_mask, att))
             if atten_terms:                                       # mean over the n_block + 1 attention maps: one launch (mg_scalar_lincomb)

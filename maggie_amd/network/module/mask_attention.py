@@ -69,42 +69,75 @@ class CrossAttentionLayer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
-    def tokens_from_features(self, tokens, token_pos, feat, feat_ids, id_table):
-        """tokens (b,T,d) <- feat (b,L,d) with key position = id_table[feat_ids] ((b,L) int32). Returns new tokens and the
-        attention matrix (b,T,L). The pass over the feature rows (scores, softmax over L, context) is one HIP pipeline
-        (mg_attn_tok_fwd / _bwd); the 10-token projections around it are fused HIP linears (mg_token_linear_*)."""
+    # Each direction is: two levels of small token-side linears (level 2 reads level 1), the pass over the feature rows, the rest. The levels are
+    # exposed as layer lists so that the caller can batch levels of DIFFERENT blocks that read the same tokens into one launch
+    # (InstanceMatteDecoder: features_from_tokens of block i and tokens_from_features of block i + 1 both start from the tokens block i's
+    # self-attention produced).
+
+    def tff_level1(self, tokens, token_pos, id_table):
         (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.multihead_attn)
+        layers = [dict(x=tokens, W=wq, b=bq, xadd=token_pos)]                                # q
+        if id_table is not None:
+            layers.append(dict(x=id_table, W=wk, b=bk))                                      # key_pos (n_id, d): E[id] Wk^T + bk
+        return layers
+
+    def tff_level2(self, res1, id_table):
+        (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.multihead_attn)
+        q = res1[0]
+        key_pos = res1[1] if id_table is not None else bk[None, :]
+        # q Wk (fold Wk into the queries; wk used as (K, N): no transposed copy) and the (b,T,n_id) score-bias table q . key_pos
+        return [dict(x=q, W=wk, wt=True), dict(x=q, W=key_pos)]
+
+    def tff_finish(self, tokens, res2, feat, feat_ids):
+        (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.multihead_attn)
+        qk, tbl = res2
         d = tokens.shape[-1]
-        # score bias of a feature row with position id: q . (E[id] Wk^T + bk)  (id_table None: every row has id 0 and no embedding)
-        if id_table is not None:                                                             # two independent layers, one launch
-            q, key_pos = MF.token_linear_multi([dict(x=tokens, W=wq, b=bq, xadd=token_pos), dict(x=id_table, W=wk, b=bk)])
-        else:
-            q, key_pos = MF.token_linear(tokens, wq, bq, xadd=token_pos), bk[None, :]
-        # q Wk (fold Wk into the queries; wk used as (K, N): no transposed copy) and the (b,T,n_id) score-bias table: one launch
-        qk, tbl = MF.token_linear_multi([dict(x=q, W=wk, wt=True), dict(x=q, W=key_pos)])
         _need_hip_attention(tokens.shape[1], d)
         p, ctx = MF.attn_tokens_from_features(qk, tbl, feat, feat_ids, 1.0 / math.sqrt(d))
         h = MF.token_linear(ctx, wv, bv)
         return MF.token_linear(h, self.multihead_attn.out_proj.weight, self.multihead_attn.out_proj.bias, res=tokens, ln=self.norm), p
 
-    def features_from_tokens(self, feat, feat_ids, id_table, tokens, token_pos, token_padding_mask):
-        """feat (b,L,d) <- tokens (b,T,d); query position = id_table[feat_ids]. Scores, masked softmax over the T tokens and
-        the value mix are one HIP kernel per direction (mg_attn_feat_fwd / _bwd); residual + LayerNorm over the b * L rows one more."""
+    def tokens_from_features(self, tokens, token_pos, feat, feat_ids, id_table, pre=None):
+        """tokens (b,T,d) <- feat (b,L,d) with key position = id_table[feat_ids] ((b,L) int32). Returns new tokens and the
+        attention matrix (b,T,L). The pass over the feature rows (scores, softmax over L, context) is one HIP pipeline
+        (mg_attn_tok_fwd / _bwd); the 10-token projections around it are fused HIP linears (mg_token_linear_*). `pre`: the level-2 results
+        (qk, tbl) when the caller already computed them in a batched launch."""
+        if pre is None:
+            res1 = MF.token_linear_multi(self.tff_level1(tokens, token_pos, id_table))
+            pre = MF.token_linear_multi(self.tff_level2(res1, id_table))
+        return self.tff_finish(tokens, pre, feat, feat_ids)
+
+    def fft_level1(self, tokens, token_pos, id_table):
         (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.multihead_attn)
-        d = feat.shape[-1]
-        first = [dict(x=tokens, W=wk, b=bk, xadd=token_pos), dict(x=tokens, W=wv, b=bv)]     # k (b,T,d), v
+        layers = [dict(x=tokens, W=wk, b=bk, xadd=token_pos), dict(x=tokens, W=wv, b=bv)]    # k (b,T,d), v
         if id_table is not None:
-            first.append(dict(x=id_table, W=wq, b=bq))                                       # qry_pos (n_id, d)
-        res = MF.token_linear_multi(first)
-        k, v = res[0], res[1]
-        qry_pos = res[2] if id_table is not None else bq[None, :]
-        # vp (b,T,d): rows of (Wo V^T)^T; kq (b,T,d): Wq folded into the keys; the (b,T,n_id) score-bias table -- three layers, one launch
-        vp, kq, tbl = MF.token_linear_multi([dict(x=v, W=self.multihead_attn.out_proj.weight), dict(x=k, W=wq, wt=True), dict(x=k, W=qry_pos)])
+            layers.append(dict(x=id_table, W=wq, b=bq))                                      # qry_pos (n_id, d)
+        return layers
+
+    def fft_level2(self, res1, id_table):
+        (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.multihead_attn)
+        k, v = res1[0], res1[1]
+        qry_pos = res1[2] if id_table is not None else bq[None, :]
+        # vp (b,T,d): rows of (Wo V^T)^T; kq (b,T,d): Wq folded into the keys; the (b,T,n_id) score-bias table
+        return [dict(x=v, W=self.multihead_attn.out_proj.weight), dict(x=k, W=wq, wt=True), dict(x=k, W=qry_pos)]
+
+    def fft_finish(self, feat, feat_ids, res2, token_padding_mask, n_tokens):
+        vp, kq, tbl = res2
+        d = feat.shape[-1]
         tbl = tbl.transpose(1, 2).contiguous()                                               # (b,n_id,T)
-        _need_hip_attention(tokens.shape[1], d)
+        _need_hip_attention(n_tokens, d)
         out = MF.attn_features_from_tokens(feat, kq, tbl, vp, self.multihead_attn.out_proj.bias, token_padding_mask, feat_ids,
                                            1.0 / math.sqrt(d))
         return MF.rows_add_layernorm(feat, out, self.norm)
+
+    def features_from_tokens(self, feat, feat_ids, id_table, tokens, token_pos, token_padding_mask, pre=None):
+        """feat (b,L,d) <- tokens (b,T,d); query position = id_table[feat_ids]. Scores, masked softmax over the T tokens and
+        the value mix are one HIP kernel per direction (mg_attn_feat_fwd / _bwd); residual + LayerNorm over the b * L rows one more.
+        `pre`: the level-2 results (vp, kq, tbl) when the caller already computed them in a batched launch."""
+        if pre is None:
+            res1 = MF.token_linear_multi(self.fft_level1(tokens, token_pos, id_table))
+            pre = MF.token_linear_multi(self.fft_level2(res1, id_table))
+        return self.fft_finish(feat, feat_ids, pre, token_padding_mask, tokens.shape[1])
 
 
 class FFNLayer(nn.Module):

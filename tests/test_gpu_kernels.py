@@ -1208,14 +1208,15 @@ def test_token_linear_multi_equals_separate_layers():
 
     base = dict(tgt=mk(4, 10, 128), pos=mk(4, 10, 128), wq=mk(128, 128) / 11, wk=mk(128, 128) / 11, wv=mk(128, 128) / 11, bq=mk(128), bk=mk(128), bv=mk(128),
                 table=mk(11, 128), kp=mk(11, 128) / 11, res=mk(4, 10, 128), w1=mk(64, 128) / 11, b1=mk(64))
-    wts = [mk(4, 10, 128), mk(4, 10, 128), mk(4, 10, 128), mk(11, 128), mk(4, 10, 128), mk(4, 10, 11), mk(4, 10, 128), mk(4, 10, 64)]
+    wts = [mk(4, 10, 128), mk(4, 10, 128), mk(4, 10, 128), mk(11, 128), mk(11, 128), mk(4, 10, 64), mk(4, 10, 128), mk(4, 10, 11), mk(4, 10, 128), mk(4, 10, 64)]
 
     def run(multi):
         t = leaves()
         prev, MF.TOKEN_MULTI = MF.TOKEN_MULTI, multi
         try:
             a = MF.token_linear_multi([dict(x=t['tgt'], W=t['wq'], b=t['bq'], xadd=t['pos']), dict(x=t['tgt'], W=t['wk'], b=t['bk'], xadd=t['pos']),
-                                       dict(x=t['tgt'], W=t['wv'], b=t['bv']), dict(x=t['table'], W=t['wk'], b=t['bk'])])
+                                       dict(x=t['tgt'], W=t['wv'], b=t['bv']), dict(x=t['table'], W=t['wk'], b=t['bk']),
+                                       dict(x=t['table'], W=t['wq'], b=t['bq']), dict(x=t['tgt'], W=t['w1'], b=t['b1'])])      # six layers: one launch
             b = MF.token_linear_multi([dict(x=a[0], W=t['wk'], wt=True), dict(x=a[0], W=t['kp']),
                                        dict(x=a[2], W=t['wq'], res=t['res'], ln=ln), dict(x=a[1], W=t['w1'], b=t['b1'], relu=True)])
         finally:
