@@ -75,25 +75,26 @@ class CrossAttentionLayer(nn.Module):
     # self-attention produced).
 
     def tff_level1(self, tokens, token_pos, id_table):
-        (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.multihead_attn)
+        (wq, wk, wv), (bq, bk, bv) = self._proj = _split_in_proj(self.multihead_attn)      # ONE unbind per forward: the later stages reuse the slices
         layers = [dict(x=tokens, W=wq, b=bq, xadd=token_pos)]                                # q
         if id_table is not None:
             layers.append(dict(x=id_table, W=wk, b=bk))                                      # key_pos (n_id, d): E[id] Wk^T + bk
         return layers
 
     def tff_level2(self, res1, id_table):
-        (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.multihead_attn)
+        (wq, wk, wv), (bq, bk, bv) = self._proj
         q = res1[0]
         key_pos = res1[1] if id_table is not None else bk[None, :]
         # q Wk (fold Wk into the queries; wk used as (K, N): no transposed copy) and the (b,T,n_id) score-bias table q . key_pos
         return [dict(x=q, W=wk, wt=True), dict(x=q, W=key_pos)]
 
     def tff_finish(self, tokens, res2, feat, feat_ids):
-        (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.multihead_attn)
+        (wq, wk, wv), (bq, bk, bv) = self._proj
         qk, tbl = res2
         d = tokens.shape[-1]
         _need_hip_attention(tokens.shape[1], d)
         p, ctx = MF.attn_tokens_from_features(qk, tbl, feat, feat_ids, 1.0 / math.sqrt(d))
+        self._proj = None
         h = MF.token_linear(ctx, wv, bv)
         return MF.token_linear(h, self.multihead_attn.out_proj.weight, self.multihead_attn.out_proj.bias, res=tokens, ln=self.norm), p
 
@@ -108,14 +109,15 @@ class CrossAttentionLayer(nn.Module):
         return self.tff_finish(tokens, pre, feat, feat_ids)
 
     def fft_level1(self, tokens, token_pos, id_table):
-        (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.multihead_attn)
+        (wq, wk, wv), (bq, bk, bv) = self._proj = _split_in_proj(self.multihead_attn)
         layers = [dict(x=tokens, W=wk, b=bk, xadd=token_pos), dict(x=tokens, W=wv, b=bv)]    # k (b,T,d), v
         if id_table is not None:
             layers.append(dict(x=id_table, W=wq, b=bq))                                      # qry_pos (n_id, d)
         return layers
 
     def fft_level2(self, res1, id_table):
-        (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.multihead_attn)
+        (wq, wk, wv), (bq, bk, bv) = self._proj
+        self._proj = None
         k, v = res1[0], res1[1]
         qry_pos = res1[2] if id_table is not None else bq[None, :]
         # vp (b,T,d): rows of (Wo V^T)^T; kq (b,T,d): Wq folded into the keys; the (b,T,n_id) score-bias table
