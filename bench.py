@@ -385,7 +385,7 @@ def trace_graph_replay(args, fam_alg):
                 d = acc.setdefault(fam, [0, 0, 0])
                 d[0] += e_ - s_
                 d[1] += 1
-                d[2] += int('igemm_fprop' in nm or 'igemm_wgrad_kernel' in nm)
+                d[2] += int('igemm_fprop' in nm or 'igemm_wgrad' in nm)
         busy = sum(e_ - s_ for s_, e_, _ in win)
         span = win[-1][1] - win[0][0]
         out = {'steps_in_window': k, 'traced_ms_per_step': ms, 'launches_per_step': round(len(win) / k, 1), 'gpu_busy_frac': round(busy / span, 4)}
