@@ -25,19 +25,6 @@ from . import functional as MF
 CAPTURE_MODE = 'thread_local'
 
 
-def foreach_copy_(dst, src):
-    """torch._foreach_copy_ per (destination dtype, source dtype) group: the multi-tensor kernel only serves homogeneous lists -- a single int32 flag
-    word or uint8 mask among fp32 planes sends the WHOLE list down the one-memcpy-per-tensor path (22 copy nodes of ~9 us per step, measured)."""
-    groups = {}
-    for d, s_ in zip(dst, src):
-        groups.setdefault((d.dtype, s_.dtype, d.device), ([], []))
-        g = groups[(d.dtype, s_.dtype, d.device)]
-        g[0].append(d)
-        g[1].append(s_)
-    for d_list, s_list in groups.values():
-        torch._foreach_copy_(d_list, s_list)
-
-
 class _Replay(torch.autograd.Function):
     """forward(g, *differentiable inputs, *parameters): the live differentiable inputs are only there so that autograd routes their
     gradients (their values were copied into the graph's static inputs by GraphedCallable.__call__)."""
@@ -83,7 +70,7 @@ class _Replay(torch.autograd.Function):
         if zero:
             torch._foreach_zero_(zero)
         if dst:
-            foreach_copy_(dst, src)
+            torch._foreach_copy_(dst, src)
         g.prepare_sink_replay()
         g.bwd.replay()
         # gradients of the differentiable inputs are handed over as the graph's own buffers: their consumer (the producing graph's
@@ -305,7 +292,7 @@ class GraphedCallable:
                 dst.append(s)
         if dst:
             with torch.no_grad():                                 # static inputs the graph differentiates through are leaves that require grad
-                foreach_copy_(dst, src)
+                torch._foreach_copy_(dst, src)
         if self.training:
             return _Replay.mark_static(_Replay.apply(self, *[inputs[i] for i in self.grad_idx], *self.params))
         self.fwd.replay()

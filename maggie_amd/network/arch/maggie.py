@@ -455,8 +455,7 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             idx = [i for i in idx if i not in set(small)]
         if idx:
             fresh = [torch.empty_like(outs[i]) for i in idx]
-            from ... import graphs
-            graphs.foreach_copy_(fresh, [outs[i] for i in idx])           # per dtype: a uint8 mask among fp32 planes would cost one memcpy per tensor
+            torch._foreach_copy_(fresh, [outs[i] for i in idx])
             for i, f in zip(idx, fresh):
                 outs[i] = f
         return tuple(t.clone() if t.requires_grad else t for t in outs)        # 'loss/total': a differentiable one-element copy
