@@ -160,10 +160,15 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         if self.training and torch.distributed.is_available() and torch.distributed.is_initialized() \
                 and (torch.distributed.get_world_size() > 1 or MF.SYNCBN_WORLD1) and any(isinstance(m, nn.SyncBatchNorm) for m in self.modules()):
             # SyncBN exchanges batch statistics layer by layer (each layer's normalisation needs the global moments of ITS input, so the
-            # ~142 small collectives of a step cannot be merged). Capturing RCCL collectives into the hipGraphs is opt-in
-            # (MAGGIE_SYNCBN_GRAPHS=1): it could only be verified in a 1-rank process group here.
+            # ~142 small collectives of a step cannot be merged). MAGGIE_SYNCBN_GRAPHS=1 (opt-in: verified in a 1-rank process group only,
+            # DESIGN.md section 6) records them into the hipGraphs -- through a PRIVATE RCCL communicator (maggie_amd/rccl_direct.py), not
+            # through ProcessGroupNCCL, whose watchdog thread aborts the process when it queries an event recorded inside a capture.
             import os
-            return os.environ.get('MAGGIE_SYNCBN_GRAPHS', '0') == '1'
+            if os.environ.get('MAGGIE_SYNCBN_GRAPHS', '0') != '1':
+                return False
+            from ... import parallel
+            parallel.syncbn_direct_comm()                         # collective on first use: every rank reaches its first training forward
+            return True
         return True
 
     @_bn_counted

@@ -25,13 +25,39 @@ def reduce_bn_stats(pack, C, group):
     return mean, var, n
 
 
+SYNCBN_COMM = None       # rccl_direct.DirectComm: the statistics exchange goes through a private RCCL communicator (capturable into hipGraphs)
+
+
+def syncbn_direct_comm(group=None):
+    """The private RCCL communicator of the SyncBN exchange, created on first use -- COLLECTIVELY: every rank must get here at the same point
+    (MaGGIe._graph_policy calls it on every rank's first training forward when MAGGIE_SYNCBN_GRAPHS=1)."""
+    global SYNCBN_COMM
+    if SYNCBN_COMM is None:
+        from .rccl_direct import DirectComm
+        SYNCBN_COMM = DirectComm(group)
+    return SYNCBN_COMM
+
+
+def syncbn_destroy_comm():
+    global SYNCBN_COMM
+    if SYNCBN_COMM is not None:
+        SYNCBN_COMM.destroy()
+        SYNCBN_COMM = None
+
+
+def _sum_over_ranks_(t, group):
+    if SYNCBN_COMM is not None and t.is_cuda:
+        SYNCBN_COMM.all_reduce_sum_(t)
+    else:
+        dist.all_reduce(t, group=group)
+    return t
+
+
 def syncbn_exchange_forward(local_pack, group):
     """Forward statistics exchange of SyncBatchNorm as functional.BNAct does it: local_pack = [sum x (C), sum x^2 (C), rows] of this
     rank's rows -> the same pack summed over the group (a copy; variable row counts per rank are fine: the count rides along).
     torch's SyncBatchNorm all-gathers (mean, invstd, count) instead (engine/train.py:160-161); the pooled moments are the same numbers."""
-    pack = local_pack.clone()
-    dist.all_reduce(pack, group=group)
-    return pack
+    return _sum_over_ranks_(local_pack.clone(), group)
 
 
 def syncbn_exchange_backward(local_sums, group):
@@ -39,9 +65,7 @@ def syncbn_exchange_backward(local_sums, group):
     untouched). torch's SyncBatchNorm all-reduces these two vectors for dx only and keeps grad_weight / grad_bias local (DDP then averages
     them over the ranks); returning the all-reduced sums as dgamma / dbeta would make every BN parameter gradient world_size times too
     large."""
-    glob = local_sums.clone()
-    dist.all_reduce(glob, group=group)
-    return glob, local_sums
+    return _sum_over_ranks_(local_sums.clone(), group), local_sums
 
 
 def shard_items(n_items, rank, world):

@@ -1,7 +1,8 @@
 """Child process of tests/test_gpu_graphs.py::test_syncbn_single_rank_rccl_*: one training step sequence of the image model with its BatchNorm
 layers converted to nn.SyncBatchNorm inside a 1-rank RCCL process group (the all-reduce of a 1-rank group is the identity, so the result must
-equal local BatchNorm up to the different statistics kernels). Runs in its own process because capturing RCCL collectives into hipGraphs was
-seen to abort with hipErrorCapturedEvent once in ~10 runs: an abort must not take the test session down.
+equal local BatchNorm up to the different statistics kernels). Runs in its own process: it owns a process group, and capturing ProcessGroupNCCL
+collectives into hipGraphs used to abort with hipErrorCapturedEvent once in ~10 runs (the in-graph exchange now goes through
+maggie_amd/rccl_direct.py instead) -- an abort must not take the test session down.
 usage: python tests/syncbn_worker.py {local|sync_eager|sync_graphs} <port>   -> one JSON line"""
 import json
 import os
@@ -53,6 +54,9 @@ res['graphs'] = sum(1 for st in ('_trunk_graphs', '_detail_graphs') for v in mod
 res['sync_layers'] = sum(isinstance(m, torch.nn.SyncBatchNorm) for m in model.modules())
 for store in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs'):
     model.__dict__.get(store, {}).clear()
+from maggie_amd import parallel                                     # noqa: E402
+res['direct_comm_calls'] = 0 if parallel.SYNCBN_COMM is None else parallel.SYNCBN_COMM.calls
+parallel.syncbn_destroy_comm()
 torch.cuda.synchronize()
 dist.destroy_process_group()
 print('RESULT ' + json.dumps(res))

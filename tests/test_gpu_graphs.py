@@ -433,14 +433,17 @@ def _syncbn_worker(mode, port):
 @pytest.mark.parametrize('mode', ['sync_eager', 'sync_graphs'])
 def test_syncbn_single_rank_rccl_matches_local_batchnorm(mode):
     """`sync_bn: true` (configs/maggie_{image,video}.yaml, engine/train.py:159-161) through a REAL RCCL process
-    group of one rank -- the eager path (host-launched collectives, the default for SyncBN) and MAGGIE_SYNCBN_GRAPHS=1 (collectives captured
-    into the hipGraphs) -- against local BatchNorm. A 1-rank all-reduce is the identity, so only the statistics kernels differ
+    group of one rank -- the eager path (host-launched collectives, the default for SyncBN) and MAGGIE_SYNCBN_GRAPHS=1 (collectives recorded
+    into the hipGraphs through a private RCCL communicator) -- against local BatchNorm. A 1-rank all-reduce is the identity, so only the statistics kernels differ
     (E[x^2] - E[x]^2 over pooled moments instead of the local exact two-pass variance)."""
     _dev()
     ref = _syncbn_worker('local', 29561)
     got = _syncbn_worker(mode, 29562 if mode == 'sync_eager' else 29563)
     assert got['sync_layers'] >= 60 and ref['sync_layers'] == 0
     assert (got['graphs'] >= 2) == (mode == 'sync_graphs'), got['graphs']
+    # in-graph mode: every exchange went through the private RCCL communicator (maggie_amd/rccl_direct.py), none through ProcessGroupNCCL -- whose
+    # watchdog is what used to abort one capture in ten
+    assert (got['direct_comm_calls'] >= 142) == (mode == 'sync_graphs'), got['direct_comm_calls']
     for i, (a, b) in enumerate(zip(got['steps'], ref['steps'])):
         assert a['n_grads'] == b['n_grads']
         assert abs(a['loss'] - b['loss']) <= 2e-3 * max(1.0, abs(b['loss'])), (i, a['loss'], b['loss'])
