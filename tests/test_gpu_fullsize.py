@@ -212,6 +212,13 @@ def test_bf16_step_at_the_reference_autocast_noise_floor(size):
     k = 2.0 if size <= 128 else 3.0
     assert float(d_gpu.mean()) <= k * float(d_cpu.mean()) + 1e-3
     assert float((d_gpu > 0.05).float().mean()) <= k * float((d_cpu > 0.05).float().mean()) + 1e-3
+    # the fp16 kernel family (the reference's `--precision 16` storage type, 11 mantissa bits) on the same step: inside the bf16 yardstick itself
+    seed_all(RSEED)
+    with torch.autocast('cuda', dtype=torch.float16), torch.no_grad():
+        out_h, _ = model(_to(batch, dev))
+    d_h = (out_h['alpha_os8'].float().cpu().reshape(a32.shape) - a32).abs()
+    print('HIP fp16 mean %.4g frac>0.05 %.4g' % (float(d_h.mean()), float((d_h > 0.05).float().mean())))
+    assert float(d_h.mean()) <= float(d_cpu.mean()) + 1e-3 and float(d_h.mean()) <= float(d_gpu.mean()) + 1e-3
 
 
 @pytest.mark.parametrize('clips', [2])
