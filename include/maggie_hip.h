@@ -550,6 +550,28 @@ int mg_token_sa_fwd(const float* q, const float* k, const float* v, const unsign
 int mg_token_sa_bwd(const float* dout, const float* q, const float* k, const float* v, const float* prob, float scale, int B, int T, int D, float* dq,
                     float* dk, float* dv, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Mailbox all-reduce (csrc/mailbox.hip): in-place fp32 sum over the ranks of a pack of <= MG_MAILBOX_PACK floats as ONE kernel launch on `stream`
+ * (capturable into hipGraphs), through peer-mapped mailboxes instead of RCCL. Replaces: the statistics all-reduce of nn.SyncBatchNorm
+ * (engine/train.py:159-161) when the step is replayed from graphs. Setup: every rank calls mg_mailbox_create (-> its mailbox + a 64-byte IPC handle),
+ * exchanges the handles out of band, opens the peers' with mg_mailbox_open and fills mg_mailbox.peer[] (its own pointer at peer[rank]). `seq_dev`
+ * (zeroed uint32) and `err_dev` (zeroed int32; set to 1 when a peer did not arrive within `spin_ticks` of the 100 MHz wall clock) are this rank's own
+ * device words. Every rank must issue the same sequence of calls.
+ * ------------------------------------------------------------------------------------------------------------- */
+#define MG_MAILBOX_MAX_RANKS 8
+#define MG_MAILBOX_SLOTS 64
+#define MG_MAILBOX_PACK 1088
+typedef struct mg_mailbox {
+    float* peer[MG_MAILBOX_MAX_RANKS]; /* peer[r]: rank r's mailbox as mapped into THIS process */
+    int32_t world, rank;
+} mg_mailbox;
+long mg_mailbox_bytes(int world);
+int mg_mailbox_create(int world, void** ptr, void* handle64);
+int mg_mailbox_open(const void* handle64, void** ptr);
+int mg_mailbox_close(void* ptr);
+int mg_mailbox_free(void* ptr);
+int mg_mailbox_allreduce(const mg_mailbox* mb, float* data, int n, uint32_t* seq_dev, int32_t* err_dev, long spin_ticks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

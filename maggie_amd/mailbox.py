@@ -1,0 +1,72 @@
+"""Mailbox all-reduce for the SyncBatchNorm statistics exchange (csrc/mailbox.hip): one ordinary kernel per exchange over peer-mapped
+mailboxes -- no RCCL, no host work, capturable into hipGraphs. Opt-in (MAGGIE_SYNCBN_COMM=mailbox): it has been exercised with TWO PROCESSES ON ONE
+GPU only (tests/test_gpu_graphs.py::test_mailbox_*); across GPUs it relies on fine-grained device memory + system-scope atomics over xGMI, which
+this project had no second GPU to validate on. The default in-graph exchange is the private RCCL communicator (rccl_direct.py).
+
+The control plane (mailbox handle exchange) goes through the existing torch.distributed group (any backend: the handles are 64-byte objects)."""
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+from . import hip
+
+MAX_RANKS, PACK = 8, 1088
+
+
+class _Mailbox(ctypes.Structure):
+    _fields_ = [('peer', ctypes.c_void_p * MAX_RANKS), ('world', ctypes.c_int32), ('rank', ctypes.c_int32)]
+
+
+class MailboxComm:
+    def __init__(self, group=None, device=None, spin_seconds=20.0):
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        if self.world > MAX_RANKS:
+            raise hip.MaggieHipError('MailboxComm: at most %d ranks (one node)' % MAX_RANKS)
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else device
+        lib = hip.lib()
+        self._own = ctypes.c_void_p()
+        handle = (ctypes.c_char * 64)()
+        hip.check(lib.mg_mailbox_create(ctypes.c_int(self.world), ctypes.byref(self._own), handle), 'mg_mailbox_create')
+        handles = [None] * self.world
+        dist.all_gather_object(handles, bytes(handle), group=group)
+        self._mb = _Mailbox()
+        self._mb.world, self._mb.rank = self.world, self.rank
+        self._opened = []
+        for r, h in enumerate(handles):
+            if r == self.rank:
+                self._mb.peer[r] = self._own.value
+            else:
+                p = ctypes.c_void_p()
+                hip.check(lib.mg_mailbox_open(ctypes.c_char_p(h), ctypes.byref(p)), 'mg_mailbox_open (rank %d)' % r)
+                self._mb.peer[r] = p.value
+                self._opened.append(p)
+        self._state = torch.zeros(2, dtype=torch.int32, device=self.device)       # [exchange counter, error word]
+        self._spin = int(spin_seconds * 1e8)                                     # wall_clock64 ticks (100 MHz)
+        self.calls = 0
+        dist.barrier(group=group)                                                # nobody deposits before every mailbox is mapped everywhere
+
+    def all_reduce_sum_(self, t):
+        """In-place sum over the ranks of a contiguous fp32 device tensor of <= PACK elements, on the current stream (eager or capturing)."""
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and 0 < t.numel() <= PACK):
+            raise hip.MaggieHipError('MailboxComm.all_reduce_sum_: contiguous fp32 device tensor of at most %d elements expected' % PACK)
+        s = self._state
+        hip.call('mg_mailbox_allreduce', ctypes.byref(self._mb), hip.ptr(t), ctypes.c_int(t.numel()), ctypes.c_void_p(s.data_ptr()),
+                 ctypes.c_void_p(s.data_ptr() + 4), ctypes.c_long(self._spin), hip.stream())
+        self.calls += 1
+        return t
+
+    def check(self):
+        """Host read of the error word (a peer that did not arrive within the spin budget)."""
+        if int(self._state[1].item()) != 0:
+            raise hip.MaggieHipError('MailboxComm: a peer did not arrive at an exchange within the spin budget')
+
+    def destroy(self):
+        lib = hip.lib()
+        torch.cuda.synchronize()
+        for p in self._opened:
+            lib.mg_mailbox_close(p)
+        self._opened = []
+        if self._own:
+            lib.mg_mailbox_free(self._own)
+            self._own = ctypes.c_void_p()

@@ -33,8 +33,13 @@ def syncbn_direct_comm(group=None):
     (MaGGIe._graph_policy calls it on every rank's first training forward when MAGGIE_SYNCBN_GRAPHS=1)."""
     global SYNCBN_COMM
     if SYNCBN_COMM is None:
-        from .rccl_direct import DirectComm
-        SYNCBN_COMM = DirectComm(group)
+        import os
+        if os.environ.get('MAGGIE_SYNCBN_COMM', 'rccl') == 'mailbox':     # experimental: one plain kernel per exchange (maggie_amd/mailbox.py)
+            from .mailbox import MailboxComm
+            SYNCBN_COMM = MailboxComm(group)
+        else:
+            from .rccl_direct import DirectComm
+            SYNCBN_COMM = DirectComm(group)
     return SYNCBN_COMM
 
 

@@ -454,3 +454,37 @@ def test_syncbn_single_rank_rccl_matches_local_batchnorm(mode):
         assert d8 <= 5e-3, (i, d8)
         rel = sorted(abs(a['grad_norms'][n] - b['grad_norms'][n]) / max(b['grad_norms'][n], 1e-12) for n in b['grad_norms'])
         assert rel[len(rel) // 2] <= 5e-2, (i, rel[len(rel) // 2])
+
+
+@pytest.mark.gpu
+def test_mailbox_allreduce_two_processes_on_one_gpu():
+    """the SyncBN statistics exchange as a hand-written small-message all-reduce over peer-mapped mailboxes
+    (csrc/mailbox.hip, maggie_amd/mailbox.py) -- an ordinary kernel node, so it replays with the rest of a captured step. Two PROCESSES share this
+    one GPU (hipIpc handles exchanged over a gloo group): raw exchanges eager and from a replayed hipGraph equal the host's sum; BatchNorm through
+    functional.batch_norm_act with an nn.SyncBatchNorm holder on 40 + 72 rows equals BatchNorm over the 112 concatenated rows (forward, dx, and
+    dgamma / dbeta summed over the ranks) to 1e-5. (One GPU: the two ranks share an L2, so this validates the protocol and the SyncBN plumbing,
+    not cross-GPU coherence -- DESIGN.md section 6.)"""
+    import json
+    import subprocess
+    import sys
+    _dev()
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, 'mailbox_worker.py'), str(r), '29671'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+             for r in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            out, err = p.communicate(timeout=300)
+            line = [l for l in out.decode(errors='replace').splitlines() if l.startswith('RESULT ')]
+            assert p.returncode == 0 and line, err.decode(errors='replace')[-3000:]
+            outs.append(json.loads(line[-1][7:]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r in outs:
+        assert r['raw_max_err'] <= 1e-6 and r['graph_max_err'] <= 1e-6, r
+        assert r['y_err'] <= 1e-5 and r['dx_err'] <= 1e-5, r
+        assert r['dgamma_err'] <= 1e-5 and r['dbeta_err'] <= 1e-5 and r['running_mean_err'] <= 1e-5, r
+        assert r['calls'] >= 40
