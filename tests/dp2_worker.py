@@ -1,0 +1,134 @@
+"""Child process of tests/test_gpu_graphs.py::test_two_rank_data_parallel_on_one_gpu: rank r of a 2-rank gloo group, BOTH ranks on cuda:0 -- the
+closest thing to a multi-GPU run this project can execute. The data-parallel configuration of bench.py (split trunk = three backward graphs,
+parallel.OverlappedGradSync on a side stream, FlatAdamW(sync_group) with the gradient sink, rank-safe graphs) over real inter-process
+collectives (gloo: slower than RCCL, same call pattern), every rank on its OWN batch shard and with its OWN host RNG, so the ranks disagree on the
+guidance source of the detail region (iter between warm-up and 3 x warm-up: random.random() < 0.5 per rank).
+Checks: (1) the exchanged gradient of the first step == mean of the two ranks' local gradients (computed first, without any exchange);
+(2) parameters stay identical across the ranks over eager, capture and replayed steps; (3) every step reduced every parameter exactly once.
+With `syncbn`: the BatchNorm layers are nn.SyncBatchNorm and their statistics exchange runs inside the captured graphs through the mailbox all-reduce
+kernel (two processes replaying graphs that wait for each other's deposits); the running statistics must then be identical on both ranks and the
+shadow-gradient check is skipped (the shadow would need the peer's rows).
+usage: python tests/dp2_worker.py <rank> <port> [syncbn] -> 'RESULT {...}'"""
+import json
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+rank, port = int(sys.argv[1]), sys.argv[2]
+SYNCBN = len(sys.argv) > 3 and sys.argv[3] == 'syncbn'       # + nn.SyncBatchNorm with the statistics exchange INSIDE the graphs (mailbox kernel)
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=port, RANK=str(rank), WORLD_SIZE='2')
+if SYNCBN:
+    os.environ.update(MAGGIE_SYNCBN_GRAPHS='1', MAGGIE_SYNCBN_COMM='mailbox')
+
+import numpy as np                  # noqa: E402
+import torch                        # noqa: E402
+import torch.distributed as dist    # noqa: E402
+
+from helpers import reference_layout_state_dict, DSEED       # noqa: E402
+from maggie_amd import parallel                                # noqa: E402
+from maggie_amd.network import build_model                     # noqa: E402
+from maggie_amd.optim import FlatAdamW                         # noqa: E402
+from maggie_amd.utils import config, synth                     # noqa: E402
+
+dist.init_process_group('gloo', rank=rank, world_size=2)
+torch.cuda.set_device(0)
+dev = torch.device('cuda:0')
+
+
+def fresh_model():
+    model, _ = build_model(config.model_config('image'))
+    model.load_state_dict(reference_layout_state_dict('image'))
+    model.to(dev).train()
+    model.decoder.inst_spec_layer.dropout.p = 0.0
+    return model
+
+
+it = int(1.5 * fresh_model().decoder.warmup_detail_iter)      # between warm-up and 3 x warm-up: the guidance source is a per-rank coin flip
+batch = synth.synthetic_batch(2, 1, 2, 64, 64, seed=DSEED + 17 * rank, train=True, max_inst=10, it=it)
+batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+res = {'rank': rank, 'iter': it}
+
+
+def seed(step):
+    random.seed(1000 * rank + step)                            # per-rank host RNG, like tools/main.py (which never seeds `random`)
+    np.random.seed(7 + step)                                   # same width draws on both ranks are fine
+    torch.manual_seed(step)
+
+
+def flat_grads(ps):
+    return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).float().flatten() for p in ps])
+
+
+# ---- a shadow model computes every step's LOCAL gradient (eager, no exchange) from the same weights, batch and host RNG
+shadow = fresh_model()
+shadow.hip_graphs = False
+sparams = [p for p in shadow.parameters() if p.requires_grad]
+
+model = fresh_model()
+if SYNCBN:
+    model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+model.hip_graphs = True
+params = [p for p in model.parameters() if p.requires_grad]
+opt = FlatAdamW(params, lr=1e-5, weight_decay=0.01, max_grad_norm=0.01, sync_group=True)
+model.split_trunk = True
+opt.overlap = parallel.OverlappedGradSync().attach(model)
+model.grad_sink = opt.grad_views
+assert model._rank_safe_graphs()
+n_total = sum(p.numel() for p in params)
+res['param_drift'], res['loss'], res['grad_vs_mean_rel'], res['local_grads_differ'] = [], [], [], []
+res['bn_drift'] = []
+for step in range(5):
+    want = None
+    if not SYNCBN:
+        with torch.no_grad():
+            for sp, p in zip(shadow.parameters(), model.parameters()):
+                sp.copy_(p)
+        shadow.zero_grad(set_to_none=True)
+        seed(step)
+        _, sloss = shadow(batch)
+        sloss['total'].backward()
+        local = flat_grads(sparams).cpu()
+        both = [torch.zeros_like(local), torch.zeros_like(local)]
+        dist.all_gather(both, local)
+        want = (both[0] + both[1]) / 2
+        res['local_grads_differ'].append(float((both[0] - both[1]).norm() / both[0].norm()))
+
+    seed(step)
+    opt.zero_grad(set_to_none=True)
+    out, loss = model(batch)
+    loss['total'].backward()
+    opt.step()                                                  # (waits for the side stream; eager steps exchange here)
+    torch.cuda.synchronize()
+    # the exchanged gradient the update used (the clip is a coefficient inside the kernel), parameter by parameter in the shadow's order
+    slot = {id(p): gv for p, gv in zip(opt._active(), opt._g_views)}
+    got = torch.cat([slot[id(p)].detach().float().flatten() for p in params]).cpu()
+    if want is not None:
+        res['grad_vs_mean_rel'].append(float((got - want).norm() / want.norm()))
+    ex = [got.clone(), got.clone()]
+    dist.all_gather(ex, got)
+    res.setdefault('grad_drift', []).append(float((ex[0] - ex[1]).abs().max()))
+    bn = torch.cat([b.detach().float().flatten() for n_, b in model.named_buffers() if 'running_' in n_]).cpu()
+    bns = [torch.zeros_like(bn), torch.zeros_like(bn)]
+    dist.all_gather(bns, bn)
+    res['bn_drift'].append(float((bns[0] - bns[1]).abs().max()))
+    flat = torch.cat([p.detach().float().flatten() for p in params]).cpu()
+    peers = [torch.zeros_like(flat), torch.zeros_like(flat)]
+    dist.all_gather(peers, flat)
+    res['param_drift'].append(float((peers[0] - peers[1]).abs().max()))
+    res['loss'].append(float(loss['total'].detach()))
+res['graphs'] = sum(1 for st in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs') for v in model.__dict__.get(st, {}).values() if not isinstance(v, (int, str)))
+res['detail_graphs'] = sum(1 for v in model.__dict__.get('_detail_graphs', {}).values() if not isinstance(v, (int, str)))
+res['sync_layers'] = sum(isinstance(m, torch.nn.SyncBatchNorm) for m in model.modules())
+res['comm_calls'] = 0 if parallel.SYNCBN_COMM is None else parallel.SYNCBN_COMM.calls
+if parallel.SYNCBN_COMM is not None and hasattr(parallel.SYNCBN_COMM, 'check'):
+    parallel.SYNCBN_COMM.check()
+for store in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs'):
+    model.__dict__.get(store, {}).clear()
+parallel.syncbn_destroy_comm()
+torch.cuda.synchronize()
+dist.barrier()
+dist.destroy_process_group()
+print('RESULT ' + json.dumps(res))
