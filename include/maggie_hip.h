@@ -571,6 +571,13 @@ int mg_mailbox_open(const void* handle64, void** ptr);
 int mg_mailbox_close(void* ptr);
 int mg_mailbox_free(void* ptr);
 int mg_mailbox_allreduce(const mg_mailbox* mb, float* data, int n, uint32_t* seq_dev, int32_t* err_dev, long spin_ticks, void* stream);
+/* out-of-place form (src is left untouched: SyncBN backward keeps the LOCAL sums for dgamma / dbeta) */
+int mg_mailbox_allreduce_to(const mg_mailbox* mb, const float* src, float* dst, int n, uint32_t* seq_dev, int32_t* err_dev, long spin_ticks, void* stream);
+/* SyncBN forward statistics in one launch: this rank's [nrep][2C] sums (sum x | sum x^2) and row count -> exchanged -> outs = scale | shift | mean |
+ * invstd [4C], *count_out = global count, running statistics updated (the arithmetic of mg_bn_finalize on the pooled moments). 2C + 1 <= MG_MAILBOX_PACK. */
+int mg_mailbox_bn_finalize(const mg_mailbox* mb, const float* stats, int nrep, float count, int C, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps, float* outs, float* count_out,
+                           uint32_t* seq_dev, int32_t* err_dev, long spin_ticks, void* stream);
 
 #ifdef __cplusplus
 }

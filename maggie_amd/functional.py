@@ -712,17 +712,25 @@ class BNAct(torch.autograd.Function):
                     stats, centered = K.colstats_centered(x2, ARENA.take(2 * C, x.device)), True
             elif stats is None:
                 stats = K.colstats(x2)
+            fused_comm = None
             if group is not None:
-                flat = stats.sum(0) if stats.dim() == 2 else stats
-                from .parallel import syncbn_exchange_forward
-                pack = syncbn_exchange_forward(torch.cat([flat[:2 * C], torch.full((1,), float(M), device=x.device)]), group)
-                stats, cnt_t = pack[:2 * C], pack[2 * C:]
+                from . import parallel as _par
+                comm = _par.SYNCBN_COMM
+                if comm is not None and hasattr(comm, 'bn_finalize') and comm.can_finalize(C) and x.is_cuda and stats.shape[-1] == 2 * C:
+                    fused_comm = comm                             # mailbox exchange: replica sums, exchange and finalize in ONE launch (below)
+                else:
+                    flat = stats.sum(0) if stats.dim() == 2 else stats
+                    pack = _par.syncbn_exchange_forward(torch.cat([flat[:2 * C], torch.full((1,), float(M), device=x.device)]), group)
+                    stats, cnt_t = pack[:2 * C], pack[2 * C:]
             rm = running_mean if running_mean.numel() == C else None
             rv = running_var if running_var.numel() == C else None
             rm_p, rv_p = rm, rv
             if rm is None and running_mean is not None:       # padded channel count: update through a temp
                 rm_p, rv_p = pad_vec(running_mean, C).clone(), pad_vec(running_var, C).clone()
-            scale, shift, mean, invstd = K.bn_finalize(stats, count, g32, b32, rm_p, rv_p, momentum, eps, count_ptr=cnt_t, centered=centered)
+            if fused_comm is not None:
+                scale, shift, mean, invstd, cnt_t = fused_comm.bn_finalize(stats.contiguous(), count, g32, b32, rm_p, rv_p, momentum, eps)
+            else:
+                scale, shift, mean, invstd = K.bn_finalize(stats, count, g32, b32, rm_p, rv_p, momentum, eps, count_ptr=cnt_t, centered=centered)
             if rm is None and running_mean is not None:
                 running_mean.copy_(rm_p[:running_mean.numel()])
                 running_var.copy_(rv_p[:running_var.numel()])

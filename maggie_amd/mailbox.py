@@ -56,6 +56,34 @@ class MailboxComm:
         self.calls += 1
         return t
 
+    def all_reduce_sum_to(self, src, dst):
+        """Out-of-place form: dst = sum over the ranks of src (src untouched)."""
+        for t in (src, dst):
+            if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and 0 < t.numel() <= PACK):
+                raise hip.MaggieHipError('MailboxComm.all_reduce_sum_to: contiguous fp32 device tensors of at most %d elements expected' % PACK)
+        s = self._state
+        hip.call('mg_mailbox_allreduce_to', ctypes.byref(self._mb), hip.ptr(src), hip.ptr(dst), ctypes.c_int(src.numel()), ctypes.c_void_p(s.data_ptr()),
+                 ctypes.c_void_p(s.data_ptr() + 4), ctypes.c_long(self._spin), hip.stream())
+        self.calls += 1
+        return dst
+
+    def can_finalize(self, C):
+        return 2 * C + 1 <= PACK
+
+    def bn_finalize(self, stats, count, gamma, beta, running_mean, running_var, momentum, eps):
+        """SyncBN forward statistics in ONE launch (mg_mailbox_bn_finalize): this rank's statistics ([nrep][2C] or [2C]: sum x | sum x^2) and row
+        count -> (scale, shift, mean, invstd) views of one [4C] buffer, the global count [1]; running statistics updated in place."""
+        nrep = stats.shape[0] if stats.dim() == 2 else 1
+        C = stats.shape[-1] // 2
+        outs = torch.empty(4 * C, dtype=torch.float32, device=stats.device)
+        cnt = torch.empty(1, dtype=torch.float32, device=stats.device)
+        s = self._state
+        hip.call('mg_mailbox_bn_finalize', ctypes.byref(self._mb), hip.ptr(stats), ctypes.c_int(nrep), ctypes.c_float(float(count)), ctypes.c_int(C),
+                 hip.ptr(gamma), hip.ptr(beta), hip.ptr(running_mean), hip.ptr(running_var), ctypes.c_float(momentum), ctypes.c_float(eps),
+                 hip.ptr(outs), hip.ptr(cnt), ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(s.data_ptr() + 4), ctypes.c_long(self._spin), hip.stream())
+        self.calls += 1
+        return outs[:C], outs[C:2 * C], outs[2 * C:3 * C], outs[3 * C:], cnt
+
     def check(self):
         """Host read of the error word (a peer that did not arrive within the spin budget)."""
         if int(self._state[1].item()) != 0:

@@ -70,6 +70,8 @@ def syncbn_exchange_backward(local_sums, group):
     untouched). torch's SyncBatchNorm all-reduces these two vectors for dx only and keeps grad_weight / grad_bias local (DDP then averages
     them over the ranks); returning the all-reduced sums as dgamma / dbeta would make every BN parameter gradient world_size times too
     large."""
+    if SYNCBN_COMM is not None and local_sums.is_cuda:
+        return SYNCBN_COMM.all_reduce_sum_to(local_sums, torch.empty_like(local_sums)), local_sums      # out of place: no copy kernel
     return _sum_over_ranks_(local_sums.clone(), group), local_sums
 
 

@@ -74,6 +74,18 @@ class DirectComm:
         self.calls += 1
         return t
 
+    def all_reduce_sum_to(self, src, dst):
+        """Out-of-place form: dst = sum over the ranks of src (src untouched)."""
+        for t in (src, dst):
+            if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+                raise hip.MaggieHipError('DirectComm.all_reduce_sum_to: contiguous fp32 device tensors expected')
+        if self.comm is None:
+            raise hip.MaggieHipError('DirectComm used after destroy()')
+        _check(_lib().ncclAllReduce(ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(dst.data_ptr()), src.numel(), _NCCL_FLOAT, _NCCL_SUM, self.comm,
+                                    hip.stream()), 'ncclAllReduce')
+        self.calls += 1
+        return dst
+
     def destroy(self):
         if self.comm is not None:
             torch.cuda.synchronize()
