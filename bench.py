@@ -80,7 +80,11 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29517')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl')
+        # MAGGIE_DIST_BACKEND=gloo + MAGGIE_ONE_GPU=1: dry run of the multi-rank command line with every rank on cuda:0 (RCCL refuses two ranks on
+        # one device; gloo moves CUDA tensors) -- the only way to execute the N > 1 path on a one-GPU box. Never a measurement.
+        dist.init_process_group(os.environ.get('MAGGIE_DIST_BACKEND', 'nccl'))
+    if os.environ.get('MAGGIE_ONE_GPU') == '1':
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if os.environ.get('MAGGIE_MEM_FRACTION'):                 # a bound on the caching allocator: an over-sized configuration raises instead of taking the box down
