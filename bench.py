@@ -183,7 +183,7 @@ def main():
         # the reductions run after the timed region
         hist = stats.setdefault('active_masks', [])
         hist.append(out['detail_mask'])
-        del hist[:-(args.steps + 2)]
+        del hist[:-min(args.steps + 2, 66)]                       # (a mask is 10 MB: long runs keep the last 64 timed steps' only)
 
     def sync():
         torch.cuda.synchronize()
@@ -222,7 +222,7 @@ def main():
     value = inst_frames_per_step * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
     active_px = float(stats['active_px'].float().sum().item())
-    stats['active_hist'] = [m.sum() for m in stats.pop('active_masks')[-args.steps:]]      # the timed steps (the instrumented ones come later)
+    stats['active_hist'] = [m.sum() for m in stats.pop('active_masks')[-min(args.steps, 64):]]      # the timed steps (the instrumented ones come later)
     active_ratio = active_px / (b * n_f * args.instances * args.size * args.size)
     loss_val = float(stats['loss'].item())
 
