@@ -165,6 +165,11 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             # through ProcessGroupNCCL, whose watchdog thread aborts the process when it queries an event recorded inside a capture.
             import os
             if os.environ.get('MAGGIE_SYNCBN_GRAPHS', '0') != '1':
+                if not self.__dict__.get('_syncbn_hint'):
+                    self.__dict__['_syncbn_hint'] = True
+                    logging.warning('MaGGIe (MI355X build): nn.SyncBatchNorm across ranks runs the step eagerly (142 host-launched collectives per step: 30 ms '
+                                    'against 12 ms in the 1-rank measurement). MAGGIE_SYNCBN_GRAPHS=1 keeps it in the hipGraphs (13 ms; verified with one '
+                                    'rank over RCCL and with two processes on one GPU over the mailbox kernels, DESIGN.md section 6).')
                 return False
             from ... import parallel
             parallel.syncbn_direct_comm()                         # collective on first use: every rank reaches its first training forward
