@@ -39,6 +39,24 @@ int mg_abi_version(void);
  * accumulator with a fill launch of their own skip it for buffers inside the range -- the host's per-graph zero arena (one memset node per replay). */
 int mg_set_zeroed_range(void* base, long bytes);
 
+/* Bit-reproducible steps. The reference trains with torch.backends.cudnn.deterministic = True, benchmark = False (tools/main.py:135-136): two
+ * runs of one step give the same bits, so the active-pixel index map -- a threshold of the coarse alpha (maggie/utils/utils.py:31) -- is the same
+ * run to run. mg_set_deterministic(1) (the library's default) gives this library the same property: every cross-workgroup fp32 sum (BatchNorm
+ * statistics and backward sums, bias / LayerNorm gradients, the token side of the attention backward, loss sums, SpectralNorm dot products, the
+ * gradient norm) is formed as "one partial per workgroup, added in index order" instead of atomicAdd. mg_set_deterministic(0) restores the atomic
+ * forms. The ordered sums stage their partials in a library-owned scratch that mg_det_init(bytes) allocates on the CURRENT device (call it once,
+ * outside any stream capture; entry points return -7 when it is missing or too small). The scratch is shared by all launches: issue the library's
+ * kernels on ONE stream at a time (stream order also holds inside a captured graph).
+ * mg_stat_rows(): rows of the [rows][2C] statistics scratch the column-statistics kernels fill (MG_STAT_REPLICAS, or MG_DET_STAT_ROWS = 1024 in
+ * deterministic mode: one row per row block, added in row order by mg_bn_finalize). */
+#define MG_DET_STAT_ROWS 1024
+int mg_set_deterministic(int on);
+int mg_get_deterministic(void);
+int mg_det_init(long bytes);
+int mg_stat_rows(void);
+/* test hook: dst[g][c] += sum_b slots[g][b][c] in the library's fixed order ([groups][nblk][nv] fp32) */
+int mg_det_reduce_test(const float* slots, int nblk, int groups, int nv, float* dst, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution (MFMA):  Y[m, yoff+co] = epi( sum_{tap,ci} X[src(m,tap), ci] * W[co, tap, ci] )
  *   epi(v): if pre_act v = act(v);  v = v*scale[co] + shift[co];  v += res;  if !pre_act v = act(v);  v += res2
@@ -82,6 +100,10 @@ typedef struct mg_conv_params {
     const float* bnb_mean;
     const float* bnb_invstd;
     int32_t bnb_act, bnb_ld;
+    int32_t stat_rep;    /* rows of `stats` in stat_mode 0 (0 = MG_STAT_REPLICAS): output tile t adds to row t % stat_rep. With stat_rep >= the number of
+                            output tiles (mg_conv_stat_rows) every word receives ONE addition and mg_bn_finalize adds the rows in index order: the
+                            statistics are then bit-reproducible run to run (the reference runs with cudnn.deterministic = True, tools/main.py:135-136) */
+    int32_t reserved0;
 } mg_conv_params;
 
 int mg_conv_fprop(const mg_conv_params* p, void* stream);
@@ -210,6 +232,10 @@ int mg_gather_rows(const void* dense, int dtype, const int32_t* coords, int R, i
 int mg_gather_rows_bwd(const void* dout, int dtype, int ldo, int yoff, const int32_t* coords, int R, int n_i, int Hd, int Wd, int C,
                        const float* mul, int mul_ninst, const void* dense, float* ddense, float* dmul, void* stream);
 /* atomic-free d(dense): each dense pixel sums the rows of the instance planes active there (bits/wordoff of that level) */
+/* dmul[frame, inst, c] = sum over the rows r of plane (frame, inst) of dout[r, yoff + c] * dense[frame, y_r, x_r, c] (fp32 [N, mul_ninst, C],
+ * OVERWRITTEN): the token-multiplier gradient of mg_gather_rows without atomics -- per-plane row ranges (coords sorted by plane), fixed-order sums. */
+int mg_gather_rows_dmul_det(const void* dout, int dtype, int ldo, int yoff, const int32_t* coords, int R, int n_i, int N, int Hd, int Wd, int C,
+                            int mul_ninst, const void* dense, float* dmul, const int32_t* r_dev, void* stream);
 int mg_gather_rows_bwd_dense(const void* dout, int dtype, int ldo, int yoff, const void* bits, const int32_t* wordoff, int n_i, int N,
                              int Hd, int Wd, int C, const float* mul, int mul_ninst, void* ddense, void* stream);
 /* plane[P,H,W] = fill everywhere, vals[r, col] at the active sites (SparseConvTensor.dense() - 99 trick) */
@@ -324,12 +350,16 @@ typedef struct mg_sn_desc {
     int32_t A, B, taps, transposed, pad_in;
     int32_t plain;       /* != 0: an ordinary (not spectrally normalised) conv weight: converted / transposed with sigma = 1, u and v unused;
                             its gradient comes back unchanged in the parameter's layout                      */
+    int32_t k3_first, k3_count; /* this conv's run of (16 x 32) parameter tiles in items_k3: the backward adds their <G, W> partials in item order */
 } mg_sn_desc;
 int mg_spectral_norm_batched(const mg_sn_desc* descs, int n_conv, const int32_t* items_k1, int n1, const int32_t* items_k2, int n2,
                              const int32_t* items_k3, int n3, float* work_base, long work_floats, void* out_base, void* out_t_base,
                              int out_dtype, void* stream);   /* out_t_base (or NULL): same offsets, (Cin_pad, taps, Cout) copies for dgrad */
+/* items_k1: (conv, block of 32 columns of W^T u, -, -); items_k2: (conv, group of 4 rows of W v, -, -); items_k3: (conv, a tile, b tile, -).
+ * Every sum of the pipeline (W^T u, the two norms, <G, W>) is formed in a fixed order: no atomics, bit-reproducible u / v / sigma.
+ * dot_part: n3 floats of scratch (per-tile partials of <G, W>). */
 int mg_spectral_norm_batched_bwd(const mg_sn_desc* descs, int n_conv, const int32_t* items_k3, int n3, const void* const* Gptrs,
-                                 int g_dtype, float* work_base, float* dW_base, void* stream);
+                                 int g_dtype, float* work_base, float* dW_base, float* dot_part, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Temporal (video) elementwise kernels. Rows x channels (NHWC) in `dtype`; rz = first gate conv's output (M, 2C) = [r | z] before

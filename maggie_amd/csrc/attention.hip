@@ -47,8 +47,9 @@ __device__ __forceinline__ void stage_tokens(float* dst, const float* __restrict
     for (int i = threadIdx.x; i < n; i += NT) dst[i] = src[i];
 }
 // acc[T][CPL] summed over the 4 groups of a wave, then over the 4 waves through LDS, then atomically into dst[T][D]
+// `slot` (deterministic mode, csrc/det.hip): the workgroup's partial is STORED there (T * D floats) instead of being added to dst atomically
 template <int T>
-__device__ __forceinline__ void reduce_token_acc(float (&acc)[T][CPL], float* sred, float* __restrict__ dst) {
+__device__ __forceinline__ void reduce_token_acc(float (&acc)[T][CPL], float* sred, float* __restrict__ dst, float* __restrict__ slot = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & (GL - 1);
 #pragma unroll
     for (int t = 0; t < T; ++t)
@@ -68,9 +69,23 @@ __device__ __forceinline__ void reduce_token_acc(float (&acc)[T][CPL], float* sr
     __syncthreads();
     for (int i = threadIdx.x; i < T * D; i += NT) {
         const float v = (sred[i] + sred[T * D + i]) + (sred[2 * T * D + i] + sred[3 * T * D + i]);
-        if (v != 0.f) atomicAdd(dst + i, v);
+        if (slot) slot[i] = v;
+        else if (v != 0.f) atomicAdd(dst + i, v);
     }
     __syncthreads();
+}
+
+// Per-id sums of a workgroup's rows in ROW order (was: LDS float atomics, whose order depends on wave timing): the lanes li < T of every row
+// publish their value and the row's id (rows that do not exist: id -1); value (t, id) then walks the RPB rows once.
+// out[i], i = (TMAJOR ? t * NID + id : id * T + t).
+template <int T, bool TMAJOR>
+__device__ __forceinline__ void id_sums_ordered(const float* __restrict__ sds, const int* __restrict__ sid, int NID, float* __restrict__ out) {
+    for (int i = threadIdx.x; i < T * NID; i += NT) {
+        const int t = TMAJOR ? i / NID : i % T, id = TMAJOR ? i % NID : i / T;
+        float a = 0.f;
+        for (int lr = 0; lr < RPB; ++lr) a += (sid[lr] == id) ? sds[lr * T + t] : 0.f;
+        out[i] = a;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ tokens <- features
@@ -127,7 +142,8 @@ __global__ __launch_bounds__(NT) void softmax_rows_kernel(float* __restrict__ x,
 
 // ctx[t, c] += sum_{l in chunk} P[t,l] F[l,c]
 template <int T>
-__global__ __launch_bounds__(NT) void tok_ctx_kernel(const float* __restrict__ p, const float* __restrict__ feat, int L, float* __restrict__ ctx) {
+__global__ __launch_bounds__(NT) void tok_ctx_kernel(const float* __restrict__ p, const float* __restrict__ feat, int L, float* __restrict__ ctx,
+                                                     float* __restrict__ slots) {
     constexpr int CH = 128;
     __shared__ float sp[T * CH];
     __shared__ float sr[T * D];
@@ -154,14 +170,18 @@ __global__ __launch_bounds__(NT) void tok_ctx_kernel(const float* __restrict__ p
     __syncthreads();
     if (half == 0) {
 #pragma unroll
-        for (int t = 0; t < T; ++t) atomicAdd(&ctx[((long)b * T + t) * D + c], acc[t] + sr[t * D + c]);
+        for (int t = 0; t < T; ++t) {
+            if (slots) slots[(((size_t)b * gridDim.x + blockIdx.x) * T + t) * D + c] = acc[t] + sr[t * D + c];     // deterministic mode: one row [T][D] per workgroup
+            else atomicAdd(&ctx[((long)b * T + t) * D + c], acc[t] + sr[t * D + c]);
+        }
     }
 }
 
 // backward pass 1: G[t,l] = dP[t,l] + dCtx[t] . F[l];  rowdot[t] += sum_l P[t,l] G[t,l]
 template <int T>
 __global__ __launch_bounds__(NT) void tok_bwd1_kernel(const float* __restrict__ p, const float* __restrict__ feat, const float* __restrict__ dctx,
-                                                      const float* __restrict__ dp, int L, float* __restrict__ gbuf, float* __restrict__ rowdot) {
+                                                      const float* __restrict__ dp, int L, float* __restrict__ gbuf, float* __restrict__ rowdot,
+                                                      float* __restrict__ slots) {
     __shared__ float sd[T * D];
     __shared__ float sacc[(NT / 64) * 16];
     const int b = blockIdx.y;
@@ -195,7 +215,8 @@ __global__ __launch_bounds__(NT) void tok_bwd1_kernel(const float* __restrict__ 
     __syncthreads();
     if (threadIdx.x < T) {
         const float v = (sacc[threadIdx.x] + sacc[16 + threadIdx.x]) + (sacc[32 + threadIdx.x] + sacc[48 + threadIdx.x]);
-        atomicAdd(&rowdot[b * T + threadIdx.x], v);
+        if (slots) slots[((size_t)b * gridDim.x + blockIdx.x) * T + threadIdx.x] = v;
+        else atomicAdd(&rowdot[b * T + threadIdx.x], v);
     }
 }
 
@@ -204,12 +225,14 @@ template <int T>
 __global__ __launch_bounds__(NT) void tok_bwd2_kernel(const float* __restrict__ p, const float* __restrict__ feat, const float* __restrict__ qk,
                                                       const float* __restrict__ dctx, const int32_t* __restrict__ ids, const float* __restrict__ gbuf,
                                                       const float* __restrict__ rowdot, int L, int NID, float scale, float* __restrict__ dfeat,
-                                                      float* __restrict__ dqk, float* __restrict__ dbtab) {
+                                                      float* __restrict__ dqk, float* __restrict__ dbtab, float* __restrict__ slots) {
     extern __shared__ float smem[];
     float* sq = smem;                    // [T][D]
     float* sd = smem + T * D;            // [T][D]
     float* sred = smem + 2 * T * D;      // [4][T][D]
     float* sb = sred + 4 * T * D;        // [T][NID]
+    float* sds = sb + T * NID;           // [RPB][T]  dS of the workgroup's rows
+    int* sid = (int*)(sds + RPB * T);    // [RPB]     their ids (-1: no such row)
     const int b = blockIdx.y;
     stage_tokens(sq, qk + (long)b * T * D, T * D);
     stage_tokens(sd, dctx + (long)b * T * D, T * D);
@@ -235,9 +258,10 @@ __global__ __launch_bounds__(NT) void tok_bwd2_kernel(const float* __restrict__ 
                 const long o = ((long)b * T + li) * L + l;
                 pv = p[o];
                 ds = pv * (gbuf[o] - rdot) * scale;
-                if (ds != 0.f) atomicAdd(&sb[li * NID + ids[(long)b * L + l]], ds);
             }
         }
+        if (li < T) sds[(r * NG + g) * T + li] = ds;
+        if (li == 0) sid[r * NG + g] = ok ? ids[(long)b * L + l] : -1;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const float dst = __shfl(ds, gbase + t, 64), pt = __shfl(pv, gbase + t, 64);
@@ -249,9 +273,13 @@ __global__ __launch_bounds__(NT) void tok_bwd2_kernel(const float* __restrict__ 
         }
         if (ok) st8(dfeat + ((long)b * L + l) * D + li * CPL, out);
     }
-    reduce_token_acc<T>(acc, sred, dqk + (long)b * T * D);
-    for (int i = threadIdx.x; i < T * NID; i += NT)
-        if (sb[i] != 0.f) atomicAdd(&dbtab[(long)b * T * NID + i], sb[i]);
+    float* slot = slots ? slots + ((size_t)b * gridDim.x + blockIdx.x) * (T * D + T * NID) : nullptr;     // row [dQk (T x D) | dBtab (T x NID)]
+    reduce_token_acc<T>(acc, sred, dqk + (long)b * T * D, slot);       // (its barriers also publish sds / sid)
+    id_sums_ordered<T, true>(sds, sid, NID, sb);
+    for (int i = threadIdx.x; i < T * NID; i += NT) {                 // each thread reads back what it wrote itself
+        if (slot) slot[T * D + i] = sb[i];
+        else if (sb[i] != 0.f) atomicAdd(&dbtab[(long)b * T * NID + i], sb[i]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ features <- tokens
@@ -310,12 +338,14 @@ template <int T>
 __global__ __launch_bounds__(NT) void feat_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ p, const float* __restrict__ feat,
                                                       const float* __restrict__ kq, const float* __restrict__ vp, const int32_t* __restrict__ ids,
                                                       int L, int NID, float scale, float* __restrict__ dfeat, float* __restrict__ dkq,
-                                                      float* __restrict__ dvp, float* __restrict__ db2, float* __restrict__ dob) {
+                                                      float* __restrict__ dvp, float* __restrict__ db2, float* __restrict__ dob, float* __restrict__ slots) {
     extern __shared__ float smem[];
     float* sk = smem;                    // [T][D]
     float* sv = smem + T * D;            // [T][D]
     float* sred = smem + 2 * T * D;      // [4][T][D]
     float* sb = sred + 4 * T * D;        // [NID][T]
+    float* sds = sb + T * NID;           // [RPB][T]  dS of the workgroup's rows
+    int* sid = (int*)(sds + RPB * T);    // [RPB]     their ids (-1: no such row)
     const int b = blockIdx.y;
     stage_tokens(sk, kq + (long)b * T * D, T * D);
     stage_tokens(sv, vp + (long)b * T * D, T * D);
@@ -365,16 +395,14 @@ __global__ __launch_bounds__(NT) void feat_bwd_kernel(const float* __restrict__ 
         }
 #pragma unroll
         for (int e = 0; e < CPL; ++e) aob[e] += go[e];
-        if (ok) {
-            st8(dfeat + ((long)b * L + l) * D + li * CPL, df);
-            if (li < T) {
-                const float v = pick<T>(ds, li);
-                if (v != 0.f) atomicAdd(&sb[ids[(long)b * L + l] * T + li], v);
-            }
-        }
+        if (ok) st8(dfeat + ((long)b * L + l) * D + li * CPL, df);
+        if (li < T) sds[(r * NG + g) * T + li] = ok ? pick<T>(ds, li) : 0.f;
+        if (li == 0) sid[r * NG + g] = ok ? ids[(long)b * L + l] : -1;
     }
-    reduce_token_acc<T>(akq, sred, dkq + (long)b * T * D);
-    reduce_token_acc<T>(avp, sred, dvp + (long)b * T * D);
+    // deterministic mode: the workgroup's row [dKq (T x D) | dVp (T x D) | dB2 (NID x T) | dObias (D)]
+    float* slot = slots ? slots + ((size_t)b * gridDim.x + blockIdx.x) * (2 * T * D + T * NID + D) : nullptr;
+    reduce_token_acc<T>(akq, sred, dkq + (long)b * T * D, slot);
+    reduce_token_acc<T>(avp, sred, dvp + (long)b * T * D, slot ? slot + T * D : nullptr);
     // bias gradient: 16-lane channel slices over the 16 groups of the block
     {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -385,13 +413,17 @@ __global__ __launch_bounds__(NT) void feat_bwd_kernel(const float* __restrict__ 
             for (int e = 0; e < CPL; ++e) sred[wave * D + li * CPL + e] = aob[e];
         }
         __syncthreads();
-        if (dob && threadIdx.x < D) {
+        if (threadIdx.x < D) {
             const float v = (sred[threadIdx.x] + sred[D + threadIdx.x]) + (sred[2 * D + threadIdx.x] + sred[3 * D + threadIdx.x]);
-            if (v != 0.f) atomicAdd(&dob[threadIdx.x], v);
+            if (slot) slot[2 * T * D + T * NID + threadIdx.x] = v;
+            else if (dob && v != 0.f) atomicAdd(&dob[threadIdx.x], v);
         }
     }
-    for (int i = threadIdx.x; i < T * NID; i += NT)
-        if (sb[i] != 0.f) atomicAdd(&db2[(long)b * NID * T + i], sb[i]);
+    id_sums_ordered<T, false>(sds, sid, NID, sb);
+    for (int i = threadIdx.x; i < T * NID; i += NT) {
+        if (slot) slot[2 * T * D + i] = sb[i];
+        else if (sb[i] != 0.f) atomicAdd(&db2[(long)b * NID * T + i], sb[i]);
+    }
 }
 
 inline dim3 row_grid(int L, int B) { return dim3((L + RPB - 1) / RPB, B); }
@@ -427,8 +459,15 @@ extern "C" int mg_attn_tok_fwd(const float* qk, const float* btab, const float* 
     hipLaunchKernelGGL(tok_scores_kernel<TT>, row_grid(L, B), dim3(NT), 0, st, qk, btab, feat, ids, L, NID, scale, p);
     hipLaunchKernelGGL(softmax_rows_kernel, dim3(B * T), dim3(NT), 0, st, p, L);
     hipError_t e = mg_zero_words(ctx, (long)B * T * Dm, st); if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(tok_ctx_kernel<TT>, dim3((L + 127) / 128, B), dim3(NT), 0, st, p, feat, L, ctx);
+    const int nblk = (L + 127) / 128;
+    float* slots = nullptr;
+    if (mg_det_on && nblk > 1) { slots = mg_det_scratch((long)B * nblk * T * Dm); if (!slots) return MG_DET_NO_SCRATCH; }
+    hipLaunchKernelGGL(tok_ctx_kernel<TT>, dim3(nblk, B), dim3(NT), 0, st, p, feat, L, ctx, slots);
     MG_CHECK_LAUNCH();
+    if (slots) {
+        mg_det_seg sg{ctx, T * Dm, (long)T * Dm};
+        return mg_det_reduce(slots, nblk, B, T * Dm, 0, &sg, 1, st);
+    }
     return 0;
 }
 
@@ -442,10 +481,23 @@ extern "C" int mg_attn_tok_bwd(const float* p, const float* feat, const float* q
         const long words[3] = {(long)B * T, (long)B * T * Dm, (long)B * T * NID};
         int rcz = zero_adjacent(bufs, words, 3, st); if (rcz) return rcz;
     }
-    hipLaunchKernelGGL(tok_bwd1_kernel<TT>, row_grid(L, B), dim3(NT), 0, st, p, feat, dctx, dp, L, gbuf, rowdot);
-    const size_t lds = (size_t)(6 * TT * D + TT * NID) * sizeof(float);
-    hipLaunchKernelGGL(tok_bwd2_kernel<TT>, row_grid(L, B), dim3(NT), lds, st, p, feat, qk, dctx, ids, gbuf, rowdot, L, NID, scale, dfeat, dqk, dbtab);
+    // deterministic mode (csrc/det.hip): both kernels store one partial row per workgroup, added in workgroup order right behind them
+    const int nblk = (int)row_grid(L, B).x;
+    const int w2 = T * Dm + T * NID;
+    float* slots = nullptr;
+    if (mg_det_on && nblk > 1) { slots = mg_det_scratch((long)B * nblk * w2); if (!slots) return MG_DET_NO_SCRATCH; }
+    hipLaunchKernelGGL(tok_bwd1_kernel<TT>, row_grid(L, B), dim3(NT), 0, st, p, feat, dctx, dp, L, gbuf, rowdot, slots);
+    if (slots) {
+        mg_det_seg sg{rowdot, T, (long)T};
+        int rcd = mg_det_reduce(slots, nblk, B, T, 0, &sg, 1, st); if (rcd) return rcd;
+    }
+    const size_t lds = (size_t)(6 * TT * D + TT * NID + RPB * TT + RPB) * sizeof(float);
+    hipLaunchKernelGGL(tok_bwd2_kernel<TT>, row_grid(L, B), dim3(NT), lds, st, p, feat, qk, dctx, ids, gbuf, rowdot, L, NID, scale, dfeat, dqk, dbtab, slots);
     MG_CHECK_LAUNCH();
+    if (slots) {
+        mg_det_seg sg[2] = {{dqk, T * Dm, (long)T * Dm}, {dbtab, T * NID, (long)T * NID}};
+        return mg_det_reduce(slots, nblk, B, w2, 0, sg, 2, st);
+    }
     return 0;
 }
 
@@ -466,8 +518,20 @@ extern "C" int mg_attn_feat_bwd(const float* dout, const float* p, const float* 
         const long words[4] = {(long)B * T * Dm, (long)B * T * Dm, (long)B * NID * T, dobias ? (long)Dm : 0l};
         int rcz = zero_adjacent(bufs, words, 4, st); if (rcz) return rcz;
     }
-    const size_t lds = (size_t)(6 * TT * D + TT * NID) * sizeof(float);
-    hipLaunchKernelGGL(feat_bwd_kernel<TT>, row_grid(L, B), dim3(NT), lds, st, dout, p, feat, kq, vp, ids, L, NID, scale, dfeat, dkq, dvp, db2, dobias);
+    const size_t lds = (size_t)(6 * TT * D + TT * NID + RPB * TT + RPB) * sizeof(float);
+    const int nblk = (int)row_grid(L, B).x;
+    const int w = 2 * T * Dm + T * NID + Dm;
+    float* slots = nullptr;
+    if (mg_det_on && (nblk > 1 || B > 1)) { slots = mg_det_scratch((long)B * nblk * w); if (!slots) return MG_DET_NO_SCRATCH; }
+    hipLaunchKernelGGL(feat_bwd_kernel<TT>, row_grid(L, B), dim3(NT), lds, st, dout, p, feat, kq, vp, ids, L, NID, scale, dfeat, dkq, dvp, db2, dobias, slots);
     MG_CHECK_LAUNCH();
+    if (slots) {
+        mg_det_seg sg[3] = {{dkq, T * Dm, (long)T * Dm}, {dvp, T * Dm, (long)T * Dm}, {db2, T * NID, (long)T * NID}};
+        int rcd = mg_det_reduce(slots, nblk, B, w, 0, sg, 3, st); if (rcd) return rcd;
+        if (dobias) {                                             // the output bias is shared by the samples: one sum over all B * nblk rows
+            mg_det_seg sb{dobias, Dm, 0};
+            return mg_det_reduce(slots, B * nblk, 1, w, 2 * T * Dm + T * NID, &sb, 1, st);
+        }
+    }
     return 0;
 }

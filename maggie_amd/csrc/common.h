@@ -154,6 +154,24 @@ static inline hipError_t mg_zero_words(void* p, long n_words, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ---- deterministic cross-workgroup sums (csrc/det.hip) -------------------------------------------------------------------------
+// mg_det_on (MAGGIE_DETERMINISTIC, default 1): kernels that end in a cross-workgroup fp32 sum store one partial per workgroup into a
+// slot buffer (mg_det_scratch) instead of atomicAdd, and mg_det_reduce adds the slots in index order behind them.
+#define MG_DET_MAX_SEGS 4
+#ifndef MG_DET_STAT_ROWS
+#define MG_DET_STAT_ROWS 1024      /* rows of a BatchNorm statistics scratch in deterministic mode (one per row block, <= 1024 of them) */
+#endif
+struct mg_det_seg { float* dst; int nv; long group_stride; };
+extern int mg_det_on;
+float* mg_det_scratch(long floats);                    // the library's slot scratch (nullptr: not initialised / too small)
+// slots: [groups][nblk][rowstride]; the segments cover the columns [col0, col0 + sum nv) of a row
+int mg_det_reduce(const float* slots, int nblk, int groups, int rowstride, int col0, const mg_det_seg* segs, int nseg, hipStream_t st);
+static inline int mg_det_reduce1(const float* slots, int nblk, float* dst, int nv, hipStream_t st) {
+    mg_det_seg s{dst, nv, 0};
+    return mg_det_reduce(slots, nblk, 1, nv, 0, &s, 1, st);
+}
+#define MG_DET_NO_SCRATCH (-7)     /* deterministic mode without (enough) slot scratch: mg_det_init was not called or the request is too large */
+
 #define MG_CHECK_LAUNCH()                              \
     do {                                               \
         hipError_t e__ = hipGetLastError();            \

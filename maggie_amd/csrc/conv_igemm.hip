@@ -281,7 +281,10 @@ __device__ __forceinline__ void tile_epilogue_impl(const mg_conv_params& p, f32x
                 if (p.stat_mode == 1) {                                       // one row, sums only
                     if (t < BN) atomicAdd(&p.stats[n0 + c], val);
                 } else {
-                    float* st = p.stats + (size_t)(stat_slot & (MG_STAT_REPLICAS - 1)) * 2 * p.Cout;   // spread same-address atomics
+                    // row of the statistics buffer: tile index modulo the rows the caller allocated. 32 rows (default) only spread the same-address
+                    // atomics; with at least as many rows as output tiles (deterministic mode) every word receives exactly ONE addition and the
+                    // finalize kernel adds the rows in index order
+                    float* st = p.stats + (size_t)((unsigned)stat_slot % (unsigned)(p.stat_rep > 0 ? p.stat_rep : MG_STAT_REPLICAS)) * 2 * p.Cout;
                     atomicAdd(&st[(t < BN ? 0 : p.Cout) + n0 + c], val);
                 }
             }
@@ -1306,7 +1309,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const mg_conv_params
             const int c = (blockIdx.y * tx + cx) * CE + e;
             if (c < p.Cout) {
                 if (p.stat_mode == 1) { if (!sq) atomicAdd(&p.stats[c], a); }
-                else atomicAdd(&p.stats[(size_t)(blockIdx.x & (MG_STAT_REPLICAS - 1)) * 2 * p.Cout + (sq ? p.Cout : 0) + c], a);
+                else atomicAdd(&p.stats[(size_t)(blockIdx.x % (unsigned)(p.stat_rep > 0 ? p.stat_rep : MG_STAT_REPLICAS)) * 2 * p.Cout + (sq ? p.Cout : 0) + c], a);
             }
         }
     }

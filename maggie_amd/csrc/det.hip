@@ -1,0 +1,118 @@
+// Deterministic cross-workgroup sums (MAGGIE_DETERMINISTIC, on by default).
+//
+// The reference trains with torch.backends.cudnn.deterministic = True (tools/main.py:135-136): two runs of one step give the same
+// bits. Every kernel of this library that used to finish a cross-workgroup sum with fp32 atomicAdd (BatchNorm backward sums, bias /
+// LayerNorm gradients, the token side of the attention backward, loss sums, the SpectralNorm dot products, the gradient norm) has a
+// second form: each workgroup STORES its partial into its own slot of a scratch buffer, and mg_det_reduce -- one small launch behind
+// the producer -- adds the slots in index order. The order of the additions is then a function of the launch geometry only.
+//
+// Slots layout: [groups][nblk][rowstride] fp32. A launch covers the columns [col0, col0 + sum of the segment widths) of a row: column c of
+// segment s of group g is added into segs[s].dst[g * segs[s].group_stride + c] (+=: the destinations keep the semantics they had under
+// atomicAdd).
+//
+// The scratch is ONE library-owned device buffer: launches on a stream execute in order, and a (producer, reduce) pair is always
+// issued back to back on the same stream -- also inside a captured graph, where stream order becomes a dependency edge. Kernels of
+// this library that run CONCURRENTLY on several streams (MAGGIE_BRANCHES, MAGGIE_SIDE_WGRAD: both off by default) must not use it.
+#include "common.h"
+#include "../../include/maggie_hip.h"
+
+int mg_det_on = 1;
+static char* g_buf = nullptr;
+static long g_bytes = 0;
+static int g_dev = -1;
+
+extern "C" int mg_set_deterministic(int on) { mg_det_on = on ? 1 : 0; return 0; }
+extern "C" int mg_get_deterministic(void) { return mg_det_on; }
+extern "C" int mg_stat_rows(void) { return mg_det_on ? MG_DET_STAT_ROWS : MG_STAT_REPLICAS; }
+
+/* Allocate the slot scratch on the CURRENT device (idempotent; grows). Must be called outside a stream capture -- the Python binding
+ * does so on its first call into the library. */
+extern "C" int mg_det_init(long bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (g_buf && dev == g_dev && g_bytes >= bytes) return 0;
+    if (g_buf) { (void)hipSetDevice(g_dev); (void)hipFree(g_buf); (void)hipSetDevice(dev); g_buf = nullptr; g_bytes = 0; }
+    void* p = nullptr;
+    e = hipMalloc(&p, (size_t)bytes);
+    if (e != hipSuccess) return (int)e;
+    g_buf = (char*)p; g_bytes = bytes; g_dev = dev;
+    return 0;
+}
+
+float* mg_det_scratch(long floats) {
+    if (!g_buf || floats * 4 > g_bytes) return nullptr;
+    return (float*)g_buf;
+}
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int VPB = 16;                 // values per workgroup
+constexpr int CH = NT / VPB;            // slot chunks per value (16)
+
+struct Segs { mg_det_seg s[MG_DET_MAX_SEGS]; int n; };
+
+// One workgroup: VPB consecutive columns of one group; thread (v = t % 16, k = t / 16) adds the slots of chunk k in index order (four
+// independent running sums over slot index mod 4, combined in a fixed order: the loads of a chunk are independent, the arithmetic is a
+// function of (nblk) alone), the 16 chunk sums meet in LDS and are added in chunk order.
+__global__ __launch_bounds__(NT) void det_reduce_kernel(const float* __restrict__ slots, int nblk, int rowstride, int col0, int ncols, const Segs segs) {
+    __shared__ float sh[CH][VPB + 1];
+    const int v = threadIdx.x & (VPB - 1), k = threadIdx.x / VPB;
+    const int col = blockIdx.x * VPB + v;                      // relative to col0
+    const int g = blockIdx.y;
+    const int cs = (nblk + CH - 1) / CH;
+    const int b0 = k * cs, b1 = min(nblk, b0 + cs);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (col < ncols) {
+        const float* p = slots + ((size_t)g * nblk + b0) * rowstride + col0 + col;
+        int b = b0;
+        for (; b + 3 < b1; b += 4) {
+            const float x0 = p[0], x1 = p[(size_t)rowstride], x2 = p[2 * (size_t)rowstride], x3 = p[3 * (size_t)rowstride];
+            a0 += x0; a1 += x1; a2 += x2; a3 += x3;
+            p += 4 * (size_t)rowstride;
+        }
+        for (; b < b1; ++b) { a0 += p[0]; p += rowstride; }
+    }
+    sh[k][v] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (k == 0 && col < ncols) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) t += sh[i][v];
+        int c = col;
+#pragma unroll
+        for (int s = 0; s < MG_DET_MAX_SEGS; ++s) {
+            if (s < segs.n) {
+                if (c >= 0 && c < segs.s[s].nv) {
+                    float* d = segs.s[s].dst + (size_t)g * segs.s[s].group_stride + c;
+                    *d += t;
+                }
+                c -= segs.s[s].nv;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int mg_det_reduce(const float* slots, int nblk, int groups, int rowstride, int col0, const mg_det_seg* segs, int nseg, hipStream_t st) {
+    if (nseg < 1 || nseg > MG_DET_MAX_SEGS || nblk < 1 || groups < 1) return -2;
+    Segs sg;
+    sg.n = nseg;
+    int ncols = 0;
+    for (int i = 0; i < nseg; ++i) { sg.s[i] = segs[i]; ncols += segs[i].nv; }
+    for (int i = nseg; i < MG_DET_MAX_SEGS; ++i) sg.s[i] = mg_det_seg{nullptr, 0, 0};
+    if (ncols <= 0) return 0;
+    if (col0 < 0 || col0 + ncols > rowstride) return -2;
+    hipLaunchKernelGGL(det_reduce_kernel, dim3((ncols + VPB - 1) / VPB, groups), dim3(NT), 0, st, slots, nblk, rowstride, col0, ncols, sg);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+/* Test hook: dst[g][c] += sum over the nblk slots, through the kernel above (tests/test_gpu_kernels.py compares it with a host sum in
+ * the same order and with itself across runs). */
+extern "C" int mg_det_reduce_test(const float* slots, int nblk, int groups, int nv, float* dst, void* stream) {
+    mg_det_seg s{dst, nv, (long)nv};
+    return mg_det_reduce(slots, nblk, groups, nv, 0, &s, 1, (hipStream_t)stream);
+}

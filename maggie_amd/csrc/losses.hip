@@ -30,7 +30,8 @@ constexpr int LOSS_REPLICAS = 32, LOSS_STRIDE = 16;
 struct P3 { const float* a[3]; };
 constexpr int LOSS_SUMS = LOSS_REPLICAS * LOSS_STRIDE;
 
-__device__ __forceinline__ void block_add(float v, float* dst, float* sh) {
+// `slot` (deterministic mode, csrc/det.hip): the workgroup's sum is STORED there; mg_det_reduce adds the workgroups in index order
+__device__ __forceinline__ void block_add(float v, float* dst, float* sh, float* slot = nullptr) {
     v = wave_sum(v);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) sh[wave] = v;
@@ -38,7 +39,8 @@ __device__ __forceinline__ void block_add(float v, float* dst, float* sh) {
     if (threadIdx.x == 0) {
         float s = 0.f;
         for (int i = 0; i < NT / 64; ++i) s += sh[i];
-        if (s != 0.f) atomicAdd(dst, s);
+        if (slot) *slot = s;
+        else if (s != 0.f) atomicAdd(dst, s);
     }
     __syncthreads();
 }
@@ -98,10 +100,11 @@ __device__ __forceinline__ float sobel_mag(const float* __restrict__ a, const fl
 // d = p - t ; sums[0] += w|d| ; sums[1] += |sobel(p w) - sobel(t w)| ; sums[2] += w
 __global__ __launch_bounds__(NT) void point_fwd_kernel(const P3 p, const float* __restrict__ t, const P3 w,
                                                        const int* __restrict__ flags, int H, int W, float* __restrict__ d,
-                                                       float* __restrict__ sums, const int* __restrict__ pvalid, int Pper) {
+                                                       float* __restrict__ sums, const int* __restrict__ pvalid, int Pper, float* __restrict__ slots) {
     __shared__ float sh[NT / 64];
     const int pl = blockIdx.y;
-    if (!flags[pl]) return;
+    float* slot = slots ? slots + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 3 : nullptr;     // row [l1, grad, w] of this workgroup
+    if (!flags[pl]) { if (slot && threadIdx.x < 3) slot[threadIdx.x] = 0.f; return; }
     const int sc = pl / Pper, pq = pl - sc * Pper;
     // pvalid (0 / 1 per plane): `pred * valid_masks` of arch/maggie.py:112-118 -- the prediction of a plane without ground-truth transition
     // region counts as zero -- applied on the fly instead of by three multiplies over the (N, 10, H, W) planes (and three in backward)
@@ -121,9 +124,9 @@ __global__ __launch_bounds__(NT) void point_fwd_kernel(const P3 p, const float* 
         s1 += fabsf(mp - mt);
     }
     float* srep = sums + sc * LOSS_SUMS + ((blockIdx.y * gridDim.x + blockIdx.x) & (LOSS_REPLICAS - 1)) * LOSS_STRIDE;   // spread the same-address atomics
-    block_add(s0, &srep[0], sh);
-    block_add(s1, &srep[1], sh);
-    block_add(s2, &srep[2], sh);
+    block_add(s0, &srep[0], sh, slot);
+    block_add(s1, &srep[1], sh, slot ? slot + 1 : nullptr);
+    block_add(s2, &srep[2], sh, slot ? slot + 2 : nullptr);
 }
 
 // out[P, h/2, w/2] = (gauss5 * x)(2y, 2x), reflect padding
@@ -151,10 +154,11 @@ __global__ __launch_bounds__(NT) void pyr_down_kernel(const float* __restrict__ 
 // L = x - 4 * gauss5 * zero_stuff(down);  sums[0] += |L| wl ; sums[1] += wl ; G = wl * sign(L);  wl = w0[(y << lvl), (x << lvl)]
 __global__ __launch_bounds__(NT) void pyr_lap_fwd_kernel(const float* __restrict__ x, const float* __restrict__ down, const P3 w0,
                                                          int lvl, int H0, int W0, const int* __restrict__ flags, int h, int w,
-                                                         float* __restrict__ G, float* __restrict__ sums, int Pper) {
+                                                         float* __restrict__ G, float* __restrict__ sums, int Pper, float* __restrict__ slots) {
     __shared__ float sh[NT / 64];
     const int pl = blockIdx.y;
-    if (!flags[pl]) return;
+    float* slot = slots ? slots + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 : nullptr;     // row [lap, w] of this workgroup
+    if (!flags[pl]) { if (slot && threadIdx.x < 2) slot[threadIdx.x] = 0.f; return; }
     const int sc = pl / Pper;
     const int hd = h >> 1, wd = w >> 1;
     const float* xp = x + (long)pl * h * w;
@@ -203,8 +207,8 @@ __global__ __launch_bounds__(NT) void pyr_lap_fwd_kernel(const float* __restrict
         G[(long)pl * h * w + o] = L > 0.f ? wl : (L < 0.f ? -wl : 0.f);
     }
     float* srep = sums + sc * LOSS_SUMS + ((blockIdx.y * gridDim.x + blockIdx.x) & (LOSS_REPLICAS - 1)) * LOSS_STRIDE;
-    block_add(s0, &srep[0], sh);
-    block_add(s1, &srep[1], sh);
+    block_add(s0, &srep[0], sh, slot);
+    block_add(s1, &srep[1], sh, slot ? slot + 1 : nullptr);
 }
 
 // r[P, h/2, w/2] = add - coef * U^T(q),  U = 4 * gauss5 * zero_stuff (reflect); q: [P, h, w]
@@ -409,6 +413,20 @@ __global__ void loss_coef_kernel(const float* __restrict__ g, const float* __res
 
 }  // namespace
 
+// deterministic mode: the slot rows of a reducing launch ([S][P * blocks per plane][ncol], scale-major like the planes) are added in order into
+// replica 0 of each scale's accumulators, columns [col, col + ncol)
+static int loss_slots(dim3 g, int ncol, float** slots) {
+    *slots = nullptr;
+    if (!mg_det_on) return 0;
+    *slots = mg_det_scratch((long)g.x * g.y * ncol);
+    return *slots ? 0 : MG_DET_NO_SCRATCH;
+}
+static int loss_slot_reduce(const float* slots, dim3 g, int S, int ncol, float* sums, int col, hipStream_t st) {
+    if (!slots) return 0;
+    mg_det_seg sg{sums + col, ncol, (long)LOSS_SUMS};
+    return mg_det_reduce(slots, (int)(g.x * (g.y / S)), S, ncol, 0, &sg, 1, st);
+}
+
 extern "C" int mg_loss_finish(const float* sums, float* out3, void* stream) {
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, out3);
     MG_CHECK_LAUNCH();
@@ -452,9 +470,11 @@ extern "C" int mg_os8_weight_ex(const float* gt, const float* a8, int P, long HW
 extern "C" int mg_loss_point_fwd(const float* p, const float* t, const float* w, const int32_t* flags, int P, int H, int W, float* d,
                                  float* sums, const int32_t* pvalid, void* stream) {
     if (P <= 0) return 0;
-    hipLaunchKernelGGL(point_fwd_kernel, grid2((long)H * W, P, REDUCING_BLOCKS_PER_PLANE), dim3(NT), 0, (hipStream_t)stream, P3{{p, nullptr, nullptr}}, t, P3{{w, nullptr, nullptr}}, flags, H, W, d, sums, pvalid, P);
+    const dim3 g = grid2((long)H * W, P, REDUCING_BLOCKS_PER_PLANE);
+    float* slots; int rc = loss_slots(g, 3, &slots); if (rc) return rc;
+    hipLaunchKernelGGL(point_fwd_kernel, g, dim3(NT), 0, (hipStream_t)stream, P3{{p, nullptr, nullptr}}, t, P3{{w, nullptr, nullptr}}, flags, H, W, d, sums, pvalid, P, slots);
     MG_CHECK_LAUNCH();
-    return 0;
+    return loss_slot_reduce(slots, g, 1, 3, sums, 0, (hipStream_t)stream);
 }
 
 extern "C" int mg_pyr_down(const float* x, const int32_t* flags, int P, int h, int w, float* out, void* stream) {
@@ -468,9 +488,11 @@ extern "C" int mg_pyr_down(const float* x, const int32_t* flags, int P, int h, i
 extern "C" int mg_pyr_lap_fwd(const float* x, const float* down, const float* w0, int lvl, int H0, int W0, const int32_t* flags, int P, int h,
                               int w, float* G, float* sums, void* stream) {
     if (P <= 0) return 0;
-    hipLaunchKernelGGL(pyr_lap_fwd_kernel, grid2((long)h * w, P, REDUCING_BLOCKS_PER_PLANE), dim3(NT), 0, (hipStream_t)stream, x, down, P3{{w0, nullptr, nullptr}}, lvl, H0, W0, flags, h, w, G, sums, P);
+    const dim3 g = grid2((long)h * w, P, REDUCING_BLOCKS_PER_PLANE);
+    float* slots; int rc = loss_slots(g, 2, &slots); if (rc) return rc;
+    hipLaunchKernelGGL(pyr_lap_fwd_kernel, g, dim3(NT), 0, (hipStream_t)stream, x, down, P3{{w0, nullptr, nullptr}}, lvl, H0, W0, flags, h, w, G, sums, P, slots);
     MG_CHECK_LAUNCH();
-    return 0;
+    return loss_slot_reduce(slots, g, 1, 2, sums, 0, (hipStream_t)stream);
 }
 
 extern "C" int mg_pyr_upT(const float* q, const float* coef, const float* add, const int32_t* flags, int P, int h, int w, float* r, void* stream) {
@@ -512,13 +534,21 @@ extern "C" int mg_matting_losses_fwd(const float* const* p, const float* t, cons
     hipError_t e = mg_zero_words(flags, (long)SP, st); if (e != hipSuccess) return (int)e;
     e = mg_zero_words(sums, (long)S * LOSS_SUMS, st); if (e != hipSuccess) return (int)e;
     { dim3 g = grid2((long)H * W, SP); if (g.x > 64) g.x = 64; hipLaunchKernelGGL(plane_flags3_kernel, g, dim3(NT), 0, st, ww, P, H * W, flags); }
-    hipLaunchKernelGGL(point_fwd_kernel, grid2((long)H * W, SP, REDUCING_BLOCKS_PER_PLANE), dim3(NT), 0, st, pp, t, ww, flags, H, W, d, sums, pvalid, P);
+    {
+        const dim3 g = grid2((long)H * W, SP, REDUCING_BLOCKS_PER_PLANE);
+        float* slots; int rc = loss_slots(g, 3, &slots); if (rc) return rc;
+        hipLaunchKernelGGL(point_fwd_kernel, g, dim3(NT), 0, st, pp, t, ww, flags, H, W, d, sums, pvalid, P, slots);
+        rc = loss_slot_reduce(slots, g, S, 3, sums, 0, st); if (rc) return rc;
+    }
     const float* x = d; float* downs[3] = {down0, down1, down2}; float* Gs[3] = {G0, G1, G2};
     int h = H, wd = W;
     for (int lvl = 0; lvl < 3; ++lvl) {
         hipLaunchKernelGGL(pyr_down_kernel, grid2((long)(h / 2) * (wd / 2), SP), dim3(NT), 0, st, x, flags, h, wd, downs[lvl]);
-        hipLaunchKernelGGL(pyr_lap_fwd_kernel, grid2((long)h * wd, SP, REDUCING_BLOCKS_PER_PLANE), dim3(NT), 0, st, x, (const float*)downs[lvl], ww, lvl, H, W,
-                           flags, h, wd, Gs[lvl], sums + 3 + 2 * lvl, P);
+        const dim3 g = grid2((long)h * wd, SP, REDUCING_BLOCKS_PER_PLANE);
+        float* slots; int rc = loss_slots(g, 2, &slots); if (rc) return rc;
+        hipLaunchKernelGGL(pyr_lap_fwd_kernel, g, dim3(NT), 0, st, x, (const float*)downs[lvl], ww, lvl, H, W,
+                           flags, h, wd, Gs[lvl], sums + 3 + 2 * lvl, P, slots);
+        rc = loss_slot_reduce(slots, g, S, 2, sums, 3 + 2 * lvl, st); if (rc) return rc;
         x = downs[lvl]; h >>= 1; wd >>= 1;
     }
     hipLaunchKernelGGL(loss_finish_kernel, dim3(S), dim3(64), 0, st, (const float*)sums, out);

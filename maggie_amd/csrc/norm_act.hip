@@ -34,9 +34,12 @@ static inline ColGeom col_geom(int M, int C, int ce, int max_rb, int nt = NT, in
     return g;
 }
 
+// `slot` (deterministic mode, csrc/det.hip): this workgroup's row [NACC][C] of the slot buffer -- the partial is STORED there (every row
+// block owns its row; mg_det_reduce adds the rows in index order) instead of being added to dst0 / dst1 atomically.
 template <int NV>
 __device__ __forceinline__ void col_block_reduce(float* sred, const float* part, int tx, int ty, int ix, int iy, bool active,
-                                                 float* __restrict__ dst0, float* __restrict__ dst1, int c_base, int C, int ce) {
+                                                 float* __restrict__ dst0, float* __restrict__ dst1, int c_base, int C, int ce,
+                                                 float* __restrict__ slot = nullptr) {
     // sred: [ty][tx*NV]; part: this thread's NV values (NV = ce * NACC, channel-major: [acc][e])
     const int width = tx * NV;
     if (active) {
@@ -49,7 +52,10 @@ __device__ __forceinline__ void col_block_reduce(float* sred, const float* part,
         for (int r = 0; r < ty; ++r) acc += sred[r * width + j];
         const int cx = j / NV, k = j - cx * NV, a = k / ce, e = k - a * ce;
         const int c = c_base + cx * ce + e;
-        if (c < C) atomicAdd((a == 0 ? dst0 : dst1) + c, acc);
+        if (c < C) {
+            if (slot) slot[a * C + c] = acc;
+            else atomicAdd((a == 0 ? dst0 : dst1) + c, acc);
+        }
     }
 }
 
@@ -57,7 +63,8 @@ __device__ __forceinline__ void col_block_reduce(float* sred, const float* part,
 // channel chunk), so LDS holds one row per WAVE instead of one per thread row (64 KB -> 8 KB at 1024 threads)
 template <int NV>
 __device__ __forceinline__ void col_block_reduce_wave(float* sred, float* part, int tx, int ix, bool active,
-                                                      float* __restrict__ dst0, float* __restrict__ dst1, int c_base, int C, int ce) {
+                                                      float* __restrict__ dst0, float* __restrict__ dst1, int c_base, int C, int ce,
+                                                      float* __restrict__ slot = nullptr) {
     const int width = tx * NV;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)blockDim.x >> 6;
     for (int off = tx; off < 64; off <<= 1) {
@@ -75,7 +82,8 @@ __device__ __forceinline__ void col_block_reduce_wave(float* sred, float* part, 
         if (c < C) {
             float acc = 0.f;
             for (int r = 0; r < nw; ++r) acc += sred[r * width + j];
-            atomicAdd((a == 0 ? dst0 : dst1) + c, acc);
+            if (slot) slot[a * C + c] = acc;
+            else atomicAdd((a == 0 ? dst0 : dst1) + c, acc);
         }
     }
 }
@@ -83,7 +91,8 @@ __device__ __forceinline__ void col_block_reduce_wave(float* sred, float* part, 
 // column statistics: stats[c] += sum_m x[m,c]; stats[C+c] += sum_m x[m,c]^2
 template <typename T>
 __global__ __launch_bounds__(NT) void colstats_kernel(const T* __restrict__ x, int M, int C, int ld, float* __restrict__ stats,
-                                                      int rows_per_block, int nrep, int only_sum, int tx, int ty, const int32_t* __restrict__ m_dev) {
+                                                      int rows_per_block, int nrep, int only_sum, int tx, int ty, const int32_t* __restrict__ m_dev,
+                                                      float* __restrict__ slots) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
     extern __shared__ float sred[];
@@ -112,16 +121,18 @@ __global__ __launch_bounds__(NT) void colstats_kernel(const T* __restrict__ x, i
             for (int e = 0; e < CE; ++e) { part[e] += f0[e]; part[CE + e] += f0[e] * f0[e]; }
         }
     }
+    // nrep >= gridDim.x (deterministic mode: MG_DET_STAT_ROWS rows): every row block adds to its OWN row -- one addition per word, no order
     float* st = stats + (size_t)(blockIdx.x & (nrep - 1)) * 2 * C;
-    if (only_sum) col_block_reduce<CE>(sred, part, tx, ty, ix, iy, active, st, st, blockIdx.y * tx * CE, C, CE);
-    else col_block_reduce<2 * CE>(sred, part, tx, ty, ix, iy, active, st, st + C, blockIdx.y * tx * CE, C, CE);
+    if (only_sum) col_block_reduce<CE>(sred, part, tx, ty, ix, iy, active, st, st, blockIdx.y * tx * CE, C, CE, slots ? slots + (size_t)blockIdx.x * C : nullptr);
+    else col_block_reduce<2 * CE>(sred, part, tx, ty, ix, iy, active, st, st + C, blockIdx.y * tx * CE, C, CE, slots ? slots + (size_t)blockIdx.x * 2 * C : nullptr);
 }
 
 // backward of "+ bias, ReLU" epilogues (sparse convs / linears without a BatchNorm behind them): g = dy * (y > 0) and
 // db[c] = sum_m g[m,c] in one pass (the torch formulation was compare + cast + multiply + cast + sum: 5 launches)
 template <typename T>
 __global__ __launch_bounds__(NT) void bias_act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ g, int M, int C,
-                                                          float* __restrict__ db, int rows_per_block, int tx, int ty, const int32_t* __restrict__ m_dev) {
+                                                          float* __restrict__ db, int rows_per_block, int tx, int ty, const int32_t* __restrict__ m_dev,
+                                                          float* __restrict__ slots) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
     extern __shared__ float sred[];
@@ -149,13 +160,14 @@ __global__ __launch_bounds__(NT) void bias_act_bwd_kernel(const T* __restrict__ 
             for (int e = 0; e < CE; ++e) part[e] += f[e];
         }
     }
-    if (db) col_block_reduce<CE>(sred, part, tx, ty, ix, iy, active, db, db, blockIdx.y * tx * CE, C, CE);
+    if (db) col_block_reduce<CE>(sred, part, tx, ty, ix, iy, active, db, db, blockIdx.y * tx * CE, C, CE, slots ? slots + (size_t)blockIdx.x * C : nullptr);
 }
 
 // second pass of the exact two-pass variance: stats[C+c] += sum_m (x[m,c] - stats[c]/M)^2   (stats[0:C] = column sums)
 template <typename T>
 __global__ __launch_bounds__(NT) void colstats_centered_kernel(const T* __restrict__ x, int M, int C, int ld, float* __restrict__ stats,
-                                                               int rows_per_block, int tx, int ty, const int32_t* __restrict__ m_dev) {
+                                                               int rows_per_block, int tx, int ty, const int32_t* __restrict__ m_dev,
+                                                               float* __restrict__ slots) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
     extern __shared__ float sred[];
@@ -185,7 +197,7 @@ __global__ __launch_bounds__(NT) void colstats_centered_kernel(const T* __restri
             for (int e = 0; e < CE; ++e) { float d0 = f0[e] - mu[e]; part[e] += d0 * d0; }
         }
     }
-    col_block_reduce<CE>(sred, part, tx, ty, ix, iy, active, stats + C, stats + C, blockIdx.y * tx * CE, C, CE);
+    col_block_reduce<CE>(sred, part, tx, ty, ix, iy, active, stats + C, stats + C, blockIdx.y * tx * CE, C, CE, slots ? slots + (size_t)blockIdx.x * C : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -206,6 +218,57 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int nrep, co
     }
     float s1 = 0.f, s2 = 0.f;
     for (int r = 0; r < nrep; ++r) { s1 += stats[(size_t)r * 2 * C + c]; s2 += stats[(size_t)r * 2 * C + C + c]; }
+    float mean = s1 / n;
+    float var = centered ? s2 / n : s2 / n - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    float invstd = rsqrtf(var + eps);
+    float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    scale[c] = g * invstd;
+    shift[c] = b - mean * g * invstd;
+    mean_out[c] = mean;
+    invstd_out[c] = invstd;
+    if (running_mean) {
+        float unbiased = n > 1.f ? var * n / (n - 1.f) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
+// The same for MANY rows (deterministic mode: one row per row block / per output tile of the producing conv, up to tens of thousands): one
+// workgroup per channel, thread t adds rows t, t + 256, ... in that order, the 256 partial sums meet in a fixed tree. The result depends on
+// (nrep) only -- never on which workgroup of the producer finished first.
+__global__ __launch_bounds__(NT) void bn_finalize_rows_kernel(const float* __restrict__ stats, int nrep, const float* __restrict__ count_ptr, float count, int C,
+                                                             int centered, const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+                                                             float* running_var, float momentum, float eps, float* __restrict__ scale,
+                                                             float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ invstd_out,
+                                                             const int32_t* __restrict__ m_dev) {
+    __shared__ float sh[2][NT];
+    const int c = blockIdx.x, t = threadIdx.x;
+    float n = count_ptr ? *count_ptr : count;
+    if (m_dev) n = (float)dev_rows(m_dev, (int)count);
+    if ((m_dev || count_ptr) && n <= 0.f) {
+        if (t == 0) { scale[c] = gamma ? gamma[c] : 1.f; shift[c] = beta ? beta[c] : 0.f; mean_out[c] = 0.f; invstd_out[c] = 1.f; }
+        return;
+    }
+    float a1 = 0.f, a2 = 0.f;
+    int r = t;
+    for (; r + 3 * NT < nrep; r += 4 * NT) {                  // four independent loads per column in flight, added in row order
+        const float x0 = stats[(size_t)r * 2 * C + c], x1 = stats[(size_t)(r + NT) * 2 * C + c];
+        const float x2 = stats[(size_t)(r + 2 * NT) * 2 * C + c], x3 = stats[(size_t)(r + 3 * NT) * 2 * C + c];
+        const float y0 = stats[(size_t)r * 2 * C + C + c], y1 = stats[(size_t)(r + NT) * 2 * C + C + c];
+        const float y2 = stats[(size_t)(r + 2 * NT) * 2 * C + C + c], y3 = stats[(size_t)(r + 3 * NT) * 2 * C + C + c];
+        a1 += x0; a1 += x1; a1 += x2; a1 += x3;
+        a2 += y0; a2 += y1; a2 += y2; a2 += y3;
+    }
+    for (; r < nrep; r += NT) { a1 += stats[(size_t)r * 2 * C + c]; a2 += stats[(size_t)r * 2 * C + C + c]; }
+    sh[0][t] = a1; sh[1][t] = a2;
+    __syncthreads();
+    for (int o = NT / 2; o > 0; o >>= 1) {
+        if (t < o) { sh[0][t] += sh[0][t + o]; sh[1][t] += sh[1][t + o]; }
+        __syncthreads();
+    }
+    if (t != 0) return;
+    const float s1 = sh[0][0], s2 = sh[1][0];
     float mean = s1 / n;
     float var = centered ? s2 / n : s2 / n - mean * mean;
     var = var > 0.f ? var : 0.f;
@@ -471,7 +534,7 @@ __device__ __forceinline__ void load_g(const mg_rowwise_params& p, int m, int c0
 }
 
 template <typename T, int BT = NT>
-__global__ __launch_bounds__(BT) void bn_bwd_reduce_kernel(const mg_rowwise_params p, int rows_per_block, int tx, int ty) {
+__global__ __launch_bounds__(BT) void bn_bwd_reduce_kernel(const mg_rowwise_params p, int rows_per_block, int tx, int ty, float* __restrict__ slots) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
     extern __shared__ float sred[];
@@ -511,8 +574,9 @@ __global__ __launch_bounds__(BT) void bn_bwd_reduce_kernel(const mg_rowwise_para
             for (int e = 0; e < CE; ++e) { part[e] += g0[e]; part[CE + e] += g0[e] * (x0[e] - mu[e]) * is[e]; }
         }
     }
-    if (BT > NT) col_block_reduce_wave<2 * CE>(sred, part, tx, ix, active, p.sums, p.sums + C, blockIdx.y * tx * CE, C, CE);
-    else col_block_reduce<2 * CE>(sred, part, tx, ty, ix, iy, active, p.sums, p.sums + C, blockIdx.y * tx * CE, C, CE);
+    float* slot = slots ? slots + (size_t)blockIdx.x * 2 * C : nullptr;
+    if (BT > NT) col_block_reduce_wave<2 * CE>(sred, part, tx, ix, active, p.sums, p.sums + C, blockIdx.y * tx * CE, C, CE, slot);
+    else col_block_reduce<2 * CE>(sred, part, tx, ty, ix, iy, active, p.sums, p.sums + C, blockIdx.y * tx * CE, C, CE, slot);
 }
 
 template <typename T>
@@ -666,9 +730,12 @@ extern "C" int mg_colstats_dev(const void* x, int dtype, int M, int C, int ld, f
     const ColGeom g = col_geom(M, C, ce, 1024);
     const size_t lds = (size_t)g.ty * g.tx * 2 * ce * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MG_BF16) hipLaunchKernelGGL(colstats_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const bf16raw*)x, M, C, ld, stats, g.rpb, MG_STAT_REPLICAS, 0, g.tx, g.ty, m_dev);
-    else if (dtype == MG_F16) hipLaunchKernelGGL(colstats_kernel<f16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const f16raw*)x, M, C, ld, stats, g.rpb, MG_STAT_REPLICAS, 0, g.tx, g.ty, m_dev);
-    else hipLaunchKernelGGL(colstats_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const float*)x, M, C, ld, stats, g.rpb, MG_STAT_REPLICAS, 0, g.tx, g.ty, m_dev);
+    // deterministic mode: MG_DET_STAT_ROWS (1024 >= the row-block count) rows, i.e. one row per row block -- a word receives ONE addition, the
+    // finalize kernel adds the rows in index order
+    const int nrep = mg_det_on ? MG_DET_STAT_ROWS : MG_STAT_REPLICAS;
+    if (dtype == MG_BF16) hipLaunchKernelGGL(colstats_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const bf16raw*)x, M, C, ld, stats, g.rpb, nrep, 0, g.tx, g.ty, m_dev, nullptr);
+    else if (dtype == MG_F16) hipLaunchKernelGGL(colstats_kernel<f16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const f16raw*)x, M, C, ld, stats, g.rpb, nrep, 0, g.tx, g.ty, m_dev, nullptr);
+    else hipLaunchKernelGGL(colstats_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const float*)x, M, C, ld, stats, g.rpb, nrep, 0, g.tx, g.ty, m_dev, nullptr);
     MG_CHECK_LAUNCH();
     return 0;
 }
@@ -690,10 +757,13 @@ extern "C" int mg_bias_act_bwd_dev(const void* dy, const void* y, void* g, int d
     if (y && !g) return -3;
     const ColGeom gm = col_geom(M, C, ce, 512);          // like MG_BN_RB: enough blocks to stream at HBM rate, few enough atomics per channel
     const size_t lds = (size_t)gm.ty * gm.tx * ce * sizeof(float);
-    if (dtype == MG_BF16) hipLaunchKernelGGL(bias_act_bwd_kernel<bf16raw>, dim3(gm.rb, gm.groups), dim3(NT), lds, st, (const bf16raw*)dy, (const bf16raw*)y, (bf16raw*)g, M, C, db, gm.rpb, gm.tx, gm.ty, m_dev);
-    else if (dtype == MG_F16) hipLaunchKernelGGL(bias_act_bwd_kernel<f16raw>, dim3(gm.rb, gm.groups), dim3(NT), lds, st, (const f16raw*)dy, (const f16raw*)y, (f16raw*)g, M, C, db, gm.rpb, gm.tx, gm.ty, m_dev);
-    else hipLaunchKernelGGL(bias_act_bwd_kernel<float>, dim3(gm.rb, gm.groups), dim3(NT), lds, st, (const float*)dy, (const float*)y, (float*)g, M, C, db, gm.rpb, gm.tx, gm.ty, m_dev);
+    float* slots = nullptr;
+    if (db && mg_det_on && gm.rb > 1) { slots = mg_det_scratch((long)gm.rb * C); if (!slots) return MG_DET_NO_SCRATCH; }
+    if (dtype == MG_BF16) hipLaunchKernelGGL(bias_act_bwd_kernel<bf16raw>, dim3(gm.rb, gm.groups), dim3(NT), lds, st, (const bf16raw*)dy, (const bf16raw*)y, (bf16raw*)g, M, C, db, gm.rpb, gm.tx, gm.ty, m_dev, slots);
+    else if (dtype == MG_F16) hipLaunchKernelGGL(bias_act_bwd_kernel<f16raw>, dim3(gm.rb, gm.groups), dim3(NT), lds, st, (const f16raw*)dy, (const f16raw*)y, (f16raw*)g, M, C, db, gm.rpb, gm.tx, gm.ty, m_dev, slots);
+    else hipLaunchKernelGGL(bias_act_bwd_kernel<float>, dim3(gm.rb, gm.groups), dim3(NT), lds, st, (const float*)dy, (const float*)y, (float*)g, M, C, db, gm.rpb, gm.tx, gm.ty, m_dev, slots);
     MG_CHECK_LAUNCH();
+    if (slots) return mg_det_reduce1(slots, gm.rb, db, C, st);
     return 0;
 }
 
@@ -709,17 +779,23 @@ extern "C" int mg_colstats_centered_dev(const void* x, int dtype, int M, int C, 
     const size_t lds = (size_t)g.ty * g.tx * 2 * ce * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     // `stats` must arrive zeroed (the caller hands out slices of a per-step zero arena): pass 1 adds the column sums only
-    // (skipped when the producing conv's epilogue already did: have_sum), pass 2 the centred second moments
-    if (dtype == MG_BF16) {
-        if (!have_sum) hipLaunchKernelGGL(colstats_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const bf16raw*)x, M, C, ld, stats, g.rpb, 1, 1, g.tx, g.ty, m_dev);
-        hipLaunchKernelGGL(colstats_centered_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const bf16raw*)x, M, C, ld, stats, g.rpb, g.tx, g.ty, m_dev);
-    } else if (dtype == MG_F16) {
-        if (!have_sum) hipLaunchKernelGGL(colstats_kernel<f16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const f16raw*)x, M, C, ld, stats, g.rpb, 1, 1, g.tx, g.ty, m_dev);
-        hipLaunchKernelGGL(colstats_centered_kernel<f16raw>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const f16raw*)x, M, C, ld, stats, g.rpb, g.tx, g.ty, m_dev);
-    } else {
-        if (!have_sum) hipLaunchKernelGGL(colstats_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const float*)x, M, C, ld, stats, g.rpb, 1, 1, g.tx, g.ty, m_dev);
-        hipLaunchKernelGGL(colstats_centered_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const float*)x, M, C, ld, stats, g.rpb, g.tx, g.ty, m_dev);
-    }
+    // (skipped when the producing conv's epilogue already did: have_sum), pass 2 the centred second moments.
+    // Deterministic mode: each pass stores one partial row per row block, mg_det_reduce adds them in order (two more small launches).
+    float* slots = nullptr;
+    if (mg_det_on && g.rb > 1) { slots = mg_det_scratch((long)g.rb * C); if (!slots) return MG_DET_NO_SCRATCH; }
+#define MG_CENTERED_CASE(T)                                                                                                                              \
+    do {                                                                                                                                                 \
+        if (!have_sum) {                                                                                                                                 \
+            hipLaunchKernelGGL(colstats_kernel<T>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const T*)x, M, C, ld, stats, g.rpb, 1, 1, g.tx, g.ty, m_dev, slots); \
+            if (slots) { int rc_ = mg_det_reduce1(slots, g.rb, stats, C, st); if (rc_) return rc_; }                                                    \
+        }                                                                                                                                                \
+        hipLaunchKernelGGL(colstats_centered_kernel<T>, dim3(g.rb, g.groups), dim3(NT), lds, st, (const T*)x, M, C, ld, stats, g.rpb, g.tx, g.ty, m_dev, slots); \
+        if (slots) { int rc_ = mg_det_reduce1(slots, g.rb, stats + C, C, st); if (rc_) return rc_; }                                                    \
+    } while (0)
+    if (dtype == MG_BF16) MG_CENTERED_CASE(bf16raw);
+    else if (dtype == MG_F16) MG_CENTERED_CASE(f16raw);
+    else MG_CENTERED_CASE(float);
+#undef MG_CENTERED_CASE
     MG_CHECK_LAUNCH();
     return 0;
 }
@@ -727,8 +803,12 @@ extern "C" int mg_colstats_centered_dev(const void* x, int dtype, int M, int C, 
 static int bn_finalize_launch(const float* stats, int nrep, const float* count_ptr, float count, int C, int centered, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
                               float* mean_out, float* invstd_out, const int32_t* m_dev, void* stream) {
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, nrep, count_ptr, count, C, centered, gamma,
-                       beta, running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out, m_dev);
+    if (nrep > MG_STAT_REPLICAS)
+        hipLaunchKernelGGL(bn_finalize_rows_kernel, dim3(C), dim3(NT), 0, (hipStream_t)stream, stats, nrep, count_ptr, count, C, centered, gamma,
+                           beta, running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out, m_dev);
+    else
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, nrep, count_ptr, count, C, centered, gamma,
+                           beta, running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out, m_dev);
     MG_CHECK_LAUNCH();
     return 0;
 }
@@ -783,14 +863,18 @@ extern "C" int mg_bn_bwd_reduce(const mg_rowwise_params* p, void* stream) {
     const bool wide = wide_on && !p->m_dev && max_rb == 256 && g.rpb >= 256 && (g.tx & (g.tx - 1)) == 0;      // (the >= 16 M element layers: 25 -> 36 us)
     if (wide) g = col_geom(p->M, p->C, ce, max_rb, 1024, 2);
     const size_t lds = wide ? (size_t)16 * g.tx * 2 * ce * sizeof(float) : (size_t)g.ty * g.tx * 2 * ce * sizeof(float);
+    // deterministic mode: one partial row [2C] per row block in the slot scratch, added in row-block order by mg_det_reduce into p->sums
+    float* slots = nullptr;
+    if (mg_det_on && g.rb > 1) { slots = mg_det_scratch((long)g.rb * 2 * p->C); if (!slots) return MG_DET_NO_SCRATCH; }
     if (wide) {
-        if (p->dtype == MG_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16raw, 1024>), dim3(g.rb, g.groups), dim3(1024), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty);
-        else if (p->dtype == MG_F16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<f16raw, 1024>), dim3(g.rb, g.groups), dim3(1024), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty);
-        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 1024>), dim3(g.rb, g.groups), dim3(1024), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty);
-    } else if (p->dtype == MG_BF16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty);
-    else if (p->dtype == MG_F16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<f16raw>, dim3(g.rb, g.groups), dim3(NT), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty);
-    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty);
+        if (p->dtype == MG_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16raw, 1024>), dim3(g.rb, g.groups), dim3(1024), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty, slots);
+        else if (p->dtype == MG_F16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<f16raw, 1024>), dim3(g.rb, g.groups), dim3(1024), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty, slots);
+        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 1024>), dim3(g.rb, g.groups), dim3(1024), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty, slots);
+    } else if (p->dtype == MG_BF16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty, slots);
+    else if (p->dtype == MG_F16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<f16raw>, dim3(g.rb, g.groups), dim3(NT), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty, slots);
+    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty, slots);
     MG_CHECK_LAUNCH();
+    if (slots) return mg_det_reduce1(slots, g.rb, p->sums, 2 * p->C, (hipStream_t)stream);
     return 0;
 }
 
@@ -1069,6 +1153,23 @@ extern "C" int mg_bn_train_fwd(const mg_rowwise_params* p_in, float* stats_ws, i
                                    : bn_small_fwd_launch<float>(p, gamma, beta, running_mean, running_var, momentum, eps, outs, st);
     const float* stats = stats_in;
     int nrep = stats_in_rows, centered = 0;
+    if (mg_det_on) {
+        // deterministic mode: one-pass statistics with one row per row block / conv output tile (`own`: [MG_DET_STAT_ROWS][2C]), added in row
+        // order by bn_finalize_rows_kernel. The two-pass variance needs the column sums BEFORE its second pass, i.e. a cross-workgroup sum in the
+        // middle of the layer: it stays with the <= 1024-row layers, which run it inside one workgroup (bn_small, above).
+        if (!stats) {
+            if (!own) return -3;
+            if (!ws_zeroed) { hipError_t e = mg_zero_words(own, (long)MG_DET_STAT_ROWS * 2 * C, st); if (e != hipSuccess) return (int)e; }
+            if (p.M > 0) { rc = mg_colstats_dev(p.x, p.dtype, p.M, C, p.ldx, own, p.m_dev, stream); if (rc) return rc; }
+            stats = own; nrep = MG_DET_STAT_ROWS;
+        } else if (exact && stats_in_rows == 1) return -3;       // a sums-only row of a conv epilogue is not reproducible: callers hand over row sets
+        p.count = (float)p.M;
+        rc = bn_finalize_launch(stats, nrep, nullptr, (float)p.M, C, 0, gamma, beta, running_mean, running_var, momentum, eps, outs, outs + C, outs + 2 * C,
+                                outs + 3 * C, p.m_dev, stream);
+        if (rc) return rc;
+        p.scale = outs; p.shift = outs + C;
+        return mg_affine_act(&p, stream);
+    }
     if (p.m_dev) {
         // sparse head: the row count is a device word -> always the exact two-pass variance over min(*m_dev, M) rows (no host knowledge of
         // the count is needed to choose a path), statistics in `own` [2C]

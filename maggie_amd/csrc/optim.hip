@@ -9,8 +9,9 @@
 
 namespace {
 
-// sumsq[0] += sum g^2 (fp32 partials per thread, fp64 atomics)
-__global__ __launch_bounds__(256) void sumsq_kernel(const float4* __restrict__ g, long n4, double* __restrict__ out) {
+// sumsq[0] += sum g^2 (fp32 partials per thread, fp64 atomics). Deterministic mode (`part` != NULL): one fp64 partial per workgroup, added
+// in workgroup order by sumsq_finish_kernel -- the clip coefficient, and with it every parameter, is then bit-reproducible.
+__global__ __launch_bounds__(256) void sumsq_kernel(const float4* __restrict__ g, long n4, double* __restrict__ out, double* __restrict__ part) {
     float acc = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const float4 v = g[i];
@@ -22,7 +23,22 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float4* __restrict__ g
     __shared__ double sh[4];
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = d;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, sh[0] + sh[1] + sh[2] + sh[3]);
+    if (threadIdx.x == 0) {
+        const double v = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        if (part) part[blockIdx.x] = v; else atomicAdd(out, v);
+    }
+}
+__global__ __launch_bounds__(256) void sumsq_finish_kernel(const double* __restrict__ part, int n, double* __restrict__ out) {
+    __shared__ double sh[256];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) a += part[i];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out += sh[0];
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m, float4* __restrict__ v,
@@ -64,7 +80,11 @@ extern "C" int mg_adamw_flat(float* p, const float* g, float* m, float* v, long 
     if (sumsq_scratch && (phases & 1)) {
         hipError_t e = mg_zero_words(sumsq_scratch, 2, st);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks)), dim3(256), 0, st, (const float4*)g, n4, sumsq_scratch);
+        const unsigned nb = (unsigned)(blocks > 1024 ? 1024 : blocks);
+        double* part = nullptr;
+        if (mg_det_on && nb > 1) { part = (double*)mg_det_scratch(2l * nb); if (!part) return MG_DET_NO_SCRATCH; }
+        hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, st, (const float4*)g, n4, sumsq_scratch, part);
+        if (part) hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, st, (const double*)part, (int)nb, sumsq_scratch);
     }
     if (phases & 2)
         hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (float4*)p, (const float4*)g, (float4*)m, (float4*)v, n4, lr, beta1,

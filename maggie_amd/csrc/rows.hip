@@ -162,7 +162,7 @@ template <typename T>
 __global__ __launch_bounds__(NT) void add_layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ r,
                                                                const float* __restrict__ gamma, const float* __restrict__ rstat, T* __restrict__ dz,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C,
-                                                               const int32_t* __restrict__ m_dev) {
+                                                               const int32_t* __restrict__ m_dev, float* __restrict__ slots) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
     __shared__ float sred[NT * 2 * 8];
@@ -212,7 +212,8 @@ __global__ __launch_bounds__(NT) void add_layernorm_bwd_kernel(const T* __restri
         float a = 0.f;
         for (int rr = 0; rr < rows_per_block; ++rr) a += sred[rr * lpr * 2 * CE + j];
         const int lc = j / (2 * CE), k = j - lc * 2 * CE;
-        if (k < CE) atomicAdd(&dgamma[lc * CE + k], a); else atomicAdd(&dbeta[lc * CE + k - CE], a);
+        if (slots) slots[(size_t)blockIdx.x * 2 * C + (k < CE ? lc * CE + k : C + lc * CE + k - CE)] = a;    // deterministic mode: one row [dgamma | dbeta] per workgroup
+        else if (k < CE) atomicAdd(&dgamma[lc * CE + k], a); else atomicAdd(&dbeta[lc * CE + k - CE], a);
     }
 }
 
@@ -319,10 +320,16 @@ extern "C" int mg_rows_add_layernorm_bwd(const void* dy, const void* x, const vo
     if (M <= 0) return 0;
     const int lpr = C / (MG_IS16(dtype) ? 8 : 4), rpb = NT / lpr;
     long blocks = ((long)M + rpb - 1) / rpb; if (blocks > 512) blocks = 512;
-    if (dtype == MG_BF16) hipLaunchKernelGGL(add_layernorm_bwd_kernel<bf16raw>, dim3((unsigned)blocks), dim3(NT), 0, st, (const bf16raw*)dy, (const bf16raw*)x, (const bf16raw*)r, gamma, rstat, (bf16raw*)dz, dgamma, dbeta, M, C, m_dev);
-    else if (dtype == MG_F16) hipLaunchKernelGGL(add_layernorm_bwd_kernel<f16raw>, dim3((unsigned)blocks), dim3(NT), 0, st, (const f16raw*)dy, (const f16raw*)x, (const f16raw*)r, gamma, rstat, (f16raw*)dz, dgamma, dbeta, M, C, m_dev);
-    else hipLaunchKernelGGL(add_layernorm_bwd_kernel<float>, dim3((unsigned)blocks), dim3(NT), 0, st, (const float*)dy, (const float*)x, (const float*)r, gamma, rstat, (float*)dz, dgamma, dbeta, M, C, m_dev);
+    float* slots = nullptr;
+    if (mg_det_on) { slots = mg_det_scratch(blocks * 2 * C); if (!slots) return MG_DET_NO_SCRATCH; }
+    if (dtype == MG_BF16) hipLaunchKernelGGL(add_layernorm_bwd_kernel<bf16raw>, dim3((unsigned)blocks), dim3(NT), 0, st, (const bf16raw*)dy, (const bf16raw*)x, (const bf16raw*)r, gamma, rstat, (bf16raw*)dz, dgamma, dbeta, M, C, m_dev, slots);
+    else if (dtype == MG_F16) hipLaunchKernelGGL(add_layernorm_bwd_kernel<f16raw>, dim3((unsigned)blocks), dim3(NT), 0, st, (const f16raw*)dy, (const f16raw*)x, (const f16raw*)r, gamma, rstat, (f16raw*)dz, dgamma, dbeta, M, C, m_dev, slots);
+    else hipLaunchKernelGGL(add_layernorm_bwd_kernel<float>, dim3((unsigned)blocks), dim3(NT), 0, st, (const float*)dy, (const float*)x, (const float*)r, gamma, rstat, (float*)dz, dgamma, dbeta, M, C, m_dev, slots);
     MG_CHECK_LAUNCH();
+    if (slots) {
+        mg_det_seg sg[2] = {{dgamma, C, 0}, {dbeta, C, 0}};
+        return mg_det_reduce(slots, (int)blocks, 1, 2 * C, 0, sg, 2, st);
+    }
     return 0;
 }
 

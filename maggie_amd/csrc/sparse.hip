@@ -120,6 +120,56 @@ __global__ __launch_bounds__(NT) void gather_rows_bwd_kernel(const T* __restrict
     if (dmul) wave_flush_dmul<CE>(run, run_row, cpr, dmul);
 }
 
+// Deterministic form of the dmul part (csrc/det.hip): rows are sorted by plane, so the rows of plane p are ONE range of `coords` (found by
+// binary search). Workgroup (chunk j, token slot q) adds the rows of its chunk of that range in a fixed order and stores one partial row [C];
+// mg_det_reduce adds the chunks in order into dmul[q]. No atomics, no dependence on which thread meets which plane.
+template <typename T, int NCH>
+__global__ __launch_bounds__(NT) void gather_rows_dmul_det_kernel(const T* __restrict__ dout, int ldo, int yoff, const int* __restrict__ coords, int R,
+                                                                  int n_i, int Hd, int Wd, int C, int mul_ninst, const T* __restrict__ dense,
+                                                                  float* __restrict__ slots, const int32_t* __restrict__ r_dev) {
+    using TR = ElemTraits<T>;
+    constexpr int CE = TR::CE;
+    __shared__ float sred[NT * CE];
+    const int cpr = C / CE, nrl = NT / cpr;
+    const int q = blockIdx.y, j = blockIdx.x;
+    const int frame = q / mul_ninst, inst = q - frame * mul_ninst;
+    float* slot = slots + ((size_t)q * NCH + j) * C;
+    R = dev_rows(r_dev, R);
+    long beg = 0, end = 0;
+    if (inst < n_i) {
+        const int p = frame * n_i + inst;
+        int lo = 0, hi = R;                                       // first row with plane >= p
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (coords[(long)mid * 3] < p) lo = mid + 1; else hi = mid; }
+        const int a = lo;
+        hi = R;                                                   // first row with plane > p
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (coords[(long)mid * 3] <= p) lo = mid + 1; else hi = mid; }
+        const long n = lo - a;
+        beg = a + n * j / NCH; end = a + n * (j + 1) / NCH;
+    }
+    const int lane_c = threadIdx.x % cpr, lrow = threadIdx.x / cpr;
+    float run[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) run[e] = 0.f;
+    if (lrow < nrl) {
+        for (long r = beg + lrow; r < end; r += nrl) {
+            const int y = coords[r * 3 + 1], x = coords[r * 3 + 2];
+            float g[CE], d[CE];
+            TR::unpack(*(const uint4*)(dout + r * ldo + yoff + lane_c * CE), g);
+            TR::unpack(*(const uint4*)(dense + (((long)frame * Hd + y) * Wd + x) * C + lane_c * CE), d);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) run[e] += g[e] * d[e];
+        }
+#pragma unroll
+        for (int e = 0; e < CE; ++e) sred[lrow * C + lane_c * CE + e] = run[e];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += NT) {
+        float a = 0.f;
+        for (int rr = 0; rr < nrl; ++rr) a += sred[rr * C + c];
+        slot[c] = a;
+    }
+}
+
 // atomic-free input gradient of the gather: every dense pixel sums the rows of the (at most n_i) instance planes that are
 // active at its position; the row id comes from the level's bit plane + per-word rank (same lookup as the gather tables)
 template <typename T>
@@ -247,6 +297,51 @@ __global__ __launch_bounds__(NT) void mask_embed_bwd_kernel(const T* __restrict_
     for (int i = threadIdx.x; i < (n_m + 1) * 3; i += NT) {
         int id = i / 3, c = i - id * 3;
         if (c < n_embed && acc[i] != 0.f) atomicAdd(&dtable[id * n_embed + c], acc[i]);
+    }
+}
+
+// Deterministic form (csrc/det.hip): ids are at most n_m <= 15, so every thread keeps its own [id][3] sums in registers (static indices:
+// the id test is a compare per candidate), a workgroup adds its threads in a fixed order and stores ONE row [16][3] of the slot buffer.
+template <typename T>
+__global__ __launch_bounds__(NT) void mask_embed_bwd_det_kernel(const T* __restrict__ dx, const float* __restrict__ masks, int N, int H, int W,
+                                                                int n_m, int Hm, int Wm, int n_embed, float* __restrict__ slots) {
+    constexpr int NID = 16;
+    __shared__ float sh[NT / 64][NID * 3];
+    float acc[NID][3];
+#pragma unroll
+    for (int j = 0; j < NID; ++j) { acc[j][0] = 0.f; acc[j][1] = 0.f; acc[j][2] = 0.f; }
+    const long total = (long)N * H * W;
+    const int sy = H / Hm, sx = W / Wm;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        int x = (int)(i % W); long r = i / W; int y = (int)(r % H); int n = (int)(r / H);
+        const float* mp = masks + ((long)n * n_m * Hm + (y / sy)) * Wm + (x / sx);
+        float cnt = 0.f;
+        for (int k = 0; k < n_m; ++k) { long id = (long)(mp[(long)k * Hm * Wm] * (float)(k + 1)); if (id > 0) cnt += 1.f; }
+        if (cnt == 0.f) continue;
+        float inv = 1.f / (cnt + 1e-6f);
+        float g[3];
+        for (int c = 0; c < 3; ++c) g[c] = c < n_embed ? ElemTraits<T>::ld(dx + i * 8 + 3 + c) * inv : 0.f;
+        for (int k = 0; k < n_m; ++k) {
+            const int id = (int)(long)(mp[(long)k * Hm * Wm] * (float)(k + 1));
+#pragma unroll
+            for (int j = 1; j < NID; ++j)
+                if (id == j) { acc[j][0] += g[0]; acc[j][1] += g[1]; acc[j][2] += g[2]; }
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int j = 0; j < NID; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = wave_sum(acc[j][c]);
+            if (lane == 0) sh[wave][j * 3 + c] = v;
+        }
+    __syncthreads();
+    const int nv = (n_m + 1) * 3;                                 // slot row = the table [n_m + 1][3]
+    for (int i = threadIdx.x; i < nv; i += NT) {
+        float v = 0.f;
+        for (int wv = 0; wv < NT / 64; ++wv) v += sh[wv][i];
+        slots[(size_t)blockIdx.x * nv + i] = v;
     }
 }
 
@@ -378,7 +473,7 @@ __global__ __launch_bounds__(NT) void upsample_tanh_bwd_tile_kernel(const float*
     }
     acc += __shfl_xor(acc, 1, 64);
     acc += __shfl_xor(acc, 2, 64);
-    if (part == 0) din[n * sn + c * sc + ys * sy + xs * sx] = acc;            // one writer per element: no pre-zeroed buffer needed for the planes it covers
+    if (part == 0 && ys < h && xs < w) din[n * sn + c * sc + ys * sy + xs * sx] = acc;   // one writer per element: no pre-zeroed buffer needed for the planes it covers
 }
 
 }  // namespace
@@ -421,6 +516,29 @@ extern "C" int mg_gather_rows_bwd_dev(const void* dout, int dtype, int ldo, int 
     else hipLaunchKernelGGL(gather_rows_bwd_kernel<float>, dim3(grid_for(total) > 512 ? 512 : grid_for(total)), dim3(NT), 0, st, (const float*)dout, ldo, yoff, coords, R, n_i, Hd, Wd, C, mul, mul_ninst, (const float*)dense, ddense, dmul, r_dev);
     MG_CHECK_LAUNCH();
     return 0;
+}
+
+/* dmul[frame, inst, c] = sum over the rows r of plane (frame, inst) of dout[r, yoff + c] * dense[frame, y_r, x_r, c]   (fp32 [N, mul_ninst, C], OVERWRITTEN):
+ * the token-multiplier gradient of mg_gather_rows in bit-reproducible form (rows sorted by plane, as the site lists are). */
+extern "C" int mg_gather_rows_dmul_det(const void* dout, int dtype, int ldo, int yoff, const int32_t* coords, int R, int n_i, int N, int Hd, int Wd, int C,
+                                       int mul_ninst, const void* dense, float* dmul, const int32_t* r_dev, void* stream) {
+    const int ce = MG_IS16(dtype) ? 8 : 4;
+    if (C % ce || ldo % ce || yoff % ce || NT % (C / ce) || n_i > mul_ninst) return -3;
+    if (N <= 0 || mul_ninst <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    constexpr int NCH = 16;
+    const int Q = N * mul_ninst;
+    hipError_t e = mg_zero_words(dmul, (long)Q * C, st);
+    if (e != hipSuccess) return (int)e;
+    if (R <= 0) return 0;
+    float* slots = mg_det_scratch((long)Q * NCH * C);
+    if (!slots) return MG_DET_NO_SCRATCH;
+    if (dtype == MG_BF16) hipLaunchKernelGGL((gather_rows_dmul_det_kernel<bf16raw, NCH>), dim3(NCH, Q), dim3(NT), 0, st, (const bf16raw*)dout, ldo, yoff, coords, R, n_i, Hd, Wd, C, mul_ninst, (const bf16raw*)dense, slots, r_dev);
+    else if (dtype == MG_F16) hipLaunchKernelGGL((gather_rows_dmul_det_kernel<f16raw, NCH>), dim3(NCH, Q), dim3(NT), 0, st, (const f16raw*)dout, ldo, yoff, coords, R, n_i, Hd, Wd, C, mul_ninst, (const f16raw*)dense, slots, r_dev);
+    else hipLaunchKernelGGL((gather_rows_dmul_det_kernel<float, NCH>), dim3(NCH, Q), dim3(NT), 0, st, (const float*)dout, ldo, yoff, coords, R, n_i, Hd, Wd, C, mul_ninst, (const float*)dense, slots, r_dev);
+    MG_CHECK_LAUNCH();
+    mg_det_seg sg{dmul, C, (long)C};
+    return mg_det_reduce(slots, NCH, Q, C, 0, &sg, 1, st);
 }
 
 extern "C" int mg_gather_rows_bwd_dense(const void* dout, int dtype, int ldo, int yoff, const void* bits, const int32_t* wordoff, int n_i, int N,
@@ -495,6 +613,17 @@ extern "C" int mg_mask_embed_bwd(const void* dx, int dtype, const float* masks, 
     if (n_m + 1 > 64) return -2;
     hipStream_t st = (hipStream_t)stream;
     int g = grid_for(total); if (g > 1024) g = 1024;
+    if (mg_det_on && n_embed == 3 && n_m < 16) {                  // one partial table per workgroup, added in workgroup order (csrc/det.hip)
+        const int nv = (n_m + 1) * 3;
+        if (g > 512) g = 512;
+        float* slots = mg_det_scratch((long)g * nv);
+        if (!slots) return MG_DET_NO_SCRATCH;
+        if (dtype == MG_BF16) hipLaunchKernelGGL(mask_embed_bwd_det_kernel<bf16raw>, dim3(g), dim3(NT), 0, st, (const bf16raw*)dx, masks, N, H, W, n_m, Hm, Wm, n_embed, slots);
+        else if (dtype == MG_F16) hipLaunchKernelGGL(mask_embed_bwd_det_kernel<f16raw>, dim3(g), dim3(NT), 0, st, (const f16raw*)dx, masks, N, H, W, n_m, Hm, Wm, n_embed, slots);
+        else hipLaunchKernelGGL(mask_embed_bwd_det_kernel<float>, dim3(g), dim3(NT), 0, st, (const float*)dx, masks, N, H, W, n_m, Hm, Wm, n_embed, slots);
+        MG_CHECK_LAUNCH();
+        return mg_det_reduce1(slots, g, dtable, nv, st);
+    }
     if (dtype == MG_BF16) hipLaunchKernelGGL(mask_embed_bwd_kernel<bf16raw>, dim3(g), dim3(NT), 0, st, (const bf16raw*)dx, masks, N, H, W, n_m, Hm, Wm, n_embed, dtable);
     else if (dtype == MG_F16) hipLaunchKernelGGL(mask_embed_bwd_kernel<f16raw>, dim3(g), dim3(NT), 0, st, (const f16raw*)dx, masks, N, H, W, n_m, Hm, Wm, n_embed, dtable);
     else hipLaunchKernelGGL(mask_embed_bwd_kernel<float>, dim3(g), dim3(NT), 0, st, (const float*)dx, masks, N, H, W, n_m, Hm, Wm, n_embed, dtable);
@@ -534,10 +663,12 @@ extern "C" int mg_upsample_tanh_bwd_ex(const float* dout, const float* out, long
     long total = (long)N * C * h * w * scale * scale;
     if (total <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    if (scale == 4 && h % 8 == 0 && w % 8 == 0)
-        hipLaunchKernelGGL(upsample_tanh_bwd_tile_kernel<4>, dim3(w / 8, h / 8, N * C), dim3(NT), 0, st, dout, out, sn, sc, sy, sx, C, h, w, apply_tanh, din, pscale);
-    else if (scale == 8 && h % 8 == 0 && w % 8 == 0)
-        hipLaunchKernelGGL(upsample_tanh_bwd_tile_kernel<8>, dim3(w / 8, h / 8, N * C), dim3(NT), 0, st, dout, out, sn, sc, sy, sx, C, h, w, apply_tanh, din, pscale);
+    // (ragged source sizes: the last tiles run past the plane, their extra source pixels are not written -- the gather form has no atomics,
+    // so the gradient is bit-reproducible at every size)
+    if (scale == 4)
+        hipLaunchKernelGGL(upsample_tanh_bwd_tile_kernel<4>, dim3((w + 7) / 8, (h + 7) / 8, N * C), dim3(NT), 0, st, dout, out, sn, sc, sy, sx, C, h, w, apply_tanh, din, pscale);
+    else if (scale == 8)
+        hipLaunchKernelGGL(upsample_tanh_bwd_tile_kernel<8>, dim3((w + 7) / 8, (h + 7) / 8, N * C), dim3(NT), 0, st, dout, out, sn, sc, sy, sx, C, h, w, apply_tanh, din, pscale);
     else
         hipLaunchKernelGGL(upsample_tanh_bwd_kernel, dim3(grid_for(total)), dim3(NT), 0, st, dout, out, sn, sc, sy, sx, N, C, h, w, scale, apply_tanh, din, pscale);
     MG_CHECK_LAUNCH();

@@ -16,32 +16,73 @@ constexpr int NT = 256;
 constexpr float SN_EPS = 1e-12f;
 
 // scratch layout (fp32): [0] = |t|^2, [1] = |s'|^2 (s' = W t, unnormalised), [2] = <G, W>, [3] = sigma
-__global__ __launch_bounds__(NT) void sn_wt_u_kernel(const float* __restrict__ W, const float* __restrict__ u, int A, int Wd,
-                                                     float* __restrict__ t, int rows_per_block) {
-    const int j = blockIdx.x * NT + threadIdx.x;
-    const int i0 = blockIdx.y * rows_per_block, i1 = min(A, i0 + rows_per_block);
-    if (j >= Wd) return;
-    float acc = 0.f;
-    for (int i = i0; i < i1; ++i) acc += W[(long)i * Wd + j] * u[i];
-    atomicAdd(&t[j], acc);
+// Fixed-order block sum of one value per thread (wave butterfly, then the four waves in order): the building block of every norm / dot
+// product below -- the result depends on the thread -> element mapping only, never on timing.
+__device__ __forceinline__ float block_sum_ordered(float v, float* sh4) {
+    v = wave_sum(v);
+    __syncthreads();                                              // sh4 may still be read from a previous call
+    if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh4[0] + sh4[1]) + (sh4[2] + sh4[3]);
 }
 
-// one wave per row: s'[i] = sum_j W[i,j] t[j];  block (0,0) also reduces |t|^2
+// t[j] = sum_i W[i, j] u[i]: a workgroup owns 32 columns over ALL rows -- thread (column c = t % 32, row lane r = t / 32) adds rows r, r + 8, ...
+// in order, the 8 row lanes meet in LDS in order. (The earlier form split the rows over workgroups and added their partials atomically.)
+__device__ __forceinline__ void wt_u_columns(const float* __restrict__ W, const float* __restrict__ u, int A, int Wd, int j0, float* __restrict__ t,
+                                             float* sh /* [8][33] */) {
+    const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+    const int j = j0 + c;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (j < Wd) {
+        int i = r;
+        for (; i + 24 < A; i += 32) {                             // four independent loads in flight, added in row order per accumulator
+            a0 += W[(long)i * Wd + j] * u[i];
+            a1 += W[(long)(i + 8) * Wd + j] * u[i + 8];
+            a2 += W[(long)(i + 16) * Wd + j] * u[i + 16];
+            a3 += W[(long)(i + 24) * Wd + j] * u[i + 24];
+        }
+        for (; i < A; i += 8) a0 += W[(long)i * Wd + j] * u[i];
+    }
+    sh[r * 33 + c] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (r == 0 && j < Wd) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += sh[k * 33 + c];
+        t[j] = v;
+    }
+}
+
+__global__ __launch_bounds__(NT) void sn_wt_u_kernel(const float* __restrict__ W, const float* __restrict__ u, int A, int Wd, float* __restrict__ t) {
+    __shared__ float sh[8 * 33];
+    wt_u_columns(W, u, A, Wd, blockIdx.x * 32, t, sh);
+}
+
+// scratch[0] = |t|^2, scratch[1] = |s'|^2 in a fixed order (one workgroup)
+__device__ __forceinline__ void sn_norms(const float* __restrict__ t, int Wd, const float* __restrict__ s, int A, float* __restrict__ scratch, float* sh4) {
+    float a = 0.f;
+    for (int j = threadIdx.x; j < Wd; j += NT) a += t[j] * t[j];
+    a = block_sum_ordered(a, sh4);
+    float b = 0.f;
+    for (int i = threadIdx.x; i < A; i += NT) b += s[i] * s[i];
+    b = block_sum_ordered(b, sh4);
+    if (threadIdx.x == 0) { scratch[0] = a; scratch[1] = b; }
+}
+__global__ __launch_bounds__(NT) void sn_norms_kernel(const float* __restrict__ t, int Wd, const float* __restrict__ s, int A, float* __restrict__ scratch) {
+    __shared__ float sh4[4];
+    sn_norms(t, Wd, s, A, scratch, sh4);
+}
+
+// one wave per row: s'[i] = sum_j W[i,j] t[j]   (the two norms follow in sn_norms_kernel: fixed order, no atomics)
 __global__ __launch_bounds__(NT) void sn_w_t_kernel(const float* __restrict__ W, const float* __restrict__ t, int A, int Wd,
-                                                    float* __restrict__ s, float* __restrict__ scratch) {
+                                                    float* __restrict__ s) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * 4 + wave;
     if (i < A) {
         float acc = 0.f;
         for (int j = lane; j < Wd; j += 64) acc += W[(long)i * Wd + j] * t[j];
         acc = wave_sum(acc);
-        if (lane == 0) { s[i] = acc; atomicAdd(&scratch[1], acc * acc); }
-    }
-    if (blockIdx.x == 0) {
-        float a = 0.f;
-        for (int j = threadIdx.x; j < Wd; j += NT) a += t[j] * t[j];
-        a = wave_sum(a);
-        if (lane == 0) atomicAdd(&scratch[0], a);
+        if (lane == 0) s[i] = acc;
     }
 }
 
@@ -74,9 +115,9 @@ __global__ __launch_bounds__(NT) void sn_finish_kernel(const float* __restrict__
     }
 }
 
-// <G, W> with G in (Cout, taps, pad_in) fp32 layout
+// <G, W> with G in (Cout, taps, pad_in) fp32 layout: one partial per workgroup into `part`, summed in order by sn_bwd_dot_finish_kernel
 __global__ __launch_bounds__(NT) void sn_bwd_dot_kernel(const float* __restrict__ G, const float* __restrict__ W, int A, int B, int taps,
-                                                        int transposed, int pad_in, float* __restrict__ scratch) {
+                                                        int transposed, int pad_in, float* __restrict__ part) {
     const long total = (long)A * B * taps;
     float acc = 0.f;
     for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total; e += (long)gridDim.x * NT) {
@@ -85,10 +126,15 @@ __global__ __launch_bounds__(NT) void sn_bwd_dot_kernel(const float* __restrict_
         acc += G[((long)co * taps + tap) * pad_in + ci] * W[e];
     }
     __shared__ float sh[NT / 64];
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&scratch[2], sh[0] + sh[1] + sh[2] + sh[3]);
+    acc = block_sum_ordered(acc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(NT) void sn_bwd_dot_finish_kernel(const float* __restrict__ part, int n, float* __restrict__ scratch) {
+    __shared__ float sh[NT / 64];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n; i += NT) a += part[i];
+    a = block_sum_ordered(a, sh);
+    if (threadIdx.x == 0) scratch[2] = a;
 }
 
 __global__ __launch_bounds__(NT) void sn_bwd_apply_kernel(const float* __restrict__ G, const float* __restrict__ u, const float* __restrict__ v,
@@ -119,12 +165,9 @@ extern "C" int mg_spectral_norm(const float* W, float* u, float* v, int A, int B
     float* t = work;
     float* s = work + Wd;
     float* scratch = work + Wd + A;
-    hipError_t e = mg_zero_words(work, (long)(Wd + A + 4), st);
-    if (e != hipSuccess) return (int)e;
-    int rpb = 32;
-    dim3 g1((Wd + NT - 1) / NT, (A + rpb - 1) / rpb);
-    hipLaunchKernelGGL(sn_wt_u_kernel, g1, dim3(NT), 0, st, W, u, A, Wd, t, rpb);
-    hipLaunchKernelGGL(sn_w_t_kernel, dim3((A + 3) / 4), dim3(NT), 0, st, W, t, A, Wd, s, scratch);
+    hipLaunchKernelGGL(sn_wt_u_kernel, dim3((Wd + 31) / 32), dim3(NT), 0, st, W, u, A, Wd, t);
+    hipLaunchKernelGGL(sn_w_t_kernel, dim3((A + 3) / 4), dim3(NT), 0, st, W, t, A, Wd, s);
+    hipLaunchKernelGGL(sn_norms_kernel, dim3(1), dim3(NT), 0, st, (const float*)t, Wd, (const float*)s, A, scratch);
     const int Cout = transposed ? B : A;
     long total = (long)Cout * taps * pad_in;
     long need = total > Wd ? total : Wd;
@@ -144,11 +187,12 @@ extern "C" int mg_spectral_norm_bwd(const float* G, const float* W, const float*
     const int Wd = B * taps;
     hipStream_t st = (hipStream_t)stream;
     float* scratch = work + Wd + A;
-    hipError_t e = mg_zero_words(scratch + 2, 1, st);
-    if (e != hipSuccess) return (int)e;
     long total = (long)A * B * taps;
     int dot_blocks = grid_for(total / 8); if (dot_blocks > 256) dot_blocks = 256;
-    hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(dot_blocks), dim3(NT), 0, st, G, W, A, B, taps, transposed, pad_in, scratch);
+    // the per-workgroup partials of <G, W> land in dW (overwritten by the apply kernel afterwards; total >= 256 floats whenever 256 blocks run)
+    if (dot_blocks > total) dot_blocks = (int)total;
+    hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(dot_blocks), dim3(NT), 0, st, G, W, A, B, taps, transposed, pad_in, dW);
+    hipLaunchKernelGGL(sn_bwd_dot_finish_kernel, dim3(1), dim3(NT), 0, st, (const float*)dW, dot_blocks, scratch);
     hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(grid_for(total)), dim3(NT), 0, st, G, u, v, scratch, A, B, taps, transposed, pad_in, dW);
     MG_CHECK_LAUNCH();
     return 0;
@@ -162,38 +206,38 @@ extern "C" int mg_spectral_norm_bwd(const float* G, const float* W, const float*
 namespace {
 
 __global__ __launch_bounds__(NT) void snb_wt_u_kernel(const mg_sn_desc* __restrict__ descs, const int4* __restrict__ items, float* __restrict__ work_base) {
-    const int4 it = items[blockIdx.x];                       // (conv, column block, row block, -)
+    __shared__ float sh[8 * 33];
+    const int4 it = items[blockIdx.x];                       // (conv, block of 32 columns, -, -)
     const mg_sn_desc d = descs[it.x];
-    const int Wd = d.B * d.taps;
-    const int j = it.y * NT + threadIdx.x;
-    const int i0 = it.z * 32, i1 = min(d.A, i0 + 32);
-    if (j >= Wd) return;
-    float acc = 0.f;
-    for (int i = i0; i < i1; ++i) acc += d.W[(long)i * Wd + j] * d.u[i];
-    atomicAdd(&work_base[d.work_off + j], acc);
+    wt_u_columns(d.W, d.u, d.A, d.B * d.taps, it.y * 32, work_base + d.work_off, sh);
 }
 
 __global__ __launch_bounds__(NT) void snb_w_t_kernel(const mg_sn_desc* __restrict__ descs, const int4* __restrict__ items, float* __restrict__ work_base) {
-    const int4 it = items[blockIdx.x];                       // (conv, row group of 4, first-group flag, -)
+    const int4 it = items[blockIdx.x];                       // (conv, row group of 4, -, -)
     const mg_sn_desc d = descs[it.x];
     const int Wd = d.B * d.taps;
     const float* t = work_base + d.work_off;
     float* s = work_base + d.work_off + Wd;
-    float* scratch = s + d.A;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = it.y * 4 + wave;
     if (i < d.A) {
         float acc = 0.f;
         for (int j = lane; j < Wd; j += 64) acc += d.W[(long)i * Wd + j] * t[j];
         acc = wave_sum(acc);
-        if (lane == 0) { s[i] = acc; atomicAdd(&scratch[1], acc * acc); }
+        if (lane == 0) s[i] = acc;
     }
-    if (it.y == 0) {
-        float a = 0.f;
-        for (int j = threadIdx.x; j < Wd; j += NT) a += t[j] * t[j];
-        a = wave_sum(a);
-        if (lane == 0) atomicAdd(&scratch[0], a);
-    }
+}
+
+// |t|^2 and |W t|^2 of every conv in a fixed order: one workgroup per conv (was: atomics from every row's wave)
+__global__ __launch_bounds__(NT) void snb_norms_kernel(const mg_sn_desc* __restrict__ descs, int n, float* __restrict__ work_base) {
+    __shared__ float sh4[4];
+    const int c = blockIdx.x;
+    if (c >= n) return;
+    const mg_sn_desc d = descs[c];
+    if (d.plain) return;
+    const int Wd = d.B * d.taps;
+    float* t = work_base + d.work_off;
+    sn_norms(t, Wd, t + Wd, d.A, t + Wd + d.A, sh4);
 }
 
 // ---- tiled passes over a parameter W[A][B][taps] (OIHW / IOHW, fp32) ------------------------------------------------------------
@@ -312,16 +356,16 @@ __device__ __forceinline__ void sn_load_grad_tile(const mg_sn_desc& d, const SnT
     }
 }
 
-// scratch[2] += <G, W> over the tile
+// dot_part[item] = <G, W> over the tile; the apply kernel adds a conv's tiles in item order (was: one atomicAdd per tile onto scratch[2])
 template <typename T>
 __global__ __launch_bounds__(NT) void snb_bwd_dot_kernel(const mg_sn_desc* __restrict__ descs, const int4* __restrict__ items,
-                                                         const void* const* __restrict__ Gptrs, float* __restrict__ work_base) {
+                                                         const void* const* __restrict__ Gptrs, float* __restrict__ dot_part) {
     __shared__ float sT[SN_TA * SN_PITCH];
     __shared__ float sh[NT / 64];
     const int4 it = items[blockIdx.x];                       // (conv, a tile, b tile, -)
     const mg_sn_desc d = descs[it.x];
     const T* G = (const T*)Gptrs[it.x];
-    if (!G || d.plain) return;
+    if (!G || d.plain) { if (threadIdx.x == 0) dot_part[blockIdx.x] = 0.f; return; }
     const SnTile t = sn_tile(d, it);
     sn_load_grad_tile<T>(d, t, G, sT);
     __syncthreads();
@@ -331,18 +375,17 @@ __global__ __launch_bounds__(NT) void snb_bwd_dot_kernel(const mg_sn_desc* __res
         const int al = i / run, r = i - al * run;
         acc += sT[al * SN_PITCH + r] * d.W[((long)(t.a0 + al) * d.B + t.b0) * d.taps + r];
     }
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&work_base[d.work_off + d.B * d.taps + d.A + 2], sh[0] + sh[1] + sh[2] + sh[3]);
+    acc = block_sum_ordered(acc, sh);
+    if (threadIdx.x == 0) dot_part[blockIdx.x] = acc;
 }
 
 // dW[a][b][tap] = G / sigma - <G,W> / sigma^2 * u[a] v[b, tap]   (parameter layout, fp32)
 template <typename T>
 __global__ __launch_bounds__(NT) void snb_bwd_apply_kernel(const mg_sn_desc* __restrict__ descs, const int4* __restrict__ items,
                                                            const void* const* __restrict__ Gptrs, const float* __restrict__ work_base,
-                                                           float* __restrict__ dW_base) {
+                                                           float* __restrict__ dW_base, const float* __restrict__ dot_part) {
     __shared__ float sT[SN_TA * SN_PITCH];
+    __shared__ float sh4[4];
     const int4 it = items[blockIdx.x];
     const mg_sn_desc d = descs[it.x];
     const T* G = (const T*)Gptrs[it.x];
@@ -369,8 +412,12 @@ __global__ __launch_bounds__(NT) void snb_bwd_apply_kernel(const mg_sn_desc* __r
         }
         return;
     }
+    // <G, W> of the conv = its tiles' partials, items [k3_first, k3_first + k3_count), added in item order by every workgroup of the conv
+    float dot = 0.f;
+    for (int i = threadIdx.x; i < d.k3_count; i += NT) dot += dot_part[d.k3_first + i];
+    dot = block_sum_ordered(dot, sh4);
     const float inv_sigma = 1.f / scratch[3];
-    const float coef = scratch[2] * inv_sigma * inv_sigma;
+    const float coef = dot * inv_sigma * inv_sigma;
     for (int i = threadIdx.x; i < t.na * run; i += NT) {
         const int al = i / run, r = i - al * run;
         dW[((long)(t.a0 + al) * d.B + t.b0) * d.taps + r] = sT[al * SN_PITCH + r] * inv_sigma - coef * u[t.a0 + al] * v[t.b0 * d.taps + r];
@@ -385,10 +432,10 @@ extern "C" int mg_spectral_norm_batched(const mg_sn_desc* descs, int n_conv, con
                                         int out_dtype, void* stream) {
     if (n_conv <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = mg_zero_words(work_base, (long)work_floats, st);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(snb_wt_u_kernel, dim3(n1), dim3(NT), 0, st, descs, (const int4*)items_k1, work_base);
-    hipLaunchKernelGGL(snb_w_t_kernel, dim3(n2), dim3(NT), 0, st, descs, (const int4*)items_k2, work_base);
+    (void)work_floats;                                       // every word of the work block that is read has been written by the launches below
+    if (n1 > 0) hipLaunchKernelGGL(snb_wt_u_kernel, dim3(n1), dim3(NT), 0, st, descs, (const int4*)items_k1, work_base);
+    if (n2 > 0) hipLaunchKernelGGL(snb_w_t_kernel, dim3(n2), dim3(NT), 0, st, descs, (const int4*)items_k2, work_base);
+    hipLaunchKernelGGL(snb_norms_kernel, dim3(n_conv), dim3(NT), 0, st, descs, n_conv, work_base);
     if (out_dtype == MG_BF16) hipLaunchKernelGGL(snb_finish_kernel<bf16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, work_base, (bf16raw*)out_base, (bf16raw*)out_t_base);
     else if (out_dtype == MG_F16) hipLaunchKernelGGL(snb_finish_kernel<f16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, work_base, (f16raw*)out_base, (f16raw*)out_t_base);
     else hipLaunchKernelGGL(snb_finish_kernel<float>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, work_base, (float*)out_base, (float*)out_t_base);
@@ -400,18 +447,19 @@ extern "C" int mg_spectral_norm_batched(const mg_sn_desc* descs, int n_conv, con
 // Gptrs: device array of n_conv pointers to the weight gradients in the (Cout, taps, pad_in) layout (NULL = no gradient);
 // work_base: the forward's work buffer; dW_base: fp32 output, conv c at descs[c].dw_off laid out like the parameter.
 extern "C" int mg_spectral_norm_batched_bwd(const mg_sn_desc* descs, int n_conv, const int32_t* items_k3, int n3, const void* const* Gptrs,
-                                            int g_dtype, float* work_base, float* dW_base, void* stream) {
+                                            int g_dtype, float* work_base, float* dW_base, float* dot_part, void* stream) {
     if (n_conv <= 0) return 0;
+    if (!dot_part) return -2;
     hipStream_t st = (hipStream_t)stream;
     if (g_dtype == MG_BF16) {
-        hipLaunchKernelGGL(snb_bwd_dot_kernel<bf16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, work_base);
-        hipLaunchKernelGGL(snb_bwd_apply_kernel<bf16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, work_base, dW_base);
+        hipLaunchKernelGGL(snb_bwd_dot_kernel<bf16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, dot_part);
+        hipLaunchKernelGGL(snb_bwd_apply_kernel<bf16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, work_base, dW_base, dot_part);
     } else if (g_dtype == MG_F16) {
-        hipLaunchKernelGGL(snb_bwd_dot_kernel<f16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, work_base);
-        hipLaunchKernelGGL(snb_bwd_apply_kernel<f16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, work_base, dW_base);
+        hipLaunchKernelGGL(snb_bwd_dot_kernel<f16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, dot_part);
+        hipLaunchKernelGGL(snb_bwd_apply_kernel<f16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, work_base, dW_base, dot_part);
     } else {
-        hipLaunchKernelGGL(snb_bwd_dot_kernel<float>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, work_base);
-        hipLaunchKernelGGL(snb_bwd_apply_kernel<float>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, work_base, dW_base);
+        hipLaunchKernelGGL(snb_bwd_dot_kernel<float>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, dot_part);
+        hipLaunchKernelGGL(snb_bwd_apply_kernel<float>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, work_base, dW_base, dot_part);
     }
     MG_CHECK_LAUNCH();
     return 0;

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(NT) void bifuse_bwd_kernel(const float* __restrict_
 // ---- loss_dtSSD: sum_{b, t >= 1, e} ((p[t] - p[t-1]) - (g[t] - g[t-1]))^2 m[t] / sum (m[t] + 1e-6) ------------------------------------
 // p / g / m: T frames of E elements, `xbs` elements between batches; `sig`: p = sigmoid(logits); m == NULL: ones
 __global__ __launch_bounds__(NT) void dtssd_fwd_kernel(const float* __restrict__ p, long pbs, const float* __restrict__ g, long gbs, const float* __restrict__ m,
-                                                       long mbs, int B, int T, long E, int sig, float* __restrict__ sums) {
+                                                       long mbs, int B, int T, long E, int sig, float* __restrict__ sums, float* __restrict__ slots) {
     __shared__ float red[2][NT / 64];
     float a0 = 0.f, a1 = 0.f;
     const long total = (long)B * E;
@@ -126,7 +126,8 @@ __global__ __launch_bounds__(NT) void dtssd_fwd_kernel(const float* __restrict__
     if (threadIdx.x == 0) {
         float s0 = 0.f, s1 = 0.f;
         for (int w = 0; w < NT / 64; ++w) { s0 += red[0][w]; s1 += red[1][w]; }
-        atomicAdd(&sums[0], s0); atomicAdd(&sums[1], s1);
+        if (slots) { slots[2 * blockIdx.x] = s0; slots[2 * blockIdx.x + 1] = s1; }     // deterministic mode: one row per workgroup (csrc/det.hip)
+        else { atomicAdd(&sums[0], s0); atomicAdd(&sums[1], s1); }
     }
 }
 
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(NT) void dtssd_bwd_kernel(const float* __restrict__
 
 // ---- mean BCE with logits over (B, T, E) with batch strides -----------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void bce_fwd_kernel(const float* __restrict__ x, long xbs, const float* __restrict__ y, long ybs, int B, long TE,
-                                                     float* __restrict__ sum) {
+                                                     float* __restrict__ sum, float* __restrict__ slots) {
     __shared__ float red[NT / 64];
     float a = 0.f;
     const long total = (long)B * TE;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(NT) void bce_fwd_kernel(const float* __restrict__ x
     a = wave_sum(a);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
     __syncthreads();
-    if (threadIdx.x == 0) { float s = 0.f; for (int w = 0; w < NT / 64; ++w) s += red[w]; atomicAdd(sum, s); }
+    if (threadIdx.x == 0) { float s = 0.f; for (int w = 0; w < NT / 64; ++w) s += red[w]; if (slots) slots[blockIdx.x] = s; else atomicAdd(sum, s); }
 }
 
 __global__ __launch_bounds__(NT) void bce_bwd_kernel(const float* __restrict__ x, long xbs, const float* __restrict__ y, long ybs, int B, long TE,
@@ -301,8 +302,11 @@ extern "C" int mg_dtssd_fwd(const float* p, long pbs, const float* g, long gbs, 
     { hipError_t e = mg_zero_words(sums, 2, st); if (e != hipSuccess) return (int)e; }
     if (T < 2 || (long)B * E <= 0) return 0;
     long blocks = ((long)B * E + NT - 1) / NT; if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(dtssd_fwd_kernel, dim3((unsigned)blocks), dim3(NT), 0, st, p, pbs, g, gbs, m, mbs, B, T, E, sig, sums);
+    float* slots = nullptr;
+    if (mg_det_on && blocks > 1) { slots = mg_det_scratch(2 * blocks); if (!slots) return MG_DET_NO_SCRATCH; }
+    hipLaunchKernelGGL(dtssd_fwd_kernel, dim3((unsigned)blocks), dim3(NT), 0, st, p, pbs, g, gbs, m, mbs, B, T, E, sig, sums, slots);
     MG_CHECK_LAUNCH();
+    if (slots) return mg_det_reduce1(slots, (int)blocks, sums, 2, st);
     return 0;
 }
 
@@ -319,8 +323,11 @@ extern "C" int mg_bce_logits_fwd(const float* x, long xbs, const float* y, long 
     { hipError_t e = mg_zero_words(sum, 1, st); if (e != hipSuccess) return (int)e; }
     if ((long)B * TE <= 0) return 0;
     long blocks = ((long)B * TE + NT - 1) / NT; if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(bce_fwd_kernel, dim3((unsigned)blocks), dim3(NT), 0, st, x, xbs, y, ybs, B, TE, sum);
+    float* slots = nullptr;
+    if (mg_det_on && blocks > 1) { slots = mg_det_scratch(blocks); if (!slots) return MG_DET_NO_SCRATCH; }
+    hipLaunchKernelGGL(bce_fwd_kernel, dim3((unsigned)blocks), dim3(NT), 0, st, x, xbs, y, ybs, B, TE, sum, slots);
     MG_CHECK_LAUNCH();
+    if (slots) return mg_det_reduce1(slots, (int)blocks, sum, 1, st);
     return 0;
 }
 

@@ -469,7 +469,7 @@ __global__ __launch_bounds__(NT) void token_einsum_fwd_kernel(const T* __restric
 // over the tile rows (a first version reduced every (q, c) product with a wave butterfly: 320 x 6 shuffles per thread, 164 us per launch).
 template <typename T, int C>
 __global__ __launch_bounds__(NT) void token_einsum_bwd_kernel(const T* __restrict__ dlog, const T* __restrict__ feat, const float* __restrict__ tok, int L, int Q,
-                                                              int QP, T* __restrict__ dfeat, float* __restrict__ dtok) {
+                                                              int QP, T* __restrict__ dfeat, float* __restrict__ dtok, float* __restrict__ slots) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
     constexpr int TR_ROWS = 64;
@@ -528,7 +528,13 @@ __global__ __launch_bounds__(NT) void token_einsum_bwd_kernel(const T* __restric
         }
     }
 #pragma unroll
-    for (int j = 0; j < QPT; ++j) { const int q = qg + j * QG; if (q < Q) atomicAdd(&dtok[((size_t)b * Q + q) * C + c], acc[j]); }
+    for (int j = 0; j < QPT; ++j) {
+        const int q = qg + j * QG;
+        if (q < Q) {
+            if (slots) slots[(((size_t)b * gridDim.x + blockIdx.x) * Q + q) * C + c] = acc[j];      // deterministic mode: one row [Q][C] per workgroup (csrc/det.hip)
+            else atomicAdd(&dtok[((size_t)b * Q + q) * C + c], acc[j]);
+        }
+    }
 }
 
 }  // namespace
@@ -636,12 +642,18 @@ extern "C" int mg_token_einsum_bwd(const void* dlog, const void* feat, int dtype
     hipError_t e = mg_zero_words(dtok, (long)B * Q * C, st);
     if (e != hipSuccess) return (int)e;
     dim3 grid((L + NT - 1) / NT, B);
-#define EINSUM_BWD(T, CC) hipLaunchKernelGGL((token_einsum_bwd_kernel<T, CC>), grid, dim3(NT), 0, st, (const T*)dlog, (const T*)feat, tok, L, Q, QP, (T*)dfeat, dtok)
+    float* slots = nullptr;
+    if (mg_det_on && grid.x > 1) { slots = mg_det_scratch((long)B * grid.x * Q * C); if (!slots) return MG_DET_NO_SCRATCH; }
+#define EINSUM_BWD(T, CC) hipLaunchKernelGGL((token_einsum_bwd_kernel<T, CC>), grid, dim3(NT), 0, st, (const T*)dlog, (const T*)feat, tok, L, Q, QP, (T*)dfeat, dtok, slots)
     if (dtype == MG_BF16) { if (C == 32) EINSUM_BWD(bf16raw, 32); else EINSUM_BWD(bf16raw, 64); }
     else if (dtype == MG_F16) { if (C == 32) EINSUM_BWD(f16raw, 32); else EINSUM_BWD(f16raw, 64); }
     else { if (C == 32) EINSUM_BWD(float, 32); else EINSUM_BWD(float, 64); }
 #undef EINSUM_BWD
     MG_CHECK_LAUNCH();
+    if (slots) {
+        mg_det_seg sg{dtok, Q * C, (long)Q * C};
+        return mg_det_reduce(slots, (int)grid.x, B, Q * C, 0, &sg, 1, st);
+    }
     return 0;
 }
 

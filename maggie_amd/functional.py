@@ -411,14 +411,15 @@ class SpectralNormPlan:
             self.out_slices.append((out_off, n_out))
             self.dw_slices.append((dw_off, w.numel()))
             if not plain:                                         # power iteration work items
-                for cb in range((Wd + 255) // 256):
-                    for rb in range((A + 31) // 32):
-                        k1.append((c, cb, rb, 0))
+                for cb in range((Wd + 31) // 32):                 # W^T u: a workgroup owns 32 columns over all rows (fixed-order sums)
+                    k1.append((c, cb, 0, 0))
                 for rg in range((A + 3) // 4):
                     k2.append((c, rg, 0, 0))
+            d.k3_first = len(k3)
             for at in range((A + 15) // 16):                      # (SN_TA x SN_TB) parameter tiles, csrc/spectral_norm.hip
                 for bt in range((B + 31) // 32):
                     k3.append((c, at, bt, 0))
+            d.k3_count = len(k3) - d.k3_first
             out_off += (n_out + 7) // 8 * 8
             work_off += (Wd + A + 4 + 3) // 4 * 4
             dw_off += (w.numel() + 3) // 4 * 4
@@ -488,8 +489,9 @@ class SpectralNormBatch(torch.autograd.Function):
         else:
             ptrs = host_ptrs.to(dev, non_blocking=True)
         dW = torch.empty(plan.total_dw, dtype=torch.float32, device=dev)
+        dot_part = torch.empty(plan.k3.shape[0], dtype=torch.float32, device=dev)      # per-tile partials of <G, W>, added in tile order
         K.hip.call('mg_spectral_norm_batched_bwd', K.hip.ptr(plan.descs), K.c_int(plan.n), K.hip.ptr(plan.k3), K.c_int(plan.k3.shape[0]),
-                   K.hip.ptr(ptrs), K.c_int(K.hip.code_of(plan.dtype)), K.hip.ptr(work), K.hip.ptr(dW),
+                   K.hip.ptr(ptrs), K.c_int(K.hip.code_of(plan.dtype)), K.hip.ptr(work), K.hip.ptr(dW), K.hip.ptr(dot_part),
                    K.hip.stream())
         outs = tuple(dW[o:o + n].view(sh[3]) for (o, n), sh in zip(plan.dw_slices, plan.shapes))
         return (None,) + outs
@@ -679,12 +681,13 @@ class BNAct(torch.autograd.Function):
         if training and group is None and gamma.dtype == torch.float32 and gamma.numel() == C and M > 0 and \
                 (running_mean is None or running_mean.numel() == C):
             # the common case (local statistics, unpadded channels) in one C call: statistics, finalize, apply
-            exact = M <= EXACT_STATS_ROWS
+            exact = M <= (BN_SMALL_ROWS if K.hip.DETERMINISTIC else EXACT_STATS_ROWS)      # (deterministic mode: exact only where one workgroup does it)
             if exact and stats is not None and stats.dim() != 1:
                 stats = None                                      # replicas from a conv epilogue: the exact path recomputes
             r2 = None if res is None else res.contiguous().view(-1, C)
             own = stats is None
-            ws = ARENA.take((2 if exact else 2 * K.STAT_REPLICAS) * C, x.device) if own else None      # zeroed once per step / per graph
+            small = exact and 1 < M <= BN_SMALL_ROWS              # one workgroup per channel chunk: no statistics scratch at all
+            ws = ARENA.take(K.stats_ws_floats(C, exact), x.device) if (own and not small) else None      # zeroed once per step / per graph
             y, pack = K.bn_train_fwd(x2, gamma, beta, running_mean, running_var, momentum, eps, act, LRELU_SLOPE, r2, res_mode, H, W_,
                                      stats, exact, ws)
             ctx.save_for_backward(x2, y, pack)
@@ -814,9 +817,14 @@ def batch_norm_act(x, bn, act=ACT_NONE, res=None, stats=None, res_mode=1, mask_x
                        _sync_group(bn) if training else None, mask_x_pos, link)
 
 
-def new_stats(channels, device, rows=None, bn=None):
+def new_stats(channels, device, rows=None, bn=None, geom=None):
     """Zeroed accumulator for the conv epilogue's BatchNorm statistics. Layers that will use the exact two-pass variance
     (`rows` <= EXACT_STATS_ROWS, no SyncBN) only need the column sums: one row [2*channels] (conv stat_mode 1)."""
+    if K.hip.DETERMINISTIC:
+        if rows is not None and rows <= BN_SMALL_ROWS and (bn is None or _sync_group(bn) is None):
+            return None                                            # the one-workgroup BatchNorm computes its own (exact) statistics
+        n = K.conv_stat_rows(rows if rows is not None else 1, *geom) if geom else K.conv_stat_rows(rows if rows is not None else 1)
+        return ARENA.take(n * 2 * channels, device).view(n, 2 * channels)
     if rows is not None and rows <= EXACT_STATS_ROWS and (bn is None or _sync_group(bn) is None):
         return ARENA.take(2 * channels, device)
     return ARENA.take(K.STAT_REPLICAS * 2 * channels, device).view(K.STAT_REPLICAS, 2 * channels)
@@ -847,9 +855,10 @@ def conv_bn_act(x, w, bn, act=ACT_NONE, R=3, S=3, stride=1, pad=1, dil=1, transp
     stats = None
     if bn.training:
         mode_ = MODE_TCONV if transposed else MODE_CONV
-        rows = x.shape[0] * K.conv_out_size(mode_, x.shape[1], R, stride, pad, dil) * K.conv_out_size(mode_, x.shape[2], S, stride, pad, dil)
+        ho_, wo_ = K.conv_out_size(mode_, x.shape[1], R, stride, pad, dil), K.conv_out_size(mode_, x.shape[2], S, stride, pad, dil)
+        rows = x.shape[0] * ho_ * wo_
         # fused statistics in the conv epilogue -- except on the largest, thinnest tensors (UNFUSED_STATS_ROWS)
-        stats = new_stats(Cout, x.device, rows, bn) if rows < UNFUSED_STATS_ROWS else None
+        stats = new_stats(Cout, x.device, rows, bn, geom=(x.shape[0], ho_, wo_)) if rows < UNFUSED_STATS_ROWS else None
     xc = None
     # ReLU-before-BN (encoder shortcuts): the BatchNorm's backward applies the ReLU mask itself (mask_x_pos: its input IS the ReLU output),
     # so the conv's backward needs neither its saved output nor a masking pass over the gradient

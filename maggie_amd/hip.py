@@ -12,6 +12,12 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libmaggie_hip.so')
 _LIB = None
+# Bit-reproducible steps (default): the reference runs with torch.backends.cudnn.deterministic = True (tools/main.py:135-136). Every cross-workgroup
+# fp32 sum of the library then runs as "one partial per workgroup, added in index order" instead of atomicAdd (csrc/det.hip). MAGGIE_DETERMINISTIC=0
+# switches back to the atomic forms.
+DETERMINISTIC = os.environ.get('MAGGIE_DETERMINISTIC', '1') != '0'
+DET_SCRATCH_BYTES = int(os.environ.get('MAGGIE_DET_SCRATCH_MB', '64')) << 20
+_DET_READY = False
 
 F32, BF16, F16 = 0, 1, 3          # MG_F32 / MG_BF16 / MG_F16 (2 is MG_U8, mask planes only)
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
@@ -39,6 +45,7 @@ class ConvParams(ctypes.Structure):
         ('m_dev', ctypes.c_void_p),
         ('bnb_y', ctypes.c_void_p), ('bnb_x', ctypes.c_void_p), ('bnb_mean', ctypes.c_void_p), ('bnb_invstd', ctypes.c_void_p),
         ('bnb_act', ctypes.c_int32), ('bnb_ld', ctypes.c_int32),
+        ('stat_rep', ctypes.c_int32), ('reserved0', ctypes.c_int32),
     ]
 
 
@@ -52,7 +59,25 @@ def lib():
                 '(hipcc --offload-arch=gfx950). There is no CPU / PyTorch fallback for the MaGGIe hot path.' % LIB_PATH)
         _LIB = ctypes.CDLL(LIB_PATH)
         _LIB.mg_abi_version.restype = ctypes.c_int
+        _LIB.mg_set_deterministic(ctypes.c_int(int(DETERMINISTIC)))
     return _LIB
+
+
+def set_deterministic(on):
+    """Switch the library between the ordered-slot sums (bit-reproducible, default) and the atomic forms. Graphs captured before the switch keep
+    the kernels they recorded; buffers sized by the old mode (kernels.STAT_ROWS) must not be reused."""
+    global DETERMINISTIC
+    DETERMINISTIC = bool(on)
+    lib().mg_set_deterministic(ctypes.c_int(int(DETERMINISTIC)))
+
+
+def _det_init():
+    """The library's slot scratch lives on the device the process computes on: allocated at the first call into the library (never inside a
+    stream capture -- every captured path runs eagerly first)."""
+    global _DET_READY
+    if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+        check(lib().mg_det_init(ctypes.c_long(DET_SCRATCH_BYTES)), 'mg_det_init')
+        _DET_READY = True
 
 
 def code_of(dtype):
@@ -124,6 +149,8 @@ _FN = {}
 
 
 def call(name, *args, work=None, tag=None):
+    if not _DET_READY:
+        _det_init()
     fn = _FN.get(name)
     if fn is None:
         fn = getattr(lib(), name)
@@ -176,4 +203,5 @@ class WbEntry(ctypes.Structure):
 class SnDesc(ctypes.Structure):
     _fields_ = [('W', ctypes.c_void_p), ('u', ctypes.c_void_p), ('v', ctypes.c_void_p), ('out_off', ctypes.c_int64),
                 ('work_off', ctypes.c_int64), ('dw_off', ctypes.c_int64), ('A', ctypes.c_int32), ('B', ctypes.c_int32),
-                ('taps', ctypes.c_int32), ('transposed', ctypes.c_int32), ('pad_in', ctypes.c_int32), ('plain', ctypes.c_int32)]
+                ('taps', ctypes.c_int32), ('transposed', ctypes.c_int32), ('pad_in', ctypes.c_int32), ('plain', ctypes.c_int32),
+                ('k3_first', ctypes.c_int32), ('k3_count', ctypes.c_int32)]

@@ -66,16 +66,18 @@ def conv_fprop(x, w, *, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=None, Wout=None,
         assert res.dtype == x.dtype
     if res2 is not None:
         assert res2.dtype == x.dtype
-    stat_mode = 0
+    stat_mode = stat_rep = 0
     if stats is not None:
         stat_mode = 1 if stats.dim() == 1 else 0                 # 1-D [2*Cout]: single row, column sums only
-        assert stats.dtype == torch.float32 and stats.numel() >= (1 if stat_mode else STAT_REPLICAS) * 2 * Cout
+        stat_rep = 0 if stat_mode else stats.shape[0]            # rows of the statistics buffer: output tile t adds to row t % rows
+        assert stats.dtype == torch.float32 and stats.numel() >= (1 if stat_mode else stat_rep) * 2 * Cout and stats.is_contiguous()
+        assert not (stat_mode and hip.DETERMINISTIC), 'a sums-only statistics row is accumulated with atomics: not available in deterministic mode' 
     for v in (scale, shift):
         if v is not None:
             assert v.dtype == torch.float32 and v.numel() >= Cout
     p = _conv_params(x, w, out, mode, N, Hin, Win, Hout, Wout, R, S, stride, pad, dil, M, Cin, Cout, nbr, scale, shift,
                      res, res_mode, res2, act, pre_act, slope, stats, yoff)
-    p.stat_mode = stat_mode
+    p.stat_mode, p.stat_rep = stat_mode, stat_rep
     p.m_dev = hip.ptr(rows)                    # device row count (sparse head): M is then the capacity, the launch a persistent grid
     if bnb is not None:
         # this launch produces the gradient at the OUTPUT of a training BatchNorm layer: its epilogue writes g = dz * act'(z) and accumulates
@@ -176,16 +178,32 @@ from .hip import RowwiseParams, c_int, c_float, c_long  # noqa: E402
 STAT_REPLICAS = 32
 
 
+def stat_rows():
+    """Rows of a BatchNorm statistics scratch filled by the column-statistics kernels: 32 replicas that only spread same-address atomics, or --
+    deterministic mode -- 1024 >= the row-block count, one row per row block (MG_DET_STAT_ROWS, csrc/common.h)."""
+    return 1024 if hip.DETERMINISTIC else STAT_REPLICAS
+
+
+def conv_stat_rows(M, N=1, Hout=1, Wout=1):
+    """Rows of the statistics buffer a conv epilogue adds into: in deterministic mode at least the number of output tiles of ANY kernel form
+    (spatial halo tiles of >= 4 x 16 pixels, row tiles of >= 64 rows, the four padded phases of a stride-2 transposed walk), so that every
+    word receives exactly one addition; rows nobody writes stay zero."""
+    if not hip.DETERMINISTIC:
+        return STAT_REPLICAS
+    return max(N * ((Hout + 3) // 4) * ((Wout + 15) // 16), (M + 63) // 64 + 8, STAT_REPLICAS + 1)
+
+
 def ACC(n, device, dtype=torch.float32):
     """Accumulator the callee clears itself; functional.py re-points this at its zero arena (ZeroArena.acc)."""
     return torch.empty(n, dtype=dtype, device=device)
 
 
 def colstats(x, stats=None):
-    """stats[STAT_REPLICAS][2C] (fp32) += column sum / sum of squares of x (M, C), spread over replicas."""
+    """stats[stat_rows()][2C] (fp32) += column sum / sum of squares of x (M, C), spread over the rows."""
     M, C = x.shape[0], x.shape[-1]
     if stats is None:
-        stats = torch.zeros((STAT_REPLICAS, 2 * C), dtype=torch.float32, device=x.device)
+        stats = torch.zeros((stat_rows(), 2 * C), dtype=torch.float32, device=x.device)
+    assert stats.numel() >= stat_rows() * 2 * C
     hip.need_cuda(x, stats)
     hip.call('mg_colstats', hip.ptr(x), c_int(hip.dtype_code(x)), c_int(M), c_int(C), c_int(_ld(x)), hip.ptr(stats), hip.stream())
     return stats
@@ -310,16 +328,27 @@ def bn_bwd_apply_linked(g, x, outs, sums_rep, count, mask_x_pos=False, rows=None
     return dx, sums
 
 
+def stats_ws_floats(C, exact=False):
+    """Size of the statistics scratch mg_bn_train_fwd wants: [2C] for the exact two-pass variance, [32][2C] replicas otherwise -- in
+    deterministic mode always [1024][2C] (one row per row block; the exact form then only runs inside one workgroup, without scratch)."""
+    if hip.DETERMINISTIC:
+        return 2 * stat_rows() * C
+    return (2 if exact else 2 * STAT_REPLICAS) * C
+
+
 def bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, act, slope, res=None, res_mode=1, H=1, W=1, stats=None,
                  exact=False, stats_ws=None, rows=None):
     """Training BatchNorm forward in ONE C call (statistics -> finalize -> apply): -> y, outs = scale|shift|mean|invstd (4C).
-    `stats_ws`: zeroed scratch for the statistics ([2C] with `exact`, else [STAT_REPLICAS * 2C]); None: allocated and zeroed here."""
+    `stats_ws`: zeroed scratch of stats_ws_floats(C, exact) floats for the statistics; None: allocated and zeroed here."""
     M, C = x.shape[0], x.shape[-1]
     y = torch.empty((M, C), dtype=x.dtype, device=x.device)
     outs = torch.empty(4 * C, dtype=torch.float32, device=x.device)
     zeroed = stats_ws is not None
+    two_pass = exact or rows is not None                      # a device row count always takes the two-pass form (outside deterministic mode)
+    if stats_ws is not None:
+        assert stats_ws.numel() >= stats_ws_floats(C, two_pass), (stats_ws.numel(), C, exact)
     if stats_ws is None and stats is None:
-        stats_ws = torch.empty((2 if exact else 2 * STAT_REPLICAS) * C, dtype=torch.float32, device=x.device)
+        stats_ws = torch.empty(stats_ws_floats(C, two_pass), dtype=torch.float32, device=x.device)
     p = _rowwise(x, M, C)
     p.y, p.ldy, p.yoff = hip.ptr(y), C, 0
     if res is not None:
@@ -500,6 +529,16 @@ def gather_rows(dense, coords, n_i, mul=None, out=None, yoff=0, rows=None):
 def gather_rows_bwd(dout, coords, n_i, dense_shape, mul=None, dense=None, yoff=0, want_ddense=True, want_dmul=False, rows=None):
     N, Hd, Wd, C = dense_shape
     R = coords.shape[0]
+    if hip.DETERMINISTIC and not want_ddense and want_dmul and mul is not None and 256 % (C // (8 if dout.element_size() == 2 else 4)) == 0:
+        # bit-reproducible form: per-plane row ranges, fixed-order sums (csrc/sparse.hip: gather_rows_dmul_det_kernel)
+        dmul = torch.empty_like(mul)
+        hip.need_cuda(dout, coords, dense, mul)
+        assert dense.is_contiguous() and mul.dtype == torch.float32
+        hip.call('mg_gather_rows_dmul_det', hip.ptr(dout), c_int(hip.dtype_code(dout)), c_int(_ld(dout)), c_int(yoff), hip.ptr(coords), c_int(R), c_int(n_i),
+                 c_int(N), c_int(Hd), c_int(Wd), c_int(C), c_int(mul.shape[1]), hip.ptr(dense), hip.ptr(dmul), hip.ptr(rows), hip.stream())
+        return None, dmul
+    if hip.DETERMINISTIC and want_ddense:
+        raise hip.MaggieHipError('gather_rows_bwd(want_ddense=True) scatters with atomics: use gather_rows_bwd_dense in deterministic mode')
     ddense = torch.zeros(dense_shape, dtype=torch.float32, device=dout.device) if want_ddense else None
     dmul = torch.zeros_like(mul) if (want_dmul and mul is not None) else None
     hip.call('mg_gather_rows_bwd_dev', hip.ptr(dout), c_int(hip.dtype_code(dout)), c_int(_ld(dout)), c_int(yoff), hip.ptr(coords), c_int(R),

@@ -136,11 +136,11 @@ class _BN:
             mom = 0.1 if bn.momentum is None else bn.momentum
             if self.group is None:
                 self.y, self.pack = K.bn_train_fwd(x, gamma, beta, bn.running_mean, bn.running_var, mom, bn.eps, self.act, SLOPE,
-                                                   stats_ws=MF.ARENA.take(2 * C, x.device), rows=rows)
+                                                   stats_ws=MF.ARENA.take(K.stats_ws_floats(C, True), x.device), rows=rows)
                 return self.y
             # SyncBN: pooled moments of all ranks' live rows; the (variable) row count rides along in the pack
             from .parallel import syncbn_exchange_forward
-            stats = torch.zeros((K.STAT_REPLICAS, 2 * C), dtype=torch.float32, device=x.device)
+            stats = torch.zeros((K.stat_rows(), 2 * C), dtype=torch.float32, device=x.device)
             K.hip.call('mg_colstats_dev', K.hip.ptr(x), K.c_int(K.hip.dtype_code(x)), K.c_int(x.shape[0]), K.c_int(C), K.c_int(C), K.hip.ptr(stats),
                        K.hip.ptr(rows), K.hip.stream())
             pack = syncbn_exchange_forward(torch.cat([stats.sum(0), rows.float()]), self.group)
