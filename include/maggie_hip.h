@@ -150,6 +150,11 @@ typedef struct mg_rowwise_params {
     float slope, count;
     const int32_t* m_dev; /* optional DEVICE row count (see mg_conv_params.m_dev): rows = min(*m_dev, M); BatchNorm then uses it as
                              the sample count (exact two-pass variance), NULL: M rows */
+    int32_t count_mult;   /* mg_bn_train_fwd: every row stands for count_mult samples in the unbiased running-variance factor n / (n - 1)
+                             (0 = 1). The decoder's skip branch (UpsamplingNearest2d(2) -> 1x1 conv -> BatchNorm, maggie/network/decoder/resnet.py:
+                             143-147 of the reference) is evaluated BEFORE the up-sampling here: mean and biased variance are unchanged by the 2x2
+                             replication, the reference's sample count is 4x the rows (count_mult = 4) */
+    int32_t reserved0;
 } mg_rowwise_params;
 
 /* stats[rep][c] += sum_m x[m,c], stats[rep][C+c] += sum_m x[m,c]^2 (fp32 [MG_STAT_REPLICAS][2C], pre-zeroed) */

@@ -207,7 +207,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int nrep, co
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
                                    float* running_var, float momentum, float eps, float* __restrict__ scale,
                                    float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ invstd_out,
-                                   const int32_t* __restrict__ m_dev) {
+                                   const int32_t* __restrict__ m_dev, float nmult) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float n = count_ptr ? *count_ptr : count;
@@ -228,7 +228,8 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int nrep, co
     mean_out[c] = mean;
     invstd_out[c] = invstd;
     if (running_mean) {
-        float unbiased = n > 1.f ? var * n / (n - 1.f) : var;
+        const float nu = n * nmult;                           // samples the reference's BatchNorm saw (rows x count_mult)
+        float unbiased = nu > 1.f ? var * nu / (nu - 1.f) : var;
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
     }
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(NT) void bn_finalize_rows_kernel(const float* __res
                                                              int centered, const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
                                                              float* running_var, float momentum, float eps, float* __restrict__ scale,
                                                              float* __restrict__ shift, float* __restrict__ mean_out, float* __restrict__ invstd_out,
-                                                             const int32_t* __restrict__ m_dev) {
+                                                             const int32_t* __restrict__ m_dev, float nmult) {
     __shared__ float sh[2][NT];
     const int c = blockIdx.x, t = threadIdx.x;
     float n = count_ptr ? *count_ptr : count;
@@ -279,7 +280,8 @@ __global__ __launch_bounds__(NT) void bn_finalize_rows_kernel(const float* __res
     mean_out[c] = mean;
     invstd_out[c] = invstd;
     if (running_mean) {
-        float unbiased = n > 1.f ? var * n / (n - 1.f) : var;
+        const float nu = n * nmult;                           // samples the reference's BatchNorm saw (rows x count_mult)
+        float unbiased = nu > 1.f ? var * nu / (nu - 1.f) : var;
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
     }
@@ -802,13 +804,14 @@ extern "C" int mg_colstats_centered_dev(const void* x, int dtype, int M, int C, 
 
 static int bn_finalize_launch(const float* stats, int nrep, const float* count_ptr, float count, int C, int centered, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
-                              float* mean_out, float* invstd_out, const int32_t* m_dev, void* stream) {
+                              float* mean_out, float* invstd_out, const int32_t* m_dev, void* stream, int count_mult = 1) {
+    const float nmult = count_mult > 1 ? (float)count_mult : 1.f;
     if (nrep > MG_STAT_REPLICAS)
         hipLaunchKernelGGL(bn_finalize_rows_kernel, dim3(C), dim3(NT), 0, (hipStream_t)stream, stats, nrep, count_ptr, count, C, centered, gamma,
-                           beta, running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out, m_dev);
+                           beta, running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out, m_dev, nmult);
     else
         hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, (hipStream_t)stream, stats, nrep, count_ptr, count, C, centered, gamma,
-                           beta, running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out, m_dev);
+                           beta, running_mean, running_var, momentum, eps, scale, shift, mean_out, invstd_out, m_dev, nmult);
     MG_CHECK_LAUNCH();
     return 0;
 }
@@ -995,7 +998,7 @@ __global__ __launch_bounds__(NT) void bn_small_fwd_kernel(const mg_rowwise_param
             const int c = c0 + e;
             outs[c] = sc[e]; outs[C + c] = sh[e]; outs[2 * C + c] = mean[e]; outs[3 * C + c] = invstd;
             if (running_mean) {
-                const float n = (float)M, unbiased = n > 1.f ? var[e] * n / (n - 1.f) : var[e];
+                const float n = (float)M * (p.count_mult > 1 ? (float)p.count_mult : 1.f), unbiased = n > 1.f ? var[e] * n / (n - 1.f) : var[e];
                 running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean[e];
                 running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
             }
@@ -1165,7 +1168,7 @@ extern "C" int mg_bn_train_fwd(const mg_rowwise_params* p_in, float* stats_ws, i
         } else if (exact && stats_in_rows == 1) return -3;       // a sums-only row of a conv epilogue is not reproducible: callers hand over row sets
         p.count = (float)p.M;
         rc = bn_finalize_launch(stats, nrep, nullptr, (float)p.M, C, 0, gamma, beta, running_mean, running_var, momentum, eps, outs, outs + C, outs + 2 * C,
-                                outs + 3 * C, p.m_dev, stream);
+                                outs + 3 * C, p.m_dev, stream, p.count_mult);
         if (rc) return rc;
         p.scale = outs; p.shift = outs + C;
         return mg_affine_act(&p, stream);
@@ -1196,8 +1199,8 @@ extern "C" int mg_bn_train_fwd(const mg_rowwise_params* p_in, float* stats_ws, i
     }
     p.count = (float)p.M;
     if (bn_fused_ok(p)) return bn_apply_fused_launch(p, stats, nrep, centered, gamma, beta, running_mean, running_var, momentum, eps, outs, st);
-    rc = mg_bn_finalize(stats, nrep, nullptr, (float)p.M, C, centered, gamma, beta, running_mean, running_var, momentum, eps, outs, outs + C,
-                        outs + 2 * C, outs + 3 * C, stream);
+    rc = bn_finalize_launch(stats, nrep, nullptr, (float)p.M, C, centered, gamma, beta, running_mean, running_var, momentum, eps, outs, outs + C,
+                            outs + 2 * C, outs + 3 * C, nullptr, stream, p.count_mult);
     if (rc) return rc;
     p.scale = outs; p.shift = outs + C;
     return mg_affine_act(&p, stream);

@@ -671,7 +671,7 @@ class BNAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, res, running_mean, running_var, training, momentum, eps, act, stats, res_mode, group,
-                mask_x_pos, link=None):
+                mask_x_pos, link=None, count_mult=1):
         ctx.link = None
         shape = x.shape
         C = shape[-1]
@@ -689,7 +689,7 @@ class BNAct(torch.autograd.Function):
             small = exact and 1 < M <= BN_SMALL_ROWS              # one workgroup per channel chunk: no statistics scratch at all
             ws = ARENA.take(K.stats_ws_floats(C, exact), x.device) if (own and not small) else None      # zeroed once per step / per graph
             y, pack = K.bn_train_fwd(x2, gamma, beta, running_mean, running_var, momentum, eps, act, LRELU_SLOPE, r2, res_mode, H, W_,
-                                     stats, exact, ws)
+                                     stats, exact, ws, count_mult=count_mult)
             ctx.save_for_backward(x2, y, pack)
             ctx.fast = True
             ctx.meta = (shape, M, C, act, res is not None, res_mode, training, group, mask_x_pos, C, res.shape if res is not None else None)
@@ -760,7 +760,7 @@ class BNAct(torch.autograd.Function):
                 link.clear()
                 if has_res:
                     dres = K.pool2x2(dres, 1, shape[0], shape[1] // 2, shape[2] // 2).view(res_shape) if res_mode == 2 else dres.view(res_shape)
-                return dx.view(shape), sums[C:], sums[:C], dres, None, None, None, None, None, None, None, None, None, None, None
+                return dx.view(shape), sums[C:], sums[:C], dres, None, None, None, None, None, None, None, None, None, None, None, None
             if link is not None:
                 link.clear()
             # inside a graph capture the accumulator is a slice of the graph's own zero arena (no fill kernel per layer); eagerly the
@@ -769,7 +769,7 @@ class BNAct(torch.autograd.Function):
             dx, dres, sums = K.bn_train_bwd(dy.contiguous().view(-1, C), y, x2, pack, act, LRELU_SLOPE, has_res, mask_x_pos, sums)
             if has_res:
                 dres = K.pool2x2(dres, 1, shape[0], shape[1] // 2, shape[2] // 2).view(res_shape) if res_mode == 2 else dres.view(res_shape)
-            return dx.view(shape), sums[C:], sums[:C], dres, None, None, None, None, None, None, None, None, None, None, None
+            return dx.view(shape), sums[C:], sums[:C], dres, None, None, None, None, None, None, None, None, None, None, None, None
         x2, y, scale, mean, invstd, cnt_t = ctx.saved_tensors
         shape, M, C, act, has_res, res_mode, training, group, mask_x_pos, nch, res_shape = ctx.meta
         dy2 = dy.contiguous().view(-1, C)
@@ -801,10 +801,10 @@ class BNAct(torch.autograd.Function):
                 dres = K.pool2x2(dres, 1, N, H // 2, W_ // 2).view(res_shape)
             else:
                 dres = dres.view(res_shape)
-        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, dres, None, None, None, None, None, None, None, None, None, None, None, None
 
 
-def batch_norm_act(x, bn, act=ACT_NONE, res=None, stats=None, res_mode=1, mask_x_pos=False, link=None):
+def batch_norm_act(x, bn, act=ACT_NONE, res=None, stats=None, res_mode=1, mask_x_pos=False, link=None, count_mult=1):
     """`bn` is an nn.BatchNorm{1,2}d / nn.SyncBatchNorm used as the parameter + running-stat holder."""
     training = bn.training or (bn.running_mean is None)
     if training and bn.num_batches_tracked is not None and not DEFER_BN_COUNTERS:
@@ -814,7 +814,7 @@ def batch_norm_act(x, bn, act=ACT_NONE, res=None, stats=None, res_mode=1, mask_x
             bn.num_batches_tracked.add_(1)
     mom = 0.1 if bn.momentum is None else bn.momentum
     return BNAct.apply(x, bn.weight, bn.bias, res, bn.running_mean, bn.running_var, training, mom, bn.eps, act, stats, res_mode,
-                       _sync_group(bn) if training else None, mask_x_pos, link)
+                       _sync_group(bn) if training else None, mask_x_pos, link, count_mult)
 
 
 def new_stats(channels, device, rows=None, bn=None, geom=None):
@@ -831,7 +831,7 @@ def new_stats(channels, device, rows=None, bn=None, geom=None):
 
 
 def conv_bn_act(x, w, bn, act=ACT_NONE, R=3, S=3, stride=1, pad=1, dil=1, transposed=False, res=None, res_mode=1, res2=None,
-                relu_before_bn=False, bias=None, carry=False, link_out=False):
+                relu_before_bn=False, bias=None, carry=False, link_out=False, count_mult=1):
     """conv -> BN -> (+res) -> act (-> +res2).  In inference (no grad, eval BN) this is ONE fused kernel; in training the
     conv epilogue accumulates the batch statistics and a second HBM pass applies them.
     `link_out`: the caller guarantees that the returned activation is consumed by exactly ONE conv2d / conv_bn_act call (see BnLink)."""
@@ -868,7 +868,8 @@ def conv_bn_act(x, w, bn, act=ACT_NONE, R=3, S=3, stride=1, pad=1, dil=1, transp
     else:
         y = conv2d(x, w, bias, R, S, stride, pad, dil, transposed, relu_before_bn, stats, mask_upstream=mask_up)
     link = BnLink() if (link_out and BN_LINK and bn.training and res2 is None and torch.is_grad_enabled()) else None
-    y = batch_norm_act(y, bn, ACT_NONE if relu_before_bn else act, res=res, stats=stats, res_mode=res_mode, mask_x_pos=mask_up, link=link)
+    y = batch_norm_act(y, bn, ACT_NONE if relu_before_bn else act, res=res, stats=stats, res_mode=res_mode, mask_x_pos=mask_up, link=link,
+                       count_mult=count_mult)
     if link is not None and link.x2 is not None:
         y._mg_bnlink = link
     if res2 is not None:

@@ -219,6 +219,17 @@ class GraphedCallable:
             return
         acc = [(v, p.grad) for v, p in zip(self.sink_views, self.params) if p.grad is not None and p.grad.data_ptr() == v.data_ptr()]
         if acc:
+            # Under the overlapped exchange the slots may still be written by the SIDE stream (the in-place all-reduce of the previous backward and
+            # the add-back of the earlier sum): the clone below and the replay that follows must see them finished. The events stay in the owner's
+            # list -- the optimizer's wait() still covers them.
+            owner = getattr(self.grad_hook, '__self__', None) if self.grad_hook is not None else None
+            if owner is not None and acc[0][0].is_cuda:
+                cur = torch.cuda.current_stream()
+                for ev in list(getattr(owner, 'events', ())):
+                    cur.wait_event(ev)
+                side = getattr(owner, 'stream', None)
+                if side is not None:
+                    cur.wait_stream(side)
             self._sink_saved = ([v for v, _ in acc], [g.clone() for _, g in acc])
 
     def _export_to_sink(self):

@@ -179,6 +179,7 @@ class RowwiseParams(ctypes.Structure):
         ('act', ctypes.c_int32), ('res_mode', ctypes.c_int32), ('mask_x_pos', ctypes.c_int32),
         ('slope', ctypes.c_float), ('count', ctypes.c_float),
         ('m_dev', ctypes.c_void_p),
+        ('count_mult', ctypes.c_int32), ('reserved0', ctypes.c_int32),
     ]
 
 

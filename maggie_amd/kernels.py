@@ -337,7 +337,7 @@ def stats_ws_floats(C, exact=False):
 
 
 def bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, act, slope, res=None, res_mode=1, H=1, W=1, stats=None,
-                 exact=False, stats_ws=None, rows=None):
+                 exact=False, stats_ws=None, rows=None, count_mult=1):
     """Training BatchNorm forward in ONE C call (statistics -> finalize -> apply): -> y, outs = scale|shift|mean|invstd (4C).
     `stats_ws`: zeroed scratch of stats_ws_floats(C, exact) floats for the statistics; None: allocated and zeroed here."""
     M, C = x.shape[0], x.shape[-1]
@@ -355,6 +355,7 @@ def bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, act, 
         p.res, p.ldr, p.res_mode = hip.ptr(res), _ld(res), res_mode
     p.act, p.slope, p.H, p.W = act, slope, H, W
     p.m_dev = hip.ptr(rows)                    # device row count: always the exact two-pass variance over the live rows
+    p.count_mult = int(count_mult)             # every row stands for this many samples of the reference's BatchNorm (unbiased running variance)
     srows = 0 if stats is None else (stats.shape[0] if stats.dim() == 2 else 1)
     hip.call('mg_bn_train_fwd', ctypes.byref(p), hip.ptr(stats_ws), c_int(int(zeroed)), hip.ptr(outs), hip.ptr(stats), c_int(srows), c_int(int(exact)),
              hip.ptr(gamma), hip.ptr(beta), hip.ptr(running_mean), hip.ptr(running_var), c_float(momentum), c_float(eps), hip.stream())

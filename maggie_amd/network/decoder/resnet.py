@@ -35,8 +35,9 @@ class BasicBlock(nn.Module):
         if self.upsample is not None:
             u = self.upsample
             if isinstance(u[0], Marker):
-                # UpsamplingNearest2d(2) -> SN 1x1 -> BN  ==  (SN 1x1 -> BN) at low resolution, replicated 2x2 in the residual add
-                identity = MF.conv_bn_act(x, u[1].krsc(dt, x.shape[-1]), u[2], MF.ACT_NONE, 1, 1, 1, 0, 1)
+                # UpsamplingNearest2d(2) -> SN 1x1 -> BN  ==  (SN 1x1 -> BN) at low resolution, replicated 2x2 in the residual add. Mean and
+                # biased variance are those of the replicated tensor; its BatchNorm counts 4 samples per row (unbiased running variance)
+                identity = MF.conv_bn_act(x, u[1].krsc(dt, x.shape[-1]), u[2], MF.ACT_NONE, 1, 1, 1, 0, 1, count_mult=4)
                 res_mode = 2
             else:
                 identity = MF.conv_bn_act(x, u[0].krsc(dt, x.shape[-1]), u[1], MF.ACT_NONE, 1, 1, 1, 0, 1)

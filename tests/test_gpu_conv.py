@@ -254,10 +254,16 @@ def test_conv_fprop_split_k(case, dtype):
             and W >= 16 and H >= 4)
     need = K._fprop_workspace_fn()(ctypes.byref(p))
     assert need == 0 if halo else need >= 2 * N * Ho * Wo * Cout
-    for stat_rows in (K.STAT_REPLICAS, 1):
-        stats = torch.zeros((stat_rows, 2 * Cout), device=dev) if stat_rows > 1 else torch.zeros(2 * Cout, device=dev)
-        y = K.conv_fprop(xd.view(-1, Cin), wd, scale=scale.to(dev), shift=shift.to(dev), res=_nhwc(res).to(dev, dtype).view(-1, Cout),
-                         res_mode=2 if even else 1, res2=_nhwc(res2).to(dev, dtype).view(-1, Cout), act=K.ACT_LRELU, slope=0.2, stats=stats, **geo)
+    # statistics rows: 32 replicas (the atomic form), one row per output tile (the deterministic form), one sums-only row (feeds the exact
+    # two-pass variance; accumulated with atomics, so only outside deterministic mode)
+    for stat_rows in (K.STAT_REPLICAS, K.conv_stat_rows(N * Ho * Wo, N, Ho, Wo), 1):
+        hip.set_deterministic(stat_rows != 1)
+        try:
+            stats = torch.zeros((stat_rows, 2 * Cout), device=dev) if stat_rows > 1 else torch.zeros(2 * Cout, device=dev)
+            y = K.conv_fprop(xd.view(-1, Cin), wd, scale=scale.to(dev), shift=shift.to(dev), res=_nhwc(res).to(dev, dtype).view(-1, Cout),
+                             res_mode=2 if even else 1, res2=_nhwc(res2).to(dev, dtype).view(-1, Cout), act=K.ACT_LRELU, slope=0.2, stats=stats, **geo)
+        finally:
+            hip.set_deterministic(True)
         yf = y.float().cpu().reshape(N, Ho, Wo, Cout).permute(0, 3, 1, 2)
         assert (yf - y_ref.detach()).abs().max().item() <= _tol(dtype) * y_ref.abs().max().item()
         s = stats.sum(0).cpu() if stat_rows > 1 else stats.cpu()

@@ -221,6 +221,90 @@ def test_bf16_step_at_the_reference_autocast_noise_floor(size):
     assert float(d_h.mean()) <= float(d_cpu.mean()) + 1e-3 and float(d_h.mean()) <= float(d_gpu.mean()) + 1e-3
 
 
+def test_config3_geometry_video_t3_512():
+    """BASELINE configs[3]: maggie_video.yaml, T = 3 frames, 512x512, 2 instances, temporal-sparse refinement on, one GPU (reference:
+    configs/maggie_video.yaml:32-37, arch/maggie_temp.py, decoder/resnet_inst_matt_spconv_temp.py). Train: shapes, range, fusion invariant,
+    finite losses / gradients, and the step replayed from hipGraphs EQUALS the eager step bit for bit (deterministic mode). Eval: shapes and the
+    temporal outputs, the graph replay equals the eager forward, and the index map is the region pipeline of the reference applied to the
+    model's OWN coarse alpha (oracle/refmodel.py:video_eval_region restates resnet_inst_matt_spconv_temp.py:115-142), bit for bit."""
+    from maggie_amd.utils import synth
+    from oracle import refmodel
+    dev = _dev()
+    n_f, n_inst, hw = 3, 2, 512
+    # ---- train (one clip: b = 1, as configs[3] says; fp32 so that "equal" means equal)
+    model, _ = _build('video', dev, True)
+    batch = _to(synth.synthetic_batch(1, n_f, n_inst, hw, hw, seed=DSEED, train=True, max_inst=10, it=10000), dev)
+    state = copy.deepcopy(model.state_dict())
+    res = []
+    for graphs in (False, True, True, True):                                         # eager, first sight, capture, replay
+        model.load_state_dict(state)
+        rng = model.decoder.__dict__.get('_head_rng')
+        if rng is not None:
+            rng.state.copy_(torch.tensor([11, 0], dtype=torch.int64))
+        model.hip_graphs = graphs
+        model.zero_grad(set_to_none=True)
+        seed_all(11)
+        out, loss = model(batch)
+        loss['total'].backward()
+        res.append(({k: v.detach().clone() for k, v in out.items() if torch.is_tensor(v)}, {k: float(v.detach()) for k, v in loss.items()},
+                    torch.cat([p.grad.flatten().float() for p in model.parameters() if p.grad is not None]).clone()))
+    out, loss, g = res[0]
+    _check_outputs(out, (1, n_f, 10, hw, hw))
+    for k in ('diff_pred_forward', 'diff_pred_backward', 'temp_alpha'):
+        assert bool(torch.isfinite(out[k].float()).all()), k
+    assert all(np.isfinite(v) for v in loss.values()), loss
+    assert 'loss_temp' in loss and any(k.startswith('loss_dtSSD') for k in loss), sorted(loss)     # the temporal loss terms of the video recipe
+    assert bool(torch.isfinite(g).all()) and float(g.norm()) > 0
+    m = out['detail_mask'].float()
+    assert 0.0 < float(m[:, :, :n_inst].mean()) < 1.0 and float(m[:, :, n_inst:].sum()) == 0.0
+    for i in (2, 3):                                                                   # capture and replay against eager: the same bits
+        o_r, l_r, g_r = res[i]
+        assert l_r == loss, (i, l_r, loss)
+        for k in out:
+            assert torch.equal(o_r[k], out[k]), (i, k, float((o_r[k].float() - out[k].float()).abs().max()))
+        assert torch.equal(g_r, g), (i, float((g_r - g).norm() / g.norm()))
+    # ---- eval (the 3-frame window of engine/test.py:219 with the alpha-level post-fusion of arch/maggie_temp.py:34-77)
+    model, _ = _build('video', dev, False)
+    ebatch = synth.synthetic_batch(1, n_f, n_inst, hw, hw, seed=DSEED, train=False)
+    seen = {}
+    orig = model.decoder.detail_stage
+
+    def spy(dense, *a, **k):
+        seen['x_os8'] = dense[0].detach().float().cpu().clone()
+        return orig(dense, *a, **k)
+
+    model.decoder.detail_stage = spy
+    model.hip_graphs = False
+    with torch.no_grad():
+        e_out = model(_to(ebatch, dev))
+    for k in ('alpha_os8', 'alpha_os4', 'alpha_os1', 'refined_masks', 'detail_mask', 'temp_alpha'):
+        assert e_out[k].shape == (1, n_f, n_inst, hw, hw), (k, e_out[k].shape)
+        assert bool(torch.isfinite(e_out[k].float()).all())
+    assert e_out['diff_pred_forward'].shape[:2] == (1, n_f) and e_out['diff_pred_backward'].shape[:2] == (1, n_f)
+    x8 = seen['x_os8'][:, :n_inst]
+    ref_a8, ref_mask = refmodel.video_eval_region(x8, n_inst, hw, hw)
+    dm = e_out['detail_mask'].cpu().reshape(-1, n_inst, hw, hw)
+    assert dm.float().sum() > 0
+    assert torch.equal(dm.float(), ref_mask.float()), 'detail mask: %d pixels differ' % int((dm.float() != ref_mask.float()).sum())
+    assert torch.equal(e_out['alpha_os8'].float().cpu().reshape(-1, n_inst, hw, hw), ref_a8)
+    model.decoder.detail_stage = orig
+    model.hip_graphs = True
+    sd0 = copy.deepcopy(model.state_dict())
+    outs = []
+    for _ in range(3):                                                                 # SpectralNorm advances u / v per forward: restart from one state
+        model.load_state_dict(sd0)
+        with torch.no_grad():
+            o = model(_to(ebatch, dev))
+        outs.append({k: v.detach().clone() for k, v in o.items() if torch.is_tensor(v)})
+    model.load_state_dict(sd0)
+    model.hip_graphs = False
+    with torch.no_grad():
+        o_e = model(_to(ebatch, dev))
+    for k in ('alpha_os8', 'alpha_os1', 'refined_masks', 'detail_mask', 'temp_alpha'):
+        assert torch.equal(outs[2][k], outs[1][k]), k
+        assert torch.equal(outs[2][k], o_e[k]), (k, float((outs[2][k].float() - o_e[k].float()).abs().max()))
+
+
 @pytest.mark.parametrize('clips', [2])
 def test_config4_geometry_768_video_t5_stays_finite(clips):
     """BASELINE configs[4] geometry: maggie_video.yaml, T = 5, 768x768, 3 instances, bf16 -- 10 optimizer steps stay finite.

@@ -406,11 +406,13 @@ def test_rank_safe_graphs_one_detail_graph_serves_both_guidance_sources():
     assert n_safe == 1, 'rank-safe mode must serve both guidance sources from ONE captured detail graph (got %d)' % n_safe
     assert n_plain == 2, 'plain mode keys the detail graph by use_gt (got %d graphs)' % n_plain
     assert not torch.equal(safe[2][2], safe[5][2]), 'the two guidance sources must give different detail regions for this test to mean anything'
+    # Deterministic mode (default: every cross-workgroup sum in a fixed order, csrc/det.hip): the two modes run the same kernels on the same
+    # data, so loss, alphas, detail mask and gradients are EQUAL -- not close (round 3 compared them with noise-sized bars and still flaked)
     for i, (a, b_) in enumerate(zip(safe, plain)):
-        assert abs(a[0] - b_[0]) <= 2e-4 * max(1.0, abs(b_[0])), (i, a[0], b_[0])
+        assert a[0] == b_[0], (i, a[0], b_[0])
         assert torch.equal(a[2], b_[2]), 'detail mask, step %d' % i
-        assert (a[1] - b_[1]).abs().max().item() <= 1e-3, i         # (two eager runs of the same step differ by ~2e-4: fp32 atomics under train-mode BatchNorm)
-        assert (a[3] - b_[3]).norm().item() <= 8e-2 * b_[3].norm().item(), i      # (structural errors -- a missing or doubled gradient -- are O(1))
+        assert torch.equal(a[1], b_[1]), 'refined alpha, step %d: max diff %g' % (i, (a[1] - b_[1]).abs().max().item())
+        assert torch.equal(a[3], b_[3]), 'gradients, step %d: rel diff %g' % (i, (a[3] - b_[3]).norm().item() / b_[3].norm().item())
 
 
 def _syncbn_worker(mode, port):
@@ -423,8 +425,6 @@ def _syncbn_worker(mode, port):
     out, err = pr.stdout.decode(errors='replace'), pr.stderr.decode(errors='replace')
     line = [l for l in out.splitlines() if l.startswith('RESULT ')]
     if pr.returncode != 0 or not line:
-        if 'CapturedEvent' in err or 'operation not permitted when stream is capturing' in err:
-            pytest.skip('known ROCm 7.2 flake: the process-group watchdog queried an event during capture (DESIGN.md section 6)')
         raise AssertionError('syncbn worker %s failed (rc %d):\n%s' % (mode, pr.returncode, err[-3000:]))
     return json.loads(line[-1][7:])
 

@@ -161,6 +161,30 @@ def test_train_step_matches_oracle_and_golden(kind, b, n_f, n_inst, hw, it, max_
     # running statistics were updated like the reference's BatchNorm
     msd = model.state_dict()
     assert np.abs(msd['encoder.bn1.running_mean'].cpu().numpy() - gold['bn/encoder.bn1.running_mean']).max() < 1e-4
+    # ... and EVERY buffer the step leaves behind agrees with the oracle's (which updated `sd` in place like the reference's modules do): all
+    # running_mean / running_var / num_batches_tracked (incl. the 9 sparse BatchNorm1d over active rows and the decoder's skip BatchNorm, which
+    # this build evaluates before the up-sampling: same mean / biased variance, 4 samples per row in the unbiased factor), all SpectralNorm u / v.
+    # Bars: relative to the buffer's own scale -- batch statistics over 2-32 samples per channel carry the same conditioning as the outputs above.
+    checked = {'running_mean': 0, 'running_var': 0, 'num_batches_tracked': 0, 'weight_u': 0, 'weight_v': 0}
+    worst_b = {}
+    for n, v in msd.items():
+        kind_ = n.rsplit('.', 1)[-1]
+        if kind_ not in checked or n.startswith('decoder.dummy_downscale'):
+            continue
+        r = sd[n].detach()
+        a = v.detach().cpu()
+        checked[kind_] += 1
+        if kind_ == 'num_batches_tracked':
+            assert int(a) == int(r), (n, int(a), int(r))
+            continue
+        scale_ = max(float(r.abs().max()), 1e-3)
+        err = float((a.float() - r.float()).abs().max()) / scale_
+        if err > worst_b.get(kind_, (0.0, None))[0]:
+            worst_b[kind_] = (err, n)
+    print('  buffers checked', checked, 'worst', {k: (round(e, 6), n) for k, (e, n) in worst_b.items()})
+    assert checked['running_mean'] >= 71 and checked['running_var'] >= 71 and checked['weight_u'] >= 54 and checked['weight_v'] >= 54, checked
+    assert worst_b.get('weight_u', (0.0, None))[0] <= 1e-5 and worst_b.get('weight_v', (0.0, None))[0] <= 1e-5, worst_b
+    assert worst_b.get('running_mean', (0.0, None))[0] <= 2e-3 and worst_b.get('running_var', (0.0, None))[0] <= 2e-3, worst_b
 
 
 def _oracle_train_step(kind, batch, dtype):
