@@ -1005,6 +1005,13 @@ __global__ __launch_bounds__(256) void igemm_fprop_halo_kernel(const mg_conv_par
     igemm_fprop_halo_tile<TH, BN, NS, MODE, BNB, T>(p, work, smem);
 }
 
+// Deterministic mode: the statistics buffer must have one row per output tile of the kernel form that runs (mg_conv_params.stat_rep) -- with
+// fewer rows two tiles would add to one word and their order would show. A caller that sized the buffer too small gets an error, not noise.
+#define MG_STAT_ROWS_SHORT (-8)
+static inline int stat_rows_check(const mg_conv_params& p, long mtiles) {
+    return (mg_det_on && p.stats && p.stat_mode == 0 && (long)(p.stat_rep > 0 ? p.stat_rep : MG_STAT_REPLICAS) < mtiles) ? MG_STAT_ROWS_SHORT : 0;
+}
+
 static inline bool halo_eligible(const mg_conv_params& p) {
     static const int enabled = [] { const char* e = getenv("MG_FPROP_HALO"); return e ? atoi(e) : 1; }();
     if (!enabled || !MG_IS16(p.dtype) || p.m_dev || p.mode == MG_MODE_GATHER) return false;
@@ -1027,6 +1034,7 @@ static int launch_fprop_halo(const mg_conv_params& p, hipStream_t st) {
         attr_set = true;
     }
     const long tiles = (long)p.N * ((p.Hout + TH - 1) / TH) * ((p.Wout + 15) / 16) * ((p.Cout + BN - 1) / BN);
+    if (int rcs = stat_rows_check(p, (long)p.N * ((p.Hout + TH - 1) / TH) * ((p.Wout + 15) / 16))) return rcs;
     dim3 grid(xcd_grid(tiles));
     if (p.bnb_x) {                                           // the data gradient of a 3x3 / stride 1 conv behind a BatchNorm layer
         if (p.mode != MG_MODE_TCONV) return -2;
@@ -1081,6 +1089,7 @@ int launch_fprop_async(const mg_conv_params& p, hipStream_t st) {
         attr_set = true;
     }
     const long tiles = (long)((p.M + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
+    if (int rcs = stat_rows_check(p, (p.M + BM - 1) / BM)) return rcs;
     if (p.bnb_x) {                                           // data gradient of a 1x1 conv behind a BatchNorm layer
         if (p.m_dev || p.mode != MG_MODE_TCONV) return -2;
         hipLaunchKernelGGL((igemm_fprop_async_kernel<BM, BN, KS, NS, MG_MODE_TCONV, true, T>), dim3(xcd_grid(tiles)), dim3(256), lds, st, p);
@@ -1125,6 +1134,7 @@ static int dispatch_fprop_async(const mg_conv_params& p, hipStream_t st) {
 template <typename T, int BM, int BN, int KS>
 int launch_fprop(const mg_conv_params& p, hipStream_t st) {
     dim3 grid(xcd_grid(row_tiles(p, p.M, BM) * ((p.Cout + BN - 1) / BN)));
+    if (int rcs = stat_rows_check(p, row_tiles(p, p.M, BM))) return rcs;
     constexpr size_t lds = lds_bytes<BM, BN, KS>();
     static bool attr_set = false;
     if (lds > 65536 && !attr_set) {
@@ -1368,6 +1378,7 @@ static int launch_fprop_split(const mg_conv_params& p, float* ws, int splits, hi
     if (rb < 1) rb = 1;
     if (rb > 512) rb = 512;
     const int rpb = (p.M + rb - 1) / rb;
+    if (int rcs = stat_rows_check(p, (p.M + rpb - 1) / rpb)) return rcs;
     hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3((p.M + rpb - 1) / rpb, groups), dim3(256), 0, st, p, (const float*)ws, splits, rpb);
     MG_CHECK_LAUNCH();
     return 0;
@@ -1451,6 +1462,7 @@ static inline bool fprop_c8_eligible(const mg_conv_params& p) {
 template <typename T>
 static int launch_fprop_c8(const mg_conv_params& p, hipStream_t st) {
     static const int th = [] { const char* e = getenv("MG_FPROP_C8_TH"); return e ? atoi(e) : 8; }();
+    if (int rcs = stat_rows_check(p, (long)p.N * ((p.Hout + 7) / 8) * ((p.Wout + 15) / 16))) return rcs;
     if (th == 16) {
         const long tiles = (long)p.N * ((p.Hout + 15) / 16) * ((p.Wout + 15) / 16);
         const size_t lds = (size_t)ctile_bytes<256, 32>() + (18 * 18 + 1) * 16;

@@ -611,7 +611,8 @@ class ConvRaw(torch.autograd.Function):
             if link is not None and link.ready() and link.C == Cin and link.M == N * H * W_ and link.x2.dtype == dy2.dtype:
                 # x is the output of a training BatchNorm layer with no other consumer: its backward reductions ride on this kernel's epilogue
                 Cb = link.C
-                sums_rep = ARENA.take(K.STAT_REPLICAS * 2 * Cb, dy2.device).view(K.STAT_REPLICAS, 2 * Cb)
+                nrow = K.conv_stat_rows(N * H * W_, N, H, W_)       # one row per output tile in deterministic mode, else 32 replicas
+                sums_rep = ARENA.take(nrow * 2 * Cb, dy2.device).view(nrow, 2 * Cb)
                 bnb = (link.y if link.act != ACT_NONE else None, link.x2, link.pack[2 * Cb:3 * Cb], link.pack[3 * Cb:4 * Cb], link.act)
             dx = K.conv_fprop(dy2, wt, mode=dmode, N=N, Hin=Ho, Win=Wo, Hout=H, Wout=W_, R=R, S=S, stride=stride, pad=pad,
                               dil=dil, alg_cout=ctx.cin_real, res2=r2, stats=sums_rep, bnb=bnb, slope=LRELU_SLOPE).view(N, H, W_, Cin)

@@ -190,7 +190,10 @@ def conv_stat_rows(M, N=1, Hout=1, Wout=1):
     word receives exactly one addition; rows nobody writes stay zero."""
     if not hip.DETERMINISTIC:
         return STAT_REPLICAS
-    return max(N * ((Hout + 3) // 4) * ((Wout + 15) // 16), (M + 63) // 64 + 8, STAT_REPLICAS + 1)
+    rows = max(N * ((Hout + 3) // 4) * ((Wout + 15) // 16), (M + 63) // 64 + 8, STAT_REPLICAS + 1)
+    if M <= 8192:
+        rows = max(rows, min(512, (M + 15) // 16 + 1))             # split-K layers: the statistics come from the finish kernel's row blocks
+    return rows
 
 
 def ACC(n, device, dtype=torch.float32):
@@ -538,14 +541,18 @@ def gather_rows_bwd(dout, coords, n_i, dense_shape, mul=None, dense=None, yoff=0
         hip.call('mg_gather_rows_dmul_det', hip.ptr(dout), c_int(hip.dtype_code(dout)), c_int(_ld(dout)), c_int(yoff), hip.ptr(coords), c_int(R), c_int(n_i),
                  c_int(N), c_int(Hd), c_int(Wd), c_int(C), c_int(mul.shape[1]), hip.ptr(dense), hip.ptr(dmul), hip.ptr(rows), hip.stream())
         return None, dmul
-    if hip.DETERMINISTIC and want_ddense:
-        raise hip.MaggieHipError('gather_rows_bwd(want_ddense=True) scatters with atomics: use gather_rows_bwd_dense in deterministic mode')
+    det_dmul = None
+    if hip.DETERMINISTIC and want_ddense and want_dmul and mul is not None and 256 % (C // (8 if dout.element_size() == 2 else 4)) == 0:
+        # both asked for: the multiplier gradient in its reproducible form; the dense gradient below still scatters with atomics (rows of several
+        # instance planes meet at one pixel) -- the product uses gather_rows_bwd_dense for it, which has none
+        _, det_dmul = gather_rows_bwd(dout, coords, n_i, dense_shape, mul=mul, dense=dense, yoff=yoff, want_ddense=False, want_dmul=True, rows=rows)
+        want_dmul = False
     ddense = torch.zeros(dense_shape, dtype=torch.float32, device=dout.device) if want_ddense else None
     dmul = torch.zeros_like(mul) if (want_dmul and mul is not None) else None
     hip.call('mg_gather_rows_bwd_dev', hip.ptr(dout), c_int(hip.dtype_code(dout)), c_int(_ld(dout)), c_int(yoff), hip.ptr(coords), c_int(R),
              c_int(n_i), c_int(Hd), c_int(Wd), c_int(C), hip.ptr(mul), c_int(mul.shape[1] if mul is not None else 0), hip.ptr(dense),
              hip.ptr(ddense), hip.ptr(dmul), hip.ptr(rows), hip.stream())
-    return ddense, dmul
+    return ddense, (det_dmul if det_dmul is not None else dmul)
 
 
 def gather_rows_bwd_dense(dout, bits, wordoff, n_i, dense_shape, mul=None, yoff=0):

@@ -123,7 +123,7 @@ def test_conv_epilogue_and_stats(dtype):
     shift = torch.from_numpy(rs.normal(size=Cout).astype(np.float32))
     y_ref = F.conv2d(x, w, None, 1, 1) * scale[None, :, None, None] + shift[None, :, None, None]
     y_ref = F.leaky_relu(y_ref + F.interpolate(res, scale_factor=2, mode='nearest'), 0.2) + res2
-    stats = torch.zeros((K.STAT_REPLICAS, 2 * Cout), device=dev)
+    stats = torch.zeros((K.conv_stat_rows(N * H * W, N, H, W), 2 * Cout), device=dev)
     big = torch.zeros((N * H * W, 2 * Cout), device=dev, dtype=dtype)
     K.conv_fprop(_nhwc(x).to(dev, dtype), _krsc(w).to(dev, dtype), N=N, Hin=H, Win=W, R=3, S=3, pad=1,
                  scale=scale.to(dev), shift=shift.to(dev), res=_nhwc(res).to(dev, dtype), res_mode=2,
@@ -170,7 +170,7 @@ def test_conv_transpose_phased_epilogue(dtype):
     shift = torch.from_numpy(rs.normal(size=Cout).astype(np.float32))
     y_ref = F.relu(F.conv_transpose2d(x, w, None, 2, 1) * scale[None, :, None, None] + shift[None, :, None, None]) + res2
     wk = w.permute(1, 2, 3, 0).reshape(Cout, 16, Cin).contiguous().to(dev, dtype)
-    stats = torch.zeros((K.STAT_REPLICAS, 2 * Cout), device=dev)
+    stats = torch.zeros((K.conv_stat_rows(N * 4 * H * W, N, 2 * H, 2 * W), 2 * Cout), device=dev)
     big = torch.zeros((N * 4 * H * W, 2 * Cout), device=dev, dtype=dtype)
     K.conv_fprop(_nhwc(x).to(dev, dtype), wk, mode=K.MODE_TCONV, N=N, Hin=H, Win=W, Hout=2 * H, Wout=2 * W, R=4, S=4, stride=2, pad=1,
                  scale=scale.to(dev), shift=shift.to(dev), res2=_nhwc(res2).to(dev, dtype), act=K.ACT_RELU, stats=stats, out=big, yoff=Cout)
@@ -257,7 +257,7 @@ def test_conv_fprop_split_k(case, dtype):
     # statistics rows: 32 replicas (the atomic form), one row per output tile (the deterministic form), one sums-only row (feeds the exact
     # two-pass variance; accumulated with atomics, so only outside deterministic mode)
     for stat_rows in (K.STAT_REPLICAS, K.conv_stat_rows(N * Ho * Wo, N, Ho, Wo), 1):
-        hip.set_deterministic(stat_rows != 1)
+        hip.set_deterministic(stat_rows > K.STAT_REPLICAS)      # 32 replicas / one sums-only row: the atomic forms
         try:
             stats = torch.zeros((stat_rows, 2 * Cout), device=dev) if stat_rows > 1 else torch.zeros(2 * Cout, device=dev)
             y = K.conv_fprop(xd.view(-1, Cin), wd, scale=scale.to(dev), shift=shift.to(dev), res=_nhwc(res).to(dev, dtype).view(-1, Cout),

@@ -265,6 +265,15 @@ def test_batchnorm_statistics_rows_cover_every_conv_tile():
         assert torch.allclose(s[Cout:], (yf * yf).sum(0), rtol=2e-3, atol=2e-2)
         # every word of the buffer received at most one addition: a row is either untouched (zero) or one tile's partial; with FEWER rows than
         # tiles the sums stay right (32-replica mode) -- that form is what MAGGIE_DETERMINISTIC=0 runs
+        from maggie_amd import hip
         st32 = torch.zeros((K.STAT_REPLICAS, 2 * Cout), device=dev)
-        K.conv_fprop(x, w, mode=mode, N=N, Hin=H, Win=W, R=k, S=k, stride=stride, pad=pad, dil=1, stats=st32)
+        hip.set_deterministic(False)
+        try:
+            K.conv_fprop(x, w, mode=mode, N=N, Hin=H, Win=W, R=k, S=k, stride=stride, pad=pad, dil=1, stats=st32)
+        finally:
+            hip.set_deterministic(True)
         assert torch.allclose(st32.sum(0), s, rtol=1e-4, atol=1e-2)
+        # ... and in deterministic mode a buffer with fewer rows than tiles is an ERROR (two tiles on one word would be order-dependent)
+        if K.conv_stat_rows(N * Ho * Wo, N, Ho, Wo) > 64 and N * Ho * Wo >= 64 * 64:
+            with pytest.raises(hip.MaggieHipError):
+                K.conv_fprop(x, w, mode=mode, N=N, Hin=H, Win=W, R=k, S=k, stride=stride, pad=pad, dil=1, stats=torch.zeros((K.STAT_REPLICAS, 2 * Cout), device=dev))
