@@ -32,8 +32,8 @@ SPARSE_KFLOP_PER_ACTIVE_PX_FWD = 64.5
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=4, help='frames per GPU')
     ap.add_argument('--instances', type=int, default=2)
     ap.add_argument('--size', type=int, default=512)
@@ -52,7 +52,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
-    ap.add_argument('--cpu-threads', type=int, default=0)
+    ap.add_argument('--cpu-threads', type=int, default=0, help='cpu_baseline: torch threads (0 = try 32 and all host cores, report the faster)')
+    ap.add_argument('--acc-file', default='', help=argparse.SUPPRESS)
     ap.add_argument('--layers', action='store_true', help='print the per-shape conv kernel table to stderr')
     ap.add_argument('--ddp', action='store_true', help='all-reduce gradients with torch DistributedDataParallel (like the reference) instead of '
                                                       'maggie_amd.parallel.GradSync (flat-buffer RCCL all-reduce, the default for N > 1)')
@@ -310,8 +311,17 @@ def main():
         }
 
     cpu_baseline = None
+    accuracy = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # BASELINE.json's metric also names "alpha max-abs err vs CPU": configs[0] (maggie_image.yaml, 1 instance, 1 x 256 x 256, batch 1, fp32 eval
+        # forward) through the HIP path here, through the CPU oracle in the child below, compared there (the oracle is the checker, never the product)
+        acc_file = hip_accuracy_outputs(dev)
+        args.acc_file = acc_file or ''
         cpu_baseline = cpu_baseline_subprocess(args)
+        if acc_file and os.path.isfile(acc_file):
+            os.remove(acc_file)
+        if isinstance(cpu_baseline, dict):
+            accuracy = cpu_baseline.pop('accuracy', None)
 
     if rank == 0:
         line = {
@@ -328,6 +338,9 @@ def main():
                        'grad_allreduce': None if world == 1 and not force_ddp else ('torch DDP' if args.ddp else ('RCCL all-reduce (mean) of each of the three backward graphs\' stretches of the optimizer\'s flat gradient buffer, in place on a side stream, overlapped with the rest of backward (parallel.OverlappedGradSync + FlatAdamW gradient sink)' if (args.optimizer == 'flat' and os.environ.get('MAGGIE_GRAD_OVERLAP', '1') != '0') else 'one RCCL all-reduce of the flat gradient buffer inside FlatAdamW.step' if args.optimizer == 'flat' else 'GradSync (flat-buffer RCCL all-reduce)')),
                        'peak_hbm_gb': round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1), 'active_ratio': round(active_ratio, 4), 'active_ratio_per_timed_step': [round(float(v) / (b * n_f * args.instances * args.size * args.size), 3) for v in stats['active_hist']] if not args.no_roofline else None, 'active_pixels_per_step_per_gpu': int(active_px), 'loss_total': round(loss_val, 4)},
             'roofline': roofline, 'cpu_baseline': cpu_baseline,
+            'alpha_max_abs_err': None if not accuracy else accuracy.get('alpha_max_abs_err'),
+            'detail_mask_bit_exact': None if not accuracy else accuracy.get('detail_mask_bit_exact'),
+            'accuracy': accuracy,
         }
     if world > 1 or force_ddp:
         # graphs that captured RCCL collectives (SyncBN statistics) must go before the communicator does
@@ -405,13 +418,66 @@ def trace_graph_replay(args, fam_alg):
         shutil.rmtree(out_dir, ignore_errors=True)
 
 
+ACC_CFG = dict(b=1, n_f=1, n_inst=1, size=256, seed=1234)         # BASELINE.json configs[0]
+
+
+def hip_accuracy_outputs(dev):
+    """fp32 eval forward of BASELINE configs[0] through the HIP path (fresh model, the bench's deterministic synthetic weights) -> path of an .npz
+    with its outputs; the cpu_baseline child runs the CPU oracle on the same inputs / weights and compares."""
+    import tempfile
+    from maggie_amd.network import build_model
+    from maggie_amd.utils import config, synth
+    try:
+        model, _ = build_model(config.model_config('image'))
+        sd = model.state_dict()
+        synth.fill_state_dict_(sd, ACC_CFG['seed'])
+        model.load_state_dict(sd)
+        model.to(dev).eval()
+        c = ACC_CFG
+        batch = synth.synthetic_batch(c['b'], c['n_f'], c['n_inst'], c['size'], c['size'], seed=c['seed'], train=False)
+        with torch.no_grad():
+            out = model({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()})
+        fd, path = tempfile.mkstemp(prefix='mg_acc_', suffix='.npz', dir='/tmp')
+        os.close(fd)
+        np.savez(path, **{k: out[k].float().cpu().numpy() for k in ('alpha_os8', 'alpha_os4', 'alpha_os1', 'refined_masks', 'detail_mask')})
+        return path
+    except Exception as e:                                          # evidence, never a reason to fail the bench
+        sys.stderr.write('accuracy leg (HIP side) failed: %s: %s\n' % (type(e).__name__, e))
+        return None
+
+
+def cpu_accuracy(acc_file):
+    """CPU oracle on BASELINE configs[0] against the HIP outputs in `acc_file` -> dict(alpha_max_abs_err, detail_mask_bit_exact, ...)."""
+    import copy
+    from maggie_amd.network import build_model
+    from maggie_amd.utils import config, synth
+    from oracle import refmodel
+    c = ACC_CFG
+    hipo = np.load(acc_file)
+    model, _ = build_model(config.model_config('image'))
+    sd = model.state_dict()
+    synth.fill_state_dict_(sd, c['seed'])
+    batch = synth.synthetic_batch(c['b'], c['n_f'], c['n_inst'], c['size'], c['size'], seed=c['seed'], train=False)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ref = refmodel.maggie_forward({k: v.clone() for k, v in sd.items()}, copy.deepcopy(config.MODEL_IMAGE), batch, False)
+    dt = time.perf_counter() - t0
+    errs = {k: float(np.abs(hipo[k] - ref[k].float().numpy()).max()) for k in ('alpha_os8', 'alpha_os4', 'alpha_os1', 'refined_masks')}
+    dm_ref = ref['detail_mask'].numpy()
+    return {'config': 'BASELINE configs[0]: maggie_image.yaml, 1 instance, 1x256x256, batch 1, fp32 eval forward; HIP path vs CPU oracle (oracle/refmodel.py), same synthetic weights and inputs',
+            'alpha_max_abs_err': errs['refined_masks'], 'max_abs_err_per_output': {k: float('%.3g' % v) for k, v in errs.items()},
+            'detail_mask_bit_exact': bool(np.array_equal(hipo['detail_mask'] != 0, dm_ref != 0)),
+            'detail_pixels': int((dm_ref != 0).sum()), 'tolerance': 1e-3, 'cpu_forward_s': round(dt, 3)}
+
+
 def cpu_baseline_subprocess(args):
     """Run the CPU oracle legs in a child process with a hard time limit so the default bench always finishes in minutes."""
     import subprocess
     limit_s = 900 if args.cpu_baseline_full else 330
     cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--size', str(args.size), '--instances', str(args.instances),
            '--batch', str(args.batch), '--iter', str(args.iter), '--edge', str(args.edge), '--workload', args.workload,
-           '--cpu-threads', str(args.cpu_threads)] + (['--video'] if args.video else []) + (['--cpu-baseline-full'] if args.cpu_baseline_full else [])
+           '--cpu-threads', str(args.cpu_threads)] + (['--video'] if args.video else []) + (['--cpu-baseline-full'] if args.cpu_baseline_full else []) + \
+          (['--acc-file', args.acc_file] if getattr(args, 'acc_file', '') else [])
     env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
     part = None
     try:
@@ -439,8 +505,9 @@ def run_cpu_baseline(kind, args):
     from maggie_amd.utils import config, synth
     from oracle import refmodel
     cores = os.cpu_count() or 1
-    threads = args.cpu_threads if args.cpu_threads > 0 else min(cores, 32)      # beyond ~32 threads the many small ops regress
-    torch.set_num_threads(threads)
+    # SURVEY 8(d) asks for os.cpu_count() threads; the many small ops of this model regress beyond ~32 torch threads on a 256-core host: both
+    # settings are timed (32 first), the faster one is `value` / `cores`, the other is reported next to it
+    settings = [args.cpu_threads] if args.cpu_threads > 0 else ([min(cores, 32)] + ([cores] if cores > 32 else []))
     model, _ = build_model(config.model_config(kind))
     sd0 = model.state_dict()
     synth.fill_state_dict_(sd0, 1234)
@@ -448,25 +515,43 @@ def run_cpu_baseline(kind, args):
     b = 1 if kind == 'video' else args.batch
     size = args.size
     mcfg = copy.deepcopy(config.MODEL_VIDEO if kind == 'video' else config.MODEL_IMAGE)
-    n_warm, n_timed = (2, 9) if args.cpu_baseline_full else (2, 5)
-    res = {'unit': 'instance-frames/s', 'cores': threads, 'host_cores': cores, 'kind': 'port'}
+    n_warm, n_timed = (2, 9) if args.cpu_baseline_full else (1, 3)
+    res = {'unit': 'instance-frames/s', 'cores': settings[0], 'host_cores': cores, 'kind': 'port', 'per_thread_setting': {}}
     inst = b * n_f * args.instances
+    if args.acc_file:
+        try:
+            torch.set_num_threads(min(cores, 32))
+            res['accuracy'] = cpu_accuracy(args.acc_file)
+        except Exception as e:
+            res['accuracy'] = {'error': '%s: %s' % (type(e).__name__, e)}
+    best = {}
 
-    def emit():
-        tr, ev = res.get('train_s', []), res.get('eval_s', [])
-        res['value'] = round(inst / float(np.median(tr)), 4) if tr else None
-        res['eval_forward_value'] = round(inst / float(np.median(ev)), 4) if ev else None
-        res['sample'] = ('oracle/refmodel.py fp32 on %d of %d host cores (torch threads), same workload as the GPU line: %dx%d, batch %d x %d frame(s), %d '
-                         'instances, %s-guided detail region, active ratio %.3f; train leg = forward + losses + backward (no optimizer): %d warm-up + %d '
-                         'timed steps, median %.2f s/step; eval-forward leg: %d timed, median %.2f s' % (
-                             threads, cores, size, size, b, n_f, args.instances, 'ground-truth' if args.workload == 'gt' else 'prediction',
-                             res.get('active_ratio', float('nan')), n_warm, len(tr), float(np.median(tr)) if tr else float('nan'), len(ev),
-                             float(np.median(ev)) if ev else float('nan')))
-        print('CPU_BASELINE ' + json.dumps({k: v for k, v in res.items() if k not in ('train_s', 'eval_s')}), flush=True)
+    def emit(threads, tr, ev):
+        cur = {'value': round(inst / float(np.median(tr)), 4) if tr else None, 'eval_forward_value': round(inst / float(np.median(ev)), 4) if ev else None,
+               'train_median_s': round(float(np.median(tr)), 3) if tr else None, 'eval_median_s': round(float(np.median(ev)), 3) if ev else None,
+               'timed_steps': [len(tr), len(ev)]}
+        res['per_thread_setting'][str(threads)] = cur
+        if cur['value'] is not None and (best.get('value') is None or cur['value'] > best['value']):
+            best.update(cur, cores=threads)
+        if best:
+            res['value'], res['eval_forward_value'], res['cores'] = best['value'], best.get('eval_forward_value'), best['cores']
+            if cur.get('eval_forward_value') and str(best['cores']) == str(threads):
+                res['eval_forward_value'] = cur['eval_forward_value']
+        res['sample'] = ('oracle/refmodel.py fp32 (torch threads: %s of %d host cores tried, `value` / `cores` = the faster setting), same workload as the GPU '
+                         'line: %dx%d, batch %d x %d frame(s), %d instances, %s-guided detail region, active ratio %.3f; train leg = forward + losses + '
+                         'backward (no optimizer): %d warm-up + %d timed steps per setting, medians; eval-forward leg likewise' % (
+                             '/'.join(str(t) for t in settings), cores, size, size, b, n_f, args.instances,
+                             'ground-truth' if args.workload == 'gt' else 'prediction', res.get('active_ratio', float('nan')), n_warm, n_timed))
+        print('CPU_BASELINE ' + json.dumps(res), flush=True)
 
     batch = synth.synthetic_batch(b, n_f, args.instances, size, size, seed=1234, train=True, it=args.iter, max_inst=10, edge=args.edge * size / 512.0)
     ev_batch = {k: (v[:, :, :args.instances] if k == 'mask' else v) for k, v in batch.items() if k in ('image', 'mask')}
-    for i in range(n_warm + n_timed):
+    if res.get('accuracy') is not None:
+        print('CPU_BASELINE ' + json.dumps(dict(res, value=None, sample='accuracy leg only so far')), flush=True)
+    for threads in settings:
+      torch.set_num_threads(threads)
+      tr_s, ev_s = [], []
+      for i in range(n_warm + n_timed):
         sd = {k: v.clone() for k, v in sd0.items()}
         for k, v in sd.items():
             if v.is_floating_point() and not k.endswith(('_u', '_v', 'running_mean', 'running_var')):
@@ -478,18 +563,18 @@ def run_cpu_baseline(kind, args):
         dt = time.perf_counter() - t0
         res['active_ratio'] = round(float(out['detail_mask'].float().mean()) * 10.0 / args.instances, 4)
         if i >= n_warm:
-            res.setdefault('train_s', []).append(dt)
-            emit()
-    for i in range(n_warm + n_timed):
+            tr_s.append(dt)
+            emit(threads, tr_s, ev_s)
+      for i in range(n_warm + n_timed):
         sd = {k: v.clone() for k, v in sd0.items()}
         t0 = time.perf_counter()
         with torch.no_grad():
             refmodel.maggie_forward(sd, mcfg, ev_batch, False)
         dt = time.perf_counter() - t0
         if i >= n_warm:
-            res.setdefault('eval_s', []).append(dt)
-            emit()
-    return {k: v for k, v in res.items() if k not in ('train_s', 'eval_s')}
+            ev_s.append(dt)
+            emit(threads, tr_s, ev_s)
+    return res
 
 
 if __name__ == '__main__':
