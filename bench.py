@@ -473,7 +473,7 @@ def cpu_accuracy(acc_file):
 def cpu_baseline_subprocess(args):
     """Run the CPU oracle legs in a child process with a hard time limit so the default bench always finishes in minutes."""
     import subprocess
-    limit_s = 900 if args.cpu_baseline_full else 330
+    limit_s = 900 if args.cpu_baseline_full else 420
     cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--size', str(args.size), '--instances', str(args.instances),
            '--batch', str(args.batch), '--iter', str(args.iter), '--edge', str(args.edge), '--workload', args.workload,
            '--cpu-threads', str(args.cpu_threads)] + (['--video'] if args.video else []) + (['--cpu-baseline-full'] if args.cpu_baseline_full else []) + \
@@ -548,9 +548,11 @@ def run_cpu_baseline(kind, args):
     ev_batch = {k: (v[:, :, :args.instances] if k == 'mask' else v) for k, v in batch.items() if k in ('image', 'mask')}
     if res.get('accuracy') is not None:
         print('CPU_BASELINE ' + json.dumps(dict(res, value=None, sample='accuracy leg only so far')), flush=True)
-    for threads in settings:
+    for si, threads in enumerate(settings):
       torch.set_num_threads(threads)
       tr_s, ev_s = [], []
+      if si > 0 and not args.cpu_baseline_full:
+          n_timed = 2                                              # the second setting only has to show which one is faster
       for i in range(n_warm + n_timed):
         sd = {k: v.clone() for k, v in sd0.items()}
         for k, v in sd.items():

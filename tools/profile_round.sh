@@ -6,7 +6,7 @@ root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $root/bench.py --no-roofline --no-cpu-baseline"
+BENCH="python $root/bench.py --steps 10 --warmup 3 --no-roofline --no-cpu-baseline"
 
 # 1. kernel trace + stats of the default command (graph replay)
 rm -rf /tmp/pr_stats
