@@ -163,6 +163,8 @@ int mg_colstats(const void* x, int dtype, int M, int C, int ld, float* stats, vo
 /* exact two-pass variant for small M: stats[0:C] += sum, stats[C:2C] += sum (x - mean)^2 (stats [2C] must arrive zeroed) */
 int mg_colstats_centered(const void* x, int dtype, int M, int C, int ld, float* stats, int have_sum, void* stream);
 /* `centered` != 0: stats[C:2C] holds the centred second moment (mg_colstats_centered) instead of sum x^2 */
+/* out[n] = sum over the rows of stats[nrep][n] in the library's fixed order (local statistics of a SyncBatchNorm layer before the exchange) */
+int mg_stat_rows_sum(const float* stats, int nrep, int n, float* out, void* stream);
 int mg_bn_finalize(const float* stats, int nrep, const float* count_ptr, float count, int C, int centered, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
                    float* mean_out, float* invstd_out, void* stream);

@@ -44,7 +44,7 @@ __device__ __forceinline__ void mailbox_exchange(const mg_mailbox& mb, int n, ui
         const uint32_t* flag = (const uint32_t*)(own + (long)t * CELL + PACK);
         const long t0 = (long)wall_clock64();
         while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-            if ((long)wall_clock64() - t0 > spin_ticks) { atomicExch(err_dev, 1); break; }
+            if ((long)wall_clock64() - t0 > spin_ticks) { atomicCAS(err_dev, 0, 1 + t); break; }     // error word = 1 + the (first) rank that did not arrive
             __builtin_amdgcn_s_sleep(8);
         }
     }
@@ -119,9 +119,10 @@ extern "C" long mg_mailbox_bytes(int world) { return (long)SLOTS * world * CELL 
 extern "C" int mg_mailbox_create(int world, void** ptr, void* handle64) {
     if (!ptr || !handle64 || world < 1 || world > MG_MAILBOX_MAX_RANKS) return -2;
     const size_t bytes = (size_t)mg_mailbox_bytes(world);
-    hipError_t e = hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocFinegrained);      // peers poll it: must not be cached incoherently
-    if (e != hipSuccess) { (void)hipGetLastError(); e = hipMalloc(ptr, bytes); }
-    if (e != hipSuccess) return (int)e;
+    // peers poll it: it must not be cached incoherently. No coarse-grained fallback: across GPUs plain hipMalloc memory breaks the polling
+    // protocol silently -- the caller falls back to the RCCL exchange instead (maggie_amd/parallel.py)
+    hipError_t e = hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocFinegrained);
+    if (e != hipSuccess) { (void)hipGetLastError(); return (int)e; }
     e = hipMemset(*ptr, 0, bytes);
     if (e != hipSuccess) return (int)e;
     e = hipDeviceSynchronize();

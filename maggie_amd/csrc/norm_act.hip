@@ -802,6 +802,16 @@ extern "C" int mg_colstats_centered_dev(const void* x, int dtype, int M, int C, 
     return 0;
 }
 
+/* out[n] = sum over the nrep rows of stats[nrep][n], added in the library's fixed order (csrc/det.hip): the local [sum x | sum x^2] of a SyncBatchNorm
+ * layer whose statistics arrive as one row per tile / row block, before they go into the cross-rank exchange. */
+extern "C" int mg_stat_rows_sum(const float* stats, int nrep, int n, float* out, void* stream) {
+    if (!stats || !out || nrep < 1 || n < 1) return -2;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = mg_zero_words(out, n, st);
+    if (e != hipSuccess) return (int)e;
+    return mg_det_reduce1(stats, nrep, out, n, st);
+}
+
 static int bn_finalize_launch(const float* stats, int nrep, const float* count_ptr, float count, int C, int centered, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
                               float* mean_out, float* invstd_out, const int32_t* m_dev, void* stream, int count_mult = 1) {

@@ -321,11 +321,16 @@ __global__ __launch_bounds__(NT) void mask_embed_bwd_det_kernel(const T* __restr
         float inv = 1.f / (cnt + 1e-6f);
         float g[3];
         for (int c = 0; c < 3; ++c) g[c] = c < n_embed ? ElemTraits<T>::ld(dx + i * 8 + 3 + c) * inv : 0.f;
-        for (int k = 0; k < n_m; ++k) {
-            const int id = (int)(long)(mp[(long)k * Hm * Wm] * (float)(k + 1));
 #pragma unroll
-            for (int j = 1; j < NID; ++j)
-                if (id == j) { acc[j][0] += g[0]; acc[j][1] += g[1]; acc[j][2] += g[2]; }
+        for (int k = 0; k < NID - 1; ++k) {
+            if (k >= n_m) break;
+            const int id = (int)(long)(mp[(long)k * Hm * Wm] * (float)(k + 1));
+            if (id == k + 1) { acc[k + 1][0] += g[0]; acc[k + 1][1] += g[1]; acc[k + 1][2] += g[2]; }      // a 0 / 1 mask: id is 0 or k + 1 (static index)
+            else if (id > 0) {                                                                             // fractional mask value: any id below k + 1
+#pragma unroll
+                for (int j = 1; j < NID; ++j)
+                    if (id == j) { acc[j][0] += g[0]; acc[j][1] += g[1]; acc[j][2] += g[2]; }
+            }
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

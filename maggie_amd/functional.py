@@ -722,8 +722,10 @@ class BNAct(torch.autograd.Function):
                 comm = _par.SYNCBN_COMM
                 if comm is not None and hasattr(comm, 'bn_finalize') and comm.can_finalize(C) and x.is_cuda and stats.shape[-1] == 2 * C:
                     fused_comm = comm                             # mailbox exchange: replica sums, exchange and finalize in ONE launch (below)
+                    if stats.dim() == 2 and stats.shape[0] > K.STAT_REPLICAS:
+                        stats = K.stat_rows_sum(stats)            # one row per tile / row block (deterministic mode): added in order, in parallel, first
                 else:
-                    flat = stats.sum(0) if stats.dim() == 2 else stats
+                    flat = (K.stat_rows_sum(stats) if x.is_cuda else stats.sum(0)) if stats.dim() == 2 else stats
                     pack = _par.syncbn_exchange_forward(torch.cat([flat[:2 * C], torch.full((1,), float(M), device=x.device)]), group)
                     stats, cnt_t = pack[:2 * C], pack[2 * C:]
             rm = running_mean if running_mean.numel() == C else None

@@ -212,6 +212,17 @@ def colstats(x, stats=None):
     return stats
 
 
+def stat_rows_sum(stats):
+    """[nrep][n] fp32 statistics rows -> [n]: their sum in the library's fixed order (mg_stat_rows_sum)."""
+    if stats.dim() == 1:
+        return stats
+    nrep, n = stats.shape
+    out = torch.empty(n, dtype=torch.float32, device=stats.device)
+    hip.need_cuda(stats)
+    hip.call('mg_stat_rows_sum', hip.ptr(stats.contiguous()), c_int(nrep), c_int(n), hip.ptr(out), hip.stream())
+    return out
+
+
 def bias_act_bwd(dy, y, want_db, rows=None):
     """g = dy * (y > 0) (y None: g = dy) and db = g.sum(0) in fp32 (None unless want_db) -- one pass (mg_bias_act_bwd).
     `rows`: device row count (int32 tensor), dy.shape[0] is then the capacity."""

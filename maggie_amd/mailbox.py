@@ -1,7 +1,10 @@
 """Mailbox all-reduce for the SyncBatchNorm statistics exchange (csrc/mailbox.hip): one ordinary kernel per exchange over peer-mapped
-mailboxes -- no RCCL, no host work, capturable into hipGraphs. Opt-in (MAGGIE_SYNCBN_COMM=mailbox): it has been exercised with TWO PROCESSES ON ONE
-GPU only (tests/test_gpu_graphs.py::test_mailbox_*); across GPUs it relies on fine-grained device memory + system-scope atomics over xGMI, which
-this project had no second GPU to validate on. The default in-graph exchange is the private RCCL communicator (rccl_direct.py).
+mailboxes -- no RCCL, no host work, capturable into hipGraphs. The default exchange of `sync_bn: true` when every rank of the group sits on ONE
+node and the devices can access each other (parallel.syncbn_direct_comm, MAGGIE_SYNCBN_COMM=auto); the private RCCL communicator (rccl_direct.py)
+otherwise. It has been exercised with two and four PROCESSES ON ONE GPU (tests/test_gpu_graphs.py); across GPUs it relies on fine-grained device
+memory + system-scope atomics over xGMI, which this project had no second GPU to validate on (MAGGIE_SYNCBN_COMM=rccl selects the RCCL exchange).
+A peer that does not arrive within the spin budget raises the error word (1 + its rank): MaGGIe.forward reads it with the step's other flags and
+raises MaggieHipError naming the rank -- never a silent wrong normalisation.
 
 The control plane (mailbox handle exchange) goes through the existing torch.distributed group (any backend: the handles are 64-byte objects)."""
 import ctypes
@@ -47,24 +50,24 @@ class MailboxComm:
         dist.barrier(group=group)                                                # nobody deposits before every mailbox is mapped everywhere
 
     def all_reduce_sum_(self, t):
-        """In-place sum over the ranks of a contiguous fp32 device tensor of <= PACK elements, on the current stream (eager or capturing)."""
-        if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and 0 < t.numel() <= PACK):
-            raise hip.MaggieHipError('MailboxComm.all_reduce_sum_: contiguous fp32 device tensor of at most %d elements expected' % PACK)
-        s = self._state
-        hip.call('mg_mailbox_allreduce', ctypes.byref(self._mb), hip.ptr(t), ctypes.c_int(t.numel()), ctypes.c_void_p(s.data_ptr()),
-                 ctypes.c_void_p(s.data_ptr() + 4), ctypes.c_long(self._spin), hip.stream())
-        self.calls += 1
-        return t
+        """In-place sum over the ranks of a contiguous fp32 device tensor, on the current stream (eager or capturing)."""
+        return self.all_reduce_sum_to(t, t)
 
     def all_reduce_sum_to(self, src, dst):
-        """Out-of-place form: dst = sum over the ranks of src (src untouched)."""
+        """dst = sum over the ranks of src (src untouched unless dst is src). Packs larger than a mailbox cell (PACK floats: BatchNorm layers wider
+        than 543 channels) go through several exchanges of PACK elements -- the same chunks in the same order on every rank."""
         for t in (src, dst):
-            if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and 0 < t.numel() <= PACK):
-                raise hip.MaggieHipError('MailboxComm.all_reduce_sum_to: contiguous fp32 device tensors of at most %d elements expected' % PACK)
+            if not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.numel() > 0):
+                raise hip.MaggieHipError('MailboxComm.all_reduce_sum: contiguous fp32 device tensors expected')
+        if src.numel() != dst.numel():
+            raise hip.MaggieHipError('MailboxComm.all_reduce_sum_to: source and destination differ in size')
         s = self._state
-        hip.call('mg_mailbox_allreduce_to', ctypes.byref(self._mb), hip.ptr(src), hip.ptr(dst), ctypes.c_int(src.numel()), ctypes.c_void_p(s.data_ptr()),
-                 ctypes.c_void_p(s.data_ptr() + 4), ctypes.c_long(self._spin), hip.stream())
-        self.calls += 1
+        n = src.numel()
+        for off in range(0, n, PACK):
+            m = min(PACK, n - off)
+            hip.call('mg_mailbox_allreduce_to', ctypes.byref(self._mb), ctypes.c_void_p(src.data_ptr() + 4 * off), ctypes.c_void_p(dst.data_ptr() + 4 * off),
+                     ctypes.c_int(m), ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(s.data_ptr() + 4), ctypes.c_long(self._spin), hip.stream())
+            self.calls += 1
         return dst
 
     def can_finalize(self, C):
@@ -84,10 +87,19 @@ class MailboxComm:
         self.calls += 1
         return outs[:C], outs[C:2 * C], outs[2 * C:3 * C], outs[3 * C:], cnt
 
+    @property
+    def error_word(self):
+        """Device int32 [1]: 0, or 1 + the rank that did not arrive at an exchange within the spin budget (read with the step's other flags)."""
+        return self._state[1:2]
+
+    def raise_for(self, word):
+        if int(word) != 0:
+            raise hip.MaggieHipError('SyncBatchNorm statistics exchange (mailbox): rank %d did not arrive within the spin budget of %.0f s on rank %d -- '
+                                     'the step\'s normalisation is invalid' % (int(word) - 1, self._spin / 1e8, self.rank))
+
     def check(self):
         """Host read of the error word (a peer that did not arrive within the spin budget)."""
-        if int(self._state[1].item()) != 0:
-            raise hip.MaggieHipError('MailboxComm: a peer did not arrive at an exchange within the spin budget')
+        self.raise_for(int(self._state[1].item()))
 
     def destroy(self):
         lib = hip.lib()

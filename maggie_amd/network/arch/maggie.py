@@ -163,13 +163,19 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             # ~142 small collectives of a step cannot be merged). MAGGIE_SYNCBN_GRAPHS=1 (opt-in: verified in a 1-rank process group only,
             # DESIGN.md section 6) records them into the hipGraphs -- through a PRIVATE RCCL communicator (maggie_amd/rccl_direct.py), not
             # through ProcessGroupNCCL, whose watchdog thread aborts the process when it queries an event recorded inside a capture.
+            # Default since round 4 (the reference's target configs both set sync_bn: true, configs/maggie_image.yaml:33): the exchange is recorded
+            # INTO the graphs -- mailbox kernels when every rank sits on one node with peer access, the private RCCL communicator otherwise
+            # (parallel.syncbn_direct_comm). MAGGIE_SYNCBN_GRAPHS=0 asks for the eager path (host-launched torch.distributed collectives: 30 ms
+            # against 12-13 ms per step in the 1-rank measurement); a SyncBatchNorm bound to a sub-group takes it, too (the communicator spans the
+            # default group).
             import os
-            if os.environ.get('MAGGIE_SYNCBN_GRAPHS', '0') != '1':
+            sub = any(isinstance(m, nn.SyncBatchNorm) and m.process_group is not None and m.process_group is not torch.distributed.group.WORLD
+                      for m in self.modules())
+            if os.environ.get('MAGGIE_SYNCBN_GRAPHS', '1') == '0' or sub:
                 if not self.__dict__.get('_syncbn_hint'):
                     self.__dict__['_syncbn_hint'] = True
-                    logging.warning('MaGGIe (MI355X build): nn.SyncBatchNorm across ranks runs the step eagerly (142 host-launched collectives per step: 30 ms '
-                                    'against 12 ms in the 1-rank measurement). MAGGIE_SYNCBN_GRAPHS=1 keeps it in the hipGraphs (13 ms; verified with one '
-                                    'rank over RCCL and with two processes on one GPU over the mailbox kernels, DESIGN.md section 6).')
+                    logging.warning('MaGGIe (MI355X build): nn.SyncBatchNorm across ranks runs the step eagerly (142 host-launched collectives per step) -- %s',
+                                    'a BatchNorm layer is bound to a sub-group' if sub else 'MAGGIE_SYNCBN_GRAPHS=0')
                 return False
             from ... import parallel
             parallel.syncbn_direct_comm()                         # collective on first use: every rank reaches its first training forward
@@ -316,7 +322,19 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         ovf = self.decoder.__dict__.get('_sparse_overflow') if self.decoder.sparse_capacity() < 1.0 else None
         if ovf is not None:
             fl.append(ovf[0] != 0)                                    # sticky: raised by an EARLIER step's detail stage (sparse_head.DeviceLevel)
+        comm = None
+        if self.training:
+            from ... import parallel as _par
+            comm = _par.SYNCBN_COMM if hasattr(_par.SYNCBN_COMM, 'error_word') else None
+        if comm is not None:
+            # the mailbox exchange of SyncBatchNorm never hangs the GPU: a peer that did not arrive leaves 1 + its rank in this word
+            fl = [f.to(torch.int32) for f in fl] + [comm.error_word[0]]
         flags = torch.stack(fl).tolist()
+        if comm is not None:
+            word = flags.pop()
+            if word:
+                comm.error_word.zero_()
+                comm.raise_for(word)
         if flags[0]:
             raise ValueError("Mask is empty")
         if ovf is not None and flags[-1]:

