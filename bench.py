@@ -526,17 +526,17 @@ def run_cpu_baseline(kind, args):
             res['accuracy'] = {'error': '%s: %s' % (type(e).__name__, e)}
     best = {}
 
-    def emit(threads, tr, ev):
+    def emit(threads, tr, ev, note=None):
         cur = {'value': round(inst / float(np.median(tr)), 4) if tr else None, 'eval_forward_value': round(inst / float(np.median(ev)), 4) if ev else None,
                'train_median_s': round(float(np.median(tr)), 3) if tr else None, 'eval_median_s': round(float(np.median(ev)), 3) if ev else None,
                'timed_steps': [len(tr), len(ev)]}
+        if note:
+            cur['note'] = note
         res['per_thread_setting'][str(threads)] = cur
-        if cur['value'] is not None and (best.get('value') is None or cur['value'] > best['value']):
-            best.update(cur, cores=threads)
-        if best:
-            res['value'], res['eval_forward_value'], res['cores'] = best['value'], best.get('eval_forward_value'), best['cores']
-            if cur.get('eval_forward_value') and str(best['cores']) == str(threads):
-                res['eval_forward_value'] = cur['eval_forward_value']
+        done = {k: v for k, v in res['per_thread_setting'].items() if v.get('value') is not None}
+        if done:                                                  # `value` / `cores`: the faster setting, by its latest median
+            k_best = max(done, key=lambda k: done[k]['value'])
+            res['value'], res['eval_forward_value'], res['cores'] = done[k_best]['value'], done[k_best].get('eval_forward_value'), int(k_best)
         res['sample'] = ('oracle/refmodel.py fp32 (torch threads: %s of %d host cores tried, `value` / `cores` = the faster setting), same workload as the GPU '
                          'line: %dx%d, batch %d x %d frame(s), %d instances, %s-guided detail region, active ratio %.3f; train leg = forward + losses + '
                          'backward (no optimizer): %d warm-up + %d timed steps per setting, medians; eval-forward leg likewise' % (
@@ -551,6 +551,7 @@ def run_cpu_baseline(kind, args):
     for si, threads in enumerate(settings):
       torch.set_num_threads(threads)
       tr_s, ev_s = [], []
+      slow = False
       if si > 0 and not args.cpu_baseline_full:
           n_timed = 2                                              # the second setting only has to show which one is faster
       for i in range(n_warm + n_timed):
@@ -567,6 +568,13 @@ def run_cpu_baseline(kind, args):
         if i >= n_warm:
             tr_s.append(dt)
             emit(threads, tr_s, ev_s)
+        elif si > 0 and res.get('value') and dt > 2.5 * inst / res['value']:
+            # this setting's warm-up step alone is far slower than the first setting's median: record that and do not spend minutes on it
+            emit(threads, [dt], [], note='warm-up step only (%.1f s): more than 2.5x slower than the other setting, not timed further' % dt)
+            slow = True
+            break
+      if slow:
+          continue
       for i in range(n_warm + n_timed):
         sd = {k: v.clone() for k, v in sd0.items()}
         t0 = time.perf_counter()
