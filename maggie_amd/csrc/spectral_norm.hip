@@ -259,10 +259,40 @@ __device__ __forceinline__ SnTile sn_tile(const mg_sn_desc& d, const int4& it) {
 // sT[al][bl * taps + tap] = W[a0 + al][b0 + bl][tap] * mul
 __device__ __forceinline__ void sn_load_param_tile(const mg_sn_desc& d, const SnTile& t, float mul, float* sT) {
     const int run = t.nb * d.taps;
+    if ((run & 3) == 0 && (((long)d.B * d.taps) & 3) == 0 && ((t.b0 * d.taps) & 3) == 0 && (((size_t)d.W) & 15) == 0) {
+        const int r4 = run >> 2;                                  // 16-byte loads: a parameter row of the tile is one contiguous run
+        for (int i = threadIdx.x; i < t.na * r4; i += NT) {
+            const int al = i / r4, q = i - al * r4;
+            const float4 v = *(const float4*)(d.W + ((long)(t.a0 + al) * d.B + t.b0) * d.taps + 4 * q);
+            float* dst = sT + al * SN_PITCH + 4 * q;
+            dst[0] = v.x * mul; dst[1] = v.y * mul; dst[2] = v.z * mul; dst[3] = v.w * mul;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < t.na * run; i += NT) {
         const int al = i / run, r = i - al * run;
         sT[al * SN_PITCH + r] = d.W[((long)(t.a0 + al) * d.B + t.b0) * d.taps + r] * mul;
     }
+}
+
+// dst[row(i) * ld + c0 + (chunk of CE channels)] = pack(CE values gathered from the LDS tile by `val(row, channel)`), rows x nch channels, nch % CE == 0
+// and every row start 16-byte aligned: one 16-byte store per CE channels instead of one 2-byte store per element
+template <typename T, typename RowOff, typename Val>
+__device__ __forceinline__ void sn_store_rows(T* __restrict__ dst, int rows, int nch, RowOff rowoff, Val val) {
+    using TR = ElemTraits<T>;
+    constexpr int CE = TR::CE;
+    const int cpr = nch / CE;
+    for (int i = threadIdx.x; i < rows * cpr; i += NT) {
+        const int cc = i % cpr, r = i / cpr;
+        float v[CE];
+#pragma unroll
+        for (int e = 0; e < CE; ++e) v[e] = val(r, cc * CE + e);
+        *(uint4*)(dst + rowoff(r) + cc * CE) = TR::pack(v);
+    }
+}
+template <typename T> __device__ __forceinline__ bool sn_vec_ok(const void* base, long ld, int nch, int c0) {
+    constexpr int CE = ElemTraits<T>::CE;
+    return (nch % CE) == 0 && (ld % CE) == 0 && (c0 % CE) == 0 && (((size_t)base) & 15) == 0;
 }
 
 // emits W / sigma in the conv layouts; the vectors are finalised by snb_vectors_kernel (no block reads t/s after they changed)
@@ -290,16 +320,26 @@ __global__ __launch_bounds__(NT) void snb_finish_kernel(const mg_sn_desc* __rest
     if (!d.transposed) {
         // out[co = a][tap][ci = b]: runs of nb channels; the last b tile also zero-fills the channel padding [Cin, pad_in)
         const int nb_w = (t.b0 + t.nb == d.B) ? (d.pad_in - t.b0) : t.nb;
-        for (int i = threadIdx.x; i < t.na * taps * nb_w; i += NT) {
-            const int bl = i % nb_w, r = i / nb_w, tap = r % taps, al = r / taps;
-            const float v = bl < t.nb ? sT[al * SN_PITCH + bl * taps + tap] : 0.f;
-            ElemTraits<T>::st(out + ((long)(t.a0 + al) * taps + tap) * d.pad_in + t.b0 + bl, v);
+        if (sn_vec_ok<T>(out, d.pad_in, nb_w, t.b0)) {
+            sn_store_rows<T>(out, t.na * taps, nb_w, [&](int r) { return ((long)(t.a0 + r / taps) * taps + r % taps) * d.pad_in + t.b0; },
+                             [&](int r, int bl) { return bl < t.nb ? sT[(r / taps) * SN_PITCH + bl * taps + r % taps] : 0.f; });
+        } else {
+            for (int i = threadIdx.x; i < t.na * taps * nb_w; i += NT) {
+                const int bl = i % nb_w, r = i / nb_w, tap = r % taps, al = r / taps;
+                const float v = bl < t.nb ? sT[al * SN_PITCH + bl * taps + tap] : 0.f;
+                ElemTraits<T>::st(out + ((long)(t.a0 + al) * taps + tap) * d.pad_in + t.b0 + bl, v);
+            }
         }
         if (out_t_base) {                                    // out_t[ci = b][tap][co = a]: runs of na output channels
             T* ot = out_t_base + d.out_off;
-            for (int i = threadIdx.x; i < t.nb * taps * t.na; i += NT) {
-                const int al = i % t.na, r = i / t.na, tap = r % taps, bl = r / taps;
-                ElemTraits<T>::st(ot + ((long)(t.b0 + bl) * taps + tap) * Cout + t.a0 + al, sT[al * SN_PITCH + bl * taps + tap]);
+            if (sn_vec_ok<T>(ot, Cout, t.na, t.a0)) {
+                sn_store_rows<T>(ot, t.nb * taps, t.na, [&](int r) { return ((long)(t.b0 + r / taps) * taps + r % taps) * Cout + t.a0; },
+                                 [&](int r, int al) { return sT[al * SN_PITCH + (r / taps) * taps + r % taps]; });
+            } else {
+                for (int i = threadIdx.x; i < t.nb * taps * t.na; i += NT) {
+                    const int al = i % t.na, r = i / t.na, tap = r % taps, bl = r / taps;
+                    ElemTraits<T>::st(ot + ((long)(t.b0 + bl) * taps + tap) * Cout + t.a0 + al, sT[al * SN_PITCH + bl * taps + tap]);
+                }
             }
             if (t.b0 + t.nb == d.B) {                        // padded input channels of the twin: zero rows
                 const int extra = d.pad_in - d.B;
@@ -312,10 +352,15 @@ __global__ __launch_bounds__(NT) void snb_finish_kernel(const mg_sn_desc* __rest
     } else {
         // ConvTranspose parameter [Cin = A][Cout = B][taps] -> out[co = b][tap][ci = a]: runs of na input channels
         const int na_w = (t.a0 + t.na == d.A) ? (d.pad_in - t.a0) : t.na;
-        for (int i = threadIdx.x; i < t.nb * taps * na_w; i += NT) {
-            const int al = i % na_w, r = i / na_w, tap = r % taps, bl = r / taps;
-            const float v = al < t.na ? sT[al * SN_PITCH + bl * taps + tap] : 0.f;
-            ElemTraits<T>::st(out + ((long)(t.b0 + bl) * taps + tap) * d.pad_in + t.a0 + al, v);
+        if (sn_vec_ok<T>(out, d.pad_in, na_w, t.a0)) {
+            sn_store_rows<T>(out, t.nb * taps, na_w, [&](int r) { return ((long)(t.b0 + r / taps) * taps + r % taps) * d.pad_in + t.a0; },
+                             [&](int r, int al) { return al < t.na ? sT[al * SN_PITCH + (r / taps) * taps + r % taps] : 0.f; });
+        } else {
+            for (int i = threadIdx.x; i < t.nb * taps * na_w; i += NT) {
+                const int al = i % na_w, r = i / na_w, tap = r % taps, bl = r / taps;
+                const float v = al < t.na ? sT[al * SN_PITCH + bl * taps + tap] : 0.f;
+                ElemTraits<T>::st(out + ((long)(t.b0 + bl) * taps + tap) * d.pad_in + t.a0 + al, v);
+            }
         }
     }
     (void)Cin;
@@ -343,12 +388,36 @@ __global__ __launch_bounds__(NT) void snb_vectors_kernel(const mg_sn_desc* __res
 template <typename T>
 __device__ __forceinline__ void sn_load_grad_tile(const mg_sn_desc& d, const SnTile& t, const T* __restrict__ G, float* sT) {
     const int taps = d.taps;
+    using TR = ElemTraits<T>;
+    constexpr int CE = TR::CE;
     if (!d.transposed) {
+        if (sn_vec_ok<T>(G, d.pad_in, t.nb, t.b0)) {             // 16-byte loads along the channel runs
+            const int cpr = t.nb / CE;
+            for (int i = threadIdx.x; i < t.na * taps * cpr; i += NT) {
+                const int cc = i % cpr, r = i / cpr, tap = r % taps, al = r / taps;
+                float v[CE];
+                TR::unpack(*(const uint4*)(G + ((long)(t.a0 + al) * taps + tap) * d.pad_in + t.b0 + cc * CE), v);
+#pragma unroll
+                for (int e = 0; e < CE; ++e) sT[al * SN_PITCH + (cc * CE + e) * taps + tap] = v[e];
+            }
+            return;
+        }
         for (int i = threadIdx.x; i < t.na * taps * t.nb; i += NT) {
             const int bl = i % t.nb, r = i / t.nb, tap = r % taps, al = r / taps;
             sT[al * SN_PITCH + bl * taps + tap] = ElemTraits<T>::ld(G + ((long)(t.a0 + al) * taps + tap) * d.pad_in + t.b0 + bl);
         }
     } else {
+        if (sn_vec_ok<T>(G, d.pad_in, t.na, t.a0)) {
+            const int cpr = t.na / CE;
+            for (int i = threadIdx.x; i < t.nb * taps * cpr; i += NT) {
+                const int cc = i % cpr, r = i / cpr, tap = r % taps, bl = r / taps;
+                float v[CE];
+                TR::unpack(*(const uint4*)(G + ((long)(t.b0 + bl) * taps + tap) * d.pad_in + t.a0 + cc * CE), v);
+#pragma unroll
+                for (int e = 0; e < CE; ++e) sT[(cc * CE + e) * SN_PITCH + bl * taps + tap] = v[e];
+            }
+            return;
+        }
         for (int i = threadIdx.x; i < t.nb * taps * t.na; i += NT) {
             const int al = i % t.na, r = i / t.na, tap = r % taps, bl = r / taps;
             sT[al * SN_PITCH + bl * taps + tap] = ElemTraits<T>::ld(G + ((long)(t.b0 + bl) * taps + tap) * d.pad_in + t.a0 + al);
