@@ -256,6 +256,10 @@ def parallel_branches(fns, device, tag=''):
 # Off by default: measured on the frozen workload (round 3), the three loss scales + the five ASPP branches as parallel graph branches
 # made the step 2.0 ms SLOWER (14.45 -> 16.44 ms) -- fork / join edges of a replayed hipGraph cost far more than the launch floors they hide.
 PAR_BRANCHES = os.environ.get('MAGGIE_BRANCHES', '0')        # '0' | '1' | comma list of tags ('loss', 'aspp')
+if K.hip.DETERMINISTIC and (SIDE_WGRAD or PAR_BRANCHES != '0'):
+    # the ordered sums stage their partials in ONE library-owned scratch (csrc/det.hip): kernels of this library must then run on one stream at a time
+    raise K.hip.MaggieHipError('MAGGIE_SIDE_WGRAD / MAGGIE_BRANCHES run library kernels on concurrent streams, which share the slot scratch of the deterministic '
+                               'sums: set MAGGIE_DETERMINISTIC=0 with them')
 
 
 class WeightBankPlan:
