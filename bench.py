@@ -234,7 +234,8 @@ def main():
         # (2) the graph-replayed steps themselves: a rocprofv3 --kernel-trace child of this same command (fewer steps) gives the average
         #     duration of the same kernels inside the replayed graphs -- `frac` is computed from (2) when the tracer is available.
         # FLOPs are ALGORITHMIC (kernels.py): existing taps of transposed / strided data-gradient convs, unpadded channels.
-        names = ['mg_conv_fprop', 'mg_conv_fprop_ws', 'mg_conv_wgrad_ws']        # _ws: the split-K form of the same fprop family
+        names = ['mg_conv_fprop', 'mg_conv_fprop_ws', 'mg_conv_wgrad_ws', 'mg_conv_wgrad_park']   # fprop_ws: the split-K form of the fprop family; wgrad_park: the same GEMMs with the slab reduction batched
+        fam_of = {'mg_conv_fprop_ws': 'mg_conv_fprop', 'mg_conv_wgrad_park': 'mg_conv_wgrad_ws'}
         graphs_flag = model.__dict__.get('hip_graphs')
         model.hip_graphs = False
         hip.enable_timing(names)
@@ -247,7 +248,7 @@ def main():
         fam, sparse_t = {}, {}
         for n in names:
             for s_, e_, work, tag in rec[n]:
-                key = '%s/%s' % ('mg_conv_fprop' if n == 'mg_conv_fprop_ws' else n, tag[0])
+                key = '%s/%s' % (fam_of.get(n, n), tag[0])
                 dt_ = s_.elapsed_time(e_) * 1e-3
                 if work is None:                                   # sparse head (device row count): time only
                     d = sparse_t.setdefault(key, [0.0, 0]); d[0] += dt_; d[1] += 1

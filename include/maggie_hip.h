@@ -121,6 +121,18 @@ int mg_conv_wgrad(const mg_conv_params* p, void* stream);
  * partial and a second kernel reduces them; dW is then OVERWRITTEN (no pre-zeroing needed). */
 long mg_conv_wgrad_workspace(const mg_conv_params* p);
 int mg_conv_wgrad_ws(const mg_conv_params* p, float* workspace, long workspace_floats, void* stream);
+/* Parked slab reduction: mg_conv_wgrad_park runs the weight-gradient GEMM of mg_conv_wgrad_ws WITHOUT its trailing "row-split slabs -> dW"
+ * kernel and returns that reduction's descriptor; the caller keeps `workspace` alive and untouched and later hands all the descriptors of a
+ * backward pass to mg_wgrad_reduce_batched: one launch (per 64 layers) instead of one per layer (~80 per training step), same arithmetic per
+ * element, so dW has the same bits either way. splits == 0 in a returned descriptor: nothing was parked, dW is already complete. */
+typedef struct mg_wgrad_parked {
+    const float* ws;     /* the slabs: [splits][n] fp32 */
+    void* dw;            /* destination, n elements of dw_dtype */
+    long n;
+    int32_t splits, form, dw_dtype, blocks;
+} mg_wgrad_parked;
+int mg_conv_wgrad_park(const mg_conv_params* p, float* workspace, long workspace_floats, mg_wgrad_parked* out, void* stream);
+int mg_wgrad_reduce_batched(const mg_wgrad_parked* items, int count, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------------------------

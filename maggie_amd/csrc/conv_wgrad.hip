@@ -221,9 +221,11 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const mg_conv_params p
     }
 }
 
+// ---- split slabs -> dW. Three forms, each a fixed function of (splits, n): the sum of an element never depends on the launch geometry, so
+// the per-layer kernels below and the batched kernel (all the parked layers of a backward pass in one launch) give the same bits. ----
 template <typename TO>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, long n, TO* __restrict__ dw) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+__device__ __forceinline__ void reduce_elems(const float* __restrict__ ws, int splits, long n, TO* __restrict__ dw, long lb, long nblk) {
+    for (long i = lb * 256 + threadIdx.x; i < n; i += nblk * 256) {
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         int s = 0;
         for (; s + 4 <= splits; s += 4) {
@@ -233,25 +235,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         ElemTraits<TO>::st(dw + i, (a0 + a1) + (a2 + a3));
     }
 }
-
 // many splits x few elements: one wave per element, lanes stride over the splits
 template <typename TO>
-__global__ __launch_bounds__(256) void wgrad_reduce_wave_kernel(const float* __restrict__ ws, int splits, long n, TO* __restrict__ dw) {
+__device__ __forceinline__ void reduce_waves(const float* __restrict__ ws, int splits, long n, TO* __restrict__ dw, long lb, long nblk) {
     const int lane = threadIdx.x & 63;
-    for (long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += (long)gridDim.x * 4) {
+    for (long i = lb * 4 + (threadIdx.x >> 6); i < n; i += nblk * 4) {
         float a = 0.f;
         for (int s = lane; s < splits; s += 64) a += ws[(long)s * n + i];
         a = wave_sum(a);
         if (lane == 0) ElemTraits<TO>::st(dw + i, a);
     }
 }
-
 // many splits: 32 consecutive elements x 8 split groups per block -- 128-byte coalesced rows, splits/8 loads per thread, LDS finish
 template <typename TO>
-__global__ __launch_bounds__(256) void wgrad_reduce_tile_kernel(const float* __restrict__ ws, int splits, long n, TO* __restrict__ dw) {
-    __shared__ float part[8][33];
+__device__ __forceinline__ void reduce_tile(const float* __restrict__ ws, int splits, long n, TO* __restrict__ dw, long lb, float (*part)[33]) {
     const int e = threadIdx.x & 31, sg = threadIdx.x >> 5;
-    const long i = (long)blockIdx.x * 32 + e;
+    const long i = lb * 32 + e;
     float a0 = 0.f, a1 = 0.f;
     if (i < n) {
         int s = sg;
@@ -264,11 +263,64 @@ __global__ __launch_bounds__(256) void wgrad_reduce_tile_kernel(const float* __r
         ElemTraits<TO>::st(dw + i, ((part[0][e] + part[1][e]) + (part[2][e] + part[3][e])) + ((part[4][e] + part[5][e]) + (part[6][e] + part[7][e])));
 }
 
+template <typename TO>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, long n, TO* __restrict__ dw) {
+    reduce_elems<TO>(ws, splits, n, dw, blockIdx.x, gridDim.x);
+}
+template <typename TO>
+__global__ __launch_bounds__(256) void wgrad_reduce_wave_kernel(const float* __restrict__ ws, int splits, long n, TO* __restrict__ dw) {
+    reduce_waves<TO>(ws, splits, n, dw, blockIdx.x, gridDim.x);
+}
+template <typename TO>
+__global__ __launch_bounds__(256) void wgrad_reduce_tile_kernel(const float* __restrict__ ws, int splits, long n, TO* __restrict__ dw) {
+    __shared__ float part[8][33];
+    reduce_tile<TO>(ws, splits, n, dw, blockIdx.x, part);
+}
 
-// split slabs -> dW in the weight-gradient dtype (fp32, bf16 or fp16)
+// ---- parked reductions (mg_conv_wgrad_park / mg_wgrad_reduce_batched) ----------------------------------------------------------
+// A backward pass launches ~80 of the reduce kernels above, each a few microseconds of work behind ~6 us of launch: 0.55 ms per step.
+// A caller that keeps every layer's slabs until the point where all the weight gradients meet anyway (the batched SpectralNorm backward,
+// the weight bank's backward) parks the reduction instead -- the GEMM writes its slabs, the descriptor comes back -- and runs ALL of them
+// as one launch there. The table travels by value in the kernel arguments (a captured graph node owns its arguments).
+#define RED_FORM_wgrad_reduce_kernel 0
+#define RED_FORM_wgrad_reduce_wave_kernel 1
+#define RED_FORM_wgrad_reduce_tile_kernel 2
+struct ParkState { bool on; const float* ws; long n; int splits, form; long blocks; };
+static thread_local ParkState g_park = {false, nullptr, 0, 0, 0, 0};
+
+#define MG_RED_MAX 64
+struct RedEntry { const float* ws; void* dw; long n; int splits; int16_t form, dtype; uint32_t blk0, nblk; };
+struct RedTable { RedEntry e[MG_RED_MAX]; int count; };
+
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const RedTable tb) {
+    __shared__ float part[8][33];
+    int lo = 0, hi = tb.count - 1;                              // last entry whose first block is <= this block (uniform: scalar loads)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (blockIdx.x >= tb.e[mid].blk0) lo = mid; else hi = mid - 1;
+    }
+    const float* __restrict__ ws = tb.e[lo].ws;
+    void* dw = tb.e[lo].dw;
+    const long n = tb.e[lo].n;
+    const int splits = tb.e[lo].splits, form = tb.e[lo].form, dtype = tb.e[lo].dtype;
+    const long lb = (long)blockIdx.x - tb.e[lo].blk0, nblk = tb.e[lo].nblk;
+#define MG_RED_FORMS(TO)                                                          \
+    do {                                                                          \
+        if (form == 0) reduce_elems<TO>(ws, splits, n, (TO*)dw, lb, nblk);        \
+        else if (form == 1) reduce_waves<TO>(ws, splits, n, (TO*)dw, lb, nblk);   \
+        else reduce_tile<TO>(ws, splits, n, (TO*)dw, lb, part);                   \
+    } while (0)
+    if (dtype == MG_BF16) MG_RED_FORMS(bf16raw);
+    else if (dtype == MG_F16) MG_RED_FORMS(f16raw);
+    else MG_RED_FORMS(float);
+#undef MG_RED_FORMS
+}
+
+// split slabs -> dW in the weight-gradient dtype (fp32, bf16 or fp16); parked: only the descriptor is recorded
 #define MG_REDUCE_LAUNCH(KERN, B, WS, SPLITS)                                                                                                          \
     do {                                                                                                                                               \
-        if (p.dw_dtype == MG_BF16) hipLaunchKernelGGL(KERN<bf16raw>, dim3((unsigned)(B)), dim3(256), 0, st, WS, (int)(SPLITS), n, (bf16raw*)p.stats);  \
+        if (g_park.on) { g_park.ws = (WS); g_park.n = n; g_park.splits = (int)(SPLITS); g_park.form = RED_FORM_##KERN; g_park.blocks = (long)(B); }    \
+        else if (p.dw_dtype == MG_BF16) hipLaunchKernelGGL(KERN<bf16raw>, dim3((unsigned)(B)), dim3(256), 0, st, WS, (int)(SPLITS), n, (bf16raw*)p.stats);  \
         else if (p.dw_dtype == MG_F16) hipLaunchKernelGGL(KERN<f16raw>, dim3((unsigned)(B)), dim3(256), 0, st, WS, (int)(SPLITS), n, (f16raw*)p.stats); \
         else hipLaunchKernelGGL(KERN<float>, dim3((unsigned)(B)), dim3(256), 0, st, WS, (int)(SPLITS), n, p.stats);                                    \
     } while (0)
@@ -918,3 +970,50 @@ extern "C" int mg_conv_wgrad_ws(const mg_conv_params* pp, float* workspace, long
 }
 
 extern "C" int mg_conv_wgrad(const mg_conv_params* pp, void* stream) { return mg_conv_wgrad_ws(pp, nullptr, 0, stream); }
+
+/* Same as mg_conv_wgrad_ws, but the slab reduction is PARKED: the GEMM writes its row-split slabs into `workspace` (which the caller keeps
+ * untouched until the reduction has run) and `out` receives the descriptor of the reduction that was not launched (out->splits == 0: this
+ * geometry needed none, dW is complete). mg_wgrad_reduce_batched runs any number of parked reductions as one launch (per 64 of them), with
+ * the arithmetic of the per-layer kernels: parked or not, dW has the same bits. */
+extern "C" int mg_conv_wgrad_park(const mg_conv_params* pp, float* workspace, long workspace_floats, mg_wgrad_parked* out, void* stream) {
+    if (!out) return -1;
+    out->ws = nullptr; out->dw = nullptr; out->n = 0; out->splits = 0; out->form = 0; out->dw_dtype = 0; out->blocks = 0;
+    g_park = ParkState{true, nullptr, 0, 0, 0, 0};
+    const int rc = mg_conv_wgrad_ws(pp, workspace, workspace_floats, stream);
+    const ParkState got = g_park;
+    g_park.on = false;
+    if (rc) return rc;
+    if (got.splits > 0) {
+        out->ws = got.ws; out->dw = pp->stats; out->n = got.n; out->splits = got.splits; out->form = got.form; out->dw_dtype = pp->dw_dtype;
+        out->blocks = got.blocks;
+    }
+    return 0;
+}
+
+extern "C" int mg_wgrad_reduce_batched(const mg_wgrad_parked* items, int count, void* stream) {
+    if (count <= 0) return 0;
+    if (!items) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    RedTable tb;
+    int k = 0;
+    uint32_t blocks = 0;
+    auto flush = [&]() -> int {
+        if (k == 0) return 0;
+        tb.count = k;
+        hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3(blocks), dim3(256), 0, st, tb);
+        k = 0; blocks = 0;
+        hipError_t e = hipGetLastError();
+        return e == hipSuccess ? 0 : (int)e;
+    };
+    for (int i = 0; i < count; ++i) {
+        const mg_wgrad_parked& it = items[i];
+        if (it.splits <= 0 || it.n <= 0) continue;
+        if (!it.ws || !it.dw || it.blocks <= 0 || it.form < 0 || it.form > 2) return -2;
+        if (k == MG_RED_MAX || (uint64_t)blocks + (uint64_t)it.blocks > 0x3fffffffull) { int rc = flush(); if (rc) return rc; }
+        tb.e[k] = RedEntry{it.ws, it.dw, it.n, it.splits, (int16_t)it.form, (int16_t)it.dw_dtype, blocks, (uint32_t)it.blocks};
+        blocks += (uint32_t)it.blocks;
+        ++k;
+    }
+    return flush();
+}
+

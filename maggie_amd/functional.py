@@ -40,6 +40,7 @@ class ZeroArena:
 
     def reset(self, device):
         self.epoch += 1
+        del PARKED[:]                                             # leftovers of a backward pass that was abandoned halfway
         self.need = max(self.need, self.used + (1 << 16))
         if self.buf is None or self.buf.device != device or self.buf.numel() < self.need:
             self.buf = torch.zeros(self.need, dtype=torch.float32, device=device)
@@ -194,6 +195,29 @@ def _pad_krsc(w, dtype, cin_pad, cout_pad):
 # -- and nothing on the whole backward graph (9.2-9.3 ms either way: the deep layers are a small share). Off by default.
 # ----------------------------------------------------------------------------------------------------------------------
 SIDE_WGRAD = os.environ.get('MAGGIE_SIDE_WGRAD', '0') == '1'
+# Parked slab reductions (round 4): a conv whose weight came out of the batched weight pipeline or the weight bank does not launch its
+# "row-split slabs -> dW" kernel; the descriptors wait in PARKED and ONE launch runs them all where the weight gradients meet anyway
+# (SpectralNormBatch.backward / WeightBank.backward) -- ~80 launches of a few microseconds each per training step become one or two.
+# Only weights used by exactly one convolution call of the step are parked (autograd would add the gradients of a second use before the join).
+PARK_WGRAD = os.environ.get('MAGGIE_PARK_WGRAD', '1') != '0'
+PARKED = []
+
+
+def flush_parked():
+    if PARKED:
+        K.wgrad_reduce_batched(PARKED)
+
+
+def _count_use(w):
+    """-> the per-step use counter of a joined weight (a one-element list shared by every call that consumes `w`), or None."""
+    if not (PARK_WGRAD and getattr(w, '_mg_join', False)):
+        return None
+    cnt = getattr(w, '_mg_uses', None)
+    if cnt is None:
+        cnt = [0]
+        w._mg_uses = cnt
+    cnt[0] += 1
+    return cnt
 _SIDE_STREAMS = {}
 _FORKED = []
 
@@ -319,6 +343,7 @@ class WeightBank(torch.autograd.Function):
                 v = w[o:o + n_out].view(co_pad, taps, ci_pad)
                 if want_t:
                     v._mg_wt = wt[o:o + n_out].view(ci_pad, taps, co_pad)
+                v._mg_join = True                                 # its dW comes back to backward() below
                 outs.append(v)
         K.hip.call('mg_weight_bank', plan.fwd, K.c_int(plan.n), K.c_int(0), K.hip.stream())
         ctx.plan, ctx.code, ctx.dtype = plan, code, dtype
@@ -327,6 +352,7 @@ class WeightBank(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         plan = ctx.plan
+        flush_parked()                                            # the dW tensors below may still be slabs
         dev = next(g for g in grads if g is not None).device
         flat = torch.empty(plan.total_g, dtype=torch.float32, device=dev)
         fp = flat.data_ptr()
@@ -467,6 +493,7 @@ class SpectralNormBatch(torch.autograd.Function):
         outs = tuple(out[o:o + n].view(sh[0], sh[1], sh[2]) for (o, n), sh in zip(plan.out_slices, plan.shapes))
         for t_, src in zip(outs, plan.sources):
             t_._mg_side_wgrad = True                              # every dW of these weights meets again in backward() below: the join point
+            t_._mg_join = True
             t_._mg_cin = src[4]                                   # real (unpadded) input channels: algorithmic-FLOP accounting of the bench
         if out_t is not None:
             # (Cin_pad, taps, Cout) twins for the data-gradient convolution ride along as a Python attribute of each weight
@@ -481,6 +508,7 @@ class SpectralNormBatch(torch.autograd.Function):
         (work,) = ctx.saved_tensors
         dev = work.device
         join_side()                                               # the weight-gradient GEMMs ran on the side stream
+        flush_parked()                                            # ... and their slab reductions were parked until here
         keep = [None if g is None else g.to(plan.dtype).contiguous() for g in grads]
         host_ptrs = torch.tensor([0 if g is None else g.data_ptr() for g in keep], dtype=torch.int64)
         if torch.cuda.is_current_stream_capturing():
@@ -587,6 +615,7 @@ class ConvRaw(torch.autograd.Function):
         y = y.view(N, Ho, Wo, Cout)
         ctx.wt = getattr(w, '_mg_wt', None)                       # pre-transposed weights from the batched SpectralNorm kernel
         ctx.side = SIDE_WGRAD and getattr(w, '_mg_side_wgrad', False) and not transposed
+        ctx.uses = None if (transposed or ctx.side) else _count_use(w)
         # mask_upstream: the BatchNorm behind this conv's ReLU applies the ReLU mask in its own backward pass (mask_x_pos), y is not needed
         ctx.save_for_backward(x, w, y if (pre_relu and not ctx.mask_upstream) else None)
         ctx.geom = (N, H, W_, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, transposed, pre_relu, bias is not None)
@@ -634,8 +663,9 @@ class ConvRaw(torch.autograd.Function):
                 dy2.record_stream(side)
                 dw.record_stream(main)
             elif not transposed:
+                park = PARKED if (ctx.uses is not None and ctx.uses[0] == 1) else None
                 dw = K.conv_wgrad(x.view(-1, Cin), dy2, cout=Cout, mode=MODE_CONV, N=N, Hin=H, Win=W_, Hout=Ho, Wout=Wo,
-                                  R=R, S=S, stride=stride, pad=pad, dil=dil, out_dtype=w.dtype, alg_cin=ctx.cin_real)
+                                  R=R, S=S, stride=stride, pad=pad, dil=dil, out_dtype=w.dtype, alg_cin=ctx.cin_real, park=park)
             else:
                 # dW[ci, tap, co] = sum_o x[o, ci] * dy[2o - pad + k, co]  (roles of x and dy swapped)
                 dwt = K.conv_wgrad(dy2, x.view(-1, Cin), cout=Cin, mode=MODE_CONV, N=N, Hin=Ho, Win=Wo, Hout=H, Wout=W_,
@@ -900,6 +930,7 @@ class GatherConv(torch.autograd.Function):
         ctx.save_for_backward(x, w, nbr, nbr_t, y if act != ACT_NONE else None)
         ctx.meta = (reverse_taps, ksize, Cout, bias is not None, act)
         ctx.wt = getattr(w, '_mg_wt', None)          # (Cin_pad, taps [reversed for submanifold], Cout) twin from the weight bank
+        ctx.uses = _count_use(w)
         return y
 
     @staticmethod
@@ -920,7 +951,8 @@ class GatherConv(torch.autograd.Function):
                 wt = wt.contiguous()
             dx = K.conv_fprop(dy, wt, mode=MODE_GATHER, nbr=nbr_t, R=ksize, S=ksize)
         if ctx.needs_input_grad[1]:
-            dw = K.conv_wgrad(x, dy, cout=Cout, mode=MODE_GATHER, nbr=nbr, R=ksize, S=ksize, out_dtype=w.dtype)
+            park = PARKED if (ctx.uses is not None and ctx.uses[0] == 1) else None
+            dw = K.conv_wgrad(x, dy, cout=Cout, mode=MODE_GATHER, nbr=nbr, R=ksize, S=ksize, out_dtype=w.dtype, park=park)
         return dx, dw, db, None, None, None, None, None, None
 
 

@@ -201,6 +201,12 @@ class WbEntry(ctypes.Structure):
                 ('flip_t', ctypes.c_int32), ('dtype', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
+class WgradParked(ctypes.Structure):
+    """mg_wgrad_parked (include/maggie_hip.h): a weight-gradient slab reduction that was not launched yet."""
+    _fields_ = [('ws', ctypes.c_void_p), ('dw', ctypes.c_void_p), ('n', ctypes.c_long), ('splits', ctypes.c_int32), ('form', ctypes.c_int32),
+                ('dw_dtype', ctypes.c_int32), ('blocks', ctypes.c_int32)]
+
+
 class SnDesc(ctypes.Structure):
     _fields_ = [('W', ctypes.c_void_p), ('u', ctypes.c_void_p), ('v', ctypes.c_void_p), ('out_off', ctypes.c_int64),
                 ('work_off', ctypes.c_int64), ('dw_off', ctypes.c_int64), ('A', ctypes.c_int32), ('B', ctypes.c_int32),

@@ -122,10 +122,13 @@ def _fprop_workspace_fn():
 
 
 def conv_wgrad(x, dy, *, cout, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=1, Wout=1, R=1, S=1, stride=1, pad=0, dil=1,
-               M=None, nbr=None, yoff=0, out=None, out_dtype=torch.float32, rows=None, alg_cin=None, alg_cout=None):
+               M=None, nbr=None, yoff=0, out=None, out_dtype=torch.float32, rows=None, alg_cin=None, alg_cout=None, park=None):
     """dW[co, tap, ci] = sum_m dY[m, co] X[src(m,tap), ci]; (Cout, R*S, Cin) accumulated in fp32 and written as
     `out_dtype` (fp32 / bf16 -- the converting reduce saves a separate cast pass). `dy` may be a channel slice (yoff) of
-    a wider buffer."""
+    a wider buffer.
+
+    `park` (a list): the "row-split slabs -> dW" reduction is not launched; its descriptor and the slabs are appended to the list and the
+    returned dW is NOT valid until wgrad_reduce_batched(park) has run on this stream (one launch for all the parked layers)."""
     Cin = x.shape[-1]
     if mode == MODE_GATHER:
         M = nbr.shape[0] if M is None else M
@@ -144,13 +147,32 @@ def conv_wgrad(x, dy, *, cout, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=1, Wout=1
         # with a workspace (or a single row split) dW is overwritten; only the (rare) atomic fallback needs zeros
         out = torch.empty((cout, R * S, Cin), dtype=out_dtype, device=x.device) if M > 0 else \
             torch.zeros((cout, R * S, Cin), dtype=out_dtype, device=x.device)
-    ws = _wgrad_workspace(need, x.device) if need > 0 else None
     p.stats = hip.ptr(out)
     executed = 2.0 * M * cout * R * S * Cin
     work = None if rows is not None else executed * ((alg_cin or Cin) / Cin) * ((alg_cout or cout) / cout) / (stride * stride if mode == MODE_TCONV else 1)
-    hip.call('mg_conv_wgrad_ws', ctypes.byref(p), hip.ptr(ws), ctypes.c_long(need if ws is not None else 0), hip.stream(),
-             work=work, tag=(_DT_TAG[x.dtype], mode, cout, R * S * Cin, M, executed, rows is not None))
+    tag = (_DT_TAG[x.dtype], mode, cout, R * S * Cin, M, executed, rows is not None)
+    if park is not None and need > 0:
+        ws = torch.empty(int(need), dtype=torch.float32, device=x.device)      # this layer's own slabs: they live until the batched reduction
+        d = hip.WgradParked()
+        hip.call('mg_conv_wgrad_park', ctypes.byref(p), hip.ptr(ws), ctypes.c_long(need), ctypes.byref(d), hip.stream(), work=work, tag=tag)
+        if d.splits > 0:
+            park.append((d, ws, out))
+        return out
+    ws = _wgrad_workspace(need, x.device) if need > 0 else None
+    hip.call('mg_conv_wgrad_ws', ctypes.byref(p), hip.ptr(ws), ctypes.c_long(need if ws is not None else 0), hip.stream(), work=work, tag=tag)
     return out
+
+
+def wgrad_reduce_batched(park):
+    """Run every parked slab reduction of `park` (conv_wgrad(park=...)) in one launch per 64 layers and empty the list."""
+    n = len(park)
+    if n == 0:
+        return
+    arr = (hip.WgradParked * n)()
+    for i, (d, _ws, _out) in enumerate(park):
+        arr[i] = d
+    hip.call('mg_wgrad_reduce_batched', arr, c_int(n), hip.stream())
+    del park[:]
 
 
 _WS = {}

@@ -105,14 +105,14 @@ def _lin(x, w, rows, bias=None, relu=False, out=None, yoff=0, cout=None):
                         act=ACT_RELU if relu else ACT_NONE, pre_act=False, rows=rows, out=out, yoff=yoff, cout=cout)
 
 
-def _wgrad_g(x, dy, cout, nbr, rows, dtype):
-    return K.conv_wgrad(x, dy, cout=cout, mode=MODE_GATHER, nbr=nbr, R=3, S=3, M=nbr.shape[0], out_dtype=dtype, rows=rows)
+def _wgrad_g(x, dy, cout, nbr, rows, dtype, park=None):
+    return K.conv_wgrad(x, dy, cout=cout, mode=MODE_GATHER, nbr=nbr, R=3, S=3, M=nbr.shape[0], out_dtype=dtype, rows=rows, park=park)
 
 
-def _wgrad_l(x, dy, cout, rows, dtype):
+def _wgrad_l(x, dy, cout, rows, dtype, park=None):
     cap = x.shape[0]
     return K.conv_wgrad(x, dy, cout=cout, mode=MODE_CONV, N=1, Hin=1, Win=cap, Hout=1, Wout=cap, R=1, S=1, stride=1, pad=0, dil=1,
-                        out_dtype=dtype, rows=rows)
+                        out_dtype=dtype, rows=rows, park=park)
 
 
 class _BN:
@@ -276,6 +276,7 @@ class SparseHead(torch.autograd.Function):
         inv4, dn8, inv2, dn4, inv1, dn2, t4, t1 = s.tabs
         W, bn = s.W, s.bn
         gW, gB, gBN = {}, {}, {}
+        park = [] if MF.PARK_WGRAD else None                       # all the slab reductions of this backward run as ONE launch at its end
 
         def wt(name, reverse):
             t = s.wt[name]
@@ -291,16 +292,16 @@ class SparseHead(torch.autograd.Function):
 
         def subm_b(name, x, dy, tab, rows, cap, cout, need_dx=True):
             """SubM 3x3: dgrad = gather conv with the tap-reversed twin over the same table; wgrad over the table."""
-            gW[name] = _wgrad_g(x, dy, cout, tab, rows, dt)
+            gW[name] = _wgrad_g(x, dy, cout, tab, rows, dt, park)
             return _gconv(dy, wt(name, True), tab, rows, cap) if need_dx else None
 
         def inv_b(name, x, dy, tab_f, tab_c, rows_f, rows_c, cap_c, cout):
             """inverse conv (fine rows <- coarse rows): dgrad over the coarse rows with the strided table; wgrad over the fine rows."""
-            gW[name] = _wgrad_g(x, dy, cout, tab_f, rows_f, dt)
+            gW[name] = _wgrad_g(x, dy, cout, tab_f, rows_f, dt, park)
             return _gconv(dy, wt(name, False), tab_c, rows_c, cap_c)
 
         def lin_b(name, x, dy, rows, cout):
-            gW[name] = _wgrad_l(x, dy, cout, rows, dt)
+            gW[name] = _wgrad_l(x, dy, cout, rows, dt, park)
             return _lin(dy, wt(name, False), rows)
 
         fea1, fea2, fea3 = s.fea
@@ -368,6 +369,8 @@ class SparseHead(torch.autograd.Function):
         dA0 = K.rows_add(dA0, dz, out=dA0, rows=m8)               # A0 feeds the FFN AND the residual
         d_os8 = K.gather_rows_bwd_dense(dA0, l8.bits, l8.wordoff, n_i, s.os8_feat.shape, mul=s.tok32)
         _, dtok = K.gather_rows_bwd(dA0, l8.coords, n_i, s.os8_feat.shape, mul=s.tok32, dense=s.os8_feat, want_ddense=False, want_dmul=True, rows=m8)
+        if park:
+            K.wgrad_reduce_batched(park)
         # ---- hand the gradients back in the order of `params` ---------------------------------------------------------------------------
         n_par = env.n_params
         out = [None] * n_par

@@ -208,6 +208,48 @@ def test_gather_conv(dtype):
     assert (dw.cpu().reshape(Cout, 3, 3, Cin) - w_.grad).abs().max().item() <= _tol(dtype) * w_.grad.abs().max().item()
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_parked_weight_gradient_reductions_give_the_same_bits(dtype):
+    """mg_conv_wgrad_park + mg_wgrad_reduce_batched (one launch for all the layers of a backward pass) against mg_conv_wgrad_ws (one reduce
+    launch per layer): every geometry of CASES (all the kernel forms: halo, per-tap, 8-channel input, single split) plus a gather layer, fp32 and
+    16-bit dW, 70+ descriptors (more than one table of 64) -- torch.equal on every dW."""
+    from maggie_amd import kernels as K
+    from oracle import region
+    dev = _dev()
+    rs = np.random.RandomState(11)
+    park, pairs, n_parked = [], [], 0
+    for rep in range(2):
+        for (N, Cin, Cout, H, W, k, stride, pad, dil) in CASES:
+            if Cout % 8:
+                continue
+            Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+            Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+            x = torch.from_numpy(rs.normal(size=(N * H * W, Cin)).astype(np.float32)).to(dev, dtype)
+            gy = torch.from_numpy(rs.normal(size=(N * Ho * Wo, Cout)).astype(np.float32)).to(dev, dtype)
+            for od in ((torch.float32,) if dtype == torch.float32 else (torch.float32, dtype)):
+                kw = dict(cout=Cout, mode=K.MODE_CONV, N=N, Hin=H, Win=W, Hout=Ho, Wout=Wo, R=k, S=k, stride=stride, pad=pad, dil=dil, out_dtype=od)
+                ref = K.conv_wgrad(x, gy, **kw)
+                before = len(park)
+                got = K.conv_wgrad(x, gy, park=park, **kw)
+                n_parked += len(park) - before
+                pairs.append((ref, got))
+    act = rs.uniform(size=(2, 24, 20)) > 0.6
+    nbr = torch.from_numpy(region.subm_neighbors(act)).to(dev)
+    feat = torch.from_numpy(rs.normal(size=(nbr.shape[0], 64)).astype(np.float32)).to(dev, dtype)
+    gy = torch.from_numpy(rs.normal(size=(nbr.shape[0], 32)).astype(np.float32)).to(dev, dtype)
+    rows = torch.tensor([nbr.shape[0] - 37], dtype=torch.int32, device=dev)
+    for r in (None, rows):
+        ref = K.conv_wgrad(feat, gy, cout=32, mode=K.MODE_GATHER, nbr=nbr, R=3, S=3, out_dtype=dtype, rows=r)
+        got = K.conv_wgrad(feat, gy, cout=32, mode=K.MODE_GATHER, nbr=nbr, R=3, S=3, out_dtype=dtype, rows=r, park=park)
+        pairs.append((ref, got))
+    assert len(park) >= n_parked and n_parked > (64 if dtype != torch.float32 else 10), (len(park), n_parked)
+    K.wgrad_reduce_batched(park)
+    assert park == []
+    torch.cuda.synchronize()
+    for i, (ref, got) in enumerate(pairs):
+        assert ref.dtype == got.dtype and torch.equal(ref, got), i
+
+
 SPLITK_CASES = [
     # N, Cin, Cout, H, W, k, stride, pad, dil   -- deep K, few output rows: the split-K plan of mg_conv_fprop_ws
     (2, 256, 256, 16, 16, 3, 1, 1, 1),          # K 2304 (the shallowest K that splits), M 512
