@@ -860,8 +860,11 @@ extern "C" int mg_affine_act(const mg_rowwise_params* p, void* stream) {
     return 0;
 }
 
-extern "C" int mg_bn_bwd_reduce(const mg_rowwise_params* p, void* stream) {
+// `hand_over` (deterministic mode): when the partial rows number at most `hand_over_max`, they are NOT summed here -- *hand_over receives
+// them ([*hand_over_rows][2C]) and the caller's apply pass adds them in row order itself (bn_bwd_apply_fixed_kernel: one launch less per layer).
+static int bn_bwd_reduce_impl(const mg_rowwise_params* p, void* stream, float** hand_over, int* hand_over_rows, int hand_over_max) {
     int rc = rowwise_check(p); if (rc) return rc;
+    if (hand_over) { *hand_over = nullptr; *hand_over_rows = 0; }
     if (p->M <= 0) return 0;
     const int ce = MG_IS16(p->dtype) ? 8 : 4;
     // row blocks: every block ends with one atomic per channel, all blocks on the same 2C addresses -- past ~256 blocks those serialise into a
@@ -887,9 +890,11 @@ extern "C" int mg_bn_bwd_reduce(const mg_rowwise_params* p, void* stream) {
     else if (p->dtype == MG_F16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<f16raw>, dim3(g.rb, g.groups), dim3(NT), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty, slots);
     else hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty, slots);
     MG_CHECK_LAUNCH();
+    if (slots && hand_over && g.rb <= hand_over_max) { *hand_over = slots; *hand_over_rows = g.rb; return 0; }
     if (slots) return mg_det_reduce1(slots, g.rb, p->sums, 2 * p->C, (hipStream_t)stream);
     return 0;
 }
+extern "C" int mg_bn_bwd_reduce(const mg_rowwise_params* p, void* stream) { return bn_bwd_reduce_impl(p, stream, nullptr, nullptr, 0); }
 
 static bool bn_fixed_shape_ok(const mg_rowwise_params& p) {
     const int ce = MG_IS16(p.dtype) ? 8 : 4;
@@ -1224,7 +1229,13 @@ extern "C" int mg_bn_train_bwd(const mg_rowwise_params* p, int sums_zeroed, void
         hipError_t e = mg_zero_words(p->sums, 2 * p->C, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
     }
-    rc = mg_bn_bwd_reduce(p, stream); if (rc) return rc;
+    // few row blocks (the OS16 / OS32 layers and the sparse head's coarse levels): the apply pass adds the partial rows itself, in row order
+    static const int max_rows = [] { const char* e = getenv("MG_BN_BWD_HANDOVER"); return e ? atoi(e) : 32; }();
+    float* part = nullptr;
+    int nrows = 0;
+    const bool can = max_rows > 0 && !p->count_ptr && bn_fixed_shape_ok(*p);
+    rc = bn_bwd_reduce_impl(p, stream, can ? &part : nullptr, &nrows, max_rows); if (rc) return rc;
+    if (part) return bn_bwd_apply_fixed_launch(*p, part, nrows, 0, p->sums, (hipStream_t)stream);
     return mg_bn_bwd_apply(p, stream);
 }
 
