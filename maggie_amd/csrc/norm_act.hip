@@ -1229,8 +1229,10 @@ extern "C" int mg_bn_train_bwd(const mg_rowwise_params* p, int sums_zeroed, void
         hipError_t e = mg_zero_words(p->sums, 2 * p->C, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;
     }
-    // few row blocks (the OS16 / OS32 layers and the sparse head's coarse levels): the apply pass adds the partial rows itself, in row order
-    static const int max_rows = [] { const char* e = getenv("MG_BN_BWD_HANDOVER"); return e ? atoi(e) : 32; }();
+    // MG_BN_BWD_HANDOVER=n: layers with <= n row blocks skip the ordered-sum launch, the apply pass adds the partial rows itself. Off by default:
+    // measured 11.97 / 11.77 ms (n = 32) against 11.74 / 11.71 ms (off) on one lease, 12.05 at n = 64 -- every workgroup of the apply pass repeats
+    // the row sum in front of its streaming part, which costs what the removed ~6 us launch saved.
+    static const int max_rows = [] { const char* e = getenv("MG_BN_BWD_HANDOVER"); return e ? atoi(e) : 0; }();
     float* part = nullptr;
     int nrows = 0;
     const bool can = max_rows > 0 && !p->count_ptr && bn_fixed_shape_ok(*p);
