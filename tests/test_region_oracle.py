@@ -25,6 +25,18 @@ def test_dilate_matches_bruteforce_all_widths():
         assert np.array_equal(region.dilate(img, k), region.dilate_bruteforce(img, k)), k
 
 
+def test_dilate_matches_scipy_ndimage_all_widths():
+    """A third, independent implementation: scipy.ndimage.maximum_filter with the ellipse as footprint is the same correlation-form
+    dilation with the anchor at k // 2 and "pixels outside the image do not count" (mode='constant', cval=0) that cv2.dilate documents."""
+    import scipy.ndimage as ndi
+    rs = np.random.RandomState(3)
+    img = (rs.uniform(size=(37, 41)) > 0.95).astype(np.uint8)
+    img[0, 0] = img[-1, -1] = img[0, -1] = 1
+    for k in range(1, 30):
+        ref = ndi.maximum_filter(img, footprint=region.ellipse_kernel(k).astype(bool), mode='constant', cval=0)
+        assert np.array_equal(region.dilate(img, k), ref), k
+
+
 def test_compute_unknown_thresholds_and_single_pixel():
     a = np.zeros((1, 32, 32), np.float32)
     a[0, 16, 16] = 0.5
