@@ -790,7 +790,10 @@ struct WgradHaloPlan { long splits; int tpb; };
 static WgradHaloPlan plan_wgrad_halo(const mg_conv_params& p) {
     const long cc = (long)(p.Cin / 32) * (p.Cout / 32);
     const long S = (long)p.N * ((p.Hout + 7) / 8) * ((p.Wout + 15) / 16);
-    static const long target = [] { const char* e = getenv("MG_WGRAD_HALO_BLOCKS"); return e ? atol(e) : 512l; }();
+    // ~one workgroup per CU: with the slab reductions parked (mg_conv_wgrad_park) the slabs come back from HBM, not from the Infinity Cache, and
+    // every spatial split is 36 KB per (co, ci) tile written and read once more -- 256 against 512: 11.61 against 11.70 ms per step (3 x 200-step
+    // pairs on one lease; 128: 11.83)
+    static const long target = [] { const char* e = getenv("MG_WGRAD_HALO_BLOCKS"); return e ? atol(e) : 256l; }();
     const long n = (long)p.Cout * 9 * p.Cin;
     long splits = (target + cc - 1) / cc;
     if (splits > S) splits = S;
