@@ -335,7 +335,7 @@ def main():
                                    'fwd+loss+bwd+clip+AdamW' % (kind, args.size, args.size, args.instances, b, n_f, args.iter,
                                                                 'detail region guided by the ground-truth alphas, soft edge %g px: constant active ratio' % args.edge
                                                                 if args.workload == 'gt' else 'detail region from the predicted coarse alpha: drifts with the random-init weights'),
-                       'global_batch': b * world, 'parallelism': 'dp%d' % world, 'sync_bn': bool(args.sync_bn and (world > 1 or (force_ddp and os.environ.get('MAGGIE_SYNCBN_WORLD1') == '1'))), 'sync_bn_path': None if not args.sync_bn else ('eager (host-launched collectives, MAGGIE_SYNCBN_GRAPHS=0)' if parallel.SYNCBN_COMM is None else 'hipGraphs (statistics exchange recorded into the graphs through %s; default for sync_bn: true)' % ('the mailbox all-reduce kernels (one node, peer access)' if type(parallel.SYNCBN_COMM).__name__ == 'MailboxComm' else 'a private RCCL communicator')), 'optimizer': 'FlatAdamW (clip 0.01 folded in)' if args.optimizer == 'flat' else 'torch AdamW(%s) + flat-buffer grad-norm clip' % args.optimizer,
+                       'global_batch': b * world, 'parallelism': 'dp%d' % world, 'sync_bn': bool(args.sync_bn and (world > 1 or (force_ddp and os.environ.get('MAGGIE_SYNCBN_WORLD1') == '1'))), 'sync_bn_path': None if not args.sync_bn else ('eager (host-launched collectives: MAGGIE_SYNCBN_GRAPHS=0, or no in-graph exchange could be set up on this group)' if parallel.SYNCBN_COMM is None else 'hipGraphs (statistics exchange recorded into the graphs through %s; default for sync_bn: true)' % ('the mailbox all-reduce kernels (one node, peer access)' if type(parallel.SYNCBN_COMM).__name__ == 'MailboxComm' else 'a private RCCL communicator')), 'optimizer': 'FlatAdamW (clip 0.01 folded in)' if args.optimizer == 'flat' else 'torch AdamW(%s) + flat-buffer grad-norm clip' % args.optimizer,
                        'grad_allreduce': None if world == 1 and not force_ddp else ('torch DDP' if args.ddp else ('RCCL all-reduce (mean) of each of the three backward graphs\' stretches of the optimizer\'s flat gradient buffer, in place on a side stream, overlapped with the rest of backward (parallel.OverlappedGradSync + FlatAdamW gradient sink)' if (args.optimizer == 'flat' and os.environ.get('MAGGIE_GRAD_OVERLAP', '1') != '0') else 'one RCCL all-reduce of the flat gradient buffer inside FlatAdamW.step' if args.optimizer == 'flat' else 'GradSync (flat-buffer RCCL all-reduce)')),
                        'peak_hbm_gb': round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1), 'active_ratio': round(active_ratio, 4), 'active_ratio_per_timed_step': [round(float(v) / (b * n_f * args.instances * args.size * args.size), 3) for v in stats['active_hist']] if not args.no_roofline else None, 'active_pixels_per_step_per_gpu': int(active_px), 'loss_total': round(loss_val, 4)},
             'roofline': roofline, 'cpu_baseline': cpu_baseline,

@@ -29,25 +29,63 @@ class MailboxComm:
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else device
         lib = hip.lib()
         self._own = ctypes.c_void_p()
+        self._opened = []
+        # Every step of the set-up is followed by a vote over the group, so that ALL ranks leave this constructor the same way (communicator or
+        # exception): a rank that failed alone would otherwise go on to other collectives while its peers still wait in this one.
         handle = (ctypes.c_char * 64)()
-        hip.check(lib.mg_mailbox_create(ctypes.c_int(self.world), ctypes.byref(self._own), handle), 'mg_mailbox_create')
+        rc = lib.mg_mailbox_create(ctypes.c_int(self.world), ctypes.byref(self._own), handle)
         handles = [None] * self.world
-        dist.all_gather_object(handles, bytes(handle), group=group)
+        dist.all_gather_object(handles, (int(rc), bytes(handle)), group=group)
+        bad = [r for r, (c, _) in enumerate(handles) if c != 0]
+        if bad:
+            self.destroy()
+            raise hip.MaggieHipError('MailboxComm: mg_mailbox_create failed on rank(s) %s (no fine-grained device memory / IPC export there)' % bad)
         self._mb = _Mailbox()
         self._mb.world, self._mb.rank = self.world, self.rank
-        self._opened = []
-        for r, h in enumerate(handles):
+        rc_open = 0
+        for r, (_, h) in enumerate(handles):
             if r == self.rank:
                 self._mb.peer[r] = self._own.value
             else:
                 p = ctypes.c_void_p()
-                hip.check(lib.mg_mailbox_open(ctypes.c_char_p(h), ctypes.byref(p)), 'mg_mailbox_open (rank %d)' % r)
-                self._mb.peer[r] = p.value
-                self._opened.append(p)
+                rc_open = rc_open or int(lib.mg_mailbox_open(ctypes.c_char_p(h), ctypes.byref(p)))
+                if p.value:
+                    self._mb.peer[r] = p.value
+                    self._opened.append(p)
         self._state = torch.zeros(2, dtype=torch.int32, device=self.device)       # [exchange counter, error word]
         self._spin = int(spin_seconds * 1e8)                                     # wall_clock64 ticks (100 MHz)
         self.calls = 0
-        dist.barrier(group=group)                                                # nobody deposits before every mailbox is mapped everywhere
+        votes = [None] * self.world                                              # also the barrier: nobody deposits before every mailbox is mapped everywhere
+        dist.all_gather_object(votes, rc_open, group=group)
+        if any(votes):
+            self.destroy()
+            raise hip.MaggieHipError('MailboxComm: mapping a peer mailbox failed on rank(s) %s' % [r for r, v in enumerate(votes) if v])
+        # ... and the protocol itself is tried before anything relies on it: two exchanges with a short spin budget (peer-mapped fine-grained memory and
+        # system-scope atomics between DIFFERENT devices are the one thing the single-GPU tests of this project cannot exercise)
+        ok = self._self_test()
+        dist.all_gather_object(votes, bool(ok), group=group)
+        if not all(votes):
+            self.destroy()
+            raise hip.MaggieHipError('MailboxComm: the exchange self-test failed on rank(s) %s' % [r for r, v in enumerate(votes) if not v])
+
+    def _self_test(self):
+        spin, self._spin = self._spin, int(3.0 * 1e8)
+        try:
+            base = torch.arange(1, 9, dtype=torch.float32, device=self.device)
+            ok = True
+            for it in range(2):
+                t = base * float(self.rank + 1) + float(it)
+                self.all_reduce_sum_(t)
+                want = torch.arange(1, 9, dtype=torch.float32) * (self.world * (self.world + 1) / 2.0) + float(it * self.world)
+                ok = ok and bool(torch.equal(t.cpu(), want))
+            ok = ok and int(self._state[1].item()) == 0
+            self._state[1].zero_()
+            self.calls = 0
+            return ok
+        except Exception:
+            return False
+        finally:
+            self._spin = spin
 
     def all_reduce_sum_(self, t):
         """In-place sum over the ranks of a contiguous fp32 device tensor, on the current stream (eager or capturing)."""

@@ -178,7 +178,8 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
                                     'a BatchNorm layer is bound to a sub-group' if sub else 'MAGGIE_SYNCBN_GRAPHS=0')
                 return False
             from ... import parallel
-            parallel.syncbn_direct_comm()                         # collective on first use: every rank reaches its first training forward
+            if parallel.syncbn_direct_comm() is None:             # collective on first use: every rank reaches its first training forward
+                return False                                      # neither exchange form could be set up on this group (warned once): eager step
             return True
         return True
 

@@ -47,39 +47,66 @@ def _mailbox_possible(group):
     return all(votes)
 
 
+SYNCBN_COMM_FAILED = False     # no in-graph exchange could be set up (decided once, collectively): sync_bn then runs through torch.distributed, eagerly
+
+
+def _all_ranks(ok, group):
+    votes = [None] * dist.get_world_size(group)
+    dist.all_gather_object(votes, bool(ok), group=group)
+    return all(votes)
+
+
 def syncbn_direct_comm(group=None):
     """The communicator of the in-graph SyncBN statistics exchange, created on first use -- COLLECTIVELY: every rank must get here at the same
     point (MaGGIe._graph_policy calls it on every rank's first training forward; `setup_syncbn` does it explicitly at set-up time).
     MAGGIE_SYNCBN_COMM = auto (default): the mailbox kernels (one plain kernel per exchange, fused with the BatchNorm finalize, rank-ordered sums)
-    when every rank is on one node with peer access and every rank could create its fine-grained mailbox, else the private RCCL communicator;
-    `mailbox` / `rccl` force one."""
-    global SYNCBN_COMM
-    if SYNCBN_COMM is None:
-        import os
-        kind = os.environ.get('MAGGIE_SYNCBN_COMM', 'auto')
-        if kind == 'auto':
-            kind = 'mailbox' if _mailbox_possible(group) else 'rccl'
-            if kind == 'mailbox':
-                from .mailbox import MailboxComm
-                try:
-                    comm, ok = MailboxComm(group), True
-                except Exception:                                 # e.g. no fine-grained allocation on this device
-                    comm, ok = None, False
-                votes = [None] * dist.get_world_size(group)
-                dist.all_gather_object(votes, ok, group=group)
-                if all(votes):
-                    SYNCBN_COMM = comm
-                    return SYNCBN_COMM
-                if comm is not None:
-                    comm.destroy()
-                kind = 'rccl'
+    when every rank is on one node with peer access, every rank could create and map the fine-grained mailboxes AND a trial exchange gave the right
+    sums everywhere; else the private RCCL communicator (also tried with one small all-reduce); else None -- the caller then keeps the eager
+    torch.distributed exchange. Every decision is a vote over the group: all ranks end up on the same path. `mailbox` / `rccl` force one form and
+    raise when it cannot be had."""
+    global SYNCBN_COMM, SYNCBN_COMM_FAILED
+    if SYNCBN_COMM is not None or SYNCBN_COMM_FAILED:
+        return SYNCBN_COMM
+    import logging
+    import os
+    kind = os.environ.get('MAGGIE_SYNCBN_COMM', 'auto')
+    if kind not in ('auto', 'mailbox', 'rccl'):
+        raise ValueError('MAGGIE_SYNCBN_COMM must be auto, mailbox or rccl, not %r' % kind)
+    why = []
+    if kind == 'mailbox' or (kind == 'auto' and _mailbox_possible(group)):
+        from .mailbox import MailboxComm
+        comm = None
+        try:
+            comm = MailboxComm(group)                             # votes inside: all ranks get a communicator or all get the exception
+        except Exception as e:                                   # noqa: BLE001 -- whatever went wrong, the answer is the next form
+            why.append('mailbox: %s' % e)
+        if _all_ranks(comm is not None, group):
+            SYNCBN_COMM = comm
+            return SYNCBN_COMM
+        if comm is not None:
+            comm.destroy()
         if kind == 'mailbox':
-            from .mailbox import MailboxComm
-            SYNCBN_COMM = MailboxComm(group)
-        else:
-            from .rccl_direct import DirectComm
-            SYNCBN_COMM = DirectComm(group)
-    return SYNCBN_COMM
+            raise RuntimeError('MAGGIE_SYNCBN_COMM=mailbox: the mailbox exchange could not be set up (%s)' % '; '.join(why))
+    from .rccl_direct import DirectComm
+    comm = None
+    try:
+        comm = DirectComm(group)
+        if not comm.self_test():
+            raise RuntimeError('trial all-reduce gave wrong sums')
+    except Exception as e:                                       # noqa: BLE001
+        why.append('rccl: %s' % e)
+        comm = None
+    if _all_ranks(comm is not None, group):
+        SYNCBN_COMM = comm
+        return SYNCBN_COMM
+    if comm is not None:
+        comm.destroy()
+    if kind == 'rccl':
+        raise RuntimeError('MAGGIE_SYNCBN_COMM=rccl: the private RCCL communicator could not be set up (%s)' % '; '.join(why))
+    SYNCBN_COMM_FAILED = True
+    logging.warning('MaGGIe (MI355X build): no in-graph SyncBN exchange on this group (%s) -- sync_bn runs through torch.distributed, eagerly',
+                    '; '.join(why) or 'a peer rank failed')
+    return None
 
 
 def setup_syncbn(model=None, group=None):
@@ -95,7 +122,8 @@ def setup_syncbn(model=None, group=None):
 
 
 def syncbn_destroy_comm():
-    global SYNCBN_COMM
+    global SYNCBN_COMM, SYNCBN_COMM_FAILED
+    SYNCBN_COMM_FAILED = False
     if SYNCBN_COMM is not None:
         SYNCBN_COMM.destroy()
         SYNCBN_COMM = None

@@ -53,15 +53,25 @@ class DirectComm:
         lib = _lib()
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         uid = _UniqueId()
-        if self.rank == 0:
-            _check(lib.ncclGetUniqueId(ctypes.byref(uid)), 'ncclGetUniqueId')
-        box = [bytes(bytearray(uid)) if self.rank == 0 else None]
+        rc0 = lib.ncclGetUniqueId(ctypes.byref(uid)) if self.rank == 0 else 0
+        box = [(rc0, bytes(bytearray(uid))) if self.rank == 0 else None]      # a failure on rank 0 travels WITH the broadcast: nobody waits for an id that never comes
         src = dist.get_global_rank(group, 0) if group is not None else 0
         dist.broadcast_object_list(box, src=src, group=group)
-        ctypes.memmove(ctypes.addressof(uid), box[0], 128)
-        self.comm = ctypes.c_void_p()
-        _check(lib.ncclCommInitRank(ctypes.byref(self.comm), self.world, uid, self.rank), 'ncclCommInitRank')
+        self.comm = None
+        _check(box[0][0], 'ncclGetUniqueId (rank 0)')
+        ctypes.memmove(ctypes.addressof(uid), box[0][1], 128)
+        comm = ctypes.c_void_p()
+        _check(lib.ncclCommInitRank(ctypes.byref(comm), self.world, uid, self.rank), 'ncclCommInitRank')
+        self.comm = comm
         self.calls = 0
+
+    def self_test(self):
+        """One small all-reduce outside any capture: rank r contributes (r + 1) * [1, 2, 3, 4] -> world * (world + 1) / 2 * [1, 2, 3, 4] everywhere."""
+        t = torch.tensor([1.0, 2.0, 3.0, 4.0], device='cuda') * float(self.rank + 1)
+        self.all_reduce_sum_(t)
+        self.calls -= 1
+        want = torch.tensor([1.0, 2.0, 3.0, 4.0]) * (self.world * (self.world + 1) / 2.0)
+        return bool(torch.equal(t.cpu(), want))
 
     def all_reduce_sum_(self, t):
         """In-place sum over the ranks of a contiguous fp32 device tensor, on the current torch stream (eager or capturing)."""
