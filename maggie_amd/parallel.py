@@ -95,6 +95,8 @@ def syncbn_direct_comm(group=None):
             raise RuntimeError('trial all-reduce gave wrong sums')
     except Exception as e:                                       # noqa: BLE001
         why.append('rccl: %s' % e)
+        if comm is not None:
+            comm.destroy()
         comm = None
     if _all_ranks(comm is not None, group):
         SYNCBN_COMM = comm

@@ -269,6 +269,87 @@ def test_syncbn_exchange_world_size_2_gloo(tmp_path):
         assert p.returncode == 0, out.decode()
 
 
+_COMM_VOTE_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+dist.init_process_group('gloo', rank=int(os.environ['RANK']), world_size=2)
+from maggie_amd import parallel, mailbox, rccl_direct
+r = dist.get_rank()
+made = []
+
+class FakeComm:
+    def __init__(self, kind):
+        self.kind, self.destroyed, self.calls = kind, False, 0
+        made.append(self)
+    def self_test(self):
+        return True
+    def destroy(self):
+        self.destroyed = True
+
+def mailbox_ctor(fail_on):
+    def ctor(group=None):
+        # the real constructor votes inside, so it raises on EVERY rank or on none; here one rank alone fails: the outer vote must still agree
+        if r in fail_on:
+            raise RuntimeError('no fine-grained memory on rank %%d' %% r)
+        return FakeComm('mailbox')
+    return ctor
+
+def rccl_ctor(fail_on, bad_sums_on=()):
+    def ctor(group=None):
+        if r in fail_on:
+            raise RuntimeError('ncclCommInitRank failed on rank %%d' %% r)
+        c = FakeComm('rccl')
+        if r in bad_sums_on:
+            c.self_test = lambda: False
+        return c
+    return ctor
+
+def run(kind, mb_possible, mb_fail, rc_fail, rc_bad=()):
+    os.environ['MAGGIE_SYNCBN_COMM'] = kind
+    parallel.syncbn_destroy_comm()
+    del made[:]
+    parallel._mailbox_possible = lambda group: mb_possible
+    mailbox.MailboxComm = mailbox_ctor(mb_fail)
+    rccl_direct.DirectComm = rccl_ctor(rc_fail, rc_bad)
+    try:
+        got = parallel.syncbn_direct_comm()
+        res = None if got is None else got.kind
+    except RuntimeError as e:
+        res = 'raised'
+    kinds = [None, None]
+    dist.all_gather_object(kinds, res)
+    assert kinds[0] == kinds[1], (kind, kinds)              # every rank on the same path, whatever failed where
+    live = [c for c in made if not c.destroyed]
+    assert len(live) == (0 if res in (None, 'raised') else 1), (res, [(c.kind, c.destroyed) for c in made])
+    return res
+
+assert run('auto', True, (), ()) == 'mailbox'
+assert run('auto', True, (1,), ()) == 'rccl'                 # one rank cannot build its mailbox -> both take the RCCL communicator, rank 0's mailbox is destroyed
+assert run('auto', True, (0,), (1,)) is None                 # ... and RCCL fails on the other rank -> both keep the eager exchange
+assert parallel.SYNCBN_COMM_FAILED and parallel.syncbn_direct_comm() is None      # decided once
+assert run('auto', False, (), ()) == 'rccl'
+assert run('auto', False, (), (), rc_bad=(1,)) is None       # the trial all-reduce gave wrong sums on one rank
+assert run('mailbox', False, (1,), ()) == 'raised'           # a forced form that cannot be had raises on every rank
+assert run('rccl', True, (), (0,)) == 'raised'
+assert run('rccl', True, (), ()) == 'rccl'
+dist.destroy_process_group()
+"""
+
+
+def test_syncbn_comm_setup_votes_world_size_2_gloo(tmp_path):
+    """parallel.syncbn_direct_comm's fallback chain (mailbox -> private RCCL communicator -> eager exchange) with communicators that fail on ONE
+    rank only: both ranks must come out on the same path, the half-built communicator of the other rank destroyed."""
+    script = tmp_path / 'vote.py'
+    script.write_text(_COMM_VOTE_WORKER % ROOT)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29619')
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=120)
+        assert p.returncode == 0, out.decode()
+
+
 _OVERLAP_WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %r)
