@@ -481,6 +481,7 @@ def cpu_baseline_subprocess(args):
           (['--acc-file', args.acc_file] if getattr(args, 'acc_file', '') else [])
     env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
     part = None
+    timed_out = False
     try:
         pr = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
         out, _ = pr.communicate(timeout=limit_s)
@@ -488,10 +489,17 @@ def cpu_baseline_subprocess(args):
     except subprocess.TimeoutExpired:
         pr.kill()
         out = pr.communicate()[0].decode(errors='replace')
+        timed_out = True
     for line in out.splitlines():                                   # the worker prints a (growing) result line after every timed step
         if line.startswith('CPU_BASELINE '):
             part = json.loads(line[len('CPU_BASELINE '):])
     if part is not None:
+        if timed_out and 'per_thread_setting' in part and args.cpu_threads <= 0:
+            # a thread setting the worker had started but not finished a single step of when the budget ran out (the all-cores setting on a
+            # 256-core host: the model's many small ops take minutes per step there) is reported as such, not dropped
+            cores = os.cpu_count() or 1
+            for t in [min(cores, 32)] + ([cores] if cores > 32 else []):
+                part['per_thread_setting'].setdefault(str(t), {'value': None, 'note': 'not one step finished within the %d s budget of the CPU legs' % limit_s})
         return part
     return {'value': None, 'unit': 'instance-frames/s', 'cores': os.cpu_count(), 'kind': 'port', 'sample': 'failed: ' + out[-300:]}
 
