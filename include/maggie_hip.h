@@ -38,6 +38,10 @@ int mg_abi_version(void);
 /* Declare [base, base + bytes) zero-filled with every part handed to at most one accumulator (NULL, 0: no such range). Entry points that clear an
  * accumulator with a fill launch of their own skip it for buffers inside the range -- the host's per-graph zero arena (one memset node per replay). */
 int mg_set_zeroed_range(void* base, long bytes);
+/* The invariant is checked: an entry point asked to clear words of the range that an earlier call already claimed fails with hipErrorAlreadyMapped
+ * (208) instead of silently keeping stale sums; mg_zeroed_range_conflicts() returns (and resets) how often that happened. */
+int mg_zero_claim(void* p, long bytes);
+int mg_zeroed_range_conflicts(void);
 
 /* Bit-reproducible steps. The reference trains with torch.backends.cudnn.deterministic = True, benchmark = False (tools/main.py:135-136): two
  * runs of one step give the same bits, so the active-pixel index map -- a threshold of the coarse alpha (maggie/utils/utils.py:31) -- is the same

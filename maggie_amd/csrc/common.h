@@ -145,9 +145,11 @@ static __global__ void mg_zero_words_kernel(uint32_t* __restrict__ p, long n) {
 // (mg_set_zeroed_range) and promises to hand every slice out once. ~60 fill launches of ~4.7 us per step disappear from the captured graphs.
 extern "C" char* mg_zeroed_lo;
 extern "C" char* mg_zeroed_hi;
+extern "C" int mg_zero_claim(void* p, long bytes);        // csrc/abi.hip: 1 = these words were already handed to an accumulator in the current range
 static inline hipError_t mg_zero_words(void* p, long n_words, hipStream_t st) {
     if (n_words <= 0) return hipSuccess;
-    if ((char*)p >= mg_zeroed_lo && (char*)p + 4 * n_words <= mg_zeroed_hi) return hipSuccess;
+    if ((char*)p >= mg_zeroed_lo && (char*)p + 4 * n_words <= mg_zeroed_hi)
+        return mg_zero_claim(p, 4 * n_words) ? hipErrorAlreadyMapped : hipSuccess;
     long blocks = (n_words + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(mg_zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint32_t*)p, n_words);

@@ -167,6 +167,38 @@ def test_graphs_are_dropped_when_parameters_move():
         assert float((r['alpha'] - eager['alpha']).abs().max()) <= 1e-4 and torch.equal(r['mask'], eager['mask'])
 
 
+@pytest.mark.gpu
+def test_zero_arena_slice_cannot_be_cleared_twice_inside_a_capture():
+    """Inside a capture the library skips its own fill launch for accumulators carved from the graph's zero arena (mg_set_zeroed_range). The
+    invariant behind that -- every slice is cleared by ONE callee, once -- is checked: a second clear of the same words fails the entry point
+    (hipErrorAlreadyMapped) instead of leaving stale sums in a replayed graph (csrc/common.h mg_zero_words)."""
+    from maggie_amd import functional as MF, hip
+    dev = torch.device('cuda:0')
+    stats = torch.randn(64, 16, device=dev)
+    ref = torch.empty(16, device=dev)
+    call = lambda out: hip.call('mg_stat_rows_sum', hip.ptr(stats), hip.c_int(64), hip.c_int(16), hip.ptr(out), hip.stream())      # noqa: E731
+    call(ref)                                                     # eager: plain fill launch, any number of times
+    call(ref)
+    hip.lib().mg_zeroed_range_conflicts()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        MF.ARENA.begin_capture(dev)
+        try:
+            a, b = MF.ARENA.acc(16, dev), MF.ARENA.acc(16, dev)
+            call(a)
+            call(b)                                               # another slice: fine
+            with pytest.raises(hip.MaggieHipError):
+                call(a)                                           # the same words again: refused
+        finally:
+            MF.ARENA.end_capture()
+    assert hip.lib().mg_zeroed_range_conflicts() == 1
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(a, ref) and torch.equal(b, ref)
+    call(ref)                                                     # outside the capture the range is gone: fills again
+    assert hip.lib().mg_zeroed_range_conflicts() == 0
+
+
 def test_flat_adamw_rehoming_with_graphs():
     """FlatAdamW moves every trainable parameter into one flat buffer. Graphs captured before that must be dropped (addresses
     changed), the re-captured ones must read the re-homed parameters (an optimizer step changes what the next replay computes),
