@@ -122,6 +122,47 @@ def test_train_step_is_bit_reproducible(kind, bf16, it):
     assert 0.0 < float(m.mean()) < 1.0, 'the step must refine something for the index map to mean anything'
 
 
+@pytest.mark.parametrize('kind', ['image', 'video'])
+def test_parked_slab_reductions_leave_the_step_unchanged(kind):
+    """The weight-gradient slab reductions parked until the gradients meet (functional.PARKED, one launch per backward pass) against one reduce
+    launch per layer (MAGGIE_PARK_WGRAD=0): the same step, eagerly and from a replayed graph, bit for bit -- every gradient, loss and buffer."""
+    from maggie_amd import functional as MF
+    from maggie_amd.utils import synth
+    dev = _dev()
+    n_f = 3 if kind == 'video' else 1
+    model, _ = _build(kind, dev, True)
+    batch = _to(synth.synthetic_batch(2 if kind == 'image' else 1, n_f, 2, 64, 64, seed=DSEED, train=True, max_inst=10, it=10000), dev)
+    state = copy.deepcopy(model.state_dict())
+
+    def step(graphs):
+        model.load_state_dict(state)
+        _reset_dropout(model)
+        model.hip_graphs = graphs
+        model.zero_grad(set_to_none=True)
+        seed_all(5)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            out, loss = model(batch)
+        loss['total'].backward()
+        assert MF.PARKED == [], 'every parked reduction must have run by the end of the backward pass'
+        return _snapshot(model, out, loss)
+
+    assert MF.PARK_WGRAD, 'parking is the default'
+    snaps = {}
+    try:
+        for park in (True, False):
+            MF.PARK_WGRAD = park
+            for store in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs', '_detail_names'):
+                model.__dict__.get(store, {}).clear()              # graphs captured under the other setting hold its launches
+            snaps[park, 'eager'] = step(False)
+            snaps[park, 'graph'] = [step(True) for _ in range(4)][-1]
+    finally:
+        MF.PARK_WGRAD = True
+    _assert_same_bits(snaps[True, 'eager'], snaps[False, 'eager'], 'eager step, parked vs per-layer reductions')
+    _assert_same_bits(snaps[True, 'graph'], snaps[False, 'graph'], 'replayed step, parked vs per-layer reductions')
+    _assert_same_bits(snaps[True, 'graph'], snaps[True, 'eager'], 'parked reductions: replay vs eager')
+    assert any(k.startswith('grad/') for k in snaps[True, 'eager'])
+
+
 def _reset_dropout(model):
     """The sparse head's dropout draws from a counter (seed, step) kept on the device (maggie_amd/sparse_head.py:DeviceRng, created at the first
     training forward under torch.initial_seed()): put it back to step 0 of seed 5 -- what the first run, made under seed_all(5), found."""
