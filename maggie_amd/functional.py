@@ -700,6 +700,23 @@ def _sync_group(bn):
     return None
 
 
+def rows_of(t, C):
+    """(rows, C) view of a channels-last tensor for the row-wise kernels (they take a row pitch): no copy when `t` is a channel slice of a wider
+    row-major buffer -- the gradient torch.cat hands to each of its inputs (the five ASPP branches) -- else the contiguous copy."""
+    if t.is_contiguous():
+        return t.view(-1, C)
+    if t.dim() >= 2 and t.shape[-1] == C and t.stride(-1) == 1 and t.data_ptr() % 16 == 0:
+        ld = t.stride(-2)
+        ok, pitch = ld >= C and ld % 8 == 0, ld
+        for d in range(t.dim() - 2, -1, -1):                      # the leading dimensions must walk rows of one pitch, row-major
+            if t.shape[d] > 1 and t.stride(d) != pitch:
+                ok = False
+            pitch *= t.shape[d]
+        if ok:
+            return t.as_strided((t.numel() // C, C), (ld, 1))
+    return t.contiguous().view(-1, C)
+
+
 class BNAct(torch.autograd.Function):
     """y = act( BN(x) + res ).  x, y: (..., C) rows x channels. Training uses batch statistics (optionally
     pre-accumulated by the producing conv's epilogue) and updates running stats in place."""
@@ -803,7 +820,7 @@ class BNAct(torch.autograd.Function):
             # inside a graph capture the accumulator is a slice of the graph's own zero arena (no fill kernel per layer); eagerly the
             # sums leave as gradients and must outlive the step's arena, so they get their own (zeroed in the call)
             sums = ARENA.take(2 * C, dy.device) if torch.cuda.is_current_stream_capturing() else None
-            dx, dres, sums = K.bn_train_bwd(dy.contiguous().view(-1, C), y, x2, pack, act, LRELU_SLOPE, has_res, mask_x_pos, sums)
+            dx, dres, sums = K.bn_train_bwd(rows_of(dy, C), y, x2, pack, act, LRELU_SLOPE, has_res, mask_x_pos, sums)
             if has_res:
                 dres = K.pool2x2(dres, 1, shape[0], shape[1] // 2, shape[2] // 2).view(res_shape) if res_mode == 2 else dres.view(res_shape)
             return dx.view(shape), sums[C:], sums[:C], dres, None, None, None, None, None, None, None, None, None, None, None, None

@@ -131,6 +131,22 @@ print('SHIM_OK')
 
 
 @pytest.mark.gpu
+def test_rows_of_takes_channel_slices_without_a_copy():
+    """functional.rows_of: the (rows, C) operand of the row-wise kernels is a strided VIEW for a channel slice of a wider row-major buffer (what
+    torch.cat's backward hands to each input) and a contiguous copy for anything the kernels' single row pitch cannot express."""
+    import torch
+    from maggie_amd.functional import rows_of
+    g = torch.randn(4, 16, 16, 1280)
+    v = g.narrow(-1, 256, 256)
+    r = rows_of(v, 256)
+    assert r.data_ptr() == v.data_ptr() and r.stride() == (1280, 1) and torch.equal(r, v.reshape(-1, 256))
+    for bad in (g.permute(0, 2, 1, 3)[..., :256], g[:, ::2, :, :256], g.narrow(-1, 1, 256)):     # transposed rows / row gaps / a start that is not 16-byte aligned
+        rb = rows_of(bad, 256)
+        assert rb.is_contiguous() and torch.equal(rb, bad.reshape(-1, 256))
+    c = torch.randn(2, 3, 8)
+    assert rows_of(c, 8).data_ptr() == c.data_ptr()
+
+
 def test_autocast_dtype_selects_the_kernel_family():
     """engine/train.py:208,227-229 runs fp16 autocast + GradScaler under `--precision 16`: served by the fp16 kernel family (not silently by
     bf16 under a loss scaler); bf16 autocast -> the bf16 family; MAGGIE_FP16_AUTOCAST=bf16 is the explicit mapping of fp16 autocast onto bf16."""
