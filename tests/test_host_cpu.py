@@ -130,7 +130,6 @@ print('SHIM_OK')
     assert out.returncode == 0 and b'SHIM_OK' in out.stdout, out.stdout.decode()
 
 
-@pytest.mark.gpu
 def test_rows_of_takes_channel_slices_without_a_copy():
     """functional.rows_of: the (rows, C) operand of the row-wise kernels is a strided VIEW for a channel slice of a wider row-major buffer (what
     torch.cat's backward hands to each input) and a contiguous copy for anything the kernels' single row pitch cannot express."""
@@ -147,6 +146,7 @@ def test_rows_of_takes_channel_slices_without_a_copy():
     assert rows_of(c, 8).data_ptr() == c.data_ptr()
 
 
+@pytest.mark.gpu
 def test_autocast_dtype_selects_the_kernel_family():
     """engine/train.py:208,227-229 runs fp16 autocast + GradScaler under `--precision 16`: served by the fp16 kernel family (not silently by
     bf16 under a loss scaler); bf16 autocast -> the bf16 family; MAGGIE_FP16_AUTOCAST=bf16 is the explicit mapping of fp16 autocast onto bf16."""
