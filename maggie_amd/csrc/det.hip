@@ -67,6 +67,24 @@ __global__ __launch_bounds__(NT) void det_reduce_kernel(const float* __restrict_
     if (col < ncols) {
         const float* p = slots + ((size_t)g * nblk + b0) * rowstride + col0 + col;
         int b = b0;
+        // sixteen loads in flight per batch (a chunk is <= 32 rows: one or two L2 round trips instead of eight); the additions keep the order of
+        // the four-wide loop below, so the sums have the same bits whichever loop ran
+        for (; b + 15 < b1; b += 16) {
+            float x[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) x[u] = p[(size_t)u * rowstride];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) { a0 += x[u]; a1 += x[u + 1]; a2 += x[u + 2]; a3 += x[u + 3]; }
+            p += 16 * (size_t)rowstride;
+        }
+        for (; b + 7 < b1; b += 8) {
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = p[(size_t)u * rowstride];
+#pragma unroll
+            for (int u = 0; u < 8; u += 4) { a0 += x[u]; a1 += x[u + 1]; a2 += x[u + 2]; a3 += x[u + 3]; }
+            p += 8 * (size_t)rowstride;
+        }
         for (; b + 3 < b1; b += 4) {
             const float x0 = p[0], x1 = p[(size_t)rowstride], x2 = p[2 * (size_t)rowstride], x3 = p[3 * (size_t)rowstride];
             a0 += x0; a1 += x1; a2 += x2; a3 += x3;
