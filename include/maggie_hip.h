@@ -598,6 +598,9 @@ int mg_token_linear_multi_bwd(const mg_tok_lin* ops, int n, void* stream);
 int mg_token_einsum_fwd(const void* feat, int dtype, const float* tok, int B, int L, int C, int Q, int QP, void* out, void* stream);
 int mg_token_einsum_bwd(const void* dlog, const void* feat, int dtype, const float* tok, int B, int L, int C, int Q, int QP, void* dfeat,
                         float* dtok, void* stream);
+/* out[i] = ((srcs[0][i] + srcs[1][i]) + srcs[2][i]) + ... : the gradient of a tensor with k <= 16 consumers in one launch and a fixed order (replaces
+ * the k - 1 pairwise adds of the autograd engine; maggie/network/module/mask_attention.py:63-133 uses every token tensor several times). fp32. */
+int mg_sum_k(const float* const* srcs, int k, long n, float* out, void* stream);
 int mg_token_sa_fwd(const float* q, const float* k, const float* v, const unsigned char* pad, float scale, int B, int T, int D, float* out, float* prob,
                     void* stream);
 int mg_token_sa_bwd(const float* dout, const float* q, const float* k, const float* v, const float* prob, float scale, int B, int T, int D, float* dq,

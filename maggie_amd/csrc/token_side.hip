@@ -733,3 +733,32 @@ extern "C" int mg_token_linear_multi_bwd(const mg_tok_lin* ops, int n, void* str
     MG_CHECK_LAUNCH();
     return 0;
 }
+
+// ---- gradient of a tensor with several consumers as ONE launch: out[i] = ((src_0[i] + src_1[i]) + src_2[i]) + ... in the given order (autograd
+// adds the k gradients pairwise, k - 1 launches of a few microseconds each; the token side of the instance matte decoder has ~45 of them per step:
+// maggie_amd/functional.py FanOut). fp32, n elements, k <= 16.
+namespace {
+struct SumSrcs { const float* p[16]; int k; };
+__global__ __launch_bounds__(256) void sum_k_kernel(const SumSrcs s, long n, float* __restrict__ out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = j < s.k ? s.p[j][i] : 0.f;
+        float a = v[0];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) if (j < s.k) a += v[j];
+        out[i] = a;
+    }
+}
+}  // namespace
+extern "C" int mg_sum_k(const float* const* srcs, int k, long n, float* out, void* stream) {
+    if (!srcs || !out || k < 1 || k > 16 || n < 0) return -2;
+    if (n == 0) return 0;
+    SumSrcs s; s.k = k;
+    for (int j = 0; j < 16; ++j) { s.p[j] = j < k ? srcs[j] : nullptr; if (j < k && !srcs[j]) return -2; }
+    long b = (n + 255) / 256; if (b > 2048) b = 2048;
+    hipLaunchKernelGGL(sum_k_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, s, n, out);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+

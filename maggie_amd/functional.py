@@ -1657,6 +1657,58 @@ def token_linear(x, W, b=None, xadd=None, res=None, relu=False, ln=None, wt=Fals
     return TokenLinear.apply(x, xadd, W, b, res, relu, g, be, eps, wt)
 
 
+FAN_OUT = os.environ.get('MAGGIE_FAN_OUT', '1') != '0'
+
+
+class FanOut(torch.autograd.Function):
+    """k aliases of one tensor, one per consumer: the k gradients then arrive HERE together and are added by one launch in alias order
+    (mg_sum_k), instead of the k - 1 pairwise add kernels the autograd engine issues for a tensor it sees consumed k times. The token side of the
+    instance matte decoder uses its tokens, their position embedding and the ID table 4-13 times each (mask_attention.py:63-133)."""
+
+    @staticmethod
+    def forward(ctx, t, k):
+        ctx.set_materialize_grads(False)
+        return tuple(t.view_as(t) for _ in range(k))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        live = [g for g in gs if g is not None]
+        if not live:
+            return None, None
+        ok = all(g.is_cuda and g.dtype == torch.float32 and g.shape == live[0].shape for g in live)
+        if not ok:
+            total = live[0]
+            for g in live[1:]:
+                total = total + g
+            return total, None
+        live = [g.contiguous() for g in live]
+        while len(live) > 1:                                      # (more than 16 consumers: the first 16 collapse into one term)
+            live = [K.sum_k(live[:16])] + live[16:]
+        return live[0], None
+
+
+class Fan:
+    """Hands out the aliases of FanOut one by one: `f = Fan(t, k)`, then `f()` wherever `t` would have been passed to a consumer. A tensor that needs
+    no gradient (or MAGGIE_FAN_OUT=0) is handed out as it is; running out of aliases falls back to the tensor itself (autograd then adds that
+    consumer's gradient the ordinary way)."""
+    __slots__ = ('t', 'outs')
+
+    def __init__(self, t, k):
+        self.t = t
+        use = FAN_OUT and t is not None and torch.is_grad_enabled() and t.requires_grad and t.is_cuda and t.dtype == torch.float32 and k > 2
+        self.outs = list(FanOut.apply(t, k)) if use else None
+
+    def __call__(self):
+        if self.outs:
+            return self.outs.pop()
+        return self.t
+
+
+def take(x):
+    """x() for a Fan, x for a tensor / None: layer code that accepts either."""
+    return x() if isinstance(x, Fan) else x
+
+
 class TokenLinearMulti(torch.autograd.Function):
     """Up to six INDEPENDENT TokenLinear layers in one launch each way (mg_token_linear_multi_fwd / _bwd): inputs are 7 slots per layer
     (x, xadd, W, b, res, gamma, beta; None where absent), `specs` = per layer (relu, eps, wt)."""

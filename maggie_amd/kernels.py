@@ -163,6 +163,16 @@ def conv_wgrad(x, dy, *, cout, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=1, Wout=1
     return out
 
 
+def sum_k(ts):
+    """Sum of up to 16 same-shaped contiguous fp32 device tensors in ONE launch, added in list order (mg_sum_k)."""
+    n = ts[0].numel()
+    out = torch.empty_like(ts[0])
+    hip.need_cuda(*ts)
+    arr = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    hip.call('mg_sum_k', arr, c_int(len(ts)), ctypes.c_long(n), hip.ptr(out), hip.stream())
+    return out
+
+
 def wgrad_reduce_batched(park):
     """Run every parked slab reduction of `park` (conv_wgrad(park=...)) in one launch per 64 layers and empty the list."""
     n = len(park)

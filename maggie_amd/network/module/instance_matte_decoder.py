@@ -105,8 +105,12 @@ class InstanceMatteDecoder(nn.Module):
         feat = MF.linear_rows(ori_feat.reshape(-1, C), wproj, lin.bias.float()).float().view(b, n_f * h * w, -1)
 
         max_loss, atten_terms = 0, []
-        pos_t = token_pos if self.use_id_pe else None
-        tbl = id_table if self.use_id_pe else None
+        # the position embedding (13 consumers), the ID table (7) and every block's tokens (4) are handed out as one alias per consumer
+        # (functional.Fan): the gradients of a tensor then meet in ONE launch instead of consumer-count - 1 autograd add kernels (~30 per step)
+        pos = MF.Fan(token_pos, 16)
+        idt = MF.Fan(id_table, 10) if id_table is not None else None
+        pos_t = pos if self.use_id_pe else None
+        tbl = idt if self.use_id_pe else None
         if not self.use_id_pe:
             feat_ids = torch.zeros_like(feat_ids)
 
@@ -119,23 +123,26 @@ class InstanceMatteDecoder(nn.Module):
                 if self.training:
                     atten_terms.append(self.compute_atten_loss(b, n_f, guidance_mask, att))
                 tokens = self.mlp_layers[i](tokens)
-                tokens = self.sa_layers[i](tokens, tgt_key_padding_mask=token_padding_mask, query_pos=token_pos)
+                tokens = self.sa_layers[i](tokens, tgt_key_padding_mask=token_padding_mask, query_pos=pos)
                 # both cross attentions that follow start from THESE tokens (the features <- tokens block does not change them): their two
                 # levels of token-side linears run as ONE launch per level (5 independent layers each) instead of two
                 fft = self.feat_token_ca_layers[i]
+                tk = MF.Fan(tokens, 4)                            # k and v of the features <- tokens block, q of the next block, its residual
                 if not MF.TOKEN_XBLOCK:
-                    feat = fft.features_from_tokens(feat, feat_ids, tbl, tokens, pos_t, token_padding_mask)
+                    feat = fft.features_from_tokens(feat, feat_ids, tbl, tk, pos_t, token_padding_mask)
+                    tokens = tk
                     continue
                 last = i + 1 == self.n_block
                 nxt = self.final_token_feat_ca if last else self.token_feat_ca_layers[i + 1]
-                nxt_pos, nxt_tbl = (token_pos, id_table) if last else (pos_t, tbl)
-                l1a, l1b = fft.fft_level1(tokens, pos_t, tbl), nxt.tff_level1(tokens, nxt_pos, nxt_tbl)
+                nxt_pos, nxt_tbl = (pos, idt) if last else (pos_t, tbl)
+                l1a, l1b = fft.fft_level1(tk, pos_t, tbl), nxt.tff_level1(tk, nxt_pos, nxt_tbl)
                 r1 = MF.token_linear_multi(l1a + l1b)
                 l2a, l2b = fft.fft_level2(r1[:len(l1a)], tbl), nxt.tff_level2(r1[len(l1a):], nxt_tbl)
                 r2 = MF.token_linear_multi(l2a + l2b)
                 feat = fft.features_from_tokens(feat, feat_ids, tbl, tokens, pos_t, token_padding_mask, pre=r2[:len(l2a)])
                 pre = r2[len(l2a):]
-            tokens, att = self.final_token_feat_ca.tokens_from_features(tokens, token_pos, feat, feat_ids, id_table, pre=pre)
+                tokens = tk                                       # the next tokens <- features block takes its residual alias (tff_finish)
+            tokens, att = self.final_token_feat_ca.tokens_from_features(tokens, pos, feat, feat_ids, idt, pre=pre)
             if self.training:
                 atten_terms.append(self.compute_atten_loss(b, n_f, guidance_mask, att))
             if atten_terms:                                       # mean over the n_block + 1 attention maps: one launch (mg_scalar_lincomb)

@@ -53,10 +53,11 @@ class SelfAttentionLayer(nn.Module):
         """tgt: (b, T, d) tokens; key padding mask (b, T) True = ignore. Five HIP launches: three projections (position added inside),
         the T x T attention core, out-projection + residual + LayerNorm (mg_token_linear_*, mg_token_sa_*)."""
         (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.self_attn)
-        q, k, v = MF.token_linear_multi([dict(x=tgt, W=wq, b=bq, xadd=query_pos), dict(x=tgt, W=wk, b=bk, xadd=query_pos),
-                                         dict(x=tgt, W=wv, b=bv)])                                       # three projections, one launch
+        tg = MF.Fan(tgt, 4)                                        # four consumers: their gradients meet in one launch (functional.FanOut)
+        q, k, v = MF.token_linear_multi([dict(x=tg(), W=wq, b=bq, xadd=MF.take(query_pos)), dict(x=tg(), W=wk, b=bk, xadd=MF.take(query_pos)),
+                                         dict(x=tg(), W=wv, b=bv)])                                      # three projections, one launch
         ctx = MF.token_self_attention(q, k, v, tgt_key_padding_mask)
-        return MF.token_linear(ctx, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, res=tgt, ln=self.norm)
+        return MF.token_linear(ctx, self.self_attn.out_proj.weight, self.self_attn.out_proj.bias, res=tg(), ln=self.norm)
 
 
 class CrossAttentionLayer(nn.Module):
@@ -76,9 +77,10 @@ class CrossAttentionLayer(nn.Module):
 
     def tff_level1(self, tokens, token_pos, id_table):
         (wq, wk, wv), (bq, bk, bv) = self._proj = _split_in_proj(self.multihead_attn)      # ONE unbind per forward: the later stages reuse the slices
-        layers = [dict(x=tokens, W=wq, b=bq, xadd=token_pos)]                                # q
+        # (tokens / token_pos / id_table: tensors, or functional.Fan objects handing out one alias per consumer)
+        layers = [dict(x=MF.take(tokens), W=wq, b=bq, xadd=MF.take(token_pos))]              # q
         if id_table is not None:
-            layers.append(dict(x=id_table, W=wk, b=bk))                                      # key_pos (n_id, d): E[id] Wk^T + bk
+            layers.append(dict(x=MF.take(id_table), W=wk, b=bk))                             # key_pos (n_id, d): E[id] Wk^T + bk
         return layers
 
     def tff_level2(self, res1, id_table):
@@ -91,6 +93,7 @@ class CrossAttentionLayer(nn.Module):
     def tff_finish(self, tokens, res2, feat, feat_ids):
         (wq, wk, wv), (bq, bk, bv) = self._proj
         qk, tbl = res2
+        tokens = MF.take(tokens)
         d = tokens.shape[-1]
         _need_hip_attention(tokens.shape[1], d)
         p, ctx = MF.attn_tokens_from_features(qk, tbl, feat, feat_ids, 1.0 / math.sqrt(d))
@@ -110,9 +113,9 @@ class CrossAttentionLayer(nn.Module):
 
     def fft_level1(self, tokens, token_pos, id_table):
         (wq, wk, wv), (bq, bk, bv) = self._proj = _split_in_proj(self.multihead_attn)
-        layers = [dict(x=tokens, W=wk, b=bk, xadd=token_pos), dict(x=tokens, W=wv, b=bv)]    # k (b,T,d), v
+        layers = [dict(x=MF.take(tokens), W=wk, b=bk, xadd=MF.take(token_pos)), dict(x=MF.take(tokens), W=wv, b=bv)]    # k (b,T,d), v
         if id_table is not None:
-            layers.append(dict(x=id_table, W=wq, b=bq))                                      # qry_pos (n_id, d)
+            layers.append(dict(x=MF.take(id_table), W=wq, b=bq))                             # qry_pos (n_id, d)
         return layers
 
     def fft_level2(self, res1, id_table):
@@ -136,10 +139,11 @@ class CrossAttentionLayer(nn.Module):
         """feat (b,L,d) <- tokens (b,T,d); query position = id_table[feat_ids]. Scores, masked softmax over the T tokens and
         the value mix are one HIP kernel per direction (mg_attn_feat_fwd / _bwd); residual + LayerNorm over the b * L rows one more.
         `pre`: the level-2 results (vp, kq, tbl) when the caller already computed them in a batched launch."""
+        n_tokens = (tokens.t if isinstance(tokens, MF.Fan) else tokens).shape[1]
         if pre is None:
             res1 = MF.token_linear_multi(self.fft_level1(tokens, token_pos, id_table))
             pre = MF.token_linear_multi(self.fft_level2(res1, id_table))
-        return self.fft_finish(feat, feat_ids, pre, token_padding_mask, tokens.shape[1])
+        return self.fft_finish(feat, feat_ids, pre, token_padding_mask, n_tokens)
 
 
 class FFNLayer(nn.Module):
