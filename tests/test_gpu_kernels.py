@@ -1278,3 +1278,26 @@ def test_matting_losses_of_three_scales_in_one_pipeline(with_valid):
         assert torch.allclose(o1, ref, rtol=2e-6, atol=1e-7)
         for g_ in g1:
             assert float(g_.view(10, H, W)[2].abs().max()) == 0.0 and float(g_.view(10, H, W)[8].abs().max()) == 0.0
+
+
+def test_fan_out_adds_the_consumer_gradients_in_one_ordered_launch():
+    """functional.Fan / FanOut: k aliases of a tensor, one per consumer; the k gradients are added by mg_sum_k as ((g0 + g1) + g2) + ... in alias
+    order. Against plain autograd (pairwise adds) and against the same order written out; 20 consumers (> one table of 16); an unused alias."""
+    from maggie_amd import functional as MF, kernels as K
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(3)
+    ws = [torch.randn(4, 10, 128, generator=g).to(dev) for _ in range(20)]
+    for k in (3, 5, 20):
+        t = torch.randn(4, 10, 128, generator=g).to(dev).requires_grad_(True)
+        f = MF.Fan(t, k + 1)                                       # one alias stays unused
+        assert f.outs is not None
+        used = [f() for _ in range(k)]
+        sum((a * w).sum() for a, w in zip(used, ws)).backward()
+        got = t.grad.clone()
+        t.grad = None
+        sum((t * w).sum() for w in ws[:k]).backward()
+        assert torch.allclose(got, t.grad, rtol=1e-6, atol=1e-6)
+    a, b, c = ws[:3]
+    assert torch.equal(K.sum_k([a, b, c]), (a + b) + c)
+    plain = torch.randn(3, 4, device=dev)                          # no gradient wanted: the tensor itself is handed out
+    assert MF.Fan(plain, 4)() is plain and MF.take(plain) is plain and MF.take(None) is None
