@@ -60,7 +60,7 @@ class MailboxComm:
         if any(votes):
             self.destroy()
             raise hip.MaggieHipError('MailboxComm: mapping a peer mailbox failed on rank(s) %s' % [r for r, v in enumerate(votes) if v])
-        # ... and the protocol itself is tried before anything relies on it: two exchanges with a short spin budget (peer-mapped fine-grained memory and
+        # ... and the protocol itself is tried before anything relies on it: two exchanges with a 10 s spin budget (peer-mapped fine-grained memory and
         # system-scope atomics between DIFFERENT devices are the one thing the single-GPU tests of this project cannot exercise)
         ok = self._self_test()
         dist.all_gather_object(votes, bool(ok), group=group)
@@ -69,7 +69,7 @@ class MailboxComm:
             raise hip.MaggieHipError('MailboxComm: the exchange self-test failed on rank(s) %s' % [r for r, v in enumerate(votes) if not v])
 
     def _self_test(self):
-        spin, self._spin = self._spin, int(3.0 * 1e8)
+        spin, self._spin = self._spin, int(10.0 * 1e8)       # (ranks sharing ONE GPU time-slice: an exchange can take a good fraction of a second)
         try:
             base = torch.arange(1, 9, dtype=torch.float32, device=self.device)
             ok = True
