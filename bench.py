@@ -561,8 +561,22 @@ def run_cpu_baseline(kind, args):
       torch.set_num_threads(threads)
       tr_s, ev_s = [], []
       slow = False
+      watchdog = None
       if si > 0 and not args.cpu_baseline_full:
           n_timed = 2                                              # the second setting only has to show which one is faster
+          # ... and must not hold the bench line back: on a 256-core host one step of this model's many small ops under 256 torch threads takes
+          # minutes. If its warm-up step is not done after `cap` seconds the setting is reported as unfinished and the worker ends here.
+          import threading
+          cap = max(60.0, 4.0 * inst / res['value']) if res.get('value') else 120.0
+
+          def bail(threads=threads, cap=cap):
+              res['per_thread_setting'][str(threads)] = {'value': None, 'note': 'warm-up step not finished after %.0f s (the other setting: %.1f s per step): abandoned' % (
+                  cap, inst / res['value'] if res.get('value') else float('nan'))}
+              print('CPU_BASELINE ' + json.dumps(res), flush=True)
+              os._exit(0)
+          watchdog = threading.Timer(cap, bail)
+          watchdog.daemon = True
+          watchdog.start()
       for i in range(n_warm + n_timed):
         sd = {k: v.clone() for k, v in sd0.items()}
         for k, v in sd.items():
@@ -574,6 +588,9 @@ def run_cpu_baseline(kind, args):
         loss['total'].backward()
         dt = time.perf_counter() - t0
         res['active_ratio'] = round(float(out['detail_mask'].float().mean()) * 10.0 / args.instances, 4)
+        if watchdog is not None:
+            watchdog.cancel()
+            watchdog = None
         if i >= n_warm:
             tr_s.append(dt)
             emit(threads, tr_s, ev_s)
