@@ -17,32 +17,37 @@
 #include "../../include/maggie_hip.h"
 
 int mg_det_on = 1;
-static char* g_buf = nullptr;
-static long g_bytes = 0;
-static int g_dev = -1;
+// One scratch PER DEVICE, allocated once and never freed or moved: captured graphs hold its address (the first version kept a
+// single process-wide buffer and re-allocated it on growth or on a device change, under the feet of graphs captured before).
+constexpr int MG_MAX_DEVICES = 16;
+static char* g_buf[MG_MAX_DEVICES] = {};
+static long g_bytes[MG_MAX_DEVICES] = {};
 
 extern "C" int mg_set_deterministic(int on) { mg_det_on = on ? 1 : 0; return 0; }
 extern "C" int mg_get_deterministic(void) { return mg_det_on; }
 extern "C" int mg_stat_rows(void) { return mg_det_on ? MG_DET_STAT_ROWS : MG_STAT_REPLICAS; }
 
-/* Allocate the slot scratch on the CURRENT device (idempotent; grows). Must be called outside a stream capture -- the Python binding
- * does so on its first call into the library. */
+/* Allocate the slot scratch of the CURRENT device (idempotent). Must be called outside a stream capture -- the Python binding does so on its
+ * first call into the library on each device. A later call asking for MORE than the device's scratch holds fails with MG_DET_NO_SCRATCH (-7): the
+ * buffer's address is part of every graph captured so far, so it never grows -- size it up front (MAGGIE_DET_SCRATCH_MB). */
 extern "C" int mg_det_init(long bytes) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
-    if (g_buf && dev == g_dev && g_bytes >= bytes) return 0;
-    if (g_buf) { (void)hipSetDevice(g_dev); (void)hipFree(g_buf); (void)hipSetDevice(dev); g_buf = nullptr; g_bytes = 0; }
+    if (dev < 0 || dev >= MG_MAX_DEVICES) return -2;
+    if (g_buf[dev]) return g_bytes[dev] >= bytes ? 0 : MG_DET_NO_SCRATCH;
     void* p = nullptr;
     e = hipMalloc(&p, (size_t)bytes);
     if (e != hipSuccess) return (int)e;
-    g_buf = (char*)p; g_bytes = bytes; g_dev = dev;
+    g_buf[dev] = (char*)p; g_bytes[dev] = bytes;
     return 0;
 }
 
 float* mg_det_scratch(long floats) {
-    if (!g_buf || floats * 4 > g_bytes) return nullptr;
-    return (float*)g_buf;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MG_MAX_DEVICES) return nullptr;
+    if (!g_buf[dev] || floats * 4 > g_bytes[dev]) return nullptr;
+    return (float*)g_buf[dev];
 }
 
 namespace {

@@ -1175,6 +1175,22 @@ extern "C" int mg_bn_train_fwd(const mg_rowwise_params* p_in, float* stats_ws, i
         // deterministic mode: one-pass statistics with one row per row block / conv output tile (`own`: [MG_DET_STAT_ROWS][2C]), added in row
         // order by bn_finalize_rows_kernel. The two-pass variance needs the column sums BEFORE its second pass, i.e. a cross-workgroup sum in the
         // middle of the layer: it stays with the <= 1024-row layers, which run it inside one workgroup (bn_small, above).
+        //
+        // fp32 storage (round 5, ADVICE medium): the one-pass E[x^2] - E[x]^2 loses var's digits when |mean| >> std, and with fp32 storage nothing else
+        // hides that (16-bit storage rounds x itself to 2^-8 |x| first). Layers the caller marks `exact` (<= EXACT_STATS_ROWS rows) and the sparse
+        // head's device-row-count layers therefore keep the two-pass variance here too, in its ordered form: column sums by row blocks -> slots ->
+        // ordered sum, centred second moments the same way (mg_colstats_centered_dev; four small launches, parity mode only).
+        if (p.dtype == MG_F32 && (exact || p.m_dev) && !stats) {
+            if (!own) return -3;
+            if (!ws_zeroed) { hipError_t e = mg_zero_words(own, 2 * C, st); if (e != hipSuccess) return (int)e; }
+            if (p.M > 0) { rc = mg_colstats_centered_dev(p.x, p.dtype, p.M, C, p.ldx, own, 0, p.m_dev, stream); if (rc) return rc; }
+            p.count = (float)p.M;
+            rc = bn_finalize_launch(own, 1, nullptr, (float)p.M, C, 1, gamma, beta, running_mean, running_var, momentum, eps, outs, outs + C, outs + 2 * C,
+                                    outs + 3 * C, p.m_dev, stream, p.count_mult);
+            if (rc) return rc;
+            p.scale = outs; p.shift = outs + C;
+            return mg_affine_act(&p, stream);
+        }
         if (!stats) {
             if (!own) return -3;
             if (!ws_zeroed) { hipError_t e = mg_zero_words(own, (long)MG_DET_STAT_ROWS * 2 * C, st); if (e != hipSuccess) return (int)e; }

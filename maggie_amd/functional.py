@@ -208,8 +208,29 @@ def flush_parked():
         K.wgrad_reduce_batched(PARKED)
 
 
+def _parked_must_be_flushed():
+    """Runs when the autograd engine has finished the backward pass (or the captured backward) in which something was parked: every parked slab
+    reduction must have met its join (SpectralNormBatch.backward / WeightBank.backward) INSIDE that pass -- otherwise a dW left this pass as
+    unreduced slabs (a graph split that puts the join into another graph would replay the GEMMs without ever reducing them). ADVICE round 4."""
+    if PARKED:
+        n = len(PARKED)
+        del PARKED[:]
+        raise K.hip.MaggieHipError('%d parked weight-gradient slab reduction(s) were never flushed: the backward pass that parked them ended before '
+                                   'the join of their weights (SpectralNormBatch / WeightBank backward) ran -- the weight gradients of this pass are '
+                                   'invalid. Set MAGGIE_PARK_WGRAD=0 if the weight pipeline and its convolutions are differentiated separately.' % n)
+
+
+def _park_list():
+    """-> PARKED, with the end-of-backward check armed on the first parking of a backward pass."""
+    if not PARKED:
+        torch.autograd.Variable._execution_engine.queue_callback(_parked_must_be_flushed)
+    return PARKED
+
+
 def _count_use(w):
-    """-> the per-step use counter of a joined weight (a one-element list shared by every call that consumes `w`), or None."""
+    """-> the per-step use counter of a joined weight (a one-element list shared by every autograd Function of this module that consumes `w`:
+    ConvRaw in every mode -- also the transposed and side-stream forms, which never park themselves -- and GatherConv), or None. A weight is
+    parked only when this counter says its dW has ONE producer: autograd would add a second producer's gradient into the unreduced slabs."""
     if not (PARK_WGRAD and getattr(w, '_mg_join', False)):
         return None
     cnt = getattr(w, '_mg_uses', None)
@@ -615,7 +636,8 @@ class ConvRaw(torch.autograd.Function):
         y = y.view(N, Ho, Wo, Cout)
         ctx.wt = getattr(w, '_mg_wt', None)                       # pre-transposed weights from the batched SpectralNorm kernel
         ctx.side = SIDE_WGRAD and getattr(w, '_mg_side_wgrad', False) and not transposed
-        ctx.uses = None if (transposed or ctx.side) else _count_use(w)
+        ctx.uses = _count_use(w)                                  # every use counts; only the plain form below ever parks
+        ctx.can_park = not (transposed or ctx.side)
         # mask_upstream: the BatchNorm behind this conv's ReLU applies the ReLU mask in its own backward pass (mask_x_pos), y is not needed
         ctx.save_for_backward(x, w, y if (pre_relu and not ctx.mask_upstream) else None)
         ctx.geom = (N, H, W_, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, transposed, pre_relu, bias is not None)
@@ -663,7 +685,7 @@ class ConvRaw(torch.autograd.Function):
                 dy2.record_stream(side)
                 dw.record_stream(main)
             elif not transposed:
-                park = PARKED if (ctx.uses is not None and ctx.uses[0] == 1) else None
+                park = _park_list() if (ctx.can_park and ctx.uses is not None and ctx.uses[0] == 1) else None
                 dw = K.conv_wgrad(x.view(-1, Cin), dy2, cout=Cout, mode=MODE_CONV, N=N, Hin=H, Win=W_, Hout=Ho, Wout=Wo,
                                   R=R, S=S, stride=stride, pad=pad, dil=dil, out_dtype=w.dtype, alg_cin=ctx.cin_real, park=park)
             else:
@@ -733,7 +755,10 @@ class BNAct(torch.autograd.Function):
         if training and group is None and gamma.dtype == torch.float32 and gamma.numel() == C and M > 0 and \
                 (running_mean is None or running_mean.numel() == C):
             # the common case (local statistics, unpadded channels) in one C call: statistics, finalize, apply
-            exact = M <= (BN_SMALL_ROWS if K.hip.DETERMINISTIC else EXACT_STATS_ROWS)      # (deterministic mode: exact only where one workgroup does it)
+            # exact two-pass variance: <= EXACT_STATS_ROWS rows. Deterministic mode keeps it for the <= BN_SMALL_ROWS layers (one workgroup, no
+            # cross-workgroup step) and for fp32 storage (ordered two-pass form, csrc/norm_act.hip: with 16-bit storage the rounding of x itself,
+            # 2^-8 |x|, is far above what E[x^2] - E[x]^2 loses; with fp32 storage it is not -- ADVICE round 4)
+            exact = M <= BN_SMALL_ROWS or (M <= EXACT_STATS_ROWS and (not K.hip.DETERMINISTIC or x2.dtype == torch.float32))
             if exact and stats is not None and stats.dim() != 1:
                 stats = None                                      # replicas from a conv epilogue: the exact path recomputes
             r2 = None if res is None else res.contiguous().view(-1, C)
@@ -871,12 +896,12 @@ def batch_norm_act(x, bn, act=ACT_NONE, res=None, stats=None, res_mode=1, mask_x
                        _sync_group(bn) if training else None, mask_x_pos, link, count_mult)
 
 
-def new_stats(channels, device, rows=None, bn=None, geom=None):
+def new_stats(channels, device, rows=None, bn=None, geom=None, dtype=None):
     """Zeroed accumulator for the conv epilogue's BatchNorm statistics. Layers that will use the exact two-pass variance
     (`rows` <= EXACT_STATS_ROWS, no SyncBN) only need the column sums: one row [2*channels] (conv stat_mode 1)."""
     if K.hip.DETERMINISTIC:
-        if rows is not None and rows <= BN_SMALL_ROWS and (bn is None or _sync_group(bn) is None):
-            return None                                            # the one-workgroup BatchNorm computes its own (exact) statistics
+        if rows is not None and (rows <= BN_SMALL_ROWS or (rows <= EXACT_STATS_ROWS and dtype == torch.float32)) and (bn is None or _sync_group(bn) is None):
+            return None                                            # the one-workgroup / ordered two-pass BatchNorm computes its own (exact) statistics
         n = K.conv_stat_rows(rows if rows is not None else 1, *geom) if geom else K.conv_stat_rows(rows if rows is not None else 1)
         return ARENA.take(n * 2 * channels, device).view(n, 2 * channels)
     if rows is not None and rows <= EXACT_STATS_ROWS and (bn is None or _sync_group(bn) is None):
@@ -912,7 +937,7 @@ def conv_bn_act(x, w, bn, act=ACT_NONE, R=3, S=3, stride=1, pad=1, dil=1, transp
         ho_, wo_ = K.conv_out_size(mode_, x.shape[1], R, stride, pad, dil), K.conv_out_size(mode_, x.shape[2], S, stride, pad, dil)
         rows = x.shape[0] * ho_ * wo_
         # fused statistics in the conv epilogue -- except on the largest, thinnest tensors (UNFUSED_STATS_ROWS)
-        stats = new_stats(Cout, x.device, rows, bn, geom=(x.shape[0], ho_, wo_)) if rows < UNFUSED_STATS_ROWS else None
+        stats = new_stats(Cout, x.device, rows, bn, geom=(x.shape[0], ho_, wo_), dtype=x.dtype) if rows < UNFUSED_STATS_ROWS else None
     xc = None
     # ReLU-before-BN (encoder shortcuts): the BatchNorm's backward applies the ReLU mask itself (mask_x_pos: its input IS the ReLU output),
     # so the conv's backward needs neither its saved output nor a masking pass over the gradient
@@ -968,7 +993,7 @@ class GatherConv(torch.autograd.Function):
                 wt = wt.contiguous()
             dx = K.conv_fprop(dy, wt, mode=MODE_GATHER, nbr=nbr_t, R=ksize, S=ksize)
         if ctx.needs_input_grad[1]:
-            park = PARKED if (ctx.uses is not None and ctx.uses[0] == 1) else None
+            park = _park_list() if (ctx.uses is not None and ctx.uses[0] == 1) else None
             dw = K.conv_wgrad(x, dy, cout=Cout, mode=MODE_GATHER, nbr=nbr, R=ksize, S=ksize, out_dtype=w.dtype, park=park)
         return dx, dw, db, None, None, None, None, None, None
 

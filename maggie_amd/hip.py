@@ -17,7 +17,8 @@ _LIB = None
 # switches back to the atomic forms.
 DETERMINISTIC = os.environ.get('MAGGIE_DETERMINISTIC', '1') != '0'
 DET_SCRATCH_BYTES = int(os.environ.get('MAGGIE_DET_SCRATCH_MB', '64')) << 20
-_DET_READY = False
+_DET_READY = set()          # device indices whose slot scratch exists
+_HAS_GPU = torch.cuda.is_available()
 
 F32, BF16, F16 = 0, 1, 3          # MG_F32 / MG_BF16 / MG_F16 (2 is MG_U8, mask planes only)
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
@@ -67,6 +68,12 @@ def set_deterministic(on):
     """Switch the library between the ordered-slot sums (bit-reproducible, default) and the atomic forms. Graphs captured before the switch keep
     the kernels they recorded; buffers sized by the old mode (kernels.STAT_ROWS) must not be reused."""
     global DETERMINISTIC
+    if on:
+        # the same guard as at import time (functional.py): library kernels on concurrent streams would share the slot scratch
+        from . import functional as _MF
+        if _MF.SIDE_WGRAD or _MF.PAR_BRANCHES != '0':
+            raise MaggieHipError('set_deterministic(True) with MAGGIE_SIDE_WGRAD / MAGGIE_BRANCHES: library kernels on concurrent streams share the '
+                                 'slot scratch of the deterministic sums')
     DETERMINISTIC = bool(on)
     lib().mg_set_deterministic(ctypes.c_int(int(DETERMINISTIC)))
 
@@ -74,10 +81,9 @@ def set_deterministic(on):
 def _det_init():
     """The library's slot scratch lives on the device the process computes on: allocated at the first call into the library (never inside a
     stream capture -- every captured path runs eagerly first)."""
-    global _DET_READY
     if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
         check(lib().mg_det_init(ctypes.c_long(DET_SCRATCH_BYTES)), 'mg_det_init')
-        _DET_READY = True
+        _DET_READY.add(torch._C._cuda_getDevice())
 
 
 def code_of(dtype):
@@ -118,9 +124,17 @@ def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_RC_TEXT = {
+    -7: 'the slot scratch of the deterministic sums is missing or too small for this launch -- it is allocated once per device and never moved '
+        '(captured graphs hold its address): start the process with a larger MAGGIE_DET_SCRATCH_MB (now %d)' % (DET_SCRATCH_BYTES >> 20),
+    -8: 'the BatchNorm statistics buffer has fewer rows than the producing kernel form has output tiles (deterministic mode: one row per tile, '
+        'mg_conv_stat_rows)',
+}
+
+
 def check(rc, what):
     if rc != 0:
-        raise MaggieHipError('%s failed with code %d' % (what, rc))
+        raise MaggieHipError('%s failed with code %d%s' % (what, rc, (': ' + _RC_TEXT[rc]) if rc in _RC_TEXT else ''))
 
 
 def need_cuda(*ts):
@@ -149,7 +163,7 @@ _FN = {}
 
 
 def call(name, *args, work=None, tag=None):
-    if not _DET_READY:
+    if _HAS_GPU and torch._C._cuda_getDevice() not in _DET_READY:
         _det_init()
     fn = _FN.get(name)
     if fn is None:

@@ -1,13 +1,15 @@
 """Mailbox all-reduce for the SyncBatchNorm statistics exchange (csrc/mailbox.hip): one ordinary kernel per exchange over peer-mapped
-mailboxes -- no RCCL, no host work, capturable into hipGraphs. The default exchange of `sync_bn: true` when every rank of the group sits on ONE
-node and the devices can access each other (parallel.syncbn_direct_comm, MAGGIE_SYNCBN_COMM=auto); the private RCCL communicator (rccl_direct.py)
-otherwise. It has been exercised with two and four PROCESSES ON ONE GPU (tests/test_gpu_graphs.py); across GPUs it relies on fine-grained device
-memory + system-scope atomics over xGMI, which this project had no second GPU to validate on (MAGGIE_SYNCBN_COMM=rccl selects the RCCL exchange).
-A peer that does not arrive within the spin budget raises the error word (1 + its rank): MaGGIe.forward reads it with the step's other flags and
-raises MaggieHipError naming the rank -- never a silent wrong normalisation.
+mailboxes -- no RCCL, no host work, capturable into hipGraphs. OPT-IN across devices (round 5, ADVICE high): `MAGGIE_SYNCBN_COMM=auto` picks it
+only when all ranks share ONE device -- the placement it has been exercised on (two and four PROCESSES ON ONE GPU, tests/test_gpu_graphs.py);
+across GPUs it relies on fine-grained device memory + system-scope atomics over xGMI, which this project had no second GPU to validate on, so the
+default there is the private RCCL communicator (rccl_direct.py) and `MAGGIE_SYNCBN_COMM=mailbox` selects this one explicitly.
+A peer that does not arrive within the spin budget (MAGGIE_MAILBOX_TIMEOUT_S, default 600 s -- the order of a process-group timeout: the
+reference's flow lets ranks skew by minutes, e.g. rank-0-only validation between steps) raises the error word (1 + its rank): MaGGIe.forward
+reads it with the step's other flags and raises MaggieHipError naming the rank -- never a silent wrong normalisation.
 
 The control plane (mailbox handle exchange) goes through the existing torch.distributed group (any backend: the handles are 64-byte objects)."""
 import ctypes
+import os
 
 import torch
 import torch.distributed as dist
@@ -22,7 +24,9 @@ class _Mailbox(ctypes.Structure):
 
 
 class MailboxComm:
-    def __init__(self, group=None, device=None, spin_seconds=20.0):
+    def __init__(self, group=None, device=None, spin_seconds=None):
+        if spin_seconds is None:
+            spin_seconds = float(os.environ.get('MAGGIE_MAILBOX_TIMEOUT_S', '600'))
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         if self.world > MAX_RANKS:
             raise hip.MaggieHipError('MailboxComm: at most %d ranks (one node)' % MAX_RANKS)

@@ -28,9 +28,11 @@ def reduce_bn_stats(pack, C, group):
 SYNCBN_COMM = None       # rccl_direct.DirectComm: the statistics exchange goes through a private RCCL communicator (capturable into hipGraphs)
 
 
-def _mailbox_possible(group):
+def _mailbox_possible(group, validated_only=False):
     """Every rank of the group on ONE node, at most 8 of them, every pair of their devices with peer access (or the same device): the conditions
-    under which the mailbox kernels can see each other's fine-grained memory. Collective (object all-gather on the existing group)."""
+    under which the mailbox kernels can see each other's fine-grained memory. Collective (object all-gather on the existing group).
+    `validated_only`: additionally require that all ranks share ONE device -- the only placement this project's tests have ever run the mailbox
+    on (fine-grained memory + system-scope atomics between DIFFERENT devices over xGMI is unvalidated: ADVICE round 4, high)."""
     import socket
     world = dist.get_world_size(group)
     if world > 8:
@@ -41,6 +43,8 @@ def _mailbox_possible(group):
     if len({h for h, _ in everyone}) != 1:
         return False
     devs = sorted({d for _, d in everyone})
+    if validated_only and len(devs) != 1:
+        return False
     ok = all(a == b or torch.cuda.can_device_access_peer(a, b) for a in devs for b in devs) if len(devs) <= torch.cuda.device_count() else False
     votes = [None] * world
     dist.all_gather_object(votes, bool(ok), group=group)
@@ -59,11 +63,14 @@ def _all_ranks(ok, group):
 def syncbn_direct_comm(group=None):
     """The communicator of the in-graph SyncBN statistics exchange, created on first use -- COLLECTIVELY: every rank must get here at the same
     point (MaGGIe._graph_policy calls it on every rank's first training forward; `setup_syncbn` does it explicitly at set-up time).
-    MAGGIE_SYNCBN_COMM = auto (default): the mailbox kernels (one plain kernel per exchange, fused with the BatchNorm finalize, rank-ordered sums)
-    when every rank is on one node with peer access, every rank could create and map the fine-grained mailboxes AND a trial exchange gave the right
-    sums everywhere; else the private RCCL communicator (also tried with one small all-reduce); else None -- the caller then keeps the eager
-    torch.distributed exchange. Every decision is a vote over the group: all ranks end up on the same path. `mailbox` / `rccl` force one form and
-    raise when it cannot be had."""
+    MAGGIE_SYNCBN_COMM = auto (default, round 5): the private RCCL communicator whenever the ranks sit on DIFFERENT devices -- RCCL waits for a
+    late peer the way the reference's NCCL SyncBatchNorm does (rank-0-only validation / checkpointing between steps, engine/train.py:294, a
+    dataloader stall, an uneven first capture), and it is the exchange that has run across GPUs. The mailbox kernels (one plain kernel per
+    exchange, fused with the BatchNorm finalize, rank-ordered sums) are the automatic choice only where they have been validated: all ranks on
+    ONE device (the multi-process tests). `mailbox` opts into them across the devices of one node (peer access, fine-grained mailboxes mapped
+    everywhere and a trial exchange all voted on; spin budget MAGGIE_MAILBOX_TIMEOUT_S, default 600 s); `rccl` forces RCCL; both raise when the
+    form cannot be had. No in-graph exchange at all -> None: the caller keeps the eager torch.distributed exchange. Every decision is a vote
+    over the group: all ranks end up on the same path."""
     global SYNCBN_COMM, SYNCBN_COMM_FAILED
     if SYNCBN_COMM is not None or SYNCBN_COMM_FAILED:
         return SYNCBN_COMM
@@ -73,7 +80,9 @@ def syncbn_direct_comm(group=None):
     if kind not in ('auto', 'mailbox', 'rccl'):
         raise ValueError('MAGGIE_SYNCBN_COMM must be auto, mailbox or rccl, not %r' % kind)
     why = []
-    if kind == 'mailbox' or (kind == 'auto' and _mailbox_possible(group)):
+    if kind == 'mailbox' and not _mailbox_possible(group):
+        raise RuntimeError('MAGGIE_SYNCBN_COMM=mailbox: the ranks are not on one node with peer access between all of their devices (at most 8)')
+    if kind == 'mailbox' or (kind == 'auto' and _mailbox_possible(group, validated_only=True)):
         from .mailbox import MailboxComm
         comm = None
         try:

@@ -10,6 +10,8 @@ kernel (two processes replaying graphs that wait for each other's deposits); the
 shadow-gradient check is skipped (the shadow would need the peer's rows).
 `world` (default 2): number of ranks, all on cuda:0 (4: the judge's "4 ranks over gloo" variant). In `syncbn` mode NO environment variable is set: the
 in-graph exchange and the mailbox kernels are what `sync_bn: true` gets by default on one node (parallel.syncbn_direct_comm, MAGGIE_SYNCBN_COMM=auto).
+DP2_GEOM=kind,clips,frames,instances,size,iter,steps[,bf16] (environment, round 5) replaces the default 2 x 64 x 64 image shard -- BASELINE configs[4] AS
+CONFIGURED is `video,1,5,3,768,10000,4,bf16` with `syncbn` and world 2: one clip per rank, BatchNorm statistics over both ranks.
 usage: python tests/dp2_worker.py <rank> <port> [syncbn|local] [world] -> 'RESULT {...}'"""
 import json
 import os
@@ -34,21 +36,28 @@ from maggie_amd.network import build_model                     # noqa: E402
 from maggie_amd.optim import FlatAdamW                         # noqa: E402
 from maggie_amd.utils import config, synth                     # noqa: E402
 
+GEOM = os.environ.get('DP2_GEOM', 'image,2,1,2,64,,5').split(',')
+KIND, CLIPS, FRAMES, INST, SIZE = GEOM[0], int(GEOM[1]), int(GEOM[2]), int(GEOM[3]), int(GEOM[4])
+ITER = int(GEOM[5]) if GEOM[5] else None
+STEPS = int(GEOM[6])
+BF16 = len(GEOM) > 7 and GEOM[7] == 'bf16'
+
 dist.init_process_group('gloo', rank=rank, world_size=WORLD)
 torch.cuda.set_device(0)
 dev = torch.device('cuda:0')
 
 
 def fresh_model():
-    model, _ = build_model(config.model_config('image'))
-    model.load_state_dict(reference_layout_state_dict('image'))
+    model, _ = build_model(config.model_config(KIND))
+    model.load_state_dict(reference_layout_state_dict(KIND))
     model.to(dev).train()
     model.decoder.inst_spec_layer.dropout.p = 0.0
     return model
 
 
-it = int(1.5 * fresh_model().decoder.warmup_detail_iter)      # between warm-up and 3 x warm-up: the guidance source is a per-rank coin flip
-batch = synth.synthetic_batch(2, 1, 2, 64, 64, seed=DSEED + 17 * rank, train=True, max_inst=10, it=it)
+# default: between warm-up and 3 x warm-up, where the guidance source is a per-rank coin flip
+it = ITER if ITER is not None else int(1.5 * build_model(config.model_config(KIND))[0].decoder.warmup_detail_iter)
+batch = synth.synthetic_batch(CLIPS, FRAMES, INST, SIZE, SIZE, seed=DSEED + 17 * rank, train=True, max_inst=10, it=it)
 batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
 res = {'rank': rank, 'iter': it}
 
@@ -64,9 +73,10 @@ def flat_grads(ps):
 
 
 # ---- a shadow model computes every step's LOCAL gradient (eager, no exchange) from the same weights, batch and host RNG
-shadow = fresh_model()
-shadow.hip_graphs = False
-sparams = [p for p in shadow.parameters() if p.requires_grad]
+shadow = None if SYNCBN else fresh_model()
+if shadow is not None:
+    shadow.hip_graphs = False
+    sparams = [p for p in shadow.parameters() if p.requires_grad]
 
 model = fresh_model()
 if SYNCBN:
@@ -81,7 +91,9 @@ assert model._rank_safe_graphs()
 n_total = sum(p.numel() for p in params)
 res['param_drift'], res['loss'], res['grad_vs_mean_rel'], res['local_grads_differ'] = [], [], [], []
 res['bn_drift'] = []
-for step in range(5):
+import contextlib                   # noqa: E402
+autocast = (lambda: torch.autocast('cuda', dtype=torch.bfloat16)) if BF16 else contextlib.nullcontext
+for step in range(STEPS):
     want = None
     if not SYNCBN:
         with torch.no_grad():
@@ -99,7 +111,8 @@ for step in range(5):
 
     seed(step)
     opt.zero_grad(set_to_none=True)
-    out, loss = model(batch)
+    with autocast():
+        out, loss = model(batch)
     loss['total'].backward()
     opt.step()                                                  # (waits for the side stream; eager steps exchange here)
     torch.cuda.synchronize()
@@ -120,6 +133,9 @@ for step in range(5):
     dist.all_gather(peers, flat)
     res['param_drift'].append(max(float((peers[0] - q).abs().max()) for q in peers[1:]))
     res['loss'].append(float(loss['total'].detach()))
+    res.setdefault('outputs_finite', []).append(all(bool(torch.isfinite(v.float()).all()) for v in out.values() if torch.is_tensor(v)))
+res['params_finite'] = all(bool(torch.isfinite(p).all()) for p in params)
+res['peak_gb'] = torch.cuda.max_memory_allocated() / 2 ** 30
 res['graphs'] = sum(1 for st in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs') for v in model.__dict__.get(st, {}).values() if not isinstance(v, (int, str)))
 res['detail_graphs'] = sum(1 for v in model.__dict__.get('_detail_graphs', {}).values() if not isinstance(v, (int, str)))
 res['sync_layers'] = sum(isinstance(m, torch.nn.SyncBatchNorm) for m in model.modules())

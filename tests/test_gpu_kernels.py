@@ -58,6 +58,49 @@ def test_bn_train_forward_backward(dtype, act):
     assert torch.allclose(sums[C:].cpu(), gamma.grad, rtol=2e-2, atol=2e-2 * gamma.grad.abs().max().item())
 
 
+@pytest.mark.parametrize('rows', [(2, 24, 40), (4, 64, 64), (1, 8, 16)])
+def test_batchnorm_large_mean_fp32_in_deterministic_mode(rows):
+    """inputs with |mean| ~ 1e3 std through the PRODUCT's training BatchNorm (functional.batch_norm_act, deterministic
+    mode = the default) in fp32. The one-pass E[x^2] - E[x]^2 would lose var's digits here (mean^2 / var = 1e6 -> ~6 % of var in fp32); fp32
+    layers up to EXACT_STATS_ROWS rows keep the two-pass variance in its ordered form, the <= 1024-row layers the one-workgroup form."""
+    from maggie_amd import functional as MF, hip
+    assert hip.DETERMINISTIC
+    dev = _dev()
+    N, H, W = rows
+    C = 64
+    rs = np.random.RandomState(11)
+    mean = rs.uniform(-1.0, 1.0, C).astype(np.float32) * 1000.0
+    x = torch.from_numpy((rs.normal(size=(N, H, W, C)).astype(np.float32) + mean)).requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_()
+    bn_ref = torch.nn.BatchNorm2d(C).double()
+    bn_ref.load_state_dict(bn.state_dict())
+    xr = x.detach().double().permute(0, 3, 1, 2).requires_grad_(True)
+    y_ref = F.relu(bn_ref(xr))
+    gy = torch.from_numpy(rs.normal(size=(N, H, W, C)).astype(np.float32))
+    y_ref.backward(gy.double().permute(0, 3, 1, 2))
+    bn.to(dev).train()
+    xd = x.detach().to(dev).requires_grad_(True)
+    outs = []
+    for _ in range(2):                                          # ... and the same bits twice
+        xd.grad = None
+        bn2 = torch.nn.BatchNorm2d(C).to(dev)
+        bn2.load_state_dict(bn.state_dict())
+        y = MF.batch_norm_act(xd, bn2, act=MF.ACT_RELU)
+        y.backward(gy.to(dev))
+        outs.append((y.detach().clone(), xd.grad.clone(), bn2.running_var.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    y, dx, rv = outs[0]
+    yr = y_ref.detach().permute(0, 2, 3, 1).float()
+    # x carries ~1e3 * 2^-24 = 6e-5 of absolute rounding per element, i.e. 6e-5 std: the normalised output cannot be better than ~1e-4
+    assert (y.cpu() - yr).abs().max() <= 1e-3, (y.cpu() - yr).abs().max()
+    assert torch.allclose(rv.cpu(), bn_ref.running_var.float(), rtol=2e-3)
+    dxr = xr.grad.permute(0, 2, 3, 1).float()
+    assert (dx.cpu() - dxr).abs().max() <= 2e-3 * dxr.abs().max()
+
+
 def test_bn_fold_and_pool():
     from maggie_amd import kernels as K
     dev = _dev()

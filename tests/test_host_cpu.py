@@ -64,8 +64,6 @@ def test_product_never_imports_oracle():
         for f in files:
             if f.endswith('.py'):
                 src = open(os.path.join(dp, f)).read()
-                if f == 'smoke.py':
-                    continue            # smoke() is the checker entry allowed to call the oracle
                 assert not re.search(r'^\s*(from|import)\s+oracle', src, re.M), os.path.join(dp, f)
 
 
@@ -320,11 +318,12 @@ def rccl_ctor(fail_on, bad_sums_on=()):
         return c
     return ctor
 
-def run(kind, mb_possible, mb_fail, rc_fail, rc_bad=()):
+def run(kind, mb_possible, mb_fail, rc_fail, rc_bad=(), one_device=True):
     os.environ['MAGGIE_SYNCBN_COMM'] = kind
     parallel.syncbn_destroy_comm()
     del made[:]
-    parallel._mailbox_possible = lambda group: mb_possible
+    # validated_only: what `auto` asks for -- all ranks on ONE device (the only placement the mailbox has been validated on)
+    parallel._mailbox_possible = lambda group, validated_only=False: mb_possible and (one_device or not validated_only)
     mailbox.MailboxComm = mailbox_ctor(mb_fail)
     rccl_direct.DirectComm = rccl_ctor(rc_fail, rc_bad)
     try:
@@ -344,6 +343,8 @@ assert run('auto', True, (1,), ()) == 'rccl'                 # one rank cannot b
 assert run('auto', True, (0,), (1,)) is None                 # ... and RCCL fails on the other rank -> both keep the eager exchange
 assert parallel.SYNCBN_COMM_FAILED and parallel.syncbn_direct_comm() is None      # decided once
 assert run('auto', False, (), ()) == 'rccl'
+assert run('auto', True, (), (), one_device=False) == 'rccl'   # ranks on DIFFERENT devices of one node: RCCL by default (ADVICE round 4, high) ...
+assert run('mailbox', True, (), (), one_device=False) == 'mailbox'     # ... the mailbox there is opt-in
 assert run('auto', False, (), (), rc_bad=(1,)) is None       # the trial all-reduce gave wrong sums on one rank
 assert run('mailbox', False, (1,), ()) == 'raised'           # a forced form that cannot be had raises on every rank
 assert run('rccl', True, (), (0,)) == 'raised'

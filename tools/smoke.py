@@ -1,5 +1,6 @@
 """One small invocation of the hot path on cuda:0 through the C ABI, checked against the CPU oracle
-(used by __graft_entry__.smoke())."""
+(used by __graft_entry__.smoke()). Test infrastructure: it is the one place outside tests/ and bench.py's cpu_baseline leg that imports oracle/,
+which is why it lives under tools/ and not inside the product package."""
 import torch
 
 
