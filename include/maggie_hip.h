@@ -108,7 +108,21 @@ typedef struct mg_conv_params {
                             output tiles (mg_conv_stat_rows) every word receives ONE addition and mg_bn_finalize adds the rows in index order: the
                             statistics are then bit-reproducible run to run (the reference runs with cudnn.deterministic = True, tools/main.py:135-136) */
     int32_t reserved0;
+    /* Operand transform (round 5; conv + BatchNorm + activation as one pass in TRAINING, maggie/network/encoder/resnet.py:26-37,
+     * maggie/network/decoder/resnet.py:20-45): xf_scale != NULL makes every IN-IMAGE element of `x` enter the contraction as
+     *     x_eff[m, ci] = act(x[m, ci] * xf_scale[ci] + xf_shift[ci]),   act = xf_act with LeakyReLU slope xf_slope,
+     * rounded to the storage type -- the value mg_affine_act would have written -- while padding (out-of-image taps) stays 0. `x` is then the RAW
+     * output of the producing convolution and (xf_scale, xf_shift) the folded batch statistics of the BatchNorm layer between the two
+     * convolutions (mg_bn_finalize): the normalised activation is never stored. Honoured by mg_conv_fprop (MG_MODE_CONV) and by
+     * mg_conv_wgrad* (the `x` operand) for the kernel forms mg_conv_xform_ok reports; other forms return -9. */
+    const float* xf_scale;
+    const float* xf_shift;
+    int32_t xf_act;
+    float xf_slope;
 } mg_conv_params;
+
+/* 1 when the kernel form this geometry dispatches to applies the operand transform (xf_*) in flight: which = 0 mg_conv_fprop[_ws], 1 mg_conv_wgrad*. */
+int mg_conv_xform_ok(const mg_conv_params* p, int which);
 
 int mg_conv_fprop(const mg_conv_params* p, void* stream);
 /* Same, allowed to split the K dimension over several blocks per tile for deep layers with few output rows (M <= 8192,

@@ -106,6 +106,20 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     return v;
 }
 
+// Operand transform of the convolution family (mg_conv_params.xf_*): one 16-byte chunk (8 elements of the 16-bit storage type T) of the raw
+// producer output -> act(x * scale + shift), rounded to T -- the bits mg_affine_act would have stored. `sl` = 1 (no activation), 0 (ReLU) or the
+// LeakyReLU slope: act(v) = max(v, v * sl), branch-free like the conv epilogue.
+#define MG_XF_UNSUPPORTED (-9)     /* xf_scale given but the kernel form this geometry dispatches to cannot transform its operand in flight */
+template <typename T>
+__device__ __forceinline__ uint4 xf_apply8(const uint4& q, const float* sc, const float* sh, float sl) {
+    float f[8];
+    ElemTraits<T>::unpack(q, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float v = f[e] * sc[e] + sh[e]; f[e] = fmaxf(v, v * sl); }
+    return ElemTraits<T>::pack(f);
+}
+__host__ __device__ __forceinline__ float xf_slope_of(int act, float slope) { return act == MG_ACT_NONE ? 1.f : (act == MG_ACT_RELU ? 0.f : slope); }
+
 // Row count of a sparse-head launch: the device word when given (clamped to the capacity the buffers were sized for), else the host value.
 __device__ __forceinline__ int dev_rows(const int32_t* __restrict__ m_dev, int cap) {
     if (!m_dev) return cap;

@@ -838,7 +838,13 @@ template <int TH, int BN, int NS> struct HaloCfg {
 };
 
 
-template <int TH, int BN, int NS, int MODE, bool BNB = false, typename T = bf16raw>
+// XF (round 5, mg_conv_params.xf_*): `x` is the RAW output of the producing convolution and the BatchNorm + activation between the two layers is
+// applied to the staged halo image IN LDS, once per pixel (not once per tap): after the counted wait that says "this lane's LDS-DMA loads of
+// stage s have landed" every lane rewrites the 16-byte chunks its own loads deposited -- act(x * scale + shift), rounded to T -- and skips the
+// chunks it pointed at the zero page (padding stays 0); the stage's barrier, which already separates the deposit from the fragment reads, then
+// publishes the transformed image. scale | shift sit in an LDS table behind the ring ([2 * Cin] floats), filled from registers loaded before the
+// first LDS-DMA instruction (in-order return: the first wait covers them) -- one extra barrier per tile.
+template <int TH, int BN, int NS, int MODE, bool BNB = false, typename T = bf16raw, bool XF = false>
 __device__ __forceinline__ void igemm_fprop_halo_tile(const mg_conv_params& p, int work, char* smem) {
     using TR = ElemTraits<T>;
     using HC = HaloCfg<TH, BN, NS>;
@@ -921,11 +927,47 @@ __device__ __forceinline__ void igemm_fprop_halo_tile(const mg_conv_params& p, i
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    [[maybe_unused]] u32x4 xf_reg = (u32x4){0u, 0u, 0u, 0u};
+    [[maybe_unused]] const unsigned xf_tab = lds_base + (unsigned)HC::LDS;            // [Cin] scale | [Cin] shift, fp32
+    [[maybe_unused]] const float xf_sl = xf_slope_of(p.xf_act, p.xf_slope);
+    [[maybe_unused]] const int xf_ach = (lane & 3) ^ (((lane >> 4) & 1) * 2);         // the 8-channel group of a slab this lane's halo chunks hold
+    if constexpr (XF) {
+        if (t * 4 < 2 * p.Cin) xf_reg = *(const u32x4*)(t * 4 < p.Cin ? p.xf_scale + t * 4 : p.xf_shift + (t * 4 - p.Cin));
+    }
     MG_STAMP(0);
 #pragma unroll
     for (int u = 0; u < NS - 1; ++u)
         if (u < nstage) issue_stage(u, u);
     MG_STAMP(1);
+    [[maybe_unused]] auto xf_stage = [&](int s) {
+        if (s == 0) {                                        // the table: every wave's share must be in LDS before anyone transforms
+            if (t * 4 < 2 * p.Cin) asm volatile("ds_write_b128 %0, %1" ::"v"(xf_tab + (unsigned)t * 16u), "v"(xf_reg) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        const unsigned sb = lds_base + (unsigned)((s % NS) * STAGE);
+        const unsigned tsc = xf_tab + (unsigned)((s * EPS + xf_ach * 8) * 4), tsh = tsc + (unsigned)(p.Cin * 4);
+        f32x4 c0, c1, h0, h1;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(c0) : "v"(tsc) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(c1) : "v"(tsc) : "memory");
+        asm volatile("ds_read_b128 %0, %1" : "=v"(h0) : "v"(tsh) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(h1) : "v"(tsh) : "memory");
+        u32x4 q[HC::A_PER_WAVE];
+#pragma unroll
+        for (int i = 0; i < HC::A_PER_WAVE; ++i)
+            asm volatile("ds_read_b128 %0, %1" : "=v"(q[i]) : "v"(sb + (unsigned)((wave + 4 * i) * 1024 + lane * 16)) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const float sc[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]}, sh[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+#pragma unroll
+        for (int i = 0; i < HC::A_PER_WAVE; ++i) {
+            if (asrc[i]) {                                   // an in-image pixel: transformed; zero-page chunks (padding, spare slots) stay 0
+                const uint4 r = xf_apply8<T>(__builtin_bit_cast(uint4, q[i]), sc, sh, xf_sl);
+                asm volatile("ds_write_b128 %0, %1" ::"v"(sb + (unsigned)((wave + 4 * i) * 1024 + lane * 16)), "v"(__builtin_bit_cast(u32x4, r)) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
     for (int s = 0; s < nstage; ++s) {
         if (s < 6) MG_STAMP(2 + 2 * s);
         if constexpr (NS == 1) {
@@ -934,12 +976,14 @@ __device__ __forceinline__ void igemm_fprop_halo_tile(const mg_conv_params& p, i
             if (s > 0) __builtin_amdgcn_s_barrier();
             issue_stage(s, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (XF) xf_stage(s);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         } else {
             const int younger = min(NS - 2, nstage - 1 - s);
             if (NS == 2 || younger == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+            if constexpr (XF) xf_stage(s);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (s + NS - 1 < nstage) issue_stage(s + NS - 1, (s + NS - 1) % NS);
@@ -996,13 +1040,13 @@ __device__ __forceinline__ void igemm_fprop_halo_tile(const mg_conv_params& p, i
     MG_STAMP(15);
 }
 
-template <int TH, int BN, int NS, int MODE, bool BNB = false, typename T = bf16raw>
+template <int TH, int BN, int NS, int MODE, bool BNB = false, typename T = bf16raw, bool XF = false>
 __global__ __launch_bounds__(256) void igemm_fprop_halo_kernel(const mg_conv_params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tiles = p.N * ((p.Hout + TH - 1) / TH) * ((p.Wout + 15) / 16) * ((p.Cout + BN - 1) / BN);
     int work;
     if (!xcd_order(tiles, work)) return;
-    igemm_fprop_halo_tile<TH, BN, NS, MODE, BNB, T>(p, work, smem);
+    igemm_fprop_halo_tile<TH, BN, NS, MODE, BNB, T, XF>(p, work, smem);
 }
 
 // Deterministic mode: the statistics buffer must have one row per output tile of the kernel form that runs (mg_conv_params.stat_rep) -- with
@@ -1036,6 +1080,20 @@ static int launch_fprop_halo(const mg_conv_params& p, hipStream_t st) {
     const long tiles = (long)p.N * ((p.Hout + TH - 1) / TH) * ((p.Wout + 15) / 16) * ((p.Cout + BN - 1) / BN);
     if (int rcs = stat_rows_check(p, (long)p.N * ((p.Hout + TH - 1) / TH) * ((p.Wout + 15) / 16))) return rcs;
     dim3 grid(xcd_grid(tiles));
+    if (p.xf_scale) {                                        // BatchNorm + activation of the producing layer applied to the staged halo (forward only)
+        if constexpr (NS <= 2 && BN >= 32) {
+            constexpr size_t lds_xf = lds + 4096;            // + the [2 * Cin] fp32 table (Cin <= 512)
+            if (p.mode != MG_MODE_CONV || p.bnb_x || p.Cin > 512 || lds_xf > 160 * 1024) return MG_XF_UNSUPPORTED;
+            static bool xf_attr = false;
+            if (!xf_attr) {
+                hipFuncSetAttribute((const void*)igemm_fprop_halo_kernel<TH, BN, NS, MG_MODE_CONV, false, T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_xf);
+                xf_attr = true;
+            }
+            hipLaunchKernelGGL((igemm_fprop_halo_kernel<TH, BN, NS, MG_MODE_CONV, false, T, true>), grid, dim3(256), lds_xf, st, p);
+            MG_CHECK_LAUNCH();
+            return 0;
+        } else return MG_XF_UNSUPPORTED;
+    }
     if (p.bnb_x) {                                           // the data gradient of a 3x3 / stride 1 conv behind a BatchNorm layer
         if (p.mode != MG_MODE_TCONV) return -2;
         hipLaunchKernelGGL((igemm_fprop_halo_kernel<TH, BN, NS, MG_MODE_TCONV, true, T>), grid, dim3(256), lds, st, p);
@@ -1059,6 +1117,7 @@ static int dispatch_fprop_halo(const mg_conv_params& p, hipStream_t st) {
     // 64-wide three-slab form owns the whole CU). Costs 30 % more halo traffic; measured C512->256 32x32 18.0 -> 15.5 us, C256->128 64x64
     // 15.2 -> 14.1 us, C128 / C256 unchanged, step 14.91 -> 14.74 ms. MG_HALO_NARROW=0 selects the wide form.
     static const int narrow = [] { const char* e = getenv("MG_HALO_NARROW"); return e ? atoi(e) : 1; }();
+    if (p.xf_scale && p.Hout >= 8) return launch_fprop_halo<T, 8, 32, 2>(p, st);      // the operand transform lives in the one- / two-slab forms
     if (narrow && p.Hout >= 8) return launch_fprop_halo<T, 8, 32, 2>(p, st);      // (4 x 16 tiles for the layers with < 300 workgroups: no gain, measured)
     if (t8 >= want && p.Hout >= 8) return launch_fprop_halo<T, 8>(p, st);
     return launch_fprop_halo<T, 4>(p, st);
@@ -1476,8 +1535,18 @@ static int launch_fprop_c8(const mg_conv_params& p, hipStream_t st) {
     return 0;
 }
 
+// operand transform (mg_conv_params.xf_*): lives in the one- / two-slab halo forms of the forward 3x3 / stride-1 convolution
+static inline bool fprop_xf_ok(const mg_conv_params& p) {
+    return MG_IS16(p.dtype) && p.mode == MG_MODE_CONV && !p.bnb_x && !fprop_c8_eligible(p) && halo_eligible(p) && p.Cin <= 512 &&
+           (p.Cin < 96 ? p.Cout > 16 : p.Hout >= 8);
+}
+
 template <typename T>
 int dispatch_fprop(const mg_conv_params& p, hipStream_t st) {
+    if (p.xf_scale) {
+        if constexpr (sizeof(T) == 2) { if (fprop_xf_ok(p)) return dispatch_fprop_halo<T>(p, st); }
+        return MG_XF_UNSUPPORTED;
+    }
     if constexpr (sizeof(T) == 2) {
         if (!p.bnb_x && fprop_c8_eligible(p)) return launch_fprop_c8<T>(p, st);
         if (halo_eligible(p)) return dispatch_fprop_halo<T>(p, st);
@@ -1540,6 +1609,13 @@ extern "C" long mg_conv_fprop_workspace(const mg_conv_params* pp) {
     if (!pp || pp->M <= 0) return 0;
     const SplitPlan sp = MG_IS16(pp->dtype) ? plan_splitk<bf16raw>(*pp) : plan_splitk<float>(*pp);
     return sp.bn ? (long)sp.splits * pp->M * pp->Cout : 0;
+}
+
+bool mg_wgrad_xform_ok(const mg_conv_params& p);          // conv_wgrad.hip
+
+extern "C" int mg_conv_xform_ok(const mg_conv_params* pp, int which) {
+    if (!pp || pp->M <= 0) return 0;
+    return which == 0 ? (int)fprop_xf_ok(*pp) : (which == 1 ? (int)mg_wgrad_xform_ok(*pp) : 0);
 }
 
 static int conv_fprop_check(const mg_conv_params& p) {

@@ -333,7 +333,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const RedTabl
 // row-major LDS tiles with ds_read_b64_tr_b16, the x rows shifted by the tap's (ky, kx) inside the halo tile. Waves own the four
 // quadrants of the block tile (no cross-wave reduction); accumulators leave the registers as fp32 partials, one slab per spatial split.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int FM, int FN, typename T = bf16raw>
+// XF (round 5): the x operand is the RAW output of the producing convolution; act(x * xf_scale + xf_shift) -- the BatchNorm + activation between the
+// two convolutions -- is applied to the in-image chunks on their way from the staging registers into LDS (padding stays 0). A thread's chunks all
+// sit in one 8-channel group (256 % CPX == 0), so its 16 constants live in registers for the whole walk.
+template <int FM, int FN, typename T = bf16raw, bool XF = false>
 __global__ __launch_bounds__(256) void igemm_wgrad_halo_kernel(const mg_conv_params p, int tiles_per_block, float* __restrict__ ws) {
     constexpr int TCO = 32 * FM, TCI = 32 * FN;
     constexpr int TH = 8, TW = 16, HW_ = TW + 2, HH = TH + 2;
@@ -378,6 +381,15 @@ __global__ __launch_bounds__(256) void igemm_wgrad_halo_kernel(const mg_conv_par
         x_off[i] = idx < NX ? (x_hy[i] * p.Win + x_hx[i]) * p.ldx + c * 8 : 0;
     }
     uint4 ry[ITY], rx[ITX];
+    [[maybe_unused]] float xsc[8], xsh[8];
+    [[maybe_unused]] unsigned xlive = 0;                       // bit i: chunk i of the x halo is an in-image pixel (transformed), else padding (0)
+    [[maybe_unused]] const float xsl = xf_slope_of(p.xf_act, p.xf_slope);
+    if constexpr (XF) {
+        static_assert(256 % CPX == 0, "a thread's x chunks must share one channel group");
+        const int c = t % CPX;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xsc[e] = p.xf_scale[ci0 + c * 8 + e]; xsh[e] = p.xf_shift[ci0 + c * 8 + e]; }
+    }
     auto load_tile = [&](int s) {
         const int n = s / (tiles_y * tiles_x);
         const int r = s - n * tiles_y * tiles_x;
@@ -393,7 +405,9 @@ __global__ __launch_bounds__(256) void igemm_wgrad_halo_kernel(const mg_conv_par
 #pragma unroll
         for (int i = 0; i < ITX; ++i) {
             uint4 q = make_uint4(0, 0, 0, 0);
-            if ((unsigned)(y0 + x_hy[i]) < (unsigned)p.Hin && (unsigned)(x0 + x_hx[i]) < (unsigned)p.Win) q = *(const uint4*)(xbase + x_off[i]);
+            const bool in_img = (unsigned)(y0 + x_hy[i]) < (unsigned)p.Hin && (unsigned)(x0 + x_hx[i]) < (unsigned)p.Win;
+            if (in_img) q = *(const uint4*)(xbase + x_off[i]);
+            if constexpr (XF) xlive = in_img ? (xlive | (1u << i)) : (xlive & ~(1u << i));
             rx[i] = q;
         }
     };
@@ -408,6 +422,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_halo_kernel(const mg_conv_par
         for (int i = 0; i < ITX; ++i) {
             const int idx = t + i * 256;
             const int px = idx / CPX, c = idx - px * CPX;
+            if constexpr (XF) { if (xlive & (1u << i)) rx[i] = xf_apply8<T>(rx[i], xsc, xsh, xsl); }
             if (idx < NX) *(uint4*)(sX + px * PX + c * 8) = rx[i];
         }
     };
@@ -816,7 +831,10 @@ static int launch_wgrad_halo(const mg_conv_params& p, float* ws, long ws_floats,
     const long cc = (long)(p.Cin / 32) * (p.Cout / 32);
     dim3 grid(xcd_grid(pl.splits * cc));
     const size_t lds = (size_t)(8 * 16 * (32 + 16) + 10 * 18 * (32 + 16)) * sizeof(bf16raw);
-    if (p.dtype == MG_F16) hipLaunchKernelGGL((igemm_wgrad_halo_kernel<1, 1, f16raw>), grid, dim3(256), lds, st, p, pl.tpb, use_ws);
+    if (p.xf_scale) {
+        if (p.dtype == MG_F16) hipLaunchKernelGGL((igemm_wgrad_halo_kernel<1, 1, f16raw, true>), grid, dim3(256), lds, st, p, pl.tpb, use_ws);
+        else hipLaunchKernelGGL((igemm_wgrad_halo_kernel<1, 1, bf16raw, true>), grid, dim3(256), lds, st, p, pl.tpb, use_ws);
+    } else if (p.dtype == MG_F16) hipLaunchKernelGGL((igemm_wgrad_halo_kernel<1, 1, f16raw>), grid, dim3(256), lds, st, p, pl.tpb, use_ws);
     else hipLaunchKernelGGL((igemm_wgrad_halo_kernel<1, 1>), grid, dim3(256), lds, st, p, pl.tpb, use_ws);
     if (use_ws != p.stats) {
         if (pl.splits >= 8) {
@@ -906,10 +924,16 @@ int launch_wgrad(const mg_conv_params& p, float* ws, long ws_floats, hipStream_t
     return 0;
 }
 
+// operand transform (mg_conv_params.xf_*): the halo form applies it between its staging registers and LDS
+static inline bool wgrad_xf_ok(const mg_conv_params& p) {
+    return MG_IS16(p.dtype) && wgrad_halo_eligible(p) && !wgrad_c8_eligible(p) && !wgrad_gather9_eligible(p);
+}
+
 template <typename T>
 int dispatch_wgrad(const mg_conv_params& p, float* ws, long ws_floats, long* need, hipStream_t st) {
     const bool small_co = p.Cout <= 32, small_ci = p.Cin <= 32;
     const long n = (long)p.Cout * p.R * p.S * p.Cin;
+    if (p.xf_scale && !wgrad_xf_ok(p)) { if (need) { *need = 0; return 0; } return MG_XF_UNSUPPORTED; }
     if (sizeof(T) == 2 && wgrad_c8_eligible(p)) {
         const long splits = plan_wgrad_c8(p, nullptr);
         if (need) { *need = splits * n; return 0; }
@@ -925,6 +949,7 @@ int dispatch_wgrad(const mg_conv_params& p, float* ws, long ws_floats, long* nee
         const WgradHaloPlan pl = plan_wgrad_halo(p);
         if (pl.splits == 1 || (ws && ws_floats >= pl.splits * n)) return launch_wgrad_halo(p, ws, ws_floats, st);
     }
+    if (p.xf_scale) return MG_XF_UNSUPPORTED;                      // (no workspace for the halo form: the per-tap kernels do not transform)
 #define MG_WG(TCO, TCI)                                                                             \
     do {                                                                                            \
         if (need) { WgradPlan pl = plan_wgrad<T, TCO, TCI>(p); *need = (pl.splits > 1 || MG_IS16(p.dw_dtype)) ? pl.splits * n : 0; return 0; } \
@@ -949,6 +974,8 @@ int wgrad_check(const mg_conv_params* pp) {
 }
 
 }  // namespace
+
+bool mg_wgrad_xform_ok(const mg_conv_params& p) { return wgrad_xf_ok(p); }
 
 // floats of workspace that make mg_conv_wgrad_ws deterministic and atomic-free for this geometry (0 = none needed)
 extern "C" long mg_conv_wgrad_workspace(const mg_conv_params* pp) {

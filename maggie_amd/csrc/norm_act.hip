@@ -519,7 +519,17 @@ __device__ __forceinline__ void load_g(const mg_rowwise_params& p, int m, int c0
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
     TR::unpack(*(const uint4*)((const T*)p.dy + (long)m * p.lddy + c0), g);
-    if (p.act != MG_ACT_NONE) {
+    if (p.act != MG_ACT_NONE && !p.y) {
+        // the activation output was never stored (round 5: the consumer convolution applies BatchNorm + activation to its operand in flight,
+        // mg_conv_params.xf_*): its sign is that of x * scale + shift, re-formed from the raw input with the arithmetic of xf_apply8
+        float xv[CE];
+        TR::unpack(*(const uint4*)((const T*)p.x + (long)m * p.ldx + c0), xv);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) {
+            const float z = xv[e] * p.scale[c0 + e] + p.shift[c0 + e];
+            if (!(z > 0.f)) g[e] = (p.act == MG_ACT_RELU) ? 0.f : g[e] * p.slope;
+        }
+    } else if (p.act != MG_ACT_NONE) {
         float yv[CE];
         TR::unpack(*(const uint4*)((const T*)p.y + (long)m * p.ldy + p.yoff + c0), yv);
         if (p.res2) {                      // y = act(.) + res2  -> recover the activation output sign

@@ -47,6 +47,7 @@ class ConvParams(ctypes.Structure):
         ('bnb_y', ctypes.c_void_p), ('bnb_x', ctypes.c_void_p), ('bnb_mean', ctypes.c_void_p), ('bnb_invstd', ctypes.c_void_p),
         ('bnb_act', ctypes.c_int32), ('bnb_ld', ctypes.c_int32),
         ('stat_rep', ctypes.c_int32), ('reserved0', ctypes.c_int32),
+        ('xf_scale', ctypes.c_void_p), ('xf_shift', ctypes.c_void_p), ('xf_act', ctypes.c_int32), ('xf_slope', ctypes.c_float),
     ]
 
 

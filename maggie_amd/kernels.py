@@ -42,10 +42,42 @@ def _conv_params(x, w, y, mode, N, Hin, Win, Hout, Wout, R, S, stride, pad, dil,
     return p
 
 
+def _set_xf(p, xf, Cin):
+    if xf is None:
+        return
+    sc, sh, act, slope = xf
+    assert sc.dtype == torch.float32 and sh.dtype == torch.float32 and sc.numel() >= Cin and sh.numel() >= Cin and sc.is_contiguous() and sh.is_contiguous()
+    hip.need_cuda(sc, sh)
+    p.xf_scale, p.xf_shift, p.xf_act, p.xf_slope = hip.ptr(sc), hip.ptr(sh), int(act), float(slope)
+
+
+_XF_OK = {}
+
+
+def conv_xform_ok(dtype, N, H, W, Cin, Cout, R=3, S=3, stride=1, pad=1, dil=1, which=0):
+    """Does the kernel form a dense (N, H, W, Cin) -> Cout convolution of this geometry dispatches to apply the operand transform in flight?
+    which: 0 forward (mg_conv_fprop), 1 weight gradient (mg_conv_wgrad*). Asked of the library (mg_conv_xform_ok), cached per geometry."""
+    key = (dtype, N, H, W, Cin, Cout, R, S, stride, pad, dil, which)
+    ok = _XF_OK.get(key)
+    if ok is None:
+        p = ConvParams()
+        p.dtype, p.mode = hip.code_of(dtype), MODE_CONV
+        Ho, Wo = conv_out_size(MODE_CONV, H, R, stride, pad, dil), conv_out_size(MODE_CONV, W, S, stride, pad, dil)
+        p.N, p.Hin, p.Win, p.Cin, p.Hout, p.Wout, p.Cout = N, H, W, Cin, Ho, Wo, Cout
+        p.R, p.S, p.stride, p.pad, p.dil, p.M = R, S, stride, pad, dil, N * Ho * Wo
+        p.ldx, p.ldy, p.yoff = Cin, Cout, 0
+        fn = hip.lib().mg_conv_xform_ok
+        fn.restype = ctypes.c_int
+        ok = _XF_OK[key] = bool(fn(ctypes.byref(p), ctypes.c_int(which)))
+    return ok
+
+
 def conv_fprop(x, w, *, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=None, Wout=None, R=1, S=1, stride=1, pad=0, dil=1,
                M=None, nbr=None, scale=None, shift=None, res=None, res_mode=1, res2=None, act=ACT_NONE, pre_act=False,
-               slope=0.2, stats=None, out=None, yoff=0, cout=None, rows=None, alg_cin=None, alg_cout=None, bnb=None):
+               slope=0.2, stats=None, out=None, yoff=0, cout=None, rows=None, alg_cin=None, alg_cout=None, bnb=None, xf=None):
     """Y = epilogue(implicit GEMM). x: (..., Cin) channel-contiguous; w: (Cout, R*S, Cin) same dtype.
+    `xf` = (scale, shift, act, slope): operand transform -- x is the RAW output of the producing conv, the BatchNorm + activation between the two
+    layers is applied in flight (mg_conv_params.xf_*; only for geometries conv_xform_ok reports).
     Dense modes: rows of x are (n, h, w) of an (N, Hin, Win) map; gather mode: rows of x are sparse sites, `nbr` (M, R*S).
     `out`/`yoff` let the result land in a channel slice of a wider buffer (zero-copy concat)."""
     Cin = x.shape[-1]
@@ -79,6 +111,7 @@ def conv_fprop(x, w, *, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=None, Wout=None,
                      res, res_mode, res2, act, pre_act, slope, stats, yoff)
     p.stat_mode, p.stat_rep = stat_mode, stat_rep
     p.m_dev = hip.ptr(rows)                    # device row count (sparse head): M is then the capacity, the launch a persistent grid
+    _set_xf(p, xf, Cin)
     if bnb is not None:
         # this launch produces the gradient at the OUTPUT of a training BatchNorm layer: its epilogue writes g = dz * act'(z) and accumulates
         # that layer's backward sums into `stats` (replicated layout) -- bnb = (z | None, x, mean, invstd, act), rows x Cout like `out`
@@ -122,7 +155,7 @@ def _fprop_workspace_fn():
 
 
 def conv_wgrad(x, dy, *, cout, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=1, Wout=1, R=1, S=1, stride=1, pad=0, dil=1,
-               M=None, nbr=None, yoff=0, out=None, out_dtype=torch.float32, rows=None, alg_cin=None, alg_cout=None, park=None):
+               M=None, nbr=None, yoff=0, out=None, out_dtype=torch.float32, rows=None, alg_cin=None, alg_cout=None, park=None, xf=None):
     """dW[co, tap, ci] = sum_m dY[m, co] X[src(m,tap), ci]; (Cout, R*S, Cin) accumulated in fp32 and written as
     `out_dtype` (fp32 / bf16 -- the converting reduce saves a separate cast pass). `dy` may be a channel slice (yoff) of
     a wider buffer.
@@ -140,6 +173,7 @@ def conv_wgrad(x, dy, *, cout, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=1, Wout=1
         out_dtype = out.dtype
     p.dw_dtype = hip.code_of(out_dtype)
     p.m_dev = hip.ptr(rows)
+    _set_xf(p, xf, Cin)                        # the x operand is a raw conv output: BatchNorm + activation applied in flight
     lib = hip.lib()
     lib.mg_conv_wgrad_workspace.restype = ctypes.c_long
     need = lib.mg_conv_wgrad_workspace(ctypes.byref(p)) if M > 0 else 0
@@ -414,9 +448,9 @@ def bn_train_bwd(dy, y, x, outs, act, slope, want_dres=False, mask_x_pos=False, 
     M, C = x.shape[0], x.shape[-1]
     p = _rowwise(x, M, C)
     p.dy, p.lddy = hip.ptr(dy), _ld(dy)
-    p.y, p.ldy, p.yoff = hip.ptr(y), C, 0
+    p.y, p.ldy, p.yoff = hip.ptr(y), C, 0      # y None: the activation output was never stored (operand-path BatchNorm), its sign is re-formed from x
     base = outs.data_ptr()
-    p.scale, p.mean, p.invstd = ctypes.c_void_p(base), ctypes.c_void_p(base + 8 * C), ctypes.c_void_p(base + 12 * C)
+    p.scale, p.shift, p.mean, p.invstd = ctypes.c_void_p(base), ctypes.c_void_p(base + 4 * C), ctypes.c_void_p(base + 8 * C), ctypes.c_void_p(base + 12 * C)
     zeroed = sums is not None
     if sums is None:
         sums = torch.empty(2 * C, dtype=torch.float32, device=x.device)

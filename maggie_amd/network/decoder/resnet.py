@@ -28,9 +28,9 @@ class BasicBlock(nn.Module):
         dt = x.dtype
         # `carry`: the skip branch takes x back from the first conv, whose data-gradient kernel then adds the skip gradient in its epilogue
         if self.stride > 1:
-            out, x = MF.conv_bn_act(x, self.conv1.krsc(dt, x.shape[-1]), self.bn1, MF.ACT_LRELU, 4, 4, 2, 1, 1, transposed=True, carry=True, link_out=True)
+            out, x = MF.conv_bn_act(x, self.conv1.krsc(dt, x.shape[-1]), self.bn1, MF.ACT_LRELU, 4, 4, 2, 1, 1, transposed=True, carry=True, link_out=True, lazy_out=True)
         else:
-            out, x = MF.conv_bn_act(x, self.conv1.krsc(dt, x.shape[-1]), self.bn1, MF.ACT_LRELU, 3, 3, 1, 1, 1, carry=True, link_out=True)
+            out, x = MF.conv_bn_act(x, self.conv1.krsc(dt, x.shape[-1]), self.bn1, MF.ACT_LRELU, 3, 3, 1, 1, 1, carry=True, link_out=True, lazy_out=True)
         identity, res_mode = x, 1
         if self.upsample is not None:
             u = self.upsample

@@ -26,7 +26,7 @@ class BasicBlock(nn.Module):
         dt = x.dtype
         # the skip branch takes x back FROM the first conv (`carry`): in backward the skip gradient is added inside that conv's
         # data-gradient kernel instead of by a separate add over the feature map
-        out, x = MF.conv_bn_act(x, self.conv1.krsc(dt, x.shape[-1]), self.bn1, MF.ACT_RELU, 3, 3, self.stride, 1, 1, carry=True, link_out=True)
+        out, x = MF.conv_bn_act(x, self.conv1.krsc(dt, x.shape[-1]), self.bn1, MF.ACT_RELU, 3, 3, self.stride, 1, 1, carry=True, link_out=True, lazy_out=True)
         identity = x
         if self.downsample is not None:
             d = self.downsample
@@ -111,14 +111,14 @@ class ResShortCut_D(ResNet_D):
         the branch's first conv (`carry`), whose data-gradient kernel then adds the backbone's gradient in its epilogue instead of autograd summing
         the two with a feature-map-sized add (five of them per step, 16 MB each at the fine levels)."""
         dt = x.dtype
-        y, x = MF.conv_bn_act(x, seq[0].krsc(dt, x.shape[-1]), seq[2], MF.ACT_NONE, 3, 3, 1, 1, 1, relu_before_bn=True, link_out=True, carry=True)
+        y, x = MF.conv_bn_act(x, seq[0].krsc(dt, x.shape[-1]), seq[2], MF.ACT_NONE, 3, 3, 1, 1, 1, relu_before_bn=True, link_out=True, carry=True, lazy_out=True)
         return MF.conv_bn_act(y, seq[3].krsc(dt, y.shape[-1]), seq[5], MF.ACT_NONE, 3, 3, 1, 1, 1, relu_before_bn=True), x
 
     def forward_features(self, x):
         """x: (N, H, W, 8) NHWC (RGB + 3 embedding channels + 2 zero pad)."""
         dt = x.dtype
         fea1, x = self._run_shortcut(self.shortcut[0], x)
-        out = MF.conv_bn_act(x, self.conv1.krsc(dt, 8), self.bn1, MF.ACT_RELU, 3, 3, self.start_stride[0], 1, 1, link_out=True)
+        out = MF.conv_bn_act(x, self.conv1.krsc(dt, 8), self.bn1, MF.ACT_RELU, 3, 3, self.start_stride[0], 1, 1, link_out=True, lazy_out=True)
         x1 = MF.conv_bn_act(out, self.conv2.krsc(dt), self.bn2, MF.ACT_RELU, 3, 3, self.start_stride[1], 1, 1)       # x1 also feeds shortcut[1]
         fea2, x1 = self._run_shortcut(self.shortcut[1], x1)
         out = MF.conv_bn_act(x1, self.conv3.krsc(dt), self.bn3, MF.ACT_RELU, 3, 3, self.start_stride[2], 1, 1, link_out=True)

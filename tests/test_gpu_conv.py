@@ -418,3 +418,73 @@ def test_bn_backward_sums_in_the_consumer_dgrad_epilogue(case, dtype):
         # linked vs unlinked path of this build: same arithmetic up to the order of the fp32 reductions (and, in bf16, one rounding of g
         # where the unlinked path rounds dz and re-derives g in fp32)
         assert (got[k_] - base[k_]).abs().max().item() <= (2e-5 if dtype == torch.float32 else 2e-2) * sc_, ('vs unlinked', k_)
+
+
+XF_CASES = [
+    # N, Cin, Cout, H, W: 3x3 / stride 1 / pad 1 consumers of a BatchNorm layer's raw input
+    (2, 32, 32, 24, 40),            # one slab, 32-wide tiles (the 512 x 512 shortcut / stem layers)
+    (1, 64, 64, 16, 32),            # two slabs, single-stage form
+    (2, 32, 64, 20, 24),            # ragged spatial tiles
+    (1, 64, 32, 9, 17),             # ragged in both directions, H not a multiple of 8
+    (2, 128, 64, 16, 16),           # two-slab ring (Cin >= 96), four slabs
+    (1, 96, 64, 16, 24),            # odd number of slabs through the ring
+    (1, 256, 128, 8, 16),           # eight slabs, two channel tiles
+    (1, 512, 64, 8, 16),            # the widest table (Cin 512)
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('act', [0, 1, 2])
+@pytest.mark.parametrize('case', XF_CASES)
+def test_operand_transform_equals_the_stored_batchnorm_output(case, act, dtype):
+    """mg_conv_params.xf_* (round 5: conv + BatchNorm + activation as one pass in training, maggie/network/encoder/resnet.py:26-37): the forward
+    and the weight-gradient kernel fed the RAW producer output y plus (scale, shift, act) must give EXACTLY what they give when fed
+    z = mg_affine_act(y) -- the transform forms the same bits on the operand's way into LDS, and padding stays zero (a transformed zero would be
+    act(shift) != 0). Against torch (fp32, conv2d of the stored z) as well."""
+    from maggie_amd import kernels as K
+    dev = _dev()
+    N, Cin, Cout, H, W = case
+    rs = np.random.RandomState(Cin + Cout + H)
+    y = torch.from_numpy(rs.normal(0.3, 1.5, (N * H * W, Cin)).astype(np.float32)).to(dev, dtype)
+    sc = torch.from_numpy(rs.uniform(0.5, 1.5, Cin).astype(np.float32) * rs.choice([-1.0, 1.0], Cin).astype(np.float32)).to(dev)
+    sh = torch.from_numpy(rs.normal(0.0, 0.7, Cin).astype(np.float32)).to(dev)
+    w = torch.from_numpy((rs.normal(size=(Cout, 9, Cin)) / np.sqrt(9 * Cin)).astype(np.float32)).to(dev, dtype)
+    dy = torch.from_numpy(rs.normal(size=(N * H * W, Cout)).astype(np.float32)).to(dev, dtype)
+    assert K.conv_xform_ok(dtype, N, H, W, Cin, Cout, 3, 3, 1, 1, 1, 0) and K.conv_xform_ok(dtype, N, H, W, Cin, Cout, 3, 3, 1, 1, 1, 1)
+    z = K.affine_act(y, sc, sh, act=act, slope=0.2)
+    geo = dict(mode=K.MODE_CONV, N=N, Hin=H, Win=W, R=3, S=3, stride=1, pad=1, dil=1)
+    xf = (sc, sh, act, 0.2)
+    o_ref = K.conv_fprop(z, w, **geo)
+    o_xf = K.conv_fprop(y, w, xf=xf, **geo)
+    assert torch.equal(o_xf, o_ref), 'forward: %d of %d values differ, max %.3g' % (
+        int((o_xf != o_ref).sum()), o_ref.numel(), float((o_xf.float() - o_ref.float()).abs().max()))
+    # statistics epilogue rides along unchanged
+    nrow = K.conv_stat_rows(N * H * W, N, H, W)
+    st_a, st_b = torch.zeros((nrow, 2 * Cout), device=dev), torch.zeros((nrow, 2 * Cout), device=dev)
+    K.conv_fprop(z, w, stats=st_a, **geo)
+    K.conv_fprop(y, w, stats=st_b, xf=xf, **geo)
+    assert torch.equal(st_a, st_b)
+    for out_dtype in (torch.float32, dtype):
+        g_ref = K.conv_wgrad(z, dy, cout=Cout, Hout=H, Wout=W, out_dtype=out_dtype, **geo)
+        g_xf = K.conv_wgrad(y, dy, cout=Cout, Hout=H, Wout=W, out_dtype=out_dtype, xf=xf, **geo)
+        assert torch.equal(g_xf, g_ref), 'weight gradient (%s): max %.3g' % (out_dtype, float((g_xf.float() - g_ref.float()).abs().max()))
+    # ... and the stored form itself against torch
+    zt = z.float().cpu().view(N, H, W, Cin).permute(0, 3, 1, 2)
+    wt = w.float().cpu().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+    ref = F.conv2d(zt, wt, padding=1).permute(0, 2, 3, 1).reshape(-1, Cout)
+    assert (o_xf.float().cpu() - ref).abs().max() <= _tol(dtype) * ref.abs().max()
+
+
+def test_operand_transform_is_refused_where_no_kernel_form_has_it():
+    """A geometry whose kernel form cannot transform its operand reports so (mg_conv_xform_ok) and the launch itself fails with -9 instead of
+    silently convolving un-normalised values."""
+    from maggie_amd import kernels as K, hip
+    dev = _dev()
+    assert not K.conv_xform_ok(torch.bfloat16, 1, 16, 16, 64, 64, 3, 3, 2, 1, 1, 0)          # stride 2: im2col form
+    assert not K.conv_xform_ok(torch.bfloat16, 1, 16, 16, 64, 64, 1, 1, 1, 0, 1, 0)          # 1x1: direct-to-LDS im2col ring
+    assert not K.conv_xform_ok(torch.float32, 1, 16, 16, 64, 64, 3, 3, 1, 1, 1, 0)           # fp32 storage
+    y = torch.randn(256, 64, device=dev).bfloat16()
+    w = torch.randn(64, 1, 64, device=dev).bfloat16()
+    one = torch.ones(64, device=dev)
+    with pytest.raises(hip.MaggieHipError, match='-9'):
+        K.conv_fprop(y, w, mode=K.MODE_CONV, N=1, Hin=16, Win=16, R=1, S=1, stride=1, pad=0, dil=1, xf=(one, one, 1, 0.2))

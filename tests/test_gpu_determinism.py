@@ -318,3 +318,58 @@ def test_batchnorm_statistics_rows_cover_every_conv_tile():
         if K.conv_stat_rows(N * Ho * Wo, N, Ho, Wo) > 64 and N * Ho * Wo >= 64 * 64:
             with pytest.raises(hip.MaggieHipError):
                 K.conv_fprop(x, w, mode=mode, N=N, Hin=H, Win=W, R=k, S=k, stride=stride, pad=pad, dil=1, stats=torch.zeros((K.STAT_REPLICAS, 2 * Cout), device=dev))
+
+
+@pytest.mark.parametrize('kind,size', [('image', 128), ('video', 64)])
+def test_operand_path_batchnorm_gives_the_bits_of_the_stored_form(kind, size):
+    """Round 5: with MAGGIE_LAZY_BN (default) the conv -> BatchNorm -> activation -> conv chains of the encoder blocks,
+    shortcut branches, stem and decoder blocks never store the normalised activation -- the consumer's forward and weight-gradient kernels form it
+    on load, the BatchNorm backward re-forms the activation mask from the raw conv output. That must change NOTHING: the same bf16 training step
+    with the operand path on and off gives identical outputs, losses, gradients and buffers (eager, and replayed from hipGraphs), and the lazy
+    path really ran (the apply kernel is launched for fewer layers)."""
+    from maggie_amd import functional as MF, hip
+    from maggie_amd.utils import synth
+    dev = _dev()
+    n_f = 3 if kind == 'video' else 1
+    model, _ = _build(kind, dev, True)
+    batch = _to(synth.synthetic_batch(2 if kind == 'image' else 1, n_f, 2, size, size, seed=DSEED, train=True, max_inst=10, it=10000), dev)
+    state = copy.deepcopy(model.state_dict())
+    calls = {}
+    orig_call = hip.call
+
+    def counting_call(name, *a, **kw):
+        calls[name] = calls.get(name, 0) + 1
+        return orig_call(name, *a, **kw)
+
+    def step(lazy, graphs):
+        MF.LAZY_BN = lazy
+        for store in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs'):
+            model.__dict__.get(store, {}).clear()
+        snaps = []
+        for _ in range(3 if graphs else 1):
+            model.load_state_dict(state)
+            _reset_dropout(model)
+            model.hip_graphs = graphs
+            model.zero_grad(set_to_none=True)
+            seed_all(5)
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                out, loss = model(batch)
+            loss['total'].backward()
+            snaps.append(_snapshot(model, out, loss))
+        return snaps[-1]
+
+    try:
+        hip.call = MF.K.hip.call = counting_call
+        calls.clear(); stored = step(False, False); n_stored = dict(calls)
+        calls.clear(); lazy = step(True, False); n_lazy = dict(calls)
+        hip.call = MF.K.hip.call = orig_call
+        _assert_same_bits(lazy, stored, 'operand-path BatchNorm vs stored BatchNorm (eager)')
+        fused = n_lazy.get('mg_bn_finalize', 0) - n_stored.get('mg_bn_finalize', 0)
+        print(kind, 'layers on the operand path:', fused, '| mg_bn_train_fwd calls', n_stored.get('mg_bn_train_fwd'), '->', n_lazy.get('mg_bn_train_fwd'))
+        assert fused >= (6 if kind == 'image' else 3) and n_lazy.get('mg_bn_train_fwd', 0) == n_stored.get('mg_bn_train_fwd', 0) - fused
+        _assert_same_bits(step(True, True), stored, 'operand-path BatchNorm replayed from hipGraphs vs stored BatchNorm (eager)')
+    finally:
+        hip.call = MF.K.hip.call = orig_call
+        MF.LAZY_BN = True
+        for store in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs'):
+            model.__dict__.get(store, {}).clear()

@@ -98,7 +98,11 @@ def test_batchnorm_large_mean_fp32_in_deterministic_mode(rows):
     assert (y.cpu() - yr).abs().max() <= 1e-3, (y.cpu() - yr).abs().max()
     assert torch.allclose(rv.cpu(), bn_ref.running_var.float(), rtol=2e-3)
     dxr = xr.grad.permute(0, 2, 3, 1).float()
-    assert (dx.cpu() - dxr).abs().max() <= 2e-3 * dxr.abs().max()
+    # an activation whose pre-image sits within the forward's ~1e-4 of zero takes the other ReLU branch than in the fp64 reference (a handful of the
+    # 1e5 elements; each moves dx by its whole g): those are excluded, everything else must agree
+    near0 = (yr.abs() < 1e-3) & ((y.cpu() > 0) != (yr > 0))
+    assert float(near0.float().mean()) <= 1e-3
+    assert ((dx.cpu() - dxr).abs() * (~near0).float()).max() <= 2e-3 * dxr.abs().max(), ((dx.cpu() - dxr).abs() * (~near0).float()).max()
 
 
 def test_bn_fold_and_pool():

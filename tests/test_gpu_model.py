@@ -20,14 +20,17 @@ ALPHA_TOL = 1e-3
 # north-star tolerance (a site that flips in the index map switches its OS1 / OS4 pixel between refined and coarse); mism: fraction of index-map pixels that differ; loss_rel: worst relative loss-term error
 # (incl. the reference-pinned entries); grad_med / grad_worst: per-parameter relative L2 gradient error; running: worst running-statistic error
 # relative to the buffer's scale.
-EVAL_IMAGE_MAX = 1e-3          # max-abs alpha error, image eval fixtures, fp32 (vs oracle and vs golden)
-WELL_BARS = dict(alpha_os8_vs_fp64=1e-3, mism=2e-4, loss_rel=1e-3, grad_med=1.5e-2, grad_p90=2.5e-2, grad_worst=4e-2)
+EVAL_IMAGE_MAX = 2.3e-5        # max-abs alpha error, image eval fixtures, fp32 (vs oracle and vs golden): measured 1.13e-5 (alpha_os8 vs golden, 4 instances)
+# measured (round 5, profiles/r05_parity_observed.json): alpha_os8 vs fp64 6.7e-4 (the CPU fp32 path: 2.8e-4), one index-map pixel of 2.6 M, loss 8.1e-6,
+# gradients 2.7e-3 / 8.9e-3 / 1.2e-2 (CPU fp32: 1.4e-3 / 6.8e-3 / 1.15e-2)
+WELL_BARS = dict(alpha_os8_vs_fp64=1e-3, mism=8e-7, loss_rel=2e-5, grad_med=5.4e-3, grad_p90=1.8e-2, grad_worst=2.4e-2)
+# measured per fixture (same file); `frac` / `mism` floors of 2e-5 / 1e-5 = a few pixels where the measurement is 0
 TRAIN_BARS = {
-    'model_image_train.npz': dict(os8_max=5e-3, frac=5e-2, mism=2e-3, loss_rel=5e-3, grad_med=2.5e-2, grad_worst=1e-1, running=2e-3),
-    'model_image_train_warmup.npz': dict(os8_max=5e-3, frac=5e-2, mism=2e-3, loss_rel=5e-3, grad_med=2.5e-2, grad_worst=1e-1, running=2e-3),
-    'model_video_train.npz': dict(os8_max=5e-3, frac=5e-2, mism=2e-3, loss_rel=5e-3, grad_med=2.5e-2, grad_worst=1e-1, running=2e-3),
-    'model_image_train_4inst_b4.npz': dict(os8_max=5e-3, frac=5e-2, mism=2e-3, loss_rel=5e-3, grad_med=2.5e-2, grad_worst=1e-1, running=2e-3),
-    'model_video_train_t5.npz': dict(os8_max=5e-3, frac=5e-2, mism=2e-3, loss_rel=5e-3, grad_med=2.5e-2, grad_worst=1e-1, running=2e-3),
+    'model_image_train.npz': dict(os8_max=2.9e-3, frac=8.2e-4, mism=2.5e-5, loss_rel=1.9e-4, grad_med=1.1e-2, grad_worst=4e-2, running=1.1e-4),
+    'model_image_train_warmup.npz': dict(os8_max=6e-4, frac=2e-5, mism=1e-5, loss_rel=1.6e-5, grad_med=3.6e-3, grad_worst=4e-2, running=1.6e-5),
+    'model_video_train.npz': dict(os8_max=8.3e-4, frac=2e-4, mism=1e-5, loss_rel=3e-5, grad_med=4.6e-3, grad_worst=2.5e-2, running=6.2e-5),
+    'model_image_train_4inst_b4.npz': dict(os8_max=1.1e-3, frac=8e-5, mism=1e-5, loss_rel=4e-5, grad_med=7.6e-3, grad_worst=3.4e-2, running=4e-5),
+    'model_video_train_t5.npz': dict(os8_max=2.8e-4, frac=2e-5, mism=1e-5, loss_rel=1.2e-4, grad_med=3.1e-3, grad_worst=2e-2, running=1.4e-5),
 }
 
 
