@@ -184,7 +184,8 @@ typedef struct mg_rowwise_params {
                              (0 = 1). The decoder's skip branch (UpsamplingNearest2d(2) -> 1x1 conv -> BatchNorm, maggie/network/decoder/resnet.py:
                              143-147 of the reference) is evaluated BEFORE the up-sampling here: mean and biased variance are unchanged by the 2x2
                              replication, the reference's sample count is 4x the rows (count_mult = 4) */
-    int32_t reserved0;
+    int32_t mask_from_x;  /* backward of an operand-path BatchNorm layer (round 5, mg_conv_params.xf_*): the activation output was never stored -- `y` is
+                             ignored and the sign of act's argument is re-formed as x * scale + shift (needs `shift`) */
 } mg_rowwise_params;
 
 /* stats[rep][c] += sum_m x[m,c], stats[rep][C+c] += sum_m x[m,c]^2 (fp32 [MG_STAT_REPLICAS][2C], pre-zeroed) */

@@ -519,7 +519,7 @@ __device__ __forceinline__ void load_g(const mg_rowwise_params& p, int m, int c0
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
     TR::unpack(*(const uint4*)((const T*)p.dy + (long)m * p.lddy + c0), g);
-    if (p.act != MG_ACT_NONE && !p.y) {
+    if (p.act != MG_ACT_NONE && p.mask_from_x) {
         // the activation output was never stored (round 5: the consumer convolution applies BatchNorm + activation to its operand in flight,
         // mg_conv_params.xf_*): its sign is that of x * scale + shift, re-formed from the raw input with the arithmetic of xf_apply8
         float xv[CE];

@@ -161,9 +161,21 @@ def disable_timing():
 
 
 _FN = {}
+_SYNC_CALLS = os.environ.get('MAGGIE_SYNC_CALLS', '0') == '1'      # debugging: synchronise after every launch, so that an asynchronous GPU fault names its entry point
 
 
 def call(name, *args, work=None, tag=None):
+    if _SYNC_CALLS and not torch.cuda.is_current_stream_capturing():
+        import sys
+        sys.stderr.write('[mg] %s\n' % name)
+        sys.stderr.flush()
+        _call(name, *args, work=work, tag=tag)
+        torch.cuda.synchronize()
+        return
+    _call(name, *args, work=work, tag=tag)
+
+
+def _call(name, *args, work=None, tag=None):
     if _HAS_GPU and torch._C._cuda_getDevice() not in _DET_READY:
         _det_init()
     fn = _FN.get(name)
@@ -194,7 +206,7 @@ class RowwiseParams(ctypes.Structure):
         ('act', ctypes.c_int32), ('res_mode', ctypes.c_int32), ('mask_x_pos', ctypes.c_int32),
         ('slope', ctypes.c_float), ('count', ctypes.c_float),
         ('m_dev', ctypes.c_void_p),
-        ('count_mult', ctypes.c_int32), ('reserved0', ctypes.c_int32),
+        ('count_mult', ctypes.c_int32), ('mask_from_x', ctypes.c_int32),
     ]
 
 

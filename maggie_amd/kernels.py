@@ -448,7 +448,9 @@ def bn_train_bwd(dy, y, x, outs, act, slope, want_dres=False, mask_x_pos=False, 
     M, C = x.shape[0], x.shape[-1]
     p = _rowwise(x, M, C)
     p.dy, p.lddy = hip.ptr(dy), _ld(dy)
-    p.y, p.ldy, p.yoff = hip.ptr(y), C, 0      # y None: the activation output was never stored (operand-path BatchNorm), its sign is re-formed from x
+    # y None: the activation output was never stored (operand-path BatchNorm): its sign is re-formed from x (mask_from_x; `y` then only has to be a
+    # valid address)
+    p.y, p.ldy, p.yoff, p.mask_from_x = hip.ptr(x if y is None else y), C, 0, int(y is None)
     base = outs.data_ptr()
     p.scale, p.shift, p.mean, p.invstd = ctypes.c_void_p(base), ctypes.c_void_p(base + 4 * C), ctypes.c_void_p(base + 8 * C), ctypes.c_void_p(base + 12 * C)
     zeroed = sums is not None

@@ -1348,3 +1348,27 @@ def test_fan_out_adds_the_consumer_gradients_in_one_ordered_launch():
     assert torch.equal(K.sum_k([a, b, c]), (a + b) + c)
     plain = torch.randn(3, 4, device=dev)                          # no gradient wanted: the tensor itself is handed out
     assert MF.Fan(plain, 4)() is plain and MF.take(plain) is plain and MF.take(None) is None
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('act', [0, 1, 2])
+@pytest.mark.parametrize('M,C', [(2048, 64), (5000, 32), (40000, 128)])
+def test_batchnorm_backward_with_the_activation_mask_reformed_from_the_raw_input(M, C, act, dtype):
+    """Operand-path BatchNorm (round 5): the normalised activation z = act(x * scale + shift) is never stored, so mg_bn_train_bwd gets y = NULL and
+    re-forms the sign of z from the raw input. Same bits as the stored form (dx and both sums), for every activation, with and without the
+    ReLU-before-BatchNorm input mask."""
+    from maggie_amd import kernels as K
+    dev = _dev()
+    rs = np.random.RandomState(M + C + act)
+    x = torch.from_numpy(rs.normal(0.2, 1.3, (M, C)).astype(np.float32)).to(dev, dtype)
+    dz = torch.from_numpy(rs.normal(size=(M, C)).astype(np.float32)).to(dev, dtype)
+    gamma = torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32) * rs.choice([-1.0, 1.0], C).astype(np.float32)).to(dev)
+    beta = torch.from_numpy(rs.normal(size=C).astype(np.float32)).to(dev)
+    stats = K.colstats(x)
+    sc, sh, mean, invstd = K.bn_finalize(stats, M, gamma, beta, None, None, 0.1, 1e-5)
+    pack = sc._base.view(-1)
+    z = K.affine_act(x, sc, sh, act=act, slope=0.2)
+    for mask_x_pos in (False, True):
+        dx_a, _, s_a = K.bn_train_bwd(dz, z, x, pack, act, 0.2, False, mask_x_pos)
+        dx_b, _, s_b = K.bn_train_bwd(dz, None, x, pack, act, 0.2, False, mask_x_pos)
+        assert torch.equal(dx_a, dx_b) and torch.equal(s_a, s_b), (int((dx_a != dx_b).sum()), float((s_a - s_b).abs().max()))
