@@ -678,12 +678,15 @@ class BNLazy(torch.autograd.Function):
         ctx.save_for_backward(x2, pack)
         ctx.meta = (x.shape, M, C, act, mask_x_pos)
         ctx.mark_non_differentiable(sc, sh)
+        ctx.set_materialize_grads(False)                          # (else autograd fills a zero gradient for scale and shift on every backward: two launches per layer)
         return x.view_as(x), sc, sh
 
     @staticmethod
     def backward(ctx, dz, _dsc, _dsh):
         x2, pack = ctx.saved_tensors
         shape, M, C, act, mask_x_pos = ctx.meta
+        if dz is None:
+            return (None,) * 10
         sums = ARENA.take(2 * C, dz.device) if torch.cuda.is_current_stream_capturing() else None
         dx, _, sums = K.bn_train_bwd(rows_of(dz, C), None, x2, pack.view(-1), act, LRELU_SLOPE, False, mask_x_pos, sums)
         return dx.view(shape), sums[C:], sums[:C], None, None, None, None, None, None, None
