@@ -61,6 +61,8 @@ def parse():
                     help='flat: maggie_amd.optim.FlatAdamW (one flat buffer, clip folded into the update; default); fused / foreach: '
                          'torch.optim.AdamW implementations after maggie_amd.parallel.clip_grad_norm_')
     ap.add_argument('--video', action='store_true', help='maggie_video.yaml, T=3 (BASELINE configs[3]); not the headline line')
+    ap.add_argument('--frames', type=int, default=3, help='--video: frames per clip (maggie_video.yaml:32 trains with clip_length 8)')
+    ap.add_argument('--clips', type=int, default=1, help='--video: clips per GPU (maggie_video.yaml:89 trains with batch_size 4)')
     return ap.parse_args()
 
 
@@ -96,8 +98,8 @@ def main():
     from maggie_amd import hip, parallel
 
     kind = 'video' if args.video else 'image'
-    n_f = 3 if args.video else 1
-    b = 1 if args.video else args.batch
+    n_f = args.frames if args.video else 1
+    b = args.clips if args.video else args.batch
     cfg = config.model_config(kind)
     model, _ = build_model(cfg)
     sd = model.state_dict()
@@ -377,7 +379,7 @@ def trace_graph_replay(args, fam_alg):
     out_dir = tempfile.mkdtemp(prefix='mg_trace_', dir='/tmp')
     cmd = [prof, '--kernel-trace', '--output-format', 'csv', '-d', out_dir, '--', sys.executable, os.path.abspath(__file__), '--steps', str(n_steps),
            '--warmup', '2', '--no-roofline', '--no-cpu-baseline', '--batch', str(args.batch), '--instances', str(args.instances), '--size', str(args.size),
-           '--workload', args.workload, '--iter', str(args.iter), '--edge', str(args.edge), '--dtype', args.dtype] + (['--video'] if args.video else [])
+           '--workload', args.workload, '--iter', str(args.iter), '--edge', str(args.edge), '--dtype', args.dtype] + (['--video', '--frames', str(args.frames), '--clips', str(args.clips)] if args.video else [])
     try:
         res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'))
         line = [l for l in res.stdout.decode(errors='replace').splitlines() if l.startswith('{"metric"')]
@@ -477,7 +479,7 @@ def cpu_baseline_subprocess(args):
     limit_s = 900 if args.cpu_baseline_full else 420
     cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--size', str(args.size), '--instances', str(args.instances),
            '--batch', str(args.batch), '--iter', str(args.iter), '--edge', str(args.edge), '--workload', args.workload,
-           '--cpu-threads', str(args.cpu_threads)] + (['--video'] if args.video else []) + (['--cpu-baseline-full'] if args.cpu_baseline_full else []) + \
+           '--cpu-threads', str(args.cpu_threads)] + (['--video', '--frames', str(args.frames), '--clips', str(args.clips)] if args.video else []) + (['--cpu-baseline-full'] if args.cpu_baseline_full else []) + \
           (['--acc-file', args.acc_file] if getattr(args, 'acc_file', '') else [])
     env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
     part = None
@@ -520,8 +522,8 @@ def run_cpu_baseline(kind, args):
     model, _ = build_model(config.model_config(kind))
     sd0 = model.state_dict()
     synth.fill_state_dict_(sd0, 1234)
-    n_f = 3 if kind == 'video' else 1
-    b = 1 if kind == 'video' else args.batch
+    n_f = args.frames if kind == 'video' else 1
+    b = args.clips if kind == 'video' else args.batch
     size = args.size
     mcfg = copy.deepcopy(config.MODEL_VIDEO if kind == 'video' else config.MODEL_IMAGE)
     n_warm, n_timed = (2, 9) if args.cpu_baseline_full else (1, 3)

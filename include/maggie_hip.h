@@ -125,6 +125,9 @@ typedef struct mg_conv_params {
 int mg_conv_xform_ok(const mg_conv_params* p, int which);
 
 int mg_conv_fprop(const mg_conv_params* p, void* stream);
+/* Rows of a `stats` buffer (stat_mode 0) that give every output tile of any forward kernel form its own row for an [M = N * Hout * Wout] output
+ * (deterministic mode; MG_STAT_REPLICAS in atomic mode): what mg_conv_params.stat_rep must be at least, else the launch fails with -8. */
+int mg_conv_stat_rows(int M, int N, int Hout, int Wout);
 /* Same, allowed to split the K dimension over several blocks per tile for deep layers with few output rows (M <= 8192,
  * K >= ~1152, Cout >= 64): mg_conv_fprop_workspace(p) = floats of scratch that plan needs (0: no split, identical to
  * mg_conv_fprop); partial tiles go to the workspace, a second kernel sums them and applies the epilogue (deterministic). */
@@ -616,6 +619,9 @@ int mg_token_einsum_bwd(const void* dlog, const void* feat, int dtype, const flo
 /* out[i] = ((srcs[0][i] + srcs[1][i]) + srcs[2][i]) + ... : the gradient of a tensor with k <= 16 consumers in one launch and a fixed order (replaces
  * the k - 1 pairwise adds of the autograd engine; maggie/network/module/mask_attention.py:63-133 uses every token tensor several times). fp32. */
 int mg_sum_k(const float* const* srcs, int k, long n, float* out, void* stream);
+/* dsts[j][0 .. bytes[j]) = srcs[j][...] for j < k <= 16 as ONE launch (replaces torch._foreach_copy_ of contiguous same-type tensors = one hipMemcpyAsync
+ * each: the outputs a replayed graph hands to the caller, engine/train.py:229-241 keeps them across steps; gradient hand-over between graphs). */
+int mg_copy_k(const void* const* srcs, void* const* dsts, const long* bytes, int k, void* stream);
 int mg_token_sa_fwd(const float* q, const float* k, const float* v, const unsigned char* pad, float scale, int B, int T, int D, float* out, float* prob,
                     void* stream);
 int mg_token_sa_bwd(const float* dout, const float* q, const float* k, const float* v, const float* prob, float scale, int B, int T, int D, float* dq,

@@ -29,3 +29,50 @@ extern "C" int mg_zero_claim(void* p, long bytes) {
     return 0;
 }
 extern "C" int mg_zeroed_range_conflicts(void) { const int n = g_conflicts; g_conflicts = 0; return n; }
+
+
+// ---- up to 16 device-to-device copies as ONE launch (round 5). The step hands tensors across graph boundaries -- what the caller receives from a
+// replayed graph (four 42 MB alpha planes + the index map), the detail graph's input gradients into the trunk graph's gradient slots -- and
+// torch._foreach_copy_ of contiguous same-type tensors turns into one hipMemcpyAsync per tensor: 5 + 7 copy kernels of 5-25 us per step, each with
+// its own launch floor and ramp. Here the jobs share one grid: a workgroup walks the concatenated 16-byte chunk space (sizes / addresses that are
+// not 16-byte multiples take a byte tail), 2048 workgroups stream all buffers at once.
+namespace {
+struct CopyJobs { const char* src[16]; char* dst[16]; long bytes[16]; long first[17]; int k; };      // first[j]: first 4 KiB block of job j
+__global__ __launch_bounds__(256) void copy_k_kernel(const CopyJobs c) {
+    const long nblk = c.first[c.k];
+    for (long b = blockIdx.x; b < nblk; b += gridDim.x) {
+        int j = 0;
+#pragma unroll
+        for (int q = 1; q < 16; ++q) if (q < c.k && b >= c.first[q]) j = q;
+        const long off = (b - c.first[j]) * 4096;
+        const long n = c.bytes[j] - off < 4096 ? c.bytes[j] - off : 4096;
+        const char* s = c.src[j] + off;
+        char* d = c.dst[j] + off;
+        if (n == 4096 && (((size_t)s | (size_t)d) & 15) == 0) {
+            ((uint4*)d)[threadIdx.x] = ((const uint4*)s)[threadIdx.x];
+        } else {
+            for (long i = threadIdx.x; i < n; i += 256) d[i] = s[i];
+        }
+    }
+}
+}  // namespace
+extern "C" int mg_copy_k(const void* const* srcs, void* const* dsts, const long* bytes, int k, void* stream) {
+    if (k < 0 || k > 16 || (k > 0 && (!srcs || !dsts || !bytes))) return -2;
+    CopyJobs c;
+    long blocks = 0;
+    int m = 0;
+    for (int j = 0; j < k; ++j) {
+        if (bytes[j] < 0 || (bytes[j] > 0 && (!srcs[j] || !dsts[j]))) return -2;
+        if (bytes[j] == 0 || srcs[j] == dsts[j]) continue;
+        c.src[m] = (const char*)srcs[j]; c.dst[m] = (char*)dsts[j]; c.bytes[m] = bytes[j]; c.first[m] = blocks;
+        blocks += (bytes[j] + 4095) / 4096;
+        ++m;
+    }
+    if (m == 0) return 0;
+    for (int j = m; j < 16; ++j) { c.src[j] = nullptr; c.dst[j] = nullptr; c.bytes[j] = 0; c.first[j] = blocks; }
+    c.first[m] = blocks; c.first[16] = blocks; c.k = m;
+    const long grid = blocks < 4096 ? blocks : 4096;
+    hipLaunchKernelGGL(copy_k_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, c);
+    MG_CHECK_LAUNCH();
+    return 0;
+}

@@ -1618,6 +1618,25 @@ extern "C" int mg_conv_xform_ok(const mg_conv_params* pp, int which) {
     return which == 0 ? (int)fprop_xf_ok(*pp) : (which == 1 ? (int)mg_wgrad_xform_ok(*pp) : 0);
 }
 
+/* Rows a BatchNorm statistics buffer needs so that every output tile of ANY forward kernel form of this file owns a row (deterministic mode:
+ * one addition per word, mg_conv_params.stat_rep): the single source of this bound, next to the tile shapes it depends on (the
+ * binding used to re-derive it). Forms: spatial halo tiles of >= 4 x 16 pixels (halo / c8 kernels); row tiles of >= 64 rows, four padded phases
+ * for a stride-2 transposed walk (im2col and direct-to-LDS forms: row_tiles(p, M, 64) <= M / 64 + 8); the split-K finish kernel's row blocks
+ * (M <= 8192: at most 512 blocks of >= 16 rows). Atomic mode: the 32 replicas. */
+extern "C" int mg_conv_stat_rows(int M, int N, int Hout, int Wout) {
+    if (!mg_det_on) return MG_STAT_REPLICAS;
+    long rows = (long)N * ((Hout + 3) / 4) * ((Wout + 15) / 16);
+    const long by_rows = (M + 63) / 64 + 8;
+    if (by_rows > rows) rows = by_rows;
+    if (rows < MG_STAT_REPLICAS + 1) rows = MG_STAT_REPLICAS + 1;
+    if (M <= 8192) {
+        long fin = (M + 15) / 16 + 1;
+        if (fin > 512) fin = 512;
+        if (fin > rows) rows = fin;
+    }
+    return (int)rows;
+}
+
 static int conv_fprop_check(const mg_conv_params& p) {
     const int ce = MG_IS16(p.dtype) ? 8 : 4;
     if (p.Cin % ce != 0 || p.ldx % ce != 0) return -3;                 // K chunks must not straddle taps / be 16-B aligned

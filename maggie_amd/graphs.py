@@ -70,7 +70,7 @@ class _Replay(torch.autograd.Function):
         if zero:
             torch._foreach_zero_(zero)
         if dst:
-            torch._foreach_copy_(dst, src)
+            MF.K.copy_k(dst, src)                                 # the downstream graph's input gradients into this graph's slots: one launch
         g.prepare_sink_replay()
         g.bwd.replay()
         # gradients of the differentiable inputs are handed over as the graph's own buffers: their consumer (the producing graph's
@@ -303,7 +303,7 @@ class GraphedCallable:
                 dst.append(s)
         if dst:
             with torch.no_grad():                                 # static inputs the graph differentiates through are leaves that require grad
-                torch._foreach_copy_(dst, src)
+                MF.K.copy_k([d.detach() for d in dst], [s_.detach() for s_ in src])
         if self.training:
             return _Replay.mark_static(_Replay.apply(self, *[inputs[i] for i in self.grad_idx], *self.params))
         self.fwd.replay()

@@ -207,6 +207,28 @@ def sum_k(ts):
     return out
 
 
+def copy_k(dsts, srcs):
+    """dst.copy_(src) for lists of device tensors, 16 per launch (mg_copy_k); pairs that are not plain byte copies (different dtype / shape, a
+    non-contiguous side) go through torch._foreach_copy_."""
+    plain, rest_d, rest_s = [], [], []
+    for d, s_ in zip(dsts, srcs):
+        if d.dtype == s_.dtype and d.shape == s_.shape and d.is_contiguous() and s_.is_contiguous() and d.is_cuda and s_.is_cuda:
+            if d.numel() and d.data_ptr() != s_.data_ptr():
+                plain.append((d, s_))
+        else:
+            rest_d.append(d)
+            rest_s.append(s_)
+    for i in range(0, len(plain), 16):
+        grp = plain[i:i + 16]
+        n = len(grp)
+        sp = (ctypes.c_void_p * n)(*[s_.data_ptr() for _, s_ in grp])
+        dp = (ctypes.c_void_p * n)(*[d.data_ptr() for d, _ in grp])
+        nb = (ctypes.c_long * n)(*[d.numel() * d.element_size() for d, _ in grp])
+        hip.call('mg_copy_k', sp, dp, nb, c_int(n), hip.stream())
+    if rest_d:
+        torch._foreach_copy_(rest_d, rest_s)
+
+
 def wgrad_reduce_batched(park):
     """Run every parked slab reduction of `park` (conv_wgrad(park=...)) in one launch per 64 layers and empty the list."""
     n = len(park)
@@ -254,12 +276,16 @@ def conv_stat_rows(M, N=1, Hout=1, Wout=1):
     """Rows of the statistics buffer a conv epilogue adds into: in deterministic mode at least the number of output tiles of ANY kernel form
     (spatial halo tiles of >= 4 x 16 pixels, row tiles of >= 64 rows, the four padded phases of a stride-2 transposed walk), so that every
     word receives exactly one addition; rows nobody writes stay zero."""
-    if not hip.DETERMINISTIC:
-        return STAT_REPLICAS
-    rows = max(N * ((Hout + 3) // 4) * ((Wout + 15) // 16), (M + 63) // 64 + 8, STAT_REPLICAS + 1)
-    if M <= 8192:
-        rows = max(rows, min(512, (M + 15) // 16 + 1))             # split-K layers: the statistics come from the finish kernel's row blocks
+    key = (hip.DETERMINISTIC, M, N, Hout, Wout)
+    rows = _STAT_ROWS.get(key)
+    if rows is None:                                               # asked of the library, which owns the tile shapes (mg_conv_stat_rows)
+        fn = hip.lib().mg_conv_stat_rows
+        fn.restype = ctypes.c_int
+        rows = _STAT_ROWS[key] = int(fn(c_int(M), c_int(N), c_int(Hout), c_int(Wout)))
     return rows
+
+
+_STAT_ROWS = {}
 
 
 def ACC(n, device, dtype=torch.float32):

@@ -484,7 +484,7 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             idx = [i for i in idx if i not in set(small)]
         if idx:
             fresh = [torch.empty_like(outs[i]) for i in idx]
-            torch._foreach_copy_(fresh, [outs[i] for i in idx])
+            MF.K.copy_k(fresh, [outs[i] for i in idx])            # one launch for the four 42 MB alpha planes + the index map (was one copy kernel each)
             for i, f in zip(idx, fresh):
                 outs[i] = f
         return tuple(t.clone() if t.requires_grad else t for t in outs)        # 'loss/total': a differentiable one-element copy

@@ -373,3 +373,48 @@ def test_operand_path_batchnorm_gives_the_bits_of_the_stored_form(kind, size):
         MF.LAZY_BN = True
         for store in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs'):
             model.__dict__.get(store, {}).clear()
+
+
+def test_video_clip_length_8_trains_and_replays_like_eager():
+    """The reference's own video training shape has clip_length 8 (configs/maggie_video.yaml:32; bench.py --video --frames 8): two optimizer
+    steps of a T = 8 clip stay finite, and the step replayed from hipGraphs gives the bits of the eager step (the ConvGRU recurrence and the
+    bidirectional fusion walk 8 frames; T = 3 and T = 5 are the fixture geometries)."""
+    from maggie_amd.optim import FlatAdamW
+    from maggie_amd.utils import synth
+    dev = _dev()
+    model, _ = _build('video', dev, True)
+    batch = _to(synth.synthetic_batch(1, 8, 2, 96, 96, seed=DSEED, train=True, max_inst=10, it=10000), dev)
+    state = copy.deepcopy(model.state_dict())
+
+    def step(graphs):
+        model.load_state_dict(state)
+        _reset_dropout(model)
+        model.hip_graphs = graphs
+        model.zero_grad(set_to_none=True)
+        seed_all(5)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            out, loss = model(batch)
+        loss['total'].backward()
+        return _snapshot(model, out, loss)
+
+    e0 = step(False)
+    assert e0['out/alpha_os1'].shape == (1, 8, 10, 96, 96) and all(bool(torch.isfinite(v.float()).all()) for v in e0.values())
+    for k in ('loss/loss_temp', 'loss/total'):
+        assert k in e0 and bool(torch.isfinite(e0[k]).all()), k
+    g = [step(True) for _ in range(4)]
+    _assert_same_bits(g[3], g[2], 'T = 8: replay 2 vs replay 1')
+    _assert_same_bits(g[2], e0, 'T = 8: replayed step vs eager step')
+    # ... and it trains: two FlatAdamW steps with the reference's clip stay finite
+    model.load_state_dict(state)
+    opt = FlatAdamW([p for p in model.parameters() if p.requires_grad], lr=5e-5 / 25, weight_decay=0.01, max_grad_norm=0.01)
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        seed_all(5)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            _, loss = model(batch)
+        loss['total'].backward()
+        opt.step()
+        assert bool(torch.isfinite(loss['total']))
+    assert all(bool(torch.isfinite(p).all()) for p in model.parameters())
+    for store in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs'):
+        model.__dict__.get(store, {}).clear()

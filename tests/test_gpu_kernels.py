@@ -1372,3 +1372,25 @@ def test_batchnorm_backward_with_the_activation_mask_reformed_from_the_raw_input
         dx_a, _, s_a = K.bn_train_bwd(dz, z, x, pack, act, 0.2, False, mask_x_pos)
         dx_b, _, s_b = K.bn_train_bwd(dz, None, x, pack, act, 0.2, False, mask_x_pos)
         assert torch.equal(dx_a, dx_b) and torch.equal(s_a, s_b), (int((dx_a != dx_b).sum()), float((s_a - s_b).abs().max()))
+
+
+def test_copy_k_many_buffers_in_one_launch():
+    """mg_copy_k (round 5): up to 16 device copies per launch -- odd byte counts, unaligned addresses, empty and aliased jobs, more than 16 jobs,
+    mixed dtypes; pairs that are not plain byte copies fall back to torch's copy."""
+    from maggie_amd import kernels as K
+    dev = _dev()
+    g = torch.Generator(device='cpu').manual_seed(3)
+    sizes = [1, 7, 4096, 4097, 65536 + 3, 10 * 512 * 512, 0, 33, 16, 15, 1 << 20, 5, 1000003, 64, 2, 9, 4095, 8192 + 1, 12345]
+    srcs = [torch.randn(max(n, 1), generator=g)[:n].to(dev) for n in sizes]
+    srcs[3] = torch.randn(4098, generator=g).to(dev)[1:]                       # a 4-byte-aligned (not 16-byte-aligned) source
+    srcs.append((torch.randn(777, generator=g) * 100).to(dev).to(torch.bfloat16))
+    srcs.append(torch.randint(0, 255, (4, 10, 64, 64), generator=g).to(dev).to(torch.uint8))
+    dsts = [torch.full_like(s, 7) for s in srcs]
+    alias = torch.arange(100, device=dev, dtype=torch.float32)
+    srcs.append(alias); dsts.append(alias)                                     # same address: skipped
+    srcs.append(torch.randn(6, 5, generator=g).to(dev).t()); dsts.append(torch.zeros(5, 6, device=dev))        # non-contiguous: torch's copy
+    srcs.append(torch.randn(32, generator=g).to(dev)); dsts.append(torch.zeros(32, device=dev, dtype=torch.bfloat16))   # dtype change: torch's copy
+    K.copy_k(dsts, srcs)
+    torch.cuda.synchronize()
+    for d, s_ in zip(dsts, srcs):
+        assert torch.equal(d.float(), s_.to(d.dtype).float()), (d.shape, d.dtype)
