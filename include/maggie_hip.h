@@ -119,6 +119,10 @@ typedef struct mg_conv_params {
     const float* xf_shift;
     int32_t xf_act;
     float xf_slope;
+    /* bnb_* launches whose BatchNorm layer never stored its activation output (operand-path BatchNorm: bnb_y == NULL although bnb_act != none): the
+     * sign of the activation's argument is re-formed as bnb_x * bnb_scale + bnb_shift (the layer's folded scale | shift, as in xf_*). */
+    const float* bnb_scale;
+    const float* bnb_shift;
 } mg_conv_params;
 
 /* 1 when the kernel form this geometry dispatches to applies the operand transform (xf_*) in flight: which = 0 mg_conv_fprop[_ws], 1 mg_conv_wgrad*. */

@@ -20,6 +20,7 @@
 #include "../../include/maggie_hip.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -108,13 +109,16 @@ __device__ __forceinline__ void tile_epilogue_impl(const mg_conv_params& p, f32x
     // BNB (round 3): this launch is the data gradient arriving at the OUTPUT of a training BatchNorm(+activation) layer. The epilogue
     // then writes g = dz * act'(z) and accumulates that layer's backward sums (sum g, sum g * xhat) -- the whole bn_bwd_reduce pass
     // (59 launches, three tensor reads each per step) rides on tiles that are in registers anyway.
-    [[maybe_unused]] float bmu[CE], bis[CE];
+    [[maybe_unused]] float bmu[CE], bis[CE], bsc[CE], bsh[CE];
+    [[maybe_unused]] const bool bnb_lazy = BNB && p.bnb_scale != nullptr;       // the layer's activation output was never stored: mask from x * scale + shift
     if constexpr (BNB) {
 #pragma unroll
         for (int e = 0; e < CE; ++e) {
             const int c = cbase + e;
             bmu[e] = c < p.Cout ? p.bnb_mean[c] : 0.f;
             bis[e] = c < p.Cout ? p.bnb_invstd[c] : 0.f;
+            bsc[e] = (bnb_lazy && c < p.Cout) ? p.bnb_scale[c] : 0.f;
+            bsh[e] = (bnb_lazy && c < p.Cout) ? p.bnb_shift[c] : 1.f;
         }
     }
     if (full_vec) {                                    // vector loads, in flight under the LDS tile write below
@@ -236,6 +240,9 @@ __device__ __forceinline__ void tile_epilogue_impl(const mg_conv_params& p, f32x
                 if (byb) {
 #pragma unroll
                     for (int e = 0; e < CE; ++e) v[k][e] = byv[e] > 0.f ? v[k][e] : v[k][e] * bsl;
+                } else if (bnb_lazy) {
+#pragma unroll
+                    for (int e = 0; e < CE; ++e) v[k][e] = (bxv[e] * bsc[e] + bsh[e]) > 0.f ? v[k][e] : v[k][e] * bsl;
                 }
             }
             const uint4 packed = TR::pack(v[k]);               // rounded once; the statistics are those of the rounded values
@@ -826,6 +833,13 @@ __global__ __launch_bounds__(256) void igemm_fprop_async_persistent_kernel(const
 // LDS image of the halo: [TH+2][24 pixels][64 B] (pitch 24 px so that the bank swizzle slot = chunk ^ 2*((pixel>>2)&1) depends on
 // x + kx only), weights per tap [64 rows][64 B] swizzled as in the im2col ring. NS = 3 stages in flight, one barrier per stage.
 // =====================================================================================================================
+template <int... Ks, typename F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, Ks...>, F&& f) { (f(std::integral_constant<int, Ks>{}), ...); }
+
+#ifndef MG_HALO_ROW_SLIDE
+#define MG_HALO_ROW_SLIDE 1              // 0: the per-tap walk (9 * (FM + FN) LDS reads per stage) -- kept for A/B builds of the halo kernels (-DMG_HALO_ROW_SLIDE=0)
+#endif
+
 template <int TH, int BN, int NS> struct HaloCfg {
     static constexpr int TW = 16, BM = TH * TW, PW = 24, HH = TH + 2;
     static constexpr int A_INSTR = (HH * PW + 15) / 16, A_PER_WAVE = (A_INSTR + 3) / 4, A_BYTES = A_PER_WAVE * 4 * 1024;
@@ -990,6 +1004,68 @@ __device__ __forceinline__ void igemm_fprop_halo_tile(const mg_conv_params& p, i
         }
         if (s < 6) MG_STAMP(3 + 2 * s);
         const unsigned sb = lds_base + (unsigned)((s % NS) * STAGE);
+        // Row-sliding tap walk (round 5). The tap loop below it (kept for A/B builds) reads FM A fragments + FN B fragments per tap: 9 * (FM + FN)
+        // ds_read_b128 per stage and wave -- with 32-wide tiles (FN = 1) 45 KiB for 36 MFMAs, and the LDS read port (128 B / clk / CU, shared by
+        // the two co-resident workgroups) is then busy ~2.5x as long as the matrix pipe: the K loop is LDS-read-bound. But output row i under tap
+        // row ky reads the SAME halo row r = i + ky as output row i + 1 under ky - 1: a wave's FM output rows touch FM + 2 halo rows x 3 column
+        // shifts = 3 * (FM + 2) distinct A fragments, not 9 * FM. So: all nine weight fragments of the stage are loaded once into registers
+        // (9 * FN reads), the halo rows are walked top to bottom, each row's three fragments are read ONCE and feed every (output row, tap row)
+        // pair that meets them -- 9 * FN + 3 * (FM + 2) reads per stage (27 against 45 at FM = 4, FN = 1; 36 against 54 at FN = 2). The next halo
+        // row is in flight under the current row's MFMAs (counted lgkmcnt, as before).
+#if MG_HALO_ROW_SLIDE
+        // The walk is column-major: for column shift c = 0, 1, 2 the halo rows r = 0 .. FM + 1 stream through a three-deep fragment ring (two rows
+        // in flight under the current row's MFMAs) and meet the three weight fragments B(ky, c) of that column; B(0, c + 1) and B(1, c + 1) are
+        // loaded over their dead predecessors during the last two rows of column c, B(2, c) during row 0 -- one continuous stream of
+        // 3 * (FM + 2) + 9 * FN reads with compile-time lgkmcnt counts, 12 * FN + 12 fragment registers.
+        u32x4 rfb[3][FN], rfa[3];
+        constexpr int NR = FM + 2, NSTEP = 3 * NR;
+        const unsigned baddr = sb + b_lane;
+        auto tap_of = [](int ky, int c) { return MODE == MG_MODE_TCONV ? (2 - ky) * 3 + (2 - c) : ky * 3 + c; };
+        auto read_b = [&](auto ky_c, auto c_c) {
+            constexpr int KY = decltype(ky_c)::value, C_ = decltype(c_c)::value;
+            constexpr int TAP = MODE == MG_MODE_TCONV ? (2 - KY) * 3 + (2 - C_) : KY * 3 + C_;
+            u32x4(&rb)[FN] = rfb[KY];
+            const unsigned ba = baddr;
+            if constexpr (FN >= 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[0]) : "v"(ba), "n"(TAP * BN * 64 + 0 * 1024) : "memory");
+            if constexpr (FN >= 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[1]) : "v"(ba), "n"(TAP * BN * 64 + 1 * 1024) : "memory");
+        };
+        auto read_a = [&](auto k_c) {                             // halo row r under column shift c, stream position k = c * NR + r
+            constexpr int K_ = decltype(k_c)::value, C_ = K_ / NR, R_ = K_ % NR;
+            u32x4& ra = rfa[K_ % 3];
+            const unsigned aa = sb + a_lane[C_];
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ra) : "v"(aa), "n"(R_ * PW * 64) : "memory");
+        };
+        // weight fragments (FN reads each) issued at stream position k: B(0, c + 1) at r == FM, B(1, c + 1) at r == FM + 1, B(2, c) at r == 0 (c > 0)
+        auto nb_at = [](int k) { const int c = k / NR, r = k % NR; return k < 0 ? 0 : ((r == FM && c < 2) ? 1 : 0) + ((r == FM + 1 && c < 2) ? 1 : 0) + ((r == 0 && c > 0) ? 1 : 0); };
+        (void)tap_of;
+        read_b(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        read_b(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+        read_b(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+        read_a(std::integral_constant<int, 0>{});
+        read_a(std::integral_constant<int, 1>{});
+        auto step = [&](auto k_c) {
+            constexpr int K_ = decltype(k_c)::value, C_ = K_ / NR, R_ = K_ % NR;
+            if constexpr (R_ == FM && C_ < 2) read_b(std::integral_constant<int, 0>{}, std::integral_constant<int, C_ + 1>{});
+            if constexpr (R_ == FM + 1 && C_ < 2) read_b(std::integral_constant<int, 1>{}, std::integral_constant<int, C_ + 1>{});
+            if constexpr (R_ == 0 && C_ > 0) read_b(std::integral_constant<int, 2>{}, std::integral_constant<int, C_>{});
+            if constexpr (K_ + 2 < NSTEP) read_a(std::integral_constant<int, K_ + 2>{});
+            // everything up to A(K_) has landed once at most the reads issued after it are outstanding: the weight loads of positions K_ - 1 and
+            // K_ and the rows K_ + 1, K_ + 2 (in-order return)
+            constexpr int after = (nb_at(K_ - 1) + nb_at(K_)) * FN + (K_ + 1 < NSTEP ? 1 : 0) + (K_ + 2 < NSTEP ? 1 : 0);
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(after) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            u32x4& ra = rfa[K_ % 3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int i = R_ - ky;                           // the output row that meets halo row R_ under tap row ky
+                if (i >= 0 && i < FM) {
+#pragma unroll
+                    for (int jj = 0; jj < FN; ++jj) acc[i][jj] = mfma16<T>(ra, rfb[ky][jj], acc[i][jj]);
+                }
+            }
+        };
+        static_for(std::make_integer_sequence<int, NSTEP>{}, step);
+#else
         u32x4 fa[2][FM], fb[2][FN];
         // taps are software-pipelined: the reads of tap t + 1 are issued before the MFMAs of tap t (fragment row i of the wave sits
         // i halo rows further down: a literal offset)
@@ -1027,6 +1103,7 @@ __device__ __forceinline__ void igemm_fprop_halo_tile(const mg_conv_params& p, i
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         mma_tap(I0{});
+#endif
     }
     MG_STAMP(14);
     __syncthreads();
@@ -1341,8 +1418,10 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const mg_conv_params
 #pragma unroll
                 for (int e = 0; e < CE; ++e) {
                     const bool ok = cbase + e < p.Cout;
-                    bxv[e] = ok ? (TR::ld(bxb + (long)m * p.bnb_ld + cbase + e) - p.bnb_mean[cbase + e]) * p.bnb_invstd[cbase + e] : 0.f;
+                    const float bx_ = ok ? TR::ld(bxb + (long)m * p.bnb_ld + cbase + e) : 0.f;
+                    bxv[e] = ok ? (bx_ - p.bnb_mean[cbase + e]) * p.bnb_invstd[cbase + e] : 0.f;
                     if (byb && ok && !(TR::ld(byb + (long)m * p.bnb_ld + cbase + e) > 0.f)) v[e] *= bsl;
+                    else if (!byb && p.bnb_scale && ok && !(bx_ * p.bnb_scale[cbase + e] + p.bnb_shift[cbase + e] > 0.f)) v[e] *= bsl;
                 }
             }
             const uint4 packed = TR::pack(v);                  // rounded once; the statistics are those of the rounded values

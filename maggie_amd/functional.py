@@ -592,6 +592,13 @@ BN_SMALL_ROWS = int(_os.environ.get('MG_BN_SMALL_ROWS', '1024'))     # layers up
 # data-gradient epilogues (+0.17 ms over 30 launches: two more HBM tiles per output tile at one workgroup per CU) and the replica reduction
 # in front of the apply pass (+0.3 ms) -- 13.42 / 13.60 ms with the link against 13.43 / 13.44 ms without. Kept for the tests and as the
 # starting point of a register-staged variant; MAGGIE_BN_LINK=1 switches it on.
+# Round 5: re-built in a deterministic form and measured again. The epilogue's sums arrive as one row per output tile (mg_conv_stat_rows); ONE
+# ordered-sum launch (mg_stat_rows_sum -- the launch that follows bn_bwd_reduce anyway) folds them into [2C] and the apply pass reads that single
+# row, so the bn_bwd_reduce kernel (10 us, three tensor reads) is gone for every linked layer; operand-path layers (LazyAct) link too, their
+# activation mask re-formed from x * scale + shift inside the epilogue (mg_conv_params.bnb_scale / bnb_shift: only the raw x tile is loaded).
+# Same-lease A/B, 2 x 150 steps each: 11.22 / 11.25 ms linked against 11.18 / 11.11 ms unlinked -- the data-gradient kernels are bound by their
+# prologue / epilogue latency at this batch size, and a longer epilogue costs what the removed launch saved. Still off by default; parity-tested
+# both ways (tests/test_gpu_kernels.py, tests/test_gpu_determinism.py run with either setting).
 BN_LINK = _os.environ.get('MAGGIE_BN_LINK', '0') != '0'
 
 
@@ -603,11 +610,11 @@ class BnLink:
     the layer's two reductions (sum g, sum g * xhat) itself (mg_conv_params.bnb_*), so only the apply pass is left: 59 launches and ~1.5 GB of
     reads per step gone. The producer (`conv_bn_act(..., link_out=True)`) promises that z has no other consumer than one conv2d / conv_bn_act
     call (a skip connection taken back through that conv's `carry` output is fine: its gradient is added inside the same epilogue)."""
-    __slots__ = ('x2', 'y', 'pack', 'act', 'C', 'M', 'consumers', 'sums', 'g')
+    __slots__ = ('x2', 'y', 'pack', 'act', 'C', 'M', 'consumers', 'sums', 'g', 'lazy')
 
     def __init__(self):
         self.x2 = self.y = self.pack = self.sums = self.g = None
-        self.act, self.C, self.M, self.consumers = ACT_NONE, 0, 0, 0
+        self.act, self.C, self.M, self.consumers, self.lazy = ACT_NONE, 0, 0, 0, False
 
     def ready(self):
         return self.x2 is not None and self.consumers == 1
@@ -642,10 +649,10 @@ class _Materialize(torch.autograd.Function):
 class LazyAct:
     """A training BatchNorm(+activation) output that was never stored: `t` (the raw conv output, carrying the autograd edge into BNLazy) and the
     transform act(t * scale + shift). Gradients sent back through `t` are gradients with respect to the NORMALISED activation."""
-    __slots__ = ('t', 'scale', 'shift', 'act', 'slope', '_z')
+    __slots__ = ('t', 'scale', 'shift', 'act', 'slope', '_z', 'link')
 
-    def __init__(self, t, scale, shift, act, slope):
-        self.t, self.scale, self.shift, self.act, self.slope, self._z = t, scale, shift, act, slope, None
+    def __init__(self, t, scale, shift, act, slope, link=None):
+        self.t, self.scale, self.shift, self.act, self.slope, self._z, self.link = t, scale, shift, act, slope, None, link
 
     shape = property(lambda self: self.t.shape)
     dtype = property(lambda self: self.t.dtype)
@@ -658,13 +665,21 @@ class LazyAct:
         return self._z
 
 
+def _linked_sums(rows):
+    """Backward sums a data-gradient epilogue left as rows [nrow][2C] -> what the apply pass reads: the rows themselves while they are the few
+    replicas of the atomic mode, ONE row after the ordered sum (deterministic mode: one row per output tile, up to tens of thousands)."""
+    if rows.dim() == 2 and rows.shape[0] > K.STAT_REPLICAS:
+        return K.stat_rows_sum(rows).view(1, -1)
+    return rows
+
+
 class BNLazy(torch.autograd.Function):
     """Training BatchNorm whose apply pass is left to the consumer: batch statistics -> (scale, shift, mean, invstd) + running-stat update, ONE
     launch (mg_bn_finalize over the rows the producing conv's epilogue filled). Returns (alias of x, scale, shift). Backward receives dz -- the
     gradient with respect to act(BN(x)) -- and runs the ordinary reduce + apply pair with the activation mask re-formed from x."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, act, stats, mask_x_pos):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, act, stats, mask_x_pos, link=None):
         C = x.shape[-1]
         x2 = x.contiguous().view(-1, C)
         M = x2.shape[0]
@@ -677,6 +692,11 @@ class BNLazy(torch.autograd.Function):
         pack = sc._base if sc._base is not None else torch.cat([sc, sh, mean, invstd])       # (4, C) = scale | shift | mean | invstd
         ctx.save_for_backward(x2, pack)
         ctx.meta = (x.shape, M, C, act, mask_x_pos)
+        ctx.link = None
+        if link is not None and (C * x2.element_size()) % 16 == 0 and ((C * x2.element_size()) // 16 & ((C * x2.element_size()) // 16 - 1)) == 0:
+            # the consumer's data-gradient epilogue may produce g = dz * act' and this layer's two backward sums (BnLink, lazy form)
+            link.x2, link.y, link.pack, link.act, link.C, link.M, link.lazy = x2, None, pack.view(-1), act, C, M, True
+            ctx.link = link
         ctx.mark_non_differentiable(sc, sh)
         ctx.set_materialize_grads(False)                          # (else autograd fills a zero gradient for scale and shift on every backward: two launches per layer)
         return x.view_as(x), sc, sh
@@ -685,11 +705,19 @@ class BNLazy(torch.autograd.Function):
     def backward(ctx, dz, _dsc, _dsh):
         x2, pack = ctx.saved_tensors
         shape, M, C, act, mask_x_pos = ctx.meta
+        link, ctx.link = ctx.link, None
         if dz is None:
-            return (None,) * 10
+            return (None,) * 11
+        if link is not None and link.g is not None and link.sums is not None and link.g.data_ptr() == dz.data_ptr() and dz.is_contiguous():
+            # the consumer conv's data-gradient epilogue already wrote g = dz * act'(z) (into `dz`) and one row of the two sums per output tile
+            dx, sums = K.bn_bwd_apply_linked(dz.view(-1, C), x2, pack.view(-1), _linked_sums(link.sums), M, mask_x_pos)
+            link.clear()
+            return dx.view(shape), sums[C:], sums[:C], None, None, None, None, None, None, None, None
+        if link is not None:
+            link.clear()
         sums = ARENA.take(2 * C, dz.device) if torch.cuda.is_current_stream_capturing() else None
         dx, _, sums = K.bn_train_bwd(rows_of(dz, C), None, x2, pack.view(-1), act, LRELU_SLOPE, False, mask_x_pos, sums)
-        return dx.view(shape), sums[C:], sums[:C], None, None, None, None, None, None, None
+        return dx.view(shape), sums[C:], sums[:C], None, None, None, None, None, None, None, None
 
 
 def lazy_bn_ok(x, bn, res, res2):
@@ -756,7 +784,10 @@ class ConvRaw(torch.autograd.Function):
                 Cb = link.C
                 nrow = K.conv_stat_rows(N * H * W_, N, H, W_)       # one row per output tile in deterministic mode, else 32 replicas
                 sums_rep = ARENA.take(nrow * 2 * Cb, dy2.device).view(nrow, 2 * Cb)
-                bnb = (link.y if link.act != ACT_NONE else None, link.x2, link.pack[2 * Cb:3 * Cb], link.pack[3 * Cb:4 * Cb], link.act)
+                if link.lazy:                                   # the layer never stored its activation output: mask from x * scale + shift
+                    bnb = (None, link.x2, link.pack[2 * Cb:3 * Cb], link.pack[3 * Cb:4 * Cb], link.act, link.pack[:Cb], link.pack[Cb:2 * Cb])
+                else:
+                    bnb = (link.y if link.act != ACT_NONE else None, link.x2, link.pack[2 * Cb:3 * Cb], link.pack[3 * Cb:4 * Cb], link.act)
             dx = K.conv_fprop(dy2, wt, mode=dmode, N=N, Hin=Ho, Win=Wo, Hout=H, Wout=W_, R=R, S=S, stride=stride, pad=pad,
                               dil=dil, alg_cout=ctx.cin_real, res2=r2, stats=sums_rep, bnb=bnb, slope=LRELU_SLOPE).view(N, H, W_, Cin)
             if bnb is not None:
@@ -795,7 +826,9 @@ def conv2d(x, w, bias=None, R=3, S=3, stride=1, pad=1, dil=1, transposed=False, 
             K.conv_xform_ok(x.dtype, N_, H_, W__, Cin_, w.shape[0], R, S, stride, pad, dil, 0) and \
             (not w.requires_grad or K.conv_xform_ok(x.dtype, N_, H_, W__, Cin_, w.shape[0], R, S, stride, pad, dil, 1))
         if ok:
-            xf, x = (x.scale, x.shift, x.act, x.slope), x.t
+            xf, lz, x = (x.scale, x.shift, x.act, x.slope), x, x.t
+            if lz.link is not None:
+                x._mg_bnlink = lz.link
         else:
             x = x.materialize()
     link = getattr(x, '_mg_bnlink', None) if (BN_LINK and torch.is_grad_enabled()) else None
@@ -935,7 +968,7 @@ class BNAct(torch.autograd.Function):
             link = ctx.link
             if link is not None and link.g is not None and link.sums is not None and link.g.data_ptr() == dy.data_ptr() and dy.is_contiguous():
                 # the consumer conv's data-gradient epilogue already produced g = dy * act'(y) (in `dy`) and the two reductions
-                dx, sums = K.bn_bwd_apply_linked(dy.view(-1, C), x2, pack, link.sums, M, mask_x_pos)
+                dx, sums = K.bn_bwd_apply_linked(dy.view(-1, C), x2, pack, _linked_sums(link.sums), M, mask_x_pos)
                 dres = dy.view(-1, C) if has_res else None
                 link.clear()
                 if has_res:
@@ -1059,8 +1092,9 @@ def conv_bn_act(x, w, bn, act=ACT_NONE, R=3, S=3, stride=1, pad=1, dil=1, transp
             else:
                 bn.num_batches_tracked.add_(1)
         a = ACT_NONE if relu_before_bn else act
-        t, sc, sh = BNLazy.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, 0.1 if bn.momentum is None else bn.momentum, bn.eps, a, stats, mask_up)
-        lz = LazyAct(t, sc, sh, a, LRELU_SLOPE)
+        lk = BnLink() if BN_LINK else None
+        t, sc, sh = BNLazy.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, 0.1 if bn.momentum is None else bn.momentum, bn.eps, a, stats, mask_up, lk)
+        lz = LazyAct(t, sc, sh, a, LRELU_SLOPE, lk if (lk is not None and lk.x2 is not None) else None)
         return (lz, x if xc is None else xc) if carry else lz
     link = BnLink() if (link_out and BN_LINK and bn.training and res2 is None and torch.is_grad_enabled()) else None
     y = batch_norm_act(y, bn, ACT_NONE if relu_before_bn else act, res=res, stats=stats, res_mode=res_mode, mask_x_pos=mask_up, link=link,

@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmaggie_hip.so')
+LIB_PATH = os.environ.get('MAGGIE_LIB_PATH') or os.path.join(_HERE, 'libmaggie_hip.so')      # (MAGGIE_LIB_PATH: an A/B build of the same ABI, tools/build_variant.sh)
 _LIB = None
 # Bit-reproducible steps (default): the reference runs with torch.backends.cudnn.deterministic = True (tools/main.py:135-136). Every cross-workgroup
 # fp32 sum of the library then runs as "one partial per workgroup, added in index order" instead of atomicAdd (csrc/det.hip). MAGGIE_DETERMINISTIC=0
@@ -48,6 +48,7 @@ class ConvParams(ctypes.Structure):
         ('bnb_act', ctypes.c_int32), ('bnb_ld', ctypes.c_int32),
         ('stat_rep', ctypes.c_int32), ('reserved0', ctypes.c_int32),
         ('xf_scale', ctypes.c_void_p), ('xf_shift', ctypes.c_void_p), ('xf_act', ctypes.c_int32), ('xf_slope', ctypes.c_float),
+        ('bnb_scale', ctypes.c_void_p), ('bnb_shift', ctypes.c_void_p),
     ]
 
 

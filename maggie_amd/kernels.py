@@ -115,12 +115,15 @@ def conv_fprop(x, w, *, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=None, Wout=None,
     if bnb is not None:
         # this launch produces the gradient at the OUTPUT of a training BatchNorm layer: its epilogue writes g = dz * act'(z) and accumulates
         # that layer's backward sums into `stats` (replicated layout) -- bnb = (z | None, x, mean, invstd, act), rows x Cout like `out`
-        bz, bx, bmean, binv, bact = bnb
+        # (+ scale, shift: the layer never stored z -- operand-path BatchNorm -- and the mask is re-formed from x * scale + shift)
+        bz, bx, bmean, binv, bact = bnb[:5]
+        bsc, bsh = (bnb[5], bnb[6]) if len(bnb) > 5 else (None, None)
         assert stats is not None and stat_mode == 0 and bx.dtype == x.dtype and bx.shape[-1] == Cout and _ld(bx) == Cout
         assert bz is None or (bz.dtype == x.dtype and _ld(bz) == Cout)
-        hip.need_cuda(bx, bmean, binv)
+        hip.need_cuda(bx, bmean, binv, bsc, bsh)
         p.bnb_y, p.bnb_x, p.bnb_mean, p.bnb_invstd = hip.ptr(bz), hip.ptr(bx), hip.ptr(bmean), hip.ptr(binv)
         p.bnb_act, p.bnb_ld = bact, Cout
+        p.bnb_scale, p.bnb_shift = hip.ptr(bsc), hip.ptr(bsh)
     # bench accounting: `work` = ALGORITHMIC FLOPs -- the taps that exist (a stride-s transposed / data-gradient conv touches
     # R*S/s^2 taps per output row on average; the rest of what MG_MODE_TCONV multiplies are structural zeros) and the real, unpadded
     # channel counts; the executed FLOPs ride along in the tag. A device row count (sparse head) makes the work unknown here: None.
@@ -207,12 +210,15 @@ def sum_k(ts):
     return out
 
 
+COPY_K = __import__('os').environ.get('MAGGIE_COPY_K', '1') != '0'      # 0: torch._foreach_copy_ (one copy kernel per tensor) -- A/B switch
+
+
 def copy_k(dsts, srcs):
     """dst.copy_(src) for lists of device tensors, 16 per launch (mg_copy_k); pairs that are not plain byte copies (different dtype / shape, a
     non-contiguous side) go through torch._foreach_copy_."""
     plain, rest_d, rest_s = [], [], []
     for d, s_ in zip(dsts, srcs):
-        if d.dtype == s_.dtype and d.shape == s_.shape and d.is_contiguous() and s_.is_contiguous() and d.is_cuda and s_.is_cuda:
+        if COPY_K and d.dtype == s_.dtype and d.shape == s_.shape and d.is_contiguous() and s_.is_contiguous() and d.is_cuda and s_.is_cuda:
             if d.numel() and d.data_ptr() != s_.data_ptr():
                 plain.append((d, s_))
         else:
@@ -309,7 +315,7 @@ def stat_rows_sum(stats):
     if stats.dim() == 1:
         return stats
     nrep, n = stats.shape
-    out = torch.empty(n, dtype=torch.float32, device=stats.device)
+    out = ACC(n, stats.device)                 # cleared by the callee; inside a capture a slice of the graph's zero arena (no fill launch)
     hip.need_cuda(stats)
     hip.call('mg_stat_rows_sum', hip.ptr(stats.contiguous()), c_int(nrep), c_int(n), hip.ptr(out), hip.stream())
     return out
