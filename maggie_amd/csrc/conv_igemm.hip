@@ -945,7 +945,19 @@ __device__ __forceinline__ void igemm_fprop_halo_tile(const mg_conv_params& p, i
     [[maybe_unused]] const unsigned xf_tab = lds_base + (unsigned)HC::LDS;            // [Cin] scale | [Cin] shift, fp32
     [[maybe_unused]] const float xf_sl = xf_slope_of(p.xf_act, p.xf_slope);
     [[maybe_unused]] const int xf_ach = (lane & 3) ^ (((lane >> 4) & 1) * 2);         // the 8-channel group of a slab this lane's halo chunks hold
-    if constexpr (XF) {
+    // Single-stage forms (NS == 1: Cin 32 / 64, the large high-resolution layers): a lane's halo chunks always hold the same 8-channel group, and
+    // there are at most two slabs -- its 2 x 16 constants sit in registers (loaded before the first LDS-DMA instruction; in-order return: the
+    // stage's vmcnt(0) covers them), no LDS table, no extra barrier. (The table form cost the 512 x 512 C32 layer +9 us: nine-tap MFMA work of
+    // a one-slab tile is as short as the table detour.)
+    [[maybe_unused]] float xr_sc[2][8], xr_sh[2][8];
+    if constexpr (XF && NS == 1) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c0 = (q < nstage ? q : 0) * EPS + xf_ach * 8;
+            *(float4*)&xr_sc[q][0] = *(const float4*)(p.xf_scale + c0); *(float4*)&xr_sc[q][4] = *(const float4*)(p.xf_scale + c0 + 4);
+            *(float4*)&xr_sh[q][0] = *(const float4*)(p.xf_shift + c0); *(float4*)&xr_sh[q][4] = *(const float4*)(p.xf_shift + c0 + 4);
+        }
+    } else if constexpr (XF) {
         if (t * 4 < 2 * p.Cin) xf_reg = *(const u32x4*)(t * 4 < p.Cin ? p.xf_scale + t * 4 : p.xf_shift + (t * 4 - p.Cin));
     }
     MG_STAMP(0);
@@ -954,6 +966,24 @@ __device__ __forceinline__ void igemm_fprop_halo_tile(const mg_conv_params& p, i
         if (u < nstage) issue_stage(u, u);
     MG_STAMP(1);
     [[maybe_unused]] auto xf_stage = [&](int s) {
+        if constexpr (NS == 1) {
+            const unsigned sb = lds_base;
+            u32x4 q[HC::A_PER_WAVE];
+#pragma unroll
+            for (int i = 0; i < HC::A_PER_WAVE; ++i)
+                asm volatile("ds_read_b128 %0, %1" : "=v"(q[i]) : "v"(sb + (unsigned)((wave + 4 * i) * 1024 + lane * 16)) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < HC::A_PER_WAVE; ++i) {
+                if (asrc[i]) {
+                    const uint4 r = s == 0 ? xf_apply8<T>(__builtin_bit_cast(uint4, q[i]), xr_sc[0], xr_sh[0], xf_sl)
+                                           : xf_apply8<T>(__builtin_bit_cast(uint4, q[i]), xr_sc[1], xr_sh[1], xf_sl);
+                    asm volatile("ds_write_b128 %0, %1" ::"v"(sb + (unsigned)((wave + 4 * i) * 1024 + lane * 16)), "v"(__builtin_bit_cast(u32x4, r)) : "memory");
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            return;
+        }
         if (s == 0) {                                        // the table: every wave's share must be in LDS before anyone transforms
             if (t * 4 < 2 * p.Cin) asm volatile("ds_write_b128 %0, %1" ::"v"(xf_tab + (unsigned)t * 16u), "v"(xf_reg) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -4,17 +4,20 @@
 TAG=${1:-rXX}
 mkdir -p gpurun_out/$TAG
 python -m pytest tests -m gpu -x -q -p no:cacheprovider --timeout 1500 2>&1 | tail -40 > gpurun_out/$TAG/pytest_x.txt
-python bench.py > gpurun_out/$TAG/bench_default.json 2> gpurun_out/$TAG/bench_default.err
+python bench.py --cpu-baseline-full > gpurun_out/$TAG/bench_default.json 2> gpurun_out/$TAG/bench_default.err
 B="--steps 60 --warmup 10 --no-cpu-baseline"
 python bench.py $B --video > gpurun_out/$TAG/bench_video.json 2>/dev/null
 python bench.py $B --instances 4 > gpurun_out/$TAG/bench_4inst.json 2>/dev/null
 python bench.py $B --dtype fp16 > gpurun_out/$TAG/bench_fp16.json 2>/dev/null
-python bench.py $B --batch 12 > gpurun_out/$TAG/bench_batch12.json 2>/dev/null
+MAGGIE_MEM_FRACTION=0.92 python bench.py $B --batch 12 > gpurun_out/$TAG/bench_batch12_full.json 2>/dev/null                      # maggie_image.yaml:83, sparse capacity 1.0
+MAGGIE_MEM_FRACTION=0.92 MAGGIE_SPARSE_CAPACITY=0.4 python bench.py $B --video --frames 8 --clips 4 > gpurun_out/$TAG/bench_video_t8.json 2>/dev/null   # maggie_video.yaml:32,89
+python bench.py $B --workload pred > gpurun_out/$TAG/bench_pred.json 2>/dev/null                                                   # iter = 10000
+MAGGIE_LAZY_BN=0 python bench.py $B > gpurun_out/$TAG/bench_stored_bn.json 2>/dev/null                                              # the stored BatchNorm form (A/B of the operand path)
 MAGGIE_FORCE_DDP=1 python bench.py $B > gpurun_out/$TAG/bench_force_ddp.json 2>/dev/null
 MAGGIE_SYNCBN_WORLD1=1 MAGGIE_FORCE_DDP=1 python bench.py $B --sync-bn > gpurun_out/$TAG/bench_syncbn_default.json 2>/dev/null
 MAGGIE_DETERMINISTIC=0 python bench.py $B > gpurun_out/$TAG/bench_nondet.json 2>/dev/null
 bash tools/profile_round.sh $TAG > gpurun_out/$TAG/profile.log 2>&1
 grep -n "passed\|failed" gpurun_out/$TAG/pytest_x.txt
-for f in default video 4inst fp16 batch12 force_ddp syncbn_default nondet; do python -c "
+for f in default video 4inst fp16 batch12_full video_t8 pred stored_bn force_ddp syncbn_default nondet; do python -c "
 import json,sys
 d=json.loads([l for l in open('gpurun_out/$TAG/bench_$f.json') if l.startswith('{')][-1]); print('$f', d['value'], d['ms_per_step'], (d.get('roofline') or {}).get('frac'))"; done

@@ -13,3 +13,4 @@ head -1 $f > $root/gpurun_out/${tag}_csv_header.txt
 python $root/tools/trace_summary.py $f 10 $ms 80 --torch > $root/gpurun_out/${tag}_trace_summary.txt
 python $root/tools/trace_neighbours.py $f $ms > $root/gpurun_out/${tag}_neighbours.txt
 echo "ms_per_step (traced) $ms"
+python $root/tools/step_kernels.py $f $ms > $root/gpurun_out/${tag}_step_kernels.txt
