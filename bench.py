@@ -286,7 +286,7 @@ def main():
         # HBM-side traffic of the dominant family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
         # corrected per MI355X_MICROARCH.md; tools/pmc_traffic.py) -- only for the configuration they were collected on
         traffic, traffic_src = None, None
-        for cand in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic_final_eager.json'):
+        for cand in ('r05_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic_final_eager.json'):
             pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', cand)
             if os.path.isfile(pmc_path) and not args.video and args.size == 512 and args.batch == 4 and use_bf16:
                 traffic = json.load(open(pmc_path)).get('igemm_fprop', {}).get('hbm_bytes_per_launch')

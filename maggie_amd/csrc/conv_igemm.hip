@@ -317,7 +317,11 @@ __device__ __forceinline__ void tile_epilogue(const mg_conv_params& p, f32x4 (&a
 // raw fp32 partial tile to its own slab of `ws` ([splits][M][Cout]); splitk_finish_kernel sums the slabs and applies the epilogue.
 // These layers could only fill the chip with 64x32 tiles (21 FLOP per byte staged through L2/LDS: ~100-220 TFLOP/s whatever the
 // shape); with the K split, 128x128 tiles (64 FLOP/B) reach the same block count.
-template <typename T, int BM, int BN, int KS, int MODE, bool SPLIT = false, bool BNB = false>
+// XF (round 5, the sparse head's BatchNorm1d layers on the operand path): x is the RAW output of the producing convolution; the in-image /
+// live-neighbour chunks are transformed -- act(x * xf_scale + xf_shift), rounded to T -- between the staging registers and LDS (missing
+// neighbours and rows beyond the live count stay 0). Channel-aligned layers with Cin <= 64 only: a thread's chunk column is fixed, so its
+// constants are one or two sets of 16 registers (slab parity).
+template <typename T, int BM, int BN, int KS, int MODE, bool SPLIT = false, bool BNB = false, bool XF = false>
 __device__ __forceinline__ void igemm_fprop_tile(const mg_conv_params& p, const int M, int work, float* __restrict__ ws, int splits, char* smem) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE, EPS = TR::EPS;
@@ -390,6 +394,18 @@ __device__ __forceinline__ void igemm_fprop_tile(const mg_conv_params& p, const 
     // register prefetch depth: PF stages of loads in flight per thread
     constexpr int PF = 1;           // measured (PMC): waves are parked ~40% / issuing ~40% per stage; deeper prefetch only costs registers
     uint4 ra[PF][KS][A_ROWS], rb[PF][KS][B_ITERS];
+    [[maybe_unused]] float xsc[2][8], xsh[2][8];
+    [[maybe_unused]] unsigned xlive[PF] = {}, xsub[PF] = {};         // per staged chunk: bit (j * A_ROWS + i) = live, bit j = which constant set
+    [[maybe_unused]] const float xsl = xf_slope_of(p.xf_act, p.xf_slope);
+    if constexpr (XF) {
+        static_assert(sizeof(T) == 2 && KS * A_ROWS <= 32, "operand transform: 16-bit storage");
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int c0 = (q * EPS < p.Cin ? q * EPS : 0) + (t & 3) * CE;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xsc[q][e] = p.xf_scale[c0 + e]; xsh[q][e] = p.xf_shift[c0 + e]; }
+        }
+    }
     const int invS = (65536 + p.S - 1) / p.S;                       // tap / S == (tap * invS) >> 16 for tap < 256
     const int sshift = p.stride == 1 ? 0 : (p.stride == 2 ? 1 : (p.stride == 4 ? 2 : -1));
 
@@ -491,9 +507,12 @@ __device__ __forceinline__ void igemm_fprop_tile(const mg_conv_params& p, const 
                 } else {
                     if (rc[i].ok && live) src = p.nbr[(long)rbase[i] + tap_g];
                 }
-                if (src >= 0 && rc[i].ok && live) ra[u][j][i] = *(const uint4*)(xb + src * ((long)p.ldx * (long)sizeof(T)) + coff);
+                const bool have = src >= 0 && rc[i].ok && live;
+                if (have) ra[u][j][i] = *(const uint4*)(xb + src * ((long)p.ldx * (long)sizeof(T)) + coff);
                 else ra[u][j][i] = make_uint4(0, 0, 0, 0);
+                if constexpr (XF) xlive[u] = have ? (xlive[u] | (1u << (j * A_ROWS + i))) : (xlive[u] & ~(1u << (j * A_ROWS + i)));
             }
+            if constexpr (XF) xsub[u] = (q_sub & 1) ? (xsub[u] | (1u << j)) : (xsub[u] & ~(1u << j));
             const long boff = ph ? ((long)(q_ky * p.S + q_kx) * p.Cin + (long)q_sub * EPS) * (long)sizeof(T) : (long)q_slab * EPS * (long)sizeof(T);
 #pragma unroll
             for (int i = 0; i < B_ITERS; ++i) {
@@ -510,8 +529,13 @@ __device__ __forceinline__ void igemm_fprop_tile(const mg_conv_params& p, const 
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
 #pragma unroll
-            for (int i = 0; i < A_ROWS; ++i)
+            for (int i = 0; i < A_ROWS; ++i) {
+                if constexpr (XF) {
+                    if (xlive[u] & (1u << (j * A_ROWS + i)))
+                        ra[u][j][i] = (xsub[u] & (1u << j)) ? xf_apply8<T>(ra[u][j][i], xsc[1], xsh[1], xsl) : xf_apply8<T>(ra[u][j][i], xsc[0], xsh[0], xsl);
+                }
                 *(uint4*)(sA + ((t >> 2) + i * 64) * ROWB + j * 64 + a_c * 16) = ra[u][j][i];
+            }
 #pragma unroll
             for (int i = 0; i < B_ITERS; ++i) {
                 int idx = t + i * 256;
@@ -604,7 +628,7 @@ __global__ __launch_bounds__(256) void igemm_fprop_kernel(const mg_conv_params p
 
 // Persistent form for the sparse head (p.m_dev): the row count lives in a device word, the grid is fixed (a multiple of 8 workgroups,
 // a few per CU) and every workgroup walks tiles grid-stride in the same XCD-contiguous order. No host code depends on the count.
-template <typename T, int BM, int BN, int KS, int MODE>
+template <typename T, int BM, int BN, int KS, int MODE, bool XF = false>
 __global__ __launch_bounds__(256) void igemm_fprop_persistent_kernel(const mg_conv_params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int M = dev_rows(p.m_dev, p.M);
@@ -613,7 +637,7 @@ __global__ __launch_bounds__(256) void igemm_fprop_persistent_kernel(const mg_co
     const int chunk = (L + NXCD - 1) / NXCD;
     for (int vb = blockIdx.x; vb / NXCD < chunk; vb += gridDim.x) {          // gridDim.x % 8 == 0: vb stays on this workgroup's XCD
         const int work = (vb % NXCD) * chunk + vb / NXCD;
-        if (work < L) igemm_fprop_tile<T, BM, BN, KS, MODE, false>(p, M, work, nullptr, 1, smem);
+        if (work < L) igemm_fprop_tile<T, BM, BN, KS, MODE, false, false, XF>(p, M, work, nullptr, 1, smem);
         __syncthreads();                                                      // the next tile's staging reuses the epilogue's LDS
     }
 }
@@ -1297,6 +1321,13 @@ static int dispatch_fprop_async(const mg_conv_params& p, hipStream_t st) {
     return ns_small >= 4 ? launch_fprop_async<T, 64, 64, 2, 4>(p, st) : launch_fprop_async<T, 64, 64, 2, 3>(p, st);
 }
 
+// operand transform in the register-staged persistent form (the sparse head's row matrices: device row count, gather 3x3 or 1x1, Cin 32 / 64,
+// Cout <= 32 -- wider outputs run the direct-to-LDS ring, which cannot transform in flight)
+static inline bool fprop_xf_rows_ok(const mg_conv_params& p) {
+    return MG_IS16(p.dtype) && p.m_dev && (p.mode == MG_MODE_GATHER || (p.mode == MG_MODE_CONV && p.R * p.S == 1 && p.stride == 1 && p.pad == 0)) &&
+           (p.Cin == 32 || p.Cin == 64) && p.Cout <= 32 && p.ldx % 8 == 0;
+}
+
 template <typename T, int BM, int BN, int KS>
 int launch_fprop(const mg_conv_params& p, hipStream_t st) {
     dim3 grid(xcd_grid(row_tiles(p, p.M, BM) * ((p.Cout + BN - 1) / BN)));
@@ -1330,12 +1361,22 @@ int launch_fprop(const mg_conv_params& p, hipStream_t st) {
             hipFuncSetAttribute((const void*)igemm_fprop_persistent_kernel<T, BM, BN, KS, MG_MODE_GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set_p = true;
         }
+        if (p.xf_scale) {                                    // sparse head: BatchNorm1d + activation of the producing layer applied on the operand's way into LDS
+            if constexpr (sizeof(T) == 2 && BM == 128 && BN <= 32 && KS <= 2) {
+                if (!fprop_xf_rows_ok(p)) return MG_XF_UNSUPPORTED;
+                if (p.mode == MG_MODE_CONV) hipLaunchKernelGGL((igemm_fprop_persistent_kernel<T, BM, BN, KS, MG_MODE_CONV, true>), pg, dim3(256), lds, st, p);
+                else hipLaunchKernelGGL((igemm_fprop_persistent_kernel<T, BM, BN, KS, MG_MODE_GATHER, true>), pg, dim3(256), lds, st, p);
+                MG_CHECK_LAUNCH();
+                return 0;
+            } else return MG_XF_UNSUPPORTED;
+        }
         if (p.mode == MG_MODE_CONV) hipLaunchKernelGGL((igemm_fprop_persistent_kernel<T, BM, BN, KS, MG_MODE_CONV>), pg, dim3(256), lds, st, p);
         else if (p.mode == MG_MODE_GATHER) hipLaunchKernelGGL((igemm_fprop_persistent_kernel<T, BM, BN, KS, MG_MODE_GATHER>), pg, dim3(256), lds, st, p);
         else return -2;
         MG_CHECK_LAUNCH();
         return 0;
     }
+    if (p.xf_scale) return MG_XF_UNSUPPORTED;
     switch (p.mode) {
         case MG_MODE_CONV: hipLaunchKernelGGL((igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_CONV>), grid, dim3(256), lds, st, p, (float*)nullptr, 1); break;
         case MG_MODE_TCONV: hipLaunchKernelGGL((igemm_fprop_kernel<T, BM, BN, KS, MG_MODE_TCONV>), grid, dim3(256), lds, st, p, (float*)nullptr, 1); break;
@@ -1653,7 +1694,13 @@ static inline bool fprop_xf_ok(const mg_conv_params& p) {
 template <typename T>
 int dispatch_fprop(const mg_conv_params& p, hipStream_t st) {
     if (p.xf_scale) {
-        if constexpr (sizeof(T) == 2) { if (fprop_xf_ok(p)) return dispatch_fprop_halo<T>(p, st); }
+        if constexpr (sizeof(T) == 2) {
+            if (fprop_xf_ok(p)) return dispatch_fprop_halo<T>(p, st);
+            if (fprop_xf_rows_ok(p)) {                       // (the stage-width choice of the ordinary path below)
+                const int nsl = p.R * p.S * p.Cin / 32;
+                return nsl >= 8 ? dispatch_fprop_ks<T, 2>(p, st) : dispatch_fprop_ks<T, 1>(p, st);
+            }
+        }
         return MG_XF_UNSUPPORTED;
     }
     if constexpr (sizeof(T) == 2) {

@@ -22,7 +22,9 @@ namespace {
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
 
-template <typename T, int TCO, int TCI, int MODE>
+// XF (round 5): the x operand is a RAW conv output; act(x * xf_scale + xf_shift) is applied to the chunks that exist (in-image / live neighbour)
+// between the staging registers and LDS. A thread's x chunks share one channel group (256 % CPX == 0): 16 constants in registers.
+template <typename T, int TCO, int TCI, int MODE, bool XF = false>
 __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const mg_conv_params p, int rows_per_block, float* __restrict__ ws) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
@@ -73,6 +75,18 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const mg_conv_params p
     const bool yvec = (p.ldy % CE == 0) && (p.yoff % CE == 0);
 
     uint4 ry[ITY], rx[ITX];
+    [[maybe_unused]] float xsc[CE < 8 ? 8 : CE], xsh[CE < 8 ? 8 : CE];
+    [[maybe_unused]] unsigned xlive = 0;
+    [[maybe_unused]] const float xsl = xf_slope_of(p.xf_act, p.xf_slope);
+    if constexpr (XF) {
+        static_assert(BF && 256 % CPX == 0, "operand transform: 16-bit storage, one channel group per thread");
+        const int c = t % CPX;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ci = ci0 + c * CE + e;
+            xsc[e] = ci < p.Cin ? p.xf_scale[ci] : 0.f; xsh[e] = ci < p.Cin ? p.xf_shift[ci] : 0.f;
+        }
+    }
     auto load_step = [&](int mb) {
 #pragma unroll
         for (int i = 0; i < ITY; ++i) {
@@ -121,6 +135,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const mg_conv_params p
                 }
             }
             rx[i] = (src >= 0) ? *(const uint4*)(xb + src * p.ldx + ci) : make_uint4(0, 0, 0, 0);
+            if constexpr (XF) xlive = src >= 0 ? (xlive | (1u << i)) : (xlive & ~(1u << i));
         }
     };
     auto store_step = [&]() {
@@ -132,6 +147,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_kernel(const mg_conv_params p
 #pragma unroll
         for (int i = 0; i < ITX; ++i) {
             int idx = t + i * 256; int row = idx / CPX, c = idx - row * CPX;
+            if constexpr (XF) { if (xlive & (1u << i)) rx[i] = xf_apply8<T>(rx[i], xsc, xsh, xsl); }
             *(uint4*)(sX + row * PCI + c * CE) = rx[i];
         }
     };
@@ -496,7 +512,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_halo_kernel(const mg_conv_par
 // 370 MB per C64 launch). Same MFMA structure as the halo kernel (transposed LDS reads, waves own quadrants, fp32 slabs per row split); the
 // row count is a device word: the fixed grid divides the live rows evenly, empty splits write zero slabs.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int FM, typename T = bf16raw>
+template <int FM, typename T = bf16raw, bool XF = false>
 __global__ __launch_bounds__(256) void igemm_wgrad_gather9_kernel(const mg_conv_params p, int nsplit, float* __restrict__ ws) {
     constexpr int FN = 1, TCO = 32 * FM, TCI = 32, RC = 64;
     constexpr int PY = TCO + 16, PX = TCI + 16;
@@ -523,6 +539,15 @@ __global__ __launch_bounds__(256) void igemm_wgrad_gather9_kernel(const mg_conv_
     const bf16raw* __restrict__ xb = (const bf16raw*)p.x;
 
     uint4 ry[ITY], rx[ITX];
+    [[maybe_unused]] float xsc[8], xsh[8];
+    [[maybe_unused]] unsigned xlive = 0;                          // bit i: gathered chunk i exists (a live neighbour) -> transformed; missing neighbours stay 0
+    [[maybe_unused]] const float xsl = xf_slope_of(p.xf_act, p.xf_slope);
+    if constexpr (XF) {
+        static_assert(256 % CPX == 0 && ITX <= 32, "operand transform: one channel group per thread");
+        const int c = t % CPX;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xsc[e] = p.xf_scale[ci0 + c * 8 + e]; xsh[e] = p.xf_shift[ci0 + c * 8 + e]; }
+    }
     auto load_stage = [&](int mb) {
 #pragma unroll
         for (int i = 0; i < ITY; ++i) {
@@ -539,6 +564,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_gather9_kernel(const mg_conv_
             int src = -1;
             if (m < mend) src = p.nbr[(long)m * 9 + tap];
             rx[i] = src >= 0 ? *(const uint4*)(xb + (long)src * p.ldx + ci0 + c * 8) : make_uint4(0, 0, 0, 0);
+            if constexpr (XF) xlive = src >= 0 ? (xlive | (1u << i)) : (xlive & ~(1u << i));
         }
     };
     auto store_stage = [&]() {
@@ -552,6 +578,7 @@ __global__ __launch_bounds__(256) void igemm_wgrad_gather9_kernel(const mg_conv_
         for (int i = 0; i < ITX; ++i) {
             const int idx = t + i * 256;
             const int c = idx % CPX, row = (idx / CPX) % RC, tap = idx / (CPX * RC);
+            if constexpr (XF) { if (xlive & (1u << i)) rx[i] = xf_apply8<T>(rx[i], xsc, xsh, xsl); }
             *(uint4*)(sX + (tap * RC + row) * PX + c * 8) = rx[i];
         }
     };
@@ -647,7 +674,17 @@ static int launch_wgrad_gather9(const mg_conv_params& p, float* ws, long ws_floa
         (void)hipFuncSetAttribute((const void*)igemm_wgrad_gather9_kernel<2, f16raw>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         attr_set = true;
     }
-    if (p.dtype == MG_F16) {
+    if (p.xf_scale) {                                        // x = a raw conv output, BatchNorm1d + activation applied on the way into LDS
+        if (tco != 32) return MG_XF_UNSUPPORTED;
+        static bool xattr = false;
+        if (!xattr) {
+            (void)hipFuncSetAttribute((const void*)igemm_wgrad_gather9_kernel<1, bf16raw, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void*)igemm_wgrad_gather9_kernel<1, f16raw, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            xattr = true;
+        }
+        if (p.dtype == MG_F16) hipLaunchKernelGGL((igemm_wgrad_gather9_kernel<1, f16raw, true>), grid, dim3(256), lds, st, p, (int)splits, ws);
+        else hipLaunchKernelGGL((igemm_wgrad_gather9_kernel<1, bf16raw, true>), grid, dim3(256), lds, st, p, (int)splits, ws);
+    } else if (p.dtype == MG_F16) {
         if (tco == 64) hipLaunchKernelGGL((igemm_wgrad_gather9_kernel<2, f16raw>), grid, dim3(256), lds, st, p, (int)splits, ws);
         else hipLaunchKernelGGL((igemm_wgrad_gather9_kernel<1, f16raw>), grid, dim3(256), lds, st, p, (int)splits, ws);
     } else if (tco == 64) hipLaunchKernelGGL((igemm_wgrad_gather9_kernel<2>), grid, dim3(256), lds, st, p, (int)splits, ws);
@@ -905,6 +942,13 @@ int launch_wgrad(const mg_conv_params& p, float* ws, long ws_floats, hipStream_t
     size_t stage = (size_t)KSTEP * (TCO + PAD + TCI + PAD) * sizeof(T);
     size_t red = (size_t)4 * TCO * (TCI + 1) * 4;
     size_t lds = stage > red ? stage : red;
+    if (p.xf_scale) {
+        if constexpr (BF && TCO == 32 && TCI == 32) {
+            if (p.mode == MG_MODE_CONV) hipLaunchKernelGGL((igemm_wgrad_kernel<T, TCO, TCI, MG_MODE_CONV, true>), grid, dim3(256), lds, st, q, pl.rpb, use_ws);
+            else if (p.mode == MG_MODE_GATHER) hipLaunchKernelGGL((igemm_wgrad_kernel<T, TCO, TCI, MG_MODE_GATHER, true>), grid, dim3(256), lds, st, q, pl.rpb, use_ws);
+            else return MG_XF_UNSUPPORTED;
+        } else return MG_XF_UNSUPPORTED;
+    } else
     switch (p.mode) {
         case MG_MODE_CONV: hipLaunchKernelGGL((igemm_wgrad_kernel<T, TCO, TCI, MG_MODE_CONV>), grid, dim3(256), lds, st, q, pl.rpb, use_ws); break;
         case MG_MODE_TCONV: hipLaunchKernelGGL((igemm_wgrad_kernel<T, TCO, TCI, MG_MODE_TCONV>), grid, dim3(256), lds, st, q, pl.rpb, use_ws); break;
@@ -925,8 +969,15 @@ int launch_wgrad(const mg_conv_params& p, float* ws, long ws_floats, hipStream_t
 }
 
 // operand transform (mg_conv_params.xf_*): the halo form applies it between its staging registers and LDS
+// ... and the sparse head's row matrices (device row count): gather 3x3 through the all-taps kernel (Cin 64) or the per-tap kernel (Cin 32), 1x1
+// through the per-tap kernel (Cin 32); Cout <= 32 (32-wide co tiles)
+static inline bool wgrad_xf_rows_ok(const mg_conv_params& p) {
+    if (!MG_IS16(p.dtype) || !p.m_dev || p.Cout > 32 || p.ldx % 8) return false;
+    if (p.mode == MG_MODE_GATHER && p.R * p.S == 9) return p.Cin == 32 || (p.Cin == 64 && wgrad_gather9_eligible(p));
+    return p.mode == MG_MODE_CONV && p.R * p.S == 1 && p.stride == 1 && p.pad == 0 && p.Cin == 32;
+}
 static inline bool wgrad_xf_ok(const mg_conv_params& p) {
-    return MG_IS16(p.dtype) && wgrad_halo_eligible(p) && !wgrad_c8_eligible(p) && !wgrad_gather9_eligible(p);
+    return (MG_IS16(p.dtype) && wgrad_halo_eligible(p) && !wgrad_c8_eligible(p) && !wgrad_gather9_eligible(p)) || wgrad_xf_rows_ok(p);
 }
 
 template <typename T>
@@ -949,7 +1000,7 @@ int dispatch_wgrad(const mg_conv_params& p, float* ws, long ws_floats, long* nee
         const WgradHaloPlan pl = plan_wgrad_halo(p);
         if (pl.splits == 1 || (ws && ws_floats >= pl.splits * n)) return launch_wgrad_halo(p, ws, ws_floats, st);
     }
-    if (p.xf_scale) return MG_XF_UNSUPPORTED;                      // (no workspace for the halo form: the per-tap kernels do not transform)
+    if (p.xf_scale && !wgrad_xf_rows_ok(p)) return MG_XF_UNSUPPORTED;      // (no workspace for the halo form: the per-tap kernels transform only the row-matrix forms)
 #define MG_WG(TCO, TCI)                                                                             \
     do {                                                                                            \
         if (need) { WgradPlan pl = plan_wgrad<T, TCO, TCI>(p); *need = (pl.splits > 1 || MG_IS16(p.dw_dtype)) ? pl.splits * n : 0; return 0; } \

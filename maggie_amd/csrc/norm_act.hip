@@ -1175,7 +1175,7 @@ extern "C" int mg_bn_train_fwd(const mg_rowwise_params* p_in, float* stats_ws, i
     hipStream_t st = (hipStream_t)stream;
     float* own = stats_ws;                               // [2C] (exact) or [MG_STAT_REPLICAS][2C] statistics scratch; outs: scale | shift | mean | invstd
     if (!stats_in && !own) return -3;
-    if (exact && bn_small_ok(p))                         // one launch: the statistics never leave the registers (stats_in / stats_ws unused)
+    if (exact && bn_small_ok(p) && p.y)                  // one launch: the statistics never leave the registers (stats_in / stats_ws unused)
         return p.dtype == MG_BF16 ? bn_small_fwd_launch<bf16raw>(p, gamma, beta, running_mean, running_var, momentum, eps, outs, st)
                : p.dtype == MG_F16 ? bn_small_fwd_launch<f16raw>(p, gamma, beta, running_mean, running_var, momentum, eps, outs, st)
                                    : bn_small_fwd_launch<float>(p, gamma, beta, running_mean, running_var, momentum, eps, outs, st);
@@ -1199,7 +1199,7 @@ extern "C" int mg_bn_train_fwd(const mg_rowwise_params* p_in, float* stats_ws, i
                                     outs + 3 * C, p.m_dev, stream, p.count_mult);
             if (rc) return rc;
             p.scale = outs; p.shift = outs + C;
-            return mg_affine_act(&p, stream);
+            return p.y ? mg_affine_act(&p, stream) : 0;
         }
         if (!stats) {
             if (!own) return -3;
@@ -1212,7 +1212,7 @@ extern "C" int mg_bn_train_fwd(const mg_rowwise_params* p_in, float* stats_ws, i
                                 outs + 3 * C, p.m_dev, stream, p.count_mult);
         if (rc) return rc;
         p.scale = outs; p.shift = outs + C;
-        return mg_affine_act(&p, stream);
+        return p.y ? mg_affine_act(&p, stream) : 0;          // (y == NULL: the consumer applies scale | shift to its operand, mg_conv_params.xf_*)
     }
     if (p.m_dev) {
         // sparse head: the row count is a device word -> always the exact two-pass variance over min(*m_dev, M) rows (no host knowledge of
@@ -1220,12 +1220,12 @@ extern "C" int mg_bn_train_fwd(const mg_rowwise_params* p_in, float* stats_ws, i
         if (!own) return -3;
         if (!ws_zeroed) { hipError_t e = mg_zero_words(own, 2 * C, st); if (e != hipSuccess) return (int)e; }
         if (p.M > 0) { rc = mg_colstats_centered_dev(p.x, p.dtype, p.M, C, p.ldx, own, 0, p.m_dev, stream); if (rc) return rc; }
-        if (bn_fused_ok(p)) return bn_apply_fused_launch(p, own, 1, 1, gamma, beta, running_mean, running_var, momentum, eps, outs, st);
+        if (bn_fused_ok(p) && p.y) return bn_apply_fused_launch(p, own, 1, 1, gamma, beta, running_mean, running_var, momentum, eps, outs, st);
         rc = bn_finalize_launch(own, 1, nullptr, (float)p.M, C, 1, gamma, beta, running_mean, running_var, momentum, eps, outs, outs + C, outs + 2 * C,
                                 outs + 3 * C, p.m_dev, stream);
         if (rc) return rc;
         p.scale = outs; p.shift = outs + C;
-        return mg_affine_act(&p, stream);
+        return p.y ? mg_affine_act(&p, stream) : 0;          // (y == NULL: the consumer applies scale | shift to its operand, mg_conv_params.xf_*)
     }
     if (exact) {
         // two-pass variance; a 1-row stats_in already carries the column sums from the producing conv's epilogue
@@ -1239,12 +1239,12 @@ extern "C" int mg_bn_train_fwd(const mg_rowwise_params* p_in, float* stats_ws, i
         stats = own; nrep = MG_STAT_REPLICAS;
     }
     p.count = (float)p.M;
-    if (bn_fused_ok(p)) return bn_apply_fused_launch(p, stats, nrep, centered, gamma, beta, running_mean, running_var, momentum, eps, outs, st);
+    if (bn_fused_ok(p) && p.y) return bn_apply_fused_launch(p, stats, nrep, centered, gamma, beta, running_mean, running_var, momentum, eps, outs, st);
     rc = bn_finalize_launch(stats, nrep, nullptr, (float)p.M, C, centered, gamma, beta, running_mean, running_var, momentum, eps, outs, outs + C,
                             outs + 2 * C, outs + 3 * C, nullptr, stream, p.count_mult);
     if (rc) return rc;
     p.scale = outs; p.shift = outs + C;
-    return mg_affine_act(&p, stream);
+    return p.y ? mg_affine_act(&p, stream) : 0;
 }
 
 extern "C" int mg_bn_train_bwd(const mg_rowwise_params* p, int sums_zeroed, void* stream) {

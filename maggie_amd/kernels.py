@@ -449,11 +449,12 @@ def stats_ws_floats(C, exact=False):
 
 
 def bn_train_fwd(x, gamma, beta, running_mean, running_var, momentum, eps, act, slope, res=None, res_mode=1, H=1, W=1, stats=None,
-                 exact=False, stats_ws=None, rows=None, count_mult=1):
+                 exact=False, stats_ws=None, rows=None, count_mult=1, apply=True):
     """Training BatchNorm forward in ONE C call (statistics -> finalize -> apply): -> y, outs = scale|shift|mean|invstd (4C).
-    `stats_ws`: zeroed scratch of stats_ws_floats(C, exact) floats for the statistics; None: allocated and zeroed here."""
+    `stats_ws`: zeroed scratch of stats_ws_floats(C, exact) floats for the statistics; None: allocated and zeroed here.
+    apply=False: statistics and finalize only (y is None): the consumer applies scale | shift to its operand in flight (conv_fprop(xf=...))."""
     M, C = x.shape[0], x.shape[-1]
-    y = torch.empty((M, C), dtype=x.dtype, device=x.device)
+    y = torch.empty((M, C), dtype=x.dtype, device=x.device) if apply else None
     outs = torch.empty(4 * C, dtype=torch.float32, device=x.device)
     zeroed = stats_ws is not None
     two_pass = exact or rows is not None                      # a device row count always takes the two-pass form (outside deterministic mode)

@@ -94,25 +94,25 @@ class DeviceRng:
         return snap
 
 
-def _gconv(x, w, nbr, rows, cap, bias=None, act=ACT_NONE, out=None, yoff=0, cout=None):
+def _gconv(x, w, nbr, rows, cap, bias=None, act=ACT_NONE, out=None, yoff=0, cout=None, xf=None):
     return K.conv_fprop(x, w, mode=MODE_GATHER, nbr=nbr, R=3, S=3, M=cap, shift=bias, act=act, pre_act=False, rows=rows, out=out, yoff=yoff,
-                        cout=cout)
+                        cout=cout, xf=xf)
 
 
-def _lin(x, w, rows, bias=None, relu=False, out=None, yoff=0, cout=None):
+def _lin(x, w, rows, bias=None, relu=False, out=None, yoff=0, cout=None, xf=None):
     cap = x.shape[0]
     return K.conv_fprop(x, w, mode=MODE_CONV, N=1, Hin=1, Win=cap, Hout=1, Wout=cap, R=1, S=1, stride=1, pad=0, dil=1, shift=bias,
-                        act=ACT_RELU if relu else ACT_NONE, pre_act=False, rows=rows, out=out, yoff=yoff, cout=cout)
+                        act=ACT_RELU if relu else ACT_NONE, pre_act=False, rows=rows, out=out, yoff=yoff, cout=cout, xf=xf)
 
 
-def _wgrad_g(x, dy, cout, nbr, rows, dtype, park=None):
-    return K.conv_wgrad(x, dy, cout=cout, mode=MODE_GATHER, nbr=nbr, R=3, S=3, M=nbr.shape[0], out_dtype=dtype, rows=rows, park=park)
+def _wgrad_g(x, dy, cout, nbr, rows, dtype, park=None, xf=None):
+    return K.conv_wgrad(x, dy, cout=cout, mode=MODE_GATHER, nbr=nbr, R=3, S=3, M=nbr.shape[0], out_dtype=dtype, rows=rows, park=park, xf=xf)
 
 
-def _wgrad_l(x, dy, cout, rows, dtype, park=None):
+def _wgrad_l(x, dy, cout, rows, dtype, park=None, xf=None):
     cap = x.shape[0]
     return K.conv_wgrad(x, dy, cout=cout, mode=MODE_CONV, N=1, Hin=1, Win=cap, Hout=1, Wout=cap, R=1, S=1, stride=1, pad=0, dil=1,
-                        out_dtype=dtype, rows=rows, park=park)
+                        out_dtype=dtype, rows=rows, park=park, xf=xf)
 
 
 class _BN:
@@ -123,10 +123,26 @@ class _BN:
         self.bn, self.act = bn, act
         self.training = bn.training or bn.running_mean is None
 
-    def fwd(self, x, rows, gamma, beta):
+    def fwd(self, x, rows, gamma, beta, lazy=False):
+        """-> the normalised, activated rows -- or, `lazy` (round 5: every consumer of this layer is a convolution whose kernels transform their
+        operand in flight, csrc/conv_igemm.hip XF forms): x itself, with `self.xf` = (scale, shift, act, slope) for those consumers; the apply pass
+        and the stored activation disappear, the backward re-forms the activation mask from x."""
         bn, C = self.bn, x.shape[1]
         self.x = x
+        self.xf = None
         self.group = MF._sync_group(bn) if self.training else None
+        if lazy and MF.LAZY_BN and self.training and self.group is None and x.dtype != torch.float32:
+            if bn.num_batches_tracked is not None and not MF.DEFER_BN_COUNTERS:
+                if MF.BN_COUNT_LOG is not None:
+                    MF.BN_COUNT_LOG.append(bn.num_batches_tracked)
+                else:
+                    bn.num_batches_tracked.add_(1)
+            mom = 0.1 if bn.momentum is None else bn.momentum
+            _, self.pack = K.bn_train_fwd(x, gamma, beta, bn.running_mean, bn.running_var, mom, bn.eps, self.act, SLOPE,
+                                          stats_ws=MF.ARENA.take(K.stats_ws_floats(C, True), x.device), rows=rows, apply=False)
+            self.y = None
+            self.xf = (self.pack[:C], self.pack[C:2 * C], self.act, SLOPE)
+            return x
         if self.training:
             if bn.num_batches_tracked is not None and not MF.DEFER_BN_COUNTERS:
                 if MF.BN_COUNT_LOG is not None:
@@ -215,9 +231,11 @@ class SparseHead(torch.autograd.Function):
         # ---- layer3: inverse conv OS8 -> OS4, BN, LeakyReLU, SubM 3x3  (:69-74) ----------------------------------------------------
         bn = s.bn = {}
 
-        def BN(name, x, rows, act):
+        def BN(name, x, rows, act, lazy=False):
             b = bn[name] = _BN(getattr(dec, name.split('.')[0])[int(name.split('.')[1])], act)
-            return b.fwd(x, rows, *bnp[name])
+            return b.fwd(x, rows, *bnp[name], lazy=lazy)
+
+        XF = lambda name: bn[name].xf                                     # noqa: E731  (None: the layer stored its output)
 
         B0 = _gconv(A1, W['layer3.0'], inv4, m4, l4.cap)
         B1 = BN('layer3.1', B0, m4, ACT_LRELU)
@@ -229,32 +247,34 @@ class SparseHead(torch.autograd.Function):
         G2 = _gconv(G1, W['guidance_layer.3'], t4, m4, l4.cap, bias=Bv['guidance_layer.3'])
         X4 = K.rows_sigmoid_mul(CAT3[:, :64], G2, rows=m4)
         S0 = _lin(X4, W['layer3_smooth.0'], m4, Bv['layer3_smooth.0'], relu=True)
-        S1 = BN('layer3_smooth.2', S0, m4, ACT_NONE)
-        R0 = _gconv(S1, W['refine_OS4.0'], t4, m4, l4.cap)
-        R1 = BN('refine_OS4.1', R0, m4, ACT_LRELU)
-        R2 = _gconv(R1, W['refine_OS4.3'], t4, m4, l4.cap, bias=Bv['refine_OS4.3'])
+        # (lazy: the BatchNorm1d output is never stored -- both consumers of S1, and the consumer of every layer marked below, are register-staged
+        # gather / 1x1 kernels with Cout <= 32, which apply scale | shift | activation to their operand in flight)
+        S1 = BN('layer3_smooth.2', S0, m4, ACT_NONE, lazy=True)
+        R0 = _gconv(S1, W['refine_OS4.0'], t4, m4, l4.cap, xf=XF('layer3_smooth.2'))
+        R1 = BN('refine_OS4.1', R0, m4, ACT_LRELU, lazy=True)
+        R2 = _gconv(R1, W['refine_OS4.3'], t4, m4, l4.cap, bias=Bv['refine_OS4.3'], xf=XF('refine_OS4.1'))
         x_os4 = K.scatter_plane(R2, 0, l4.coords, l4.P, l4.H, l4.W, -99.0, rows=m4)
         s.CAT3, s.G2, s.X4, s.S0 = CAT3, G2, X4, S0
         # ---- layer4 (OS4 -> OS2), fea2, layer4_smooth  (:91-102) ----------------------------------------------------------------------
-        C0 = _gconv(S1, W['layer4.0'], inv2, m2, l2.cap)
-        C1 = BN('layer4.1', C0, m2, ACT_LRELU)
+        C0 = _gconv(S1, W['layer4.0'], inv2, m2, l2.cap, xf=XF('layer3_smooth.2'))
+        C1 = BN('layer4.1', C0, m2, ACT_LRELU, lazy=True)
         CAT2 = new(l2.cap, 64)
         K.gather_rows(fea2, l2.coords, n_i, out=CAT2, yoff=0, rows=m2)
-        _lin(C1, W['layer4.3'], m2, out=CAT2, yoff=32)
+        _lin(C1, W['layer4.3'], m2, out=CAT2, yoff=32, xf=XF('layer4.1'))
         D0 = _lin(CAT2, W['layer4_smooth.0'], m2, Bv['layer4_smooth.0'], relu=True)
-        D1 = BN('layer4_smooth.2', D0, m2, ACT_NONE)
+        D1 = BN('layer4_smooth.2', D0, m2, ACT_NONE, lazy=True)
         s.CAT2, s.D0 = CAT2, D0
         # ---- layer5 (OS2 -> OS1), fea1, layer5_smooth, refine_OS1  (:105-130) -------------------------------------------------------
-        E0 = _gconv(D1, W['layer5.0'], inv1, m1, l1.cap)
-        E1 = BN('layer5.1', E0, m1, ACT_LRELU)
+        E0 = _gconv(D1, W['layer5.0'], inv1, m1, l1.cap, xf=XF('layer4_smooth.2'))
+        E1 = BN('layer5.1', E0, m1, ACT_LRELU, lazy=True)
         CAT1 = new(l1.cap, 64)
         K.gather_rows(fea1, l1.coords, n_i, out=CAT1, yoff=0, rows=m1)
-        _gconv(E1, W['layer5.3'], t1, m1, l1.cap, out=CAT1, yoff=32)
+        _gconv(E1, W['layer5.3'], t1, m1, l1.cap, out=CAT1, yoff=32, xf=XF('layer5.1'))
         F0 = _lin(CAT1, W['layer5_smooth.0'], m1, Bv['layer5_smooth.0'], relu=True)
-        F1 = BN('layer5_smooth.2', F0, m1, ACT_NONE)
-        Q0 = _gconv(F1, W['refine_OS1.0'], t1, m1, l1.cap)
-        Q1 = BN('refine_OS1.1', Q0, m1, ACT_LRELU)
-        Q2 = _gconv(Q1, W['refine_OS1.3'], t1, m1, l1.cap, bias=Bv['refine_OS1.3'])
+        F1 = BN('layer5_smooth.2', F0, m1, ACT_NONE, lazy=True)
+        Q0 = _gconv(F1, W['refine_OS1.0'], t1, m1, l1.cap, xf=XF('layer5_smooth.2'))
+        Q1 = BN('refine_OS1.1', Q0, m1, ACT_LRELU, lazy=True)
+        Q2 = _gconv(Q1, W['refine_OS1.3'], t1, m1, l1.cap, bias=Bv['refine_OS1.3'], xf=XF('refine_OS1.1'))
         x_os1 = K.scatter_plane(Q2, 0, l1.coords, l1.P, l1.H, l1.W, -99.0, rows=m1)
         s.CAT1, s.F0 = CAT1, F0
         s.W = W
@@ -290,18 +310,22 @@ class SparseHead(torch.autograd.Function):
             gBN[name] = (dg, db)
             return dx
 
-        def subm_b(name, x, dy, tab, rows, cap, cout, need_dx=True):
+        def src(b):
+            """(x operand, transform) of a conv fed by BatchNorm layer `b`: its stored output, or -- operand-path layers -- its RAW input + xf."""
+            return (b.y, None) if b.xf is None else (b.x, b.xf)
+
+        def subm_b(name, x, dy, tab, rows, cap, cout, need_dx=True, xf=None):
             """SubM 3x3: dgrad = gather conv with the tap-reversed twin over the same table; wgrad over the table."""
-            gW[name] = _wgrad_g(x, dy, cout, tab, rows, dt, park)
+            gW[name] = _wgrad_g(x, dy, cout, tab, rows, dt, park, xf=xf)
             return _gconv(dy, wt(name, True), tab, rows, cap) if need_dx else None
 
-        def inv_b(name, x, dy, tab_f, tab_c, rows_f, rows_c, cap_c, cout):
+        def inv_b(name, x, dy, tab_f, tab_c, rows_f, rows_c, cap_c, cout, xf=None):
             """inverse conv (fine rows <- coarse rows): dgrad over the coarse rows with the strided table; wgrad over the fine rows."""
-            gW[name] = _wgrad_g(x, dy, cout, tab_f, rows_f, dt, park)
+            gW[name] = _wgrad_g(x, dy, cout, tab_f, rows_f, dt, park, xf=xf)
             return _gconv(dy, wt(name, False), tab_c, rows_c, cap_c)
 
-        def lin_b(name, x, dy, rows, cout):
-            gW[name] = _wgrad_l(x, dy, cout, rows, dt, park)
+        def lin_b(name, x, dy, rows, cout, xf=None):
+            gW[name] = _wgrad_l(x, dy, cout, rows, dt, park, xf=xf)
             return _lin(dy, wt(name, False), rows)
 
         fea1, fea2, fea3 = s.fea
@@ -310,37 +334,37 @@ class SparseHead(torch.autograd.Function):
         dQ2 = K.gather_plane(d_os1.contiguous(), l1.coords, dt, width=co, rows=m1)
         _, gB['refine_OS1.3'] = K.bias_act_bwd(dQ2, None, True, rows=m1)
         b = bn['refine_OS1.1']
-        dQ1 = subm_b('refine_OS1.3', b.y, dQ2, t1, m1, l1.cap, co)
+        dQ1 = subm_b('refine_OS1.3', src(b)[0], dQ2, t1, m1, l1.cap, co, xf=src(b)[1])
         dQ0 = bn_b('refine_OS1.1', dQ1, m1)
         bF = bn['layer5_smooth.2']
-        dF1 = subm_b('refine_OS1.0', bF.y, dQ0, t1, m1, l1.cap, 32)
+        dF1 = subm_b('refine_OS1.0', src(bF)[0], dQ0, t1, m1, l1.cap, 32, xf=src(bF)[1])
         dF0 = bn_b('layer5_smooth.2', dF1, m1)
         g, gB['layer5_smooth.0'] = K.bias_act_bwd(dF0, s.F0, True, rows=m1)
         dCAT1 = lin_b('layer5_smooth.0', s.CAT1, g, m1, 32)
         dfea1 = K.gather_rows_bwd_dense(dCAT1, l1.bits, l1.wordoff, n_i, fea1.shape, yoff=0)
         bE = bn['layer5.1']
-        dE1 = subm_b('layer5.3', bE.y, dCAT1[:, 32:], t1, m1, l1.cap, 32)
+        dE1 = subm_b('layer5.3', src(bE)[0], dCAT1[:, 32:], t1, m1, l1.cap, 32, xf=src(bE)[1])
         dE0 = bn_b('layer5.1', dE1, m1)
         bD = bn['layer4_smooth.2']
-        dD1 = inv_b('layer5.0', bD.y, dE0, inv1, dn2, m1, m2, l2.cap, 32)
+        dD1 = inv_b('layer5.0', src(bD)[0], dE0, inv1, dn2, m1, m2, l2.cap, 32, xf=src(bD)[1])
         # ---- layer4 ----------------------------------------------------------------------------------------------------------------
         dD0 = bn_b('layer4_smooth.2', dD1, m2)
         g, gB['layer4_smooth.0'] = K.bias_act_bwd(dD0, s.D0, True, rows=m2)
         dCAT2 = lin_b('layer4_smooth.0', s.CAT2, g, m2, 32)
         dfea2 = K.gather_rows_bwd_dense(dCAT2, l2.bits, l2.wordoff, n_i, fea2.shape, yoff=0)
         bC = bn['layer4.1']
-        dC1 = lin_b('layer4.3', bC.y, dCAT2[:, 32:], m2, 32)
+        dC1 = lin_b('layer4.3', src(bC)[0], dCAT2[:, 32:], m2, 32, xf=src(bC)[1])
         dC0 = bn_b('layer4.1', dC1, m2)
         bS = bn['layer3_smooth.2']
-        dS1_a = inv_b('layer4.0', bS.y, dC0, inv2, dn4, m2, m4, l4.cap, 32)
+        dS1_a = inv_b('layer4.0', src(bS)[0], dC0, inv2, dn4, m2, m4, l4.cap, 32, xf=src(bS)[1])
         # ---- refine_OS4 ------------------------------------------------------------------------------------------------------------
         co4 = W['refine_OS4.3'].shape[0]
         dR2 = K.gather_plane(d_os4.contiguous(), l4.coords, dt, width=co4, rows=m4)
         _, gB['refine_OS4.3'] = K.bias_act_bwd(dR2, None, True, rows=m4)
         bR = bn['refine_OS4.1']
-        dR1 = subm_b('refine_OS4.3', bR.y, dR2, t4, m4, l4.cap, co4)
+        dR1 = subm_b('refine_OS4.3', src(bR)[0], dR2, t4, m4, l4.cap, co4, xf=src(bR)[1])
         dR0 = bn_b('refine_OS4.1', dR1, m4)
-        dS1_b = subm_b('refine_OS4.0', bS.y, dR0, t4, m4, l4.cap, 32)
+        dS1_b = subm_b('refine_OS4.0', src(bS)[0], dR0, t4, m4, l4.cap, 32, xf=src(bS)[1])
         dS1 = K.rows_add(dS1_a, dS1_b, out=dS1_a, rows=m4)        # S1 feeds layer4 AND refine_OS4
         dS0 = bn_b('layer3_smooth.2', dS1, m4)
         g, gB['layer3_smooth.0'] = K.bias_act_bwd(dS0, s.S0, True, rows=m4)

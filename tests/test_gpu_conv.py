@@ -488,3 +488,76 @@ def test_operand_transform_is_refused_where_no_kernel_form_has_it():
     one = torch.ones(64, device=dev)
     with pytest.raises(hip.MaggieHipError, match='-9'):
         K.conv_fprop(y, w, mode=K.MODE_CONV, N=1, Hin=16, Win=16, R=1, S=1, stride=1, pad=0, dil=1, xf=(one, one, 1, 0.2))
+
+
+def test_parked_reductions_must_meet_their_join_inside_the_same_backward():
+    """a weight that comes out of the batched weight pipeline parks its slab reduction until the pipeline's backward (the
+    join) flushes it. (1) A backward pass that ends WITHOUT the join -- the weight pipeline differentiated separately, a graph split that puts it
+    elsewhere -- must raise instead of handing out unreduced slabs; (2) a weight consumed by a SECOND convolution (here: a transposed use, which never
+    parks itself) is not parked at all: autograd adds the two gradients, both complete."""
+    from maggie_amd import functional as MF, hip
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((2, 16, 32, 64), generator=g).to(dev, torch.bfloat16).requires_grad_(True)
+
+    def joined_weight():
+        w = (torch.randn((64, 9, 64), generator=g) / 24).to(dev, torch.bfloat16).requires_grad_(True)
+        w._mg_join = True                      # what SpectralNormBatch / WeightBank put on the tensors they hand out
+        return w
+
+    if not MF.PARK_WGRAD:
+        pytest.skip('MAGGIE_PARK_WGRAD=0')
+    w = joined_weight()
+    y = MF.conv2d(x, w)
+    with pytest.raises(hip.MaggieHipError, match='never flushed'):
+        y.float().sum().backward()
+    assert MF.PARKED == []
+    # two uses: counted, so neither parks; gradients are complete and equal to the sum of the two uses' own gradients
+    w3 = joined_weight()
+    y1, y2 = MF.conv2d(x, w3), MF.conv2d(x, w3)
+    (y1.float().sum() + 2.0 * y2.float().sum()).backward()
+    assert MF.PARKED == []
+    w_ref = w3.detach().clone().requires_grad_(True)
+    yr = MF.conv2d(x.detach(), w_ref)
+    (3.0 * yr.float().sum()).backward()
+    torch.cuda.synchronize()
+    assert (w3.grad.float() - w_ref.grad.float()).abs().max() <= 2e-2 * w_ref.grad.float().abs().max()
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('act', [0, 2])
+@pytest.mark.parametrize('Cin,Cout,kind', [(32, 32, 'gather'), (64, 32, 'gather'), (32, 8, 'gather'), (32, 32, 'lin')])
+def test_operand_transform_on_the_sparse_row_matrices(Cin, Cout, kind, act, dtype):
+    """The sparse head's BatchNorm1d layers on the operand path (round 5): gather 3x3 and 1x1 convolutions over row matrices with a DEVICE row count
+    (persistent register-staged forward kernels, all-taps / per-tap weight-gradient kernels) fed the raw rows + (scale, shift, act) give exactly
+    what they give on the stored BatchNorm output -- missing neighbours and rows beyond the live count stay zero."""
+    from maggie_amd import kernels as K
+    from oracle import region
+    dev = _dev()
+    rs = np.random.RandomState(Cin + Cout + act)
+    active = rs.uniform(size=(3, 40, 56)) > 0.55
+    nbr = torch.from_numpy(region.subm_neighbors(active)).to(dev)
+    cap = nbr.shape[0]
+    live = cap - 101
+    rows = torch.tensor([live], dtype=torch.int32, device=dev)
+    y = torch.from_numpy(rs.normal(0.2, 1.4, (cap, Cin)).astype(np.float32)).to(dev, dtype)
+    sc = torch.from_numpy(rs.uniform(0.5, 1.5, Cin).astype(np.float32) * rs.choice([-1.0, 1.0], Cin).astype(np.float32)).to(dev)
+    sh = torch.from_numpy(rs.normal(0.0, 0.7, Cin).astype(np.float32)).to(dev)
+    taps = 9 if kind == 'gather' else 1
+    w = torch.from_numpy((rs.normal(size=(Cout, taps, Cin)) / np.sqrt(taps * Cin)).astype(np.float32)).to(dev, dtype)
+    dy = torch.from_numpy(rs.normal(size=(cap, Cout)).astype(np.float32)).to(dev, dtype)
+    z = K.affine_act(y, sc, sh, act=act, slope=0.2)         # (all capacity rows: this test's table lets live rows gather rows beyond the live count)
+    xf = (sc, sh, act, 0.2)
+    if kind == 'gather':
+        fkw = dict(mode=K.MODE_GATHER, nbr=nbr, R=3, S=3, M=cap, rows=rows)
+        wkw = dict(cout=Cout, mode=K.MODE_GATHER, nbr=nbr, R=3, S=3, M=cap, rows=rows)
+    else:
+        fkw = dict(mode=K.MODE_CONV, N=1, Hin=1, Win=cap, Hout=1, Wout=cap, R=1, S=1, stride=1, pad=0, dil=1, rows=rows)
+        wkw = dict(cout=Cout, mode=K.MODE_CONV, N=1, Hin=1, Win=cap, Hout=1, Wout=cap, R=1, S=1, stride=1, pad=0, dil=1, rows=rows)
+    o_ref = K.conv_fprop(z, w, **fkw)
+    o_xf = K.conv_fprop(y, w, xf=xf, **fkw)
+    assert torch.equal(o_xf[:live], o_ref[:live]), float((o_xf[:live].float() - o_ref[:live].float()).abs().max())
+    for od in (torch.float32, dtype):
+        g_ref = K.conv_wgrad(z, dy, out_dtype=od, **wkw)
+        g_xf = K.conv_wgrad(y, dy, out_dtype=od, xf=xf, **wkw)
+        assert torch.equal(g_xf, g_ref), (od, float((g_xf.float() - g_ref.float()).abs().max()))
