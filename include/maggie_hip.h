@@ -132,6 +132,12 @@ int mg_conv_fprop(const mg_conv_params* p, void* stream);
 /* Rows of a `stats` buffer (stat_mode 0) that give every output tile of any forward kernel form its own row for an [M = N * Hout * Wout] output
  * (deterministic mode; MG_STAT_REPLICAS in atomic mode): what mg_conv_params.stat_rep must be at least, else the launch fails with -8. */
 int mg_conv_stat_rows(int M, int N, int Hout, int Wout);
+/* *out = the sticky error word of the cooperative single-launch kernels on the current device (mg_bn_train_bwd's one-launch form: a workgroup gave up
+ * waiting for its peers -- the launch's result is then invalid); 0 = none. A host read (hipMemcpy): for tests and end-of-run checks. */
+int mg_coop_error(int* out);
+/* Switch mg_bn_train_bwd's one-launch form (reduce + ordered sum + apply behind a flag hand-shake; measured slower than the three launches, off by
+ * default, MG_BN_COOP=1) on or off; returns the previous setting. */
+int mg_set_bn_coop(int on);
 /* Same, allowed to split the K dimension over several blocks per tile for deep layers with few output rows (M <= 8192,
  * K >= ~1152, Cout >= 64): mg_conv_fprop_workspace(p) = floats of scratch that plan needs (0: no split, identical to
  * mg_conv_fprop); partial tiles go to the workspace, a second kernel sums them and applies the epilogue (deterministic). */

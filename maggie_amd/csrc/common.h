@@ -186,6 +186,8 @@ static inline int mg_det_reduce1(const float* slots, int nblk, float* dst, int n
     mg_det_seg s{dst, nv, 0};
     return mg_det_reduce(slots, nblk, 1, nv, 0, &s, 1, st);
 }
+#define MG_COOP_WORDS 1024                             /* mg_coop_sync(): generation | error | 62 spare | <= 512 arrival flags ... */
+unsigned* mg_coop_sync();                              // per-device hand-shake words of the cooperative single-launch kernels (zeroed once, persistent)
 #define MG_DET_NO_SCRATCH (-7)     /* deterministic mode without (enough) slot scratch: mg_det_init was not called or the request is too large */
 
 #define MG_CHECK_LAUNCH()                              \

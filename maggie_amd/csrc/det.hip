@@ -22,6 +22,7 @@ int mg_det_on = 1;
 constexpr int MG_MAX_DEVICES = 16;
 static char* g_buf[MG_MAX_DEVICES] = {};
 static long g_bytes[MG_MAX_DEVICES] = {};
+static unsigned* g_coop[MG_MAX_DEVICES] = {};     // mg_coop_sync(), below
 
 extern "C" int mg_set_deterministic(int on) { mg_det_on = on ? 1 : 0; return 0; }
 extern "C" int mg_get_deterministic(void) { return mg_det_on; }
@@ -40,7 +41,30 @@ extern "C" int mg_det_init(long bytes) {
     e = hipMalloc(&p, (size_t)bytes);
     if (e != hipSuccess) return (int)e;
     g_buf[dev] = (char*)p; g_bytes[dev] = bytes;
+    void* c = nullptr;
+    e = hipMalloc(&c, MG_COOP_WORDS * 4);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemset(c, 0, MG_COOP_WORDS * 4);
+    if (e != hipSuccess) return (int)e;
+    g_coop[dev] = (unsigned*)c;
     return 0;
+}
+
+/* Cross-workgroup hand-shake words of the single-launch BatchNorm backward (csrc/norm_act.hip: bn_bwd_coop_kernel): [0] generation, [1] sticky
+ * error (a peer workgroup that never arrived), [64 ...] one arrival flag per workgroup. Per device, allocated and ZEROED once (mg_det_init), never
+ * moved: the generation scheme needs the words to survive from launch to launch, also across replays of a captured graph. */
+unsigned* mg_coop_sync() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MG_MAX_DEVICES) return nullptr;
+    return g_coop[dev];
+}
+extern "C" int mg_coop_error(int* out) {
+    unsigned* w = mg_coop_sync();
+    if (!w || !out) return -2;
+    unsigned v = 0;
+    hipError_t e = hipMemcpy(&v, w + 1, 4, hipMemcpyDeviceToHost);
+    *out = (int)v;
+    return e == hipSuccess ? 0 : (int)e;
 }
 
 float* mg_det_scratch(long floats) {

@@ -1247,10 +1247,190 @@ extern "C" int mg_bn_train_fwd(const mg_rowwise_params* p_in, float* stats_ws, i
     return p.y ? mg_affine_act(&p, stream) : 0;
 }
 
+
+// =====================================================================================================================
+// Training BatchNorm backward as ONE launch for the mid-size layers (round 5): reduce -> ordered sum -> apply used to be three launches
+// (bn_bwd_reduce 10 us + det_reduce 5 us + bn_bwd_apply 8 us per layer, dz and x read twice). Here every workgroup owns a (row block, 32-channel
+// group), keeps its rows of dz and x IN REGISTERS (<= 8 rows per thread: the layer fits the chip's register file), writes its partial
+// sums [sum g | sum g xhat] as one 64-float row, and meets the other row blocks of its channel group in a flag hand-shake -- no atomics:
+// a workgroup stores its arrival flag (release), then polls the <= 256 flags of its group with one coalesced load per round. The rows are then
+// added in row-block order by every workgroup for itself (4 row lanes x 64 columns, fixed tree: the result depends on the launch geometry
+// only) and the apply pass runs from the registers: dz and x are read once, dx written once.
+// Generation scheme instead of a reset: the flags carry generation G + 1, G is read from a device word at kernel entry and bumped by
+// workgroup (0, 0) after ITS wait -- every workgroup has read G by then (it could not have arrived otherwise) -- so a replayed graph needs no
+// memset between replays. The grid is at most 256 workgroups of 256 threads (one per CU: co-resident by construction); a peer that does not
+// arrive within the spin budget sets the sticky error word (mg_coop_error) instead of hanging the GPU.
+// =====================================================================================================================
+constexpr int COOP_TX = 4, COOP_TY = NT / COOP_TX, COOP_CH = 32;          // 4 lanes x 8 channels = one 32-channel group per workgroup
+
+template <typename T, int KEEP>
+__global__ __launch_bounds__(NT) void bn_bwd_coop_kernel(const mg_rowwise_params p, int rb, int rpb, unsigned long long* __restrict__ sync, float* __restrict__ slots) {
+    using TR = ElemTraits<T>;
+    constexpr int CE = TR::CE;
+    static_assert(CE == 8 && KEEP <= 8, "16-bit storage, at most 8 rows per thread");
+    __shared__ float sred[NT / 64][COOP_TX * 2 * CE];
+    __shared__ float stot[4][2 * COOP_CH];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int ix = t & (COOP_TX - 1), iy = t / COOP_TX;
+    const int b = blockIdx.x, g = blockIdx.y, C = p.C;
+    const int c0 = g * COOP_CH + ix * CE;
+    const int mbeg = b * rpb, mend = min(p.M, mbeg + rpb);
+    // hand-shake words (64-bit): generation of channel group g at [8 + g], arrival flags of its row blocks at [128 + g * rb + b]. A flag carries
+    // (generation + 1, group, row-block count): words left behind by other layers (another geometry maps other (g, b) pairs to the same word) or by
+    // earlier launches can never compare equal.
+    unsigned long long* gen_w = sync + 8 + g;
+    unsigned long long* flags = sync + 128 + (size_t)g * rb;
+    const unsigned long long gen = __hip_atomic_load(gen_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+    const unsigned long long want = (gen << 16) | ((unsigned long long)g << 9) | (unsigned long long)rb;
+    float mu[CE], is[CE], sc[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { mu[e] = p.mean[c0 + e]; is[e] = p.invstd[c0 + e]; sc[e] = p.scale[c0 + e]; }
+    const float sl = p.act == MG_ACT_RELU ? 0.f : p.slope;     // what a masked element's gradient is multiplied by
+    // ---- phase 1: this thread's rows -> registers (raw dz, x, one mask bit per element), partial sums
+    uint4 qd[KEEP], qx[KEEP];
+    unsigned long long mk = 0ull;                             // bit (k * 8 + e): the activation passes the gradient of element e of row k unchanged
+    float part[2 * CE];
+#pragma unroll
+    for (int e = 0; e < 2 * CE; ++e) part[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < KEEP; ++k) {
+        const int m = mbeg + iy + k * COOP_TY;
+        qd[k] = make_uint4(0, 0, 0, 0); qx[k] = make_uint4(0, 0, 0, 0);
+        if (m < mend) {
+            float gv[CE], dv[CE], xv[CE];
+            load_g<T>(p, m, c0, gv);                            // dz * act'(.) (mask from y, or re-formed from x: mask_from_x)
+            qd[k] = *(const uint4*)((const T*)p.dy + (long)m * p.lddy + c0);
+            qx[k] = *(const uint4*)((const T*)p.x + (long)m * p.ldx + c0);
+            TR::unpack(qd[k], dv);
+            TR::unpack(qx[k], xv);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
+                if (gv[e] == dv[e]) mk |= 1ull << (k * 8 + e);
+                part[e] += gv[e]; part[CE + e] += gv[e] * (xv[e] - mu[e]) * is[e];
+            }
+        }
+    }
+    // rows of a wave meet by butterfly over the lanes that share a channel chunk, the four waves through LDS in wave order
+    for (int off = COOP_TX; off < 64; off <<= 1) {
+#pragma unroll
+        for (int e = 0; e < 2 * CE; ++e) part[e] += __shfl_xor(part[e], off);
+    }
+    if (lane < COOP_TX) {
+#pragma unroll
+        for (int e = 0; e < 2 * CE; ++e) sred[wave][ix * 2 * CE + e] = part[e];
+    }
+    __syncthreads();
+    if (t < 2 * COOP_CH) {
+        // column t of the row: accumulator a = t / 32 (0: sum g, 1: sum g xhat), channel ch = t % 32 -> lane cx = ch / 8, element e = ch % 8
+        const int a = t / COOP_CH, ch = t - a * COOP_CH, cx = ch / CE, e = ch - cx * CE;
+        const int j = cx * 2 * CE + a * CE + e;
+        slots[((size_t)g * rb + b) * (2 * COOP_CH) + t] = (sred[0][j] + sred[1][j]) + (sred[2][j] + sred[3][j]);
+    }
+    // ---- arrival: the row is visible device-wide before the flag is; then wait for the rb flags of this channel group
+    __threadfence();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(flags + b, want, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    int ok_all = 0;
+    for (int spin = 0; spin < (1 << 18); ++spin) {
+        const int ok = (t >= rb) || (__hip_atomic_load(flags + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == want);
+        ok_all = __syncthreads_and(ok);
+        if (ok_all) break;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    if (!ok_all && t == 0) __hip_atomic_store((unsigned*)sync + 1, 1u + (unsigned)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (b == 0 && t == 0) __hip_atomic_store(gen_w, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // every workgroup of the group has read the old generation
+    // ---- the rb rows of this channel group, added in row order: 4 row lanes x 64 columns, then a fixed combine
+    {
+        const int col = t & (2 * COOP_CH - 1), rl = t / (2 * COOP_CH);
+        const float* base = slots + (size_t)g * rb * (2 * COOP_CH) + col;
+        float a0 = 0.f;
+        for (int r = rl; r < rb; r += 4) a0 += base[(size_t)r * (2 * COOP_CH)];
+        stot[rl][col] = a0;
+    }
+    __syncthreads();
+    float sg[CE], sgx[CE];
+    const float inv_n = 1.f / p.count;
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+        const int c = ix * CE + e;
+        sg[e] = ((stot[0][c] + stot[1][c]) + (stot[2][c] + stot[3][c])) * inv_n;
+        sgx[e] = ((stot[0][COOP_CH + c] + stot[1][COOP_CH + c]) + (stot[2][COOP_CH + c] + stot[3][COOP_CH + c])) * inv_n;
+    }
+    if (b == 0 && t < 2 * COOP_CH) {                          // dbeta | dgamma of this channel group
+        const int a = t / COOP_CH, ch = t - a * COOP_CH;
+        p.sums[a * C + g * COOP_CH + ch] = (stot[0][t] + stot[1][t]) + (stot[2][t] + stot[3][t]);
+    }
+    // ---- phase 2: apply from the registers
+#pragma unroll
+    for (int k = 0; k < KEEP; ++k) {
+        const int m = mbeg + iy + k * COOP_TY;
+        if (m < mend) {
+            float gv[CE], xv[CE], o[CE];
+            TR::unpack(qd[k], gv);
+            TR::unpack(qx[k], xv);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) gv[e] = ((mk >> (k * 8 + e)) & 1ull) ? gv[e] : gv[e] * sl;      // the arithmetic of load_g
+            if (p.dres) *(uint4*)((T*)p.dres + (long)m * p.lddres + c0) = TR::pack(gv);
+            if (p.dx) {
+#pragma unroll
+                for (int e = 0; e < CE; ++e) {
+                    const float xh = (xv[e] - mu[e]) * is[e];
+                    float v = sc[e] * (gv[e] - sg[e] - xh * sgx[e]);
+                    if (p.mask_x_pos && !(xv[e] > 0.f)) v = 0.f;
+                    o[e] = v;
+                }
+                *(uint4*)((T*)p.dx + (long)m * p.lddx + c0) = TR::pack(o);
+            }
+        }
+    }
+}
+
+static int g_bn_coop = [] { const char* e = getenv("MG_BN_COOP"); return e ? atoi(e) : 0; }();
+extern "C" int mg_set_bn_coop(int on) { const int was = g_bn_coop; g_bn_coop = on ? 1 : 0; return was; }
+struct CoopPlan { int rb, rpb, keep, groups; };
+// the one-launch form serves 16-bit layers whose rows fit the register file: C % 32 == 0, host row count, rows per thread <= 8
+static bool bn_bwd_coop_plan(const mg_rowwise_params& p, CoopPlan& pl) {
+    // OFF by default (measured, profiles/r05_ab_bn_coop.txt: 12.40 / 12.43 ms against 11.24 / 11.37 ms): a software hand-shake between the workgroups of one
+    // launch costs ~70 ns PER WORKGROUP on this part (tools/micro_gridbar.hip: +6 / +10 / +18 us for 64 / 128 / 256 workgroups, release fence + relaxed
+    // polls; 57 us with acquire polls), a kernel boundary ~1.5 us whatever the grid -- three launches beat one with a barrier inside. Kept for the record
+    // and the tests (mg_set_bn_coop / MG_BN_COOP=1).
+    if (!g_bn_coop || !mg_det_on || !MG_IS16(p.dtype) || p.m_dev || p.count_ptr || p.C % COOP_CH || p.M <= 1024 || !p.dx) return false;
+    if (p.ldx % 8 || p.lddy % 8 || p.lddx % 8 || (p.dres && p.lddres % 8) || (p.act != MG_ACT_NONE && !p.mask_from_x && (p.ldy % 8 || p.yoff % 8))) return false;
+    pl.groups = p.C / COOP_CH;
+    if (pl.groups > 64) return false;
+    int rb = 256 / pl.groups;
+    const int by_rows = (p.M + COOP_TY - 1) / COOP_TY;        // at least one row per thread row
+    if (rb > by_rows) rb = by_rows;
+    if (rb < 1) rb = 1;
+    pl.rpb = (p.M + rb - 1) / rb;
+    pl.rb = (p.M + pl.rpb - 1) / pl.rpb;
+    const int rows_per_thread = (pl.rpb + COOP_TY - 1) / COOP_TY;
+    pl.keep = rows_per_thread <= 2 ? 2 : (rows_per_thread <= 4 ? 4 : (rows_per_thread <= 8 ? 8 : 0));
+    return pl.keep != 0 && pl.rb <= 256 && 2 * (128 + pl.groups * pl.rb) <= MG_COOP_WORDS;
+}
+template <typename T>
+static int bn_bwd_coop_launch(const mg_rowwise_params& p, const CoopPlan& pl, hipStream_t st) {
+    unsigned long long* sync = (unsigned long long*)mg_coop_sync();
+    float* slots = mg_det_scratch((long)pl.groups * pl.rb * 2 * COOP_CH);
+    if (!sync || !slots) return MG_DET_NO_SCRATCH;
+    dim3 grid(pl.rb, pl.groups);
+    if (pl.keep == 2) hipLaunchKernelGGL((bn_bwd_coop_kernel<T, 2>), grid, dim3(NT), 0, st, p, pl.rb, pl.rpb, sync, slots);
+    else if (pl.keep == 4) hipLaunchKernelGGL((bn_bwd_coop_kernel<T, 4>), grid, dim3(NT), 0, st, p, pl.rb, pl.rpb, sync, slots);
+    else hipLaunchKernelGGL((bn_bwd_coop_kernel<T, 8>), grid, dim3(NT), 0, st, p, pl.rb, pl.rpb, sync, slots);
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int mg_bn_train_bwd(const mg_rowwise_params* p, int sums_zeroed, void* stream) {
     int rc = rowwise_check(p); if (rc) return rc;
     if (bn_small_ok(*p) && p->lddy % (MG_IS16(p->dtype) ? 8 : 4) == 0)
         return p->dtype == MG_BF16 ? bn_small_bwd_launch<bf16raw>(*p, (hipStream_t)stream) : p->dtype == MG_F16 ? bn_small_bwd_launch<f16raw>(*p, (hipStream_t)stream) : bn_small_bwd_launch<float>(*p, (hipStream_t)stream);
+    {
+        CoopPlan pl;
+        if (bn_bwd_coop_plan(*p, pl))                          // mid-size 16-bit layers: reduce + ordered sum + apply in ONE launch (sums are stored, not added)
+            return p->dtype == MG_BF16 ? bn_bwd_coop_launch<bf16raw>(*p, pl, (hipStream_t)stream) : bn_bwd_coop_launch<f16raw>(*p, pl, (hipStream_t)stream);
+    }
     if (!sums_zeroed) {
         hipError_t e = mg_zero_words(p->sums, 2 * p->C, (hipStream_t)stream);
         if (e != hipSuccess) return (int)e;

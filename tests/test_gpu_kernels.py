@@ -1394,3 +1394,43 @@ def test_copy_k_many_buffers_in_one_launch():
     torch.cuda.synchronize()
     for d, s_ in zip(dsts, srcs):
         assert torch.equal(d.float(), s_.to(d.dtype).float()), (d.shape, d.dtype)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('act,mask_x_pos,lazy', [(1, False, False), (2, False, True), (0, True, False), (1, False, True)])
+@pytest.mark.parametrize('M,C', [(2048, 64), (16384, 128), (65536, 64), (4096, 256), (16001, 128), (5000, 32), (1500, 512)])
+def test_batchnorm_backward_single_launch_form(M, C, act, mask_x_pos, lazy, dtype):
+    """mg_bn_train_bwd's one-launch form (round 5: bn_bwd_coop_kernel -- reduce, ordered sum and apply in ONE kernel, rows kept in registers, flag
+    hand-shake between the row blocks of a channel group) against the three-launch kernels (mg_bn_bwd_reduce + ordered sum + mg_bn_bwd_apply): same
+    dx up to the order of the fp32 sums, same dgamma / dbeta to 1e-5 relative, the residual gradient g EXACTLY; repeated launches give the same bits
+    (the generation words advance from launch to launch) and no workgroup ever gave up waiting (mg_coop_error)."""
+    import ctypes
+    from maggie_amd import kernels as K, hip
+    dev = _dev()
+    rs = np.random.RandomState(M % 1000 + C + act)
+    x = torch.from_numpy(rs.normal(0.2, 1.3, (M, C)).astype(np.float32)).to(dev, dtype)
+    dz = torch.from_numpy(rs.normal(size=(M, C)).astype(np.float32)).to(dev, dtype)
+    gamma = torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32) * rs.choice([-1.0, 1.0], C).astype(np.float32)).to(dev)
+    beta = torch.from_numpy(rs.normal(size=C).astype(np.float32)).to(dev)
+    sc, sh, mean, invstd = K.bn_finalize(K.colstats(x), M, gamma, beta, None, None, 0.1, 1e-5)
+    pack = sc._base.view(-1)
+    z = K.affine_act(x, sc, sh, act=act, slope=0.2)
+    y = None if lazy else z
+    was = hip.lib().mg_set_bn_coop(ctypes.c_int(1))          # (off by default: a hand-shake inside a launch costs more than two kernel boundaries here)
+    try:
+        outs = [K.bn_train_bwd(dz, y, x, pack, act, 0.2, True, mask_x_pos) for _ in range(4)]
+    finally:
+        hip.lib().mg_set_bn_coop(ctypes.c_int(was))
+    for dx_, dres_, s_ in outs[1:]:
+        assert torch.equal(dx_, outs[0][0]) and torch.equal(dres_, outs[0][1]) and torch.equal(s_, outs[0][2])
+    dx, dres, sums = outs[0]
+    err = ctypes.c_int(-1)
+    assert hip.lib().mg_coop_error(ctypes.byref(err)) == 0 and err.value == 0
+    # the three-launch kernels (stored activation: they know no mask_from_x): reduce -> ordered sum -> apply
+    _, _, s_ref = K.bn_backward(dz, z, x, sc, mean, invstd, M, act=act, slope=0.2, reduce_only=True)
+    dx_ref, dres_ref, _ = K.bn_backward(dz, z, x, sc, mean, invstd, M, act=act, slope=0.2, want_dres=True, mask_x_pos=mask_x_pos, sums=s_ref, apply_only=True)
+    assert torch.equal(dres, dres_ref)
+    assert torch.allclose(sums, s_ref, rtol=1e-5, atol=1e-5 * float(s_ref.abs().max()))
+    tol = 8e-3 if dtype == torch.bfloat16 else 1e-3                       # one storage ulp where the sums' last bits move a rounding boundary
+    assert (dx.float() - dx_ref.float()).abs().max() <= tol * dx_ref.float().abs().max()
+    assert float((dx != dx_ref).float().mean()) <= 2e-3
