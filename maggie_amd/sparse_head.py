@@ -115,6 +115,13 @@ def _wgrad_l(x, dy, cout, rows, dtype, park=None, xf=None):
                         out_dtype=dtype, rows=rows, park=park, xf=xf)
 
 
+# The operand path for the head's BatchNorm1d layers is built and bit-exact (tests/test_gpu_conv.py::test_operand_transform_on_the_sparse_row_matrices,
+# the model-level equality test runs with it on) but OFF by default: a gather 3x3 reads every neighbour row once PER TAP, so the transform runs nine times per
+# element (the dense halo form transforms a staged pixel once) -- measured on the headline step: persistent gather kernels 0.635 -> 0.788 ms, per-tap weight
+# gradients +0.03 ms, against 0.086 ms of apply passes saved (profiles/r05_trace_summary.txt vs r05_trace_summary_sparse_xf.txt). MAGGIE_LAZY_BN_SPARSE=1.
+LAZY_SPARSE = __import__('os').environ.get('MAGGIE_LAZY_BN_SPARSE', '0') != '0'
+
+
 class _BN:
     """BatchNorm1d over the live rows of a (capacity x C) matrix: training (batch statistics, running-stat update, optional SyncBN
     exchange) or eval (running statistics); keeps what its backward needs."""
@@ -131,7 +138,7 @@ class _BN:
         self.x = x
         self.xf = None
         self.group = MF._sync_group(bn) if self.training else None
-        if lazy and MF.LAZY_BN and self.training and self.group is None and x.dtype != torch.float32:
+        if lazy and MF.LAZY_BN and LAZY_SPARSE and self.training and self.group is None and x.dtype != torch.float32:
             if bn.num_batches_tracked is not None and not MF.DEFER_BN_COUNTERS:
                 if MF.BN_COUNT_LOG is not None:
                     MF.BN_COUNT_LOG.append(bn.num_batches_tracked)

@@ -327,13 +327,14 @@ def test_operand_path_batchnorm_gives_the_bits_of_the_stored_form(kind, size):
     on load, the BatchNorm backward re-forms the activation mask from the raw conv output. That must change NOTHING: the same bf16 training step
     with the operand path on and off gives identical outputs, losses, gradients and buffers (eager, and replayed from hipGraphs), and the lazy
     path really ran (the apply kernel is launched for fewer layers)."""
-    from maggie_amd import functional as MF, hip
+    from maggie_amd import functional as MF, hip, sparse_head
     from maggie_amd.utils import synth
     dev = _dev()
     n_f = 3 if kind == 'video' else 1
     model, _ = _build(kind, dev, True)
     batch = _to(synth.synthetic_batch(2 if kind == 'image' else 1, n_f, 2, size, size, seed=DSEED, train=True, max_inst=10, it=10000), dev)
     state = copy.deepcopy(model.state_dict())
+    sparse_was, sparse_head.LAZY_SPARSE = sparse_head.LAZY_SPARSE, True      # the sparse head's (off-by-default) operand path is held to the same equality
     calls = {}
     orig_call = hip.call
 
@@ -371,6 +372,7 @@ def test_operand_path_batchnorm_gives_the_bits_of_the_stored_form(kind, size):
     finally:
         hip.call = MF.K.hip.call = orig_call
         MF.LAZY_BN = True
+        sparse_head.LAZY_SPARSE = sparse_was
         for store in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs'):
             model.__dict__.get(store, {}).clear()
 
