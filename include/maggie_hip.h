@@ -411,6 +411,13 @@ int mg_spectral_norm_batched(const mg_sn_desc* descs, int n_conv, const int32_t*
  * dot_part: n3 floats of scratch (per-tile partials of <G, W>). */
 int mg_spectral_norm_batched_bwd(const mg_sn_desc* descs, int n_conv, const int32_t* items_k3, int n3, const void* const* Gptrs,
                                  int g_dtype, float* work_base, float* dW_base, float* dot_part, void* stream);
+/* Round 5: the same with (a) per-conv destinations -- dWptrs: device array of n_conv float* (NULL entries / NULL array: dW_base + dw_off), so that
+ * the gradients land in the caller's own storage (the optimizer's flat buffer) without a gather copy; (b) bit 0 of a ConvTranspose weight's
+ * Gptrs entry set = that gradient is laid out like the twin, (Cin_pad, taps, Cout) -- what the role-swapped weight-gradient GEMM of a
+ * transposed convolution writes -- and is read as such (no permute + copy in front). mg_spectral_norm_batched now emits the twin of ConvTranspose
+ * weights as well (out_t_base). */
+int mg_spectral_norm_batched_bwd_to(const mg_sn_desc* descs, int n_conv, const int32_t* items_k3, int n3, const void* const* Gptrs,
+                                    int g_dtype, float* work_base, float* dW_base, float* const* dWptrs, float* dot_part, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Temporal (video) elementwise kernels. Rows x channels (NHWC) in `dtype`; rz = first gate conv's output (M, 2C) = [r | z] before

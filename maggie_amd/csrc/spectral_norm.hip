@@ -362,6 +362,27 @@ __global__ __launch_bounds__(NT) void snb_finish_kernel(const mg_sn_desc* __rest
                 ElemTraits<T>::st(out + ((long)(t.b0 + bl) * taps + tap) * d.pad_in + t.a0 + al, v);
             }
         }
+        if (out_t_base) {
+            // the twin the data-gradient convolution of a ConvTranspose reads: out_t[ci = a][tap][co = b], the parameter's own index order with the
+            // taps moved in front of the output channels -- runs of nb output channels (round 5: was a strided permute + copy per step and layer)
+            T* ot = out_t_base + d.out_off;
+            if (sn_vec_ok<T>(ot, Cout, t.nb, t.b0)) {
+                sn_store_rows<T>(ot, t.na * taps, t.nb, [&](int r) { return ((long)(t.a0 + r / taps) * taps + r % taps) * Cout + t.b0; },
+                                 [&](int r, int bl) { return sT[(r / taps) * SN_PITCH + bl * taps + r % taps]; });
+            } else {
+                for (int i = threadIdx.x; i < t.na * taps * t.nb; i += NT) {
+                    const int bl = i % t.nb, r = i / t.nb, tap = r % taps, al = r / taps;
+                    ElemTraits<T>::st(ot + ((long)(t.a0 + al) * taps + tap) * Cout + t.b0 + bl, sT[al * SN_PITCH + bl * taps + tap]);
+                }
+            }
+            if (t.a0 + t.na == d.A) {                        // padded input channels of the twin: zero rows
+                const int extra = d.pad_in - d.A;
+                for (int i = threadIdx.x; i < extra * taps * t.nb; i += NT) {
+                    const int bl = i % t.nb, r = i / t.nb;
+                    ElemTraits<T>::st(ot + ((long)d.A * taps + r) * Cout + t.b0 + bl, 0.f);
+                }
+            }
+        }
     }
     (void)Cin;
 }
@@ -385,11 +406,31 @@ __global__ __launch_bounds__(NT) void snb_vectors_kernel(const mg_sn_desc* __res
 }
 
 // KRSC-side gradient G[co][tap][ci_pad] of a tile -> sT[al][bl * taps + tap] (read in G's own order: channel runs)
+// `twin` (ConvTranspose weights only): G is laid out like the twin, G[ci = a][tap][co = b] -- what the role-swapped weight-gradient GEMM of a
+// transposed convolution writes; read in runs of output channels (was: a strided permute + copy into the (Cout, taps, Cin) layout per step)
 template <typename T>
-__device__ __forceinline__ void sn_load_grad_tile(const mg_sn_desc& d, const SnTile& t, const T* __restrict__ G, float* sT) {
+__device__ __forceinline__ void sn_load_grad_tile(const mg_sn_desc& d, const SnTile& t, const T* __restrict__ G, float* sT, bool twin = false) {
     const int taps = d.taps;
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
+    if (twin) {
+        if (sn_vec_ok<T>(G, d.B, t.nb, t.b0)) {
+            const int cpr = t.nb / CE;
+            for (int i = threadIdx.x; i < t.na * taps * cpr; i += NT) {
+                const int cc = i % cpr, r = i / cpr, tap = r % taps, al = r / taps;
+                float v[CE];
+                TR::unpack(*(const uint4*)(G + ((long)(t.a0 + al) * taps + tap) * d.B + t.b0 + cc * CE), v);
+#pragma unroll
+                for (int e = 0; e < CE; ++e) sT[al * SN_PITCH + (cc * CE + e) * taps + tap] = v[e];
+            }
+            return;
+        }
+        for (int i = threadIdx.x; i < t.na * taps * t.nb; i += NT) {
+            const int bl = i % t.nb, r = i / t.nb, tap = r % taps, al = r / taps;
+            sT[al * SN_PITCH + bl * taps + tap] = ElemTraits<T>::ld(G + ((long)(t.a0 + al) * taps + tap) * d.B + t.b0 + bl);
+        }
+        return;
+    }
     if (!d.transposed) {
         if (sn_vec_ok<T>(G, d.pad_in, t.nb, t.b0)) {             // 16-byte loads along the channel runs
             const int cpr = t.nb / CE;
@@ -433,10 +474,11 @@ __global__ __launch_bounds__(NT) void snb_bwd_dot_kernel(const mg_sn_desc* __res
     __shared__ float sh[NT / 64];
     const int4 it = items[blockIdx.x];                       // (conv, a tile, b tile, -)
     const mg_sn_desc d = descs[it.x];
-    const T* G = (const T*)Gptrs[it.x];
+    const size_t graw = (size_t)Gptrs[it.x];                 // bit 0: twin layout (ConvTranspose weights, see sn_load_grad_tile)
+    const T* G = (const T*)(graw & ~(size_t)1);
     if (!G || d.plain) { if (threadIdx.x == 0) dot_part[blockIdx.x] = 0.f; return; }
     const SnTile t = sn_tile(d, it);
-    sn_load_grad_tile<T>(d, t, G, sT);
+    sn_load_grad_tile<T>(d, t, G, sT, (graw & 1) && d.transposed);
     __syncthreads();
     float acc = 0.f;
     const int run = t.nb * d.taps;
@@ -452,17 +494,20 @@ __global__ __launch_bounds__(NT) void snb_bwd_dot_kernel(const mg_sn_desc* __res
 template <typename T>
 __global__ __launch_bounds__(NT) void snb_bwd_apply_kernel(const mg_sn_desc* __restrict__ descs, const int4* __restrict__ items,
                                                            const void* const* __restrict__ Gptrs, const float* __restrict__ work_base,
-                                                           float* __restrict__ dW_base, const float* __restrict__ dot_part) {
+                                                           float* __restrict__ dW_base, float* const* __restrict__ dWptrs,
+                                                           const float* __restrict__ dot_part) {
     __shared__ float sT[SN_TA * SN_PITCH];
     __shared__ float sh4[4];
     const int4 it = items[blockIdx.x];
     const mg_sn_desc d = descs[it.x];
-    const T* G = (const T*)Gptrs[it.x];
+    const size_t graw = (size_t)Gptrs[it.x];
+    const T* G = (const T*)(graw & ~(size_t)1);
     const int Wd = d.B * d.taps;
     const float* v = work_base + d.work_off;
     const float* u = v + Wd;
     const float* scratch = u + d.A;
     float* dW = dW_base + d.dw_off;
+    if (dWptrs && dWptrs[it.x]) dW = dWptrs[it.x];           // the caller's own destination (the optimizer's flat gradient buffer)
     const SnTile t = sn_tile(d, it);
     const int run = t.nb * d.taps;
     if (!G) {
@@ -472,7 +517,7 @@ __global__ __launch_bounds__(NT) void snb_bwd_apply_kernel(const mg_sn_desc* __r
         }
         return;
     }
-    sn_load_grad_tile<T>(d, t, G, sT);
+    sn_load_grad_tile<T>(d, t, G, sT, (graw & 1) && d.transposed);
     __syncthreads();
     if (d.plain) {                                           // plain conv: the gradient itself, back in the parameter's layout
         for (int i = threadIdx.x; i < t.na * run; i += NT) {
@@ -513,23 +558,30 @@ extern "C" int mg_spectral_norm_batched(const mg_sn_desc* descs, int n_conv, con
     return 0;
 }
 
-// Gptrs: device array of n_conv pointers to the weight gradients in the (Cout, taps, pad_in) layout (NULL = no gradient);
-// work_base: the forward's work buffer; dW_base: fp32 output, conv c at descs[c].dw_off laid out like the parameter.
-extern "C" int mg_spectral_norm_batched_bwd(const mg_sn_desc* descs, int n_conv, const int32_t* items_k3, int n3, const void* const* Gptrs,
-                                            int g_dtype, float* work_base, float* dW_base, float* dot_part, void* stream) {
+// Gptrs: device array of n_conv pointers to the weight gradients in the (Cout, taps, pad_in) layout (NULL = no gradient; bit 0 set on a
+// ConvTranspose weight's entry: the gradient is in the twin's (Cin_pad, taps, Cout) layout); work_base: the forward's work buffer;
+// dW_base: fp32 output, conv c at descs[c].dw_off laid out like the parameter -- unless dWptrs (device array of n_conv float*, or NULL) names
+// another destination for it.
+extern "C" int mg_spectral_norm_batched_bwd_to(const mg_sn_desc* descs, int n_conv, const int32_t* items_k3, int n3, const void* const* Gptrs,
+                                               int g_dtype, float* work_base, float* dW_base, float* const* dWptrs, float* dot_part, void* stream) {
     if (n_conv <= 0) return 0;
     if (!dot_part) return -2;
     hipStream_t st = (hipStream_t)stream;
     if (g_dtype == MG_BF16) {
         hipLaunchKernelGGL(snb_bwd_dot_kernel<bf16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, dot_part);
-        hipLaunchKernelGGL(snb_bwd_apply_kernel<bf16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, work_base, dW_base, dot_part);
+        hipLaunchKernelGGL(snb_bwd_apply_kernel<bf16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, work_base, dW_base, dWptrs, dot_part);
     } else if (g_dtype == MG_F16) {
         hipLaunchKernelGGL(snb_bwd_dot_kernel<f16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, dot_part);
-        hipLaunchKernelGGL(snb_bwd_apply_kernel<f16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, work_base, dW_base, dot_part);
+        hipLaunchKernelGGL(snb_bwd_apply_kernel<f16raw>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, work_base, dW_base, dWptrs, dot_part);
     } else {
         hipLaunchKernelGGL(snb_bwd_dot_kernel<float>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, dot_part);
-        hipLaunchKernelGGL(snb_bwd_apply_kernel<float>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, work_base, dW_base, dot_part);
+        hipLaunchKernelGGL(snb_bwd_apply_kernel<float>, dim3(n3), dim3(NT), 0, st, descs, (const int4*)items_k3, Gptrs, work_base, dW_base, dWptrs, dot_part);
     }
     MG_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int mg_spectral_norm_batched_bwd(const mg_sn_desc* descs, int n_conv, const int32_t* items_k3, int n3, const void* const* Gptrs,
+                                            int g_dtype, float* work_base, float* dW_base, float* dot_part, void* stream) {
+    return mg_spectral_norm_batched_bwd_to(descs, n_conv, items_k3, n3, Gptrs, g_dtype, work_base, dW_base, nullptr, dot_part, stream);
 }

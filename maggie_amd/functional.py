@@ -41,6 +41,9 @@ class ZeroArena:
     def reset(self, device):
         self.epoch += 1
         del PARKED[:]                                             # leftovers of a backward pass that was abandoned halfway
+        for g_ in _OPEN_GROUPS:
+            g_.reset()
+        del _OPEN_GROUPS[:]
         self.need = max(self.need, self.used + (1 << 16))
         if self.buf is None or self.buf.device != device or self.buf.numel() < self.need:
             self.buf = torch.zeros(self.need, dtype=torch.float32, device=device)
@@ -201,6 +204,9 @@ SIDE_WGRAD = os.environ.get('MAGGIE_SIDE_WGRAD', '0') == '1'
 # Only weights used by exactly one convolution call of the step are parked (autograd would add the gradients of a second use before the join).
 PARK_WGRAD = os.environ.get('MAGGIE_PARK_WGRAD', '1') != '0'
 PARKED = []
+# id(parameter) -> fp32 tensor its gradient should be WRITTEN to (set by graphs.GraphedCallable around the backward capture when the optimizer
+# offers a gradient sink). Producers that know it (SpectralNormBatch.backward) write there and return that very tensor as the gradient.
+GRAD_DEST = {}
 
 
 def flush_parked():
@@ -212,6 +218,14 @@ def _parked_must_be_flushed():
     """Runs when the autograd engine has finished the backward pass (or the captured backward) in which something was parked: every parked slab
     reduction must have met its join (SpectralNormBatch.backward / WeightBank.backward) INSIDE that pass -- otherwise a dW left this pass as
     unreduced slabs (a graph split that puts the join into another graph would replay the GEMMs without ever reducing them). ADVICE round 4."""
+    if _OPEN_GROUPS:
+        n = len(_OPEN_GROUPS)
+        for g in _OPEN_GROUPS:
+            g.reset()
+        del _OPEN_GROUPS[:]
+        del PARKED[:]
+        raise K.hip.MaggieHipError('%d weight(s) used by several convolution calls did not see the backward of all their uses in this pass: their '
+                                   'gradients are incomplete. Set MAGGIE_GROUP_WGRAD=0 if some uses are differentiated separately.' % n)
     if PARKED:
         n = len(PARKED)
         del PARKED[:]
@@ -227,17 +241,93 @@ def _park_list():
     return PARKED
 
 
-def _count_use(w):
+class _UseGroup:
+    """A joined weight consumed by SEVERAL convolution calls of one step (the ConvGRU gate weights: one call per frame and direction). When all
+    the calls are plain convolutions of ONE geometry, their weight-gradient GEMMs write their row-split slabs side by side into one workspace
+    and the LAST of them to run parks ONE reduction over all the slabs -- instead of one reduce launch per call plus the autograd engine's
+    pairwise adds of the per-call dW (video step, T = 3, bidirectional: 10 reduce launches of 14 us + 8 adds; and the sum is formed in fp32 once
+    instead of being rounded to the weight's 16-bit type per call). The calls before the last return no gradient of their own."""
+    __slots__ = ('geoms', 'done', 'ws', 'need', 'out', 'desc', 'plain')
+
+    def __init__(self):
+        self.geoms = []
+        self.reset()
+
+    def reset(self):
+        self.done, self.ws, self.need, self.out, self.desc, self.plain = 0, None, 0, None, None, False
+
+    def uniform(self):
+        g = self.geoms
+        return len(g) > 1 and g[0] is not None and all(q == g[0] for q in g)
+
+
+GROUP_WGRAD = os.environ.get('MAGGIE_GROUP_WGRAD', '1') != '0'     # 0: every call reduces its own slabs, autograd adds the dW (A/B switch)
+_OPEN_GROUPS = []
+
+
+def _group_wgrad(grp, call):
+    """`call(out, park, park_ws)` runs this use's K.conv_wgrad. -> this use's contribution to dW: None for every use but the one that completes the
+    group (or every use's own dW when the geometry turns out to need no slab reduction)."""
+    k = len(grp.geoms)
+    if grp.plain:
+        grp.done += 1
+        if grp.done == k:
+            grp.reset()
+        return call(None, None, None)
+    first = grp.done == 0
+    tmp = []
+
+    def park_ws(need, device):
+        if grp.ws is None:
+            grp.need, grp.ws = need, torch.empty(k * need, dtype=torch.float32, device=device)
+        if need != grp.need:
+            raise K.hip.MaggieHipError('grouped weight gradient: the workspace size changed between the uses of one weight (%d != %d)' % (need, grp.need))
+        return grp.ws[grp.done * need:(grp.done + 1) * need]
+
+    out = call(grp.out, tmp, park_ws)
+    if first:
+        d = tmp[0][0] if tmp else None
+        if d is None or d.splits * d.n != grp.need or d.ws != grp.ws.data_ptr():
+            # no slab reduction for this geometry (dW was written directly), or slabs that do not tile the workspace: every use on its own
+            if tmp:
+                K.wgrad_reduce_batched(tmp)
+            grp.reset()
+            grp.plain, grp.done = True, 1
+            if k == 1:
+                grp.reset()
+            return out
+        grp.out, grp.desc = out, d
+        if not _OPEN_GROUPS and not PARKED:
+            torch.autograd.Variable._execution_engine.queue_callback(_parked_must_be_flushed)
+        _OPEN_GROUPS.append(grp)
+    grp.done += 1
+    if grp.done < k:
+        return None
+    d = K.hip.WgradParked()
+    for f, _ in d._fields_:
+        setattr(d, f, getattr(grp.desc, f))
+    d.splits = grp.desc.splits * k                                # the k calls' slabs lie back to back: one reduction over all of them
+    _park_list().append((d, grp.ws, grp.out))
+    out = grp.out
+    _OPEN_GROUPS.remove(grp)
+    grp.reset()
+    return out
+
+
+def _count_use(w, geom=None):
     """-> the per-step use counter of a joined weight (a one-element list shared by every autograd Function of this module that consumes `w`:
     ConvRaw in every mode -- also the transposed and side-stream forms, which never park themselves -- and GatherConv), or None. A weight is
-    parked only when this counter says its dW has ONE producer: autograd would add a second producer's gradient into the unreduced slabs."""
+    parked only when this counter says its dW has ONE producer: autograd would add a second producer's gradient into the unreduced slabs.
+    `geom`: what a plain convolution call looks like to the grouped form above (None: this use can not take part)."""
     if not (PARK_WGRAD and getattr(w, '_mg_join', False)):
         return None
     cnt = getattr(w, '_mg_uses', None)
     if cnt is None:
         cnt = [0]
         w._mg_uses = cnt
+        w._mg_group = _UseGroup()
     cnt[0] += 1
+    w._mg_group.geoms.append(geom)
     return cnt
 _SIDE_STREAMS = {}
 _FORKED = []
@@ -510,6 +600,7 @@ class SpectralNormBatch(torch.autograd.Function):
              c_int(plan.k2.shape[0]), K.hip.ptr(plan.k3), c_int(plan.k3.shape[0]), K.hip.ptr(work), K.c_long(plan.total_work), K.hip.ptr(out),
              K.hip.ptr(out_t), c_int(K.hip.dtype_code(out)), K.hip.stream())
         ctx.plan = plan
+        ctx.w_ids = tuple(id(w) for w in w_bars)                  # GRAD_DEST lookups in backward()
         ctx.save_for_backward(work)
         outs = tuple(out[o:o + n].view(sh[0], sh[1], sh[2]) for (o, n), sh in zip(plan.out_slices, plan.shapes))
         for t_, src in zip(outs, plan.sources):
@@ -517,10 +608,10 @@ class SpectralNormBatch(torch.autograd.Function):
             t_._mg_join = True
             t_._mg_cin = src[4]                                   # real (unpadded) input channels: algorithmic-FLOP accounting of the bench
         if out_t is not None:
-            # (Cin_pad, taps, Cout) twins for the data-gradient convolution ride along as a Python attribute of each weight
+            # (Cin_pad, taps, Cout) twins for the data-gradient convolution ride along as a Python attribute of each weight (ConvTranspose
+            # weights too since round 5: their twin was a strided permute + copy of up to 8 MB per step in ConvRaw.backward)
             for t_, (o, n), sh, src in zip(outs, plan.out_slices, plan.shapes, plan.sources):
-                if not src[3]:
-                    t_._mg_wt = out_t[o:o + n].view(sh[2], sh[1], sh[0])
+                t_._mg_wt = out_t[o:o + n].view(sh[2], sh[1], sh[0])
         return outs
 
     @staticmethod
@@ -530,23 +621,47 @@ class SpectralNormBatch(torch.autograd.Function):
         dev = work.device
         join_side()                                               # the weight-gradient GEMMs ran on the side stream
         flush_parked()                                            # ... and their slab reductions were parked until here
-        keep = [None if g is None else g.to(plan.dtype).contiguous() for g in grads]
-        host_ptrs = torch.tensor([0 if g is None else g.data_ptr() for g in keep], dtype=torch.int64)
+        n = len(grads)
+        keep, table = [], [0] * (2 * n)
+        for i, (g, src) in enumerate(zip(grads, plan.sources)):
+            if g is None:
+                keep.append(None)
+                continue
+            if g.dtype != plan.dtype:
+                g = g.to(plan.dtype)
+            if src[3] and g.dim() == 3 and not g.is_contiguous() and g.permute(2, 1, 0).is_contiguous():
+                # a ConvTranspose weight's gradient as its role-swapped GEMM wrote it, (Cin_pad, taps, Cout): read in that layout (bit 0 of the entry)
+                g = g.permute(2, 1, 0)
+                table[i] = g.data_ptr() | 1
+            else:
+                g = g.contiguous()
+                table[i] = g.data_ptr()
+            keep.append(g)
+        # destinations named by the caller (graphs.GraphedCallable with a gradient sink: slices of the optimizer's flat gradient buffer) -- the
+        # kernel writes there, the capture's closing multi-tensor copy has nothing left to move for these parameters (~110 MB per step)
+        dests = [None] * n
+        if GRAD_DEST:
+            for i, (wid, (_o, cnt)) in enumerate(zip(ctx.w_ids, plan.dw_slices)):
+                d = GRAD_DEST.get(wid)
+                if d is not None and d.dtype == torch.float32 and d.is_contiguous() and d.numel() == cnt and d.device == dev:
+                    dests[i] = d
+                    table[n + i] = d.data_ptr()
+        host_ptrs = torch.tensor(table, dtype=torch.int64)
         if torch.cuda.is_current_stream_capturing():
             # no host->device traffic inside a capture: the table is carved from a buffer the graph builder allocated
             # BEFORE the capture (memory allocated during a capture is recycled between the nodes of the graphs sharing
             # its pool, so it cannot hold constants) and is filled once, right after the capture ends -- the gradient
             # addresses are fixed for the life of the graph
-            ptrs = capture_table(len(keep))
+            ptrs = capture_table(2 * n)
             CAPTURE_FIXUPS.append((ptrs, host_ptrs))
         else:
             ptrs = host_ptrs.to(dev, non_blocking=True)
         dW = torch.empty(plan.total_dw, dtype=torch.float32, device=dev)
         dot_part = torch.empty(plan.k3.shape[0], dtype=torch.float32, device=dev)      # per-tile partials of <G, W>, added in tile order
-        K.hip.call('mg_spectral_norm_batched_bwd', K.hip.ptr(plan.descs), K.c_int(plan.n), K.hip.ptr(plan.k3), K.c_int(plan.k3.shape[0]),
-                   K.hip.ptr(ptrs), K.c_int(K.hip.code_of(plan.dtype)), K.hip.ptr(work), K.hip.ptr(dW), K.hip.ptr(dot_part),
-                   K.hip.stream())
-        outs = tuple(dW[o:o + n].view(sh[3]) for (o, n), sh in zip(plan.dw_slices, plan.shapes))
+        K.hip.call('mg_spectral_norm_batched_bwd_to', K.hip.ptr(plan.descs), K.c_int(plan.n), K.hip.ptr(plan.k3), K.c_int(plan.k3.shape[0]),
+                   K.hip.ptr(ptrs), K.c_int(K.hip.code_of(plan.dtype)), K.hip.ptr(work), K.hip.ptr(dW),
+                   K.hip.ptr(ptrs[n:]) if any(d is not None for d in dests) else None, K.hip.ptr(dot_part), K.hip.stream())
+        outs = tuple((dW[o:o + cnt] if d is None else d).view(sh[3]) for (o, cnt), sh, d in zip(plan.dw_slices, plan.shapes, dests))
         return (None,) + outs
 
 
@@ -752,8 +867,10 @@ class ConvRaw(torch.autograd.Function):
         y = y.view(N, Ho, Wo, Cout)
         ctx.wt = getattr(w, '_mg_wt', None)                       # pre-transposed weights from the batched SpectralNorm kernel
         ctx.side = SIDE_WGRAD and getattr(w, '_mg_side_wgrad', False) and not transposed
-        ctx.uses = _count_use(w)                                  # every use counts; only the plain form below ever parks
         ctx.can_park = not (transposed or ctx.side)
+        # every use counts; only the plain form below ever parks (alone, or with the other uses of the same weight: _UseGroup)
+        ctx.uses = _count_use(w, (N, H, W_, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, x.dtype, ctx.cin_real) if ctx.can_park else None)
+        ctx.group = getattr(w, '_mg_group', None) if ctx.uses is not None else None
         # mask_upstream: the BatchNorm behind this conv's ReLU applies the ReLU mask in its own backward pass (mask_x_pos), y is not needed
         ctx.save_for_backward(x, w, y if (pre_relu and not ctx.mask_upstream) else None)
         ctx.geom = (N, H, W_, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, transposed, pre_relu, bias is not None)
@@ -775,7 +892,7 @@ class ConvRaw(torch.autograd.Function):
         if mask_here or want_db:                                  # ReLU mask and bias gradient in one pass
             dy2, db = K.bias_act_bwd(dy2, y.view(-1, Cout) if mask_here else None, want_db)
         if ctx.needs_input_grad[0]:
-            wt = ctx.wt if (ctx.wt is not None and not transposed) else w.permute(2, 1, 0).contiguous()      # (Cin, taps, Cout)
+            wt = ctx.wt if ctx.wt is not None else w.permute(2, 1, 0).contiguous()      # (Cin, taps, Cout)
             dmode = MODE_CONV if transposed else MODE_TCONV
             r2 = None if d_carry is None else d_carry.to(dy2.dtype).contiguous().view(-1, Cin)
             link, bnb, sums_rep = ctx.link, None, None
@@ -804,14 +921,20 @@ class ConvRaw(torch.autograd.Function):
                 dy2.record_stream(side)
                 dw.record_stream(main)
             elif not transposed:
-                park = _park_list() if (ctx.can_park and ctx.uses is not None and ctx.uses[0] == 1) else None
-                dw = K.conv_wgrad(x.view(-1, Cin), dy2, cout=Cout, mode=MODE_CONV, N=N, Hin=H, Win=W_, Hout=Ho, Wout=Wo,
-                                  R=R, S=S, stride=stride, pad=pad, dil=dil, out_dtype=w.dtype, alg_cin=ctx.cin_real, park=park, xf=ctx.xf)
+                def wgrad(out, park, park_ws):
+                    return K.conv_wgrad(x.view(-1, Cin), dy2, cout=Cout, mode=MODE_CONV, N=N, Hin=H, Win=W_, Hout=Ho, Wout=Wo, R=R, S=S, stride=stride,
+                                        pad=pad, dil=dil, out=out, out_dtype=w.dtype, alg_cin=ctx.cin_real, park=park, xf=ctx.xf, park_ws=park_ws)
+                single = ctx.can_park and ctx.uses is not None and ctx.uses[0] == 1
+                if not single and GROUP_WGRAD and ctx.can_park and ctx.group is not None and ctx.group.uniform():
+                    dw = _group_wgrad(ctx.group, wgrad)           # several calls, one geometry: one reduction over all their slabs
+                else:
+                    dw = wgrad(None, _park_list() if single else None, None)
             else:
                 # dW[ci, tap, co] = sum_o x[o, ci] * dy[2o - pad + k, co]  (roles of x and dy swapped)
                 dwt = K.conv_wgrad(dy2, x.view(-1, Cin), cout=Cin, mode=MODE_CONV, N=N, Hin=Ho, Win=Wo, Hout=H, Wout=W_,
                                    R=R, S=S, stride=stride, pad=pad, dil=dil, out_dtype=w.dtype)
-                dw = dwt.permute(2, 1, 0).contiguous()
+                # the batched weight pipeline's backward reads this gradient in the layout it was written in (a permuted view, no copy)
+                dw = dwt.permute(2, 1, 0) if getattr(w, '_mg_join', False) else dwt.permute(2, 1, 0).contiguous()
         return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None
 
 
@@ -1770,6 +1893,73 @@ def temporal_crop_(alpha, bits, sigma=3, thr=0.1, pad=30):
 # token side of the instance matte decoder (maggie_amd/csrc/token_side.hip)
 # ----------------------------------------------------------------------------------------------------------------------
 
+class GradSlots:
+    """One buffer per backward pass that will hold the gradients of the k slices of a PACKED parameter (nn.MultiheadAttention's in_proj_weight /
+    in_proj_bias). The kernels that produce a slice's gradient write it into the buffer's slice (grad_slot_out) and return that very view;
+    SplitPacked.backward then hands the buffer back as the packed parameter's gradient -- no `stack` of three separate tensors (18 copy launches
+    per training step over the nine attention layers of the instance matte decoder)."""
+    __slots__ = ('k', 'buf', 'taken')
+
+    def __init__(self, k):
+        self.k, self.buf, self.taken = k, None, set()
+
+
+def grad_slot_out(slot, shape, device):
+    """-> the fp32 destination inside the packed buffer for a gradient of `shape`, or None (no slot / already handed out in this pass / another shape):
+    the caller then allocates its own tensor and SplitPacked.backward falls back to stacking."""
+    if slot is None:
+        return None
+    holder, i = slot
+    shape = tuple(shape)
+    if i in holder.taken:
+        return None
+    if holder.buf is None:
+        holder.buf = torch.empty((holder.k,) + shape, dtype=torch.float32, device=device)
+    elif tuple(holder.buf.shape[1:]) != shape or holder.buf.device != device:
+        return None
+    holder.taken.add(i)
+    return holder.buf[i]
+
+
+class SplitPacked(torch.autograd.Function):
+    """P (k * d, ...) -> its k slices (views). Backward: the slices' gradients, already sitting in the slices of ONE buffer when their producers took
+    the offered slots (GradSlots), else stacked."""
+
+    @staticmethod
+    def forward(ctx, P, k, holder):
+        ctx.set_materialize_grads(False)
+        ctx.holder, ctx.k, ctx.shape = holder, k, P.shape
+        v = P.view(k, P.shape[0] // k, *P.shape[1:])
+        return tuple(v[i] for i in range(k))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        holder = ctx.holder
+        buf, holder.buf = holder.buf, None
+        holder.taken.clear()
+        if buf is not None and all(g is not None and g.dtype == buf.dtype and g.shape == buf.shape[1:] and g.data_ptr() == buf[i].data_ptr()
+                                   for i, g in enumerate(gs)):
+            return buf.view(ctx.shape), None, None
+        live = [g for g in gs if g is not None]
+        if not live:
+            return None, None, None
+        return torch.stack([g if g is not None else torch.zeros_like(live[0]) for g in gs]).view(ctx.shape), None, None
+
+
+GRAD_SLOTS = os.environ.get('MAGGIE_GRAD_SLOTS', '1') != '0'      # 0: unbind + stack (A/B switch)
+
+
+def split_packed(P, k):
+    """The k equal slices of a packed parameter along dim 0, each carrying the slot its gradient should be written to (`_mg_gslot`)."""
+    if not (GRAD_SLOTS and P.requires_grad and torch.is_grad_enabled() and P.is_cuda and P.dtype == torch.float32):
+        return P.view(k, P.shape[0] // k, *P.shape[1:]).unbind(0)
+    holder = GradSlots(k)
+    outs = SplitPacked.apply(P, k, holder)
+    for i, o in enumerate(outs):
+        o._mg_gslot = (holder, i)
+    return outs
+
+
 class TokenLinear(torch.autograd.Function):
     """y = LN( res + act( (x + xadd) W^T + b ) ) over (..., K) -> (..., N) fp32; every optional piece may be None. One HIP launch each way
     (the reference: up to 2 adds + cuBLAS + bias + ReLU + add + LayerNorm forward, twice that backward)."""
@@ -1795,6 +1985,7 @@ class TokenLinear(torch.autograd.Function):
                    K.c_int(N), K.c_int(int(bool(wt))), K.hip.stream())
         ctx.save_for_backward(x2, xa, W_, y if relu else None, g_, z, rstat)
         ctx.wt = bool(wt)
+        ctx.gslots = (getattr(W, '_mg_gslot', None), getattr(b, '_mg_gslot', None))      # slices of a packed parameter: gradients go into its buffer
         ctx.meta = (shape, R, Kd, N, bool(relu), b is not None, res is not None, None if xadd is None else xadd.shape)
         return y.view(*shape[:-1], N)
 
@@ -1806,8 +1997,14 @@ class TokenLinear(torch.autograd.Function):
         dy2 = dy.float().contiguous().view(R, N)
         need_dx = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         dx = torch.empty((R, Kd), dtype=torch.float32, device=dev) if need_dx else None
-        dW = torch.empty((Kd, N) if ctx.wt else (N, Kd), dtype=torch.float32, device=dev)
-        db = torch.empty(N, dtype=torch.float32, device=dev) if has_b else None
+        dW = grad_slot_out(ctx.gslots[0], (Kd, N) if ctx.wt else (N, Kd), dev)
+        if dW is None:
+            dW = torch.empty((Kd, N) if ctx.wt else (N, Kd), dtype=torch.float32, device=dev)
+        db = None
+        if has_b:
+            db = grad_slot_out(ctx.gslots[1], (N,), dev)
+            if db is None:
+                db = torch.empty(N, dtype=torch.float32, device=dev)
         plain = g_ is None and not relu                      # dz == dy: no dz kernel, the residual gradient IS dy
         dres = torch.empty((R, N), dtype=torch.float32, device=dev) if (has_res and not plain) else None
         dgb = torch.empty(2 * N, dtype=torch.float32, device=dev) if g_ is not None else None
@@ -1843,6 +2040,7 @@ class FanOut(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t, k):
         ctx.set_materialize_grads(False)
+        ctx.gslot = getattr(t, '_mg_gslot', None)                 # a slice of a packed parameter: the sum is written into the packed buffer's slice
         return tuple(t.view_as(t) for _ in range(k))
 
     @staticmethod
@@ -1850,6 +2048,11 @@ class FanOut(torch.autograd.Function):
         live = [g for g in gs if g is not None]
         if not live:
             return None, None
+        if ctx.gslot is not None and len(live) > 1 and all(g.is_cuda and g.dtype == torch.float32 and g.shape == live[0].shape for g in live) \
+                and len(live) <= 16:
+            out = grad_slot_out(ctx.gslot, live[0].shape, live[0].device)
+            if out is not None:
+                return K.sum_k([g.contiguous() for g in live], out=out), None
         ok = all(g.is_cuda and g.dtype == torch.float32 and g.shape == live[0].shape for g in live)
         if not ok:
             total = live[0]
@@ -1870,7 +2073,8 @@ class Fan:
 
     def __init__(self, t, k):
         self.t = t
-        use = FAN_OUT and t is not None and torch.is_grad_enabled() and t.requires_grad and t.is_cuda and t.dtype == torch.float32 and k > 2
+        use = FAN_OUT and t is not None and torch.is_grad_enabled() and t.requires_grad and t.is_cuda and t.dtype == torch.float32 and \
+            (k > 2 or (k == 2 and getattr(t, '_mg_gslot', None) is not None))
         self.outs = list(FanOut.apply(t, k)) if use else None
 
     def __call__(self):
@@ -1914,7 +2118,8 @@ class TokenLinearMulti(torch.autograd.Function):
             o.y, o.z, o.rstat = K.hip.ptr(y), K.hip.ptr(z), K.hip.ptr(rstat)
             o.R, o.K, o.N, o.relu, o.wt, o.eps = R, Kd, N, int(bool(relu)), int(bool(wt)), float(eps)
             saved += [x2, xa, W_, y if relu else None, g_, z, rstat]
-            metas.append((shape, R, Kd, N, bool(relu), b is not None, res is not None, None if xadd is None else xadd.shape, bool(wt)))
+            metas.append((shape, R, Kd, N, bool(relu), b is not None, res is not None, None if xadd is None else xadd.shape, bool(wt),
+                          getattr(W, '_mg_gslot', None), getattr(b, '_mg_gslot', None)))
             outs.append(y.view(*shape[:-1], N))
         K.hip.need_cuda(*[t for t in saved if t is not None])
         K.hip.call('mg_token_linear_multi_fwd', ops, K.c_int(n), K.hip.stream())
@@ -1928,15 +2133,21 @@ class TokenLinearMulti(torch.autograd.Function):
         n = len(metas)
         ops = (K.hip.TokLin * n)()
         keep, results = [], []
-        for i, (shape, R, Kd, N, relu, has_b, has_res, xadd_shape, wt) in enumerate(metas):
+        for i, (shape, R, Kd, N, relu, has_b, has_res, xadd_shape, wt, slot_w, slot_b) in enumerate(metas):
             x2, xa, W_, yout, g_, z, rstat = saved[7 * i:7 * i + 7]
             dev = x2.device
             dy = dys[i]
             dy2 = (torch.zeros((R, N), dtype=torch.float32, device=dev) if dy is None else dy.float().contiguous().view(R, N))
             need_dx = ctx.needs_input_grad[1 + 7 * i] or ctx.needs_input_grad[2 + 7 * i]
             dx = torch.empty((R, Kd), dtype=torch.float32, device=dev) if need_dx else None
-            dW = torch.empty((Kd, N) if wt else (N, Kd), dtype=torch.float32, device=dev)
-            db = torch.empty(N, dtype=torch.float32, device=dev) if has_b else None
+            dW = grad_slot_out(slot_w, (Kd, N) if wt else (N, Kd), dev)
+            if dW is None:
+                dW = torch.empty((Kd, N) if wt else (N, Kd), dtype=torch.float32, device=dev)
+            db = None
+            if has_b:
+                db = grad_slot_out(slot_b, (N,), dev)
+                if db is None:
+                    db = torch.empty(N, dtype=torch.float32, device=dev)
             plain = g_ is None and not relu
             dres = torch.empty((R, N), dtype=torch.float32, device=dev) if (has_res and not plain) else None
             dgb = torch.empty(2 * N, dtype=torch.float32, device=dev) if g_ is not None else None

@@ -174,9 +174,17 @@ class GraphedCallable:
                     with torch.cuda.graph(self.bwd, pool=self.pool, stream=side, capture_error_mode=CAPTURE_MODE), \
                             torch.autocast('cuda', enabled=False):
                         MF.ARENA.begin_capture(dev)
-                        allg = torch.autograd.grad(
-                            [o for o in self.static_outputs if o.requires_grad], cap_params + gin,
-                            [g for g in self.static_grad_outputs if g is not None], allow_unused=True)
+                        # with a gradient sink the producers that can (the batched weight pipeline's backward) write their parameter gradients
+                        # straight into the sink's slices; _pack_grads below then only moves what did not land there
+                        dest = self.grad_sink(self.params) if self.grad_sink is not None else None
+                        if dest is not None:
+                            MF.GRAD_DEST.update({id(cp): v for cp, v in zip(cap_params, dest) if v is not None})
+                        try:
+                            allg = torch.autograd.grad(
+                                [o for o in self.static_outputs if o.requires_grad], cap_params + gin,
+                                [g for g in self.static_grad_outputs if g is not None], allow_unused=True)
+                        finally:
+                            MF.GRAD_DEST.clear()
                         self.static_param_grads = allg[:len(cap_params)]
                         self.static_input_grads = list(allg[len(cap_params):])
                         MF.join_side()                            # every forked branch must be back before the capture ends
@@ -280,7 +288,9 @@ class GraphedCallable:
                                          for v, g in zip(views, self.static_param_grads)):
                 # one multi-tensor launch: torch falls back to ONE COPY PER TENSOR for the whole list as soon as a single source is not
                 # contiguous (the video model's ConvGRU weight gradients are permuted views: 305 memcpy nodes per backward graph)
-                torch._foreach_copy_(list(views), [g if g.is_contiguous() else g.contiguous() for g in self.static_param_grads])
+                todo = [(v, g) for v, g in zip(views, self.static_param_grads) if g.data_ptr() != v.data_ptr()]     # the rest was written in place
+                if todo:
+                    torch._foreach_copy_([v for v, _ in todo], [g if g.is_contiguous() else g.contiguous() for _, g in todo])
                 self.sink_views = list(views)
                 self.sink_runs = runs if runs is not None else list(views)    # contiguous stretches of the sink covering these parameters
                 self.flat_grads, self.grad_slots = {}, []

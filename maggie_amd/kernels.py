@@ -158,13 +158,14 @@ def _fprop_workspace_fn():
 
 
 def conv_wgrad(x, dy, *, cout, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=1, Wout=1, R=1, S=1, stride=1, pad=0, dil=1,
-               M=None, nbr=None, yoff=0, out=None, out_dtype=torch.float32, rows=None, alg_cin=None, alg_cout=None, park=None, xf=None):
+               M=None, nbr=None, yoff=0, out=None, out_dtype=torch.float32, rows=None, alg_cin=None, alg_cout=None, park=None, xf=None, park_ws=None):
     """dW[co, tap, ci] = sum_m dY[m, co] X[src(m,tap), ci]; (Cout, R*S, Cin) accumulated in fp32 and written as
     `out_dtype` (fp32 / bf16 -- the converting reduce saves a separate cast pass). `dy` may be a channel slice (yoff) of
     a wider buffer.
 
     `park` (a list): the "row-split slabs -> dW" reduction is not launched; its descriptor and the slabs are appended to the list and the
-    returned dW is NOT valid until wgrad_reduce_batched(park) has run on this stream (one launch for all the parked layers)."""
+    returned dW is NOT valid until wgrad_reduce_batched(park) has run on this stream (one launch for all the parked layers).
+    `park_ws(floats, device)` -> where this call's slabs go (functional._UseGroup: the calls sharing one weight write them side by side)."""
     Cin = x.shape[-1]
     if mode == MODE_GATHER:
         M = nbr.shape[0] if M is None else M
@@ -189,7 +190,8 @@ def conv_wgrad(x, dy, *, cout, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=1, Wout=1
     work = None if rows is not None else executed * ((alg_cin or Cin) / Cin) * ((alg_cout or cout) / cout) / (stride * stride if mode == MODE_TCONV else 1)
     tag = (_DT_TAG[x.dtype], mode, cout, R * S * Cin, M, executed, rows is not None)
     if park is not None and need > 0:
-        ws = torch.empty(int(need), dtype=torch.float32, device=x.device)      # this layer's own slabs: they live until the batched reduction
+        # this layer's own slabs: they live until the batched reduction
+        ws = torch.empty(int(need), dtype=torch.float32, device=x.device) if park_ws is None else park_ws(int(need), x.device)
         d = hip.WgradParked()
         hip.call('mg_conv_wgrad_park', ctypes.byref(p), hip.ptr(ws), ctypes.c_long(need), ctypes.byref(d), hip.stream(), work=work, tag=tag)
         if d.splits > 0:
@@ -200,10 +202,12 @@ def conv_wgrad(x, dy, *, cout, mode=MODE_CONV, N=1, Hin=1, Win=1, Hout=1, Wout=1
     return out
 
 
-def sum_k(ts):
-    """Sum of up to 16 same-shaped contiguous fp32 device tensors in ONE launch, added in list order (mg_sum_k)."""
+def sum_k(ts, out=None):
+    """Sum of up to 16 same-shaped contiguous fp32 device tensors in ONE launch, added in list order (mg_sum_k). `out`: a contiguous fp32 tensor of
+    that size to write to (it may not be one of the terms)."""
     n = ts[0].numel()
-    out = torch.empty_like(ts[0])
+    if out is None:
+        out = torch.empty_like(ts[0])
     hip.need_cuda(*ts)
     arr = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
     hip.call('mg_sum_k', arr, c_int(len(ts)), ctypes.c_long(n), hip.ptr(out), hip.stream())

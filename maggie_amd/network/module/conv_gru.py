@@ -33,13 +33,17 @@ class ConvGRU(nn.Module):
         cand = self._gate_conv(self.hh, MF.GruGate.apply(rz, x, h))      # pre-activation candidate from [x | r.h]
         return MF.GruOut.apply(rz, cand, h)
 
+    def run_frames(self, frames, h):
+        """frames: sequence of (b, H, W, C) -> list of hidden states, one per frame."""
+        states = []
+        for x in frames:
+            h = self.cell(x, h)
+            states.append(h)
+        return states
+
     def run(self, clip, h):
         """clip (b, n, H, W, C) -> all hidden states (b, n, H, W, C)."""
-        states = []
-        for t in range(clip.shape[1]):
-            h = self.cell(clip[:, t], h)
-            states.append(h)
-        return torch.stack(states, 1)
+        return torch.stack(self.run_frames(clip.unbind(1), h), 1)
 
     def forward(self, x, h):
         """Single frame (b, H, W, C) -> (h', h'); clip (b, n, H, W, C) -> (states, states), like the reference."""
@@ -66,8 +70,13 @@ class ConvGRU(nn.Module):
         if temp_method == 'none':
             frames = [self.forward(feat[:, j], None) for j in range(n_f)]
             return torch.stack([f[0] for f in frames], 1), frames[-1][1]
-        fwd = self.run(feat, prev_h_state if prev_h_state is not None else feat.new_zeros(feat.shape[:1] + feat.shape[-3:]))
+        # frames leave the clip through ONE unbind (its backward is one stack; n selects cost a fill, a copy and an accumulation add each) and
+        # the reversed pass runs over the frame list backwards -- no flipped copies of the clip or of its states
+        frames = feat.unbind(1)
+        states = self.run_frames(frames, prev_h_state if prev_h_state is not None else feat.new_zeros(feat.shape[:1] + feat.shape[-3:]))
+        fwd = torch.stack(states, 1)
         if temp_method != 'bi':
             return fwd, fwd
-        rev = self.run(feat[:, :-1].flip(1), fwd[:, -1]).flip(1)
-        return torch.cat(((fwd[:, :-1] + rev) * 0.5, fwd[:, -1:]), 1), fwd
+        rev = self.run_frames(frames[-2::-1], states[-1])         # rev[k] belongs to frame n - 2 - k
+        # every frame but the last is the mean of the two passes; the last one pairs with itself: (f + f) * 0.5 == f bit for bit
+        return (fwd + torch.stack(rev[::-1] + [states[-1]], 1)) * 0.5, fwd

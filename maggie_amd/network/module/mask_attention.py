@@ -34,9 +34,9 @@ def _need_hip_attention(n_tokens, d):
 
 
 def _split_in_proj(mha):
-    d = mha.embed_dim
-    # unbind, not three slices: its backward is ONE stack of the three gradients (a slice costs zeros + copy + add each)
-    return mha.in_proj_weight.view(3, d, d).unbind(0), mha.in_proj_bias.view(3, d).unbind(0)
+    # three views whose gradients are written straight into the slices of ONE (3d, d) / (3d) buffer by the kernels that produce them
+    # (functional.split_packed; was: unbind, whose backward is a stack of three tensors per packed parameter and step)
+    return MF.split_packed(mha.in_proj_weight, 3), MF.split_packed(mha.in_proj_bias, 3)
 
 
 class SelfAttentionLayer(nn.Module):
@@ -76,11 +76,14 @@ class CrossAttentionLayer(nn.Module):
     # self-attention produced).
 
     def tff_level1(self, tokens, token_pos, id_table):
-        (wq, wk, wv), (bq, bk, bv) = self._proj = _split_in_proj(self.multihead_attn)      # ONE unbind per forward: the later stages reuse the slices
+        (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.multihead_attn)      # ONE split per forward: the later stages reuse the slices
+        if id_table is not None:
+            wk = MF.Fan(wk, 2)                                    # two consumers (here and level 2): their gradients meet in the packed buffer's slice
+        self._proj = (wq, wk, wv), (bq, bk, bv)
         # (tokens / token_pos / id_table: tensors, or functional.Fan objects handing out one alias per consumer)
         layers = [dict(x=MF.take(tokens), W=wq, b=bq, xadd=MF.take(token_pos))]              # q
         if id_table is not None:
-            layers.append(dict(x=MF.take(id_table), W=wk, b=bk))                             # key_pos (n_id, d): E[id] Wk^T + bk
+            layers.append(dict(x=MF.take(id_table), W=MF.take(wk), b=bk))                    # key_pos (n_id, d): E[id] Wk^T + bk
         return layers
 
     def tff_level2(self, res1, id_table):
@@ -88,7 +91,7 @@ class CrossAttentionLayer(nn.Module):
         q = res1[0]
         key_pos = res1[1] if id_table is not None else bk[None, :]
         # q Wk (fold Wk into the queries; wk used as (K, N): no transposed copy) and the (b,T,n_id) score-bias table q . key_pos
-        return [dict(x=q, W=wk, wt=True), dict(x=q, W=key_pos)]
+        return [dict(x=q, W=MF.take(wk), wt=True), dict(x=q, W=key_pos)]
 
     def tff_finish(self, tokens, res2, feat, feat_ids):
         (wq, wk, wv), (bq, bk, bv) = self._proj
@@ -112,10 +115,13 @@ class CrossAttentionLayer(nn.Module):
         return self.tff_finish(tokens, pre, feat, feat_ids)
 
     def fft_level1(self, tokens, token_pos, id_table):
-        (wq, wk, wv), (bq, bk, bv) = self._proj = _split_in_proj(self.multihead_attn)
+        (wq, wk, wv), (bq, bk, bv) = _split_in_proj(self.multihead_attn)
+        if id_table is not None:
+            wq = MF.Fan(wq, 2)                                    # two consumers (here and level 2)
+        self._proj = (wq, wk, wv), (bq, bk, bv)
         layers = [dict(x=MF.take(tokens), W=wk, b=bk, xadd=MF.take(token_pos)), dict(x=MF.take(tokens), W=wv, b=bv)]    # k (b,T,d), v
         if id_table is not None:
-            layers.append(dict(x=MF.take(id_table), W=wq, b=bq))                             # qry_pos (n_id, d)
+            layers.append(dict(x=MF.take(id_table), W=MF.take(wq), b=bq))                    # qry_pos (n_id, d)
         return layers
 
     def fft_level2(self, res1, id_table):
@@ -124,7 +130,7 @@ class CrossAttentionLayer(nn.Module):
         k, v = res1[0], res1[1]
         qry_pos = res1[2] if id_table is not None else bq[None, :]
         # vp (b,T,d): rows of (Wo V^T)^T; kq (b,T,d): Wq folded into the keys; the (b,T,n_id) score-bias table
-        return [dict(x=v, W=self.multihead_attn.out_proj.weight), dict(x=k, W=wq, wt=True), dict(x=k, W=qry_pos)]
+        return [dict(x=v, W=self.multihead_attn.out_proj.weight), dict(x=k, W=MF.take(wq), wt=True), dict(x=k, W=qry_pos)]
 
     def fft_finish(self, feat, feat_ids, res2, token_padding_mask, n_tokens):
         vp, kq, tbl = res2

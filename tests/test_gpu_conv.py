@@ -512,16 +512,79 @@ def test_parked_reductions_must_meet_their_join_inside_the_same_backward():
     with pytest.raises(hip.MaggieHipError, match='never flushed'):
         y.float().sum().backward()
     assert MF.PARKED == []
-    # two uses: counted, so neither parks; gradients are complete and equal to the sum of the two uses' own gradients
+    # two uses of DIFFERENT geometry: counted, so neither parks (and they do not form a group); gradients are complete and equal to the sum of the
+    # two uses' own gradients
     w3 = joined_weight()
-    y1, y2 = MF.conv2d(x, w3), MF.conv2d(x, w3)
+    y1, y2 = MF.conv2d(x, w3), MF.conv2d(x[:, :8].contiguous(), w3)
     (y1.float().sum() + 2.0 * y2.float().sum()).backward()
-    assert MF.PARKED == []
+    assert MF.PARKED == [] and MF._OPEN_GROUPS == []
     w_ref = w3.detach().clone().requires_grad_(True)
-    yr = MF.conv2d(x.detach(), w_ref)
-    (3.0 * yr.float().sum()).backward()
+    (MF.conv2d(x.detach(), w_ref).float().sum() + 2.0 * MF.conv2d(x.detach()[:, :8].contiguous(), w_ref).float().sum()).backward()
     torch.cuda.synchronize()
     assert (w3.grad.float() - w_ref.grad.float()).abs().max() <= 2e-2 * w_ref.grad.float().abs().max()
+
+
+def test_one_weight_used_by_several_identical_convolutions_reduces_all_slabs_once():
+    """Round 5 (video: the ConvGRU gate weights serve one convolution per frame and direction, maggie/network/module/conv_gru.py:17-27). k calls of ONE
+    geometry on a joined weight: the weight-gradient GEMMs write their slabs side by side, only the call whose backward runs last returns a gradient,
+    and ONE parked reduction adds all k * splits slabs in fp32 -- closer to the fp32 sum than k separately rounded gradients added in bf16, and one
+    launch at the join instead of k reductions + k - 1 adds. A backward pass that misses one of the uses raises."""
+    from maggie_amd import functional as MF, kernels as K, hip
+    dev = _dev()
+    if not (MF.PARK_WGRAD and MF.GROUP_WGRAD):
+        pytest.skip('grouped weight gradients switched off')
+    g = torch.Generator().manual_seed(9)
+    xs = [torch.randn((1, 64, 64, 128), generator=g).to(dev, torch.bfloat16) for _ in range(5)]
+    w0 = (torch.randn((128, 9, 128), generator=g) / 34).to(dev, torch.bfloat16)
+    dys = [torch.randn((1, 64, 64, 128), generator=g).to(dev, torch.bfloat16) for _ in range(5)]
+
+    class Join(torch.autograd.Function):                          # stands in for SpectralNormBatch.backward: the point where the parked work is flushed
+        @staticmethod
+        def forward(ctx, w):
+            return w.view_as(w)
+
+        @staticmethod
+        def backward(ctx, gw):
+            MF.flush_parked()
+            return gw
+
+    def grad(grouped, skip_last=False):
+        MF.GROUP_WGRAD = grouped
+        try:
+            leaf = w0.clone().requires_grad_(True)
+            w = Join.apply(leaf)
+            w._mg_join = True
+            ys = [MF.conv2d(x_, w) for x_ in xs]
+            use = list(zip(ys, dys))[:-1] if skip_last else list(zip(ys, dys))
+            torch.autograd.backward([y for y, _ in use], [d for _, d in use])
+            torch.cuda.synchronize()
+            return leaf.grad
+        finally:
+            MF.GROUP_WGRAD = True
+
+    n_before = []
+    orig = K.wgrad_reduce_batched
+
+    def counting(park):
+        n_before.append(len(park))
+        return orig(park)
+    K.wgrad_reduce_batched = counting
+    try:
+        got = grad(True)
+    finally:
+        K.wgrad_reduce_batched = orig
+    assert n_before == [1]                                         # ONE parked reduction for the five calls
+    assert MF.PARKED == [] and MF._OPEN_GROUPS == []
+    sep = grad(False)
+    ref = sum(K.conv_wgrad(x_.view(-1, 128), d_.view(-1, 128), cout=128, mode=K.MODE_CONV, N=1, Hin=64, Win=64, Hout=64, Wout=64, R=3, S=3, stride=1,
+                           pad=1, dil=1, out_dtype=torch.float32) for x_, d_ in zip(xs, dys))
+    scale = float(ref.abs().max())
+    e_grp, e_sep = float((got.float() - ref).abs().max()) / scale, float((sep.float() - ref).abs().max()) / scale
+    assert e_grp <= 4e-3 and e_grp <= e_sep, (e_grp, e_sep)        # one rounding to bf16 (2^-9 relative) against five + four adds
+    with pytest.raises(hip.MaggieHipError, match='did not see the backward of all their uses'):
+        grad(True, skip_last=True)
+    assert MF.PARKED == [] and MF._OPEN_GROUPS == []
+    assert torch.equal(grad(True), got)                            # and the state is clean for the next pass
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])

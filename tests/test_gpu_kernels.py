@@ -885,6 +885,104 @@ def test_batched_weight_pipeline_mixes_spectral_norm_and_plain_convs(dtype):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_batched_weight_pipeline_transposed_twin_gradient_layout_and_destinations(dtype):
+    """Round 5, the ConvTranspose entries of the batched weight pipeline (decoder up-convolutions, maggie/network/decoder/resnet.py:20-45):
+    (a) the dgrad twin (Cin_pad, taps, Cout) is emitted by the kernel and equals the permuted weight; (b) a gradient handed back in the twin's
+    layout (a permuted view -- what ConvRaw.backward returns for a transposed convolution) gives the bits of the same gradient in the
+    (Cout, taps, Cin_pad) layout; (c) with functional.GRAD_DEST the parameter gradients are written into the caller's tensors and those very
+    tensors come back."""
+    from maggie_amd import functional as MF
+    from maggie_amd.network.module import SpectralNorm, ConvWeight
+    dev = _dev()
+    torch.manual_seed(11)
+    mods = [SpectralNorm(ConvWeight(64, 40, 4, 2, 1, 1, transposed=True)).to(dev), ConvWeight(24, 48, 3, 1, 1, 1).to(dev),
+            SpectralNorm(ConvWeight(20, 32, 4, 2, 1, 1, transposed=True)).to(dev)]
+    state = [{k: v.clone() for k, v in m.state_dict().items()} for m in mods]
+    params = [m.module.weight_bar if isinstance(m, SpectralNorm) else m.weight for m in mods]
+
+    def run(twin_layout, dest):
+        for m, sd in zip(mods, state):
+            m.load_state_dict(sd)
+        MF.ARENA.reset(dev)
+        MF.spectral_norm_prepare(mods, dtype, {})
+        outs = [m.__dict__['_prepared'] for m in mods]
+        gen = torch.Generator(device=dev).manual_seed(5)
+        grads = [torch.randn(o.shape, device=dev, generator=gen).to(dtype) for o in outs]
+        fed = [g.permute(2, 1, 0).contiguous().permute(2, 1, 0) if (twin_layout and isinstance(m, SpectralNorm)) else g for m, g in zip(mods, grads)]
+        if dest is not None:
+            MF.GRAD_DEST.update({id(p): d for p, d in zip(params, dest)})
+        try:
+            got = torch.autograd.grad(outs, params, fed)
+        finally:
+            MF.GRAD_DEST.clear()
+        return outs, got
+
+    outs, ref = run(False, None)
+    for m, w in zip(mods, outs):
+        assert torch.equal(w._mg_wt, w.permute(2, 1, 0).contiguous())              # the twin, transposed entries included
+    _, got = run(True, None)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    flat = torch.full((sum(p.numel() for p in params) + 64,), float('nan'), device=dev)
+    dest, o = [], 0
+    for p_ in params:
+        dest.append(flat[o:o + p_.numel()].view(p_.shape))
+        o += p_.numel() + 16
+    _, got = run(True, dest)
+    for a, b, d in zip(got, ref, dest):
+        assert a.data_ptr() == d.data_ptr() and torch.equal(a, b) and torch.equal(d, b)
+    assert torch.isnan(flat[params[0].numel():params[0].numel() + 16]).all()        # nothing written between the destinations
+
+
+@pytest.mark.gpu
+def test_packed_parameter_slices_collect_their_gradients_in_one_buffer():
+    """functional.split_packed (nn.MultiheadAttention.in_proj_weight / in_proj_bias -> q, k, v slices, maggie/network/module/mask_attention.py): the
+    token-side linears write the slices' gradients into ONE buffer that comes back as the packed gradient -- same bits as unbind + stack; a slice
+    with two consumers goes through functional.Fan and is summed into its slot; a slice consumed outside the slot-aware kernels falls back to
+    stacking."""
+    from maggie_amd import functional as MF
+    dev = _dev()
+    torch.manual_seed(3)
+    d = 128
+    P = torch.randn(3 * d, d, device=dev, requires_grad=True)
+    Pb = torch.randn(3 * d, device=dev, requires_grad=True)
+    x = torch.randn(4, 10, d, device=dev, requires_grad=True)
+
+    def net(split, fan, torch_tail=False):
+        (wq, wk, wv), (bq, bk, bv) = split(P), split(Pb)
+        wk2 = fan(wk)
+        q, k = MF.token_linear_multi([dict(x=x, W=wq, b=bq), dict(x=x, W=MF.take(wk2), b=bk)])
+        k2 = MF.token_linear(q, MF.take(wk2), None, wt=True)
+        v = (x @ wv.t() + bv) if torch_tail else MF.token_linear(x, wv, bv)
+        return (q * 0.5 + k * 0.25 + k2 * 0.125 + v).sum()
+
+    plain = lambda t: t.view(3, d, *t.shape[1:]).unbind(0)            # noqa: E731
+    ref = torch.autograd.grad(net(plain, lambda t: t), (P, Pb, x))
+    seen = []
+    orig = MF.SplitPacked.backward
+
+    def spy(ctx, *gs):
+        out = orig(ctx, *gs)
+        seen.append(ctx.holder.k == 3 and out[0].data_ptr() == gs[0].data_ptr())      # the buffer itself came back (slice 0 starts it)
+        return out
+    MF.SplitPacked.backward = staticmethod(spy)
+    try:
+        got = torch.autograd.grad(net(lambda t: MF.split_packed(t, 3), lambda t: MF.Fan(t, 2)), (P, Pb, x))
+        assert seen == [True, True]
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+        del seen[:]
+        got = torch.autograd.grad(net(lambda t: MF.split_packed(t, 3), lambda t: MF.Fan(t, 2), torch_tail=True), (P, Pb, x))
+        assert seen == [False, False]                                  # the v slice's gradient came from torch: stacked
+        ref2 = torch.autograd.grad(net(plain, lambda t: t, torch_tail=True), (P, Pb, x))
+        for a, b in zip(got, ref2):
+            assert torch.equal(a, b)
+    finally:
+        MF.SplitPacked.backward = orig
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('T', [2, 3, 5])
 def test_bidirectional_fusion_kernel_matches_torch_restatement(T):
     """mg_bifuse_fwd / _bwd against the statement-by-statement torch form of bidirectional_fusion's blend
