@@ -344,6 +344,12 @@ int mg_attn_feat_fwd(const float* feat, const float* kq, const float* b2, const 
                      const int32_t* ids, int B, int T, int L, int D, int NID, float scale, float* out, float* p, void* stream);
 int mg_attn_feat_bwd(const float* dout, const float* p, const float* feat, const float* kq, const float* vp, const int32_t* ids, int B, int T,
                      int L, int D, int NID, float scale, float* dfeat, float* dkq, float* dvp, float* db2, float* dobias, void* stream);
+/* Round 5: b2_tn != 0 -- the score-bias table b2 and its gradient db2 are laid out (B, T, NID), the layout the token-side linear that forms the table
+ * writes (no transposed copy in front of / behind the kernels). */
+int mg_attn_feat_fwd_ex(const float* feat, const float* kq, const float* b2, const float* vp, const float* obias, const uint8_t* pad_mask,
+                        const int32_t* ids, int B, int T, int L, int Dm, int NID, float scale, float* out, float* p, int b2_tn, void* stream);
+int mg_attn_feat_bwd_ex(const float* dout, const float* p, const float* feat, const float* kq, const float* vp, const int32_t* ids, int B, int T,
+                        int L, int Dm, int NID, float scale, float* dfeat, float* dkq, float* dvp, float* db2, float* dobias, int b2_tn, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Fused matting losses on fp32 planes [P,H,W] (maggie/network/arch/maggie.py:237-266,290-346; maggie/network/loss.py:67-191):
@@ -636,9 +642,18 @@ int mg_token_einsum_bwd(const void* dlog, const void* feat, int dtype, const flo
 /* out[i] = ((srcs[0][i] + srcs[1][i]) + srcs[2][i]) + ... : the gradient of a tensor with k <= 16 consumers in one launch and a fixed order (replaces
  * the k - 1 pairwise adds of the autograd engine; maggie/network/module/mask_attention.py:63-133 uses every token tensor several times). fp32. */
 int mg_sum_k(const float* const* srcs, int k, long n, float* out, void* stream);
+/* The same for tensors of `dtype` (MG_F32 / MG_BF16 / MG_F16; 16-byte aligned): 16-bit terms are added in fp32 in the given order and rounded once. */
+int mg_sum_k_t(const void* const* srcs, int k, long n, void* out, int dtype, void* stream);
+/* AdaptiveAvgPool2d(1) over NHWC rows (maggie/network/module/aspp.py:24-27): backward == 0: x (N, HW, C) -> out (N, C), the mean of each sample's rows
+ * (fp32 sums in a fixed order); backward != 0: x = dy (N, C) -> out = dx (N, HW, C) = dy / HW. */
+int mg_spatial_mean(const void* x, void* out, int dtype, int N, int HW, int C, int backward, void* stream);
 /* dsts[j][0 .. bytes[j]) = srcs[j][...] for j < k <= 16 as ONE launch (replaces torch._foreach_copy_ of contiguous same-type tensors = one hipMemcpyAsync
  * each: the outputs a replayed graph hands to the caller, engine/train.py:229-241 keeps them across steps; gradient hand-over between graphs). */
 int mg_copy_k(const void* const* srcs, void* const* dsts, const long* bytes, int k, void* stream);
+/* out[4] (int32, device) = [a NaN among the n fp32 tokens, nonzero[0] == 0, ovf[0] != 0, err[0]] -- NULL inputs give 0. The four words the host reads
+ * between the trunk and the detail stage (maggie/network/module/mask_attention.py:95-98 raises on NaN tokens; resnet_inst_matt_spconv.py:314 switches
+ * the guidance to the ground truth when the coarse alpha is zero), in one launch. */
+int mg_step_flags(const float* tokens, long n, const int* nonzero, const int* ovf, const int* err, int* out, void* stream);
 int mg_token_sa_fwd(const float* q, const float* k, const float* v, const unsigned char* pad, float scale, int B, int T, int D, float* out, float* prob,
                     void* stream);
 int mg_token_sa_bwd(const float* dout, const float* q, const float* k, const float* v, const float* prob, float scale, int B, int T, int D, float* dq,

@@ -76,3 +76,32 @@ extern "C" int mg_copy_k(const void* const* srcs, void* const* dsts, const long*
     MG_CHECK_LAUNCH();
     return 0;
 }
+
+// ---- the step's device -> host flags in ONE launch ------------------------------------------------------------------------------------------
+// Between the trunk and the detail stage the host needs four words (maggie_amd/network/arch/maggie.py:_forward_impl): NaN among the instance
+// tokens (the reference raises, mask_attention.py:95-98), coarse alpha identically zero, the sparse head's sticky overflow word, the SyncBatchNorm
+// mailbox's error word. Formed by isnan + any + two compares + a stack they were five small launches in front of the copy the host waits for.
+namespace {
+__global__ __launch_bounds__(256) void step_flags_kernel(const float* __restrict__ tokens, long n, const int* __restrict__ nonzero, const int* __restrict__ ovf,
+                                                         const int* __restrict__ err, int* __restrict__ out) {
+    __shared__ int bad;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    int mine = 0;
+    for (long i = threadIdx.x; i < n; i += 256) { const float v = tokens[i]; mine |= (v != v); }
+    if (mine) bad = 1;                                       // (benign race: every writer stores 1)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = bad;
+        out[1] = nonzero ? (nonzero[0] == 0) : 0;
+        out[2] = ovf ? (ovf[0] != 0) : 0;
+        out[3] = err ? err[0] : 0;
+    }
+}
+}  // namespace
+extern "C" int mg_step_flags(const float* tokens, long n, const int* nonzero, const int* ovf, const int* err, int* out, void* stream) {
+    if (!out || n < 0 || (n > 0 && !tokens)) return -2;
+    hipLaunchKernelGGL(step_flags_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, tokens, n, nonzero, ovf, err, out);
+    MG_CHECK_LAUNCH();
+    return 0;
+}

@@ -287,7 +287,7 @@ template <int T>
 __global__ __launch_bounds__(NT) void feat_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ kq, const float* __restrict__ b2,
                                                       const float* __restrict__ vp, const float* __restrict__ obias, const uint8_t* __restrict__ pad,
                                                       const int32_t* __restrict__ ids, int L, int NID, float scale, float* __restrict__ out,
-                                                      float* __restrict__ p_out) {
+                                                      float* __restrict__ p_out, int b2_tn) {
     __shared__ float sk[T * D];
     __shared__ float sv[T * D];
     const int b = blockIdx.y;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(NT) void feat_fwd_kernel(const float* __restrict__ 
             float a = 0.f;
 #pragma unroll
             for (int e = 0; e < CPL; ++e) a += f[e] * sk[t * D + li * CPL + e];
-            a = (group_sum(a) + b2[((long)b * NID + id) * T + t]) * scale;
+            a = (group_sum(a) + b2[(long)b * NID * T + (b2_tn ? t * NID + id : id * T + t)]) * scale;   // b2_tn: the table as (B, T, NID)
             if (pad && pad[b * T + t]) a = -INFINITY;
             s[t] = a;
             m = fmaxf(m, a);
@@ -338,7 +338,8 @@ template <int T>
 __global__ __launch_bounds__(NT) void feat_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ p, const float* __restrict__ feat,
                                                       const float* __restrict__ kq, const float* __restrict__ vp, const int32_t* __restrict__ ids,
                                                       int L, int NID, float scale, float* __restrict__ dfeat, float* __restrict__ dkq,
-                                                      float* __restrict__ dvp, float* __restrict__ db2, float* __restrict__ dob, float* __restrict__ slots) {
+                                                      float* __restrict__ dvp, float* __restrict__ db2, float* __restrict__ dob, float* __restrict__ slots,
+                                                      int b2_tn) {
     extern __shared__ float smem[];
     float* sk = smem;                    // [T][D]
     float* sv = smem + T * D;            // [T][D]
@@ -421,8 +422,9 @@ __global__ __launch_bounds__(NT) void feat_bwd_kernel(const float* __restrict__ 
     }
     id_sums_ordered<T, false>(sds, sid, NID, sb);
     for (int i = threadIdx.x; i < T * NID; i += NT) {
-        if (slot) slot[2 * T * D + i] = sb[i];
-        else if (sb[i] != 0.f) atomicAdd(&db2[(long)b * NID * T + i], sb[i]);
+        const int o = b2_tn ? (i % T) * NID + i / T : i;          // sb is [NID][T]; b2_tn: the gradient leaves as (T, NID), like the table came
+        if (slot) slot[2 * T * D + o] = sb[i];
+        else if (sb[i] != 0.f) atomicAdd(&db2[(long)b * NID * T + o], sb[i]);
     }
 }
 
@@ -501,16 +503,30 @@ extern "C" int mg_attn_tok_bwd(const float* p, const float* feat, const float* q
     return 0;
 }
 
-extern "C" int mg_attn_feat_fwd(const float* feat, const float* kq, const float* b2, const float* vp, const float* obias, const uint8_t* pad_mask,
-                                const int32_t* ids, int B, int T, int L, int Dm, int NID, float scale, float* out, float* p, void* stream) {
+// b2_tn != 0: the score-bias table (and its gradient) is laid out (B, T, NID) -- the way the token-side linear writes it -- instead of (B, NID, T)
+extern "C" int mg_attn_feat_fwd_ex(const float* feat, const float* kq, const float* b2, const float* vp, const float* obias, const uint8_t* pad_mask,
+                                   const int32_t* ids, int B, int T, int L, int Dm, int NID, float scale, float* out, float* p, int b2_tn, void* stream) {
     int rc = attn_check(B, T, L, Dm, NID); if (rc) return rc;
-    hipLaunchKernelGGL(feat_fwd_kernel<TT>, row_grid(L, B), dim3(NT), 0, (hipStream_t)stream, feat, kq, b2, vp, obias, pad_mask, ids, L, NID, scale, out, p);
+    hipLaunchKernelGGL(feat_fwd_kernel<TT>, row_grid(L, B), dim3(NT), 0, (hipStream_t)stream, feat, kq, b2, vp, obias, pad_mask, ids, L, NID, scale, out, p,
+                       b2_tn);
     MG_CHECK_LAUNCH();
     return 0;
 }
+extern "C" int mg_attn_feat_fwd(const float* feat, const float* kq, const float* b2, const float* vp, const float* obias, const uint8_t* pad_mask,
+                                const int32_t* ids, int B, int T, int L, int Dm, int NID, float scale, float* out, float* p, void* stream) {
+    return mg_attn_feat_fwd_ex(feat, kq, b2, vp, obias, pad_mask, ids, B, T, L, Dm, NID, scale, out, p, 0, stream);
+}
 
+extern "C" int mg_attn_feat_bwd_ex(const float* dout, const float* p, const float* feat, const float* kq, const float* vp, const int32_t* ids, int B, int T,
+                                   int L, int Dm, int NID, float scale, float* dfeat, float* dkq, float* dvp, float* db2, float* dobias, int b2_tn,
+                                   void* stream);
 extern "C" int mg_attn_feat_bwd(const float* dout, const float* p, const float* feat, const float* kq, const float* vp, const int32_t* ids, int B, int T,
                                 int L, int Dm, int NID, float scale, float* dfeat, float* dkq, float* dvp, float* db2, float* dobias, void* stream) {
+    return mg_attn_feat_bwd_ex(dout, p, feat, kq, vp, ids, B, T, L, Dm, NID, scale, dfeat, dkq, dvp, db2, dobias, 0, stream);
+}
+extern "C" int mg_attn_feat_bwd_ex(const float* dout, const float* p, const float* feat, const float* kq, const float* vp, const int32_t* ids, int B, int T,
+                                   int L, int Dm, int NID, float scale, float* dfeat, float* dkq, float* dvp, float* db2, float* dobias, int b2_tn,
+                                   void* stream) {
     int rc = attn_check(B, T, L, Dm, NID); if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     {
@@ -523,7 +539,8 @@ extern "C" int mg_attn_feat_bwd(const float* dout, const float* p, const float* 
     const int w = 2 * T * Dm + T * NID + Dm;
     float* slots = nullptr;
     if (mg_det_on && (nblk > 1 || B > 1)) { slots = mg_det_scratch((long)B * nblk * w); if (!slots) return MG_DET_NO_SCRATCH; }
-    hipLaunchKernelGGL(feat_bwd_kernel<TT>, row_grid(L, B), dim3(NT), lds, st, dout, p, feat, kq, vp, ids, L, NID, scale, dfeat, dkq, dvp, db2, dobias, slots);
+    hipLaunchKernelGGL(feat_bwd_kernel<TT>, row_grid(L, B), dim3(NT), lds, st, dout, p, feat, kq, vp, ids, L, NID, scale, dfeat, dkq, dvp, db2, dobias, slots,
+                       b2_tn);
     MG_CHECK_LAUNCH();
     if (slots) {
         mg_det_seg sg[3] = {{dkq, T * Dm, (long)T * Dm}, {dvp, T * Dm, (long)T * Dm}, {db2, T * NID, (long)T * NID}};

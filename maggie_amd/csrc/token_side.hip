@@ -762,3 +762,53 @@ extern "C" int mg_sum_k(const float* const* srcs, int k, long n, float* out, voi
     return 0;
 }
 
+
+// The same for 16-bit tensors (bf16 / fp16 activation gradients with several consumers: the ASPP input feeds five branches): the k terms are added in
+// fp32 in the given order and rounded ONCE (autograd's k - 1 pairwise adds round k - 1 times). n % 8 == 0 is not required.
+namespace {
+struct SumSrcsRaw { const void* p[16]; int k; };
+template <typename T>
+__global__ __launch_bounds__(256) void sum_k16_kernel(const SumSrcsRaw s, long n, T* __restrict__ out) {
+    using TR = ElemTraits<T>;
+    constexpr int CE = TR::CE;
+    const long nv = n / CE;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        float a[CE];
+        TR::unpack(((const uint4*)s.p[0])[i], a);
+#pragma unroll
+        for (int j = 1; j < 16; ++j) {
+            if (j < s.k) {
+                float v[CE];
+                TR::unpack(((const uint4*)s.p[j])[i], v);
+#pragma unroll
+                for (int e = 0; e < CE; ++e) a[e] += v[e];
+            }
+        }
+        ((uint4*)out)[i] = TR::pack(a);
+    }
+    if (blockIdx.x == 0) {
+        for (long i = nv * CE + threadIdx.x; i < n; i += 256) {
+            float a = TR::ld((const T*)s.p[0] + i);
+            for (int j = 1; j < s.k; ++j) a += TR::ld((const T*)s.p[j] + i);
+            TR::st(out + i, a);
+        }
+    }
+}
+}  // namespace
+extern "C" int mg_sum_k_t(const void* const* srcs, int k, long n, void* out, int dtype, void* stream) {
+    if (dtype == MG_F32) return mg_sum_k((const float* const*)srcs, k, n, (float*)out, stream);
+    if (!MG_IS16(dtype)) return -3;
+    if (!srcs || !out || k < 1 || k > 16 || n < 0) return -2;
+    if (n == 0) return 0;
+    SumSrcsRaw s; s.k = k;
+    for (int j = 0; j < 16; ++j) {
+        s.p[j] = j < k ? srcs[j] : nullptr;
+        if (j < k && (!srcs[j] || (((size_t)srcs[j]) & 15))) return -2;
+    }
+    if (((size_t)out) & 15) return -2;
+    long b = (n / 8 + 255) / 256; if (b > 2048) b = 2048; if (b < 1) b = 1;
+    if (dtype == MG_BF16) hipLaunchKernelGGL(sum_k16_kernel<bf16raw>, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, s, n, (bf16raw*)out);
+    else hipLaunchKernelGGL(sum_k16_kernel<f16raw>, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, s, n, (f16raw*)out);
+    MG_CHECK_LAUNCH();
+    return 0;
+}

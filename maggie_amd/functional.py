@@ -1642,31 +1642,32 @@ class AttnTokensFromFeatures(torch.autograd.Function):
 
 
 class AttnFeaturesFromTokens(torch.autograd.Function):
-    """out = softmax_t((F . kq^T + b2[ids]) * scale, masked) vp + obias.   kq / vp (B,T,D), b2 (B,NID,T), pad (B,T) bool or None."""
+    """out = softmax_t((F . kq^T + b2[ids]) * scale, masked) vp + obias.   kq / vp (B,T,D), b2 (B,NID,T) -- or (B,T,NID) with tn=True, the layout
+    the token-side linear writes the table in (no transposed copy either way) --, pad (B,T) bool or None."""
 
     @staticmethod
-    def forward(ctx, feat, kq, b2, vp, obias, pad, ids, scale):
+    def forward(ctx, feat, kq, b2, vp, obias, pad, ids, scale, tn=False):
         feat, kq, b2, vp = feat.float().contiguous(), kq.float().contiguous(), b2.float().contiguous(), vp.float().contiguous()
         ob = None if obias is None else obias.float().contiguous()
-        pd = None if pad is None else pad.to(torch.uint8).contiguous()
-        out, p = K.attn_feat_fwd(feat, kq, b2, vp, ob, pd, ids, scale)
+        pd = None if pad is None else as_u8(pad)
+        out, p = K.attn_feat_fwd(feat, kq, b2, vp, ob, pd, ids, scale, tn)
         ctx.save_for_backward(feat, kq, vp, ids, p)
-        ctx.scale, ctx.nid, ctx.has_bias = scale, b2.shape[1], obias is not None
+        ctx.scale, ctx.nid, ctx.has_bias, ctx.tn = scale, (b2.shape[2] if tn else b2.shape[1]), obias is not None, bool(tn)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         feat, kq, vp, ids, p = ctx.saved_tensors
-        dfeat, dkq, dvp, db2, dob = K.attn_feat_bwd(dout.float().contiguous(), p, feat, kq, vp, ids, ctx.scale, ctx.nid, ctx.has_bias)
-        return dfeat, dkq, db2, dvp, dob, None, None, None
+        dfeat, dkq, dvp, db2, dob = K.attn_feat_bwd(dout.float().contiguous(), p, feat, kq, vp, ids, ctx.scale, ctx.nid, ctx.has_bias, ctx.tn)
+        return dfeat, dkq, db2, dvp, dob, None, None, None, None
 
 
 def attn_tokens_from_features(qk, btab, feat, ids, scale):
     return AttnTokensFromFeatures.apply(qk, btab, feat, ids, scale)
 
 
-def attn_features_from_tokens(feat, kq, b2, vp, obias, pad, ids, scale):
-    return AttnFeaturesFromTokens.apply(feat, kq, b2, vp, obias, pad, ids, scale)
+def attn_features_from_tokens(feat, kq, b2, vp, obias, pad, ids, scale, tn=False):
+    return AttnFeaturesFromTokens.apply(feat, kq, b2, vp, obias, pad, ids, scale, tn)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -1960,6 +1961,14 @@ def split_packed(P, k):
     return outs
 
 
+def as_u8(mask):
+    """A 0/1 mask as contiguous uint8: a bool tensor is re-interpreted in place (one byte per element, 0 / 1) -- no cast kernel per consumer (the token
+    padding mask met six of them per step)."""
+    if mask.dtype == torch.bool:
+        return mask.contiguous().view(torch.uint8)
+    return mask.to(torch.uint8).contiguous()
+
+
 class TokenLinear(torch.autograd.Function):
     """y = LN( res + act( (x + xadd) W^T + b ) ) over (..., K) -> (..., N) fp32; every optional piece may be None. One HIP launch each way
     (the reference: up to 2 adds + cuBLAS + bias + ReLU + add + LayerNorm forward, twice that backward)."""
@@ -2032,6 +2041,26 @@ def token_linear(x, W, b=None, xadd=None, res=None, relu=False, ln=None, wt=Fals
 FAN_OUT = os.environ.get('MAGGIE_FAN_OUT', '1') != '0'
 
 
+class SpatialMean(torch.autograd.Function):
+    """AdaptiveAvgPool2d(1) of an NHWC map: (N, H, W, C) -> (N, 1, 1, C) in the map's dtype, fp32 sums in a fixed order; one launch each way."""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, H, W_, C = x.shape
+        ctx.hw = (H, W_)
+        return K.spatial_mean(x.view(N, H * W_, C), N, H * W_).view(N, 1, 1, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        H, W_ = ctx.hw
+        N, C = dy.shape[0], dy.shape[-1]
+        return K.spatial_mean(dy.reshape(N, C), N, H * W_, backward=True).view(N, H, W_, C)
+
+
+def spatial_mean(x):
+    return SpatialMean.apply(x)
+
+
 class FanOut(torch.autograd.Function):
     """k aliases of one tensor, one per consumer: the k gradients then arrive HERE together and are added by one launch in alias order
     (mg_sum_k), instead of the k - 1 pairwise add kernels the autograd engine issues for a tensor it sees consumed k times. The token side of the
@@ -2053,7 +2082,8 @@ class FanOut(torch.autograd.Function):
             out = grad_slot_out(ctx.gslot, live[0].shape, live[0].device)
             if out is not None:
                 return K.sum_k([g.contiguous() for g in live], out=out), None
-        ok = all(g.is_cuda and g.dtype == torch.float32 and g.shape == live[0].shape for g in live)
+        ok = all(g.is_cuda and g.dtype == live[0].dtype and g.shape == live[0].shape for g in live) and \
+            live[0].dtype in (torch.float32, torch.bfloat16, torch.float16)
         if not ok:
             total = live[0]
             for g in live[1:]:
@@ -2073,7 +2103,8 @@ class Fan:
 
     def __init__(self, t, k):
         self.t = t
-        use = FAN_OUT and t is not None and torch.is_grad_enabled() and t.requires_grad and t.is_cuda and t.dtype == torch.float32 and \
+        use = FAN_OUT and t is not None and torch.is_grad_enabled() and t.requires_grad and t.is_cuda and \
+            t.dtype in (torch.float32, torch.bfloat16, torch.float16) and \
             (k > 2 or (k == 2 and getattr(t, '_mg_gslot', None) is not None))
         self.outs = list(FanOut.apply(t, k)) if use else None
 
@@ -2203,7 +2234,7 @@ class TokenSelfAttention(torch.autograd.Function):
     def forward(ctx, q, k, v, pad):
         q, k, v = q.float().contiguous(), k.float().contiguous(), v.float().contiguous()
         B, T, D = q.shape
-        pd = None if pad is None else pad.to(torch.uint8).contiguous()
+        pd = None if pad is None else as_u8(pad)
         out = torch.empty_like(q)
         prob = torch.empty((B, T, T), dtype=torch.float32, device=q.device)
         scale = 1.0 / (D ** 0.5)

@@ -210,7 +210,20 @@ def sum_k(ts, out=None):
         out = torch.empty_like(ts[0])
     hip.need_cuda(*ts)
     arr = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
-    hip.call('mg_sum_k', arr, c_int(len(ts)), ctypes.c_long(n), hip.ptr(out), hip.stream())
+    if ts[0].dtype == torch.float32:
+        hip.call('mg_sum_k', arr, c_int(len(ts)), ctypes.c_long(n), hip.ptr(out), hip.stream())
+    else:                                                         # 16-bit terms: fp32 sum in list order, rounded once
+        hip.call('mg_sum_k_t', arr, c_int(len(ts)), ctypes.c_long(n), hip.ptr(out), c_int(hip.dtype_code(ts[0])), hip.stream())
+    return out
+
+
+def spatial_mean(x, N, HW, backward=False):
+    """AdaptiveAvgPool2d(1) over NHWC rows: x (N, HW, C) -> (N, C); backward: x = dy (N, C) -> dx (N, HW, C) = dy / HW (mg_spatial_mean)."""
+    C = x.shape[-1]
+    x = x.contiguous()
+    hip.need_cuda(x)
+    out = torch.empty((N, HW, C) if backward else (N, C), dtype=x.dtype, device=x.device)
+    hip.call('mg_spatial_mean', hip.ptr(x), hip.ptr(out), c_int(hip.dtype_code(x)), c_int(N), c_int(HW), c_int(C), c_int(int(backward)), hip.stream())
     return out
 
 
@@ -812,19 +825,20 @@ def attn_tok_bwd(p, feat, qk, ids, dctx, dp, scale, NID):
     return dqk, dbtab, dfeat
 
 
-def attn_feat_fwd(feat, kq, b2, vp, obias, pad, ids, scale):
-    """features <- tokens. feat (B,L,D), kq / vp (B,T,D), b2 (B,NID,T), obias (D) or None, pad (B,T) uint8 or None -> out (B,L,D), p (B,L,T)."""
+def attn_feat_fwd(feat, kq, b2, vp, obias, pad, ids, scale, tn=False):
+    """features <- tokens. feat (B,L,D), kq / vp (B,T,D), b2 (B,NID,T) [tn: (B,T,NID)], obias (D) or None, pad (B,T) uint8 or None -> out (B,L,D),
+    p (B,L,T)."""
     hip.need_cuda(feat, kq, b2, vp, ids)
     B, L, D = feat.shape
-    T, NID = kq.shape[1], b2.shape[1]
+    T, NID = kq.shape[1], (b2.shape[2] if tn else b2.shape[1])
     out = torch.empty((B, L, D), dtype=torch.float32, device=feat.device)
     p = torch.empty((B, L, T), dtype=torch.float32, device=feat.device)
-    hip.call('mg_attn_feat_fwd', hip.ptr(feat), hip.ptr(kq), hip.ptr(b2), hip.ptr(vp), hip.ptr(obias), hip.ptr(pad), hip.ptr(ids), c_int(B), c_int(T),
-             c_int(L), c_int(D), c_int(NID), c_float(scale), hip.ptr(out), hip.ptr(p), hip.stream())
+    hip.call('mg_attn_feat_fwd_ex', hip.ptr(feat), hip.ptr(kq), hip.ptr(b2), hip.ptr(vp), hip.ptr(obias), hip.ptr(pad), hip.ptr(ids), c_int(B), c_int(T),
+             c_int(L), c_int(D), c_int(NID), c_float(scale), hip.ptr(out), hip.ptr(p), c_int(int(tn)), hip.stream())
     return out, p
 
 
-def attn_feat_bwd(dout, p, feat, kq, vp, ids, scale, NID, want_bias):
+def attn_feat_bwd(dout, p, feat, kq, vp, ids, scale, NID, want_bias, tn=False):
     B, L, D = feat.shape
     T = kq.shape[1]
     dev = feat.device
@@ -833,10 +847,10 @@ def attn_feat_bwd(dout, p, feat, kq, vp, ids, scale, NID, want_bias):
     acc = ACC(2 * n1 + n2 + (D if want_bias else 0), dev)                                           # one buffer, one fill launch (see attn_tok_bwd)
     dkq = acc[:n1].view(B, T, D)
     dvp = acc[n1:2 * n1].view(B, T, D)
-    db2 = acc[2 * n1:2 * n1 + n2].view(B, NID, T)
+    db2 = acc[2 * n1:2 * n1 + n2].view((B, T, NID) if tn else (B, NID, T))
     dob = acc[2 * n1 + n2:] if want_bias else None
-    hip.call('mg_attn_feat_bwd', hip.ptr(dout), hip.ptr(p), hip.ptr(feat), hip.ptr(kq), hip.ptr(vp), hip.ptr(ids), c_int(B), c_int(T), c_int(L),
-             c_int(D), c_int(NID), c_float(scale), hip.ptr(dfeat), hip.ptr(dkq), hip.ptr(dvp), hip.ptr(db2), hip.ptr(dob), hip.stream())
+    hip.call('mg_attn_feat_bwd_ex', hip.ptr(dout), hip.ptr(p), hip.ptr(feat), hip.ptr(kq), hip.ptr(vp), hip.ptr(ids), c_int(B), c_int(T), c_int(L),
+             c_int(D), c_int(NID), c_float(scale), hip.ptr(dfeat), hip.ptr(dkq), hip.ptr(dvp), hip.ptr(db2), hip.ptr(dob), c_int(int(tn)), hip.stream())
     return dfeat, dkq, dvp, db2, dob
 
 

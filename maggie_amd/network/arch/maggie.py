@@ -319,23 +319,33 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         # coarse alpha is identically zero (resnet_inst_matt_spconv.py:314: the ground truth then guides the detail region). Everything
         # else the detail stage needs from the host is drawn below, in the reference's order; no site count is ever read back.
         x_os8 = dense[0]
-        fl = [torch.isnan(dense[2]).any()] + ([nonzero[0] == 0] if self.training else [])      # (the flag is written by the up-sampling kernel)
         ovf = self.decoder.__dict__.get('_sparse_overflow') if self.decoder.sparse_capacity() < 1.0 else None
-        if ovf is not None:
-            fl.append(ovf[0] != 0)                                    # sticky: raised by an EARLIER step's detail stage (sparse_head.DeviceLevel)
         comm = None
         if self.training:
             from ... import parallel as _par
             comm = _par.SYNCBN_COMM if hasattr(_par.SYNCBN_COMM, 'error_word') else None
-        if comm is not None:
-            # the mailbox exchange of SyncBatchNorm never hangs the GPU: a peer that did not arrive leaves 1 + its rank in this word
-            fl = [f.to(torch.int32) for f in fl] + [comm.error_word[0]]
-        flags = torch.stack(fl).tolist()
-        if comm is not None:
-            word = flags.pop()
-            if word:
-                comm.error_word.zero_()
-                comm.raise_for(word)
+        tok = dense[2]
+        if tok.is_cuda and tok.dtype == torch.float32 and tok.is_contiguous():
+            # [NaN tokens, coarse alpha all zero (written by the up-sampling kernel), sparse overflow (sticky: raised by an EARLIER step's detail stage,
+            # sparse_head.DeviceLevel), mailbox error word (a SyncBatchNorm peer that did not arrive leaves 1 + its rank)] in one launch
+            # (mg_step_flags; was isnan + any + compare(s) + stack in front of the copy the host waits for)
+            words = torch.empty(4, dtype=torch.int32, device=tok.device)
+            K.hip.call('mg_step_flags', K.hip.ptr(tok), K.c_long(tok.numel()), K.hip.ptr(nonzero if self.training else None), K.hip.ptr(ovf),
+                       K.hip.ptr(None if comm is None else comm.error_word), K.hip.ptr(words), K.hip.stream())
+            words = words.tolist()
+            flags = [bool(words[0])] + ([bool(words[1])] if self.training else []) + ([bool(words[2])] if ovf is not None else [])
+            word = words[3]
+        else:
+            fl = [torch.isnan(tok).any()] + ([nonzero[0] == 0] if self.training else [])
+            if ovf is not None:
+                fl.append(ovf[0] != 0)
+            if comm is not None:
+                fl = [f.to(torch.int32) for f in fl] + [comm.error_word[0]]
+            flags = torch.stack(fl).tolist()
+            word = flags.pop() if comm is not None else 0
+        if comm is not None and word:
+            comm.error_word.zero_()
+            comm.raise_for(word)
         if flags[0]:
             raise ValueError("Mask is empty")
         if ovf is not None and flags[-1]:

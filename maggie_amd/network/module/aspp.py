@@ -30,12 +30,17 @@ class ASPP(nn.Module):
         dt = x.dtype
         N, H, W_, C = x.shape
 
+        xs = MF.Fan(x, 5)                                         # five consumers: their gradients meet in one launch (fp32 sum, rounded once)
+
         def branch(conv, bn):
             w = MF.plain_krsc(conv, dt)                           # (looked up on the calling stream: host-side only)
-            return lambda: MF.conv_bn_act(x, w, bn, MF.ACT_RELU, conv.kernel_size, conv.kernel_size, 1, conv.padding, conv.dilation)
+            xb = xs()
+            return lambda: MF.conv_bn_act(xb, w, bn, MF.ACT_RELU, conv.kernel_size, conv.kernel_size, 1, conv.padding, conv.dilation)
+
+        x5_in = xs()
 
         def pooled_branch():
-            pooled = x.float().mean((1, 2), keepdim=True).to(dt)                   # AdaptiveAvgPool2d(1)
+            pooled = MF.spatial_mean(x5_in)                        # AdaptiveAvgPool2d(1): one launch each way (was cast + strided reduce + cast)
             return MF.conv_bn_act(pooled, w5, self.aspp5_bn, MF.ACT_RELU, 1, 1, 1, 0, 1)
 
         w5 = MF.plain_krsc(self.aspp5, dt)

@@ -119,6 +119,9 @@ class InstanceMatteDecoder(nn.Module):
         with torch.autocast('cuda', enabled=False):
             pre = None                                            # (qk, tbl) of the NEXT tokens <- features block, computed one block early
             for i in range(self.n_block):
+                # this version of the feature rows has three consumers (tokens <- features here, then the features <- tokens attention and its
+                # residual): one alias each, their 8 MB gradients meet in one launch instead of two autograd adds
+                feat = MF.Fan(feat, 3)
                 tokens, att = self.token_feat_ca_layers[i].tokens_from_features(tokens, pos_t, feat, feat_ids, tbl, pre=pre)
                 if self.training:
                     atten_terms.append(self.compute_atten_loss(b, n_f, guidance_mask, att))

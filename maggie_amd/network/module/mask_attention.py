@@ -99,7 +99,7 @@ class CrossAttentionLayer(nn.Module):
         tokens = MF.take(tokens)
         d = tokens.shape[-1]
         _need_hip_attention(tokens.shape[1], d)
-        p, ctx = MF.attn_tokens_from_features(qk, tbl, feat, feat_ids, 1.0 / math.sqrt(d))
+        p, ctx = MF.attn_tokens_from_features(qk, tbl, MF.take(feat), feat_ids, 1.0 / math.sqrt(d))
         self._proj = None
         h = MF.token_linear(ctx, wv, bv)
         return MF.token_linear(h, self.multihead_attn.out_proj.weight, self.multihead_attn.out_proj.bias, res=tokens, ln=self.norm), p
@@ -134,12 +134,13 @@ class CrossAttentionLayer(nn.Module):
 
     def fft_finish(self, feat, feat_ids, res2, token_padding_mask, n_tokens):
         vp, kq, tbl = res2
+        feat, res = MF.take(feat), MF.take(feat)                 # (a functional.Fan hands out one alias per consumer: the attention and the residual)
         d = feat.shape[-1]
-        tbl = tbl.transpose(1, 2).contiguous()                                               # (b,n_id,T)
         _need_hip_attention(n_tokens, d)
+        # tbl stays (b,T,n_id) as the token-side linear wrote it: the kernels index it that way (tn) -- was a transposed copy each way per block
         out = MF.attn_features_from_tokens(feat, kq, tbl, vp, self.multihead_attn.out_proj.bias, token_padding_mask, feat_ids,
-                                           1.0 / math.sqrt(d))
-        return MF.rows_add_layernorm(feat, out, self.norm)
+                                           1.0 / math.sqrt(d), tn=True)
+        return MF.rows_add_layernorm(res, out, self.norm)
 
     def features_from_tokens(self, feat, feat_ids, id_table, tokens, token_pos, token_padding_mask, pre=None):
         """feat (b,L,d) <- tokens (b,T,d); query position = id_table[feat_ids]. Scores, masked softmax over the T tokens and

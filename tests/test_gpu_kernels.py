@@ -397,6 +397,13 @@ def test_attention_features_from_tokens(L, nid, masked):
     assert close(out.detach(), out_ref.detach(), 2e-5)
     for g, r, name in zip(gin, ref_in, ('dfeat', 'dkq', 'db2', 'dvp', 'dobias')):
         assert close(g.grad, r.grad, 2e-4), name
+    # the table in the layout the token-side linear writes it, (B, T, NID) with tn=True: same bits, gradient in that layout
+    gtn = [x.clone().to(dev).requires_grad_(True) for x in (feat, kq, b2.transpose(1, 2).contiguous(), vp, ob)]
+    out_tn = MF.attn_features_from_tokens(gtn[0], gtn[1], gtn[2], gtn[3], gtn[4], pad.to(dev) if masked else None, ids.to(dev), scale, tn=True)
+    (out_tn * r_out.to(dev)).sum().backward()
+    assert torch.equal(out_tn, out)
+    for i, (a, b_) in enumerate(zip(gtn, gin)):
+        assert torch.equal(a.grad, b_.grad.transpose(1, 2) if i == 2 else b_.grad), i
 
 
 def test_postprocess_alpha_matches_reference_fixture_and_oracle():
@@ -933,6 +940,42 @@ def test_batched_weight_pipeline_transposed_twin_gradient_layout_and_destination
     for a, b, d in zip(got, ref, dest):
         assert a.data_ptr() == d.data_ptr() and torch.equal(a, b) and torch.equal(d, b)
     assert torch.isnan(flat[params[0].numel():params[0].numel() + 16]).all()        # nothing written between the destinations
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32])
+def test_spatial_mean_and_k_way_sum(dtype):
+    """mg_spatial_mean (AdaptiveAvgPool2d(1) of ASPP's pooled branch, maggie/network/module/aspp.py:24-27,50-52) forward / backward against torch in
+    fp64, ragged channel count; mg_sum_k_t: k same-shaped tensors added in fp32 in list order and rounded once (functional.FanOut for 16-bit
+    activations), ragged length."""
+    from maggie_amd import functional as MF, kernels as K
+    dev = _dev()
+    g = torch.Generator().manual_seed(13)
+    for N, H, W, C in ((4, 16, 16, 512), (2, 7, 9, 40)):
+        x = (torch.randn((N, H, W, C), generator=g) + 0.5).to(dev, dtype).requires_grad_(True)
+        y = MF.spatial_mean(x)
+        ref = x.detach().double().mean((1, 2), keepdim=True)
+        assert y.shape == (N, 1, 1, C) and y.dtype == dtype
+        tol = 1e-6 if dtype == torch.float32 else 2.0 ** -8
+        assert float((y.double() - ref).abs().max()) <= tol * float(ref.abs().max())
+        dy = torch.randn((N, 1, 1, C), generator=g).to(dev, dtype)
+        (dx,) = torch.autograd.grad(y, x, dy)
+        want = (dy.double() / (H * W)).expand(N, H, W, C)
+        assert float((dx.double() - want).abs().max()) <= tol * float(want.abs().max())
+    for n in (4 * 16 * 16 * 512, 1003):
+        ts = [torch.randn(n, generator=g).to(dev, dtype) for _ in range(5)]
+        got = K.sum_k(ts)
+        acc = ts[0].float()
+        for t in ts[1:]:
+            acc = acc + t.float()
+        assert got.dtype == dtype and torch.equal(got, acc.to(dtype))
+    # through autograd: a 16-bit tensor with five consumers
+    x = torch.randn((2, 8, 8, 64), generator=g).to(dev, dtype).requires_grad_(True)
+    fan = MF.Fan(x, 5)
+    ws = [float(i + 1) for i in range(5)]
+    out = sum((fan() * w_).float().sum() for w_ in ws)
+    (gx,) = torch.autograd.grad(out, x)
+    assert torch.equal(gx, torch.full_like(x, 15.0))
 
 
 @pytest.mark.gpu
