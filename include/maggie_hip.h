@@ -357,6 +357,8 @@ int mg_attn_feat_bwd_ex(const float* dout, const float* p, const float* feat, co
  * plane has any non-zero weight (planes with all-zero weights contribute nothing and are skipped).
  * ------------------------------------------------------------------------------------------------------------- */
 int mg_plane_flags(const float* w, int P, int HW, int32_t* flags, void* stream);
+/* as_float != 0: flags is float[P], 0.0 / 1.0 (a per-plane scale: `valid_masks`, resnet_inst_matt_spconv.py:320) */
+int mg_plane_flags_ex(const float* w, int P, int HW, void* flags, int as_float, void* stream);
 /* loss weight of the OS8 prediction (arch/maggie.py:271-281): out = [plane p of gt has a positive pixel] + (reweight && (gt or a8 in
  * [1/255, 254/255])); fp32 planes [P][HW]; flags_scratch: P int32 */
 int mg_os8_weight(const float* gt, const float* a8, int P, long HW, int reweight, int32_t* flags_scratch, float* out, void* stream);
@@ -644,12 +646,16 @@ int mg_token_einsum_bwd(const void* dlog, const void* feat, int dtype, const flo
 int mg_sum_k(const float* const* srcs, int k, long n, float* out, void* stream);
 /* The same for tensors of `dtype` (MG_F32 / MG_BF16 / MG_F16; 16-byte aligned): 16-bit terms are added in fp32 in the given order and rounded once. */
 int mg_sum_k_t(const void* const* srcs, int k, long n, void* out, int dtype, void* stream);
-/* AdaptiveAvgPool2d(1) over NHWC rows (maggie/network/module/aspp.py:24-27): backward == 0: x (N, HW, C) -> out (N, C), the mean of each sample's rows
- * (fp32 sums in a fixed order); backward != 0: x = dy (N, C) -> out = dx (N, HW, C) = dy / HW. */
-int mg_spatial_mean(const void* x, void* out, int dtype, int N, int HW, int C, int backward, void* stream);
+/* AdaptiveAvgPool2d(1) over NHWC rows (maggie/network/module/aspp.py:24-27,50-52). mode 0: x (N, HW, C) -> out (N, C), the mean of each sample's rows
+ * (fp32 sums in a fixed order); mode 1: x = dy (N, C) -> out = dx (N, HW, C) = dy / HW; mode 2: like 0 without the division (the backward of broadcasting
+ * the pooled row back over the map). ld: element stride between the rows of x in modes 0 / 2 (0 = C; a channel slice of a wider map is read in place). */
+int mg_spatial_mean(const void* x, void* out, int dtype, int N, int HW, int C, int mode, int ld, void* stream);
 /* dsts[j][0 .. bytes[j]) = srcs[j][...] for j < k <= 16 as ONE launch (replaces torch._foreach_copy_ of contiguous same-type tensors = one hipMemcpyAsync
  * each: the outputs a replayed graph hands to the caller, engine/train.py:229-241 keeps them across steps; gradient hand-over between graphs). */
 int mg_copy_k(const void* const* srcs, void* const* dsts, const long* bytes, int k, void* stream);
+/* Any number of copies in one launch, the job list in DEVICE memory: table = int64[4 * jobs], (src, dst, bytes, first 4 KiB block) per job with the first
+ * blocks ascending from 0; nblk = total number of 4 KiB blocks. (A captured graph fills the table once, after the capture.) */
+int mg_copy_table(const long* table, int jobs, long nblk, void* stream);
 /* out[4] (int32, device) = [a NaN among the n fp32 tokens, nonzero[0] == 0, ovf[0] != 0, err[0]] -- NULL inputs give 0. The four words the host reads
  * between the trunk and the detail stage (maggie/network/module/mask_attention.py:95-98 raises on NaN tokens; resnet_inst_matt_spconv.py:314 switches
  * the guidance to the ground truth when the coarse alpha is zero), in one launch. */

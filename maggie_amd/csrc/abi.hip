@@ -105,3 +105,39 @@ extern "C" int mg_step_flags(const float* tokens, long n, const int* nonzero, co
     MG_CHECK_LAUNCH();
     return 0;
 }
+
+// ---- any number of device-to-device copies as ONE launch, the job list in device memory ------------------------------------------------------------
+// table: int64[4 * jobs] = (src, dst, bytes, first 4 KiB block) per job, first blocks ascending; nblk = total blocks. A captured backward graph ends by
+// moving the ~190 small parameter gradients nobody wrote in place (BatchNorm weights, biases, token-side matrices) into the optimizer's flat buffer:
+// torch._foreach_copy_ takes three multi-tensor launches (31 us) for them.
+namespace {
+__global__ __launch_bounds__(256) void copy_table_kernel(const long* __restrict__ table, int jobs, long nblk) {
+    for (long b = blockIdx.x; b < nblk; b += gridDim.x) {
+        int lo = 0, hi = jobs - 1;                               // last job whose first block is <= b
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (b >= table[4 * mid + 3]) lo = mid; else hi = mid - 1;
+        }
+        const long bytes = table[4 * lo + 2];
+        const long off = (b - table[4 * lo + 3]) * 4096;
+        const long n = bytes - off < 4096 ? bytes - off : 4096;
+        const char* s = (const char*)table[4 * lo] + off;
+        char* d = (char*)table[4 * lo + 1] + off;
+        if (n == 4096 && (((size_t)s | (size_t)d) & 15) == 0) {
+            ((uint4*)d)[threadIdx.x] = ((const uint4*)s)[threadIdx.x];
+        } else if (((n | (long)(size_t)s | (long)(size_t)d) & 3) == 0) {
+            for (long i = threadIdx.x; i < n / 4; i += 256) ((uint32_t*)d)[i] = ((const uint32_t*)s)[i];
+        } else {
+            for (long i = threadIdx.x; i < n; i += 256) d[i] = s[i];
+        }
+    }
+}
+}  // namespace
+extern "C" int mg_copy_table(const long* table, int jobs, long nblk, void* stream) {
+    if (jobs <= 0 || nblk <= 0) return 0;
+    if (!table) return -2;
+    const long grid = nblk < 2048 ? nblk : 2048;
+    hipLaunchKernelGGL(copy_table_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, table, jobs, nblk);
+    MG_CHECK_LAUNCH();
+    return 0;
+}

@@ -46,13 +46,13 @@ __device__ __forceinline__ void block_add(float v, float* dst, float* sh, float*
 }
 
 // flags[p] = any(w[p] > 0)
-__global__ __launch_bounds__(NT) void plane_flags_kernel(const float* __restrict__ w, int HW, int* __restrict__ flags) {
+__global__ __launch_bounds__(NT) void plane_flags_kernel(const float* __restrict__ w, int HW, int* __restrict__ flags, int one) {
     const int p = blockIdx.y;
     const float* wp = w + (long)p * HW;
     int any = 0;
     for (int i = blockIdx.x * NT + threadIdx.x; i < HW; i += gridDim.x * NT) any |= (wp[i] > 0.f);
     // every writer stores the same value: a plain store (no read-modify-write) is enough, and one per workgroup instead of one atomic per wave
-    if (__syncthreads_or(any) && threadIdx.x == 0) flags[p] = 1;
+    if (__syncthreads_or(any) && threadIdx.x == 0) flags[p] = one;
 }
 
 __global__ __launch_bounds__(NT) void plane_flags3_kernel(const P3 w, int Pper, int HW, int* __restrict__ flags) {
@@ -439,17 +439,20 @@ extern "C" int mg_loss_coef(const float* g3, const float* sums, float* coef5, vo
     return 0;
 }
 
-extern "C" int mg_plane_flags(const float* w, int P, int HW, int32_t* flags, void* stream) {
+// as_float != 0: the flags are written as fp32 0.0 / 1.0 (a per-plane scale that a kernel multiplies with, `valid_masks` of
+// resnet_inst_matt_spconv.py:320) instead of int32 0 / 1
+extern "C" int mg_plane_flags_ex(const float* w, int P, int HW, void* flags, int as_float, void* stream) {
     if (P <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = mg_zero_words(flags, (long)P, st);
     if (e != hipSuccess) return (int)e;
     dim3 g = grid2(HW, P);
     if (g.x > 64) g.x = 64;
-    hipLaunchKernelGGL(plane_flags_kernel, g, dim3(NT), 0, st, w, HW, flags);
+    hipLaunchKernelGGL(plane_flags_kernel, g, dim3(NT), 0, st, w, HW, (int*)flags, as_float ? 0x3f800000 : 1);
     MG_CHECK_LAUNCH();
     return 0;
 }
+extern "C" int mg_plane_flags(const float* w, int P, int HW, int32_t* flags, void* stream) { return mg_plane_flags_ex(w, P, HW, flags, 0, stream); }
 
 extern "C" int mg_os8_weight_ex(const float* gt, const float* a8, int P, long HW, int reweight, int32_t* flags_scratch, float* out, const int32_t* pvalid,
                                 void* stream);

@@ -1474,20 +1474,20 @@ extern "C" int mg_pool2x2(const void* in, void* out, int dtype, int op, int N, i
 // a strided torch reduction, cast back: 27 us for a 1 MB tensor; expand + divide + cast on the way back).
 namespace {
 template <typename T>
-__global__ __launch_bounds__(256) void spatial_mean_fwd_kernel(const T* __restrict__ x, int HW, int C, T* __restrict__ out) {
+__global__ __launch_bounds__(256) void spatial_mean_fwd_kernel(const T* __restrict__ x, int HW, int C, int ld, float mul, T* __restrict__ out) {
     __shared__ float part[4][64];
     const int n = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
     float a = 0.f;
     if (c < C) {
-        const T* p = x + ((long)n * HW) * C + c;
-        for (int r = g; r < HW; r += 4) a += ElemTraits<T>::ld(p + (long)r * C);
+        const T* p = x + ((long)n * HW) * ld + c;
+        for (int r = g; r < HW; r += 4) a += ElemTraits<T>::ld(p + (long)r * ld);
     }
     part[g][threadIdx.x & 63] = a;
     __syncthreads();
     if (g == 0 && c < C) {
         const int l = threadIdx.x;
         const float sum = (part[0][l] + part[1][l]) + (part[2][l] + part[3][l]);
-        ElemTraits<T>::st(out + (long)n * C + c, sum / (float)HW);
+        ElemTraits<T>::st(out + (long)n * C + c, sum * mul);
     }
 }
 template <typename T>
@@ -1499,15 +1499,19 @@ __global__ __launch_bounds__(256) void spatial_mean_bwd_kernel(const T* __restri
         ElemTraits<T>::st(dx + (long)n * total + i, ElemTraits<T>::ld(dy + (long)n * C + (i % C)) * inv);
 }
 }  // namespace
-extern "C" int mg_spatial_mean(const void* x, void* out, int dtype, int N, int HW, int C, int backward, void* stream) {
-    if (!x || !out || N <= 0 || HW <= 0 || C <= 0) return -2;
+extern "C" int mg_spatial_mean(const void* x, void* out, int dtype, int N, int HW, int C, int mode, int ld, void* stream) {
+    if (!x || !out || N <= 0 || HW <= 0 || C <= 0 || mode < 0 || mode > 2) return -2;
+    if (ld <= 0) ld = C;
+    if (ld < C || (mode == 1 && ld != C)) return -2;
+    const int backward = mode == 1;
+    const float mul = mode == 2 ? 1.f : 1.f / (float)HW;         // mode 2: the plain sum over the rows (backward of broadcasting one row to HW rows)
     hipStream_t st = (hipStream_t)stream;
 #define MG_SM(T)                                                                                                                                       \
     do {                                                                                                                                               \
         if (backward) {                                                                                                                                \
             long b = ((long)HW * C + 255) / 256; if (b > 1024) b = 1024;                                                                               \
             hipLaunchKernelGGL(spatial_mean_bwd_kernel<T>, dim3((unsigned)b, N), dim3(256), 0, st, (const T*)x, HW, C, (T*)out);                       \
-        } else hipLaunchKernelGGL(spatial_mean_fwd_kernel<T>, dim3((C + 63) / 64, N), dim3(256), 0, st, (const T*)x, HW, C, (T*)out);                  \
+        } else hipLaunchKernelGGL(spatial_mean_fwd_kernel<T>, dim3((C + 63) / 64, N), dim3(256), 0, st, (const T*)x, HW, C, ld, mul, (T*)out);         \
     } while (0)
     if (dtype == MG_BF16) MG_SM(bf16raw);
     else if (dtype == MG_F16) MG_SM(f16raw);

@@ -35,6 +35,8 @@ class ZeroArena:
         self.need = 1 << 20
         self.cap_buf = None
         self.cap_off = 0
+        self.spills = 0                                           # takes a capture's arena could not serve
+        self.tally = 0                                            # words handed out so far, eager or captured (graphs.py sizes a graph's arena by it)
 
     epoch = 0                                                     # bumped once per model forward: stamps per-step prepared weights
 
@@ -52,9 +54,13 @@ class ZeroArena:
         self.off = 0
         self.used = 0
 
-    def begin_capture(self, device):
-        """Called by the graph builder right after capture starts (forward graph and backward graph each get their own)."""
-        self.cap_buf = torch.zeros(max(self.need, 1 << 20), dtype=torch.float32, device=device)
+    def begin_capture(self, device, words=None):
+        """Called by the graph builder right after capture starts (forward graph and backward graph each get their own). `words`: what the same
+        function took in the warm-up run (`tally` difference): the graph's memset then covers what THIS graph uses, not the largest arena any
+        stage ever needed (four fills of 26 MB per step at the headline geometry)."""
+        # (+25 % + 1 MB: a few call sites take accumulators only while capturing)
+        n = max(self.need, 1 << 20) if words is None else int(words) + int(words) // 4 + (1 << 18)
+        self.cap_buf = torch.zeros(n, dtype=torch.float32, device=device)
         self.cap_off = 0
         # the library skips its own fill launches for accumulators inside this (zeroed once per replay) buffer: csrc/common.h mg_zero_words
         K.hip.lib().mg_set_zeroed_range(K.ctypes.c_void_p(self.cap_buf.data_ptr()), K.ctypes.c_long(4 * self.cap_buf.numel()))
@@ -69,6 +75,7 @@ class ZeroArena:
         if self.cap_buf is not None and torch.cuda.is_current_stream_capturing():
             v = self.take(n, device)
             return v if dtype == torch.float32 else v.view(dtype)
+        self.tally += (n + 63) // 64 * 64
         return torch.empty(n, dtype=dtype, device=device)
 
     def zeros(self, n, device, dtype=torch.float32):
@@ -76,12 +83,15 @@ class ZeroArena:
         if self.cap_buf is not None and torch.cuda.is_current_stream_capturing():
             v = self.take(n, device)
             return v if dtype == torch.float32 else v.view(dtype)
+        self.tally += (n + 63) // 64 * 64
         return torch.zeros(n, dtype=dtype, device=device)
 
     def take(self, n, device):
         n_al = (n + 63) // 64 * 64
+        self.tally += n_al
         if self.cap_buf is not None and torch.cuda.is_current_stream_capturing():
             if self.cap_off + n_al > self.cap_buf.numel():
+                self.spills += 1                                  # (correct, but a fill launch of its own: tests/test_gpu_graphs.py expects none)
                 return torch.zeros(n, dtype=torch.float32, device=device)
             v = self.cap_buf[self.cap_off:self.cap_off + n]
             self.cap_off += n_al
@@ -2054,11 +2064,30 @@ class SpatialMean(torch.autograd.Function):
     def backward(ctx, dy):
         H, W_ = ctx.hw
         N, C = dy.shape[0], dy.shape[-1]
-        return K.spatial_mean(dy.reshape(N, C), N, H * W_, backward=True).view(N, H, W_, C)
+        return K.spatial_mean(dy.reshape(N, C), N, H * W_, mode=1).view(N, H, W_, C)
 
 
 def spatial_mean(x):
     return SpatialMean.apply(x)
+
+
+class SpatialBroadcast(torch.autograd.Function):
+    """(N, 1, 1, C) -> its expansion over an (H, W) map (a view: the nearest up-sampling of a 1 x 1 map). Backward: the sum over the map in ONE launch,
+    read in place from a channel slice of a wider gradient (torch: a strided reduction, 18 us for the ASPP's pooled branch)."""
+
+    @staticmethod
+    def forward(ctx, x, H, W_):
+        return x.expand(x.shape[0], H, W_, x.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W_, C = dy.shape
+        rows = dy.as_strided((N, H * W_, C), (dy.stride(0), dy.stride(2), dy.stride(3))) if dy.stride(1) == W_ * dy.stride(2) else dy.reshape(N, H * W_, C)
+        return K.spatial_mean(rows, N, H * W_, mode=2).view(N, 1, 1, C), None, None
+
+
+def spatial_broadcast(x, H, W_):
+    return SpatialBroadcast.apply(x, H, W_)
 
 
 class FanOut(torch.autograd.Function):

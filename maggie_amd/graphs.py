@@ -141,12 +141,17 @@ class GraphedCallable:
         side.wait_stream(cur)
         with torch.cuda.stream(side), _ParamAliases(module, training) as aliases:
             self.params, cap_params, used = aliases.params, aliases.aliases, None
+            arena_fwd = arena_bwd = None
             for _ in range(warmup):
+                t0 = MF.ARENA.tally
                 outs = fn(*self.static_inputs)
+                arena_fwd = MF.ARENA.tally - t0                   # zero-arena words of the forward: sizes the forward graph's memset
                 if training:
                     req = [o for o in outs if o.requires_grad]
+                    t0 = MF.ARENA.tally
                     with torch.autocast('cuda', enabled=False):      # backward never runs under autocast (see below)
                         gr = torch.autograd.grad(req, cap_params + gin, [torch.ones_like(o) for o in req], allow_unused=True)
+                    arena_bwd = MF.ARENA.tally - t0
                     used = [x is not None for x in gr[:len(cap_params)]]
                     MF.join_side()
                     del gr
@@ -161,7 +166,7 @@ class GraphedCallable:
             MF.CAPTURE_TABLE[:] = [self.table, 0]
             try:
                 with torch.cuda.graph(self.fwd, pool=self.pool, stream=side, capture_error_mode=CAPTURE_MODE):
-                    MF.ARENA.begin_capture(dev)
+                    MF.ARENA.begin_capture(dev, arena_fwd)
                     self.static_outputs = tuple(fn(*self.static_inputs))
                     MF.join_side()
                 self.static_grad_outputs, self.static_param_grads, self.bwd = None, None, None
@@ -173,7 +178,7 @@ class GraphedCallable:
                     # or every fp32 matmul gradient is re-cast to bf16 (~300 extra cast kernels and a precision loss).
                     with torch.cuda.graph(self.bwd, pool=self.pool, stream=side, capture_error_mode=CAPTURE_MODE), \
                             torch.autocast('cuda', enabled=False):
-                        MF.ARENA.begin_capture(dev)
+                        MF.ARENA.begin_capture(dev, arena_bwd)
                         # with a gradient sink the producers that can (the batched weight pipeline's backward) write their parameter gradients
                         # straight into the sink's slices; _pack_grads below then only moves what did not land there
                         dest = self.grad_sink(self.params) if self.grad_sink is not None else None
@@ -288,9 +293,22 @@ class GraphedCallable:
                                          for v, g in zip(views, self.static_param_grads)):
                 # one multi-tensor launch: torch falls back to ONE COPY PER TENSOR for the whole list as soon as a single source is not
                 # contiguous (the video model's ConvGRU weight gradients are permuted views: 305 memcpy nodes per backward graph)
-                todo = [(v, g) for v, g in zip(views, self.static_param_grads) if g.data_ptr() != v.data_ptr()]     # the rest was written in place
-                if todo:
-                    torch._foreach_copy_([v for v, _ in todo], [g if g.is_contiguous() else g.contiguous() for _, g in todo])
+                todo = [(v, g if g.is_contiguous() else g.contiguous()) for v, g in zip(views, self.static_param_grads)
+                        if g.data_ptr() != v.data_ptr()]         # the rest was written in place
+                if todo and torch.cuda.is_current_stream_capturing() and all(v.is_contiguous() and v.is_cuda for v, _ in todo):
+                    # ONE launch for the ~190 small gradients (BatchNorm weights, biases, token-side matrices): the job list sits in the graph's
+                    # constants table, filled once after the capture (torch._foreach_copy_: three multi-tensor launches, 31 us)
+                    rows, blk = [], 0
+                    for v, g in todo:
+                        nbytes = g.numel() * g.element_size()
+                        rows += [g.data_ptr(), v.data_ptr(), nbytes, blk]
+                        blk += (nbytes + 4095) // 4096
+                    table = MF.capture_table(len(rows))
+                    MF.CAPTURE_FIXUPS.append((table, torch.tensor(rows, dtype=torch.int64)))
+                    self._sink_keep = [g for _, g in todo]       # the sources' memory belongs to the graph's pool: keep the tensors alive with it
+                    MF.K.hip.call('mg_copy_table', MF.K.hip.ptr(table), MF.K.c_int(len(todo)), MF.K.c_long(blk), MF.K.hip.stream())
+                elif todo:
+                    torch._foreach_copy_([v for v, _ in todo], [g for _, g in todo])
                 self.sink_views = list(views)
                 self.sink_runs = runs if runs is not None else list(views)    # contiguous stretches of the sink covering these parameters
                 self.flat_grads, self.grad_slots = {}, []

@@ -217,13 +217,18 @@ def sum_k(ts, out=None):
     return out
 
 
-def spatial_mean(x, N, HW, backward=False):
-    """AdaptiveAvgPool2d(1) over NHWC rows: x (N, HW, C) -> (N, C); backward: x = dy (N, C) -> dx (N, HW, C) = dy / HW (mg_spatial_mean)."""
+def spatial_mean(x, N, HW, mode=0):
+    """AdaptiveAvgPool2d(1) over NHWC rows (mg_spatial_mean). mode 0: x (N, HW, C) -> (N, C) mean; 1: x = dy (N, C) -> dx (N, HW, C) = dy / HW;
+    2: x (N, HW, C) -> (N, C) sum. In modes 0 / 2 x may be a channel slice of a wider (N, HW, C') map (uniform row stride): read in place."""
     C = x.shape[-1]
-    x = x.contiguous()
+    ld = C
+    if mode != 1 and x.dim() == 3 and x.stride(2) == 1 and x.stride(0) == HW * x.stride(1) and x.stride(1) >= C:
+        ld = x.stride(1)
+    else:
+        x = x.contiguous()
     hip.need_cuda(x)
-    out = torch.empty((N, HW, C) if backward else (N, C), dtype=x.dtype, device=x.device)
-    hip.call('mg_spatial_mean', hip.ptr(x), hip.ptr(out), c_int(hip.dtype_code(x)), c_int(N), c_int(HW), c_int(C), c_int(int(backward)), hip.stream())
+    out = torch.empty((N, HW, C) if mode == 1 else (N, C), dtype=x.dtype, device=x.device)
+    hip.call('mg_spatial_mean', hip.ptr(x), hip.ptr(out), c_int(hip.dtype_code(x)), c_int(N), c_int(HW), c_int(C), c_int(mode), c_int(ld), hip.stream())
     return out
 
 
@@ -754,14 +759,14 @@ def upsample_tanh_bwd(dout, out, strides, N, C, h, w, scale, din, apply_tanh=Tru
     return din
 
 
-def plane_flags(planes):
-    """int32 [P]: 1 where a (.., H, W) fp32 plane holds any value > 0 (mg_plane_flags)."""
+def plane_flags(planes, as_float=False):
+    """int32 [P]: 1 where a (.., H, W) fp32 plane holds any value > 0 (mg_plane_flags); as_float: fp32 0.0 / 1.0 instead."""
     H, W = planes.shape[-2:]
     P = planes.numel() // (H * W)
-    flags = ACC(P, planes.device, torch.int32)
+    flags = ACC(P, planes.device, torch.float32 if as_float else torch.int32)
     hip.need_cuda(planes)
     assert planes.dtype == torch.float32 and planes.is_contiguous()
-    hip.call('mg_plane_flags', hip.ptr(planes), c_int(P), c_int(H * W), hip.ptr(flags), hip.stream())
+    hip.call('mg_plane_flags_ex', hip.ptr(planes), c_int(P), c_int(H * W), hip.ptr(flags), c_int(int(as_float)), hip.stream())
     return flags
 
 

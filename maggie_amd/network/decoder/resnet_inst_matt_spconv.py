@@ -205,7 +205,12 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
 
     def os32_to_os8(self, x, mid_fea, b, n_f, n_i, masks, gt_alphas):
         masks = masks.reshape(b, n_f, n_i, masks.shape[2], masks.shape[3])
-        valid_masks = masks.flatten(0, 1).sum((2, 3), keepdim=True) > 0
+        m2 = masks.flatten(0, 1)
+        if m2.is_cuda and m2.dtype == torch.float32 and m2.is_contiguous():
+            # `sum > 0` of a non-negative mask plane == "some element > 0": one launch, already the 0.0 / 1.0 scale the up-sampling kernel multiplies with
+            valid_masks = K.plane_flags(m2, as_float=True).view(m2.shape[0], m2.shape[1], 1, 1)
+        else:
+            valid_masks = m2.sum((2, 3), keepdim=True) > 0
         gt_masks = None
         if self.training:
             # (gt_alphas > 0) of :322 is applied AFTER the decoder's max-pooling to OS8 (max > 0 <=> any > 0): no full-resolution compare pass

@@ -50,7 +50,7 @@ class ASPP(nn.Module):
                                          (self.aspp4, self.aspp4_bn))] + [pooled_branch]
         outs = MF.parallel_branches(fns, x.device, 'aspp')
         x5 = outs[4]
-        outs = list(outs[:4]) + [x5.expand(N, H, W_, x5.shape[-1])]                # nearest upsample of a 1x1 map
+        outs = list(outs[:4]) + [MF.spatial_broadcast(x5, H, W_)]                   # nearest upsample of a 1x1 map
         y = torch.cat(outs, -1)
         w2 = MF.plain_krsc(self.conv2, dt)
         return MF.conv_bn_act(y, w2, self.bn2, MF.ACT_RELU, 1, 1, 1, 0, 1, link_out=True)     # sole consumer: the decoder's first (transposed) conv

@@ -61,6 +61,8 @@ def test_graphed_step_matches_eager_step(kind, train, bf16):
     model, _ = _build(kind, dev, train)
     batch = _to(synth.synthetic_batch(b, n_f, 2, 64, 64, seed=DSEED, train=train, max_inst=10, it=10000), dev)
     state = copy.deepcopy(model.state_dict())
+    from maggie_amd import functional as MF
+    spills0 = MF.ARENA.spills
     e0 = _one_step(model, state, batch, False, train, bf16)
     e1 = _one_step(model, state, batch, False, train, bf16)
     g_first = _one_step(model, state, batch, True, train, bf16)       # geometry seen for the first time: eager
@@ -68,6 +70,8 @@ def test_graphed_step_matches_eager_step(kind, train, bf16):
     g_rep = _one_step(model, state, batch, True, train, bf16)         # pure replay
     n_graphs = sum(1 for v in model.__dict__.get('_trunk_graphs', {}).values() if not isinstance(v, (int, str)))
     assert n_graphs == 1, 'exactly one trunk graph must have been captured (got %d)' % n_graphs
+    # every graph's zero arena is sized by what its function took in the warm-up run (round 5): nothing may have spilled into fill launches of its own
+    assert MF.ARENA.spills == spills0, 'a captured graph took more zero-arena words than its warm-up run'
     assert set(g_rep['grads']) == set(e0['grads'])
     noise = _dist(e1, e0)
     # Gradients: batch-statistic BN over 2..8 samples amplifies fp32 atomics noise into percent-level relative differences that

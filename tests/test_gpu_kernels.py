@@ -962,6 +962,14 @@ def test_spatial_mean_and_k_way_sum(dtype):
         (dx,) = torch.autograd.grad(y, x, dy)
         want = (dy.double() / (H * W)).expand(N, H, W, C)
         assert float((dx.double() - want).abs().max()) <= tol * float(want.abs().max())
+        # the broadcast back over the map: a view forward; backward = the sum over the map, read in place from a channel slice of a wider gradient
+        p_ = torch.randn((N, 1, 1, C), generator=g).to(dev, dtype).requires_grad_(True)
+        wide = torch.cat([MF.spatial_broadcast(p_, H, W), x.detach()], -1)
+        assert torch.equal(wide[..., :C], p_.detach().expand(N, H, W, C))
+        gw = torch.randn((N, H, W, 2 * C), generator=g).to(dev, dtype)
+        (gp,) = torch.autograd.grad(wide, p_, gw)
+        want = gw[..., :C].double().sum((1, 2), keepdim=True)
+        assert float((gp.double() - want).abs().max()) <= tol * float(want.abs().max())
     for n in (4 * 16 * 16 * 512, 1003):
         ts = [torch.randn(n, generator=g).to(dev, dtype) for _ in range(5)]
         got = K.sum_k(ts)
