@@ -1603,7 +1603,34 @@ def matting_losses_multi(preds, target, weights, pvalid=None):
     if not LOSS_MULTI or len(preds) == 1 or len(preds) > 3:
         return [matting_losses(p_, target, w_, pvalid) for p_, w_ in zip(preds, weights)]
     out = MattingLossesMulti.apply(target, pvalid, *preds, *weights)
-    return [row.unbind(0) for row in out.unbind(0)]
+    cells = SplitGrid.apply(out)
+    n = out.shape[1]
+    return [cells[i * n:(i + 1) * n] for i in range(out.shape[0])]
+
+
+class SplitGrid(torch.autograd.Function):
+    """A small 2-D tensor -> its elements as zero-dim views, row-major. Backward: when the elements' gradients are consecutive words of ONE buffer in
+    that order (the weighted sum of the loss terms hands them out that way: ScalarLinComb.backward, arch/maggie.py compute_loss orders its terms to
+    match) the buffer's window IS the gradient -- no launch; otherwise they are stacked (unbind + unbind cost four stack launches per step)."""
+
+    @staticmethod
+    def forward(ctx, t):
+        ctx.set_materialize_grads(False)
+        ctx.shape = t.shape
+        return tuple(t[i, j] for i in range(t.shape[0]) for j in range(t.shape[1]))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        R, C = ctx.shape
+        g0 = gs[0]
+        if g0 is not None and all(g is not None and g.dtype == torch.float32 and g.numel() == 1 and g.is_cuda and
+                                  g.untyped_storage().data_ptr() == g0.untyped_storage().data_ptr() and g.data_ptr() == g0.data_ptr() + 4 * i
+                                  for i, g in enumerate(gs)):
+            return g0.as_strided((R, C), (C, 1))
+        live = next((g for g in gs if g is not None), None)
+        if live is None:
+            return None
+        return torch.stack([(g if g is not None else torch.zeros_like(live)).reshape(()).to(live.dtype) for g in gs]).view(R, C)
 
 
 LOSS_MULTI = os.environ.get('MAGGIE_LOSS_MULTI', '1') != '0'

@@ -643,6 +643,11 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             d4 = MF.dtssd_loss(rs(a4), rs(alphas), rs(weight_os4))
             d8 = MF.dtssd_loss(rs(a8), rs(alphas), rs(weight_os8))
             family('loss_dtSSD', self.loss_dtSSD_w, d1, d4, d8)
+        if len(terms) == 9 and self.loss_dtSSD_w <= 0:
+            # scale-major order [rec, lap, grad of OS1 | of OS4 | of OS8] -- the order the fused loss pipeline holds its nine sums in: the gradients of
+            # the weighted sum then ARE that tensor's gradient, in place (functional.SplitGrid; family-major order cost four stack launches per step)
+            order = [3 * j + s_ for s_ in range(3) for j in range(3)]
+            terms, coefs = [terms[i] for i in order], [coefs[i] for i in order]
         if defer_total:
             loss_dict['_total_terms'] = (terms, coefs)       # update_additional_decoder_loss appends the decoder's terms; _finish_total sums once
         else:
