@@ -24,13 +24,14 @@ class ResShortCut_InstMattSpconv_BiTempSpar_Dec(ResShortCut_InstMattSpconv_Dec):
             SpectralNorm(conv3x3(64, 32)), self._norm_layer(32), Marker('ReLU'),
             conv3x3(32, 1))
 
-    def _diff(self, x):
-        """x: (b, h, w, 128) NHWC -> fp32 logits upsampled x8: (b, 1, H, W)."""
+    def _diff(self, x, w_last=None):
+        """x: (b, h, w, 128) NHWC -> fp32 logits upsampled x8: (b, 1, H, W). `w_last`: the last (plain) conv's weight, already in the kernels'
+        layout (frame_diffs converts it once for all the pairs)."""
         m = self.diff_module
         dt = x.dtype
         x = MF.conv_bn_act(x, m[0].krsc(dt, x.shape[-1]), m[1], MF.ACT_RELU, 1, 1, 1, 0, 1, link_out=True)
         x = MF.conv_bn_act(x, m[3].krsc(dt, x.shape[-1]), m[4], MF.ACT_RELU, 3, 3, 1, 1, 1, link_out=True)
-        x = MF.conv2d(x, MF.weight_oihw_to_krsc(m[6].weight, dt, None, 8), None, 3, 3, 1, 1, 1)
+        x = MF.conv2d(x, MF.weight_oihw_to_krsc(m[6].weight, dt, None, 8) if w_last is None else w_last, None, 3, 3, 1, 1, 1)
         return MF.upsample_tanh(x, 1, 8, True, apply_tanh=False)
 
     def frame_diffs(self, feat):
@@ -40,7 +41,9 @@ class ResShortCut_InstMattSpconv_BiTempSpar_Dec(ResShortCut_InstMattSpconv_Dec):
         trunk graphs. feat (b, n_f, h, w, C) NHWC -> (2*(n_f-1), b, 1, H, W) fp32 logits."""
         n_f = feat.shape[1]
         pairs = [(i - 1, i) for i in range(1, n_f)] + [(i, i - 1) for i in range(n_f - 1, 0, -1)]
-        return torch.stack([self._diff(torch.cat([feat[:, a], feat[:, b]], dim=-1)) for a, b in pairs], 0)
+        # the plain last conv's weight is the same for every pair (the two SpectralNorm convs advance per call): converted once
+        w_last = MF.weight_oihw_to_krsc(self.diff_module[6].weight, feat.dtype, None, 8)
+        return torch.stack([self._diff(torch.cat([feat[:, a], feat[:, b]], dim=-1), w_last) for a, b in pairs], 0)
 
     def dense_stage(self, x, mid_fea, b, n_f, n_i, masks, gt_alphas, mem_feat=None):
         out = super().dense_stage(x, mid_fea, b, n_f, n_i, masks, gt_alphas, mem_feat)

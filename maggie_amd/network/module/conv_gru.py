@@ -19,11 +19,16 @@ class ConvGRU(nn.Module):
         self.ih = nn.Sequential(gate(channels * 2), nn.Sigmoid())        # activations live in the fused kernels; kept for the
         self.hh = nn.Sequential(gate(channels), nn.Tanh())               # reference's module / state_dict layout
 
-    @staticmethod
-    def _gate_conv(seq, inp):
+    def _gate_conv(self, seq, inp):
         conv = seq[0]
-        return MF.conv2d(inp, MF.plain_krsc(conv, inp.dtype, keep=True), conv.bias.float(), conv.kernel_size, conv.kernel_size, 1,
+        fan = self.__dict__.get('_bias_fans', {}).get(id(conv))          # the bias serves every cell of the clip: one alias per cell (functional.Fan)
+        bias = MF.take(fan) if fan is not None else conv.bias.float()
+        return MF.conv2d(inp, MF.plain_krsc(conv, inp.dtype, keep=True), bias, conv.kernel_size, conv.kernel_size, 1,
                          conv.padding, conv.dilation)                    # keep: one cell per frame and direction, same weights
+
+    def _fan_biases(self, cells):
+        """`cells` gate evaluations follow: their bias gradients meet in ONE launch each (was cells - 1 autograd adds per bias)."""
+        self.__dict__['_bias_fans'] = {id(c): MF.Fan(c.bias.float(), cells) for c in (self.ih[0], self.hh[0])} if cells > 2 else {}
 
     def plain_convs(self):
         return [self.ih[0], self.hh[0]]
@@ -73,10 +78,13 @@ class ConvGRU(nn.Module):
         # frames leave the clip through ONE unbind (its backward is one stack; n selects cost a fill, a copy and an accumulation add each) and
         # the reversed pass runs over the frame list backwards -- no flipped copies of the clip or of its states
         frames = feat.unbind(1)
+        self._fan_biases(len(frames) + (len(frames) - 1 if temp_method == 'bi' else 0))
         states = self.run_frames(frames, prev_h_state if prev_h_state is not None else feat.new_zeros(feat.shape[:1] + feat.shape[-3:]))
         fwd = torch.stack(states, 1)
         if temp_method != 'bi':
+            self.__dict__['_bias_fans'] = {}
             return fwd, fwd
         rev = self.run_frames(frames[-2::-1], states[-1])         # rev[k] belongs to frame n - 2 - k
+        self.__dict__['_bias_fans'] = {}
         # every frame but the last is the mean of the two passes; the last one pairs with itself: (f + f) * 0.5 == f bit for bit
         return (fwd + torch.stack(rev[::-1] + [states[-1]], 1)) * 0.5, fwd
