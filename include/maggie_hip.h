@@ -693,6 +693,10 @@ int mg_mailbox_allreduce_to(const mg_mailbox* mb, const float* src, float* dst, 
 int mg_mailbox_bn_finalize(const mg_mailbox* mb, const float* stats, int nrep, float count, int C, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, float momentum, float eps, float* outs, float* count_out,
                            uint32_t* seq_dev, int32_t* err_dev, long spin_ticks, void* stream);
+/* the same with this rank's row count read from the device (count_dev: int32 [1], NULL = use `count`): BatchNorm1d over the sparse head's live rows */
+int mg_mailbox_bn_finalize_dev(const mg_mailbox* mb, const float* stats, int nrep, float count, const int32_t* count_dev, int C, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* outs, float* count_out,
+                               uint32_t* seq_dev, int32_t* err_dev, long spin_ticks, void* stream);
 
 #ifdef __cplusplus
 }

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(1024) void mailbox_bn_finalize_kernel(const mg_mail
                                                                    const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
                                                                    float* running_var, float momentum, float eps, float* __restrict__ outs,
                                                                    float* __restrict__ count_out, uint32_t* __restrict__ seq_dev, int32_t* __restrict__ err_dev,
-                                                                   long spin_ticks) {
+                                                                   long spin_ticks, const int32_t* __restrict__ count_dev) {
     __shared__ float pooled[PACK];
     // replica sums first, all loads in flight at once (1024 threads, four independent accumulators): inside the deposit loop every element's 32
     // loads would wait behind the previous element's system-scope stores (19 us per launch, measured)
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(1024) void mailbox_bn_finalize_kernel(const mg_mail
         for (; r < nrep; ++r) a0 += stats[(size_t)r * 2 * C + i];
         pooled[i] = (a0 + a1) + (a2 + a3);
     }
-    if (threadIdx.x == 0) pooled[2 * C] = count;
+    if (threadIdx.x == 0) pooled[2 * C] = count_dev ? (float)count_dev[0] : count;      // (the sparse head's live-row count lives on the device)
     __syncthreads();
     mailbox_exchange(mb, 2 * C + 1, seq_dev, err_dev, spin_ticks, [&](int i) { return pooled[i]; }, [&](int i, float a) { pooled[i] = a; });
     __syncthreads();
@@ -154,13 +154,20 @@ extern "C" int mg_mailbox_allreduce_to(const mg_mailbox* mb, const float* src, f
     return 0;
 }
 
-extern "C" int mg_mailbox_bn_finalize(const mg_mailbox* mb, const float* stats, int nrep, float count, int C, const float* gamma, const float* beta,
-                                      float* running_mean, float* running_var, float momentum, float eps, float* outs, float* count_out,
-                                      uint32_t* seq_dev, int32_t* err_dev, long spin_ticks, void* stream) {
+// count_dev (or NULL): this rank's row count as a device int32 (BatchNorm1d over the sparse head's live rows) -- `count` is then ignored
+extern "C" int mg_mailbox_bn_finalize_dev(const mg_mailbox* mb, const float* stats, int nrep, float count, const int32_t* count_dev, int C,
+                                          const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                          float* outs, float* count_out, uint32_t* seq_dev, int32_t* err_dev, long spin_ticks, void* stream) {
     if (!mb || !stats || !outs || !count_out || !seq_dev || !err_dev) return -1;
     if (C < 1 || 2 * C + 1 > PACK || nrep < 1 || mb->world < 1 || mb->world > MG_MAILBOX_MAX_RANKS || mb->rank < 0 || mb->rank >= mb->world) return -2;
     hipLaunchKernelGGL(mailbox_bn_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, *mb, stats, nrep, count, C, gamma, beta, running_mean,
-                       running_var, momentum, eps, outs, count_out, seq_dev, err_dev, spin_ticks);
+                       running_var, momentum, eps, outs, count_out, seq_dev, err_dev, spin_ticks, count_dev);
     MG_CHECK_LAUNCH();
     return 0;
+}
+extern "C" int mg_mailbox_bn_finalize(const mg_mailbox* mb, const float* stats, int nrep, float count, int C, const float* gamma, const float* beta,
+                                      float* running_mean, float* running_var, float momentum, float eps, float* outs, float* count_out,
+                                      uint32_t* seq_dev, int32_t* err_dev, long spin_ticks, void* stream) {
+    return mg_mailbox_bn_finalize_dev(mb, stats, nrep, count, nullptr, C, gamma, beta, running_mean, running_var, momentum, eps, outs, count_out, seq_dev,
+                                      err_dev, spin_ticks, stream);
 }

@@ -755,6 +755,7 @@ class BnLink:
 # the activation mask from y. What travels between the two layers is a LazyAct, NOT a tensor: only conv2d / conv_bn_act understand it, anything
 # else fails loudly instead of silently consuming un-normalised values. MAGGIE_LAZY_BN=0 restores the stored form.
 LAZY_BN = _os.environ.get('MAGGIE_LAZY_BN', '1') != '0'
+LAZY_BN_SYNC = os.environ.get('MAGGIE_LAZY_BN_SYNC', '1') != '0'   # the operand path under SyncBatchNorm too (mailbox exchange only); 0: stored form (A/B)
 
 
 class _Materialize(torch.autograd.Function):
@@ -804,18 +805,29 @@ class BNLazy(torch.autograd.Function):
     gradient with respect to act(BN(x)) -- and runs the ordinary reduce + apply pair with the activation mask re-formed from x."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, act, stats, mask_x_pos, link=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, act, stats, mask_x_pos, link=None, group=None):
         C = x.shape[-1]
         x2 = x.contiguous().view(-1, C)
         M = x2.shape[0]
         centered = False
         if stats is None:
             stats = K.colstats(x2)
-        elif stats.dim() == 1:                                    # (MAGGIE_DETERMINISTIC=0: a sums-only row from the conv epilogue -> exact two-pass variance)
+        elif stats.dim() == 1 and group is None:                  # (MAGGIE_DETERMINISTIC=0: a sums-only row from the conv epilogue -> exact two-pass variance)
             stats, centered = K.colstats_centered(x2, stats, have_sum=True), True
-        sc, sh, mean, invstd = K.bn_finalize(stats, M, gamma, beta, running_mean, running_var, momentum, eps, centered=centered)
+        cnt_t = None
+        if group is not None:
+            # SyncBatchNorm (lazy_bn_ok: only with the mailbox exchange): this rank's statistics rows -> [ordered row sum] -> exchange + finalize in
+            # ONE launch (mailbox.MailboxComm.bn_finalize) -> the same (scale | shift | mean | invstd) pack, over the rows of ALL ranks
+            from . import parallel as _par
+            if stats.dim() == 2 and stats.shape[0] > K.STAT_REPLICAS:
+                stats = K.stat_rows_sum(stats)
+            sc, sh, mean, invstd, cnt_t = _par.SYNCBN_COMM.bn_finalize(stats.contiguous(), float(M), gamma, beta, running_mean, running_var, momentum, eps)
+            link = None                                           # (the linked backward sums are local: not under SyncBatchNorm)
+        else:
+            sc, sh, mean, invstd = K.bn_finalize(stats, M, gamma, beta, running_mean, running_var, momentum, eps, centered=centered)
         pack = sc._base if sc._base is not None else torch.cat([sc, sh, mean, invstd])       # (4, C) = scale | shift | mean | invstd
-        ctx.save_for_backward(x2, pack)
+        ctx.save_for_backward(x2, pack, cnt_t)
+        ctx.group = group
         ctx.meta = (x.shape, M, C, act, mask_x_pos)
         ctx.link = None
         if link is not None and (C * x2.element_size()) % 16 == 0 and ((C * x2.element_size()) // 16 & ((C * x2.element_size()) // 16 - 1)) == 0:
@@ -828,28 +840,48 @@ class BNLazy(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dz, _dsc, _dsh):
-        x2, pack = ctx.saved_tensors
+        x2, pack, cnt_t = ctx.saved_tensors
         shape, M, C, act, mask_x_pos = ctx.meta
         link, ctx.link = ctx.link, None
         if dz is None:
-            return (None,) * 11
+            return (None,) * 12
+        if ctx.group is not None:
+            # SyncBatchNorm: dx needs the two sums over ALL ranks' rows, dgamma / dbeta stay local (BNAct.backward): reduce | exchange | apply
+            from .parallel import syncbn_exchange_backward
+            flat = pack.view(-1)
+            sc, sh, mean, invstd = flat[:C], flat[C:2 * C], flat[2 * C:3 * C], flat[3 * C:4 * C]
+            dz2 = rows_of(dz, C)
+            _, _, local = K.bn_backward(dz2, None, x2, sc, mean, invstd, M, act=act, slope=LRELU_SLOPE, reduce_only=True, mask_x_pos=mask_x_pos,
+                                        sums=ARENA.take(2 * C, dz.device), shift=sh)
+            sums, local = syncbn_exchange_backward(local, ctx.group)
+            dx, _, _ = K.bn_backward(dz2, None, x2, sc, mean, invstd, M, act=act, slope=LRELU_SLOPE, mask_x_pos=mask_x_pos, sums=sums, apply_only=True,
+                                     count_ptr=cnt_t, shift=sh)
+            if not torch.cuda.is_current_stream_capturing():
+                local = local.clone()                             # the arena slice dies with the step; inside a graph it is the graph's own
+            return dx.view(shape), local[C:2 * C], local[:C], None, None, None, None, None, None, None, None, None
         if link is not None and link.g is not None and link.sums is not None and link.g.data_ptr() == dz.data_ptr() and dz.is_contiguous():
             # the consumer conv's data-gradient epilogue already wrote g = dz * act'(z) (into `dz`) and one row of the two sums per output tile
             dx, sums = K.bn_bwd_apply_linked(dz.view(-1, C), x2, pack.view(-1), _linked_sums(link.sums), M, mask_x_pos)
             link.clear()
-            return dx.view(shape), sums[C:], sums[:C], None, None, None, None, None, None, None, None
+            return dx.view(shape), sums[C:], sums[:C], None, None, None, None, None, None, None, None, None
         if link is not None:
             link.clear()
         sums = ARENA.take(2 * C, dz.device) if torch.cuda.is_current_stream_capturing() else None
         dx, _, sums = K.bn_train_bwd(rows_of(dz, C), None, x2, pack.view(-1), act, LRELU_SLOPE, False, mask_x_pos, sums)
-        return dx.view(shape), sums[C:], sums[:C], None, None, None, None, None, None, None, None
+        return dx.view(shape), sums[C:], sums[:C], None, None, None, None, None, None, None, None, None
 
 
 def lazy_bn_ok(x, bn, res, res2):
     """May this conv -> BatchNorm (+ activation) layer leave its apply pass to the consumer? Training with local batch statistics, 16-bit storage,
     more rows than the one-launch small-layer path takes, no residual entering the activation."""
     C = x.shape[-1]
-    return (LAZY_BN and bn.training and torch.is_grad_enabled() and res is None and res2 is None and x.dtype != torch.float32 and _sync_group(bn) is None
+    if _sync_group(bn) is not None:
+        # SyncBatchNorm: with the in-graph mailbox exchange (one launch: exchange + finalize); the collective-based exchanges keep the stored form
+        from . import parallel as _par
+        comm = _par.SYNCBN_COMM
+        if not (LAZY_BN_SYNC and comm is not None and hasattr(comm, 'bn_finalize') and comm.can_finalize(C) and x.is_cuda):
+            return False
+    return (LAZY_BN and bn.training and torch.is_grad_enabled() and res is None and res2 is None and x.dtype != torch.float32
             and bn.weight is not None and bn.weight.dtype == torch.float32 and bn.weight.numel() == C and bn.running_mean is not None
             and bn.running_mean.numel() == C and x.numel() // C > BN_SMALL_ROWS)
 
@@ -1226,7 +1258,8 @@ def conv_bn_act(x, w, bn, act=ACT_NONE, R=3, S=3, stride=1, pad=1, dil=1, transp
                 bn.num_batches_tracked.add_(1)
         a = ACT_NONE if relu_before_bn else act
         lk = BnLink() if BN_LINK else None
-        t, sc, sh = BNLazy.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, 0.1 if bn.momentum is None else bn.momentum, bn.eps, a, stats, mask_up, lk)
+        t, sc, sh = BNLazy.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, 0.1 if bn.momentum is None else bn.momentum, bn.eps, a, stats, mask_up, lk,
+                                 _sync_group(bn))
         lz = LazyAct(t, sc, sh, a, LRELU_SLOPE, lk if (lk is not None and lk.x2 is not None) else None)
         return (lz, x if xc is None else xc) if carry else lz
     link = BnLink() if (link_out and BN_LINK and bn.training and res2 is None and torch.is_grad_enabled()) else None

@@ -413,14 +413,17 @@ def affine_act(x, scale=None, shift=None, res=None, res_mode=1, res2=None, act=A
 
 
 def bn_backward(dy, y, x, scale, mean, invstd, count, act=ACT_NONE, slope=0.2, want_dres=False, mask_x_pos=False, yoff=0,
-                count_ptr=None, sums=None, want_dx=True, reduce_only=False, apply_only=False, rows=None):
+                count_ptr=None, sums=None, want_dx=True, reduce_only=False, apply_only=False, rows=None, shift=None):
     """BatchNorm(+activation) backward over rows x channels.
-    Returns (dx, dres, sums) with sums = [sum g, sum g*xhat] (= dbeta, dgamma)."""
+    Returns (dx, dres, sums) with sums = [sum g, sum g*xhat] (= dbeta, dgamma). `shift` with y None: the activation output was never stored
+    (operand-path BatchNorm); its sign is re-formed from x * scale + shift (mask_from_x)."""
     M, C = x.shape[0], x.shape[-1]
     hip.need_cuda(dy, y, x, scale, mean, invstd)
     p = _rowwise(x, M, C)
     p.dy, p.lddy = hip.ptr(dy), _ld(dy)
     p.y, p.ldy, p.yoff = hip.ptr(y), (_ld(y) if y is not None else 0), yoff
+    if y is None and shift is not None and act != ACT_NONE:
+        p.y, p.ldy, p.yoff, p.mask_from_x, p.shift = hip.ptr(x), C, 0, 1, hip.ptr(shift)
     p.scale, p.mean, p.invstd = hip.ptr(scale), hip.ptr(mean), hip.ptr(invstd)
     if sums is None:
         sums = torch.zeros(2 * C, dtype=torch.float32, device=x.device)

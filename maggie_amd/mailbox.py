@@ -115,16 +115,17 @@ class MailboxComm:
     def can_finalize(self, C):
         return 2 * C + 1 <= PACK
 
-    def bn_finalize(self, stats, count, gamma, beta, running_mean, running_var, momentum, eps):
+    def bn_finalize(self, stats, count, gamma, beta, running_mean, running_var, momentum, eps, count_dev=None):
         """SyncBN forward statistics in ONE launch (mg_mailbox_bn_finalize): this rank's statistics ([nrep][2C] or [2C]: sum x | sum x^2) and row
-        count -> (scale, shift, mean, invstd) views of one [4C] buffer, the global count [1]; running statistics updated in place."""
+        count -> (scale, shift, mean, invstd) views of one [4C] buffer, the global count [1]; running statistics updated in place.
+        `count_dev` (int32 [1] on the device): the row count when only the device knows it (the sparse head's live rows)."""
         nrep = stats.shape[0] if stats.dim() == 2 else 1
         C = stats.shape[-1] // 2
         outs = torch.empty(4 * C, dtype=torch.float32, device=stats.device)
         cnt = torch.empty(1, dtype=torch.float32, device=stats.device)
         s = self._state
-        hip.call('mg_mailbox_bn_finalize', ctypes.byref(self._mb), hip.ptr(stats), ctypes.c_int(nrep), ctypes.c_float(float(count)), ctypes.c_int(C),
-                 hip.ptr(gamma), hip.ptr(beta), hip.ptr(running_mean), hip.ptr(running_var), ctypes.c_float(momentum), ctypes.c_float(eps),
+        hip.call('mg_mailbox_bn_finalize_dev', ctypes.byref(self._mb), hip.ptr(stats), ctypes.c_int(nrep), ctypes.c_float(float(count)), hip.ptr(count_dev),
+                 ctypes.c_int(C), hip.ptr(gamma), hip.ptr(beta), hip.ptr(running_mean), hip.ptr(running_var), ctypes.c_float(momentum), ctypes.c_float(eps),
                  hip.ptr(outs), hip.ptr(cnt), ctypes.c_void_p(s.data_ptr()), ctypes.c_void_p(s.data_ptr() + 4), ctypes.c_long(self._spin), hip.stream())
         self.calls += 1
         return outs[:C], outs[C:2 * C], outs[2 * C:3 * C], outs[3 * C:], cnt

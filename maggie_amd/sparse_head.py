@@ -162,14 +162,22 @@ class _BN:
                                                    stats_ws=MF.ARENA.take(K.stats_ws_floats(C, True), x.device), rows=rows)
                 return self.y
             # SyncBN: pooled moments of all ranks' live rows; the (variable) row count rides along in the pack
-            from .parallel import syncbn_exchange_forward
-            stats = torch.zeros((K.stat_rows(), 2 * C), dtype=torch.float32, device=x.device)
+            from . import parallel as _par
+            stats = MF.ARENA.zeros(K.stat_rows() * 2 * C, x.device).view(K.stat_rows(), 2 * C)
             K.hip.call('mg_colstats_dev', K.hip.ptr(x), K.c_int(K.hip.dtype_code(x)), K.c_int(x.shape[0]), K.c_int(C), K.c_int(C), K.hip.ptr(stats),
                        K.hip.ptr(rows), K.hip.stream())
-            pack = syncbn_exchange_forward(torch.cat([K.stat_rows_sum(stats), rows.float()]), self.group)
-            self.cnt = pack[2 * C:]
-            scale, shift, mean, invstd = K.bn_finalize(pack[:2 * C], 0.0, gamma, beta, bn.running_mean, bn.running_var, mom, bn.eps, count_ptr=self.cnt)
-            self.pack = torch.cat([scale, shift, mean, invstd])
+            comm = _par.SYNCBN_COMM
+            if comm is not None and hasattr(comm, 'bn_finalize') and comm.can_finalize(C) and x.is_cuda and rows.dtype == torch.int32:
+                # mailbox exchange: ordered row sum, then exchange + finalize in ONE launch with the live-row count read from the device (was: cast +
+                # cat + copy + exchange + finalize + cat)
+                flat = K.stat_rows_sum(stats) if stats.shape[0] > K.STAT_REPLICAS else stats
+                scale, shift, mean, invstd, self.cnt = comm.bn_finalize(flat, 0.0, gamma, beta, bn.running_mean, bn.running_var, mom, bn.eps, count_dev=rows)
+                self.pack = scale._base
+            else:
+                pack = _par.syncbn_exchange_forward(torch.cat([K.stat_rows_sum(stats), rows.float()]), self.group)
+                self.cnt = pack[2 * C:]
+                scale, shift, mean, invstd = K.bn_finalize(pack[:2 * C], 0.0, gamma, beta, bn.running_mean, bn.running_var, mom, bn.eps, count_ptr=self.cnt)
+                self.pack = torch.cat([scale, shift, mean, invstd])
         else:
             scale, shift = K.bn_fold(gamma, beta, bn.running_mean, bn.running_var, bn.eps)
             self.pack = torch.cat([scale, shift, bn.running_mean.float(), torch.rsqrt(bn.running_var.float() + bn.eps)])

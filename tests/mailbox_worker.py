@@ -92,6 +92,41 @@ dist.all_reduce(db)
 res['dgamma_err'] = float((dg - ga.grad).abs().max() / ga.grad.abs().max())
 res['dbeta_err'] = float((db - ba.grad).abs().max() / ba.grad.abs().max())
 res['running_mean_err'] = float((bn.running_mean.cpu() - 0.1 * xa.detach().mean(0)).abs().max())
+
+# ---- (c) round 5: conv -> SyncBatchNorm -> LeakyReLU -> conv in bf16 with the BatchNorm on the consumer's operand path (functional.BNLazy under the
+# mailbox exchange: statistics over BOTH ranks' rows, the normalised activation never stored) against the stored form, bit for bit -- outputs, input
+# gradient, both weight gradients, dgamma / dbeta, running statistics. Rank 0 has 2 samples, rank 1 has 3.
+def chain(lazy):
+    MF.LAZY_BN_SYNC = lazy
+    gc = torch.Generator().manual_seed(77)
+    w1 = (torch.randn(64, 9, 32, generator=gc) / 17).to(dev, torch.bfloat16).requires_grad_(True)
+    w2 = (torch.randn(32, 9, 64, generator=gc) / 24).to(dev, torch.bfloat16).requires_grad_(True)
+    xin = [torch.randn(2, 40, 48, 32, generator=gc), torch.randn(3, 40, 48, 32, generator=gc)][rank].to(dev, torch.bfloat16).requires_grad_(True)
+    dout = [torch.randn(2, 40, 48, 32, generator=gc), torch.randn(3, 40, 48, 32, generator=gc)][rank].to(dev, torch.bfloat16)
+    bn2 = torch.nn.SyncBatchNorm(64).to(dev)
+    with torch.no_grad():
+        bn2.weight.copy_(torch.rand(64, generator=gc) + 0.5)
+        bn2.bias.copy_(torch.randn(64, generator=gc) * 0.3)
+    bn2.train()
+    MF.ARENA.reset(dev)
+    h = MF.conv_bn_act(xin, w1, bn2, MF.ACT_LRELU, 3, 3, 1, 1, 1, lazy_out=True)
+    was_lazy = isinstance(h, MF.LazyAct)
+    out = MF.conv2d(h, w2, None, 3, 3, 1, 1, 1)
+    out.backward(dout)
+    torch.cuda.synchronize()
+    return was_lazy, [t.detach().float().cpu() for t in (out, xin.grad, w1.grad, w2.grad, bn2.weight.grad, bn2.bias.grad, bn2.running_mean, bn2.running_var)]
+
+
+keep = MF.LAZY_BN_SYNC
+try:
+    lazy_on, a = chain(True)
+    lazy_off, b = chain(False)
+finally:
+    MF.LAZY_BN_SYNC = keep
+comm.check()
+res['lazy_sync_taken'] = bool(lazy_on and not lazy_off)
+res['lazy_sync_same_bits'] = all(torch.equal(p_, q_) for p_, q_ in zip(a, b))
+res['lazy_sync_max_diff'] = max(float((p_ - q_).abs().max()) for p_, q_ in zip(a, b))
 res['calls'] = comm.calls
 dist.barrier()
 parallel.syncbn_destroy_comm()

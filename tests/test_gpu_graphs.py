@@ -524,6 +524,8 @@ def test_mailbox_allreduce_two_processes_on_one_gpu():
         assert r['y_err'] <= 1e-5 and r['dx_err'] <= 1e-5, r
         assert r['dgamma_err'] <= 1e-5 and r['dbeta_err'] <= 1e-5 and r['running_mean_err'] <= 1e-5, r
         assert r['calls'] >= 40
+        # (c) round 5: the operand-path BatchNorm under the mailbox SyncBatchNorm == the stored form, bit for bit, on both ranks
+        assert r['lazy_sync_taken'] and r['lazy_sync_same_bits'], r
 
 
 @pytest.mark.gpu
