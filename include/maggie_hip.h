@@ -632,6 +632,9 @@ typedef struct mg_tok_lin {
     float *dx, *dW, *db, *dres, *dgamma, *dbeta, *dz;        /* backward outputs (dz: [R,N] scratch; = dy for a plain layer)               */
     int32_t R, K, N, relu, wt;
     float eps;
+    int32_t dx_pair;                                         /* backward (round 5): 1 + index of another layer of the call that reads the SAME x (neither
+                                                                has an xadd; that layer passes dx = NULL): its dz . W is added into this layer's dx --
+                                                                one input gradient for the shared tensor instead of two and an add; 0: none */
 } mg_tok_lin;
 int mg_token_linear_multi_fwd(const mg_tok_lin* ops, int n, void* stream);
 int mg_token_linear_multi_bwd(const mg_tok_lin* ops, int n, void* stream);

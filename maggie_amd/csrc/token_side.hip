@@ -119,6 +119,8 @@ struct TokLin {
     float *dx, *dW, *db, *dres, *dgamma, *dbeta, *dz;
     int R, K, N, relu, wt;
     float eps;
+    int dx_pair;                         // backward: 1 + index of another layer of the set that reads the SAME x (no xadd on either): its dz . W is added into
+                                         // this layer's dx (that layer has dx == NULL) -- one input gradient instead of two and an autograd add; 0: none
 };
 constexpr int TOK_MULTI = 6;
 struct TokLinSet { TokLin op[TOK_MULTI]; int n; };
@@ -170,6 +172,7 @@ __global__ __launch_bounds__(NT) void token_linear_multi_dz_kernel(const TokLinS
 }
 
 // dx[r][k] = sum_n dz[r][n] W[n][k]: RB rows per workgroup, W staged once in LDS (the row-parallel half of the main backward launch)
+template <bool ADD = false>
 __device__ __forceinline__ void token_linear_bwd_rows(float* sm, int rblock, const float* __restrict__ dz, const float* __restrict__ W,
                                                       float* __restrict__ dx, int R, int K, int N, int wt) {
     float* sdz = sm;                     // [RB][N]
@@ -202,7 +205,8 @@ __device__ __forceinline__ void token_linear_bwd_rows(float* sm, int rblock, con
             const float* g = sdz + rl * N;
 #pragma unroll 8
             for (int n = 0; n < N; ++n) acc += g[n] * sw[n * K + k];
-            dx[(size_t)(r0 + rl) * K + k] = acc;
+            // ADD: the second source of a pair -- the same thread wrote this element in the first pass (same (k, rl) walk)
+            if (ADD) dx[(size_t)(r0 + rl) * K + k] += acc; else dx[(size_t)(r0 + rl) * K + k] = acc;
         }
     }
 }
@@ -316,8 +320,14 @@ __global__ __launch_bounds__(NT) void token_linear_multi_bwd_main_kernel(const T
     const int nrb = p.dx ? (p.R + RB - 1) / RB : 0;
     const int ncb = (p.N + CB - 1) / CB;
     if ((int)blockIdx.x >= nrb + ncb) return;
-    if ((int)blockIdx.x < nrb) token_linear_bwd_rows(sm, blockIdx.x, p.dz, p.W, p.dx, p.R, p.K, p.N, p.wt);
-    else token_linear_bwd_cols(sm, blockIdx.x - nrb, p.dz, p.dy, p.x, p.xadd, p.gamma, p.z, p.rstat, p.dW, p.db, p.dgamma, p.dbeta, p.R, p.K, p.N, p.wt);
+    if ((int)blockIdx.x < nrb) {
+        token_linear_bwd_rows(sm, blockIdx.x, p.dz, p.W, p.dx, p.R, p.K, p.N, p.wt);
+        if (p.dx_pair > 0) {                                  // a second layer reads the same x: its contribution is added here, in a fixed order
+            const TokLin& q = set.op[p.dx_pair - 1];
+            __syncthreads();                                  // the LDS tiles of the first pass are free
+            token_linear_bwd_rows<true>(sm, blockIdx.x, q.dz, q.W, p.dx, p.R, p.K, q.N, q.wt);
+        }
+    } else token_linear_bwd_cols(sm, blockIdx.x - nrb, p.dz, p.dy, p.x, p.xadd, p.gamma, p.z, p.rstat, p.dW, p.db, p.dgamma, p.dbeta, p.R, p.K, p.N, p.wt);
 }
 
 // ---- token self-attention core: one workgroup per batch element, T <= 16 tokens, D <= 256 -------------------------------------------------
@@ -690,6 +700,12 @@ static int tok_set(const mg_tok_lin* ops, int n, TokLinSet* set, int bwd) {
         t.x = o.x; t.xadd = o.xadd; t.W = o.W; t.bias = o.bias; t.res = o.res; t.gamma = o.gamma; t.beta = o.beta;
         t.y = o.y; t.z = o.z; t.rstat = o.rstat; t.dy = o.dy; t.yout = o.yout; t.dx = o.dx; t.dW = o.dW; t.db = o.db; t.dres = o.dres;
         t.dgamma = o.dgamma; t.dbeta = o.dbeta; t.dz = o.dz; t.R = o.R; t.K = o.K; t.N = o.N; t.relu = o.relu; t.wt = o.wt; t.eps = o.eps;
+        t.dx_pair = 0;
+        if (bwd && o.dx_pair) {
+            const int j = o.dx_pair - 1;
+            if (j < 0 || j >= n || j == i || !o.dx || ops[j].dx || ops[j].dx_pair || ops[j].R != o.R || ops[j].K != o.K || o.xadd || ops[j].xadd) return -2;
+            t.dx_pair = o.dx_pair;
+        }
     }
     return 0;
 }
@@ -718,7 +734,8 @@ extern "C" int mg_token_linear_multi_bwd(const mg_tok_lin* ops, int n, void* str
     size_t lds = 0; int gx = 0, gz = 0; bool need_dz = false;
     for (int i = 0; i < n; ++i) {
         const mg_tok_lin& o = ops[i];
-        const size_t lr = ((size_t)RB * o.N + (size_t)o.N * o.K) * sizeof(float), lc = (size_t)32 * (CB + o.K) * sizeof(float);
+        const int nmax = o.dx_pair ? (ops[o.dx_pair - 1].N > o.N ? ops[o.dx_pair - 1].N : o.N) : o.N;      // (validated by tok_set)
+        const size_t lr = ((size_t)RB * nmax + (size_t)nmax * o.K) * sizeof(float), lc = (size_t)32 * (CB + o.K) * sizeof(float);
         const size_t l = o.dx ? (lr > lc ? lr : lc) : lc;
         if (l > lds) lds = l;
         const int g = (o.dx ? (o.R + RB - 1) / RB : 0) + (o.N + CB - 1) / CB; if (g > gx) gx = g;

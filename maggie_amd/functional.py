@@ -2245,6 +2245,17 @@ class TokenLinearMulti(torch.autograd.Function):
         K.hip.call('mg_token_linear_multi_fwd', ops, K.c_int(n), K.hip.stream())
         ctx.save_for_backward(*saved)
         ctx.metas = metas
+        # layers reading the SAME tensor (no xadd on either): the backward forms ONE input gradient for it (dx_pair) instead of two and an autograd add
+        ctx.pairs = {}
+        if TOKEN_DX_PAIRS:
+            taken = set()
+            for i in range(n):
+                for j in range(i + 1, n):
+                    xi, xj = slots[7 * i], slots[7 * j]
+                    if i not in taken and j not in taken and xi is xj and slots[7 * i + 1] is None and slots[7 * j + 1] is None \
+                            and ctx.needs_input_grad[1 + 7 * i] and ctx.needs_input_grad[1 + 7 * j]:
+                        ctx.pairs[i] = j
+                        taken.update((i, j))
         return tuple(outs)
 
     @staticmethod
@@ -2258,7 +2269,7 @@ class TokenLinearMulti(torch.autograd.Function):
             dev = x2.device
             dy = dys[i]
             dy2 = (torch.zeros((R, N), dtype=torch.float32, device=dev) if dy is None else dy.float().contiguous().view(R, N))
-            need_dx = ctx.needs_input_grad[1 + 7 * i] or ctx.needs_input_grad[2 + 7 * i]
+            need_dx = (ctx.needs_input_grad[1 + 7 * i] or ctx.needs_input_grad[2 + 7 * i]) and i not in ctx.pairs.values()
             dx = torch.empty((R, Kd), dtype=torch.float32, device=dev) if need_dx else None
             dW = grad_slot_out(slot_w, (Kd, N) if wt else (N, Kd), dev)
             if dW is None:
@@ -2277,6 +2288,7 @@ class TokenLinearMulti(torch.autograd.Function):
             o.dy, o.yout, o.dx, o.dW, o.db, o.dres, o.dz = (K.hip.ptr(t) for t in (dy2, yout, dx, dW, db, dres, dz))
             o.dgamma, o.dbeta = K.hip.ptr(None if dgb is None else dgb[:N]), K.hip.ptr(None if dgb is None else dgb[N:])
             o.R, o.K, o.N, o.relu, o.wt = R, Kd, N, int(relu), int(wt)
+            o.dx_pair = ctx.pairs[i] + 1 if i in ctx.pairs else 0
             keep += [dy2, dx, dW, db, dres, dgb, dz]
             dxv = None if dx is None else dx.view(shape)
             dxadd = None
@@ -2284,13 +2296,14 @@ class TokenLinearMulti(torch.autograd.Function):
                 dxadd = dxv if tuple(xadd_shape) == tuple(shape) else dxv.sum_to_size(xadd_shape)
             if plain and has_res:
                 dres = dy2
-            results += [dxv if ctx.needs_input_grad[1 + 7 * i] else None, dxadd, dW, db, None if dres is None else dres.view(*shape[:-1], N),
+            results += [dxv if (ctx.needs_input_grad[1 + 7 * i] and dxv is not None) else None, dxadd, dW, db, None if dres is None else dres.view(*shape[:-1], N),
                         None if dgb is None else dgb[:N], None if dgb is None else dgb[N:]]
         K.hip.call('mg_token_linear_multi_bwd', ops, K.c_int(n), K.hip.stream())
         return (None,) + tuple(results)
 
 
 TOKEN_MULTI = os.environ.get('MAGGIE_TOKEN_MULTI', '1') != '0'
+TOKEN_DX_PAIRS = os.environ.get('MAGGIE_TOKEN_DX_PAIRS', '1') != '0'     # 0: one input gradient per layer, autograd adds those of a shared tensor (A/B)
 
 
 TOKEN_MULTI_MAX = 6            # csrc/token_side.hip: TOK_MULTI

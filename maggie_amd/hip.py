@@ -219,7 +219,7 @@ class TokLin(ctypes.Structure):
     """mg_tok_lin (include/maggie_hip.h): one layer of mg_token_linear_multi_fwd / _bwd."""
     _fields_ = [(n, ctypes.c_void_p) for n in ('x', 'xadd', 'W', 'bias', 'res', 'gamma', 'beta', 'y', 'z', 'rstat', 'dy', 'yout', 'dx', 'dW', 'db',
                                                'dres', 'dgamma', 'dbeta', 'dz')] + \
-               [(n, ctypes.c_int32) for n in ('R', 'K', 'N', 'relu', 'wt')] + [('eps', ctypes.c_float)]
+               [(n, ctypes.c_int32) for n in ('R', 'K', 'N', 'relu', 'wt')] + [('eps', ctypes.c_float), ('dx_pair', ctypes.c_int32)]
 
 
 class WbEntry(ctypes.Structure):
