@@ -57,6 +57,10 @@ int mg_zeroed_range_conflicts(void);
 int mg_set_deterministic(int on);
 int mg_get_deterministic(void);
 int mg_det_init(long bytes);
+/* Round 5: ONE side stream per device may run this library's BatchNorm kernels concurrently with the main stream (the encoder's shortcut branches next to
+ * the backbone, maggie/network/encoder/resnet.py:167-175): register it here (NULL: none) -- it gets a slot scratch of its own (`bytes`, allocated once,
+ * never moved). Outside a stream capture. */
+int mg_det_side_stream(void* stream, long bytes);
 int mg_stat_rows(void);
 /* test hook: dst[g][c] += sum_b slots[g][b][c] in the library's fixed order ([groups][nblk][nv] fp32) */
 int mg_det_reduce_test(const float* slots, int nblk, int groups, int nv, float* dst, void* stream);

@@ -180,6 +180,7 @@ static inline hipError_t mg_zero_words(void* p, long n_words, hipStream_t st) {
 struct mg_det_seg { float* dst; int nv; long group_stride; };
 extern int mg_det_on;
 float* mg_det_scratch(long floats);                    // the library's slot scratch (nullptr: not initialised / too small)
+float* mg_det_scratch_on(long floats, hipStream_t st);    // the same for a kernel that may run on the registered side stream (its own scratch there: det.hip)
 // slots: [groups][nblk][rowstride]; the segments cover the columns [col0, col0 + sum nv) of a row
 int mg_det_reduce(const float* slots, int nblk, int groups, int rowstride, int col0, const mg_det_seg* segs, int nseg, hipStream_t st);
 static inline int mg_det_reduce1(const float* slots, int nblk, float* dst, int nv, hipStream_t st) {

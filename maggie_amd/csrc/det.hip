@@ -74,6 +74,42 @@ float* mg_det_scratch(long floats) {
     return (float*)g_buf[dev];
 }
 
+// ---- a second scratch for ONE registered side stream per device (round 5) -------------------------------------------------------------------------
+// The encoder's shortcut branches (maggie/network/encoder/resnet.py:167-175,194-198: conv -> ReLU -> BN, twice; needed only by the detail stage) run
+// on a side stream next to the backbone -> ASPP -> decoder -> instance-token chain, forward and backward. Their BatchNorm kernels stage partial rows
+// like everybody else: with a scratch of their own the two streams never meet in one buffer. Kernels that may run on the side stream ask with their
+// stream (mg_det_scratch_on); everything else keeps mg_det_scratch.
+static char* g_side_buf[MG_MAX_DEVICES] = {};
+static long g_side_bytes[MG_MAX_DEVICES] = {};
+static hipStream_t g_side_stream[MG_MAX_DEVICES] = {};
+
+/* Register `stream` as the side stream of the CURRENT device (NULL: none) and allocate its scratch (`bytes`, once: never freed or moved -- captured
+ * graphs hold the address). Call outside a stream capture. */
+extern "C" int mg_det_side_stream(void* stream, long bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= MG_MAX_DEVICES) return -2;
+    if (stream && !g_side_buf[dev]) {
+        void* p = nullptr;
+        e = hipMalloc(&p, (size_t)bytes);
+        if (e != hipSuccess) return (int)e;
+        g_side_buf[dev] = (char*)p; g_side_bytes[dev] = bytes;
+    }
+    g_side_stream[dev] = (hipStream_t)stream;
+    return 0;
+}
+
+float* mg_det_scratch_on(long floats, hipStream_t st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MG_MAX_DEVICES) return nullptr;
+    if (st && st == g_side_stream[dev]) {
+        if (!g_side_buf[dev] || floats * 4 > g_side_bytes[dev]) return nullptr;
+        return (float*)g_side_buf[dev];
+    }
+    return mg_det_scratch(floats);
+}
+
 namespace {
 
 constexpr int NT = 256;

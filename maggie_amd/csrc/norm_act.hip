@@ -770,7 +770,7 @@ extern "C" int mg_bias_act_bwd_dev(const void* dy, const void* y, void* g, int d
     const ColGeom gm = col_geom(M, C, ce, 512);          // like MG_BN_RB: enough blocks to stream at HBM rate, few enough atomics per channel
     const size_t lds = (size_t)gm.ty * gm.tx * ce * sizeof(float);
     float* slots = nullptr;
-    if (db && mg_det_on && gm.rb > 1) { slots = mg_det_scratch((long)gm.rb * C); if (!slots) return MG_DET_NO_SCRATCH; }
+    if (db && mg_det_on && gm.rb > 1) { slots = mg_det_scratch_on((long)gm.rb * C, st); if (!slots) return MG_DET_NO_SCRATCH; }
     if (dtype == MG_BF16) hipLaunchKernelGGL(bias_act_bwd_kernel<bf16raw>, dim3(gm.rb, gm.groups), dim3(NT), lds, st, (const bf16raw*)dy, (const bf16raw*)y, (bf16raw*)g, M, C, db, gm.rpb, gm.tx, gm.ty, m_dev, slots);
     else if (dtype == MG_F16) hipLaunchKernelGGL(bias_act_bwd_kernel<f16raw>, dim3(gm.rb, gm.groups), dim3(NT), lds, st, (const f16raw*)dy, (const f16raw*)y, (f16raw*)g, M, C, db, gm.rpb, gm.tx, gm.ty, m_dev, slots);
     else hipLaunchKernelGGL(bias_act_bwd_kernel<float>, dim3(gm.rb, gm.groups), dim3(NT), lds, st, (const float*)dy, (const float*)y, (float*)g, M, C, db, gm.rpb, gm.tx, gm.ty, m_dev, slots);
@@ -794,7 +794,7 @@ extern "C" int mg_colstats_centered_dev(const void* x, int dtype, int M, int C, 
     // (skipped when the producing conv's epilogue already did: have_sum), pass 2 the centred second moments.
     // Deterministic mode: each pass stores one partial row per row block, mg_det_reduce adds them in order (two more small launches).
     float* slots = nullptr;
-    if (mg_det_on && g.rb > 1) { slots = mg_det_scratch((long)g.rb * C); if (!slots) return MG_DET_NO_SCRATCH; }
+    if (mg_det_on && g.rb > 1) { slots = mg_det_scratch_on((long)g.rb * C, st); if (!slots) return MG_DET_NO_SCRATCH; }
 #define MG_CENTERED_CASE(T)                                                                                                                              \
     do {                                                                                                                                                 \
         if (!have_sum) {                                                                                                                                 \
@@ -891,7 +891,7 @@ static int bn_bwd_reduce_impl(const mg_rowwise_params* p, void* stream, float** 
     const size_t lds = wide ? (size_t)16 * g.tx * 2 * ce * sizeof(float) : (size_t)g.ty * g.tx * 2 * ce * sizeof(float);
     // deterministic mode: one partial row [2C] per row block in the slot scratch, added in row-block order by mg_det_reduce into p->sums
     float* slots = nullptr;
-    if (mg_det_on && g.rb > 1) { slots = mg_det_scratch((long)g.rb * 2 * p->C); if (!slots) return MG_DET_NO_SCRATCH; }
+    if (mg_det_on && g.rb > 1) { slots = mg_det_scratch_on((long)g.rb * 2 * p->C, (hipStream_t)stream); if (!slots) return MG_DET_NO_SCRATCH; }
     if (wide) {
         if (p->dtype == MG_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16raw, 1024>), dim3(g.rb, g.groups), dim3(1024), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty, slots);
         else if (p->dtype == MG_F16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<f16raw, 1024>), dim3(g.rb, g.groups), dim3(1024), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty, slots);

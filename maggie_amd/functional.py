@@ -361,6 +361,62 @@ def fork_side(device, idx=0):
     return side, main
 
 
+# The encoder's shortcut branches on a side stream (round 5): conv -> ReLU -> BN twice per branch, needed only by the detail stage, next to the
+# backbone -> ASPP -> decoder -> instance-token chain (a long string of 10-token kernels that leaves the chip almost idle) -- forward and, through
+# autograd's per-node streams, backward; inside a captured hipGraph a parallel branch with ONE join. The library's deterministic sums stay
+# deterministic: the side stream has a slot scratch of its own (csrc/det.hip: mg_det_side_stream). MAGGIE_SIDE_SHORTCUTS=0 keeps one stream.
+SIDE_SHORTCUTS = os.environ.get('MAGGIE_SIDE_SHORTCUTS', '0') != '0'
+_SIDE_LANE = {}
+
+
+def side_lane(device):
+    """-> the registered side stream of `device` (created and registered with the library on first use, outside any capture), or None."""
+    if not (SIDE_SHORTCUTS and device.type == 'cuda'):
+        return None
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    s = _SIDE_LANE.get(key)
+    if s is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None                                           # (first use inside a capture: the scratch cannot be allocated now)
+        s = side_stream(device, 3)
+        with torch.cuda.device(device):
+            K.hip.call('mg_det_side_stream', K.ctypes.c_void_p(s.cuda_stream), K.c_long(64 << 20))
+        _SIDE_LANE[key] = s
+    return s
+
+
+class Deferred:
+    """A launch sequence to be issued later (`run()`: on the side lane) together with the tensors it reads."""
+    __slots__ = ('fn', 'tensors')
+
+    def __init__(self, fn, *tensors):
+        self.fn, self.tensors = fn, tensors
+
+    def run(self):
+        return on_side_lane(self.fn, *self.tensors)
+
+
+def on_side_lane(fn, *tensors):
+    """fn() on the device's side stream, ordered after everything issued so far on the current stream; the current stream is NOT made to wait
+    (join_side() does that where the results are first needed). `tensors`: inputs allocated on the current stream that fn reads."""
+    dev = tensors[0].device
+    side = side_lane(dev) if torch.is_grad_enabled() else None
+    if side is None:
+        return fn()
+    main = torch.cuda.current_stream(dev)
+    side.wait_stream(main)
+    if side not in _FORKED:
+        _FORKED.append(side)
+    for t in tensors:
+        t.record_stream(side)
+    with torch.cuda.stream(side):
+        out = fn()
+    for t in (out if isinstance(out, (tuple, list)) else (out,)):
+        if torch.is_tensor(t):
+            t.record_stream(main)
+    return out
+
+
 def join_side():
     """The current stream waits for every side stream that was forked since the last join."""
     if _FORKED:

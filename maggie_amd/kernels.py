@@ -263,8 +263,13 @@ def wgrad_reduce_batched(park):
     if n == 0:
         return
     arr = (hip.WgradParked * n)()
-    for i, (d, _ws, _out) in enumerate(park):
+    cur = torch.cuda.current_stream()
+    for i, (d, ws, out) in enumerate(park):
         arr[i] = d
+        # the GEMM may have run on another stream (the encoder's shortcut branches: functional.on_side_lane); autograd has already ordered this
+        # stream behind it -- the allocator must learn that slabs and dW are read / written HERE as well
+        ws.record_stream(cur)
+        out.record_stream(cur)
     hip.call('mg_wgrad_reduce_batched', arr, c_int(n), hip.stream())
     del park[:]
 

@@ -142,9 +142,14 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         b, n_f, n_i = geom
         if prepare_sn:
             self._prepare_spectral_norm('trunk')
-        embedding, mid_fea = self.encoder(x, enc_masks)
+        self.encoder.__dict__['defer_shortcuts'] = True           # (one graph holds encoder and decoder: the decoder may issue the fine shortcut branches)
+        try:
+            embedding, mid_fea = self.encoder(x, enc_masks)
+        finally:
+            self.encoder.__dict__['defer_shortcuts'] = False
         embedding = self.aspp(embedding)
         dense = self.decoder.dense_stage(embedding, mid_fea, b, n_f, n_i, masks, gt_alphas, mem_feat)
+        MF.join_side()                                            # deferred shortcut branches ran on the side stream (functional.on_side_lane)
         return tuple(t for t in dense if t is not None)
 
     def _graph_policy(self):

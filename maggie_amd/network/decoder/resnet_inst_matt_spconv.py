@@ -285,6 +285,10 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
         hidden_state | None, fea1, fea2, fea3) and, in training, as LAST element an int32 [1] device flag: 1 when alpha_os8 has a non-zero
         element (split_dense_flag() takes it off again)."""
         x, masks, valid_masks, gt_masks, fea1, fea2, fea3, image, h, w = self.os32_to_os8(x, mid_fea, b, n_f, n_i, masks, gt_alphas)
+        if isinstance(fea1, MF.Deferred):
+            # the three fine shortcut branches of the encoder, deferred to here (MAGGIE_SIDE_SHORTCUTS): issued on the side stream, next to the
+            # instance-token chain below; the trunk joins the streams before it returns
+            fea1, fea2, fea3 = fea1.run(), fea2.run(), fea3.run()
         x_os8, x, queries, loss_max_atten, hidden_state = self._refine_os8(x, masks, gt_masks, n_f, mem_feat)
         if self.training:
             # `x_os8 * valid_masks` (:331) and the `x_os8.sum() == 0` test of :314 ride on the up-sampling kernel: a 0 / 1 scale per plane and

@@ -106,24 +106,37 @@ class ResShortCut_D(ResNet_D):
             SpectralNorm(ConvWeight(planes, planes, 3, 1, 1)), Marker('ReLU'), self._norm_layer(planes))
 
     @staticmethod
-    def _run_shortcut(seq, x):
+    def _run_shortcut(seq, x, carry=True):
         """-> (shortcut feature, x handed back). The tapped activation has a second consumer (the next stage of the backbone): it takes x back FROM
         the branch's first conv (`carry`), whose data-gradient kernel then adds the backbone's gradient in its epilogue instead of autograd summing
         the two with a feature-map-sized add (five of them per step, 16 MB each at the fine levels)."""
         dt = x.dtype
+        if not carry:                                             # (a deferred branch: the backbone went on with x itself)
+            y = MF.conv_bn_act(x, seq[0].krsc(dt, x.shape[-1]), seq[2], MF.ACT_NONE, 3, 3, 1, 1, 1, relu_before_bn=True, link_out=True, lazy_out=True)
+            return MF.conv_bn_act(y, seq[3].krsc(dt, y.shape[-1]), seq[5], MF.ACT_NONE, 3, 3, 1, 1, 1, relu_before_bn=True)
         y, x = MF.conv_bn_act(x, seq[0].krsc(dt, x.shape[-1]), seq[2], MF.ACT_NONE, 3, 3, 1, 1, 1, relu_before_bn=True, link_out=True, carry=True, lazy_out=True)
         return MF.conv_bn_act(y, seq[3].krsc(dt, y.shape[-1]), seq[5], MF.ACT_NONE, 3, 3, 1, 1, 1, relu_before_bn=True), x
 
     def forward_features(self, x):
         """x: (N, H, W, 8) NHWC (RGB + 3 embedding channels + 2 zero pad)."""
         dt = x.dtype
-        fea1, x = self._run_shortcut(self.shortcut[0], x)
+        # MAGGIE_SIDE_SHORTCUTS=1 (measured slower, off by default: DESIGN.md 11.11): fea1..fea3 (the 512^2 / 256^2 / 128^2 branches) are read by the
+        # detail stage only -- they are handed on as DEFERRED calls; the decoder issues them on the side stream right before the instance-token chain
+        # (functional.on_side_lane), forward and -- through autograd's per-node streams -- backward. fea4 / fea5 feed the decoder directly.
+        defer = bool(self.__dict__.get('defer_shortcuts')) and MF.side_lane(x.device) is not None and torch.is_grad_enabled()
+
+        def branch(seq, t):
+            if not defer:
+                return self._run_shortcut(seq, t)
+            return MF.Deferred(lambda: self._run_shortcut(seq, t, carry=False), t), t
+
+        fea1, x = branch(self.shortcut[0], x)
         out = MF.conv_bn_act(x, self.conv1.krsc(dt, 8), self.bn1, MF.ACT_RELU, 3, 3, self.start_stride[0], 1, 1, link_out=True, lazy_out=True)
         x1 = MF.conv_bn_act(out, self.conv2.krsc(dt), self.bn2, MF.ACT_RELU, 3, 3, self.start_stride[1], 1, 1)       # x1 also feeds shortcut[1]
-        fea2, x1 = self._run_shortcut(self.shortcut[1], x1)
+        fea2, x1 = branch(self.shortcut[1], x1)
         out = MF.conv_bn_act(x1, self.conv3.krsc(dt), self.bn3, MF.ACT_RELU, 3, 3, self.start_stride[2], 1, 1, link_out=True)
         x2 = self.layer1(out)
-        fea3, x2 = self._run_shortcut(self.shortcut[2], x2)
+        fea3, x2 = branch(self.shortcut[2], x2)
         x3 = self.layer2(x2)
         fea4, x3 = self._run_shortcut(self.shortcut[3], x3)
         x4 = self.layer3(x3)

@@ -437,3 +437,50 @@ def test_video_clip_length_8_trains_and_replays_like_eager():
     assert all(bool(torch.isfinite(p).all()) for p in model.parameters())
     for store in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs'):
         model.__dict__.get(store, {}).clear()
+
+
+def test_side_stream_shortcut_branches_keep_the_step_reproducible():
+    """MAGGIE_SIDE_SHORTCUTS (round 5, measured slower and OFF by default: DESIGN.md 11.11): the encoder's three fine shortcut branches issued on a
+    side stream next to the instance-token chain, forward and backward -- a parallel branch of the captured graphs. The library's ordered sums have a
+    slot scratch per stream (mg_det_side_stream), so the step stays bit-reproducible: replay == replay == eager, and against the one-stream step only
+    the accumulation order of the three tapped activations' gradients differs (autograd's add instead of the data-gradient epilogue)."""
+    from maggie_amd import functional as MF
+    from maggie_amd.utils import synth
+    dev = _dev()
+    model, _ = _build('image', dev, True)
+    batch = _to(synth.synthetic_batch(2, 1, 2, 64, 64, seed=DSEED, train=True, max_inst=10, it=10000), dev)
+    state = copy.deepcopy(model.state_dict())
+
+    def step(graphs):
+        model.load_state_dict(state)
+        _reset_dropout(model)
+        model.hip_graphs = graphs
+        model.zero_grad(set_to_none=True)
+        seed_all(5)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            out, loss = model(batch)
+        loss['total'].backward()
+        torch.cuda.synchronize()
+        return _snapshot(model, out, loss)
+
+    def clear():
+        for store in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs', '_detail_names'):
+            model.__dict__.get(store, {}).clear()
+
+    ref = step(False)
+    keep = MF.SIDE_SHORTCUTS
+    MF.SIDE_SHORTCUTS = True
+    try:
+        clear()
+        e0 = step(False)
+        assert MF.side_lane(dev) is not None
+        g = [step(True) for _ in range(4)]
+    finally:
+        MF.SIDE_SHORTCUTS = keep
+        clear()
+    _assert_same_bits(g[3], g[2], 'side stream: replay 2 vs replay 1')
+    _assert_same_bits(g[2], e0, 'side stream: replayed step vs eager step')
+    for k in ('out/alpha_os1', 'out/alpha_os8', 'loss/total'):
+        assert torch.equal(e0[k], ref[k]), k                       # the forward pass does the same arithmetic on either stream
+    worst = max(float((e0[k].double() - ref[k].double()).abs().max()) / max(float(ref[k].double().abs().max()), 1e-12) for k in ref if k.startswith('grad/'))
+    assert worst <= 0.25, worst                                    # (bf16, BatchNorm over a handful of samples: a missing or doubled gradient would be O(1))

@@ -18,5 +18,6 @@ print('step: %d launches, busy %.3f ms, gaps %.3f ms (median %.2f us, p90 %.2f u
 for i, (s, e, n) in enumerate(win):
     if names and not any(k in n for k in names):
         continue
-    short = n.split('(')[0][-70:]
+    short = n.replace('void ', '').replace('(anonymous namespace)::', '')
+    short = short.split('<')[0].split('(')[0][-60:] if not short.startswith('at::') else short[:110]
     print('%5d %8.2f us  gap %6.2f us  %s' % (i, (e - s) / 1e3, (gaps[i - 1] / 1e3) if i else 0.0, short))
