@@ -36,6 +36,33 @@ __device__ __forceinline__ void st8(float* __restrict__ p, const float* f) {
     *(float4*)p = make_float4(f[0], f[1], f[2], f[3]);
     *(float4*)(p + 4) = make_float4(f[4], f[5], f[6], f[7]);
 }
+// Sum over the 16 lanes of a row group of T <= 16 per-lane partials s[t], lane li receiving the total of token li (0 for li >= T): a reduce-scatter
+// butterfly -- at every step a lane hands the half of the values its partner keeps and adds what it receives to the half it keeps (8 + 4 + 2 + 1 = 15
+// shuffles). group_sum per token is 4 * T = 40 shuffles for the ten tokens, and the kernels built on it ran 34-37 us against 22 us for the pass that
+// needs none (tok_bwd2): the reduction, not the 8 MB of feature rows, was their bound.
+template <int T>
+__device__ __forceinline__ float group_reduce_scatter(const float* s, int li) {
+    float a[8], b[4], c[2];
+    const bool h8 = li & 8, h4 = li & 4, h2 = li & 2, h1 = li & 1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float lo = j < T ? s[j] : 0.f, hi = j + 8 < T ? s[j + 8] : 0.f;
+        const float got = __shfl_xor(h8 ? lo : hi, 8, 64);
+        a[j] = (h8 ? hi : lo) + got;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float got = __shfl_xor(h4 ? a[j] : a[j + 4], 4, 64);
+        b[j] = (h4 ? a[j + 4] : a[j]) + got;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float got = __shfl_xor(h2 ? b[j] : b[j + 2], 2, 64);
+        c[j] = (h2 ? b[j + 2] : b[j]) + got;
+    }
+    const float got = __shfl_xor(h1 ? c[0] : c[1], 1, 64);
+    return (h1 ? c[1] : c[0]) + got;
+}
 template <int T>
 __device__ __forceinline__ float pick(const float* v, int i) {       // v[i] for a lane-dependent i without dynamic register indexing
     float r = v[0];
@@ -108,11 +135,12 @@ __global__ __launch_bounds__(NT) void tok_scores_kernel(const float* __restrict_
             float a = 0.f;
 #pragma unroll
             for (int e = 0; e < CPL; ++e) a += f[e] * sq[t * D + li * CPL + e];
-            s[t] = group_sum(a);
+            s[t] = a;
         }
+        const float mine = group_reduce_scatter<T>(s, li);       // lane li: the dot product of token li
         if (li < T) {
             const int id = ids[(long)b * L + l];
-            s_out[((long)b * T + li) * L + l] = (pick<T>(s, li) + btab[((long)b * T + li) * NID + id]) * scale;
+            s_out[((long)b * T + li) * L + l] = (mine + btab[((long)b * T + li) * NID + id]) * scale;
         }
     }
 }
@@ -200,11 +228,12 @@ __global__ __launch_bounds__(NT) void tok_bwd1_kernel(const float* __restrict__ 
             float a = 0.f;
 #pragma unroll
             for (int e = 0; e < CPL; ++e) a += f[e] * sd[t * D + li * CPL + e];
-            s[t] = group_sum(a);
+            s[t] = a;
         }
+        const float mine = group_reduce_scatter<T>(s, li);
         if (li < T) {
             const long o = ((long)b * T + li) * L + l;
-            const float gv = pick<T>(s, li) + (dp ? dp[o] : 0.f);
+            const float gv = mine + (dp ? dp[o] : 0.f);
             gbuf[o] = gv;
             rd += p[o] * gv;
         }
