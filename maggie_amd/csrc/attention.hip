@@ -12,6 +12,7 @@
 // accumulators stay in registers across the rows of a group and are reduced wave -> LDS -> one atomicAdd per value per block.
 // All kernels are HBM/L2-bound: F is read once (forward) / twice (backward) per direction.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/maggie_hip.h"
 
 namespace {
@@ -23,9 +24,21 @@ constexpr int CPL = D / GL;     // channels per lane (8)
 constexpr int NG = NT / GL;     // row groups per block (16)
 constexpr int RPG = 4;          // rows per group per block
 constexpr int RPB = NG * RPG;   // rows per block (64)
+constexpr int TOK_CTX_CH = 64;  // feature rows per workgroup of tok_ctx_kernel (two halves of 32 rows)
 
+// Sum over the 16 lanes of a row group, result in all of them -- on the VALU's data-parallel-primitive path (DPP), no LDS crossbar: quad_perm
+// [1,0,3,2] and [2,3,0,1] make the quads uniform, row_half_mirror (lane i <-> 7 - i) then pairs quad 0 with quad 1 (2 with 3) and row_mirror
+// (i <-> 15 - i) the two halves; with uniform quads / halves any pairing across the boundary gives the sum. (__shfl_xor is ds_bpermute_b32: ~40 of
+// them per feature row made the row passes shuffle-bound -- feat_fwd 34-46 us for 16 MB of traffic.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float group_sum(float v) {
-    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    v += dpp_move<0xB1>(v);              // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);              // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);             // row_half_mirror
+    v += dpp_move<0x140>(v);             // row_mirror
     return v;
 }
 __device__ __forceinline__ void ld8(const float* __restrict__ p, float* f) {
@@ -116,7 +129,9 @@ __device__ __forceinline__ void id_sums_ordered(const float* __restrict__ sds, c
 }
 
 // ------------------------------------------------------------------------------------------------ tokens <- features
-template <int T>
+// RG: feature rows per 16-lane group and workgroup. The forward row passes have no cross-workgroup sums, so their grid is free: fewer rows per
+// workgroup = more workgroups per CU = more of the per-row latency chain (row load -> dots -> id -> table -> store) in flight.
+template <int T, int RG>
 __global__ __launch_bounds__(NT) void tok_scores_kernel(const float* __restrict__ qk, const float* __restrict__ btab, const float* __restrict__ feat,
                                                         const int32_t* __restrict__ ids, int L, int NID, float scale, float* __restrict__ s_out) {
     __shared__ float sq[T * D];
@@ -125,8 +140,8 @@ __global__ __launch_bounds__(NT) void tok_scores_kernel(const float* __restrict_
     __syncthreads();
     const int g = threadIdx.x / GL, li = threadIdx.x % GL;
 #pragma unroll
-    for (int r = 0; r < RPG; ++r) {
-        const int l = blockIdx.x * RPB + r * NG + g;
+    for (int r = 0; r < RG; ++r) {
+        const int l = blockIdx.x * (NG * RG) + r * NG + g;
         if (l >= L) continue;
         float f[CPL], s[T];
         ld8(feat + ((long)b * L + l) * D + li * CPL, f);
@@ -172,7 +187,7 @@ __global__ __launch_bounds__(NT) void softmax_rows_kernel(float* __restrict__ x,
 template <int T>
 __global__ __launch_bounds__(NT) void tok_ctx_kernel(const float* __restrict__ p, const float* __restrict__ feat, int L, float* __restrict__ ctx,
                                                      float* __restrict__ slots) {
-    constexpr int CH = 128;
+    constexpr int CH = TOK_CTX_CH;
     __shared__ float sp[T * CH];
     __shared__ float sr[T * D];
     const int b = blockIdx.y, l0 = blockIdx.x * CH;
@@ -186,7 +201,20 @@ __global__ __launch_bounds__(NT) void tok_ctx_kernel(const float* __restrict__ p
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = 0.f;
     const int rbeg = half * (CH / 2), rend = min(rbeg + CH / 2, L - l0);
-    for (int r = rbeg; r < rend; ++r) {
+    int r = rbeg;
+    // sixteen rows' loads in flight per batch (the one-row-per-iteration loop waited for every load before issuing the next: 64 memory round trips per
+    // thread, 20 us per launch for 8 MB); the additions keep the row order
+    for (; r + 16 <= rend; r += 16) {
+        float fv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) fv[u] = feat[((long)b * L + l0 + r + u) * D + c];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[t] += sp[t * CH + r + u] * fv[u];
+        }
+    }
+    for (; r < rend; ++r) {
         const float f = feat[((long)b * L + l0 + r) * D + c];
 #pragma unroll
         for (int t = 0; t < T; ++t) acc[t] += sp[t * CH + r] * f;
@@ -312,7 +340,7 @@ __global__ __launch_bounds__(NT) void tok_bwd2_kernel(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------ features <- tokens
-template <int T>
+template <int T, int RG>
 __global__ __launch_bounds__(NT) void feat_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ kq, const float* __restrict__ b2,
                                                       const float* __restrict__ vp, const float* __restrict__ obias, const uint8_t* __restrict__ pad,
                                                       const int32_t* __restrict__ ids, int L, int NID, float scale, float* __restrict__ out,
@@ -327,21 +355,31 @@ __global__ __launch_bounds__(NT) void feat_fwd_kernel(const float* __restrict__ 
     float ob[CPL];
 #pragma unroll
     for (int e = 0; e < CPL; ++e) ob[e] = obias ? obias[li * CPL + e] : 0.f;
+    unsigned padmask = 0u;                                     // the sample's key-padding flags, one bit per token (loaded once)
+    if (pad) {
 #pragma unroll
-    for (int r = 0; r < RPG; ++r) {
-        const int l = blockIdx.x * RPB + r * NG + g;
+        for (int t = 0; t < T; ++t) padmask |= (pad[b * T + t] ? 1u : 0u) << t;
+    }
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+        const int l = blockIdx.x * (NG * RG) + r * NG + g;
         if (l >= L) continue;
         float f[CPL], s[T];
         ld8(feat + ((long)b * L + l) * D + li * CPL, f);
         const int id = ids[(long)b * L + l];
+        // the row's T table values as T independent loads in front of the token loop (inside it the compiler serialised
+        // "load mask byte -> wait -> branch -> load table value -> wait" per token: ~20 memory round trips per row, 28-43 us per launch)
+        float tb[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) tb[t] = b2[(long)b * NID * T + (b2_tn ? t * NID + id : id * T + t)];      // b2_tn: the table as (B, T, NID)
         float m = -INFINITY;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             float a = 0.f;
 #pragma unroll
             for (int e = 0; e < CPL; ++e) a += f[e] * sk[t * D + li * CPL + e];
-            a = (group_sum(a) + b2[(long)b * NID * T + (b2_tn ? t * NID + id : id * T + t)]) * scale;   // b2_tn: the table as (B, T, NID)
-            if (pad && pad[b * T + t]) a = -INFINITY;
+            a = (group_sum(a) + tb[t]) * scale;
+            a = ((padmask >> t) & 1u) ? -INFINITY : a;
             s[t] = a;
             m = fmaxf(m, a);
         }
@@ -458,6 +496,10 @@ __global__ __launch_bounds__(NT) void feat_bwd_kernel(const float* __restrict__ 
 }
 
 inline dim3 row_grid(int L, int B) { return dim3((L + RPB - 1) / RPB, B); }
+inline int fwd_rows_per_group() {                               // MG_ATTN_FWD_RG = 1 | 2 | 4 (A/B switch)
+    static const int v = [] { const char* e = getenv("MG_ATTN_FWD_RG"); const int x = e ? atoi(e) : 1; return (x == 1 || x == 2) ? x : 4; }();
+    return v;
+}
 inline int attn_check(int B, int T, int L, int Dm, int NID) {
     if (Dm != D || T != 10 || NID < 1 || NID > 64) return -3;      // built for maggie_{image,video}.yaml: attention_dim 128, max_inst 10
     if (B <= 0 || L <= 0) return -1;
@@ -487,10 +529,16 @@ extern "C" int mg_attn_tok_fwd(const float* qk, const float* btab, const float* 
                                float scale, float* p, float* ctx, void* stream) {
     int rc = attn_check(B, T, L, Dm, NID); if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(tok_scores_kernel<TT>, row_grid(L, B), dim3(NT), 0, st, qk, btab, feat, ids, L, NID, scale, p);
+    {
+        const int rg = fwd_rows_per_group();
+        const dim3 grid((L + NG * rg - 1) / (NG * rg), B);
+        if (rg == 1) hipLaunchKernelGGL((tok_scores_kernel<TT, 1>), grid, dim3(NT), 0, st, qk, btab, feat, ids, L, NID, scale, p);
+        else if (rg == 2) hipLaunchKernelGGL((tok_scores_kernel<TT, 2>), grid, dim3(NT), 0, st, qk, btab, feat, ids, L, NID, scale, p);
+        else hipLaunchKernelGGL((tok_scores_kernel<TT, 4>), grid, dim3(NT), 0, st, qk, btab, feat, ids, L, NID, scale, p);
+    }
     hipLaunchKernelGGL(softmax_rows_kernel, dim3(B * T), dim3(NT), 0, st, p, L);
     hipError_t e = mg_zero_words(ctx, (long)B * T * Dm, st); if (e != hipSuccess) return (int)e;
-    const int nblk = (L + 127) / 128;
+    const int nblk = (L + TOK_CTX_CH - 1) / TOK_CTX_CH;
     float* slots = nullptr;
     if (mg_det_on && nblk > 1) { slots = mg_det_scratch((long)B * nblk * T * Dm); if (!slots) return MG_DET_NO_SCRATCH; }
     hipLaunchKernelGGL(tok_ctx_kernel<TT>, dim3(nblk, B), dim3(NT), 0, st, p, feat, L, ctx, slots);
@@ -536,8 +584,11 @@ extern "C" int mg_attn_tok_bwd(const float* p, const float* feat, const float* q
 extern "C" int mg_attn_feat_fwd_ex(const float* feat, const float* kq, const float* b2, const float* vp, const float* obias, const uint8_t* pad_mask,
                                    const int32_t* ids, int B, int T, int L, int Dm, int NID, float scale, float* out, float* p, int b2_tn, void* stream) {
     int rc = attn_check(B, T, L, Dm, NID); if (rc) return rc;
-    hipLaunchKernelGGL(feat_fwd_kernel<TT>, row_grid(L, B), dim3(NT), 0, (hipStream_t)stream, feat, kq, b2, vp, obias, pad_mask, ids, L, NID, scale, out, p,
-                       b2_tn);
+    const int rg = fwd_rows_per_group();
+    const dim3 grid((L + NG * rg - 1) / (NG * rg), B);
+    if (rg == 1) hipLaunchKernelGGL((feat_fwd_kernel<TT, 1>), grid, dim3(NT), 0, (hipStream_t)stream, feat, kq, b2, vp, obias, pad_mask, ids, L, NID, scale, out, p, b2_tn);
+    else if (rg == 2) hipLaunchKernelGGL((feat_fwd_kernel<TT, 2>), grid, dim3(NT), 0, (hipStream_t)stream, feat, kq, b2, vp, obias, pad_mask, ids, L, NID, scale, out, p, b2_tn);
+    else hipLaunchKernelGGL((feat_fwd_kernel<TT, 4>), grid, dim3(NT), 0, (hipStream_t)stream, feat, kq, b2, vp, obias, pad_mask, ids, L, NID, scale, out, p, b2_tn);
     MG_CHECK_LAUNCH();
     return 0;
 }
