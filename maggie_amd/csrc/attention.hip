@@ -302,6 +302,12 @@ __global__ __launch_bounds__(NT) void tok_bwd2_kernel(const float* __restrict__ 
     for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int e = 0; e < CPL; ++e) acc[t][e] = 0.f;
+    int idr[RPG];                                                // the rows' ids, loaded up front (inside the loop each one was a late round trip of its own,
+#pragma unroll                                                   // issued behind -- and so waiting for -- the previous row's stores)
+    for (int r = 0; r < RPG; ++r) {
+        const int l = blockIdx.x * RPB + r * NG + g;
+        idr[r] = l < L ? ids[(long)b * L + l] : -1;
+    }
 #pragma unroll
     for (int r = 0; r < RPG; ++r) {
         const int l = blockIdx.x * RPB + r * NG + g;
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(NT) void tok_bwd2_kernel(const float* __restrict__ 
             }
         }
         if (li < T) sds[(r * NG + g) * T + li] = ds;
-        if (li == 0) sid[r * NG + g] = ok ? ids[(long)b * L + l] : -1;
+        if (li == 0) sid[r * NG + g] = idr[r];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const float dst = __shfl(ds, gbase + t, 64), pt = __shfl(pv, gbase + t, 64);
@@ -427,6 +433,12 @@ __global__ __launch_bounds__(NT) void feat_bwd_kernel(const float* __restrict__ 
         for (int e = 0; e < CPL; ++e) { akq[t][e] = 0.f; avp[t][e] = 0.f; }
 #pragma unroll
     for (int e = 0; e < CPL; ++e) aob[e] = 0.f;
+    int idr[RPG];                                                // (see tok_bwd2_kernel)
+#pragma unroll
+    for (int r = 0; r < RPG; ++r) {
+        const int l = blockIdx.x * RPB + r * NG + g;
+        idr[r] = l < L ? ids[(long)b * L + l] : -1;
+    }
 #pragma unroll
     for (int r = 0; r < RPG; ++r) {
         const int l = blockIdx.x * RPB + r * NG + g;
@@ -465,7 +477,7 @@ __global__ __launch_bounds__(NT) void feat_bwd_kernel(const float* __restrict__ 
         for (int e = 0; e < CPL; ++e) aob[e] += go[e];
         if (ok) st8(dfeat + ((long)b * L + l) * D + li * CPL, df);
         if (li < T) sds[(r * NG + g) * T + li] = ok ? pick<T>(ds, li) : 0.f;
-        if (li == 0) sid[r * NG + g] = ok ? ids[(long)b * L + l] : -1;
+        if (li == 0) sid[r * NG + g] = idr[r];
     }
     // deterministic mode: the workgroup's row [dKq (T x D) | dVp (T x D) | dB2 (NID x T) | dObias (D)]
     float* slot = slots ? slots + ((size_t)b * gridDim.x + blockIdx.x) * (2 * T * D + T * NID + D) : nullptr;
