@@ -14,6 +14,9 @@
 
 namespace {
 
+#define MG_STENCIL_FN __device__ __forceinline__
+#include "loss_stencils.h"
+
 constexpr int NT = 256;
 __device__ __constant__ float c_g1[5] = {1.f / 16.f, 4.f / 16.f, 6.f / 16.f, 4.f / 16.f, 1.f / 16.f};
 
@@ -297,6 +300,102 @@ __global__ __launch_bounds__(NT) void pyr_downT_kernel(const float* __restrict__
     }
 }
 
+// ---- round 5, second pass: the same four stencils with their loads in front of the arithmetic ---------------------------------------------------
+// The walks above compile to one `global_load` + `s_waitcnt vmcnt(0)` per tap (hipcc -S: pyr_lap_fwd 124 loads / 112 full waits, pyr_downT 144 / 144,
+// pyr_upT 57 / 57, point_bwd 22 / 36): every tap sits behind a run-time condition, so a pixel is 6-25 dependent memory round trips and the kernels ran
+// at 12-18 % of the HBM rate. Away from the border the tap set is a function of the pixel's parity alone: a 2 x 2 output quad (2a + dy, 2b + dx) of
+// pyr_lap_fwd / pyr_downT reads ONE 3 x 3 window of the half-resolution plane, an output of pyr_upT one 5 x 5 window, a pixel of point_bwd two
+// 3 x 3 windows -- loaded unconditionally as a batch, then combined with the terms of the walks above in the same order (csrc/loss_stencils.h: the
+// per-pixel values keep their bits; the per-workgroup sums of pyr_lap_fwd add the same values in a different order). Border cells take the general
+// walks, and ring_map() enumerates them behind the inner cells so that whole waves take one path. MG_LOSS_BATCHED=0 selects the first forms.
+__global__ __launch_bounds__(NT) void pyr_lap_fwd_quad_kernel(const float* __restrict__ x, const float* __restrict__ down, const P3 w0,
+                                                              int lvl, int H0, int W0, const int* __restrict__ flags, int h, int w,
+                                                              float* __restrict__ G, float* __restrict__ sums, int Pper, float* __restrict__ slots) {
+    __shared__ float sh[NT / 64];
+    const int pl = blockIdx.y;
+    float* slot = slots ? slots + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 : nullptr;
+    if (!flags[pl]) { if (slot && threadIdx.x < 2) slot[threadIdx.x] = 0.f; return; }
+    const int sc = pl / Pper;
+    const int hd = h >> 1, wd = w >> 1;
+    const float* __restrict__ xp = x + (long)pl * h * w;
+    const float* __restrict__ dp = down + (long)pl * hd * wd;
+    const float* __restrict__ wp = w0.a[sc] + (long)(pl - sc * Pper) * H0 * W0;
+    float* __restrict__ Gp = G + (long)pl * h * w;
+    float s0 = 0.f, s1 = 0.f;
+    for (int q = blockIdx.x * NT + threadIdx.x; q < hd * wd; q += gridDim.x * NT) {
+        int a, b;
+        const bool inner = ring_map(q, hd, wd, 1, 1, 1, 1, a, b);
+        const int y0 = 2 * a, x0 = 2 * b;
+        const float* __restrict__ xr0 = xp + (long)y0 * w + x0;
+        const float xv[4] = {xr0[0], xr0[1], xr0[w], xr0[w + 1]};
+        const long wr0 = (long)(y0 << lvl) * W0, wr1 = (long)((y0 + 1) << lvl) * W0;
+        const int wc0 = x0 << lvl, wc1 = (x0 + 1) << lvl;
+        const float wl[4] = {wp[wr0 + wc0], wp[wr0 + wc1], wp[wr1 + wc0], wp[wr1 + wc1]};
+        float up[4];
+        if (inner) lap_up_inner(dp, a, b, wd, up);
+        else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) up[u] = lap_up_general(dp, y0 + (u >> 1), x0 + (u & 1), h, w, wd);
+        }
+        float gq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float L = xv[u] - 4.f * up[u];
+            s0 += fabsf(L) * wl[u];
+            s1 += wl[u];
+            gq[u] = L > 0.f ? wl[u] : (L < 0.f ? -wl[u] : 0.f);
+        }
+        float* __restrict__ gr0 = Gp + (long)y0 * w + x0;
+        gr0[0] = gq[0]; gr0[1] = gq[1]; gr0[w] = gq[2]; gr0[w + 1] = gq[3];
+    }
+    float* srep = sums + sc * LOSS_SUMS + ((blockIdx.y * gridDim.x + blockIdx.x) & (LOSS_REPLICAS - 1)) * LOSS_STRIDE;
+    block_add(s0, &srep[0], sh, slot);
+    block_add(s1, &srep[1], sh, slot ? slot + 1 : nullptr);
+}
+
+__global__ __launch_bounds__(NT) void pyr_upT_batched_kernel(const float* __restrict__ q, const float* __restrict__ coef, const float* __restrict__ add,
+                                                             const int* __restrict__ flags, int h, int w, float* __restrict__ r, int Pper) {
+    const int pl = blockIdx.y;
+    if (!flags[pl]) return;
+    const int hd = h >> 1, wd = w >> 1;
+    const float* __restrict__ qp = q + (long)pl * h * w;
+    const float c = coef[(pl / Pper) * 5];
+    for (int o = blockIdx.x * NT + threadIdx.x; o < hd * wd; o += gridDim.x * NT) {
+        int a, b;
+        const bool inner = ring_map(o, hd, wd, 2, 1, 2, 1, a, b);
+        const long oo = (long)pl * hd * wd + a * wd + b;
+        const float base = add ? add[oo] : 0.f;
+        const float acc = inner ? upT_inner(qp, a, b, w) : upT_general(qp, a, b, h, w);
+        r[oo] = base - 4.f * c * acc;
+    }
+}
+
+__global__ __launch_bounds__(NT) void pyr_downT_quad_kernel(const float* __restrict__ r, const float* __restrict__ q, const float* __restrict__ coef,
+                                                            const int* __restrict__ flags, int h, int w, float* __restrict__ dd, int Pper) {
+    const int pl = blockIdx.y;
+    if (!flags[pl]) return;
+    const int hd = h >> 1, wd = w >> 1;
+    const float* __restrict__ rp = r + (long)pl * hd * wd;
+    const float* __restrict__ qp = q + (long)pl * h * w;
+    float* __restrict__ op = dd + (long)pl * h * w;
+    const float c = coef[(pl / Pper) * 5];
+    for (int t = blockIdx.x * NT + threadIdx.x; t < hd * wd; t += gridDim.x * NT) {
+        int a, b;
+        const bool inner = ring_map(t, hd, wd, 2, 2, 2, 2, a, b);
+        const int y0 = 2 * a, x0 = 2 * b;
+        const float* __restrict__ qr0 = qp + (long)y0 * w + x0;
+        const float qv[4] = {qr0[0], qr0[1], qr0[w], qr0[w + 1]};
+        float acc[4];
+        if (inner) downT_inner(rp, a, b, wd, acc);
+        else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = downT_general(rp, y0 + (u >> 1), x0 + (u & 1), h, w, hd, wd);
+        }
+        float* __restrict__ o0 = op + (long)y0 * w + x0;
+        o0[0] = c * qv[0] + acc[0]; o0[1] = c * qv[1] + acc[1]; o0[w] = c * qv[2] + acc[2]; o0[w + 1] = c * qv[3] + acc[3];
+    }
+}
+
 // Sobel backward pass 1: A = s * gx / mag, B = s * gy / mag with s = sign(mag_p - mag_t)   (coef applied in pass 2)
 __global__ __launch_bounds__(NT) void sobel_bwd1_kernel(const P3 p, const float* __restrict__ t, const P3 w,
                                                         const int* __restrict__ flags, int H, int W, float* __restrict__ A, float* __restrict__ B,
@@ -367,6 +466,40 @@ __global__ __launch_bounds__(NT) void point_bwd_kernel(const P3 p, const float* 
     }
 }
 
+// point_bwd with the two 3 x 3 windows of A and B loaded as one batch for the pixels whose neighbourhood does not touch the border
+// (sobel_adj_inner); border pixels keep the walk (sobel_adj_general), enumerated last (ring_map)
+__global__ __launch_bounds__(NT) void point_bwd_batched_kernel(const P3 p, const float* __restrict__ t, const P3 w,
+                                                               const int* __restrict__ flags, int H, int W, const float* __restrict__ coef_rec,
+                                                               const float* __restrict__ coef_grad, const float* __restrict__ dd,
+                                                               const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ dp,
+                                                               const int* __restrict__ pvalid, int Pper) {
+    const int pl = blockIdx.y;
+    const int sc = pl / Pper, pq = pl - sc * Pper;
+    const long off = (long)pl * H * W, offq = (long)pq * H * W;
+    if (!flags[pl] || (pvalid && !pvalid[pq])) {
+        for (int idx = blockIdx.x * NT + threadIdx.x; idx < H * W; idx += gridDim.x * NT) dp[off + idx] = 0.f;
+        return;
+    }
+    const float cr = coef_rec[sc * 5], cg = coef_grad[sc * 5];
+    const float* __restrict__ pp = p.a[sc] + offq;
+    const float* __restrict__ tp = t + offq;
+    const float* __restrict__ wp = w.a[sc] + offq;
+    const float* __restrict__ Ap = A + off;
+    const float* __restrict__ Bp = B + off;
+    for (int idx = blockIdx.x * NT + threadIdx.x; idx < H * W; idx += gridDim.x * NT) {
+        int Y, X;
+        const bool inner = ring_map(idx, H, W, 1, 1, 1, 1, Y, X);
+        const int px = Y * W + X;
+        const float dv = pp[px] - tp[px];
+        const float wv = wp[px];
+        const float ddv = dd ? dd[off + px] : 0.f;
+        const float acc = inner ? sobel_adj_inner(Ap, Bp, Y, X, W) : sobel_adj_general(Ap, Bp, Y, X, H, W);
+        float g = cr * wv * (dv > 0.f ? 1.f : (dv < 0.f ? -1.f : 0.f));
+        if (dd) g += ddv;
+        dp[off + px] = g + cg * wv * acc * 0.125f;
+    }
+}
+
 inline dim3 grid2(long per_plane, int P, long max_blocks = 1024) {
     long b = (per_plane + NT - 1) / NT;
     if (b > max_blocks) b = max_blocks;
@@ -376,6 +509,37 @@ inline dim3 grid2(long per_plane, int P, long max_blocks = 1024) {
 // kernels that end with one atomicAdd per sum per block: every block hits the same 2-3 addresses, so keep the block count low
 // (8 planes x 1024 blocks x 3 same-address atomics cost more than the stencil itself)
 static const long REDUCING_BLOCKS_PER_PLANE = [] { const char* e = getenv("MG_LOSS_BLOCKS"); return e ? atol(e) : 256l; }();
+
+// MG_LOSS_BATCHED (default 1): the batched-load forms of the pyramid / Sobel-adjoint stencils (even plane sizes; odd ones keep the first forms)
+static const int LOSS_BATCHED = [] { const char* e = getenv("MG_LOSS_BATCHED"); return e ? atoi(e) : 1; }();
+
+static void launch_pyr_lap_fwd(dim3 g, hipStream_t st, const float* x, const float* down, P3 ww, int lvl, int H0, int W0, const int* flags, int h, int w,
+                               float* G, float* sums, int Pper, float* slots) {
+    if (LOSS_BATCHED && !(h & 1) && !(w & 1))
+        hipLaunchKernelGGL(pyr_lap_fwd_quad_kernel, g, dim3(NT), 0, st, x, down, ww, lvl, H0, W0, flags, h, w, G, sums, Pper, slots);
+    else
+        hipLaunchKernelGGL(pyr_lap_fwd_kernel, g, dim3(NT), 0, st, x, down, ww, lvl, H0, W0, flags, h, w, G, sums, Pper, slots);
+}
+static void launch_pyr_upT(int SP, hipStream_t st, const float* q, const float* coef, const float* add, const int* flags, int h, int w, float* r, int Pper) {
+    const dim3 g = grid2((long)(h / 2) * (w / 2), SP);
+    if (LOSS_BATCHED && !(h & 1) && !(w & 1))
+        hipLaunchKernelGGL(pyr_upT_batched_kernel, g, dim3(NT), 0, st, q, coef, add, flags, h, w, r, Pper);
+    else
+        hipLaunchKernelGGL(pyr_upT_kernel, g, dim3(NT), 0, st, q, coef, add, flags, h, w, r, Pper);
+}
+static void launch_pyr_downT(int SP, hipStream_t st, const float* r, const float* q, const float* coef, const int* flags, int h, int w, float* dd, int Pper) {
+    if (LOSS_BATCHED && !(h & 1) && !(w & 1))
+        hipLaunchKernelGGL(pyr_downT_quad_kernel, grid2((long)(h / 2) * (w / 2), SP), dim3(NT), 0, st, r, q, coef, flags, h, w, dd, Pper);
+    else
+        hipLaunchKernelGGL(pyr_downT_kernel, grid2((long)h * w, SP), dim3(NT), 0, st, r, q, coef, flags, h, w, dd, Pper);
+}
+static void launch_point_bwd(int SP, hipStream_t st, P3 pp, const float* t, P3 ww, const int* flags, int H, int W, const float* coef_rec,
+                             const float* coef_grad, const float* dd, const float* A, const float* B, float* dp, const int* pvalid, int Pper) {
+    if (LOSS_BATCHED)
+        hipLaunchKernelGGL(point_bwd_batched_kernel, grid2((long)H * W, SP), dim3(NT), 0, st, pp, t, ww, flags, H, W, coef_rec, coef_grad, dd, A, B, dp, pvalid, Pper);
+    else
+        hipLaunchKernelGGL(point_bwd_kernel, grid2((long)H * W, SP), dim3(NT), 0, st, pp, t, ww, flags, H, W, coef_rec, coef_grad, dd, A, B, dp, pvalid, Pper);
+}
 
 // sums = [l1, grad, w, lap0, w0, lap1, w1, lap2, w2] -> (rec, lap, grad) exactly as arch/maggie.py:237-262 / loss.py:67-191
 // normalise them (eps 1e-8 for the L1 term, 1e-6 for the others; LapLoss is the 3-fold channel sum)
@@ -493,21 +657,21 @@ extern "C" int mg_pyr_lap_fwd(const float* x, const float* down, const float* w0
     if (P <= 0) return 0;
     const dim3 g = grid2((long)h * w, P, REDUCING_BLOCKS_PER_PLANE);
     float* slots; int rc = loss_slots(g, 2, &slots); if (rc) return rc;
-    hipLaunchKernelGGL(pyr_lap_fwd_kernel, g, dim3(NT), 0, (hipStream_t)stream, x, down, P3{{w0, nullptr, nullptr}}, lvl, H0, W0, flags, h, w, G, sums, P, slots);
+    launch_pyr_lap_fwd(g, (hipStream_t)stream, x, down, P3{{w0, nullptr, nullptr}}, lvl, H0, W0, flags, h, w, G, sums, P, slots);
     MG_CHECK_LAUNCH();
     return loss_slot_reduce(slots, g, 1, 2, sums, 0, (hipStream_t)stream);
 }
 
 extern "C" int mg_pyr_upT(const float* q, const float* coef, const float* add, const int32_t* flags, int P, int h, int w, float* r, void* stream) {
     if (P <= 0) return 0;
-    hipLaunchKernelGGL(pyr_upT_kernel, grid2((long)(h / 2) * (w / 2), P), dim3(NT), 0, (hipStream_t)stream, q, coef, add, flags, h, w, r, P);
+    launch_pyr_upT(P, (hipStream_t)stream, q, coef, add, flags, h, w, r, P);
     MG_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int mg_pyr_downT(const float* r, const float* q, const float* coef, const int32_t* flags, int P, int h, int w, float* dd, void* stream) {
     if (P <= 0) return 0;
-    hipLaunchKernelGGL(pyr_downT_kernel, grid2((long)h * w, P), dim3(NT), 0, (hipStream_t)stream, r, q, coef, flags, h, w, dd, P);
+    launch_pyr_downT(P, (hipStream_t)stream, r, q, coef, flags, h, w, dd, P);
     MG_CHECK_LAUNCH();
     return 0;
 }
@@ -518,7 +682,7 @@ extern "C" int mg_loss_point_bwd(const float* p, const float* t, const float* w,
     hipStream_t st = (hipStream_t)stream;
     const P3 pp{{p, nullptr, nullptr}}, ww{{w, nullptr, nullptr}};
     hipLaunchKernelGGL(sobel_bwd1_kernel, grid2((long)H * W, P), dim3(NT), 0, st, pp, t, ww, flags, H, W, A, B, pvalid, P);
-    hipLaunchKernelGGL(point_bwd_kernel, grid2((long)H * W, P), dim3(NT), 0, st, pp, t, ww, flags, H, W, coef_rec, coef_grad, dd, A, B, dp, pvalid, P);
+    launch_point_bwd(P, st, pp, t, ww, flags, H, W, coef_rec, coef_grad, dd, A, B, dp, pvalid, P);
     MG_CHECK_LAUNCH();
     return 0;
 }
@@ -549,8 +713,7 @@ extern "C" int mg_matting_losses_fwd(const float* const* p, const float* t, cons
         hipLaunchKernelGGL(pyr_down_kernel, grid2((long)(h / 2) * (wd / 2), SP), dim3(NT), 0, st, x, flags, h, wd, downs[lvl]);
         const dim3 g = grid2((long)h * wd, SP, REDUCING_BLOCKS_PER_PLANE);
         float* slots; int rc = loss_slots(g, 2, &slots); if (rc) return rc;
-        hipLaunchKernelGGL(pyr_lap_fwd_kernel, g, dim3(NT), 0, st, x, (const float*)downs[lvl], ww, lvl, H, W,
-                           flags, h, wd, Gs[lvl], sums + 3 + 2 * lvl, P, slots);
+        launch_pyr_lap_fwd(g, st, x, (const float*)downs[lvl], ww, lvl, H, W, flags, h, wd, Gs[lvl], sums + 3 + 2 * lvl, P, slots);
         rc = loss_slot_reduce(slots, g, S, 2, sums, 3 + 2 * lvl, st); if (rc) return rc;
         x = downs[lvl]; h >>= 1; wd >>= 1;
     }
@@ -571,15 +734,14 @@ extern "C" int mg_matting_losses_bwd(const float* g, const float* sums, const fl
     for (int i = 0; i < S; ++i) { pp.a[i] = p[i]; ww.a[i] = w[i]; }
     const int SP = S * P;
     hipLaunchKernelGGL(loss_coef_kernel, dim3(S), dim3(64), 0, st, g, sums, coef);
-    hipLaunchKernelGGL(pyr_upT_kernel, grid2((long)(H / 8) * (W / 8), SP), dim3(NT), 0, st, G2, (const float*)(coef + 4), (const float*)nullptr, flags, H / 4, W / 4, r2, P);
-    hipLaunchKernelGGL(pyr_downT_kernel, grid2((long)(H / 4) * (W / 4), SP), dim3(NT), 0, st, (const float*)r2, G2, (const float*)(coef + 4), flags, H / 4, W / 4, dd2, P);
-    hipLaunchKernelGGL(pyr_upT_kernel, grid2((long)(H / 4) * (W / 4), SP), dim3(NT), 0, st, G1, (const float*)(coef + 3), (const float*)dd2, flags, H / 2, W / 2, r1, P);
-    hipLaunchKernelGGL(pyr_downT_kernel, grid2((long)(H / 2) * (W / 2), SP), dim3(NT), 0, st, (const float*)r1, G1, (const float*)(coef + 3), flags, H / 2, W / 2, dd1, P);
-    hipLaunchKernelGGL(pyr_upT_kernel, grid2((long)(H / 2) * (W / 2), SP), dim3(NT), 0, st, G0, (const float*)(coef + 2), (const float*)dd1, flags, H, W, r0, P);
-    hipLaunchKernelGGL(pyr_downT_kernel, grid2((long)H * W, SP), dim3(NT), 0, st, (const float*)r0, G0, (const float*)(coef + 2), flags, H, W, dd0, P);
+    launch_pyr_upT(SP, st, G2, (const float*)(coef + 4), (const float*)nullptr, flags, H / 4, W / 4, r2, P);
+    launch_pyr_downT(SP, st, (const float*)r2, G2, (const float*)(coef + 4), flags, H / 4, W / 4, dd2, P);
+    launch_pyr_upT(SP, st, G1, (const float*)(coef + 3), (const float*)dd2, flags, H / 2, W / 2, r1, P);
+    launch_pyr_downT(SP, st, (const float*)r1, G1, (const float*)(coef + 3), flags, H / 2, W / 2, dd1, P);
+    launch_pyr_upT(SP, st, G0, (const float*)(coef + 2), (const float*)dd1, flags, H, W, r0, P);
+    launch_pyr_downT(SP, st, (const float*)r0, G0, (const float*)(coef + 2), flags, H, W, dd0, P);
     hipLaunchKernelGGL(sobel_bwd1_kernel, grid2((long)H * W, SP), dim3(NT), 0, st, pp, t, ww, flags, H, W, A, B, pvalid, P);
-    hipLaunchKernelGGL(point_bwd_kernel, grid2((long)H * W, SP), dim3(NT), 0, st, pp, t, ww, flags, H, W, (const float*)coef, (const float*)(coef + 1),
-                       (const float*)dd0, (const float*)A, (const float*)B, dp, pvalid, P);
+    launch_point_bwd(SP, st, pp, t, ww, flags, H, W, (const float*)coef, (const float*)(coef + 1), (const float*)dd0, (const float*)A, (const float*)B, dp, pvalid, P);
     MG_CHECK_LAUNCH();
     return 0;
 }

@@ -984,7 +984,12 @@ __global__ __launch_bounds__(NT) void bn_small_fwd_kernel(const mg_rowwise_param
     __shared__ float sred[4 * CE];
     const int c0 = blockIdx.x * CE, t = threadIdx.x, M = p.M, C = p.C;
     const T* __restrict__ x = (const T*)p.x;
-    uint4 q[RPT];
+    const T* __restrict__ r1 = (const T*)p.res;
+    const T* __restrict__ r2 = (const T*)p.res2;
+    // PRE (the <= 1024-row layers, RPT == 4): the residual rows are requested together with the x rows -- they do not depend on the statistics, and
+    // asked for after the two block reductions they were one more exposed memory round trip in a kernel that is nothing but round trips
+    constexpr bool PRE = RPT <= 4;
+    uint4 q[RPT], qa[PRE ? RPT : 1], qb[PRE ? RPT : 1];
     float s[CE];
 #pragma unroll
     for (int e = 0; e < CE; ++e) s[e] = 0.f;
@@ -992,6 +997,34 @@ __global__ __launch_bounds__(NT) void bn_small_fwd_kernel(const mg_rowwise_param
     for (int k = 0; k < RPT; ++k) {
         const int m = t + k * NT;
         q[k] = m < M ? *(const uint4*)(x + (long)m * p.ldx + c0) : make_uint4(0, 0, 0, 0);
+    }
+    if constexpr (PRE) {
+#pragma unroll
+        for (int k = 0; k < (PRE ? RPT : 1); ++k) { qa[k] = make_uint4(0, 0, 0, 0); qb[k] = qa[k]; }
+        if (r1) {
+#pragma unroll
+            for (int k = 0; k < (PRE ? RPT : 1); ++k) {
+                const int m = t + k * NT;
+                if (m < M) {
+                    long rrow = m;
+                    if (p.res_mode == 2) {
+                        const int hw = p.H * p.W; const int n = m / hw; const int rem = m - n * hw; const int ho = rem / p.W; const int wo = rem - ho * p.W;
+                        rrow = ((long)n * (p.H >> 1) + (ho >> 1)) * (p.W >> 1) + (wo >> 1);
+                    }
+                    qa[k] = *(const uint4*)(r1 + rrow * p.ldr + c0);
+                }
+            }
+        }
+        if (r2) {
+#pragma unroll
+            for (int k = 0; k < (PRE ? RPT : 1); ++k) {
+                const int m = t + k * NT;
+                if (m < M) qb[k] = *(const uint4*)(r2 + (long)m * p.ldr2 + c0);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
         float f[CE];
         TR::unpack(q[k], f);
 #pragma unroll
@@ -1012,25 +1045,38 @@ __global__ __launch_bounds__(NT) void bn_small_fwd_kernel(const mg_rowwise_param
         }
     }
     block_sum_vec<CE>(var, sred);
-    float sc[CE], sh[CE];
+    float sc[CE], sh[CE], invstd[CE], gam[CE], bet[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { gam[e] = gamma ? gamma[c0 + e] : 1.f; bet[e] = beta ? beta[c0 + e] : 0.f; }
 #pragma unroll
     for (int e = 0; e < CE; ++e) {
         var[e] = fmaxf(var[e] * inv_n, 0.f);
-        const float invstd = rsqrtf(var[e] + eps);
-        const float g = gamma ? gamma[c0 + e] : 1.f, b = beta ? beta[c0 + e] : 0.f;
-        sc[e] = g * invstd; sh[e] = b - mean[e] * g * invstd;
-        if (t == 0) {
+        invstd[e] = rsqrtf(var[e] + eps);
+        sc[e] = gam[e] * invstd[e]; sh[e] = bet[e] - mean[e] * gam[e] * invstd[e];
+    }
+    if (t == 0) {
+        // the running statistics of the chunk are READ as one batch before anything is stored: written as load -> store per channel, the possible
+        // aliasing of the four destination arrays made every load wait for the store in front of it -- 2 * CE dependent round trips in one thread
+        // while the rest of the workgroup had long finished (hipcc -S: 16 of this kernel's 24 full waits)
+        float rm[CE], rv[CE];
+        if (running_mean) {
+#pragma unroll
+            for (int e = 0; e < CE; ++e) { rm[e] = running_mean[c0 + e]; rv[e] = running_var[c0 + e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < CE; ++e) {
             const int c = c0 + e;
-            outs[c] = sc[e]; outs[C + c] = sh[e]; outs[2 * C + c] = mean[e]; outs[3 * C + c] = invstd;
-            if (running_mean) {
+            outs[c] = sc[e]; outs[C + c] = sh[e]; outs[2 * C + c] = mean[e]; outs[3 * C + c] = invstd[e];
+        }
+        if (running_mean) {
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
                 const float n = (float)M * (p.count_mult > 1 ? (float)p.count_mult : 1.f), unbiased = n > 1.f ? var[e] * n / (n - 1.f) : var[e];
-                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean[e];
-                running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+                running_mean[c0 + e] = (1.f - momentum) * rm[e] + momentum * mean[e];
+                running_var[c0 + e] = (1.f - momentum) * rv[e] + momentum * unbiased;
             }
         }
     }
-    const T* __restrict__ r1 = (const T*)p.res;
-    const T* __restrict__ r2 = (const T*)p.res2;
     T* __restrict__ y = (T*)p.y;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
@@ -1038,6 +1084,14 @@ __global__ __launch_bounds__(NT) void bn_small_fwd_kernel(const mg_rowwise_param
         if (m >= M) continue;
         float f[CE], a[CE], b[CE];
         TR::unpack(q[k], f);
+        if constexpr (PRE) {
+            TR::unpack(qa[k], a);
+            TR::unpack(qb[k], b);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) f[e] = apply_act(f[e] * sc[e] + sh[e] + a[e], p.act, p.slope) + b[e];
+            *(uint4*)(y + (long)m * p.ldy + p.yoff + c0) = TR::pack(f);
+            continue;
+        }
 #pragma unroll
         for (int e = 0; e < CE; ++e) { a[e] = 0.f; b[e] = 0.f; }
         if (r1) {
@@ -1066,6 +1120,65 @@ __global__ __launch_bounds__(NT) void bn_small_bwd_kernel(const mg_rowwise_param
     for (int e = 0; e < CE; ++e) { mu[e] = p.mean[c0 + e]; is[e] = p.invstd[c0 + e]; sg[e] = 0.f; sgx[e] = 0.f; }
     float g[RPT][CE];
     uint4 qx[RPT];
+    if constexpr (RPT <= 4) {
+        // the <= 1024-row layers: every row of dy, x and (stored-activation form) y / res2 is requested before the first is used. load_g() per row
+        // compiled to load dy -> wait -> load y -> wait -> load x -> wait, row after row: 12 dependent round trips for 4 rows (hipcc -S). Rows past M
+        // read row M - 1 (M > 1 here) and are zeroed after the fact, so that no load sits behind a per-lane condition.
+        const bool from_x = p.act != MG_ACT_NONE && p.mask_from_x, from_y = p.act != MG_ACT_NONE && !p.mask_from_x;
+        uint4 qd[RPT], qy[RPT], qr[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int m = min(t + k * NT, M - 1);
+            qd[k] = *(const uint4*)((const T*)p.dy + (long)m * p.lddy + c0);
+            qx[k] = *(const uint4*)((const T*)p.x + (long)m * p.ldx + c0);
+            qy[k] = make_uint4(0, 0, 0, 0); qr[k] = qy[k];
+        }
+        if (from_y) {
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) qy[k] = *(const uint4*)((const T*)p.y + (long)min(t + k * NT, M - 1) * p.ldy + p.yoff + c0);
+            if (p.res2) {
+#pragma unroll
+                for (int k = 0; k < RPT; ++k) qr[k] = *(const uint4*)((const T*)p.res2 + (long)min(t + k * NT, M - 1) * p.ldr2 + c0);
+            }
+        }
+        float xsc[CE], xsh[CE];
+#pragma unroll
+        for (int e = 0; e < CE; ++e) { xsc[e] = from_x ? p.scale[c0 + e] : 0.f; xsh[e] = from_x ? p.shift[c0 + e] : 0.f; }
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const bool live = t + k * NT < M;
+            float xv[CE];
+            TR::unpack(qd[k], g[k]);
+            TR::unpack(qx[k], xv);
+            if (from_x) {                                    // the arithmetic of load_g(): sign of x * scale + shift
+#pragma unroll
+                for (int e = 0; e < CE; ++e) {
+                    const float z = xv[e] * xsc[e] + xsh[e];
+                    if (!(z > 0.f)) g[k][e] = (p.act == MG_ACT_RELU) ? 0.f : g[k][e] * p.slope;
+                }
+            } else if (from_y) {                             // y = act(.) + res2 -> the activation output's sign
+                float yv[CE], rb[CE];
+                TR::unpack(qy[k], yv);
+                TR::unpack(qr[k], rb);
+                if (p.res2) {
+#pragma unroll
+                    for (int e = 0; e < CE; ++e) yv[e] -= rb[e];
+                }
+#pragma unroll
+                for (int e = 0; e < CE; ++e) {
+                    if (!(yv[e] > 0.f)) g[k][e] = (p.act == MG_ACT_RELU) ? 0.f : g[k][e] * p.slope;
+                }
+            }
+            if (live) {
+#pragma unroll
+                for (int e = 0; e < CE; ++e) { sg[e] += g[k][e]; sgx[e] += g[k][e] * (xv[e] - mu[e]) * is[e]; }
+            } else {
+                qx[k] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < CE; ++e) g[k][e] = 0.f;
+            }
+        }
+    } else {
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int m = t + k * NT;
@@ -1081,6 +1194,7 @@ __global__ __launch_bounds__(NT) void bn_small_bwd_kernel(const mg_rowwise_param
 #pragma unroll
             for (int e = 0; e < CE; ++e) g[k][e] = 0.f;
         }
+    }
     }
     block_sum_vec<CE>(sg, sred);
     block_sum_vec<CE>(sgx, sred);

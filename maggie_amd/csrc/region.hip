@@ -150,16 +150,26 @@ __global__ __launch_bounds__(256) void dilate_kernel(const u64* __restrict__ in,
         int a = k / 2;
         u64 acc = 0;
         const u64* plane = in + (long)p * H * Ww;
-        for (int row = 0; row < k; ++row) {
-            int lo = c_se.lo[k][row], hi = c_se.hi[k][row];
-            if (lo > hi) continue;
-            int ys = y + row - a;
-            if (ys < 0 || ys >= H) continue;
-            const u64* rp = plane + (long)ys * Ww;
-            u64 cur = rp[wj];
-            u64 prev = wj > 0 ? rp[wj - 1] : 0ull;
-            u64 next = wj + 1 < Ww ? rp[wj + 1] : 0ull;
-            acc |= span_or(prev, cur, next, lo, hi);
+        // eight element rows per trip, their words and spans loaded as one batch from clamped addresses and masked afterwards: the row-by-row walk
+        // (`if (lo > hi) continue; if (ys outside) continue; three loads`) was one memory round trip per element row, up to 29 per word
+        const int wjm = wj > 0 ? wj - 1 : 0, wjp = wj + 1 < Ww ? wj + 1 : Ww - 1;
+        for (int r0 = 0; r0 < k; r0 += 8) {
+            u64 cur[8], prev[8], next[8];
+            int lo[8], hi[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = min(r0 + u, MAXK - 1);
+                const int ys = min(max(y + row - a, 0), H - 1);
+                const u64* rp = plane + (long)ys * Ww;
+                cur[u] = rp[wj]; prev[u] = rp[wjm]; next[u] = rp[wjp];
+                lo[u] = c_se.lo[k][row]; hi[u] = c_se.hi[k][row];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int row = r0 + u, ys = y + row - a;
+                if (row < k && lo[u] <= hi[u] && ys >= 0 && ys < H)
+                    acc |= span_or(wj > 0 ? prev[u] : 0ull, cur[u], wj + 1 < Ww ? next[u] : 0ull, lo[u], hi[u]);
+            }
         }
         int rem = W - wj * 64;
         if (rem < 64) acc &= (rem <= 0) ? 0ull : ((1ull << rem) - 1ull);

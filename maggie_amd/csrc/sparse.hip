@@ -312,19 +312,28 @@ __global__ __launch_bounds__(NT) void mask_embed_bwd_det_kernel(const T* __restr
     for (int j = 0; j < NID; ++j) { acc[j][0] = 0.f; acc[j][1] = 0.f; acc[j][2] = 0.f; }
     const long total = (long)N * H * W;
     const int sy = H / Hm, sx = W / Wm;
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; n_m > 0 && i < total; i += (long)gridDim.x * NT) {
         int x = (int)(i % W); long r = i / W; int y = (int)(r % H); int n = (int)(r / H);
         const float* mp = masks + ((long)n * n_m * Hm + (y / sy)) * Wm + (x / sx);
+        // the pixel's mask values and gradient as ONE batch of loads (planes past n_m read plane n_m - 1 and are not used): the run-time-length
+        // loop `for k < n_m: load, convert, compare` was a memory round trip per plane, twice per pixel (76 us for 1 M pixels)
+        float mv[NID - 1], gx[3];
+#pragma unroll
+        for (int k = 0; k < NID - 1; ++k) mv[k] = mp[(long)min(k, n_m - 1) * Hm * Wm];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gx[c] = c < n_embed ? ElemTraits<T>::ld(dx + i * 8 + 3 + c) : 0.f;
         float cnt = 0.f;
-        for (int k = 0; k < n_m; ++k) { long id = (long)(mp[(long)k * Hm * Wm] * (float)(k + 1)); if (id > 0) cnt += 1.f; }
+#pragma unroll
+        for (int k = 0; k < NID - 1; ++k) { if (k < n_m) { long id = (long)(mv[k] * (float)(k + 1)); if (id > 0) cnt += 1.f; } }
         if (cnt == 0.f) continue;
         float inv = 1.f / (cnt + 1e-6f);
         float g[3];
-        for (int c = 0; c < 3; ++c) g[c] = c < n_embed ? ElemTraits<T>::ld(dx + i * 8 + 3 + c) * inv : 0.f;
+        for (int c = 0; c < 3; ++c) g[c] = c < n_embed ? gx[c] * inv : 0.f;
 #pragma unroll
         for (int k = 0; k < NID - 1; ++k) {
-            if (k >= n_m) break;
-            const int id = (int)(long)(mp[(long)k * Hm * Wm] * (float)(k + 1));
+            // (a predicate, not `if (k >= n_m) break`: with the early exit the loop was not unrolled, acc[][] was indexed at run time and lived in
+            // scratch memory -- 208 bytes per thread, a scratch read-modify-write per hit)
+            const int id = k < n_m ? (int)(long)(mv[k] * (float)(k + 1)) : 0;
             if (id == k + 1) { acc[k + 1][0] += g[0]; acc[k + 1][1] += g[1]; acc[k + 1][2] += g[2]; }      // a 0 / 1 mask: id is 0 or k + 1 (static index)
             else if (id > 0) {                                                                             // fractional mask value: any id below k + 1
 #pragma unroll

@@ -441,6 +441,60 @@ __global__ __launch_bounds__(NT) void imd_prep_kernel(const float* __restrict__ 
     }
 }
 
+// The same in a (cells, 1 + n_i) grid (round 5): blockIdx.y == 0 forms the instance-ID position and the token validity, blockIdx.y == 1 + k the
+// ground-truth guidance of slot k. The single-thread-per-cell form walked n_in + n_gt windows one after the other with run-time loop bounds -- one
+// memory round trip per load, ~170 of them per thread, on 64 workgroups (57 us at 64 x 64 cells). Here a thread owns one (cell, plane) pair and its
+// window is a compile-time GS x GS block loaded as one batch (GS = 8: sixteen 16-byte loads); the ID position batches the n_in <= 16 pooled values of a
+// cell the same way (S == 1: the guidance masks usually arrive at the cell resolution). Same values, same comparisons: bit-identical outputs.
+template <int S, int GS>
+__global__ __launch_bounds__(NT) void imd_prep_planes_kernel(const float* __restrict__ mask, int n_in, const float* __restrict__ gt, int n_gt,
+                                                             int B, int NF, int h, int w, int n_i, int32_t* __restrict__ feat_ids,
+                                                             float* __restrict__ guidance, unsigned char* __restrict__ valid) {
+    const long cells = (long)B * NF * h * w;
+    const long i = (long)blockIdx.x * NT + threadIdx.x;
+    if (i >= cells) return;
+    const int x = (int)(i % w); long r = i / w; const int y = (int)(r % h); r /= h; const int f = (int)(r % NF); const int b = (int)(r / NF);
+    const long L = (long)NF * h * w, l = ((long)f * h + y) * w + x;
+    if (blockIdx.y == 0) {
+        constexpr int MAXP = 16;
+        const int Hm = h * S, Wm = w * S;
+        float acc[MAXP];
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+            const float* mp = mask + (((long)(b * NF + f) * n_in + min(k, n_in - 1)) * Hm + (long)y * S) * Wm + (long)x * S;
+            float a = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < S; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < S; ++dx) a += mp[(long)dy * Wm + dx];
+            acc[k] = a;
+        }
+        int id = 0;
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k)
+            if (k < n_in && acc[k] / (float)(S * S) > 0.f) { id = k + 1; valid[b * n_i + k] = 1; }
+        feat_ids[b * L + l] = id;
+        return;
+    }
+    const int k = (int)blockIdx.y - 1;
+    float m = 0.f;
+    if (k < n_gt) {
+        const int H = h * GS, W = w * GS;
+        const float* gp = gt + (((long)(b * NF + f) * n_gt + k) * H + (long)y * GS) * W + (long)x * GS;
+        float4 v[GS][GS / 4];
+#pragma unroll
+        for (int dy = 0; dy < GS; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < GS / 4; ++dx) v[dy][dx] = *(const float4*)(gp + (long)dy * W + dx * 4);
+        m = v[0][0].x;
+#pragma unroll
+        for (int dy = 0; dy < GS; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < GS / 4; ++dx) m = fmaxf(fmaxf(m, fmaxf(v[dy][dx].x, v[dy][dx].y)), fmaxf(v[dy][dx].z, v[dy][dx].w));
+    }
+    guidance[((long)b * n_i + k) * L + l] = m > 0.f ? 1.f : 0.f;
+}
+
 // ---- einsum('bqc,blc->blq') of the instance matte decoder (instance_matte_decoder.py:296-299: logits of every OS8 pixel against the Q = 10
 // instance tokens of its batch element; C = output_dim = 32). The reference runs it as one einsum; round 2 ran it as one 1x1 convolution PER
 // batch element (weights = that element's tokens: 4 fprop + 4 dgrad + 4 wgrad + 4 reduce launches, 4 weight conversions and a stack per
@@ -678,6 +732,14 @@ extern "C" int mg_imd_prep(const float* mask, int n_in, int s, const float* gt, 
     hipError_t e = mg_zero_words(valid, ((long)B * n_i + 3) / 4, st);          // `valid` must be padded to a multiple of 4 bytes by the caller
     if (e != hipSuccess) return (int)e;
     const long cells = (long)B * NF * h * w;
+    static const int planes_on = [] { const char* e = getenv("MG_IMD_PREP_PLANES"); return e ? atoi(e) : 1; }();
+    if (planes_on && gt && guidance && gs == 8 && n_in >= 1 && n_in <= 16 && (s == 1 || s == 2)) {
+        const dim3 grid((unsigned)((cells + NT - 1) / NT), (unsigned)(1 + n_i));
+        if (s == 1) hipLaunchKernelGGL((imd_prep_planes_kernel<1, 8>), grid, dim3(NT), 0, st, mask, n_in, gt, n_gt, B, NF, h, w, n_i, feat_ids, guidance, valid);
+        else hipLaunchKernelGGL((imd_prep_planes_kernel<2, 8>), grid, dim3(NT), 0, st, mask, n_in, gt, n_gt, B, NF, h, w, n_i, feat_ids, guidance, valid);
+        MG_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(imd_prep_kernel, dim3((unsigned)((cells + NT - 1) / NT)), dim3(NT), 0, st, mask, n_in, s, gt, gt ? n_gt : 0, gs, B, NF, h, w, n_i,
                        feat_ids, gt ? guidance : nullptr, valid);
     MG_CHECK_LAUNCH();
