@@ -188,6 +188,43 @@ __global__ __launch_bounds__(NT) void gather_rows_bwd_dense_kernel(const T* __re
         float acc[CE];
 #pragma unroll
         for (int e = 0; e < CE; ++e) acc[e] = 0.f;
+        constexpr int MAXI = 16;
+        if (n_i <= MAXI) {
+            // the planes' words, then their ranks, then the active rows: three batches of loads instead of one dependent chain (word -> rank -> row) per
+            // plane, plane after plane (up to 3 * n_i memory round trips per pixel chunk); the rows are added in plane order as before
+            const int b = x & 63;
+            unsigned long long m[MAXI];
+            int wo[MAXI];
+            uint4 q[MAXI];
+#pragma unroll
+            for (int inst = 0; inst < MAXI; ++inst) {
+                const long wi = ((long)(frame * n_i + min(inst, n_i - 1)) * Hd + y) * Ww + (x >> 6);
+                m[inst] = bits[wi];
+                wo[inst] = wordoff[wi];
+            }
+#pragma unroll
+            for (int inst = 0; inst < MAXI; ++inst) {
+                q[inst] = make_uint4(0, 0, 0, 0);
+                if (inst < n_i && ((m[inst] >> b) & 1ull)) {
+                    const int row = wo[inst] + __popcll(m[inst] & ((1ull << b) - 1ull));
+                    q[inst] = *(const uint4*)(dout + (long)row * ldo + yoff + cc * CE);
+                }
+            }
+#pragma unroll
+            for (int inst = 0; inst < MAXI; ++inst) {
+                if (inst < n_i && ((m[inst] >> b) & 1ull)) {
+                    float g[CE];
+                    TR::unpack(q[inst], g);
+                    if (mul) {
+                        const float* mv = mul + ((long)frame * mul_ninst + inst) * C + cc * CE;
+#pragma unroll
+                        for (int e = 0; e < CE; ++e) g[e] *= mv[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < CE; ++e) acc[e] += g[e];
+                }
+            }
+        } else
         for (int inst = 0; inst < n_i; ++inst) {
             int p = frame * n_i + inst;
             long wi = ((long)p * Hd + y) * Ww + (x >> 6);
