@@ -48,12 +48,27 @@ __device__ __forceinline__ void block_add(float v, float* dst, float* sh, float*
     __syncthreads();
 }
 
+// any(wp[i] > 0) over the workgroup's share of a plane, eight loads in flight per thread (the plain grid-stride loop is one load -> wait per trip)
+__device__ __forceinline__ int plane_any_pos(const float* __restrict__ wp, int HW) {
+    const int stride = gridDim.x * NT;
+    int i = blockIdx.x * NT + threadIdx.x;
+    int any = 0;
+    for (; i + 7 * stride < HW; i += 8 * stride) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = wp[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) any |= (v[u] > 0.f);
+    }
+    for (; i < HW; i += stride) any |= (wp[i] > 0.f);
+    return any;
+}
+
 // flags[p] = any(w[p] > 0)
 __global__ __launch_bounds__(NT) void plane_flags_kernel(const float* __restrict__ w, int HW, int* __restrict__ flags, int one) {
     const int p = blockIdx.y;
     const float* wp = w + (long)p * HW;
-    int any = 0;
-    for (int i = blockIdx.x * NT + threadIdx.x; i < HW; i += gridDim.x * NT) any |= (wp[i] > 0.f);
+    const int any = plane_any_pos(wp, HW);
     // every writer stores the same value: a plain store (no read-modify-write) is enough, and one per workgroup instead of one atomic per wave
     if (__syncthreads_or(any) && threadIdx.x == 0) flags[p] = one;
 }
@@ -61,8 +76,7 @@ __global__ __launch_bounds__(NT) void plane_flags_kernel(const float* __restrict
 __global__ __launch_bounds__(NT) void plane_flags3_kernel(const P3 w, int Pper, int HW, int* __restrict__ flags) {
     const int p = blockIdx.y, sc = p / Pper;
     const float* wp = w.a[sc] + (long)(p - sc * Pper) * HW;
-    int any = 0;
-    for (int i = blockIdx.x * NT + threadIdx.x; i < HW; i += gridDim.x * NT) any |= (wp[i] > 0.f);
+    const int any = plane_any_pos(wp, HW);
     if (__syncthreads_or(any) && threadIdx.x == 0) flags[p] = 1;
 }
 

@@ -188,19 +188,21 @@ __global__ __launch_bounds__(NT) void gather_rows_bwd_dense_kernel(const T* __re
         float acc[CE];
 #pragma unroll
         for (int e = 0; e < CE; ++e) acc[e] = 0.f;
-        constexpr int MAXI = 16;
+        constexpr int MAXI = 10;                                  // the model's instance slots (resnet_inst_matt_spconv.py: max_inst = 10)
         if (n_i <= MAXI) {
-            // the planes' words, then their ranks, then the active rows: three batches of loads instead of one dependent chain (word -> rank -> row) per
-            // plane, plane after plane (up to 3 * n_i memory round trips per pixel chunk); the rows are added in plane order as before
+            // the planes' words, then the ranks of the active ones, then their rows: three batches of loads instead of one dependent chain
+            // (word -> rank -> row) per plane, plane after plane; the rows are added in plane order as before
             const int b = x & 63;
             unsigned long long m[MAXI];
             int wo[MAXI];
             uint4 q[MAXI];
 #pragma unroll
+            for (int inst = 0; inst < MAXI; ++inst)
+                m[inst] = bits[((long)(frame * n_i + min(inst, n_i - 1)) * Hd + y) * Ww + (x >> 6)];
+#pragma unroll
             for (int inst = 0; inst < MAXI; ++inst) {
-                const long wi = ((long)(frame * n_i + min(inst, n_i - 1)) * Hd + y) * Ww + (x >> 6);
-                m[inst] = bits[wi];
-                wo[inst] = wordoff[wi];
+                wo[inst] = 0;
+                if (inst < n_i && ((m[inst] >> b) & 1ull)) wo[inst] = wordoff[((long)(frame * n_i + inst) * Hd + y) * Ww + (x >> 6)];
             }
 #pragma unroll
             for (int inst = 0; inst < MAXI; ++inst) {
@@ -423,6 +425,33 @@ __global__ __launch_bounds__(NT) void upsample_tanh_kernel(const T* __restrict__
     int nz = 0;
     if (pscale && ps == 0.f) {
         for (int i = blockIdx.x * NT + threadIdx.x; i < H * W; i += gridDim.x * NT) op[i] = 0.f;
+        return;
+    }
+    if (scale != 1) {
+        // four output pixels per trip, their sixteen source values requested before the first is used (the one-pixel loop below was load x 4 ->
+        // wait -> exp -> store, sixteen dependent round trips per thread at 512 x 512); a pixel's arithmetic is unchanged
+        const int stride = gridDim.x * NT;
+        for (int i0 = blockIdx.x * NT + threadIdx.x; i0 < H * W; i0 += 4 * stride) {
+            float v00[4], v01[4], v10[4], v11[4], ly[4], lx[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + u * stride, H * W - 1);             // past the plane: the last pixel again, not stored
+                const int Y = i / W, X = i - Y * W;
+                int y0, y1, x0, x1;
+                bil_src(Y, scale, h, y0, y1, ly[u]);
+                bil_src(X, scale, w, x0, x1, lx[u]);
+                v00[u] = ElemTraits<T>::ld(base + y0 * sy + x0 * sx); v01[u] = ElemTraits<T>::ld(base + y0 * sy + x1 * sx);
+                v10[u] = ElemTraits<T>::ld(base + y1 * sy + x0 * sx); v11[u] = ElemTraits<T>::ld(base + y1 * sy + x1 * sx);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * stride;
+                const float v = (1.f - ly[u]) * ((1.f - lx[u]) * v00[u] + lx[u] * v01[u]) + ly[u] * ((1.f - lx[u]) * v10[u] + lx[u] * v11[u]);
+                const float o = (apply_tanh ? 1.f / (1.f + __expf(-2.f * v)) : v) * ps;
+                if (i < H * W) { op[i] = o; nz |= (o != 0.f); }
+            }
+        }
+        if (any_nonzero && __syncthreads_or(nz) && threadIdx.x == 0) *any_nonzero = 1;
         return;
     }
     for (int i = blockIdx.x * NT + threadIdx.x; i < H * W; i += gridDim.x * NT) {
