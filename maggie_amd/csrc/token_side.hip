@@ -396,6 +396,112 @@ __global__ __launch_bounds__(NT) void token_sa_bwd_kernel(const float* __restric
 }
 
 
+// The same two kernels with their operands in LDS (round 5; T <= 16, D <= 128): the forms above read q / k / v / dout straight from global memory
+// inside run-time-length loops -- `for d < D: s += q[i][d] * k[j][d]` is two loads and a full wait per d, 128 dependent round trips for one score,
+// and the output loops another T per element (18 / 21 us per launch for 40 x 128 operands). Here the (T x D) matrices of the batch element are
+// staged once, up to 8 predicated 4-byte loads per matrix and thread in flight, rows at pitch D + 1 (the (i, j) lanes of a wave read D-strided rows: at
+// pitch 128 all on one bank); every sum keeps its order (d ascending, j ascending), so the results have the bits of the first forms.
+constexpr int SA_MAXT = 16, SA_MAXD = 128, SA_P = SA_MAXD + 1;
+template <int N>
+__device__ __forceinline__ void sa_stage(float* const (&dst)[N], const float* const (&src)[N], int T, int D) {     // all N matrices' loads, then the stores
+    float v[N][8];
+#pragma unroll
+    for (int m = 0; m < N; ++m)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = threadIdx.x + u * NT; v[m][u] = i < T * D ? src[m][i] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = threadIdx.x + u * NT;
+        if (i < T * D) {
+            const int r = i / D, c = i - r * D;
+#pragma unroll
+            for (int m = 0; m < N; ++m) dst[m][r * SA_P + c] = v[m][u];
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void token_sa_fwd_lds_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                              const unsigned char* __restrict__ pad, float scale, int T, int D, float* __restrict__ out,
+                                                              float* __restrict__ prob) {
+    __shared__ float sp[16 * 16];
+    __shared__ float sq[SA_MAXT * SA_P], sk[SA_MAXT * SA_P], sv[SA_MAXT * SA_P];
+    const int b = blockIdx.x, t = threadIdx.x;
+    {
+        float* const dst[3] = {sq, sk, sv};
+        const float* const src[3] = {q + (size_t)b * T * D, k + (size_t)b * T * D, v + (size_t)b * T * D};
+        sa_stage<3>(dst, src, T, D);
+    }
+    const bool padded = (t < T * T && pad) ? pad[b * T + (t % T)] != 0 : false;
+    __syncthreads();
+    if (t < T * T) {
+        const int i = t / T, j = t - i * T;
+        float s = 0.f;
+#pragma unroll 8
+        for (int d = 0; d < D; ++d) s += sq[i * SA_P + d] * sk[j * SA_P + d];
+        s *= scale;
+        if (padded) s = -INFINITY;
+        sp[i * 16 + j] = s;
+    }
+    __syncthreads();
+    if (t < T) {
+        float m = -INFINITY;
+        for (int j = 0; j < T; ++j) m = fmaxf(m, sp[t * 16 + j]);
+        float sum = 0.f;
+        for (int j = 0; j < T; ++j) { const float e = __expf(sp[t * 16 + j] - m); sp[t * 16 + j] = e; sum += e; }
+        const float inv = 1.f / sum;
+        for (int j = 0; j < T; ++j) { sp[t * 16 + j] *= inv; prob[((size_t)b * T + t) * T + j] = sp[t * 16 + j]; }
+    }
+    __syncthreads();
+    for (int i = t; i < T * D; i += NT) {
+        const int r = i / D, d = i - r * D;
+        float a = 0.f;
+        for (int j = 0; j < T; ++j) a += sp[r * 16 + j] * sv[j * SA_P + d];
+        out[(size_t)b * T * D + i] = a;
+    }
+}
+
+__global__ __launch_bounds__(NT) void token_sa_bwd_lds_kernel(const float* __restrict__ dout, const float* __restrict__ q, const float* __restrict__ k,
+                                                              const float* __restrict__ v, const float* __restrict__ prob, float scale, int T, int D,
+                                                              float* __restrict__ dq, float* __restrict__ dk, float* __restrict__ dv) {
+    __shared__ float sp[16 * 16], sds[16 * 16];
+    __shared__ float sq[SA_MAXT * SA_P], sk[SA_MAXT * SA_P], sv[SA_MAXT * SA_P], sg[SA_MAXT * SA_P];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const size_t o = (size_t)b * T * D;
+    {
+        float* const dst[4] = {sg, sv, sq, sk};
+        const float* const src[4] = {dout + o, v + o, q + o, k + o};
+        sa_stage<4>(dst, src, T, D);
+    }
+    const float pr = t < T * T ? prob[((size_t)b * T + t / T) * T + (t % T)] : 0.f;
+    __syncthreads();
+    if (t < T * T) {
+        const int i = t / T, j = t - i * T;
+        sp[i * 16 + j] = pr;
+        float a = 0.f;                                               // dP[i][j] = dout[i] . v[j]
+#pragma unroll 8
+        for (int d = 0; d < D; ++d) a += sg[i * SA_P + d] * sv[j * SA_P + d];
+        sds[i * 16 + j] = a;
+    }
+    __syncthreads();
+    if (t < T) {                                                     // softmax backward per row, then the 1/sqrt(d) factor
+        float dot = 0.f;
+        for (int j = 0; j < T; ++j) dot += sp[t * 16 + j] * sds[t * 16 + j];
+        for (int j = 0; j < T; ++j) sds[t * 16 + j] = sp[t * 16 + j] * (sds[t * 16 + j] - dot) * scale;
+    }
+    __syncthreads();
+    for (int i = t; i < T * D; i += NT) {
+        const int r = i / D, d = i - r * D;
+        float aq = 0.f, ak = 0.f, av = 0.f;
+        for (int j = 0; j < T; ++j) {
+            aq += sds[r * 16 + j] * sk[j * SA_P + d];                 // dq[r] = sum_j dS[r][j] k[j]
+            ak += sds[j * 16 + r] * sq[j * SA_P + d];                 // dk[r] = sum_i dS[i][r] q[i]
+            av += sp[j * 16 + r] * sg[j * SA_P + d];                  // dv[r] = sum_i P[i][r] dout[i]
+        }
+        dq[o + i] = aq; dk[o + i] = ak; dv[o + i] = av;
+    }
+}
+
+
 // ---- mask pre-processing of the instance matte decoder (instance_matte_decoder.py:131-153 + utils.py:16-21 resizeAnyShape(use_avg_pool_binary)):
 // per OS8 cell: the guidance masks average-pooled and thresholded (> 0), the instance-ID position = max_i (i + 1) * m8_i, which instance slots
 // have any mask pixel (token validity), and -- training -- the ground-truth guidance (max-pool of the alphas > 0). ~15 small torch launches
@@ -666,7 +772,11 @@ extern "C" int mg_token_sa_fwd(const float* q, const float* k, const float* v, c
                                float* prob, void* stream) {
     if (B <= 0) return 0;
     if (T <= 0 || T > 16 || D <= 0) return -3;
-    hipLaunchKernelGGL(token_sa_fwd_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, q, k, v, pad, scale, T, D, out, prob);
+    static const int lds_on = [] { const char* e = getenv("MG_TOKEN_SA_LDS"); return e ? atoi(e) : 1; }();
+    if (lds_on && T <= SA_MAXT && D <= SA_MAXD && T * D <= 8 * NT)
+        hipLaunchKernelGGL(token_sa_fwd_lds_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, q, k, v, pad, scale, T, D, out, prob);
+    else
+        hipLaunchKernelGGL(token_sa_fwd_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, q, k, v, pad, scale, T, D, out, prob);
     MG_CHECK_LAUNCH();
     return 0;
 }
@@ -675,7 +785,11 @@ extern "C" int mg_token_sa_bwd(const float* dout, const float* q, const float* k
                                float* dq, float* dk, float* dv, void* stream) {
     if (B <= 0) return 0;
     if (T <= 0 || T > 16 || D <= 0) return -3;
-    hipLaunchKernelGGL(token_sa_bwd_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, dout, q, k, v, prob, scale, T, D, dq, dk, dv);
+    static const int lds_on = [] { const char* e = getenv("MG_TOKEN_SA_LDS"); return e ? atoi(e) : 1; }();
+    if (lds_on && T <= SA_MAXT && D <= SA_MAXD && T * D <= 8 * NT)
+        hipLaunchKernelGGL(token_sa_bwd_lds_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, dout, q, k, v, prob, scale, T, D, dq, dk, dv);
+    else
+        hipLaunchKernelGGL(token_sa_bwd_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, dout, q, k, v, prob, scale, T, D, dq, dk, dv);
     MG_CHECK_LAUNCH();
     return 0;
 }

@@ -4,7 +4,7 @@
 # (maggie_amd/_variants/lib_old.so, MAGGIE_LIB_PATH) and a kernel trace of the new build. usage (through gpurun): bash tools/r05b_check.sh
 out=gpurun_out/r05b
 mkdir -p $out
-K="upsample_tanh or plane_flags or three_scales or gather_scatter or gather_tables or video_region or matting_losses or batch_norm_act_one_call or bn_train_forward_backward or reformed_from_the_raw_input or mask_embed or compute_unknown or active_pyramid or os8_weight or atten_guidance or bits_ or bn_fold"
+K="token_self_attention or spatial_mean or bn_fold_and_pool or upsample_tanh or plane_flags or three_scales or gather_scatter or gather_tables or video_region or matting_losses or batch_norm_act_one_call or bn_train_forward_backward or reformed_from_the_raw_input or mask_embed or compute_unknown or active_pyramid or os8_weight or atten_guidance or bits_ or bn_fold"
 timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -p no:cacheprovider -k "$K" 2>&1 | tail -15 > $out/pytest_kernels.txt
 timeout 1200 python -m pytest tests/test_gpu_model.py tests/test_gpu_determinism.py -m gpu -x -q -p no:cacheprovider -k "train_step_matches or eval_forward_matches or train_step_is_bit_reproducible or former_atomic or video_consecutive" 2>&1 | tail -15 > $out/pytest_model.txt
 grep -h "passed\|failed\|error" $out/pytest_kernels.txt $out/pytest_model.txt
