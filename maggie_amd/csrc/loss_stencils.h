@@ -1,11 +1,13 @@
 // Per-cell arithmetic of the Laplacian-pyramid / Sobel-adjoint stencils of csrc/losses.hip (reference: maggie/network/loss.py:67-191, LapLoss /
 // GradientLoss; the adjoints are ours). Every stencil exists twice:
-//   *_general : the walk over all taps with the reflect / replicate border folded into run-time conditions -- valid for every cell, but each tap sits
-//               behind a condition, so it compiles to one load + one full wait per tap;
+//   *_general : the walk over all taps with the reflect / replicate border folded into run-time conditions -- valid for every cell. Written tap by
+//               tap (load behind its condition) it compiles to one load + one full wait per tap; the forms here request a pixel's 25 taps
+//               (lap_up), or a row's 15 column candidates (upT / downT), as one batch and apply the conditions when the terms are added;
 //   *_inner   : the same terms in the same order for a cell whose taps do not touch the border, where the tap set depends on the cell's parity
 //               alone: the window is loaded unconditionally as one batch, then combined.
 // The includer defines MG_STENCIL_FN (`__device__ __forceinline__` in losses.hip; `static inline` in tests/csrc/loss_stencils_check.cpp, which
-// checks on the host that both forms agree on every inner cell and that ring_map enumerates every cell once).
+// checks on the host that both forms agree on every inner cell, that the general forms equal the tap-by-tap walks they replaced on EVERY cell, bit for bit,
+// and that ring_map enumerates every cell once).
 #pragma once
 
 MG_STENCIL_FN int st_refl(int k, int n) { return k < 0 ? -k : (k >= n ? 2 * (n - 1) - k : k); }
@@ -34,17 +36,26 @@ MG_STENCIL_FN bool ring_map(int t, int nh, int nw, int T, int Bt, int Lw, int Rw
 
 // ---- up = gauss5 * zero_stuff(down) at pixel (y, xx) of the (h x w) plane; down is (h/2 x w/2) = (. x wd) ------------------------------------
 MG_STENCIL_FN float lap_up_general(const float* __restrict__ dp, int y, int xx, int h, int w, int wd) {
+    // the 5 x 5 reflected taps all land on a cell of `down` ((yy >> 1, xs >> 1) is always inside): they are loaded as one batch, the odd (zero-stuffed)
+    // rows / columns are skipped when the terms are added -- the terms and their order are those of the tap-by-tap walk (border waves used to spend one
+    // memory round trip per tap, which set an ~11 us floor under every launch of the pyramid kernels whatever the level's size)
     const float g[5] = MG_G1;
+    int yy[5], xs[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { yy[i] = st_refl(y + i - 2, h); xs[i] = st_refl(xx + i - 2, w); }
+    float v[5][5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) v[i][j] = dp[(yy[i] >> 1) * wd + (xs[j] >> 1)];
     float up = 0.f;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
-        int yy = st_refl(y + i - 2, h);
-        if (yy & 1) continue;
+        if (yy[i] & 1) continue;
         float r = 0.f;
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            int xs = st_refl(xx + j - 2, w);
-            if (!(xs & 1)) r += g[j] * dp[(yy >> 1) * wd + (xs >> 1)];
+            if (!(xs[j] & 1)) r += g[j] * v[i][j];
         }
         up += g[i] * r;
     }
@@ -96,19 +107,27 @@ MG_STENCIL_FN float upT_general(const float* __restrict__ qp, int a, int b, int 
         for (int i = 0; i < 5; ++i) {
             int y = ma - i + 2;
             if (y < 0 || y >= h) continue;
-            float rowacc = 0.f;
+            // the row's 15 column candidates as one batch of loads (clamped columns), added under the tap-by-tap conditions in the same order
+            float v[3][5];
+            bool ok[3][5];
 #pragma unroll
             for (int sb = 0; sb < 3; ++sb) {
-                int mb = sb == 0 ? 2 * b : (sb == 1 ? -2 * b : 2 * (w - 1) - 2 * b);
-                if (sb == 1 && b != 1) continue;
-                if (sb == 2 && mb != w) continue;
+                const int mb = sb == 0 ? 2 * b : (sb == 1 ? -2 * b : 2 * (w - 1) - 2 * b);
+                const bool on = !(sb == 1 && b != 1) && !(sb == 2 && mb != w);
 #pragma unroll
                 for (int j = 0; j < 5; ++j) {
-                    int xq = mb - j + 2;
-                    if (xq < 0 || xq >= w) continue;
-                    rowacc += g[j] * qp[y * w + xq];
+                    const int xq = mb - j + 2;
+                    ok[sb][j] = on && xq >= 0 && xq < w;
+                    v[sb][j] = qp[y * w + (xq < 0 ? 0 : (xq >= w ? w - 1 : xq))];      // unconditional, from a clamped column: used only where ok
                 }
             }
+            float rowacc = 0.f;
+#pragma unroll
+            for (int sb = 0; sb < 3; ++sb)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    if (ok[sb][j]) rowacc += g[j] * v[sb][j];
+                }
             acc += g[i] * rowacc;
         }
     }
@@ -150,21 +169,27 @@ MG_STENCIL_FN float downT_general(const float* __restrict__ rp, int Y, int X, in
             if (ty < 0 || (ty & 1)) continue;
             int y = ty >> 1;
             if (y >= hd) continue;
-            float rowacc = 0.f;
+            float v[3][5];
+            bool ok[3][5];
 #pragma unroll
             for (int sb = 0; sb < 3; ++sb) {
-                int mx = sb == 0 ? X : (sb == 1 ? -X : 2 * (w - 1) - X);
-                if (sb == 1 && !(X == 1 || X == 2)) continue;
-                if (sb == 2 && !(X == w - 2 || X == w - 3)) continue;
+                const int mx = sb == 0 ? X : (sb == 1 ? -X : 2 * (w - 1) - X);
+                const bool on = !(sb == 1 && !(X == 1 || X == 2)) && !(sb == 2 && !(X == w - 2 || X == w - 3));
 #pragma unroll
                 for (int j = 0; j < 5; ++j) {
-                    int tx = mx - j + 2;
-                    if (tx < 0 || (tx & 1)) continue;
-                    int xr = tx >> 1;
-                    if (xr >= wd) continue;
-                    rowacc += g[j] * rp[y * wd + xr];
+                    const int tx = mx - j + 2;
+                    const int xr = tx >> 1;
+                    ok[sb][j] = on && tx >= 0 && !(tx & 1) && xr < wd;
+                    v[sb][j] = rp[y * wd + (xr < 0 ? 0 : (xr >= wd ? wd - 1 : xr))];   // unconditional, from a clamped column: used only where ok
                 }
             }
+            float rowacc = 0.f;
+#pragma unroll
+            for (int sb = 0; sb < 3; ++sb)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    if (ok[sb][j]) rowacc += g[j] * v[sb][j];
+                }
             acc += g[i] * rowacc;
         }
     }

@@ -336,9 +336,27 @@ __global__ __launch_bounds__(NT) void pyr_lap_fwd_quad_kernel(const float* __res
     const float* __restrict__ wp = w0.a[sc] + (long)(pl - sc * Pper) * H0 * W0;
     float* __restrict__ Gp = G + (long)pl * h * w;
     float s0 = 0.f, s1 = 0.f;
-    for (int q = blockIdx.x * NT + threadIdx.x; q < hd * wd; q += gridDim.x * NT) {
+    // index space: the inner quads (one thread each, four pixels), then the border ring PIXEL by pixel (four threads per border quad: a border pixel
+    // is a chain of dependent steps, and four of them in one thread were the longest path of the launch)
+    const int hi = hd - 2, wi = wd - 2;
+    const int n_int = (hi > 0 && wi > 0) ? hi * wi : 0;
+    const int total = n_int + 4 * (hd * wd - n_int);
+    for (int q = blockIdx.x * NT + threadIdx.x; q < total; q += gridDim.x * NT) {
+        if (q >= n_int) {
+            const int bt = q - n_int;
+            int a, b;
+            ring_map(n_int + (bt >> 2), hd, wd, 1, 1, 1, 1, a, b);
+            const int y = 2 * a + ((bt >> 1) & 1), xx = 2 * b + (bt & 1);
+            const float xv1 = xp[(long)y * w + xx];
+            const float wl1 = wp[(long)(y << lvl) * W0 + (xx << lvl)];
+            const float L = xv1 - 4.f * lap_up_general(dp, y, xx, h, w, wd);
+            s0 += fabsf(L) * wl1;
+            s1 += wl1;
+            Gp[(long)y * w + xx] = L > 0.f ? wl1 : (L < 0.f ? -wl1 : 0.f);
+            continue;
+        }
         int a, b;
-        const bool inner = ring_map(q, hd, wd, 1, 1, 1, 1, a, b);
+        ring_map(q, hd, wd, 1, 1, 1, 1, a, b);
         const int y0 = 2 * a, x0 = 2 * b;
         const float* __restrict__ xr0 = xp + (long)y0 * w + x0;
         const float xv[4] = {xr0[0], xr0[1], xr0[w], xr0[w + 1]};
@@ -346,11 +364,7 @@ __global__ __launch_bounds__(NT) void pyr_lap_fwd_quad_kernel(const float* __res
         const int wc0 = x0 << lvl, wc1 = (x0 + 1) << lvl;
         const float wl[4] = {wp[wr0 + wc0], wp[wr0 + wc1], wp[wr1 + wc0], wp[wr1 + wc1]};
         float up[4];
-        if (inner) lap_up_inner(dp, a, b, wd, up);
-        else {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) up[u] = lap_up_general(dp, y0 + (u >> 1), x0 + (u & 1), h, w, wd);
-        }
+        lap_up_inner(dp, a, b, wd, up);
         float gq[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -393,18 +407,26 @@ __global__ __launch_bounds__(NT) void pyr_downT_quad_kernel(const float* __restr
     const float* __restrict__ qp = q + (long)pl * h * w;
     float* __restrict__ op = dd + (long)pl * h * w;
     const float c = coef[(pl / Pper) * 5];
-    for (int t = blockIdx.x * NT + threadIdx.x; t < hd * wd; t += gridDim.x * NT) {
+    const int hi = hd - 4, wi = wd - 4;                          // inner quads first, then the border ring pixel by pixel (see pyr_lap_fwd_quad_kernel)
+    const int n_int = (hi > 0 && wi > 0) ? hi * wi : 0;
+    const int total = n_int + 4 * (hd * wd - n_int);
+    for (int t = blockIdx.x * NT + threadIdx.x; t < total; t += gridDim.x * NT) {
+        if (t >= n_int) {
+            const int bt = t - n_int;
+            int a, b;
+            ring_map(n_int + (bt >> 2), hd, wd, 2, 2, 2, 2, a, b);
+            const int Y = 2 * a + ((bt >> 1) & 1), X = 2 * b + (bt & 1);
+            const float qv1 = qp[(long)Y * w + X];
+            op[(long)Y * w + X] = c * qv1 + downT_general(rp, Y, X, h, w, hd, wd);
+            continue;
+        }
         int a, b;
-        const bool inner = ring_map(t, hd, wd, 2, 2, 2, 2, a, b);
+        ring_map(t, hd, wd, 2, 2, 2, 2, a, b);
         const int y0 = 2 * a, x0 = 2 * b;
         const float* __restrict__ qr0 = qp + (long)y0 * w + x0;
         const float qv[4] = {qr0[0], qr0[1], qr0[w], qr0[w + 1]};
         float acc[4];
-        if (inner) downT_inner(rp, a, b, wd, acc);
-        else {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc[u] = downT_general(rp, y0 + (u >> 1), x0 + (u & 1), h, w, hd, wd);
-        }
+        downT_inner(rp, a, b, wd, acc);
         float* __restrict__ o0 = op + (long)y0 * w + x0;
         o0[0] = c * qv[0] + acc[0]; o0[1] = c * qv[1] + acc[1]; o0[w] = c * qv[2] + acc[2]; o0[w + 1] = c * qv[3] + acc[3];
     }
