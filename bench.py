@@ -54,6 +54,7 @@ def parse():
     ap.add_argument('--cpu-baseline-worker', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--cpu-threads', type=int, default=0, help='cpu_baseline: torch threads (0 = try 32 and all host cores, report the faster)')
     ap.add_argument('--acc-file', default='', help=argparse.SUPPRESS)
+    ap.add_argument('--dry-run', action='store_true', help=argparse.SUPPRESS)     # rank plumbing only (tests): rendezvous, count the ranks, print, no model
     ap.add_argument('--layers', action='store_true', help='print the per-shape conv kernel table to stderr')
     ap.add_argument('--ddp', action='store_true', help='all-reduce gradients with torch DistributedDataParallel (like the reference) instead of '
                                                       'maggie_amd.parallel.GradSync (flat-buffer RCCL all-reduce, the default for N > 1)')
@@ -73,10 +74,20 @@ def main():
     if args.cpu_baseline_worker:
         run_cpu_baseline('video' if args.video else 'image', args)
         return
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        spawn_ranks(args.gpus)                                 # does not return: this process becomes the launcher of N ranks
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and os.environ.get('MAGGIE_FORCE_DDP') != '1':
+        # the driver contract: --gpus N IS the number of ranks. A launcher that started a different number (or none) must not produce a line
+        # that says n_gpus = something else than what was asked for
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d: launch with `python bench.py --gpus N` (spawns the ranks itself) or '
+                         '`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`' % (args.gpus, world))
     import torch.distributed as dist
+    if args.dry_run:
+        dry_run(args, world, rank)
+        return
     force_ddp = os.environ.get('MAGGIE_FORCE_DDP') == '1'          # exercise the RCCL/DDP path on a single GPU (smoke test)
     if world > 1 or force_ddp:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -96,6 +107,15 @@ def main():
     from maggie_amd.network import build_model
     from maggie_amd.utils import config, synth
     from maggie_amd import hip, parallel
+
+    ranks_seen = 1
+    if dist.is_initialized():
+        # how many ranks the collective backend really connects (an all-reduce of ones ON the device): goes into the line next to n_gpus
+        one = torch.ones(1, device=dev if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
+        assert ranks_seen == world, 'the %s group connects %d ranks, WORLD_SIZE says %d' % (dist.get_backend(), ranks_seen, world)
+    devices = sorted(set(gather_device_ids(local_rank, world)))          # collective: every rank calls it
 
     kind = 'video' if args.video else 'image'
     n_f = args.frames if args.video else 1
@@ -337,7 +357,9 @@ def main():
                                    'fwd+loss+bwd+clip+AdamW' % (kind, args.size, args.size, args.instances, b, n_f, args.iter,
                                                                 'detail region guided by the ground-truth alphas, soft edge %g px: constant active ratio' % args.edge
                                                                 if args.workload == 'gt' else 'detail region from the predicted coarse alpha: drifts with the random-init weights'),
-                       'global_batch': b * world, 'parallelism': 'dp%d' % world, 'sync_bn': bool(args.sync_bn and (world > 1 or (force_ddp and os.environ.get('MAGGIE_SYNCBN_WORLD1') == '1'))), 'sync_bn_path': None if not args.sync_bn else ('eager (host-launched collectives: MAGGIE_SYNCBN_GRAPHS=0, or no in-graph exchange could be set up on this group)' if parallel.SYNCBN_COMM is None else 'hipGraphs (statistics exchange recorded into the graphs through %s; default for sync_bn: true)' % ('the mailbox all-reduce kernels (one node, peer access)' if type(parallel.SYNCBN_COMM).__name__ == 'MailboxComm' else 'a private RCCL communicator')), 'optimizer': 'FlatAdamW (clip 0.01 folded in)' if args.optimizer == 'flat' else 'torch AdamW(%s) + flat-buffer grad-norm clip' % args.optimizer,
+                       'global_batch': b * world, 'parallelism': 'dp%d' % world, 'ranks_seen_by_collective_backend': ranks_seen,
+                       'collective_backend': (dist.get_backend() + (' (RCCL)' if dist.get_backend() == 'nccl' else '')) if dist.is_initialized() else None,
+                       'devices': devices, 'sync_bn': bool(args.sync_bn and (world > 1 or (force_ddp and os.environ.get('MAGGIE_SYNCBN_WORLD1') == '1'))), 'sync_bn_path': None if not args.sync_bn else ('eager (host-launched collectives: MAGGIE_SYNCBN_GRAPHS=0, or no in-graph exchange could be set up on this group)' if parallel.SYNCBN_COMM is None else 'hipGraphs (statistics exchange recorded into the graphs through %s; default for sync_bn: true)' % ('the mailbox all-reduce kernels (one node, peer access)' if type(parallel.SYNCBN_COMM).__name__ == 'MailboxComm' else 'a private RCCL communicator')), 'optimizer': 'FlatAdamW (clip 0.01 folded in)' if args.optimizer == 'flat' else 'torch AdamW(%s) + flat-buffer grad-norm clip' % args.optimizer,
                        'grad_allreduce': None if world == 1 and not force_ddp else ('torch DDP' if args.ddp else ('RCCL all-reduce (mean) of each of the three backward graphs\' stretches of the optimizer\'s flat gradient buffer, in place on a side stream, overlapped with the rest of backward (parallel.OverlappedGradSync + FlatAdamW gradient sink)' if (args.optimizer == 'flat' and os.environ.get('MAGGIE_GRAD_OVERLAP', '1') != '0') else 'one RCCL all-reduce of the flat gradient buffer inside FlatAdamW.step' if args.optimizer == 'flat' else 'GradSync (flat-buffer RCCL all-reduce)')),
                        'peak_hbm_gb': round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1), 'active_ratio': round(active_ratio, 4), 'active_ratio_per_timed_step': [round(float(v) / (b * n_f * args.instances * args.size * args.size), 3) for v in stats['active_hist']] if not args.no_roofline else None, 'active_pixels_per_step_per_gpu': int(active_px), 'loss_total': round(loss_val, 4)},
             'roofline': roofline, 'cpu_baseline': cpu_baseline,
@@ -361,6 +383,56 @@ def main():
         except Exception:
             pass
         sys.stdout.write(json.dumps(line) + '\n')
+        sys.stdout.flush()
+
+
+def gather_device_ids(local_rank, world):
+    """device index of every rank (rank 0 prints them: N ranks must sit on N different devices for a measurement)"""
+    import torch.distributed as dist
+    if not dist.is_initialized() or world == 1:
+        return [local_rank]
+    out = [None] * world
+    dist.all_gather_object(out, int(torch.cuda.current_device()))
+    return out
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-exec this command line under torch.distributed.run, one rank per GPU of this node
+    (the reference's launcher does the same job: tools/main.py:41 under torchrun). 127.0.0.1 rendezvous on a free port."""
+    import socket
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')           # dmabuf IPC: what RCCL needs on these hosts
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execvpe(sys.executable, cmd, env)
+
+
+def dry_run(args, world, rank):
+    """Rank plumbing only (tests/test_host_cpu.py): rendezvous over the configured backend, count the ranks with an all-reduce, rank 0 prints a
+    line of the same shape as the real one with `dry_run: true`. Never a measurement."""
+    import torch.distributed as dist
+    from maggie_amd import parallel
+    backend = os.environ.get('MAGGIE_DIST_BACKEND', 'nccl')
+    if world > 1:
+        dist.init_process_group(backend)
+    seen = torch.ones(1, dtype=torch.float64)
+    if world > 1:
+        if backend == 'nccl':
+            seen = seen.cuda(int(os.environ.get('LOCAL_RANK', '0')))
+        dist.all_reduce(seen)
+        dist.barrier()
+    t = parallel.max_over_ranks(0.001 * (rank + 1))
+    if world > 1:
+        dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.write(json.dumps({'metric': 'dry run (rank plumbing only)', 'dry_run': True, 'value': None, 'n_gpus': world, 'gpus_arg': args.gpus,
+                                     'ranks_seen': int(seen.item()), 'backend': backend if world > 1 else None, 'steps': args.steps, 'warmup': args.warmup,
+                                     'max_over_ranks_s': t}) + '\n')
         sys.stdout.flush()
 
 

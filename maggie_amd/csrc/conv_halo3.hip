@@ -1,0 +1,551 @@
+// Spatial halo-tile convolution, round-6 form ("halo3"): the 3x3 / stride 1 / pad 1 layers with Cin % 32 == 0 in the 16-bit storage types --
+// the encoder's BasicBlocks, the shortcut branches and the decoder convs, forward (MG_MODE_CONV) and data gradient (MG_MODE_TCONV: the same
+// convolution with mirrored taps over the transposed weights): maggie/network/encoder/resnet.py:23-39,167-175, decoder/resnet.py:20-45.
+//
+// What the s_memtime timeline of the round-2 halo kernel showed (tools/halo_timeline.py, C128 64x64, batch 4: 13.3 k cycles per tile of
+// which 2.3 k are MFMA issue): (1) every wave issued its LDS-DMA instructions of the next stage as ONE burst behind the stage barrier --
+// 9 x 1 KiB per wave, 72 KiB per CU against a 64 B / clk vector-memory path: ~1100 cycles in which the wave sits in the issue queue and
+// its MFMAs wait; (2) with a two-slab ring the next stage had one compute phase (~950 cycles) to land and did not (+400 cycles of
+// vmcnt wait per stage); (3) the epilogue took the accumulators through an fp32 LDS tile, two barriers and a second pass (2.8 k cycles);
+// (4) two 128 x 32 tiles per CU staged the same halo twice. This form:
+//   * operands swapped in the MFMA (A := weight fragment, B := pixel fragment), so a lane's accumulator registers are 4 x FN CONSECUTIVE
+//     output channels of ONE pixel (the weight rows are permuted on their way into LDS: row r of fragment j = channel r * FN + j). The
+//     epilogue -- scale / shift, residuals, activation, rounding, 16-byte stores, BatchNorm statistics by DPP row sums -- runs from the
+//     accumulator registers: no LDS tile, no barrier before the stores;
+//   * the LDS-DMA instructions of stage s + NS - 1 are spread between the MFMAs of stage s (one per walk step), never a burst;
+//   * ring depth NS up to 4 (160 KiB of LDS: one workgroup per CU owns it), tile 8 x 16 pixels x 64 channels where that still gives
+//     >= one workgroup per CU (halo staged once for both channel halves);
+//   * row-sliding tap walk of round 5 kept (9 FN + 3 (FM + 2) fragment reads per stage).
+// LDS image of a stage: halo [TH + 2][24 px][64 B] (slot = chunk ^ 2 * ((px >> 2) & 1)) | weights [9 taps][BN rows][64 B]
+// (slot = chunk ^ 3 * ((row >> 3) & 1)), both conflict-free for ds_read_b128 (as in conv_igemm.hip).
+#include "common.h"
+#include "conv_xcd.h"
+#include "../../include/maggie_hip.h"
+#include <stdlib.h>
+#include <type_traits>
+#include <utility>
+
+#include <stdio.h>
+
+namespace {
+
+__device__ uint4 mg_h3_zero_page[4];            // zero-initialised device memory: what a lane outside the image / beyond Cout fetches
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
+
+template <int... Ks, typename F>
+__device__ __forceinline__ void static_for(std::integer_sequence<int, Ks...>, F&& f) { (f(std::integral_constant<int, Ks>{}), ...); }
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over the 16 lanes of a DPP row (fixed order: a function of the lane layout only)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_move<0xB1>(v);              // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);              // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);             // row_half_mirror
+    v += dpp_move<0x140>(v);             // row_mirror
+    return v;
+}
+
+#ifdef MG_H3_TIMING
+__device__ long long mg_h3_dbg[32 * 32];
+#define H3_STAMP(i) do { if (threadIdx.x == 0 && (work & 31) == 0 && work / 32 < 32) mg_h3_dbg[(work / 32) * 32 + (i)] = (i) >= 30 ? (long long)wall_clock64() : (long long)clock64(); } while (0)
+#else
+#define H3_STAMP(i)
+#endif
+
+template <int TH, int BN, int NS> struct H3Cfg {
+    static constexpr int TW = 16, BM = TH * TW, PW = 24, HH = TH + 2;
+    static constexpr int A_INSTR = (HH * PW + 15) / 16, A_PER_WAVE = (A_INSTR + 3) / 4, A_BYTES = A_PER_WAVE * 4 * 1024;
+    static constexpr int B_GRP = BN / 16, B_INSTR = 9 * B_GRP, B_PER_WAVE = (B_INSTR + 3) / 4, B_BYTES = B_PER_WAVE * 4 * 1024;
+    static constexpr int STAGE = A_BYTES + B_BYTES, L = A_PER_WAVE + B_PER_WAVE;
+    static constexpr int WAVES_N = BN >= 64 ? 2 : 1, WAVES_M = 4 / WAVES_N;
+    static constexpr int FM = TH / WAVES_M, FN = 2, WN = 16 * FN;
+    static constexpr int STAT_BYTES = WAVES_M * 2 * BN * 4;
+    static constexpr int LDS = NS * STAGE > STAT_BYTES ? NS * STAGE : STAT_BYTES;
+    static_assert(WAVES_N * WN == BN && FM >= 1 && TH % WAVES_M == 0, "halo3 tile configuration");
+    static_assert((NS - 1) * L <= 63 || NS == 1, "vmcnt is a 6-bit counter");
+};
+
+#ifndef MG_H3_AD
+#define MG_H3_AD 4
+#endif
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ void h3_load_affine(const mg_conv_params& p, int c0, float (&sc)[8], float (&sh)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
+    if (c0 < p.Cout) {                                       // (Cout % 8 == 0: all or nothing)
+        if (p.scale) { *(float4*)&sc[0] = *(const float4*)(p.scale + c0); *(float4*)&sc[4] = *(const float4*)(p.scale + c0 + 4); }
+        if (p.shift) { *(float4*)&sh[0] = *(const float4*)(p.shift + c0); *(float4*)&sh[4] = *(const float4*)(p.shift + c0 + 4); }
+    }
+}
+
+// One stage (a 32-channel slab, all nine taps) of a wave's FM x FN accumulator block from the LDS image at `sb`.
+// Row-sliding tap walk: for column shift c = 0, 1, 2 the halo rows r = 0 .. FM + 1 of this wave stream through a three-deep fragment ring and
+// meet the three weight fragments W(ky, c); W(0, c + 1) and W(1, c + 1) are loaded over their dead predecessors during the last two rows of
+// column c, W(2, c) during row 0. One continuous LDS stream with compile-time lgkmcnt counts (inline asm: hipcc otherwise drains vmcnt(0)
+// before every LDS read it can see next to LDS-DMA). A := weight fragment, B := pixel fragment.
+template <typename T, int FM, int FN, int BN, int PW, int MODE>
+__device__ __forceinline__ void h3_compute_stage(const unsigned sb, const unsigned (&a_lane)[3], const unsigned b_lane, f32x4 (&acc)[FM][FN]) {
+    static_assert(FN == 2, "two weight fragments per wave");
+    constexpr int AD = MG_H3_AD;                              // halo-row fragments in flight + 1 (LDS latency ~ 2-3 walk steps of 2-6 MFMAs)
+    u32x4 rfb[3][FN], rfa[AD];
+    constexpr int NR = FM + 2, NSTEP = 3 * NR;
+    const unsigned baddr = sb + b_lane;
+    auto read_b = [&](auto ky_c, auto c_c) {
+        constexpr int KY = decltype(ky_c)::value, C_ = decltype(c_c)::value;
+        constexpr int TAP = MODE == MG_MODE_TCONV ? (2 - KY) * 3 + (2 - C_) : KY * 3 + C_;
+        u32x4(&rb)[FN] = rfb[KY];
+        const unsigned ba = baddr;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[0]) : "v"(ba), "n"(TAP * BN * 64 + 0 * 1024) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[1]) : "v"(ba), "n"(TAP * BN * 64 + 1 * 1024) : "memory");
+    };
+    auto read_a = [&](auto k_c) {                             // halo row r under column shift c, stream position k = c * NR + r
+        constexpr int K_ = decltype(k_c)::value, C_ = K_ / NR, R_ = K_ % NR;
+        const unsigned aa = sb + a_lane[C_];
+        u32x4& ra = rfa[K_ % AD];
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ra) : "v"(aa), "n"(R_ * PW * 64) : "memory");
+    };
+    // weight fragments (FN reads each) issued at stream position k: W(0, c + 1) at r == FM, W(1, c + 1) at r == FM + 1, W(2, c) at r == 0 (c > 0)
+    auto nb_at = [](int k) { const int c = k / NR, r = k % NR; return k < 0 ? 0 : ((r == FM && c < 2) ? 1 : 0) + ((r == FM + 1 && c < 2) ? 1 : 0) + ((r == 0 && c > 0) ? 1 : 0); };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    read_b(I0{}, I0{});
+    read_b(I1{}, I0{});
+    read_b(I2{}, I0{});
+    static_for(std::make_integer_sequence<int, AD - 1>{}, [&](auto d_c) { if constexpr (decltype(d_c)::value < NSTEP) read_a(d_c); });
+    auto step = [&](auto k_c) {
+        constexpr int K_ = decltype(k_c)::value, C_ = K_ / NR, R_ = K_ % NR;
+        if constexpr (R_ == FM && C_ < 2) read_b(I0{}, std::integral_constant<int, C_ + 1>{});
+        if constexpr (R_ == FM + 1 && C_ < 2) read_b(I1{}, std::integral_constant<int, C_ + 1>{});
+        if constexpr (R_ == 0 && C_ > 0) read_b(I2{}, std::integral_constant<int, C_>{});
+        if constexpr (K_ + AD - 1 < NSTEP) read_a(std::integral_constant<int, K_ + AD - 1>{});
+        // A(K_) and the weight fragments this step meets (issued at position K_ - 2 or earlier) have landed once at most the reads issued behind
+        // them are outstanding: the weight loads of positions K_ - 1 and K_ and the rows K_ + 1 .. K_ + AD - 1 (in-order return)
+        constexpr int rows_after = (K_ + AD - 1 < NSTEP ? AD - 1 : NSTEP - 1 - K_);
+        constexpr int after = (nb_at(K_ - 1) + nb_at(K_)) * FN + rows_after;
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(after) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4& ra = rfa[K_ % AD];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int i = R_ - ky;                           // the output row that meets halo row R_ under tap row ky
+            if (i >= 0 && i < FM) {
+#pragma unroll
+                for (int jj = 0; jj < FN; ++jj) acc[i][jj] = mfma16<T>(rfb[ky][jj], ra, acc[i][jj]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    static_for(std::make_integer_sequence<int, NSTEP>{}, step);
+}
+
+// Epilogue from the accumulator registers: acc[i][j][e] = pixel (y0 + wm * FM + i, x0 + lr), channel c0 + e * FN + j. Consumer waves only; the
+// statistics tail has two workgroup barriers (the producers of the split form mirror them).
+template <typename T, int TH, int BN, int FM, int FN, int WAVES_N, bool RES>
+__device__ __forceinline__ void h3_epilogue(const mg_conv_params& p, f32x4 (&acc)[FM][FN], const float (&sc)[8], const float (&sh)[8], char* smem,
+                                            int t, int wave, int lane, int img, int y0, int x0, int n0, int mt, [[maybe_unused]] int work) {
+    using TR = ElemTraits<T>;
+    constexpr int WN = 16 * FN, WAVES_M = 4 / WAVES_N;
+    const int H = p.Hout, W = p.Wout;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int c0 = n0 + wn * WN + lg * 4 * FN;
+    const bool col_ok = c0 < p.Cout;
+    const float sl = p.act == MG_ACT_NONE ? 1.f : (p.act == MG_ACT_RELU ? 0.f : p.slope);
+    T* __restrict__ yb = (T*)p.y;
+    [[maybe_unused]] const T* __restrict__ r1b = (const T*)p.res;
+    [[maybe_unused]] const T* __restrict__ r2b = (const T*)p.res2;
+    const bool stats = p.stats != nullptr;
+    const int x = x0 + lr;
+    int mrow[FM];                                            // output row (M < 2^31), -1: outside the tensor
+    [[maybe_unused]] uint4 q1[FM], q2[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int y = y0 + wm * FM + i;
+        mrow[i] = (col_ok && y < H && x < W) ? (img * H + y) * W + x : -1;
+        if constexpr (RES) {                                 // both residual rows of every pixel requested before the first use
+            q1[i] = make_uint4(0, 0, 0, 0); q2[i] = make_uint4(0, 0, 0, 0);
+            if (mrow[i] >= 0) {
+                if (r1b) {
+                    int rrow = mrow[i];
+                    if (p.res_mode == 2) rrow = (img * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1);   // residual at half resolution (nearest x2)
+                    q1[i] = *(const uint4*)(r1b + (long)rrow * p.ldr + c0);
+                }
+                if (r2b) q2[i] = *(const uint4*)(r2b + (long)mrow[i] * p.ldr2 + c0);
+            }
+        }
+    }
+    H3_STAMP(16);
+    // All FM x 8 values go through the epilogue one STEP at a time (source order = issue order): with one wave per SIMD a dependent VALU
+    // chain costs ~8 cycles per instruction (measured: 660 cycles per pixel row when the five steps of a value sat back to back), independent
+    // neighbours issue every 4. act(v) = max(v, v * slope): none -> 1, ReLU -> 0, LeakyReLU -> slope; before or after the affine part.
+    float v[FM][8];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) v[i][e * FN + j] = acc[i][j][e];
+    if (p.pre_act && sl != 1.f) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[i][q] = fmaxf(v[i][q], v[i][q] * sl);
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[i][q] = v[i][q] * sc[q] + sh[q];
+    if constexpr (RES) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            float rv[8];
+            TR::unpack(q1[i], rv);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[i][q] += rv[q];
+        }
+    }
+    if (!p.pre_act && sl != 1.f) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[i][q] = fmaxf(v[i][q], v[i][q] * sl);
+    }
+    if constexpr (RES) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            float rv2[8];
+            TR::unpack(q2[i], rv2);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[i][q] += rv2[q];
+        }
+    }
+    uint4 packed[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) packed[i] = TR::pack(v[i]);      // rounded once; the statistics are those of the rounded values
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+        if (mrow[i] >= 0) *(uint4*)(yb + (long)mrow[i] * p.ldy + p.yoff + c0) = packed[i];
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    if (stats) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            TR::unpack(packed[i], v[i]);
+            const bool keep = mrow[i] >= 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const float u = keep ? v[i][q] : 0.f; s1[q] += u; s2[q] += u * u; }
+        }
+    }
+    H3_STAMP(15);
+    if (stats) {
+        // per channel: this lane's FM pixels -> the 16 pixel lanes of its DPP row -> the WAVES_M waves of the channel block (LDS, fixed order)
+        // -> ONE addition into the tile's row of the statistics buffer (deterministic mode: a row per spatial tile)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] = row16_sum(s1[e]); s2[e] = row16_sum(s2[e]); }
+        float* sStat = (float*)smem;                         // [WAVES_M][2][BN]
+        __syncthreads();                                     // every wave is out of the ring
+        if (lr == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sStat[wm * 2 * BN + wn * WN + lg * 8 + e] = s1[e];
+                sStat[wm * 2 * BN + BN + wn * WN + lg * 8 + e] = s2[e];
+            }
+        }
+        __syncthreads();
+        if (t < 2 * BN) {
+            const int c = t < BN ? t : t - BN;
+            if (n0 + c < p.Cout) {
+                float val = sStat[t];
+#pragma unroll
+                for (int w_ = 1; w_ < WAVES_M; ++w_) val += sStat[w_ * 2 * BN + t];
+                if (p.stat_mode == 1) {                                       // one row, sums only
+                    if (t < BN) atomicAdd(&p.stats[n0 + c], val);
+                } else {
+                    float* st = p.stats + (size_t)((unsigned)mt % (unsigned)(p.stat_rep > 0 ? p.stat_rep : MG_STAT_REPLICAS)) * 2 * p.Cout;
+                    atomicAdd(&st[(t < BN ? 0 : p.Cout) + n0 + c], val);
+                }
+            }
+        }
+    }
+    H3_STAMP(31);
+}
+
+
+// Roles (NS > 1): waves 0-3 are CONSUMERS (fragment reads + MFMA + epilogue), waves 4-7 are PRODUCERS (LDS-DMA only). Measured on the
+// single-role form (tools/h3_timeline.py): an LDS-DMA instruction holds the issuing wave ~90 cycles while four waves feed the one vector-memory
+// path (36 pieces of a 128 x 32 stage: ~840 cycles per wave), and a wave that waits in the vector-memory issue queue issues no MFMA -- with one
+// wave per SIMD a stage cost compute (1220) + issue (840) whatever the ring depth or the placement of the pieces. A producer wave shares its
+// SIMD with one consumer wave and blocks alone. One s_barrier per stage joins the roles: behind barrier s every producer has seen its pieces
+// of stage s land (counted vmcnt) and every consumer is done reading stage s - 1, whose buffer the producers then refill with stage s + NS - 1.
+// NS == 1 (Cin 32 / 64: one or two slabs) stays single-role, 256 threads: up to four workgroups per CU overlap each other instead.
+template <typename T, int TH, int BN, int NS, int MODE, bool RES>
+__global__ __launch_bounds__(NS > 1 ? 512 : 256) void conv_halo3_kernel(const mg_conv_params p) {
+    using TR = ElemTraits<T>;
+    using HC = H3Cfg<TH, BN, NS>;
+    constexpr bool SPLIT = NS > 1;
+    constexpr int EPS = 32, TW = HC::TW, PW = HC::PW, HH = HC::HH;
+    constexpr int WAVES_N = HC::WAVES_N, FM = HC::FM, FN = HC::FN, WN = HC::WN;
+    constexpr int STAGE = HC::STAGE, L = HC::L, A_BYTES = HC::A_BYTES, APW = HC::A_PER_WAVE, BPW = HC::B_PER_WAVE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int H = p.Hout, W = p.Wout;                        // stride 1, pad 1: input and output share the geometry
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int ntn = (p.Cout + BN - 1) / BN;
+    int work;
+    if (!xcd_order(p.N * tiles_y * tiles_x * ntn, work)) return;
+    H3_STAMP(30);
+    H3_STAMP(0);
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = (t >> 6) & 3;                           // index inside the role
+    const bool producer = SPLIT && (t >> 8) != 0;
+    const int mt = work / ntn;
+    const int n0 = (work - mt * ntn) * BN;
+    const int img = mt / (tiles_y * tiles_x);
+    const int trem = mt - img * tiles_y * tiles_x;
+    const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+    const int Ktot = 9 * p.Cin;
+    const int nstage = p.Cin / EPS;                          // one stage = one 32-channel slab, all nine taps
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    if (!SPLIT || producer) {
+        // ---- what this lane fetches: A = halo pixels (A_PER_WAVE instructions per wave and stage), B = weight rows ---------------
+        const char* __restrict__ xb = (const char*)p.x;
+        const char* __restrict__ wb = (const char*)p.w;
+        const char* zpage = (const char*)mg_h3_zero_page;
+        const long xpitch = (long)p.ldx * 2l;
+        const char* asrc[APW];
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            const int a = wave + 4 * i;
+            const int q = a * 16 + (lane >> 2);                  // pixel slot of the linear [HH][PW] halo image
+            const int hy = q / PW, hx = q - hy * PW;
+            const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+            const bool ok = a < HC::A_INSTR && hy < HH && hx < TW + 2 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const int ach = (lane & 3) ^ (((lane >> 4) & 1) * 2);  // chunk landing in this lane's slot: slot = chunk ^ 2*((q>>2)&1)
+            asrc[i] = ok ? xb + ((long)(img * H + iy) * W + ix) * xpitch + ach * 16 : nullptr;
+        }
+        const char* bsrc[BPW];
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) {
+            const int bi = wave + 4 * i;
+            const int tap = bi / HC::B_GRP, grp = bi - tap * HC::B_GRP;
+            const int rho = grp * 16 + (lane >> 2);              // LDS row of the tap's [BN][64 B] tile
+            // row permutation: fragment j of channel block wn holds, in its row r, output channel r * FN + j of the block -- a lane's
+            // accumulator registers (rows 4 lg .. 4 lg + 3 of FN fragments) are then 4 * FN consecutive channels
+            const int blk = rho / WN, within = rho - blk * WN;
+            const int co = n0 + blk * WN + (within & 15) * FN + (within >> 4);
+            const int bch = (lane & 3) ^ (((lane >> 5) & 1) * 3);
+            const bool ok = bi < HC::B_INSTR && co < p.Cout;
+            bsrc[i] = ok ? wb + ((long)co * Ktot + (long)tap * p.Cin) * 2l + bch * 16 : nullptr;
+        }
+        // all LDS-DMA instructions (1 KiB each: 64 lanes x 16 B) of stage s into ring buffer `buf`: halo pieces, then weight pieces
+        auto issue_stage = [&](int s, int buf) {
+            char* sbase = smem + buf * STAGE;
+            const long coff = (long)s * EPS * 2l;
+#pragma unroll
+            for (int i = 0; i < APW; ++i) {
+                const char* g = asrc[i] ? asrc[i] + coff : zpage;
+                __builtin_amdgcn_global_load_lds((gbl_void_ptr)g, (lds_void_ptr)(sbase + (wave + 4 * i) * 1024), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < BPW; ++i) {
+                const char* g = bsrc[i] ? bsrc[i] + coff : zpage;
+                // instruction bi = (tap, 16-row group): its 1 KiB lands at tap * BN * 64 + group * 1024 = bi * 1024 (B_GRP groups per tap)
+                __builtin_amdgcn_global_load_lds((gbl_void_ptr)g, (lds_void_ptr)(sbase + A_BYTES + (wave + 4 * i) * 1024), 16, 0, 0);
+            }
+        };
+        if constexpr (SPLIT) {
+            // Stage 0 alone goes out before the first barrier (the consumers' first MFMA waits for nothing else: issuing the whole ring first
+            // put 27 pieces per wave -- ~3 k cycles of issue -- in front of it); the rest of the ring follows behind barrier 0.
+            issue_stage(0, 0);
+            wait_vm<0>();
+            __builtin_amdgcn_s_barrier();                    // barrier 0
+#pragma unroll
+            for (int u = 1; u < NS; ++u)
+                if (u < nstage) issue_stage(u, u);
+            int fbuf = 0;                                    // ring buffer of stage s + NS - 1 = buffer of stage s - 1
+            for (int s = 1; s < nstage; ++s) {
+                const int infl = min(NS - 1, nstage - s) - 1;    // stages behind s already issued: s + 1 .. min(s + NS - 2, nstage - 1)
+                if (infl <= 0) wait_vm<0>();
+                else if (infl == 1) wait_vm<L>();
+                else wait_vm<(NS > 3 ? 2 * L : 0)>();
+                __builtin_amdgcn_s_barrier();                // barrier s: stage s is in LDS for everybody; stage s - 1 has been consumed
+                if (s + NS - 1 < nstage) issue_stage(s + NS - 1, fbuf);
+                fbuf = fbuf + 1 == NS ? 0 : fbuf + 1;
+            }
+            if (p.stats) { __syncthreads(); __syncthreads(); }   // the two barriers of the consumers' statistics tail
+            return;
+        } else {
+            issue_stage(0, 0);
+            // (single-role form continues below as its own consumer; later stages are issued between the barriers of the loop)
+            (void)issue_stage;
+        }
+        if constexpr (!SPLIT) {
+            // single-role K loop needs issue_stage in scope: run the whole consumer body here
+            H3_STAMP(1);
+            const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+            const int lr = lane & 15, lg = lane >> 4;
+            unsigned a_lane[3];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int px = lr + kx;
+                a_lane[kx] = (unsigned)((wm * FM * PW + px) * 64 + ((lg ^ (((px >> 2) & 1) * 2)) << 4));
+            }
+            const unsigned b_lane = (unsigned)(A_BYTES + (wn * WN + lr) * 64 + ((lg ^ (((lr >> 3) & 1) * 3)) << 4));
+            f32x4 acc[FM][FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            float sc[8], sh[8];
+            const int c0 = n0 + wn * WN + lg * 4 * FN;
+            h3_load_affine(p, c0, sc, sh);
+            for (int s = 0; s < nstage; ++s) {
+                if (s < 6) H3_STAMP(2 + 2 * s);
+                if (s > 0) {
+                    __builtin_amdgcn_s_barrier();
+                    issue_stage(s, 0);
+                }
+                wait_vm<0>();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (s < 6) H3_STAMP(3 + 2 * s);
+                h3_compute_stage<T, FM, FN, BN, PW, MODE>(lds_base, a_lane, b_lane, acc);
+            }
+            H3_STAMP(14);
+            h3_epilogue<T, TH, BN, FM, FN, WAVES_N, RES>(p, acc, sc, sh, smem, t, wave, lane, img, y0, x0, n0, mt, work);
+            return;
+        }
+    }
+    if constexpr (SPLIT) {
+        // ---------------- consumer waves ----------------
+        H3_STAMP(1);
+        const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+        const int lr = lane & 15, lg = lane >> 4;
+        // pixel fragment i of this wave = tile row ty = wm * FM + i, pixel tx = lr; tap (ky, kx) reads halo pixel (ty + ky, lr + kx)
+        unsigned a_lane[3];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int px = lr + kx;
+            a_lane[kx] = (unsigned)((wm * FM * PW + px) * 64 + ((lg ^ (((px >> 2) & 1) * 2)) << 4));
+        }
+        const unsigned b_lane = (unsigned)(A_BYTES + (wn * WN + lr) * 64 + ((lg ^ (((lr >> 3) & 1) * 3)) << 4));
+        f32x4 acc[FM][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // epilogue operands that do not depend on the accumulators: requested now, in flight under the whole K loop
+        float sc[8], sh[8];
+        const int c0 = n0 + wn * WN + lg * 4 * FN;               // this lane's 8 consecutive output channels
+        h3_load_affine(p, c0, sc, sh);
+        int buf = 0;
+        for (int s = 0; s < nstage; ++s) {
+            if (s < 6) H3_STAMP(2 + 2 * s);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (s < 6) H3_STAMP(3 + 2 * s);
+            h3_compute_stage<T, FM, FN, BN, PW, MODE>(lds_base + (unsigned)(buf * STAGE), a_lane, b_lane, acc);
+            buf = buf + 1 == NS ? 0 : buf + 1;
+        }
+        H3_STAMP(14);
+        h3_epilogue<T, TH, BN, FM, FN, WAVES_N, RES>(p, acc, sc, sh, smem, t, wave, lane, img, y0, x0, n0, mt, work);
+    }
+}
+
+int g_h3_enabled = -1;
+int g_h3_force[3] = {0, 0, 0};          // MG_H3_CFG=TH,BN,NS: one tile form for every eligible layer (experiments)
+
+template <typename T, int TH, int BN, int NS>
+int launch_h3(const mg_conv_params& p, hipStream_t st) {
+    using HC = H3Cfg<TH, BN, NS>;
+    constexpr size_t lds = HC::LDS;
+    const bool res = p.res || p.res2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_halo3_kernel<T, TH, BN, NS, MG_MODE_CONV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)conv_halo3_kernel<T, TH, BN, NS, MG_MODE_CONV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)conv_halo3_kernel<T, TH, BN, NS, MG_MODE_TCONV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)conv_halo3_kernel<T, TH, BN, NS, MG_MODE_TCONV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const long mtiles = (long)p.N * ((p.Hout + TH - 1) / TH) * ((p.Wout + 15) / 16);
+    const long tiles = mtiles * ((p.Cout + BN - 1) / BN);
+    if (mg_det_on && p.stats && p.stat_mode == 0 && (long)(p.stat_rep > 0 ? p.stat_rep : MG_STAT_REPLICAS) < mtiles) return -8;
+    dim3 grid(xcd_grid(tiles));
+    if (p.mode == MG_MODE_CONV) {
+        if (res) hipLaunchKernelGGL((conv_halo3_kernel<T, TH, BN, NS, MG_MODE_CONV, true>), grid, dim3(NS > 1 ? 512 : 256), lds, st, p);
+        else hipLaunchKernelGGL((conv_halo3_kernel<T, TH, BN, NS, MG_MODE_CONV, false>), grid, dim3(NS > 1 ? 512 : 256), lds, st, p);
+    } else {
+        if (res) hipLaunchKernelGGL((conv_halo3_kernel<T, TH, BN, NS, MG_MODE_TCONV, true>), grid, dim3(NS > 1 ? 512 : 256), lds, st, p);
+        else hipLaunchKernelGGL((conv_halo3_kernel<T, TH, BN, NS, MG_MODE_TCONV, false>), grid, dim3(NS > 1 ? 512 : 256), lds, st, p);
+    }
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T>
+int dispatch_h3(const mg_conv_params& p, hipStream_t st) {
+    const int nstage = p.Cin / 32;
+    const long sp8 = (long)p.N * ((p.Hout + 7) / 8) * ((p.Wout + 15) / 16);
+    int th = 8, bn = 64, ns = 3;
+    if (g_h3_force[0]) { th = g_h3_force[0]; bn = g_h3_force[1]; ns = g_h3_force[2]; }
+    else {
+        // 64-channel tiles (halo staged once for both halves) where they still give about one workgroup per CU
+        bn = (p.Cout > 32 && sp8 * ((p.Cout + 63) / 64) >= 200) ? 64 : 32;
+        th = p.Hout >= 8 ? 8 : 4;
+        ns = nstage >= 3 ? (bn == 64 ? 3 : 4) : nstage;
+    }
+#define H3_CASE(TH_, BN_, NS_) if (th == TH_ && bn == BN_ && ns == NS_) return launch_h3<T, TH_, BN_, NS_>(p, st);
+    H3_CASE(8, 64, 3) H3_CASE(8, 64, 2) H3_CASE(8, 64, 1)
+    H3_CASE(8, 32, 4) H3_CASE(8, 32, 2) H3_CASE(8, 32, 1)
+    H3_CASE(4, 32, 4) H3_CASE(4, 64, 3)
+#undef H3_CASE
+    return 1;
+}
+
+void h3_init() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    const char* e = getenv("MG_HALO3");
+    if (g_h3_enabled < 0) g_h3_enabled = e ? atoi(e) : 1;
+    if (const char* f = getenv("MG_H3_CFG")) sscanf(f, "%d,%d,%d", &g_h3_force[0], &g_h3_force[1], &g_h3_force[2]);
+}
+
+bool h3_eligible(const mg_conv_params& p) {
+    h3_init();
+    if (!g_h3_enabled || !MG_IS16(p.dtype) || p.m_dev || (p.mode != MG_MODE_CONV && p.mode != MG_MODE_TCONV)) return false;
+    if (p.R != 3 || p.S != 3 || p.stride != 1 || p.dil != 1 || p.pad != 1 || p.Cin % 32 != 0 || p.Cout % 8 != 0 || p.Cout < 16) return false;
+    if (p.Hin != p.Hout || p.Win != p.Wout || p.Wout < 16 || p.Hout < 4) return false;
+    if (p.bnb_x || p.xf_scale) return false;
+    if (p.ldx % 8 || p.ldy % 8 || p.yoff % 8 || (p.res && p.ldr % 8) || (p.res2 && p.ldr2 % 8)) return false;
+    return true;
+}
+
+}  // namespace
+
+// 0: launched; 1: not a layer of this form (the caller goes on to the older kernel forms); < 0: error
+extern "C" __attribute__((visibility("hidden"))) int mg_conv_halo3(const mg_conv_params* pp, void* stream) {
+    const mg_conv_params& p = *pp;
+    if (!h3_eligible(p)) return 1;
+    if (p.dtype == MG_BF16) return dispatch_h3<bf16raw>(p, (hipStream_t)stream);
+#ifndef MG_H3_BF16_ONLY
+    if (p.dtype == MG_F16) return dispatch_h3<f16raw>(p, (hipStream_t)stream);
+#endif
+    return 1;
+}
+extern "C" int mg_set_halo3(int on) { h3_init(); const int old = g_h3_enabled; g_h3_enabled = on; return old; }
+extern "C" int mg_set_halo3_cfg(int th, int bn, int ns) { g_h3_force[0] = th; g_h3_force[1] = bn; g_h3_force[2] = ns; return 0; }
+#ifdef MG_H3_TIMING
+extern "C" int mg_h3_debug_read(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(mg_h3_dbg), sizeof(mg_h3_dbg)); }
+#endif

@@ -1817,11 +1817,14 @@ extern "C" int mg_conv_fprop_ws(const mg_conv_params* pp, float* workspace, long
     return -6;
 }
 
+extern "C" int mg_conv_halo3(const mg_conv_params* pp, void* stream);        // conv_halo3.hip: 1 = not a layer of that form
+
 extern "C" int mg_conv_fprop(const mg_conv_params* pp, void* stream) {
     if (!pp) return -1;
     const mg_conv_params& p = *pp;
     if (p.M <= 0) return 0;
     { int rc = conv_fprop_check(p); if (rc) return rc; }
+    { int rc = mg_conv_halo3(pp, stream); if (rc != 1) return rc; }
     if (p.dtype == MG_BF16) return mg_conv_fprop_bf16(pp, stream);
     if (p.dtype == MG_F16) return mg_conv_fprop_f16(pp, stream);
     if (p.dtype == MG_F32) return mg_conv_fprop_f32(pp, stream);

@@ -659,3 +659,29 @@ def test_world_size_2_ranks_that_disagree_on_the_guidance_source_look_up_the_sam
     for p in procs:
         out, _ = p.communicate(timeout=180)
         assert p.returncode == 0, out.decode()
+
+
+def test_bench_gpus_flag_spawns_one_rank_per_gpu():
+    """`python bench.py --gpus N` is the driver contract (bench.py:2): without a launcher it must BECOME N ranks (re-exec under
+    torch.distributed.run, tools/main.py:41's job in the reference), rank 0 prints ONE line with n_gpus = N; a launcher that started a different
+    number of ranks is an error, never a line about fewer GPUs. Argument plumbing only (gloo, --dry-run: no model, no measurement)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MAGGIE_DIST_BACKEND='gloo', MAGGIE_ONE_GPU='1')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--dry-run'],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    lines = [l for l in res.stdout.decode().splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, res.stdout.decode()[-2000:]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['ranks_seen'] == 2 and line['gpus_arg'] == 2 and line['steps'] == 1 and line['warmup'] == 0
+    assert line['max_over_ranks_s'] == pytest.approx(0.002)         # the max over BOTH ranks' values reached rank 0
+    # N = 1 stays one process, no rendezvous
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--dry-run'], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+    line = json.loads([l for l in res.stdout.decode().splitlines() if l.startswith('{"metric"')][0])
+    assert line['n_gpus'] == 1 and line['backend'] is None
+    # a launcher that started fewer ranks than --gpus says: refused
+    res = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--dry-run'], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         env=dict(env, WORLD_SIZE='1', RANK='0'), timeout=300)
+    assert res.returncode != 0 and b'--gpus 2 but WORLD_SIZE=1' in res.stderr

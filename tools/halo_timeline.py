@@ -4,7 +4,7 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from maggie_amd import hip
-hip.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_dbg', 'libmaggie_dbg.so')
+hip.LIB_PATH = os.environ.get('MAGGIE_LIB_PATH') or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'maggie_amd', '_variants', 'lib_dbg.so')
 from maggie_amd import kernels as K
 N, Cin, Cout, HW = map(int, sys.argv[1:5])
 wgrad = len(sys.argv) > 5 and sys.argv[5] == 'wgrad' 
