@@ -71,8 +71,11 @@ template <int TH, int BN, int NS> struct H3Cfg {
     static_assert((NS - 1) * L <= 63 || NS == 1, "vmcnt is a 6-bit counter");
 };
 
+#ifndef MG_H3_EXP
+#define MG_H3_EXP 0      /* timing experiments only (results wrong): 1 = producers stop after the first ring fill, 2 = consumers only pass the barriers */
+#endif
 #ifndef MG_H3_AD
-#define MG_H3_AD 4
+#define MG_H3_AD 6
 #endif
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -87,21 +90,49 @@ __device__ __forceinline__ void h3_load_affine(const mg_conv_params& p, int c0, 
 }
 
 // One stage (a 32-channel slab, all nine taps) of a wave's FM x FN accumulator block from the LDS image at `sb`.
-// Row-sliding tap walk: for column shift c = 0, 1, 2 the halo rows r = 0 .. FM + 1 of this wave stream through a three-deep fragment ring and
+// Row-sliding tap walk: for column shift c = 0, 1, 2 the halo rows r = 0 .. FM + 1 of this wave stream through an AD-deep fragment ring and
 // meet the three weight fragments W(ky, c); W(0, c + 1) and W(1, c + 1) are loaded over their dead predecessors during the last two rows of
 // column c, W(2, c) during row 0. One continuous LDS stream with compile-time lgkmcnt counts (inline asm: hipcc otherwise drains vmcnt(0)
 // before every LDS read it can see next to LDS-DMA). A := weight fragment, B := pixel fragment.
-template <typename T, int FM, int FN, int BN, int PW, int MODE>
-__device__ __forceinline__ void h3_compute_stage(const unsigned sb, const unsigned (&a_lane)[3], const unsigned b_lane, f32x4 (&acc)[FM][FN]) {
-    static_assert(FN == 2, "two weight fragments per wave");
-    constexpr int AD = MG_H3_AD;                              // halo-row fragments in flight + 1 (LDS latency ~ 2-3 walk steps of 2-6 MFMAs)
-    u32x4 rfb[3][FN], rfa[AD];
+// Across stages: the fragment registers exist twice (PAR). Once the last LDS read of stage s has been issued and has landed (walk position
+// KT = NSTEP - AD + 1) the wave is DONE with the stage's buffer although ~20 of its MFMAs are still to come: `tail()` runs there -- the caller
+// arrives at the barrier that hands the buffer back and publishes stage s + 1, and issues stage s + 1's first nine fragment reads into the
+// other register set -- so the barrier and one LDS round trip (together ~400 of a 1000-cycle stage, tools/h3_timeline.py) sit under MFMAs.
+template <int FN, int AD> struct H3Frags { u32x4 b[2][3][FN]; u32x4 a[2][AD]; };
+
+template <int FM, int FN, int BN, int PW, int MODE, int AD, int PAR>
+__device__ __forceinline__ void h3_first_reads(const unsigned sb, const unsigned (&a_lane)[3], const unsigned b_lane, H3Frags<FN, AD>& fr) {
     constexpr int NR = FM + 2, NSTEP = 3 * NR;
+    const unsigned ba = sb + b_lane;
+    static_for(std::make_integer_sequence<int, 3>{}, [&](auto ky_c) {
+        constexpr int KY = decltype(ky_c)::value;
+        constexpr int TAP = MODE == MG_MODE_TCONV ? (2 - KY) * 3 + 2 : KY * 3;
+        u32x4(&rb)[FN] = fr.b[PAR][KY];
+        const unsigned ba_ = ba;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[0]) : "v"(ba_), "n"(TAP * BN * 64 + 0 * 1024) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[1]) : "v"(ba_), "n"(TAP * BN * 64 + 1 * 1024) : "memory");
+    });
+    const unsigned aa = sb + a_lane[0];
+    static_for(std::make_integer_sequence<int, (AD - 1 < NSTEP ? AD - 1 : NSTEP)>{}, [&](auto d_c) {
+        constexpr int R_ = decltype(d_c)::value;               // AD - 1 <= NR: all in column 0
+        u32x4& ra = fr.a[PAR][R_ % AD];
+        const unsigned aa_ = aa;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ra) : "v"(aa_), "n"(R_ * PW * 64) : "memory");
+    });
+}
+
+template <typename T, int FM, int FN, int BN, int PW, int MODE, int AD, int PAR, typename Tail>
+__device__ __forceinline__ void h3_walk(const unsigned sb, const unsigned (&a_lane)[3], const unsigned b_lane, f32x4 (&acc)[FM][FN],
+                                        H3Frags<FN, AD>& fr, Tail&& tail) {
+    static_assert(FN == 2, "two weight fragments per wave");
+    constexpr int NR = FM + 2, NSTEP = 3 * NR;
+    static_assert(AD - 1 <= NR && AD >= 3, "the first reads of a stage stay inside column 0");
+    constexpr int KT = NSTEP - AD + 1;                       // first walk position behind the stage's last LDS read
     const unsigned baddr = sb + b_lane;
     auto read_b = [&](auto ky_c, auto c_c) {
         constexpr int KY = decltype(ky_c)::value, C_ = decltype(c_c)::value;
         constexpr int TAP = MODE == MG_MODE_TCONV ? (2 - KY) * 3 + (2 - C_) : KY * 3 + C_;
-        u32x4(&rb)[FN] = rfb[KY];
+        u32x4(&rb)[FN] = fr.b[PAR][KY];
         const unsigned ba = baddr;
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[0]) : "v"(ba), "n"(TAP * BN * 64 + 0 * 1024) : "memory");
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[1]) : "v"(ba), "n"(TAP * BN * 64 + 1 * 1024) : "memory");
@@ -109,40 +140,46 @@ __device__ __forceinline__ void h3_compute_stage(const unsigned sb, const unsign
     auto read_a = [&](auto k_c) {                             // halo row r under column shift c, stream position k = c * NR + r
         constexpr int K_ = decltype(k_c)::value, C_ = K_ / NR, R_ = K_ % NR;
         const unsigned aa = sb + a_lane[C_];
-        u32x4& ra = rfa[K_ % AD];
+        u32x4& ra = fr.a[PAR][K_ % AD];
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ra) : "v"(aa), "n"(R_ * PW * 64) : "memory");
     };
     // weight fragments (FN reads each) issued at stream position k: W(0, c + 1) at r == FM, W(1, c + 1) at r == FM + 1, W(2, c) at r == 0 (c > 0)
     auto nb_at = [](int k) { const int c = k / NR, r = k % NR; return k < 0 ? 0 : ((r == FM && c < 2) ? 1 : 0) + ((r == FM + 1 && c < 2) ? 1 : 0) + ((r == 0 && c > 0) ? 1 : 0); };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-    read_b(I0{}, I0{});
-    read_b(I1{}, I0{});
-    read_b(I2{}, I0{});
-    static_for(std::make_integer_sequence<int, AD - 1>{}, [&](auto d_c) { if constexpr (decltype(d_c)::value < NSTEP) read_a(d_c); });
     auto step = [&](auto k_c) {
         constexpr int K_ = decltype(k_c)::value, C_ = K_ / NR, R_ = K_ % NR;
         if constexpr (R_ == FM && C_ < 2) read_b(I0{}, std::integral_constant<int, C_ + 1>{});
         if constexpr (R_ == FM + 1 && C_ < 2) read_b(I1{}, std::integral_constant<int, C_ + 1>{});
         if constexpr (R_ == 0 && C_ > 0) read_b(I2{}, std::integral_constant<int, C_>{});
         if constexpr (K_ + AD - 1 < NSTEP) read_a(std::integral_constant<int, K_ + AD - 1>{});
-        // A(K_) and the weight fragments this step meets (issued at position K_ - 2 or earlier) have landed once at most the reads issued behind
-        // them are outstanding: the weight loads of positions K_ - 1 and K_ and the rows K_ + 1 .. K_ + AD - 1 (in-order return)
-        constexpr int rows_after = (K_ + AD - 1 < NSTEP ? AD - 1 : NSTEP - 1 - K_);
-        constexpr int after = (nb_at(K_ - 1) + nb_at(K_)) * FN + rows_after;
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(after) : "memory");
+        if constexpr (K_ < KT) {
+            // A(K_) and the weight fragments this step meets (issued at position K_ - 2 or earlier) have landed once at most the reads issued
+            // behind them are outstanding: the weight loads of positions K_ - 1 and K_ and the rows K_ + 1 .. K_ + AD - 1 (in-order return)
+            constexpr int rows_after = (K_ + AD - 1 < NSTEP ? AD - 1 : NSTEP - 1 - K_);
+            constexpr int after = (nb_at(K_ - 1) + nb_at(K_)) * FN + rows_after;
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(after) : "memory");
+        } else if constexpr (K_ == KT) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every read of the stage has landed: the buffer is not needed any more
+            tail();
+        }                                                    // K_ > KT: operands in registers since KT
         __builtin_amdgcn_sched_barrier(0);
-        u32x4& ra = rfa[K_ % AD];
+        u32x4& ra = fr.a[PAR][K_ % AD];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int i = R_ - ky;                           // the output row that meets halo row R_ under tap row ky
             if (i >= 0 && i < FM) {
 #pragma unroll
-                for (int jj = 0; jj < FN; ++jj) acc[i][jj] = mfma16<T>(rfb[ky][jj], ra, acc[i][jj]);
+                for (int jj = 0; jj < FN; ++jj) acc[i][jj] = mfma16<T>(fr.b[PAR][ky][jj], ra, acc[i][jj]);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
     };
+#if MG_H3_EXP == 2
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    tail();
+#else
     static_for(std::make_integer_sequence<int, NSTEP>{}, step);
+#endif
 }
 
 // Epilogue from the accumulator registers: acc[i][j][e] = pixel (y0 + wm * FM + i, x0 + lr), channel c0 + e * FN + j. Consumer waves only; the
@@ -286,7 +323,13 @@ __device__ __forceinline__ void h3_epilogue(const mg_conv_params& p, f32x4 (&acc
 // SIMD with one consumer wave and blocks alone. One s_barrier per stage joins the roles: behind barrier s every producer has seen its pieces
 // of stage s land (counted vmcnt) and every consumer is done reading stage s - 1, whose buffer the producers then refill with stage s + NS - 1.
 // NS == 1 (Cin 32 / 64: one or two slabs) stays single-role, 256 threads: up to four workgroups per CU overlap each other instead.
-template <typename T, int TH, int BN, int NS, int MODE, bool RES>
+// XF (mg_conv_params.xf_*, forward only): `x` is the RAW output of the producing convolution; the BatchNorm + activation between the two layers is
+// applied to the staged halo image IN LDS, once per pixel: behind the counted wait that says "this lane's LDS-DMA pieces of stage s have landed"
+// every lane rewrites the 16-byte chunks its own loads deposited -- act(x * scale + shift), rounded to T, the bits mg_affine_act would have
+// stored -- and skips the chunks it pointed at the zero page (padding stays 0); the stage's barrier publishes the result. In the split form this
+// is PRODUCER work (they idle between issue bursts). Constants: stage 0's in registers (loaded before the first piece), the rest from an LDS
+// table behind the ring ([2 * Cin] floats, written before barrier 0); the single-role forms (Cin 32 / 64) keep both slabs' in registers.
+template <typename T, int TH, int BN, int NS, int MODE, bool RES, bool XF = false>
 __global__ __launch_bounds__(NS > 1 ? 512 : 256) void conv_halo3_kernel(const mg_conv_params p) {
     using TR = ElemTraits<T>;
     using HC = H3Cfg<TH, BN, NS>;
@@ -294,6 +337,7 @@ __global__ __launch_bounds__(NS > 1 ? 512 : 256) void conv_halo3_kernel(const mg
     constexpr int EPS = 32, TW = HC::TW, PW = HC::PW, HH = HC::HH;
     constexpr int WAVES_N = HC::WAVES_N, FM = HC::FM, FN = HC::FN, WN = HC::WN;
     constexpr int STAGE = HC::STAGE, L = HC::L, A_BYTES = HC::A_BYTES, APW = HC::A_PER_WAVE, BPW = HC::B_PER_WAVE;
+    constexpr int AD = (MG_H3_AD - 1 <= FM + 2) ? MG_H3_AD : FM + 3;      // fragment-ring depth of the halo rows (first reads stay in column 0)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int H = p.Hout, W = p.Wout;                        // stride 1, pad 1: input and output share the geometry
@@ -347,6 +391,56 @@ __global__ __launch_bounds__(NS > 1 ? 512 : 256) void conv_halo3_kernel(const mg
             const bool ok = bi < HC::B_INSTR && co < p.Cout;
             bsrc[i] = ok ? wb + ((long)co * Ktot + (long)tap * p.Cin) * 2l + bch * 16 : nullptr;
         }
+        // ---- operand transform state (XF) ----
+        [[maybe_unused]] const int xf_ach = (lane & 3) ^ (((lane >> 4) & 1) * 2);     // the 8-channel group of a slab this lane's halo chunks hold
+        [[maybe_unused]] const float xf_sl = xf_slope_of(p.xf_act, p.xf_slope);
+        [[maybe_unused]] const unsigned xf_tab = lds_base + (unsigned)(NS * STAGE);   // [Cin] scale | [Cin] shift, fp32 (split form)
+        [[maybe_unused]] float xr_sc[2][8], xr_sh[2][8];
+        [[maybe_unused]] u32x4 xf_reg = (u32x4){0u, 0u, 0u, 0u};
+        if constexpr (XF) {
+#pragma unroll
+            for (int q = 0; q < (SPLIT ? 1 : 2); ++q) {
+                const int c0 = (q < nstage ? q : 0) * EPS + xf_ach * 8;
+                *(float4*)&xr_sc[q][0] = *(const float4*)(p.xf_scale + c0); *(float4*)&xr_sc[q][4] = *(const float4*)(p.xf_scale + c0 + 4);
+                *(float4*)&xr_sh[q][0] = *(const float4*)(p.xf_shift + c0); *(float4*)&xr_sh[q][4] = *(const float4*)(p.xf_shift + c0 + 4);
+            }
+            if constexpr (SPLIT) {
+                const int tt = t - 256;                          // producer thread index: 4 floats of the table each
+                if (tt * 4 < 2 * p.Cin) xf_reg = *(const u32x4*)(tt * 4 < p.Cin ? p.xf_scale + tt * 4 : p.xf_shift + (tt * 4 - p.Cin));
+            }
+        }
+        // this lane's chunks of the stage in ring buffer `buf`, in place; `reg` >= 0: constants from the registers of slab `reg`, else from the table
+        [[maybe_unused]] auto xf_stage = [&](int s, int buf, int reg) {
+            const unsigned sb = lds_base + (unsigned)(buf * STAGE);
+            float scv[8], shv[8];
+            if (reg >= 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { scv[e] = reg == 0 ? xr_sc[0][e] : xr_sc[1][e]; shv[e] = reg == 0 ? xr_sh[0][e] : xr_sh[1][e]; }
+            } else {
+                const unsigned tsc = xf_tab + (unsigned)((s * EPS + xf_ach * 8) * 4), tsh = tsc + (unsigned)(p.Cin * 4);
+                f32x4 c0, c1, h0, h1;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(c0) : "v"(tsc) : "memory");
+                asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(c1) : "v"(tsc) : "memory");
+                asm volatile("ds_read_b128 %0, %1" : "=v"(h0) : "v"(tsh) : "memory");
+                asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(h1) : "v"(tsh) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { scv[e] = c0[e]; scv[4 + e] = c1[e]; shv[e] = h0[e]; shv[4 + e] = h1[e]; }
+            }
+            u32x4 q[APW];
+#pragma unroll
+            for (int i = 0; i < APW; ++i)
+                asm volatile("ds_read_b128 %0, %1" : "=v"(q[i]) : "v"(sb + (unsigned)((wave + 4 * i) * 1024 + lane * 16)) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < APW; ++i) {
+                if (asrc[i]) {                                   // an in-image pixel: transformed; zero-page chunks (padding, spare slots) stay 0
+                    const uint4 r = xf_apply8<T>(__builtin_bit_cast(uint4, q[i]), scv, shv, xf_sl);
+                    asm volatile("ds_write_b128 %0, %1" ::"v"(sb + (unsigned)((wave + 4 * i) * 1024 + lane * 16)), "v"(__builtin_bit_cast(u32x4, r)) : "memory");
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
         // all LDS-DMA instructions (1 KiB each: 64 lanes x 16 B) of stage s into ring buffer `buf`: halo pieces, then weight pieces
         auto issue_stage = [&](int s, int buf) {
             char* sbase = smem + buf * STAGE;
@@ -368,7 +462,12 @@ __global__ __launch_bounds__(NS > 1 ? 512 : 256) void conv_halo3_kernel(const mg
             // put 27 pieces per wave -- ~3 k cycles of issue -- in front of it); the rest of the ring follows behind barrier 0.
             issue_stage(0, 0);
             wait_vm<0>();
-            __builtin_amdgcn_s_barrier();                    // barrier 0
+            if constexpr (XF) {
+                const int tt = t - 256;
+                if (tt * 4 < 2 * p.Cin) asm volatile("ds_write_b128 %0, %1" ::"v"(xf_tab + (unsigned)tt * 16u), "v"(xf_reg) : "memory");
+                xf_stage(0, 0, 0);                           // (ends in lgkmcnt(0): the table words are written, too)
+            }
+            __builtin_amdgcn_s_barrier();                    // barrier 0 (publishes the table to the other producer waves as well)
 #pragma unroll
             for (int u = 1; u < NS; ++u)
                 if (u < nstage) issue_stage(u, u);
@@ -378,8 +477,11 @@ __global__ __launch_bounds__(NS > 1 ? 512 : 256) void conv_halo3_kernel(const mg
                 if (infl <= 0) wait_vm<0>();
                 else if (infl == 1) wait_vm<L>();
                 else wait_vm<(NS > 3 ? 2 * L : 0)>();
+                if constexpr (XF) xf_stage(s, fbuf + 1 == NS ? 0 : fbuf + 1, -1);   // stage s sits in the buffer behind stage s - 1's
                 __builtin_amdgcn_s_barrier();                // barrier s: stage s is in LDS for everybody; stage s - 1 has been consumed
+#if MG_H3_EXP != 1
                 if (s + NS - 1 < nstage) issue_stage(s + NS - 1, fbuf);
+#endif
                 fbuf = fbuf + 1 == NS ? 0 : fbuf + 1;
             }
             if (p.stats) { __syncthreads(); __syncthreads(); }   // the two barriers of the consumers' statistics tail
@@ -409,6 +511,7 @@ __global__ __launch_bounds__(NS > 1 ? 512 : 256) void conv_halo3_kernel(const mg
             float sc[8], sh[8];
             const int c0 = n0 + wn * WN + lg * 4 * FN;
             h3_load_affine(p, c0, sc, sh);
+            H3Frags<FN, AD> fr;
             for (int s = 0; s < nstage; ++s) {
                 if (s < 6) H3_STAMP(2 + 2 * s);
                 if (s > 0) {
@@ -416,10 +519,12 @@ __global__ __launch_bounds__(NS > 1 ? 512 : 256) void conv_halo3_kernel(const mg
                     issue_stage(s, 0);
                 }
                 wait_vm<0>();
+                if constexpr (XF) xf_stage(s, 0, s == 0 ? 0 : 1);
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 if (s < 6) H3_STAMP(3 + 2 * s);
-                h3_compute_stage<T, FM, FN, BN, PW, MODE>(lds_base, a_lane, b_lane, acc);
+                h3_first_reads<FM, FN, BN, PW, MODE, AD, 0>(lds_base, a_lane, b_lane, fr);
+                h3_walk<T, FM, FN, BN, PW, MODE, AD, 0>(lds_base, a_lane, b_lane, acc, fr, [] {});
             }
             H3_STAMP(14);
             h3_epilogue<T, TH, BN, FM, FN, WAVES_N, RES>(p, acc, sc, sh, smem, t, wave, lane, img, y0, x0, n0, mt, work);
@@ -448,14 +553,43 @@ __global__ __launch_bounds__(NS > 1 ? 512 : 256) void conv_halo3_kernel(const mg
         float sc[8], sh[8];
         const int c0 = n0 + wn * WN + lg * 4 * FN;               // this lane's 8 consecutive output channels
         h3_load_affine(p, c0, sc, sh);
+        H3Frags<FN, AD> fr;
+        H3_STAMP(2);
+        __builtin_amdgcn_s_barrier();                        // barrier 0: stage 0 is in LDS
+        asm volatile("" ::: "memory");
+        H3_STAMP(3);
+        h3_first_reads<FM, FN, BN, PW, MODE, AD, 0>(lds_base, a_lane, b_lane, fr);
         int buf = 0;
-        for (int s = 0; s < nstage; ++s) {
-            if (s < 6) H3_STAMP(2 + 2 * s);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (s < 6) H3_STAMP(3 + 2 * s);
-            h3_compute_stage<T, FM, FN, BN, PW, MODE>(lds_base + (unsigned)(buf * STAGE), a_lane, b_lane, acc);
-            buf = buf + 1 == NS ? 0 : buf + 1;
+        // two stages per trip: the fragment register sets alternate (PAR 0 | 1); barrier s + 1 and stage s + 1's first reads sit inside stage s's walk
+        for (int s = 0; s < nstage; s += 2) {
+            {
+                const unsigned sb = lds_base + (unsigned)(buf * STAGE);
+                buf = buf + 1 == NS ? 0 : buf + 1;
+                const unsigned sbn = lds_base + (unsigned)(buf * STAGE);
+                const bool nxt = s + 1 < nstage;
+                h3_walk<T, FM, FN, BN, PW, MODE, AD, 0>(sb, a_lane, b_lane, acc, fr, [&] {
+                    if (nxt) {
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                        h3_first_reads<FM, FN, BN, PW, MODE, AD, 1>(sbn, a_lane, b_lane, fr);
+                    }
+                });
+                if (s + 1 < 3) H3_STAMP(2 + 2 * (s + 1));
+            }
+            if (s + 1 < nstage) {
+                const unsigned sb = lds_base + (unsigned)(buf * STAGE);
+                buf = buf + 1 == NS ? 0 : buf + 1;
+                const unsigned sbn = lds_base + (unsigned)(buf * STAGE);
+                const bool nxt = s + 2 < nstage;
+                h3_walk<T, FM, FN, BN, PW, MODE, AD, 1>(sb, a_lane, b_lane, acc, fr, [&] {
+                    if (nxt) {
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                        h3_first_reads<FM, FN, BN, PW, MODE, AD, 0>(sbn, a_lane, b_lane, fr);
+                    }
+                });
+                if (s + 2 < 3) H3_STAMP(2 + 2 * (s + 2));
+            }
         }
         H3_STAMP(14);
         h3_epilogue<T, TH, BN, FM, FN, WAVES_N, RES>(p, acc, sc, sh, smem, t, wave, lane, img, y0, x0, n0, mt, work);
@@ -482,6 +616,20 @@ int launch_h3(const mg_conv_params& p, hipStream_t st) {
     const long tiles = mtiles * ((p.Cout + BN - 1) / BN);
     if (mg_det_on && p.stats && p.stat_mode == 0 && (long)(p.stat_rep > 0 ? p.stat_rep : MG_STAT_REPLICAS) < mtiles) return -8;
     dim3 grid(xcd_grid(tiles));
+    if (p.xf_scale) {                                        // BatchNorm + activation of the producing layer applied to the staged halo (forward only)
+        constexpr size_t lds_xf = lds + (NS > 1 ? 4096 : 0);     // + the [2 * Cin] fp32 table of the split form (Cin <= 512)
+        if (p.mode != MG_MODE_CONV || p.Cin > 512 || (NS == 1 && p.Cin > 64) || lds_xf > 160 * 1024) return MG_XF_UNSUPPORTED;
+        static bool xf_attr = false;
+        if (!xf_attr) {
+            (void)hipFuncSetAttribute((const void*)conv_halo3_kernel<T, TH, BN, NS, MG_MODE_CONV, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_xf);
+            (void)hipFuncSetAttribute((const void*)conv_halo3_kernel<T, TH, BN, NS, MG_MODE_CONV, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_xf);
+            xf_attr = true;
+        }
+        if (res) hipLaunchKernelGGL((conv_halo3_kernel<T, TH, BN, NS, MG_MODE_CONV, true, true>), grid, dim3(NS > 1 ? 512 : 256), lds_xf, st, p);
+        else hipLaunchKernelGGL((conv_halo3_kernel<T, TH, BN, NS, MG_MODE_CONV, false, true>), grid, dim3(NS > 1 ? 512 : 256), lds_xf, st, p);
+        MG_CHECK_LAUNCH();
+        return 0;
+    }
     if (p.mode == MG_MODE_CONV) {
         if (res) hipLaunchKernelGGL((conv_halo3_kernel<T, TH, BN, NS, MG_MODE_CONV, true>), grid, dim3(NS > 1 ? 512 : 256), lds, st, p);
         else hipLaunchKernelGGL((conv_halo3_kernel<T, TH, BN, NS, MG_MODE_CONV, false>), grid, dim3(NS > 1 ? 512 : 256), lds, st, p);
@@ -500,15 +648,26 @@ int dispatch_h3(const mg_conv_params& p, hipStream_t st) {
     int th = 8, bn = 64, ns = 3;
     if (g_h3_force[0]) { th = g_h3_force[0]; bn = g_h3_force[1]; ns = g_h3_force[2]; }
     else {
-        // 64-channel tiles (halo staged once for both halves) where they still give about one workgroup per CU
-        bn = (p.Cout > 32 && sp8 * ((p.Cout + 63) / 64) >= 200) ? 64 : 32;
-        th = p.Hout >= 8 ? 8 : 4;
-        ns = nstage >= 3 ? (bn == 64 ? 3 : 4) : nstage;
+        // Measured forms (tools/h3_check.py, batch 4 / 12 of the trunk's layers):
+        //   * one or two slabs (Cin 32 / 64), or >= ~1.3 tiles per CU: single-role workgroups, no ring -- three or four of them share a CU and
+        //     overlap each other's load / MFMA / epilogue phases;
+        //   * about one tile per CU: the producer / consumer form with a ring (64 channels wide where that still gives ~a tile per CU, the halo
+        //     is then staged once for both channel halves; 4 x 16 pixel tiles for the 16 x 16 maps).
+        const long t64 = sp8 * ((p.Cout + 63) / 64), t32 = sp8 * ((p.Cout + 31) / 32);
+        bn = p.Cout > 32 && (nstage <= 2 || t64 >= 200) ? 64 : 32;
+        th = 8;
+        if (nstage <= 2 || (bn == 64 && t64 >= 320)) ns = 1;
+        else if (bn == 64) ns = 3;
+        else { ns = 4; if (t32 < 200 || p.Hout < 8) th = 4; }
+        if (p.Hout < 8) th = 4;
+        if (th == 4 && !(bn == 32 && ns == 4)) { bn = 32; ns = 4; }
+        if (p.xf_scale && ns == 1 && p.Cin > 64) ns = bn == 64 ? 3 : 4;      // the single-role transform keeps its constants in registers (two slabs)
     }
 #define H3_CASE(TH_, BN_, NS_) if (th == TH_ && bn == BN_ && ns == NS_) return launch_h3<T, TH_, BN_, NS_>(p, st);
-    H3_CASE(8, 64, 3) H3_CASE(8, 64, 2) H3_CASE(8, 64, 1)
-    H3_CASE(8, 32, 4) H3_CASE(8, 32, 2) H3_CASE(8, 32, 1)
-    H3_CASE(4, 32, 4) H3_CASE(4, 64, 3)
+    H3_CASE(8, 64, 3) H3_CASE(8, 64, 1) H3_CASE(8, 32, 4) H3_CASE(8, 32, 1) H3_CASE(4, 32, 4)
+#ifdef MG_H3_EXTRA_FORMS
+    H3_CASE(8, 64, 2) H3_CASE(8, 32, 2) H3_CASE(4, 64, 3)
+#endif
 #undef H3_CASE
     return 1;
 }
@@ -527,7 +686,8 @@ bool h3_eligible(const mg_conv_params& p) {
     if (!g_h3_enabled || !MG_IS16(p.dtype) || p.m_dev || (p.mode != MG_MODE_CONV && p.mode != MG_MODE_TCONV)) return false;
     if (p.R != 3 || p.S != 3 || p.stride != 1 || p.dil != 1 || p.pad != 1 || p.Cin % 32 != 0 || p.Cout % 8 != 0 || p.Cout < 16) return false;
     if (p.Hin != p.Hout || p.Win != p.Wout || p.Wout < 16 || p.Hout < 4) return false;
-    if (p.bnb_x || p.xf_scale) return false;
+    if (p.bnb_x) return false;
+    if (p.xf_scale && (p.mode != MG_MODE_CONV || p.Cin > 512)) return false;
     if (p.ldx % 8 || p.ldy % 8 || p.yoff % 8 || (p.res && p.ldr % 8) || (p.res2 && p.ldr2 % 8)) return false;
     return true;
 }

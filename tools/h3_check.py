@@ -108,17 +108,40 @@ def check():
             bad += not ok
             print('%s N%d C%d->%d %dx%d mode %d variant %d: vs torch %.2e  vs old kernel %.2e  stats %.2e  slice intact %s' % (
                 'ok  ' if ok else 'FAIL', N, Cin, Cout, H, W, mode, vi, e_ref, e_old, e_st, pad_ok))
+    # operand transform (xf): the raw producer output + (scale, shift, act) must give the bits of the stored z = affine_act(y)
+    for (N, Cin, Cout, H, W) in [(2, 32, 64, 20, 24), (1, 64, 32, 9, 17), (2, 128, 64, 16, 16), (1, 96, 64, 16, 24), (1, 256, 128, 8, 16), (1, 512, 64, 8, 16), (4, 128, 128, 64, 64), (4, 64, 64, 128, 128)]:
+        for act in (0, 1, 2):
+            M = N * H * W
+            y = (torch.randn(M, Cin, device=dev) * 1.5 + 0.3).bfloat16()
+            sc = (torch.rand(Cin, device=dev) + 0.5) * torch.where(torch.rand(Cin, device=dev) < 0.5, -1.0, 1.0)
+            sh = torch.randn(Cin, device=dev) * 0.7
+            w = (torch.randn(Cout, 9, Cin, device=dev) / (9 * Cin) ** 0.5).bfloat16()
+            z = K.affine_act(y, sc, sh, act=act, slope=0.2)
+            geo = dict(mode=K.MODE_CONV, N=N, Hin=H, Win=W, R=3, S=3, stride=1, pad=1, dil=1)
+            rows = K.conv_stat_rows(M, N, H, W)
+            h3(1)
+            sa, sb = torch.zeros(rows, 2 * Cout, device=dev), torch.zeros(rows, 2 * Cout, device=dev)
+            o_ref = K.conv_fprop(z, w, stats=sa, **geo)
+            o_xf = K.conv_fprop(y, w, stats=sb, xf=(sc, sh, act, 0.2), **geo)
+            h3(0)
+            o_old = K.conv_fprop(y, w, xf=(sc, sh, act, 0.2), **geo)
+            ok = torch.equal(o_ref, o_xf) and torch.equal(sa, sb)
+            bad += not ok
+            print('%s xf N%d C%d->%d %dx%d act %d: %d of %d values differ from the stored form; vs old xf kernel %.2e' % (
+                'ok  ' if ok else 'FAIL', N, Cin, Cout, H, W, act, int((o_ref != o_xf).sum()), o_ref.numel(), (o_xf.float() - o_old.float()).abs().max().item()))
     print('FAILED: %d' % bad if bad else 'all cases ok')
     return bad
 
 
-SHAPES = [(4, 32, 32, 512, 0), (4, 32, 32, 512, 1), (4, 32, 32, 256, 0), (4, 32, 64, 128, 0), (4, 64, 64, 128, 0), (4, 64, 64, 128, 1), (4, 128, 128, 64, 0), (4, 128, 128, 64, 1),
+SHAPES_ALL = [(4, 32, 32, 512, 0), (4, 32, 32, 512, 1), (4, 32, 32, 256, 0), (4, 32, 64, 128, 0), (4, 64, 64, 128, 0), (4, 64, 64, 128, 1), (4, 128, 128, 64, 0), (4, 128, 128, 64, 1),
           (4, 256, 256, 32, 0), (4, 256, 256, 32, 1), (4, 512, 512, 16, 0), (4, 512, 256, 32, 0), (4, 256, 128, 64, 0), (12, 128, 128, 64, 0), (12, 256, 256, 32, 0), (12, 64, 64, 128, 0)]
 
 
 def timing(cfgs):
     tot = {}
-    for (N, Cin, Cout, HW, mode) in SHAPES:
+    sel = os.environ.get('H3_SHAPES')
+    shapes = [sh for sh in SHAPES_ALL if not sel or ('%d@%d' % (sh[1], sh[3])) in sel.split(',')]
+    for (N, Cin, Cout, HW, mode) in shapes:
         NSET = 4                                                 # operand sets in rotation: a launch does not find its own inputs hot in L2
         xs = [torch.randn(N * HW * HW, Cin, device=dev).bfloat16() for _ in range(NSET)]
         ws = [(torch.randn(Cout, 9, Cin, device=dev) / (9 * Cin) ** 0.5).bfloat16() for _ in range(NSET)]
