@@ -233,11 +233,16 @@ def main():
         pr.disable()
         sync()
         pstats.Stats(pr, stream=sys.stderr).sort_stats(os.environ['MAGGIE_CPROFILE']).print_stats(70)
+    # per-step device times of the timed region: one event per step boundary on the launch stream (no host sync inside the region)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i_ in range(args.steps):
         step()
+        marks[i_ + 1].record()
     sync()
     elapsed = parallel.max_over_ranks(time.perf_counter() - t0)
+    step_ms = [marks[i_].elapsed_time(marks[i_ + 1]) for i_ in range(args.steps)]
 
     if host_t and rank == 0:
         sys.stderr.write('host ms/step (forward+loss, backward, clip+AdamW): %s\n' % np.round(np.mean(host_t[-args.steps:], 0), 2).tolist())
@@ -306,11 +311,12 @@ def main():
         # HBM-side traffic of the dominant family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
         # corrected per MI355X_MICROARCH.md; tools/pmc_traffic.py) -- only for the configuration they were collected on
         traffic, traffic_src = None, None
-        for cand in ('r05_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic_final_eager.json'):
+        for cand in ('r06_pmc_traffic.json', 'r05_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic_final_eager.json'):
             pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', cand)
             if os.path.isfile(pmc_path) and not args.video and args.size == 512 and args.batch == 4 and use_bf16:
-                traffic = json.load(open(pmc_path)).get('igemm_fprop', {}).get('hbm_bytes_per_launch')
-                traffic_src = 'profiles/' + cand
+                pmc_doc = json.load(open(pmc_path))
+                traffic = pmc_doc.get('igemm_fprop', {}).get('hbm_bytes_per_launch')
+                traffic_src = 'profiles/' + cand + (', collected on commit %s' % pmc_doc['commit'] if pmc_doc.get('commit') else ', a committed file: not collected by this run')
                 break
         fp = {k: v for k, v in fam.items() if 'fprop' in k}
         fp_launches = sum(v[2] for v in fp.values()) // n_prof
@@ -350,7 +356,10 @@ def main():
         line = {
             'metric': 'instance-frames/sec (fwd+bwd+optimizer step, %dx%d, %s)' % (args.size, args.size, args.dtype),
             'value': round(value, 3), 'unit': 'instance-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'ms_per_step': round(ms_per_step, 3),
+            'ms_per_step_spread': {'min': round(min(step_ms), 3), 'median': round(float(np.median(step_ms)), 3), 'max': round(max(step_ms), 3),
+                                   'note': 'device time between per-step events of the timed region (rank 0)'},
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
             'per_gpu': round(value / world, 3),
             'config': {'workload': 'maggie_%s.yaml train step: %dx%d, %d instances (10 slots), batch %d frames/GPU x %d frame(s), iter=%d (%s), '
@@ -472,13 +481,14 @@ def trace_graph_replay(args, fam_alg):
         for s_, e_, nm in win:
             # dense fprop family = every igemm_fprop_* kernel that is not the persistent (sparse-head) form: the register-staged im2col loop,
             # the direct-to-LDS im2col ring, the spatial halo-tile kernel, split-K + its finishing kernel
-            fam = 'sparse' if ('igemm_fprop' in nm and 'persistent' in nm) else 'fprop' if ('igemm_fprop' in nm or 'splitk_finish' in nm) else \
+            # (conv_halo3_kernel: the round-6 producer / consumer halo-tile form of the same family, csrc/conv_halo3.hip)
+            fam = 'sparse' if ('igemm_fprop' in nm and 'persistent' in nm) else 'fprop' if ('igemm_fprop' in nm or 'splitk_finish' in nm or 'conv_halo3' in nm) else \
                 'wgrad' if ('igemm_wgrad' in nm or 'wgrad_reduce' in nm) else None
             if fam:
                 d = acc.setdefault(fam, [0, 0, 0])
                 d[0] += e_ - s_
                 d[1] += 1
-                d[2] += int('igemm_fprop' in nm or 'igemm_wgrad' in nm)
+                d[2] += int('igemm_fprop' in nm or 'igemm_wgrad' in nm or 'conv_halo3' in nm)
         busy = sum(e_ - s_ for s_, e_, _ in win)
         span = win[-1][1] - win[0][0]
         out = {'steps_in_window': k, 'traced_ms_per_step': ms, 'launches_per_step': round(len(win) / k, 1), 'gpu_busy_frac': round(busy / span, 4)}
@@ -548,7 +558,7 @@ def cpu_accuracy(acc_file):
 def cpu_baseline_subprocess(args):
     """Run the CPU oracle legs in a child process with a hard time limit so the default bench always finishes in minutes."""
     import subprocess
-    limit_s = 900 if args.cpu_baseline_full else 420
+    limit_s = 900 if args.cpu_baseline_full else 480
     cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', '--size', str(args.size), '--instances', str(args.instances),
            '--batch', str(args.batch), '--iter', str(args.iter), '--edge', str(args.edge), '--workload', args.workload,
            '--cpu-threads', str(args.cpu_threads)] + (['--video', '--frames', str(args.frames), '--clips', str(args.clips)] if args.video else []) + (['--cpu-baseline-full'] if args.cpu_baseline_full else []) + \
@@ -598,7 +608,7 @@ def run_cpu_baseline(kind, args):
     b = args.clips if kind == 'video' else args.batch
     size = args.size
     mcfg = copy.deepcopy(config.MODEL_VIDEO if kind == 'video' else config.MODEL_IMAGE)
-    n_warm, n_timed = (2, 9) if args.cpu_baseline_full else (1, 3)
+    n_warm, n_timed = (2, 9) if args.cpu_baseline_full else (2, 5)          # 2 warm-ups + >= 5 timed steps, medians
     res = {'unit': 'instance-frames/s', 'cores': settings[0], 'host_cores': cores, 'kind': 'port', 'per_thread_setting': {}}
     inst = b * n_f * args.instances
     if args.acc_file:
@@ -637,7 +647,7 @@ def run_cpu_baseline(kind, args):
       slow = False
       watchdog = None
       if si > 0 and not args.cpu_baseline_full:
-          n_timed = 2                                              # the second setting only has to show which one is faster
+          n_warm, n_timed = 1, 1                                   # the second setting only has to show which one is faster (one probe step)
           # ... and must not hold the bench line back: on a 256-core host one step of this model's many small ops under 256 torch threads takes
           # minutes. If its warm-up step is not done after `cap` seconds the setting is reported as unfinished and the worker ends here.
           import threading

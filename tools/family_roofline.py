@@ -25,7 +25,7 @@ print('%-52s %9s %9s %11s %9s %7s' % ('family', 'launches', 'ms/step', 'HBM MB/s
 for name, (n, ms) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
     if ms < 0.03:
         continue
-    mb = None if name.startswith('igemm_') else mb_of(name)
+    mb = None if name.startswith(('igemm_', 'conv_halo3')) else mb_of(name)
     if mb:
         gbs = mb / ms
         print('%-52s %9.1f %9.3f %11.1f %9.0f %6.1f%%' % (name[:52], n, ms, mb, gbs, 100.0 * gbs / PEAK))
@@ -34,8 +34,9 @@ for name, (n, ms) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
 
 # the two conv families as a whole (the PMC pass runs eagerly and keys all forms of a family by one name)
 for key, pat in (('igemm_fprop', 'igemm_fprop'), ('igemm_wgrad', 'igemm_wgrad')):
-    ms = sum(v[1] for k, v in fam.items() if k.startswith(pat)) + (fam.get('splitk_finish_kernel', (0, 0))[1] if key == 'igemm_fprop' else 0.0)
-    n = sum(v[0] for k, v in fam.items() if k.startswith(pat))
+    match = lambda k: k.startswith(pat) or (key == 'igemm_fprop' and k.startswith('conv_halo3'))
+    ms = sum(v[1] for k, v in fam.items() if match(k)) + (fam.get('splitk_finish_kernel', (0, 0))[1] if key == 'igemm_fprop' else 0.0)
+    n = sum(v[0] for k, v in fam.items() if match(k))
     v = pm.get(key)
     if isinstance(v, dict) and ms:
         mb = v['hbm_MB_per_step']

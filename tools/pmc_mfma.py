@@ -3,7 +3,7 @@ MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs)  (th
 import csv, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 def fam(name):
-    if 'igemm_fprop' in name: return 'igemm_fprop'
+    if 'igemm_fprop' in name or 'conv_halo3' in name: return 'igemm_fprop'
     if 'igemm_wgrad' in name: return 'igemm_wgrad'
     return None
 for r in csv.DictReader(open(sys.argv[1])):

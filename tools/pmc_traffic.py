@@ -7,7 +7,14 @@ import csv, json, sys, collections
 
 
 def family(name):
-    if 'igemm_fprop' in name: return 'igemm_fprop'
+    # the sparse head's launches (persistent row-count-from-device forms: every m_dev launch of the step; gather9 and the MODE = 2 per-tap weight
+    # gradients) are kept apart from the dense trunk's (the head's own HBM bytes could not be read)
+    if 'igemm_fprop' in name and 'persistent' in name: return 'igemm_fprop_sparse_head'
+    if 'igemm_wgrad_gather9' in name: return 'igemm_wgrad_sparse_head'
+    if 'igemm_wgrad_kernel' in name:
+        args = name.split('igemm_wgrad_kernel<')[1].split('>')[0].split(',')
+        if len(args) >= 4 and args[3].strip() == '2': return 'igemm_wgrad_sparse_head'
+    if 'igemm_fprop' in name or 'conv_halo3' in name: return 'igemm_fprop'
     if 'igemm_wgrad' in name: return 'igemm_wgrad'
     if 'wgrad_reduce' in name: return 'wgrad_reduce'
     if 'anonymous namespace' in name and 'at::' not in name:
@@ -37,6 +44,11 @@ for f in sorted(set(fetch) | set(write)):
               'write_bytes_per_launch': round(1024.0 * ws / max(wn, 1)),
               'hbm_bytes_per_launch': round(2.0 * 1024.0 * fs / max(fn, 1) + 1024.0 * ws / max(wn, 1)),
               'hbm_MB_per_step': round((2.0 * 1024.0 * fs + 1024.0 * ws) / steps / 1e6, 2)}
+import subprocess
+try:
+    out['commit'] = subprocess.check_output(['git', '-C', __file__.rsplit('/', 2)[0], 'rev-parse', '--short', 'HEAD'], stderr=subprocess.DEVNULL).decode().strip()
+except Exception:
+    out['commit'] = None                                     # (no .git on the GPU box: the caller stamps it)
 json.dump(out, open(sys.argv[4], 'w'), indent=1)
-for f, d in sorted(out.items(), key=lambda kv: -kv[1]['hbm_MB_per_step'])[:14]:
+for f, d in sorted(((k, v) for k, v in out.items() if isinstance(v, dict)), key=lambda kv: -kv[1]['hbm_MB_per_step'])[:16]:
     print('%-28s %6.1f launches/step  %10.0f B/launch  %8.2f MB/step' % (f, d['launches_per_step'], d['hbm_bytes_per_launch'], d['hbm_MB_per_step']))

@@ -14,6 +14,7 @@ win = [r for r in rows if r[0] >= t_end - steps * ms * 1e6]
 
 
 def family(nm):
+    if 'conv_halo3' in nm: return 'maggie: conv_halo3 (3x3 s1 halo tiles, producer / consumer waves)'
     if 'igemm_fprop' in nm and 'persistent' in nm: return 'maggie: igemm_fprop persistent (sparse head)'
     if 'igemm_fprop_halo' in nm: return 'maggie: igemm_fprop_halo (3x3 s1 halo tiles)'
     if 'igemm_fprop_async' in nm: return 'maggie: igemm_fprop_async (direct-to-LDS im2col)'
