@@ -184,7 +184,11 @@ __device__ __forceinline__ void h3_walk(const unsigned sb, const unsigned (&a_la
 
 // Epilogue from the accumulator registers: acc[i][j][e] = pixel (y0 + wm * FM + i, x0 + lr), channel c0 + e * FN + j. Consumer waves only; the
 // statistics tail has two workgroup barriers (the producers of the split form mirror them).
-template <typename T, int TH, int BN, int FM, int FN, int WAVES_N, bool RES>
+// BNB (mg_conv_params.bnb_*, MAGGIE_BN_LINK): this launch is the data gradient arriving at the OUTPUT z = act(BN(x)) of a training BatchNorm layer whose only
+// consumer is this convolution. The epilogue writes g = dz * act'(z) (mask from the stored z, or re-formed as x * scale + shift for an operand-path layer)
+// and the layer's two backward sums (sum g | sum g * xhat, xhat = (x - mean) * invstd) go out through the statistics rows -- bn_bwd_reduce (10 us, three
+// tensor reads) and its ordered-sum launch disappear for that layer. x / z rows arrive like a residual: one 16-byte load per lane and pixel.
+template <typename T, int TH, int BN, int FM, int FN, int WAVES_N, bool RES, bool BNB = false>
 __device__ __forceinline__ void h3_epilogue(const mg_conv_params& p, f32x4 (&acc)[FM][FN], const float (&sc)[8], const float (&sh)[8], char* smem,
                                             int t, int wave, int lane, int img, int y0, int x0, int n0, int mt, [[maybe_unused]] int work) {
     using TR = ElemTraits<T>;
@@ -263,6 +267,42 @@ __device__ __forceinline__ void h3_epilogue(const mg_conv_params& p, f32x4 (&acc
             for (int q = 0; q < 8; ++q) v[i][q] += rv2[q];
         }
     }
+    [[maybe_unused]] float bxv[FM][8];
+    if constexpr (BNB) {
+        const T* __restrict__ bxb = (const T*)p.bnb_x;
+        const T* __restrict__ byb = (const T*)p.bnb_y;
+        const float bsl = p.bnb_act == MG_ACT_NONE ? 1.f : (p.bnb_act == MG_ACT_RELU ? 0.f : p.slope);
+        const bool lazy = p.bnb_scale != nullptr;
+        uint4 qx[FM], qy[FM];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            qx[i] = make_uint4(0, 0, 0, 0); qy[i] = make_uint4(0, 0, 0, 0);
+            if (mrow[i] >= 0) {
+                qx[i] = *(const uint4*)(bxb + (long)mrow[i] * p.bnb_ld + c0);
+                if (byb) qy[i] = *(const uint4*)(byb + (long)mrow[i] * p.bnb_ld + c0);
+            }
+        }
+        float bsc[8], bsh[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bsc[e] = 0.f; bsh[e] = 1.f; }
+        if (lazy && col_ok) {
+            *(float4*)&bsc[0] = *(const float4*)(p.bnb_scale + c0); *(float4*)&bsc[4] = *(const float4*)(p.bnb_scale + c0 + 4);
+            *(float4*)&bsh[0] = *(const float4*)(p.bnb_shift + c0); *(float4*)&bsh[4] = *(const float4*)(p.bnb_shift + c0 + 4);
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            float byv[8];
+            TR::unpack(qx[i], bxv[i]);
+            TR::unpack(qy[i], byv);
+            if (byb) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[i][q] = byv[q] > 0.f ? v[i][q] : v[i][q] * bsl;
+            } else if (lazy) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[i][q] = (bxv[i][q] * bsc[q] + bsh[q]) > 0.f ? v[i][q] : v[i][q] * bsl;
+            }
+        }
+    }
     uint4 packed[FM];
 #pragma unroll
     for (int i = 0; i < FM; ++i) packed[i] = TR::pack(v[i]);      // rounded once; the statistics are those of the rounded values
@@ -272,7 +312,24 @@ __device__ __forceinline__ void h3_epilogue(const mg_conv_params& p, f32x4 (&acc
     float s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-    if (stats) {
+    if constexpr (BNB) {
+        if (stats) {
+            float bmu[8], bis[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { bmu[e] = 0.f; bis[e] = 0.f; }
+            if (col_ok) {
+                *(float4*)&bmu[0] = *(const float4*)(p.bnb_mean + c0); *(float4*)&bmu[4] = *(const float4*)(p.bnb_mean + c0 + 4);
+                *(float4*)&bis[0] = *(const float4*)(p.bnb_invstd + c0); *(float4*)&bis[4] = *(const float4*)(p.bnb_invstd + c0 + 4);
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                TR::unpack(packed[i], v[i]);
+                const bool keep = mrow[i] >= 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const float u = keep ? v[i][q] : 0.f; s1[q] += u; s2[q] += u * (bxv[i][q] - bmu[q]) * bis[q]; }
+            }
+        }
+    } else if (stats) {
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             TR::unpack(packed[i], v[i]);
@@ -329,7 +386,7 @@ __device__ __forceinline__ void h3_epilogue(const mg_conv_params& p, f32x4 (&acc
 // stored -- and skips the chunks it pointed at the zero page (padding stays 0); the stage's barrier publishes the result. In the split form this
 // is PRODUCER work (they idle between issue bursts). Constants: stage 0's in registers (loaded before the first piece), the rest from an LDS
 // table behind the ring ([2 * Cin] floats, written before barrier 0); the single-role forms (Cin 32 / 64) keep both slabs' in registers.
-template <typename T, int TH, int BN, int NS, int MODE, bool RES, bool XF = false>
+template <typename T, int TH, int BN, int NS, int MODE, bool RES, bool XF = false, bool BNB = false>
 __global__ __launch_bounds__(NS > 1 ? 512 : 256) void conv_halo3_kernel(const mg_conv_params p) {
     using TR = ElemTraits<T>;
     using HC = H3Cfg<TH, BN, NS>;
@@ -527,7 +584,7 @@ __global__ __launch_bounds__(NS > 1 ? 512 : 256) void conv_halo3_kernel(const mg
                 h3_walk<T, FM, FN, BN, PW, MODE, AD, 0>(lds_base, a_lane, b_lane, acc, fr, [] {});
             }
             H3_STAMP(14);
-            h3_epilogue<T, TH, BN, FM, FN, WAVES_N, RES>(p, acc, sc, sh, smem, t, wave, lane, img, y0, x0, n0, mt, work);
+            h3_epilogue<T, TH, BN, FM, FN, WAVES_N, RES, BNB>(p, acc, sc, sh, smem, t, wave, lane, img, y0, x0, n0, mt, work);
             return;
         }
     }
@@ -592,7 +649,7 @@ __global__ __launch_bounds__(NS > 1 ? 512 : 256) void conv_halo3_kernel(const mg
             }
         }
         H3_STAMP(14);
-        h3_epilogue<T, TH, BN, FM, FN, WAVES_N, RES>(p, acc, sc, sh, smem, t, wave, lane, img, y0, x0, n0, mt, work);
+        h3_epilogue<T, TH, BN, FM, FN, WAVES_N, RES, BNB>(p, acc, sc, sh, smem, t, wave, lane, img, y0, x0, n0, mt, work);
     }
 }
 
@@ -627,6 +684,17 @@ int launch_h3(const mg_conv_params& p, hipStream_t st) {
         }
         if (res) hipLaunchKernelGGL((conv_halo3_kernel<T, TH, BN, NS, MG_MODE_CONV, true, true>), grid, dim3(NS > 1 ? 512 : 256), lds_xf, st, p);
         else hipLaunchKernelGGL((conv_halo3_kernel<T, TH, BN, NS, MG_MODE_CONV, false, true>), grid, dim3(NS > 1 ? 512 : 256), lds_xf, st, p);
+        MG_CHECK_LAUNCH();
+        return 0;
+    }
+    if (p.bnb_x) {                                           // the data gradient of a 3x3 / stride 1 conv behind a training BatchNorm layer (BnLink)
+        if (p.mode != MG_MODE_TCONV || !p.stats || p.stat_mode != 0) return -2;
+        static bool bnb_attr = false;
+        if (!bnb_attr) {
+            (void)hipFuncSetAttribute((const void*)conv_halo3_kernel<T, TH, BN, NS, MG_MODE_TCONV, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            bnb_attr = true;
+        }
+        hipLaunchKernelGGL((conv_halo3_kernel<T, TH, BN, NS, MG_MODE_TCONV, true, false, true>), grid, dim3(NS > 1 ? 512 : 256), lds, st, p);
         MG_CHECK_LAUNCH();
         return 0;
     }
@@ -686,7 +754,7 @@ bool h3_eligible(const mg_conv_params& p) {
     if (!g_h3_enabled || !MG_IS16(p.dtype) || p.m_dev || (p.mode != MG_MODE_CONV && p.mode != MG_MODE_TCONV)) return false;
     if (p.R != 3 || p.S != 3 || p.stride != 1 || p.dil != 1 || p.pad != 1 || p.Cin % 32 != 0 || p.Cout % 8 != 0 || p.Cout < 16) return false;
     if (p.Hin != p.Hout || p.Win != p.Wout || p.Wout < 16 || p.Hout < 4) return false;
-    if (p.bnb_x) return false;
+    if (p.bnb_x && (p.mode != MG_MODE_TCONV || p.bnb_ld % 8)) return false;
     if (p.xf_scale && (p.mode != MG_MODE_CONV || p.Cin > 512)) return false;
     if (p.ldx % 8 || p.ldy % 8 || p.yoff % 8 || (p.res && p.ldr % 8) || (p.res2 && p.ldr2 % 8)) return false;
     return true;

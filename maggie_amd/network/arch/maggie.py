@@ -324,7 +324,8 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         # coarse alpha is identically zero (resnet_inst_matt_spconv.py:314: the ground truth then guides the detail region). Everything
         # else the detail stage needs from the host is drawn below, in the reference's order; no site count is ever read back.
         x_os8 = dense[0]
-        ovf = self.decoder.__dict__.get('_sparse_overflow') if self.decoder.sparse_capacity() < 1.0 else None
+        auto_cap = self.decoder.sparse_capacity() == 'auto'
+        ovf = self.decoder.__dict__.get('_sparse_overflow') if self.decoder.sparse_bounded() else None
         comm = None
         if self.training:
             from ... import parallel as _par
@@ -334,14 +335,29 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             # [NaN tokens, coarse alpha all zero (written by the up-sampling kernel), sparse overflow (sticky: raised by an EARLIER step's detail stage,
             # sparse_head.DeviceLevel), mailbox error word (a SyncBatchNorm peer that did not arrive leaves 1 + its rank)] in one launch
             # (mg_step_flags; was isnan + any + compare(s) + stack in front of the copy the host waits for)
-            words = torch.empty(4, dtype=torch.int32, device=tok.device)
+            # ('auto' sparse capacity: the flag words are the head of a persistent int32 [8] whose tail the previous detail stage filled with its live
+            # site counts -- the same single copy brings them along)
+            words = self.decoder.sparse_flag_words(tok.device) if auto_cap else torch.empty(4, dtype=torch.int32, device=tok.device)
             K.hip.call('mg_step_flags', K.hip.ptr(tok), K.c_long(tok.numel()), K.hip.ptr(nonzero if self.training else None), K.hip.ptr(ovf),
                        K.hip.ptr(None if comm is None else comm.error_word), K.hip.ptr(words), K.hip.stream())
             words = words.tolist()
+            if auto_cap:
+                self.decoder.sparse_note_counts(words[4:8], bool(ovf is not None and words[2]))
+                if ovf is not None and words[2]:
+                    ovf.zero_()
+                    words[2] = 0
             flags = [bool(words[0])] + ([bool(words[1])] if self.training else []) + ([bool(words[2])] if ovf is not None else [])
             word = words[3]
         else:
             fl = [torch.isnan(tok).any()] + ([nonzero[0] == 0] if self.training else [])
+            if auto_cap:
+                # (fp16 / bf16 tokens: the generic path) counts and overflow of the previous detail stage in their own small read
+                prev = self.decoder.sparse_flag_words(tok.device)[4:8].tolist()
+                over = bool(ovf is not None and int(ovf[0]) != 0)
+                self.decoder.sparse_note_counts(prev, over)
+                if over:
+                    ovf.zero_()
+                ovf = None
             if ovf is not None:
                 fl.append(ovf[0] != 0)
             if comm is not None:
@@ -358,8 +374,9 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             raise K.hip.MaggieHipError(
                 'MaGGIe (MI355X build): the detail region of a previous step had more active sites than the sparse head was sized for '
                 '(sparse_capacity = %.2f of all sites); the sites beyond the capacity were dropped, i.e. that step\'s refinement and gradients are '
-                'incomplete. Raise model.decoder.sparse_capacity_frac / MAGGIE_SPARSE_CAPACITY (1.0 cannot overflow).' % self.decoder.sparse_capacity())
+                'incomplete. Raise model.decoder.sparse_capacity_frac / MAGGIE_SPARSE_CAPACITY (1.0 cannot overflow; \'auto\' follows the workload).' % self.decoder.sparse_capacity())
         P = b * n_f * (x_os8.shape[1] if self.training else n_i)
+        self.decoder.__dict__['_sparse_last_key'] = (P, h, w, bool(self.training))     # whose site counts the NEXT step's flag read brings ('auto' capacity)
         plan = self.decoder.detail_plan(batch.get('iter', 0), bool(self.training and flags[1]), P, x.device)
         use_fuse_w = bool(self.training and np.random.rand() < 0.75)            # arch/maggie.py:99-101
         names, tensors = self._run_detail(dense, (b, n_f, n_i, h, w), plan, use_fuse_w, alphas, trans_gt)
@@ -481,7 +498,7 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
         """What selects a captured detail graph: geometry, mode, dtype, the STATIC part of the plan and the input signature -- never per-rank
         data when `static_plan['use_gt']` is None (rank-safe mode: the guidance choice is a device flag among `inputs`)."""
         return (geom, self.training, MF.compute_dtype(), static_plan['use_gt'], static_plan['with_atten'],
-                tuple((tuple(t.shape), t.dtype) for t in inputs))
+                tuple((tuple(t.shape), t.dtype) for t in inputs), self.decoder.sparse_caps_version())      # (row capacities are baked into a capture)
 
     @staticmethod
     def _own_outputs(names, outs):

@@ -161,21 +161,93 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
         # "dummy code to prevent all zeros" (:347-348): `unknown_os8[:, :, 200:250, 200:250] = 1` -- a slice assignment, so the square
         # is clipped to the plane (and is a no-op on planes of 200 pixels or less)
         patch = (200, min(250, H), 200, min(250, W)) if (self.training and H > 200 and W > 200) else None
-        pyr = DevicePyramid(roi_bits, H, W, patch, self.sparse_capacity(), self.sparse_overflow_flag(roi_bits.device))
+        cap = self.sparse_capacity()
+        if cap == 'auto':
+            pyr = DevicePyramid(roi_bits, H, W, patch, 1.0, self.sparse_overflow_flag(roi_bits.device), caps=self.sparse_auto_caps(roi_bits.shape[0], H, W, self.training))
+            # live site counts of the four levels into the persistent flag words: the NEXT step's one host read picks them up (no extra sync)
+            torch.cat([l.count for l in pyr.levels], out=self.sparse_flag_words(roi_bits.device)[4:8])
+        else:
+            pyr = DevicePyramid(roi_bits, H, W, patch, cap, self.sparse_overflow_flag(roi_bits.device))
         env = self._head_env(pyr, n_i, os8_feat.dtype)
         x_os4, x_os1 = SparseHead.apply(env, os8_feat.contiguous(), inst_guidance_os8, fea1.contiguous(), fea2.contiguous(), fea3.contiguous(),
                                         *env.params)
         return x_os4, x_os1, pyr
 
     def sparse_capacity(self):
-        """Fraction of "every site active" the sparse head's row buffers are sized for: attribute `sparse_capacity`, env MAGGIE_SPARSE_CAPACITY,
-        default 1.0 (cannot overflow). With a smaller value a step whose detail region exceeds it raises MaggieHipError (after the fact: at the next
-        forward's flag read) instead of silently refining fewer sites."""
+        """How the sparse head's row buffers are sized: attribute `sparse_capacity_frac`, env MAGGIE_SPARSE_CAPACITY.
+        * 'auto' (default, one process): capacities follow the WORKLOAD -- 1.5x the high-water mark of live sites per level seen so far (first
+          step of a geometry: every site, capped at 8 M OS1 rows), grown and the detail graphs re-captured when a step comes within 20 % of a
+          capacity. Training only: inference keeps the initial sizing (its planes are the real instances only). The reference sizes nothing in advance (spconv allocates per call, resnet_inst_matt_spconv.py:170-177); the
+          round-3 default -- all sites of all 10 padded instance slots -- needed 18 GB at batch 4 and 400 GB at the reference's own video shape
+          (maggie_video.yaml:32,89). A step that exceeds its capacity all the same drops the sites beyond it ON THE DEVICE (nothing reads or
+          writes past a buffer), is reported with a warning at the next step, and the capacity is raised 4x.
+        * a fraction < 1.0: fixed fraction of all sites; a step that exceeds it raises MaggieHipError (after the fact: at the next forward's flag read).
+        * 1.0: every site may be active, nothing can overflow. Also what 'auto' means in a multi-rank job: the ranks must replay the same graphs."""
         v = self.__dict__.get('sparse_capacity_frac')
         if v is None:
             import os
-            v = float(os.environ.get('MAGGIE_SPARSE_CAPACITY', '1.0'))
+            v = os.environ.get('MAGGIE_SPARSE_CAPACITY', 'auto')
+        if isinstance(v, str):
+            if v.strip().lower() == 'auto':
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                    return 1.0
+                return 'auto'
+            v = float(v)
         return float(v)
+
+    def sparse_bounded(self):
+        cap = self.sparse_capacity()
+        return cap == 'auto' or cap < 1.0
+
+    # ---- 'auto' capacity: per (planes, H, W) geometry the four level capacities, their high-water marks and whether they were tuned yet ----
+    def sparse_auto_caps(self, P, H, W, training=True):
+        auto = self.__dict__.setdefault('_sparse_auto', {})
+        st = auto.get((P, H, W, bool(training)))
+        if st is None:
+            full = [P * max(1, H >> k) * max(1, W >> k) for k in range(4)]
+            # before anything has been observed: every site (cannot overflow) up to 8 M OS1 rows (~14 GB of head buffers), half per coarser level
+            caps = [min(f, (8 << 20) >> k) for k, f in enumerate(full)]
+            st = auto[(P, H, W, bool(training))] = {'full': full, 'caps': caps, 'hwm': [0, 0, 0, 0], 'tuned': False}
+        return list(st['caps'])
+
+    def sparse_caps_version(self):
+        return self.__dict__.get('_sparse_caps_version', 0)
+
+    def sparse_note_counts(self, counts, overflowed):
+        """Host side of 'auto', at the step's one flag read: `counts` = live sites per level of the PREVIOUS detail stage (clamped to its capacities),
+        `overflowed` = its sticky overflow flag. Raises the capacities when needed (new version -> the detail graphs are captured again)."""
+        key = self.__dict__.get('_sparse_last_key')
+        st = self.__dict__.get('_sparse_auto', {}).get(key)
+        if st is None:
+            return
+        st['hwm'] = [max(h, int(c)) for h, c in zip(st['hwm'], counts)]
+        want = [min(f, max(4096, -(-int(h * 1.5) // 4096) * 4096)) for f, h in zip(st['full'], st['hwm'])]
+        new = list(st['caps'])
+        if overflowed:
+            import logging
+            logging.warning('MaGGIe (MI355X build): the detail region of the previous step had more active sites than the sparse head was sized for '
+                            '(capacities %s, auto mode); the sites beyond were dropped for that step. Capacities raised 4x, detail graphs re-captured.', st['caps'])
+            new = [min(f, max(w, 4 * c)) for f, w, c in zip(st['full'], want, st['caps'])]
+        elif not key[3]:
+            pass                                                  # inference: never below the initial sizing (only the real instances' planes exist there,
+            #                                                       and a dropped site is a wrong output, not a perturbed gradient) -- growth on overflow only
+        elif not st['tuned']:
+            new = want                                            # first observation: from the initial guess to the workload (either direction)
+        else:
+            new = [max(c, w) if h * 1.2 > c else c for c, w, h in zip(st['caps'], want, st['hwm'])]
+        st['tuned'] = True
+        if new != st['caps']:
+            st['caps'] = new
+            self.__dict__['_sparse_caps_version'] = self.sparse_caps_version() + 1
+
+    def sparse_flag_words(self, device):
+        """Persistent int32 [8]: words 0-3 = the step flags (mg_step_flags), 4-7 = live sites per level of the last detail stage ('auto' capacity).
+        Created once: its address is baked into the captured graphs."""
+        f = self.__dict__.get('_sparse_flag_words')
+        if f is None or f.device != device:
+            f = self.__dict__['_sparse_flag_words'] = torch.zeros(8, dtype=torch.int32, device=device)
+        return f
 
     def sparse_overflow_flag(self, device):
         """Sticky int32 [1] device flag: 1 once any level of any step dropped sites (created once: its address is baked into the captured graphs)."""
@@ -267,7 +339,8 @@ class ResShortCut_InstMattSpconv_Dec(nn.Module):
     def head_state(self):
         """Device state the detail stage mutates besides module buffers (rolled back after a capture's warm-up runs): the dropout counter."""
         rng = self.__dict__.get('_head_rng')
-        return ([rng.state] if rng is not None else []) + ([self.__dict__['_sparse_overflow']] if '_sparse_overflow' in self.__dict__ else [])
+        return ([rng.state] if rng is not None else []) + ([self.__dict__['_sparse_overflow']] if '_sparse_overflow' in self.__dict__ else []) + \
+               ([self.__dict__['_sparse_flag_words']] if '_sparse_flag_words' in self.__dict__ else [])
 
     def dense_modules(self):
         """Sub-modules whose parameters are touched by dense_stage only."""

@@ -28,7 +28,7 @@ SLOPE = MF.LRELU_SLOPE
 class DeviceLevel:
     """Active sites of one resolution level. `count` is a 1-element int32 DEVICE tensor (a view of the rank table's last entry)."""
 
-    def __init__(self, bits, H, W, cap_frac=1.0, overflow=None):
+    def __init__(self, bits, H, W, cap_frac=1.0, overflow=None, cap_abs=None):
         self.bits, self.H, self.W = bits, H, W
         self.P = bits.shape[0]
         full = self.P * H * W
@@ -36,6 +36,8 @@ class DeviceLevel:
         # the head's memory (dense-sized otherwise: ~50 GB at 512^2 x 40 planes); sites beyond it are dropped on the device and the sticky
         # `overflow` flag makes the model raise at its next flag read (MaGGIe._forward_impl)
         self.cap = full if (cap_frac >= 1.0 or overflow is None) else max(1024, int(full * cap_frac + 0.5))
+        if cap_abs is not None and overflow is not None:      # an absolute row capacity (decoder.sparse_capacity 'auto': follows the workload's high-water mark)
+            self.cap = max(1024, min(full, int(cap_abs)))
         self.rowoff, self.wordoff = K.bits_rank(bits, W)
         self.count = self.rowoff[-1:]
         if self.cap < full:
@@ -56,16 +58,17 @@ class DevicePyramid:
     """OS1 / OS2 / OS4 / OS8 levels of the detail region (spconv SparseConv2d(k3,s2,p1) output rule), no host read.
     `patch`: (y0, y1, x0, x1) forced when the region is empty (training, resnet_inst_matt_spconv.py:347-348) -- decided on the device."""
 
-    def __init__(self, roi_bits, H, W, patch=None, cap_frac=1.0, overflow=None):
+    def __init__(self, roi_bits, H, W, patch=None, cap_frac=1.0, overflow=None, caps=None):
         if patch is not None:
             probe = K.bits_rank(roi_bits, W)[0][-1:]
             K.bits_patch_if_empty_(roi_bits, probe, H, W, *patch)
         # `cap_frac` is the OS1 fraction; a thin band of active OS1 sites covers a LARGER fraction of the coarser lattices (up to 4x per level,
         # about 2x for a band), so OS2 / OS4 / OS8 are sized for 2x / 4x / 8x the fraction (at most all sites): OS1 dominates the memory anyway
-        lv = [DeviceLevel(roi_bits, H, W, cap_frac, overflow)]
+        # `caps`: absolute row capacities of the four levels instead of the fraction
+        lv = [DeviceLevel(roi_bits, H, W, cap_frac, overflow, None if caps is None else caps[0])]
         for k in range(1, 4):
             b, h, w = K.bits_downsample(lv[-1].bits, lv[-1].W)
-            lv.append(DeviceLevel(b, h, w, min(1.0, cap_frac * (2 ** k)), overflow))
+            lv.append(DeviceLevel(b, h, w, min(1.0, cap_frac * (2 ** k)), overflow, None if caps is None else caps[k]))
         for l in lv:
             l.finalize()
         self.levels = lv

@@ -82,9 +82,9 @@ def _assert_same_bits(a, b, what):
     assert not bad, '%s: %d tensors differ, e.g. %s' % (what, len(bad), bad[:6])
 
 
-@pytest.mark.parametrize('kind,bf16,it', [('image', False, 10000), ('image', True, 10000), ('image', False, 100), ('video', False, 10000),
-                                          ('video', True, 10000)])
-def test_train_step_is_bit_reproducible(kind, bf16, it):
+@pytest.mark.parametrize('kind,bf16,it,cap', [('image', False, 10000, 1.0), ('image', True, 10000, 1.0), ('image', False, 100, 1.0), ('video', False, 10000, 1.0),
+                                              ('video', True, 10000, 1.0), ('image', True, 100, 'auto'), ('video', True, 10000, 'auto')])
+def test_train_step_is_bit_reproducible(kind, bf16, it, cap):
     """the same training step twice -- eagerly, from the capturing step and from pure hipGraph replays -- gives
     IDENTICAL outputs (all alphas, the detail mask), losses, gradients and updated buffers (BatchNorm running statistics, SpectralNorm u / v).
     it = 10000: the detail region is guided by the model's own coarse alpha (its threshold is then reproducible, too); it = 100: by the ground
@@ -110,6 +110,13 @@ def test_train_step_is_bit_reproducible(kind, bf16, it):
         loss['total'].backward()
         return _snapshot(model, out, loss)
 
+    model.decoder.sparse_capacity_frac = cap
+    if cap == 'auto':
+        # the product default: the sparse head's row capacities follow the workload (1.5x the live sites of the first step). They size the
+        # persistent grids, so the bits are those of ONE capacity setting: two throw-away steps let them settle, then everything below holds
+        step(False), step(False)
+        st = list(model.decoder._sparse_auto.values())[0]
+        assert st['tuned'] and st['caps'][0] < st['full'][0]
     e0, e1, e2 = step(False), step(False), step(False)
     _assert_same_bits(e1, e0, 'eager run 2 vs eager run 1')
     _assert_same_bits(e2, e0, 'eager run 3 vs eager run 1')

@@ -437,6 +437,7 @@ def test_train_step_512_fp32_matches_oracle(kind, b, n_f):
     hw, n_i = 512, 2
     model, _ = _build(kind, dev, True)
     model.decoder.inst_spec_layer.dropout.p = 0.0            # dropout masks are device-RNG dependent
+    model.decoder.sparse_capacity_frac = 'auto'              # the product default (the suite pins 1.0, tests/conftest.py)
     from helpers import reference_layout_state_dict, RSEED
     sd = reference_layout_state_dict(kind, requires_grad=True)
     batch = synth.synthetic_batch(b, n_f, n_i, hw, hw, seed=DSEED, train=True, it=100, max_inst=10, edge=40.0)

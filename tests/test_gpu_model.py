@@ -645,6 +645,71 @@ def test_bounded_sparse_capacity_raises_instead_of_refining_fewer_sites():
     assert torch.equal(again['detail_mask'], ref['detail_mask'])
 
 
+def test_auto_sparse_capacity_follows_the_workload(caplog):
+    """the default capacity of the sparse head's row buffers follows the workload ('auto': 1.5x the high-water mark of
+    live sites per level, maggie_amd/network/decoder/resnet_inst_matt_spconv.py sparse_capacity) instead of "all sites of all 10 padded slots"
+    (18 GB at the headline shape, 400 GB at the reference's video shape). Same results as the unbounded setting, step after step, eager and
+    replayed; capacities end up between the live count and a fraction of the full size; a step that exceeds them all the same is reported, the
+    capacities grow and the NEXT step is complete again."""
+    import logging
+    from maggie_amd.utils import synth
+    dev = _dev()
+    batch = _to(synth.synthetic_batch(2, 1, 2, 128, 128, seed=DSEED, train=True, max_inst=10, it=100), dev)
+    outs = {}
+    for mode in (1.0, 'auto'):
+        model, _ = _build('image', dev, True)
+        model.decoder.inst_spec_layer.dropout.p = 0.0
+        model.decoder.sparse_capacity_frac = mode
+        seq = []
+        for i in range(6):                                       # eager, eager (capacities tuned: new graph key), capture, replays
+            seed_all(5)
+            with torch.no_grad():
+                o = model(batch)[0]
+            seq.append({k: o[k].clone() for k in ('detail_mask', 'refined_masks', 'alpha_os1', 'alpha_os4')})
+        outs[mode] = (seq, model)
+    # same index map, exactly; the alphas to rounding: the capacity sizes the persistent grids of the head's kernels, and the order in which the
+    # BatchNorm1d partial sums over the live rows are added is a function of the launch geometry (bit-reproducible for ONE capacity, csrc/det.hip)
+    worst = 0.0
+    for a, b_ in zip(outs[1.0][0], outs['auto'][0]):
+        assert torch.equal(a['detail_mask'], b_['detail_mask'])
+        for k in ('refined_masks', 'alpha_os1', 'alpha_os4'):
+            worst = max(worst, float((a[k] - b_[k]).abs().max()))
+    record('auto_sparse_capacity', max_alpha_diff_vs_unbounded=worst)
+    assert worst <= 1e-4, worst
+    dec = outs['auto'][1].decoder
+    st = dec._sparse_auto[(2 * 10, 128, 128, True)]
+    live = int(outs['auto'][0][-1]['detail_mask'].sum())
+    assert st['tuned'] and st['hwm'][0] == live, (st, live)
+    assert live <= st['caps'][0] <= max(4096, 2 * live) and st['caps'][0] < st['full'][0] // 4, st
+    assert all(h <= c <= f for h, c, f in zip(st['hwm'], st['caps'], st['full'])), st
+    # a step that exceeds its capacity (same geometry, 5 instances with wide soft edges instead of 2 with narrow ones): the dropped sites are REPORTED
+    # at the next flag read, the capacities grow, and the step after that is complete again
+    big = _to(synth.synthetic_batch(2, 1, 5, 128, 128, seed=DSEED + 1, train=True, max_inst=10, it=100, edge=24.0), dev)
+    ref_model = outs[1.0][1]
+    seed_all(5)
+    with torch.no_grad():
+        want_big = ref_model(big)[0]
+    live_big = int(want_big['detail_mask'].sum())
+    assert live_big > st['caps'][0], (live_big, st)              # (otherwise this part tests nothing)
+    model = outs['auto'][1]
+    seed_all(5)
+    with torch.no_grad():
+        small = model(big)[0]
+    assert 0 < int(small['detail_mask'].sum()) < live_big
+    with caplog.at_level(logging.WARNING):
+        for _ in range(4):
+            seed_all(5)
+            with torch.no_grad():
+                got = model(big)[0]
+    assert any('more active sites than the sparse head was sized for' in r.message for r in caplog.records)
+    for _ in range(4):                                           # (every forward advances the SpectralNorm power iteration: same number of calls on both sides)
+        seed_all(5)
+        with torch.no_grad():
+            want_big = ref_model(big)[0]
+    assert torch.equal(got['detail_mask'], want_big['detail_mask']) and st['caps'][0] >= live_big
+    assert float((got['refined_masks'] - want_big['refined_masks']).abs().max()) <= 1e-4
+
+
 @pytest.mark.parametrize('kind,b,n_f', [('video', 2, 3), ('image', 4, 1)])
 def test_fp16_train_step_of_both_models_close_to_fp32(kind, b, n_f):
     """The fp16 kernel family at model level for both architectures (the video model adds the ConvGRU gate kernels, the frame-difference module and
