@@ -385,7 +385,7 @@ __device__ __forceinline__ void h3_epilogue(const mg_conv_params& p, f32x4 (&acc
 // every lane rewrites the 16-byte chunks its own loads deposited -- act(x * scale + shift), rounded to T, the bits mg_affine_act would have
 // stored -- and skips the chunks it pointed at the zero page (padding stays 0); the stage's barrier publishes the result. In the split form this
 // is PRODUCER work (they idle between issue bursts). Constants: stage 0's in registers (loaded before the first piece), the rest from an LDS
-// table behind the ring ([2 * Cin] floats, written before barrier 0); the single-role forms (Cin 32 / 64) keep both slabs' in registers.
+// table behind the ring ([2 * Cin] floats, written before barrier 0), in the single-role forms too.
 template <typename T, int TH, int BN, int NS, int MODE, bool RES, bool XF = false, bool BNB = false>
 __global__ __launch_bounds__(NS > 1 ? 512 : 256) void conv_halo3_kernel(const mg_conv_params p) {
     using TR = ElemTraits<T>;
@@ -452,17 +452,17 @@ __global__ __launch_bounds__(NS > 1 ? 512 : 256) void conv_halo3_kernel(const mg
         [[maybe_unused]] const int xf_ach = (lane & 3) ^ (((lane >> 4) & 1) * 2);     // the 8-channel group of a slab this lane's halo chunks hold
         [[maybe_unused]] const float xf_sl = xf_slope_of(p.xf_act, p.xf_slope);
         [[maybe_unused]] const unsigned xf_tab = lds_base + (unsigned)(NS * STAGE);   // [Cin] scale | [Cin] shift, fp32 (split form)
-        [[maybe_unused]] float xr_sc[2][8], xr_sh[2][8];
+        [[maybe_unused]] float xr_sc[1][8], xr_sh[1][8];
         [[maybe_unused]] u32x4 xf_reg = (u32x4){0u, 0u, 0u, 0u};
         if constexpr (XF) {
 #pragma unroll
-            for (int q = 0; q < (SPLIT ? 1 : 2); ++q) {
-                const int c0 = (q < nstage ? q : 0) * EPS + xf_ach * 8;
+            for (int q = 0; q < 1; ++q) {                        // stage 0's constants in registers; later stages read the LDS table
+                const int c0 = q * EPS + xf_ach * 8;
                 *(float4*)&xr_sc[q][0] = *(const float4*)(p.xf_scale + c0); *(float4*)&xr_sc[q][4] = *(const float4*)(p.xf_scale + c0 + 4);
                 *(float4*)&xr_sh[q][0] = *(const float4*)(p.xf_shift + c0); *(float4*)&xr_sh[q][4] = *(const float4*)(p.xf_shift + c0 + 4);
             }
-            if constexpr (SPLIT) {
-                const int tt = t - 256;                          // producer thread index: 4 floats of the table each
+            {
+                const int tt = SPLIT ? t - 256 : t;              // (producer) thread index: 4 floats of the table each
                 if (tt * 4 < 2 * p.Cin) xf_reg = *(const u32x4*)(tt * 4 < p.Cin ? p.xf_scale + tt * 4 : p.xf_shift + (tt * 4 - p.Cin));
             }
         }
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(NS > 1 ? 512 : 256) void conv_halo3_kernel(const mg
             float scv[8], shv[8];
             if (reg >= 0) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { scv[e] = reg == 0 ? xr_sc[0][e] : xr_sc[1][e]; shv[e] = reg == 0 ? xr_sh[0][e] : xr_sh[1][e]; }
+                for (int e = 0; e < 8; ++e) { scv[e] = xr_sc[0][e]; shv[e] = xr_sh[0][e]; }
             } else {
                 const unsigned tsc = xf_tab + (unsigned)((s * EPS + xf_ach * 8) * 4), tsh = tsc + (unsigned)(p.Cin * 4);
                 f32x4 c0, c1, h0, h1;
@@ -576,7 +576,10 @@ __global__ __launch_bounds__(NS > 1 ? 512 : 256) void conv_halo3_kernel(const mg
                     issue_stage(s, 0);
                 }
                 wait_vm<0>();
-                if constexpr (XF) xf_stage(s, 0, s == 0 ? 0 : 1);
+                if constexpr (XF) {
+                    if (s == 0 && t * 4 < 2 * p.Cin) asm volatile("ds_write_b128 %0, %1" ::"v"(xf_tab + (unsigned)t * 16u), "v"(xf_reg) : "memory");
+                    xf_stage(s, 0, s == 0 ? 0 : -1);             // (ends in lgkmcnt(0); the barrier below publishes the table with stage 0)
+                }
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 if (s < 6) H3_STAMP(3 + 2 * s);
@@ -674,8 +677,8 @@ int launch_h3(const mg_conv_params& p, hipStream_t st) {
     if (mg_det_on && p.stats && p.stat_mode == 0 && (long)(p.stat_rep > 0 ? p.stat_rep : MG_STAT_REPLICAS) < mtiles) return -8;
     dim3 grid(xcd_grid(tiles));
     if (p.xf_scale) {                                        // BatchNorm + activation of the producing layer applied to the staged halo (forward only)
-        constexpr size_t lds_xf = lds + (NS > 1 ? 4096 : 0);     // + the [2 * Cin] fp32 table of the split form (Cin <= 512)
-        if (p.mode != MG_MODE_CONV || p.Cin > 512 || (NS == 1 && p.Cin > 64) || lds_xf > 160 * 1024) return MG_XF_UNSUPPORTED;
+        constexpr size_t lds_xf = lds + 4096;                    // + the [2 * Cin] fp32 table (Cin <= 512)
+        if (p.mode != MG_MODE_CONV || p.Cin > 512 || lds_xf > 160 * 1024) return MG_XF_UNSUPPORTED;
         static bool xf_attr = false;
         if (!xf_attr) {
             (void)hipFuncSetAttribute((const void*)conv_halo3_kernel<T, TH, BN, NS, MG_MODE_CONV, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_xf);
@@ -729,7 +732,8 @@ int dispatch_h3(const mg_conv_params& p, hipStream_t st) {
         else { ns = 4; if (t32 < 200 || p.Hout < 8) th = 4; }
         if (p.Hout < 8) th = 4;
         if (th == 4 && !(bn == 32 && ns == 4)) { bn = 32; ns = 4; }
-        if (p.xf_scale && ns == 1 && p.Cin > 64) ns = bn == 64 ? 3 : 4;      // the single-role transform keeps its constants in registers (two slabs)
+        static const int xf_single = [] { const char* e = getenv("MG_H3_XF_SINGLE"); return e ? atoi(e) : 1; }();   // A/B: 0 = operand transform of Cin > 64 layers in the ring form only
+        if (!xf_single && p.xf_scale && ns == 1 && p.Cin > 64) ns = bn == 64 ? 3 : 4;
     }
 #define H3_CASE(TH_, BN_, NS_) if (th == TH_ && bn == BN_ && ns == NS_) return launch_h3<T, TH_, BN_, NS_>(p, st);
     H3_CASE(8, 64, 3) H3_CASE(8, 64, 1) H3_CASE(8, 32, 4) H3_CASE(8, 32, 1) H3_CASE(4, 32, 4)
