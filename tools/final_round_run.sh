@@ -9,8 +9,8 @@ B="--steps 60 --warmup 10 --no-cpu-baseline"
 python bench.py $B --video > gpurun_out/$TAG/bench_video.json 2>/dev/null
 python bench.py $B --instances 4 > gpurun_out/$TAG/bench_4inst.json 2>/dev/null
 python bench.py $B --dtype fp16 > gpurun_out/$TAG/bench_fp16.json 2>/dev/null
-MAGGIE_MEM_FRACTION=0.92 python bench.py $B --batch 12 > gpurun_out/$TAG/bench_batch12_full.json 2>/dev/null                      # maggie_image.yaml:83, sparse capacity 1.0
-MAGGIE_MEM_FRACTION=0.92 MAGGIE_SPARSE_CAPACITY=0.4 python bench.py $B --video --frames 8 --clips 4 > gpurun_out/$TAG/bench_video_t8.json 2>/dev/null   # maggie_video.yaml:32,89
+MAGGIE_MEM_FRACTION=0.92 python bench.py $B --batch 12 > gpurun_out/$TAG/bench_batch12_full.json 2>/dev/null                      # maggie_image.yaml:83
+MAGGIE_MEM_FRACTION=0.92 python bench.py $B --video --frames 8 --clips 4 > gpurun_out/$TAG/bench_video_t8.json 2>/dev/null   # maggie_video.yaml:32,89
 python bench.py $B --workload pred > gpurun_out/$TAG/bench_pred.json 2>/dev/null                                                   # iter = 10000
 MAGGIE_LAZY_BN=0 python bench.py $B > gpurun_out/$TAG/bench_stored_bn.json 2>/dev/null                                              # the stored BatchNorm form (A/B of the operand path)
 MAGGIE_FORCE_DDP=1 python bench.py $B > gpurun_out/$TAG/bench_force_ddp.json 2>/dev/null
