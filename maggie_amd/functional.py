@@ -92,6 +92,10 @@ class ZeroArena:
         if self.cap_buf is not None and torch.cuda.is_current_stream_capturing():
             if self.cap_off + n_al > self.cap_buf.numel():
                 self.spills += 1                                  # (correct, but a fill launch of its own: tests/test_gpu_graphs.py expects none)
+                if self.spills == 1:
+                    import logging
+                    logging.warning('maggie_amd: a captured graph asked its zero arena for more accumulator words than the eager warm-up tallied; '
+                                    'the excess is served by fill launches inside the graph (correct, slower).')
                 return torch.zeros(n, dtype=torch.float32, device=device)
             v = self.cap_buf[self.cap_off:self.cap_off + n]
             self.cap_off += n_al
@@ -330,6 +334,10 @@ def _count_use(w, geom=None):
     parked only when this counter says its dW has ONE producer: autograd would add a second producer's gradient into the unreduced slabs.
     `geom`: what a plain convolution call looks like to the grouped form above (None: this use can not take part)."""
     if not (PARK_WGRAD and getattr(w, '_mg_join', False)):
+        return None
+    if not (torch.is_grad_enabled() and w.requires_grad):
+        # (ADVICE round 5) a use whose backward can never run -- under no_grad, or of a frozen weight -- must not be counted: every counted use but
+        # the last returns dW = None and leaves its slabs to the group, which a missing backward would keep open for ever
         return None
     cnt = getattr(w, '_mg_uses', None)
     if cnt is None:

@@ -26,7 +26,11 @@ class _Mailbox(ctypes.Structure):
 class MailboxComm:
     def __init__(self, group=None, device=None, spin_seconds=None):
         if spin_seconds is None:
-            spin_seconds = float(os.environ.get('MAGGIE_MAILBOX_TIMEOUT_S', '600'))
+            #  the long budget is for peers on OTHER devices (a late peer = a slow step somewhere else). Ranks that share one device
+            # -- the only placement that is selected automatically -- compete with the very peer they wait for: a dead one must not hold the device,
+            # and every captured graph replay, for ten minutes before the error word is read
+            shared = os.environ.get('MAGGIE_ONE_GPU') == '1' or torch.cuda.device_count() == 1
+            spin_seconds = float(os.environ.get('MAGGIE_MAILBOX_TIMEOUT_S', '30' if shared else '600'))
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         if self.world > MAX_RANKS:
             raise hip.MaggieHipError('MailboxComm: at most %d ranks (one node)' % MAX_RANKS)

@@ -42,9 +42,22 @@ ITER = int(GEOM[5]) if GEOM[5] else None
 STEPS = int(GEOM[6])
 BF16 = len(GEOM) > 7 and GEOM[7] == 'bf16'
 
-dist.init_process_group('gloo', rank=rank, world_size=WORLD)
-torch.cuda.set_device(0)
-dev = torch.device('cuda:0')
+# DP2_DEVICES=0,1 (round 6): rank r on its OWN device DP2_DEVICES[r], gradients (and SyncBatchNorm statistics) over RCCL -- what a multi-GPU node runs.
+# The suite arms this mode by itself when torch.cuda.device_count() >= 2 (tests/test_gpu_graphs.py::test_two_rank_data_parallel_on_two_devices), so
+# the first box with two GPUs validates the cross-device assumptions (RCCL gradient + SyncBN communicators live together; the mailbox's
+# fine-grained IPC memory and system-scope atomics over xGMI with MAGGIE_SYNCBN_COMM=mailbox) before anything is timed. The test's own
+# comparisons travel over a gloo side group (CPU tensors).
+DEVS = [int(v) for v in os.environ['DP2_DEVICES'].split(',')] if os.environ.get('DP2_DEVICES') else None
+if DEVS is not None:
+    torch.cuda.set_device(DEVS[rank])
+    dev = torch.device('cuda', DEVS[rank])
+    dist.init_process_group('nccl', rank=rank, world_size=WORLD)
+    CMP = dist.new_group(backend='gloo')
+else:
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda:0')
+    CMP = None
 
 
 def fresh_model():
@@ -59,7 +72,7 @@ def fresh_model():
 it = ITER if ITER is not None else int(1.5 * build_model(config.model_config(KIND))[0].decoder.warmup_detail_iter)
 batch = synth.synthetic_batch(CLIPS, FRAMES, INST, SIZE, SIZE, seed=DSEED + 17 * rank, train=True, max_inst=10, it=it)
 batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
-res = {'rank': rank, 'iter': it}
+res = {'rank': rank, 'iter': it, 'device': str(dev), 'backend': dist.get_backend()}
 
 
 def seed(step):
@@ -105,7 +118,7 @@ for step in range(STEPS):
         sloss['total'].backward()
         local = flat_grads(sparams).cpu()
         both = [torch.zeros_like(local) for _ in range(WORLD)]
-        dist.all_gather(both, local)
+        dist.all_gather(both, local, group=CMP)
         want = sum(both) / WORLD
         res['local_grads_differ'].append(float((both[0] - both[1]).norm() / both[0].norm()))
 
@@ -122,15 +135,15 @@ for step in range(STEPS):
     if want is not None:
         res['grad_vs_mean_rel'].append(float((got - want).norm() / want.norm()))
     ex = [got.clone() for _ in range(WORLD)]
-    dist.all_gather(ex, got)
+    dist.all_gather(ex, got, group=CMP)
     res.setdefault('grad_drift', []).append(max(float((ex[0] - e).abs().max()) for e in ex[1:]))
     bn = torch.cat([b.detach().float().flatten() for n_, b in model.named_buffers() if 'running_' in n_]).cpu()
     bns = [torch.zeros_like(bn) for _ in range(WORLD)]
-    dist.all_gather(bns, bn)
+    dist.all_gather(bns, bn, group=CMP)
     res['bn_drift'].append(max(float((bns[0] - b_).abs().max()) for b_ in bns[1:]))
     flat = torch.cat([p.detach().float().flatten() for p in params]).cpu()
     peers = [torch.zeros_like(flat) for _ in range(WORLD)]
-    dist.all_gather(peers, flat)
+    dist.all_gather(peers, flat, group=CMP)
     res['param_drift'].append(max(float((peers[0] - q).abs().max()) for q in peers[1:]))
     res['loss'].append(float(loss['total'].detach()))
     res.setdefault('outputs_finite', []).append(all(bool(torch.isfinite(v.float()).all()) for v in out.values() if torch.is_tensor(v)))

@@ -579,3 +579,52 @@ def test_two_rank_data_parallel_on_one_gpu(mode, world):
             # instead of the mean would sit at 50-350 % here
             assert r['grad_vs_mean_rel'][0] <= 0.02 and max(r['grad_vs_mean_rel']) <= 0.3, r['grad_vs_mean_rel']
             assert max(r['bn_drift']) > 0.0                                       # local BatchNorm: every rank keeps its own running statistics
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', ['local_bn', 'syncbn_rccl', 'syncbn_mailbox'])
+def test_two_rank_data_parallel_on_two_devices(mode):
+    """ARMS ITSELF on a box with >= 2 GPUs (this pool's boxes have one: skipped there, and said so). The same worker as above with each rank on its
+    OWN device and RCCL underneath (tests/dp2_worker.py DP2_DEVICES): gradient exchange overlapped with backward, rank-safe graphs, parameters and
+    exchanged gradients bit-identical on both ranks; with nn.SyncBatchNorm the statistics exchange inside the graphs through the DEFAULT across
+    devices (a private RCCL communicator living next to the gradient communicator) and through the mailbox kernels (fine-grained IPC memory +
+    system-scope atomics over xGMI: MAGGIE_SYNCBN_COMM=mailbox) -- running statistics identical on both ranks. Neither has ever run across two
+    devices: this test is there so that the first multi-GPU box checks them before anything is timed on it."""
+    import json
+    import subprocess
+    import sys
+    _dev()
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs: the cross-device paths (RCCL gradient exchange + SyncBN communicator, mailbox over xGMI) stay unexecuted on this box')
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', DP2_DEVICES='0,1')
+    for k in ('MAGGIE_RANK_SAFE_GRAPHS', 'MAGGIE_SYNCBN_GRAPHS', 'MAGGIE_SYNCBN_COMM', 'MAGGIE_ONE_GPU'):
+        env.pop(k, None)
+    if mode == 'syncbn_mailbox':
+        env['MAGGIE_SYNCBN_COMM'] = 'mailbox'
+        env['MAGGIE_MAILBOX_TIMEOUT_S'] = '60'
+    extra = ['local' if mode == 'local_bn' else 'syncbn', '2']
+    port = {'local_bn': '29691', 'syncbn_rccl': '29692', 'syncbn_mailbox': '29693'}[mode]
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, 'dp2_worker.py'), str(r), port] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+             for r in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            out, err = p.communicate(timeout=900)
+            line = [l for l in out.decode(errors='replace').splitlines() if l.startswith('RESULT ')]
+            assert p.returncode == 0 and line, err.decode(errors='replace')[-3000:]
+            outs.append(json.loads(line[-1][7:]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert {r['device'] for r in outs} == {'cuda:0', 'cuda:1'} and all(r['backend'] == 'nccl' for r in outs), outs
+    for r in outs:
+        assert r['graphs'] == 3 and r['detail_graphs'] == 1, r
+        assert all(d == 0.0 for d in r['param_drift']) and all(d == 0.0 for d in r['grad_drift']), r
+        assert all(np.isfinite(v) for v in r['loss'])
+        if mode == 'local_bn':
+            assert r['grad_vs_mean_rel'][0] <= 0.02 and max(r['grad_vs_mean_rel']) <= 0.3, r['grad_vs_mean_rel']
+        else:
+            assert r['sync_layers'] >= 60 and all(d == 0.0 for d in r['bn_drift']), r
+            assert (r['comm_kind'] == 'MailboxComm') == (mode == 'syncbn_mailbox'), r['comm_kind']
