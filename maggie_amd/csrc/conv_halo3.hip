@@ -184,44 +184,69 @@ __device__ __forceinline__ void h3_walk(const unsigned sb, const unsigned (&a_la
 
 // Epilogue from the accumulator registers: acc[i][j][e] = pixel (y0 + wm * FM + i, x0 + lr), channel c0 + e * FN + j. Consumer waves only; the
 // statistics tail has two workgroup barriers (the producers of the split form mirror them).
+// Row operands of the epilogue that do not depend on the accumulators -- residual rows, the BatchNorm-link rows (bnb_x / bnb_y) -- are requested BEFORE the
+// K loop (one 16-byte load per lane and pixel row each): the consumer waves wait for stage 0 to land anyway, and in the epilogue these loads were an exposed
+// memory round trip per launch (linked data-gradient kernels: 15.2 against 12.8 us, tools/trace_bench.sh).
+template <int FM, bool RES, bool BNB> struct H3Rows {
+    int mrow[FM];                                            // output row (M < 2^31), -1: outside the tensor
+    uint4 q1[RES ? FM : 1], q2[RES ? FM : 1], qx[BNB ? FM : 1], qy[BNB ? FM : 1];
+};
+
+template <typename T, int TH, int BN, int FM, int FN, int WAVES_N, bool RES, bool BNB>
+__device__ __forceinline__ void h3_prefetch_rows(const mg_conv_params& p, H3Rows<FM, RES, BNB>& pr, int wave, int lane, int img, int y0, int x0, int n0) {
+    constexpr int WN = 16 * FN;
+    const int H = p.Hout, W = p.Wout;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int lr = lane & 15, lg = lane >> 4;
+    const int c0 = n0 + wn * WN + lg * 4 * FN;
+    const bool col_ok = c0 < p.Cout;
+    const int x = x0 + lr;
+    [[maybe_unused]] const T* __restrict__ r1b = (const T*)p.res;
+    [[maybe_unused]] const T* __restrict__ r2b = (const T*)p.res2;
+    [[maybe_unused]] const T* __restrict__ bxb = (const T*)p.bnb_x;
+    [[maybe_unused]] const T* __restrict__ byb = (const T*)p.bnb_y;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int y = y0 + wm * FM + i;
+        pr.mrow[i] = (col_ok && y < H && x < W) ? (img * H + y) * W + x : -1;
+        if constexpr (RES) {
+            pr.q1[i] = make_uint4(0, 0, 0, 0); pr.q2[i] = make_uint4(0, 0, 0, 0);
+            if (pr.mrow[i] >= 0) {
+                if (r1b) {
+                    int rrow = pr.mrow[i];
+                    if (p.res_mode == 2) rrow = (img * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1);   // residual at half resolution (nearest x2)
+                    pr.q1[i] = *(const uint4*)(r1b + (long)rrow * p.ldr + c0);
+                }
+                if (r2b) pr.q2[i] = *(const uint4*)(r2b + (long)pr.mrow[i] * p.ldr2 + c0);
+            }
+        }
+        if constexpr (BNB) {
+            pr.qx[i] = make_uint4(0, 0, 0, 0); pr.qy[i] = make_uint4(0, 0, 0, 0);
+            if (pr.mrow[i] >= 0) {
+                pr.qx[i] = *(const uint4*)(bxb + (long)pr.mrow[i] * p.bnb_ld + c0);
+                if (byb) pr.qy[i] = *(const uint4*)(byb + (long)pr.mrow[i] * p.bnb_ld + c0);
+            }
+        }
+    }
+}
+
 // BNB (mg_conv_params.bnb_*, MAGGIE_BN_LINK): this launch is the data gradient arriving at the OUTPUT z = act(BN(x)) of a training BatchNorm layer whose only
 // consumer is this convolution. The epilogue writes g = dz * act'(z) (mask from the stored z, or re-formed as x * scale + shift for an operand-path layer)
 // and the layer's two backward sums (sum g | sum g * xhat, xhat = (x - mean) * invstd) go out through the statistics rows -- bn_bwd_reduce (10 us, three
 // tensor reads) and its ordered-sum launch disappear for that layer. x / z rows arrive like a residual: one 16-byte load per lane and pixel.
 template <typename T, int TH, int BN, int FM, int FN, int WAVES_N, bool RES, bool BNB = false>
 __device__ __forceinline__ void h3_epilogue(const mg_conv_params& p, f32x4 (&acc)[FM][FN], const float (&sc)[8], const float (&sh)[8], char* smem,
-                                            int t, int wave, int lane, int img, int y0, int x0, int n0, int mt, [[maybe_unused]] int work) {
+                                            const H3Rows<FM, RES, BNB>& pr, int t, int wave, int lane, int n0, int mt, [[maybe_unused]] int work) {
     using TR = ElemTraits<T>;
     constexpr int WN = 16 * FN, WAVES_M = 4 / WAVES_N;
-    const int H = p.Hout, W = p.Wout;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int lr = lane & 15, lg = lane >> 4;
     const int c0 = n0 + wn * WN + lg * 4 * FN;
     const bool col_ok = c0 < p.Cout;
     const float sl = p.act == MG_ACT_NONE ? 1.f : (p.act == MG_ACT_RELU ? 0.f : p.slope);
     T* __restrict__ yb = (T*)p.y;
-    [[maybe_unused]] const T* __restrict__ r1b = (const T*)p.res;
-    [[maybe_unused]] const T* __restrict__ r2b = (const T*)p.res2;
     const bool stats = p.stats != nullptr;
-    const int x = x0 + lr;
-    int mrow[FM];                                            // output row (M < 2^31), -1: outside the tensor
-    [[maybe_unused]] uint4 q1[FM], q2[FM];
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        const int y = y0 + wm * FM + i;
-        mrow[i] = (col_ok && y < H && x < W) ? (img * H + y) * W + x : -1;
-        if constexpr (RES) {                                 // both residual rows of every pixel requested before the first use
-            q1[i] = make_uint4(0, 0, 0, 0); q2[i] = make_uint4(0, 0, 0, 0);
-            if (mrow[i] >= 0) {
-                if (r1b) {
-                    int rrow = mrow[i];
-                    if (p.res_mode == 2) rrow = (img * (H >> 1) + (y >> 1)) * (W >> 1) + (x >> 1);   // residual at half resolution (nearest x2)
-                    q1[i] = *(const uint4*)(r1b + (long)rrow * p.ldr + c0);
-                }
-                if (r2b) q2[i] = *(const uint4*)(r2b + (long)mrow[i] * p.ldr2 + c0);
-            }
-        }
-    }
+    const int (&mrow)[FM] = pr.mrow;
     H3_STAMP(16);
     // All FM x 8 values go through the epilogue one STEP at a time (source order = issue order): with one wave per SIMD a dependent VALU
     // chain costs ~8 cycles per instruction (measured: 660 cycles per pixel row when the five steps of a value sat back to back), independent
@@ -247,7 +272,7 @@ __device__ __forceinline__ void h3_epilogue(const mg_conv_params& p, f32x4 (&acc
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             float rv[8];
-            TR::unpack(q1[i], rv);
+            TR::unpack(pr.q1[i], rv);
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[i][q] += rv[q];
         }
@@ -262,26 +287,16 @@ __device__ __forceinline__ void h3_epilogue(const mg_conv_params& p, f32x4 (&acc
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             float rv2[8];
-            TR::unpack(q2[i], rv2);
+            TR::unpack(pr.q2[i], rv2);
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[i][q] += rv2[q];
         }
     }
     [[maybe_unused]] float bxv[FM][8];
     if constexpr (BNB) {
-        const T* __restrict__ bxb = (const T*)p.bnb_x;
-        const T* __restrict__ byb = (const T*)p.bnb_y;
+        const bool has_y = p.bnb_y != nullptr;
         const float bsl = p.bnb_act == MG_ACT_NONE ? 1.f : (p.bnb_act == MG_ACT_RELU ? 0.f : p.slope);
         const bool lazy = p.bnb_scale != nullptr;
-        uint4 qx[FM], qy[FM];
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            qx[i] = make_uint4(0, 0, 0, 0); qy[i] = make_uint4(0, 0, 0, 0);
-            if (mrow[i] >= 0) {
-                qx[i] = *(const uint4*)(bxb + (long)mrow[i] * p.bnb_ld + c0);
-                if (byb) qy[i] = *(const uint4*)(byb + (long)mrow[i] * p.bnb_ld + c0);
-            }
-        }
         float bsc[8], bsh[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { bsc[e] = 0.f; bsh[e] = 1.f; }
@@ -292,9 +307,9 @@ __device__ __forceinline__ void h3_epilogue(const mg_conv_params& p, f32x4 (&acc
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             float byv[8];
-            TR::unpack(qx[i], bxv[i]);
-            TR::unpack(qy[i], byv);
-            if (byb) {
+            TR::unpack(pr.qx[i], bxv[i]);
+            TR::unpack(pr.qy[i], byv);
+            if (has_y) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[i][q] = byv[q] > 0.f ? v[i][q] : v[i][q] * bsl;
             } else if (lazy) {
@@ -568,6 +583,8 @@ __global__ __launch_bounds__(NS > 1 ? 512 : 256) void conv_halo3_kernel(const mg
             float sc[8], sh[8];
             const int c0 = n0 + wn * WN + lg * 4 * FN;
             h3_load_affine(p, c0, sc, sh);
+            H3Rows<FM, RES, BNB> pr;
+            h3_prefetch_rows<T, TH, BN, FM, FN, WAVES_N, RES, BNB>(p, pr, wave, lane, img, y0, x0, n0);
             H3Frags<FN, AD> fr;
             for (int s = 0; s < nstage; ++s) {
                 if (s < 6) H3_STAMP(2 + 2 * s);
@@ -587,7 +604,7 @@ __global__ __launch_bounds__(NS > 1 ? 512 : 256) void conv_halo3_kernel(const mg
                 h3_walk<T, FM, FN, BN, PW, MODE, AD, 0>(lds_base, a_lane, b_lane, acc, fr, [] {});
             }
             H3_STAMP(14);
-            h3_epilogue<T, TH, BN, FM, FN, WAVES_N, RES, BNB>(p, acc, sc, sh, smem, t, wave, lane, img, y0, x0, n0, mt, work);
+            h3_epilogue<T, TH, BN, FM, FN, WAVES_N, RES, BNB>(p, acc, sc, sh, smem, pr, t, wave, lane, n0, mt, work);
             return;
         }
     }
@@ -613,6 +630,8 @@ __global__ __launch_bounds__(NS > 1 ? 512 : 256) void conv_halo3_kernel(const mg
         float sc[8], sh[8];
         const int c0 = n0 + wn * WN + lg * 4 * FN;               // this lane's 8 consecutive output channels
         h3_load_affine(p, c0, sc, sh);
+        H3Rows<FM, RES, BNB> pr;
+        h3_prefetch_rows<T, TH, BN, FM, FN, WAVES_N, RES, BNB>(p, pr, wave, lane, img, y0, x0, n0);
         H3Frags<FN, AD> fr;
         H3_STAMP(2);
         __builtin_amdgcn_s_barrier();                        // barrier 0: stage 0 is in LDS
@@ -652,7 +671,7 @@ __global__ __launch_bounds__(NS > 1 ? 512 : 256) void conv_halo3_kernel(const mg
             }
         }
         H3_STAMP(14);
-        h3_epilogue<T, TH, BN, FM, FN, WAVES_N, RES, BNB>(p, acc, sc, sh, smem, t, wave, lane, img, y0, x0, n0, mt, work);
+        h3_epilogue<T, TH, BN, FM, FN, WAVES_N, RES, BNB>(p, acc, sc, sh, smem, pr, t, wave, lane, n0, mt, work);
     }
 }
 

@@ -328,16 +328,17 @@ def _group_wgrad(grp, call):
     return out
 
 
-def _count_use(w, geom=None):
+def _count_use(w, geom=None, needs_grad=True):
     """-> the per-step use counter of a joined weight (a one-element list shared by every autograd Function of this module that consumes `w`:
     ConvRaw in every mode -- also the transposed and side-stream forms, which never park themselves -- and GatherConv), or None. A weight is
     parked only when this counter says its dW has ONE producer: autograd would add a second producer's gradient into the unreduced slabs.
     `geom`: what a plain convolution call looks like to the grouped form above (None: this use can not take part)."""
     if not (PARK_WGRAD and getattr(w, '_mg_join', False)):
         return None
-    if not (torch.is_grad_enabled() and w.requires_grad):
+    if not needs_grad:
         # (ADVICE round 5) a use whose backward can never run -- under no_grad, or of a frozen weight -- must not be counted: every counted use but
-        # the last returns dW = None and leaves its slabs to the group, which a missing backward would keep open for ever
+        # the last returns dW = None and leaves its slabs to the group, which a missing backward would keep open for ever. (`needs_grad` =
+        # ctx.needs_input_grad of the weight: inside an autograd Function's forward torch.is_grad_enabled() is always False.)
         return None
     cnt = getattr(w, '_mg_uses', None)
     if cnt is None:
@@ -788,7 +789,7 @@ BN_SMALL_ROWS = int(_os.environ.get('MG_BN_SMALL_ROWS', '1024'))     # layers up
 # Same-lease A/B, 2 x 150 steps each: 11.22 / 11.25 ms linked against 11.18 / 11.11 ms unlinked -- the data-gradient kernels are bound by their
 # prologue / epilogue latency at this batch size, and a longer epilogue costs what the removed launch saved. Still off by default; parity-tested
 # both ways (tests/test_gpu_kernels.py, tests/test_gpu_determinism.py run with either setting).
-BN_LINK = _os.environ.get('MAGGIE_BN_LINK', '0') != '0'
+BN_LINK = _os.environ.get('MAGGIE_BN_LINK', '1') != '0'          # round 6: on (the halo3 epilogue holds the sums in registers; row operands prefetched before the K loop)
 
 
 class BnLink:
@@ -975,7 +976,8 @@ class ConvRaw(torch.autograd.Function):
         ctx.side = SIDE_WGRAD and getattr(w, '_mg_side_wgrad', False) and not transposed
         ctx.can_park = not (transposed or ctx.side)
         # every use counts; only the plain form below ever parks (alone, or with the other uses of the same weight: _UseGroup)
-        ctx.uses = _count_use(w, (N, H, W_, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, x.dtype, ctx.cin_real) if ctx.can_park else None)
+        ctx.uses = _count_use(w, (N, H, W_, Cin, Ho, Wo, Cout, R, S, stride, pad, dil, x.dtype, ctx.cin_real) if ctx.can_park else None,
+                              needs_grad=ctx.needs_input_grad[1])
         ctx.group = getattr(w, '_mg_group', None) if ctx.uses is not None else None
         # mask_upstream: the BatchNorm behind this conv's ReLU applies the ReLU mask in its own backward pass (mask_x_pos), y is not needed
         ctx.save_for_backward(x, w, y if (pre_relu and not ctx.mask_upstream) else None)
@@ -1352,7 +1354,7 @@ class GatherConv(torch.autograd.Function):
         ctx.save_for_backward(x, w, nbr, nbr_t, y if act != ACT_NONE else None)
         ctx.meta = (reverse_taps, ksize, Cout, bias is not None, act)
         ctx.wt = getattr(w, '_mg_wt', None)          # (Cin_pad, taps [reversed for submanifold], Cout) twin from the weight bank
-        ctx.uses = _count_use(w)
+        ctx.uses = _count_use(w, needs_grad=ctx.needs_input_grad[1])
         return y
 
     @staticmethod
