@@ -789,7 +789,7 @@ BN_SMALL_ROWS = int(_os.environ.get('MG_BN_SMALL_ROWS', '1024'))     # layers up
 # Same-lease A/B, 2 x 150 steps each: 11.22 / 11.25 ms linked against 11.18 / 11.11 ms unlinked -- the data-gradient kernels are bound by their
 # prologue / epilogue latency at this batch size, and a longer epilogue costs what the removed launch saved. Still off by default; parity-tested
 # both ways (tests/test_gpu_kernels.py, tests/test_gpu_determinism.py run with either setting).
-BN_LINK = _os.environ.get('MAGGIE_BN_LINK', '1') != '0'          # round 6: on (the halo3 epilogue holds the sums in registers; row operands prefetched before the K loop)
+BN_LINK = _os.environ.get('MAGGIE_BN_LINK', '0') != '0'          # round 6, re-measured with the halo3 register epilogue + prefetched rows: -0.03 ... -0.15 ms per step over three leases, but the 35 linked data-gradient launches grow by ~4 us (family 1.15 -> 1.29 ms, roofline.frac 0.114 -> 0.104): still off
 
 
 class BnLink:
