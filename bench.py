@@ -378,6 +378,7 @@ def main():
         }
     if world > 1 or force_ddp:
         # graphs that captured RCCL collectives (SyncBN statistics) must go before the communicator does
+        torch.cuda.synchronize()                                      # never destroy a graph the device may still be executing
         for store in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs'):
             model.__dict__.get(store, {}).clear()
         parallel.syncbn_destroy_comm()

@@ -504,12 +504,25 @@ __global__ __launch_bounds__(NS > 1 ? 512 : 256) void conv_halo3_kernel(const mg
             for (int i = 0; i < APW; ++i)
                 asm volatile("ds_read_b128 %0, %1" : "=v"(q[i]) : "v"(sb + (unsigned)((wave + 4 * i) * 1024 + lane * 16)) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // all chunks through the transform one STEP at a time (independent chains side by side: a dependent VALU chain costs ~8 cycles per
+            // instruction with the one or two waves a SIMD has here); an in-image pixel is transformed, zero-page chunks (padding, spare slots) keep
+            // their zeros (a transformed zero would be act(shift))
+            float f[APW][8];
+#pragma unroll
+            for (int i = 0; i < APW; ++i) ElemTraits<T>::unpack(__builtin_bit_cast(uint4, q[i]), f[i]);
+#pragma unroll
+            for (int i = 0; i < APW; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[i][e] = f[i][e] * scv[e] + shv[e];
+#pragma unroll
+            for (int i = 0; i < APW; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[i][e] = fmaxf(f[i][e], f[i][e] * xf_sl);
 #pragma unroll
             for (int i = 0; i < APW; ++i) {
-                if (asrc[i]) {                                   // an in-image pixel: transformed; zero-page chunks (padding, spare slots) stay 0
-                    const uint4 r = xf_apply8<T>(__builtin_bit_cast(uint4, q[i]), scv, shv, xf_sl);
-                    asm volatile("ds_write_b128 %0, %1" ::"v"(sb + (unsigned)((wave + 4 * i) * 1024 + lane * 16)), "v"(__builtin_bit_cast(u32x4, r)) : "memory");
-                }
+                const uint4 r = ElemTraits<T>::pack(f[i]);
+                const u32x4 w_ = asrc[i] ? __builtin_bit_cast(u32x4, r) : q[i];
+                asm volatile("ds_write_b128 %0, %1" ::"v"(sb + (unsigned)((wave + 4 * i) * 1024 + lane * 16)), "v"(w_) : "memory");
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };

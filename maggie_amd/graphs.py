@@ -116,6 +116,15 @@ class GraphedCallable:
     """fn(*inputs) -> tuple of tensors, captured for fixed input shapes. `module`: the nn.Module whose parameters fn reads
     (requires_grad ones get gradients). `mutable`: tensors fn mutates in place (rolled back after warm-up)."""
 
+    def __del__(self):
+        # A hipGraph executable (its kernel-argument buffers, its private memory pool) must not be destroyed while kernels of its last replay are
+        # still queued: drain the device first. Rare (a model going away, a graph evicted): a few microseconds when the device is idle.
+        try:
+            if getattr(self, 'fwd', None) is not None and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+                torch.cuda.synchronize()
+        except Exception:
+            pass
+
     def __init__(self, fn, inputs, module, mutable, training, warmup=2, grad_inputs=(), grad_sink=None):
         """`grad_inputs`: indices of `inputs` whose gradient the caller needs back (a graph fed by another graph's outputs).
         `grad_sink(params) -> list of fp32 tensors | None`: where the parameter gradients should be written (FlatAdamW.grad_views: slices of

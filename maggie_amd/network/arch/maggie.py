@@ -105,8 +105,7 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             tensors = self.__dict__['_addr_tensors'] = list(self.parameters()) + list(self.buffers())
         sig = tuple([t.data_ptr() for t in tensors])
         if self.__dict__.get('_addr_sig') != sig:
-            for store in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs', '_detail_names'):
-                self.__dict__.get(store, {}).clear()
+            self.drop_graphs()
             self.__dict__.pop('_bn_counters', None)
             self.__dict__['_addr_sig'] = sig
         if self._defer_bn_counters():
@@ -233,6 +232,17 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
                 flag = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
         return bool(flag)
 
+    def drop_graphs(self):
+        """Forget every captured hipGraph of this model (they are captured again at the second sight of their geometry). The device is drained
+        first: destroying a graph executable -- its kernel-argument buffers and private memory pool -- while kernels of its last replay are still
+        queued is a use-after-free on the device (round 6: one fatal memory fault in 13 runs of the test that swaps graph sets between steps)."""
+        stores = [self.__dict__.get(st) for st in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs', '_detail_names')]
+        if any(stores) and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        for st in stores:
+            if st:
+                st.clear()
+
     def _graphed(self, store, key, fn, inputs, grad_inputs=()):
         """fn(*inputs) eagerly the first time `key` is seen, captured into hipGraphs (forward + backward) the second time, replayed from
         then on. -> (outputs, replayed?). `key` None: always eager."""
@@ -245,6 +255,8 @@ class MaGGIe(nn.Module, PyTorchModelHubMixin):
             # bounded: each captured graph pins its own activation pool. Evict the least recently USED graph (never the one just
             # captured); sighting counters of geometries that were never captured are bounded separately
             captured = [k for k, v in graphs.items() if not isinstance(v, int)]
+            if len(captured) > 4:
+                torch.cuda.synchronize()                          # (see drop_graphs: never destroy a graph the device may still be executing)
             for k in captured[:max(0, len(captured) - 4)]:
                 graphs.pop(k)
             counters = [k for k, v in graphs.items() if isinstance(v, int)]

@@ -156,6 +156,7 @@ res['comm_calls'] = 0 if parallel.SYNCBN_COMM is None else parallel.SYNCBN_COMM.
 res['comm_kind'] = None if parallel.SYNCBN_COMM is None else type(parallel.SYNCBN_COMM).__name__
 if parallel.SYNCBN_COMM is not None and hasattr(parallel.SYNCBN_COMM, 'check'):
     parallel.SYNCBN_COMM.check()
+torch.cuda.synchronize()                                      # never destroy a graph the device may still be executing
 for store in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs'):
     model.__dict__.get(store, {}).clear()
 parallel.syncbn_destroy_comm()

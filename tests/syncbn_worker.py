@@ -52,6 +52,7 @@ for i in range(4):
         'alpha_os8_sample': out['alpha_os8'].float().flatten()[::997][:64].cpu().tolist()})
 res['graphs'] = sum(1 for st in ('_trunk_graphs', '_detail_graphs') for v in model.__dict__.get(st, {}).values() if not isinstance(v, (int, str)))
 res['sync_layers'] = sum(isinstance(m, torch.nn.SyncBatchNorm) for m in model.modules())
+torch.cuda.synchronize()                                      # never destroy a graph the device may still be executing
 for store in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs'):
     model.__dict__.get(store, {}).clear()
 from maggie_amd import parallel                                     # noqa: E402

@@ -167,6 +167,7 @@ def test_parked_slab_reductions_leave_the_step_unchanged(kind):
         MF.GROUP_WGRAD = False
         for park in (True, False):
             MF.PARK_WGRAD = park
+            torch.cuda.synchronize()                                      # never destroy a graph the device may still be executing
             for store in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs', '_detail_names'):
                 model.__dict__.get(store, {}).clear()              # graphs captured under the other setting hold its launches
             snaps[park, 'eager'] = step(False)
@@ -368,6 +369,7 @@ def test_operand_path_batchnorm_gives_the_bits_of_the_stored_form(kind, size):
 
     def step(lazy, graphs):
         MF.LAZY_BN = lazy
+        torch.cuda.synchronize()                                      # never destroy a graph the device may still be executing
         for store in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs'):
             model.__dict__.get(store, {}).clear()
         snaps = []
@@ -397,6 +399,7 @@ def test_operand_path_batchnorm_gives_the_bits_of_the_stored_form(kind, size):
         hip.call = MF.K.hip.call = orig_call
         MF.LAZY_BN = True
         sparse_head.LAZY_SPARSE = sparse_was
+        torch.cuda.synchronize()                                      # never destroy a graph the device may still be executing
         for store in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs'):
             model.__dict__.get(store, {}).clear()
 
@@ -442,6 +445,7 @@ def test_video_clip_length_8_trains_and_replays_like_eager():
         opt.step()
         assert bool(torch.isfinite(loss['total']))
     assert all(bool(torch.isfinite(p).all()) for p in model.parameters())
+    torch.cuda.synchronize()                                      # never destroy a graph the device may still be executing
     for store in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs'):
         model.__dict__.get(store, {}).clear()
 
@@ -471,6 +475,7 @@ def test_side_stream_shortcut_branches_keep_the_step_reproducible():
         return _snapshot(model, out, loss)
 
     def clear():
+        torch.cuda.synchronize()                                      # never destroy a graph the device may still be executing
         for store in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs', '_detail_names'):
             model.__dict__.get(store, {}).clear()
 

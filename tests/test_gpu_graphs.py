@@ -417,6 +417,7 @@ def test_rank_safe_graphs_one_detail_graph_serves_both_guidance_sources():
 
     def run(rank_safe, rnd_seed, steps):
         model.__dict__['rank_safe_graphs'] = rank_safe
+        torch.cuda.synchronize()                                      # never destroy a graph the device may still be executing
         for store in ('_trunk_graphs', '_trunk_enc_graphs', '_detail_graphs', '_detail_names'):
             model.__dict__.get(store, {}).clear()
         outs = []
