@@ -133,6 +133,13 @@ typedef struct mg_conv_params {
 int mg_conv_xform_ok(const mg_conv_params* p, int which);
 
 int mg_conv_fprop(const mg_conv_params* p, void* stream);
+/* Round 6: the 3x3 / stride-1 / pad-1 layers with Cin % 32 == 0 in the 16-bit types (forward and data gradient, with the operand transform, the
+ * residual / statistics epilogue and the BatchNorm-link sums) are tried first on the producer / consumer halo-tile kernel of csrc/conv_halo3.hip
+ * (reference: maggie/network/encoder/resnet.py:23-39,167-175, decoder/resnet.py:20-45). These two are A/B and experiment switches, not part of the
+ * path's contract: mg_set_halo3(0) restores the round-2..5 kernel forms (returns the previous setting; environment MG_HALO3),
+ * mg_set_halo3_cfg(TH, BN, NS) forces one tile form (tile rows 4 | 8, channels 32 | 64, ring depth 1 | 3 | 4; 0, 0, 0 = the measured dispatch). */
+int mg_set_halo3(int on);
+int mg_set_halo3_cfg(int th, int bn, int ns);
 /* Rows of a `stats` buffer (stat_mode 0) that give every output tile of any forward kernel form its own row for an [M = N * Hout * Wout] output
  * (deterministic mode; MG_STAT_REPLICAS in atomic mode): what mg_conv_params.stat_rep must be at least, else the launch fails with -8. */
 int mg_conv_stat_rows(int M, int N, int Hout, int Wout);
