@@ -688,6 +688,181 @@ __global__ __launch_bounds__(NS > 1 ? 512 : 256) void conv_halo3_kernel(const mg
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Persistent producer / consumer form ("persistent workgroups that issue tile n + 1's first stages under tile
+// n's epilogue"). One 512-thread workgroup per CU walks a LIST of tiles (virtual block ids blockIdx.x + k * gridDim.x through the XCD order);
+// the ring of stages runs ACROSS tile boundaries: the producers are up to NS - 1 stages ahead whatever tile those stages belong to, so from the
+// second tile on a tile's first stage has landed before the consumers have finished the previous tile's epilogue (the cold start -- 3-5 k of
+// a 13 k-cycle launch -- is paid once per workgroup), and the consumers' early barrier puts the next tile's first fragment reads under the last
+// MFMAs of this one. The statistics tail of tile k (two workgroup barriers) comes BEHIND the barrier of tile k + 1's first stage in both roles.
+// For layers with >= ~2 tiles per CU (batch 12, the video shapes); plain forward / data gradient (no operand transform, no BatchNorm link).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool h3_work_of(int v, int L, int& work) {
+    const int chunk = (L + NXCD - 1) / NXCD;
+    work = (v % NXCD) * chunk + v / NXCD;
+    return v / NXCD < chunk && work < L;
+}
+
+template <typename T, int TH, int BN, int NS, int MODE, bool RES>
+__global__ __launch_bounds__(512) void conv_halo3_persist_kernel(const mg_conv_params p) {
+    using HC = H3Cfg<TH, BN, NS>;
+    static_assert(NS >= 3, "the persistent form runs a ring");
+    constexpr int EPS = 32, TW = HC::TW, PW = HC::PW, HH = HC::HH;
+    constexpr int WAVES_N = HC::WAVES_N, FM = HC::FM, FN = HC::FN, WN = HC::WN;
+    constexpr int STAGE = HC::STAGE, L = HC::L, A_BYTES = HC::A_BYTES, APW = HC::A_PER_WAVE, BPW = HC::B_PER_WAVE;
+    constexpr int AD = (MG_H3_AD - 1 <= FM + 2) ? MG_H3_AD : FM + 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* stat_lds = smem + NS * STAGE;                      // the ring stays live across tiles: the statistics tail has its own words
+
+    const int H = p.Hout, W = p.Wout;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int ntn = (p.Cout + BN - 1) / BN;
+    const int total = p.N * tiles_y * tiles_x * ntn;
+    const int G = (int)gridDim.x;
+    int nt = 0;                                              // tiles of this workgroup
+    { int w_; while (h3_work_of((int)blockIdx.x + nt * G, total, w_)) ++nt; }
+    if (nt == 0) return;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = (t >> 6) & 3;
+    const bool producer = (t >> 8) != 0;
+    const int Ktot = 9 * p.Cin;
+    const int nstage = p.Cin / EPS;
+    const int Gt = nt * nstage;                              // stages of this workgroup, all tiles
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    [[maybe_unused]] int work = 0;
+
+    if (producer) {
+        const char* __restrict__ xb = (const char*)p.x;
+        const char* __restrict__ wb = (const char*)p.w;
+        const char* zpage = (const char*)mg_h3_zero_page;
+        const long xpitch = (long)p.ldx * 2l;
+        const char* asrc[APW];
+        const char* bsrc[BPW];
+        auto setup_tile = [&](int k) {                       // addresses of tile k of this workgroup's list
+            int w_;
+            h3_work_of((int)blockIdx.x + k * G, total, w_);
+            const int mt = w_ / ntn, n0 = (w_ - mt * ntn) * BN;
+            const int img = mt / (tiles_y * tiles_x), trem = mt - img * tiles_y * tiles_x;
+            const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+#pragma unroll
+            for (int i = 0; i < APW; ++i) {
+                const int a = wave + 4 * i;
+                const int q = a * 16 + (lane >> 2);
+                const int hy = q / PW, hx = q - hy * PW;
+                const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+                const bool ok = a < HC::A_INSTR && hy < HH && hx < TW + 2 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                const int ach = (lane & 3) ^ (((lane >> 4) & 1) * 2);
+                asrc[i] = ok ? xb + ((long)(img * H + iy) * W + ix) * xpitch + ach * 16 : nullptr;
+            }
+#pragma unroll
+            for (int i = 0; i < BPW; ++i) {
+                const int bi = wave + 4 * i;
+                const int tap = bi / HC::B_GRP, grp = bi - tap * HC::B_GRP;
+                const int rho = grp * 16 + (lane >> 2);
+                const int blk = rho / WN, within = rho - blk * WN;
+                const int co = n0 + blk * WN + (within & 15) * FN + (within >> 4);
+                const int bch = (lane & 3) ^ (((lane >> 5) & 1) * 3);
+                const bool ok = bi < HC::B_INSTR && co < p.Cout;
+                bsrc[i] = ok ? wb + ((long)co * Ktot + (long)tap * p.Cin) * 2l + bch * 16 : nullptr;
+            }
+        };
+        int gi = 0, ki = 0, si = 0, ibuf = 0;                // next stage to issue: global index, its tile, its slab, its ring buffer
+        setup_tile(0);
+        auto issue_next = [&]() {
+            char* sbase = smem + ibuf * STAGE;
+            const long coff = (long)si * EPS * 2l;
+#pragma unroll
+            for (int i = 0; i < APW; ++i) {
+                const char* g = asrc[i] ? asrc[i] + coff : zpage;
+                __builtin_amdgcn_global_load_lds((gbl_void_ptr)g, (lds_void_ptr)(sbase + (wave + 4 * i) * 1024), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < BPW; ++i) {
+                const char* g = bsrc[i] ? bsrc[i] + coff : zpage;
+                __builtin_amdgcn_global_load_lds((gbl_void_ptr)g, (lds_void_ptr)(sbase + A_BYTES + (wave + 4 * i) * 1024), 16, 0, 0);
+            }
+            ++gi;
+            ibuf = ibuf + 1 == NS ? 0 : ibuf + 1;
+            if (++si == nstage) { si = 0; if (++ki < nt) setup_tile(ki); }
+        };
+        for (int u = 0; u < NS - 1 && gi < Gt; ++u) issue_next();
+        int stile = 0;                                       // stage index inside its tile of global stage g
+        for (int g = 0; g < Gt; ++g) {
+            const int infl = gi - 1 - g;                     // stage groups issued behind stage g
+            if (infl <= 0) wait_vm<0>();
+            else if (infl == 1) wait_vm<L>();
+            else wait_vm<(NS > 3 ? 2 * L : 0)>();
+            __builtin_amdgcn_s_barrier();                    // barrier g: stage g is in LDS for everybody; stage g - 1 has been consumed
+            if (g > 0 && stile == 0 && p.stats) { __syncthreads(); __syncthreads(); }     // the previous tile's statistics tail
+            if (gi < Gt) issue_next();
+            if (++stile == nstage) stile = 0;
+        }
+        if (p.stats) { __syncthreads(); __syncthreads(); }   // the last tile's
+        return;
+    }
+
+    // ---------------- consumer waves ----------------
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int lr = lane & 15, lg = lane >> 4;
+    unsigned a_lane[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int px = lr + kx;
+        a_lane[kx] = (unsigned)((wm * FM * PW + px) * 64 + ((lg ^ (((px >> 2) & 1) * 2)) << 4));
+    }
+    const unsigned b_lane = (unsigned)(A_BYTES + (wn * WN + lr) * 64 + ((lg ^ (((lr >> 3) & 1) * 3)) << 4));
+    H3Frags<FN, AD> fr;
+    __builtin_amdgcn_s_barrier();                            // barrier 0
+    asm volatile("" ::: "memory");
+    h3_first_reads<FM, FN, BN, PW, MODE, AD, 0>(lds_base, a_lane, b_lane, fr);
+    int g = 0, buf = 0;
+    for (int k = 0; k < nt; ++k) {
+        h3_work_of((int)blockIdx.x + k * G, total, work);
+        const int mt = work / ntn, n0 = (work - mt * ntn) * BN;
+        const int img = mt / (tiles_y * tiles_x), trem = mt - img * tiles_y * tiles_x;
+        const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+        f32x4 acc[FM][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float sc[8], sh[8];
+        h3_load_affine(p, n0 + wn * WN + lg * 4 * FN, sc, sh);
+        H3Rows<FM, RES, false> pr;
+        h3_prefetch_rows<T, TH, BN, FM, FN, WAVES_N, RES, false>(p, pr, wave, lane, img, y0, x0, n0);
+        // two stages per trip (nstage is even for this form: the fragment register sets alternate at compile-time positions)
+        for (int s = 0; s < nstage; s += 2, g += 2) {
+            {
+                const unsigned sb = lds_base + (unsigned)(buf * STAGE);
+                buf = buf + 1 == NS ? 0 : buf + 1;
+                const unsigned sbn = lds_base + (unsigned)(buf * STAGE);
+                h3_walk<T, FM, FN, BN, PW, MODE, AD, 0>(sb, a_lane, b_lane, acc, fr, [&] {
+                    __builtin_amdgcn_s_barrier();            // (a second stage of the pair always exists)
+                    asm volatile("" ::: "memory");
+                    h3_first_reads<FM, FN, BN, PW, MODE, AD, 1>(sbn, a_lane, b_lane, fr);
+                });
+            }
+            {
+                const unsigned sb = lds_base + (unsigned)(buf * STAGE);
+                buf = buf + 1 == NS ? 0 : buf + 1;
+                const unsigned sbn = lds_base + (unsigned)(buf * STAGE);
+                const bool nxt = g + 2 < Gt;
+                h3_walk<T, FM, FN, BN, PW, MODE, AD, 1>(sb, a_lane, b_lane, acc, fr, [&] {
+                    if (nxt) {
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                        h3_first_reads<FM, FN, BN, PW, MODE, AD, 0>(sbn, a_lane, b_lane, fr);
+                    }
+                });
+            }
+        }
+        // (the consumers are behind the barrier of the next tile's first stage here: its first fragments are in flight under this epilogue)
+        h3_epilogue<T, TH, BN, FM, FN, WAVES_N, RES, false>(p, acc, sc, sh, stat_lds, pr, t, wave, lane, n0, mt, work);
+    }
+}
+
+
 int g_h3_enabled = -1;
 int g_h3_force[3] = {0, 0, 0};          // MG_H3_CFG=TH,BN,NS: one tile form for every eligible layer (experiments)
 
@@ -744,6 +919,40 @@ int launch_h3(const mg_conv_params& p, hipStream_t st) {
     return 0;
 }
 
+template <typename T, int TH, int BN, int NS>
+int launch_h3_persist(const mg_conv_params& p, hipStream_t st) {
+    using HC = H3Cfg<TH, BN, NS>;
+    constexpr size_t lds = (size_t)NS * HC::STAGE + HC::STAT_BYTES;
+    static_assert(lds <= 160 * 1024, "LDS of the persistent form");
+    const bool res = p.res || p.res2;
+    static bool attr_set = false;
+    static int ncu = 256;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_halo3_persist_kernel<T, TH, BN, NS, MG_MODE_CONV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)conv_halo3_persist_kernel<T, TH, BN, NS, MG_MODE_CONV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)conv_halo3_persist_kernel<T, TH, BN, NS, MG_MODE_TCONV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)conv_halo3_persist_kernel<T, TH, BN, NS, MG_MODE_TCONV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        attr_set = true;
+    }
+    const long mtiles = (long)p.N * ((p.Hout + TH - 1) / TH) * ((p.Wout + 15) / 16);
+    const long tiles = mtiles * ((p.Cout + BN - 1) / BN);
+    if (mg_det_on && p.stats && p.stat_mode == 0 && (long)(p.stat_rep > 0 ? p.stat_rep : MG_STAT_REPLICAS) < mtiles) return -8;
+    long g = tiles < ncu ? tiles : ncu;
+    dim3 grid(xcd_grid(g));
+    if (p.mode == MG_MODE_CONV) {
+        if (res) hipLaunchKernelGGL((conv_halo3_persist_kernel<T, TH, BN, NS, MG_MODE_CONV, true>), grid, dim3(512), lds, st, p);
+        else hipLaunchKernelGGL((conv_halo3_persist_kernel<T, TH, BN, NS, MG_MODE_CONV, false>), grid, dim3(512), lds, st, p);
+    } else {
+        if (res) hipLaunchKernelGGL((conv_halo3_persist_kernel<T, TH, BN, NS, MG_MODE_TCONV, true>), grid, dim3(512), lds, st, p);
+        else hipLaunchKernelGGL((conv_halo3_persist_kernel<T, TH, BN, NS, MG_MODE_TCONV, false>), grid, dim3(512), lds, st, p);
+    }
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
 template <typename T>
 int dispatch_h3(const mg_conv_params& p, hipStream_t st) {
     const int nstage = p.Cin / 32;
@@ -766,6 +975,12 @@ int dispatch_h3(const mg_conv_params& p, hipStream_t st) {
         if (th == 4 && !(bn == 32 && ns == 4)) { bn = 32; ns = 4; }
         static const int xf_single = [] { const char* e = getenv("MG_H3_XF_SINGLE"); return e ? atoi(e) : 1; }();   // A/B: 0 = operand transform of Cin > 64 layers in the ring form only
         if (!xf_single && p.xf_scale && ns == 1 && p.Cin > 64) ns = bn == 64 ? 3 : 4;
+    }
+    if (ns >= 100) {                                         // persistent ring forms (forced: mg_set_halo3_cfg(TH, BN, 100 + NS); chosen: see above)
+        if (p.xf_scale || p.bnb_x || (nstage & 1)) return 1;
+        if (th == 8 && bn == 64 && ns == 103) return launch_h3_persist<T, 8, 64, 3>(p, st);
+        if (th == 8 && bn == 32 && ns == 104) return launch_h3_persist<T, 8, 32, 4>(p, st);
+        return 1;
     }
 #define H3_CASE(TH_, BN_, NS_) if (th == TH_ && bn == BN_ && ns == NS_) return launch_h3<T, TH_, BN_, NS_>(p, st);
     H3_CASE(8, 64, 3) H3_CASE(8, 64, 1) H3_CASE(8, 32, 4) H3_CASE(8, 32, 1) H3_CASE(4, 32, 4)

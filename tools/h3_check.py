@@ -52,6 +52,8 @@ def ref_conv(x, w, N, H, W, mode):
 
 def check():
     torch.manual_seed(0)
+    if os.environ.get('H3_CHECK_CFG'):                        # one tile form for every halo3 launch of the check (e.g. 8,64,103: the persistent ring form)
+        cfg(*[int(v) for v in os.environ['H3_CHECK_CFG'].split(',')])
     cases = []
     for (N, Cin, Cout, H, W) in [(2, 128, 128, 16, 32), (1, 64, 64, 24, 40), (2, 32, 32, 20, 36), (1, 256, 96, 8, 16), (3, 96, 48, 12, 20), (1, 512, 64, 5, 17),
                                  (4, 128, 128, 64, 64), (1, 160, 32, 9, 33)]:
@@ -133,7 +135,7 @@ def check():
     return bad
 
 
-SHAPES_ALL = [(4, 32, 32, 512, 0), (4, 32, 32, 512, 1), (4, 32, 32, 256, 0), (4, 32, 64, 128, 0), (4, 64, 64, 128, 0), (4, 64, 64, 128, 1), (4, 128, 128, 64, 0), (4, 128, 128, 64, 1),
+SHAPES_ALL = [(12, 128, 128, 64, 1), (12, 256, 128, 64, 0), (32, 128, 128, 64, 0), (32, 256, 256, 32, 0), (4, 32, 32, 512, 0), (4, 32, 32, 512, 1), (4, 32, 32, 256, 0), (4, 32, 64, 128, 0), (4, 64, 64, 128, 0), (4, 64, 64, 128, 1), (4, 128, 128, 64, 0), (4, 128, 128, 64, 1),
           (4, 256, 256, 32, 0), (4, 256, 256, 32, 1), (4, 512, 512, 16, 0), (4, 512, 256, 32, 0), (4, 256, 128, 64, 0), (12, 128, 128, 64, 0), (12, 256, 256, 32, 0), (12, 64, 64, 128, 0)]
 
 

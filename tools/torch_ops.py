@@ -17,10 +17,11 @@ from maggie_amd.optim import FlatAdamW
 from maggie_amd.utils import config, synth
 
 dev = torch.device('cuda:0')
-model, _ = build_model(config.model_config('image'))
+VIDEO = '--video' in sys.argv
+model, _ = build_model(config.model_config('video' if VIDEO else 'image'))
 sd = model.state_dict(); synth.fill_state_dict_(sd, 1234); model.load_state_dict(sd)
 model.to(dev).train()
-batch = synth.synthetic_batch(4, 1, 2, 512, 512, seed=1234, train=True, it=100, max_inst=10, edge=40.0)
+batch = synth.synthetic_batch(1 if VIDEO else 4, 3 if VIDEO else 1, 2, 512, 512, seed=1234, train=True, it=100, max_inst=10, edge=40.0)
 batch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
 np.random.seed(1); random.seed(1); torch.manual_seed(1)
 params = [p for p in model.parameters() if p.requires_grad]
@@ -64,7 +65,7 @@ for ev in prof.events():
     key = '%-28s %s' % (ev.name[:28], where)
     hits[key] += len(names)
     time_us[key] += sum(k.duration for k in ev.kernels)
-top = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+top = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 60
 print('torch kernel launches in one eager step: %d, %.2f ms' % (sum(hits.values()), sum(time_us.values()) / 1e3))
 for k, v in sorted(hits.items(), key=lambda kv: -time_us[kv[0]])[:top]:
     print('%4d  %8.1f us  %s' % (v, time_us[k], k))
