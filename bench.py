@@ -358,6 +358,7 @@ def main():
             'value': round(value, 3), 'unit': 'instance-frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_per_step, 3),
             'ms_per_step_spread': {'min': round(min(step_ms), 3), 'median': round(float(np.median(step_ms)), 3), 'max': round(max(step_ms), 3),
+                                   'slowest_steps': sorted(((round(v, 2), i) for i, v in enumerate(step_ms)), reverse=True)[:3],
                                    'note': 'device time between per-step events of the timed region (rank 0)'},
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
