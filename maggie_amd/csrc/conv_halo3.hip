@@ -74,11 +74,23 @@ template <int TH, int BN, int NS> struct H3Cfg {
 #ifndef MG_H3_EXP
 #define MG_H3_EXP 0      /* timing experiments only (results wrong): 1 = producers stop after the first ring fill, 2 = consumers only pass the barriers */
 #endif
+// MG_H3_EARLY = 1: a consumer wave arrives at the next stage's barrier (and issues that stage's first fragment reads) as soon as its LAST LDS read of
+// the current stage has landed, ~20 MFMAs before the end of the stage. Worth 1.4 % on the trunk's shapes -- and OFF: with a second process time-slicing
+// the GPU (two ranks on one device: bench.py --gpus 2 with MAGGIE_ONE_GPU=1) the split form then produced NaNs in 9 of 12 runs, with the hand-over behind
+// the last MFMA in 0 of 9 (draining every counted wait, or keeping the producers alive to the end, changed nothing). The protocol reads correct on paper
+// (DESIGN.md 12.1); what breaks it under wave save / restore is not understood, so the form that cannot be told apart from the round-2 kernels' barrier use runs.
+#ifndef MG_H3_EARLY
+#define MG_H3_EARLY 0
+#endif
 #ifndef MG_H3_AD
 #define MG_H3_AD 6
 #endif
 
+#ifdef MG_H3_DRAIN
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }     // (experiment: no counted waits)
+#else
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#endif
 
 __device__ __forceinline__ void h3_load_affine(const mg_conv_params& p, int c0, float (&sc)[8], float (&sh)[8]) {
 #pragma unroll
@@ -127,7 +139,11 @@ __device__ __forceinline__ void h3_walk(const unsigned sb, const unsigned (&a_la
     static_assert(FN == 2, "two weight fragments per wave");
     constexpr int NR = FM + 2, NSTEP = 3 * NR;
     static_assert(AD - 1 <= NR && AD >= 3, "the first reads of a stage stay inside column 0");
+#if !MG_H3_EARLY
+    constexpr int KT = NSTEP;                                // the hand-over behind the last MFMA of the stage (default, see MG_H3_EARLY above)
+#else
     constexpr int KT = NSTEP - AD + 1;                       // first walk position behind the stage's last LDS read
+#endif
     const unsigned baddr = sb + b_lane;
     auto read_b = [&](auto ky_c, auto c_c) {
         constexpr int KY = decltype(ky_c)::value, C_ = decltype(c_c)::value;
@@ -179,6 +195,10 @@ __device__ __forceinline__ void h3_walk(const unsigned sb, const unsigned (&a_la
     tail();
 #else
     static_for(std::make_integer_sequence<int, NSTEP>{}, step);
+#if !MG_H3_EARLY
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    tail();
+#endif
 #endif
 }
 
@@ -570,6 +590,7 @@ __global__ __launch_bounds__(NS > 1 ? 512 : 256) void conv_halo3_kernel(const mg
                 fbuf = fbuf + 1 == NS ? 0 : fbuf + 1;
             }
             if (p.stats) { __syncthreads(); __syncthreads(); }   // the two barriers of the consumers' statistics tail
+            __syncthreads();                                     // the producers stay until the consumers are done (see the end of the kernel)
             return;
         } else {
             issue_stage(0, 0);
@@ -685,6 +706,10 @@ __global__ __launch_bounds__(NS > 1 ? 512 : 256) void conv_halo3_kernel(const mg
         }
         H3_STAMP(14);
         h3_epilogue<T, TH, BN, FM, FN, WAVES_N, RES, BNB>(p, acc, sc, sh, smem, pr, t, wave, lane, n0, mt, work);
+        // No wave of the workgroup ends before the others: a producer that returned while the consumers still had barriers to pass left the barrier's
+        // member count to the hardware's bookkeeping of ended waves -- fine on an idle device, but with a second process time-slicing the GPU
+        // (wave save / restore) two of three 2-rank runs of bench.py produced NaNs with this form and none without it.
+        __syncthreads();
     }
 }
 
@@ -799,6 +824,7 @@ __global__ __launch_bounds__(512) void conv_halo3_persist_kernel(const mg_conv_p
             if (++stile == nstage) stile = 0;
         }
         if (p.stats) { __syncthreads(); __syncthreads(); }   // the last tile's
+        __syncthreads();                                     // stay until the consumers are done
         return;
     }
 
@@ -860,6 +886,7 @@ __global__ __launch_bounds__(512) void conv_halo3_persist_kernel(const mg_conv_p
         // (the consumers are behind the barrier of the next tile's first stage here: its first fragments are in flight under this epilogue)
         h3_epilogue<T, TH, BN, FM, FN, WAVES_N, RES, false>(p, acc, sc, sh, stat_lds, pr, t, wave, lane, n0, mt, work);
     }
+    __syncthreads();                                         // (the producers wait here)
 }
 
 

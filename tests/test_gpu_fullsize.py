@@ -499,3 +499,30 @@ def test_train_step_512_fp32_matches_oracle(kind, b, n_f):
         if bars[key] is not None:
             assert obs[name] <= bars[key], (name, obs[name], bars[key])
     assert int(ref['detail_mask'].sum()) > 10000
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_time_slicing_one_gpu_stay_finite():
+    """`bench.py --gpus 2` as the driver runs it, with both ranks on THIS box's one GPU (MAGGIE_ONE_GPU=1 over gloo): the headline workload at full size
+    while a second process time-slices the device. Round 6 found the producer/consumer conv form (conv_halo3.hip) producing NaNs in exactly this
+    situation, 9 runs out of 12, when its consumer waves arrived EARLY at the next stage's barrier (MG_H3_EARLY: compiled out since) -- single-process
+    runs, the whole GPU suite and two concurrent kernel-level checks never showed it. A NaN anywhere ends the run ("Mask is empty" in the token side),
+    so a JSON line with a finite value is the check; three repetitions, since one run of the faulty form passed 1 time in 4."""
+    import json
+    import os
+    import subprocess
+    import sys
+    _dev()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MAGGIE_DIST_BACKEND='gloo', MAGGIE_ONE_GPU='1')
+    for k in ('MAGGIE_SPARSE_CAPACITY', 'MG_H3_CFG', 'MG_HALO3', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    for rep in range(3):
+        p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2', '--no-cpu-baseline', '--no-roofline'],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600, cwd=root)
+        out, err = p.stdout.decode(errors='replace'), p.stderr.decode(errors='replace')
+        assert p.returncode == 0, 'repetition %d: %s' % (rep, err[-3000:])
+        line = [l for l in out.splitlines() if l.startswith('{') and '"metric"' in l]
+        assert line, out[-2000:]
+        r = json.loads(line[-1])
+        assert r['n_gpus'] == 2 and np.isfinite(r['value']) and r['value'] > 0, r
