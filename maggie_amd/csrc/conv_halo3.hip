@@ -75,10 +75,9 @@ template <int TH, int BN, int NS> struct H3Cfg {
 #define MG_H3_EXP 0      /* timing experiments only (results wrong): 1 = producers stop after the first ring fill, 2 = consumers only pass the barriers */
 #endif
 // MG_H3_EARLY = 1: a consumer wave arrives at the next stage's barrier (and issues that stage's first fragment reads) as soon as its LAST LDS read of
-// the current stage has landed, ~20 MFMAs before the end of the stage. Worth 1.4 % on the trunk's shapes -- and OFF: with a second process time-slicing
-// the GPU (two ranks on one device: bench.py --gpus 2 with MAGGIE_ONE_GPU=1) the split form then produced NaNs in 9 of 12 runs, with the hand-over behind
-// the last MFMA in 0 of 9 (draining every counted wait, or keeping the producers alive to the end, changed nothing). The protocol reads correct on paper
-// (DESIGN.md 12.1); what breaks it under wave save / restore is not understood, so the form that cannot be told apart from the round-2 kernels' barrier use runs.
+// the current stage has landed, ~20 MFMAs before the end of the stage. Correct (two-rank runs 6 of 6 once the lgkmcnt counts of h3_walk were right: the
+// NaNs first blamed on this hand-over were the counts) and worth 1.4 % summed over the trunk's shapes, nothing in the step (798.0 / 796.6 against
+// 796.3 / 799.2 inst-frames/s on one lease): off, the hand-over sits behind the stage's last MFMA. The ISA test covers both.
 #ifndef MG_H3_EARLY
 #define MG_H3_EARLY 0
 #endif
@@ -169,10 +168,18 @@ __device__ __forceinline__ void h3_walk(const unsigned sb, const unsigned (&a_la
         if constexpr (R_ == 0 && C_ > 0) read_b(I2{}, std::integral_constant<int, C_>{});
         if constexpr (K_ + AD - 1 < NSTEP) read_a(std::integral_constant<int, K_ + AD - 1>{});
         if constexpr (K_ < KT) {
-            // A(K_) and the weight fragments this step meets (issued at position K_ - 2 or earlier) have landed once at most the reads issued
-            // behind them are outstanding: the weight loads of positions K_ - 1 and K_ and the rows K_ + 1 .. K_ + AD - 1 (in-order return)
+            // In-order return: an operand has landed once at most the reads issued BEHIND it are outstanding.
+            //  * A(K_) was issued at position K_ - AD + 1: behind it the rows K_ + 1 .. K_ + AD - 1 and the weight loads of positions K_ - AD + 2 .. K_
+            //    (counted here: those of K_ - 1 and K_ only -- fewer than there are, the safe side);
+            //  * weight fragments are first used two positions behind their issue: when position K_ - 2 issued any, only what came behind THEM may be
+            //    outstanding -- the row reads of positions K_ - 2, K_ - 1, K_ (three, not AD - 1: the rows K_ + 1 .. K_ + AD - 3 were issued BEFORE those
+            //    weights) and the weight loads of K_ - 1 and K_. Round 6 shipped the first count for both with AD = 6: two reads too many, the first use of
+            //    W(ky, c + 1) could meet W(ky, c) still in the registers -- never in a single process (an LDS read lands in ~100 cycles, the two positions
+            //    are ~250), with a second process on the GPU in 3 runs out of 4 (tests/test_isa_load_chains_cpu.py now checks the counts in the ISA).
             constexpr int rows_after = (K_ + AD - 1 < NSTEP ? AD - 1 : NSTEP - 1 - K_);
-            constexpr int after = (nb_at(K_ - 1) + nb_at(K_)) * FN + rows_after;
+            constexpr int rows_behind_w = (K_ - 2 + AD - 1 < NSTEP ? 1 : 0) + (K_ - 1 + AD - 1 < NSTEP ? 1 : 0) + (K_ + AD - 1 < NSTEP ? 1 : 0);
+            constexpr int w_after = (nb_at(K_ - 1) + nb_at(K_)) * FN;
+            constexpr int after = w_after + ((nb_at(K_ - 2) > 0 && rows_behind_w < rows_after) ? rows_behind_w : rows_after);
             asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(after) : "memory");
         } else if constexpr (K_ == KT) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every read of the stage has landed: the buffer is not needed any more

@@ -505,9 +505,10 @@ def test_train_step_512_fp32_matches_oracle(kind, b, n_f):
 def test_bench_two_ranks_time_slicing_one_gpu_stay_finite():
     """`bench.py --gpus 2` as the driver runs it, with both ranks on THIS box's one GPU (MAGGIE_ONE_GPU=1 over gloo): the headline workload at full size
     while a second process time-slices the device. Round 6 found the producer/consumer conv form (conv_halo3.hip) producing NaNs in exactly this
-    situation, 9 runs out of 12, when its consumer waves arrived EARLY at the next stage's barrier (MG_H3_EARLY: compiled out since) -- single-process
-    runs, the whole GPU suite and two concurrent kernel-level checks never showed it. A NaN anywhere ends the run ("Mask is empty" in the token side),
-    so a JSON line with a finite value is the check; three repetitions, since one run of the faulty form passed 1 time in 4."""
+    situation, 9 runs out of 12: a hand-counted `s_waitcnt lgkmcnt` left the first use of a weight fragment two LDS reads short, which never shows
+    in a single process (the read lands ~150 cycles before the use) -- the whole GPU suite and two concurrent kernel-level checks were green.
+    tests/test_isa_load_chains_cpu.py replays the counts over the ISA; this is the end-to-end side: a NaN anywhere ends the run ("Mask is empty" in
+    the token side), so a JSON line with a finite value is the check; three repetitions, since one run of the faulty build passed 1 time in 4."""
     import json
     import os
     import subprocess
