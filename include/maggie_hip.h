@@ -150,6 +150,10 @@ int mg_coop_error(int* out);
 /* Switch mg_bn_train_bwd's one-launch form (reduce + ordered sum + apply behind a flag hand-shake; measured slower than the three launches, off by
  * default, MG_BN_COOP=1) on or off; returns the previous setting. */
 int mg_set_bn_coop(int on);
+/* Switch the last-arriver form of mg_bn_bwd_reduce / mg_bn_train_bwd (deterministic mode: the last row block of a channel group to finish adds the
+ * partial rows in row order in its own tail, with the arithmetic of the separate ordered-sum launch -> same bits, one launch less per layer; measured
+ * +30 us per layer, off by default, MG_BN_BWD_TAIL=1) on or off; returns the previous setting. */
+int mg_set_bn_bwd_tail(int on);
 /* Same, allowed to split the K dimension over several blocks per tile for deep layers with few output rows (M <= 8192,
  * K >= ~1152, Cout >= 64): mg_conv_fprop_workspace(p) = floats of scratch that plan needs (0: no split, identical to
  * mg_conv_fprop); partial tiles go to the workspace, a second kernel sums them and applies the epilogue (deterministic). */

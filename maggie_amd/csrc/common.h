@@ -183,6 +183,41 @@ float* mg_det_scratch(long floats);                    // the library's slot scr
 float* mg_det_scratch_on(long floats, hipStream_t st);    // the same for a kernel that may run on the registered side stream (its own scratch there: det.hip)
 // slots: [groups][nblk][rowstride]; the segments cover the columns [col0, col0 + sum nv) of a row
 int mg_det_reduce(const float* slots, int nblk, int groups, int rowstride, int col0, const mg_det_seg* segs, int nseg, hipStream_t st);
+// The arithmetic of det_reduce_kernel for ONE chunk of one column (rows b0 .. b0 + n of a slot matrix, `stride` floats apart): four running sums over
+// the row index mod 4, sixteen / eight / four loads in flight, combined (a0 + a1) + (a2 + a3). Shared with the kernels that add their partial rows in
+// their own tail (norm_act.hip: bn_bwd_reduce_kernel's last-arriver form): same chunking (MG_DET_CHUNKS chunks of ceil(nblk / MG_DET_CHUNKS) rows, chunk
+// sums added in chunk order) -> same bits as the separate launch.
+constexpr int MG_DET_CHUNKS = 16;
+__device__ __forceinline__ float det_chunk_sum(const float* __restrict__ p, int n, size_t stride) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int b = 0;
+    for (; b + 15 < n; b += 16) {
+        float x[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) x[u] = p[(size_t)u * stride];
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) { a0 += x[u]; a1 += x[u + 1]; a2 += x[u + 2]; a3 += x[u + 3]; }
+        p += 16 * stride;
+    }
+    for (; b + 7 < n; b += 8) {
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = p[(size_t)u * stride];
+#pragma unroll
+        for (int u = 0; u < 8; u += 4) { a0 += x[u]; a1 += x[u + 1]; a2 += x[u + 2]; a3 += x[u + 3]; }
+        p += 8 * stride;
+    }
+    for (; b + 3 < n; b += 4) {
+        const float x0 = p[0], x1 = p[stride], x2 = p[2 * stride], x3 = p[3 * stride];
+        a0 += x0; a1 += x1; a2 += x2; a3 += x3;
+        p += 4 * stride;
+    }
+    for (; b < n; ++b) { a0 += p[0]; p += stride; }
+    return (a0 + a1) + (a2 + a3);
+}
+// Ticket words of the last-arriver tails (zeroed once per device, self-resetting): one set for the registered side stream, one for everything else.
+constexpr int MG_TAIL_WORDS = 64;
+unsigned* mg_det_tail_words(hipStream_t st);
 static inline int mg_det_reduce1(const float* slots, int nblk, float* dst, int nv, hipStream_t st) {
     mg_det_seg s{dst, nv, 0};
     return mg_det_reduce(slots, nblk, 1, nv, 0, &s, 1, st);

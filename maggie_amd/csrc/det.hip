@@ -23,6 +23,7 @@ constexpr int MG_MAX_DEVICES = 16;
 static char* g_buf[MG_MAX_DEVICES] = {};
 static long g_bytes[MG_MAX_DEVICES] = {};
 static unsigned* g_coop[MG_MAX_DEVICES] = {};     // mg_coop_sync(), below
+static unsigned* g_tail[MG_MAX_DEVICES] = {};     // mg_det_tail_words(), below
 
 extern "C" int mg_set_deterministic(int on) { mg_det_on = on ? 1 : 0; return 0; }
 extern "C" int mg_get_deterministic(void) { return mg_det_on; }
@@ -47,6 +48,12 @@ extern "C" int mg_det_init(long bytes) {
     e = hipMemset(c, 0, MG_COOP_WORDS * 4);
     if (e != hipSuccess) return (int)e;
     g_coop[dev] = (unsigned*)c;
+    void* t = nullptr;
+    e = hipMalloc(&t, 2 * MG_TAIL_WORDS * 4);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemset(t, 0, 2 * MG_TAIL_WORDS * 4);
+    if (e != hipSuccess) return (int)e;
+    g_tail[dev] = (unsigned*)t;
     return 0;
 }
 
@@ -100,6 +107,12 @@ extern "C" int mg_det_side_stream(void* stream, long bytes) {
     return 0;
 }
 
+unsigned* mg_det_tail_words(hipStream_t st) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MG_MAX_DEVICES || !g_tail[dev]) return nullptr;
+    return g_tail[dev] + ((st && st == g_side_stream[dev]) ? MG_TAIL_WORDS : 0);
+}
+
 float* mg_det_scratch_on(long floats, hipStream_t st) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MG_MAX_DEVICES) return nullptr;
@@ -115,6 +128,7 @@ namespace {
 constexpr int NT = 256;
 constexpr int VPB = 16;                 // values per workgroup
 constexpr int CH = NT / VPB;            // slot chunks per value (16)
+static_assert(CH == MG_DET_CHUNKS, "det_chunk_sum's users chunk the rows the way this kernel does");
 
 struct Segs { mg_det_seg s[MG_DET_MAX_SEGS]; int n; };
 
@@ -128,36 +142,9 @@ __global__ __launch_bounds__(NT) void det_reduce_kernel(const float* __restrict_
     const int g = blockIdx.y;
     const int cs = (nblk + CH - 1) / CH;
     const int b0 = k * cs, b1 = min(nblk, b0 + cs);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (col < ncols) {
-        const float* p = slots + ((size_t)g * nblk + b0) * rowstride + col0 + col;
-        int b = b0;
-        // sixteen loads in flight per batch (a chunk is <= 32 rows: one or two L2 round trips instead of eight); the additions keep the order of
-        // the four-wide loop below, so the sums have the same bits whichever loop ran
-        for (; b + 15 < b1; b += 16) {
-            float x[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) x[u] = p[(size_t)u * rowstride];
-#pragma unroll
-            for (int u = 0; u < 16; u += 4) { a0 += x[u]; a1 += x[u + 1]; a2 += x[u + 2]; a3 += x[u + 3]; }
-            p += 16 * (size_t)rowstride;
-        }
-        for (; b + 7 < b1; b += 8) {
-            float x[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = p[(size_t)u * rowstride];
-#pragma unroll
-            for (int u = 0; u < 8; u += 4) { a0 += x[u]; a1 += x[u + 1]; a2 += x[u + 2]; a3 += x[u + 3]; }
-            p += 8 * (size_t)rowstride;
-        }
-        for (; b + 3 < b1; b += 4) {
-            const float x0 = p[0], x1 = p[(size_t)rowstride], x2 = p[2 * (size_t)rowstride], x3 = p[3 * (size_t)rowstride];
-            a0 += x0; a1 += x1; a2 += x2; a3 += x3;
-            p += 4 * (size_t)rowstride;
-        }
-        for (; b < b1; ++b) { a0 += p[0]; p += rowstride; }
-    }
-    sh[k][v] = (a0 + a1) + (a2 + a3);
+    float a = 0.f;
+    if (col < ncols && b0 < b1) a = det_chunk_sum(slots + ((size_t)g * nblk + b0) * rowstride + col0 + col, b1 - b0, (size_t)rowstride);
+    sh[k][v] = a;
     __syncthreads();
     if (k == 0 && col < ncols) {
         float t = 0.f;

@@ -546,7 +546,7 @@ __device__ __forceinline__ void load_g(const mg_rowwise_params& p, int m, int c0
 }
 
 template <typename T, int BT = NT>
-__global__ __launch_bounds__(BT) void bn_bwd_reduce_kernel(const mg_rowwise_params p, int rows_per_block, int tx, int ty, float* __restrict__ slots) {
+__global__ __launch_bounds__(BT) void bn_bwd_reduce_kernel(const mg_rowwise_params p, int rows_per_block, int tx, int ty, float* __restrict__ slots, unsigned* __restrict__ tail_cnt) {
     using TR = ElemTraits<T>;
     constexpr int CE = TR::CE;
     extern __shared__ float sred[];
@@ -589,6 +589,40 @@ __global__ __launch_bounds__(BT) void bn_bwd_reduce_kernel(const mg_rowwise_para
     float* slot = slots ? slots + (size_t)blockIdx.x * 2 * C : nullptr;
     if (BT > NT) col_block_reduce_wave<2 * CE>(sred, part, tx, ix, active, p.sums, p.sums + C, blockIdx.y * tx * CE, C, CE, slot);
     else col_block_reduce<2 * CE>(sred, part, tx, ty, ix, iy, active, p.sums, p.sums + C, blockIdx.y * tx * CE, C, CE, slot);
+    if (!tail_cnt) return;
+    // ---- ordered sum of the partial rows by the LAST row block of this channel group to arrive (round 6; the separate mg_det_reduce launch of this
+    // layer disappears). No workgroup waits for another one: every block publishes its row (release), takes a ticket, and the one that draws the last
+    // ticket adds all rows of its group IN ROW ORDER -- chunk by chunk with det_reduce_kernel's own arithmetic (det_chunk_sum), so the sums have the bits
+    // the separate launch gave them, whichever block happens to be last. The ticket word returns to 0 for the next launch on the stream.
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(tail_cnt + blockIdx.y, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev + 1u == gridDim.x;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const int nblk = (int)gridDim.x, gw = tx * CE, ncol = 2 * gw, c_base = blockIdx.y * gw;      // columns of this group: [a][gw], a = 0: sum g, 1: sum g xhat
+    const int cs = (nblk + MG_DET_CHUNKS - 1) / MG_DET_CHUNKS;
+    float* sh = sred;                                          // [MG_DET_CHUNKS][ncol] <= 8 KB: inside both reduction layouts above (all reads of them are done)
+    for (int j = threadIdx.x; j < MG_DET_CHUNKS * ncol; j += BT) {
+        const int k = j / ncol, col = j - k * ncol, a = col / gw, c = c_base + col - a * gw;
+        const int b0 = k * cs, b1 = min(nblk, b0 + cs);
+        sh[j] = (c < C && b0 < b1) ? det_chunk_sum(slots + (size_t)b0 * 2 * C + a * C + c, b1 - b0, 2 * C) : 0.f;
+    }
+    __syncthreads();
+    for (int col = threadIdx.x; col < ncol; col += BT) {
+        const int a = col / gw, c = c_base + col - a * gw;
+        if (c < C) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < MG_DET_CHUNKS; ++i) t += sh[i * ncol + col];
+            p.sums[a * C + c] += t;
+        }
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(tail_cnt + blockIdx.y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <typename T>
@@ -870,6 +904,14 @@ extern "C" int mg_affine_act(const mg_rowwise_params* p, void* stream) {
     return 0;
 }
 
+// OFF by default, measured (one lease, two runs each): 11.78 / 11.84 ms against 10.04 / 10.09 ms -- +1.75 ms over 59 layers, ~30 us per layer or ~120 ns per
+// row block: the release fence + ticket of EVERY block (an L2 write-back each, 128-512 blocks per layer) costs several times the 5.4 us launch + 1.5 us
+// kernel boundary it removes. Same verdict as the flag hand-shake of bn_bwd_coop_kernel: on this part a cross-workgroup meeting point
+// inside a launch is dearer than a kernel boundary, with or without waiting. Kept for the tests and as the measured answer to "let the last block of
+// the reduction do the ordered sum" (VERDICT round 5, item 4a): mg_set_bn_bwd_tail / MG_BN_BWD_TAIL=1.
+static int g_bn_bwd_tail = [] { const char* e = getenv("MG_BN_BWD_TAIL"); return e ? atoi(e) : 0; }();
+extern "C" int mg_set_bn_bwd_tail(int on) { const int was = g_bn_bwd_tail; g_bn_bwd_tail = on ? 1 : 0; return was; }
+
 // `hand_over` (deterministic mode): when the partial rows number at most `hand_over_max`, they are NOT summed here -- *hand_over receives
 // them ([*hand_over_rows][2C]) and the caller's apply pass adds them in row order itself (bn_bwd_apply_fixed_kernel: one launch less per layer).
 static int bn_bwd_reduce_impl(const mg_rowwise_params* p, void* stream, float** hand_over, int* hand_over_rows, int hand_over_max) {
@@ -892,14 +934,19 @@ static int bn_bwd_reduce_impl(const mg_rowwise_params* p, void* stream, float** 
     // deterministic mode: one partial row [2C] per row block in the slot scratch, added in row-block order by mg_det_reduce into p->sums
     float* slots = nullptr;
     if (mg_det_on && g.rb > 1) { slots = mg_det_scratch_on((long)g.rb * 2 * p->C, (hipStream_t)stream); if (!slots) return MG_DET_NO_SCRATCH; }
+    // MG_BN_BWD_TAIL=1: the ordered sum of the partial rows rides in the tail of this launch (last-arriver form, see the kernel) instead of its own launch
+    unsigned* tail = nullptr;
+    if (g_bn_bwd_tail && slots && !(hand_over && g.rb <= hand_over_max) && g.groups <= MG_TAIL_WORDS && g.tx * ce * 2 * MG_DET_CHUNKS * sizeof(float) <= lds)
+        tail = mg_det_tail_words((hipStream_t)stream);
     if (wide) {
-        if (p->dtype == MG_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16raw, 1024>), dim3(g.rb, g.groups), dim3(1024), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty, slots);
-        else if (p->dtype == MG_F16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<f16raw, 1024>), dim3(g.rb, g.groups), dim3(1024), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty, slots);
-        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 1024>), dim3(g.rb, g.groups), dim3(1024), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty, slots);
-    } else if (p->dtype == MG_BF16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty, slots);
-    else if (p->dtype == MG_F16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<f16raw>, dim3(g.rb, g.groups), dim3(NT), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty, slots);
-    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty, slots);
+        if (p->dtype == MG_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16raw, 1024>), dim3(g.rb, g.groups), dim3(1024), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty, slots, tail);
+        else if (p->dtype == MG_F16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<f16raw, 1024>), dim3(g.rb, g.groups), dim3(1024), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty, slots, tail);
+        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 1024>), dim3(g.rb, g.groups), dim3(1024), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty, slots, tail);
+    } else if (p->dtype == MG_BF16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16raw>, dim3(g.rb, g.groups), dim3(NT), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty, slots, tail);
+    else if (p->dtype == MG_F16) hipLaunchKernelGGL(bn_bwd_reduce_kernel<f16raw>, dim3(g.rb, g.groups), dim3(NT), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty, slots, tail);
+    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(g.rb, g.groups), dim3(NT), lds, (hipStream_t)stream, *p, g.rpb, g.tx, g.ty, slots, tail);
     MG_CHECK_LAUNCH();
+    if (tail) return 0;                                        // the last row block of every channel group added the rows itself
     if (slots && hand_over && g.rb <= hand_over_max) { *hand_over = slots; *hand_over_rows = g.rb; return 0; }
     if (slots) return mg_det_reduce1(slots, g.rb, p->sums, 2 * p->C, (hipStream_t)stream);
     return 0;

@@ -1583,3 +1583,31 @@ def test_batchnorm_backward_single_launch_form(M, C, act, mask_x_pos, lazy, dtyp
     tol = 8e-3 if dtype == torch.bfloat16 else 1e-3                       # one storage ulp where the sums' last bits move a rounding boundary
     assert (dx.float() - dx_ref.float()).abs().max() <= tol * dx_ref.float().abs().max()
     assert float((dx != dx_ref).float().mean()) <= 2e-3
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('M,C', [(16384, 128), (65536, 64), (4096, 256), (16001, 128), (5000, 32), (1500, 512), (262144, 32)])
+def test_batchnorm_backward_sums_by_the_last_row_block(M, C, dtype):
+    """mg_bn_bwd_reduce's last-arriver form (round 6, VERDICT round 5 item 4a: mg_set_bn_bwd_tail): the row block that draws the last ticket of its
+    channel group adds the partial rows in row order with det_reduce_kernel's arithmetic -- the sums must equal the separate ordered-sum launch BIT FOR
+    BIT, whichever block was last, launch after launch (the ticket words reset themselves)."""
+    import ctypes
+    from maggie_amd import kernels as K, hip
+    dev = _dev()
+    rs = np.random.RandomState(M % 1000 + C)
+    x = torch.from_numpy(rs.normal(0.2, 1.3, (M, C)).astype(np.float32)).to(dev, dtype)
+    dz = torch.from_numpy(rs.normal(size=(M, C)).astype(np.float32)).to(dev, dtype)
+    gamma = torch.from_numpy(rs.uniform(0.5, 1.5, C).astype(np.float32)).to(dev)
+    beta = torch.from_numpy(rs.normal(size=C).astype(np.float32)).to(dev)
+    sc, sh, mean, invstd = K.bn_finalize(K.colstats(x), M, gamma, beta, None, None, 0.1, 1e-5)
+    z = K.affine_act(x, sc, sh, act=1, slope=0.2)
+    _, _, s_ref = K.bn_backward(dz, z, x, sc, mean, invstd, M, act=1, slope=0.2, reduce_only=True)
+    was = hip.lib().mg_set_bn_bwd_tail(ctypes.c_int(1))
+    try:
+        outs = [K.bn_backward(dz, z, x, sc, mean, invstd, M, act=1, slope=0.2, reduce_only=True)[2] for _ in range(5)]
+    finally:
+        hip.lib().mg_set_bn_bwd_tail(ctypes.c_int(was))
+    torch.cuda.synchronize()
+    assert float(s_ref.abs().max()) > 0
+    for s_ in outs:
+        assert torch.equal(s_, s_ref)
