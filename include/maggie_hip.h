@@ -138,7 +138,8 @@ int mg_conv_fprop(const mg_conv_params* p, void* stream);
  * (reference: maggie/network/encoder/resnet.py:23-39,167-175, decoder/resnet.py:20-45). These two are A/B and experiment switches, not part of the
  * path's contract: mg_set_halo3(0) restores the round-2..5 kernel forms (returns the previous setting; environment MG_HALO3),
  * mg_set_halo3_cfg(TH, BN, NS) forces one tile form (tile rows 4 | 8, channels 32 | 64, ring depth 1 | 3 | 4, or 100 + depth = the persistent ring form that walks several tiles per workgroup -- measured, not selected by the
- * dispatch: DESIGN.md 12.1; 0, 0, 0 = the measured dispatch). */
+ * dispatch: DESIGN.md 12.1; 200 | 201 = never | always the one-slab persistent form for Cin == 32, Cout <= 32 layers, which the dispatch takes from 4 096 tiles up;
+ * 0, 0, 0 = the measured dispatch). */
 int mg_set_halo3(int on);
 int mg_set_halo3_cfg(int th, int bn, int ns);
 /* Rows of a `stats` buffer (stat_mode 0) that give every output tile of any forward kernel form its own row for an [M = N * Hout * Wout] output

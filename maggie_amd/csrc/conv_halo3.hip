@@ -713,9 +713,7 @@ __global__ __launch_bounds__(NS > 1 ? 512 : 256) void conv_halo3_kernel(const mg
         }
         H3_STAMP(14);
         h3_epilogue<T, TH, BN, FM, FN, WAVES_N, RES, BNB>(p, acc, sc, sh, smem, pr, t, wave, lane, n0, mt, work);
-        // No wave of the workgroup ends before the others: a producer that returned while the consumers still had barriers to pass left the barrier's
-        // member count to the hardware's bookkeeping of ended waves -- fine on an idle device, but with a second process time-slicing the GPU
-        // (wave save / restore) two of three 2-rank runs of bench.py produced NaNs with this form and none without it.
+        // (no wave of the workgroup ends before the others: the producers wait at the same barrier)
         __syncthreads();
     }
 }
@@ -897,6 +895,215 @@ __global__ __launch_bounds__(512) void conv_halo3_persist_kernel(const mg_conv_p
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------
+// One-slab persistent form (Cin == 32, Cout <= 32: the OS1 / OS2 layers of the decoder and of the fine shortcut branches -- 512 x 512 and 256 x 256
+// maps at the headline geometry, 2 048 - 8 192 tiles per layer). In the per-tile forms above such a layer pays, PER 8 x 16-pixel tile: a workgroup start,
+// 18 KiB of weights through the LDS-DMA path next to 15 KiB of pixels (that path delivers ~50 B per clock and CU: tools/h3_timeline.py), and the
+// latency chain address set-up -> first piece landed -> first MFMA with nothing of its own to hide it. Here a 256-thread workgroup (three per CU: 52 KiB)
+// stages the layer's weights ONCE and walks a list of tiles with the halo image double-buffered: tile k + 1's pieces are issued before tile k's tap walk,
+// and its operand transform (XF: the producing layer's BatchNorm + activation, constants of the one slab in registers) runs between the walk and the
+// epilogue of tile k. One workgroup barrier per tile (+ the two of the statistics tail).
+// LDS: [A0 16 K][B 20 K][A1 16 K]; the weight image uses 18 of its 20 KiB, the statistics words live in the rest. The tap walk addresses the weights
+// relative to the halo image of ITS buffer: buffer 1 passes b_lane - (A1 - A0).
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, int MODE, bool RES, bool XF>
+__global__ __launch_bounds__(256) void conv_halo3_slab_kernel(const mg_conv_params p) {
+    constexpr int TH = 8, BN = 32;
+    using HC = H3Cfg<TH, BN, 1>;
+    constexpr int TW = HC::TW, PW = HC::PW, HH = HC::HH;
+    constexpr int WAVES_N = HC::WAVES_N, FM = HC::FM, FN = HC::FN, WN = HC::WN;
+    constexpr int A_BYTES = HC::A_BYTES, B_BYTES = HC::B_BYTES, APW = HC::A_PER_WAVE, BPW = HC::B_PER_WAVE;
+    constexpr int AD = (MG_H3_AD - 1 <= FM + 2) ? MG_H3_AD : FM + 3;
+    constexpr unsigned A1_OFF = (unsigned)(A_BYTES + B_BYTES);
+    static_assert(HC::B_INSTR * 1024 + HC::STAT_BYTES <= B_BYTES, "the statistics words sit behind the weight image");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* stat_lds = smem + A_BYTES + HC::B_INSTR * 1024;
+
+    const int H = p.Hout, W = p.Wout;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+    const int total = p.N * tiles_y * tiles_x;               // (one channel tile: Cout <= BN)
+    const int G = (int)gridDim.x;
+    int nt = 0;
+    { int w_; while (h3_work_of((int)blockIdx.x + nt * G, total, w_)) ++nt; }
+    if (nt == 0) return;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const char* __restrict__ xb = (const char*)p.x;
+    const char* __restrict__ wb = (const char*)p.w;
+    const char* zpage = (const char*)mg_h3_zero_page;
+    const long xpitch = (long)p.ldx * 2l;
+
+    // ---- the weights, once -------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < BPW; ++i) {
+        const int bi = wave + 4 * i;
+        if (bi < HC::B_INSTR) {                              // (wave-uniform)
+            const int tap = bi / HC::B_GRP, grp = bi - tap * HC::B_GRP;
+            const int rho = grp * 16 + (lane >> 2);
+            const int blk = rho / WN, within = rho - blk * WN;
+            const int co = blk * WN + (within & 15) * FN + (within >> 4);
+            const int bch = (lane & 3) ^ (((lane >> 5) & 1) * 3);
+            const char* g = co < p.Cout ? wb + ((long)co * (9 * 32) + (long)tap * 32) * 2l + bch * 16 : zpage;
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)g, (lds_void_ptr)(smem + A_BYTES + bi * 1024), 16, 0, 0);
+        }
+    }
+    // ---- halo pieces of a tile: the slot geometry of this lane is the same for every tile ------------------------------------
+    int hy_[APW], hx_[APW];
+    bool slot_ok[APW];
+#pragma unroll
+    for (int i = 0; i < APW; ++i) {
+        const int a = wave + 4 * i;
+        const int q = a * 16 + (lane >> 2);
+        hy_[i] = q / PW; hx_[i] = q - hy_[i] * PW;
+        slot_ok[i] = a < HC::A_INSTR && hy_[i] < HH && hx_[i] < TW + 2;
+    }
+    const int ach = (lane & 3) ^ (((lane >> 4) & 1) * 2);
+    auto tile_of = [&](int k, int& mt, int& img, int& y0, int& x0) {
+        int w_;
+        h3_work_of((int)blockIdx.x + k * G, total, w_);
+        mt = w_;
+        img = mt / (tiles_y * tiles_x);
+        const int trem = mt - img * tiles_y * tiles_x;
+        y0 = (trem / tiles_x) * TH; x0 = (trem % tiles_x) * TW;
+    };
+    // issues tile (img, y0, x0) into the halo buffer at `abase`; returns which of this lane's chunks are in-image pixels (the operand transform skips padding)
+    auto issue_tile = [&](int img, int y0, int x0, char* abase) -> unsigned {
+        unsigned m = 0;
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            const int iy = y0 - 1 + hy_[i], ix = x0 - 1 + hx_[i];
+            const bool ok = slot_ok[i] && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            const char* g = ok ? xb + ((long)(img * H + iy) * W + ix) * xpitch + ach * 16 : zpage;
+            m |= ok ? 1u << i : 0u;
+            __builtin_amdgcn_global_load_lds((gbl_void_ptr)g, (lds_void_ptr)(abase + (wave + 4 * i) * 1024), 16, 0, 0);
+        }
+        return m;
+    };
+    [[maybe_unused]] float xsc[8], xsh[8];
+    [[maybe_unused]] const float xf_sl = xf_slope_of(p.xf_act, p.xf_slope);
+    if constexpr (XF) {
+        *(float4*)&xsc[0] = *(const float4*)(p.xf_scale + ach * 8); *(float4*)&xsc[4] = *(const float4*)(p.xf_scale + ach * 8 + 4);
+        *(float4*)&xsh[0] = *(const float4*)(p.xf_shift + ach * 8); *(float4*)&xsh[4] = *(const float4*)(p.xf_shift + ach * 8 + 4);
+    }
+    [[maybe_unused]] auto xf_buf = [&](unsigned sb, unsigned m) {   // this lane's landed chunks of the halo image at `sb`, in place (see xf_stage above)
+        u32x4 q[APW];
+#pragma unroll
+        for (int i = 0; i < APW; ++i)
+            asm volatile("ds_read_b128 %0, %1" : "=v"(q[i]) : "v"(sb + (unsigned)((wave + 4 * i) * 1024 + lane * 16)) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float f[APW][8];
+#pragma unroll
+        for (int i = 0; i < APW; ++i) ElemTraits<T>::unpack(__builtin_bit_cast(uint4, q[i]), f[i]);
+#pragma unroll
+        for (int i = 0; i < APW; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[i][e] = f[i][e] * xsc[e] + xsh[e];
+#pragma unroll
+        for (int i = 0; i < APW; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[i][e] = fmaxf(f[i][e], f[i][e] * xf_sl);
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            const uint4 r = ElemTraits<T>::pack(f[i]);
+            const u32x4 w_ = ((m >> i) & 1u) ? __builtin_bit_cast(u32x4, r) : q[i];
+            asm volatile("ds_write_b128 %0, %1" ::"v"(sb + (unsigned)((wave + 4 * i) * 1024 + lane * 16)), "v"(w_) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+
+    int mt, img, y0, x0;
+    tile_of(0, mt, img, y0, x0);
+    [[maybe_unused]] const unsigned amask0 = issue_tile(img, y0, x0, smem);
+    int mtn = 0, imgn = 0, y0n = 0, x0n = 0;                 // tile k + 1
+    [[maybe_unused]] unsigned amask_n = 0;
+    if (nt > 1) {
+        tile_of(1, mtn, imgn, y0n, x0n);
+        amask_n = issue_tile(imgn, y0n, x0n, smem + A1_OFF);
+    }
+    // ---- consumer geometry ---------------------------------------------------------------------------------------------------
+    const int wm = wave / WAVES_N;
+    const int lr = lane & 15, lg = lane >> 4;
+    unsigned a_lane[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int px = lr + kx;
+        a_lane[kx] = (unsigned)((wm * FM * PW + px) * 64 + ((lg ^ (((px >> 2) & 1) * 2)) << 4));
+    }
+    const unsigned b_lane0 = (unsigned)(A_BYTES + lr * 64 + ((lg ^ (((lr >> 3) & 1) * 3)) << 4));
+    float sc[8], sh[8];
+    h3_load_affine(p, lg * 4 * FN, sc, sh);
+    wait_vm<0>();
+    if constexpr (XF) {
+        xf_buf(lds_base, amask0);
+        if (nt > 1) xf_buf(lds_base + A1_OFF, amask_n);
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // Tile k: walk from buffer k & 1 | everything outstanding has landed (tile k + 1's pieces were issued a whole epilogue + walk ago; only loads and
+    // stores of the SAME age class are ever waited for together: vmcnt(0), no counted wait over mixed loads and stores) | transform tile k + 1 in its
+    // buffer | ONE barrier: tile k + 1 is published, buffer k & 1 is free | tile k + 2's pieces into it | epilogue of tile k.
+    for (int k = 0; k < nt; ++k) {
+        const int cur = k & 1;
+        const unsigned sb = lds_base + (cur ? A1_OFF : 0u);
+        const unsigned b_lane = cur ? b_lane0 - A1_OFF : b_lane0;
+        H3Rows<FM, RES, false> pr;
+        h3_prefetch_rows<T, TH, BN, FM, FN, WAVES_N, RES, false>(p, pr, wave, lane, img, y0, x0, 0);
+        f32x4 acc[FM][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        H3Frags<FN, AD> fr;
+        h3_first_reads<FM, FN, BN, PW, MODE, AD, 0>(sb, a_lane, b_lane, fr);
+        h3_walk<T, FM, FN, BN, PW, MODE, AD, 0>(sb, a_lane, b_lane, acc, fr, [] {});
+        wait_vm<0>();
+        if constexpr (XF) {
+            if (k >= 1 && k + 1 < nt) xf_buf(lds_base + (cur ? 0u : A1_OFF), amask_n);      // (tile 1 went through it in the prologue)
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        int mt2 = 0, img2 = 0, y02 = 0, x02 = 0;
+        unsigned amask_2 = 0;
+        if (k + 2 < nt) {
+            tile_of(k + 2, mt2, img2, y02, x02);
+            amask_2 = issue_tile(img2, y02, x02, smem + (cur ? A1_OFF : 0u));
+        }
+        h3_epilogue<T, TH, BN, FM, FN, WAVES_N, RES, false>(p, acc, sc, sh, stat_lds, pr, t, wave, lane, 0, mt, mt);
+        mt = mtn; img = imgn; y0 = y0n; x0 = x0n;
+        mtn = mt2; imgn = img2; y0n = y02; x0n = x02; amask_n = amask_2;
+    }
+}
+
+template <typename T>
+int launch_h3_slab(const mg_conv_params& p, hipStream_t st) {
+    using HC = H3Cfg<8, 32, 1>;
+    constexpr size_t lds = (size_t)2 * HC::A_BYTES + HC::B_BYTES;
+    static_assert(3 * lds <= 160 * 1024, "three workgroups per CU");
+    const bool res = p.res || p.res2;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    const long tiles = (long)p.N * ((p.Hout + 7) / 8) * ((p.Wout + 15) / 16);
+    if (mg_det_on && p.stats && p.stat_mode == 0 && (long)(p.stat_rep > 0 ? p.stat_rep : MG_STAT_REPLICAS) < tiles) return -8;
+    const long maxwg = 3l * ncu, per = (tiles + maxwg - 1) / maxwg;
+    dim3 grid(xcd_grid((tiles + per - 1) / per));
+#define H3_SLAB(MODE_, RES_, XF_) hipLaunchKernelGGL((conv_halo3_slab_kernel<T, MODE_, RES_, XF_>), grid, dim3(256), lds, st, p)
+    if (p.xf_scale) {
+        if (p.mode != MG_MODE_CONV) return MG_XF_UNSUPPORTED;
+        if (res) H3_SLAB(MG_MODE_CONV, true, true); else H3_SLAB(MG_MODE_CONV, false, true);
+    } else if (p.mode == MG_MODE_CONV) {
+        if (res) H3_SLAB(MG_MODE_CONV, true, false); else H3_SLAB(MG_MODE_CONV, false, false);
+    } else {
+        if (res) H3_SLAB(MG_MODE_TCONV, true, false); else H3_SLAB(MG_MODE_TCONV, false, false);
+    }
+#undef H3_SLAB
+    MG_CHECK_LAUNCH();
+    return 0;
+}
+
 int g_h3_enabled = -1;
 int g_h3_force[3] = {0, 0, 0};          // MG_H3_CFG=TH,BN,NS: one tile form for every eligible layer (experiments)
 
@@ -1010,6 +1217,14 @@ int dispatch_h3(const mg_conv_params& p, hipStream_t st) {
         static const int xf_single = [] { const char* e = getenv("MG_H3_XF_SINGLE"); return e ? atoi(e) : 1; }();   // A/B: 0 = operand transform of Cin > 64 layers in the ring form only
         if (!xf_single && p.xf_scale && ns == 1 && p.Cin > 64) ns = bn == 64 ? 3 : 4;
     }
+    // one slab, one channel tile, >= ~5 tiles per resident workgroup: the persistent form with the weights staged once (ns 201 forces it, 200 forbids it).
+    // Measured (tools/h3_check.py time, us, per-tile single-role form | this form): batch 4 C32 512 x 512 forward 47.1 | 41.6, data gradient 41.9 | 33.8,
+    // C32 -> 8 data gradient 34.3 (round-2 im2col form) | 29.7; batch 12 512 x 512 131.5 | 115.7, 256 x 256 30.7 | 26.5; batch 4 256 x 256 (2 048 tiles,
+    // 2.7 per workgroup) 13.0 | 14.3 -- hence the threshold. What bounds it is not the matrix pipe (36 MFMAs per wave and tile = 11 us of the 42) but the
+    // ~450 vector-ALU instructions a wave spends per tile on addresses, the epilogue and the statistics' DPP sums (hipcc -S, counted per basic block).
+    static const int slab_min = [] { const char* e = getenv("MG_H3_SLAB_MIN"); return e ? atoi(e) : 4096; }();
+    if (ns != 200 && nstage == 1 && p.Cout <= 32 && !p.bnb_x && (ns == 201 || (!g_h3_force[0] && sp8 >= slab_min))) return launch_h3_slab<T>(p, st);
+    if (ns >= 200 || p.Cout < 16) return 1;
     if (ns >= 100) {                                         // persistent ring forms (forced: mg_set_halo3_cfg(TH, BN, 100 + NS); chosen: see above)
         if (p.xf_scale || p.bnb_x || (nstage & 1)) return 1;
         if (th == 8 && bn == 64 && ns == 103) return launch_h3_persist<T, 8, 64, 3>(p, st);
@@ -1037,7 +1252,7 @@ void h3_init() {
 bool h3_eligible(const mg_conv_params& p) {
     h3_init();
     if (!g_h3_enabled || !MG_IS16(p.dtype) || p.m_dev || (p.mode != MG_MODE_CONV && p.mode != MG_MODE_TCONV)) return false;
-    if (p.R != 3 || p.S != 3 || p.stride != 1 || p.dil != 1 || p.pad != 1 || p.Cin % 32 != 0 || p.Cout % 8 != 0 || p.Cout < 16) return false;
+    if (p.R != 3 || p.S != 3 || p.stride != 1 || p.dil != 1 || p.pad != 1 || p.Cin % 32 != 0 || p.Cout % 8 != 0 || (p.Cout < 16 && p.Cin != 32)) return false;     // (Cout 8: the one-slab persistent form only)
     if (p.Hin != p.Hout || p.Win != p.Wout || p.Wout < 16 || p.Hout < 4) return false;
     if (p.bnb_x && (p.mode != MG_MODE_TCONV || p.bnb_ld % 8)) return false;
     if (p.xf_scale && (p.mode != MG_MODE_CONV || p.Cin > 512)) return false;

@@ -624,3 +624,97 @@ def test_operand_transform_on_the_sparse_row_matrices(Cin, Cout, kind, act, dtyp
         g_ref = K.conv_wgrad(z, dy, out_dtype=od, **wkw)
         g_xf = K.conv_wgrad(y, dy, out_dtype=od, xf=xf, **wkw)
         assert torch.equal(g_xf, g_ref), (od, float((g_xf.float() - g_ref.float()).abs().max()))
+
+
+SLAB_CASES = [
+    # N, Cin, Cout, H, W: one 32-channel slab, one channel tile -- the persistent weights-once form (conv_halo3_slab_kernel)
+    (4, 32, 32, 128, 128),          # 512 tiles: most workgroups walk one tile, some none
+    (3, 32, 32, 200, 72),           # 1 125 tiles over 768 workgroups: one and two tiles per workgroup, ragged in x (72 = 4.5 tiles)
+    (2, 32, 32, 256, 256),          # 2 048 tiles: two and three per workgroup -- the double buffer turns over
+    (1, 32, 8, 40, 40),             # 8 output channels (three quarters of the lanes hold no column), ragged in y
+    (2, 32, 16, 24, 56),
+    (1, 32, 24, 9, 33),             # ragged both ways, H not a multiple of 8
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('case', SLAB_CASES)
+def test_one_slab_persistent_form(case, dtype):
+    """conv_halo3.hip's one-slab persistent form (round 6: Cin == 32, Cout <= 32 -- weights staged once per workgroup, halo image double-buffered, a
+    list of tiles per workgroup; selected by the dispatch from 4 096 tiles up, forced here with mg_set_halo3_cfg(8, 32, 201)): forward and data
+    gradient (taps mirrored) with every epilogue the layer family uses -- scale / shift / activation before or after, residuals at full and half
+    resolution, output into a channel slice of a wider buffer, BatchNorm statistics -- against torch fp32 on the rounded operands and against the
+    round-2 kernels (MG_HALO3 off); the operand transform must give the BITS of the stored form, statistics rows included."""
+    import ctypes
+    from maggie_amd import kernels as K, hip
+    dev = _dev()
+    N, Cin, Cout, H, W = case
+    M = N * H * W
+    rs = np.random.RandomState(Cout + H + W)
+    lib = hip.lib()
+
+    def t(a):
+        return torch.from_numpy(a.astype(np.float32)).to(dev)
+    x = t(rs.normal(size=(M, Cin))).to(dtype)
+    w = t(rs.normal(size=(Cout, 9, Cin)) / np.sqrt(9 * Cin)).to(dtype)
+    scale, shift = t(rs.uniform(0.5, 1.5, Cout)), t(rs.normal(size=Cout))
+    res, res2 = t(rs.normal(size=(M, Cout))).to(dtype), t(rs.normal(size=(M, Cout))).to(dtype)
+    variants = [dict(), dict(scale=scale, shift=shift, act=K.ACT_RELU), dict(shift=shift, act=K.ACT_LRELU, slope=0.2, res=res),
+                dict(scale=scale, shift=shift, act=K.ACT_RELU, pre_act=True, res2=res2)]
+    if H % 2 == 0 and W % 2 == 0:
+        variants.append(dict(scale=scale, shift=shift, res=t(rs.normal(size=(N * (H // 2) * (W // 2), Cout))).to(dtype), res_mode=2))
+    rows = K.conv_stat_rows(M, N, H, W)
+    tol = _tol(dtype)
+    try:
+        for mode in (K.MODE_CONV, K.MODE_TCONV):
+            geo = dict(N=N, Hin=H, Win=W, R=3, S=3, stride=1, pad=1, dil=1, mode=mode)
+            xi = x.float().view(N, H, W, Cin).permute(0, 3, 1, 2)
+            wk = w.float().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+            base = F.conv2d(xi, wk.flip(2, 3) if mode == K.MODE_TCONV else wk, padding=1).permute(0, 2, 3, 1).reshape(M, Cout)
+            for kw in variants:
+                outs = []
+                for forced in (False, True):
+                    lib.mg_set_halo3(ctypes.c_int(1 if forced else 0))
+                    lib.mg_set_halo3_cfg(ctypes.c_int(8 if forced else 0), ctypes.c_int(32 if forced else 0), ctypes.c_int(201 if forced else 0))
+                    st = torch.zeros(rows, 2 * Cout, device=dev)
+                    wide = torch.zeros(M, Cout + 16, device=dev, dtype=dtype)
+                    K.conv_fprop(x, w, stats=st, out=wide, yoff=8, cout=Cout, **geo, **kw)
+                    torch.cuda.synchronize()
+                    outs.append((wide, st.sum(0)))
+                (yo, so), (yn, sn) = outs
+                sl = 1.0 if kw.get('act', K.ACT_NONE) == K.ACT_NONE else (0.0 if kw['act'] == K.ACT_RELU else 0.2)
+                r = base
+                if kw.get('pre_act'):
+                    r = torch.maximum(r, r * sl)
+                r = r * kw.get('scale', torch.ones_like(scale)) + kw.get('shift', torch.zeros_like(shift))
+                if 'res' in kw:
+                    rr = kw['res'].float()
+                    if kw.get('res_mode') == 2:
+                        rr = rr.view(N, H // 2, W // 2, Cout).repeat_interleave(2, 1).repeat_interleave(2, 2).reshape(M, Cout)
+                    r = r + rr
+                if not kw.get('pre_act'):
+                    r = torch.maximum(r, r * sl)
+                if 'res2' in kw:
+                    r = r + kw['res2'].float()
+                got = yn[:, 8:8 + Cout].float()
+                assert bool((yn[:, :8] == 0).all()) and bool((yn[:, 8 + Cout:] == 0).all()), 'wrote outside its channel slice'
+                assert float((got - r).abs().max()) <= tol * max(1.0, float(r.abs().max())), (mode, sorted(kw))
+                assert float((got - yo[:, 8:8 + Cout].float()).abs().max()) <= tol * max(1.0, float(r.abs().max()))        # the round-2 kernel
+                want = torch.cat([got.sum(0), (got * got).sum(0)])
+                assert float(((sn - want).abs() / (want.abs() + 1.0)).max()) <= 2e-3
+        # operand transform: raw producer output + (scale, shift, act) == the stored z, bit for bit, statistics rows included
+        lib.mg_set_halo3(ctypes.c_int(1))
+        lib.mg_set_halo3_cfg(ctypes.c_int(8), ctypes.c_int(32), ctypes.c_int(201))
+        geo = dict(N=N, Hin=H, Win=W, R=3, S=3, stride=1, pad=1, dil=1, mode=K.MODE_CONV)
+        for act in (0, 1, 2):
+            y = t(rs.normal(0.3, 1.5, (M, Cin))).to(dtype)
+            sc = t(rs.uniform(0.5, 1.5, Cin) * rs.choice([-1.0, 1.0], Cin))
+            sh = t(rs.normal(0.0, 0.7, Cin))
+            z = K.affine_act(y, sc, sh, act=act, slope=0.2)
+            sa, sb = torch.zeros(rows, 2 * Cout, device=dev), torch.zeros(rows, 2 * Cout, device=dev)
+            o_ref = K.conv_fprop(z, w, stats=sa, **geo)
+            o_xf = K.conv_fprop(y, w, stats=sb, xf=(sc, sh, act, 0.2), **geo)
+            assert torch.equal(o_ref, o_xf) and torch.equal(sa, sb), (act, int((o_ref != o_xf).sum()))
+    finally:
+        lib.mg_set_halo3(ctypes.c_int(1))
+        lib.mg_set_halo3_cfg(ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0))
