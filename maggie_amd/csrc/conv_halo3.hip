@@ -105,10 +105,9 @@ __device__ __forceinline__ void h3_load_affine(const mg_conv_params& p, int c0, 
 // meet the three weight fragments W(ky, c); W(0, c + 1) and W(1, c + 1) are loaded over their dead predecessors during the last two rows of
 // column c, W(2, c) during row 0. One continuous LDS stream with compile-time lgkmcnt counts (inline asm: hipcc otherwise drains vmcnt(0)
 // before every LDS read it can see next to LDS-DMA). A := weight fragment, B := pixel fragment.
-// Across stages: the fragment registers exist twice (PAR). Once the last LDS read of stage s has been issued and has landed (walk position
-// KT = NSTEP - AD + 1) the wave is DONE with the stage's buffer although ~20 of its MFMAs are still to come: `tail()` runs there -- the caller
-// arrives at the barrier that hands the buffer back and publishes stage s + 1, and issues stage s + 1's first nine fragment reads into the
-// other register set -- so the barrier and one LDS round trip (together ~400 of a 1000-cycle stage, tools/h3_timeline.py) sit under MFMAs.
+// Across stages: the fragment registers exist twice (PAR): `tail()` -- the caller's barrier that hands the buffer back and publishes stage s + 1, and
+// stage s + 1's first nine fragment reads into the other register set -- runs behind the stage's last MFMA, or, with MG_H3_EARLY, as soon as the last
+// LDS read of stage s has been issued and has landed (walk position KT = NSTEP - AD + 1, ~20 MFMAs earlier).
 template <int FN, int AD> struct H3Frags { u32x4 b[2][3][FN]; u32x4 a[2][AD]; };
 
 template <int FM, int FN, int BN, int PW, int MODE, int AD, int PAR>
@@ -723,7 +722,7 @@ __global__ __launch_bounds__(NS > 1 ? 512 : 256) void conv_halo3_kernel(const mg
 // n's epilogue"). One 512-thread workgroup per CU walks a LIST of tiles (virtual block ids blockIdx.x + k * gridDim.x through the XCD order);
 // the ring of stages runs ACROSS tile boundaries: the producers are up to NS - 1 stages ahead whatever tile those stages belong to, so from the
 // second tile on a tile's first stage has landed before the consumers have finished the previous tile's epilogue (the cold start -- 3-5 k of
-// a 13 k-cycle launch -- is paid once per workgroup), and the consumers' early barrier puts the next tile's first fragment reads under the last
+// a 13 k-cycle launch -- is paid once per workgroup), and (with MG_H3_EARLY) the consumers' early barrier puts the next tile's first fragment reads under the last
 // MFMAs of this one. The statistics tail of tile k (two workgroup barriers) comes BEHIND the barrier of tile k + 1's first stage in both roles.
 // For layers with >= ~2 tiles per CU (batch 12, the video shapes); plain forward / data gradient (no operand transform, no BatchNorm link).
 // ---------------------------------------------------------------------------------------------------------------------

@@ -38,3 +38,19 @@ def pytest_collection_modifyitems(session, config, items):
 @pytest.fixture(scope='session')
 def golden_dir():
     return os.path.join(ROOT, 'tests', 'golden')
+
+
+@pytest.fixture(autouse=True)
+def _quiesce_between_tests():
+    """Models of a finished test (and the hipGraphs they captured) die HERE, with the device idle -- not whenever the cyclic collector happens to run
+    inside a later test's forward pass. Twice in ~20 full-suite runs of round 6 the suite died with a fatal fault inside
+    test_parked_slab_reductions_leave_the_step_unchanged[video] (a forward of a freshly built model, four test files into the run); the test alone (24 x),
+    its file (10 x) and its file behind test_gpu_conv.py (7 x) never did. What the collector destroys mid-step depends on everything allocated before --
+    this fixture takes that dependence out."""
+    yield
+    torch = sys.modules.get('torch')
+    if torch is not None and torch.cuda.is_available():
+        import gc
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.synchronize()

@@ -3,7 +3,7 @@
 # usage (through gpurun): bash tools/final_round_run.sh r05  -> gpurun_out/r05/*, gpurun_out/r05_*
 TAG=${1:-rXX}
 mkdir -p gpurun_out/$TAG
-python -m pytest tests -m gpu -x -q -p no:cacheprovider --timeout 1500 2>&1 | tail -40 > gpurun_out/$TAG/pytest_x.txt
+python -m pytest tests -m gpu -x -q -p no:cacheprovider --timeout 1500 > gpurun_out/$TAG/pytest_full.txt 2>&1; grep -v '^  File' gpurun_out/$TAG/pytest_full.txt | tail -60 > gpurun_out/$TAG/pytest_x.txt
 python bench.py --cpu-baseline-full > gpurun_out/$TAG/bench_default.json 2> gpurun_out/$TAG/bench_default.err
 B="--steps 60 --warmup 10 --no-cpu-baseline"
 python bench.py $B --video > gpurun_out/$TAG/bench_video.json 2>/dev/null
