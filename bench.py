@@ -478,7 +478,17 @@ def trace_graph_replay(args, fam_alg):
         # the last (n_steps - 1) steps of the timed region: whole steps, all replayed from graphs
         k = n_steps - 1
         t_end = rows[-1][1]
-        win = [r for r in rows if r[0] >= t_end - k * ms * 1e6]
+        # Whole steps by a marker, not by the clock: the optimizer kernel runs exactly once per step, so the launches between the ends of marker
+        # (k + 1)-from-last and the last marker are k steps whatever the host did meanwhile. (The window used to be "the last k x ms_per_step of the trace":
+        # one host stall inside it -- the traced child of the round's final run: 15.6 ms per step, 63 % busy -- and it held 4.7 steps' launches counted as 5:
+        # frac 0.124 instead of 0.112.) Workloads without an optimizer step (--workload pred) keep the clock window.
+        marks = [e_ for _, e_, nm in rows if 'adamw_kernel' in nm]
+        window_by = 'clock'
+        if len(marks) >= k + 1:
+            win = [r for r in rows if r[0] >= marks[-(k + 1)] and r[1] <= marks[-1]]
+            window_by = 'optimizer kernel'
+        else:
+            win = [r for r in rows if r[0] >= t_end - k * ms * 1e6]
         acc = {}
         for s_, e_, nm in win:
             # dense fprop family = every igemm_fprop_* kernel that is not the persistent (sparse-head) form: the register-staged im2col loop,
@@ -493,7 +503,7 @@ def trace_graph_replay(args, fam_alg):
                 d[2] += int('igemm_fprop' in nm or 'igemm_wgrad' in nm or 'conv_halo3' in nm)
         busy = sum(e_ - s_ for s_, e_, _ in win)
         span = win[-1][1] - win[0][0]
-        out = {'steps_in_window': k, 'traced_ms_per_step': ms, 'launches_per_step': round(len(win) / k, 1), 'gpu_busy_frac': round(busy / span, 4)}
+        out = {'steps_in_window': k, 'window_by': window_by, 'traced_ms_per_step': ms, 'launches_per_step': round(len(win) / k, 1), 'gpu_busy_frac': round(busy / span, 4)}
         for fam, (t, c, cm) in acc.items():
             out[fam + '_ms_per_step'] = round(t / 1e6 / k, 4)
             out[fam + '_launches_per_step'] = round(c / k, 1)
