@@ -1219,8 +1219,8 @@ int dispatch_h3(const mg_conv_params& p, hipStream_t st) {
     // one slab, one channel tile, >= ~5 tiles per resident workgroup: the persistent form with the weights staged once (ns 201 forces it, 200 forbids it).
     // Measured (tools/h3_check.py time, us, per-tile single-role form | this form): batch 4 C32 512 x 512 forward 47.1 | 41.6, data gradient 41.9 | 33.8,
     // C32 -> 8 data gradient 34.3 (round-2 im2col form) | 29.7; batch 12 512 x 512 131.5 | 115.7, 256 x 256 30.7 | 26.5; batch 4 256 x 256 (2 048 tiles,
-    // 2.7 per workgroup) 13.0 | 14.3 -- hence the threshold. What bounds it is not the matrix pipe (36 MFMAs per wave and tile = 11 us of the 42) but the
-    // ~450 vector-ALU instructions a wave spends per tile on addresses, the epilogue and the statistics' DPP sums (hipcc -S, counted per basic block).
+    // 2.7 per workgroup) 13.0 | 14.3 -- hence the threshold. PMC (profiles/r06_pmc_slab.txt, C32 512 x 512 forward, per launch): vector-ALU instructions
+    // 13.6 M -> 6.4 M (414 -> 194 per wave and tile), L2 read requests 1.59 M -> 0.82 M, wave cycles 57.9 M -> 35.3 M; the matrix pipe's share is 11 us of the 42.
     static const int slab_min = [] { const char* e = getenv("MG_H3_SLAB_MIN"); return e ? atoi(e) : 4096; }();
     if (ns != 200 && nstage == 1 && p.Cout <= 32 && !p.bnb_x && (ns == 201 || (!g_h3_force[0] && sp8 >= slab_min))) return launch_h3_slab<T>(p, st);
     if (ns >= 200 || p.Cout < 16) return 1;
