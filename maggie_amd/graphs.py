@@ -112,6 +112,16 @@ class _ParamAliases:
         return False
 
 
+_GRAVEYARD = []          # contents of GraphedCallable objects collected while a capture was running (see __del__)
+
+
+def bury():
+    """Destroy what __del__ had to keep alive: called where no capture is running and the device may be drained (before a new capture starts)."""
+    if _GRAVEYARD and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.synchronize()
+        del _GRAVEYARD[:]
+
+
 class GraphedCallable:
     """fn(*inputs) -> tuple of tensors, captured for fixed input shapes. `module`: the nn.Module whose parameters fn reads
     (requires_grad ones get gradients). `mutable`: tensors fn mutates in place (rolled back after warm-up)."""
@@ -119,8 +129,13 @@ class GraphedCallable:
     def __del__(self):
         # A hipGraph executable (its kernel-argument buffers, its private memory pool) must not be destroyed while kernels of its last replay are
         # still queued: drain the device first. Rare (a model going away, a graph evicted): a few microseconds when the device is idle.
+        # The cyclic collector may run this in the MIDDLE of another graph's capture (a model of an earlier test, a dropped graph set): nothing may
+        # synchronise or destroy a graph there -- the object's contents move to _GRAVEYARD and die at the next quiescent point (bury()).
         try:
-            if getattr(self, 'fwd', None) is not None and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            if getattr(self, 'fwd', None) is not None and torch.cuda.is_available():
+                if torch.cuda.is_current_stream_capturing():
+                    _GRAVEYARD.append(dict(self.__dict__))
+                    return
                 torch.cuda.synchronize()
         except Exception:
             pass
@@ -130,6 +145,7 @@ class GraphedCallable:
         `grad_sink(params) -> list of fp32 tensors | None`: where the parameter gradients should be written (FlatAdamW.grad_views: slices of
         the optimizer's flat gradient buffer). The captured backward then ends by copying the gradients THERE, `.grad` becomes a view of the
         optimizer's buffer and neither the export copy nor the optimizer's gather copy runs (two passes over ~120 MB per step)."""
+        bury()
         dev = inputs[0].device
         self.training = training
         self.grad_sink = grad_sink
